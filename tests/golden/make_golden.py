@@ -1,0 +1,346 @@
+"""Generate the golden vectors under tests/golden/ from the REFERENCE itself.
+
+Runs only in the build container (needs /root/reference, Cython, gcc).  The
+reference tree is read-only and numpy>=1.24 incompatible, so:
+
+  1. copy /root/reference/dynetlsm to a scratch dir and build its four .pyx
+     in place;
+  2. alias np.int / np.bool, stub ``statsmodels.regression.linear_model``;
+  3. import it and record inputs + outputs of every hot-path function.
+
+Nothing of the reference's source is written to the repo: only arrays
+(inputs / expected outputs) and the MIT-licensed Sampson monks adjacency data.
+Usage:  python tests/golden/make_golden.py
+"""
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+import types
+import warnings
+
+import numpy as np
+
+os.environ.setdefault('TQDM_DISABLE', '1')
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = os.environ.get('DYNETLSM_REFERENCE', '/root/reference')
+
+
+def import_reference():
+    scratch = os.path.join(tempfile.gettempdir(), 'dynetlsm_ref_build')
+    pkg = os.path.join(scratch, 'dynetlsm')
+    if not os.path.exists(pkg):
+        os.makedirs(scratch, exist_ok=True)
+        shutil.copytree(os.path.join(REF, 'dynetlsm'), pkg)
+    built = [f for f in os.listdir(pkg) if f.endswith('.so')]
+    if len(built) < 4:
+        setup = os.path.join(scratch, 'build_ref.py')
+        with open(setup, 'w') as f:
+            f.write(
+                "from setuptools import setup, Extension\n"
+                "from Cython.Build import cythonize\n"
+                "import numpy\n"
+                "names = ['static_network_fast', 'directed_likelihoods_fast',\n"
+                "         'gaussian_likelihood_fast', 'forecast']\n"
+                "exts = [Extension('dynetlsm.' + n, ['dynetlsm/%s.pyx' % n],\n"
+                "                  include_dirs=[numpy.get_include()],\n"
+                "                  extra_compile_args=['-O3']) for n in names]\n"
+                "setup(ext_modules=cythonize(exts, language_level=3),\n"
+                "      script_args=['build_ext', '--inplace'])\n")
+        subprocess.check_call([sys.executable, setup], cwd=scratch,
+                              stdout=subprocess.DEVNULL)
+    # import the third-party stack BEFORE aliasing (numpy.ma breaks otherwise)
+    import numpy.ma  # noqa
+    import scipy.stats, scipy.optimize, scipy.linalg, scipy.sparse  # noqa
+    import sklearn.cluster, sklearn.manifold, sklearn.metrics  # noqa
+    import sklearn.preprocessing, sklearn.utils, sklearn.datasets  # noqa
+    import pandas, networkx  # noqa
+    np.int = int
+    np.bool = np.bool_
+    sm = types.ModuleType('statsmodels')
+    smr = types.ModuleType('statsmodels.regression')
+    sml = types.ModuleType('statsmodels.regression.linear_model')
+    sml.yule_walker = lambda *a, **k: (np.zeros(1), 1.0)
+    sys.modules['statsmodels'] = sm
+    sys.modules['statsmodels.regression'] = smr
+    sys.modules['statsmodels.regression.linear_model'] = sml
+    sys.path.insert(0, scratch)
+    warnings.filterwarnings('ignore')
+    import dynetlsm  # noqa
+    return dynetlsm
+
+
+def make_inputs(seed, T, N, D=2, density=0.4):
+    rng = np.random.RandomState(seed)
+    X = rng.randn(T, N, D)
+    Yd = (rng.rand(T, N, N) < density).astype(np.float64)
+    for t in range(T):
+        np.fill_diagonal(Yd[t], 0)
+    Yu = np.triu(Yd, 1)
+    Yu = Yu + Yu.transpose(0, 2, 1)
+    radii = rng.dirichlet(np.ones(N))
+    return X, Yd, Yu, radii
+
+
+def gen_likelihoods(ref):
+    from dynetlsm.static_network_fast import partial_loglikelihood
+    from dynetlsm.directed_likelihoods_fast import (
+        directed_partial_loglikelihood, approx_directed_partial_loglikelihood,
+        directed_network_loglikelihood_fast,
+        approx_directed_network_loglikelihood)
+    from dynetlsm.network_likelihoods import (
+        dynamic_network_loglikelihood_undirected,
+        dynamic_network_loglikelihood_directed)
+    from dynetlsm.gaussian_likelihood_fast import compute_gaussian_likelihood
+    from dynetlsm.case_control_likelihood import DirectedCaseControlSampler
+
+    out = {}
+    for tag, (seed, T, N, D, dens) in {
+            'a': (12345, 3, 7, 2, 0.4), 'b': (777, 2, 32, 2, 0.15),
+            'c': (4242, 2, 9, 3, 0.3)}.items():
+        X, Yd, Yu, radii = make_inputs(seed, T, N, D, dens)
+        b, b_in, b_out = 0.75, 0.3, 0.7
+        out[tag + '_X'], out[tag + '_Yd'], out[tag + '_Yu'] = X, Yd, Yu
+        out[tag + '_radii'] = radii
+        out[tag + '_b'] = np.array([b, b_in, b_out])
+        for sq in (0, 1):
+            pu = np.zeros((T, N)); pd = np.zeros((T, N))
+            for t in range(T):
+                for j in range(N):
+                    pu[t, j] = partial_loglikelihood(Yu[t], X[t], b, j,
+                                                     squared=bool(sq))
+                    pd[t, j] = directed_partial_loglikelihood(
+                        Yd[t], X[t], radii, b_in, b_out, j, squared=bool(sq))
+            out['%s_partial_undirected_sq%d' % (tag, sq)] = pu
+            out['%s_partial_directed_sq%d' % (tag, sq)] = pd
+            out['%s_full_undirected_sq%d' % (tag, sq)] = np.float64(
+                dynamic_network_loglikelihood_undirected(Yu, X, b,
+                                                         squared=bool(sq)))
+            out['%s_full_directed_sq%d' % (tag, sq)] = np.float64(
+                dynamic_network_loglikelihood_directed(Yd, X, b_in, b_out, radii,
+                                                       squared=bool(sq)))
+        # case-control structures from the reference sampler (a7)
+        ccs = DirectedCaseControlSampler(
+            n_control=3, random_state=np.random.RandomState(7)).init(Yd)
+        out[tag + '_degrees'] = ccs.degrees_
+        out[tag + '_in_edges'] = ccs.in_edges_
+        out[tag + '_out_edges'] = ccs.out_edges_
+        out[tag + '_ctrl_in'] = ccs.control_nodes_in_
+        out[tag + '_ctrl_out'] = ccs.control_nodes_out_
+        for sq in (0, 1):
+            pa = np.zeros((T, N))
+            for t in range(T):
+                for j in range(N):
+                    pa[t, j] = approx_directed_partial_loglikelihood(
+                        X[t], radii, ccs.in_edges_[t], ccs.out_edges_[t],
+                        ccs.degrees_[t], ccs.control_nodes_in_[t],
+                        ccs.control_nodes_out_[t], b_in, b_out, j,
+                        squared=bool(sq))
+            out['%s_partial_approx_sq%d' % (tag, sq)] = pa
+            out['%s_full_approx_sq%d' % (tag, sq)] = np.float64(
+                approx_directed_network_loglikelihood(
+                    X, radii, ccs.in_edges_, ccs.out_edges_, ccs.degrees_,
+                    ccs.control_nodes_out_, b_in, b_out, squared=bool(sq)))
+        # exhaustive controls: approx full == exact full
+        ccs_all = DirectedCaseControlSampler(
+            n_control=N, random_state=np.random.RandomState(8)).init(Yd)
+        out[tag + '_ctrl_out_all'] = ccs_all.control_nodes_out_
+        out[tag + '_ctrl_in_all'] = ccs_all.control_nodes_in_
+        out[tag + '_full_approx_all'] = np.float64(
+            approx_directed_network_loglikelihood(
+                X, radii, ccs_all.in_edges_, ccs_all.out_edges_,
+                ccs_all.degrees_, ccs_all.control_nodes_out_, b_in, b_out))
+        # gaussian AR-mixture table (a11)
+        rng = np.random.RandomState(seed + 1)
+        K = 4
+        mu = rng.randn(K, D); sigma = rng.uniform(0.3, 2.0, K); lmbda = 0.8
+        out[tag + '_mu'], out[tag + '_sigma'] = mu, sigma
+        for nz in (0, 1):
+            tab = np.zeros((N, T, K))
+            for i in range(N):
+                tab[i] = compute_gaussian_likelihood(X[:, i], mu, sigma, lmbda,
+                                                     normalize=bool(nz))
+            out['%s_gauss_norm%d' % (tag, nz)] = tab
+    np.savez_compressed(os.path.join(HERE, 'likelihoods.npz'), **out)
+    print('likelihoods.npz: %d arrays' % len(out))
+
+
+def sampler_state(samplers):
+    return (np.array([[s.step_size for s in row] for row in samplers]),
+            np.array([[s.n_accepted for s in row] for row in samplers]),
+            np.array([[s.n_steps for s in row] for row in samplers]),
+            np.array([[s.steps_until_tune for s in row] for row in samplers]))
+
+
+def gen_sweeps(ref):
+    """direct calls of sample_latent_positions / _mixture / sample_labels_block
+    with the reference's own Metropolis objects"""
+    from dynetlsm.metropolis import Metropolis
+    from dynetlsm.sample_latent_positions import (
+        sample_latent_positions, sample_latent_positions_mixture)
+    from dynetlsm.sample_labels import sample_labels_block
+    from dynetlsm.case_control_likelihood import DirectedCaseControlSampler
+
+    out = {}
+    T, N, D = 3, 10, 2
+    X, Yd, Yu, radii = make_inputs(2024, T, N, D, 0.3)
+    out['X0'], out['Yd'], out['Yu'], out['radii'] = X, Yd, Yu, radii
+    n_sweeps, tune, tune_interval = 6, 5, 2
+
+    def new_samplers():
+        return [[Metropolis(step_size=0.2, tune=tune, tune_interval=tune_interval,
+                            proposal_type='random_walk') for _ in range(N)]
+                for _ in range(T)]
+
+    ccs = DirectedCaseControlSampler(
+        n_control=3, random_state=np.random.RandomState(11)).init(Yd)
+    out['cc_degrees'], out['cc_in_edges'] = ccs.degrees_, ccs.in_edges_
+    out['cc_out_edges'] = ccs.out_edges_
+    out['cc_ctrl_in'], out['cc_ctrl_out'] = (ccs.control_nodes_in_,
+                                             ccs.control_nodes_out_)
+
+    K = 3
+    rng0 = np.random.RandomState(99)
+    mu = rng0.randn(K, D); sigma = rng0.uniform(0.5, 1.5, K)
+    lmbda = np.array([0.8]); z = rng0.randint(0, K, size=(T, N)).astype(np.int64)
+    out['mu'], out['sigma'], out['lmbda'], out['z'] = mu, sigma, lmbda, z
+
+    cases = {
+        'undirected': dict(Y=Yu, intercept=np.array([0.5]), is_directed=False),
+        'directed': dict(Y=Yd, intercept=np.array([0.3, 0.7]), radii=radii,
+                         is_directed=True),
+        'casecontrol': dict(Y=Yd, intercept=np.array([0.3, 0.7]), radii=radii,
+                            is_directed=True, case_control_sampler=ccs),
+    }
+    for prior in ('rw', 'mix'):
+        for name, kw in cases.items():
+            samplers = new_samplers()
+            rng = np.random.RandomState(5)
+            Xc = X.copy()
+            trace = np.zeros((n_sweeps, T, N, D))
+            for s in range(n_sweeps):
+                if prior == 'rw':
+                    Xc = sample_latent_positions(
+                        kw['Y'], Xc, kw['intercept'], tau_sq=2.0, sigma_sq=0.1,
+                        samplers=samplers, radii=kw.get('radii'),
+                        is_directed=kw['is_directed'], squared=False,
+                        case_control_sampler=kw.get('case_control_sampler'),
+                        random_state=rng)
+                else:
+                    Xc = sample_latent_positions_mixture(
+                        kw['Y'], Xc, kw['intercept'], mu, sigma, lmbda, z,
+                        samplers=samplers, radii=kw.get('radii'),
+                        is_directed=kw['is_directed'], squared=False,
+                        case_control_sampler=kw.get('case_control_sampler'),
+                        random_state=rng)
+                trace[s] = Xc
+            key = 'sweep_%s_%s' % (prior, name)
+            out[key + '_X'] = trace
+            st = sampler_state(samplers)
+            out[key + '_step'], out[key + '_nacc'] = st[0], st[1]
+            out[key + '_nsteps'], out[key + '_until'] = st[2], st[3]
+
+    # label block update (a12)
+    Tl, Nl, Kl = 4, 25, 5
+    rng0 = np.random.RandomState(31)
+    Xl = rng0.randn(Tl, Nl, D)
+    mul = rng0.randn(Kl, D) * 1.5; sgl = rng0.uniform(0.3, 1.2, Kl)
+    w = rng0.dirichlet(np.ones(Kl), size=(Tl, Kl))
+    zl, nl, nkl, respl = sample_labels_block(Xl, mul, sgl, 0.8, w,
+                                             random_state=np.random.RandomState(3))
+    out['lab_X'], out['lab_mu'], out['lab_sigma'], out['lab_w'] = Xl, mul, sgl, w
+    out['lab_z'], out['lab_n'], out['lab_nk'], out['lab_resp'] = zl, nl, nkl, respl
+    np.savez_compressed(os.path.join(HERE, 'sweeps.npz'), **out)
+    print('sweeps.npz: %d arrays' % len(out))
+
+
+def gen_monks(ref):
+    from dynetlsm.datasets import load_monks
+    Yd, groups, names = load_monks(dynamic=True, is_directed=True)
+    Yu, _, _ = load_monks(dynamic=True, is_directed=False)
+    np.savez_compressed(os.path.join(HERE, 'monks.npz'), Y_directed=Yd,
+                        Y_undirected=Yu, groups=groups)
+    print('monks.npz')
+    return Yd, Yu
+
+
+def capture_fit(ref, Y, **kw):
+    """run the reference's DynamicNetworkLSM.fit, capturing the numpy RNG state
+    at the first call of the hot loop (= right after the init pipeline)."""
+    import dynetlsm.lsm as lsm_mod
+    cap = {}
+    orig = lsm_mod.sample_latent_positions
+
+    def spy(*a, **k):
+        if 'rng_state' not in cap:
+            cap['rng_state'] = k['random_state'].get_state()
+        return orig(*a, **k)
+    lsm_mod.sample_latent_positions = spy
+    try:
+        rng = np.random.RandomState(kw.pop('seed'))
+        model = ref.DynamicNetworkLSM(random_state=rng, **kw).fit(Y)
+    finally:
+        lsm_mod.sample_latent_positions = orig
+    st = cap['rng_state']
+    res = dict(Xs=model.Xs_, intercepts=model.intercepts_, logps=model.logps_,
+               rng_keys=st[1], rng_pos=np.int64(st[2]),
+               rng_has_gauss=np.int64(st[3]), rng_cached=np.float64(st[4]),
+               tau_sq=np.float64(model.tau_sq),
+               intercept_prior=np.asarray(model.intercept_prior, dtype=np.float64))
+    st = sampler_state(model.latent_samplers)
+    res.update(step=st[0], nacc=st[1], nsteps=st[2], until=st[3])
+    res['istep'] = np.array([s.step_size for s in model.intercept_samplers])
+    if model.is_directed:
+        res['radiis'] = model.radiis_
+    if model.case_control_sampler_ is not None:
+        c = model.case_control_sampler_
+        res.update(cc_degrees=c.degrees_, cc_in_edges=c.in_edges_,
+                   cc_out_edges=c.out_edges_, cc_ctrl_in=c.control_nodes_in_,
+                   cc_ctrl_out=c.control_nodes_out_)
+    return res
+
+
+def gen_fit_traces(ref, Yd, Yu):
+    out = {}
+    r = capture_fit(ref, Yu, seed=42, n_iter=10, tune=4, burn=2, tune_interval=2)
+    out.update({'monks_u_' + k: v for k, v in r.items()})
+    r = capture_fit(ref, Yd, seed=43, n_iter=8, tune=4, burn=2, tune_interval=2,
+                    is_directed=True)
+    out.update({'monks_d_' + k: v for k, v in r.items()})
+    r = capture_fit(ref, Yd, seed=44, n_iter=8, tune=4, burn=2, tune_interval=2,
+                    is_directed=True, n_control=5, n_resample_control=1000)
+    out.update({'monks_cc_' + k: v for k, v in r.items()})
+    np.savez_compressed(os.path.join(HERE, 'fit_traces.npz'), **out)
+    print('fit_traces.npz: %d arrays' % len(out))
+
+
+def gen_chain_envelopes(ref, Yu):
+    """config 1: posterior summaries of the reference on monks, several seeds."""
+    seeds = list(range(8))
+    rows = []
+    for s in seeds:
+        m = ref.DynamicNetworkLSM(n_iter=500, tune=250, burn=250,
+                                  random_state=s).fit(Yu)
+        keep = slice(500, None)
+        d = np.sqrt(((m.Xs_[keep, :, :, None, :] -
+                      m.Xs_[keep, :, None, :, :]) ** 2).sum(-1))
+        rows.append([m.intercepts_[keep, 0].mean(), m.intercepts_[keep, 0].std(),
+                     m.logps_[keep].mean(), m.logps_[keep].std(),
+                     d.mean(), float(m.tau_sq), float(m.intercept_prior[0])])
+    np.savez_compressed(os.path.join(HERE, 'monks_envelopes.npz'),
+                        seeds=np.array(seeds), summaries=np.array(rows),
+                        columns=np.array(['intercept_mean', 'intercept_sd',
+                                          'logp_mean', 'logp_sd',
+                                          'mean_pairwise_distance', 'tau_sq',
+                                          'intercept_prior']))
+    print('monks_envelopes.npz')
+
+
+if __name__ == '__main__':
+    ref = import_reference()
+    gen_likelihoods(ref)
+    gen_sweeps(ref)
+    Yd, Yu = gen_monks(ref)
+    gen_fit_traces(ref, Yd, Yu)
+    gen_chain_envelopes(ref, Yu)
