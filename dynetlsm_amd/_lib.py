@@ -1,0 +1,115 @@
+"""ctypes binding of include/dynetlsm_hip.h.
+
+There is no fallback: if the HIP library is missing or no gfx950 device is
+usable, every entry point raises.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'libdynetlsm_hip.so')
+
+c_double_p = C.POINTER(C.c_double)
+c_i64_p = C.POINTER(C.c_int64)
+c_i32_p = C.POINTER(C.c_int32)
+handle_t = C.c_void_p
+
+K_LOGLIK, K_SWEEP, K_CENTER, K_LABELS, K_FINALIZE = range(5)
+UNDIRECTED, DIRECTED, DIRECTED_CASE_CONTROL = 0, 1, 2
+
+
+class LsmConfig(C.Structure):
+    """mirror of ``dlsm_lsm_config``"""
+    _fields_ = [('intercept_prior', C.c_double * 2),
+                ('intercept_variance_prior', C.c_double),
+                ('i_step_size', C.c_double * 2),
+                ('i_n_accepted', C.c_int32 * 2), ('i_n_steps', C.c_int32 * 2),
+                ('i_steps_until_tune', C.c_int32 * 2),
+                ('i_tune', C.c_int32), ('i_tune_interval', C.c_int32),
+                ('n_iter_procrustes', C.c_int32), ('sweep_algo', C.c_int32)]
+
+
+class EngineError(RuntimeError):
+    def __init__(self, code, msg):
+        RuntimeError.__init__(self, 'dynetlsm_hip error %d: %s' % (code, msg))
+        self.code = code
+
+
+# every exported symbol of include/dynetlsm_hip.h : (restype, argtypes)
+SIGNATURES = {
+    'dlsm_abi_version': (C.c_int, []),
+    'dlsm_device_count': (C.c_int, [C.POINTER(C.c_int)]),
+    'dlsm_last_error': (C.c_char_p, [handle_t]),
+    'dlsm_create': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                              C.c_uint64, C.c_uint32, C.POINTER(handle_t)]),
+    'dlsm_destroy': (None, [handle_t]),
+    'dlsm_synchronize': (C.c_int, [handle_t]),
+    'dlsm_upload_network': (C.c_int, [handle_t, c_double_p]),
+    'dlsm_upload_edges': (C.c_int, [handle_t, c_i64_p, C.c_int, c_i64_p, C.c_int,
+                                    c_i64_p]),
+    'dlsm_set_controls': (C.c_int, [handle_t, c_i64_p, c_i64_p, C.c_int]),
+    'dlsm_get_controls': (C.c_int, [handle_t, c_i64_p, c_i64_p]),
+    'dlsm_resample_controls': (C.c_int, [handle_t, C.c_uint32, C.c_int]),
+    'dlsm_set_positions': (C.c_int, [handle_t, c_double_p]),
+    'dlsm_get_positions': (C.c_int, [handle_t, c_double_p]),
+    'dlsm_set_intercepts': (C.c_int, [handle_t, c_double_p, C.c_int]),
+    'dlsm_get_intercepts': (C.c_int, [handle_t, c_double_p, C.c_int]),
+    'dlsm_set_radii': (C.c_int, [handle_t, c_double_p]),
+    'dlsm_get_radii': (C.c_int, [handle_t, c_double_p]),
+    'dlsm_set_squared': (C.c_int, [handle_t, C.c_int]),
+    'dlsm_set_samplers': (C.c_int, [handle_t, c_double_p, c_i32_p, c_i32_p, c_i32_p,
+                                    C.c_int, C.c_int]),
+    'dlsm_get_samplers': (C.c_int, [handle_t, c_double_p, c_i32_p, c_i32_p, c_i32_p]),
+    'dlsm_set_prior_random_walk': (C.c_int, [handle_t, C.c_double, C.c_double]),
+    'dlsm_set_prior_mixture': (C.c_int, [handle_t, c_double_p, c_double_p, C.c_double,
+                                         c_i64_p, C.c_int]),
+    'dlsm_loglik_full': (C.c_int, [handle_t, C.c_int, c_double_p, c_double_p]),
+    'dlsm_loglik_full_radii': (C.c_int, [handle_t, c_double_p, c_double_p]),
+    'dlsm_loglik_partial': (C.c_int, [handle_t, C.c_int, C.c_int, c_double_p, C.c_int,
+                                      c_double_p]),
+    'dlsm_loglik_partial_all': (C.c_int, [handle_t, C.c_int, c_double_p]),
+    'dlsm_sweep_positions': (C.c_int, [handle_t, C.c_uint32, C.c_int]),
+    'dlsm_center': (C.c_int, [handle_t]),
+    'dlsm_procrustes': (C.c_int, [handle_t, c_double_p, c_double_p]),
+    'dlsm_gaussian_likelihood': (C.c_int, [handle_t, C.c_int, C.c_int, c_double_p]),
+    'dlsm_sample_labels': (C.c_int, [handle_t, C.c_uint32, c_double_p, c_i64_p,
+                                     c_double_p, c_i64_p]),
+    'dlsm_lsm_configure': (C.c_int, [handle_t, C.POINTER(LsmConfig)]),
+    'dlsm_lsm_get_config': (C.c_int, [handle_t, C.POINTER(LsmConfig)]),
+    'dlsm_trace_alloc': (C.c_int, [handle_t, C.c_int, C.c_double]),
+    'dlsm_lsm_run': (C.c_int, [handle_t, C.c_int, C.c_int, C.c_int]),
+    'dlsm_trace_read': (C.c_int, [handle_t, C.c_int, C.c_int, c_double_p, c_double_p,
+                                  c_double_p]),
+    'dlsm_profile_enable': (C.c_int, [handle_t, C.c_int]),
+    'dlsm_profile_read': (C.c_int, [handle_t, C.c_int, c_double_p, C.POINTER(C.c_int)]),
+    'dlsm_timer_start': (C.c_int, [handle_t]),
+    'dlsm_timer_stop': (C.c_int, [handle_t, c_double_p]),
+}
+
+_LIB = None
+
+
+def load():
+    """Load the engine; raises if it has not been built (no fallback)."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                'dynetlsm_amd: %s is missing. Build it with '
+                '`python -m dynetlsm_amd.build` (needs hipcc); there is no CPU '
+                'fallback.' % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        if L.dlsm_abi_version() != 1:
+            raise ImportError('dynetlsm_amd: ABI version mismatch')
+        _LIB = L
+    return _LIB
+
+
+def device_count():
+    n = C.c_int(0)
+    load().dlsm_device_count(C.byref(n))
+    return n.value

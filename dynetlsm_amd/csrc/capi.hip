@@ -1,0 +1,945 @@
+// C-ABI of the MI355X engine (include/dynetlsm_hip.h).  gfx950 only; there is
+// deliberately no CPU path in this library.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "chain.hpp"
+#include "device_common.hpp"
+#include "kernels_labels.hpp"
+#include "kernels_loglik.hpp"
+#include "kernels_sweep.hpp"
+#include "kernels_spec.hpp"
+
+using namespace dlsm;
+
+static thread_local std::string g_err;
+
+#define FAIL(h, code, ...)                                      \
+    do {                                                        \
+        char _b[512];                                           \
+        snprintf(_b, sizeof(_b), __VA_ARGS__);                  \
+        if (h) (h)->err = _b; else g_err = _b;                  \
+        return (code);                                          \
+    } while (0)
+
+#define HIPCHK(h, call)                                                          \
+    do {                                                                         \
+        hipError_t _e = (call);                                                  \
+        if (_e != hipSuccess)                                                    \
+            FAIL(h, DLSM_E_HIP, "%s failed: %s (%s:%d)", #call,                  \
+                 hipGetErrorString(_e), __FILE__, __LINE__);                     \
+    } while (0)
+
+#define NEED(h, cond, ...)                               \
+    do {                                                 \
+        if (!(cond)) FAIL(h, DLSM_E_ARG, __VA_ARGS__);   \
+    } while (0)
+
+// dispatch on the compile-time latent dimension
+#define DISPATCH_D(h, D_, ...)                                              \
+    switch (D_) {                                                           \
+        case 1: { constexpr int DD = 1; __VA_ARGS__; } break;               \
+        case 2: { constexpr int DD = 2; __VA_ARGS__; } break;               \
+        case 3: { constexpr int DD = 3; __VA_ARGS__; } break;               \
+        case 4: { constexpr int DD = 4; __VA_ARGS__; } break;               \
+        default: FAIL(h, DLSM_E_LIMIT, "n_features=%d unsupported (1..4)", D_); \
+    }
+
+namespace {
+
+struct ProfScope {
+    dlsm_chain *h; int k; hipEvent_t e0 = nullptr, e1 = nullptr;
+    ProfScope(dlsm_chain *h_, int k_) : h(h_), k(k_) {
+        if (h->profiling) {
+            hipEventCreate(&e0); hipEventCreate(&e1);
+            hipEventRecord(e0, h->stream);
+        }
+    }
+    ~ProfScope() {
+        if (h->profiling) {
+            hipEventRecord(e1, h->stream);
+            h->prof[k].pending.emplace_back(e0, e1);
+        }
+    }
+};
+
+template <typename T>
+int dev_alloc(dlsm_chain *h, T **p, size_t n) {
+    HIPCHK(h, hipMalloc((void **)p, std::max<size_t>(n, 1) * sizeof(T)));
+    return DLSM_OK;
+}
+
+template <typename T>
+int h2d(dlsm_chain *h, T *dst, const T *src, size_t n) {
+    HIPCHK(h, hipMemcpyAsync(dst, src, n * sizeof(T), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return DLSM_OK;
+}
+
+template <typename T>
+int d2h(dlsm_chain *h, T *dst, const T *src, size_t n) {
+    HIPCHK(h, hipMemcpyAsync(dst, src, n * sizeof(T), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return DLSM_OK;
+}
+
+// int64 host array -> int32 device array (indices < 2^31 by construction)
+int upload_i64_as_i32(dlsm_chain *h, int32_t **dst, const int64_t *src, size_t n) {
+    std::vector<int32_t> tmp(n);
+    for (size_t i = 0; i < n; ++i) tmp[i] = (int32_t)src[i];
+    if (*dst) { hipFree(*dst); *dst = nullptr; }
+    int rc = dev_alloc(h, dst, n);
+    if (rc) return rc;
+    return h2d(h, *dst, tmp.data(), n);
+}
+
+int ensure_partials(dlsm_chain *h, size_t n) {
+    if (h->partials_cap >= n) return DLSM_OK;
+    if (h->partials) hipFree(h->partials);
+    h->partials = nullptr; h->partials_cap = 0;
+    int rc = dev_alloc(h, &h->partials, n);
+    if (rc) return rc;
+    h->partials_cap = n;
+    return DLSM_OK;
+}
+
+int ll_blocks(const dlsm_chain *h) {
+    if (h->model == DLSM_DIRECTED_CASE_CONTROL)
+        return (int)(((long)h->T * h->N + 3) / 4);
+    int nt = (h->N + LL_TILE - 1) / LL_TILE;
+    return h->T * (nt * (nt + 1) / 2);
+}
+
+int check_ready_loglik(dlsm_chain *h) {
+    NEED(h, h->have_X, "latent positions not set");
+    if (h->model == DLSM_DIRECTED_CASE_CONTROL) {
+        NEED(h, h->have_edges && h->have_controls, "edge lists / controls not set");
+    } else {
+        NEED(h, h->have_network, "network not uploaded");
+    }
+    if (h->model != DLSM_UNDIRECTED) NEED(h, h->have_radii, "radii not set");
+    return DLSM_OK;
+}
+
+// Enqueue the log-likelihood record kernel for M candidates whose intercepts
+// are at device address `d_ic` (and radii r0 / r1); returns the record count.
+template <int DD>
+int launch_loglik_records(dlsm_chain *h, int M, const double *d_ic,
+                          const double *r0, const double *r1, int *nrec_out) {
+    const int nb = ll_blocks(h);
+    int rc = ensure_partials(h, (size_t)nb * 4);
+    if (rc) return rc;
+    ChainView v = h->view();
+    LoglikCand cand{d_ic, {r0, r1}};
+    ProfScope ps(h, DLSM_K_LOGLIK);
+    if (h->model == DLSM_UNDIRECTED) {
+        if (M == 1) hipLaunchKernelGGL((k_loglik_undirected<DD, 1>), dim3(nb), dim3(LL_THREADS), 0, h->stream, v, cand, h->partials);
+        else hipLaunchKernelGGL((k_loglik_undirected<DD, 2>), dim3(nb), dim3(LL_THREADS), 0, h->stream, v, cand, h->partials);
+    } else if (h->model == DLSM_DIRECTED) {
+        if (M == 1) hipLaunchKernelGGL((k_loglik_directed<DD, 1>), dim3(nb), dim3(LL_THREADS), 0, h->stream, v, cand, h->partials);
+        else hipLaunchKernelGGL((k_loglik_directed<DD, 2>), dim3(nb), dim3(LL_THREADS), 0, h->stream, v, cand, h->partials);
+    } else {
+        if (M == 1) hipLaunchKernelGGL((k_loglik_casecontrol<DD, 1>), dim3(nb), dim3(256), 0, h->stream, v, cand, h->partials);
+        else hipLaunchKernelGGL((k_loglik_casecontrol<DD, 2>), dim3(nb), dim3(256), 0, h->stream, v, cand, h->partials);
+    }
+    HIPCHK(h, hipGetLastError());
+    *nrec_out = nb;
+    return DLSM_OK;
+}
+
+int loglik_records(dlsm_chain *h, int M, const double *d_ic, const double *r0,
+                   const double *r1, int *nrec) {
+    DISPATCH_D(h, h->D, return launch_loglik_records<DD>(h, M, d_ic, r0, r1, nrec));
+    return DLSM_OK;
+}
+
+int drain_profile(dlsm_chain *h) {
+    for (int k = 0; k < DLSM_K_COUNT; ++k) {
+        for (auto &pr : h->prof[k].pending) {
+            float ms = 0.f;
+            hipEventSynchronize(pr.second);
+            hipEventElapsedTime(&ms, pr.first, pr.second);
+            h->prof[k].ms += ms;
+            h->prof[k].launches += 1;
+            hipEventDestroy(pr.first);
+            hipEventDestroy(pr.second);
+        }
+        h->prof[k].pending.clear();
+    }
+    return DLSM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dlsm_abi_version(void) { return DLSM_ABI_VERSION; }
+
+int dlsm_device_count(int *count) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count = 0; g_err = hipGetErrorString(e); return DLSM_E_NODEV; }
+    *count = n;
+    return DLSM_OK;
+}
+
+const char *dlsm_last_error(const dlsm_chain *h) {
+    return h ? h->err.c_str() : g_err.c_str();
+}
+
+int dlsm_create(int device, int T, int N, int D, int model, uint64_t seed,
+                uint32_t chain_id, dlsm_chain **out) {
+    dlsm_chain *nullh = nullptr;
+    if (!out) FAIL(nullh, DLSM_E_ARG, "out is NULL");
+    *out = nullptr;
+    if (T < 1 || N < 2 || D < 1 || D > 4)
+        FAIL(nullh, DLSM_E_ARG, "bad shape T=%d N=%d D=%d (need T>=1, N>=2, 1<=D<=4)", T, N, D);
+    if (T > 65535) FAIL(nullh, DLSM_E_LIMIT, "T=%d > 65535", T);
+    if (model < 0 || model > 2) FAIL(nullh, DLSM_E_ARG, "bad model %d", model);
+    if (chain_id >= (1u << 24)) FAIL(nullh, DLSM_E_ARG, "chain_id must be < 2^24");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        FAIL(nullh, DLSM_E_NODEV, "no HIP device available (the engine has no CPU path)");
+    if (device < 0 || device >= ndev)
+        FAIL(nullh, DLSM_E_NODEV, "device %d out of range (%d devices)", device, ndev);
+    hipDeviceProp_t prop;
+    HIPCHK(nullh, hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        FAIL(nullh, DLSM_E_NODEV, "device %d is %s; this engine is built for gfx950 only",
+             device, prop.gcnArchName);
+    HIPCHK(nullh, hipSetDevice(device));
+    dlsm_chain *h = new dlsm_chain();
+    h->device = device; h->T = T; h->N = N; h->D = D; h->model = model;
+    h->seed = seed; h->chain = chain_id;
+    h->W = ((N + 31) / 32 + 3) / 4 * 4;
+    auto bail = [&](int rc) { g_err = h->err; dlsm_destroy(h); return rc; };
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess)
+        { h->err = "hipStreamCreate failed"; return bail(DLSM_E_HIP); }
+    const size_t TN = (size_t)T * N;
+    int rc = 0;
+    rc |= dev_alloc(h, &h->X, TN * D);
+    rc |= dev_alloc(h, &h->intercept, 2);
+    rc |= dev_alloc(h, &h->radii, N);
+    rc |= dev_alloc(h, &h->radii_alt, N);
+    rc |= dev_alloc(h, &h->step, TN);
+    rc |= dev_alloc(h, &h->nacc, TN);
+    rc |= dev_alloc(h, &h->nsteps, TN);
+    rc |= dev_alloc(h, &h->until, TN);
+    rc |= dev_alloc(h, &h->dsmall, 64);
+    rc |= dev_alloc(h, &h->xref, TN * D);
+    rc |= dev_alloc(h, &h->lsm, 1);
+    rc |= dev_alloc(h, &h->z, TN);
+    if (rc) return bail(DLSM_E_HIP);
+    if (hipHostMalloc((void **)&h->hsmall, 64 * sizeof(double)) != hipSuccess)
+        { h->err = "hipHostMalloc failed"; return bail(DLSM_E_HIP); }
+    hipMemsetAsync(h->intercept, 0, 2 * sizeof(double), h->stream);
+    hipMemsetAsync(h->lsm, 0, sizeof(LsmDeviceState), h->stream);
+    hipEventCreate(&h->timer0);
+    hipEventCreate(&h->timer1);
+    hipStreamSynchronize(h->stream);
+    *out = h;
+    return DLSM_OK;
+}
+
+void dlsm_destroy(dlsm_chain *h) {
+    if (!h) return;
+    hipSetDevice(h->device);
+    if (h->stream) hipStreamSynchronize(h->stream);
+    drain_profile(h);
+    void *ptrs[] = {h->ybits, h->ytbits, h->in_edges, h->out_edges, h->degree,
+                    h->ctrl_in, h->ctrl_out, h->X, h->intercept, h->radii,
+                    h->radii_alt, h->step, h->nacc, h->nsteps, h->until, h->mu,
+                    h->sigma, h->z, h->partials, h->dsmall, h->xref, h->lab_n,
+                    h->lab_nk, h->lab_w, h->spec, h->lsm, h->trace_X, h->trace_ic,
+                    h->trace_logp};
+    for (void *p : ptrs) if (p) hipFree(p);
+    if (h->hsmall) hipHostFree(h->hsmall);
+    if (h->timer0) hipEventDestroy(h->timer0);
+    if (h->timer1) hipEventDestroy(h->timer1);
+    if (h->stream) hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int dlsm_synchronize(dlsm_chain *h) {
+    NEED(h, h != nullptr, "null handle");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return DLSM_OK;
+}
+
+// ---------------------------------------------------------------- network
+int dlsm_upload_network(dlsm_chain *h, const double *Y) {
+    NEED(h, h && Y, "null argument");
+    NEED(h, h->model != DLSM_DIRECTED_CASE_CONTROL,
+         "case-control chains take edge lists (dlsm_upload_edges)");
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t TN = (size_t)h->T * h->N;
+    const size_t words = TN * h->W;
+    if (!h->ybits) { int rc = dev_alloc(h, &h->ybits, words); if (rc) return rc; }
+    if (h->model == DLSM_DIRECTED && !h->ytbits) {
+        int rc = dev_alloc(h, &h->ytbits, words); if (rc) return rc;
+    }
+    // stage the float64 network one time slice at a time (bounded staging memory)
+    double *dY = nullptr;
+    int *dflag = nullptr;
+    const size_t slice = (size_t)h->N * h->N;
+    HIPCHK(h, hipMalloc((void **)&dY, slice * sizeof(double)));
+    HIPCHK(h, hipMalloc((void **)&dflag, sizeof(int)));
+    HIPCHK(h, hipMemsetAsync(dflag, 0, sizeof(int), h->stream));
+    for (int t = 0; t < h->T; ++t) {
+        hipError_t e = hipMemcpyAsync(dY, Y + (size_t)t * slice, slice * sizeof(double),
+                                      hipMemcpyHostToDevice, h->stream);
+        if (e != hipSuccess) { hipFree(dY); hipFree(dflag); HIPCHK(h, e); }
+        hipLaunchKernelGGL(k_pack_bits, dim3(h->N), dim3(256), 0, h->stream, dY, h->N,
+                           h->W, 0, h->ybits + (size_t)t * h->N * h->W, dflag);
+        if (h->model == DLSM_DIRECTED)
+            hipLaunchKernelGGL(k_pack_bits, dim3(h->N), dim3(256), 0, h->stream, dY,
+                               h->N, h->W, 1, h->ytbits + (size_t)t * h->N * h->W, dflag);
+        hipStreamSynchronize(h->stream);
+    }
+    int flag = 0;
+    hipMemcpy(&flag, dflag, sizeof(int), hipMemcpyDeviceToHost);
+    hipFree(dY); hipFree(dflag);
+    HIPCHK(h, hipGetLastError());
+    if (flag) FAIL(h, DLSM_E_DATA, "network has entries other than 0.0 / 1.0 "
+                                   "(missing-edge sampling is not supported)");
+    h->have_network = true;
+    return DLSM_OK;
+}
+
+int dlsm_upload_edges(dlsm_chain *h, const int64_t *in_edges, int Din,
+                      const int64_t *out_edges, int Dout, const int64_t *degree) {
+    NEED(h, h && in_edges && out_edges && degree, "null argument");
+    NEED(h, h->model == DLSM_DIRECTED_CASE_CONTROL, "not a case-control chain");
+    NEED(h, Din >= 0 && Dout >= 0, "negative padded degree");
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t TN = (size_t)h->T * h->N;
+    for (size_t i = 0; i < TN; ++i) {
+        int64_t a = degree[i * 2], b = degree[i * 2 + 1];
+        if (a < 0 || a > Din || b < 0 || b > Dout)
+            FAIL(h, DLSM_E_DATA, "degree out of range at node %zu", i);
+    }
+    int rc = upload_i64_as_i32(h, &h->in_edges, in_edges, TN * Din); if (rc) return rc;
+    rc = upload_i64_as_i32(h, &h->out_edges, out_edges, TN * Dout); if (rc) return rc;
+    rc = upload_i64_as_i32(h, &h->degree, degree, TN * 2); if (rc) return rc;
+    h->Din = Din; h->Dout = Dout;
+    h->have_edges = true;
+    return DLSM_OK;
+}
+
+static int refresh_nctrl(dlsm_chain *h) {
+    const long TN = (long)h->T * h->N;
+    if (!h->lab_nk) {   // reuse: int32 [T*N*2] count buffer lives in spec-free slot
+    }
+    return DLSM_OK;
+}
+
+int dlsm_set_controls(dlsm_chain *h, const int64_t *ctrl_in, const int64_t *ctrl_out,
+                      int C) {
+    NEED(h, h && ctrl_in && ctrl_out && C > 0, "bad argument");
+    NEED(h, h->model == DLSM_DIRECTED_CASE_CONTROL, "not a case-control chain");
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t TN = (size_t)h->T * h->N;
+    int rc = upload_i64_as_i32(h, &h->ctrl_in, ctrl_in, TN * C); if (rc) return rc;
+    rc = upload_i64_as_i32(h, &h->ctrl_out, ctrl_out, TN * C); if (rc) return rc;
+    h->C = C;
+    h->have_controls = true;
+    (void)refresh_nctrl;
+    return DLSM_OK;
+}
+
+int dlsm_get_controls(dlsm_chain *h, int64_t *ctrl_in, int64_t *ctrl_out) {
+    NEED(h, h && ctrl_in && ctrl_out, "null argument");
+    NEED(h, h->have_controls, "controls not set");
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t n = (size_t)h->T * h->N * h->C;
+    std::vector<int32_t> tmp(n);
+    int rc = d2h(h, tmp.data(), h->ctrl_in, n); if (rc) return rc;
+    for (size_t i = 0; i < n; ++i) ctrl_in[i] = tmp[i];
+    rc = d2h(h, tmp.data(), h->ctrl_out, n); if (rc) return rc;
+    for (size_t i = 0; i < n; ++i) ctrl_out[i] = tmp[i];
+    return DLSM_OK;
+}
+
+int dlsm_resample_controls(dlsm_chain *h, uint32_t iter, int n_control) {
+    NEED(h, h != nullptr, "null handle");
+    NEED(h, h->model == DLSM_DIRECTED_CASE_CONTROL && h->have_edges,
+         "needs a case-control chain with edge lists");
+    NEED(h, n_control > 0, "n_control must be positive");
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t TN = (size_t)h->T * h->N;
+    if (h->C != n_control || !h->ctrl_in) {
+        if (h->ctrl_in) hipFree(h->ctrl_in);
+        if (h->ctrl_out) hipFree(h->ctrl_out);
+        h->ctrl_in = h->ctrl_out = nullptr;
+        int rc = dev_alloc(h, &h->ctrl_in, TN * n_control); if (rc) return rc;
+        rc = dev_alloc(h, &h->ctrl_out, TN * n_control); if (rc) return rc;
+        h->C = n_control;
+    }
+    ChainView v = h->view();
+    const int waves = 4;
+    const size_t lds = (size_t)waves * ((h->N + 31) / 32) * sizeof(uint32_t);
+    if (lds > 150 * 1024) FAIL(h, DLSM_E_LIMIT, "N too large for the control sampler");
+    hipLaunchKernelGGL(k_resample_controls, dim3((unsigned)((TN + waves - 1) / waves)),
+                       dim3(64 * waves), lds, h->stream, v, h->ctrl_in, h->ctrl_out,
+                       iter);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->have_controls = true;
+    return DLSM_OK;
+}
+
+// ---------------------------------------------------------------- state
+int dlsm_set_positions(dlsm_chain *h, const double *X) {
+    NEED(h, h && X, "null argument");
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc = h2d(h, h->X, X, (size_t)h->T * h->N * h->D);
+    if (!rc) h->have_X = true;
+    return rc;
+}
+
+int dlsm_get_positions(dlsm_chain *h, double *X) {
+    NEED(h, h && X, "null argument");
+    NEED(h, h->have_X, "latent positions not set");
+    HIPCHK(h, hipSetDevice(h->device));
+    return d2h(h, X, h->X, (size_t)h->T * h->N * h->D);
+}
+
+int dlsm_set_intercepts(dlsm_chain *h, const double *b, int n) {
+    NEED(h, h && b, "null argument");
+    NEED(h, n == (h->model == DLSM_UNDIRECTED ? 1 : 2), "wrong number of intercepts");
+    HIPCHK(h, hipSetDevice(h->device));
+    return h2d(h, h->intercept, b, n);
+}
+
+int dlsm_get_intercepts(dlsm_chain *h, double *b, int n) {
+    NEED(h, h && b && n >= 1 && n <= 2, "bad argument");
+    HIPCHK(h, hipSetDevice(h->device));
+    return d2h(h, b, h->intercept, n);
+}
+
+int dlsm_set_radii(dlsm_chain *h, const double *radii) {
+    NEED(h, h && radii, "null argument");
+    NEED(h, h->model != DLSM_UNDIRECTED, "radii belong to directed models");
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc = h2d(h, h->radii, radii, h->N);
+    if (!rc) h->have_radii = true;
+    return rc;
+}
+
+int dlsm_get_radii(dlsm_chain *h, double *radii) {
+    NEED(h, h && radii, "null argument");
+    NEED(h, h->have_radii, "radii not set");
+    HIPCHK(h, hipSetDevice(h->device));
+    return d2h(h, radii, h->radii, h->N);
+}
+
+int dlsm_set_squared(dlsm_chain *h, int squared) {
+    NEED(h, h != nullptr, "null handle");
+    h->squared = squared ? 1 : 0;
+    return DLSM_OK;
+}
+
+int dlsm_set_samplers(dlsm_chain *h, const double *step_size, const int32_t *n_accepted,
+                      const int32_t *n_steps, const int32_t *steps_until_tune, int tune,
+                      int tune_interval) {
+    NEED(h, h && step_size && n_accepted && n_steps && steps_until_tune, "null argument");
+    NEED(h, tune_interval > 0, "tune_interval must be positive");
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t TN = (size_t)h->T * h->N;
+    int rc = h2d(h, h->step, step_size, TN); if (rc) return rc;
+    rc = h2d(h, h->nacc, n_accepted, TN); if (rc) return rc;
+    rc = h2d(h, h->nsteps, n_steps, TN); if (rc) return rc;
+    rc = h2d(h, h->until, steps_until_tune, TN); if (rc) return rc;
+    h->tune = tune < 0 ? -1 : tune;
+    h->tune_interval = tune_interval;
+    h->have_samplers = true;
+    return DLSM_OK;
+}
+
+int dlsm_get_samplers(dlsm_chain *h, double *step_size, int32_t *n_accepted,
+                      int32_t *n_steps, int32_t *steps_until_tune) {
+    NEED(h, h && step_size && n_accepted && n_steps && steps_until_tune, "null argument");
+    NEED(h, h->have_samplers, "samplers not set");
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t TN = (size_t)h->T * h->N;
+    int rc = d2h(h, step_size, h->step, TN); if (rc) return rc;
+    rc = d2h(h, n_accepted, h->nacc, TN); if (rc) return rc;
+    rc = d2h(h, n_steps, h->nsteps, TN); if (rc) return rc;
+    return d2h(h, steps_until_tune, h->until, TN);
+}
+
+int dlsm_set_prior_random_walk(dlsm_chain *h, double tau_sq, double sigma_sq) {
+    NEED(h, h != nullptr, "null handle");
+    NEED(h, tau_sq > 0 && sigma_sq > 0, "variances must be positive");
+    h->prior_kind = DLSM_PRIOR_RANDOM_WALK;
+    h->tau_sq = tau_sq; h->sigma_sq = sigma_sq;
+    h->have_prior = true;
+    return DLSM_OK;
+}
+
+int dlsm_set_prior_mixture(dlsm_chain *h, const double *mu, const double *sigma,
+                           double lmbda, const int64_t *z, int K) {
+    NEED(h, h && mu && sigma && z, "null argument");
+    NEED(h, K >= 1 && K <= 64, "n_components must be in 1..64");
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t TN = (size_t)h->T * h->N;
+    for (size_t i = 0; i < TN; ++i)
+        if (z[i] < 0 || z[i] >= K) FAIL(h, DLSM_E_DATA, "label out of range at %zu", i);
+    if (h->K != K) {
+        if (h->mu) hipFree(h->mu);
+        if (h->sigma) hipFree(h->sigma);
+        h->mu = h->sigma = nullptr;
+        int rc = dev_alloc(h, &h->mu, (size_t)K * h->D); if (rc) return rc;
+        rc = dev_alloc(h, &h->sigma, K); if (rc) return rc;
+        h->K = K;
+    }
+    int rc = h2d(h, h->mu, mu, (size_t)K * h->D); if (rc) return rc;
+    rc = h2d(h, h->sigma, sigma, K); if (rc) return rc;
+    std::vector<int32_t> zz(TN);
+    for (size_t i = 0; i < TN; ++i) zz[i] = (int32_t)z[i];
+    rc = h2d(h, h->z, zz.data(), TN); if (rc) return rc;
+    h->lmbda = lmbda;
+    h->prior_kind = DLSM_PRIOR_MIXTURE;
+    h->have_prior = true;
+    return DLSM_OK;
+}
+
+// ---------------------------------------------------------------- log-lik
+int dlsm_loglik_full(dlsm_chain *h, int m, const double *intercepts, double *out) {
+    NEED(h, h && out, "null argument");
+    NEED(h, m >= 1 && m <= 16, "m must be in 1..16");
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc = check_ready_loglik(h); if (rc) return rc;
+    const int nic = h->model == DLSM_UNDIRECTED ? 1 : 2;
+    if (!intercepts) NEED(h, m == 1, "intercepts == NULL requires m == 1");
+    for (int k0 = 0; k0 < m; k0 += 2) {
+        const int M = std::min(2, m - k0);
+        const double *d_ic = h->intercept;
+        if (intercepts) {
+            memcpy(h->hsmall, intercepts + (size_t)k0 * nic, sizeof(double) * M * nic);
+            HIPCHK(h, hipMemcpyAsync(h->dsmall, h->hsmall, sizeof(double) * M * nic,
+                                     hipMemcpyHostToDevice, h->stream));
+            d_ic = h->dsmall;
+        }
+        int nrec = 0;
+        rc = loglik_records(h, M, d_ic, h->radii, h->radii, &nrec); if (rc) return rc;
+        hipLaunchKernelGGL(k_reduce_loglik, dim3(1), dim3(256), 0, h->stream, h->partials,
+                           nrec, h->model, M, d_ic, h->dsmall + 16);
+        HIPCHK(h, hipGetLastError());
+        HIPCHK(h, hipMemcpyAsync(h->hsmall + 16, h->dsmall + 16, sizeof(double) * M,
+                                 hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        for (int k = 0; k < M; ++k) out[k0 + k] = h->hsmall[16 + k];
+    }
+    return DLSM_OK;
+}
+
+int dlsm_loglik_full_radii(dlsm_chain *h, const double *radii_alt, double *out) {
+    NEED(h, h && radii_alt && out, "null argument");
+    NEED(h, h->model != DLSM_UNDIRECTED, "radii belong to directed models");
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc = check_ready_loglik(h); if (rc) return rc;
+    rc = h2d(h, h->radii_alt, radii_alt, h->N); if (rc) return rc;
+    // both candidates use the current intercepts
+    HIPCHK(h, hipMemcpyAsync(h->dsmall, h->intercept, 2 * sizeof(double),
+                             hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->dsmall + 2, h->intercept, 2 * sizeof(double),
+                             hipMemcpyDeviceToDevice, h->stream));
+    int nrec = 0;
+    rc = loglik_records(h, 2, h->dsmall, h->radii, h->radii_alt, &nrec); if (rc) return rc;
+    hipLaunchKernelGGL(k_reduce_loglik, dim3(1), dim3(256), 0, h->stream, h->partials, nrec,
+                       h->model, 2, h->dsmall, h->dsmall + 16);
+    HIPCHK(h, hipGetLastError());
+    return d2h(h, out, h->dsmall + 16, 2);
+}
+
+}  // extern "C"
+
+template <int DD>
+static int launch_partial(dlsm_chain *h, int with_prior, int t, int j, const double *d_x,
+                          double *d_out) {
+    ChainView v = h->view();
+    dim3 grid = t >= 0 ? dim3(1, 1) : dim3(h->N, h->T);
+    hipLaunchKernelGGL((k_partial_all<DD>), grid, dim3(256), 0, h->stream, v, with_prior,
+                       t, j, d_x, d_out);
+    HIPCHK(h, hipGetLastError());
+    return DLSM_OK;
+}
+
+static int check_ready_partial(dlsm_chain *h, int with_prior) {
+    int rc = check_ready_loglik(h); if (rc) return rc;
+    if (with_prior) NEED(h, h->have_prior, "prior not set");
+    return DLSM_OK;
+}
+
+extern "C" {
+
+int dlsm_loglik_partial(dlsm_chain *h, int t, int j, const double *x, int with_prior,
+                        double *out) {
+    NEED(h, h && out, "null argument");
+    NEED(h, t >= 0 && t < h->T && j >= 0 && j < h->N, "node (t=%d, j=%d) out of range", t, j);
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc = check_ready_partial(h, with_prior); if (rc) return rc;
+    const double *d_x = nullptr;
+    if (x) {
+        memcpy(h->hsmall, x, sizeof(double) * h->D);
+        HIPCHK(h, hipMemcpyAsync(h->dsmall, h->hsmall, sizeof(double) * h->D,
+                                 hipMemcpyHostToDevice, h->stream));
+        d_x = h->dsmall;
+    }
+    DISPATCH_D(h, h->D, rc = launch_partial<DD>(h, with_prior, t, j, d_x, h->dsmall + 16));
+    if (rc) return rc;
+    return d2h(h, out, h->dsmall + 16, 1);
+}
+
+int dlsm_loglik_partial_all(dlsm_chain *h, int with_prior, double *out) {
+    NEED(h, h && out, "null argument");
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc = check_ready_partial(h, with_prior); if (rc) return rc;
+    const size_t TN = (size_t)h->T * h->N;
+    rc = ensure_partials(h, TN); if (rc) return rc;
+    DISPATCH_D(h, h->D, rc = launch_partial<DD>(h, with_prior, -1, -1, nullptr, h->partials));
+    if (rc) return rc;
+    return d2h(h, out, h->partials, TN);
+}
+
+// ---------------------------------------------------------------- sweep
+}  // extern "C"
+
+static bool spec_supported(const dlsm_chain *h) { (void)h; return false; }
+
+template <int DD>
+static int launch_sweep_spec(dlsm_chain *h, uint32_t iter) {
+    (void)iter;
+    FAIL(h, DLSM_E_ARG, "speculative-batch sweep not available in this build");
+}
+
+template <int DD>
+static int launch_sweep(dlsm_chain *h, uint32_t iter, int algo) {
+    ChainView v = h->view();
+    ProfScope ps(h, DLSM_K_SWEEP);
+    if (h->model == DLSM_DIRECTED_CASE_CONTROL) {
+        const size_t TN = (size_t)h->T * h->N;
+        if (!h->lab_nk) {}
+        // nctrl lives at the tail of `spec`
+        size_t need = TN * 2 * sizeof(int32_t);
+        if (h->spec_cap < need) {
+            if (h->spec) hipFree(h->spec);
+            h->spec = nullptr; h->spec_cap = 0;
+            HIPCHK(h, hipMalloc((void **)&h->spec, need));
+            h->spec_cap = need;
+        }
+        int32_t *nctrl = (int32_t *)h->spec;
+        hipLaunchKernelGGL(k_count_controls, dim3((unsigned)((TN + 255) / 256)), dim3(256),
+                           0, h->stream, h->ctrl_in, h->ctrl_out, (long)TN, h->C, nctrl);
+        for (int parity = 0; parity < 2; ++parity) {
+            int nsl = (h->T - parity + 1) / 2;
+            if (nsl <= 0) continue;
+            hipLaunchKernelGGL((k_sweep_casecontrol<DD>), dim3(nsl), dim3(CC_THREADS), 0,
+                               h->stream, v, nctrl, iter, parity);
+        }
+        HIPCHK(h, hipGetLastError());
+        return DLSM_OK;
+    }
+    if (algo == 0) algo = spec_supported(h) && h->N >= 256 ? 2 : 1;
+    if (algo == 2) return launch_sweep_spec<DD>(h, iter);
+    const size_t lds = sweep_slice_lds_bytes(h->N, DD, h->W, h->model);
+    if (lds > 160 * 1024)
+        FAIL(h, DLSM_E_LIMIT, "N=%d needs %zu B of LDS in the slice sweep (max 163840)",
+             h->N, lds);
+    for (int parity = 0; parity < 2; ++parity) {
+        int nsl = (h->T - parity + 1) / 2;
+        if (nsl <= 0) continue;
+        if (h->model == DLSM_UNDIRECTED) {
+            auto kern = k_sweep_slice<DD, DLSM_UNDIRECTED>;
+            HIPCHK(h, hipFuncSetAttribute((const void *)kern,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(kern, dim3(nsl), dim3(SW_THREADS), lds, h->stream, v, iter, parity);
+        } else {
+            auto kern = k_sweep_slice<DD, DLSM_DIRECTED>;
+            HIPCHK(h, hipFuncSetAttribute((const void *)kern,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(kern, dim3(nsl), dim3(SW_THREADS), lds, h->stream, v, iter, parity);
+        }
+    }
+    HIPCHK(h, hipGetLastError());
+    return DLSM_OK;
+}
+
+static int check_ready_sweep(dlsm_chain *h) {
+    int rc = check_ready_loglik(h); if (rc) return rc;
+    NEED(h, h->have_samplers, "samplers not set");
+    NEED(h, h->have_prior, "prior not set");
+    return DLSM_OK;
+}
+
+static int enqueue_sweep(dlsm_chain *h, uint32_t iter, int algo) {
+    int rc = DLSM_OK;
+    DISPATCH_D(h, h->D, rc = launch_sweep<DD>(h, iter, algo));
+    return rc;
+}
+
+extern "C" {
+
+int dlsm_sweep_positions(dlsm_chain *h, uint32_t iter, int algo) {
+    NEED(h, h != nullptr, "null handle");
+    NEED(h, algo >= 0 && algo <= 2, "algo must be 0, 1 or 2");
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc = check_ready_sweep(h); if (rc) return rc;
+    rc = enqueue_sweep(h, iter, algo); if (rc) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return DLSM_OK;
+}
+
+}  // extern "C"
+
+template <int DD>
+static int launch_post(dlsm_chain *h, const double *d_xref, int do_center,
+                       LsmDeviceState *lsm, uint32_t iter, double *d_R) {
+    ChainView v = h->view();
+    ProfScope ps(h, DLSM_K_CENTER);
+    hipLaunchKernelGGL((k_post_sweep<DD>), dim3(1), dim3(PS_THREADS), 0, h->stream, v,
+                       d_xref, do_center, lsm, iter, d_R);
+    HIPCHK(h, hipGetLastError());
+    return DLSM_OK;
+}
+
+extern "C" {
+
+int dlsm_center(dlsm_chain *h) {
+    NEED(h, h != nullptr, "null handle");
+    NEED(h, h->have_X, "latent positions not set");
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc = DLSM_OK;
+    DISPATCH_D(h, h->D, rc = launch_post<DD>(h, nullptr, 1, nullptr, 0, nullptr));
+    if (rc) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return DLSM_OK;
+}
+
+int dlsm_procrustes(dlsm_chain *h, const double *X_ref, double *R_out) {
+    NEED(h, h && X_ref, "null argument");
+    NEED(h, h->have_X, "latent positions not set");
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc = h2d(h, h->xref, X_ref, (size_t)h->T * h->N * h->D); if (rc) return rc;
+    DISPATCH_D(h, h->D, rc = launch_post<DD>(h, h->xref, 0, nullptr, 0, h->dsmall + 32));
+    if (rc) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (R_out) return d2h(h, R_out, h->dsmall + 32, (size_t)h->D * h->D);
+    return DLSM_OK;
+}
+
+// ---------------------------------------------------------------- labels
+int dlsm_gaussian_likelihood(dlsm_chain *h, int node, int normalize, double *out) {
+    NEED(h, h && out, "null argument");
+    NEED(h, node >= 0 && node < h->N, "node out of range");
+    NEED(h, h->have_X && h->prior_kind == DLSM_PRIOR_MIXTURE && h->have_prior,
+         "needs positions and the mixture prior");
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t n = (size_t)h->T * h->K;
+    int rc = ensure_partials(h, n); if (rc) return rc;
+    ChainView v = h->view();
+    DISPATCH_D(h, h->D, hipLaunchKernelGGL((k_gauss_table<DD>), dim3(1), dim3(64), 0,
+                                           h->stream, v, node, normalize, h->partials));
+    HIPCHK(h, hipGetLastError());
+    return d2h(h, out, h->partials, n);
+}
+
+int dlsm_sample_labels(dlsm_chain *h, uint32_t iter, const double *w, int64_t *z,
+                       double *n, int64_t *nk) {
+    NEED(h, h && w && z && n && nk, "null argument");
+    NEED(h, h->have_X && h->prior_kind == DLSM_PRIOR_MIXTURE && h->have_prior,
+         "needs positions and the mixture prior");
+    HIPCHK(h, hipSetDevice(h->device));
+    const int T = h->T, K = h->K, N = h->N;
+    const size_t nn = (size_t)T * K * K, nnk = (size_t)T * K;
+    if (!h->lab_n) {
+        int rc = dev_alloc(h, &h->lab_n, nn); if (rc) return rc;
+        rc = dev_alloc(h, &h->lab_nk, nnk); if (rc) return rc;
+        rc = dev_alloc(h, &h->lab_w, nn); if (rc) return rc;
+    }
+    const size_t lds = (size_t)LAB_WAVES * 3 * T * K * sizeof(double);
+    if (lds > 160 * 1024) FAIL(h, DLSM_E_LIMIT, "T*K=%d too large for the label kernel", T * K);
+    HIPCHK(h, hipMemcpyAsync(h->lab_w, w, nn * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->lab_n, 0, nn * sizeof(int32_t), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->lab_nk, 0, nnk * sizeof(int32_t), h->stream));
+    ChainView v = h->view();
+    {
+        ProfScope ps(h, DLSM_K_LABELS);
+        DISPATCH_D(h, h->D, {
+            auto kern = k_sample_labels<DD>;
+            HIPCHK(h, hipFuncSetAttribute((const void *)kern,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(kern, dim3((N + LAB_WAVES - 1) / LAB_WAVES),
+                               dim3(64 * LAB_WAVES), lds, h->stream, v, h->lab_w, iter,
+                               h->z, h->lab_n, h->lab_nk);
+        });
+    }
+    HIPCHK(h, hipGetLastError());
+    std::vector<int32_t> zz((size_t)T * N), cn(nn), cnk(nnk);
+    int rc = d2h(h, zz.data(), h->z, zz.size()); if (rc) return rc;
+    rc = d2h(h, cn.data(), h->lab_n, nn); if (rc) return rc;
+    rc = d2h(h, cnk.data(), h->lab_nk, nnk); if (rc) return rc;
+    for (size_t i = 0; i < zz.size(); ++i) z[i] = zz[i];
+    for (size_t i = 0; i < nn; ++i) n[i] = (double)cn[i];
+    for (size_t i = 0; i < nnk; ++i) nk[i] = cnk[i];
+    return DLSM_OK;
+}
+
+// ---------------------------------------------------------------- LSM chain
+int dlsm_lsm_configure(dlsm_chain *h, const dlsm_lsm_config *cfg) {
+    NEED(h, h && cfg, "null argument");
+    NEED(h, cfg->intercept_variance_prior > 0, "intercept_variance_prior must be positive");
+    NEED(h, cfg->i_tune_interval > 0, "tune_interval must be positive");
+    HIPCHK(h, hipSetDevice(h->device));
+    LsmDeviceState s;
+    memset(&s, 0, sizeof(s));
+    for (int k = 0; k < 2; ++k) {
+        s.intercept_prior[k] = cfg->intercept_prior[k];
+        s.i_step[k] = cfg->i_step_size[k];
+        s.i_nacc[k] = cfg->i_n_accepted[k];
+        s.i_nsteps[k] = cfg->i_n_steps[k];
+        s.i_until[k] = cfg->i_steps_until_tune[k];
+    }
+    s.intercept_var = cfg->intercept_variance_prior;
+    s.i_tune = cfg->i_tune < 0 ? -1 : cfg->i_tune;
+    s.i_tune_interval = cfg->i_tune_interval;
+    HIPCHK(h, hipMemcpy(h->lsm, &s, sizeof(s), hipMemcpyHostToDevice));
+    h->lsm_cfg = *cfg;
+    h->lsm_configured = true;
+    return DLSM_OK;
+}
+
+int dlsm_lsm_get_config(dlsm_chain *h, dlsm_lsm_config *cfg) {
+    NEED(h, h && cfg, "null argument");
+    NEED(h, h->lsm_configured, "LSM chain not configured");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    LsmDeviceState s;
+    HIPCHK(h, hipMemcpy(&s, h->lsm, sizeof(s), hipMemcpyDeviceToHost));
+    *cfg = h->lsm_cfg;
+    for (int k = 0; k < 2; ++k) {
+        cfg->i_step_size[k] = s.i_step[k];
+        cfg->i_n_accepted[k] = s.i_nacc[k];
+        cfg->i_n_steps[k] = s.i_nsteps[k];
+        cfg->i_steps_until_tune[k] = s.i_until[k];
+    }
+    return DLSM_OK;
+}
+
+int dlsm_trace_alloc(dlsm_chain *h, int n_total, double logp0) {
+    NEED(h, h && n_total >= 1, "bad argument");
+    NEED(h, h->have_X, "latent positions not set");
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t row = (size_t)h->T * h->N * h->D;
+    void *old[] = {h->trace_X, h->trace_ic, h->trace_logp};
+    for (void *p : old) if (p) hipFree(p);
+    h->trace_X = h->trace_ic = h->trace_logp = nullptr;
+    int rc = dev_alloc(h, &h->trace_X, row * n_total); if (rc) return rc;
+    rc = dev_alloc(h, &h->trace_ic, (size_t)2 * n_total); if (rc) return rc;
+    rc = dev_alloc(h, &h->trace_logp, n_total); if (rc) return rc;
+    h->trace_n = n_total;
+    HIPCHK(h, hipMemsetAsync(h->trace_ic, 0, sizeof(double) * 2 * n_total, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->trace_logp, 0, sizeof(double) * n_total, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->trace_X, h->X, row * sizeof(double),
+                             hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->trace_ic, h->intercept, 2 * sizeof(double),
+                             hipMemcpyDeviceToDevice, h->stream));
+    h->hsmall[0] = logp0;
+    HIPCHK(h, hipMemcpyAsync(h->trace_logp, h->hsmall, sizeof(double),
+                             hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return DLSM_OK;
+}
+
+int dlsm_lsm_run(dlsm_chain *h, int first, int count, int procrustes_ref) {
+    NEED(h, h != nullptr, "null handle");
+    NEED(h, h->model == DLSM_UNDIRECTED, "the device-resident loop covers the undirected model");
+    NEED(h, h->lsm_configured && h->trace_X, "configure the chain and allocate the trace first");
+    NEED(h, h->prior_kind == DLSM_PRIOR_RANDOM_WALK, "LSM uses the random-walk prior");
+    NEED(h, first >= 1 && count >= 0 && first + count <= h->trace_n, "iteration range out of the trace");
+    NEED(h, procrustes_ref < h->trace_n, "procrustes_ref out of the trace");
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc = check_ready_sweep(h); if (rc) return rc;
+    const size_t row = (size_t)h->T * h->N * h->D;
+    for (int it = first; it < first + count; ++it) {
+        rc = enqueue_sweep(h, (uint32_t)it, h->lsm_cfg.sweep_algo); if (rc) return rc;
+        const double *xref = (it > h->lsm_cfg.n_iter_procrustes && procrustes_ref >= 0)
+                                 ? h->trace_X + row * procrustes_ref : nullptr;
+        DISPATCH_D(h, h->D, rc = launch_post<DD>(h, xref, 1, h->lsm, (uint32_t)it, nullptr));
+        if (rc) return rc;
+        int nrec = 0;
+        rc = loglik_records(h, 2, h->lsm->cand, nullptr, nullptr, &nrec); if (rc) return rc;
+        {
+            ProfScope ps(h, DLSM_K_FINALIZE);
+            hipLaunchKernelGGL(k_lsm_finalize, dim3(1), dim3(256), 0, h->stream, h->partials,
+                               nrec, h->lsm, h->intercept, h->trace_ic, h->trace_logp, it);
+            HIPCHK(h, hipMemcpyAsync(h->trace_X + row * it, h->X, row * sizeof(double),
+                                     hipMemcpyDeviceToDevice, h->stream));
+        }
+        HIPCHK(h, hipGetLastError());
+    }
+    return DLSM_OK;
+}
+
+int dlsm_trace_read(dlsm_chain *h, int first, int count, double *Xs, double *intercepts,
+                    double *logps) {
+    NEED(h, h != nullptr, "null handle");
+    NEED(h, h->trace_X, "no trace allocated");
+    NEED(h, first >= 0 && count >= 0 && first + count <= h->trace_n, "range out of the trace");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const size_t row = (size_t)h->T * h->N * h->D;
+    if (Xs) HIPCHK(h, hipMemcpy(Xs, h->trace_X + row * first, row * count * sizeof(double), hipMemcpyDeviceToHost));
+    if (intercepts) HIPCHK(h, hipMemcpy(intercepts, h->trace_ic + (size_t)2 * first, sizeof(double) * 2 * count, hipMemcpyDeviceToHost));
+    if (logps) HIPCHK(h, hipMemcpy(logps, h->trace_logp + first, sizeof(double) * count, hipMemcpyDeviceToHost));
+    return DLSM_OK;
+}
+
+// ---------------------------------------------------------------- measurement
+int dlsm_profile_enable(dlsm_chain *h, int on) {
+    NEED(h, h != nullptr, "null handle");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    drain_profile(h);
+    if (on) for (int k = 0; k < DLSM_K_COUNT; ++k) { h->prof[k].ms = 0; h->prof[k].launches = 0; }
+    h->profiling = on != 0;
+    return DLSM_OK;
+}
+
+int dlsm_profile_read(dlsm_chain *h, int kernel, double *total_ms, int *launches) {
+    NEED(h, h && total_ms && launches, "null argument");
+    NEED(h, kernel >= 0 && kernel < DLSM_K_COUNT, "bad kernel id");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    drain_profile(h);
+    *total_ms = h->prof[kernel].ms;
+    *launches = h->prof[kernel].launches;
+    return DLSM_OK;
+}
+
+int dlsm_timer_start(dlsm_chain *h) {
+    NEED(h, h != nullptr, "null handle");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipEventRecord(h->timer0, h->stream));
+    return DLSM_OK;
+}
+
+int dlsm_timer_stop(dlsm_chain *h, double *ms) {
+    NEED(h, h && ms, "null argument");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipEventRecord(h->timer1, h->stream));
+    HIPCHK(h, hipEventSynchronize(h->timer1));
+    float f = 0.f;
+    HIPCHK(h, hipEventElapsedTime(&f, h->timer0, h->timer1));
+    *ms = f;
+    return DLSM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,112 @@
+// Host-side chain handle and the POD view of it that kernels receive by value.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/dynetlsm_hip.h"
+
+namespace dlsm {
+
+// Everything a kernel needs to know about one chain (device pointers + scalars).
+struct ChainView {
+    int T, N, D, model, squared;
+    int W;                      // uint32 words per bit row (multiple of 4)
+    const uint32_t *ybits;      // [T][N][W]  bit i of row j = Y[t, j, i]
+    const uint32_t *ytbits;     // [T][N][W]  bit i of row j = Y[t, i, j] (directed)
+    // case-control (int32 on device)
+    const int32_t *in_edges;  int Din;
+    const int32_t *out_edges; int Dout;
+    const int32_t *degree;      // [T][N][2]
+    const int32_t *ctrl_in;     // [T][N][C], -1 padded
+    const int32_t *ctrl_out;  int C;
+    double *X;                  // [T][N][D]
+    const double *intercept;    // device [2]
+    const double *radii;        // device [N]
+    int prior_kind;
+    double tau_sq, sigma_sq;
+    const double *mu; const double *sigma; double lmbda; const int32_t *z; int K;
+    double *step; int32_t *nacc; int32_t *nsteps; int32_t *until;
+    int tune, tune_interval;
+    uint64_t seed; uint32_t chain;
+};
+
+// intercept sampler + LSM bookkeeping that lives on the device
+struct LsmDeviceState {
+    double intercept_prior[2];
+    double intercept_var;
+    double i_step[2];
+    int32_t i_nacc[2], i_nsteps[2], i_until[2];
+    int32_t i_tune, i_tune_interval;
+    double cand[4];             // candidate intercepts of the current MH step
+    double prior_x;             // latent-position prior terms of logp (lsm.py:604-613)
+    double logu;                // log-uniform of the intercept accept test
+};
+
+struct ProfileSlot {
+    double ms = 0.0;
+    int launches = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+
+}  // namespace dlsm
+
+struct dlsm_chain {
+    int device = 0;
+    int T = 0, N = 0, D = 0, model = 0, squared = 0;
+    uint64_t seed = 0; uint32_t chain = 0;
+    hipStream_t stream = nullptr;
+    // network
+    int W = 0;
+    uint32_t *ybits = nullptr, *ytbits = nullptr;
+    bool have_network = false;
+    int Din = 0, Dout = 0, C = 0;
+    int32_t *in_edges = nullptr, *out_edges = nullptr, *degree = nullptr;
+    int32_t *ctrl_in = nullptr, *ctrl_out = nullptr;
+    bool have_edges = false, have_controls = false;
+    // state
+    double *X = nullptr, *intercept = nullptr, *radii = nullptr, *radii_alt = nullptr;
+    bool have_X = false, have_radii = false;
+    double *step = nullptr; int32_t *nacc = nullptr, *nsteps = nullptr, *until = nullptr;
+    int tune = -1, tune_interval = 100;
+    bool have_samplers = false;
+    int prior_kind = 0; double tau_sq = 2.0, sigma_sq = 0.1;
+    double *mu = nullptr, *sigma = nullptr; double lmbda = 0.0; int32_t *z = nullptr;
+    int K = 0; bool have_prior = false;
+    // scratch
+    double *partials = nullptr; size_t partials_cap = 0;   // doubles
+    double *dsmall = nullptr;      // 64 doubles of device scratch
+    double *hsmall = nullptr;      // 64 doubles of pinned host scratch
+    double *xref = nullptr;        // T*N*D (procrustes reference staging)
+    int32_t *lab_n = nullptr, *lab_nk = nullptr; double *lab_w = nullptr;
+    // sweep v2 scratch
+    double *spec = nullptr; size_t spec_cap = 0;
+    // LSM device-resident chain
+    dlsm::LsmDeviceState *lsm = nullptr;
+    dlsm_lsm_config lsm_cfg{};
+    bool lsm_configured = false;
+    double *trace_X = nullptr, *trace_ic = nullptr, *trace_logp = nullptr;
+    int trace_n = 0;
+    // measurement
+    bool profiling = false;
+    dlsm::ProfileSlot prof[DLSM_K_COUNT];
+    hipEvent_t timer0 = nullptr, timer1 = nullptr;
+    std::string err;
+
+    dlsm::ChainView view() const {
+        dlsm::ChainView v;
+        v.T = T; v.N = N; v.D = D; v.model = model; v.squared = squared; v.W = W;
+        v.ybits = ybits; v.ytbits = ytbits;
+        v.in_edges = in_edges; v.Din = Din; v.out_edges = out_edges; v.Dout = Dout;
+        v.degree = degree; v.ctrl_in = ctrl_in; v.ctrl_out = ctrl_out; v.C = C;
+        v.X = X; v.intercept = intercept; v.radii = radii;
+        v.prior_kind = prior_kind; v.tau_sq = tau_sq; v.sigma_sq = sigma_sq;
+        v.mu = mu; v.sigma = sigma; v.lmbda = lmbda; v.z = z; v.K = K;
+        v.step = step; v.nacc = nacc; v.nsteps = nsteps; v.until = until;
+        v.tune = tune; v.tune_interval = tune_interval;
+        v.seed = seed; v.chain = chain;
+        return v;
+    }
+};

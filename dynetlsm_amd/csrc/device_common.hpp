@@ -1,0 +1,137 @@
+// Device-side building blocks shared by every kernel of the engine:
+// Philox4x32-10 counter RNG, wave/workgroup reductions for 64-wide wavefronts,
+// and the per-dyad log-likelihood algebra.  gfx950 only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dlsm {
+
+// ---- RNG streams (counter word 3, low byte); shared with the CPU oracle ----
+enum : uint32_t {
+    STREAM_SWEEP_NORMAL = 0,
+    STREAM_SWEEP_UNIFORM = 1,
+    STREAM_INTERCEPT = 2,
+    STREAM_LABELS = 3,
+    STREAM_CONTROLS = 4
+};
+
+struct U4 { uint32_t x, y, z, w; };
+
+__host__ __device__ __forceinline__ U4 philox4x32_10(uint64_t seed, uint32_t c0,
+                                                     uint32_t c1, uint32_t c2,
+                                                     uint32_t c3) {
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return U4{c0, c1, c2, c3};
+}
+
+// 53 random bits -> (0, 1]; every value exactly representable
+__host__ __device__ __forceinline__ double u53(uint32_t hi, uint32_t lo) {
+    double k = (double)(hi >> 5) * 67108864.0 + (double)(lo >> 6);
+    return (k + 1.0) * (1.0 / 9007199254740992.0);
+}
+
+__host__ __device__ __forceinline__ uint32_t stream_word(uint32_t chain,
+                                                         uint32_t stream) {
+    return (chain << 8) | stream;
+}
+
+__device__ __forceinline__ void philox_uniform2(uint64_t seed, uint32_t c0,
+                                                uint32_t c1, uint32_t c2,
+                                                uint32_t c3, double &u0, double &u1) {
+    U4 r = philox4x32_10(seed, c0, c1, c2, c3);
+    u0 = u53(r.x, r.y);
+    u1 = u53(r.z, r.w);
+}
+
+__device__ __forceinline__ void box_muller(double u0, double u1, double &z0,
+                                           double &z1) {
+    double r = sqrt(-2.0 * log(u0));
+    double a = 6.283185307179586476925286766559 * u1;
+    double s, c;
+    sincos(a, &s, &c);
+    z0 = r * c;
+    z1 = r * s;
+}
+
+// ---- reductions ------------------------------------------------------------
+__device__ __forceinline__ double wave_sum_all(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// Sum over the workgroup, result in every thread.  `buf` holds NW doubles of LDS
+// that nobody rewrites before every wave has passed the barrier below (callers
+// that loop alternate between two buffers).
+template <int NW>
+__device__ __forceinline__ double block_sum_all(double v, double *buf, int tid) {
+    v = wave_sum_all(v);
+    if ((tid & 63) == 0) buf[tid >> 6] = v;
+    __syncthreads();
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) s += buf[w];
+    return s;
+}
+
+// ---- geometry --------------------------------------------------------------
+template <int D>
+__device__ __forceinline__ double dist_of(const double *a, const double *b,
+                                          int squared) {
+    double s = 0.0;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        double df = a[d] - b[d];
+        s += df * df;
+    }
+    return squared ? s : sqrt(s);
+}
+
+__device__ __forceinline__ int bit_of(const uint32_t *row, int i) {
+    return (row[i >> 5] >> (i & 31)) & 1;
+}
+
+// metropolis.py:5-20
+__device__ __forceinline__ double tune_rw(double step, double rate) {
+    if (rate < 0.001) step *= 0.1;
+    else if (rate < 0.05) step *= 0.5;
+    else if (rate < 0.25) step *= 0.9;
+    else if (rate > 0.95) step *= 10.0;
+    else if (rate > 0.75) step *= 2.0;
+    else if (rate > 0.4) step *= 1.1;
+    return step;
+}
+
+// metropolis.py:110-136 (incl. the tune_interval+1 window of the reference)
+__device__ __forceinline__ void metropolis_bookkeeping(double &step, int32_t &n_acc,
+                                                       int32_t &n_steps,
+                                                       int32_t &until, int tune,
+                                                       int tune_interval,
+                                                       int accepted) {
+    n_acc += accepted;
+    n_steps += 1;
+    if (tune >= 0) {
+        if (n_steps < tune && until == 0) {
+            double rate = (double)n_acc / (double)tune_interval;
+            step = tune_rw(step, rate);
+            n_acc = 0;
+            until = tune_interval;
+        } else {
+            until -= 1;
+        }
+    }
+}
+
+}  // namespace dlsm

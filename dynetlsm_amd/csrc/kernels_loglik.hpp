@@ -1,0 +1,495 @@
+// Network packing and log-likelihood kernels.
+#pragma once
+#include "chain.hpp"
+#include "device_common.hpp"
+
+namespace dlsm {
+
+// ---------------------------------------------------------------------------
+// pack: float64 adjacency -> 1 bit / dyad.  One wave reads 64 consecutive
+// doubles of a row (coalesced 512 B) and ballots them into two uint32 words.
+// transpose != 0 builds bit i of row j = Y[t, i, j].
+// flag[0] |= 1 when an entry is neither 0.0 nor 1.0.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pack_bits(const double *__restrict__ Y,
+                                                   int N, int W, int transpose,
+                                                   uint32_t *__restrict__ bits,
+                                                   int *__restrict__ flag) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int row = blockIdx.x;            // over T*N rows
+    const int t = row / N, j = row % N;
+    const int nseg = (W * 32) / 64;        // W is a multiple of 4 -> whole segments
+    for (int seg = wave; seg < nseg; seg += 4) {
+        int i = seg * 64 + lane;
+        double y = 0.0;
+        if (i < N)
+            y = transpose ? Y[((size_t)t * N + i) * N + j]
+                          : Y[((size_t)t * N + j) * N + i];
+        if (y != 0.0 && y != 1.0) atomicOr(flag, 1);
+        unsigned long long m = __ballot(y != 0.0);
+        if (lane == 0) {
+            bits[(size_t)row * W + seg * 2] = (uint32_t)m;
+            bits[(size_t)row * W + seg * 2 + 1] = (uint32_t)(m >> 32);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Full log-likelihood, undirected (a4) and directed (a5).
+//
+// Grid: T x (upper-triangular 128x128 tiles); 256 threads; thread = one column
+// j of the tile x one half (64) of its rows.  X tiles and the tile's Y bits are
+// staged in LDS; X_i is an LDS broadcast, X_j stays in registers.
+// Per-thread accumulators in fp64, wave shuffle -> LDS -> one partial record per
+// workgroup; k_reduce_partials sums the records in a fixed order (deterministic).
+//
+// Undirected, candidate k:  ll_k = b_k*SY - SYd - sum log(1 + exp(b_k) e^{-d})
+//   (SY = sum Y, SYd = sum Y d are intercept-independent: every candidate of the
+//    intercept MH step and the log-posterior trace come out of ONE pass.)
+// Directed, candidate k = (b_in, b_out, radii_k): both directions of a pair
+//   share the distance.
+// Record layout: [SY, SYd, S_0 .. S_{M-1}] (undirected), [L_0 .. L_{M-1}] (directed)
+// ---------------------------------------------------------------------------
+constexpr int LL_TILE = 128;
+constexpr int LL_THREADS = 256;
+
+struct LoglikCand {
+    const double *intercepts;   // device, M x (1|2)
+    const double *radii[2];     // device N, per candidate (directed)
+};
+
+__device__ __forceinline__ void tile_decode(int r, int nt, int &ti, int &tj) {
+    // r-th tile of the upper triangle (ti <= tj), row-major
+    ti = 0;
+    int rowlen = nt;
+    while (r >= rowlen) { r -= rowlen; ++ti; --rowlen; }
+    tj = ti + r;
+}
+
+template <int D, int M>
+__global__ __launch_bounds__(LL_THREADS) void k_loglik_undirected(
+    ChainView c, LoglikCand cand, double *__restrict__ partials) {
+    __shared__ double sXi[LL_TILE * D];
+    __shared__ double sXj[LL_TILE * D];
+    __shared__ uint32_t sY[LL_TILE * 4];
+    __shared__ double sRed[4 * (2 + M)];
+    const int tid = threadIdx.x;
+    const int nt = (c.N + LL_TILE - 1) / LL_TILE;
+    const int ntri = nt * (nt + 1) / 2;
+    const int t = blockIdx.x / ntri;
+    int ti, tj;
+    tile_decode(blockIdx.x % ntri, nt, ti, tj);
+    const int i0 = ti * LL_TILE, j0 = tj * LL_TILE;
+    const double *Xt = c.X + (size_t)t * c.N * D;
+    for (int k = tid; k < LL_TILE * D; k += LL_THREADS) {
+        int gi = i0 * D + k, gj = j0 * D + k;
+        sXi[k] = gi < c.N * D ? Xt[gi] : 0.0;
+        sXj[k] = gj < c.N * D ? Xt[gj] : 0.0;
+    }
+    for (int k = tid; k < LL_TILE * 4; k += LL_THREADS) {
+        int r = k >> 2, w = k & 3, gi = i0 + r;
+        sY[k] = gi < c.N ? c.ybits[((size_t)t * c.N + gi) * c.W + (j0 >> 5) + w] : 0u;
+    }
+    double E[M];
+#pragma unroll
+    for (int k = 0; k < M; ++k) E[k] = exp(cand.intercepts[k]);
+    __syncthreads();
+
+    const int cj = tid & (LL_TILE - 1);
+    const int half = tid >> 7;
+    const int j = j0 + cj;
+    double xj[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) xj[d] = sXj[cj * D + d];
+    double sy = 0.0, syd = 0.0, S[M];
+#pragma unroll
+    for (int k = 0; k < M; ++k) S[k] = 0.0;
+    if (j < c.N) {
+        const int rbeg = half * 64;
+        for (int r = rbeg; r < rbeg + 64; ++r) {
+            const int i = i0 + r;
+            if (i >= j) break;           // i < j only (also stops at i >= N)
+            const double dd = dist_of<D>(&sXi[r * D], xj, c.squared);
+            const double e = exp(-dd);
+            const int y = (sY[r * 4 + (cj >> 5)] >> (cj & 31)) & 1;
+            if (y) { sy += 1.0; syd += dd; }
+#pragma unroll
+            for (int k = 0; k < M; ++k) S[k] += log(1.0 + E[k] * e);
+        }
+    }
+    double acc[2 + M];
+    acc[0] = sy; acc[1] = syd;
+#pragma unroll
+    for (int k = 0; k < M; ++k) acc[2 + k] = S[k];
+#pragma unroll
+    for (int q = 0; q < 2 + M; ++q) {
+        double v = wave_sum_all(acc[q]);
+        if ((tid & 63) == 0) sRed[(tid >> 6) * (2 + M) + q] = v;
+    }
+    __syncthreads();
+    if (tid < 2 + M) {
+        double s = 0.0;
+        for (int w = 0; w < 4; ++w) s += sRed[w * (2 + M) + tid];
+        partials[(size_t)blockIdx.x * (2 + M) + tid] = s;
+    }
+}
+
+template <int D, int M>
+__global__ __launch_bounds__(LL_THREADS) void k_loglik_directed(
+    ChainView c, LoglikCand cand, double *__restrict__ partials) {
+    __shared__ double sXi[LL_TILE * D];
+    __shared__ double sXj[LL_TILE * D];
+    __shared__ double sRi[M][LL_TILE];      // 1 / radii of the row nodes
+    __shared__ double sRj[M][LL_TILE];
+    __shared__ uint32_t sY[LL_TILE * 4];    // Y[i, j]
+    __shared__ uint32_t sYT[LL_TILE * 4];   // Y[j, i]
+    __shared__ double sRed[4 * M];
+    const int tid = threadIdx.x;
+    const int nt = (c.N + LL_TILE - 1) / LL_TILE;
+    const int ntri = nt * (nt + 1) / 2;
+    const int t = blockIdx.x / ntri;
+    int ti, tj;
+    tile_decode(blockIdx.x % ntri, nt, ti, tj);
+    const int i0 = ti * LL_TILE, j0 = tj * LL_TILE;
+    const double *Xt = c.X + (size_t)t * c.N * D;
+    for (int k = tid; k < LL_TILE * D; k += LL_THREADS) {
+        int gi = i0 * D + k, gj = j0 * D + k;
+        sXi[k] = gi < c.N * D ? Xt[gi] : 0.0;
+        sXj[k] = gj < c.N * D ? Xt[gj] : 0.0;
+    }
+    for (int k = tid; k < LL_TILE; k += LL_THREADS) {
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            sRi[m][k] = (i0 + k) < c.N ? 1.0 / cand.radii[m][i0 + k] : 1.0;
+            sRj[m][k] = (j0 + k) < c.N ? 1.0 / cand.radii[m][j0 + k] : 1.0;
+        }
+    }
+    for (int k = tid; k < LL_TILE * 4; k += LL_THREADS) {
+        int r = k >> 2, w = k & 3, gi = i0 + r;
+        size_t off = ((size_t)t * c.N + gi) * c.W + (j0 >> 5) + w;
+        sY[k] = gi < c.N ? c.ybits[off] : 0u;
+        sYT[k] = gi < c.N ? c.ytbits[off] : 0u;
+    }
+    double bin[M], bout[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+        bin[m] = cand.intercepts[2 * m];
+        bout[m] = cand.intercepts[2 * m + 1];
+    }
+    __syncthreads();
+
+    const int cj = tid & (LL_TILE - 1);
+    const int half = tid >> 7;
+    const int j = j0 + cj;
+    double xj[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) xj[d] = sXj[cj * D + d];
+    double L[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) L[m] = 0.0;
+    if (j < c.N) {
+        const int rbeg = half * 64;
+        for (int r = rbeg; r < rbeg + 64; ++r) {
+            const int i = i0 + r;
+            if (i >= j) break;
+            const double dd = dist_of<D>(&sXi[r * D], xj, c.squared);
+            const double yij = (double)((sY[r * 4 + (cj >> 5)] >> (cj & 31)) & 1);
+            const double yji = (double)((sYT[r * 4 + (cj >> 5)] >> (cj & 31)) & 1);
+#pragma unroll
+            for (int m = 0; m < M; ++m) {
+                const double ri = sRi[m][r], rj = sRj[m][cj];
+                // i -> j : directed_likelihoods_fast.pyx:199-203
+                double eta = bin[m] * (1.0 - dd * rj) + bout[m] * (1.0 - dd * ri);
+                double e2 = bin[m] * (1.0 - dd * ri) + bout[m] * (1.0 - dd * rj);
+                L[m] += yij * eta + yji * e2 -
+                        log((1.0 + exp(eta)) * (1.0 + exp(e2)));
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+        double v = wave_sum_all(L[m]);
+        if ((tid & 63) == 0) sRed[(tid >> 6) * M + m] = v;
+    }
+    __syncthreads();
+    if (tid < M) {
+        double s = 0.0;
+        for (int w = 0; w < 4; ++w) s += sRed[w * M + tid];
+        partials[(size_t)blockIdx.x * M + tid] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Case-control full log-likelihood (a6): one wave per (t, i); lanes stride over
+// the node's out-edges and out-controls (gathers of X / radii through L2).
+// Record per workgroup: [L_0 .. L_{M-1}]
+// ---------------------------------------------------------------------------
+template <int D, int M>
+__global__ __launch_bounds__(256) void k_loglik_casecontrol(
+    ChainView c, LoglikCand cand, double *__restrict__ partials) {
+    __shared__ double sRed[4 * M];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long node = (long)blockIdx.x * 4 + wave;       // over T*N
+    double L[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) L[m] = 0.0;
+    if (node < (long)c.T * c.N) {
+        const int t = (int)(node / c.N), i = (int)(node % c.N);
+        const double *Xt = c.X + (size_t)t * c.N * D;
+        double xi[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) xi[d] = Xt[(size_t)i * D + d];
+        const int out_deg = c.degree[node * 2 + 1];
+        const int32_t *oe = c.out_edges + node * c.Dout;
+        const int32_t *co = c.ctrl_out + node * c.C;
+        double bin[M], bout[M], iri[M];
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            bin[m] = cand.intercepts[2 * m];
+            bout[m] = cand.intercepts[2 * m + 1];
+            iri[m] = 1.0 / cand.radii[m][i];
+        }
+        // out edges : directed_likelihoods_fast.pyx:236-247
+        for (int k = lane; k < out_deg; k += 64) {
+            const int e = oe[k];
+            const double dd = dist_of<D>(&Xt[(size_t)e * D], xi, c.squared);
+#pragma unroll
+            for (int m = 0; m < M; ++m) {
+                double eta = bin[m] * (1.0 - dd / cand.radii[m][e]) +
+                             bout[m] * (1.0 - dd * iri[m]);
+                L[m] += eta - log(1.0 + exp(eta));
+            }
+        }
+        // control estimate : :250-268 (the list is -1 terminated)
+        double ctl[M];
+#pragma unroll
+        for (int m = 0; m < M; ++m) ctl[m] = 0.0;
+        int nctl = 0;
+        for (int k0 = 0; k0 < c.C; k0 += 64) {
+            const int k = k0 + lane;
+            const int e = k < c.C ? co[k] : -1;
+            unsigned long long valid = __ballot(e >= 0);
+            // entries after the first -1 are ignored (break at the sentinel)
+            unsigned long long inv = ~valid;
+            int first_bad = inv ? __builtin_ctzll(inv) : 64;
+            if (lane < first_bad) {
+                const double dd = dist_of<D>(&Xt[(size_t)e * D], xi, c.squared);
+#pragma unroll
+                for (int m = 0; m < M; ++m) {
+                    double eta = bin[m] * (1.0 - dd / cand.radii[m][e]) +
+                                 bout[m] * (1.0 - dd * iri[m]);
+                    ctl[m] += log(1.0 + exp(eta));
+                }
+            }
+            nctl += first_bad;
+            if (first_bad < 64) break;
+        }
+        const double adj = (double)(c.N - out_deg - 1) / (double)nctl;
+#pragma unroll
+        for (int m = 0; m < M; ++m) L[m] -= adj * ctl[m];
+    }
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+        double v = wave_sum_all(L[m]);
+        if (lane == 0) sRed[wave * M + m] = v;
+    }
+    __syncthreads();
+    if (tid < M) {
+        double s = 0.0;
+        for (int w = 0; w < 4; ++w) s += sRed[w * M + tid];
+        partials[(size_t)blockIdx.x * M + tid] = s;
+    }
+}
+
+// Deterministic final reduction of `nrec` records of `width` doubles: one
+// workgroup, fixed strided order + fixed tree.  out[q] = sum_r rec[r][q].
+__device__ __forceinline__ void reduce_records(const double *__restrict__ rec,
+                                               int nrec, int width, double *sums,
+                                               double *scratch /*256*/, int tid) {
+    for (int q = 0; q < width; ++q) {
+        double s = 0.0;
+        for (int r = tid; r < nrec; r += 256) s += rec[(size_t)r * width + q];
+        scratch[tid] = s;
+        __syncthreads();
+        for (int off = 128; off > 0; off >>= 1) {
+            if (tid < off) scratch[tid] += scratch[tid + off];
+            __syncthreads();
+        }
+        if (tid == 0) sums[q] = scratch[0];
+        __syncthreads();
+    }
+}
+
+// finish dlsm_loglik_full: turn the summed records into m log-likelihoods
+__global__ __launch_bounds__(256) void k_reduce_loglik(
+    const double *__restrict__ partials, int nrec, int model, int M,
+    const double *__restrict__ intercepts, double *__restrict__ out) {
+    __shared__ double scratch[256];
+    __shared__ double sums[8];
+    const int width = model == DLSM_UNDIRECTED ? 2 + M : M;
+    reduce_records(partials, nrec, width, sums, scratch, threadIdx.x);
+    if (threadIdx.x < M) {
+        const int k = threadIdx.x;
+        out[k] = model == DLSM_UNDIRECTED
+                     ? intercepts[k] * sums[0] - sums[1] - sums[2 + k]
+                     : sums[k];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Prior terms of the sweep's logp closure for node (t, j) at position x.
+//   random walk : sample_latent_positions.py:132-140
+//   AR mixture  : sample_latent_positions.py:187-199
+// ---------------------------------------------------------------------------
+template <int D>
+__device__ __forceinline__ double node_log_prior(const ChainView &c, int t, int j,
+                                                 const double *x) {
+    const int N = c.N;
+    double lp = 0.0;
+    if (c.prior_kind == DLSM_PRIOR_RANDOM_WALK) {
+        double s = 0.0;
+        if (t == 0) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) s += x[d] * x[d];
+            lp -= 0.5 * s / c.tau_sq;
+        } else {
+            const double *xp = c.X + ((size_t)(t - 1) * N + j) * D;
+#pragma unroll
+            for (int d = 0; d < D; ++d) s += (x[d] - xp[d]) * (x[d] - xp[d]);
+            lp -= 0.5 * s / c.sigma_sq;
+        }
+        if (t < c.T - 1) {
+            const double *xn = c.X + ((size_t)(t + 1) * N + j) * D;
+            s = 0.0;
+#pragma unroll
+            for (int d = 0; d < D; ++d) s += (xn[d] - x[d]) * (xn[d] - x[d]);
+            lp -= 0.5 * s / c.sigma_sq;
+        }
+    } else {
+        const double lm = c.lmbda;
+        const int zt = c.z[(size_t)t * N + j];
+        const double *m = c.mu + (size_t)zt * D;
+        double s = 0.0;
+        if (t == 0) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) s += (x[d] - m[d]) * (x[d] - m[d]);
+        } else {
+            const double *xp = c.X + ((size_t)(t - 1) * N + j) * D;
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                double df = x[d] - (1 - lm) * xp[d] - lm * m[d];
+                s += df * df;
+            }
+        }
+        lp -= 0.5 * s / c.sigma[zt];
+        if (t < c.T - 1) {
+            const int zn = c.z[(size_t)(t + 1) * N + j];
+            const double *mn = c.mu + (size_t)zn * D;
+            const double *xn = c.X + ((size_t)(t + 1) * N + j) * D;
+            s = 0.0;
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                double df = xn[d] - (1 - lm) * x[d] - lm * mn[d];
+                s += df * df;
+            }
+            lp -= 0.5 * s / c.sigma[zn];
+        }
+    }
+    return lp;
+}
+
+// ---------------------------------------------------------------------------
+// Per-node partial log-likelihood (a1/a2/a3), the function seam used by the
+// parity tests.  Grid (N, T), 256 threads; one node per workgroup.  Written in
+// the reference's literal form  y*eta - log(1 + exp(eta)).
+// ovr_* : replace X[ovr_t, ovr_j] by ovr_x for that one node (x argument of the
+// closure); ovr_t < 0 : none.
+// ---------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256) void k_partial_all(ChainView c, int with_prior,
+                                                     int only_t, int only_j,
+                                                     const double *__restrict__ ovr_x,
+                                                     double *__restrict__ out) {
+    __shared__ double sRed[4];
+    const int tid = threadIdx.x;
+    const int t = only_t >= 0 ? only_t : blockIdx.y;
+    const int j = only_j >= 0 ? only_j : blockIdx.x;
+    const int N = c.N;
+    const double *Xt = c.X + (size_t)t * N * D;
+    double x[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) x[d] = ovr_x ? ovr_x[d] : Xt[(size_t)j * D + d];
+    double acc = 0.0;
+    if (c.model == DLSM_UNDIRECTED) {
+        const double b = c.intercept[0];
+        const uint32_t *row = c.ybits + ((size_t)t * N + j) * c.W;
+        for (int i = tid; i < N; i += 256) {
+            if (i == j) continue;
+            double eta = b - dist_of<D>(&Xt[(size_t)i * D], x, c.squared);
+            acc += (double)bit_of(row, i) * eta - log(1.0 + exp(eta));
+        }
+    } else if (c.model == DLSM_DIRECTED) {
+        const double bin = c.intercept[0], bout = c.intercept[1];
+        const double rj = c.radii[j];
+        const uint32_t *row = c.ybits + ((size_t)t * N + j) * c.W;
+        const uint32_t *col = c.ytbits + ((size_t)t * N + j) * c.W;
+        for (int i = tid; i < N; i += 256) {
+            if (i == j) continue;
+            const double dd = dist_of<D>(&Xt[(size_t)i * D], x, c.squared);
+            const double ri = c.radii[i];
+            double eta = bin * (1 - dd / ri) + bout * (1 - dd / rj);
+            acc += (double)bit_of(row, i) * eta - log(1.0 + exp(eta));
+            eta = bin * (1 - dd / rj) + bout * (1 - dd / ri);
+            acc += (double)bit_of(col, i) * eta - log(1.0 + exp(eta));
+        }
+    } else {
+        const double bin = c.intercept[0], bout = c.intercept[1];
+        const double rj = c.radii[j];
+        const size_t node = (size_t)t * N + j;
+        const int in_deg = c.degree[node * 2], out_deg = c.degree[node * 2 + 1];
+        const int32_t *ie = c.in_edges + node * c.Din;
+        const int32_t *oe = c.out_edges + node * c.Dout;
+        const int32_t *ci = c.ctrl_in + node * c.C;
+        const int32_t *co = c.ctrl_out + node * c.C;
+        for (int k = tid; k < in_deg; k += 256) {
+            const int e = ie[k];
+            const double dd = dist_of<D>(e == j ? x : &Xt[(size_t)e * D], x, c.squared);
+            double eta = bin * (1 - dd / rj) + bout * (1 - dd / c.radii[e]);
+            acc += eta - log(1.0 + exp(eta));
+        }
+        for (int k = tid; k < out_deg; k += 256) {
+            const int e = oe[k];
+            const double dd = dist_of<D>(e == j ? x : &Xt[(size_t)e * D], x, c.squared);
+            double eta = bin * (1 - dd / c.radii[e]) + bout * (1 - dd / rj);
+            acc += eta - log(1.0 + exp(eta));
+        }
+        // number of valid controls (lists are -1 terminated)
+        int nci = 0, nco = 0;
+        for (int k = 0; k < c.C && ci[k] >= 0; ++k) ++nci;
+        for (int k = 0; k < c.C && co[k] >= 0; ++k) ++nco;
+        double ctl = 0.0;
+        for (int k = tid; k < nci; k += 256) {
+            const int e = ci[k];
+            const double dd = dist_of<D>(e == j ? x : &Xt[(size_t)e * D], x, c.squared);
+            double eta = bin * (1 - dd / rj) + bout * (1 - dd / c.radii[e]);
+            ctl += log(1.0 + exp(eta));
+        }
+        acc -= ((double)(N - in_deg - 1) / (double)nci) * ctl;
+        ctl = 0.0;
+        for (int k = tid; k < nco; k += 256) {
+            const int e = co[k];
+            const double dd = dist_of<D>(e == j ? x : &Xt[(size_t)e * D], x, c.squared);
+            double eta = bin * (1 - dd / c.radii[e]) + bout * (1 - dd / rj);
+            ctl += log(1.0 + exp(eta));
+        }
+        acc -= ((double)(N - out_deg - 1) / (double)nco) * ctl;
+    }
+    double tot = block_sum_all<4>(acc, sRed, tid);
+    if (tid == 0) {
+        if (with_prior) tot += node_log_prior<D>(c, t, j, x);
+        out[only_t >= 0 ? 0 : (size_t)t * N + j] = tot;
+    }
+}
+
+}  // namespace dlsm

@@ -1,0 +1,502 @@
+// Latent-position block update: random-walk
+// Metropolis over every (t, node), Gauss-Seidel inside a time slice, slices of
+// equal parity concurrently (they are conditionally independent given the
+// other parity: sample_latent_positions.py:132-140 / :187-199 couple (t, j)
+// only to (t-1, j) and (t+1, j)).
+#pragma once
+#include "chain.hpp"
+#include "device_common.hpp"
+#include "kernels_loglik.hpp"
+
+namespace dlsm {
+
+constexpr int SW_THREADS = 1024;
+constexpr int SW_WAVES = SW_THREADS / 64;
+constexpr int SW_CHUNK = 256;          // proposals generated per LDS refill
+
+// proposal record in LDS: x0[D], x1[D], logu, prior_delta
+template <int D> struct PropRec { static constexpr int W = 2 * D + 2; };
+
+// Generate the proposal of step (t, j): metropolis.py:44 + :49 with the
+// engine's Philox draws; x0 = current position.
+template <int D>
+__device__ __forceinline__ void make_proposal(const ChainView &c, uint32_t iter,
+                                              int t, int j, const double *x0,
+                                              double step, double *x1,
+                                              double &logu) {
+#pragma unroll
+    for (int d = 0; d < D; d += 2) {
+        double u0, u1, z0, z1;
+        philox_uniform2(c.seed, (uint32_t)j, (uint32_t)t | ((uint32_t)(d / 2) << 16),
+                        iter, stream_word(c.chain, STREAM_SWEEP_NORMAL), u0, u1);
+        box_muller(u0, u1, z0, z1);
+        x1[d] = x0[d] + step * z0;
+        if (d + 1 < D) x1[d + 1] = x0[d + 1] + step * z1;
+    }
+    double u0, u1;
+    philox_uniform2(c.seed, (uint32_t)j, (uint32_t)t, iter,
+                    stream_word(c.chain, STREAM_SWEEP_UNIFORM), u0, u1);
+    logu = log(u0);
+}
+
+// Change of node j's network log-likelihood contribution from neighbour i when
+// j moves x0 -> x1.
+//   undirected (static_network_fast.pyx:17-44):
+//     y (d0 - d1) + log((1 + E e^{-d0}) / (1 + E e^{-d1})),  E = e^{b}
+__device__ __forceinline__ double delta_undirected(double d0, double d1, int y,
+                                                   double E) {
+    const double p0 = 1.0 + E * exp(-d0);
+    const double p1 = 1.0 + E * exp(-d1);
+    double v = log(p0 / p1);
+    if (y) v += d0 - d1;
+    return v;
+}
+//   directed (directed_likelihoods_fast.pyx:46-80), both directions:
+//     eta_out = s - d a,  eta_in = s - d c,  s = b_in + b_out,
+//     a = b_in / r_i + b_out / r_j,  c = b_in / r_j + b_out / r_i
+__device__ __forceinline__ double delta_directed(double d0, double d1, int y_ji,
+                                                 int y_ij, double a, double cc,
+                                                 double Es) {
+    const double num = (1.0 + Es * exp(-d0 * a)) * (1.0 + Es * exp(-d0 * cc));
+    const double den = (1.0 + Es * exp(-d1 * a)) * (1.0 + Es * exp(-d1 * cc));
+    double v = log(num / den);
+    if (y_ji) v += (d0 - d1) * a;     // Y[j, i] : out direction of j
+    if (y_ij) v += (d0 - d1) * cc;    // Y[i, j] : in direction of j
+    return v;
+}
+
+// ---------------------------------------------------------------------------
+// v1: one 1024-thread workgroup per time slice.  X[t] (and 1/radii) live in
+// LDS; row j+1 of the bit-packed network is prefetched into an LDS double
+// buffer while step j computes; proposals, log-uniforms and prior deltas of a
+// chunk of steps are generated in parallel up front (counter RNG: no state to
+// carry).  One barrier per MH step.
+// ---------------------------------------------------------------------------
+template <int D, int MODEL>
+__global__ __launch_bounds__(SW_THREADS) void k_sweep_slice(ChainView c,
+                                                            uint32_t iter,
+                                                            int parity) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int N = c.N, W = c.W;
+    const int t = 2 * blockIdx.x + parity;
+    if (t >= c.T) return;
+    constexpr int PW = PropRec<D>::W;
+    double *sX = smem;                                   // N*D
+    double *sIR = sX + (size_t)N * D;                    // N (directed)
+    double *sProp = sIR + (MODEL == DLSM_DIRECTED ? N : 0);   // SW_CHUNK*PW
+    double *sRed = sProp + SW_CHUNK * PW;                // 2*SW_WAVES
+    uint32_t *sRow = (uint32_t *)(sRed + 2 * SW_WAVES);  // 2*W (+2*W directed)
+    uint32_t *sCol = sRow + 2 * W;
+    const int tid = threadIdx.x;
+    double *Xt = c.X + (size_t)t * N * D;
+    for (int k = tid; k < N * D; k += SW_THREADS) sX[k] = Xt[k];
+    if (MODEL == DLSM_DIRECTED)
+        for (int k = tid; k < N; k += SW_THREADS) sIR[k] = 1.0 / c.radii[k];
+    const uint32_t *rows = c.ybits + (size_t)t * N * W;
+    const uint32_t *cols = MODEL == DLSM_DIRECTED ? c.ytbits + (size_t)t * N * W
+                                                  : nullptr;
+    if (tid < W) {
+        sRow[tid] = rows[tid];
+        if (MODEL == DLSM_DIRECTED) sCol[tid] = cols[tid];
+    }
+    double E, bin = 0.0, bout = 0.0;
+    if (MODEL == DLSM_UNDIRECTED) {
+        E = exp(c.intercept[0]);
+    } else {
+        bin = c.intercept[0]; bout = c.intercept[1];
+        E = exp(bin + bout);
+    }
+    for (int j0 = 0; j0 < N; j0 += SW_CHUNK) {
+        __syncthreads();     // sX loaded / previous chunk's records consumed
+        const int nj = min(SW_CHUNK, N - j0);
+        if (tid < nj) {
+            const int j = j0 + tid;
+            double x0[D], x1[D], logu;
+#pragma unroll
+            for (int d = 0; d < D; ++d) x0[d] = sX[j * D + d];
+            make_proposal<D>(c, iter, t, j, x0, c.step[(size_t)t * N + j], x1, logu);
+            const double pd = node_log_prior<D>(c, t, j, x1) -
+                              node_log_prior<D>(c, t, j, x0);
+            double *rec = sProp + tid * PW;
+#pragma unroll
+            for (int d = 0; d < D; ++d) { rec[d] = x0[d]; rec[D + d] = x1[d]; }
+            rec[2 * D] = logu;
+            rec[2 * D + 1] = pd;
+        }
+        __syncthreads();
+        for (int jj = 0; jj < nj; ++jj) {
+            const int j = j0 + jj;
+            const int cur = j & 1;
+            // prefetch row j+1 of the network into the other LDS buffer
+            uint32_t wrow = 0, wcol = 0;
+            const bool pf = (tid < W) && (j + 1 < N);
+            if (pf) {
+                wrow = rows[(size_t)(j + 1) * W + tid];
+                if (MODEL == DLSM_DIRECTED) wcol = cols[(size_t)(j + 1) * W + tid];
+            }
+            const double *rec = sProp + jj * PW;
+            double x0[D], x1[D];
+#pragma unroll
+            for (int d = 0; d < D; ++d) { x0[d] = rec[d]; x1[d] = rec[D + d]; }
+            const double logu = rec[2 * D], pd = rec[2 * D + 1];
+            const uint32_t *yr = sRow + cur * W;
+            const uint32_t *yc = sCol + cur * W;
+            const double irj = MODEL == DLSM_DIRECTED ? sIR[j] : 0.0;
+            double acc = 0.0;
+            for (int i = tid; i < N; i += SW_THREADS) {
+                if (i == j) continue;
+                const double d0 = dist_of<D>(&sX[i * D], x0, c.squared);
+                const double d1 = dist_of<D>(&sX[i * D], x1, c.squared);
+                if (MODEL == DLSM_UNDIRECTED) {
+                    acc += delta_undirected(d0, d1, bit_of(yr, i), E);
+                } else {
+                    const double iri = sIR[i];
+                    acc += delta_directed(d0, d1, bit_of(yr, i), bit_of(yc, i),
+                                          bin * iri + bout * irj,
+                                          bin * irj + bout * iri, E);
+                }
+            }
+            if (pf) {
+                sRow[(cur ^ 1) * W + tid] = wrow;
+                if (MODEL == DLSM_DIRECTED) sCol[(cur ^ 1) * W + tid] = wcol;
+            }
+            const double total = block_sum_all<SW_WAVES>(acc, sRed + cur * SW_WAVES, tid);
+            const double ratio = total + pd;
+            const int accepted = !(logu >= ratio);      // metropolis.py:50
+            if (tid == (j & (SW_THREADS - 1))) {
+                if (accepted) {
+#pragma unroll
+                    for (int d = 0; d < D; ++d) {
+                        sX[j * D + d] = x1[d];
+                        Xt[(size_t)j * D + d] = x1[d];
+                    }
+                }
+                const size_t tj = (size_t)t * N + j;
+                double st = c.step[tj];
+                int32_t na = c.nacc[tj], ns = c.nsteps[tj], un = c.until[tj];
+                metropolis_bookkeeping(st, na, ns, un, c.tune, c.tune_interval, accepted);
+                c.step[tj] = st; c.nacc[tj] = na; c.nsteps[tj] = ns; c.until[tj] = un;
+            }
+        }
+    }
+}
+
+inline size_t sweep_slice_lds_bytes(int N, int D, int W, int model) {
+    size_t dbl = (size_t)N * D + (model == DLSM_DIRECTED ? N : 0) +
+                 (size_t)SW_CHUNK * (2 * D + 2) + 2 * SW_WAVES;
+    size_t words = (size_t)(model == DLSM_DIRECTED ? 4 : 2) * W;
+    return dbl * sizeof(double) + words * sizeof(uint32_t);
+}
+
+// ---------------------------------------------------------------------------
+// Case-control sweep (a3 inside a9/a10): O(deg + 2C) gathered terms per step.
+// 256 threads per slice; X stays in global memory (L2 resident; sc1 loads so a
+// position written by this workgroup earlier in the sweep is always re-read
+// from L2).  nctrl[T][N][2] = number of valid (non -1) in / out controls.
+// ---------------------------------------------------------------------------
+constexpr int CC_THREADS = 256;
+
+__device__ __forceinline__ double load_sc1(const double *p) {
+    unsigned long long v = __hip_atomic_load((const unsigned long long *)p,
+                                             __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_AGENT);
+    return __longlong_as_double((long long)v);
+}
+
+template <int D>
+__global__ __launch_bounds__(CC_THREADS) void k_sweep_casecontrol(
+    ChainView c, const int32_t *__restrict__ nctrl, uint32_t iter, int parity) {
+    constexpr int PW = PropRec<D>::W;
+    __shared__ double sProp[SW_CHUNK * PW];
+    __shared__ double sRed[2 * (CC_THREADS / 64)];
+    const int N = c.N;
+    const int t = 2 * blockIdx.x + parity;
+    if (t >= c.T) return;
+    const int tid = threadIdx.x;
+    double *Xt = c.X + (size_t)t * N * D;
+    const double bin = c.intercept[0], bout = c.intercept[1];
+    for (int j0 = 0; j0 < N; j0 += SW_CHUNK) {
+        __syncthreads();
+        const int nj = min(SW_CHUNK, N - j0);
+        for (int q = tid; q < nj; q += CC_THREADS) {
+            const int j = j0 + q;
+            double x0[D], x1[D], logu;
+#pragma unroll
+            for (int d = 0; d < D; ++d) x0[d] = load_sc1(&Xt[(size_t)j * D + d]);
+            make_proposal<D>(c, iter, t, j, x0, c.step[(size_t)t * N + j], x1, logu);
+            const double pd = node_log_prior<D>(c, t, j, x1) -
+                              node_log_prior<D>(c, t, j, x0);
+            double *rec = sProp + q * PW;
+#pragma unroll
+            for (int d = 0; d < D; ++d) { rec[d] = x0[d]; rec[D + d] = x1[d]; }
+            rec[2 * D] = logu;
+            rec[2 * D + 1] = pd;
+        }
+        __syncthreads();
+        for (int jj = 0; jj < nj; ++jj) {
+            const int j = j0 + jj;
+            const size_t node = (size_t)t * N + j;
+            const double *rec = sProp + jj * PW;
+            double x0[D], x1[D];
+#pragma unroll
+            for (int d = 0; d < D; ++d) { x0[d] = rec[d]; x1[d] = rec[D + d]; }
+            const double logu = rec[2 * D], pd = rec[2 * D + 1];
+            const int in_deg = c.degree[node * 2], out_deg = c.degree[node * 2 + 1];
+            const int nci = nctrl[node * 2], nco = nctrl[node * 2 + 1];
+            const double rj = c.radii[j];
+            const double adj_in = (double)(N - in_deg - 1) / (double)nci;
+            const double adj_out = (double)(N - out_deg - 1) / (double)nco;
+            const int total_terms = in_deg + out_deg + nci + nco;
+            double acc = 0.0;
+            for (int k = tid; k < total_terms; k += CC_THREADS) {
+                int e, kind = 0, q = k;          // kind: 0 in-edge 1 out-edge 2 ctrl-in 3 ctrl-out
+                if (q < in_deg) { e = c.in_edges[node * c.Din + q]; kind = 0; }
+                else if ((q -= in_deg) < out_deg) { e = c.out_edges[node * c.Dout + q]; kind = 1; }
+                else if ((q -= out_deg) < nci) { e = c.ctrl_in[node * c.C + q]; kind = 2; }
+                else { q -= nci; e = c.ctrl_out[node * c.C + q]; kind = 3; }
+                double xe[D];
+#pragma unroll
+                for (int d = 0; d < D; ++d) xe[d] = load_sc1(&Xt[(size_t)e * D + d]);
+                const double re = c.radii[e];
+                // a self reference sees the moved position (distance 0 both ways)
+                const double d0 = e == j ? 0.0 : dist_of<D>(xe, x0, c.squared);
+                const double d1 = e == j ? 0.0 : dist_of<D>(xe, x1, c.squared);
+                const bool in_dir = (kind == 0 || kind == 2);
+                const double a = in_dir ? (bin / rj + bout / re) : (bin / re + bout / rj);
+                // literal form: eta = b_in (1 - d / r_.) + b_out (1 - d / r_.)
+                const double eta0 = in_dir ? bin * (1 - d0 / rj) + bout * (1 - d0 / re)
+                                           : bin * (1 - d0 / re) + bout * (1 - d0 / rj);
+                const double eta1 = in_dir ? bin * (1 - d1 / rj) + bout * (1 - d1 / re)
+                                           : bin * (1 - d1 / re) + bout * (1 - d1 / rj);
+                (void)a;
+                const double sp = log((1.0 + exp(eta1)) / (1.0 + exp(eta0)));
+                if (kind < 2) acc += (eta1 - eta0) - sp;
+                else acc -= (kind == 2 ? adj_in : adj_out) * sp;
+            }
+            const double total = block_sum_all<CC_THREADS / 64>(
+                acc, sRed + (j & 1) * (CC_THREADS / 64), tid);
+            const double ratio = total + pd;
+            const int accepted = !(logu >= ratio);
+            if (tid == 0) {
+                if (accepted) {
+#pragma unroll
+                    for (int d = 0; d < D; ++d)
+                        __hip_atomic_store((unsigned long long *)&Xt[(size_t)j * D + d],
+                                           (unsigned long long)__double_as_longlong(x1[d]),
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                double st = c.step[node];
+                int32_t na = c.nacc[node], ns = c.nsteps[node], un = c.until[node];
+                metropolis_bookkeeping(st, na, ns, un, c.tune, c.tune_interval, accepted);
+                c.step[node] = st; c.nacc[node] = na; c.nsteps[node] = ns; c.until[node] = un;
+            }
+            // the store above must be visible to the gathers of the next step
+            __syncthreads();
+        }
+    }
+}
+
+__global__ void k_count_controls(const int32_t *__restrict__ ctrl_in,
+                                 const int32_t *__restrict__ ctrl_out, long nodes,
+                                 int C, int32_t *__restrict__ nctrl) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nodes) return;
+    int a = 0, b = 0;
+    while (a < C && ctrl_in[i * C + a] >= 0) ++a;
+    while (b < C && ctrl_out[i * C + b] >= 0) ++b;
+    nctrl[i * 2] = a;
+    nctrl[i * 2 + 1] = b;
+}
+
+// ---------------------------------------------------------------------------
+// Post-sweep glue in ONE single-workgroup kernel (T*N*D is a few 100 KB):
+//   1. optional Procrustes rotation to X_ref (procrustes.py:20-35):
+//        M = X^T X_ref, SVD M = U S V^T (one-sided Jacobi), R = U V^T, X <- X R
+//   2. centring X -= mean over (t, i) (lsm.py:501)
+//   3. optional LSM bookkeeping: latent prior terms of logp (lsm.py:604-613)
+//      and the intercept proposal + log-uniform of sample_intercepts
+//      (sample_coefficients.py:76-86) with Philox stream INTERCEPT.
+// ---------------------------------------------------------------------------
+constexpr int PS_THREADS = 1024;
+
+template <int D>
+__device__ void jacobi_polar(const double (&M)[D][D], double (&R)[D][D]) {
+    double U[D][D], V[D][D];
+    for (int a = 0; a < D; ++a)
+        for (int b = 0; b < D; ++b) { U[a][b] = M[a][b]; V[a][b] = a == b ? 1.0 : 0.0; }
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0.0;
+        for (int p = 0; p < D - 1; ++p)
+            for (int q = p + 1; q < D; ++q) {
+                double al = 0, be = 0, ga = 0;
+                for (int k = 0; k < D; ++k) {
+                    al += U[k][p] * U[k][p];
+                    be += U[k][q] * U[k][q];
+                    ga += U[k][p] * U[k][q];
+                }
+                if (fabs(ga) <= 1e-300 || fabs(ga) <= 1e-16 * sqrt(al * be)) continue;
+                off += fabs(ga);
+                const double zeta = (be - al) / (2.0 * ga);
+                const double tt = (zeta >= 0 ? 1.0 : -1.0) /
+                                  (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const double cs = 1.0 / sqrt(1.0 + tt * tt), sn = cs * tt;
+                for (int k = 0; k < D; ++k) {
+                    double up = U[k][p], uq = U[k][q];
+                    U[k][p] = cs * up - sn * uq;
+                    U[k][q] = sn * up + cs * uq;
+                    double vp = V[k][p], vq = V[k][q];
+                    V[k][p] = cs * vp - sn * vq;
+                    V[k][q] = sn * vp + cs * vq;
+                }
+            }
+        if (off == 0.0) break;
+    }
+    for (int q = 0; q < D; ++q) {
+        double nrm = 0;
+        for (int k = 0; k < D; ++k) nrm += U[k][q] * U[k][q];
+        nrm = sqrt(nrm);
+        for (int k = 0; k < D; ++k) U[k][q] /= nrm;
+    }
+    for (int a = 0; a < D; ++a)
+        for (int b = 0; b < D; ++b) {
+            double s = 0;
+            for (int k = 0; k < D; ++k) s += U[a][k] * V[b][k];
+            R[a][b] = s;
+        }
+}
+
+template <int D>
+__global__ __launch_bounds__(PS_THREADS) void k_post_sweep(
+    ChainView c, const double *__restrict__ xref, int do_center,
+    LsmDeviceState *lsm, uint32_t iter, double *__restrict__ R_out) {
+    __shared__ double sRed[2 * (PS_THREADS / 64)];
+    __shared__ double sR[D * D];
+    const int tid = threadIdx.x;
+    const long rows = (long)c.T * c.N;
+    double *X = c.X;
+    int phase = 0;
+    if (xref) {
+        double M[D][D];
+        for (int a = 0; a < D; ++a)
+            for (int b = 0; b < D; ++b) {
+                double s = 0.0;
+                for (long r = tid; r < rows; r += PS_THREADS)
+                    s += X[r * D + a] * xref[r * D + b];
+                M[a][b] = block_sum_all<PS_THREADS / 64>(
+                    s, sRed + (phase & 1) * (PS_THREADS / 64), tid);
+                ++phase;
+            }
+        if (tid == 0) {
+            double R[D][D];
+            jacobi_polar<D>(M, R);
+            for (int a = 0; a < D; ++a)
+                for (int b = 0; b < D; ++b) {
+                    sR[a * D + b] = R[a][b];
+                    if (R_out) R_out[a * D + b] = R[a][b];
+                }
+        }
+        __syncthreads();
+        for (long r = tid; r < rows; r += PS_THREADS) {
+            double x[D], y[D];
+#pragma unroll
+            for (int a = 0; a < D; ++a) x[a] = X[r * D + a];
+#pragma unroll
+            for (int b = 0; b < D; ++b) {
+                double s = 0.0;
+#pragma unroll
+                for (int a = 0; a < D; ++a) s += x[a] * sR[a * D + b];
+                y[b] = s;
+            }
+#pragma unroll
+            for (int b = 0; b < D; ++b) X[r * D + b] = y[b];
+        }
+        __syncthreads();
+    }
+    if (do_center) {
+        double mean[D];
+        for (int d = 0; d < D; ++d) {
+            double s = 0.0;
+            for (long r = tid; r < rows; r += PS_THREADS) s += X[r * D + d];
+            mean[d] = block_sum_all<PS_THREADS / 64>(
+                          s, sRed + (phase & 1) * (PS_THREADS / 64), tid) /
+                      (double)rows;
+            ++phase;
+        }
+        for (long r = tid; r < rows; r += PS_THREADS)
+#pragma unroll
+            for (int d = 0; d < D; ++d) X[r * D + d] -= mean[d];
+        __syncthreads();
+    }
+    if (lsm) {
+        // lsm.py:604-613 : - sum_t sum_i 0.5 |.|^2 / (tau_sq | sigma_sq)
+        double s = 0.0;
+        for (long r = tid; r < rows; r += PS_THREADS) {
+            double q = 0.0;
+            if (r < c.N) {
+#pragma unroll
+                for (int d = 0; d < D; ++d) q += X[r * D + d] * X[r * D + d];
+                s += 0.5 * q / c.tau_sq;
+            } else {
+#pragma unroll
+                for (int d = 0; d < D; ++d) {
+                    double df = X[r * D + d] - X[(r - c.N) * D + d];
+                    q += df * df;
+                }
+                s += 0.5 * q / c.sigma_sq;
+            }
+        }
+        const double tot = block_sum_all<PS_THREADS / 64>(
+            s, sRed + (phase & 1) * (PS_THREADS / 64), tid);
+        if (tid == 0) {
+            lsm->prior_x = -tot;
+            double u0, u1, z0, z1;
+            philox_uniform2(c.seed, 0, 0, iter, stream_word(c.chain, STREAM_INTERCEPT),
+                            u0, u1);
+            box_muller(u0, u1, z0, z1);
+            const double b0 = c.intercept[0];
+            lsm->cand[0] = b0;
+            lsm->cand[1] = b0 + lsm->i_step[0] * z0;
+            philox_uniform2(c.seed, 0, 1, iter, stream_word(c.chain, STREAM_INTERCEPT),
+                            u0, u1);
+            lsm->logu = log(u0);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// End of an undirected LSM iteration: fixed-order reduction of the fused
+// log-likelihood records, intercept accept/reject + step-size adaptation
+// (sample_coefficients.py:76-86, metropolis.py:96-136), log-posterior trace
+// (lsm.py:576-625).  One workgroup.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_lsm_finalize(
+    const double *__restrict__ partials, int nrec, LsmDeviceState *lsm,
+    double *__restrict__ intercept, double *__restrict__ trace_ic,
+    double *__restrict__ trace_logp, int it) {
+    __shared__ double scratch[256];
+    __shared__ double sums[4];
+    reduce_records(partials, nrec, 4, sums, scratch, threadIdx.x);
+    if (threadIdx.x == 0) {
+        const double b0 = lsm->cand[0], b1 = lsm->cand[1];
+        const double ll0 = b0 * sums[0] - sums[1] - sums[2];
+        const double ll1 = b1 * sums[0] - sums[1] - sums[3];
+        const double pm = lsm->intercept_prior[0], v = lsm->intercept_var;
+        const double lp0 = ll0 - (b0 - pm) * (b0 - pm) / (2 * v);
+        const double lp1 = ll1 - (b1 - pm) * (b1 - pm) / (2 * v);
+        const int accepted = !(lsm->logu >= lp1 - lp0);
+        const double b = accepted ? b1 : b0;
+        const double ll = accepted ? ll1 : ll0;
+        intercept[0] = b;
+        double st = lsm->i_step[0];
+        int32_t na = lsm->i_nacc[0], ns = lsm->i_nsteps[0], un = lsm->i_until[0];
+        metropolis_bookkeeping(st, na, ns, un, lsm->i_tune, lsm->i_tune_interval,
+                               accepted);
+        lsm->i_step[0] = st; lsm->i_nacc[0] = na; lsm->i_nsteps[0] = ns;
+        lsm->i_until[0] = un;
+        trace_ic[(size_t)it * 2] = b;
+        trace_ic[(size_t)it * 2 + 1] = 0.0;
+        trace_logp[it] = ll + lsm->prior_x - 0.5 * (b - pm) * (b - pm) / v;
+    }
+}
+
+}  // namespace dlsm

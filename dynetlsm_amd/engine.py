@@ -1,0 +1,355 @@
+"""Python face of one device-resident MCMC chain (one ``dlsm_chain`` handle).
+
+Thin: argument checking, dtype/contiguity normalisation and error mapping.
+All arithmetic happens in the HIP library; nothing here computes a likelihood.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import (EngineError, LsmConfig, c_double_p, c_i32_p, c_i64_p,
+                   UNDIRECTED, DIRECTED, DIRECTED_CASE_CONTROL)
+
+__all__ = ['Chain', 'SamplerGrid', 'EngineError']
+
+
+def _f64(a, shape=None, name='array'):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None and tuple(a.shape) != tuple(shape):
+        raise ValueError('%s has shape %s, expected %s' % (name, a.shape, shape))
+    return a
+
+
+def _i64(a, shape=None, name='array'):
+    a = np.ascontiguousarray(a, dtype=np.int64)
+    if shape is not None and tuple(a.shape) != tuple(shape):
+        raise ValueError('%s has shape %s, expected %s' % (name, a.shape, shape))
+    return a
+
+
+def _i32(a, shape=None, name='array'):
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    if shape is not None and tuple(a.shape) != tuple(shape):
+        raise ValueError('%s has shape %s, expected %s' % (name, a.shape, shape))
+    return a
+
+
+def _p(a):
+    if a.dtype == np.float64:
+        return a.ctypes.data_as(c_double_p)
+    if a.dtype == np.int64:
+        return a.ctypes.data_as(c_i64_p)
+    if a.dtype == np.int32:
+        return a.ctypes.data_as(c_i32_p)
+    raise TypeError(a.dtype)
+
+
+class SamplerGrid(object):
+    """State of the T x N random-walk Metropolis samplers (one per (t, node)),
+    the struct-of-arrays form of the reference's ``latent_samplers`` list of
+    ``Metropolis`` objects (metropolis.py:85-94, lsm.py:451-457)."""
+
+    def __init__(self, T, N, step_size=0.1, tune=500, tune_interval=100):
+        self.step_size = np.full((T, N), float(step_size))
+        self.n_accepted = np.zeros((T, N), dtype=np.int32)
+        self.n_steps = np.zeros((T, N), dtype=np.int32)
+        self.steps_until_tune = np.full((T, N), tune_interval, dtype=np.int32)
+        self.tune = tune
+        self.tune_interval = tune_interval
+
+    @classmethod
+    def from_objects(cls, samplers):
+        """Build from a list (T) of lists (N) of Metropolis-like objects."""
+        T, N = len(samplers), len(samplers[0])
+        s0 = samplers[0][0]
+        g = cls(T, N, s0.step_size, s0.tune, s0.tune_interval)
+        for t in range(T):
+            for j in range(N):
+                s = samplers[t][j]
+                g.step_size[t, j] = s.step_size
+                g.n_accepted[t, j] = s.n_accepted
+                g.n_steps[t, j] = s.n_steps
+                g.steps_until_tune[t, j] = s.steps_until_tune
+        return g
+
+    def to_objects(self, samplers):
+        for t in range(len(samplers)):
+            for j in range(len(samplers[0])):
+                s = samplers[t][j]
+                s.step_size = float(self.step_size[t, j])
+                s.n_accepted = int(self.n_accepted[t, j])
+                s.n_steps = int(self.n_steps[t, j])
+                s.steps_until_tune = int(self.steps_until_tune[t, j])
+
+
+class Chain(object):
+    """One chain on one MI355X.
+
+    Parameters mirror ``dlsm_create``: ``model`` is 'undirected', 'directed' or
+    'case_control'; (seed, chain_id) key the Philox streams.
+    """
+    MODELS = {'undirected': UNDIRECTED, 'directed': DIRECTED,
+              'case_control': DIRECTED_CASE_CONTROL}
+
+    def __init__(self, T, N, D=2, model='undirected', seed=0, chain_id=0, device=0):
+        self._L = _lib.load()
+        self._h = _lib.handle_t()
+        self.T, self.N, self.D = int(T), int(N), int(D)
+        self.model = self.MODELS[model] if isinstance(model, str) else int(model)
+        self.n_intercepts = 1 if self.model == UNDIRECTED else 2
+        rc = self._L.dlsm_create(int(device), self.T, self.N, self.D, self.model,
+                                 C.c_uint64(int(seed) & (2 ** 64 - 1)), int(chain_id),
+                                 C.byref(self._h))
+        if rc != 0:
+            msg = self._L.dlsm_last_error(None)
+            self._h = None
+            raise EngineError(rc, msg.decode() if msg else 'dlsm_create failed')
+        self.K = 0
+        self.C = 0
+
+    # -- plumbing ---------------------------------------------------------
+    def _ck(self, rc):
+        if rc != 0:
+            msg = self._L.dlsm_last_error(self._h)
+            raise EngineError(rc, msg.decode() if msg else '?')
+
+    def close(self):
+        if getattr(self, '_h', None):
+            self._L.dlsm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def synchronize(self):
+        self._ck(self._L.dlsm_synchronize(self._h))
+
+    # -- network -----------------------------------------------------------
+    def upload_network(self, Y):
+        Y = _f64(Y, (self.T, self.N, self.N), 'Y')
+        self._ck(self._L.dlsm_upload_network(self._h, _p(Y)))
+
+    def upload_edges(self, in_edges, out_edges, degree):
+        ie = _i64(in_edges); oe = _i64(out_edges)
+        dg = _i64(degree, (self.T, self.N, 2), 'degree')
+        if ie.shape[:2] != (self.T, self.N) or oe.shape[:2] != (self.T, self.N):
+            raise ValueError('edge lists must be (T, N, max_degree)')
+        self._ck(self._L.dlsm_upload_edges(self._h, _p(ie), ie.shape[2], _p(oe),
+                                           oe.shape[2], _p(dg)))
+
+    def set_controls(self, control_nodes_in, control_nodes_out):
+        ci = _i64(control_nodes_in); co = _i64(control_nodes_out)
+        if ci.shape != co.shape or ci.shape[:2] != (self.T, self.N):
+            raise ValueError('control node arrays must both be (T, N, n_control)')
+        self.C = ci.shape[2]
+        self._ck(self._L.dlsm_set_controls(self._h, _p(ci), _p(co), self.C))
+
+    def get_controls(self):
+        ci = np.zeros((self.T, self.N, self.C), dtype=np.int64)
+        co = np.zeros_like(ci)
+        self._ck(self._L.dlsm_get_controls(self._h, _p(ci), _p(co)))
+        return ci, co
+
+    def resample_controls(self, it, n_control):
+        self._ck(self._L.dlsm_resample_controls(self._h, int(it), int(n_control)))
+        self.C = int(n_control)
+
+    # -- state -------------------------------------------------------------
+    def set_positions(self, X):
+        X = _f64(X, (self.T, self.N, self.D), 'X')
+        self._ck(self._L.dlsm_set_positions(self._h, _p(X)))
+
+    def get_positions(self):
+        X = np.zeros((self.T, self.N, self.D))
+        self._ck(self._L.dlsm_get_positions(self._h, _p(X)))
+        return X
+
+    def set_intercepts(self, b):
+        b = _f64(np.atleast_1d(b).ravel(), (self.n_intercepts,), 'intercept')
+        self._ck(self._L.dlsm_set_intercepts(self._h, _p(b), self.n_intercepts))
+
+    def get_intercepts(self):
+        b = np.zeros(self.n_intercepts)
+        self._ck(self._L.dlsm_get_intercepts(self._h, _p(b), self.n_intercepts))
+        return b
+
+    def set_radii(self, radii):
+        r = _f64(radii, (self.N,), 'radii')
+        self._ck(self._L.dlsm_set_radii(self._h, _p(r)))
+
+    def get_radii(self):
+        r = np.zeros(self.N)
+        self._ck(self._L.dlsm_get_radii(self._h, _p(r)))
+        return r
+
+    def set_squared(self, squared):
+        self._ck(self._L.dlsm_set_squared(self._h, int(bool(squared))))
+
+    def set_samplers(self, grid):
+        sh = (self.T, self.N)
+        st = _f64(grid.step_size, sh, 'step_size')
+        na = _i32(grid.n_accepted, sh); ns = _i32(grid.n_steps, sh)
+        un = _i32(grid.steps_until_tune, sh)
+        tune = -1 if grid.tune is None else int(grid.tune)
+        self._ck(self._L.dlsm_set_samplers(self._h, _p(st), _p(na), _p(ns), _p(un),
+                                           tune, int(grid.tune_interval)))
+
+    def get_samplers(self, grid):
+        """read the device's sampler state back into ``grid`` (in place)"""
+        sh = (self.T, self.N)
+        st = np.zeros(sh); na = np.zeros(sh, dtype=np.int32)
+        ns = np.zeros(sh, dtype=np.int32); un = np.zeros(sh, dtype=np.int32)
+        self._ck(self._L.dlsm_get_samplers(self._h, _p(st), _p(na), _p(ns), _p(un)))
+        grid.step_size[...] = st; grid.n_accepted[...] = na
+        grid.n_steps[...] = ns; grid.steps_until_tune[...] = un
+        return grid
+
+    def set_prior_random_walk(self, tau_sq, sigma_sq):
+        self._ck(self._L.dlsm_set_prior_random_walk(self._h, float(tau_sq),
+                                                    float(sigma_sq)))
+
+    def set_prior_mixture(self, mu, sigma, lmbda, z):
+        sigma = _f64(sigma)
+        K = sigma.shape[0]
+        mu = _f64(mu, (K, self.D), 'mu')
+        z = _i64(z, (self.T, self.N), 'z')
+        lm = float(np.asarray(lmbda).ravel()[0])
+        self._ck(self._L.dlsm_set_prior_mixture(self._h, _p(mu), _p(sigma), lm, _p(z), K))
+        self.K = K
+
+    # -- kernels -----------------------------------------------------------
+    def loglik_full(self, intercepts=None):
+        """network log-likelihood at the current X; ``intercepts`` (m, n_ic)
+        evaluates m candidates in fused passes, None the current intercept."""
+        if intercepts is None:
+            out = np.zeros(1)
+            self._ck(self._L.dlsm_loglik_full(self._h, 1, None, _p(out)))
+            return float(out[0])
+        ic = _f64(np.atleast_2d(intercepts))
+        if ic.shape[1] != self.n_intercepts:
+            raise ValueError('intercepts must be (m, %d)' % self.n_intercepts)
+        out = np.zeros(ic.shape[0])
+        self._ck(self._L.dlsm_loglik_full(self._h, ic.shape[0], _p(ic), _p(out)))
+        return out
+
+    def loglik_full_radii(self, radii_alt):
+        r = _f64(radii_alt, (self.N,), 'radii_alt')
+        out = np.zeros(2)
+        self._ck(self._L.dlsm_loglik_full_radii(self._h, _p(r), _p(out)))
+        return out
+
+    def loglik_partial(self, t, j, x=None, with_prior=False):
+        out = np.zeros(1)
+        xp = None
+        if x is not None:
+            x = _f64(x, (self.D,), 'x')
+            xp = _p(x)
+        self._ck(self._L.dlsm_loglik_partial(self._h, int(t), int(j), xp,
+                                             int(with_prior), _p(out)))
+        return float(out[0])
+
+    def loglik_partial_all(self, with_prior=False):
+        out = np.zeros((self.T, self.N))
+        self._ck(self._L.dlsm_loglik_partial_all(self._h, int(with_prior), _p(out)))
+        return out
+
+    def sweep_positions(self, it, algo=0):
+        self._ck(self._L.dlsm_sweep_positions(self._h, int(it), int(algo)))
+
+    def center(self):
+        self._ck(self._L.dlsm_center(self._h))
+
+    def procrustes(self, X_ref):
+        X_ref = _f64(X_ref, (self.T, self.N, self.D), 'X_ref')
+        R = np.zeros((self.D, self.D))
+        self._ck(self._L.dlsm_procrustes(self._h, _p(X_ref), _p(R)))
+        return R
+
+    def gaussian_likelihood(self, node, normalize=True):
+        out = np.zeros((self.T, self.K))
+        self._ck(self._L.dlsm_gaussian_likelihood(self._h, int(node), int(normalize),
+                                                  _p(out)))
+        return out
+
+    def sample_labels(self, it, w):
+        K = self.K
+        w = _f64(w, (self.T, K, K), 'w')
+        z = np.zeros((self.T, self.N), dtype=np.int64)
+        n = np.zeros((self.T, K, K))
+        nk = np.zeros((self.T, K), dtype=np.int64)
+        self._ck(self._L.dlsm_sample_labels(self._h, int(it), _p(w), _p(z), _p(n), _p(nk)))
+        return z, n, nk
+
+    # -- device-resident LSM loop -------------------------------------------
+    def lsm_configure(self, intercept_prior, intercept_variance_prior,
+                      step_size_intercept=0.1, tune=None, tune_interval=100,
+                      n_iter_procrustes=0, sweep_algo=0, state=None):
+        cfg = LsmConfig()
+        ip = np.atleast_1d(np.asarray(intercept_prior, dtype=np.float64)).ravel()
+        for k in range(2):
+            cfg.intercept_prior[k] = ip[k] if k < ip.size else 0.0
+            cfg.i_step_size[k] = float(step_size_intercept)
+            cfg.i_n_accepted[k] = 0
+            cfg.i_n_steps[k] = 0
+            cfg.i_steps_until_tune[k] = int(tune_interval)
+        if state is not None:       # (step, n_accepted, n_steps, until) per sampler
+            for k, s in enumerate(state):
+                cfg.i_step_size[k], cfg.i_n_accepted[k] = s[0], s[1]
+                cfg.i_n_steps[k], cfg.i_steps_until_tune[k] = s[2], s[3]
+        cfg.intercept_variance_prior = float(intercept_variance_prior)
+        cfg.i_tune = -1 if tune is None else int(tune)
+        cfg.i_tune_interval = int(tune_interval)
+        cfg.n_iter_procrustes = int(n_iter_procrustes)
+        cfg.sweep_algo = int(sweep_algo)
+        self._ck(self._L.dlsm_lsm_configure(self._h, C.byref(cfg)))
+
+    def lsm_get_config(self):
+        cfg = LsmConfig()
+        self._ck(self._L.dlsm_lsm_get_config(self._h, C.byref(cfg)))
+        return cfg
+
+    def trace_alloc(self, n_total, logp0=0.0):
+        self._ck(self._L.dlsm_trace_alloc(self._h, int(n_total), float(logp0)))
+        self._trace_n = int(n_total)
+
+    def lsm_run(self, first, count, procrustes_ref=-1):
+        """enqueue iterations first..first+count-1 (asynchronous)"""
+        self._ck(self._L.dlsm_lsm_run(self._h, int(first), int(count),
+                                      int(procrustes_ref)))
+
+    def trace_read(self, first, count, positions=True):
+        Xs = np.zeros((count, self.T, self.N, self.D)) if positions else None
+        ics = np.zeros((count, 2))
+        lps = np.zeros(count)
+        self._ck(self._L.dlsm_trace_read(self._h, int(first), int(count),
+                                         _p(Xs) if positions else None, _p(ics),
+                                         _p(lps)))
+        return Xs, ics[:, :self.n_intercepts], lps
+
+    # -- measurement ---------------------------------------------------------
+    def profile_enable(self, on=True):
+        self._ck(self._L.dlsm_profile_enable(self._h, int(on)))
+
+    def profile_read(self, kernel):
+        ms = C.c_double(0.0)
+        n = C.c_int(0)
+        self._ck(self._L.dlsm_profile_read(self._h, int(kernel), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def timer_start(self):
+        self._ck(self._L.dlsm_timer_start(self._h))
+
+    def timer_stop(self):
+        ms = C.c_double(0.0)
+        self._ck(self._L.dlsm_timer_stop(self._h, C.byref(ms)))
+        return ms.value

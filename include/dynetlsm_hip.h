@@ -1,0 +1,180 @@
+/*
+ * dynetlsm_hip.h -- C-ABI of the MI355X (gfx950) engine for DynetLSM's
+ * Metropolis-within-Gibbs hot path.
+ *
+ * The reference (joshloyal/dynetlsm v0.1.0) has no FFI: its seams are Python
+ * function calls.  Each entry point below names the reference
+ * call it replaces (file:line relative to the reference tree).  A chain handle
+ * owns ALL device state (bit-packed network, latent positions, Metropolis
+ * state, Philox key); one handle per chain per device.  A handle is not
+ * thread-safe; different handles may be used from different host threads.
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 on error (DLSM_E_*);
+ *     dlsm_last_error() gives the message.  No exceptions, no callbacks.
+ *   - host arrays are C-contiguous little-endian float64 / int64 / int32 as
+ *     stated; the callee never keeps a host pointer past return.
+ *   - calls are synchronous at return (results are in the host buffers) except
+ *     the *_async / run calls, which only enqueue on the handle's stream and
+ *     are completed by dlsm_synchronize().
+ *   - counter RNG: Philox4x32-10 keyed by `seed`, counter (index, t|draw<<16,
+ *     iteration, chain<<8|stream); the CPU oracle uses the same draws.
+ */
+#ifndef DYNETLSM_HIP_H
+#define DYNETLSM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DLSM_ABI_VERSION 1
+
+enum {
+    DLSM_OK = 0,
+    DLSM_E_ARG = -1,      /* bad argument / wrong state */
+    DLSM_E_HIP = -2,      /* HIP runtime error */
+    DLSM_E_NODEV = -3,    /* no usable gfx950 device */
+    DLSM_E_DATA = -4,     /* network entries not in {0,1} etc. */
+    DLSM_E_LIMIT = -5     /* size beyond what the kernels support */
+};
+
+enum { DLSM_UNDIRECTED = 0, DLSM_DIRECTED = 1, DLSM_DIRECTED_CASE_CONTROL = 2 };
+enum { DLSM_PRIOR_RANDOM_WALK = 0, DLSM_PRIOR_MIXTURE = 1 };
+
+typedef struct dlsm_chain dlsm_chain;
+
+int dlsm_abi_version(void);
+int dlsm_device_count(int *count);
+/* message of the last failing call on this handle (or of dlsm_create if NULL) */
+const char *dlsm_last_error(const dlsm_chain *h);
+
+/* ---- lifecycle ------------------------------------------------------- */
+/* replaces the per-fit allocations of lsm.py:371-383,451-470 /
+ * hdp_lpcm.py:691-747: one chain of a T x N x N network, D latent features */
+int dlsm_create(int device, int T, int N, int D, int model, uint64_t seed,
+                uint32_t chain_id, dlsm_chain **out);
+void dlsm_destroy(dlsm_chain *h);
+int dlsm_synchronize(dlsm_chain *h);
+
+/* ---- network --------------------------------------------------------- */
+/* Y: T*N*N float64 row-major exactly as fit(Y) receives it (lsm.py:341).
+ * Packed on device to 1 bit/dyad (+ the transpose for directed models).
+ * Entries other than 0.0 / 1.0 -> DLSM_E_DATA (missing-edge imputation,
+ * lsm.py:525-545, is out of scope). */
+int dlsm_upload_network(dlsm_chain *h, const double *Y);
+/* case-control: zero padded edge lists and degrees exactly as
+ * DirectedCaseControlSampler.init builds them (case_control_likelihood.py:45-68):
+ * in_edges T*N*Din, out_edges T*N*Dout, degree T*N*2 (col 0 in, col 1 out). */
+int dlsm_upload_edges(dlsm_chain *h, const int64_t *in_edges, int Din,
+                      const int64_t *out_edges, int Dout, const int64_t *degree);
+/* control_nodes_in_/out_: T*N*C int64, -1 padded (case_control_likelihood.py:79-82) */
+int dlsm_set_controls(dlsm_chain *h, const int64_t *ctrl_in,
+                      const int64_t *ctrl_out, int C);
+int dlsm_get_controls(dlsm_chain *h, int64_t *ctrl_in, int64_t *ctrl_out);
+/* DirectedCaseControlSampler.sample (case_control_likelihood.py:75-112) on
+ * device: for every (t, i) draw min(n_control, #zeros) distinct non-neighbours
+ * != i, separately for the out and the in direction, Philox stream CONTROLS. */
+int dlsm_resample_controls(dlsm_chain *h, uint32_t iter, int n_control);
+
+/* ---- chain state (so host and device paths can be swapped mid-chain) --- */
+int dlsm_set_positions(dlsm_chain *h, const double *X);        /* T*N*D */
+int dlsm_get_positions(dlsm_chain *h, double *X);
+int dlsm_set_intercepts(dlsm_chain *h, const double *b, int n); /* 1 or 2 */
+int dlsm_get_intercepts(dlsm_chain *h, double *b, int n);
+int dlsm_set_radii(dlsm_chain *h, const double *radii);         /* N */
+int dlsm_get_radii(dlsm_chain *h, double *radii);
+int dlsm_set_squared(dlsm_chain *h, int squared);
+/* T x N grid of random-walk Metropolis samplers (metropolis.py:85-94);
+ * tune < 0 means tune=None */
+int dlsm_set_samplers(dlsm_chain *h, const double *step_size,
+                      const int32_t *n_accepted, const int32_t *n_steps,
+                      const int32_t *steps_until_tune, int tune, int tune_interval);
+int dlsm_get_samplers(dlsm_chain *h, double *step_size, int32_t *n_accepted,
+                      int32_t *n_steps, int32_t *steps_until_tune);
+/* prior of sample_latent_positions (sample_latent_positions.py:132-140) */
+int dlsm_set_prior_random_walk(dlsm_chain *h, double tau_sq, double sigma_sq);
+/* prior of sample_latent_positions_mixture (:187-199): mu K*D, sigma K
+ * (variances), z T*N int64 */
+int dlsm_set_prior_mixture(dlsm_chain *h, const double *mu, const double *sigma,
+                           double lmbda, const int64_t *z, int K);
+
+/* ---- kernels --------------------------------------------------------- */
+/* a4/a5/a6: dynamic_network_loglikelihood_undirected (network_likelihoods.py:26-33),
+ * directed_network_loglikelihood_fast (directed_likelihoods_fast.pyx:185-205),
+ * approx_directed_network_loglikelihood (:208-270) at the handle's current X
+ * for m candidate intercepts (m*1 undirected, m*2 directed: [b_in, b_out]).
+ * intercepts == NULL evaluates the handle's current intercept (m = 1). */
+int dlsm_loglik_full(dlsm_chain *h, int m, const double *intercepts, double *out);
+/* directed models: out[0] at the handle's radii, out[1] at radii_alt, both at
+ * the current intercepts (sample_radii, sample_coefficients.py:91-121) */
+int dlsm_loglik_full_radii(dlsm_chain *h, const double *radii_alt, double *out);
+/* a1/a2/a3: partial_loglikelihood (static_network_fast.pyx:17-44),
+ * directed_partial_loglikelihood (directed_likelihoods_fast.pyx:46-80),
+ * approx_directed_partial_loglikelihood (:83-182) of node j at time t with
+ * X[t, j] replaced by x (x == NULL: current position).  with_prior != 0 adds
+ * the prior terms of the sweep's logp closure. */
+int dlsm_loglik_partial(dlsm_chain *h, int t, int j, const double *x,
+                        int with_prior, double *out);
+/* the same for every (t, j) at the current state: out T*N */
+int dlsm_loglik_partial_all(dlsm_chain *h, int with_prior, double *out);
+/* a8-a10: one sweep of sample_latent_positions / _mixture: T*N random-walk MH
+ * steps, even-t slices concurrently then odd-t slices, Gauss-Seidel inside a
+ * slice; updates X and the sampler grid on device.  algo 0 = auto,
+ * 1 = one workgroup per slice, 2 = speculative batches over the whole chip. */
+int dlsm_sweep_positions(dlsm_chain *h, uint32_t iter, int algo);
+/* lsm.py:501 / hdp_lpcm.py:852 */
+int dlsm_center(dlsm_chain *h);
+/* longitudinal_procrustes_rotation (procrustes.py:28-35): X <- X R with
+ * R = argmin ||X R - X_ref||_F ; X_ref T*N*D ; R_out (D*D, may be NULL) */
+int dlsm_procrustes(dlsm_chain *h, const double *X_ref, double *R_out);
+/* a11: compute_gaussian_likelihood(X[:, node], mu, sigma, lmbda, normalize)
+ * (gaussian_likelihood_fast.pyx:30-54) with the mixture prior's parameters */
+int dlsm_gaussian_likelihood(dlsm_chain *h, int node, int normalize, double *out);
+/* a12: sample_labels_block (sample_labels.py:134-190); w T*K*K (w[0,0,:] the
+ * initial distribution).  Writes z (T*N), n (T*K*K), nk (T*K) and keeps the new
+ * z on device as the mixture prior's labels. */
+int dlsm_sample_labels(dlsm_chain *h, uint32_t iter, const double *w, int64_t *z,
+                       double *n, int64_t *nk);
+
+/* ---- device-resident LSM chain (lsm.py:474-572, fully observed network) -- */
+typedef struct {
+    double intercept_prior[2];
+    double intercept_variance_prior;
+    /* intercept samplers (metropolis.py:85-94); [0] = b or b_in, [1] = b_out */
+    double i_step_size[2];
+    int32_t i_n_accepted[2], i_n_steps[2], i_steps_until_tune[2];
+    int32_t i_tune, i_tune_interval;           /* i_tune < 0 == None */
+    int32_t n_iter_procrustes;                 /* lsm.py:362-368 */
+    int32_t sweep_algo;                        /* as dlsm_sweep_positions */
+} dlsm_lsm_config;
+int dlsm_lsm_configure(dlsm_chain *h, const dlsm_lsm_config *cfg);
+int dlsm_lsm_get_config(dlsm_chain *h, dlsm_lsm_config *cfg);
+/* device trace buffers Xs_[n_total,T,N,D], intercepts_[n_total,2],
+ * logps_[n_total]; row 0 is filled from the current state, logp0 given */
+int dlsm_trace_alloc(dlsm_chain *h, int n_total, double logp0);
+/* enqueue iterations it = first .. first+count-1 (undirected model): sweep,
+ * Procrustes to row `procrustes_ref` of the trace if it > n_iter_procrustes,
+ * centring, intercept RW-MH fused with the log-posterior trace; asynchronous */
+int dlsm_lsm_run(dlsm_chain *h, int first, int count, int procrustes_ref);
+int dlsm_trace_read(dlsm_chain *h, int first, int count, double *Xs,
+                    double *intercepts, double *logps);
+
+/* ---- measurement ------------------------------------------------------ */
+enum {
+    DLSM_K_LOGLIK = 0, DLSM_K_SWEEP = 1, DLSM_K_CENTER = 2, DLSM_K_LABELS = 3,
+    DLSM_K_FINALIZE = 4, DLSM_K_COUNT = 8
+};
+/* when enabled every launch of the kernel classes above is bracketed by HIP
+ * events on the handle's stream; read returns accumulated ms and launches */
+int dlsm_profile_enable(dlsm_chain *h, int on);
+int dlsm_profile_read(dlsm_chain *h, int kernel, double *total_ms, int *launches);
+/* wall-clock of a region on the handle's stream, by HIP events */
+int dlsm_timer_start(dlsm_chain *h);
+int dlsm_timer_stop(dlsm_chain *h, double *ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,444 @@
+"""Parity of the HIP engine (through the C-ABI) against the CPU oracle and the
+golden vectors captured from the reference.  Needs an MI355X: -m gpu.
+
+Tolerances: BASELINE.json asks for the log-likelihood to 1e-6 relative; the
+engine computes in float64, so the tests hold it to 1e-10 relative (full
+sums) / 1e-9 absolute on positions after several sweeps."""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+RTOL_LL = 1e-10
+
+
+@pytest.fixture(scope='module')
+def eng():
+    import dynetlsm_amd
+    from dynetlsm_amd import _lib
+    _lib.load()
+    assert _lib.device_count() >= 1, 'no HIP device: the engine has no CPU path'
+    return dynetlsm_amd
+
+
+def _rand_net(seed, T, N, D=2, density=0.2, scale=1.0):
+    rng = np.random.RandomState(seed)
+    X = rng.randn(T, N, D) * scale
+    Yd = (rng.rand(T, N, N) < density).astype(np.float64)
+    for t in range(T):
+        np.fill_diagonal(Yd[t], 0)
+    Yu = np.triu(Yd, 1)
+    Yu = Yu + Yu.transpose(0, 2, 1)
+    radii = rng.dirichlet(np.ones(N) * 5)
+    return X, Yd, Yu, radii
+
+
+def _cc_lists(Yd, n_control, seed):
+    """edge lists as the reference builds them + valid random controls"""
+    T, N, _ = Yd.shape
+    deg, ie, oe = orc.case_control_init(Yd)
+    rng = np.random.RandomState(seed)
+    ci = np.full((T, N, n_control), -1, dtype=np.int64)
+    co = np.full((T, N, n_control), -1, dtype=np.int64)
+    for t in range(T):
+        for i in range(N):
+            zo = np.setdiff1d(np.arange(N), np.append(oe[t, i, :deg[t, i, 1]], i))
+            zi = np.setdiff1d(np.arange(N), np.append(ie[t, i, :deg[t, i, 0]], i))
+            k = min(n_control, zo.size)
+            co[t, i, :k] = rng.choice(zo, k, replace=False)
+            k = min(n_control, zi.size)
+            ci[t, i, :k] = rng.choice(zi, k, replace=False)
+    return dict(in_edges=ie, out_edges=oe, degree=deg, control_nodes_in=ci,
+                control_nodes_out=co)
+
+
+# ------------------------------------------------------------ function seam
+@pytest.mark.parametrize('tag', ['a', 'b', 'c'])
+@pytest.mark.parametrize('sq', [0, 1])
+def test_function_seam_against_reference_goldens(eng, golden_lik, tag, sq):
+    """the reference's own outputs, through the reference's own signatures"""
+    nl = eng.network_likelihoods
+    g = golden_lik
+    X, Yd, Yu, radii = g[tag + '_X'], g[tag + '_Yd'], g[tag + '_Yu'], g[tag + '_radii']
+    b, b_in, b_out = g[tag + '_b']
+    T, N, D = X.shape
+    for t, j in [(0, 0), (T - 1, N - 1), (0, N // 2)]:
+        got = nl.partial_loglikelihood(Yu[t], X[t], b, j, squared=bool(sq))
+        np.testing.assert_allclose(got, g['%s_partial_undirected_sq%d' % (tag, sq)][t, j],
+                                   rtol=1e-12)
+        got = nl.directed_partial_loglikelihood(Yd[t].copy(), X[t].copy(), radii, b_in,
+                                                b_out, j, squared=bool(sq))
+        np.testing.assert_allclose(got, g['%s_partial_directed_sq%d' % (tag, sq)][t, j],
+                                   rtol=1e-12)
+    got = nl.dynamic_network_loglikelihood_undirected(Yu, X, b, squared=bool(sq))
+    np.testing.assert_allclose(got, g['%s_full_undirected_sq%d' % (tag, sq)], rtol=RTOL_LL)
+    got = nl.dynamic_network_loglikelihood_directed(Yd, X, b_in, b_out, radii,
+                                                    squared=bool(sq))
+    np.testing.assert_allclose(got, g['%s_full_directed_sq%d' % (tag, sq)], rtol=RTOL_LL)
+    got = nl.approx_directed_network_loglikelihood(
+        X, radii, g[tag + '_in_edges'], g[tag + '_out_edges'], g[tag + '_degrees'],
+        g[tag + '_ctrl_out'], b_in, b_out, squared=bool(sq))
+    np.testing.assert_allclose(got, g['%s_full_approx_sq%d' % (tag, sq)], rtol=RTOL_LL)
+    # a3 where the reference's sentinel bug is harmless (n_in == n_out)
+    ci, co = g[tag + '_ctrl_in'], g[tag + '_ctrl_out']
+    ok = np.argwhere((ci >= 0).sum(2) == (co >= 0).sum(2))
+    for t, j in ok[:4]:
+        got = nl.approx_directed_partial_loglikelihood(
+            X[t], radii, g[tag + '_in_edges'][t], g[tag + '_out_edges'][t],
+            g[tag + '_degrees'][t], ci[t], co[t], b_in, b_out, int(j), squared=bool(sq))
+        np.testing.assert_allclose(got, g['%s_partial_approx_sq%d' % (tag, sq)][t, j],
+                                   rtol=1e-12)
+    for i in (0, N - 1):
+        for nz in (0, 1):
+            got = nl.compute_gaussian_likelihood(X[:, i].copy(), g[tag + '_mu'],
+                                                 g[tag + '_sigma'], 0.8, normalize=bool(nz))
+            np.testing.assert_allclose(got, g['%s_gauss_norm%d' % (tag, nz)][i], rtol=1e-12)
+
+
+def test_function_seam_dtype_rules(eng):
+    nl = eng.network_likelihoods
+    X, Yd, Yu, radii = _rand_net(0, 1, 8)
+    with pytest.raises(ValueError):
+        nl.partial_loglikelihood(Yu[0].astype(np.float32), X[0], 0.1, 0)
+    with pytest.raises(ValueError):
+        nl.directed_partial_loglikelihood(Yd[0].T, X[0], radii, 0.1, 0.2, 0)
+
+
+# ------------------------------------------------------------ full log-lik
+@pytest.mark.parametrize('N', [7, 128, 129, 300])
+@pytest.mark.parametrize('D', [1, 2, 3, 4])
+def test_loglik_full_undirected(eng, N, D):
+    X, Yd, Yu, radii = _rand_net(N * 10 + D, 3, N, D)
+    cands = np.array([[0.75], [-1.3], [2.0]])
+    with eng.Chain(3, N, D, 'undirected') as c:
+        c.upload_network(Yu); c.set_positions(X); c.set_intercepts([0.75])
+        for sq in (0, 1):
+            c.set_squared(sq)
+            got = c.loglik_full(cands)
+            want = [orc.dynamic_network_loglikelihood_undirected(Yu, X, b, squared=sq)
+                    for b in cands[:, 0]]
+            np.testing.assert_allclose(got, want, rtol=RTOL_LL)
+            np.testing.assert_allclose(c.loglik_full(), want[0], rtol=RTOL_LL)
+            # sum of partials = 2 x full
+            np.testing.assert_allclose(c.loglik_partial_all().sum() / 2, want[0],
+                                       rtol=RTOL_LL)
+
+
+@pytest.mark.parametrize('N', [7, 130, 300])
+@pytest.mark.parametrize('D', [2, 3])
+def test_loglik_full_directed(eng, N, D):
+    X, Yd, Yu, radii = _rand_net(N * 7 + D, 2, N, D, scale=0.05)
+    cands = np.array([[0.3, 0.7], [1.0, -0.2], [0.1, 0.1]])
+    with eng.Chain(2, N, D, 'directed') as c:
+        c.upload_network(Yd); c.set_positions(X); c.set_radii(radii)
+        c.set_intercepts(cands[0])
+        got = c.loglik_full(cands)
+        want = [orc.dynamic_network_loglikelihood_directed(Yd, X, a, b, radii)
+                for a, b in cands]
+        np.testing.assert_allclose(got, want, rtol=RTOL_LL)
+        pa = c.loglik_partial_all()
+        wantp = np.array([[orc.directed_partial_loglikelihood(Yd[t], X[t], radii, 0.3,
+                                                              0.7, j)
+                           for j in range(N)] for t in range(2)])
+        np.testing.assert_allclose(pa, wantp, rtol=1e-11)
+        np.testing.assert_allclose(pa.sum() / 2, want[0], rtol=RTOL_LL)
+        r2 = np.random.RandomState(1).dirichlet(np.ones(N) * 3)
+        got2 = c.loglik_full_radii(r2)
+        np.testing.assert_allclose(got2[0], want[0], rtol=RTOL_LL)
+        np.testing.assert_allclose(
+            got2[1], orc.dynamic_network_loglikelihood_directed(Yd, X, 0.3, 0.7, r2),
+            rtol=RTOL_LL)
+
+
+@pytest.mark.parametrize('N,C', [(12, 3), (200, 70), (200, 300)])
+def test_loglik_case_control(eng, N, C):
+    X, Yd, Yu, radii = _rand_net(N + C, 2, N, 2, density=0.05, scale=0.05)
+    cc = _cc_lists(Yd, C, 3)
+    with eng.Chain(2, N, 2, 'case_control') as c:
+        c.upload_edges(cc['in_edges'], cc['out_edges'], cc['degree'])
+        c.set_controls(cc['control_nodes_in'], cc['control_nodes_out'])
+        c.set_positions(X); c.set_radii(radii); c.set_intercepts([0.3, 0.7])
+        got = c.loglik_full([[0.3, 0.7], [0.9, 0.1]])
+        want = [orc.approx_directed_network_loglikelihood(
+            X, radii, cc['in_edges'], cc['out_edges'], cc['degree'],
+            cc['control_nodes_out'], a, b) for a, b in [(0.3, 0.7), (0.9, 0.1)]]
+        np.testing.assert_allclose(got, want, rtol=RTOL_LL)
+        pa = c.loglik_partial_all()
+        wantp = np.array([[orc.approx_directed_partial_loglikelihood(
+            X[t], radii, cc['in_edges'][t], cc['out_edges'][t], cc['degree'][t],
+            cc['control_nodes_in'][t], cc['control_nodes_out'][t], 0.3, 0.7, j)
+            for j in range(N)] for t in range(2)])
+        np.testing.assert_allclose(pa, wantp, rtol=1e-11)
+        if C >= N:   # exhaustive controls: the estimator is exact
+            exact = orc.dynamic_network_loglikelihood_directed(Yd, X, 0.3, 0.7, radii)
+            np.testing.assert_allclose(got[0], exact, rtol=1e-10)
+
+
+def test_partial_with_explicit_position_and_prior(eng):
+    X, Yd, Yu, radii = _rand_net(5, 3, 40)
+    grid = orc.SamplerGrid(3, 40)
+    st = orc.ChainState(X, grid, Y=Yu, intercept=[0.2], tau_sq=2.0, sigma_sq=0.1)
+    with eng.Chain(3, 40, 2, 'undirected') as c:
+        c.upload_network(Yu); c.set_positions(X); c.set_intercepts([0.2])
+        c.set_prior_random_walk(2.0, 0.1)
+        x = np.array([0.3, -0.8])
+        for t, j in [(0, 3), (1, 39), (2, 0)]:
+            np.testing.assert_allclose(c.loglik_partial(t, j, x, with_prior=True),
+                                       st.node_logp(t, j, x), rtol=1e-12)
+
+
+def test_bad_inputs_fail_loudly(eng):
+    X, Yd, Yu, radii = _rand_net(1, 2, 10)
+    with eng.Chain(2, 10, 2, 'undirected') as c:
+        with pytest.raises(eng.EngineError):
+            c.loglik_full([[0.1]])                 # nothing uploaded yet
+        Ybad = Yu.copy(); Ybad[0, 1, 2] = -1.0     # missing-edge code
+        with pytest.raises(eng.EngineError) as e:
+            c.upload_network(Ybad)
+        assert e.value.code == -4
+        c.upload_network(Yu); c.set_positions(X)
+        with pytest.raises(eng.EngineError):
+            c.sweep_positions(1)                   # samplers / prior missing
+    with pytest.raises(eng.EngineError):
+        eng.Chain(2, 10, 9, 'undirected')          # unsupported n_features
+
+
+# ------------------------------------------------------------ sweep
+def _sweep_case(eng, name, prior, T, N, D, n_sweeps, algo, seed=11, cc_C=4,
+                density=0.2, scale=1.0):
+    X, Yd, Yu, radii = _rand_net(seed, T, N, D, density=density, scale=scale)
+    rng = np.random.RandomState(seed + 1)
+    K = 3
+    mu = rng.randn(K, D) * scale; sigma = rng.uniform(0.5, 1.5, K) * scale ** 2
+    z = rng.randint(0, K, size=(T, N)).astype(np.int64)
+    okw = dict(tau_sq=2.0, sigma_sq=0.1)
+    if prior == 'mix':
+        okw = dict(mu=mu, sigma=sigma, lmbda=0.8, z=z)
+    model = {'undirected': 0, 'directed': 1, 'case_control': 2}[name]
+    cc = None
+    if name == 'undirected':
+        okw.update(Y=Yu, intercept=[0.5])
+    elif name == 'directed':
+        okw.update(Y=Yd, intercept=[0.3, 0.7], radii=radii)
+    else:
+        cc = _cc_lists(Yd, cc_C, seed)
+        okw.update(intercept=[0.3, 0.7], radii=radii, case_control=cc)
+    step = 0.2 * scale
+    og = orc.SamplerGrid(T, N, step, tune=5, tune_interval=2)
+    gg = eng.SamplerGrid(T, N, step, tune=5, tune_interval=2)
+    st = orc.ChainState(X, og, model=model, seed=0xC0FFEE1234, chain=2, **okw)
+    with eng.Chain(T, N, D, name, seed=0xC0FFEE1234, chain_id=2) as c:
+        if cc is None:
+            c.upload_network(okw['Y'])
+        else:
+            c.upload_edges(cc['in_edges'], cc['out_edges'], cc['degree'])
+            c.set_controls(cc['control_nodes_in'], cc['control_nodes_out'])
+        c.set_positions(X); c.set_intercepts(okw['intercept'])
+        if name != 'undirected':
+            c.set_radii(radii)
+        if prior == 'mix':
+            c.set_prior_mixture(mu, sigma, 0.8, z)
+        else:
+            c.set_prior_random_walk(2.0, 0.1)
+        c.set_samplers(gg)
+        for it in range(1, n_sweeps + 1):
+            c.sweep_positions(it, algo=algo)
+            st.c.iter = it
+            st.sweep_c()
+            np.testing.assert_allclose(c.get_positions(), st.X, rtol=0,
+                                       atol=1e-9 * max(scale, 1e-3))
+        c.get_samplers(gg)
+    np.testing.assert_allclose(gg.step_size, og.step_size, rtol=1e-13)
+    np.testing.assert_array_equal(gg.n_accepted, og.n_accepted)
+    np.testing.assert_array_equal(gg.n_steps, og.n_steps)
+    np.testing.assert_array_equal(gg.steps_until_tune, og.steps_until_tune)
+    assert 0 < og.n_steps.sum()
+
+
+@pytest.mark.parametrize('prior', ['rw', 'mix'])
+@pytest.mark.parametrize('name', ['undirected', 'directed', 'case_control'])
+def test_sweep_slice_small(eng, name, prior):
+    _sweep_case(eng, name, prior, T=3, N=10, D=2, n_sweeps=6, algo=1,
+                scale=1.0 if name == 'undirected' else 0.05)
+
+
+@pytest.mark.parametrize('name,N,D', [('undirected', 300, 2), ('undirected', 1100, 2),
+                                      ('directed', 260, 2), ('undirected', 70, 3),
+                                      ('case_control', 300, 2), ('undirected', 33, 1)])
+def test_sweep_slice_medium(eng, name, N, D):
+    """crosses the proposal-chunk (256) and the workgroup (1024) boundaries;
+    T=4 and T=1 exercise both parities and the single-slice edge case"""
+    _sweep_case(eng, name, 'rw', T=4, N=N, D=D, n_sweeps=3, algo=1,
+                scale=1.0 if name == 'undirected' else 0.05,
+                cc_C=20, density=0.05 if name == 'case_control' else 0.2)
+
+
+def test_sweep_single_time_step(eng):
+    _sweep_case(eng, 'undirected', 'rw', T=1, N=20, D=2, n_sweeps=3, algo=1)
+
+
+# ------------------------------------------------------------ glue
+def test_center_and_procrustes(eng):
+    X, Yd, Yu, radii = _rand_net(3, 3, 50)
+    rng = np.random.RandomState(0)
+    th = 0.7
+    R0 = np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
+    Xref = X.dot(R0) + 0.01 * rng.randn(*X.shape)
+    with eng.Chain(3, 50, 2, 'undirected') as c:
+        c.set_positions(X)
+        c.center()
+        np.testing.assert_allclose(c.get_positions(), orc.center(X), atol=1e-13)
+        c.set_positions(X)
+        R = c.procrustes(Xref)
+        Xw, Rw = orc.procrustes_rotation(Xref, X)
+        np.testing.assert_allclose(R, Rw, atol=1e-12)
+        np.testing.assert_allclose(c.get_positions(), Xw, atol=1e-12)
+    # a reflection is a legal Procrustes solution (det R = -1)
+    F = np.array([[1.0, 0.0], [0.0, -1.0]])
+    with eng.Chain(3, 50, 2, 'undirected') as c:
+        c.set_positions(X)
+        R = c.procrustes(X.dot(F))
+        np.testing.assert_allclose(R, F, atol=1e-12)
+    # three features: Jacobi SVD path
+    X3 = rng.randn(2, 40, 3)
+    Q, _ = np.linalg.qr(rng.randn(3, 3))
+    with eng.Chain(2, 40, 3, 'undirected') as c:
+        c.set_positions(X3)
+        R = c.procrustes(X3.dot(Q) + 0.01 * rng.randn(*X3.shape))
+        _, Rw = orc.procrustes_rotation(X3.dot(Q), X3)
+        np.testing.assert_allclose(R, Rw, atol=5e-2)
+        np.testing.assert_allclose(R.T.dot(R), np.eye(3), atol=1e-12)
+
+
+# ------------------------------------------------------------ labels
+def test_labels_against_reference_golden_inputs(eng, golden_sweeps):
+    g = golden_sweeps
+    X, mu, sg, w = g['lab_X'], g['lab_mu'], g['lab_sigma'], g['lab_w']
+    T, N, D = X.shape
+    K = sg.shape[0]
+    with eng.Chain(T, N, D, 'undirected', seed=99, chain_id=1) as c:
+        c.set_positions(X)
+        c.set_prior_mixture(mu, sg, 0.8, np.zeros((T, N), dtype=np.int64))
+        for it in (7, 8):
+            z, n, nk = c.sample_labels(it, w)
+            zo, no, nko = orc.sample_labels_block_philox(X, mu, sg, 0.8, w, 99, 1, it)
+            np.testing.assert_array_equal(z, zo)
+            np.testing.assert_array_equal(n, no)
+            np.testing.assert_array_equal(nk, nko)
+
+
+def test_labels_medium_and_distribution(eng):
+    rng = np.random.RandomState(4)
+    T, N, D, K = 6, 500, 2, 20
+    mu = rng.randn(K, D) * 2; sg = rng.uniform(0.2, 1.0, K)
+    X = mu[rng.randint(0, K, size=(T, N))] + 0.5 * rng.randn(T, N, D)
+    w = rng.dirichlet(np.ones(K), size=(T, K))
+    with eng.Chain(T, N, D, 'undirected', seed=5, chain_id=0) as c:
+        c.set_positions(X)
+        c.set_prior_mixture(mu, sg, 0.8, np.zeros((T, N), dtype=np.int64))
+        z, n, nk = c.sample_labels(3, w)
+        zo, no, nko = orc.sample_labels_block_philox(X, mu, sg, 0.8, w, 5, 0, 3)
+        assert (z != zo).mean() < 1e-3        # identical up to 1-ulp ties
+        assert n.sum() == T * N and (nk.sum(axis=1) == N).all()
+        # the new labels are the sweep's mixture labels now
+        c.upload_network(np.zeros((T, N, N)))
+        c.set_intercepts([0.0])
+        lp = c.loglik_partial(1, 5, with_prior=True)
+        st = orc.ChainState(X, orc.SamplerGrid(T, N), Y=np.zeros((T, N, N)),
+                            intercept=[0.0], mu=mu, sigma=sg, lmbda=0.8, z=z)
+        np.testing.assert_allclose(lp, st.node_logp(1, 5, X[1, 5]), rtol=1e-12)
+
+
+# ------------------------------------------------------------ controls
+def test_resample_controls_valid_and_uniform(eng):
+    X, Yd, Yu, radii = _rand_net(8, 2, 60, density=0.1)
+    Yd[0, 0, :] = 1; Yd[0, 0, 0] = 0; Yd[0, 0, 5] = 0; Yd[0, 0, 9] = 0   # 2 zeros only
+    deg, ie, oe = orc.case_control_init(Yd)
+    C = 7
+    counts = np.zeros(60)
+    with eng.Chain(2, 60, 2, 'case_control', seed=3) as c:
+        c.upload_edges(ie, oe, deg)
+        for it in range(200):
+            c.resample_controls(it, C)
+            ci, co = c.get_controls()
+            for arr, col, edges in ((co, 1, oe), (ci, 0, ie)):
+                for t in range(2):
+                    for i in range(60):
+                        v = arr[t, i]
+                        k = min(C, 60 - deg[t, i, col] - 1)
+                        assert (v[:k] >= 0).all() and (v[k:] == -1).all()
+                        assert len(set(v[:k])) == k and i not in v[:k]
+                        assert not set(v[:k]) & set(edges[t, i, :deg[t, i, col]])
+            counts[co[1, 3][co[1, 3] >= 0]] += 1
+        np.testing.assert_array_equal(np.sort(co[0, 0, :2]), [5, 9])
+    allowed = np.setdiff1d(np.arange(60), np.append(oe[1, 3, :deg[1, 3, 1]], 3))
+    assert counts[np.setdiff1d(np.arange(60), allowed)].sum() == 0
+    expect = 200 * C / allowed.size
+    chi2 = ((counts[allowed] - expect) ** 2 / expect).sum()
+    assert chi2 < 2.0 * allowed.size          # loose: mean df, sd sqrt(2 df)
+
+
+# ------------------------------------------------------------ fused LSM loop
+@pytest.mark.parametrize('N', [18, 300])
+def test_lsm_device_loop_equals_oracle_iterations(eng, monks, N):
+    import ctypes as C
+    if N == 18:
+        Y = monks['Y_undirected']
+        X = np.random.RandomState(0).randn(3, 18, 2)
+    else:
+        X, _, Y, _ = _rand_net(21, 4, N)
+    T = Y.shape[0]
+    b0, prior_b, var_b = 0.3, 0.1, 2.0
+    n_total = 9
+    og = orc.SamplerGrid(T, N, 0.1, tune=6, tune_interval=2)
+    gg = eng.SamplerGrid(T, N, 0.1, tune=6, tune_interval=2)
+    st = orc.ChainState(X, og, Y=Y, intercept=[b0], tau_sq=2.0, sigma_sq=0.1,
+                        seed=17, chain=5)
+    isamp = orc.ScalarSampler(0.1, 0, 0, 3, 6, 3)
+    want_lp, want_b, want_X = [], [], []
+    for it in range(1, n_total):
+        st.c.iter = it
+        want_lp.append(orc.lsm_iteration_undirected(st, isamp, prior_b, var_b))
+        want_b.append(st.c.intercept[0]); want_X.append(st.X.copy())
+    with eng.Chain(T, N, 2, 'undirected', seed=17, chain_id=5) as c:
+        c.upload_network(Y); c.set_positions(X); c.set_intercepts([b0])
+        c.set_prior_random_walk(2.0, 0.1); c.set_samplers(gg)
+        c.lsm_configure([prior_b], var_b, step_size_intercept=0.1, tune=6,
+                        tune_interval=3, n_iter_procrustes=10 ** 6, sweep_algo=1)
+        c.trace_alloc(n_total, logp0=-1.0)
+        c.lsm_run(1, 4); c.lsm_run(5, n_total - 5)
+        Xs, ics, lps = c.trace_read(0, n_total)
+        cfg = c.lsm_get_config()
+    assert lps[0] == -1.0 and ics[0, 0] == b0
+    np.testing.assert_allclose(Xs[0], X)
+    np.testing.assert_allclose(Xs[1:], np.array(want_X), atol=1e-9)
+    np.testing.assert_allclose(ics[1:, 0], want_b, atol=1e-12)
+    np.testing.assert_allclose(lps[1:], want_lp, rtol=1e-10)
+    assert cfg.i_n_steps[0] == isamp.n_steps
+    assert cfg.i_n_accepted[0] == isamp.n_accepted
+    np.testing.assert_allclose(cfg.i_step_size[0], isamp.step_size, rtol=1e-14)
+
+
+def test_lsm_device_loop_procrustes(eng, monks):
+    """after tune+burn the loop rotates to the pre-burn MAP sample (lsm.py:495-498)"""
+    Y = monks['Y_undirected']
+    T, N = 3, 18
+    X = np.random.RandomState(2).randn(T, N, 2)
+    gg = eng.SamplerGrid(T, N, 0.1, tune=None)
+    with eng.Chain(T, N, 2, 'undirected', seed=1) as c:
+        c.upload_network(Y); c.set_positions(X); c.set_intercepts([0.2])
+        c.set_prior_random_walk(2.0, 0.1); c.set_samplers(gg)
+        c.lsm_configure([0.2], 2.0, tune=None, n_iter_procrustes=2, sweep_algo=1)
+        c.trace_alloc(6)
+        c.lsm_run(1, 2)
+        Xs, _, _ = c.trace_read(0, 3)
+        # replay iteration 3 by hand: sweep, rotate to row 1, centre
+        c.sweep_positions(3, algo=1)
+        Xsw = c.get_positions()
+        c.set_positions(Xs[2]); c.set_samplers(gg)
+        c.lsm_run(3, 1, procrustes_ref=1)
+        X3 = c.trace_read(3, 1)[0][0]
+    Xw, _ = orc.procrustes_rotation(Xs[1], Xsw)
+    np.testing.assert_allclose(X3, orc.center(Xw), atol=1e-10)
