@@ -1,0 +1,219 @@
+#!/usr/bin/env python
+"""Benchmark of the Gibbs hot path on MI355X: Gibbs iterations/s of
+DynamicNetworkLSM on a synthetic undirected network, T=10 N=2000 d=2
+(BASELINE.json configs[1]), one independent chain per GPU.
+
+One "step" = one full Gibbs iteration of lsm.py:474-572 for the fully observed
+undirected model: latent-position sweep (20 000 MH steps), Procrustes rotation
+to the reference sample, centring, intercept MH step and log-posterior trace
+(the three full log-likelihood evaluations of the reference fused into one
+pass), sample stored in the device-resident trace.
+
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1 is launched by torch.distributed.run (one rank per GPU).  Rank 0 builds
+the network and broadcasts it over RCCL; chains are independent (no
+intra-iteration collective); per-chain summaries are all-gathered at the end.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--T', type=int, default=10)
+    ap.add_argument('--N', type=int, default=2000)
+    ap.add_argument('--D', type=int, default=2)
+    ap.add_argument('--density', type=float, default=0.03)
+    ap.add_argument('--algo', type=int, default=0, help='sweep algorithm (0 auto)')
+    ap.add_argument('--profile-steps', type=int, default=20)
+    ap.add_argument('--cpu-iters', type=int, default=3,
+                    help='oracle iterations timed for cpu_baseline (0 = skip)')
+    ap.add_argument('--no-cpu', action='store_true')
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if rank == 0:
+            print('bench.py: --gpus %d but WORLD_SIZE=%d; launch with '
+                  'torch.distributed.run --nproc-per-node %d' % (args.gpus, world, args.gpus),
+                  file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+
+    from dynetlsm_amd import Chain, SamplerGrid
+    from dynetlsm_amd import _lib
+    from dynetlsm_amd.synthetic import synthetic_lsm_network
+
+    T, N, D = args.T, args.N, args.D
+    K, W, P = args.steps, args.warmup, args.profile_steps
+    dev = torch.device('cuda', local_rank)
+
+    # ---- the network: built on rank 0, broadcast over RCCL -----------------
+    t_gen = time.time()
+    if rank == 0:
+        net = synthetic_lsm_network(T, N, D, density=args.density, seed=0)
+        Y8 = torch.from_numpy(net['Y'].astype(np.uint8)).to(dev)
+        X0 = torch.from_numpy(net['X_init']).to(dev)
+        b0 = torch.tensor([net['intercept']], dtype=torch.float64, device=dev)
+    else:
+        Y8 = torch.empty((T, N, N), dtype=torch.uint8, device=dev)
+        X0 = torch.empty((T, N, D), dtype=torch.float64, device=dev)
+        b0 = torch.empty(1, dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.broadcast(Y8, 0); dist.broadcast(X0, 0); dist.broadcast(b0, 0)
+    Y = Y8.cpu().numpy().astype(np.float64)
+    X_init = X0.cpu().numpy()
+    b_init = float(b0.cpu()[0])
+    del Y8
+    density = float(Y.mean())
+    t_gen = time.time() - t_gen
+
+    # ---- one chain per rank --------------------------------------------------
+    chain = Chain(T, N, D, 'undirected', seed=20240229, chain_id=rank, device=local_rank)
+    chain.upload_network(Y)
+    chain.set_positions(X_init)
+    chain.set_intercepts([b_init])
+    chain.set_prior_random_walk(2.0, 0.1)
+    chain.set_samplers(SamplerGrid(T, N, step_size=0.1, tune=None))
+    chain.lsm_configure([b_init], 2.0, step_size_intercept=0.1, tune=None,
+                        n_iter_procrustes=0, sweep_algo=args.algo)
+    n_total = 1 + W + K + P
+    chain.trace_alloc(n_total, logp0=0.0)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    chain.lsm_run(1, W, procrustes_ref=0)
+    chain.synchronize()
+    torch.cuda.synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    chain.lsm_run(1 + W, K, procrustes_ref=0)
+    chain.synchronize()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.cpu()[0])
+
+    # ---- per-kernel timing by HIP events on the chain's stream --------------
+    roofline = None
+    extra = {}
+    if P > 0:
+        chain.profile_enable(True)
+        chain.lsm_run(1 + W + K, P, procrustes_ref=0)
+        chain.synchronize()
+        ms_sw, n_sw = chain.profile_read(_lib.K_SWEEP)
+        ms_ll, n_ll = chain.profile_read(_lib.K_LOGLIK)
+        ms_ps, n_ps = chain.profile_read(_lib.K_CENTER)
+        ms_fi, n_fi = chain.profile_read(_lib.K_FINALIZE)
+        chain.profile_enable(False)
+        sweep_ms = ms_sw / max(n_sw, 1)
+        ll_ms = ms_ll / max(n_ll, 1)
+        # algorithmic bytes: the sweep touches every float64 Y
+        # entry once (row j of slice t per MH step) + X; one fused eval reads
+        # the upper triangle once + X
+        sweep_bytes = 8.0 * T * N * N + 8.0 * T * N * D
+        ll_bytes = 8.0 * T * N * (N - 1) / 2 + 8.0 * T * N * D
+        ach = sweep_bytes / (sweep_ms * 1e-3) / 1e9
+        roofline = {'bound': 'hbm', 'kernel': 'latent-position sweep (all launches of one sweep)',
+                    'achieved': round(ach, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                    'frac': round(ach / HBM_PEAK_GBS, 5), 'traffic': None,
+                    'ms_per_launch': round(sweep_ms, 4),
+                    'algorithmic_bytes_per_launch': sweep_bytes}
+        extra = {'ms_per_loglik_eval': round(ll_ms, 4),
+                 'loglik_eval_GBps': round(ll_bytes / (ll_ms * 1e-3) / 1e9, 1),
+                 'ms_sweep': round(sweep_ms, 4), 'ms_post_sweep': round(ms_ps / max(n_ps, 1), 4),
+                 'ms_finalize': round(ms_fi / max(n_fi, 1), 4)}
+
+    # ---- chain summaries: gather over RCCL ------------------------------------
+    _, ics, lps = chain.trace_read(1 + W, K, positions=False)
+    summ = torch.tensor([ics[:, 0].mean(), ics[:, 0].std(), lps.mean(), lps[-1]],
+                        dtype=torch.float64, device=dev)
+    if world > 1:
+        allsum = [torch.empty_like(summ) for _ in range(world)]
+        dist.all_gather(allsum, summ)
+        summaries = [s.cpu().tolist() for s in allsum]
+    else:
+        summaries = [summ.cpu().tolist()]
+
+    # ---- parity spot check + CPU baseline on rank 0 ---------------------------
+    cpu = None
+    parity = None
+    if rank == 0 and not args.no_cpu:
+        from oracle import oracle as orc
+        Xf = chain.get_positions()
+        bf = chain.get_intercepts()[0]
+        g = chain.loglik_full([[bf]])[0]
+        o = orc.dynamic_network_loglikelihood_undirected(Y, Xf, bf)
+        parity = abs(g - o) / abs(o)
+        if args.cpu_iters > 0:
+            og = orc.SamplerGrid(T, N, 0.1, tune=None)
+            st = orc.ChainState(X_init, og, Y=Y, intercept=[b_init], tau_sq=2.0,
+                                sigma_sq=0.1, seed=20240229, chain=0)
+            isamp = orc.ScalarSampler(0.1, 0, 0, 100, -1, 100)
+            tc = time.perf_counter()
+            for it in range(1, args.cpu_iters + 1):
+                st.c.iter = it
+                orc.lsm_iteration_undirected(st, isamp, b_init, 2.0)
+            tc = time.perf_counter() - tc
+            cpu = {'value': round(args.cpu_iters / tc, 5), 'unit': 'Gibbs iterations/s',
+                   'cores': 1, 'kind': 'port',
+                   'sample': '%d iterations of the same T=%d N=%d d=%d workload by the '
+                             'scalar C oracle (sweep + 2 full log-lik evals per iteration), '
+                             '%.1f s' % (args.cpu_iters, T, N, D, tc)}
+
+    if rank == 0:
+        value = world * K / elapsed
+        line = {
+            'metric': 'Gibbs iterations/sec (and ms/log-lik eval), T=10 N=2000 d=2',
+            'value': round(value, 3), 'unit': 'Gibbs iterations/s', 'n_gpus': world,
+            'steps': K, 'warmup': W, 'ms_per_step': round(1e3 * elapsed / K, 4),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': 'DynamicNetworkLSM synthetic undirected T=%d N=%d d=%d, '
+                                   '1 chain per GPU' % (T, N, D),
+                       'density': round(density, 4), 'chains': world,
+                       'iteration': 'sweep + procrustes + centring + intercept MH + logp trace',
+                       'sweep_algo': args.algo},
+            'roofline': roofline, 'cpu_baseline': cpu,
+            'loglik_rel_err_vs_oracle': parity,
+            'chain_summaries[intercept_mean,intercept_sd,logp_mean,logp_last]': summaries,
+        }
+        line.update(extra)
+        print(json.dumps(line))
+    chain.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

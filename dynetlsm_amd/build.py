@@ -11,7 +11,7 @@ CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libdynetlsm_hip.so')
 SOURCES = ['capi.hip']
 HEADERS = ['chain.hpp', 'device_common.hpp', 'kernels_loglik.hpp',
-           'kernels_sweep.hpp', 'kernels_labels.hpp', 'kernels_spec.hpp',
+           'kernels_sweep.hpp', 'kernels_labels.hpp', 'kernels_spec.hpp', 'kernels_spec_sweep.hpp',
            os.path.join('..', '..', 'include', 'dynetlsm_hip.h')]
 FLAGS = ['-O3', '--offload-arch=gfx950', '-std=c++17', '-Wno-unused-value',
          '-Wno-unused-result', '-shared', '-fPIC']

@@ -14,6 +14,7 @@
 #include "kernels_loglik.hpp"
 #include "kernels_sweep.hpp"
 #include "kernels_spec.hpp"
+#include "kernels_spec_sweep.hpp"
 
 using namespace dlsm;
 
@@ -612,12 +613,56 @@ int dlsm_loglik_partial_all(dlsm_chain *h, int with_prior, double *out) {
 // ---------------------------------------------------------------- sweep
 }  // extern "C"
 
-static bool spec_supported(const dlsm_chain *h) { (void)h; return false; }
+static bool spec_supported(const dlsm_chain *h) {
+    return h->model == DLSM_UNDIRECTED || h->model == DLSM_DIRECTED;
+}
 
+// algo 2: rounds of (chip-wide eval, per-slice resolve) over batches of nodes
 template <int DD>
 static int launch_sweep_spec(dlsm_chain *h, uint32_t iter) {
-    (void)iter;
-    FAIL(h, DLSM_E_ARG, "speculative-batch sweep not available in this build");
+    if (!spec_supported(h)) FAIL(h, DLSM_E_ARG, "speculative-batch sweep needs an exact model");
+    const int N = h->N, T = h->T;
+    const int B = std::min(SP_BMAX, N);
+    const int nsl_max = (T + 1) / 2;
+    int parts = (1024 + nsl_max * B - 1) / (nsl_max * B);
+    parts = std::max(1, std::min(parts, 8));
+    const size_t n_full0 = (size_t)nsl_max * B * parts;
+    const size_t n_prop = (size_t)nsl_max * B * (DD + 2);
+    const size_t n_ht = (size_t)nsl_max * B * B;
+    const size_t need = (n_full0 + n_prop + n_ht) * sizeof(double);
+    if (h->spec_cap < need) {
+        if (h->spec) hipFree(h->spec);
+        h->spec = nullptr; h->spec_cap = 0;
+        HIPCHK(h, hipMalloc((void **)&h->spec, need));
+        h->spec_cap = need;
+    }
+    SpecBuf sb;
+    sb.full0 = h->spec; sb.prop = sb.full0 + n_full0; sb.Ht = sb.prop + n_prop;
+    sb.B = B; sb.parts = parts;
+    ChainView v = h->view();
+    auto resolve = k_spec_resolve<DD>;
+    HIPCHK(h, hipFuncSetAttribute((const void *)resolve,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)((size_t)B * B * sizeof(double))));
+    for (int parity = 0; parity < 2; ++parity) {
+        const int nsl = (T - parity + 1) / 2;
+        if (nsl <= 0) continue;
+        for (int j0 = 0; j0 < N; j0 += B) {
+            const int nb = std::min(B, N - j0);
+            const dim3 grid((unsigned)(nsl * nb * parts));
+            if (h->model == DLSM_UNDIRECTED)
+                hipLaunchKernelGGL((k_spec_eval<DD, DLSM_UNDIRECTED>), grid, dim3(SP_THREADS),
+                                   0, h->stream, v, sb, iter, parity, j0, nb);
+            else
+                hipLaunchKernelGGL((k_spec_eval<DD, DLSM_DIRECTED>), grid, dim3(SP_THREADS),
+                                   0, h->stream, v, sb, iter, parity, j0, nb);
+            hipLaunchKernelGGL(resolve, dim3(nsl), dim3(SP_THREADS),
+                               (size_t)nb * nb * sizeof(double), h->stream, v, sb, parity,
+                               j0, nb);
+        }
+    }
+    HIPCHK(h, hipGetLastError());
+    return DLSM_OK;
 }
 
 template <int DD>

@@ -277,6 +277,25 @@ def test_sweep_slice_medium(eng, name, N, D):
 
 def test_sweep_single_time_step(eng):
     _sweep_case(eng, 'undirected', 'rw', T=1, N=20, D=2, n_sweeps=3, algo=1)
+    _sweep_case(eng, 'undirected', 'rw', T=1, N=150, D=2, n_sweeps=3, algo=2)
+
+
+@pytest.mark.parametrize('prior', ['rw', 'mix'])
+@pytest.mark.parametrize('name,T,N,D', [('undirected', 4, 10, 2), ('undirected', 4, 300, 2),
+                                        ('undirected', 3, 1100, 2), ('directed', 4, 260, 2),
+                                        ('directed', 3, 128, 3), ('undirected', 5, 129, 1),
+                                        ('undirected', 2, 257, 4)])
+def test_sweep_speculative_batches(eng, name, T, N, D, prior):
+    """algo 2 (chip-wide speculative batches) is the same Gauss-Seidel scan:
+    identical decisions, positions equal to rounding.  N = 10 < one batch,
+    129 / 257 / 300 leave ragged last batches."""
+    _sweep_case(eng, name, prior, T=T, N=N, D=D, n_sweeps=3, algo=2,
+                scale=1.0 if name == 'undirected' else 0.05)
+
+
+def test_sweep_auto_picks_a_valid_algorithm(eng):
+    _sweep_case(eng, 'undirected', 'rw', T=3, N=400, D=2, n_sweeps=2, algo=0)
+    _sweep_case(eng, 'undirected', 'rw', T=3, N=40, D=2, n_sweeps=2, algo=0)
 
 
 # ------------------------------------------------------------ glue
@@ -381,8 +400,8 @@ def test_resample_controls_valid_and_uniform(eng):
 
 
 # ------------------------------------------------------------ fused LSM loop
-@pytest.mark.parametrize('N', [18, 300])
-def test_lsm_device_loop_equals_oracle_iterations(eng, monks, N):
+@pytest.mark.parametrize('N,algo', [(18, 1), (300, 1), (300, 2)])
+def test_lsm_device_loop_equals_oracle_iterations(eng, monks, N, algo):
     import ctypes as C
     if N == 18:
         Y = monks['Y_undirected']
@@ -406,7 +425,7 @@ def test_lsm_device_loop_equals_oracle_iterations(eng, monks, N):
         c.upload_network(Y); c.set_positions(X); c.set_intercepts([b0])
         c.set_prior_random_walk(2.0, 0.1); c.set_samplers(gg)
         c.lsm_configure([prior_b], var_b, step_size_intercept=0.1, tune=6,
-                        tune_interval=3, n_iter_procrustes=10 ** 6, sweep_algo=1)
+                        tune_interval=3, n_iter_procrustes=10 ** 6, sweep_algo=algo)
         c.trace_alloc(n_total, logp0=-1.0)
         c.lsm_run(1, 4); c.lsm_run(5, n_total - 5)
         Xs, ics, lps = c.trace_read(0, n_total)
