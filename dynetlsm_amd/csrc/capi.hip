@@ -622,12 +622,12 @@ template <int DD>
 static int launch_sweep_spec(dlsm_chain *h, uint32_t iter) {
     if (!spec_supported(h)) FAIL(h, DLSM_E_ARG, "speculative-batch sweep needs an exact model");
     const int N = h->N, T = h->T;
-    const int B = std::min(SP_BMAX, N);
+    const int B = std::min(SP_BMAX, (N + 1) / 2 * 2);   // even: double2 staging
     const int nsl_max = (T + 1) / 2;
     int parts = (1024 + nsl_max * B - 1) / (nsl_max * B);
     parts = std::max(1, std::min(parts, 8));
     const size_t n_full0 = (size_t)nsl_max * B * parts;
-    const size_t n_prop = (size_t)nsl_max * B * (DD + 2);
+    const size_t n_prop = (size_t)nsl_max * N * (DD + 2);
     const size_t n_ht = (size_t)nsl_max * B * B;
     const size_t need = (n_full0 + n_prop + n_ht) * sizeof(double);
     if (h->spec_cap < need) {
@@ -647,17 +647,19 @@ static int launch_sweep_spec(dlsm_chain *h, uint32_t iter) {
     for (int parity = 0; parity < 2; ++parity) {
         const int nsl = (T - parity + 1) / 2;
         if (nsl <= 0) continue;
+        hipLaunchKernelGGL((k_spec_propose<DD>), dim3((N + 255) / 256, nsl), dim3(256), 0,
+                           h->stream, v, sb, iter, parity);
         for (int j0 = 0; j0 < N; j0 += B) {
             const int nb = std::min(B, N - j0);
             const dim3 grid((unsigned)(nsl * nb * parts));
             if (h->model == DLSM_UNDIRECTED)
                 hipLaunchKernelGGL((k_spec_eval<DD, DLSM_UNDIRECTED>), grid, dim3(SP_THREADS),
-                                   0, h->stream, v, sb, iter, parity, j0, nb);
+                                   0, h->stream, v, sb, parity, j0, nb);
             else
                 hipLaunchKernelGGL((k_spec_eval<DD, DLSM_DIRECTED>), grid, dim3(SP_THREADS),
-                                   0, h->stream, v, sb, iter, parity, j0, nb);
+                                   0, h->stream, v, sb, parity, j0, nb);
             hipLaunchKernelGGL(resolve, dim3(nsl), dim3(SP_THREADS),
-                               (size_t)nb * nb * sizeof(double), h->stream, v, sb, parity,
+                               (size_t)nb * B * sizeof(double), h->stream, v, sb, parity,
                                j0, nb);
         }
     }

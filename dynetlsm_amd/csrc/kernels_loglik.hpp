@@ -102,11 +102,19 @@ __global__ __launch_bounds__(LL_THREADS) void k_loglik_undirected(
     double xj[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) xj[d] = sXj[cj * D + d];
-    double sy = 0.0, syd = 0.0, S[M];
+    // sum_i log(1 + E e^{-d_i}) = log prod_i (1 + E e^{-d_i}): one log per
+    // `nflush` dyads (the running product stays far inside the double range)
+    double Emax = E[0];
 #pragma unroll
-    for (int k = 0; k < M; ++k) S[k] = 0.0;
+    for (int k = 1; k < M; ++k) Emax = fmax(Emax, E[k]);
+    const double l1p = log1p(Emax);
+    const int nflush = !(l1p > 0.0) ? 64 : (600.0 / l1p < 1.0 ? 1 : (600.0 / l1p > 64.0 ? 64 : (int)(600.0 / l1p)));
+    double sy = 0.0, syd = 0.0, S[M], P[M];
+#pragma unroll
+    for (int k = 0; k < M; ++k) { S[k] = 0.0; P[k] = 1.0; }
     if (j < c.N) {
         const int rbeg = half * 64;
+        int cnt = 0;
         for (int r = rbeg; r < rbeg + 64; ++r) {
             const int i = i0 + r;
             if (i >= j) break;           // i < j only (also stops at i >= N)
@@ -115,8 +123,15 @@ __global__ __launch_bounds__(LL_THREADS) void k_loglik_undirected(
             const int y = (sY[r * 4 + (cj >> 5)] >> (cj & 31)) & 1;
             if (y) { sy += 1.0; syd += dd; }
 #pragma unroll
-            for (int k = 0; k < M; ++k) S[k] += log(1.0 + E[k] * e);
+            for (int k = 0; k < M; ++k) P[k] *= 1.0 + E[k] * e;
+            if (++cnt >= nflush) {
+#pragma unroll
+                for (int k = 0; k < M; ++k) { S[k] += log(P[k]); P[k] = 1.0; }
+                cnt = 0;
+            }
         }
+#pragma unroll
+        for (int k = 0; k < M; ++k) S[k] += log(P[k]);
     }
     double acc[2 + M];
     acc[0] = sy; acc[1] = syd;
