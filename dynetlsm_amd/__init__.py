@@ -7,6 +7,10 @@ first use and there is no CPU fallback (``dynetlsm_amd._lib.load`` raises when
 """
 from .engine import Chain, SamplerGrid, EngineError  # noqa
 from . import network_likelihoods  # noqa
+from .lsm import DynamicNetworkLSM  # noqa
+from .hdp_lpcm import DynamicNetworkHDPLPCM  # noqa
+from .case_control import DirectedCaseControlSampler  # noqa
 
 __version__ = '0.1.0'
-__all__ = ['Chain', 'SamplerGrid', 'EngineError', 'network_likelihoods']
+__all__ = ['Chain', 'SamplerGrid', 'EngineError', 'network_likelihoods',
+           'DynamicNetworkLSM', 'DynamicNetworkHDPLPCM', 'DirectedCaseControlSampler']

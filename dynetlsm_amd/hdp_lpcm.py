@@ -1,0 +1,298 @@
+"""DynamicNetworkHDPLPCM with the reference's constructor, ``fit(Y)`` and the
+per-sample traces (hdp_lpcm.py:144-1083), Gibbs loop on one MI355X.
+
+Per iteration (hdp_lpcm.py:823-1069): latent-position sweep with the AR-mixture
+prior, centring, intercept (and radii) MH, label block update -- all kernels of
+the engine -- then the O(TN + TK^2) conjugate / auxiliary updates in numpy
+(``hdp_updates``) and the log-posterior trace.
+
+Out of scope: the post-loop model selection by BIC / expected
+VI, co-occurrence matrices, Geweke diagnostics and forecasting.  After the loop
+this class keeps the raw traces, applies thinning, and exposes the maximum
+log-posterior sample as ``X_, z_, mu_, ...`` (``selection_type`` other than
+'map' raises).  Missing edges are rejected.
+"""
+import numpy as np
+from scipy.stats import dirichlet
+
+from .engine import Chain, SamplerGrid
+from . import hdp_updates as hu
+from . import initialization as init_mod
+from .lsm import DynamicNetworkLSM, _ScalarMetropolis, check_random_state
+
+__all__ = ['DynamicNetworkHDPLPCM']
+
+
+class DynamicNetworkHDPLPCM(object):
+    """Constructor parameters are the reference's (hdp_lpcm.py:385-455) plus
+    ``device``, ``chain_id`` and ``sweep_algo``."""
+
+    def __init__(self, n_features=2, n_components=10, is_directed=False,
+                 selection_type='map', n_iter=5000, tune=2500, tune_interval=100,
+                 burn=2500, thin=None, gamma=1.0, gamma_prior_shape=1.0,
+                 gamma_prior_rate=0.1, alpha_init=1.0, alpha_init_shape=1.,
+                 alpha_init_rate=1., alpha=1.0, kappa=4.0, alpha_kappa_shape=5,
+                 alpha_kappa_rate=0.1, intercept_prior='auto', intercept_variance_prior=2,
+                 mean_variance_prior='auto', a=2.0, b='auto', lambda_prior=0.9,
+                 lambda_variance_prior=0.01, sigma_prior_std=4.0,
+                 mean_variance_prior_std=4.0, step_size_X='auto', step_size_intercept=0.1,
+                 step_size_radii=175000, n_control=None, n_resample_control=100, copy=True,
+                 random_state=None, device=0, chain_id=0, sweep_algo=0):
+        self.n_iter = n_iter
+        self.is_directed = is_directed
+        self.n_features = n_features
+        self.n_components = n_components
+        self.step_size_X = step_size_X
+        self.intercept_prior = intercept_prior
+        self.intercept_variance_prior = intercept_variance_prior
+        self.step_size_intercept = step_size_intercept
+        self.mean_variance_prior = mean_variance_prior
+        self.a = a
+        self.b = b
+        self.alpha_init = alpha_init
+        self.alpha = alpha
+        self.alpha_init_shape = alpha_init_shape
+        self.alpha_init_rate = alpha_init_rate
+        self.gamma = gamma
+        self.gamma_prior_shape = gamma_prior_shape
+        self.gamma_prior_rate = gamma_prior_rate
+        self.kappa = kappa
+        self.alpha_kappa_shape = alpha_kappa_shape
+        self.alpha_kappa_rate = alpha_kappa_rate
+        self.lambda_prior = lambda_prior
+        self.lambda_variance_prior = lambda_variance_prior
+        self.mean_variance_prior_std = mean_variance_prior_std
+        self.sigma_prior_std = sigma_prior_std
+        self.step_size_radii = step_size_radii
+        self.tune = tune
+        self.tune_interval = tune_interval
+        self.burn = burn
+        self.thin = thin
+        self.selection_type = selection_type
+        self.n_control = n_control
+        self.n_resample_control = n_resample_control
+        self.copy = copy
+        self.random_state = random_state
+        self.device = device
+        self.chain_id = chain_id
+        self.sweep_algo = sweep_algo
+
+    @property
+    def n_burn_(self):
+        return (self.burn or 0) + (self.tune or 0)
+
+    # ------------------------------------------------------------------ init
+    def _init_sampler(self, Y, rng, init):
+        """hdp_lpcm.py:48-141 : LSM warm start, longitudinal k-means, weights"""
+        T, N, _ = Y.shape
+        K, D = self.n_components, self.n_features
+        if init is not None and 'X' in init:
+            X = np.array(init['X'], dtype=np.float64)
+            intercept = np.atleast_1d(np.asarray(init['intercept'], dtype=np.float64)).copy()
+            radii = np.array(init['radii'], dtype=np.float64) if self.is_directed else None
+        else:
+            kw = (dict(sigma_sq=0.001, tau_sq='auto', step_size_X=0.0075,
+                       n_control=self.n_control, n_resample_control=self.n_resample_control)
+                  if self.is_directed else dict(sigma_sq=0.1, tau_sq=2.0, step_size_X=0.1))
+            emb = DynamicNetworkLSM(n_iter=500, n_features=D, tune=250, burn=250,
+                                    is_directed=self.is_directed, random_state=rng,
+                                    device=self.device, chain_id=self.chain_id,
+                                    sweep_algo=self.sweep_algo, **kw).fit(Y)
+            X, intercept = emb.X_.copy(), np.array(emb.intercept_, dtype=np.float64)
+            radii = emb.radii_.copy() if self.is_directed else None
+            emb.chain_.close()
+        if init is not None and 'mu' in init:
+            mu = np.array(init['mu'], dtype=np.float64)
+            sigma = np.array(init['sigma'], dtype=np.float64)
+            z = np.array(init['z'], dtype=np.int64)
+        else:
+            mu, sigma, z = init_mod.longitudinal_kmeans(X, n_clusters=K, random_state=rng)
+            z = z.astype(np.int64)
+        weights = np.zeros((T, K, K))
+        weights[0, 0] = np.bincount(z[0], minlength=K) / N
+        lmbda = np.array([self.lambda_prior], dtype=np.float64)
+        beta = rng.dirichlet(np.repeat(self.gamma / K, K))
+        for t in range(1, T):
+            for k in range(K):
+                weights[t, k] = rng.dirichlet(self.alpha * beta + self.kappa * np.eye(K)[k])
+        return X, intercept, mu, sigma, z, beta, weights, lmbda, radii
+
+    # ------------------------------------------------------------------- fit
+    def fit(self, Y, init=None):
+        """Sample the posterior of the HDP-LPCM given ``Y`` (T, N, N).  ``init``
+        may carry starting values ``X, intercept[, radii][, mu, sigma, z]``."""
+        Y = np.array(Y, dtype=np.float64, copy=self.copy, order='C')
+        if Y.ndim != 3 or Y.shape[1] != Y.shape[2]:
+            raise ValueError('Y must have shape (n_time_steps, n_nodes, n_nodes)')
+        if np.any(Y == -1) or np.any(np.isnan(Y)):
+            raise ValueError('missing edges (-1 / nan) are not supported by the '
+                             'MI355X engine: impute them first')
+        if self.selection_type != 'map':
+            raise ValueError("selection_type=%r: only 'map' is available (BIC / VI "
+                             "model selection is outside the accelerated hot path)"
+                             % self.selection_type)
+        if self.n_control is not None and not self.is_directed:
+            raise ValueError('The case-control likelihood currently only '
+                             'supported for directed networks.')
+        T, N, _ = Y.shape
+        K, D = self.n_components, self.n_features
+        rng = check_random_state(self.random_state)
+        self.Y_fit_ = Y
+        if self.burn is not None:
+            self.n_iter += self.burn
+        if self.tune is not None:
+            self.n_iter += self.tune
+        n_total = self.n_iter
+
+        (X, intercept, mu, sigma, z, beta, weights, lmbda, radii) = \
+            self._init_sampler(Y, rng, init)
+        if isinstance(self.step_size_X, str) and self.step_size_X == 'auto':
+            self.step_size_X = 0.01 if self.is_directed else 0.1
+        if isinstance(self.intercept_prior, str) and self.intercept_prior == 'auto':
+            self.intercept_prior = intercept.copy()
+        ip = np.atleast_1d(np.asarray(self.intercept_prior, dtype=np.float64))
+
+        # hyper-priors (hdp_lpcm.py:760-793)
+        if isinstance(self.mean_variance_prior, str) and self.mean_variance_prior == 'auto':
+            mvp = (2 * (1. / N) ** (2. / D) if self.is_directed else (N ** (2. / D)) / 50.)
+        else:
+            mvp = self.mean_variance_prior
+        hp = hu.HDPHyper(K, gamma=self.gamma, alpha_init=self.alpha_init, alpha=self.alpha,
+                         kappa=self.kappa, mean_variance_prior=mvp, a=self.a,
+                         lambda_prior=self.lambda_prior,
+                         lambda_variance_prior=self.lambda_variance_prior,
+                         gamma_prior_shape=self.gamma_prior_shape,
+                         gamma_prior_rate=self.gamma_prior_rate,
+                         alpha_init_shape=self.alpha_init_shape,
+                         alpha_init_rate=self.alpha_init_rate,
+                         alpha_kappa_shape=self.alpha_kappa_shape,
+                         alpha_kappa_rate=self.alpha_kappa_rate)
+        if self.mean_variance_prior_std is not None:
+            hp.a0 = (self.mean_variance_prior_std ** 2 + 2) * 2
+            hp.b0 = (hp.a0 - 2) * mvp * 2
+        hp.b = (self.a + 2) * mvp if (isinstance(self.b, str) and self.b == 'auto') else self.b
+        if self.sigma_prior_std is not None:
+            hp.d0 = (self.sigma_prior_std ** 2 / hp.b) * 2
+            hp.c0 = hp.b * hp.d0
+        self.hyper_ = hp
+
+        # ---- the chain -----------------------------------------------------
+        model = ('undirected' if not self.is_directed else
+                 'case_control' if self.n_control is not None else 'directed')
+        seed = int(rng.randint(0, 2 ** 31 - 1)) | (int(rng.randint(0, 2 ** 31 - 1)) << 31)
+        chain = Chain(T, N, D, model, seed=seed, chain_id=self.chain_id, device=self.device)
+        self.chain_ = chain
+        self.case_control_sampler_ = None
+        if model == 'case_control':
+            from .case_control import DirectedCaseControlSampler
+            self.case_control_sampler_ = DirectedCaseControlSampler(
+                n_control=self.n_control, n_resample=self.n_resample_control,
+                chain=chain).init(Y)
+        else:
+            chain.upload_network(Y)
+        chain.set_positions(X)
+        chain.set_intercepts(intercept)
+        if self.is_directed:
+            chain.set_radii(radii)
+        self.latent_samplers = SamplerGrid(T, N, self.step_size_X, tune=self.tune,
+                                           tune_interval=self.tune_interval)
+        chain.set_samplers(self.latent_samplers)
+        n_ic = 2 if self.is_directed else 1
+        # hdp_lpcm.py:731-747: intercept samplers keep the default tune_interval
+        isamp = [_ScalarMetropolis(self.step_size_intercept, self.tune) for _ in range(n_ic)]
+        rsamp = _ScalarMetropolis(self.step_size_radii, self.tune, dirichlet=True)
+        self.intercept_samplers, self.radii_sampler = isamp, rsamp
+
+        self.Xs_ = np.zeros((n_total, T, N, D))
+        self.intercepts_ = np.zeros((n_total, n_ic))
+        self.mus_ = np.zeros((n_total, K, D))
+        self.sigmas_ = np.zeros((n_total, K))
+        self.zs_ = np.zeros((n_total, T, N), dtype=np.int64)
+        self.betas_ = np.zeros((n_total, K))
+        self.weights_ = np.zeros((n_total, T, K, K))
+        self.lambdas_ = np.zeros((n_total, 1))
+        self.radiis_ = np.zeros((n_total, N)) if self.is_directed else None
+        self.logps_ = np.zeros(n_total)
+
+        def store(it, ll):
+            self.Xs_[it], self.intercepts_[it] = X, intercept
+            self.mus_[it], self.sigmas_[it], self.zs_[it] = mu, sigma, z
+            self.betas_[it], self.weights_[it], self.lambdas_[it] = beta, weights, lmbda
+            if self.is_directed:
+                self.radiis_[it] = radii
+            self.logps_[it] = np.ravel(ll + hu.log_posterior_terms(
+                X, intercept, ip, self.intercept_variance_prior, mu, sigma, z, weights, beta,
+                lmbda, hp, radii=radii))[0]
+
+        chain.set_prior_mixture(mu, sigma, lmbda, z)
+        store(0, chain.loglik_full())
+        var = self.intercept_variance_prior
+        for it in range(1, n_total):
+            if self.case_control_sampler_ is not None:
+                self.case_control_sampler_.resample(it)
+            chain.set_prior_mixture(mu, sigma, lmbda, z)
+            chain.sweep_positions(it, self.sweep_algo)
+            chain.center()
+            # intercepts (sample_coefficients.py:12-88), fused two-candidate passes
+            for k in range(n_ic):
+                prop = intercept.copy()
+                prop[k] = intercept[k] + isamp[k].step_size * rng.randn(1)[0]
+                ll_prop, ll_cur = chain.loglik_full([prop, intercept])
+                ratio = ((ll_prop - (prop[k] - ip[k]) ** 2 / (2 * var)) -
+                         (ll_cur - (intercept[k] - ip[k]) ** 2 / (2 * var)))
+                accepted = int(not (np.log(rng.rand()) >= ratio))
+                ll = ll_cur
+                if accepted:
+                    intercept, ll = prop, ll_prop
+                isamp[k].book(accepted)
+            chain.set_intercepts(intercept)
+            if self.is_directed:
+                x = rng.dirichlet(rsamp.step_size * radii)
+                if np.any(x == 0.):
+                    x += 1e-5
+                    x /= np.sum(x)
+                ll_cur, ll_prop = chain.loglik_full_radii(x)
+                ratio = (ll_prop - ll_cur +
+                         dirichlet.logpdf(radii, rsamp.step_size * x) -
+                         dirichlet.logpdf(x, rsamp.step_size * radii))
+                accepted = int(not (np.log(rng.rand()) >= ratio))
+                ll = ll_cur
+                if accepted:
+                    radii, ll = x, ll_prop
+                    chain.set_radii(radii)
+                rsamp.book(accepted)
+            # label block update on the device (sample_labels.py:134-190)
+            z, n, nk = chain.sample_labels(it, weights)
+            X = chain.get_positions()
+            mu, sigma, weights = mu.copy(), sigma.copy(), weights.copy()
+            beta, lmbda = hu.gibbs_updates(X, z, n, nk, mu, sigma, beta, weights, lmbda, hp,
+                                           rng)
+            store(it, ll)
+        chain.get_samplers(self.latent_samplers)
+        self.gamma, self.alpha_init, self.alpha, self.kappa = (hp.gamma, hp.alpha_init,
+                                                               hp.alpha, hp.kappa)
+        self.mean_variance_prior_, self.b_ = hp.mean_variance_prior, hp.b
+
+        # thinning (hdp_lpcm.py:1072-1083)
+        if self.thin is not None:
+            for name in ('Xs_', 'intercepts_', 'mus_', 'sigmas_', 'zs_', 'betas_',
+                         'weights_', 'lambdas_', 'logps_'):
+                setattr(self, name, getattr(self, name)[::self.thin])
+            if self.is_directed:
+                self.radiis_ = self.radiis_[::self.thin]
+        # maximum log-posterior sample after burn-in
+        n_burn = min(self.n_burn_ // (self.thin or 1), self.logps_.shape[0] - 1)
+        best = n_burn + int(np.argmax(self.logps_[n_burn:]))
+        self.selected_id_ = best
+        self.logp_ = self.logps_[best]
+        self.X_, self.intercept_ = self.Xs_[best], self.intercepts_[best]
+        self.mu_, self.sigma_, self.z_ = self.mus_[best], self.sigmas_[best], self.zs_[best]
+        self.beta_, self.lambda_ = self.betas_[best], self.lambdas_[best]
+        self.init_weights_ = self.weights_[best][0, 0]
+        self.trans_weights_ = self.weights_[best][1:]
+        if self.is_directed:
+            self.radii_ = self.radiis_[best]
+        self.X_mean_ = self.Xs_[n_burn:].mean(axis=0)
+        self.lambda_mean_ = self.lambdas_[n_burn:].mean(axis=0)
+        self.intercepts_mean_ = self.intercepts_[n_burn:].mean(axis=0)
+        return self

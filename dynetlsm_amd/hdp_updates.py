@@ -1,0 +1,247 @@
+"""Host side of one DynamicNetworkHDPLPCM Gibbs iteration: the O(TN + TK^2)
+conjugate / auxiliary-variable updates that follow the latent-position sweep and
+the label block update (hdp_lpcm.py:880-1023) and the log-posterior trace
+(hdp_lpcm.py:1188-1280).
+
+These are not kernels ("host-side, restated in the build's own
+Python"): small numpy updates driven by a numpy ``RandomState``.  They follow
+the reference's draw order call for call, which tests/test_hdp_host_updates.py
+pins against a trace recorded from the reference.
+"""
+import numpy as np
+from scipy.stats import truncnorm, dirichlet
+
+SMALL_EPS = np.finfo('float64').tiny
+
+__all__ = ['HDPHyper', 'sample_tables', 'sample_mbar', 'sample_concentration_param',
+           'sample_dirichlet', 'gibbs_updates', 'log_posterior_terms']
+
+
+class HDPHyper(object):
+    """Hyper-parameters that the loop itself resamples (hdp_lpcm.py:957-1023)
+    plus the fixed hyper-priors set up before it (:760-793)."""
+
+    def __init__(self, n_components, gamma=1.0, alpha_init=1.0, alpha=1.0, kappa=4.0,
+                 mean_variance_prior=2.0, b=1.0, a=2.0, a0=None, b0=None, c0=None,
+                 d0=None, lambda_prior=0.9, lambda_variance_prior=0.01,
+                 gamma_prior_shape=1.0, gamma_prior_rate=0.1, alpha_init_shape=1.0,
+                 alpha_init_rate=1.0, alpha_kappa_shape=5, alpha_kappa_rate=0.1):
+        self.n_components = n_components
+        self.gamma, self.alpha_init, self.alpha, self.kappa = gamma, alpha_init, alpha, kappa
+        self.mean_variance_prior, self.b, self.a = mean_variance_prior, b, a
+        self.a0, self.b0, self.c0, self.d0 = a0, b0, c0, d0
+        self.lambda_prior, self.lambda_variance_prior = lambda_prior, lambda_variance_prior
+        self.gamma_prior_shape, self.gamma_prior_rate = gamma_prior_shape, gamma_prior_rate
+        self.alpha_init_shape, self.alpha_init_rate = alpha_init_shape, alpha_init_rate
+        self.alpha_kappa_shape, self.alpha_kappa_rate = alpha_kappa_shape, alpha_kappa_rate
+
+
+def sample_dirichlet(alphas, rng):
+    """distributions.py:85-92"""
+    if np.any(alphas <= 0.):
+        alphas = np.clip(alphas, a_min=SMALL_EPS, a_max=None)
+    return rng.dirichlet(alphas)
+
+
+def dirichlet_logpdf(x, alphas):
+    """distributions.py:95-100"""
+    if np.any(alphas <= 0.):
+        alphas = np.clip(alphas, a_min=SMALL_EPS, a_max=None)
+    if np.any(x <= 0):
+        x = np.clip(x, a_min=SMALL_EPS, a_max=None)
+    return dirichlet.logpdf(x, alphas)
+
+
+def truncated_normal(mean, var, rng, lower=0, upper=1):
+    """distributions.py:68-73"""
+    std = np.sqrt(var)
+    a = (lower - mean) / std
+    b = (upper - mean) / std
+    return truncnorm.rvs(a, b, size=1, loc=mean, scale=std, random_state=rng)
+
+
+def truncated_normal_logpdf(x, mean, var, lower=0, upper=1):
+    """distributions.py:76-80"""
+    std = np.sqrt(var)
+    a = (lower - mean) / std
+    b = (upper - mean) / std
+    return truncnorm.logpdf(x, a, b, loc=mean, scale=std)
+
+
+def sample_tables(n, beta, alpha_init, alpha, kappa, rng):
+    """sample_auxillary.py:6-28 : number of tables serving each dish"""
+    T, K, _ = n.shape
+    m = np.zeros((T, K, K), dtype=np.int64)
+    probas = alpha_init * beta
+    for k in range(K):
+        x = rng.binomial(1, probas[k] / (probas[k] + np.arange(n[0, 0, k])))
+        m[0, 0, k] = np.sum(x)
+    probas = alpha * beta + kappa * np.eye(K)
+    for t in range(1, T):
+        for j in range(K):
+            for k in range(K):
+                x = rng.binomial(1, probas[j, k] / (probas[j, k] + np.arange(n[t, j, k])))
+                m[t, j, k] = np.sum(x)
+    return m
+
+
+def sample_mbar(m, beta, kappa, alpha, rng):
+    """sample_auxillary.py:31-50 : override variables of the sticky HDP"""
+    T, K, _ = m.shape
+    w = np.zeros((T - 1, K), dtype=np.float64)
+    rho = kappa / (alpha + kappa)
+    for t in range(T - 1):
+        for j in range(K):
+            w[t, j] = rng.binomial(m[t + 1, j, j], rho / (rho + beta[j] * (1 - rho)))
+    m_bar = np.zeros((T - 1, K, K), dtype=np.float64)
+    for t in range(T - 1):
+        m_bar[t] = m[t + 1] - np.diag(w[t])
+    return np.sum(m_bar, axis=(0, 1)) + m[0, 0], w
+
+
+def sample_concentration_param(alpha, n_clusters, n_samples, prior_shape, prior_rate, rng):
+    """sample_concentration.py:6-21 (Escobar and West, 1995)"""
+    eta = rng.beta(alpha + 1, n_samples)
+    m_shape = prior_shape + n_clusters - 1
+    m_scale = prior_rate - np.log(eta)
+    log_odds = (m_shape / m_scale) * (1 / n_samples)
+    mix_indicator = rng.binomial(1, log_odds / (1 + log_odds))
+    m_shape = m_shape + 1 if mix_indicator else m_shape
+    return rng.gamma(shape=m_shape, scale=1. / m_scale)
+
+
+def gibbs_updates(X, z, n, nk, mu, sigma, beta, weights, lmbda, hp, rng):
+    """hdp_lpcm.py:880-1023.  ``n`` (T,K,K), ``nk`` (T,K) are the label
+    update's counts; mu, sigma, weights are updated in place; returns
+    (beta, lmbda) and mutates ``hp`` (gamma, alpha_init, alpha, kappa,
+    mean_variance_prior, b)."""
+    T, N, D = X.shape
+    K = hp.n_components
+    m = sample_tables(n, beta, hp.alpha_init, hp.alpha, hp.kappa, rng)
+    m_bar, w = sample_mbar(m, beta, hp.kappa, hp.alpha, rng)
+    # global transition distribution (:887)
+    beta = rng.dirichlet((hp.gamma / K) + m_bar)
+    # initial distribution (:890) and transition distributions (:894-898)
+    weights[0, 0] = sample_dirichlet(hp.alpha_init * beta + nk[0], rng)
+    probas = hp.alpha * beta + hp.kappa * np.eye(K)
+    for t in range(1, T):
+        for k in range(K):
+            weights[t, k] = sample_dirichlet(probas[k] + n[t, k], rng)
+    # cluster means (:901-921)
+    for k in range(K):
+        pk = 1 / hp.mean_variance_prior
+        mk = np.zeros(D)
+        for t in range(T):
+            if nk[t, k] > 0:
+                mask = z[t] == k
+                if t == 0:
+                    pk = pk + nk[0, k] / sigma[k]
+                    mk = mk + (1 / sigma[k]) * np.sum(X[t, mask], axis=0)
+                else:
+                    pk = pk + (lmbda ** 2 / sigma[k]) * nk[t, k]
+                    mk = mk + (lmbda / sigma[k]) * np.sum(
+                        X[t, mask] - (1 - lmbda) * X[t - 1, mask], axis=0)
+        pk = 1 / pk
+        mk = mk * pk
+        mu[k] = rng.multivariate_normal(mean=mk, cov=pk * np.eye(D))
+    # cluster variances (:924-938)
+    for k in range(K):
+        ak = 0.5 * (np.sum(nk[:, k]) * D + hp.a)
+        bk = 0.5 * hp.b
+        for t in range(T):
+            if nk[t, k] > 0:
+                mask = z[t] == k
+                if t == 0:
+                    bk = bk + 0.5 * np.sum((X[t, mask] - mu[k]) ** 2)
+                else:
+                    bk = bk + 0.5 * np.sum((X[t, mask] - (1 - lmbda) * X[t - 1, mask] -
+                                            lmbda * mu[k]) ** 2)
+        sigma[k] = 1. / rng.gamma(shape=ak, scale=1. / bk)
+    # blending coefficient (:941-954)
+    ml = 0.0
+    sl = 1.0 / hp.lambda_variance_prior
+    for t in range(1, T):
+        ml_diff = (mu[z[t]] - X[t - 1]) / sigma[z[t]].reshape(-1, 1)
+        ml += np.sum(ml_diff * (X[t] - X[t - 1]))
+        ml_diff = (mu[z[t]] - X[t - 1]) / np.sqrt(sigma[z[t]].reshape(-1, 1))
+        sl += np.sum(ml_diff ** 2)
+    sl = 1. / sl
+    ml += hp.lambda_prior / hp.lambda_variance_prior
+    ml *= sl
+    lmbda = truncated_normal(mean=ml, var=sl, rng=rng)
+    # hyper-parameters (:957-972)
+    if hp.a0 is not None:
+        b = 0.5 * hp.b0
+        for k in range(K):
+            b += 0.5 * np.sum(mu[k] ** 2)
+        a = 0.5 * (hp.a0 + K)
+        hp.mean_variance_prior = 1 / rng.gamma(shape=a, scale=1. / b, size=1)
+    if hp.c0 is not None:
+        scale = 0.5 * hp.d0
+        for k in range(K):
+            scale += 0.5 * (1. / sigma[k])
+        shape = 0.5 * (hp.c0 + K * hp.a)
+        hp.b = rng.gamma(shape=shape, scale=1. / scale)
+    # concentration parameters (:977-1023)
+    hp.gamma = sample_concentration_param(hp.gamma, np.sum(m_bar > 0), np.sum(m_bar),
+                                          hp.gamma_prior_shape, hp.gamma_prior_rate, rng)
+    hp.alpha_init = sample_concentration_param(hp.alpha_init, np.sum(m[0, 0]), N,
+                                               hp.alpha_init_shape, hp.alpha_init_rate, rng)
+    alpha_kappa = hp.alpha + hp.kappa
+    n_dot = np.sum(n[1:], axis=2)
+    valid = n_dot > 0
+    valid_n_dot = n_dot[valid]
+    s = rng.binomial(1, p=(valid_n_dot / (valid_n_dot + alpha_kappa)))
+    r = rng.beta(alpha_kappa + 1, valid_n_dot)
+    shape = hp.alpha_kappa_shape + np.sum(m[1:], axis=2)[valid].sum() - np.sum(s)
+    rate = hp.alpha_kappa_rate - np.sum(np.log(r))
+    alpha_kappa = rng.gamma(shape=shape, scale=1. / rate)
+    rho_a, rho_b = 8, 2
+    n_success = np.sum(w)
+    rho = rng.beta(a=rho_a + n_success, b=np.sum(m[1:]) - n_success + rho_b)
+    hp.kappa = alpha_kappa * rho
+    hp.alpha = alpha_kappa - hp.kappa
+    return beta, lmbda
+
+
+def log_posterior_terms(X, intercept, intercept_prior, intercept_variance_prior, mu,
+                        sigma, z, weights, beta, lmbda, hp, radii=None):
+    """Everything in DynamicNetworkHDPLPCM.logp (hdp_lpcm.py:1188-1280) except
+    the network log-likelihood, which the device supplies."""
+    T, N, D = X.shape
+    K = hp.n_components
+    lp = dirichlet_logpdf(beta, np.repeat(hp.gamma / K, K))
+    lp += dirichlet_logpdf(weights[0, 0], hp.alpha_init * beta)
+    deltas = hp.kappa * np.eye(K)
+    for t in range(1, T):
+        for k in range(K):
+            lp += dirichlet_logpdf(weights[t, k], hp.alpha * beta + deltas[k])
+    for i in range(N):
+        lp += np.log(weights[0, 0, z[0, i]])
+        for t in range(1, T):
+            lp += np.log(weights[t, z[t - 1, i], z[t, i]])
+    diff = intercept - intercept_prior
+    if radii is not None:
+        lp -= np.sum(0.5 * (diff * diff) / intercept_variance_prior)
+    else:
+        lp = lp - 0.5 * (diff * diff) / intercept_variance_prior
+    for t in range(T):
+        if t == 0:
+            diff = X[t] - mu[z[t]]
+        else:
+            diff = X[t] - (1 - lmbda) * X[t - 1] - lmbda * mu[z[t]]
+        lp = lp + np.sum(-0.5 * np.log(sigma[z[t]]) -
+                         0.5 * np.sum(diff * diff, axis=1) / sigma[z[t]])
+    for k in range(K):
+        lp = lp - 0.5 * np.sum(mu[k] ** 2) / hp.mean_variance_prior
+    lp = lp + np.sum(-(0.5 * hp.a + 1) * np.log(sigma[z]) - (0.5 * hp.b / sigma[z]))
+    lp = lp + truncated_normal_logpdf(lmbda, mean=hp.lambda_prior,
+                                      var=hp.lambda_variance_prior)
+    if radii is not None:
+        lp = lp + dirichlet.logpdf(radii, np.ones(N))
+    if hp.a0 is not None:
+        lp = lp + (-(0.5 * hp.a0 + 1) * np.log(hp.mean_variance_prior) -
+                   (0.5 * hp.b0 / hp.mean_variance_prior))
+    if hp.c0 is not None:
+        lp = lp + (hp.c0 - 1) * np.log(hp.b) - hp.d0 * hp.b
+    return lp

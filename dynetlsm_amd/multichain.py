@@ -1,0 +1,117 @@
+"""Independent MCMC chains sharded one per GPU.
+
+Chains never talk inside an iteration.  Collectives (RCCL over xGMI when the
+backend is ``nccl``; ``gloo`` on CPU for tests) appear only at the edges:
+
+  * ``broadcast_network``  rank 0's network -> every rank, bit-for-byte: the
+    float64 adjacency tensor is sent as uint8 (1/8 of the bytes; 40 MB at
+    T=10, N=2000) and widened locally;
+  * ``gather_arrays``      per-chain summaries / traces -> every rank
+    (all_gather of equally shaped float64 tensors).
+
+Launch with ``python -m torch.distributed.run --nproc-per-node N script.py``;
+rank r drives GPU LOCAL_RANK with Philox chain id r.
+"""
+import os
+
+import numpy as np
+
+__all__ = ['ChainGroup', 'init_chain_group']
+
+
+class ChainGroup(object):
+    """Rank / device bookkeeping of one process of the chain group."""
+
+    def __init__(self, rank, world, local_rank, backend, dist=None, torch=None):
+        self.rank, self.world, self.local_rank = rank, world, local_rank
+        self.backend = backend
+        self._dist, self._torch = dist, torch
+
+    @property
+    def chain_id(self):
+        return self.rank
+
+    @property
+    def device(self):
+        return self.local_rank
+
+    def _tensor_device(self):
+        t = self._torch
+        return t.device('cuda', self.local_rank) if self.backend == 'nccl' else t.device('cpu')
+
+    def barrier(self):
+        if self.world > 1:
+            self._dist.barrier()
+
+    def broadcast_network(self, Y, shape=None, src=0):
+        """Y (T, N, N) float64 on ``src`` (None elsewhere) -> float64 on all."""
+        if self.world == 1:
+            return np.ascontiguousarray(Y, dtype=np.float64)
+        t = self._torch
+        dev = self._tensor_device()
+        hdr = t.zeros(3, dtype=t.int64, device=dev)
+        if self.rank == src:
+            Y = np.ascontiguousarray(Y, dtype=np.float64)
+            if not np.all((Y == 0) | (Y == 1)):
+                raise ValueError('network entries must be 0 / 1')
+            hdr = t.tensor(Y.shape, dtype=t.int64, device=dev)
+        self._dist.broadcast(hdr, src)
+        shp = tuple(int(v) for v in hdr.cpu())
+        if self.rank == src:
+            buf = t.from_numpy(Y.astype(np.uint8)).to(dev)
+        else:
+            buf = t.empty(shp, dtype=t.uint8, device=dev)
+        self._dist.broadcast(buf, src)
+        return buf.cpu().numpy().astype(np.float64)
+
+    def broadcast_array(self, a, src=0):
+        """small float64 array (same shape known on every rank)"""
+        if self.world == 1:
+            return np.asarray(a, dtype=np.float64)
+        t = self._torch
+        buf = t.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(self._tensor_device())
+        self._dist.broadcast(buf, src)
+        return buf.cpu().numpy()
+
+    def gather_arrays(self, a):
+        """list (one per rank) of equally shaped float64 arrays, on every rank"""
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        if self.world == 1:
+            return [a]
+        t = self._torch
+        mine = t.from_numpy(a).to(self._tensor_device())
+        out = [t.empty_like(mine) for _ in range(self.world)]
+        self._dist.all_gather(out, mine)
+        return [o.cpu().numpy() for o in out]
+
+    def max_over_ranks(self, x):
+        if self.world == 1:
+            return float(x)
+        t = self._torch
+        v = t.tensor([float(x)], dtype=t.float64, device=self._tensor_device())
+        self._dist.all_reduce(v, op=self._dist.ReduceOp.MAX)
+        return float(v.cpu()[0])
+
+    def close(self):
+        if self.world > 1 and self._dist.is_initialized():
+            self._dist.destroy_process_group()
+
+
+def init_chain_group(backend=None):
+    """Join the process group described by RANK / WORLD_SIZE / LOCAL_RANK /
+    MASTER_ADDR / MASTER_PORT (torch.distributed.run sets them)."""
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    import torch
+    import torch.distributed as dist
+    if backend is None:
+        backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+    if backend == 'nccl':
+        torch.cuda.set_device(local_rank)
+    if world > 1:
+        kw = {}
+        if backend == 'nccl':
+            kw['device_id'] = torch.device('cuda', local_rank)
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    return ChainGroup(rank, world, local_rank, backend, dist, torch)

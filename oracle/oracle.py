@@ -211,7 +211,7 @@ def compute_gaussian_likelihood(X, mu, sigma, lmbda, normalize=True):
     T, D = X.shape
     K = sigma.shape[0]
     out = np.zeros((T, K))
-    lib().orc_gaussian_likelihood(Xp, D, mp, sp, float(lmbda), T, D, K,
+    lib().orc_gaussian_likelihood(Xp, D, mp, sp, float(np.asarray(lmbda).ravel()[0]), T, D, K,
                                   int(normalize), out.ctypes.data_as(c_double_p))
     return out
 

@@ -337,10 +337,86 @@ def gen_chain_envelopes(ref, Yu):
     print('monks_envelopes.npz')
 
 
+def gen_hdp_trace(ref):
+    """DynamicNetworkHDPLPCM._fit (hdp_lpcm.py:813-1069): state right after the
+    init pipeline, the numpy RNG state at loop entry, every hyper-parameter, and
+    the raw per-iteration traces (snapshotted before the post-loop model
+    selection rewrites them)."""
+    import dynetlsm.hdp_lpcm as hm
+    hm.geweke_diag = lambda *a, **k: np.nan
+    rng0 = np.random.RandomState(5)
+    T, N, D, K = 3, 24, 2, 4
+    centers = np.array([[-1.5, 0.0], [1.5, 0.0], [0.0, 2.0]])
+    lab = rng0.randint(0, 3, size=N)
+    X = np.zeros((T, N, D))
+    X[0] = centers[lab] + 0.3 * rng0.randn(N, D)
+    for t in range(1, T):
+        X[t] = 0.8 * centers[lab] + 0.2 * X[t - 1] + 0.2 * rng0.randn(N, D)
+    Y = np.zeros((T, N, N))
+    for t in range(T):
+        d = np.sqrt(((X[t][:, None] - X[t][None]) ** 2).sum(-1))
+        A = (rng0.rand(N, N) < 1 / (1 + np.exp(-(1.0 - d)))).astype(np.float64)
+        A = np.triu(A, 1)
+        Y[t] = A + A.T
+    cap = {}
+    orig_fit = hm.DynamicNetworkHDPLPCM._fit
+    orig_bic = hm.select_bic
+
+    def spy_fit(self, Y_, random_state):
+        st = random_state.get_state()
+        cap['rng'] = st
+        cap['hyper0'] = dict(
+            gamma=self.gamma, alpha_init=self.alpha_init, alpha=self.alpha,
+            kappa=self.kappa, mean_variance_prior=self.mean_variance_prior_,
+            b=self.b_, a0=self.a0_, b0=self.b0_, c0=self.c0_, d0=self.d0_,
+            a=self.a, step_size_X=self.step_size_X,
+            intercept_prior=np.asarray(self.intercept_prior, dtype=np.float64).copy())
+        return orig_fit(self, Y_, random_state)
+
+    def spy_bic(model):
+        cap['traces'] = dict(
+            Xs=model.Xs_.copy(), intercepts=model.intercepts_.copy(),
+            mus=model.mus_.copy(), sigmas=model.sigmas_.copy(), zs=model.zs_.copy(),
+            betas=model.betas_.copy(), weights=model.weights_.copy(),
+            lambdas=model.lambdas_.copy(), logps=model.logps_.copy())
+        cap['hyper1'] = dict(gamma=model.gamma, alpha_init=model.alpha_init,
+                             alpha=model.alpha, kappa=model.kappa,
+                             mean_variance_prior=model.mean_variance_prior_, b=model.b_)
+        return orig_bic(model)
+
+    hm.DynamicNetworkHDPLPCM._fit = spy_fit
+    hm.select_bic = spy_bic
+    try:
+        m = ref.DynamicNetworkHDPLPCM(n_iter=4, tune=3, burn=2, tune_interval=2,
+                                      n_components=K, selection_type='map',
+                                      random_state=np.random.RandomState(9)).fit(Y)
+    finally:
+        hm.DynamicNetworkHDPLPCM._fit = orig_fit
+        hm.select_bic = orig_bic
+    out = {'Y': Y}
+    st = cap['rng']
+    out.update(rng_keys=st[1], rng_pos=np.int64(st[2]), rng_has_gauss=np.int64(st[3]),
+               rng_cached=np.float64(st[4]))
+    for k, v in cap['hyper0'].items():
+        out['h0_' + k] = np.asarray(v, dtype=np.float64)
+    for k, v in cap['hyper1'].items():
+        out['h1_' + k] = np.asarray(v, dtype=np.float64)
+    for k, v in cap['traces'].items():
+        out['tr_' + k] = v
+    sst = sampler_state(m.latent_samplers)
+    out.update(step=sst[0], nacc=sst[1], nsteps=sst[2], until=sst[3])
+    np.savez_compressed(os.path.join(HERE, 'hdp_trace.npz'), **out)
+    print('hdp_trace.npz: %d arrays, %d iterations' % (len(out), cap['traces']['Xs'].shape[0]))
+
+
 if __name__ == '__main__':
     ref = import_reference()
+    if len(sys.argv) > 1 and sys.argv[1] == 'hdp':
+        gen_hdp_trace(ref)
+        sys.exit(0)
     gen_likelihoods(ref)
     gen_sweeps(ref)
     Yd, Yu = gen_monks(ref)
     gen_fit_traces(ref, Yd, Yu)
     gen_chain_envelopes(ref, Yu)
+    gen_hdp_trace(ref)

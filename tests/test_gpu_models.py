@@ -1,0 +1,123 @@
+"""The estimator facades on an MI355X: the reference's own smoke tests
+(dynetlsm/tests/test_lsm.py, test_hdp_lcpm.py: shapes after a short fit) and
+chain-level parity with the reference on Sampson's monks (BASELINE.json
+configs[0]): posterior summaries within Monte-Carlo error."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def eng():
+    import dynetlsm_amd
+    return dynetlsm_amd
+
+
+def _splitting_network(n_nodes=50, n_time_steps=2, seed=42, directed=False):
+    """two groups at t=0, one of which splits afterwards"""
+    rng = np.random.RandomState(seed)
+    lab = rng.randint(0, 2, size=n_nodes)
+    X = np.zeros((n_time_steps, n_nodes, 2))
+    c0 = np.array([[-1.5, 0.0], [1.5, 0.0]])
+    X[0] = c0[lab] + 0.4 * rng.randn(n_nodes, 2)
+    for t in range(1, n_time_steps):
+        X[t] = X[t - 1] + 0.1 * rng.randn(n_nodes, 2)
+    Y = np.zeros((n_time_steps, n_nodes, n_nodes))
+    for t in range(n_time_steps):
+        d = np.sqrt(((X[t][:, None] - X[t][None]) ** 2).sum(-1))
+        A = (rng.rand(n_nodes, n_nodes) < 1 / (1 + np.exp(-(1.0 - d)))).astype(float)
+        np.fill_diagonal(A, 0)
+        if not directed:
+            A = np.triu(A, 1); A = A + A.T
+        Y[t] = A
+    return Y, np.tile(lab, (n_time_steps, 1))
+
+
+def test_lsm_smoke(eng):
+    Y, _ = _splitting_network()
+    lsm = eng.DynamicNetworkLSM(n_iter=250, burn=250, tune=250, n_features=2,
+                                random_state=123)
+    lsm.fit(Y)
+    assert lsm.X_.shape == (2, 50, 2)
+    assert lsm.Xs_.shape == (750, 2, 50, 2) and lsm.intercepts_.shape == (750, 1)
+    assert np.isfinite(lsm.logps_).all()
+    assert lsm.logps_[250:].mean() > lsm.logps_[0] - 50      # moved to a mode
+    acc = lsm.latent_samplers.n_steps
+    assert (acc == 749).all()
+    assert lsm.probas_.shape == (2, 50, 50)
+
+
+def test_hdp_lpcm_smoke(eng):
+    Y, _ = _splitting_network()
+    m = eng.DynamicNetworkHDPLPCM(n_iter=100, burn=50, tune=50, n_features=2,
+                                  n_components=10, random_state=123)
+    m.fit(Y)
+    assert m.X_.shape == (2, 50, 2)
+    assert m.z_.shape == (2, 50)
+    assert np.isfinite(m.logps_).all()
+    assert m.zs_.min() >= 0 and m.zs_.max() < 10
+    assert (m.sigmas_[1:] > 0).all()
+    assert np.allclose(m.weights_[-1].sum(-1)[1:], 1.0)
+
+
+@pytest.mark.parametrize('n_control', [None, 10])
+def test_lsm_directed_smoke(eng, n_control):
+    Y, _ = _splitting_network(n_nodes=40, n_time_steps=3, directed=True)
+    lsm = eng.DynamicNetworkLSM(n_iter=60, burn=20, tune=20, is_directed=True,
+                                n_control=n_control, n_resample_control=25,
+                                random_state=5, tau_sq='auto', sigma_sq=0.001,
+                                step_size_X=0.0075)
+    lsm.fit(Y)
+    assert lsm.X_.shape == (3, 40, 2) and lsm.radii_.shape == (40,)
+    assert np.isfinite(lsm.logps_).all()
+    np.testing.assert_allclose(lsm.radiis_.sum(axis=1), 1.0, rtol=1e-9)
+    assert lsm.intercept_samplers[0].n_steps == 99
+
+
+def test_hdp_directed_smoke(eng):
+    Y, _ = _splitting_network(n_nodes=30, n_time_steps=2, directed=True)
+    m = eng.DynamicNetworkHDPLPCM(n_iter=30, burn=10, tune=10, is_directed=True,
+                                  n_components=4, random_state=1)
+    m.fit(Y)
+    assert m.X_.shape == (2, 30, 2) and m.radii_.shape == (30,)
+    assert np.isfinite(m.logps_).all()
+
+
+def test_missing_edges_and_bad_shapes_are_rejected(eng):
+    Y, _ = _splitting_network(n_nodes=12)
+    Y[0, 1, 2] = -1
+    with pytest.raises(ValueError):
+        eng.DynamicNetworkLSM(n_iter=5, tune=None, burn=None).fit(Y)
+    with pytest.raises(ValueError):
+        eng.DynamicNetworkLSM(n_iter=5, tune=None, burn=None).fit(np.zeros((2, 5, 4)))
+    with pytest.raises(ValueError):
+        eng.DynamicNetworkLSM(n_iter=5, n_control=3).fit(np.zeros((2, 5, 5)))
+
+
+def test_monks_posterior_within_mc_error_of_reference(eng):
+    """BASELINE.json configs[0]: DynamicNetworkLSM on Sampson's monks.  The
+    reference's per-seed posterior summaries (tests/golden/monks_envelopes.npz:
+    8 seeds x 500 kept iterations) give the between-chain spread; the engine's
+    chains (different RNG, different scan order) must land inside it."""
+    env = load_golden('monks_envelopes.npz')
+    cols = list(env['columns'])
+    ref = env['summaries']
+    Y = load_golden('monks.npz')['Y_undirected']
+    got = []
+    for seed in range(6):
+        m = eng.DynamicNetworkLSM(n_iter=500, tune=250, burn=250, random_state=seed,
+                                  chain_id=seed).fit(Y)
+        keep = slice(500, None)
+        d = np.sqrt(((m.Xs_[keep, :, :, None, :] - m.Xs_[keep, :, None, :, :]) ** 2).sum(-1))
+        got.append([m.intercepts_[keep, 0].mean(), m.intercepts_[keep, 0].std(),
+                    m.logps_[keep].mean(), m.logps_[keep].std(), d.mean()])
+    got = np.array(got)
+    for name in ('intercept_mean', 'mean_pairwise_distance', 'intercept_sd', 'logp_sd'):
+        k = cols.index(name)
+        mu_r, sd_r = ref[:, k].mean(), ref[:, k].std(ddof=1)
+        mu_g, sd_g = got[:, k].mean(), got[:, k].std(ddof=1)
+        se = np.sqrt(sd_r ** 2 / ref.shape[0] + sd_g ** 2 / got.shape[0])
+        assert abs(mu_g - mu_r) < 4 * se + 0.02 * abs(mu_r), (name, mu_g, mu_r, se)

@@ -1,0 +1,71 @@
+"""Pins the host-side part of the HDP-LPCM iteration (dynetlsm_amd.hdp_updates:
+conjugate / auxiliary-variable updates and the log-posterior) against a trace
+recorded from the reference's DynamicNetworkHDPLPCM._fit.  CPU only.
+
+The loop below replays hdp_lpcm.py:823-1069 in the reference's order with its
+MT19937 stream: sweep / labels / log-likelihood come from the (reference-pinned)
+oracle, everything else is the product's host code under test."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from oracle import oracle as orc
+from dynetlsm_amd import hdp_updates as hu
+
+
+@pytest.fixture(scope='module')
+def g():
+    return load_golden('hdp_trace.npz')
+
+
+def test_hdp_host_updates_reproduce_reference_fit(g):
+    Y = g['Y']
+    Xs, ics = g['tr_Xs'], g['tr_intercepts']
+    mus, sigmas, zs = g['tr_mus'], g['tr_sigmas'], g['tr_zs']
+    betas, weights, lambdas, logps = (g['tr_betas'], g['tr_weights'], g['tr_lambdas'],
+                                      g['tr_logps'])
+    n_total, T, N, D = Xs.shape
+    K = sigmas.shape[1]
+    tune, tune_interval = 3, 2
+    rng = np.random.RandomState(0)
+    rng.set_state(('MT19937', g['rng_keys'], int(g['rng_pos']), int(g['rng_has_gauss']),
+                   float(g['rng_cached'])))
+    hp = hu.HDPHyper(K, gamma=float(g['h0_gamma']), alpha_init=float(g['h0_alpha_init']),
+                     alpha=float(g['h0_alpha']), kappa=float(g['h0_kappa']),
+                     mean_variance_prior=float(g['h0_mean_variance_prior']),
+                     b=float(g['h0_b']), a=float(g['h0_a']), a0=float(g['h0_a0']),
+                     b0=float(g['h0_b0']), c0=float(g['h0_c0']), d0=float(g['h0_d0']))
+    intercept_prior = g['h0_intercept_prior']
+    grid = orc.SamplerGrid(T, N, float(g['h0_step_size_X']), tune=tune,
+                           tune_interval=tune_interval)
+    isamp = orc.ScalarMetropolis(0.1, tune, 100)            # hdp_lpcm.py:740-742
+    for it in range(1, n_total):
+        X = Xs[it - 1].copy(); ic = ics[it - 1].copy(); z = zs[it - 1].copy()
+        mu = mus[it - 1].copy(); sigma = sigmas[it - 1].copy()
+        w = weights[it - 1].copy(); beta = betas[it - 1].copy()
+        lmbda = lambdas[it - 1].copy()
+        st = orc.ChainState(X, grid, Y=Y, intercept=ic, mu=mu, sigma=sigma, lmbda=lmbda,
+                            z=z)
+        X = orc.center(st.sweep_py(orc.MTDraws(rng), order='reference').copy())
+
+        def lp(x):
+            return (orc.dynamic_network_loglikelihood_undirected(Y, X, x[0]) -
+                    (x[0] - intercept_prior[0]) ** 2 / (2 * 2))
+        ic = isamp.step_rw(ic, lp, rng)
+        z, n, nk, _ = orc.sample_labels_block_mt(X, mu, sigma, lmbda, w, rng)
+        beta, lmbda = hu.gibbs_updates(X, z, n, nk, mu, sigma, beta, w, lmbda, hp, rng)
+        np.testing.assert_allclose(X, Xs[it], atol=1e-9)
+        np.testing.assert_allclose(ic, ics[it], atol=1e-10)
+        np.testing.assert_array_equal(z, zs[it])
+        np.testing.assert_allclose(beta, betas[it], rtol=1e-10)
+        np.testing.assert_allclose(w, weights[it], rtol=1e-9, atol=1e-300)
+        np.testing.assert_allclose(mu, mus[it], rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(sigma, sigmas[it], rtol=1e-9)
+        np.testing.assert_allclose(lmbda, lambdas[it], rtol=1e-10)
+        ll = orc.dynamic_network_loglikelihood_undirected(Y, X, ic[0])
+        lp_it = ll + hu.log_posterior_terms(X, ic, intercept_prior, 2, mu, sigma, z, w,
+                                            beta, lmbda, hp)
+        np.testing.assert_allclose(np.ravel(lp_it)[0], logps[it], rtol=1e-9)
+    for name in ('gamma', 'alpha_init', 'alpha', 'kappa', 'mean_variance_prior', 'b'):
+        np.testing.assert_allclose(np.ravel(getattr(hp, name))[0],
+                                   np.ravel(g['h1_' + name])[0], rtol=1e-9)
