@@ -136,23 +136,46 @@ def main():
         ms_ps, n_ps = chain.profile_read(_lib.K_CENTER)
         ms_fi, n_fi = chain.profile_read(_lib.K_FINALIZE)
         chain.profile_enable(False)
+        ms_ev, n_ev = chain.profile_read(_lib.K_SWEEP_EVAL)
+        ms_rs, n_rs = chain.profile_read(_lib.K_SWEEP_RESOLVE)
         sweep_ms = ms_sw / max(n_sw, 1)
         ll_ms = ms_ll / max(n_ll, 1)
-        # algorithmic bytes: the sweep touches every float64 Y
-        # entry once (row j of slice t per MH step) + X; one fused eval reads
-        # the upper triangle once + X
+        # algorithmic bytes: a sweep touches every float64 Y entry
+        # once (row j of slice t per MH step) + X[t] once per slice; one fused
+        # eval reads the upper triangle once + X
         sweep_bytes = 8.0 * T * N * N + 8.0 * T * N * D
         ll_bytes = 8.0 * T * N * (N - 1) / 2 + 8.0 * T * N * D
-        ach = sweep_bytes / (sweep_ms * 1e-3) / 1e9
-        roofline = {'bound': 'hbm', 'kernel': 'latent-position sweep (all launches of one sweep)',
+        traffic = None
+        tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
+        if n_ev > 0:
+            # dominant kernel of the sweep: k_spec_eval, (n_ev / P) launches per
+            # sweep, each covering (slices of one parity) x (batch of <= 128 nodes)
+            launches = n_ev / float(P)
+            kname, k_ms = 'k_spec_eval', ms_ev / n_ev
+            k_bytes = sweep_bytes / launches
+        else:
+            launches = 2.0
+            kname, k_ms = 'k_sweep_slice', sweep_ms / 2.0
+            k_bytes = sweep_bytes / 2.0
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(kname, {}).get('hbm_bytes_per_launch')
+            except Exception:
+                traffic = None
+        ach = k_bytes / (k_ms * 1e-3) / 1e9
+        roofline = {'bound': 'hbm', 'kernel': kname,
                     'achieved': round(ach, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                    'frac': round(ach / HBM_PEAK_GBS, 5), 'traffic': None,
-                    'ms_per_launch': round(sweep_ms, 4),
-                    'algorithmic_bytes_per_launch': sweep_bytes}
+                    'frac': round(ach / HBM_PEAK_GBS, 5), 'traffic': traffic,
+                    'us_per_launch': round(1e3 * k_ms, 3),
+                    'launches_per_sweep': launches,
+                    'algorithmic_bytes_per_launch': round(k_bytes, 1),
+                    'sweep_GBps_all_launches': round(sweep_bytes / (sweep_ms * 1e-3) / 1e9, 2)}
+        extra_r = {'us_resolve_per_launch': round(1e3 * ms_rs / max(n_rs, 1), 3)}
         extra = {'ms_per_loglik_eval': round(ll_ms, 4),
                  'loglik_eval_GBps': round(ll_bytes / (ll_ms * 1e-3) / 1e9, 1),
                  'ms_sweep': round(sweep_ms, 4), 'ms_post_sweep': round(ms_ps / max(n_ps, 1), 4),
                  'ms_finalize': round(ms_fi / max(n_fi, 1), 4)}
+        extra.update(extra_r)
 
     # ---- chain summaries: gather over RCCL ------------------------------------
     _, ics, lps = chain.trace_read(1 + W, K, positions=False)

@@ -14,7 +14,7 @@ c_i64_p = C.POINTER(C.c_int64)
 c_i32_p = C.POINTER(C.c_int32)
 handle_t = C.c_void_p
 
-K_LOGLIK, K_SWEEP, K_CENTER, K_LABELS, K_FINALIZE = range(5)
+K_LOGLIK, K_SWEEP, K_CENTER, K_LABELS, K_FINALIZE, K_SWEEP_EVAL, K_SWEEP_RESOLVE = range(7)
 UNDIRECTED, DIRECTED, DIRECTED_CASE_CONTROL = 0, 1, 2
 
 

@@ -652,15 +652,21 @@ static int launch_sweep_spec(dlsm_chain *h, uint32_t iter) {
         for (int j0 = 0; j0 < N; j0 += B) {
             const int nb = std::min(B, N - j0);
             const dim3 grid((unsigned)(nsl * nb * parts));
-            if (h->model == DLSM_UNDIRECTED)
-                hipLaunchKernelGGL((k_spec_eval<DD, DLSM_UNDIRECTED>), grid, dim3(SP_THREADS),
-                                   0, h->stream, v, sb, parity, j0, nb);
-            else
-                hipLaunchKernelGGL((k_spec_eval<DD, DLSM_DIRECTED>), grid, dim3(SP_THREADS),
-                                   0, h->stream, v, sb, parity, j0, nb);
-            hipLaunchKernelGGL(resolve, dim3(nsl), dim3(SP_THREADS),
-                               (size_t)nb * B * sizeof(double), h->stream, v, sb, parity,
-                               j0, nb);
+            {
+                ProfScope pe(h, DLSM_K_SWEEP_EVAL);
+                if (h->model == DLSM_UNDIRECTED)
+                    hipLaunchKernelGGL((k_spec_eval<DD, DLSM_UNDIRECTED>), grid,
+                                       dim3(SP_THREADS), 0, h->stream, v, sb, parity, j0, nb);
+                else
+                    hipLaunchKernelGGL((k_spec_eval<DD, DLSM_DIRECTED>), grid,
+                                       dim3(SP_THREADS), 0, h->stream, v, sb, parity, j0, nb);
+            }
+            {
+                ProfScope pr(h, DLSM_K_SWEEP_RESOLVE);
+                hipLaunchKernelGGL(resolve, dim3(nsl), dim3(SP_THREADS),
+                                   (size_t)nb * B * sizeof(double), h->stream, v, sb, parity,
+                                   j0, nb);
+            }
         }
     }
     HIPCHK(h, hipGetLastError());

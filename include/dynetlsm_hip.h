@@ -164,7 +164,10 @@ int dlsm_trace_read(dlsm_chain *h, int first, int count, double *Xs,
 /* ---- measurement ------------------------------------------------------ */
 enum {
     DLSM_K_LOGLIK = 0, DLSM_K_SWEEP = 1, DLSM_K_CENTER = 2, DLSM_K_LABELS = 3,
-    DLSM_K_FINALIZE = 4, DLSM_K_COUNT = 8
+    DLSM_K_FINALIZE = 4,
+    DLSM_K_SWEEP_EVAL = 5,     /* k_spec_eval launches of the speculative sweep */
+    DLSM_K_SWEEP_RESOLVE = 6,  /* k_spec_resolve launches */
+    DLSM_K_COUNT = 8
 };
 /* when enabled every launch of the kernel classes above is bracketed by HIP
  * events on the handle's stream; read returns accumulated ms and launches */
