@@ -1,0 +1,161 @@
+"""Parity at BASELINE.json's full sizes (configs 2-4) on an MI355X: direct
+comparison with the scalar C oracle where it finishes in seconds, and
+size-independent properties (sum of partials = 2 x full; two independent sweep
+algorithms agree; exhaustive controls = exact likelihood)."""
+import time
+
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def eng():
+    import dynetlsm_amd
+    return dynetlsm_amd
+
+
+@pytest.fixture(scope='module')
+def c2():
+    from dynetlsm_amd.synthetic import synthetic_lsm_network
+    return synthetic_lsm_network(T=10, N=2000, D=2, density=0.03, seed=0)
+
+
+def test_c2_loglik_and_identity(eng, c2):
+    Y, X, b = c2['Y'], c2['X_init'], c2['intercept']
+    with eng.Chain(10, 2000, 2, 'undirected') as c:
+        c.upload_network(Y); c.set_positions(X); c.set_intercepts([b])
+        got = c.loglik_full([[b], [b + 0.3]])
+        want = [orc.dynamic_network_loglikelihood_undirected(Y, X, v) for v in (b, b + 0.3)]
+        np.testing.assert_allclose(got, want, rtol=1e-10)      # spec: 1e-6 relative
+        pa = c.loglik_partial_all()
+        np.testing.assert_allclose(pa.sum() / 2, want[0], rtol=1e-10)
+        for t, j in [(0, 0), (9, 1999), (4, 1234)]:
+            np.testing.assert_allclose(pa[t, j],
+                                       orc.partial_loglikelihood(Y[t], X[t], b, j), rtol=1e-11)
+
+
+def test_c2_sweep_algorithms_agree_and_match_oracle(eng, c2):
+    """20 000 MH steps: slice sweep == speculative batches == C oracle"""
+    Y, X, b = c2['Y'], c2['X_init'], c2['intercept']
+    out = {}
+    for algo in (1, 2):
+        g = eng.SamplerGrid(10, 2000, 0.1, tune=5, tune_interval=1)
+        with eng.Chain(10, 2000, 2, 'undirected', seed=99, chain_id=3) as c:
+            c.upload_network(Y); c.set_positions(X); c.set_intercepts([b])
+            c.set_prior_random_walk(2.0, 0.1); c.set_samplers(g)
+            for it in (1, 2):
+                c.sweep_positions(it, algo)
+            out[algo] = (c.get_positions(), c.get_samplers(g).n_accepted.copy(),
+                         g.step_size.copy())
+    np.testing.assert_allclose(out[1][0], out[2][0], atol=1e-9)
+    np.testing.assert_array_equal(out[1][1], out[2][1])
+    og = orc.SamplerGrid(10, 2000, 0.1, tune=5, tune_interval=1)
+    st = orc.ChainState(X, og, Y=Y, intercept=[b], tau_sq=2.0, sigma_sq=0.1, seed=99, chain=3)
+    for it in (1, 2):
+        st.c.iter = it
+        st.sweep_c()
+    np.testing.assert_allclose(out[2][0], st.X, atol=1e-9)
+    np.testing.assert_array_equal(out[2][1], og.n_accepted)
+    np.testing.assert_allclose(out[2][2], og.step_size, rtol=1e-13)
+    moved = (st.X != X).any(axis=-1).mean()      # (counters reset while tuning)
+    assert 0.05 < moved < 0.999
+
+
+def test_c3_hdp_pieces_at_full_size(eng, c2):
+    """config 3: T=10, N=2000, K_max=20: mixture-prior sweep and label update"""
+    Y, X, b = c2['Y'], c2['X_init'], c2['intercept']
+    rng = np.random.RandomState(1)
+    K = 20
+    mu = rng.randn(K, 2) * 1.5; sigma = rng.uniform(0.3, 1.5, K)
+    z = rng.randint(0, K, size=(10, 2000)).astype(np.int64)
+    w = rng.dirichlet(np.ones(K), size=(10, K))
+    og = orc.SamplerGrid(10, 2000, 0.1, tune=None)
+    st = orc.ChainState(X, og, Y=Y, intercept=[b], mu=mu, sigma=sigma, lmbda=0.8, z=z,
+                        seed=5, chain=0, it=1)
+    st.sweep_c()
+    with eng.Chain(10, 2000, 2, 'undirected', seed=5, chain_id=0) as c:
+        c.upload_network(Y); c.set_positions(X); c.set_intercepts([b])
+        c.set_prior_mixture(mu, sigma, 0.8, z)
+        c.set_samplers(eng.SamplerGrid(10, 2000, 0.1, tune=None))
+        c.sweep_positions(1, 2)
+        Xg = c.get_positions()
+        np.testing.assert_allclose(Xg, st.X, atol=1e-9)
+        t0 = time.perf_counter()
+        zg, n, nk = c.sample_labels(1, w)
+        dt = time.perf_counter() - t0
+    zo, no, nko = orc.sample_labels_block_philox(st.X, mu, sigma, 0.8, w, 5, 0, 1)
+    assert (zg != zo).mean() < 1e-4          # identical up to 1-ulp position differences
+    assert n.sum() == 20000 and (nk.sum(axis=1) == 2000).all()
+    print('labels T=10 N=2000 K=20: %.2f ms incl. transfers' % (1e3 * dt))
+
+
+def _sparse_directed(T, N, deg, seed):
+    """directed edge lists built without a dense network (config 4 is sparse)"""
+    rng = np.random.RandomState(seed)
+    X = 0.01 * rng.randn(T, N, 2)
+    radii = rng.dirichlet(np.ones(N) * 10)
+    out = rng.randint(0, N, size=(T, N, deg))
+    out_lists = [[np.setdiff1d(np.unique(out[t, i]), [i]) for i in range(N)] for t in range(T)]
+    degree = np.zeros((T, N, 2), dtype=np.int64)
+    for t in range(T):
+        for i in range(N):
+            degree[t, i, 1] = out_lists[t][i].size
+            np.add.at(degree[t, :, 0], out_lists[t][i], 1)
+    out_edges = np.zeros((T, N, degree[:, :, 1].max()), dtype=np.int64)
+    in_edges = np.zeros((T, N, degree[:, :, 0].max()), dtype=np.int64)
+    fill = np.zeros((T, N), dtype=np.int64)
+    for t in range(T):
+        for i in range(N):
+            e = out_lists[t][i]
+            out_edges[t, i, :e.size] = e
+            in_edges[t, e, fill[t, e]] = i       # sources arrive in increasing i
+            fill[t, e] += 1
+    return X, radii, degree, in_edges, out_edges
+
+
+def test_c4_case_control_at_full_size(eng):
+    """config 4: directed case-control, T=5, N=10 000, n_control=100"""
+    T, N, C = 5, 10000, 100
+    X, radii, degree, in_edges, out_edges = _sparse_directed(T, N, 20, 0)
+    b = [1.0, 0.5]
+    with eng.Chain(T, N, 2, 'case_control', seed=11, chain_id=1) as c:
+        c.upload_edges(in_edges, out_edges, degree)
+        t0 = time.perf_counter()
+        c.resample_controls(0, C)
+        t_res = time.perf_counter() - t0
+        ci, co = c.get_controls()
+        # validity on a sample of nodes (the full check is in test_gpu_parity)
+        for t, i in [(0, 0), (4, 9999), (2, 5000), (1, 77)]:
+            for arr, col, edges in ((co, 1, out_edges), (ci, 0, in_edges)):
+                v = arr[t, i]
+                assert (v >= 0).all() and len(set(v)) == C and i not in v
+                assert not set(v) & set(edges[t, i, :degree[t, i, col]])
+        c.set_positions(X); c.set_radii(radii); c.set_intercepts(b)
+        got = c.loglik_full([b])[0]
+        want = orc.approx_directed_network_loglikelihood(X, radii, in_edges, out_edges,
+                                                         degree, co, b[0], b[1])
+        np.testing.assert_allclose(got, want, rtol=1e-10)
+        cc = dict(in_edges=in_edges, out_edges=out_edges, degree=degree,
+                  control_nodes_in=ci, control_nodes_out=co)
+        og = orc.SamplerGrid(T, N, 0.002, tune=None)
+        st = orc.ChainState(X, og, model=2, intercept=b, radii=radii, case_control=cc,
+                            tau_sq=1e-4, sigma_sq=1e-5, seed=11, chain=1, it=1)
+        pa = c.loglik_partial_all()
+        for t, j in [(0, 0), (4, 9999), (3, 4321)]:
+            np.testing.assert_allclose(
+                pa[t, j], orc.approx_directed_partial_loglikelihood(
+                    X[t], radii, in_edges[t], out_edges[t], degree[t], ci[t], co[t],
+                    b[0], b[1], j), rtol=1e-11)
+        c.set_prior_random_walk(1e-4, 1e-5)
+        c.set_samplers(eng.SamplerGrid(T, N, 0.002, tune=None))
+        t0 = time.perf_counter()
+        c.sweep_positions(1, 0)
+        t_sw = time.perf_counter() - t0
+        st.sweep_c()
+        np.testing.assert_allclose(c.get_positions(), st.X, atol=1e-12)
+        assert 0.02 < og.n_accepted.mean() < 0.98
+    print('C4: resample %.1f ms, sweep %.1f ms' % (1e3 * t_res, 1e3 * t_sw))
