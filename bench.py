@@ -177,6 +177,9 @@ def main():
                  'ms_finalize': round(ms_fi / max(n_fi, 1), 4)}
         extra.update(extra_r)
 
+    grid_f = chain.get_samplers(SamplerGrid(T, N, 0.1, tune=None))
+    acc_rate = float(grid_f.n_accepted.sum()) / max(float(grid_f.n_steps.sum()), 1.0)
+
     # ---- chain summaries: gather over RCCL ------------------------------------
     _, ics, lps = chain.trace_read(1 + W, K, positions=False)
     summ = torch.tensor([ics[:, 0].mean(), ics[:, 0].std(), lps.mean(), lps[-1]],
@@ -226,7 +229,8 @@ def main():
                                    '1 chain per GPU' % (T, N, D),
                        'density': round(density, 4), 'chains': world,
                        'iteration': 'sweep + procrustes + centring + intercept MH + logp trace',
-                       'sweep_algo': args.algo},
+                       'sweep_algo': args.algo,
+                       'mh_acceptance_rate': round(acc_rate, 3)},
             'roofline': roofline, 'cpu_baseline': cpu,
             'loglik_rel_err_vs_oracle': parity,
             'chain_summaries[intercept_mean,intercept_sd,logp_mean,logp_last]': summaries,

@@ -663,9 +663,67 @@ static int launch_sweep_spec(dlsm_chain *h, uint32_t iter) {
             }
             {
                 ProfScope pr(h, DLSM_K_SWEEP_RESOLVE);
-                hipLaunchKernelGGL(resolve, dim3(nsl), dim3(SP_THREADS),
+                hipLaunchKernelGGL(resolve, dim3(nsl), dim3(SP_RES_THREADS),
                                    (size_t)nb * B * sizeof(double), h->stream, v, sb, parity,
                                    j0, nb);
+            }
+        }
+    }
+    HIPCHK(h, hipGetLastError());
+    return DLSM_OK;
+}
+
+// algo 3: two-level batches: one eval + one resolve launch per super-batch
+template <int DD>
+static int launch_sweep_spec2(dlsm_chain *h, uint32_t iter) {
+    if (!spec_supported(h)) FAIL(h, DLSM_E_ARG, "speculative-batch sweep needs an exact model");
+    const int N = h->N, T = h->T;
+    const int SB = std::min(SP2_SBMAX, (N + 1) / 2 * 2);
+    const int nsl_max = (T + 1) / 2;
+    int parts = (2048 + nsl_max * SB - 1) / (nsl_max * SB);
+    parts = std::max(1, std::min(parts, 8));
+    auto even = [](size_t n) { return (n + 1) / 2 * 2; };
+    const size_t n_full0 = even((size_t)nsl_max * SB * parts);
+    const size_t n_prop = even((size_t)nsl_max * N * (DD + 2));
+    const size_t n_ht = (size_t)nsl_max * SB * SB;
+    const size_t need = (n_full0 + n_prop + n_ht + 2) * sizeof(double);
+    if (h->spec_cap < need) {
+        if (h->spec) hipFree(h->spec);
+        h->spec = nullptr; h->spec_cap = 0;
+        HIPCHK(h, hipMalloc((void **)&h->spec, need));
+        h->spec_cap = need;
+    }
+    SpecBuf2 sb;
+    sb.full0 = h->spec; sb.prop = sb.full0 + n_full0; sb.Ht = sb.prop + n_prop;
+    sb.consts = sb.Ht + n_ht;
+    sb.SB = SB; sb.parts = parts;
+    ChainView v = h->view();
+    auto resolve = k_spec2_resolve<DD>;
+    const size_t lds = (size_t)(SP_BMAX * SP_BMAX + 2 * SP_BMAX) * sizeof(double) +
+                       (size_t)SP2_SBMAX * sizeof(int);
+    HIPCHK(h, hipFuncSetAttribute((const void *)resolve,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    for (int parity = 0; parity < 2; ++parity) {
+        const int nsl = (T - parity + 1) / 2;
+        if (nsl <= 0) continue;
+        hipLaunchKernelGGL((k_spec2_propose<DD>), dim3((N + 255) / 256, nsl), dim3(256), 0,
+                           h->stream, v, sb, iter, parity);
+        for (int j0 = 0; j0 < N; j0 += SB) {
+            const int nsb = std::min(SB, N - j0);
+            const dim3 grid((unsigned)(nsl * nsb * parts));
+            {
+                ProfScope pe(h, DLSM_K_SWEEP_EVAL);
+                if (h->model == DLSM_UNDIRECTED)
+                    hipLaunchKernelGGL((k_spec2_eval<DD, DLSM_UNDIRECTED>), grid,
+                                       dim3(SP_THREADS), 0, h->stream, v, sb, parity, j0, nsb);
+                else
+                    hipLaunchKernelGGL((k_spec2_eval<DD, DLSM_DIRECTED>), grid,
+                                       dim3(SP_THREADS), 0, h->stream, v, sb, parity, j0, nsb);
+            }
+            {
+                ProfScope pr(h, DLSM_K_SWEEP_RESOLVE);
+                hipLaunchKernelGGL(resolve, dim3(nsl), dim3(SP_THREADS), lds, h->stream, v,
+                                   sb, parity, j0, nsb);
             }
         }
     }
@@ -702,6 +760,7 @@ static int launch_sweep(dlsm_chain *h, uint32_t iter, int algo) {
     }
     if (algo == 0) algo = spec_supported(h) && h->N >= 256 ? 2 : 1;
     if (algo == 2) return launch_sweep_spec<DD>(h, iter);
+    if (algo == 3) return launch_sweep_spec2<DD>(h, iter);
     const size_t lds = sweep_slice_lds_bytes(h->N, DD, h->W, h->model);
     if (lds > 160 * 1024)
         FAIL(h, DLSM_E_LIMIT, "N=%d needs %zu B of LDS in the slice sweep (max 163840)",
@@ -742,7 +801,7 @@ extern "C" {
 
 int dlsm_sweep_positions(dlsm_chain *h, uint32_t iter, int algo) {
     NEED(h, h != nullptr, "null handle");
-    NEED(h, algo >= 0 && algo <= 2, "algo must be 0, 1 or 2");
+    NEED(h, algo >= 0 && algo <= 3, "algo must be 0..3");
     HIPCHK(h, hipSetDevice(h->device));
     int rc = check_ready_sweep(h); if (rc) return rc;
     rc = enqueue_sweep(h, iter, algo); if (rc) return rc;
