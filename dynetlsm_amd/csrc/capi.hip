@@ -625,11 +625,13 @@ static int launch_sweep_spec(dlsm_chain *h, uint32_t iter) {
     const int B = std::min(SP_BMAX, (N + 1) / 2 * 2);   // even: double2 staging
     const int nsl_max = (T + 1) / 2;
     int parts = (1024 + nsl_max * B - 1) / (nsl_max * B);
+    if (getenv("DLSM_SPEC_PARTS")) parts = atoi(getenv("DLSM_SPEC_PARTS"));
     parts = std::max(1, std::min(parts, 8));
-    const size_t n_full0 = (size_t)nsl_max * B * parts;
-    const size_t n_prop = (size_t)nsl_max * N * (DD + 2);
+    auto even2 = [](size_t n) { return (n + 1) / 2 * 2; };
+    const size_t n_full0 = even2((size_t)nsl_max * B * parts);
+    const size_t n_prop = even2((size_t)nsl_max * N * (DD + 2));
     const size_t n_ht = (size_t)nsl_max * B * B;
-    const size_t need = (n_full0 + n_prop + n_ht) * sizeof(double);
+    const size_t need = (n_full0 + n_prop + n_ht + 2) * sizeof(double);
     if (h->spec_cap < need) {
         if (h->spec) hipFree(h->spec);
         h->spec = nullptr; h->spec_cap = 0;
@@ -638,6 +640,7 @@ static int launch_sweep_spec(dlsm_chain *h, uint32_t iter) {
     }
     SpecBuf sb;
     sb.full0 = h->spec; sb.prop = sb.full0 + n_full0; sb.Ht = sb.prop + n_prop;
+    sb.consts = sb.Ht + n_ht;
     sb.B = B; sb.parts = parts;
     ChainView v = h->view();
     auto resolve = k_spec_resolve<DD>;
@@ -656,10 +659,10 @@ static int launch_sweep_spec(dlsm_chain *h, uint32_t iter) {
                 ProfScope pe(h, DLSM_K_SWEEP_EVAL);
                 if (h->model == DLSM_UNDIRECTED)
                     hipLaunchKernelGGL((k_spec_eval<DD, DLSM_UNDIRECTED>), grid,
-                                       dim3(SP_THREADS), 0, h->stream, v, sb, parity, j0, nb);
+                                       dim3(SP_EV_THREADS), 0, h->stream, v, sb, parity, j0, nb);
                 else
                     hipLaunchKernelGGL((k_spec_eval<DD, DLSM_DIRECTED>), grid,
-                                       dim3(SP_THREADS), 0, h->stream, v, sb, parity, j0, nb);
+                                       dim3(SP_EV_THREADS), 0, h->stream, v, sb, parity, j0, nb);
             }
             {
                 ProfScope pr(h, DLSM_K_SWEEP_RESOLVE);

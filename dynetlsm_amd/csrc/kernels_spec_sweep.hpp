@@ -36,8 +36,17 @@ struct SpecBuf {
     double *full0;   // [nsl][B][parts]
     double *prop;    // [nsl][N][D + 2] : x1[D], logu, prior delta
     double *Ht;      // [nsl][B][B]     : Ht[m][k] = H[k][m], k > m
+    double *consts;  // [2] : E = exp(sum of intercepts), flush interval
     int B, parts;
 };
+
+__device__ __forceinline__ int flush_interval(double E_max) {
+    // (1 + E)^n < e^600
+    const double l = log1p(E_max);
+    if (!(l > 0.0)) return 1 << 20;
+    const double n = 600.0 / l;
+    return n < 1.0 ? 1 : (n > 1048576.0 ? 1 << 20 : (int)n);
+}
 
 template <int D>
 __global__ __launch_bounds__(256) void k_spec_propose(ChainView c, SpecBuf sb,
@@ -46,6 +55,12 @@ __global__ __launch_bounds__(256) void k_spec_propose(ChainView c, SpecBuf sb,
     const int s = blockIdx.y;
     const int t = 2 * s + parity;
     const int j = blockIdx.x * 256 + threadIdx.x;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        const double E = c.model == DLSM_UNDIRECTED ? exp(c.intercept[0])
+                                                    : exp(c.intercept[0] + c.intercept[1]);
+        sb.consts[0] = E;
+        sb.consts[1] = (double)flush_interval(E);
+    }
     if (j >= N) return;
     double x0[D], x1[D], logu;
 #pragma unroll
@@ -72,13 +87,6 @@ struct RatioAcc {
     __device__ __forceinline__ double value() { flush(); return lin + lg; }
 };
 
-__device__ __forceinline__ int flush_interval(double E_max) {
-    // (1 + E)^n < e^600
-    const double l = log1p(E_max);
-    if (!(l > 0.0)) return 1 << 20;
-    const double n = 600.0 / l;
-    return n < 1.0 ? 1 : (n > 1048576.0 ? 1 << 20 : (int)n);
-}
 
 
 // In-order resolution of one batch of <= 128 nodes by one wave (lane l owns
@@ -146,12 +154,14 @@ __device__ __forceinline__ void resolve_fixed_point(bool valid0, bool valid1, do
     acc0 = g0; acc1 = g1;
 }
 
+constexpr int SP_EV_THREADS = 256;     // eval workgroup (>= SP_BMAX so tid covers m < k)
+
 template <int D, int MODEL>
-__global__ __launch_bounds__(SP_THREADS) void k_spec_eval(ChainView c, SpecBuf sb,
+__global__ __launch_bounds__(SP_EV_THREADS) void k_spec_eval(ChainView c, SpecBuf sb,
                                                           int parity, int j0, int nb) {
     __shared__ double sx0[SP_BMAX * D];
     __shared__ double sx1[SP_BMAX * D];
-    __shared__ double sRed[SP_THREADS / 64];
+    __shared__ double sRed[SP_EV_THREADS / 64];
     const int tid = threadIdx.x;
     const int N = c.N, W = c.W;
     const int p = blockIdx.x % sb.parts;
@@ -160,9 +170,28 @@ __global__ __launch_bounds__(SP_THREADS) void k_spec_eval(ChainView c, SpecBuf s
     const int t = 2 * s + parity;
     const double *Xt = c.X + (size_t)t * N * D;
     const int jk = j0 + k;
-    const bool do_h = (p == 0);
-    // positions / proposals of the batch nodes m <= k (only k itself if no H)
-    if (do_h ? (tid <= k) : (tid == k)) {
+    const uint32_t *yr = c.ybits + ((size_t)t * N + jk) * W;
+    const uint32_t *yc = MODEL == DLSM_DIRECTED ? c.ytbits + ((size_t)t * N + jk) * W
+                                                : nullptr;
+    const int per = (N + sb.parts - 1) / sb.parts;
+    const int lo = p * per, hi = min(N, lo + per);
+    // issue the first neighbours' loads before the staging barrier so that they are
+    // in flight together with the prologue's (the kernel is latency bound)
+    constexpr int NPRE = 4;
+    double xpre[NPRE][D];
+    uint32_t wpre[NPRE], wcpre[NPRE];
+#pragma unroll
+    for (int u = 0; u < NPRE; ++u) {
+        const int ic = min(lo + tid + u * SP_EV_THREADS, N - 1);
+#pragma unroll
+        for (int d = 0; d < D; ++d) xpre[u][d] = Xt[(size_t)ic * D + d];
+        wpre[u] = yr[ic >> 5];
+        wcpre[u] = MODEL == DLSM_DIRECTED ? yc[ic >> 5] : 0u;
+    }
+    const double E = sb.consts[0];
+    const int nflush = (int)sb.consts[1];
+    // positions / proposals of the batch nodes m <= k
+    if (tid <= k) {
         const int j = j0 + tid;
         const double *pr = sb.prop + ((size_t)s * N + j) * (D + 2);
 #pragma unroll
@@ -175,48 +204,48 @@ __global__ __launch_bounds__(SP_THREADS) void k_spec_eval(ChainView c, SpecBuf s
     double xk0[D], xk1[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) { xk0[d] = sx0[k * D + d]; xk1[d] = sx1[k * D + d]; }
-    const uint32_t *yr = c.ybits + ((size_t)t * N + jk) * W;
-    const uint32_t *yc = MODEL == DLSM_DIRECTED ? c.ytbits + ((size_t)t * N + jk) * W
-                                                : nullptr;
-    double E, bin = 0.0, bout = 0.0, irk = 0.0;
-    int nflush;
-    if (MODEL == DLSM_UNDIRECTED) {
-        E = exp(c.intercept[0]);
-        nflush = flush_interval(E);
-    } else {
+    double bin = 0.0, bout = 0.0, irk = 0.0;
+    if (MODEL == DLSM_DIRECTED) {
         bin = c.intercept[0]; bout = c.intercept[1];
-        E = exp(bin + bout);
         irk = 1.0 / c.radii[jk];
-        nflush = 0;                  // directed: exponents are not bounded by b
     }
-    const int per = (N + sb.parts - 1) / sb.parts;
-    const int lo = p * per, hi = min(N, lo + per);
     double acc = 0.0;
     RatioAcc ra;
-    for (int i = lo + tid; i < hi; i += SP_THREADS) {
-        if (i == jk) continue;
-        double xi[D];
-#pragma unroll
-        for (int d = 0; d < D; ++d) xi[d] = Xt[(size_t)i * D + d];
+    auto term = [&](int i, const double *xi, int ybit, int ycbit) {
         const double d0 = dist_of<D>(xi, xk0, c.squared);
         const double d1 = dist_of<D>(xi, xk1, c.squared);
         if (MODEL == DLSM_UNDIRECTED) {
-            if (bit_of(yr, i)) ra.lin += d0 - d1;
+            if (ybit) ra.lin += d0 - d1;
             ra.P0 *= 1.0 + E * exp(-d0);
             ra.P1 *= 1.0 + E * exp(-d1);
             if (++ra.cnt >= nflush) ra.flush();
         } else {
             const double iri = 1.0 / c.radii[i];
-            acc += delta_directed(d0, d1, bit_of(yr, i), bit_of(yc, i),
-                                  bin * iri + bout * irk, bin * irk + bout * iri, E);
+            acc += delta_directed(d0, d1, ybit, ycbit, bin * iri + bout * irk,
+                                  bin * irk + bout * iri, E);
         }
+    };
+#pragma unroll
+    for (int u = 0; u < NPRE; ++u) {
+        const int i = lo + tid + u * SP_EV_THREADS;
+        if (i < hi && i != jk)
+            term(i, xpre[u], (wpre[u] >> (i & 31)) & 1, (wcpre[u] >> (i & 31)) & 1);
+    }
+    for (int i = lo + tid + NPRE * SP_EV_THREADS; i < hi; i += SP_EV_THREADS) {
+        if (i == jk) continue;
+        double xi[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) xi[d] = Xt[(size_t)i * D + d];
+        term(i, xi, bit_of(yr, i), MODEL == DLSM_DIRECTED ? bit_of(yc, i) : 0);
     }
     if (MODEL == DLSM_UNDIRECTED) acc = ra.value();
-    const double total = block_sum_all<SP_THREADS / 64>(acc, sRed, tid);
+    const double total = block_sum_all<SP_EV_THREADS / 64>(acc, sRed, tid);
     if (tid == 0) sb.full0[((size_t)s * sb.B + k) * sb.parts + p] = total;
-    // effect of an earlier batch node's acceptance on this node's ratio
-    if (do_h && tid < k) {
-        const int m = tid, jm = j0 + m;
+    // effect of an earlier batch node's acceptance on this node's ratio; the parts of
+    // node k share the rows: part p takes m = p, p + parts, ...
+    const int m = tid * sb.parts + p;
+    if (m < k) {
+        const int jm = j0 + m;
         const double a0 = dist_of<D>(&sx0[m * D], xk0, c.squared);
         const double a1 = dist_of<D>(&sx0[m * D], xk1, c.squared);
         const double b0 = dist_of<D>(&sx1[m * D], xk0, c.squared);
