@@ -818,9 +818,19 @@ template <int DD>
 static int launch_post(dlsm_chain *h, const double *d_xref, int do_center,
                        LsmDeviceState *lsm, uint32_t iter, double *d_R) {
     ChainView v = h->view();
+    const long rows = (long)h->T * h->N;
+    const int nb = (int)std::min<long>(PS_BLOCKS, (rows + PS2_THREADS - 1) / PS2_THREADS);
+    constexpr int W = PostRec<DD>::W;
+    // the records live behind the log-likelihood records (both are consumed before
+    // the next producer runs: same stream)
+    int rc = ensure_partials(h, (size_t)ll_blocks(h) * 4 + (size_t)PS_BLOCKS * W);
+    if (rc) return rc;
+    double *rec = h->partials + (size_t)ll_blocks(h) * 4;
     ProfScope ps(h, DLSM_K_CENTER);
-    hipLaunchKernelGGL((k_post_sweep<DD>), dim3(1), dim3(PS_THREADS), 0, h->stream, v,
-                       d_xref, do_center, lsm, iter, d_R);
+    hipLaunchKernelGGL((k_post_reduce<DD>), dim3(nb), dim3(PS2_THREADS), 0, h->stream, v,
+                       d_xref, rec);
+    hipLaunchKernelGGL((k_post_apply<DD>), dim3(nb), dim3(PS2_THREADS), 0, h->stream, v,
+                       d_xref ? 1 : 0, do_center, rec, nb, lsm, iter, d_R);
     HIPCHK(h, hipGetLastError());
     return DLSM_OK;
 }

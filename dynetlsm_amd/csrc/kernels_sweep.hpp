@@ -365,101 +365,141 @@ __device__ void jacobi_polar(const double (&M)[D][D], double (&R)[D][D]) {
         }
 }
 
+// Pass 1 (many workgroups): per-workgroup sums over the rows r of X (T*N x D):
+//   [ sum x (D) | M = X^T X_ref (D*D) | sum_{t=0} x (D) | sum_{t=0} |x|^2 |
+//     sum_{t>0} |x_t - x_{t-1}|^2 ]
+// Everything pass 2 needs follows from these by linearity / orthogonal invariance:
+// mean(X R) = mean(X) R, |(x - m) R| = |x - m|, |(x_t - x_{t-1}) R| = |x_t - x_{t-1}|.
+constexpr int PS_BLOCKS = 64;
+constexpr int PS2_THREADS = 256;
+template <int D> struct PostRec { static constexpr int W = 2 * D + D * D + 2; };
+
 template <int D>
-__global__ __launch_bounds__(PS_THREADS) void k_post_sweep(
-    ChainView c, const double *__restrict__ xref, int do_center,
+__global__ __launch_bounds__(PS2_THREADS) void k_post_reduce(
+    ChainView c, const double *__restrict__ xref, double *__restrict__ rec) {
+    constexpr int W = PostRec<D>::W;
+    __shared__ double sRed[2 * (PS2_THREADS / 64)];
+    const int tid = threadIdx.x;
+    const long rows = (long)c.T * c.N;
+    const double *X = c.X;
+    double acc[W];
+#pragma unroll
+    for (int q = 0; q < W; ++q) acc[q] = 0.0;
+    for (long r = (long)blockIdx.x * PS2_THREADS + tid; r < rows;
+         r += (long)gridDim.x * PS2_THREADS) {
+        double x[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) { x[d] = X[r * D + d]; acc[d] += x[d]; }
+        if (xref) {
+#pragma unroll
+            for (int a = 0; a < D; ++a)
+#pragma unroll
+                for (int b = 0; b < D; ++b) acc[D + a * D + b] += x[a] * xref[r * D + b];
+        }
+        if (r < c.N) {
+            double q = 0.0;
+#pragma unroll
+            for (int d = 0; d < D; ++d) { acc[D + D * D + d] += x[d]; q += x[d] * x[d]; }
+            acc[2 * D + D * D] += q;
+        } else {
+            double q = 0.0;
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const double df = x[d] - X[(r - c.N) * D + d];
+                q += df * df;
+            }
+            acc[2 * D + D * D + 1] += q;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < W; ++q) {
+        const double v = block_sum_all<PS2_THREADS / 64>(
+            acc[q], sRed + (q & 1) * (PS2_THREADS / 64), tid);
+        if (tid == 0) rec[(size_t)blockIdx.x * W + q] = v;
+    }
+}
+
+// Pass 2 (many workgroups): every workgroup sums the records in the same fixed
+// order, gets R (one-sided Jacobi polar factor of M) and the mean, and applies
+// x <- x R - mean R to its rows.  Workgroup 0 also leaves the LSM bookkeeping.
+template <int D>
+__global__ __launch_bounds__(PS2_THREADS) void k_post_apply(
+    ChainView c, int rotate, int do_center, const double *__restrict__ rec, int nrec,
     LsmDeviceState *lsm, uint32_t iter, double *__restrict__ R_out) {
-    __shared__ double sRed[2 * (PS_THREADS / 64)];
+    constexpr int W = PostRec<D>::W;
+    __shared__ double sSum[W];
     __shared__ double sR[D * D];
+    __shared__ double sShift[D];
     const int tid = threadIdx.x;
     const long rows = (long)c.T * c.N;
     double *X = c.X;
-    int phase = 0;
-    if (xref) {
-        double M[D][D];
-        for (int a = 0; a < D; ++a)
-            for (int b = 0; b < D; ++b) {
-                double s = 0.0;
-                for (long r = tid; r < rows; r += PS_THREADS)
-                    s += X[r * D + a] * xref[r * D + b];
-                M[a][b] = block_sum_all<PS_THREADS / 64>(
-                    s, sRed + (phase & 1) * (PS_THREADS / 64), tid);
-                ++phase;
-            }
-        if (tid == 0) {
-            double R[D][D];
-            jacobi_polar<D>(M, R);
-            for (int a = 0; a < D; ++a)
-                for (int b = 0; b < D; ++b) {
-                    sR[a * D + b] = R[a][b];
-                    if (R_out) R_out[a * D + b] = R[a][b];
-                }
-        }
-        __syncthreads();
-        for (long r = tid; r < rows; r += PS_THREADS) {
-            double x[D], y[D];
-#pragma unroll
-            for (int a = 0; a < D; ++a) x[a] = X[r * D + a];
-#pragma unroll
-            for (int b = 0; b < D; ++b) {
-                double s = 0.0;
-#pragma unroll
-                for (int a = 0; a < D; ++a) s += x[a] * sR[a * D + b];
-                y[b] = s;
-            }
-#pragma unroll
-            for (int b = 0; b < D; ++b) X[r * D + b] = y[b];
-        }
-        __syncthreads();
-    }
-    if (do_center) {
-        double mean[D];
-        for (int d = 0; d < D; ++d) {
-            double s = 0.0;
-            for (long r = tid; r < rows; r += PS_THREADS) s += X[r * D + d];
-            mean[d] = block_sum_all<PS_THREADS / 64>(
-                          s, sRed + (phase & 1) * (PS_THREADS / 64), tid) /
-                      (double)rows;
-            ++phase;
-        }
-        for (long r = tid; r < rows; r += PS_THREADS)
-#pragma unroll
-            for (int d = 0; d < D; ++d) X[r * D + d] -= mean[d];
-        __syncthreads();
-    }
-    if (lsm) {
-        // lsm.py:604-613 : - sum_t sum_i 0.5 |.|^2 / (tau_sq | sigma_sq)
+    if (tid < W) {
         double s = 0.0;
-        for (long r = tid; r < rows; r += PS_THREADS) {
-            double q = 0.0;
-            if (r < c.N) {
-#pragma unroll
-                for (int d = 0; d < D; ++d) q += X[r * D + d] * X[r * D + d];
-                s += 0.5 * q / c.tau_sq;
-            } else {
-#pragma unroll
+        for (int b = 0; b < nrec; ++b) s += rec[(size_t)b * W + tid];
+        sSum[tid] = s;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double R[D][D];
+        if (rotate) {
+            double M[D][D];
+            for (int a = 0; a < D; ++a)
+                for (int b = 0; b < D; ++b) M[a][b] = sSum[D + a * D + b];
+            jacobi_polar<D>(M, R);
+        } else {
+            for (int a = 0; a < D; ++a)
+                for (int b = 0; b < D; ++b) R[a][b] = a == b ? 1.0 : 0.0;
+        }
+        double mean[D];
+        for (int d = 0; d < D; ++d) mean[d] = do_center ? sSum[d] / (double)rows : 0.0;
+        for (int b = 0; b < D; ++b) {
+            double sh = 0.0;
+            for (int a = 0; a < D; ++a) { sh += mean[a] * R[a][b]; sR[a * D + b] = R[a][b]; }
+            sShift[b] = sh;
+        }
+        if (blockIdx.x == 0) {
+            if (R_out)
+                for (int a = 0; a < D * D; ++a) R_out[a] = sR[a];
+            if (lsm) {
+                // lsm.py:604-613 on the rotated, centred positions
+                double q0 = sSum[2 * D + D * D];
+                double mm = 0.0, ms = 0.0;
                 for (int d = 0; d < D; ++d) {
-                    double df = X[r * D + d] - X[(r - c.N) * D + d];
-                    q += df * df;
+                    mm += mean[d] * mean[d];
+                    ms += mean[d] * sSum[D + D * D + d];
                 }
-                s += 0.5 * q / c.sigma_sq;
+                q0 = q0 - 2.0 * ms + (double)c.N * mm;
+                lsm->prior_x = -(0.5 * q0 / c.tau_sq +
+                                 0.5 * sSum[2 * D + D * D + 1] / c.sigma_sq);
+                double u0, u1, z0, z1;
+                philox_uniform2(c.seed, 0, 0, iter, stream_word(c.chain, STREAM_INTERCEPT),
+                                u0, u1);
+                box_muller(u0, u1, z0, z1);
+                const double b0 = c.intercept[0];
+                lsm->cand[0] = b0;
+                lsm->cand[1] = b0 + lsm->i_step[0] * z0;
+                philox_uniform2(c.seed, 0, 1, iter, stream_word(c.chain, STREAM_INTERCEPT),
+                                u0, u1);
+                lsm->logu = log(u0);
             }
         }
-        const double tot = block_sum_all<PS_THREADS / 64>(
-            s, sRed + (phase & 1) * (PS_THREADS / 64), tid);
-        if (tid == 0) {
-            lsm->prior_x = -tot;
-            double u0, u1, z0, z1;
-            philox_uniform2(c.seed, 0, 0, iter, stream_word(c.chain, STREAM_INTERCEPT),
-                            u0, u1);
-            box_muller(u0, u1, z0, z1);
-            const double b0 = c.intercept[0];
-            lsm->cand[0] = b0;
-            lsm->cand[1] = b0 + lsm->i_step[0] * z0;
-            philox_uniform2(c.seed, 0, 1, iter, stream_word(c.chain, STREAM_INTERCEPT),
-                            u0, u1);
-            lsm->logu = log(u0);
+    }
+    __syncthreads();
+    if (!rotate && !do_center) return;
+    for (long r = (long)blockIdx.x * PS2_THREADS + tid; r < rows;
+         r += (long)gridDim.x * PS2_THREADS) {
+        double x[D], y[D];
+#pragma unroll
+        for (int a = 0; a < D; ++a) x[a] = X[r * D + a];
+#pragma unroll
+        for (int b = 0; b < D; ++b) {
+            double sacc = 0.0;
+#pragma unroll
+            for (int a = 0; a < D; ++a) sacc += x[a] * sR[a * D + b];
+            y[b] = sacc - sShift[b];
         }
+#pragma unroll
+        for (int b = 0; b < D; ++b) X[r * D + b] = y[b];
     }
 }
 
