@@ -262,6 +262,9 @@ void dlsm_destroy(dlsm_chain *h) {
     if (h->hsmall) hipHostFree(h->hsmall);
     if (h->timer0) hipEventDestroy(h->timer0);
     if (h->timer1) hipEventDestroy(h->timer1);
+    if (h->ev_a) hipEventDestroy(h->ev_a);
+    if (h->ev_b) hipEventDestroy(h->ev_b);
+    if (h->stream2) { hipStreamSynchronize(h->stream2); hipStreamDestroy(h->stream2); }
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
 }
@@ -641,34 +644,68 @@ static int launch_sweep_spec(dlsm_chain *h, uint32_t iter) {
     SpecBuf sb;
     sb.full0 = h->spec; sb.prop = sb.full0 + n_full0; sb.Ht = sb.prop + n_prop;
     sb.consts = sb.Ht + n_ht;
-    sb.B = B; sb.parts = parts;
+    sb.B = B; sb.parts = parts; sb.s0 = 0;
     ChainView v = h->view();
     auto resolve = k_spec_resolve<DD>;
     HIPCHK(h, hipFuncSetAttribute((const void *)resolve,
                                   hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)((size_t)B * B * sizeof(double))));
+    // The slices of a parity are independent, so they can be split over two queues to
+    // let one group's resolve overlap the other group's eval.  Measured on MI355X this
+    // buys nothing at N=2000 (twice the launches: host bound) and 3.6 % at N=4000 (the
+    // 16-wave resolve workgroup is not placed while eval saturates the CUs), so it is
+    // opt-in: DLSM_SPEC_QUEUES=2.
+    int nq = (getenv("DLSM_SPEC_QUEUES") ? atoi(getenv("DLSM_SPEC_QUEUES")) : 1);
+    if (h->profiling || nsl_max < 2) nq = 1;
+    if (nq > 1 && !h->stream2) {
+        HIPCHK(h, hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+        HIPCHK(h, hipEventCreateWithFlags(&h->ev_a, hipEventDisableTiming));
+        HIPCHK(h, hipEventCreateWithFlags(&h->ev_b, hipEventDisableTiming));
+    }
+    hipStream_t qs[2] = {h->stream, nq > 1 ? h->stream2 : h->stream};
+    if (nq > 1) {       // fork
+        HIPCHK(h, hipEventRecord(h->ev_a, h->stream));
+        HIPCHK(h, hipStreamWaitEvent(h->stream2, h->ev_a, 0));
+    }
     for (int parity = 0; parity < 2; ++parity) {
         const int nsl = (T - parity + 1) / 2;
         if (nsl <= 0) continue;
-        hipLaunchKernelGGL((k_spec_propose<DD>), dim3((N + 255) / 256, nsl), dim3(256), 0,
-                           h->stream, v, sb, iter, parity);
+        const int ng = (nq > 1 && nsl >= 2) ? 2 : 1;
+        const int first[3] = {0, ng == 2 ? (nsl + 1) / 2 : nsl, nsl};
+        for (int g = 0; g < ng; ++g) {
+            SpecBuf sg = sb; sg.s0 = first[g];
+            hipLaunchKernelGGL((k_spec_propose<DD>), dim3((N + 255) / 256, first[g + 1] - first[g]),
+                               dim3(256), 0, qs[g], v, sg, iter, parity);
+        }
         for (int j0 = 0; j0 < N; j0 += B) {
             const int nb = std::min(B, N - j0);
-            const dim3 grid((unsigned)(nsl * nb * parts));
-            {
-                ProfScope pe(h, DLSM_K_SWEEP_EVAL);
-                if (h->model == DLSM_UNDIRECTED)
-                    hipLaunchKernelGGL((k_spec_eval<DD, DLSM_UNDIRECTED>), grid,
-                                       dim3(SP_EV_THREADS), 0, h->stream, v, sb, parity, j0, nb);
-                else
-                    hipLaunchKernelGGL((k_spec_eval<DD, DLSM_DIRECTED>), grid,
-                                       dim3(SP_EV_THREADS), 0, h->stream, v, sb, parity, j0, nb);
+            for (int g = 0; g < ng; ++g) {
+                SpecBuf sg = sb; sg.s0 = first[g];
+                const int ns = first[g + 1] - first[g];
+                const dim3 grid((unsigned)(ns * nb * parts));
+                {
+                    ProfScope pe(h, DLSM_K_SWEEP_EVAL);
+                    if (h->model == DLSM_UNDIRECTED)
+                        hipLaunchKernelGGL((k_spec_eval<DD, DLSM_UNDIRECTED>), grid,
+                                           dim3(SP_EV_THREADS), 0, qs[g], v, sg, parity, j0, nb);
+                    else
+                        hipLaunchKernelGGL((k_spec_eval<DD, DLSM_DIRECTED>), grid,
+                                           dim3(SP_EV_THREADS), 0, qs[g], v, sg, parity, j0, nb);
+                }
+                {
+                    ProfScope pr(h, DLSM_K_SWEEP_RESOLVE);
+                    hipLaunchKernelGGL(resolve, dim3(ns), dim3(SP_RES_THREADS),
+                                       (size_t)nb * B * sizeof(double), qs[g], v, sg, parity,
+                                       j0, nb);
+                }
             }
-            {
-                ProfScope pr(h, DLSM_K_SWEEP_RESOLVE);
-                hipLaunchKernelGGL(resolve, dim3(nsl), dim3(SP_RES_THREADS),
-                                   (size_t)nb * B * sizeof(double), h->stream, v, sb, parity,
-                                   j0, nb);
+        }
+        if (nq > 1) {   // the next parity (or the caller) needs every slice of this one
+            HIPCHK(h, hipEventRecord(h->ev_b, h->stream2));
+            HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_b, 0));
+            if (parity == 0) {
+                HIPCHK(h, hipEventRecord(h->ev_a, h->stream));
+                HIPCHK(h, hipStreamWaitEvent(h->stream2, h->ev_a, 0));
             }
         }
     }

@@ -58,6 +58,8 @@ struct dlsm_chain {
     int T = 0, N = 0, D = 0, model = 0, squared = 0;
     uint64_t seed = 0; uint32_t chain = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;          // second queue of the speculative sweep
+    hipEvent_t ev_a = nullptr, ev_b = nullptr;
     // network
     int W = 0;
     uint32_t *ybits = nullptr, *ytbits = nullptr;

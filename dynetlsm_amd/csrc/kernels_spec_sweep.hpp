@@ -38,6 +38,7 @@ struct SpecBuf {
     double *Ht;      // [nsl][B][B]     : Ht[m][k] = H[k][m], k > m
     double *consts;  // [2] : E = exp(sum of intercepts), flush interval
     int B, parts;
+    int s0;          // first slice (of the parity) served by this launch
 };
 
 __device__ __forceinline__ int flush_interval(double E_max) {
@@ -52,7 +53,7 @@ template <int D>
 __global__ __launch_bounds__(256) void k_spec_propose(ChainView c, SpecBuf sb,
                                                       uint32_t iter, int parity) {
     const int N = c.N;
-    const int s = blockIdx.y;
+    const int s = sb.s0 + blockIdx.y;
     const int t = 2 * s + parity;
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
@@ -166,7 +167,7 @@ __global__ __launch_bounds__(SP_EV_THREADS) void k_spec_eval(ChainView c, SpecBu
     const int N = c.N, W = c.W;
     const int p = blockIdx.x % sb.parts;
     const int k = (blockIdx.x / sb.parts) % nb;
-    const int s = blockIdx.x / (sb.parts * nb);
+    const int s = sb.s0 + blockIdx.x / (sb.parts * nb);
     const int t = 2 * s + parity;
     const double *Xt = c.X + (size_t)t * N * D;
     const int jk = j0 + k;
@@ -283,7 +284,7 @@ __global__ __launch_bounds__(SP_RES_THREADS) void k_spec_resolve(ChainView c, Sp
     __shared__ unsigned long long sMask[2][2];
     static_assert(SP_BMAX == 128, "two 64-node halves");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int s = blockIdx.x;
+    const int s = sb.s0 + blockIdx.x;
     const int t = 2 * s + parity;
     const int N = c.N;
     const int ldh = sb.B;
@@ -294,7 +295,10 @@ __global__ __launch_bounds__(SP_RES_THREADS) void k_spec_resolve(ChainView c, Sp
     const int k = 64 * half + lane;
     const bool owner = wave < 2;
     const bool valid = k < nb;
-    double r = 0.0, lu = 0.0;
+    double r = 0.0, lu = 0.0, st = 0.0, x1[D];
+    int32_t na = 0, ns = 0, un = 0;
+#pragma unroll
+    for (int d = 0; d < D; ++d) x1[d] = 0.0;
     if (owner) {
         const int kc = min(k, nb - 1);                        // clamped: no branches
         const double *f = sb.full0 + ((size_t)s * sb.B + kc) * sb.parts;
@@ -308,6 +312,11 @@ __global__ __launch_bounds__(SP_RES_THREADS) void k_spec_resolve(ChainView c, Sp
         const double *pr = sb.prop + ((size_t)s * N + j0 + kc) * (D + 2);
         r = tot + pr[D + 1];
         lu = pr[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) x1[d] = pr[d];
+        // sampler state of the node: loaded now, used after the passes
+        const size_t tjc = (size_t)t * N + j0 + kc;
+        st = c.step[tjc]; na = c.nacc[tjc]; ns = c.nsteps[tjc]; un = c.until[tjc];
     }
     // stage rows 0..nb-1 of H^T as one flat, fully coalesced copy with many loads in
     // flight per lane (entries at or below the diagonal are never read)
@@ -371,12 +380,9 @@ __global__ __launch_bounds__(SP_RES_THREADS) void k_spec_resolve(ChainView c, Sp
         const int accepted = (int)((sMask[cur][half] >> lane) & 1ull);
         const size_t tj = (size_t)t * N + j0 + k;
         if (accepted) {
-            const double *pr = sb.prop + ((size_t)s * N + j0 + k) * (D + 2);
 #pragma unroll
-            for (int d = 0; d < D; ++d) c.X[tj * D + d] = pr[d];
+            for (int d = 0; d < D; ++d) c.X[tj * D + d] = x1[d];
         }
-        double st = c.step[tj];
-        int32_t na = c.nacc[tj], ns = c.nsteps[tj], un = c.until[tj];
         metropolis_bookkeeping(st, na, ns, un, c.tune, c.tune_interval, accepted);
         c.step[tj] = st; c.nacc[tj] = na; c.nsteps[tj] = ns; c.until[tj] = un;
     }
