@@ -69,19 +69,31 @@ def truncated_normal_logpdf(x, mean, var, lower=0, upper=1):
 
 
 def sample_tables(n, beta, alpha_init, alpha, kappa, rng):
-    """sample_auxillary.py:6-28 : number of tables serving each dish"""
+    """sample_auxillary.py:6-28 : number of tables serving each dish.
+
+    The reference draws ``rng.binomial(1, p / (p + arange(n_tjk)))`` cell by cell;
+    the legacy numpy sampler consumes its stream element by element, so ONE call
+    on the concatenation of all cells' probability vectors (same cell order)
+    yields the same draws without T*K*K Python-level calls."""
     T, K, _ = n.shape
     m = np.zeros((T, K, K), dtype=np.int64)
-    probas = alpha_init * beta
-    for k in range(K):
-        x = rng.binomial(1, probas[k] / (probas[k] + np.arange(n[0, 0, k])))
-        m[0, 0, k] = np.sum(x)
-    probas = alpha * beta + kappa * np.eye(K)
-    for t in range(1, T):
-        for j in range(K):
-            for k in range(K):
-                x = rng.binomial(1, probas[j, k] / (probas[j, k] + np.arange(n[t, j, k])))
-                m[t, j, k] = np.sum(x)
+    cnt0 = n[0, 0].astype(np.int64)
+    pr0 = alpha_init * beta
+    cnt1 = n[1:].astype(np.int64).reshape(-1)                  # (t, j, k) order
+    pr1 = np.tile((alpha * beta + kappa * np.eye(K)).reshape(-1), T - 1)
+    counts = np.concatenate([cnt0, cnt1])
+    probas = np.concatenate([pr0, pr1])
+    total = int(counts.sum())
+    if total == 0:
+        return m
+    seg = np.repeat(np.arange(counts.size), counts)
+    starts = np.cumsum(counts) - counts
+    ramp = np.arange(total) - starts[seg]
+    p = probas[seg] / (probas[seg] + ramp)
+    x = rng.binomial(1, p)
+    sums = np.bincount(seg, weights=x, minlength=counts.size).astype(np.int64)
+    m[0, 0] = sums[:K]
+    m[1:] = sums[K:].reshape(T - 1, K, K)
     return m
 
 
@@ -127,35 +139,44 @@ def gibbs_updates(X, z, n, nk, mu, sigma, beta, weights, lmbda, hp, rng):
     for t in range(1, T):
         for k in range(K):
             weights[t, k] = sample_dirichlet(probas[k] + n[t, k], rng)
-    # cluster means (:901-921)
+    # cluster means (:901-921); the per-(t, k) sums over the members of a cluster
+    # are label-wise bincounts instead of T*K boolean masks
+    def by_label(V):          # V (T, N, D) -> (T, K, D) sums over nodes with z[t, i] = k
+        out = np.zeros((T, K, D))
+        for t in range(T):
+            for d in range(D):
+                out[t, :, d] = np.bincount(z[t], weights=V[t, :, d], minlength=K)
+        return out
+    V = X.copy()
+    V[1:] = X[1:] - (1 - lmbda) * X[:-1]
+    S = by_label(V)
     for k in range(K):
         pk = 1 / hp.mean_variance_prior
         mk = np.zeros(D)
         for t in range(T):
             if nk[t, k] > 0:
-                mask = z[t] == k
                 if t == 0:
                     pk = pk + nk[0, k] / sigma[k]
-                    mk = mk + (1 / sigma[k]) * np.sum(X[t, mask], axis=0)
+                    mk = mk + (1 / sigma[k]) * S[0, k]
                 else:
                     pk = pk + (lmbda ** 2 / sigma[k]) * nk[t, k]
-                    mk = mk + (lmbda / sigma[k]) * np.sum(
-                        X[t, mask] - (1 - lmbda) * X[t - 1, mask], axis=0)
+                    mk = mk + (lmbda / sigma[k]) * S[t, k]
         pk = 1 / pk
         mk = mk * pk
         mu[k] = rng.multivariate_normal(mean=mk, cov=pk * np.eye(D))
-    # cluster variances (:924-938)
+    # cluster variances (:924-938): squared residuals per node, summed by label
+    res = X - mu[z]
+    res[1:] = X[1:] - (1 - lmbda) * X[:-1] - lmbda * mu[z[1:]]
+    sq = np.sum(res * res, axis=2)
+    Q = np.zeros((T, K))
+    for t in range(T):
+        Q[t] = np.bincount(z[t], weights=sq[t], minlength=K)
     for k in range(K):
         ak = 0.5 * (np.sum(nk[:, k]) * D + hp.a)
         bk = 0.5 * hp.b
         for t in range(T):
             if nk[t, k] > 0:
-                mask = z[t] == k
-                if t == 0:
-                    bk = bk + 0.5 * np.sum((X[t, mask] - mu[k]) ** 2)
-                else:
-                    bk = bk + 0.5 * np.sum((X[t, mask] - (1 - lmbda) * X[t - 1, mask] -
-                                            lmbda * mu[k]) ** 2)
+                bk = bk + 0.5 * Q[t, k]
         sigma[k] = 1. / rng.gamma(shape=ak, scale=1. / bk)
     # blending coefficient (:941-954)
     ml = 0.0
@@ -204,22 +225,31 @@ def gibbs_updates(X, z, n, nk, mu, sigma, beta, weights, lmbda, hp, rng):
     return beta, lmbda
 
 
+def _dirichlet_logpdf_rows(x, alphas):
+    """row-wise Dirichlet log-density with the clipping of distributions.py:95-100"""
+    from scipy.special import gammaln, xlogy
+    alphas = np.where(alphas <= 0., SMALL_EPS, alphas)
+    x = np.where(x <= 0, SMALL_EPS, x)
+    return (gammaln(alphas.sum(axis=-1)) - gammaln(alphas).sum(axis=-1) +
+            xlogy(alphas - 1, x).sum(axis=-1))
+
+
 def log_posterior_terms(X, intercept, intercept_prior, intercept_variance_prior, mu,
                         sigma, z, weights, beta, lmbda, hp, radii=None):
     """Everything in DynamicNetworkHDPLPCM.logp (hdp_lpcm.py:1188-1280) except
-    the network log-likelihood, which the device supplies."""
+    the network log-likelihood, which the device supplies.  The reference's
+    Python loops over nodes / (t, k) rows are vectorised (same terms, numpy
+    summation order)."""
     T, N, D = X.shape
     K = hp.n_components
-    lp = dirichlet_logpdf(beta, np.repeat(hp.gamma / K, K))
-    lp += dirichlet_logpdf(weights[0, 0], hp.alpha_init * beta)
-    deltas = hp.kappa * np.eye(K)
+    lp = _dirichlet_logpdf_rows(beta, np.repeat(hp.gamma / K, K))
+    lp += _dirichlet_logpdf_rows(weights[0, 0], hp.alpha_init * beta)
+    if T > 1:
+        al = hp.alpha * beta[None, :] + hp.kappa * np.eye(K)          # (K, K)
+        lp += _dirichlet_logpdf_rows(weights[1:], al[None, :, :]).sum()
+    lp += np.log(weights[0, 0, z[0]]).sum()
     for t in range(1, T):
-        for k in range(K):
-            lp += dirichlet_logpdf(weights[t, k], hp.alpha * beta + deltas[k])
-    for i in range(N):
-        lp += np.log(weights[0, 0, z[0, i]])
-        for t in range(1, T):
-            lp += np.log(weights[t, z[t - 1, i], z[t, i]])
+        lp += np.log(weights[t, z[t - 1], z[t]]).sum()
     diff = intercept - intercept_prior
     if radii is not None:
         lp -= np.sum(0.5 * (diff * diff) / intercept_variance_prior)
