@@ -12,6 +12,8 @@ this class keeps the raw traces, applies thinning, and exposes the maximum
 log-posterior sample as ``X_, z_, mu_, ...`` (``selection_type`` other than
 'map' raises).  Missing edges are rejected.
 """
+import time
+
 import numpy as np
 from scipy.stats import dirichlet
 
@@ -227,6 +229,7 @@ class DynamicNetworkHDPLPCM(object):
         chain.set_prior_mixture(mu, sigma, lmbda, z)
         store(0, chain.loglik_full())
         var = self.intercept_variance_prior
+        t_loop = time.perf_counter()
         for it in range(1, n_total):
             if self.case_control_sampler_ is not None:
                 self.case_control_sampler_.resample(it)
@@ -268,6 +271,7 @@ class DynamicNetworkHDPLPCM(object):
             beta, lmbda = hu.gibbs_updates(X, z, n, nk, mu, sigma, beta, weights, lmbda, hp,
                                            rng)
             store(it, ll)
+        self.loop_seconds_ = time.perf_counter() - t_loop     # Gibbs loop only
         chain.get_samplers(self.latent_samplers)
         self.gamma, self.alpha_init, self.alpha, self.kappa = (hp.gamma, hp.alpha_init,
                                                                hp.alpha, hp.kappa)

@@ -15,6 +15,8 @@ Differences from the reference that a user can see:
   * missing edges (-1 coded dyads) are rejected (imputation is out of scope);
   * ``fit(Y, init=...)`` accepts starting values and skips the init pipeline.
 """
+import time
+
 import numpy as np
 from scipy.stats import dirichlet
 
@@ -218,12 +220,14 @@ class DynamicNetworkLSM(object):
         ll0 = chain.loglik_full()
         logp0 = self._log_prior(X, intercept, ip) + ll0
 
+        t_loop = time.perf_counter()
         if not self.is_directed:
             self._fit_undirected(chain, n_total, n_iter_procrustes, logp0, ip)
         else:
             self._fit_directed(chain, rng, X, intercept, radii, n_total, n_iter_procrustes,
                                logp0, ip)
         chain.get_samplers(self.latent_samplers)
+        self.loop_seconds_ = time.perf_counter() - t_loop     # Gibbs loop only
         self._set_map(n_total)
         return self
 
