@@ -256,7 +256,7 @@ void dlsm_destroy(dlsm_chain *h) {
                     h->ctrl_in, h->ctrl_out, h->X, h->intercept, h->radii,
                     h->radii_alt, h->step, h->nacc, h->nsteps, h->until, h->mu,
                     h->sigma, h->z, h->partials, h->dsmall, h->xref, h->lab_n,
-                    h->lab_nk, h->lab_w, h->spec, h->lsm, h->trace_X, h->trace_ic,
+                    h->lab_nk, h->lab_w, h->spec, h->nctrl, h->lsm, h->trace_X, h->trace_ic,
                     h->trace_logp};
     for (void *p : ptrs) if (p) hipFree(p);
     if (h->hsmall) hipHostFree(h->hsmall);
@@ -616,20 +616,18 @@ int dlsm_loglik_partial_all(dlsm_chain *h, int with_prior, double *out) {
 // ---------------------------------------------------------------- sweep
 }  // extern "C"
 
-static bool spec_supported(const dlsm_chain *h) {
-    return h->model == DLSM_UNDIRECTED || h->model == DLSM_DIRECTED;
-}
+static bool spec_supported(const dlsm_chain *h) { (void)h; return true; }
 
 // algo 2: rounds of (chip-wide eval, per-slice resolve) over batches of nodes
 template <int DD>
 static int launch_sweep_spec(dlsm_chain *h, uint32_t iter) {
-    if (!spec_supported(h)) FAIL(h, DLSM_E_ARG, "speculative-batch sweep needs an exact model");
     const int N = h->N, T = h->T;
     const int B = std::min(SP_BMAX, (N + 1) / 2 * 2);   // even: double2 staging
     const int nsl_max = (T + 1) / 2;
     int parts = (1024 + nsl_max * B - 1) / (nsl_max * B);
     if (getenv("DLSM_SPEC_PARTS")) parts = atoi(getenv("DLSM_SPEC_PARTS"));
     parts = std::max(1, std::min(parts, 8));
+    if (h->model == DLSM_DIRECTED_CASE_CONTROL) parts = 1;     // one wave per node
     auto even2 = [](size_t n) { return (n + 1) / 2 * 2; };
     const size_t n_full0 = even2((size_t)nsl_max * B * parts);
     const size_t n_prop = even2((size_t)nsl_max * N * (DD + 2));
@@ -688,9 +686,12 @@ static int launch_sweep_spec(dlsm_chain *h, uint32_t iter) {
                     if (h->model == DLSM_UNDIRECTED)
                         hipLaunchKernelGGL((k_spec_eval<DD, DLSM_UNDIRECTED>), grid,
                                            dim3(SP_EV_THREADS), 0, qs[g], v, sg, parity, j0, nb);
-                    else
+                    else if (h->model == DLSM_DIRECTED)
                         hipLaunchKernelGGL((k_spec_eval<DD, DLSM_DIRECTED>), grid,
                                            dim3(SP_EV_THREADS), 0, qs[g], v, sg, parity, j0, nb);
+                    else
+                        hipLaunchKernelGGL((k_spec_eval_cc<DD>), dim3((unsigned)(ns * nb)),
+                                           dim3(64), 0, qs[g], v, sg, h->nctrl, parity, j0, nb);
                 }
                 {
                     ProfScope pr(h, DLSM_K_SWEEP_RESOLVE);
@@ -776,24 +777,23 @@ static int launch_sweep(dlsm_chain *h, uint32_t iter, int algo) {
     ChainView v = h->view();
     ProfScope ps(h, DLSM_K_SWEEP);
     if (h->model == DLSM_DIRECTED_CASE_CONTROL) {
+        // number of valid (non -1) controls per node and direction
         const size_t TN = (size_t)h->T * h->N;
-        if (!h->lab_nk) {}
-        // nctrl lives at the tail of `spec`
-        size_t need = TN * 2 * sizeof(int32_t);
-        if (h->spec_cap < need) {
-            if (h->spec) hipFree(h->spec);
-            h->spec = nullptr; h->spec_cap = 0;
-            HIPCHK(h, hipMalloc((void **)&h->spec, need));
-            h->spec_cap = need;
+        if (h->nctrl_cap < TN * 2) {
+            if (h->nctrl) hipFree(h->nctrl);
+            h->nctrl = nullptr; h->nctrl_cap = 0;
+            HIPCHK(h, hipMalloc((void **)&h->nctrl, TN * 2 * sizeof(int32_t)));
+            h->nctrl_cap = TN * 2;
         }
-        int32_t *nctrl = (int32_t *)h->spec;
         hipLaunchKernelGGL(k_count_controls, dim3((unsigned)((TN + 255) / 256)), dim3(256),
-                           0, h->stream, h->ctrl_in, h->ctrl_out, (long)TN, h->C, nctrl);
+                           0, h->stream, h->ctrl_in, h->ctrl_out, (long)TN, h->C, h->nctrl);
+        if (algo == 0) algo = h->N >= 256 ? 2 : 1;
+        if (algo >= 2) return launch_sweep_spec<DD>(h, iter);
         for (int parity = 0; parity < 2; ++parity) {
             int nsl = (h->T - parity + 1) / 2;
             if (nsl <= 0) continue;
             hipLaunchKernelGGL((k_sweep_casecontrol<DD>), dim3(nsl), dim3(CC_THREADS), 0,
-                               h->stream, v, nctrl, iter, parity);
+                               h->stream, v, h->nctrl, iter, parity);
         }
         HIPCHK(h, hipGetLastError());
         return DLSM_OK;

@@ -85,6 +85,7 @@ struct dlsm_chain {
     int32_t *lab_n = nullptr, *lab_nk = nullptr; double *lab_w = nullptr;
     // sweep v2 scratch
     double *spec = nullptr; size_t spec_cap = 0;
+    int32_t *nctrl = nullptr; size_t nctrl_cap = 0;     // valid controls per (t, i, dir)
     // LSM device-resident chain
     dlsm::LsmDeviceState *lsm = nullptr;
     dlsm_lsm_config lsm_cfg{};

@@ -269,6 +269,115 @@ __global__ __launch_bounds__(SP_EV_THREADS) void k_spec_eval(ChainView c, SpecBu
     }
 }
 
+// ---------------------------------------------------------------------------
+// Speculative-batch eval for the case-control likelihood (a3 inside a9/a10):
+// one wave per (slice, batch node k).  Node k's ratio has O(deg + 2C) gathered
+// terms; H[k][m] is non-zero only for the few earlier batch nodes m that appear
+// in k's edge / control lists, so the column of H is zero-filled and the hits
+// are accumulated in term order (deterministic) by lane 0.
+//   term kinds: 0 in-edge, 1 out-edge (eta - softplus(eta)),
+//               2 in-control, 3 out-control (- adj * softplus(eta))
+// ---------------------------------------------------------------------------
+constexpr int SPCC_MAXHIT = 2 * SP_BMAX;   // an earlier batch node can sit in at most one
+                                           // in-list and one out-list of node k
+
+template <int D>
+__global__ __launch_bounds__(64) void k_spec_eval_cc(ChainView c, SpecBuf sb,
+                                                     const int32_t *__restrict__ nctrl,
+                                                     int parity, int j0, int nb) {
+    __shared__ int sHitM[SPCC_MAXHIT];
+    __shared__ double sHitV[SPCC_MAXHIT];
+    __shared__ double sCol[SP_BMAX];
+    __shared__ int sNhit;
+    const int lane = threadIdx.x;
+    const int N = c.N;
+    const int k = blockIdx.x % nb;
+    const int s = sb.s0 + blockIdx.x / nb;
+    const int t = 2 * s + parity;
+    const int jk = j0 + k;
+    const size_t node = (size_t)t * N + jk;
+    const double *Xt = c.X + (size_t)t * N * D;
+    const double *prk = sb.prop + ((size_t)s * N + jk) * (D + 2);
+    double xk0[D], xk1[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) { xk0[d] = Xt[(size_t)jk * D + d]; xk1[d] = prk[d]; }
+    const double bin = c.intercept[0], bout = c.intercept[1];
+    const double rj = c.radii[jk];
+    const int in_deg = c.degree[node * 2], out_deg = c.degree[node * 2 + 1];
+    const int nci = nctrl[node * 2], nco = nctrl[node * 2 + 1];
+    const double adj_in = (double)(N - in_deg - 1) / (double)nci;
+    const double adj_out = (double)(N - out_deg - 1) / (double)nco;
+    const int total_terms = in_deg + out_deg + nci + nco;
+    if (lane == 0) sNhit = 0;
+    for (int m = lane; m < SP_BMAX; m += 64) sCol[m] = 0.0;      // column k of H
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    double acc = 0.0;
+    for (int q0 = 0; q0 < total_terms; q0 += 64) {
+        const int q = q0 + lane;
+        int e = -1, kind = 0;
+        if (q < total_terms) {
+            int r = q;
+            if (r < in_deg) { e = c.in_edges[node * c.Din + r]; kind = 0; }
+            else if ((r -= in_deg) < out_deg) { e = c.out_edges[node * c.Dout + r]; kind = 1; }
+            else if ((r -= out_deg) < nci) { e = c.ctrl_in[node * c.C + r]; kind = 2; }
+            else { r -= nci; e = c.ctrl_out[node * c.C + r]; kind = 3; }
+        }
+        double contrib = 0.0, hval = 0.0;
+        bool hit = false;
+        if (e >= 0) {
+            double xe[D];
+#pragma unroll
+            for (int d = 0; d < D; ++d) xe[d] = Xt[(size_t)e * D + d];
+            const double re = c.radii[e];
+            const bool in_dir = (kind == 0 || kind == 2);
+            const double wsp = kind < 2 ? 1.0 : (kind == 2 ? adj_in : adj_out);
+            auto eta_of = [&](double dd) {
+                return in_dir ? bin * (1 - dd / rj) + bout * (1 - dd / re)
+                              : bin * (1 - dd / re) + bout * (1 - dd / rj);
+            };
+            // delta of this term when k moves, the neighbour at position xn
+            auto delta = [&](const double *xn, bool self) {
+                const double d0 = self ? 0.0 : dist_of<D>(xn, xk0, c.squared);
+                const double d1 = self ? 0.0 : dist_of<D>(xn, xk1, c.squared);
+                const double e0 = eta_of(d0), e1 = eta_of(d1);
+                const double sp = log((1.0 + exp(e1)) / (1.0 + exp(e0)));
+                return (kind < 2 ? (e1 - e0) : 0.0) - wsp * sp;
+            };
+            contrib = delta(xe, e == jk);
+            if (e >= j0 && e < jk) {        // an earlier node of this batch
+                const double *pre = sb.prop + ((size_t)s * N + e) * (D + 2);
+                double xe1[D];
+#pragma unroll
+                for (int d = 0; d < D; ++d) xe1[d] = pre[d];
+                hval = delta(xe1, false) - contrib;
+                hit = true;
+            }
+        }
+        acc += contrib;
+        // record the hits of this chunk in term order
+        const unsigned long long hm = __ballot(hit);
+        if (hit) {
+            const int pos = sNhit + __popcll(hm & ((1ull << lane) - 1ull));
+            if (pos < SPCC_MAXHIT) { sHitM[pos] = e - j0; sHitV[pos] = hval; }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) sNhit = min(sNhit + (int)__popcll(hm), 1 << 20);
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+    }
+    const double total = wave_sum_all(acc);
+    if (lane == 0) {
+        sb.full0[((size_t)s * sb.B + k) * sb.parts] = total;
+        const int nh = min(sNhit, SPCC_MAXHIT);
+        for (int q = 0; q < nh; ++q) sCol[sHitM[q]] += sHitV[q];     // term order
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    for (int m = lane; m < k; m += 64) sb.Ht[((size_t)s * sb.B + m) * sb.B + k] = sCol[m];
+}
+
 constexpr int SP_RES_THREADS = 1024;    // 16 waves: wide staging + parallel passes
 
 // Resolve one batch (see the header comment and resolve_fixed_point): the
