@@ -409,10 +409,47 @@ def gen_hdp_trace(ref):
     print('hdp_trace.npz: %d arrays, %d iterations' % (len(out), cap['traces']['Xs'].shape[0]))
 
 
+def gen_more_envelopes(ref, Yd):
+    """chain-level summaries of the reference for the directed LSM on monks and
+    for the HDP-LPCM on a small synthetic network (several seeds each)."""
+    import dynetlsm.hdp_lpcm as hm
+    hm.geweke_diag = lambda *a, **k: np.nan
+    rows = []
+    for s in range(6):
+        m = ref.DynamicNetworkLSM(n_iter=400, tune=200, burn=200, is_directed=True,
+                                  random_state=s).fit(Yd)
+        keep = slice(400, None)
+        rows.append([m.intercepts_[keep, 0].mean(), m.intercepts_[keep, 1].mean(),
+                     m.logps_[keep].mean(), m.logps_[keep].std(),
+                     (m.radiis_[keep] ** 2).sum(axis=1).mean()])
+    out = dict(directed_summaries=np.array(rows),
+               directed_columns=np.array(['intercept_in_mean', 'intercept_out_mean',
+                                          'logp_mean', 'logp_sd', 'radii_sq_sum_mean']))
+    g = np.load(os.path.join(HERE, 'hdp_trace.npz'))
+    Y = g['Y']
+    rows = []
+    for s in range(5):
+        m = ref.DynamicNetworkHDPLPCM(n_iter=300, tune=150, burn=150, n_components=4,
+                                      selection_type='map', random_state=s).fit(Y)
+        keep = slice(300, None)
+        nclu = np.array([[len(np.unique(z[t])) for t in range(z.shape[0])]
+                         for z in m.zs_[keep]]).mean()
+        rows.append([m.intercepts_[keep, 0].mean(), m.lambdas_[keep, 0].mean(),
+                     nclu, m.sigmas_[keep].mean()])
+    out.update(hdp_summaries=np.array(rows),
+               hdp_columns=np.array(['intercept_mean', 'lambda_mean', 'mean_n_clusters',
+                                     'sigma_mean']))
+    np.savez_compressed(os.path.join(HERE, 'more_envelopes.npz'), **out)
+    print('more_envelopes.npz')
+
+
 if __name__ == '__main__':
     ref = import_reference()
     if len(sys.argv) > 1 and sys.argv[1] == 'hdp':
         gen_hdp_trace(ref)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'env2':
+        gen_more_envelopes(ref, np.load(os.path.join(HERE, 'monks.npz'))['Y_directed'])
         sys.exit(0)
     gen_likelihoods(ref)
     gen_sweeps(ref)
@@ -420,3 +457,4 @@ if __name__ == '__main__':
     gen_fit_traces(ref, Yd, Yu)
     gen_chain_envelopes(ref, Yu)
     gen_hdp_trace(ref)
+    gen_more_envelopes(ref, Yd)

@@ -121,3 +121,56 @@ def test_monks_posterior_within_mc_error_of_reference(eng):
         mu_g, sd_g = got[:, k].mean(), got[:, k].std(ddof=1)
         se = np.sqrt(sd_r ** 2 / ref.shape[0] + sd_g ** 2 / got.shape[0])
         assert abs(mu_g - mu_r) < 4 * se + 0.02 * abs(mu_r), (name, mu_g, mu_r, se)
+
+
+def _compare_to_envelope(ref, cols, got, names, slack):
+    for name in names:
+        k = cols.index(name)
+        mu_r, sd_r = ref[:, k].mean(), ref[:, k].std(ddof=1)
+        mu_g, sd_g = got[:, k].mean(), got[:, k].std(ddof=1)
+        se = np.sqrt(sd_r ** 2 / ref.shape[0] + sd_g ** 2 / got.shape[0])
+        assert abs(mu_g - mu_r) < 4 * se + slack * abs(mu_r), (name, mu_g, mu_r, se)
+
+
+def test_monks_directed_posterior_within_mc_error_of_reference(eng):
+    """directed DynamicNetworkLSM on monks: intercepts, radii concentration and
+    log-posterior level against 6 seeds of the reference"""
+    env = load_golden('more_envelopes.npz')
+    cols = list(env['directed_columns'])
+    Y = load_golden('monks.npz')['Y_directed']
+    got = []
+    for seed in range(6):
+        m = eng.DynamicNetworkLSM(n_iter=400, tune=200, burn=200, is_directed=True,
+                                  random_state=seed, chain_id=seed).fit(Y)
+        keep = slice(400, None)
+        got.append([m.intercepts_[keep, 0].mean(), m.intercepts_[keep, 1].mean(),
+                    m.logps_[keep].mean(), m.logps_[keep].std(),
+                    (m.radiis_[keep] ** 2).sum(axis=1).mean()])
+    _compare_to_envelope(env['directed_summaries'], cols, np.array(got),
+                         ['logp_mean', 'logp_sd', 'radii_sq_sum_mean'], 0.03)
+    # the two intercepts are weakly identified individually; their sum is not
+    ref = env['directed_summaries']
+    s_ref = ref[:, 0] + ref[:, 1]
+    s_got = np.array(got)[:, 0] + np.array(got)[:, 1]
+    se = np.sqrt(s_ref.var(ddof=1) / 6 + s_got.var(ddof=1) / 6)
+    assert abs(s_got.mean() - s_ref.mean()) < 4 * se + 0.03
+
+
+def test_hdp_lpcm_posterior_within_mc_error_of_reference(eng):
+    """DynamicNetworkHDPLPCM on the small synthetic network of the HDP golden
+    trace (T=3, N=24, K=4): posterior means of the intercept, the blending
+    coefficient and the number of occupied clusters against 5 reference seeds"""
+    env = load_golden('more_envelopes.npz')
+    cols = list(env['hdp_columns'])
+    Y = load_golden('hdp_trace.npz')['Y']
+    got = []
+    for seed in range(5):
+        m = eng.DynamicNetworkHDPLPCM(n_iter=300, tune=150, burn=150, n_components=4,
+                                      random_state=seed, chain_id=seed).fit(Y)
+        keep = slice(300, None)
+        nclu = np.array([[len(np.unique(z[t])) for t in range(z.shape[0])]
+                         for z in m.zs_[keep]]).mean()
+        got.append([m.intercepts_[keep, 0].mean(), m.lambdas_[keep, 0].mean(), nclu,
+                    m.sigmas_[keep].mean()])
+    _compare_to_envelope(env['hdp_summaries'], cols, np.array(got),
+                         ['intercept_mean', 'lambda_mean', 'mean_n_clusters'], 0.05)
