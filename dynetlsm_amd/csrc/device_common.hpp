@@ -99,6 +99,58 @@ __device__ __forceinline__ double dist_of(const double *a, const double *b,
     return squared ? s : sqrt(s);
 }
 
+
+// ---- lean float64 sqrt / exp for the hot loops ---------------------------------
+// Same algorithms as the compiler's expansions (Goldschmidt refinement of
+// v_rsq_f64; argument reduction + polynomial + ldexp) without the subnormal /
+// huge-argument rescaling: squared distances between latent positions and
+// exponents in [-745, 709] never need it.  Both are accurate to ~1 ulp.
+__device__ __forceinline__ double fast_sqrt(double s) {
+    const double y = __builtin_amdgcn_rsq(s);
+    double g = s * y, h = 0.5 * y;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    double e = fma(-g, g, s);
+    g = fma(e, h, g);
+    e = fma(-g, g, s);
+    g = fma(e, h, g);
+    return s > 0.0 ? g : 0.0;             // s == 0: rsq = inf
+}
+
+__device__ __forceinline__ double fast_exp(double x) {
+    const double k = rint(x * 1.4426950408889634074);
+    double r = fma(k, -6.93147180369123816490e-01, x);
+    r = fma(k, -1.90821492927058770002e-10, r);      // |r| <= ln2 / 2
+    // Taylor to r^13: truncation < 4e-18 relative on |r| <= 0.3466
+    double p = 1.6059043836821613e-10;               // 1/13!
+    p = fma(p, r, 2.08767569878681e-09);             // 1/12!
+    p = fma(p, r, 2.505210838544172e-08);            // 1/11!
+    p = fma(p, r, 2.755731922398589e-07);            // 1/10!
+    p = fma(p, r, 2.7557319223985893e-06);           // 1/9!
+    p = fma(p, r, 2.48015873015873e-05);             // 1/8!
+    p = fma(p, r, 1.984126984126984e-04);            // 1/7!
+    p = fma(p, r, 1.388888888888889e-03);            // 1/6!
+    p = fma(p, r, 8.333333333333333e-03);            // 1/5!
+    p = fma(p, r, 4.1666666666666664e-02);           // 1/4!
+    p = fma(p, r, 1.6666666666666666e-01);           // 1/3!
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return __builtin_ldexp(p, (int)k);
+}
+
+template <int D>
+__device__ __forceinline__ double dist_fast(const double *a, const double *b, int squared) {
+    double s = 0.0;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        double df = a[d] - b[d];
+        s += df * df;
+    }
+    return squared ? s : fast_sqrt(s);
+}
+
 __device__ __forceinline__ int bit_of(const uint32_t *row, int i) {
     return (row[i >> 5] >> (i & 31)) & 1;
 }

@@ -118,12 +118,12 @@ __global__ __launch_bounds__(LL_THREADS) void k_loglik_undirected(
         for (int r = rbeg; r < rbeg + 64; ++r) {
             const int i = i0 + r;
             if (i >= j) break;           // i < j only (also stops at i >= N)
-            const double dd = dist_of<D>(&sXi[r * D], xj, c.squared);
-            const double e = exp(-dd);
+            const double dd = dist_fast<D>(&sXi[r * D], xj, c.squared);
+            const double e = fast_exp(-dd);
             const int y = (sY[r * 4 + (cj >> 5)] >> (cj & 31)) & 1;
             if (y) { sy += 1.0; syd += dd; }
 #pragma unroll
-            for (int k = 0; k < M; ++k) P[k] *= 1.0 + E[k] * e;
+            for (int k = 0; k < M; ++k) P[k] *= fma(E[k], e, 1.0);
             if (++cnt >= nflush) {
 #pragma unroll
                 for (int k = 0; k < M; ++k) { S[k] += log(P[k]); P[k] = 1.0; }
@@ -321,17 +321,21 @@ __global__ __launch_bounds__(256) void k_loglik_casecontrol(
 // workgroup, fixed strided order + fixed tree.  out[q] = sum_r rec[r][q].
 __device__ __forceinline__ void reduce_records(const double *__restrict__ rec,
                                                int nrec, int width, double *sums,
-                                               double *scratch /*256*/, int tid) {
-    for (int q = 0; q < width; ++q) {
-        double s = 0.0;
-        for (int r = tid; r < nrec; r += 256) s += rec[(size_t)r * width + q];
-        scratch[tid] = s;
+                                               double *scratch /*4 * 256*/, int tid) {
+    // up to 4 columns at a time share one tree (and its barriers)
+    for (int q0 = 0; q0 < width; q0 += 4) {
+        const int nq = min(4, width - q0);
+        double s[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int r = tid; r < nrec; r += 256)
+            for (int q = 0; q < nq; ++q) s[q] += rec[(size_t)r * width + q0 + q];
+        for (int q = 0; q < 4; ++q) scratch[q * 256 + tid] = s[q];
         __syncthreads();
         for (int off = 128; off > 0; off >>= 1) {
-            if (tid < off) scratch[tid] += scratch[tid + off];
+            if (tid < off)
+                for (int q = 0; q < 4; ++q) scratch[q * 256 + tid] += scratch[q * 256 + tid + off];
             __syncthreads();
         }
-        if (tid == 0) sums[q] = scratch[0];
+        if (tid < nq) sums[q0 + tid] = scratch[tid * 256];
         __syncthreads();
     }
 }
@@ -340,7 +344,7 @@ __device__ __forceinline__ void reduce_records(const double *__restrict__ rec,
 __global__ __launch_bounds__(256) void k_reduce_loglik(
     const double *__restrict__ partials, int nrec, int model, int M,
     const double *__restrict__ intercepts, double *__restrict__ out) {
-    __shared__ double scratch[256];
+    __shared__ double scratch[4 * 256];
     __shared__ double sums[8];
     const int width = model == DLSM_UNDIRECTED ? 2 + M : M;
     reduce_records(partials, nrec, width, sums, scratch, threadIdx.x);

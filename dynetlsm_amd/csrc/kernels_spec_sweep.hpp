@@ -163,6 +163,7 @@ __global__ __launch_bounds__(SP_EV_THREADS) void k_spec_eval(ChainView c, SpecBu
     __shared__ double sx0[SP_BMAX * D];
     __shared__ double sx1[SP_BMAX * D];
     __shared__ double sRed[SP_EV_THREADS / 64];
+    __shared__ double sLin[SP_EV_THREADS], sP0[SP_EV_THREADS], sP1[SP_EV_THREADS];
     const int tid = threadIdx.x;
     const int N = c.N, W = c.W;
     const int p = blockIdx.x % sb.parts;
@@ -213,14 +214,16 @@ __global__ __launch_bounds__(SP_EV_THREADS) void k_spec_eval(ChainView c, SpecBu
     double acc = 0.0;
     RatioAcc ra;
     auto term = [&](int i, const double *xi, int ybit, int ycbit) {
-        const double d0 = dist_of<D>(xi, xk0, c.squared);
-        const double d1 = dist_of<D>(xi, xk1, c.squared);
         if (MODEL == DLSM_UNDIRECTED) {
+            const double d0 = dist_fast<D>(xi, xk0, c.squared);
+            const double d1 = dist_fast<D>(xi, xk1, c.squared);
             if (ybit) ra.lin += d0 - d1;
-            ra.P0 *= 1.0 + E * exp(-d0);
-            ra.P1 *= 1.0 + E * exp(-d1);
+            ra.P0 *= fma(E, fast_exp(-d0), 1.0);
+            ra.P1 *= fma(E, fast_exp(-d1), 1.0);
             if (++ra.cnt >= nflush) ra.flush();
         } else {
+            const double d0 = dist_of<D>(xi, xk0, c.squared);
+            const double d1 = dist_of<D>(xi, xk1, c.squared);
             const double iri = 1.0 / c.radii[i];
             acc += delta_directed(d0, d1, ybit, ycbit, bin * iri + bout * irk,
                                   bin * irk + bout * iri, E);
@@ -239,23 +242,48 @@ __global__ __launch_bounds__(SP_EV_THREADS) void k_spec_eval(ChainView c, SpecBu
         for (int d = 0; d < D; ++d) xi[d] = Xt[(size_t)i * D + d];
         term(i, xi, bit_of(yr, i), MODEL == DLSM_DIRECTED ? bit_of(yc, i) : 0);
     }
-    if (MODEL == DLSM_UNDIRECTED) acc = ra.value();
-    const double total = block_sum_all<SP_EV_THREADS / 64>(acc, sRed, tid);
-    if (tid == 0) sb.full0[((size_t)s * sb.B + k) * sb.parts + p] = total;
+    // Workgroup total.  Undirected and the products of the whole workgroup stay in
+    // range (few factors per thread, (1 + E) small): sum the linear parts and MULTIPLY
+    // the products across the workgroup, one log at the end (lane 0 of wave 0) instead
+    // of a division + log per thread and a shuffle tree per wave.
+    // (1 + E)^(hi - lo) < e^600  <=>  flush interval >= number of factors
+    const bool prod_path = MODEL == DLSM_UNDIRECTED && nflush >= hi - lo;
+    if (prod_path) {
+        sLin[tid] = ra.lin + ra.lg; sP0[tid] = ra.P0; sP1[tid] = ra.P1;
+        __syncthreads();
+        if (tid < 64) {
+            double l = 0.0, q0 = 1.0, q1 = 1.0;
+#pragma unroll
+            for (int w = 0; w < SP_EV_THREADS / 64; ++w) {
+                l += sLin[tid + 64 * w]; q0 *= sP0[tid + 64 * w]; q1 *= sP1[tid + 64 * w];
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                l += __shfl_xor(l, off, 64);
+                q0 *= __shfl_xor(q0, off, 64);
+                q1 *= __shfl_xor(q1, off, 64);
+            }
+            if (tid == 0) sb.full0[((size_t)s * sb.B + k) * sb.parts + p] = l + log(q0 / q1);
+        }
+    } else {
+        if (MODEL == DLSM_UNDIRECTED) acc = ra.value();
+        const double total = block_sum_all<SP_EV_THREADS / 64>(acc, sRed, tid);
+        if (tid == 0) sb.full0[((size_t)s * sb.B + k) * sb.parts + p] = total;
+    }
     // effect of an earlier batch node's acceptance on this node's ratio; the parts of
     // node k share the rows: part p takes m = p, p + parts, ...
     const int m = tid * sb.parts + p;
     if (m < k) {
         const int jm = j0 + m;
-        const double a0 = dist_of<D>(&sx0[m * D], xk0, c.squared);
-        const double a1 = dist_of<D>(&sx0[m * D], xk1, c.squared);
-        const double b0 = dist_of<D>(&sx1[m * D], xk0, c.squared);
-        const double b1 = dist_of<D>(&sx1[m * D], xk1, c.squared);
+        const double a0 = dist_fast<D>(&sx0[m * D], xk0, c.squared);
+        const double a1 = dist_fast<D>(&sx0[m * D], xk1, c.squared);
+        const double b0 = dist_fast<D>(&sx1[m * D], xk0, c.squared);
+        const double b1 = dist_fast<D>(&sx1[m * D], xk1, c.squared);
         double h;
         if (MODEL == DLSM_UNDIRECTED) {
             // g1 - g0 with the four softplus terms under one log
-            const double num = (1.0 + E * exp(-b0)) * (1.0 + E * exp(-a1));
-            const double den = (1.0 + E * exp(-b1)) * (1.0 + E * exp(-a0));
+            const double num = fma(E, fast_exp(-b0), 1.0) * fma(E, fast_exp(-a1), 1.0);
+            const double den = fma(E, fast_exp(-b1), 1.0) * fma(E, fast_exp(-a0), 1.0);
             h = log(num / den);
             if (bit_of(yr, jm)) h += (b0 - b1) - (a0 - a1);
         } else {

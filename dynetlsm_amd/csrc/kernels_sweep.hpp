@@ -430,12 +430,16 @@ __global__ __launch_bounds__(PS2_THREADS) void k_post_apply(
     __shared__ double sSum[W];
     __shared__ double sR[D * D];
     __shared__ double sShift[D];
+    __shared__ double sRec[PS_BLOCKS * W];
     const int tid = threadIdx.x;
     const long rows = (long)c.T * c.N;
     double *X = c.X;
+    // records -> LDS with all loads in flight, then a fixed-order sum per column
+    for (int q = tid; q < nrec * W; q += PS2_THREADS) sRec[q] = rec[q];
+    __syncthreads();
     if (tid < W) {
         double s = 0.0;
-        for (int b = 0; b < nrec; ++b) s += rec[(size_t)b * W + tid];
+        for (int b = 0; b < nrec; ++b) s += sRec[b * W + tid];
         sSum[tid] = s;
     }
     __syncthreads();
@@ -513,7 +517,7 @@ __global__ __launch_bounds__(256) void k_lsm_finalize(
     const double *__restrict__ partials, int nrec, LsmDeviceState *lsm,
     double *__restrict__ intercept, double *__restrict__ trace_ic,
     double *__restrict__ trace_logp, int it) {
-    __shared__ double scratch[256];
+    __shared__ double scratch[4 * 256];
     __shared__ double sums[4];
     reduce_records(partials, nrec, 4, sums, scratch, threadIdx.x);
     if (threadIdx.x == 0) {
