@@ -336,13 +336,6 @@ int dlsm_upload_edges(dlsm_chain *h, const int64_t *in_edges, int Din,
     return DLSM_OK;
 }
 
-static int refresh_nctrl(dlsm_chain *h) {
-    const long TN = (long)h->T * h->N;
-    if (!h->lab_nk) {   // reuse: int32 [T*N*2] count buffer lives in spec-free slot
-    }
-    return DLSM_OK;
-}
-
 int dlsm_set_controls(dlsm_chain *h, const int64_t *ctrl_in, const int64_t *ctrl_out,
                       int C) {
     NEED(h, h && ctrl_in && ctrl_out && C > 0, "bad argument");
@@ -353,7 +346,6 @@ int dlsm_set_controls(dlsm_chain *h, const int64_t *ctrl_in, const int64_t *ctrl
     rc = upload_i64_as_i32(h, &h->ctrl_out, ctrl_out, TN * C); if (rc) return rc;
     h->C = C;
     h->have_controls = true;
-    (void)refresh_nctrl;
     return DLSM_OK;
 }
 
@@ -642,7 +634,7 @@ static int launch_sweep_spec(dlsm_chain *h, uint32_t iter) {
     SpecBuf sb;
     sb.full0 = h->spec; sb.prop = sb.full0 + n_full0; sb.Ht = sb.prop + n_prop;
     sb.consts = sb.Ht + n_ht;
-    sb.B = B; sb.parts = parts; sb.s0 = 0;
+    sb.B = B; sb.parts = parts; sb.s0 = 0; sb.per = (N + parts - 1) / parts;
     ChainView v = h->view();
     auto resolve = k_spec_resolve<DD>;
     HIPCHK(h, hipFuncSetAttribute((const void *)resolve,
@@ -680,7 +672,7 @@ static int launch_sweep_spec(dlsm_chain *h, uint32_t iter) {
             for (int g = 0; g < ng; ++g) {
                 SpecBuf sg = sb; sg.s0 = first[g];
                 const int ns = first[g + 1] - first[g];
-                const dim3 grid((unsigned)(ns * nb * parts));
+                const dim3 grid((unsigned)parts, (unsigned)nb, (unsigned)ns);
                 {
                     ProfScope pe(h, DLSM_K_SWEEP_EVAL);
                     if (h->model == DLSM_UNDIRECTED)

@@ -39,6 +39,7 @@ struct SpecBuf {
     double *consts;  // [2] : E = exp(sum of intercepts), flush interval
     int B, parts;
     int s0;          // first slice (of the parity) served by this launch
+    int per;         // neighbours per part = ceil(N / parts)
 };
 
 __device__ __forceinline__ int flush_interval(double E_max) {
@@ -166,16 +167,17 @@ __global__ __launch_bounds__(SP_EV_THREADS) void k_spec_eval(ChainView c, SpecBu
     __shared__ double sLin[SP_EV_THREADS], sP0[SP_EV_THREADS], sP1[SP_EV_THREADS];
     const int tid = threadIdx.x;
     const int N = c.N, W = c.W;
-    const int p = blockIdx.x % sb.parts;
-    const int k = (blockIdx.x / sb.parts) % nb;
-    const int s = sb.s0 + blockIdx.x / (sb.parts * nb);
+    // grid (parts, nb, slices): no integer divisions in the prologue
+    const int p = blockIdx.x;
+    const int k = blockIdx.y;
+    const int s = sb.s0 + blockIdx.z;
     const int t = 2 * s + parity;
     const double *Xt = c.X + (size_t)t * N * D;
     const int jk = j0 + k;
     const uint32_t *yr = c.ybits + ((size_t)t * N + jk) * W;
     const uint32_t *yc = MODEL == DLSM_DIRECTED ? c.ytbits + ((size_t)t * N + jk) * W
                                                 : nullptr;
-    const int per = (N + sb.parts - 1) / sb.parts;
+    const int per = sb.per;
     const int lo = p * per, hi = min(N, lo + per);
     // issue the first neighbours' loads before the staging barrier so that they are
     // in flight together with the prologue's (the kernel is latency bound)

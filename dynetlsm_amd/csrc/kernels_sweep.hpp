@@ -309,7 +309,7 @@ __global__ void k_count_controls(const int32_t *__restrict__ ctrl_in,
 }
 
 // ---------------------------------------------------------------------------
-// Post-sweep glue in ONE single-workgroup kernel (T*N*D is a few 100 KB):
+// Post-sweep glue (two multi-workgroup passes, k_post_reduce / k_post_apply):
 //   1. optional Procrustes rotation to X_ref (procrustes.py:20-35):
 //        M = X^T X_ref, SVD M = U S V^T (one-sided Jacobi), R = U V^T, X <- X R
 //   2. centring X -= mean over (t, i) (lsm.py:501)
@@ -317,7 +317,6 @@ __global__ void k_count_controls(const int32_t *__restrict__ ctrl_in,
 //      and the intercept proposal + log-uniform of sample_intercepts
 //      (sample_coefficients.py:76-86) with Philox stream INTERCEPT.
 // ---------------------------------------------------------------------------
-constexpr int PS_THREADS = 1024;
 
 template <int D>
 __device__ void jacobi_polar(const double (&M)[D][D], double (&R)[D][D]) {
