@@ -275,6 +275,29 @@ def test_sweep_slice_medium(eng, name, N, D):
                 cc_C=20, density=0.05 if name == 'case_control' else 0.2)
 
 
+def test_sweep_squared_distances(eng):
+    """squared=True (static_network_fast.pyx:37-38) through both sweep kernels"""
+    from dynetlsm_amd import Chain, SamplerGrid
+    X, Yd, Yu, radii = _rand_net(77, 3, 200, 2)
+    for algo in (1, 2):
+        og = orc.SamplerGrid(3, 200, 0.1, tune=None)
+        st = orc.ChainState(X, og, Y=Yu, intercept=[0.5], squared=True, tau_sq=2.0,
+                            sigma_sq=0.1, seed=8, chain=0)
+        with Chain(3, 200, 2, 'undirected', seed=8) as c:
+            c.upload_network(Yu); c.set_positions(X); c.set_intercepts([0.5])
+            c.set_squared(True); c.set_prior_random_walk(2.0, 0.1)
+            c.set_samplers(SamplerGrid(3, 200, 0.1, tune=None))
+            for it in (1, 2):
+                c.sweep_positions(it, algo)
+                st.c.iter = it
+                st.sweep_c()
+            np.testing.assert_allclose(c.get_positions(), st.X, atol=1e-9)
+            np.testing.assert_allclose(
+                c.loglik_full([[0.5]])[0],
+                orc.dynamic_network_loglikelihood_undirected(Yu, st.X, 0.5, squared=True),
+                rtol=1e-10)
+
+
 def test_sweep_single_time_step(eng):
     _sweep_case(eng, 'undirected', 'rw', T=1, N=20, D=2, n_sweeps=3, algo=1)
     _sweep_case(eng, 'undirected', 'rw', T=1, N=150, D=2, n_sweeps=3, algo=2)
