@@ -608,18 +608,31 @@ int dlsm_loglik_partial_all(dlsm_chain *h, int with_prior, double *out) {
 // ---------------------------------------------------------------- sweep
 }  // extern "C"
 
-static bool spec_supported(const dlsm_chain *h) { (void)h; return true; }
 
-// algo 2: rounds of (chip-wide eval, per-slice resolve) over batches of nodes
+// algo 2 / 3: rounds of (chip-wide eval, per-slice resolve) over super-batches of
+// S sub-batches of <= 128 nodes (S = 1: algo 2)
+template <int DD, int SBM>
+static void launch_spec_eval(dlsm_chain *h, const ChainView &v, const SpecBuf &sg, dim3 grid,
+                             hipStream_t q, int parity, int j0, int nsb) {
+    if (h->model == DLSM_UNDIRECTED)
+        hipLaunchKernelGGL((k_spec_eval<DD, DLSM_UNDIRECTED, SBM>), grid, dim3(SP_EV_THREADS), 0,
+                           q, v, sg, parity, j0, nsb);
+    else
+        hipLaunchKernelGGL((k_spec_eval<DD, DLSM_DIRECTED, SBM>), grid, dim3(SP_EV_THREADS), 0,
+                           q, v, sg, parity, j0, nsb);
+}
+
 template <int DD>
-static int launch_sweep_spec(dlsm_chain *h, uint32_t iter) {
+static int launch_sweep_spec(dlsm_chain *h, uint32_t iter, int S) {
     const int N = h->N, T = h->T;
-    const int B = std::min(SP_BMAX, (N + 1) / 2 * 2);   // even: double2 staging
+    if (h->model == DLSM_DIRECTED_CASE_CONTROL) S = 1;          // one wave per node there
+    S = std::max(1, std::min(S, SP_SMAX));
+    const int B = std::min(S * SP_BMAX, (N + 1) / 2 * 2);       // even: double2 staging
     const int nsl_max = (T + 1) / 2;
-    int parts = (1024 + nsl_max * B - 1) / (nsl_max * B);
+    int parts = (1024 + nsl_max * SP_BMAX - 1) / (nsl_max * SP_BMAX);
     if (getenv("DLSM_SPEC_PARTS")) parts = atoi(getenv("DLSM_SPEC_PARTS"));
     parts = std::max(1, std::min(parts, 8));
-    if (h->model == DLSM_DIRECTED_CASE_CONTROL) parts = 1;     // one wave per node
+    if (h->model == DLSM_DIRECTED_CASE_CONTROL) parts = 1;
     auto even2 = [](size_t n) { return (n + 1) / 2 * 2; };
     const size_t n_full0 = even2((size_t)nsl_max * B * parts);
     const size_t n_prop = even2((size_t)nsl_max * N * (DD + 2));
@@ -637,9 +650,9 @@ static int launch_sweep_spec(dlsm_chain *h, uint32_t iter) {
     sb.B = B; sb.parts = parts; sb.s0 = 0; sb.per = (N + parts - 1) / parts;
     ChainView v = h->view();
     auto resolve = k_spec_resolve<DD>;
+    const size_t lds = (size_t)SP_BMAX * SP_BMAX * sizeof(double);
     HIPCHK(h, hipFuncSetAttribute((const void *)resolve,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)((size_t)B * B * sizeof(double))));
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     // The slices of a parity are independent, so they can be split over two queues to
     // let one group's resolve overlap the other group's eval.  Measured on MI355X this
     // buys nothing at N=2000 (twice the launches: host bound) and 3.6 % at N=4000 (the
@@ -668,28 +681,29 @@ static int launch_sweep_spec(dlsm_chain *h, uint32_t iter) {
                                dim3(256), 0, qs[g], v, sg, iter, parity);
         }
         for (int j0 = 0; j0 < N; j0 += B) {
-            const int nb = std::min(B, N - j0);
+            const int nsb = std::min(B, N - j0);
             for (int g = 0; g < ng; ++g) {
                 SpecBuf sg = sb; sg.s0 = first[g];
                 const int ns = first[g + 1] - first[g];
-                const dim3 grid((unsigned)parts, (unsigned)nb, (unsigned)ns);
                 {
                     ProfScope pe(h, DLSM_K_SWEEP_EVAL);
-                    if (h->model == DLSM_UNDIRECTED)
-                        hipLaunchKernelGGL((k_spec_eval<DD, DLSM_UNDIRECTED>), grid,
-                                           dim3(SP_EV_THREADS), 0, qs[g], v, sg, parity, j0, nb);
-                    else if (h->model == DLSM_DIRECTED)
-                        hipLaunchKernelGGL((k_spec_eval<DD, DLSM_DIRECTED>), grid,
-                                           dim3(SP_EV_THREADS), 0, qs[g], v, sg, parity, j0, nb);
+                    if (h->model == DLSM_DIRECTED_CASE_CONTROL)
+                        hipLaunchKernelGGL((k_spec_eval_cc<DD>), dim3((unsigned)(ns * nsb)),
+                                           dim3(64), 0, qs[g], v, sg, h->nctrl, parity, j0, nsb);
+                    else if (S == 1)
+                        launch_spec_eval<DD, SP_BMAX>(h, v, sg, dim3(parts, nsb, ns), qs[g],
+                                                      parity, j0, nsb);
+                    else if (S == 2)
+                        launch_spec_eval<DD, 2 * SP_BMAX>(h, v, sg, dim3(parts, nsb, ns), qs[g],
+                                                          parity, j0, nsb);
                     else
-                        hipLaunchKernelGGL((k_spec_eval_cc<DD>), dim3((unsigned)(ns * nb)),
-                                           dim3(64), 0, qs[g], v, sg, h->nctrl, parity, j0, nb);
+                        launch_spec_eval<DD, SP_SMAX * SP_BMAX>(h, v, sg, dim3(parts, nsb, ns),
+                                                                qs[g], parity, j0, nsb);
                 }
                 {
                     ProfScope pr(h, DLSM_K_SWEEP_RESOLVE);
-                    hipLaunchKernelGGL(resolve, dim3(ns), dim3(SP_RES_THREADS),
-                                       (size_t)nb * B * sizeof(double), qs[g], v, sg, parity,
-                                       j0, nb);
+                    hipLaunchKernelGGL(resolve, dim3(ns), dim3(SP_RES_THREADS), lds, qs[g], v, sg,
+                                       parity, j0, nsb);
                 }
             }
         }
@@ -699,64 +713,6 @@ static int launch_sweep_spec(dlsm_chain *h, uint32_t iter) {
             if (parity == 0) {
                 HIPCHK(h, hipEventRecord(h->ev_a, h->stream));
                 HIPCHK(h, hipStreamWaitEvent(h->stream2, h->ev_a, 0));
-            }
-        }
-    }
-    HIPCHK(h, hipGetLastError());
-    return DLSM_OK;
-}
-
-// algo 3: two-level batches: one eval + one resolve launch per super-batch
-template <int DD>
-static int launch_sweep_spec2(dlsm_chain *h, uint32_t iter) {
-    if (!spec_supported(h)) FAIL(h, DLSM_E_ARG, "speculative-batch sweep needs an exact model");
-    const int N = h->N, T = h->T;
-    const int SB = std::min(SP2_SBMAX, (N + 1) / 2 * 2);
-    const int nsl_max = (T + 1) / 2;
-    int parts = (2048 + nsl_max * SB - 1) / (nsl_max * SB);
-    parts = std::max(1, std::min(parts, 8));
-    auto even = [](size_t n) { return (n + 1) / 2 * 2; };
-    const size_t n_full0 = even((size_t)nsl_max * SB * parts);
-    const size_t n_prop = even((size_t)nsl_max * N * (DD + 2));
-    const size_t n_ht = (size_t)nsl_max * SB * SB;
-    const size_t need = (n_full0 + n_prop + n_ht + 2) * sizeof(double);
-    if (h->spec_cap < need) {
-        if (h->spec) hipFree(h->spec);
-        h->spec = nullptr; h->spec_cap = 0;
-        HIPCHK(h, hipMalloc((void **)&h->spec, need));
-        h->spec_cap = need;
-    }
-    SpecBuf2 sb;
-    sb.full0 = h->spec; sb.prop = sb.full0 + n_full0; sb.Ht = sb.prop + n_prop;
-    sb.consts = sb.Ht + n_ht;
-    sb.SB = SB; sb.parts = parts;
-    ChainView v = h->view();
-    auto resolve = k_spec2_resolve<DD>;
-    const size_t lds = (size_t)(SP_BMAX * SP_BMAX + 2 * SP_BMAX) * sizeof(double) +
-                       (size_t)SP2_SBMAX * sizeof(int);
-    HIPCHK(h, hipFuncSetAttribute((const void *)resolve,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    for (int parity = 0; parity < 2; ++parity) {
-        const int nsl = (T - parity + 1) / 2;
-        if (nsl <= 0) continue;
-        hipLaunchKernelGGL((k_spec2_propose<DD>), dim3((N + 255) / 256, nsl), dim3(256), 0,
-                           h->stream, v, sb, iter, parity);
-        for (int j0 = 0; j0 < N; j0 += SB) {
-            const int nsb = std::min(SB, N - j0);
-            const dim3 grid((unsigned)(nsl * nsb * parts));
-            {
-                ProfScope pe(h, DLSM_K_SWEEP_EVAL);
-                if (h->model == DLSM_UNDIRECTED)
-                    hipLaunchKernelGGL((k_spec2_eval<DD, DLSM_UNDIRECTED>), grid,
-                                       dim3(SP_THREADS), 0, h->stream, v, sb, parity, j0, nsb);
-                else
-                    hipLaunchKernelGGL((k_spec2_eval<DD, DLSM_DIRECTED>), grid,
-                                       dim3(SP_THREADS), 0, h->stream, v, sb, parity, j0, nsb);
-            }
-            {
-                ProfScope pr(h, DLSM_K_SWEEP_RESOLVE);
-                hipLaunchKernelGGL(resolve, dim3(nsl), dim3(SP_THREADS), lds, h->stream, v,
-                                   sb, parity, j0, nsb);
             }
         }
     }
@@ -780,7 +736,7 @@ static int launch_sweep(dlsm_chain *h, uint32_t iter, int algo) {
         hipLaunchKernelGGL(k_count_controls, dim3((unsigned)((TN + 255) / 256)), dim3(256),
                            0, h->stream, h->ctrl_in, h->ctrl_out, (long)TN, h->C, h->nctrl);
         if (algo == 0) algo = h->N >= 256 ? 2 : 1;
-        if (algo >= 2) return launch_sweep_spec<DD>(h, iter);
+        if (algo >= 2) return launch_sweep_spec<DD>(h, iter, 1);
         for (int parity = 0; parity < 2; ++parity) {
             int nsl = (h->T - parity + 1) / 2;
             if (nsl <= 0) continue;
@@ -790,9 +746,10 @@ static int launch_sweep(dlsm_chain *h, uint32_t iter, int algo) {
         HIPCHK(h, hipGetLastError());
         return DLSM_OK;
     }
-    if (algo == 0) algo = spec_supported(h) && h->N >= 256 ? 2 : 1;
-    if (algo == 2) return launch_sweep_spec<DD>(h, iter);
-    if (algo == 3) return launch_sweep_spec2<DD>(h, iter);
+    if (algo == 0) algo = h->N >= 512 ? 3 : (h->N >= 256 ? 2 : 1);
+    if (algo == 2) return launch_sweep_spec<DD>(h, iter, 1);
+    if (algo == 3)
+        return launch_sweep_spec<DD>(h, iter, getenv("DLSM_SPEC_S") ? atoi(getenv("DLSM_SPEC_S")) : 2);
     const size_t lds = sweep_slice_lds_bytes(h->N, DD, h->W, h->model);
     if (lds > 160 * 1024)
         FAIL(h, DLSM_E_LIMIT, "N=%d needs %zu B of LDS in the slice sweep (max 163840)",

@@ -91,78 +91,15 @@ struct RatioAcc {
 
 
 
-// In-order resolution of one batch of <= 128 nodes by one wave (lane l owns
-// nodes l and l + 64).  The sequential rule is the triangular system
-//     a_k = [ log u_k < r_k + sum_{m<k} a_m H[k][m] ],   k = 0, 1, ...
-// Instead of walking it node by node (one dependent LDS read + ballot per
-// acceptance) iterate the map a -> F(a): given a guess of the accepted set, every
-// lane adds the H rows of the guessed nodes before it, in ascending order, and
-// re-tests its own nodes.  A fixed point satisfies the triangular system, whose
-// solution is unique (forward substitution), so it IS the sequential result;
-// after n passes the first n decisions are final, and because |H| is tiny next
-// to the ratios the guess "accept iff the uncorrected ratio accepts" is almost
-// always stable after two passes.  A pass has no vector->scalar dependency.
-// sH: H^T rows with leading dimension ldh (entry [m][k], k > m; junk elsewhere).
-__device__ __forceinline__ void resolve_fixed_point(bool valid0, bool valid1, double lu0,
-                                                    double lu1, double r0, double r1,
-                                                    const double *sH, int ldh, int lane,
-                                                    unsigned long long &acc0,
-                                                    unsigned long long &acc1) {
-    unsigned long long g0 = __ballot(valid0 && !(lu0 >= r0));
-    unsigned long long g1 = __ballot(valid1 && !(lu1 >= r1));
-    const double *col0 = sH + lane, *col1 = sH + 64 + lane;
-    for (int pass = 0; pass < 2 * SP_BMAX + 2; ++pass) {
-        double q0 = r0, q1 = r1;
-        unsigned long long mm = g0;
-        while (mm) {                               // guessed nodes of the first half
-            int f[4];
-            double h0[4], h1[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                f[u] = mm ? __builtin_ctzll(mm) : 64;     // 64: no node, adds nothing
-                mm &= mm - 1ull;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int fu = f[u] < 64 ? f[u] : 0;
-                h0[u] = col0[fu * ldh];
-                h1[u] = col1[fu * ldh];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                q0 += (lane > f[u] && f[u] < 64) ? h0[u] : 0.0;
-                q1 += f[u] < 64 ? h1[u] : 0.0;
-            }
-        }
-        mm = g1;
-        while (mm) {                               // guessed nodes of the second half
-            int f[4];
-            double h1[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                f[u] = mm ? __builtin_ctzll(mm) : 64;
-                mm &= mm - 1ull;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) h1[u] = col1[((f[u] < 64 ? f[u] : 0) + 64) * ldh];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) q1 += (lane > f[u] && f[u] < 64) ? h1[u] : 0.0;
-        }
-        const unsigned long long n0 = __ballot(valid0 && !(lu0 >= q0));
-        const unsigned long long n1 = __ballot(valid1 && !(lu1 >= q1));
-        if (n0 == g0 && n1 == g1) break;
-        g0 = n0; g1 = n1;
-    }
-    acc0 = g0; acc1 = g1;
-}
-
 constexpr int SP_EV_THREADS = 256;     // eval workgroup (>= SP_BMAX so tid covers m < k)
 
-template <int D, int MODEL>
+// SBM = capacity of a super-batch (S sub-batches of SP_BMAX nodes): sizes the LDS copy
+// of the batch positions / proposals.
+template <int D, int MODEL, int SBM>
 __global__ __launch_bounds__(SP_EV_THREADS) void k_spec_eval(ChainView c, SpecBuf sb,
                                                           int parity, int j0, int nb) {
-    __shared__ double sx0[SP_BMAX * D];
-    __shared__ double sx1[SP_BMAX * D];
+    __shared__ double sx0[SBM * D];
+    __shared__ double sx1[SBM * D];
     __shared__ double sRed[SP_EV_THREADS / 64];
     __shared__ double sLin[SP_EV_THREADS], sP0[SP_EV_THREADS], sP1[SP_EV_THREADS];
     const int tid = threadIdx.x;
@@ -195,13 +132,13 @@ __global__ __launch_bounds__(SP_EV_THREADS) void k_spec_eval(ChainView c, SpecBu
     const double E = sb.consts[0];
     const int nflush = (int)sb.consts[1];
     // positions / proposals of the batch nodes m <= k
-    if (tid <= k) {
-        const int j = j0 + tid;
+    for (int m = tid; m <= k; m += SP_EV_THREADS) {
+        const int j = j0 + m;
         const double *pr = sb.prop + ((size_t)s * N + j) * (D + 2);
 #pragma unroll
         for (int d = 0; d < D; ++d) {
-            sx0[tid * D + d] = Xt[(size_t)j * D + d];
-            sx1[tid * D + d] = pr[d];
+            sx0[m * D + d] = Xt[(size_t)j * D + d];
+            sx1[m * D + d] = pr[d];
         }
     }
     __syncthreads();
@@ -274,8 +211,7 @@ __global__ __launch_bounds__(SP_EV_THREADS) void k_spec_eval(ChainView c, SpecBu
     }
     // effect of an earlier batch node's acceptance on this node's ratio; the parts of
     // node k share the rows: part p takes m = p, p + parts, ...
-    const int m = tid * sb.parts + p;
-    if (m < k) {
+    for (int m = tid * sb.parts + p; m < k; m += SP_EV_THREADS * sb.parts) {
         const int jm = j0 + m;
         const double a0 = dist_fast<D>(&sx0[m * D], xk0, c.squared);
         const double a1 = dist_fast<D>(&sx0[m * D], xk1, c.squared);
@@ -300,7 +236,8 @@ __global__ __launch_bounds__(SP_EV_THREADS) void k_spec_eval(ChainView c, SpecBu
 }
 
 // ---------------------------------------------------------------------------
-// Speculative-batch eval for the case-control likelihood (a3 inside a9/a10):
+// Speculative-batch eval for the case-control likelihood (a3 inside a9/a10)
+// (sub-batches of one: the launcher uses S = 1 for this model):
 // one wave per (slice, batch node k).  Node k's ratio has O(deg + 2C) gathered
 // terms; H[k][m] is non-zero only for the few earlier batch nodes m that appear
 // in k's edge / control lists, so the column of H is zero-filled and the hits
@@ -409,365 +346,177 @@ __global__ __launch_bounds__(64) void k_spec_eval_cc(ChainView c, SpecBuf sb,
 }
 
 constexpr int SP_RES_THREADS = 1024;    // 16 waves: wide staging + parallel passes
+constexpr int SP_SMAX = 4;              // sub-batches per super-batch (launch pair)
 
-// Resolve one batch (see the header comment and resolve_fixed_point): the
-// fixed-point passes are spread over the 16 waves of the workgroup.  Wave w
-// serves the nodes of half (w & 1) and the guessed rows m in
-// [16 (w >> 1), 16 (w >> 1) + 16); waves 0 / 1 own the ratios of half 0 / 1,
-// combine the 8 partial sums in ascending-m order and re-ballot.
+// Resolve one super-batch of S <= SP_SMAX sub-batches of <= 128 nodes, in order.
+//
+// The in-order accept/reject rule of a batch is the triangular system
+//     a_k = [ log u_k < r_k + sum_{m<k} a_m H[k][m] ],   k = 0, 1, ...
+// Instead of walking it node by node (one dependent LDS read + ballot per acceptance)
+// iterate a -> F(a): given a guess of the accepted set, add the H rows of the guessed
+// nodes to the ratios of the later nodes and re-test.  A fixed point satisfies the
+// triangular system, whose solution is unique (forward substitution), so it IS the
+// sequential result; |H| is tiny next to the ratios, so the guess "accept iff the
+// uncorrected ratio accepts" is stable after 1-2 passes.  The pass is spread over the
+// 16 waves: wave w serves the nodes of half (w & 1) and the guessed rows
+// m in [16 (w >> 1), +16); waves 0 / 1 own the ratios of half 0 / 1, combine the 8
+// partial sums in ascending-m order and re-ballot.
+// For sub-batches after the first, the (final) acceptances of the earlier sub-batches
+// enter as a gathered row sum of the off-diagonal part of H, also done by all waves.
 template <int D>
 __global__ __launch_bounds__(SP_RES_THREADS) void k_spec_resolve(ChainView c, SpecBuf sb,
-                                                                 int parity, int j0, int nb) {
-    extern __shared__ __attribute__((aligned(16))) double sH[];   // nb rows, stride B
+                                                                 int parity, int j0, int nsb) {
+    extern __shared__ __attribute__((aligned(16))) double sH[];   // 128 x 128 diagonal block
     __shared__ double sPart[16 * 64];
     __shared__ unsigned long long sMask[2][2];
+    __shared__ int sAcc[SP_SMAX * SP_BMAX];                       // accepted nodes so far
+    __shared__ int sNacc;
     static_assert(SP_BMAX == 128, "two 64-node halves");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int s = sb.s0 + blockIdx.x;
     const int t = 2 * s + parity;
     const int N = c.N;
-    const int ldh = sb.B;
+    const int ldg = sb.B;                                         // leading dimension of H
     const double *Ht = sb.Ht + (size_t)s * sb.B * sb.B;
-    // waves 0 / 1: ratio and log-uniform of node k = 64 * wave + lane (issued first so
-    // the dependent global loads overlap the staging below)
     const int half = wave & 1, part = wave >> 1;
     const int k = 64 * half + lane;
     const bool owner = wave < 2;
-    const bool valid = k < nb;
-    double r = 0.0, lu = 0.0, st = 0.0, x1[D];
-    int32_t na = 0, ns = 0, un = 0;
-#pragma unroll
-    for (int d = 0; d < D; ++d) x1[d] = 0.0;
-    if (owner) {
-        const int kc = min(k, nb - 1);                        // clamped: no branches
-        const double *f = sb.full0 + ((size_t)s * sb.B + kc) * sb.parts;
-        const int p1 = sb.parts;
-        double fp[8];
-#pragma unroll
-        for (int p = 0; p < 8; ++p) fp[p] = f[min(p, p1 - 1)];
-        double tot = 0.0;
-#pragma unroll
-        for (int p = 0; p < 8; ++p) tot += p < p1 ? fp[p] : 0.0;
-        const double *pr = sb.prop + ((size_t)s * N + j0 + kc) * (D + 2);
-        r = tot + pr[D + 1];
-        lu = pr[D];
-#pragma unroll
-        for (int d = 0; d < D; ++d) x1[d] = pr[d];
-        // sampler state of the node: loaded now, used after the passes
-        const size_t tjc = (size_t)t * N + j0 + kc;
-        st = c.step[tjc]; na = c.nacc[tjc]; ns = c.nsteps[tjc]; un = c.until[tjc];
-    }
-    // stage rows 0..nb-1 of H^T as one flat, fully coalesced copy with many loads in
-    // flight per lane (entries at or below the diagonal are never read)
-    {
-        const int n2 = (nb * ldh) / 2;                 // double2 elements (B is even)
-        const double2 *src = (const double2 *)Ht;
-        double2 *dst = (double2 *)sH;
-        for (int q0 = 0; q0 < n2; q0 += SP_RES_THREADS * 8) {
-            // unconditional loads (clamped index): a predicated load makes hipcc
-            // branch around it and wait vmcnt(0) per element
-            double2 v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = src[min(q0 + u * SP_RES_THREADS + tid, n2 - 1)];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) dst[min(q0 + u * SP_RES_THREADS + tid, n2 - 1)] = v[u];
-        }
-    }
-    if (owner) {
-        const unsigned long long g = __ballot(valid && !(lu >= r));
-        if (lane == 0) sMask[0][half] = g;
-    }
-    __syncthreads();
-    int cur = 0;
-    for (int pass = 0; pass < 2 * SP_BMAX + 2; ++pass) {
-        // partial correction of node k from the guessed rows of this wave's range
-        const unsigned long long gm = sMask[cur][part >> 2];
-        unsigned int bits = (unsigned int)(gm >> (16 * (part & 3))) & 0xFFFFu;
-        const int mbase = 16 * part;
-        double sum = 0.0;
-        if (half == 1 || part < 4) {                  // rows >= 64 never touch half 0
-            const double *col = sH + k;
-            while (bits) {
-                int f[4];
-                double h[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    f[u] = bits ? mbase + __builtin_ctz(bits) : 1 << 20;
-                    bits &= bits - 1u;
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) h[u] = col[(f[u] < (1 << 20) ? f[u] : 0) * ldh];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) sum += k > f[u] ? h[u] : 0.0;
-            }
-        }
-        sPart[wave * 64 + lane] = sum;
-        __syncthreads();
-        if (owner) {
-            double q = r;
-#pragma unroll
-            for (int p = 0; p < 8; ++p) q += sPart[(2 * p + half) * 64 + lane];
-            const unsigned long long g = __ballot(valid && !(lu >= q));
-            if (lane == 0) sMask[cur ^ 1][half] = g;
-        }
-        __syncthreads();
-        const bool same = sMask[cur ^ 1][0] == sMask[cur][0] && sMask[cur ^ 1][1] == sMask[cur][1];
-        cur ^= 1;
-        if (same) break;
-    }
-    if (owner && valid) {
-        const int accepted = (int)((sMask[cur][half] >> lane) & 1ull);
-        const size_t tj = (size_t)t * N + j0 + k;
-        if (accepted) {
-#pragma unroll
-            for (int d = 0; d < D; ++d) c.X[tj * D + d] = x1[d];
-        }
-        metropolis_bookkeeping(st, na, ns, un, c.tune, c.tune_interval, accepted);
-        c.step[tj] = st; c.nacc[tj] = na; c.nsteps[tj] = ns; c.until[tj] = un;
-    }
-}
-
-}  // namespace dlsm
-
-// ===========================================================================
-// Two-level speculative batches (algo 3).  Same algebra as above, but one eval
-// and one resolve launch cover a SUPER-batch of S x 128 consecutive nodes:
-//   eval    computes full0_k for every node of the super-batch against the
-//           positions at super-batch start, and H[k][m] for every earlier node
-//           m of the super-batch (within and across its 128-node sub-batches);
-//   resolve walks the sub-batches in order inside one launch: the diagonal
-//           128 x 128 block of H is staged in LDS for the wave scan, the effect
-//           of nodes accepted in earlier sub-batches is a gathered row sum of H
-//           done by the whole workgroup.
-// 4x fewer launches per sweep and 4x more work per eval launch (the eval
-// kernel is latency bound at 128 nodes per launch).
-// ===========================================================================
-namespace dlsm {
-
-constexpr int SP2_SMAX = 4;
-constexpr int SP2_SBMAX = SP2_SMAX * SP_BMAX;       // 512 nodes per super-batch
-
-struct SpecBuf2 {
-    double *full0;   // [nsl][SB][parts]
-    double *prop;    // [nsl][N][D + 2]
-    double *Ht;      // [nsl][SB][SB] : Ht[m][k] = H[k][m], k > m
-    double *consts;  // [2] : E = exp(sum of intercepts), flush interval
-    int SB, parts;
-};
-
-template <int D>
-__global__ __launch_bounds__(256) void k_spec2_propose(ChainView c, SpecBuf2 sb,
-                                                       uint32_t iter, int parity) {
-    const int N = c.N;
-    const int s = blockIdx.y;
-    const int t = 2 * s + parity;
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
-        const double E = c.model == DLSM_UNDIRECTED ? exp(c.intercept[0])
-                                                    : exp(c.intercept[0] + c.intercept[1]);
-        sb.consts[0] = E;
-        sb.consts[1] = (double)flush_interval(E);
-    }
-    if (j >= N) return;
-    double x0[D], x1[D], logu;
-#pragma unroll
-    for (int d = 0; d < D; ++d) x0[d] = c.X[((size_t)t * N + j) * D + d];
-    make_proposal<D>(c, iter, t, j, x0, c.step[(size_t)t * N + j], x1, logu);
-    double *pr = sb.prop + ((size_t)s * N + j) * (D + 2);
-#pragma unroll
-    for (int d = 0; d < D; ++d) pr[d] = x1[d];
-    pr[D] = logu;
-    pr[D + 1] = node_log_prior<D>(c, t, j, x1) - node_log_prior<D>(c, t, j, x0);
-}
-
-template <int D, int MODEL>
-__global__ __launch_bounds__(SP_THREADS) void k_spec2_eval(ChainView c, SpecBuf2 sb,
-                                                           int parity, int j0, int nsb) {
-    __shared__ double sx0[SP2_SBMAX * D];
-    __shared__ double sx1[SP2_SBMAX * D];
-    __shared__ double sRed[SP_THREADS / 64];
-    const int tid = threadIdx.x;
-    const int N = c.N, W = c.W;
-    const int p = blockIdx.x % sb.parts;
-    const int k = (blockIdx.x / sb.parts) % nsb;
-    const int s = blockIdx.x / (sb.parts * nsb);
-    const int t = 2 * s + parity;
-    const double *Xt = c.X + (size_t)t * N * D;
-    const int jk = j0 + k;
-    const bool do_h = (p == 0);
-    for (int m = do_h ? tid : k + tid; m <= k; m += SP_THREADS) {
-        const int j = j0 + m;
-        const double *pr = sb.prop + ((size_t)s * N + j) * (D + 2);
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            sx0[m * D + d] = Xt[(size_t)j * D + d];
-            sx1[m * D + d] = pr[d];
-        }
-    }
-    __syncthreads();
-    double xk0[D], xk1[D];
-#pragma unroll
-    for (int d = 0; d < D; ++d) { xk0[d] = sx0[k * D + d]; xk1[d] = sx1[k * D + d]; }
-    const uint32_t *yr = c.ybits + ((size_t)t * N + jk) * W;
-    const uint32_t *yc = MODEL == DLSM_DIRECTED ? c.ytbits + ((size_t)t * N + jk) * W
-                                                : nullptr;
-    const double E = sb.consts[0];
-    const int nflush = (int)sb.consts[1];
-    double bin = 0.0, bout = 0.0, irk = 0.0;
-    if (MODEL == DLSM_DIRECTED) {
-        bin = c.intercept[0]; bout = c.intercept[1];
-        irk = 1.0 / c.radii[jk];
-    }
-    const int per = (N + sb.parts - 1) / sb.parts;
-    const int lo = p * per, hi = min(N, lo + per);
-    double acc = 0.0;
-    RatioAcc ra;
-    for (int i = lo + tid; i < hi; i += SP_THREADS) {
-        if (i == jk) continue;
-        double xi[D];
-#pragma unroll
-        for (int d = 0; d < D; ++d) xi[d] = Xt[(size_t)i * D + d];
-        const double d0 = dist_of<D>(xi, xk0, c.squared);
-        const double d1 = dist_of<D>(xi, xk1, c.squared);
-        if (MODEL == DLSM_UNDIRECTED) {
-            if (bit_of(yr, i)) ra.lin += d0 - d1;
-            ra.P0 *= 1.0 + E * exp(-d0);
-            ra.P1 *= 1.0 + E * exp(-d1);
-            if (++ra.cnt >= nflush) ra.flush();
-        } else {
-            const double iri = 1.0 / c.radii[i];
-            acc += delta_directed(d0, d1, bit_of(yr, i), bit_of(yc, i),
-                                  bin * iri + bout * irk, bin * irk + bout * iri, E);
-        }
-    }
-    if (MODEL == DLSM_UNDIRECTED) acc = ra.value();
-    const double total = block_sum_all<SP_THREADS / 64>(acc, sRed, tid);
-    if (tid == 0) sb.full0[((size_t)s * sb.SB + k) * sb.parts + p] = total;
-    if (do_h) {
-        for (int m = tid; m < k; m += SP_THREADS) {
-            const int jm = j0 + m;
-            const double a0 = dist_of<D>(&sx0[m * D], xk0, c.squared);
-            const double a1 = dist_of<D>(&sx0[m * D], xk1, c.squared);
-            const double b0 = dist_of<D>(&sx1[m * D], xk0, c.squared);
-            const double b1 = dist_of<D>(&sx1[m * D], xk1, c.squared);
-            double h;
-            if (MODEL == DLSM_UNDIRECTED) {
-                const double num = (1.0 + E * exp(-b0)) * (1.0 + E * exp(-a1));
-                const double den = (1.0 + E * exp(-b1)) * (1.0 + E * exp(-a0));
-                h = log(num / den);
-                if (bit_of(yr, jm)) h += (b0 - b1) - (a0 - a1);
-            } else {
-                const double irm = 1.0 / c.radii[jm];
-                const int y1 = bit_of(yr, jm), y2 = bit_of(yc, jm);
-                const double aa = bin * irm + bout * irk, cc = bin * irk + bout * irm;
-                h = delta_directed(b0, b1, y1, y2, aa, cc, E) -
-                    delta_directed(a0, a1, y1, y2, aa, cc, E);
-            }
-            sb.Ht[((size_t)s * sb.SB + m) * sb.SB + k] = h;
-        }
-    }
-}
-
-template <int D>
-__global__ __launch_bounds__(SP_THREADS) void k_spec2_resolve(ChainView c, SpecBuf2 sb,
-                                                              int parity, int j0, int nsb) {
-    extern __shared__ __attribute__((aligned(16))) double smem2[];
-    double *sH = smem2;                               // 128 x 128 diagonal block
-    double *sCorr = sH + SP_BMAX * SP_BMAX;           // 2 x 128 partial row sums
-    int *sAcc = (int *)(sCorr + 2 * SP_BMAX);         // accepted nodes so far (<= SB)
-    __shared__ int sNacc;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int s = blockIdx.x;
-    const int t = 2 * s + parity;
-    const int N = c.N, SB = sb.SB;
-    const double *Ht = sb.Ht + (size_t)s * SB * SB;
     if (tid == 0) sNacc = 0;
-    __syncthreads();
     for (int o = 0; o < nsb; o += SP_BMAX) {
         const int nb = min(SP_BMAX, nsb - o);
-        // (1) stage the diagonal block: rows o..o+nb-1, columns o..o+127
+        const bool valid = k < nb;
+        // waves 0 / 1: ratio, log-uniform, proposal and sampler state of node o + k
+        // (issued first so the dependent global loads overlap the staging below)
+        double r = 0.0, lu = 0.0, st = 0.0, x1[D];
+        int32_t na = 0, ns = 0, un = 0;
+#pragma unroll
+        for (int d = 0; d < D; ++d) x1[d] = 0.0;
+        if (owner) {
+            const int kc = o + min(k, nb - 1);                    // clamped: no branches
+            const double *f = sb.full0 + ((size_t)s * sb.B + kc) * sb.parts;
+            const int p1 = sb.parts;
+            double fp[8];
+#pragma unroll
+            for (int p = 0; p < 8; ++p) fp[p] = f[min(p, p1 - 1)];
+            double tot = 0.0;
+#pragma unroll
+            for (int p = 0; p < 8; ++p) tot += p < p1 ? fp[p] : 0.0;
+            const double *pr = sb.prop + ((size_t)s * N + j0 + kc) * (D + 2);
+            r = tot + pr[D + 1];
+            lu = pr[D];
+#pragma unroll
+            for (int d = 0; d < D; ++d) x1[d] = pr[d];
+            const size_t tjc = (size_t)t * N + j0 + kc;
+            st = c.step[tjc]; na = c.nacc[tjc]; ns = c.nsteps[tjc]; un = c.until[tjc];
+        }
+        // stage the diagonal block (rows o..o+nb-1, columns o..o+127) as one wide copy
+        // with many loads in flight per lane; entries at or below the diagonal and
+        // columns beyond the batch are never read (addresses clamped, no predication:
+        // a predicated load makes hipcc branch around it and wait vmcnt(0) per element)
         {
-            const int n2 = nb * (SP_BMAX / 2);            // double2 elements
+            const int n2 = nb * (SP_BMAX / 2);                    // double2 elements
             double2 *dst = (double2 *)sH;
-            for (int q0 = 0; q0 < n2; q0 += SP_THREADS * 8) {
+            for (int q0 = 0; q0 < n2; q0 += SP_RES_THREADS * 8) {
                 double2 v[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    const int q = min(q0 + u * SP_THREADS + tid, n2 - 1);
-                    const int r = q >> 6, cc2 = q & 63;
-                    // columns beyond the super-batch are never read: clamp the address
-                    const int col = min(o + 2 * cc2, SB - 2);
-                    v[u] = *(const double2 *)(Ht + (size_t)(o + r) * SB + col);
+                    const int q = min(q0 + u * SP_RES_THREADS + tid, n2 - 1);
+                    const int col = min(o + 2 * (q & 63), ldg - 2);
+                    v[u] = *(const double2 *)(Ht + (size_t)(o + (q >> 6)) * ldg + col);
                 }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) dst[min(q0 + u * SP_THREADS + tid, n2 - 1)] = v[u];
+                for (int u = 0; u < 8; ++u)
+                    dst[min(q0 + u * SP_RES_THREADS + tid, n2 - 1)] = v[u];
             }
         }
-        // (2) effect of the nodes accepted in earlier sub-batches: gathered row
-        //     sums of H, two halves of the accepted list in parallel
-        {
-            const int kk = tid & (SP_BMAX - 1), half = tid >> 7;
+        __syncthreads();                                          // sNacc / sAcc visible
+        if (o > 0) {
+            // nodes accepted in earlier sub-batches: gathered row sums of H from global
             const int nacc = sNacc;
-            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-            const int col = min(o + kk, SB - 1);
-            int a = half;
-            for (; a + 6 < nacc; a += 8) {
-                a0 += Ht[(size_t)sAcc[a] * SB + col];
-                a1 += Ht[(size_t)sAcc[a + 2] * SB + col];
-                a2 += Ht[(size_t)sAcc[a + 4] * SB + col];
-                a3 += Ht[(size_t)sAcc[a + 6] * SB + col];
+            const double *colp = Ht + min(o + k, ldg - 1);
+            double sum = 0.0;
+            int a = part;
+            for (; a + 24 < nacc; a += 32) {
+                const double h0 = colp[(size_t)sAcc[a] * ldg];
+                const double h1 = colp[(size_t)sAcc[a + 8] * ldg];
+                const double h2 = colp[(size_t)sAcc[a + 16] * ldg];
+                const double h3 = colp[(size_t)sAcc[a + 24] * ldg];
+                sum += h0; sum += h1; sum += h2; sum += h3;
             }
-            for (; a < nacc; a += 2) a0 += Ht[(size_t)sAcc[a] * SB + col];
-            sCorr[half * SP_BMAX + kk] = (a0 + a1) + (a2 + a3);
+            for (; a < nacc; a += 8) sum += colp[(size_t)sAcc[a] * ldg];
+            sPart[wave * 64 + lane] = sum;
+            __syncthreads();
+            if (owner) {
+#pragma unroll
+                for (int p = 0; p < 8; ++p) r += sPart[(2 * p + half) * 64 + lane];
+            }
+            __syncthreads();
+        }
+        if (owner) {
+            const unsigned long long g = __ballot(valid && !(lu >= r));
+            if (lane == 0) sMask[0][half] = g;
         }
         __syncthreads();
-        if (wave == 0) {
-            double r0 = 0.0, r1 = 0.0, lu0 = 0.0, lu1 = 0.0;
-            const bool valid0 = lane < nb, valid1 = lane + 64 < nb;
-            const int p1 = sb.parts;
+        int cur = 0;
+        for (int pass = 0; pass < 2 * SP_BMAX + 2; ++pass) {
+            // partial correction of node k from the guessed rows of this wave's range
+            const unsigned long long gm = sMask[cur][part >> 2];
+            unsigned int bits = (unsigned int)(gm >> (16 * (part & 3))) & 0xFFFFu;
+            const int mbase = 16 * part;
+            double sum = 0.0;
+            if (half == 1 || part < 4) {                          // rows >= 64 never touch half 0
+                const double *col = sH + k;
+                while (bits) {
+                    int f[4];
+                    double h[4];
 #pragma unroll
-            for (int v = 0; v < 2; ++v) {
-                const int kb = min(lane + 64 * v, nb - 1);
-                const double *f = sb.full0 + ((size_t)s * SB + o + kb) * sb.parts;
-                double fp[8];
-#pragma unroll
-                for (int p = 0; p < 8; ++p) fp[p] = f[min(p, p1 - 1)];
-                double tot = 0.0;
-#pragma unroll
-                for (int p = 0; p < 8; ++p) tot += p < p1 ? fp[p] : 0.0;
-                const double *pr = sb.prop + ((size_t)s * N + j0 + o + kb) * (D + 2);
-                const double rr = tot + pr[D + 1] + (sCorr[kb] + sCorr[SP_BMAX + kb]);
-                const double ll = pr[D];
-                if (v == 0) { r0 = rr; lu0 = ll; } else { r1 = rr; lu1 = ll; }
-            }
-            unsigned long long acc0, acc1;
-            resolve_fixed_point(valid0, valid1, lu0, lu1, r0, r1, sH, SP_BMAX, lane, acc0, acc1);
-            // append the accepted nodes (super-batch local index, ascending)
-            const int base = sNacc;
-            const int n0 = __popcll(acc0);
-            if ((acc0 >> lane) & 1ull)
-                sAcc[base + __popcll(acc0 & ((1ull << lane) - 1ull))] = o + lane;
-            if ((acc1 >> lane) & 1ull)
-                sAcc[base + n0 + __popcll(acc1 & ((1ull << lane) - 1ull))] = o + 64 + lane;
-            if (lane == 0) sNacc = base + n0 + __popcll(acc1);
-#pragma unroll
-            for (int v = 0; v < 2; ++v) {
-                const int kb = lane + 64 * v;
-                if (kb < nb) {
-                    const int accepted = (int)(((v == 0 ? acc0 : acc1) >> lane) & 1ull);
-                    const size_t tj = (size_t)t * N + j0 + o + kb;
-                    if (accepted) {
-                        const double *pr = sb.prop + ((size_t)s * N + j0 + o + kb) * (D + 2);
-#pragma unroll
-                        for (int d = 0; d < D; ++d) c.X[tj * D + d] = pr[d];
+                    for (int u = 0; u < 4; ++u) {
+                        f[u] = bits ? mbase + __builtin_ctz(bits) : 1 << 20;
+                        bits &= bits - 1u;
                     }
-                    double st = c.step[tj];
-                    int32_t na = c.nacc[tj], ns = c.nsteps[tj], un = c.until[tj];
-                    metropolis_bookkeeping(st, na, ns, un, c.tune, c.tune_interval, accepted);
-                    c.step[tj] = st; c.nacc[tj] = na; c.nsteps[tj] = ns; c.until[tj] = un;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        h[u] = col[(f[u] < (1 << 20) ? f[u] : 0) * SP_BMAX];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) sum += k > f[u] ? h[u] : 0.0;
                 }
             }
+            sPart[wave * 64 + lane] = sum;
+            __syncthreads();
+            if (owner) {
+                double q = r;
+#pragma unroll
+                for (int p = 0; p < 8; ++p) q += sPart[(2 * p + half) * 64 + lane];
+                const unsigned long long g = __ballot(valid && !(lu >= q));
+                if (lane == 0) sMask[cur ^ 1][half] = g;
+            }
+            __syncthreads();
+            const bool same = sMask[cur ^ 1][0] == sMask[cur][0] &&
+                              sMask[cur ^ 1][1] == sMask[cur][1];
+            cur ^= 1;
+            if (same) break;
         }
+        if (owner) {
+            const unsigned long long m0 = sMask[cur][0], m1 = sMask[cur][1];
+            const unsigned long long mine = half == 0 ? m0 : m1;
+            const int accepted = (int)((mine >> lane) & 1ull);
+            if (valid) {
+                const size_t tj = (size_t)t * N + j0 + o + k;
+                if (accepted) {
+#pragma unroll
+                    for (int d = 0; d < D; ++d) c.X[tj * D + d] = x1[d];
+                }
+                metropolis_bookkeeping(st, na, ns, un, c.tune, c.tune_interval, accepted);
+                c.step[tj] = st; c.nacc[tj] = na; c.nsteps[tj] = ns; c.until[tj] = un;
+            }
+            // append the accepted nodes (super-batch local index, ascending)
+            if (accepted) {
+                const int base = sNacc + (half == 0 ? 0 : __popcll(m0));
+                sAcc[base + __popcll(mine & ((1ull << lane) - 1ull))] = o + k;
+            }
+        }
+        __syncthreads();
+        if (tid == 0) sNacc += __popcll(sMask[cur][0]) + __popcll(sMask[cur][1]);
         __syncthreads();
     }
 }

@@ -123,7 +123,7 @@ int dlsm_loglik_partial_all(dlsm_chain *h, int with_prior, double *out);
  * steps, even-t slices concurrently then odd-t slices, Gauss-Seidel inside a
  * slice; updates X and the sampler grid on device.  algo 0 = auto,
  * 1 = one workgroup per slice, 2 = speculative batches over the whole chip,
- * 3 = two-level speculative batches (one launch pair per 512 nodes). */
+ * 3 = speculative batches with one launch pair per two 128-node sub-batches. */
 int dlsm_sweep_positions(dlsm_chain *h, uint32_t iter, int algo);
 /* lsm.py:501 / hdp_lpcm.py:852 */
 int dlsm_center(dlsm_chain *h);
