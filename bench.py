@@ -152,6 +152,11 @@ def main():
             # sweep, each covering (slices of one parity) x (batch of <= 128 nodes)
             launches = n_ev / float(P)
             kname, k_ms = 'k_spec_eval', ms_ev / n_ev
+            # the eval launches carry their own start/stop events (hipExtLaunchKernelGGL):
+            # the dispatch's begin/end timestamps, which is what the rocprofv3 kernel
+            # trace reports.  The in-kernel wall-clock stamps (first workgroup start to
+            # last workgroup end) are reported next to it.
+            st_us, st_n = chain.profile_read_eval_stamps()
             k_bytes = sweep_bytes / launches
         else:
             launches = 2.0
@@ -167,6 +172,7 @@ def main():
                     'achieved': round(ach, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                     'frac': round(ach / HBM_PEAK_GBS, 5), 'traffic': traffic,
                     'us_per_launch': round(1e3 * k_ms, 3),
+                    'us_per_launch_in_kernel_stamps': round(st_us, 3) if n_ev > 0 and st_n > 0 else None,
                     'launches_per_sweep': launches,
                     'algorithmic_bytes_per_launch': round(k_bytes, 1),
                     'sweep_GBps_all_launches': round(sweep_bytes / (sweep_ms * 1e-3) / 1e9, 2)}

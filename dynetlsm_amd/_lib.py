@@ -82,6 +82,7 @@ SIGNATURES = {
                                   c_double_p]),
     'dlsm_profile_enable': (C.c_int, [handle_t, C.c_int]),
     'dlsm_profile_read': (C.c_int, [handle_t, C.c_int, c_double_p, C.POINTER(C.c_int)]),
+    'dlsm_profile_read_eval_stamps': (C.c_int, [handle_t, c_double_p, C.POINTER(C.c_int)]),
     'dlsm_timer_start': (C.c_int, [handle_t]),
     'dlsm_timer_stop': (C.c_int, [handle_t, c_double_p]),
 }

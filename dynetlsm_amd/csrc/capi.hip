@@ -1,6 +1,7 @@
 // C-ABI of the MI355X engine (include/dynetlsm_hip.h).  gfx950 only; there is
 // deliberately no CPU path in this library.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <cstdio>
@@ -256,7 +257,7 @@ void dlsm_destroy(dlsm_chain *h) {
                     h->ctrl_in, h->ctrl_out, h->X, h->intercept, h->radii,
                     h->radii_alt, h->step, h->nacc, h->nsteps, h->until, h->mu,
                     h->sigma, h->z, h->partials, h->dsmall, h->xref, h->lab_n,
-                    h->lab_nk, h->lab_w, h->spec, h->nctrl, h->lsm, h->trace_X, h->trace_ic,
+                    h->lab_nk, h->lab_w, h->spec, h->nctrl, h->stamps, h->lsm, h->trace_X, h->trace_ic,
                     h->trace_logp};
     for (void *p : ptrs) if (p) hipFree(p);
     if (h->hsmall) hipHostFree(h->hsmall);
@@ -611,15 +612,22 @@ int dlsm_loglik_partial_all(dlsm_chain *h, int with_prior, double *out) {
 
 // algo 2 / 3: rounds of (chip-wide eval, per-slice resolve) over super-batches of
 // S sub-batches of <= 128 nodes (S = 1: algo 2)
+// When profiling, the eval launch carries its own start / stop events
+// (hipExtLaunchKernelGGL): they read the dispatch's begin / end timestamps, i.e. the
+// same kernel duration the rocprofv3 kernel trace reports, without the dispatch
+// latency a bracket of hipEventRecord calls would include.
 template <int DD, int SBM>
 static void launch_spec_eval(dlsm_chain *h, const ChainView &v, const SpecBuf &sg, dim3 grid,
                              hipStream_t q, int parity, int j0, int nsb) {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (h->profiling) { hipEventCreate(&e0); hipEventCreate(&e1); }
     if (h->model == DLSM_UNDIRECTED)
-        hipLaunchKernelGGL((k_spec_eval<DD, DLSM_UNDIRECTED, SBM>), grid, dim3(SP_EV_THREADS), 0,
-                           q, v, sg, parity, j0, nsb);
+        hipExtLaunchKernelGGL((k_spec_eval<DD, DLSM_UNDIRECTED, SBM>), grid, dim3(SP_EV_THREADS),
+                              0, q, e0, e1, 0, v, sg, parity, j0, nsb);
     else
-        hipLaunchKernelGGL((k_spec_eval<DD, DLSM_DIRECTED, SBM>), grid, dim3(SP_EV_THREADS), 0,
-                           q, v, sg, parity, j0, nsb);
+        hipExtLaunchKernelGGL((k_spec_eval<DD, DLSM_DIRECTED, SBM>), grid, dim3(SP_EV_THREADS),
+                              0, q, e0, e1, 0, v, sg, parity, j0, nsb);
+    if (h->profiling) h->prof[DLSM_K_SWEEP_EVAL].pending.emplace_back(e0, e1);
 }
 
 template <int DD>
@@ -648,6 +656,7 @@ static int launch_sweep_spec(dlsm_chain *h, uint32_t iter, int S) {
     sb.full0 = h->spec; sb.prop = sb.full0 + n_full0; sb.Ht = sb.prop + n_prop;
     sb.consts = sb.Ht + n_ht;
     sb.B = B; sb.parts = parts; sb.s0 = 0; sb.per = (N + parts - 1) / parts;
+    sb.stamps = nullptr;
     ChainView v = h->view();
     auto resolve = k_spec_resolve<DD>;
     const size_t lds = (size_t)SP_BMAX * SP_BMAX * sizeof(double);
@@ -685,12 +694,19 @@ static int launch_sweep_spec(dlsm_chain *h, uint32_t iter, int S) {
             for (int g = 0; g < ng; ++g) {
                 SpecBuf sg = sb; sg.s0 = first[g];
                 const int ns = first[g + 1] - first[g];
+                const size_t nblk = (size_t)parts * nsb * ns;
+                if (h->profiling && h->stamps && h->model != DLSM_DIRECTED_CASE_CONTROL &&
+                    h->stamps_used + nblk <= h->stamps_cap) {
+                    sg.stamps = h->stamps + 2 * h->stamps_used;
+                    h->stamp_launches.emplace_back(h->stamps_used, nblk);
+                    h->stamps_used += nblk;
+                }
                 {
-                    ProfScope pe(h, DLSM_K_SWEEP_EVAL);
-                    if (h->model == DLSM_DIRECTED_CASE_CONTROL)
+                    if (h->model == DLSM_DIRECTED_CASE_CONTROL) {
+                        ProfScope pe(h, DLSM_K_SWEEP_EVAL);
                         hipLaunchKernelGGL((k_spec_eval_cc<DD>), dim3((unsigned)(ns * nsb)),
                                            dim3(64), 0, qs[g], v, sg, h->nctrl, parity, j0, nsb);
-                    else if (S == 1)
+                    } else if (S == 1)
                         launch_spec_eval<DD, SP_BMAX>(h, v, sg, dim3(parts, nsb, ns), qs[g],
                                                       parity, j0, nsb);
                     else if (S == 2)
@@ -1019,6 +1035,18 @@ int dlsm_profile_enable(dlsm_chain *h, int on) {
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     drain_profile(h);
+    if (on) {
+        // in-kernel wall-clock stamps of the sweep's eval launches: [start, end] per
+        // workgroup (plain stores, no atomics: nothing contends)
+        const size_t cap = (size_t)2 << 20;                     // pairs (32 MB)
+        if (!h->stamps) {
+            HIPCHK(h, hipMalloc((void **)&h->stamps, cap * 2 * sizeof(unsigned long long)));
+            h->stamps_cap = cap;
+        }
+        HIPCHK(h, hipMemset(h->stamps, 0, h->stamps_cap * 2 * sizeof(unsigned long long)));
+        h->stamps_used = 0;
+        h->stamp_launches.clear();
+    }
     if (on) for (int k = 0; k < DLSM_K_COUNT; ++k) { h->prof[k].ms = 0; h->prof[k].launches = 0; }
     h->profiling = on != 0;
     return DLSM_OK;
@@ -1032,6 +1060,29 @@ int dlsm_profile_read(dlsm_chain *h, int kernel, double *total_ms, int *launches
     drain_profile(h);
     *total_ms = h->prof[kernel].ms;
     *launches = h->prof[kernel].launches;
+    return DLSM_OK;
+}
+
+int dlsm_profile_read_eval_stamps(dlsm_chain *h, double *mean_us, int *launches) {
+    NEED(h, h && mean_us && launches, "null argument");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    *mean_us = 0.0; *launches = 0;
+    if (!h->stamps || h->stamps_used == 0) return DLSM_OK;
+    std::vector<unsigned long long> st(h->stamps_used * 2);
+    HIPCHK(h, hipMemcpy(st.data(), h->stamps, st.size() * sizeof(unsigned long long),
+                        hipMemcpyDeviceToHost));
+    double tot = 0.0; int n = 0;
+    for (auto &L : h->stamp_launches) {
+        unsigned long long lo = ~0ull, hi = 0ull;
+        for (size_t b = L.first; b < L.first + L.second; ++b) {
+            if (st[2 * b] && st[2 * b] < lo) lo = st[2 * b];
+            if (st[2 * b + 1] > hi) hi = st[2 * b + 1];
+        }
+        if (hi > lo) { tot += (double)(hi - lo) * 0.01; ++n; }
+    }
+    if (n) *mean_us = tot / n;
+    *launches = n;
     return DLSM_OK;
 }
 

@@ -86,6 +86,9 @@ struct dlsm_chain {
     // sweep v2 scratch
     double *spec = nullptr; size_t spec_cap = 0;
     int32_t *nctrl = nullptr; size_t nctrl_cap = 0;     // valid controls per (t, i, dir)
+    unsigned long long *stamps = nullptr;               // in-kernel timestamps (profiling)
+    size_t stamps_cap = 0, stamps_used = 0;             // in [start, end] pairs
+    std::vector<std::pair<size_t, size_t>> stamp_launches;   // (first pair, pairs) per launch
     // LSM device-resident chain
     dlsm::LsmDeviceState *lsm = nullptr;
     dlsm_lsm_config lsm_cfg{};

@@ -40,6 +40,8 @@ struct SpecBuf {
     int B, parts;
     int s0;          // first slice (of the parity) served by this launch
     int per;         // neighbours per part = ceil(N / parts)
+    unsigned long long *stamps;   // profiling only: [start, end] per workgroup of this
+                                  // launch in 100 MHz wall-clock ticks (else nullptr)
 };
 
 __device__ __forceinline__ int flush_interval(double E_max) {
@@ -104,6 +106,8 @@ __global__ __launch_bounds__(SP_EV_THREADS) void k_spec_eval(ChainView c, SpecBu
     __shared__ double sLin[SP_EV_THREADS], sP0[SP_EV_THREADS], sP1[SP_EV_THREADS];
     const int tid = threadIdx.x;
     const int N = c.N, W = c.W;
+    const unsigned bl = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    if (sb.stamps && threadIdx.x == 0) sb.stamps[2 * (size_t)bl] = wall_clock64();
     // grid (parts, nb, slices): no integer divisions in the prologue
     const int p = blockIdx.x;
     const int k = blockIdx.y;
@@ -232,6 +236,10 @@ __global__ __launch_bounds__(SP_EV_THREADS) void k_spec_eval(ChainView c, SpecBu
                 delta_directed(a0, a1, y1, y2, aa, cc, E);
         }
         sb.Ht[((size_t)s * sb.B + m) * sb.B + k] = h;
+    }
+    if (sb.stamps) {
+        __syncthreads();
+        if (threadIdx.x == 0) sb.stamps[2 * (size_t)bl + 1] = wall_clock64();
     }
 }
 

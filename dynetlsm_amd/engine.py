@@ -346,6 +346,13 @@ class Chain(object):
         self._ck(self._L.dlsm_profile_read(self._h, int(kernel), C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    def profile_read_eval_stamps(self):
+        """(mean in-kernel duration in us, launches) of k_spec_eval while profiling"""
+        us = C.c_double(0.0)
+        n = C.c_int(0)
+        self._ck(self._L.dlsm_profile_read_eval_stamps(self._h, C.byref(us), C.byref(n)))
+        return us.value, n.value
+
     def timer_start(self):
         self._ck(self._L.dlsm_timer_start(self._h))
 

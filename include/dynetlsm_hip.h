@@ -174,6 +174,10 @@ enum {
  * events on the handle's stream; read returns accumulated ms and launches */
 int dlsm_profile_enable(dlsm_chain *h, int on);
 int dlsm_profile_read(dlsm_chain *h, int kernel, double *total_ms, int *launches);
+/* while profiling, the sweep's dominant kernel (k_spec_eval) also stamps the 100 MHz
+ * wall clock in-kernel (min start / max end over its workgroups): mean duration in us
+ * without the dispatch latency that brackets of HIP events include */
+int dlsm_profile_read_eval_stamps(dlsm_chain *h, double *mean_us, int *launches);
 /* wall-clock of a region on the handle's stream, by HIP events */
 int dlsm_timer_start(dlsm_chain *h);
 int dlsm_timer_stop(dlsm_chain *h, double *ms);
