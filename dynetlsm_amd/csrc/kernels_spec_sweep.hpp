@@ -390,52 +390,74 @@ __global__ __launch_bounds__(SP_RES_THREADS) void k_spec_resolve(ChainView c, Sp
     const int k = 64 * half + lane;
     const bool owner = wave < 2;
     if (tid == 0) sNacc = 0;
+    // Software pipeline over the sub-batches: the diagonal block and the owners' per-node
+    // data of sub-batch b + 1 are loaded into registers while sub-batch b is resolved
+    // (plain global loads stay in flight across the barriers), so only the first
+    // sub-batch of a launch exposes its global-load latency.
+    // One launch stages at most 128 x 128 doubles: 8 double2 per thread.
+    // (written as macros, not lambdas: arrays captured by reference end up in scratch)
+    double2 blk0, blk1, blk2, blk3, blk4, blk5, blk6, blk7;
+    double o_r = 0.0, o_lu = 0.0, o_st = 0.0, o_x1[D];
+    int32_t o_na = 0, o_ns = 0, o_un = 0;
+#pragma unroll
+    for (int d = 0; d < D; ++d) o_x1[d] = 0.0;
+    // rows o..o+nb-1, columns o..o+127 of H^T; entries at or below the diagonal and
+    // columns beyond the batch are never read (addresses clamped, no predication: a
+    // predicated load makes hipcc branch around it and wait vmcnt(0) per element)
+#define DLSM_LOAD1(U, REG, O_, NB_)                                                    \
+    {                                                                                   \
+        const int q_ = min((U) * SP_RES_THREADS + tid, (NB_) * (SP_BMAX / 2) - 1);      \
+        const int col_ = min((O_) + 2 * (q_ & 63), ldg - 2);                            \
+        REG = *(const double2 *)(Ht + (size_t)((O_) + (q_ >> 6)) * ldg + col_);         \
+    }
+#define DLSM_LOAD_BLOCK(O_, NB_)                                                        \
+    DLSM_LOAD1(0, blk0, O_, NB_) DLSM_LOAD1(1, blk1, O_, NB_) DLSM_LOAD1(2, blk2, O_, NB_) \
+    DLSM_LOAD1(3, blk3, O_, NB_) DLSM_LOAD1(4, blk4, O_, NB_) DLSM_LOAD1(5, blk5, O_, NB_) \
+    DLSM_LOAD1(6, blk6, O_, NB_) DLSM_LOAD1(7, blk7, O_, NB_)
+#define DLSM_STORE1(U, REG, NB_)                                                        \
+    ((double2 *)sH)[min((U) * SP_RES_THREADS + tid, (NB_) * (SP_BMAX / 2) - 1)] = REG;
+#define DLSM_LOAD_OWNER(O_, NB_)                                                        \
+    if (owner) {                                                                        \
+        const int kc_ = (O_) + min(k, (NB_) - 1);                                       \
+        const double *f_ = sb.full0 + ((size_t)s * sb.B + kc_) * sb.parts;              \
+        const int p1_ = sb.parts;                                                       \
+        double t0_ = f_[0], t1_ = f_[min(1, p1_ - 1)], t2_ = f_[min(2, p1_ - 1)],        \
+               t3_ = f_[min(3, p1_ - 1)], t4_ = f_[min(4, p1_ - 1)],                      \
+               t5_ = f_[min(5, p1_ - 1)], t6_ = f_[min(6, p1_ - 1)],                      \
+               t7_ = f_[min(7, p1_ - 1)];                                               \
+        double tot_ = t0_;                                                              \
+        tot_ += 1 < p1_ ? t1_ : 0.0; tot_ += 2 < p1_ ? t2_ : 0.0;                        \
+        tot_ += 3 < p1_ ? t3_ : 0.0; tot_ += 4 < p1_ ? t4_ : 0.0;                        \
+        tot_ += 5 < p1_ ? t5_ : 0.0; tot_ += 6 < p1_ ? t6_ : 0.0;                        \
+        tot_ += 7 < p1_ ? t7_ : 0.0;                                                    \
+        const double *pr_ = sb.prop + ((size_t)s * N + j0 + kc_) * (D + 2);             \
+        o_r = tot_ + pr_[D + 1];                                                        \
+        o_lu = pr_[D];                                                                  \
+        _Pragma("unroll") for (int d = 0; d < D; ++d) o_x1[d] = pr_[d];                 \
+        const size_t tjc_ = (size_t)t * N + j0 + kc_;                                   \
+        o_st = c.step[tjc_]; o_na = c.nacc[tjc_]; o_ns = c.nsteps[tjc_];                \
+        o_un = c.until[tjc_];                                                           \
+    }
+    {
+        const int nb0 = min(SP_BMAX, nsb);
+        DLSM_LOAD_OWNER(0, nb0)
+        DLSM_LOAD_BLOCK(0, nb0)
+    }
     for (int o = 0; o < nsb; o += SP_BMAX) {
         const int nb = min(SP_BMAX, nsb - o);
         const bool valid = k < nb;
-        // waves 0 / 1: ratio, log-uniform, proposal and sampler state of node o + k
-        // (issued first so the dependent global loads overlap the staging below)
-        double r = 0.0, lu = 0.0, st = 0.0, x1[D];
-        int32_t na = 0, ns = 0, un = 0;
+        // this sub-batch's data (loaded one iteration ago) -> working registers / LDS
+        double r = o_r, lu = o_lu, st = o_st, x1[D];
+        int32_t na = o_na, ns = o_ns, un = o_un;
 #pragma unroll
-        for (int d = 0; d < D; ++d) x1[d] = 0.0;
-        if (owner) {
-            const int kc = o + min(k, nb - 1);                    // clamped: no branches
-            const double *f = sb.full0 + ((size_t)s * sb.B + kc) * sb.parts;
-            const int p1 = sb.parts;
-            double fp[8];
-#pragma unroll
-            for (int p = 0; p < 8; ++p) fp[p] = f[min(p, p1 - 1)];
-            double tot = 0.0;
-#pragma unroll
-            for (int p = 0; p < 8; ++p) tot += p < p1 ? fp[p] : 0.0;
-            const double *pr = sb.prop + ((size_t)s * N + j0 + kc) * (D + 2);
-            r = tot + pr[D + 1];
-            lu = pr[D];
-#pragma unroll
-            for (int d = 0; d < D; ++d) x1[d] = pr[d];
-            const size_t tjc = (size_t)t * N + j0 + kc;
-            st = c.step[tjc]; na = c.nacc[tjc]; ns = c.nsteps[tjc]; un = c.until[tjc];
-        }
-        // stage the diagonal block (rows o..o+nb-1, columns o..o+127) as one wide copy
-        // with many loads in flight per lane; entries at or below the diagonal and
-        // columns beyond the batch are never read (addresses clamped, no predication:
-        // a predicated load makes hipcc branch around it and wait vmcnt(0) per element)
-        {
-            const int n2 = nb * (SP_BMAX / 2);                    // double2 elements
-            double2 *dst = (double2 *)sH;
-            for (int q0 = 0; q0 < n2; q0 += SP_RES_THREADS * 8) {
-                double2 v[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int q = min(q0 + u * SP_RES_THREADS + tid, n2 - 1);
-                    const int col = min(o + 2 * (q & 63), ldg - 2);
-                    v[u] = *(const double2 *)(Ht + (size_t)(o + (q >> 6)) * ldg + col);
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    dst[min(q0 + u * SP_RES_THREADS + tid, n2 - 1)] = v[u];
-            }
+        for (int d = 0; d < D; ++d) x1[d] = o_x1[d];
+        DLSM_STORE1(0, blk0, nb) DLSM_STORE1(1, blk1, nb) DLSM_STORE1(2, blk2, nb)
+        DLSM_STORE1(3, blk3, nb) DLSM_STORE1(4, blk4, nb) DLSM_STORE1(5, blk5, nb)
+        DLSM_STORE1(6, blk6, nb) DLSM_STORE1(7, blk7, nb)
+        if (o + SP_BMAX < nsb) {                                  // prefetch the next one
+            const int nbn = min(SP_BMAX, nsb - o - SP_BMAX);
+            DLSM_LOAD_OWNER(o + SP_BMAX, nbn)
+            DLSM_LOAD_BLOCK(o + SP_BMAX, nbn)
         }
         __syncthreads();                                          // sNacc / sAcc visible
         if (o > 0) {
@@ -528,5 +550,10 @@ __global__ __launch_bounds__(SP_RES_THREADS) void k_spec_resolve(ChainView c, Sp
         __syncthreads();
     }
 }
+
+#undef DLSM_LOAD1
+#undef DLSM_LOAD_BLOCK
+#undef DLSM_STORE1
+#undef DLSM_LOAD_OWNER
 
 }  // namespace dlsm
