@@ -44,13 +44,16 @@ def parse():
     ap.add_argument('--cpu-iters', type=int, default=3,
                     help='oracle iterations timed for cpu_baseline (0 = skip)')
     ap.add_argument('--no-cpu', action='store_true')
+    ap.add_argument('--backend', default=None,
+                    help='collective backend (default nccl = RCCL; gloo for dry runs)')
+    ap.add_argument('--share-device0', action='store_true',
+                    help='dry run: every rank drives cuda:0 (with --backend gloo)')
     return ap.parse_args()
 
 
 def main():
     args = parse()
     import torch
-    import torch.distributed as dist
 
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -61,37 +64,29 @@ def main():
                   'torch.distributed.run --nproc-per-node %d' % (args.gpus, world, args.gpus),
                   file=sys.stderr)
         sys.exit(2)
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
 
     from dynetlsm_amd import Chain, SamplerGrid
     from dynetlsm_amd import _lib
+    from dynetlsm_amd.multichain import init_chain_group
     from dynetlsm_amd.synthetic import synthetic_lsm_network
+
+    # one process per GPU; collectives over RCCL (backend "nccl") unless told otherwise
+    group = init_chain_group(backend=args.backend or 'nccl') if world > 1 else \
+        init_chain_group(backend='gloo')
+    if args.share_device0:
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
 
     T, N, D = args.T, args.N, args.D
     K, W, P = args.steps, args.warmup, args.profile_steps
-    dev = torch.device('cuda', local_rank)
 
-    # ---- the network: built on rank 0, broadcast over RCCL -----------------
-    t_gen = time.time()
-    if rank == 0:
-        net = synthetic_lsm_network(T, N, D, density=args.density, seed=0)
-        Y8 = torch.from_numpy(net['Y'].astype(np.uint8)).to(dev)
-        X0 = torch.from_numpy(net['X_init']).to(dev)
-        b0 = torch.tensor([net['intercept']], dtype=torch.float64, device=dev)
-    else:
-        Y8 = torch.empty((T, N, N), dtype=torch.uint8, device=dev)
-        X0 = torch.empty((T, N, D), dtype=torch.float64, device=dev)
-        b0 = torch.empty(1, dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.broadcast(Y8, 0); dist.broadcast(X0, 0); dist.broadcast(b0, 0)
-    Y = Y8.cpu().numpy().astype(np.float64)
-    X_init = X0.cpu().numpy()
-    b_init = float(b0.cpu()[0])
-    del Y8
+    # ---- the network: built on rank 0, broadcast (uint8 on the wire) -------------
+    net = synthetic_lsm_network(T, N, D, density=args.density, seed=0) if rank == 0 else None
+    Y = group.broadcast_network(net['Y'] if rank == 0 else None)
+    X_init = group.broadcast_array(net['X_init'] if rank == 0 else np.zeros((T, N, D)))
+    b_init = float(group.broadcast_array(np.array([net['intercept']]) if rank == 0
+                                         else np.zeros(1))[0])
     density = float(Y.mean())
-    t_gen = time.time() - t_gen
 
     # ---- one chain per rank --------------------------------------------------
     chain = Chain(T, N, D, 'undirected', seed=20240229, chain_id=rank, device=local_rank)
@@ -105,9 +100,7 @@ def main():
     n_total = 1 + W + K + P
     chain.trace_alloc(n_total, logp0=0.0)
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
+    barrier = group.barrier
 
     chain.lsm_run(1, W, procrustes_ref=0)
     chain.synchronize()
@@ -118,11 +111,7 @@ def main():
     chain.synchronize()
     torch.cuda.synchronize()
     barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.cpu()[0])
+    elapsed = group.max_over_ranks(time.perf_counter() - t0)
 
     # ---- per-kernel timing by HIP events on the chain's stream --------------
     roofline = None
@@ -188,14 +177,8 @@ def main():
 
     # ---- chain summaries: gather over RCCL ------------------------------------
     _, ics, lps = chain.trace_read(1 + W, K, positions=False)
-    summ = torch.tensor([ics[:, 0].mean(), ics[:, 0].std(), lps.mean(), lps[-1]],
-                        dtype=torch.float64, device=dev)
-    if world > 1:
-        allsum = [torch.empty_like(summ) for _ in range(world)]
-        dist.all_gather(allsum, summ)
-        summaries = [s.cpu().tolist() for s in allsum]
-    else:
-        summaries = [summ.cpu().tolist()]
+    summaries = [a.tolist() for a in group.gather_arrays(
+        np.array([ics[:, 0].mean(), ics[:, 0].std(), lps.mean(), lps[-1]]))]
 
     # ---- CPU baseline leg (rank 0): the scalar C oracle timed on this host's cores
     #      on a bounded sample of the same workload; the same leg checks the engine's
@@ -243,8 +226,7 @@ def main():
         line.update(extra)
         print(json.dumps(line))
     chain.close()
-    if world > 1:
-        dist.destroy_process_group()
+    group.close()
 
 
 if __name__ == '__main__':
