@@ -52,6 +52,14 @@ static thread_local std::string g_err;
         default: FAIL(h, DLSM_E_LIMIT, "n_features=%d unsupported (1..4)", D_); \
     }
 
+// A captured iteration freezes pointers and scalars of the chain: anything that changes
+// them drops the graph (it is rebuilt by the next dlsm_lsm_run).
+static void drop_graph(dlsm_chain *h) {
+    if (h->graph_exec) hipGraphExecDestroy(h->graph_exec);
+    if (h->graph) hipGraphDestroy(h->graph);
+    h->graph_exec = nullptr; h->graph = nullptr; h->graph_ref = -2; h->graph_algo = -1;
+}
+
 namespace {
 
 struct ProfScope {
@@ -266,6 +274,8 @@ void dlsm_destroy(dlsm_chain *h) {
     if (h->ev_a) hipEventDestroy(h->ev_a);
     if (h->ev_b) hipEventDestroy(h->ev_b);
     if (h->stream2) { hipStreamSynchronize(h->stream2); hipStreamDestroy(h->stream2); }
+    if (h->graph_exec) hipGraphExecDestroy(h->graph_exec);
+    if (h->graph) hipGraphDestroy(h->graph);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
 }
@@ -280,6 +290,7 @@ int dlsm_synchronize(dlsm_chain *h) {
 // ---------------------------------------------------------------- network
 int dlsm_upload_network(dlsm_chain *h, const double *Y) {
     NEED(h, h && Y, "null argument");
+    drop_graph(h);
     NEED(h, h->model != DLSM_DIRECTED_CASE_CONTROL,
          "case-control chains take edge lists (dlsm_upload_edges)");
     HIPCHK(h, hipSetDevice(h->device));
@@ -320,6 +331,7 @@ int dlsm_upload_network(dlsm_chain *h, const double *Y) {
 int dlsm_upload_edges(dlsm_chain *h, const int64_t *in_edges, int Din,
                       const int64_t *out_edges, int Dout, const int64_t *degree) {
     NEED(h, h && in_edges && out_edges && degree, "null argument");
+    drop_graph(h);
     NEED(h, h->model == DLSM_DIRECTED_CASE_CONTROL, "not a case-control chain");
     NEED(h, Din >= 0 && Dout >= 0, "negative padded degree");
     HIPCHK(h, hipSetDevice(h->device));
@@ -340,6 +352,7 @@ int dlsm_upload_edges(dlsm_chain *h, const int64_t *in_edges, int Din,
 int dlsm_set_controls(dlsm_chain *h, const int64_t *ctrl_in, const int64_t *ctrl_out,
                       int C) {
     NEED(h, h && ctrl_in && ctrl_out && C > 0, "bad argument");
+    drop_graph(h);
     NEED(h, h->model == DLSM_DIRECTED_CASE_CONTROL, "not a case-control chain");
     HIPCHK(h, hipSetDevice(h->device));
     const size_t TN = (size_t)h->T * h->N;
@@ -365,6 +378,7 @@ int dlsm_get_controls(dlsm_chain *h, int64_t *ctrl_in, int64_t *ctrl_out) {
 
 int dlsm_resample_controls(dlsm_chain *h, uint32_t iter, int n_control) {
     NEED(h, h != nullptr, "null handle");
+    drop_graph(h);
     NEED(h, h->model == DLSM_DIRECTED_CASE_CONTROL && h->have_edges,
          "needs a case-control chain with edge lists");
     NEED(h, n_control > 0, "n_control must be positive");
@@ -438,6 +452,7 @@ int dlsm_get_radii(dlsm_chain *h, double *radii) {
 
 int dlsm_set_squared(dlsm_chain *h, int squared) {
     NEED(h, h != nullptr, "null handle");
+    drop_graph(h);
     h->squared = squared ? 1 : 0;
     return DLSM_OK;
 }
@@ -446,6 +461,7 @@ int dlsm_set_samplers(dlsm_chain *h, const double *step_size, const int32_t *n_a
                       const int32_t *n_steps, const int32_t *steps_until_tune, int tune,
                       int tune_interval) {
     NEED(h, h && step_size && n_accepted && n_steps && steps_until_tune, "null argument");
+    drop_graph(h);
     NEED(h, tune_interval > 0, "tune_interval must be positive");
     HIPCHK(h, hipSetDevice(h->device));
     const size_t TN = (size_t)h->T * h->N;
@@ -473,6 +489,7 @@ int dlsm_get_samplers(dlsm_chain *h, double *step_size, int32_t *n_accepted,
 
 int dlsm_set_prior_random_walk(dlsm_chain *h, double tau_sq, double sigma_sq) {
     NEED(h, h != nullptr, "null handle");
+    drop_graph(h);
     NEED(h, tau_sq > 0 && sigma_sq > 0, "variances must be positive");
     h->prior_kind = DLSM_PRIOR_RANDOM_WALK;
     h->tau_sq = tau_sq; h->sigma_sq = sigma_sq;
@@ -483,6 +500,7 @@ int dlsm_set_prior_random_walk(dlsm_chain *h, double tau_sq, double sigma_sq) {
 int dlsm_set_prior_mixture(dlsm_chain *h, const double *mu, const double *sigma,
                            double lmbda, const int64_t *z, int K) {
     NEED(h, h && mu && sigma && z, "null argument");
+    drop_graph(h);
     NEED(h, K >= 1 && K <= 64, "n_components must be in 1..64");
     HIPCHK(h, hipSetDevice(h->device));
     const size_t TN = (size_t)h->T * h->N;
@@ -631,7 +649,7 @@ static void launch_spec_eval(dlsm_chain *h, const ChainView &v, const SpecBuf &s
 }
 
 template <int DD>
-static int launch_sweep_spec(dlsm_chain *h, uint32_t iter, int S) {
+static int launch_sweep_spec(dlsm_chain *h, IterRef iter, int S, bool alloc_only = false) {
     const int N = h->N, T = h->T;
     if (h->model == DLSM_DIRECTED_CASE_CONTROL) S = 1;          // one wave per node there
     S = std::max(1, std::min(S, SP_SMAX));
@@ -662,6 +680,7 @@ static int launch_sweep_spec(dlsm_chain *h, uint32_t iter, int S) {
     const size_t lds = (size_t)SP_BMAX * SP_BMAX * sizeof(double);
     HIPCHK(h, hipFuncSetAttribute((const void *)resolve,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (alloc_only) return DLSM_OK;
     // The slices of a parity are independent, so they can be split over two queues to
     // let one group's resolve overlap the other group's eval.  Measured on MI355X this
     // buys nothing at N=2000 (twice the launches: host bound) and 3.6 % at N=4000 (the
@@ -737,7 +756,7 @@ static int launch_sweep_spec(dlsm_chain *h, uint32_t iter, int S) {
 }
 
 template <int DD>
-static int launch_sweep(dlsm_chain *h, uint32_t iter, int algo) {
+static int launch_sweep(dlsm_chain *h, IterRef iter, int algo, bool alloc_only = false) {
     ChainView v = h->view();
     ProfScope ps(h, DLSM_K_SWEEP);
     if (h->model == DLSM_DIRECTED_CASE_CONTROL) {
@@ -751,6 +770,11 @@ static int launch_sweep(dlsm_chain *h, uint32_t iter, int algo) {
         }
         hipLaunchKernelGGL(k_count_controls, dim3((unsigned)((TN + 255) / 256)), dim3(256),
                            0, h->stream, h->ctrl_in, h->ctrl_out, (long)TN, h->C, h->nctrl);
+        if (alloc_only) {
+            hipStreamSynchronize(h->stream);
+            if (algo == 0) algo = h->N >= 256 ? 2 : 1;
+            return algo >= 2 ? launch_sweep_spec<DD>(h, iter, 1, true) : DLSM_OK;
+        }
         if (algo == 0) algo = h->N >= 256 ? 2 : 1;
         if (algo >= 2) return launch_sweep_spec<DD>(h, iter, 1);
         for (int parity = 0; parity < 2; ++parity) {
@@ -763,27 +787,32 @@ static int launch_sweep(dlsm_chain *h, uint32_t iter, int algo) {
         return DLSM_OK;
     }
     if (algo == 0) algo = h->N >= 512 ? 3 : (h->N >= 256 ? 2 : 1);
-    if (algo == 2) return launch_sweep_spec<DD>(h, iter, 1);
+    if (algo == 2) return launch_sweep_spec<DD>(h, iter, 1, alloc_only);
     if (algo == 3)
-        return launch_sweep_spec<DD>(h, iter, getenv("DLSM_SPEC_S") ? atoi(getenv("DLSM_SPEC_S")) : 2);
+        return launch_sweep_spec<DD>(h, iter, getenv("DLSM_SPEC_S") ? atoi(getenv("DLSM_SPEC_S")) : 2,
+                                     alloc_only);
     const size_t lds = sweep_slice_lds_bytes(h->N, DD, h->W, h->model);
     if (lds > 160 * 1024)
         FAIL(h, DLSM_E_LIMIT, "N=%d needs %zu B of LDS in the slice sweep (max 163840)",
              h->N, lds);
+    {
+        auto ku = k_sweep_slice<DD, DLSM_UNDIRECTED>;
+        auto kd = k_sweep_slice<DD, DLSM_DIRECTED>;
+        HIPCHK(h, hipFuncSetAttribute((const void *)ku,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(h, hipFuncSetAttribute((const void *)kd,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    if (alloc_only) return DLSM_OK;
     for (int parity = 0; parity < 2; ++parity) {
         int nsl = (h->T - parity + 1) / 2;
         if (nsl <= 0) continue;
-        if (h->model == DLSM_UNDIRECTED) {
-            auto kern = k_sweep_slice<DD, DLSM_UNDIRECTED>;
-            HIPCHK(h, hipFuncSetAttribute((const void *)kern,
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(kern, dim3(nsl), dim3(SW_THREADS), lds, h->stream, v, iter, parity);
-        } else {
-            auto kern = k_sweep_slice<DD, DLSM_DIRECTED>;
-            HIPCHK(h, hipFuncSetAttribute((const void *)kern,
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(kern, dim3(nsl), dim3(SW_THREADS), lds, h->stream, v, iter, parity);
-        }
+        if (h->model == DLSM_UNDIRECTED)
+            hipLaunchKernelGGL((k_sweep_slice<DD, DLSM_UNDIRECTED>), dim3(nsl), dim3(SW_THREADS),
+                               lds, h->stream, v, iter, parity);
+        else
+            hipLaunchKernelGGL((k_sweep_slice<DD, DLSM_DIRECTED>), dim3(nsl), dim3(SW_THREADS),
+                               lds, h->stream, v, iter, parity);
     }
     HIPCHK(h, hipGetLastError());
     return DLSM_OK;
@@ -796,9 +825,9 @@ static int check_ready_sweep(dlsm_chain *h) {
     return DLSM_OK;
 }
 
-static int enqueue_sweep(dlsm_chain *h, uint32_t iter, int algo) {
+static int enqueue_sweep(dlsm_chain *h, IterRef iter, int algo, bool alloc_only = false) {
     int rc = DLSM_OK;
-    DISPATCH_D(h, h->D, rc = launch_sweep<DD>(h, iter, algo));
+    DISPATCH_D(h, h->D, rc = launch_sweep<DD>(h, iter, algo, alloc_only));
     return rc;
 }
 
@@ -809,7 +838,7 @@ int dlsm_sweep_positions(dlsm_chain *h, uint32_t iter, int algo) {
     NEED(h, algo >= 0 && algo <= 3, "algo must be 0..3");
     HIPCHK(h, hipSetDevice(h->device));
     int rc = check_ready_sweep(h); if (rc) return rc;
-    rc = enqueue_sweep(h, iter, algo); if (rc) return rc;
+    rc = enqueue_sweep(h, IterRef{iter, nullptr}, algo); if (rc) return rc;
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return DLSM_OK;
 }
@@ -817,8 +846,9 @@ int dlsm_sweep_positions(dlsm_chain *h, uint32_t iter, int algo) {
 }  // extern "C"
 
 template <int DD>
-static int launch_post(dlsm_chain *h, const double *d_xref, int do_center,
-                       LsmDeviceState *lsm, uint32_t iter, double *d_R) {
+static int launch_post(dlsm_chain *h, const double *d_xref, int n_iter_procrustes,
+                       int do_center, LsmDeviceState *lsm, IterRef iter, double *d_R,
+                       bool alloc_only = false) {
     ChainView v = h->view();
     const long rows = (long)h->T * h->N;
     const int nb = (int)std::min<long>(PS_BLOCKS, (rows + PS2_THREADS - 1) / PS2_THREADS);
@@ -827,12 +857,13 @@ static int launch_post(dlsm_chain *h, const double *d_xref, int do_center,
     // the next producer runs: same stream)
     int rc = ensure_partials(h, (size_t)ll_blocks(h) * 4 + (size_t)PS_BLOCKS * W);
     if (rc) return rc;
+    if (alloc_only) return DLSM_OK;
     double *rec = h->partials + (size_t)ll_blocks(h) * 4;
     ProfScope ps(h, DLSM_K_CENTER);
     hipLaunchKernelGGL((k_post_reduce<DD>), dim3(nb), dim3(PS2_THREADS), 0, h->stream, v,
-                       d_xref, rec);
+                       d_xref, n_iter_procrustes, iter, rec);
     hipLaunchKernelGGL((k_post_apply<DD>), dim3(nb), dim3(PS2_THREADS), 0, h->stream, v,
-                       d_xref ? 1 : 0, do_center, rec, nb, lsm, iter, d_R);
+                       d_xref ? 1 : 0, n_iter_procrustes, do_center, rec, nb, lsm, iter, d_R);
     HIPCHK(h, hipGetLastError());
     return DLSM_OK;
 }
@@ -844,7 +875,7 @@ int dlsm_center(dlsm_chain *h) {
     NEED(h, h->have_X, "latent positions not set");
     HIPCHK(h, hipSetDevice(h->device));
     int rc = DLSM_OK;
-    DISPATCH_D(h, h->D, rc = launch_post<DD>(h, nullptr, 1, nullptr, 0, nullptr));
+    DISPATCH_D(h, h->D, rc = launch_post<DD>(h, nullptr, -1, 1, nullptr, IterRef{0, nullptr}, nullptr));
     if (rc) return rc;
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return DLSM_OK;
@@ -855,7 +886,7 @@ int dlsm_procrustes(dlsm_chain *h, const double *X_ref, double *R_out) {
     NEED(h, h->have_X, "latent positions not set");
     HIPCHK(h, hipSetDevice(h->device));
     int rc = h2d(h, h->xref, X_ref, (size_t)h->T * h->N * h->D); if (rc) return rc;
-    DISPATCH_D(h, h->D, rc = launch_post<DD>(h, h->xref, 0, nullptr, 0, h->dsmall + 32));
+    DISPATCH_D(h, h->D, rc = launch_post<DD>(h, h->xref, -1, 0, nullptr, IterRef{0, nullptr}, h->dsmall + 32));
     if (rc) return rc;
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (R_out) return d2h(h, R_out, h->dsmall + 32, (size_t)h->D * h->D);
@@ -922,6 +953,7 @@ int dlsm_sample_labels(dlsm_chain *h, uint32_t iter, const double *w, int64_t *z
 // ---------------------------------------------------------------- LSM chain
 int dlsm_lsm_configure(dlsm_chain *h, const dlsm_lsm_config *cfg) {
     NEED(h, h && cfg, "null argument");
+    drop_graph(h);
     NEED(h, cfg->intercept_variance_prior > 0, "intercept_variance_prior must be positive");
     NEED(h, cfg->i_tune_interval > 0, "tune_interval must be positive");
     HIPCHK(h, hipSetDevice(h->device));
@@ -962,6 +994,7 @@ int dlsm_lsm_get_config(dlsm_chain *h, dlsm_lsm_config *cfg) {
 
 int dlsm_trace_alloc(dlsm_chain *h, int n_total, double logp0) {
     NEED(h, h && n_total >= 1, "bad argument");
+    drop_graph(h);
     NEED(h, h->have_X, "latent positions not set");
     HIPCHK(h, hipSetDevice(h->device));
     const size_t row = (size_t)h->T * h->N * h->D;
@@ -985,6 +1018,35 @@ int dlsm_trace_alloc(dlsm_chain *h, int n_total, double logp0) {
     return DLSM_OK;
 }
 
+// One Gibbs iteration of the undirected LSM on the handle's stream (lsm.py:474-572).
+// With `counter` the iteration index is read from device memory (captured graph: the
+// first kernel advances it), otherwise it is the value `it`.
+static int enqueue_lsm_iteration(dlsm_chain *h, int it, bool counter, int procrustes_ref,
+                                 bool alloc_only = false) {
+    const size_t row = (size_t)h->T * h->N * h->D;
+    const IterRef ir{(uint32_t)it, counter ? &h->lsm->iter : nullptr};
+    int rc = DLSM_OK;
+    if (counter && !alloc_only)
+        hipLaunchKernelGGL(k_advance_iter, dim3(1), dim3(1), 0, h->stream, &h->lsm->iter);
+    rc = enqueue_sweep(h, ir, h->lsm_cfg.sweep_algo, alloc_only); if (rc) return rc;
+    const double *xref = procrustes_ref >= 0 ? h->trace_X + row * procrustes_ref : nullptr;
+    DISPATCH_D(h, h->D, rc = launch_post<DD>(h, xref, h->lsm_cfg.n_iter_procrustes, 1, h->lsm,
+                                             ir, nullptr, alloc_only));
+    if (rc) return rc;
+    if (alloc_only) return ensure_partials(h, (size_t)ll_blocks(h) * 4);
+    int nrec = 0;
+    rc = loglik_records(h, 2, h->lsm->cand, nullptr, nullptr, &nrec); if (rc) return rc;
+    {
+        ProfScope ps(h, DLSM_K_FINALIZE);
+        hipLaunchKernelGGL(k_lsm_finalize, dim3(1), dim3(256), 0, h->stream, h->partials, nrec,
+                           h->lsm, h->intercept, h->trace_ic, h->trace_logp, ir);
+        hipLaunchKernelGGL(k_trace_copy, dim3(64), dim3(256), 0, h->stream, h->X, h->trace_X,
+                           row, ir);
+    }
+    HIPCHK(h, hipGetLastError());
+    return DLSM_OK;
+}
+
 int dlsm_lsm_run(dlsm_chain *h, int first, int count, int procrustes_ref) {
     NEED(h, h != nullptr, "null handle");
     NEED(h, h->model == DLSM_UNDIRECTED, "the device-resident loop covers the undirected model");
@@ -994,23 +1056,51 @@ int dlsm_lsm_run(dlsm_chain *h, int first, int count, int procrustes_ref) {
     NEED(h, procrustes_ref < h->trace_n, "procrustes_ref out of the trace");
     HIPCHK(h, hipSetDevice(h->device));
     int rc = check_ready_sweep(h); if (rc) return rc;
-    const size_t row = (size_t)h->T * h->N * h->D;
-    for (int it = first; it < first + count; ++it) {
-        rc = enqueue_sweep(h, (uint32_t)it, h->lsm_cfg.sweep_algo); if (rc) return rc;
-        const double *xref = (it > h->lsm_cfg.n_iter_procrustes && procrustes_ref >= 0)
-                                 ? h->trace_X + row * procrustes_ref : nullptr;
-        DISPATCH_D(h, h->D, rc = launch_post<DD>(h, xref, 1, h->lsm, (uint32_t)it, nullptr));
-        if (rc) return rc;
-        int nrec = 0;
-        rc = loglik_records(h, 2, h->lsm->cand, nullptr, nullptr, &nrec); if (rc) return rc;
-        {
-            ProfScope ps(h, DLSM_K_FINALIZE);
-            hipLaunchKernelGGL(k_lsm_finalize, dim3(1), dim3(256), 0, h->stream, h->partials,
-                               nrec, h->lsm, h->intercept, h->trace_ic, h->trace_logp, it);
-            HIPCHK(h, hipMemcpyAsync(h->trace_X + row * it, h->X, row * sizeof(double),
-                                     hipMemcpyDeviceToDevice, h->stream));
+    if (count == 0) return DLSM_OK;
+    // Replay path (opt-in, DLSM_GRAPH=1): one iteration captured into a hipGraph, so an
+    // iteration costs the host one call instead of ~40 launches; kernel arguments are
+    // frozen in a graph, hence the device-side iteration counter.  On MI355X the GPU is
+    // the limit either way (eager 1874 it/s, replay 1840 it/s at C2), so eager is the
+    // default; replay is for hosts that cannot spare a core per chain.
+    const bool want_graph = !h->profiling && !h->graph_failed && count >= 2 &&
+                            getenv("DLSM_GRAPH") && atoi(getenv("DLSM_GRAPH")) == 1;
+    if (want_graph) {
+        if (!h->graph_exec || h->graph_ref != procrustes_ref ||
+            h->graph_algo != h->lsm_cfg.sweep_algo) {
+            drop_graph(h);
+            rc = enqueue_lsm_iteration(h, first, true, procrustes_ref, true);   // allocations
+            if (rc) return rc;
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            bool ok = hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+            if (ok) {
+                rc = enqueue_lsm_iteration(h, first, true, procrustes_ref);
+                hipError_t e = hipStreamEndCapture(h->stream, &h->graph);
+                ok = rc == DLSM_OK && e == hipSuccess && h->graph &&
+                     hipGraphInstantiate(&h->graph_exec, h->graph, nullptr, nullptr, 0) == hipSuccess;
+            }
+            if (!ok) {
+                (void)hipGetLastError();
+                drop_graph(h);
+                h->graph_failed = true;       // fall back to eager launches for good
+            } else {
+                h->graph_ref = procrustes_ref;
+                h->graph_algo = h->lsm_cfg.sweep_algo;
+            }
         }
-        HIPCHK(h, hipGetLastError());
+        if (h->graph_exec) {
+            uint32_t *hp = (uint32_t *)h->hsmall;
+            hp[0] = (uint32_t)(first - 1);
+            HIPCHK(h, hipMemcpyAsync(&h->lsm->iter, hp, sizeof(uint32_t), hipMemcpyHostToDevice,
+                                     h->stream));
+            HIPCHK(h, hipStreamSynchronize(h->stream));   // hsmall is reused by other calls
+            for (int i = 0; i < count; ++i) HIPCHK(h, hipGraphLaunch(h->graph_exec, h->stream));
+            return DLSM_OK;
+        }
+    }
+    for (int it = first; it < first + count; ++it) {
+        rc = enqueue_lsm_iteration(h, it, false,
+                                   it > h->lsm_cfg.n_iter_procrustes ? procrustes_ref : -1);
+        if (rc) return rc;
     }
     return DLSM_OK;
 }
@@ -1032,6 +1122,7 @@ int dlsm_trace_read(dlsm_chain *h, int first, int count, double *Xs, double *int
 // ---------------------------------------------------------------- measurement
 int dlsm_profile_enable(dlsm_chain *h, int on) {
     NEED(h, h != nullptr, "null handle");
+    drop_graph(h);
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     drain_profile(h);

@@ -43,6 +43,8 @@ struct LsmDeviceState {
     double cand[4];             // candidate intercepts of the current MH step
     double prior_x;             // latent-position prior terms of logp (lsm.py:604-613)
     double logu;                // log-uniform of the intercept accept test
+    uint32_t iter;              // iteration counter of the captured-graph path
+    uint32_t pad_;
 };
 
 struct ProfileSlot {
@@ -95,6 +97,9 @@ struct dlsm_chain {
     bool lsm_configured = false;
     double *trace_X = nullptr, *trace_ic = nullptr, *trace_logp = nullptr;
     int trace_n = 0;
+    // one captured Gibbs iteration (hipGraph), replayed by dlsm_lsm_run
+    hipGraph_t graph = nullptr; hipGraphExec_t graph_exec = nullptr;
+    int graph_ref = -2, graph_algo = -1; bool graph_failed = false;
     // measurement
     bool profiling = false;
     dlsm::ProfileSlot prof[DLSM_K_COUNT];

@@ -18,6 +18,14 @@ enum : uint32_t {
 
 struct U4 { uint32_t x, y, z, w; };
 
+// Iteration index of a launch: a plain value, or (captured graphs, where kernel
+// arguments are frozen) a counter that lives in device memory.
+struct IterRef {
+    uint32_t value;
+    const uint32_t *ptr;
+    __device__ __forceinline__ uint32_t get() const { return ptr ? *ptr : value; }
+};
+
 __host__ __device__ __forceinline__ U4 philox4x32_10(uint64_t seed, uint32_t c0,
                                                      uint32_t c1, uint32_t c2,
                                                      uint32_t c3) {

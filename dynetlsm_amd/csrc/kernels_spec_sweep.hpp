@@ -54,7 +54,8 @@ __device__ __forceinline__ int flush_interval(double E_max) {
 
 template <int D>
 __global__ __launch_bounds__(256) void k_spec_propose(ChainView c, SpecBuf sb,
-                                                      uint32_t iter, int parity) {
+                                                      IterRef ir, int parity) {
+    const uint32_t iter = ir.get();
     const int N = c.N;
     const int s = sb.s0 + blockIdx.y;
     const int t = 2 * s + parity;

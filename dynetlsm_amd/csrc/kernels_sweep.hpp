@@ -74,8 +74,9 @@ __device__ __forceinline__ double delta_directed(double d0, double d1, int y_ji,
 // ---------------------------------------------------------------------------
 template <int D, int MODEL>
 __global__ __launch_bounds__(SW_THREADS) void k_sweep_slice(ChainView c,
-                                                            uint32_t iter,
+                                                            IterRef ir,
                                                             int parity) {
+    const uint32_t iter = ir.get();
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int N = c.N, W = c.W;
     const int t = 2 * blockIdx.x + parity;
@@ -205,7 +206,8 @@ __device__ __forceinline__ double load_sc1(const double *p) {
 
 template <int D>
 __global__ __launch_bounds__(CC_THREADS) void k_sweep_casecontrol(
-    ChainView c, const int32_t *__restrict__ nctrl, uint32_t iter, int parity) {
+    ChainView c, const int32_t *__restrict__ nctrl, IterRef ir, int parity) {
+    const uint32_t iter = ir.get();
     constexpr int PW = PropRec<D>::W;
     __shared__ double sProp[SW_CHUNK * PW];
     __shared__ double sRed[2 * (CC_THREADS / 64)];
@@ -375,7 +377,11 @@ template <int D> struct PostRec { static constexpr int W = 2 * D + D * D + 2; };
 
 template <int D>
 __global__ __launch_bounds__(PS2_THREADS) void k_post_reduce(
-    ChainView c, const double *__restrict__ xref, double *__restrict__ rec) {
+    ChainView c, const double *__restrict__ xref_in, int n_iter_procrustes, IterRef ir,
+    double *__restrict__ rec) {
+    // lsm.py:495: rotate only once it > tune + burn (n_iter_procrustes < 0: always)
+    const double *xref = (xref_in && (n_iter_procrustes < 0 ||
+                                      (int)ir.get() > n_iter_procrustes)) ? xref_in : nullptr;
     constexpr int W = PostRec<D>::W;
     __shared__ double sRed[2 * (PS2_THREADS / 64)];
     const int tid = threadIdx.x;
@@ -423,8 +429,11 @@ __global__ __launch_bounds__(PS2_THREADS) void k_post_reduce(
 // x <- x R - mean R to its rows.  Workgroup 0 also leaves the LSM bookkeeping.
 template <int D>
 __global__ __launch_bounds__(PS2_THREADS) void k_post_apply(
-    ChainView c, int rotate, int do_center, const double *__restrict__ rec, int nrec,
-    LsmDeviceState *lsm, uint32_t iter, double *__restrict__ R_out) {
+    ChainView c, int has_ref, int n_iter_procrustes, int do_center,
+    const double *__restrict__ rec, int nrec, LsmDeviceState *lsm, IterRef ir,
+    double *__restrict__ R_out) {
+    const uint32_t iter = ir.get();
+    const int rotate = has_ref && (n_iter_procrustes < 0 || (int)iter > n_iter_procrustes);
     constexpr int W = PostRec<D>::W;
     __shared__ double sSum[W];
     __shared__ double sR[D * D];
@@ -515,7 +524,8 @@ __global__ __launch_bounds__(PS2_THREADS) void k_post_apply(
 __global__ __launch_bounds__(256) void k_lsm_finalize(
     const double *__restrict__ partials, int nrec, LsmDeviceState *lsm,
     double *__restrict__ intercept, double *__restrict__ trace_ic,
-    double *__restrict__ trace_logp, int it) {
+    double *__restrict__ trace_logp, IterRef ir) {
+    const int it = (int)ir.get();
     __shared__ double scratch[4 * 256];
     __shared__ double sums[4];
     reduce_records(partials, nrec, 4, sums, scratch, threadIdx.x);
@@ -541,5 +551,16 @@ __global__ __launch_bounds__(256) void k_lsm_finalize(
         trace_logp[it] = ll + lsm->prior_x - 0.5 * (b - pm) * (b - pm) / v;
     }
 }
+
+// trace row copy and the iteration counter of the captured-graph path
+__global__ __launch_bounds__(256) void k_trace_copy(const double *__restrict__ X,
+                                                    double *__restrict__ trace_X, size_t row,
+                                                    IterRef ir) {
+    double *dst = trace_X + row * (size_t)ir.get();
+    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < row; q += (size_t)gridDim.x * 256)
+        dst[q] = X[q];
+}
+
+__global__ void k_advance_iter(uint32_t *p) { *p += 1u; }
 
 }  // namespace dlsm

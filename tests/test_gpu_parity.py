@@ -474,6 +474,30 @@ def test_lsm_device_loop_equals_oracle_iterations(eng, monks, N, algo):
     np.testing.assert_allclose(cfg.i_step_size[0], isamp.step_size, rtol=1e-14)
 
 
+def test_lsm_device_loop_graph_replay_equals_eager(eng, monks, monkeypatch):
+    """DLSM_GRAPH=1: the captured iteration (device-side iteration counter, rotation
+    decided in-kernel) replays to the same trace as eager launches, including across
+    the tune+burn boundary where the Procrustes rotation switches on"""
+    Y = monks['Y_undirected']
+    T, N = 3, 18
+    X = np.random.RandomState(5).randn(T, N, 2)
+    out = {}
+    for mode in ('0', '1'):
+        monkeypatch.setenv('DLSM_GRAPH', mode)
+        gg = eng.SamplerGrid(T, N, 0.1, tune=4, tune_interval=2)
+        with eng.Chain(T, N, 2, 'undirected', seed=3, chain_id=2) as c:
+            c.upload_network(Y); c.set_positions(X); c.set_intercepts([0.2])
+            c.set_prior_random_walk(2.0, 0.1); c.set_samplers(gg)
+            c.lsm_configure([0.2], 2.0, tune=4, tune_interval=100, n_iter_procrustes=4,
+                            sweep_algo=1)
+            c.trace_alloc(12, logp0=-3.0)
+            c.lsm_run(1, 4)
+            c.lsm_run(5, 7, procrustes_ref=2)
+            out[mode] = c.trace_read(0, 12)
+    for a, b in zip(out['0'], out['1']):
+        np.testing.assert_array_equal(a, b)
+
+
 def test_lsm_device_loop_procrustes(eng, monks):
     """after tune+burn the loop rotates to the pre-burn MAP sample (lsm.py:495-498)"""
     Y = monks['Y_undirected']
