@@ -14,7 +14,8 @@ c_i64_p = C.POINTER(C.c_int64)
 c_i32_p = C.POINTER(C.c_int32)
 handle_t = C.c_void_p
 
-K_LOGLIK, K_SWEEP, K_CENTER, K_LABELS, K_FINALIZE, K_SWEEP_EVAL, K_SWEEP_RESOLVE = range(7)
+(K_LOGLIK, K_SWEEP, K_CENTER, K_LABELS, K_FINALIZE, K_SWEEP_EVAL, K_SWEEP_RESOLVE,
+ K_INIT) = range(8)
 UNDIRECTED, DIRECTED, DIRECTED_CASE_CONTROL = 0, 1, 2
 
 
@@ -80,6 +81,15 @@ SIGNATURES = {
     'dlsm_lsm_run': (C.c_int, [handle_t, C.c_int, C.c_int, C.c_int]),
     'dlsm_trace_read': (C.c_int, [handle_t, C.c_int, C.c_int, c_double_p, c_double_p,
                                   c_double_p]),
+    'dlsm_init_shortest_paths': (C.c_int, [handle_t]),
+    'dlsm_init_get_dissimilarity': (C.c_int, [handle_t, C.c_int, c_double_p]),
+    'dlsm_init_smacof': (C.c_int, [handle_t, C.c_int, C.c_int, c_double_p, C.c_int,
+                                   C.c_double, c_double_p, c_double_p, c_i32_p]),
+    'dlsm_init_gmds_step': (C.c_int, [handle_t, C.c_int, c_double_p, C.c_double, C.c_int,
+                                      C.c_double, c_double_p, c_double_p, c_i32_p,
+                                      c_double_p]),
+    'dlsm_init_mle_sums': (C.c_int, [handle_t, C.c_double, C.c_double, c_double_p]),
+    'dlsm_init_release': (C.c_int, [handle_t]),
     'dlsm_profile_enable': (C.c_int, [handle_t, C.c_int]),
     'dlsm_profile_read': (C.c_int, [handle_t, C.c_int, c_double_p, C.POINTER(C.c_int)]),
     'dlsm_profile_read_eval_stamps': (C.c_int, [handle_t, c_double_p, C.POINTER(C.c_int)]),

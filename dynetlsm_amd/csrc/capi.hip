@@ -4,6 +4,7 @@
 #include <hip/hip_ext.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -16,6 +17,7 @@
 #include "kernels_sweep.hpp"
 #include "kernels_spec.hpp"
 #include "kernels_spec_sweep.hpp"
+#include "kernels_init.hpp"
 
 using namespace dlsm;
 
@@ -266,7 +268,7 @@ void dlsm_destroy(dlsm_chain *h) {
                     h->radii_alt, h->step, h->nacc, h->nsteps, h->until, h->mu,
                     h->sigma, h->z, h->partials, h->dsmall, h->xref, h->lab_n,
                     h->lab_nk, h->lab_w, h->spec, h->nctrl, h->stamps, h->lsm, h->trace_X, h->trace_ic,
-                    h->trace_logp};
+                    h->trace_logp, h->hops, h->hops_max};
     for (void *p : ptrs) if (p) hipFree(p);
     if (h->hsmall) hipHostFree(h->hsmall);
     if (h->timer0) hipEventDestroy(h->timer0);
@@ -325,6 +327,7 @@ int dlsm_upload_network(dlsm_chain *h, const double *Y) {
     if (flag) FAIL(h, DLSM_E_DATA, "network has entries other than 0.0 / 1.0 "
                                    "(missing-edge sampling is not supported)");
     h->have_network = true;
+    h->have_hops = false;
     return DLSM_OK;
 }
 
@@ -1196,3 +1199,5 @@ int dlsm_timer_stop(dlsm_chain *h, double *ms) {
 }
 
 }  // extern "C"
+
+#include "capi_init.hpp"

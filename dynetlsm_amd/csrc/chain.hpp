@@ -91,6 +91,8 @@ struct dlsm_chain {
     unsigned long long *stamps = nullptr;               // in-kernel timestamps (profiling)
     size_t stamps_cap = 0, stamps_used = 0;             // in [start, end] pairs
     std::vector<std::pair<size_t, size_t>> stamp_launches;   // (first pair, pairs) per launch
+    // initialisation pipeline: hop matrices [T][N][N] and the per-slice maximum
+    uint16_t *hops = nullptr; int *hops_max = nullptr; bool have_hops = false;
     // LSM device-resident chain
     dlsm::LsmDeviceState *lsm = nullptr;
     dlsm_lsm_config lsm_cfg{};

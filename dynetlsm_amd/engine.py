@@ -337,6 +337,51 @@ class Chain(object):
         return Xs, ics[:, :self.n_intercepts], lps
 
     # -- measurement ---------------------------------------------------------
+    # -- starting values -----------------------------------
+    def init_shortest_paths(self):
+        self._ck(self._L.dlsm_init_shortest_paths(self._h))
+
+    def init_get_dissimilarity(self, t):
+        out = np.empty((self.N, self.N))
+        self._ck(self._L.dlsm_init_get_dissimilarity(self._h, int(t), _p(out)))
+        return out
+
+    def init_smacof(self, t, X0, max_iter=300, eps=1e-6):
+        """SMACOF runs from the starting configurations ``X0`` (n_init, N, D);
+        returns (X[n_init, N, D], stress[n_init], n_iter[n_init])."""
+        X0 = np.ascontiguousarray(X0, dtype=np.float64)
+        if X0.ndim == 2:
+            X0 = X0[None]
+        X0 = _f64(X0, (X0.shape[0], self.N, self.D), 'X0')
+        n_init = X0.shape[0]
+        X = np.empty_like(X0)
+        stress = np.empty(n_init)
+        n_iter = np.empty(n_init, dtype=np.int32)
+        self._ck(self._L.dlsm_init_smacof(self._h, int(t), n_init, _p(X0), int(max_iter),
+                                          float(eps), _p(X), _p(stress), _p(n_iter)))
+        return X, stress, n_iter
+
+    def init_gmds_step(self, t, X_prev, lmbda=10.0, max_lanczos=256, tol=1e-12):
+        """One Sarkar-Moore step; returns (X_t, evals[D], info) with info =
+        {'n_lanczos', 'residual'}."""
+        X_prev = _f64(X_prev, (self.N, self.D), 'X_prev')
+        X = np.empty_like(X_prev)
+        evals = np.empty(self.D)
+        nl = np.zeros(1, dtype=np.int32)
+        res = np.zeros(1)
+        self._ck(self._L.dlsm_init_gmds_step(self._h, int(t), _p(X_prev), float(lmbda),
+                                             int(max_lanczos), float(tol), _p(X), _p(evals),
+                                             _p(nl), _p(res)))
+        return X, evals, {'n_lanczos': int(nl[0]), 'residual': float(res[0])}
+
+    def init_mle_sums(self, p0, p1):
+        out = np.empty(3)
+        self._ck(self._L.dlsm_init_mle_sums(self._h, float(p0), float(p1), _p(out)))
+        return out
+
+    def init_release(self):
+        self._ck(self._L.dlsm_init_release(self._h))
+
     def profile_enable(self, on=True):
         self._ck(self._L.dlsm_profile_enable(self._h, int(on)))
 

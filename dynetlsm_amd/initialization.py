@@ -1,47 +1,54 @@
-"""Starting values for the chains (one-off, before the hot loop; host side).
+"""Starting values for the chains, computed on the device.
 
-SURVEY.md 8f ranks the initialisation pipeline as the first thing to move to the
-device after the hot path; until then these are compact numpy / scipy / sklearn
-restatements of what the reference computes with the same third-party libraries:
-generalised MDS (latent_space.py:47-95), radii (:140-153), the conditional MLE
-of scale / intercepts (lsm.py:32-97; each objective evaluation is one fused
-log-likelihood pass on the GPU) and longitudinal k-means (latent_space.py:98-137).
+The reference builds them with scipy / scikit-learn on the host
+(latent_space.py:36-95, lsm.py:32-97); at N = 2000 that costs minutes, far more
+than the chain itself.  Here the O(N^2)-and-up parts are kernels of the engine
+(csrc/kernels_init.hpp) behind ``Chain.init_*``:
+
+* shortest-path dissimilarities: bitset BFS on the packed network;
+* the first slice's metric MDS: SMACOF, all ``n_init`` starts concurrently, from
+  the same ``RandomState.uniform`` starts sklearn would draw;
+* the Sarkar-Moore eigen steps: Lanczos on the implicit double-centred matrix;
+* objective + gradient of the conditional MLEs in one fused pass.
+
+The host keeps what is O(1) or O(N): the 2-parameter BFGS driver
+(scipy.optimize.minimize, as the reference), the radii (a degree count) and
+longitudinal k-means on the N x (T D) trajectories.
 """
+import warnings
+
 import numpy as np
-from scipy.linalg import eigh, orthogonal_procrustes
 from scipy.optimize import minimize
-from scipy.sparse import csgraph
 
 __all__ = ['generalized_mds', 'initialize_radii', 'scale_intercept_mle',
            'directed_intercept_mle', 'longitudinal_kmeans']
 
-
-def _shortest_path_dissimilarity(Y):
-    dist = csgraph.shortest_path(Y, directed=False, unweighted=True)
-    inf = np.isinf(dist)
-    dist[inf] = np.max(dist[~inf]) + 1      # unconnected: largest distance + 1
-    return dist
+# sklearn.manifold.MDS defaults of the scikit-learn (1.7) the fixtures were made with
+MDS_N_INIT, MDS_MAX_ITER, MDS_EPS = 4, 300, 1e-6
 
 
-def generalized_mds(Y, n_features=2, is_directed=False, lmbda=10, random_state=None):
-    """Sarkar & Moore (2005) generalised MDS of a dynamic network."""
-    from sklearn.manifold import MDS
-    T, N, _ = Y.shape
-    Dm = np.stack([_shortest_path_dissimilarity(Y[t]) for t in range(T)])
-    X = np.empty((T, N, n_features))
-    X[0] = MDS(dissimilarity='precomputed', n_components=n_features,
-               random_state=random_state).fit_transform(Dm[0])
-    H = np.eye(N) - np.ones((N, N)) / N
-    alpha, beta = 1 / (1 + lmbda), lmbda / (1 + lmbda)
+def generalized_mds(chain, is_directed=False, lmbda=10, random_state=None,
+                    max_lanczos=256, tol=1e-12):
+    """Sarkar & Moore (2005) generalised MDS (latent_space.py:47-95) of the network
+    uploaded to ``chain``; returns X (T, N, D).  ``random_state`` is consumed as
+    sklearn's MDS consumes it (n_init uniform starting configurations)."""
+    T, N, D = chain.T, chain.N, chain.D
+    rng = (random_state if isinstance(random_state, np.random.RandomState)
+           else np.random.RandomState(random_state))
+    chain.init_shortest_paths()
+    X0 = np.stack([rng.uniform(size=N * D).reshape(N, D) for _ in range(MDS_N_INIT)])
+    Xs, stress, _ = chain.init_smacof(0, X0, max_iter=MDS_MAX_ITER, eps=MDS_EPS)
+    X = np.empty((T, N, D))
+    X[0] = Xs[int(np.argmin(stress))]          # first minimum, as sklearn's `<`
     for t in range(1, T):
-        G = alpha * H.dot((-0.5 * Dm[t] ** 2).dot(H)) + beta * X[t - 1].dot(X[t - 1].T)
-        evals, evecs = eigh(G)
-        evals, evecs = evals[::-1], evecs[:, ::-1]
-        X[t] = evecs[:, :n_features] * np.sqrt(evals[:n_features])
-        R, _ = orthogonal_procrustes(X[t], X[t - 1])
-        X[t] = X[t].dot(R)
+        X[t], _, info = chain.init_gmds_step(t, X[t - 1], lmbda=lmbda,
+                                             max_lanczos=max_lanczos, tol=tol)
+        if info['residual'] > 1e3 * tol:
+            warnings.warn('generalized_mds: Lanczos residual %.2e at t=%d after %d '
+                          'vectors' % (info['residual'], t, info['n_lanczos']))
+    chain.init_release()
     if is_directed:
-        X /= N           # same scale as the radii
+        X /= N           # same scale as the radii (latent_space.py:92-93)
     return X
 
 
@@ -54,55 +61,30 @@ def initialize_radii(Y, reg=1e-5):
     return radii
 
 
-def _pairwise(X):
-    sq = (X * X).sum(-1)
-    d2 = sq[:, :, None] + sq[:, None, :] - 2 * np.einsum('tid,tjd->tij', X, X)
-    return np.sqrt(np.maximum(d2, 0.0))
-
-
-def scale_intercept_mle(chain, Y, X, tol=1e-4):
+def scale_intercept_mle(chain, X, tol=1e-4):
     """Conditional MLE of (log scale, intercept) of the undirected model by BFGS
-    (lsm.py:47-70).  The objective is evaluated on the GPU (one fused pass per
-    call); the gradient is the closed form of lsm.py:32-44 in numpy."""
-    T, N, _ = X.shape
-    iu = np.triu_indices(N, 1)
-    dist = np.stack([_pairwise(X[t:t + 1])[0][iu] for t in range(T)])
-    y = np.stack([Y[t][iu] for t in range(T)])
+    (lsm.py:47-70); objective and gradient (lsm.py:32-44) are one fused pass over
+    the dyads on the device per evaluation."""
+    chain.set_positions(X)
 
     def fun(x):
-        chain.set_positions(X * np.exp(x[0]))
-        return -chain.loglik_full([[x[1]]])[0]
+        s = chain.init_mle_sums(x[0], x[1])
+        return -s[0], -s[1:]
 
-    def grad(x):
-        sd = np.exp(x[0]) * dist
-        eta = x[1] - sd
-        p = 1 / (1 + np.exp(-eta))
-        return -np.array([np.sum(-sd * (y - p)) * 2, np.sum(y - p)])
-
-    res = minimize(fun=fun, x0=np.array([0.0, 1.0]), method='BFGS', jac=grad, tol=tol)
+    res = minimize(fun=fun, x0=np.array([0.0, 1.0]), method='BFGS', jac=True, tol=tol)
     return res.x[0], res.x[1]
 
 
-def directed_intercept_mle(chain, Y, X, radii, tol=1e-4):
+def directed_intercept_mle(chain, X, radii, tol=1e-4):
     """Conditional MLE of (intercept_in, intercept_out) (lsm.py:73-97)."""
-    T, N, _ = X.shape
-    dist = _pairwise(X)
-    off = ~np.eye(N, dtype=bool)
-    d_in = (1 - dist / radii[None, None, :])[:, off]
-    d_out = (1 - dist / radii[None, :, None])[:, off]
-    y = Y[:, off]
     chain.set_positions(X)
     chain.set_radii(radii)
 
     def fun(x):
-        return -chain.loglik_full([[x[0], x[1]]])[0]
+        s = chain.init_mle_sums(x[0], x[1])
+        return -s[0], -s[1:]
 
-    def grad(x):
-        eta = x[0] * d_in + x[1] * d_out
-        step = y - 1 / (1 + np.exp(-eta))
-        return -np.array([np.sum(d_in * step), np.sum(d_out * step)])
-
-    res = minimize(fun=fun, x0=np.array([0.0, 0.0]), method='BFGS', jac=grad, tol=tol)
+    res = minimize(fun=fun, x0=np.array([0.0, 0.0]), method='BFGS', jac=True, tol=tol)
     return res.x[0], res.x[1]
 
 

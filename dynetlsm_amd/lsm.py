@@ -179,16 +179,16 @@ class DynamicNetworkLSM(object):
             if self.is_directed:
                 radii = np.array(init['radii'], dtype=np.float64)
         else:
-            X = init_mod.generalized_mds(Y, n_features=D, is_directed=self.is_directed,
-                                         random_state=rng)
             with Chain(T, N, D, exact_model, device=self.device) as c0:
                 c0.upload_network(Y)
+                X = init_mod.generalized_mds(c0, is_directed=self.is_directed,
+                                             random_state=rng)
                 if self.is_directed:
                     radii = init_mod.initialize_radii(Y)
-                    b_in, b_out = init_mod.directed_intercept_mle(c0, Y, X, radii)
+                    b_in, b_out = init_mod.directed_intercept_mle(c0, X, radii)
                     intercept = np.array([b_in, b_out])
                 else:
-                    scale, b = init_mod.scale_intercept_mle(c0, Y, X)
+                    scale, b = init_mod.scale_intercept_mle(c0, X)
                     intercept = np.array([b])
                     X = X * np.exp(scale)
         X = X - np.mean(X, axis=(0, 1))

@@ -162,12 +162,48 @@ int dlsm_lsm_run(dlsm_chain *h, int first, int count, int procrustes_ref);
 int dlsm_trace_read(dlsm_chain *h, int first, int count, double *Xs,
                     double *intercepts, double *logps);
 
+/* ---- starting values (generalized_mds + conditional MLEs) -- */
+/* shortest_path_dissimilarity (latent_space.py:36-44) of every time slice, from
+ * the bit-packed network (symmetrised for directed models, as
+ * csgraph.shortest_path(directed=False, unweighted=True) does): hop counts
+ * [T][N][N] kept on the device as uint16, unconnected pairs = largest finite
+ * hop count of the slice + 1. */
+int dlsm_init_shortest_paths(dlsm_chain *h);
+/* slice t of the above as float64 N*N */
+int dlsm_init_get_dissimilarity(dlsm_chain *h, int t, double *out);
+/* MDS(dissimilarity='precomputed').fit_transform(D[t]) (latent_space.py:66-68):
+ * sklearn's metric SMACOF (_smacof_single, scikit-learn >= 1.7 convergence rule
+ * (old_stress - stress) / (sum dis^2 / 2) < eps) run from n_init starting
+ * configurations X0 (n_init*N*D, the caller draws them: RandomState.uniform)
+ * concurrently.  Per run: final configuration, raw stress and n_iter; the caller
+ * keeps the run of least stress as sklearn.manifold.smacof does. */
+int dlsm_init_smacof(dlsm_chain *h, int t, int n_init, const double *X0, int max_iter,
+                     double eps, double *X_out, double *stress_out, int32_t *n_iter_out);
+/* one step t >= 1 of generalized_mds (latent_space.py:71-89): top-D eigenpairs of
+ * alpha H(-D_t^2/2)H + beta X_prev X_prev^T (alpha = 1/(1+lmbda), beta =
+ * lmbda/(1+lmbda)) by Lanczos with full reorthogonalisation (at most max_lanczos
+ * vectors, stop at relative residual tol), X = V sqrt(evals), then the Procrustes
+ * rotation onto X_prev (procrustes.py:20-25).  X_prev, X_out: N*D. */
+int dlsm_init_gmds_step(dlsm_chain *h, int t, const double *X_prev, double lmbda,
+                        int max_lanczos, double tol, double *X_out, double *evals_out,
+                        int32_t *n_lanczos_out, double *resid_out);
+/* objective and gradient of the conditional MLEs at the handle's positions:
+ * undirected (scale_intercept_mle, lsm.py:32-70): p0 = log scale, p1 = intercept,
+ *   out = [loglik, scale_grad, undirected_intercept_grad];
+ * directed (directed_intercept_mle, lsm.py:73-97): p0 = b_in, p1 = b_out,
+ *   out = [loglik, directed_intercept_grad in, out]
+ *   (directed_likelihoods_fast.pyx:20-43). */
+int dlsm_init_mle_sums(dlsm_chain *h, double p0, double p1, double *out);
+/* free the hop matrices */
+int dlsm_init_release(dlsm_chain *h);
+
 /* ---- measurement ------------------------------------------------------ */
 enum {
     DLSM_K_LOGLIK = 0, DLSM_K_SWEEP = 1, DLSM_K_CENTER = 2, DLSM_K_LABELS = 3,
     DLSM_K_FINALIZE = 4,
     DLSM_K_SWEEP_EVAL = 5,     /* k_spec_eval launches of the speculative sweep */
     DLSM_K_SWEEP_RESOLVE = 6,  /* k_spec_resolve launches */
+    DLSM_K_INIT = 7,           /* every kernel of the dlsm_init_* calls */
     DLSM_K_COUNT = 8
 };
 /* when enabled every launch of the kernel classes above is bracketed by HIP

@@ -37,3 +37,8 @@ def golden_fits():
 @pytest.fixture(scope='session')
 def monks():
     return load_golden('monks.npz')
+
+
+@pytest.fixture(scope='session')
+def golden_init():
+    return load_golden('init.npz')

@@ -443,10 +443,100 @@ def gen_more_envelopes(ref, Yd):
     print('more_envelopes.npz')
 
 
+def latent_network(seed, T, N, directed, intercept=1.0, drift=0.1):
+    """small latent-space network whose geometry the init pipeline can recover"""
+    rng = np.random.RandomState(seed)
+    X = np.empty((T, N, 2))
+    X[0] = rng.randn(N, 2) * 1.5
+    for t in range(1, T):
+        X[t] = X[t - 1] + drift * rng.randn(N, 2)
+    Y = np.zeros((T, N, N))
+    for t in range(T):
+        d = np.sqrt(((X[t][:, None] - X[t][None]) ** 2).sum(-1))
+        P = 1 / (1 + np.exp(-(intercept - d)))
+        U = rng.rand(N, N)
+        A = (U < P).astype(float)
+        if not directed:
+            A = np.triu(A, 1)
+            A = A + A.T
+        np.fill_diagonal(A, 0)
+        Y[t] = A
+    return Y
+
+
+def gen_init(ref):
+    """the initialisation pipeline: shortest-path dissimilarities,
+    generalized_mds (sklearn SMACOF + Sarkar-Moore eigen steps), initialize_radii and
+    the conditional MLEs with their gradients, all from the reference's functions."""
+    import sklearn
+    import scipy
+    from dynetlsm.latent_space import (shortest_path_dissimilarity, generalized_mds,
+                                       initialize_radii)
+    from dynetlsm.lsm import (scale_intercept_mle, directed_intercept_mle, scale_grad,
+                              undirected_intercept_grad)
+    from dynetlsm.directed_likelihoods_fast import directed_intercept_grad
+    from dynetlsm.network_likelihoods import (
+        dynamic_network_loglikelihood_undirected, dynamic_network_loglikelihood_directed)
+    from dynetlsm.latent_space import calculate_distances
+    out = {'sklearn_version': np.array(sklearn.__version__),
+           'scipy_version': np.array(scipy.__version__)}
+    cases = [('u', 4, 40, False, 11), ('d', 3, 30, True, 12), ('u3', 3, 25, False, 13)]
+    for tag, T, N, directed, seed in cases:
+        Y = latent_network(seed, T, N, directed)
+        if tag == 'u':
+            # two components and an isolated node in slice 1 (the imputed distance path)
+            Y[1, :5, 5:] = 0; Y[1, 5:, :5] = 0
+            Y[1, 7, :] = 0; Y[1, :, 7] = 0
+        D = 3 if tag == 'u3' else 2
+        out[tag + '_Y'] = Y
+        out[tag + '_D'] = np.stack([shortest_path_dissimilarity(Y[t]) for t in range(T)])
+        rng = np.random.RandomState(100 + seed)
+        X = generalized_mds(Y, n_features=D, is_directed=directed, random_state=rng)
+        out[tag + '_seed'] = np.array(100 + seed)
+        out[tag + '_X'] = X
+        pts = np.array([[0.0, 1.0], [0.3, -0.5], [-0.7, 2.0]])
+        if directed:
+            radii = initialize_radii(Y)
+            out[tag + '_radii'] = radii
+            dist = calculate_distances(X)
+            g = np.stack([directed_intercept_grad(Y, dist, radii, p[0], p[1]) for p in pts])
+            f = np.array([dynamic_network_loglikelihood_directed(
+                Y, X, p[0], p[1], radii, dist=dist) for p in pts])
+            out[tag + '_mle_points'] = pts
+            out[tag + '_mle_f'] = f
+            out[tag + '_mle_g'] = g
+            out[tag + '_mle'] = np.array(directed_intercept_mle(Y, X, radii))
+        else:
+            dist = calculate_distances(X)
+            f = np.array([dynamic_network_loglikelihood_undirected(
+                Y, X, p[1], dist=np.exp(p[0]) * dist) for p in pts])
+            g = np.stack([[scale_grad(Y, X, p[1], p[0], dist=dist),
+                           undirected_intercept_grad(Y, X, p[1], dist=np.exp(p[0]) * dist)]
+                          for p in pts])
+            out[tag + '_mle_points'] = pts
+            out[tag + '_mle_f'] = f
+            out[tag + '_mle_g'] = g
+            out[tag + '_mle'] = np.array(scale_intercept_mle(Y, X))
+    # static network path (2-d Y -> squeeze) and radii with an isolated node
+    Ys = latent_network(21, 1, 20, False)[0]
+    out['static_Y'] = Ys
+    out['static_X'] = generalized_mds(Ys, n_features=2,
+                                      random_state=np.random.RandomState(5))
+    Yz = latent_network(22, 2, 12, True)
+    Yz[:, 3, :] = 0; Yz[:, :, 3] = 0
+    out['radii_Y'] = Yz
+    out['radii_expected'] = initialize_radii(Yz)
+    np.savez_compressed(os.path.join(HERE, 'init.npz'), **out)
+    print('init.npz')
+
+
 if __name__ == '__main__':
     ref = import_reference()
     if len(sys.argv) > 1 and sys.argv[1] == 'hdp':
         gen_hdp_trace(ref)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'init':
+        gen_init(ref)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'env2':
         gen_more_envelopes(ref, np.load(os.path.join(HERE, 'monks.npz'))['Y_directed'])
@@ -458,3 +548,4 @@ if __name__ == '__main__':
     gen_chain_envelopes(ref, Yu)
     gen_hdp_trace(ref)
     gen_more_envelopes(ref, Yd)
+    gen_init(ref)
