@@ -410,28 +410,34 @@ __global__ __launch_bounds__(SM_THREADS) void k_mle_sums(ChainView c, double p0,
         for (int d = 0; d < D; ++d) xi[d] = X[(size_t)i * D + d];
         const uint32_t *yrow = c.ybits + ((size_t)t * N + i) * W;
         const double ri = MODEL == DLSM_UNDIRECTED ? 1.0 : c.radii[i];
-        for (int j = lane; j < N; j += 64) {
+        // undirected: each dyad once (the upper triangle j > i, as the reference's
+        // log-likelihood), weighted as its gradient sums over both orders; one exp
+        // per dyad: e = exp(-|eta|) gives both softplus and expit
+        const int jbeg = MODEL == DLSM_UNDIRECTED ? i + 1 : 0;
+        for (int j = jbeg + lane; j < N; j += 64) {
             if (j == i) continue;
             double xj[D];
 #pragma unroll
             for (int d = 0; d < D; ++d) xj[d] = X[(size_t)j * D + d];
             const double dist = dist_of<D>(xi, xj, c.squared);
             const double y = (double)bit_of(yrow, j);
+            double eta, sd = 0.0, d_in = 0.0, d_out = 0.0;
             if (MODEL == DLSM_UNDIRECTED) {
-                const double sd = scale * dist;
-                const double eta = p1 - sd;
-                const double sp = eta > 0.0 ? eta + log1p(exp(-eta)) : log1p(exp(eta));
-                const double step = y - 1.0 / (1.0 + exp(-eta));
-                s0 += 0.5 * (y * eta - sp);
-                s1 += -sd * step;
-                s2 += 0.5 * step;
+                sd = scale * dist;
+                eta = p1 - sd;
             } else {
-                const double d_in = 1.0 - dist / c.radii[j];
-                const double d_out = 1.0 - dist / ri;
-                const double eta = p0 * d_in + p1 * d_out;
-                const double sp = eta > 0.0 ? eta + log1p(exp(-eta)) : log1p(exp(eta));
-                const double step = y - 1.0 / (1.0 + exp(-eta));
-                s0 += y * eta - sp;
+                d_in = 1.0 - dist / c.radii[j];
+                d_out = 1.0 - dist / ri;
+                eta = p0 * d_in + p1 * d_out;
+            }
+            const double e = exp(-fabs(eta));
+            const double sp = fmax(eta, 0.0) + log1p(e);
+            const double step = y - (eta >= 0.0 ? 1.0 : e) / (1.0 + e);
+            s0 += y * eta - sp;
+            if (MODEL == DLSM_UNDIRECTED) {
+                s1 += -2.0 * sd * step;
+                s2 += step;
+            } else {
                 s1 += d_in * step;
                 s2 += d_out * step;
             }

@@ -161,3 +161,46 @@ def test_c4_case_control_at_full_size(eng):
         np.testing.assert_allclose(c.get_positions(), st.X, atol=1e-12)
         assert 0.02 < og.n_accepted.mean() < 0.98
     print('C4: resample %.1f ms, sweep %.1f ms' % (1e3 * t_res, 1e3 * t_sw))
+
+
+def test_c2_init_pipeline_at_full_size(eng, c2):
+    """SURVEY.md 8f-1 at N = 2000: hop matrices against the library the reference calls
+    (scipy.sparse.csgraph, one slice) and their metric properties on all slices; SMACOF
+    against the oracle over its first iterations and as a descent method over all of them;
+    the Lanczos eigen step against a dense eigh of the explicit matrix."""
+    from scipy.sparse import csgraph
+    from oracle import init_oracle as io
+    Y = c2['Y']
+    T, N = Y.shape[:2]
+    with eng.Chain(T, N, 2, 'undirected', seed=3) as c:
+        c.upload_network(Y)
+        c.init_shortest_paths()
+        D0 = c.init_get_dissimilarity(0)
+        ref = csgraph.shortest_path(Y[0], directed=False, unweighted=True)
+        inf = np.isinf(ref)
+        ref[inf] = ref[~inf].max() + 1
+        np.testing.assert_array_equal(D0, ref)
+        rng = np.random.RandomState(0)
+        for t in (3, 9):
+            Dt = c.init_get_dissimilarity(t)
+            np.testing.assert_array_equal(Dt, Dt.T)
+            assert (np.diag(Dt) == 0).all()
+            np.testing.assert_array_equal(Dt == 1, Y[t] == 1)         # one hop = an edge
+            i, j, k = rng.randint(0, N, size=(3, 20000))
+            assert (Dt[i, k] <= Dt[i, j] + Dt[j, k]).all()            # triangle inequality
+        X0 = rng.uniform(size=(2, N, 2))
+        Xa, sa, na = c.init_smacof(0, X0, max_iter=4)
+        for r in range(2):
+            Xo, so, no = io.smacof_single(D0, X0[r], max_iter=4)
+            assert na[r] == no
+            np.testing.assert_allclose(sa[r], so, rtol=1e-10)
+            assert np.abs(Xa[r] - Xo).max() < 1e-10 * np.abs(Xo).max()
+        stresses = [c.init_smacof(0, X0[:1], max_iter=m, eps=0.0)[1][0] for m in (1, 5, 25, 125)]
+        assert all(a > b for a, b in zip(stresses, stresses[1:]))     # majorisation descends
+        Xb, sb, nb = c.init_smacof(0, X0)
+        assert (sb <= stresses[-1] * 1.001).all()
+        Xp = Xb[int(np.argmin(sb))]
+        X1, evals, info = c.init_gmds_step(1, Xp)
+        Xo, eo = io.gmds_step(c.init_get_dissimilarity(1), Xp)
+        np.testing.assert_allclose(evals, eo, rtol=1e-10)
+        assert np.abs(X1 - Xo).max() < 1e-9 * np.abs(Xo).max(), info
