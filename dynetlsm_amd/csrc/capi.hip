@@ -17,6 +17,7 @@
 #include "kernels_sweep.hpp"
 #include "kernels_spec.hpp"
 #include "kernels_spec_sweep.hpp"
+#include "kernels_spec_pipe.hpp"
 #include "kernels_init.hpp"
 
 using namespace dlsm;
@@ -229,6 +230,7 @@ int dlsm_create(int device, int T, int N, int D, int model, uint64_t seed,
     h->device = device; h->T = T; h->N = N; h->D = D; h->model = model;
     h->seed = seed; h->chain = chain_id;
     h->W = ((N + 31) / 32 + 3) / 4 * 4;
+    h->n_cu = prop.multiProcessorCount;
     auto bail = [&](int rc) { g_err = h->err; dlsm_destroy(h); return rc; };
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess)
         { h->err = "hipStreamCreate failed"; return bail(DLSM_E_HIP); }
@@ -268,7 +270,7 @@ void dlsm_destroy(dlsm_chain *h) {
                     h->radii_alt, h->step, h->nacc, h->nsteps, h->until, h->mu,
                     h->sigma, h->z, h->partials, h->dsmall, h->xref, h->lab_n,
                     h->lab_nk, h->lab_w, h->spec, h->nctrl, h->stamps, h->lsm, h->trace_X, h->trace_ic,
-                    h->trace_logp, h->hops, h->hops_max};
+                    h->trace_logp, h->hops, h->hops_max, h->pipe};
     for (void *p : ptrs) if (p) hipFree(p);
     if (h->hsmall) hipHostFree(h->hsmall);
     if (h->timer0) hipEventDestroy(h->timer0);
@@ -758,6 +760,73 @@ static int launch_sweep_spec(dlsm_chain *h, IterRef iter, int S, bool alloc_only
     return DLSM_OK;
 }
 
+
+// algo 4: one fused launch per batch, resolve(b) beside eval(b + 1) (kernels_spec_pipe.hpp)
+template <int DD, int MODEL>
+static void launch_pipe_step(dlsm_chain *h, const ChainView &v, const PipeBuf &pb, int grid,
+                             size_t lds, int parity, int b, int be) {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (h->profiling) { hipEventCreate(&e0); hipEventCreate(&e1); }
+    hipExtLaunchKernelGGL((k_pipe_step<DD, MODEL>), dim3(grid), dim3(PP_THREADS), lds, h->stream,
+                          e0, e1, 0, v, pb, parity, b, be);
+    if (h->profiling) h->prof[DLSM_K_SWEEP_EVAL].pending.emplace_back(e0, e1);
+}
+
+template <int DD>
+static int launch_sweep_pipe(dlsm_chain *h, IterRef iter, bool alloc_only = false) {
+    const int N = h->N, T = h->T;
+    const int nsl_max = (T + 1) / 2;
+    const int nbat = (N + PP_B - 1) / PP_B;
+    const int ne_wg = std::max(1, h->n_cu - nsl_max);
+    int parts = (int)((double)ne_wg * PP_WAVES / ((double)nsl_max * PP_B) + 0.5);
+    if (getenv("DLSM_PIPE_PARTS")) parts = atoi(getenv("DLSM_PIPE_PARTS"));
+    parts = std::max(1, std::min(parts, PP_MAXPARTS));
+    auto even2 = [](size_t n) { return (n + 1) / 2 * 2; };
+    const size_t n_prop = even2((size_t)nsl_max * N * (2 * DD + 2));
+    const size_t n_full0 = (size_t)2 * nsl_max * PP_B * parts * 2;
+    const size_t n_h = (size_t)2 * nsl_max * PP_B * PP_B;
+    const size_t n_acc = even2(((size_t)nsl_max * (PP_B + 1) + 1) / 2);     // int32 pairs
+    const size_t need = (n_prop + n_full0 + 2 * n_h + n_acc + 2) * sizeof(double);
+    if (h->pipe_cap < need) {
+        if (h->pipe) hipFree(h->pipe);
+        h->pipe = nullptr; h->pipe_cap = 0;
+        HIPCHK(h, hipMalloc((void **)&h->pipe, need));
+        h->pipe_cap = need;
+    }
+    PipeBuf pb;
+    pb.prop = h->pipe; pb.full0 = pb.prop + n_prop; pb.Hd = pb.full0 + n_full0;
+    pb.Hx = pb.Hd + n_h; pb.acc = (int32_t *)(pb.Hx + n_h);
+    pb.consts = pb.Hx + n_h + n_acc;
+    pb.parts = parts; pb.per = (N + parts - 1) / parts;
+    pb.dbg = getenv("DLSM_PIPE_DBG") ? atoi(getenv("DLSM_PIPE_DBG")) : 0;
+    const size_t lds = (size_t)PP_B * PP_B * sizeof(double);
+    auto ku = k_pipe_step<DD, DLSM_UNDIRECTED>;
+    auto kd = k_pipe_step<DD, DLSM_DIRECTED>;
+    HIPCHK(h, hipFuncSetAttribute((const void *)ku, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds));
+    HIPCHK(h, hipFuncSetAttribute((const void *)kd, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds));
+    if (alloc_only) return DLSM_OK;
+    ChainView v = h->view();
+    for (int parity = 0; parity < 2; ++parity) {
+        const int nsl = (T - parity + 1) / 2;
+        if (nsl <= 0) continue;
+        pb.nsl = nsl;
+        hipLaunchKernelGGL((k_pipe_propose<DD>), dim3((N + 255) / 256, nsl), dim3(256), 0,
+                           h->stream, v, pb, iter, parity);
+        for (int b = -1; b < nbat; ++b) {
+            const int be = b + 1 < nbat ? b + 1 : -1;
+            const int grid = (b >= 0 ? nsl : 0) + (be >= 0 ? ne_wg : 0);
+            if (h->model == DLSM_UNDIRECTED)
+                launch_pipe_step<DD, DLSM_UNDIRECTED>(h, v, pb, grid, lds, parity, b, be);
+            else
+                launch_pipe_step<DD, DLSM_DIRECTED>(h, v, pb, grid, lds, parity, b, be);
+        }
+    }
+    HIPCHK(h, hipGetLastError());
+    return DLSM_OK;
+}
+
 template <int DD>
 static int launch_sweep(dlsm_chain *h, IterRef iter, int algo, bool alloc_only = false) {
     ChainView v = h->view();
@@ -790,6 +859,7 @@ static int launch_sweep(dlsm_chain *h, IterRef iter, int algo, bool alloc_only =
         return DLSM_OK;
     }
     if (algo == 0) algo = h->N >= 512 ? 3 : (h->N >= 256 ? 2 : 1);
+    if (algo == 4) return launch_sweep_pipe<DD>(h, iter, alloc_only);
     if (algo == 2) return launch_sweep_spec<DD>(h, iter, 1, alloc_only);
     if (algo == 3)
         return launch_sweep_spec<DD>(h, iter, getenv("DLSM_SPEC_S") ? atoi(getenv("DLSM_SPEC_S")) : 2,
@@ -838,7 +908,9 @@ extern "C" {
 
 int dlsm_sweep_positions(dlsm_chain *h, uint32_t iter, int algo) {
     NEED(h, h != nullptr, "null handle");
-    NEED(h, algo >= 0 && algo <= 3, "algo must be 0..3");
+    NEED(h, algo >= 0 && algo <= 4, "algo must be 0..4");
+    NEED(h, algo != 4 || h->model != DLSM_DIRECTED_CASE_CONTROL,
+         "algo 4 serves the exact likelihoods (case-control: algo 1 or 2)");
     HIPCHK(h, hipSetDevice(h->device));
     int rc = check_ready_sweep(h); if (rc) return rc;
     rc = enqueue_sweep(h, IterRef{iter, nullptr}, algo); if (rc) return rc;

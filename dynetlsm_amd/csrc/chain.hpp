@@ -87,6 +87,8 @@ struct dlsm_chain {
     int32_t *lab_n = nullptr, *lab_nk = nullptr; double *lab_w = nullptr;
     // sweep v2 scratch
     double *spec = nullptr; size_t spec_cap = 0;
+    double *pipe = nullptr; size_t pipe_cap = 0;        // pipelined sweep (algo 4) buffers
+    int n_cu = 256;
     int32_t *nctrl = nullptr; size_t nctrl_cap = 0;     // valid controls per (t, i, dir)
     unsigned long long *stamps = nullptr;               // in-kernel timestamps (profiling)
     size_t stamps_cap = 0, stamps_used = 0;             // in [start, end] pairs

@@ -1,0 +1,422 @@
+// Pipelined speculative sweep (algo 4): the speculative-batch scan of
+// kernels_spec_sweep.hpp with the evaluation of batch b + 1 moved off the
+// critical path.
+//
+// In the two-kernel form eval(b + 1) reads the positions resolve(b) has just
+// written, so the launches alternate strictly.  Two facts remove that edge:
+//   * a node moves at most once per parity, so "the position of node i before its
+//     own step" is its position at the start of the parity: a snapshot taken by the
+//     propose kernel is valid for every node that is not resolved yet, however far
+//     the resolver has got;
+//   * the effect of batch b's acceptances on node k of batch b + 1 is the same
+//     H[k][m] correction that already couples the nodes inside a batch.
+// So eval(b + 1) uses X for nodes of batches < b (final), the snapshot for all
+// others, and emits the cross block Hx[k][m], m in batch b, next to its own diagonal
+// block; resolve(b + 1) adds the Hx rows of the nodes batch b accepted.  eval(b + 1)
+// then depends on resolve(b - 1) only, and ONE launch carries both roles:
+//
+//     launch b:  workgroups [0, nsl)   resolve batch b of their slice
+//                workgroups [nsl, ..)  evaluate batch b + 1 (one item per wavefront)
+//
+// No workgroup of a launch reads what another one of the same launch writes; the
+// kernel boundary is the only synchronisation.  Algebraically this is still the
+// sequential Gauss-Seidel scan (differences are rounding only).
+//
+// The accept test runs in the multiplicative domain, u_k < exp(r_k) * prod_m H[k][m]:
+// the evaluators hand over products of (1 + E e^{-d}) factors as they accumulate
+// them, so a wavefront spends one division where the additive form needs a
+// float64 log per node part and per H entry (each executed by all 64 lanes); the
+// resolver pays one exp per node instead.
+#pragma once
+#include "kernels_spec_sweep.hpp"
+
+namespace dlsm {
+
+constexpr int PP_THREADS = 1024;
+constexpr int PP_WAVES = PP_THREADS / 64;
+constexpr int PP_B = 128;               // nodes per batch (two 64-lane halves)
+constexpr int PP_MAXPARTS = 8;
+
+struct PipeBuf {
+    double *prop;    // [nsl][N][2D + 2] : x1[D], u, prior delta, x0[D] (snapshot)
+    double *full0;   // [2][nsl][PP_B][parts][2] : (sum of linear terms, ratio of products)
+    double *Hd;      // [2][nsl][PP_B][PP_B] : Hd[m][k], k > m, both in the batch: the FACTOR
+                     //                       exp(H[k][m]) of node m's acceptance
+    double *Hx;      // [2][nsl][PP_B][PP_B] : Hx[m][k], m in the previous batch
+    int32_t *acc;    // [nsl][PP_B + 1] : count, accepted nodes of the last resolved batch
+    double *consts;  // [2] : E = exp(sum of intercepts), flush interval
+    int parts, per, nsl;
+    int dbg;
+};
+
+template <int D>
+__global__ __launch_bounds__(256) void k_pipe_propose(ChainView c, PipeBuf pb, IterRef ir,
+                                                      int parity) {
+    const uint32_t iter = ir.get();
+    const int N = c.N;
+    const int s = blockIdx.y;
+    const int t = 2 * s + parity;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        const double E = c.model == DLSM_UNDIRECTED ? exp(c.intercept[0])
+                                                    : exp(c.intercept[0] + c.intercept[1]);
+        pb.consts[0] = E;
+        pb.consts[1] = (double)flush_interval(E);
+    }
+    if (j >= N) return;
+    double x0[D], x1[D], logu;
+#pragma unroll
+    for (int d = 0; d < D; ++d) x0[d] = c.X[((size_t)t * N + j) * D + d];
+    make_proposal<D>(c, iter, t, j, x0, c.step[(size_t)t * N + j], x1, logu);
+    double *pr = pb.prop + ((size_t)s * N + j) * (2 * D + 2);
+#pragma unroll
+    for (int d = 0; d < D; ++d) { pr[d] = x1[d]; pr[D + 2 + d] = x0[d]; }
+    {   // the uniform itself (same draw as make_proposal's log u)
+        double u0, u1;
+        philox_uniform2(c.seed, (uint32_t)j, (uint32_t)t, iter,
+                        stream_word(c.chain, STREAM_SWEEP_UNIFORM), u0, u1);
+        pr[D] = u0;
+    }
+    pr[D + 1] = node_log_prior<D>(c, t, j, x1) - node_log_prior<D>(c, t, j, x0);
+}
+
+// One wavefront: part p of node k of batch `be` in slice s.
+template <int D, int MODEL>
+__device__ __forceinline__ void pipe_eval_item(const ChainView &c, const PipeBuf &pb,
+                                               int parity, int be, int s, int k, int p,
+                                               int lane) {
+    constexpr int PW = 2 * D + 2;
+    const int N = c.N, W = c.W;
+    const int t = 2 * s + parity;
+    const int j0 = be * PP_B, jk = j0 + k;
+    const int jprev = max(0, j0 - PP_B);       // nodes >= jprev: snapshot positions
+    const int ncross = j0 - jprev;
+    const int bb = be & 1;
+    const double *Xt = c.X + (size_t)t * N * D;
+    const double *props = pb.prop + (size_t)s * N * PW;
+    const uint32_t *yr = c.ybits + ((size_t)t * N + jk) * W;
+    const uint32_t *yc = MODEL == DLSM_DIRECTED ? c.ytbits + ((size_t)t * N + jk) * W : nullptr;
+    const double E = pb.consts[0];
+    const int nflush = (int)pb.consts[1];
+    double xk0[D], xk1[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        xk0[d] = props[(size_t)jk * PW + D + 2 + d];
+        xk1[d] = props[(size_t)jk * PW + d];
+    }
+    double bin = 0.0, bout = 0.0, irk = 0.0;
+    if (MODEL == DLSM_DIRECTED) {
+        bin = c.intercept[0]; bout = c.intercept[1];
+        irk = 1.0 / c.radii[jk];
+    }
+    const int lo = p * pb.per, hi = min(N, lo + pb.per);
+    // neighbours per lane loaded up front (the directed model carries more per neighbour)
+    constexpr int PP_NPRE = MODEL == DLSM_UNDIRECTED ? 6 : 3;
+    // The item is a chain of dependent latencies, so every load it will need is issued
+    // before the first use: PP_NPRE neighbours per lane (clamped addresses, no
+    // predication) and this lane's first H entry.
+    double xpre[PP_NPRE][D], rpre[PP_NPRE];
+    uint32_t wpre[PP_NPRE], wcpre[PP_NPRE];
+#pragma unroll
+    for (int u = 0; u < PP_NPRE; ++u) {
+        const int ic = min(lo + lane + 64 * u, N - 1);
+        const double *src = ic < jprev ? Xt + (size_t)ic * D : props + (size_t)ic * PW + D + 2;
+#pragma unroll
+        for (int d = 0; d < D; ++d) xpre[u][d] = src[d];
+        wpre[u] = yr[ic >> 5];
+        wcpre[u] = MODEL == DLSM_DIRECTED ? yc[ic >> 5] : 0u;
+        rpre[u] = MODEL == DLSM_DIRECTED ? c.radii[ic] : 1.0;
+    }
+    const int ne = ncross + k;
+    const int e0 = p + pb.parts * lane;
+    const int e0c = min(e0, max(ne - 1, 0));
+    const bool cross0 = e0c < ncross;
+    const int m0 = cross0 ? e0c : e0c - ncross;
+    const int jm0 = (cross0 ? jprev : j0) + m0;
+    double hm0[D], hm1[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        hm0[d] = props[(size_t)jm0 * PW + D + 2 + d];
+        hm1[d] = props[(size_t)jm0 * PW + d];
+    }
+    const uint32_t hw = yr[jm0 >> 5];
+    const uint32_t hwc = MODEL == DLSM_DIRECTED ? yc[jm0 >> 5] : 0u;
+    const double hr = MODEL == DLSM_DIRECTED ? c.radii[jm0] : 1.0;
+
+    double acc = 0.0;
+    RatioAcc ra;
+#define DLSM_PIPE_TERM(I_, XI_, YB_, YCB_, RI_)                                              \
+    {                                                                                         \
+        if (MODEL == DLSM_UNDIRECTED) {                                                       \
+            const double d0_ = dist_fast<D>(XI_, xk0, c.squared);                             \
+            const double d1_ = dist_fast<D>(XI_, xk1, c.squared);                             \
+            if (YB_) ra.lin += d0_ - d1_;                                                     \
+            ra.P0 *= fma(E, fast_exp(-d0_), 1.0);                                             \
+            ra.P1 *= fma(E, fast_exp(-d1_), 1.0);                                             \
+            if (++ra.cnt >= nflush) ra.flush();                                               \
+        } else {                                                                              \
+            const double d0_ = dist_of<D>(XI_, xk0, c.squared);                               \
+            const double d1_ = dist_of<D>(XI_, xk1, c.squared);                               \
+            const double iri_ = 1.0 / (RI_);                                                  \
+            acc += delta_directed(d0_, d1_, YB_, YCB_, bin * iri_ + bout * irk,               \
+                                  bin * irk + bout * iri_, E);                                \
+        }                                                                                     \
+    }
+#pragma unroll
+    for (int u = 0; u < PP_NPRE; ++u) {
+        const int i = lo + lane + 64 * u;
+        if (i < hi && i != jk && !(pb.dbg & 2))
+            DLSM_PIPE_TERM(i, xpre[u], (wpre[u] >> (i & 31)) & 1, (wcpre[u] >> (i & 31)) & 1,
+                           rpre[u])
+    }
+    for (int i = lo + lane + 64 * PP_NPRE; i < hi; i += 64) {
+        if (i == jk) continue;
+        const double *src = i < jprev ? Xt + (size_t)i * D : props + (size_t)i * PW + D + 2;
+        double xi[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) xi[d] = src[d];
+        const double ri = MODEL == DLSM_DIRECTED ? c.radii[i] : 1.0;
+        DLSM_PIPE_TERM(i, xi, bit_of(yr, i), MODEL == DLSM_DIRECTED ? bit_of(yc, i) : 0, ri)
+    }
+#undef DLSM_PIPE_TERM
+    double tot_l, tot_r;
+    if (MODEL == DLSM_UNDIRECTED && nflush >= hi - lo) {
+        // the products of the whole wave stay in range: multiply across lanes
+        double l = ra.lin + ra.lg, q0 = ra.P0, q1 = ra.P1;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            l += __shfl_xor(l, off, 64);
+            q0 *= __shfl_xor(q0, off, 64);
+            q1 *= __shfl_xor(q1, off, 64);
+        }
+        tot_l = l; tot_r = q0 / q1;
+    } else {
+        if (MODEL == DLSM_UNDIRECTED) acc = ra.value();
+        tot_l = wave_sum_all(acc); tot_r = 1.0;
+    }
+    if (lane == 0) {
+        double2 *f = (double2 *)pb.full0 + (((size_t)bb * pb.nsl + s) * PP_B + k) * pb.parts + p;
+        *f = make_double2(tot_l, tot_r);
+    }
+    // H entries of node k: the previous batch (cross block) then the earlier nodes of
+    // its own batch; the parts of a node share them round-robin (the first one per lane
+    // was prefetched above)
+    for (int e = e0; e < ne && !(pb.dbg & 1); e += pb.parts * 64) {
+        const bool cross = e < ncross;
+        const int m = cross ? e : e - ncross;
+        const int jm = (cross ? jprev : j0) + m;
+        double xm0[D], xm1[D], rm;
+        int y1, y2;
+        if (e == e0) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) { xm0[d] = hm0[d]; xm1[d] = hm1[d]; }
+            y1 = (hw >> (jm & 31)) & 1; y2 = (hwc >> (jm & 31)) & 1; rm = hr;
+        } else {
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                xm0[d] = props[(size_t)jm * PW + D + 2 + d];
+                xm1[d] = props[(size_t)jm * PW + d];
+            }
+            y1 = bit_of(yr, jm);
+            y2 = MODEL == DLSM_DIRECTED ? bit_of(yc, jm) : 0;
+            rm = MODEL == DLSM_DIRECTED ? c.radii[jm] : 1.0;
+        }
+        const double a0 = dist_fast<D>(xm0, xk0, c.squared);
+        const double a1 = dist_fast<D>(xm0, xk1, c.squared);
+        const double b0 = dist_fast<D>(xm1, xk0, c.squared);
+        const double b1 = dist_fast<D>(xm1, xk1, c.squared);
+        double h;
+        if (MODEL == DLSM_UNDIRECTED) {
+            const double num = fma(E, fast_exp(-b0), 1.0) * fma(E, fast_exp(-a1), 1.0);
+            const double den = fma(E, fast_exp(-b1), 1.0) * fma(E, fast_exp(-a0), 1.0);
+            h = num / den;
+            if (y1) h *= fast_exp((b0 - b1) - (a0 - a1));
+        } else {
+            const double irm = 1.0 / rm;
+            const double aa = bin * irm + bout * irk, cc = bin * irk + bout * irm;
+            h = exp(delta_directed(b0, b1, y1, y2, aa, cc, E) -
+                    delta_directed(a0, a1, y1, y2, aa, cc, E));
+        }
+        double *dst = cross ? pb.Hx : pb.Hd;
+        if (!(pb.dbg & 4)) dst[(((size_t)bb * pb.nsl + s) * PP_B + m) * PP_B + k] = h;
+        else if (h == 123.456) dst[0] = h;
+    }
+}
+
+// Resolve batch b of slice s: the fixed-point solve of k_spec_resolve for one batch,
+// the acceptances of batch b - 1 entering through gathered rows of the cross block.
+template <int D>
+__device__ __forceinline__ void pipe_resolve(const ChainView &c, const PipeBuf &pb, int parity,
+                                             int b, int s, double *sH, double *sPart,
+                                             unsigned long long (*sMask)[2], int *sPrev) {
+    constexpr int PW = 2 * D + 2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int t = 2 * s + parity;
+    const int N = c.N;
+    const int j0 = b * PP_B;
+    const int nb = min(PP_B, N - j0);
+    const int bb = b & 1;
+    const int half = wave & 1, part = wave >> 1;
+    const int k = 64 * half + lane;
+    const bool owner = wave < 2;
+    const bool valid = k < nb;
+    const double *Hd = pb.Hd + ((size_t)bb * pb.nsl + s) * PP_B * PP_B;
+    const double *Hx = pb.Hx + ((size_t)bb * pb.nsl + s) * PP_B * PP_B;
+    int32_t *accg = pb.acc + (size_t)s * (PP_B + 1);
+    // diagonal block -> LDS (unconditional clamped loads, see k_spec_resolve)
+    double2 blk[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int q = min(u * PP_THREADS + tid, nb * (PP_B / 2) - 1);
+        blk[u] = *(const double2 *)(Hd + (size_t)(q >> 6) * PP_B + 2 * (q & 63));
+    }
+    const int nprev = b > 0 ? accg[0] : 0;
+    for (int a = tid; a < nprev; a += PP_THREADS) sPrev[a] = accg[1 + a];
+    // multiplicative domain: r = exp(log-ratio of node k), lu = its uniform draw
+    double r = 0.0, lu = 0.0, st = 0.0, x1[D];
+    int32_t na = 0, ns = 0, un = 0;
+#pragma unroll
+    for (int d = 0; d < D; ++d) x1[d] = 0.0;
+    if (owner) {
+        const int kc = min(k, nb - 1);
+        const double2 *f = (const double2 *)pb.full0 +
+                           (((size_t)bb * pb.nsl + s) * PP_B + kc) * pb.parts;
+        const int p1 = pb.parts;
+        double2 tv[PP_MAXPARTS];
+#pragma unroll
+        for (int u = 0; u < PP_MAXPARTS; ++u) tv[u] = f[min(u, p1 - 1)];
+        double tot = tv[0].x, pr_ = tv[0].y;
+#pragma unroll
+        for (int u = 1; u < PP_MAXPARTS; ++u) {
+            tot += u < p1 ? tv[u].x : 0.0;
+            pr_ *= u < p1 ? tv[u].y : 1.0;
+        }
+        const double *pr = pb.prop + ((size_t)s * N + j0 + kc) * PW;
+        // exp(r_k): |arguments| beyond 700 decide the test on their own
+        r = exp(fmin(fmax(tot + pr[D + 1], -700.0), 700.0)) * pr_;
+        lu = pr[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) x1[d] = pr[d];
+        const size_t tjc = (size_t)t * N + j0 + kc;
+        st = c.step[tjc]; na = c.nacc[tjc]; ns = c.nsteps[tjc]; un = c.until[tjc];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+        ((double2 *)sH)[min(u * PP_THREADS + tid, nb * (PP_B / 2) - 1)] = blk[u];
+    __syncthreads();                                   // sPrev, sH visible
+    if (nprev > 0) {
+        const double *colp = Hx + min(k, PP_B - 1);
+        double prod = 1.0;
+        int a = part;
+        for (; a + 24 < nprev; a += 32) {
+            const double h0 = colp[(size_t)sPrev[a] * PP_B];
+            const double h1 = colp[(size_t)sPrev[a + 8] * PP_B];
+            const double h2 = colp[(size_t)sPrev[a + 16] * PP_B];
+            const double h3 = colp[(size_t)sPrev[a + 24] * PP_B];
+            prod *= h0; prod *= h1; prod *= h2; prod *= h3;
+        }
+        for (; a < nprev; a += 8) prod *= colp[(size_t)sPrev[a] * PP_B];
+        sPart[wave * 64 + lane] = prod;
+        __syncthreads();
+        if (owner) {
+#pragma unroll
+            for (int p = 0; p < 8; ++p) r *= sPart[(2 * p + half) * 64 + lane];
+        }
+        __syncthreads();
+    }
+    if (owner) {
+        const unsigned long long g = __ballot(valid && !(lu >= r));
+        if (lane == 0) sMask[0][half] = g;
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int pass = 0; pass < 2 * PP_B + 2; ++pass) {
+        const unsigned long long gm = sMask[cur][part >> 2];
+        unsigned int bits = (unsigned int)(gm >> (16 * (part & 3))) & 0xFFFFu;
+        const int mbase = 16 * part;
+        double sum = 1.0;
+        if (half == 1 || part < 4) {                   // rows >= 64 never touch half 0
+            const double *col = sH + k;
+            while (bits) {
+                int f[4];
+                double h[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    f[u] = bits ? mbase + __builtin_ctz(bits) : 1 << 20;
+                    bits &= bits - 1u;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) h[u] = col[(f[u] < (1 << 20) ? f[u] : 0) * PP_B];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) sum *= k > f[u] ? h[u] : 1.0;
+            }
+        }
+        sPart[wave * 64 + lane] = sum;
+        __syncthreads();
+        if (owner) {
+            double q = r;
+#pragma unroll
+            for (int p = 0; p < 8; ++p) q *= sPart[(2 * p + half) * 64 + lane];
+            const unsigned long long g = __ballot(valid && !(lu >= q));
+            if (lane == 0) sMask[cur ^ 1][half] = g;
+        }
+        __syncthreads();
+        const bool same = sMask[cur ^ 1][0] == sMask[cur][0] &&
+                          sMask[cur ^ 1][1] == sMask[cur][1];
+        cur ^= 1;
+        if (same) break;
+    }
+    if (owner) {
+        const unsigned long long m0 = sMask[cur][0], m1 = sMask[cur][1];
+        const unsigned long long mine = half == 0 ? m0 : m1;
+        const int accepted = (int)((mine >> lane) & 1ull);
+        if (valid) {
+            const size_t tj = (size_t)t * N + j0 + k;
+            if (accepted) {
+#pragma unroll
+                for (int d = 0; d < D; ++d) c.X[tj * D + d] = x1[d];
+            }
+            metropolis_bookkeeping(st, na, ns, un, c.tune, c.tune_interval, accepted);
+            c.step[tj] = st; c.nacc[tj] = na; c.nsteps[tj] = ns; c.until[tj] = un;
+        }
+        // accepted nodes of this batch (ascending) for the next batch's cross term
+        if (accepted) {
+            const int base = half == 0 ? 0 : __popcll(m0);
+            accg[1 + base + __popcll(mine & ((1ull << lane) - 1ull))] = k;
+        }
+        if (tid == 0) accg[0] = __popcll(m0) + __popcll(m1);
+    }
+}
+
+// b: batch to resolve (-1: none); be: batch to evaluate (-1: none); ne_items = items of
+// the evaluation = nsl * nb_e * parts.
+template <int D, int MODEL>
+__global__ __launch_bounds__(PP_THREADS) void k_pipe_step(ChainView c, PipeBuf pb, int parity,
+                                                          int b, int be) {
+    extern __shared__ __attribute__((aligned(16))) double pp_sH[];      // 128 x 128
+    __shared__ double sPart[PP_WAVES * 64];
+    __shared__ unsigned long long sMask[2][2];
+    __shared__ int sPrev[PP_B];
+    const int nres = b >= 0 ? pb.nsl : 0;
+    if ((int)blockIdx.x < nres) {
+        pipe_resolve<D>(c, pb, parity, b, blockIdx.x, pp_sH, sPart, sMask, sPrev);
+        return;
+    }
+    if (be < 0) return;
+    if (pb.dbg & 8) return;
+    const int lane = threadIdx.x & 63;
+    const int nbe = min(PP_B, c.N - be * PP_B);
+    const int nitems = pb.nsl * nbe * pb.parts;
+    const int nwaves = ((int)gridDim.x - nres) * PP_WAVES;
+    const int gw = __builtin_amdgcn_readfirstlane(
+        ((int)blockIdx.x - nres) * PP_WAVES + (int)(threadIdx.x >> 6));
+    for (int q = gw; q < nitems; q += nwaves) {
+        const int p = q % pb.parts;
+        const int kq = q / pb.parts;
+        const int k = kq % nbe;
+        const int s = kq / nbe;
+        pipe_eval_item<D, MODEL>(c, pb, parity, be, s, k, p, lane);
+    }
+}
+
+}  // namespace dlsm

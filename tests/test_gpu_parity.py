@@ -308,9 +308,10 @@ def test_sweep_single_time_step(eng):
                                         ('undirected', 3, 1100, 2), ('directed', 4, 260, 2),
                                         ('directed', 3, 128, 3), ('undirected', 5, 129, 1),
                                         ('undirected', 2, 257, 4)])
-@pytest.mark.parametrize('algo', [2, 3])
+@pytest.mark.parametrize('algo', [2, 3, 4])
 def test_sweep_speculative_batches(eng, name, T, N, D, prior, algo):
-    """algo 2 (chip-wide speculative batches) is the same Gauss-Seidel scan:
+    """algo 2 / 3 (chip-wide speculative batches) and 4 (the pipelined form: batch b + 1
+    evaluated beside the resolve of batch b) are the same Gauss-Seidel scan:
     identical decisions, positions equal to rounding.  N = 10 < one batch,
     129 / 257 / 300 leave ragged last batches."""
     _sweep_case(eng, name, prior, T=T, N=N, D=D, n_sweeps=3, algo=algo,
@@ -434,7 +435,8 @@ def test_resample_controls_valid_and_uniform(eng):
 
 
 # ------------------------------------------------------------ fused LSM loop
-@pytest.mark.parametrize('N,algo', [(18, 1), (300, 1), (300, 2), (300, 3), (700, 3)])
+@pytest.mark.parametrize('N,algo', [(18, 1), (300, 1), (300, 2), (300, 3), (700, 3),
+                                    (300, 4), (700, 4)])
 def test_lsm_device_loop_equals_oracle_iterations(eng, monks, N, algo):
     import ctypes as C
     if N == 18:
