@@ -140,7 +140,10 @@ def main():
             # dominant kernel of the sweep: k_spec_eval, (n_ev / P) launches per
             # sweep, each covering (slices of one parity) x (batch of <= 128 nodes)
             launches = n_ev / float(P)
-            kname, k_ms = 'k_spec_eval', ms_ev / n_ev
+            # algo 4: the fused resolve(b) + eval(b + 1) step; algo 2 / 3: the eval kernel
+            algo_used = chain.resolve_sweep_algo(args.algo)
+            kname = 'k_pipe_step' if algo_used == 4 else 'k_spec_eval'
+            k_ms = ms_ev / n_ev
             # the eval launches carry their own start/stop events (hipExtLaunchKernelGGL):
             # the dispatch's begin/end timestamps, which is what the rocprofv3 kernel
             # trace reports.  The in-kernel wall-clock stamps (first workgroup start to
@@ -218,7 +221,7 @@ def main():
                                    '1 chain per GPU' % (T, N, D),
                        'density': round(density, 4), 'chains': world,
                        'iteration': 'sweep + procrustes + centring + intercept MH + logp trace',
-                       'sweep_algo': args.algo,
+                       'sweep_algo': chain.resolve_sweep_algo(args.algo),
                        'mh_acceptance_rate': round(acc_rate, 3)},
             'roofline': roofline, 'cpu_baseline': cpu,
             'chain_summaries[intercept_mean,intercept_sd,logp_mean,logp_last]': summaries,

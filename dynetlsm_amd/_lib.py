@@ -70,6 +70,7 @@ SIGNATURES = {
                                       c_double_p]),
     'dlsm_loglik_partial_all': (C.c_int, [handle_t, C.c_int, c_double_p]),
     'dlsm_sweep_positions': (C.c_int, [handle_t, C.c_uint32, C.c_int]),
+    'dlsm_resolve_sweep_algo': (C.c_int, [handle_t, C.c_int]),
     'dlsm_center': (C.c_int, [handle_t]),
     'dlsm_procrustes': (C.c_int, [handle_t, c_double_p, c_double_p]),
     'dlsm_gaussian_likelihood': (C.c_int, [handle_t, C.c_int, C.c_int, c_double_p]),

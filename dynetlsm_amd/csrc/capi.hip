@@ -761,6 +761,15 @@ static int launch_sweep_spec(dlsm_chain *h, IterRef iter, int S, bool alloc_only
 }
 
 
+// algo 0 = auto: the pipelined speculative sweep once a slice has several batches
+// (exact likelihoods), speculative batches for wide case-control slices, else one
+// workgroup per slice
+static int resolve_sweep_algo(const dlsm_chain *h, int algo) {
+    if (algo != 0) return algo;
+    if (h->model == DLSM_DIRECTED_CASE_CONTROL) return h->N >= 256 ? 2 : 1;
+    return h->N >= 512 ? 4 : (h->N >= 256 ? 2 : 1);
+}
+
 // algo 4: one fused launch per batch, resolve(b) beside eval(b + 1) (kernels_spec_pipe.hpp)
 template <int DD, int MODEL>
 static void launch_pipe_step(dlsm_chain *h, const ChainView &v, const PipeBuf &pb, int grid,
@@ -798,7 +807,6 @@ static int launch_sweep_pipe(dlsm_chain *h, IterRef iter, bool alloc_only = fals
     pb.Hx = pb.Hd + n_h; pb.acc = (int32_t *)(pb.Hx + n_h);
     pb.consts = pb.Hx + n_h + n_acc;
     pb.parts = parts; pb.per = (N + parts - 1) / parts;
-    pb.dbg = getenv("DLSM_PIPE_DBG") ? atoi(getenv("DLSM_PIPE_DBG")) : 0;
     const size_t lds = (size_t)PP_B * PP_B * sizeof(double);
     auto ku = k_pipe_step<DD, DLSM_UNDIRECTED>;
     auto kd = k_pipe_step<DD, DLSM_DIRECTED>;
@@ -842,12 +850,11 @@ static int launch_sweep(dlsm_chain *h, IterRef iter, int algo, bool alloc_only =
         }
         hipLaunchKernelGGL(k_count_controls, dim3((unsigned)((TN + 255) / 256)), dim3(256),
                            0, h->stream, h->ctrl_in, h->ctrl_out, (long)TN, h->C, h->nctrl);
+        algo = resolve_sweep_algo(h, algo);
         if (alloc_only) {
             hipStreamSynchronize(h->stream);
-            if (algo == 0) algo = h->N >= 256 ? 2 : 1;
             return algo >= 2 ? launch_sweep_spec<DD>(h, iter, 1, true) : DLSM_OK;
         }
-        if (algo == 0) algo = h->N >= 256 ? 2 : 1;
         if (algo >= 2) return launch_sweep_spec<DD>(h, iter, 1);
         for (int parity = 0; parity < 2; ++parity) {
             int nsl = (h->T - parity + 1) / 2;
@@ -858,7 +865,7 @@ static int launch_sweep(dlsm_chain *h, IterRef iter, int algo, bool alloc_only =
         HIPCHK(h, hipGetLastError());
         return DLSM_OK;
     }
-    if (algo == 0) algo = h->N >= 512 ? 3 : (h->N >= 256 ? 2 : 1);
+    algo = resolve_sweep_algo(h, algo);
     if (algo == 4) return launch_sweep_pipe<DD>(h, iter, alloc_only);
     if (algo == 2) return launch_sweep_spec<DD>(h, iter, 1, alloc_only);
     if (algo == 3)
@@ -905,6 +912,12 @@ static int enqueue_sweep(dlsm_chain *h, IterRef iter, int algo, bool alloc_only 
 }
 
 extern "C" {
+
+int dlsm_resolve_sweep_algo(dlsm_chain *h, int algo) {
+    NEED(h, h != nullptr, "null handle");
+    NEED(h, algo >= 0 && algo <= 4, "algo must be 0..4");
+    return resolve_sweep_algo(h, algo);
+}
 
 int dlsm_sweep_positions(dlsm_chain *h, uint32_t iter, int algo) {
     NEED(h, h != nullptr, "null handle");

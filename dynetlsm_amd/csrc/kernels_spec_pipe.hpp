@@ -46,7 +46,6 @@ struct PipeBuf {
     int32_t *acc;    // [nsl][PP_B + 1] : count, accepted nodes of the last resolved batch
     double *consts;  // [2] : E = exp(sum of intercepts), flush interval
     int parts, per, nsl;
-    int dbg;
 };
 
 template <int D>
@@ -165,7 +164,7 @@ __device__ __forceinline__ void pipe_eval_item(const ChainView &c, const PipeBuf
 #pragma unroll
     for (int u = 0; u < PP_NPRE; ++u) {
         const int i = lo + lane + 64 * u;
-        if (i < hi && i != jk && !(pb.dbg & 2))
+        if (i < hi && i != jk)
             DLSM_PIPE_TERM(i, xpre[u], (wpre[u] >> (i & 31)) & 1, (wcpre[u] >> (i & 31)) & 1,
                            rpre[u])
     }
@@ -201,7 +200,7 @@ __device__ __forceinline__ void pipe_eval_item(const ChainView &c, const PipeBuf
     // H entries of node k: the previous batch (cross block) then the earlier nodes of
     // its own batch; the parts of a node share them round-robin (the first one per lane
     // was prefetched above)
-    for (int e = e0; e < ne && !(pb.dbg & 1); e += pb.parts * 64) {
+    for (int e = e0; e < ne; e += pb.parts * 64) {
         const bool cross = e < ncross;
         const int m = cross ? e : e - ncross;
         const int jm = (cross ? jprev : j0) + m;
@@ -238,8 +237,7 @@ __device__ __forceinline__ void pipe_eval_item(const ChainView &c, const PipeBuf
                     delta_directed(a0, a1, y1, y2, aa, cc, E));
         }
         double *dst = cross ? pb.Hx : pb.Hd;
-        if (!(pb.dbg & 4)) dst[(((size_t)bb * pb.nsl + s) * PP_B + m) * PP_B + k] = h;
-        else if (h == 123.456) dst[0] = h;
+        dst[(((size_t)bb * pb.nsl + s) * PP_B + m) * PP_B + k] = h;
     }
 }
 
@@ -403,7 +401,6 @@ __global__ __launch_bounds__(PP_THREADS) void k_pipe_step(ChainView c, PipeBuf p
         return;
     }
     if (be < 0) return;
-    if (pb.dbg & 8) return;
     const int lane = threadIdx.x & 63;
     const int nbe = min(PP_B, c.N - be * PP_B);
     const int nitems = pb.nsl * nbe * pb.parts;

@@ -266,6 +266,13 @@ class Chain(object):
     def sweep_positions(self, it, algo=0):
         self._ck(self._L.dlsm_sweep_positions(self._h, int(it), int(algo)))
 
+    def resolve_sweep_algo(self, algo=0):
+        """the sweep algorithm ``algo`` resolves to on this chain (0 = auto)"""
+        rc = self._L.dlsm_resolve_sweep_algo(self._h, int(algo))
+        if rc < 0:
+            self._ck(rc)
+        return rc
+
     def center(self):
         self._ck(self._L.dlsm_center(self._h))
 
