@@ -773,28 +773,27 @@ static int resolve_sweep_algo(const dlsm_chain *h, int algo) {
 // algo 4: one fused launch per batch, resolve(b) beside eval(b + 1) (kernels_spec_pipe.hpp)
 template <int DD, int MODEL>
 static void launch_pipe_step(dlsm_chain *h, const ChainView &v, const PipeBuf &pb, int grid,
-                             size_t lds, int parity, int b, int be) {
+                             size_t lds, int l) {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (h->profiling) { hipEventCreate(&e0); hipEventCreate(&e1); }
     hipExtLaunchKernelGGL((k_pipe_step<DD, MODEL>), dim3(grid), dim3(PP_THREADS), lds, h->stream,
-                          e0, e1, 0, v, pb, parity, b, be);
+                          e0, e1, 0, v, pb, l);
     if (h->profiling) h->prof[DLSM_K_SWEEP_EVAL].pending.emplace_back(e0, e1);
 }
 
 template <int DD>
 static int launch_sweep_pipe(dlsm_chain *h, IterRef iter, bool alloc_only = false) {
     const int N = h->N, T = h->T;
-    const int nsl_max = (T + 1) / 2;
     const int nbat = (N + PP_B - 1) / PP_B;
-    const int ne_wg = std::max(1, h->n_cu - nsl_max);
-    int parts = (int)((double)ne_wg * PP_WAVES / ((double)nsl_max * PP_B) + 0.5);
+    const int ne_wg = std::max(h->n_cu / 2, h->n_cu - T);
+    int parts = (int)((double)ne_wg * PP_WAVES / ((double)T * PP_B) + 0.5);
     if (getenv("DLSM_PIPE_PARTS")) parts = atoi(getenv("DLSM_PIPE_PARTS"));
     parts = std::max(1, std::min(parts, PP_MAXPARTS));
     auto even2 = [](size_t n) { return (n + 1) / 2 * 2; };
-    const size_t n_prop = even2((size_t)nsl_max * N * (2 * DD + 2));
-    const size_t n_full0 = (size_t)2 * nsl_max * PP_B * parts * 2;
-    const size_t n_h = (size_t)2 * nsl_max * PP_B * PP_B;
-    const size_t n_acc = even2(((size_t)nsl_max * (PP_B + 1) + 1) / 2);     // int32 pairs
+    const size_t n_prop = even2((size_t)T * N * (2 * DD + 2));
+    const size_t n_full0 = (size_t)2 * T * PP_B * parts * 2;
+    const size_t n_h = (size_t)2 * T * PP_B * PP_B;
+    const size_t n_acc = even2(((size_t)T * (PP_B + 1) + 1) / 2);           // int32 pairs
     const size_t need = (n_prop + n_full0 + 2 * n_h + n_acc + 2) * sizeof(double);
     if (h->pipe_cap < need) {
         if (h->pipe) hipFree(h->pipe);
@@ -806,7 +805,7 @@ static int launch_sweep_pipe(dlsm_chain *h, IterRef iter, bool alloc_only = fals
     pb.prop = h->pipe; pb.full0 = pb.prop + n_prop; pb.Hd = pb.full0 + n_full0;
     pb.Hx = pb.Hd + n_h; pb.acc = (int32_t *)(pb.Hx + n_h);
     pb.consts = pb.Hx + n_h + n_acc;
-    pb.parts = parts; pb.per = (N + parts - 1) / parts;
+    pb.parts = parts; pb.per = (N + parts - 1) / parts; pb.nbat = nbat;
     const size_t lds = (size_t)PP_B * PP_B * sizeof(double);
     auto ku = k_pipe_step<DD, DLSM_UNDIRECTED>;
     auto kd = k_pipe_step<DD, DLSM_DIRECTED>;
@@ -816,20 +815,18 @@ static int launch_sweep_pipe(dlsm_chain *h, IterRef iter, bool alloc_only = fals
                                   (int)lds));
     if (alloc_only) return DLSM_OK;
     ChainView v = h->view();
-    for (int parity = 0; parity < 2; ++parity) {
-        const int nsl = (T - parity + 1) / 2;
-        if (nsl <= 0) continue;
-        pb.nsl = nsl;
-        hipLaunchKernelGGL((k_pipe_propose<DD>), dim3((N + 255) / 256, nsl), dim3(256), 0,
-                           h->stream, v, pb, iter, parity);
-        for (int b = -1; b < nbat; ++b) {
-            const int be = b + 1 < nbat ? b + 1 : -1;
-            const int grid = (b >= 0 ? nsl : 0) + (be >= 0 ? ne_wg : 0);
-            if (h->model == DLSM_UNDIRECTED)
-                launch_pipe_step<DD, DLSM_UNDIRECTED>(h, v, pb, grid, lds, parity, b, be);
-            else
-                launch_pipe_step<DD, DLSM_DIRECTED>(h, v, pb, grid, lds, parity, b, be);
-        }
+    hipLaunchKernelGGL((k_pipe_propose<DD>), dim3((N + 255) / 256, T), dim3(256), 0, h->stream, v,
+                       pb, iter);
+    // launch l: even slices resolve batch l / evaluate l + 1, odd slices resolve l - 1 /
+    // evaluate l; with a single slice (T == 1) the trailing odd-only launch is empty
+    const int last = T > 1 ? nbat : nbat - 1;
+    for (int l = -1; l <= last; ++l) {
+        const bool any_eval = (l + 1 < nbat) || (T > 1 && l >= 0 && l < nbat);
+        const int grid = T + (any_eval ? ne_wg : 0);
+        if (h->model == DLSM_UNDIRECTED)
+            launch_pipe_step<DD, DLSM_UNDIRECTED>(h, v, pb, grid, lds, l);
+        else
+            launch_pipe_step<DD, DLSM_DIRECTED>(h, v, pb, grid, lds, l);
     }
     HIPCHK(h, hipGetLastError());
     return DLSM_OK;

@@ -22,6 +22,14 @@
 // kernel boundary is the only synchronisation.  Algebraically this is still the
 // sequential Gauss-Seidel scan (differences are rounding only).
 //
+// Both parities run in the same launches.  Slices of different parity interact only
+// through the prior term of node (t, j), which looks at X[t +- 1][j]; if the odd
+// slices run ONE BATCH BEHIND the even ones, an even node of batch l still sees the
+// odd slices' node j untouched, and an odd node of batch l - 1 sees the even slices'
+// node j final - exactly the even-then-odd order of the reference.  Launch l
+// therefore resolves batch l of the even slices and batch l - 1 of the odd ones and
+// evaluates batches l + 1 / l; the prior delta is computed by the resolver.
+//
 // The accept test runs in the multiplicative domain, u_k < exp(r_k) * prod_m H[k][m]:
 // the evaluators hand over products of (1 + E e^{-d}) factors as they accumulate
 // them, so a wavefront spends one division where the additive form needs a
@@ -38,23 +46,21 @@ constexpr int PP_B = 128;               // nodes per batch (two 64-lane halves)
 constexpr int PP_MAXPARTS = 8;
 
 struct PipeBuf {
-    double *prop;    // [nsl][N][2D + 2] : x1[D], u, prior delta, x0[D] (snapshot)
-    double *full0;   // [2][nsl][PP_B][parts][2] : (sum of linear terms, ratio of products)
-    double *Hd;      // [2][nsl][PP_B][PP_B] : Hd[m][k], k > m, both in the batch: the FACTOR
-                     //                       exp(H[k][m]) of node m's acceptance
-    double *Hx;      // [2][nsl][PP_B][PP_B] : Hx[m][k], m in the previous batch
-    int32_t *acc;    // [nsl][PP_B + 1] : count, accepted nodes of the last resolved batch
+    double *prop;    // [T][N][2D + 2] : x1[D], u, (unused), x0[D] (snapshot)
+    double *full0;   // [2][T][PP_B][parts][2] : (sum of linear terms, ratio of products)
+    double *Hd;      // [2][T][PP_B][PP_B] : Hd[m][k], k > m, both in the batch: the FACTOR
+                     //                     exp(H[k][m]) of node m's acceptance
+    double *Hx;      // [2][T][PP_B][PP_B] : Hx[m][k], m in the previous batch
+    int32_t *acc;    // [T][PP_B + 1] : count, accepted nodes of the last resolved batch
     double *consts;  // [2] : E = exp(sum of intercepts), flush interval
-    int parts, per, nsl;
+    int parts, per, nbat;
 };
 
 template <int D>
-__global__ __launch_bounds__(256) void k_pipe_propose(ChainView c, PipeBuf pb, IterRef ir,
-                                                      int parity) {
+__global__ __launch_bounds__(256) void k_pipe_propose(ChainView c, PipeBuf pb, IterRef ir) {
     const uint32_t iter = ir.get();
     const int N = c.N;
-    const int s = blockIdx.y;
-    const int t = 2 * s + parity;
+    const int t = blockIdx.y;
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
         const double E = c.model == DLSM_UNDIRECTED ? exp(c.intercept[0])
@@ -63,11 +69,12 @@ __global__ __launch_bounds__(256) void k_pipe_propose(ChainView c, PipeBuf pb, I
         pb.consts[1] = (double)flush_interval(E);
     }
     if (j >= N) return;
+    // valid for the whole sweep: X[t, j] and its step size change only at step (t, j)
     double x0[D], x1[D], logu;
 #pragma unroll
     for (int d = 0; d < D; ++d) x0[d] = c.X[((size_t)t * N + j) * D + d];
     make_proposal<D>(c, iter, t, j, x0, c.step[(size_t)t * N + j], x1, logu);
-    double *pr = pb.prop + ((size_t)s * N + j) * (2 * D + 2);
+    double *pr = pb.prop + ((size_t)t * N + j) * (2 * D + 2);
 #pragma unroll
     for (int d = 0; d < D; ++d) { pr[d] = x1[d]; pr[D + 2 + d] = x0[d]; }
     {   // the uniform itself (same draw as make_proposal's log u)
@@ -76,23 +83,21 @@ __global__ __launch_bounds__(256) void k_pipe_propose(ChainView c, PipeBuf pb, I
                         stream_word(c.chain, STREAM_SWEEP_UNIFORM), u0, u1);
         pr[D] = u0;
     }
-    pr[D + 1] = node_log_prior<D>(c, t, j, x1) - node_log_prior<D>(c, t, j, x0);
+    pr[D + 1] = 0.0;
 }
 
-// One wavefront: part p of node k of batch `be` in slice s.
+// One wavefront: part p of node k of batch `be` in slice t.
 template <int D, int MODEL>
-__device__ __forceinline__ void pipe_eval_item(const ChainView &c, const PipeBuf &pb,
-                                               int parity, int be, int s, int k, int p,
-                                               int lane) {
+__device__ __forceinline__ void pipe_eval_item(const ChainView &c, const PipeBuf &pb, int be,
+                                               int t, int k, int p, int lane) {
     constexpr int PW = 2 * D + 2;
     const int N = c.N, W = c.W;
-    const int t = 2 * s + parity;
     const int j0 = be * PP_B, jk = j0 + k;
     const int jprev = max(0, j0 - PP_B);       // nodes >= jprev: snapshot positions
     const int ncross = j0 - jprev;
     const int bb = be & 1;
     const double *Xt = c.X + (size_t)t * N * D;
-    const double *props = pb.prop + (size_t)s * N * PW;
+    const double *props = pb.prop + (size_t)t * N * PW;
     const uint32_t *yr = c.ybits + ((size_t)t * N + jk) * W;
     const uint32_t *yc = MODEL == DLSM_DIRECTED ? c.ytbits + ((size_t)t * N + jk) * W : nullptr;
     const double E = pb.consts[0];
@@ -110,21 +115,24 @@ __device__ __forceinline__ void pipe_eval_item(const ChainView &c, const PipeBuf
     }
     const int lo = p * pb.per, hi = min(N, lo + pb.per);
     // neighbours per lane loaded up front (the directed model carries more per neighbour)
-    constexpr int PP_NPRE = MODEL == DLSM_UNDIRECTED ? 6 : 3;
+    constexpr int PP_NPRE = MODEL == DLSM_UNDIRECTED ? (D == 1 ? 11 : D == 2 ? 8 : D == 3 ? 6 : 4) : 3;
     // The item is a chain of dependent latencies, so every load it will need is issued
     // before the first use: PP_NPRE neighbours per lane (clamped addresses, no
     // predication) and this lane's first H entry.
-    double xpre[PP_NPRE][D], rpre[PP_NPRE];
-    uint32_t wpre[PP_NPRE], wcpre[PP_NPRE];
+    // The bits of row k for the prefetched neighbours: lane w holds word (lo >> 5) + w of
+    // the row (64 words = 2048 neighbours, more than PP_NPRE * 64), fetched per
+    // neighbour by a lane shuffle instead of a load and a register each.
+    double xpre[PP_NPRE][D], rpre[MODEL == DLSM_DIRECTED ? PP_NPRE : 1];
+    const int w0 = lo >> 5;
+    const uint32_t yseg = yr[min(w0 + lane, W - 1)];
+    const uint32_t ycseg = MODEL == DLSM_DIRECTED ? yc[min(w0 + lane, W - 1)] : 0u;
 #pragma unroll
     for (int u = 0; u < PP_NPRE; ++u) {
         const int ic = min(lo + lane + 64 * u, N - 1);
         const double *src = ic < jprev ? Xt + (size_t)ic * D : props + (size_t)ic * PW + D + 2;
 #pragma unroll
         for (int d = 0; d < D; ++d) xpre[u][d] = src[d];
-        wpre[u] = yr[ic >> 5];
-        wcpre[u] = MODEL == DLSM_DIRECTED ? yc[ic >> 5] : 0u;
-        rpre[u] = MODEL == DLSM_DIRECTED ? c.radii[ic] : 1.0;
+        if (MODEL == DLSM_DIRECTED) rpre[u] = c.radii[ic];
     }
     const int ne = ncross + k;
     const int e0 = p + pb.parts * lane;
@@ -164,9 +172,12 @@ __device__ __forceinline__ void pipe_eval_item(const ChainView &c, const PipeBuf
 #pragma unroll
     for (int u = 0; u < PP_NPRE; ++u) {
         const int i = lo + lane + 64 * u;
+        const int wi = min((i >> 5) - w0, 63);
+        const uint32_t yw = __shfl(yseg, wi, 64);
+        const uint32_t ycw = MODEL == DLSM_DIRECTED ? __shfl(ycseg, wi, 64) : 0u;
         if (i < hi && i != jk)
-            DLSM_PIPE_TERM(i, xpre[u], (wpre[u] >> (i & 31)) & 1, (wcpre[u] >> (i & 31)) & 1,
-                           rpre[u])
+            DLSM_PIPE_TERM(i, xpre[u], (yw >> (i & 31)) & 1, (ycw >> (i & 31)) & 1,
+                           rpre[MODEL == DLSM_DIRECTED ? u : 0])
     }
     for (int i = lo + lane + 64 * PP_NPRE; i < hi; i += 64) {
         if (i == jk) continue;
@@ -194,7 +205,7 @@ __device__ __forceinline__ void pipe_eval_item(const ChainView &c, const PipeBuf
         tot_l = wave_sum_all(acc); tot_r = 1.0;
     }
     if (lane == 0) {
-        double2 *f = (double2 *)pb.full0 + (((size_t)bb * pb.nsl + s) * PP_B + k) * pb.parts + p;
+        double2 *f = (double2 *)pb.full0 + (((size_t)bb * c.T + t) * PP_B + k) * pb.parts + p;
         *f = make_double2(tot_l, tot_r);
     }
     // H entries of node k: the previous batch (cross block) then the earlier nodes of
@@ -237,19 +248,18 @@ __device__ __forceinline__ void pipe_eval_item(const ChainView &c, const PipeBuf
                     delta_directed(a0, a1, y1, y2, aa, cc, E));
         }
         double *dst = cross ? pb.Hx : pb.Hd;
-        dst[(((size_t)bb * pb.nsl + s) * PP_B + m) * PP_B + k] = h;
+        dst[(((size_t)bb * c.T + t) * PP_B + m) * PP_B + k] = h;
     }
 }
 
-// Resolve batch b of slice s: the fixed-point solve of k_spec_resolve for one batch,
+// Resolve batch b of slice t: the fixed-point solve of k_spec_resolve for one batch,
 // the acceptances of batch b - 1 entering through gathered rows of the cross block.
 template <int D>
-__device__ __forceinline__ void pipe_resolve(const ChainView &c, const PipeBuf &pb, int parity,
-                                             int b, int s, double *sH, double *sPart,
+__device__ __forceinline__ void pipe_resolve(const ChainView &c, const PipeBuf &pb, int b, int t,
+                                             double *sH, double *sPart,
                                              unsigned long long (*sMask)[2], int *sPrev) {
     constexpr int PW = 2 * D + 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int t = 2 * s + parity;
     const int N = c.N;
     const int j0 = b * PP_B;
     const int nb = min(PP_B, N - j0);
@@ -258,9 +268,9 @@ __device__ __forceinline__ void pipe_resolve(const ChainView &c, const PipeBuf &
     const int k = 64 * half + lane;
     const bool owner = wave < 2;
     const bool valid = k < nb;
-    const double *Hd = pb.Hd + ((size_t)bb * pb.nsl + s) * PP_B * PP_B;
-    const double *Hx = pb.Hx + ((size_t)bb * pb.nsl + s) * PP_B * PP_B;
-    int32_t *accg = pb.acc + (size_t)s * (PP_B + 1);
+    const double *Hd = pb.Hd + ((size_t)bb * c.T + t) * PP_B * PP_B;
+    const double *Hx = pb.Hx + ((size_t)bb * c.T + t) * PP_B * PP_B;
+    int32_t *accg = pb.acc + (size_t)t * (PP_B + 1);
     // diagonal block -> LDS (unconditional clamped loads, see k_spec_resolve)
     double2 blk[8];
 #pragma unroll
@@ -278,7 +288,7 @@ __device__ __forceinline__ void pipe_resolve(const ChainView &c, const PipeBuf &
     if (owner) {
         const int kc = min(k, nb - 1);
         const double2 *f = (const double2 *)pb.full0 +
-                           (((size_t)bb * pb.nsl + s) * PP_B + kc) * pb.parts;
+                           (((size_t)bb * c.T + t) * PP_B + kc) * pb.parts;
         const int p1 = pb.parts;
         double2 tv[PP_MAXPARTS];
 #pragma unroll
@@ -289,12 +299,17 @@ __device__ __forceinline__ void pipe_resolve(const ChainView &c, const PipeBuf &
             tot += u < p1 ? tv[u].x : 0.0;
             pr_ *= u < p1 ? tv[u].y : 1.0;
         }
-        const double *pr = pb.prop + ((size_t)s * N + j0 + kc) * PW;
-        // exp(r_k): |arguments| beyond 700 decide the test on their own
-        r = exp(fmin(fmax(tot + pr[D + 1], -700.0), 700.0)) * pr_;
-        lu = pr[D];
+        const double *pr = pb.prop + ((size_t)t * N + j0 + kc) * PW;
+        double x0[D];
 #pragma unroll
-        for (int d = 0; d < D; ++d) x1[d] = pr[d];
+        for (int d = 0; d < D; ++d) { x1[d] = pr[d]; x0[d] = pr[D + 2 + d]; }
+        // prior terms of the step's logp closure, with the neighbouring slices as they
+        // are now (see the header: the odd slices run one batch behind)
+        const double prior = node_log_prior<D>(c, t, j0 + kc, x1) -
+                             node_log_prior<D>(c, t, j0 + kc, x0);
+        // exp(r_k): |arguments| beyond 700 decide the test on their own
+        r = exp(fmin(fmax(tot + prior, -700.0), 700.0)) * pr_;
+        lu = pr[D];
         const size_t tjc = (size_t)t * N + j0 + kc;
         st = c.step[tjc]; na = c.nacc[tjc]; ns = c.nsteps[tjc]; un = c.until[tjc];
     }
@@ -386,33 +401,40 @@ __device__ __forceinline__ void pipe_resolve(const ChainView &c, const PipeBuf &
     }
 }
 
-// b: batch to resolve (-1: none); be: batch to evaluate (-1: none); ne_items = items of
-// the evaluation = nsl * nb_e * parts.
+// Launch l: even slices resolve batch l and evaluate batch l + 1; odd slices resolve
+// batch l - 1 and evaluate batch l (batches outside [0, nbat) do nothing).
+// Workgroups [0, T) are the resolvers, the rest evaluate one item per wavefront.
 template <int D, int MODEL>
-__global__ __launch_bounds__(PP_THREADS) void k_pipe_step(ChainView c, PipeBuf pb, int parity,
-                                                          int b, int be) {
+__global__ __launch_bounds__(PP_THREADS) void k_pipe_step(ChainView c, PipeBuf pb, int l) {
     extern __shared__ __attribute__((aligned(16))) double pp_sH[];      // 128 x 128
     __shared__ double sPart[PP_WAVES * 64];
     __shared__ unsigned long long sMask[2][2];
     __shared__ int sPrev[PP_B];
-    const int nres = b >= 0 ? pb.nsl : 0;
-    if ((int)blockIdx.x < nres) {
-        pipe_resolve<D>(c, pb, parity, b, blockIdx.x, pp_sH, sPart, sMask, sPrev);
+    const int T = c.T;
+    if ((int)blockIdx.x < T) {
+        const int t = blockIdx.x;
+        const int b = l - (t & 1);
+        if (b >= 0 && b < pb.nbat) pipe_resolve<D>(c, pb, b, t, pp_sH, sPart, sMask, sPrev);
         return;
     }
-    if (be < 0) return;
     const int lane = threadIdx.x & 63;
-    const int nbe = min(PP_B, c.N - be * PP_B);
-    const int nitems = pb.nsl * nbe * pb.parts;
-    const int nwaves = ((int)gridDim.x - nres) * PP_WAVES;
+    const int nE = (T + 1) / 2, nO = T / 2;
+    const int beE = l + 1, beO = l;
+    const int nbE = (beE >= 0 && beE < pb.nbat) ? min(PP_B, c.N - beE * PP_B) : 0;
+    const int nbO = (beO >= 0 && beO < pb.nbat) ? min(PP_B, c.N - beO * PP_B) : 0;
+    const int itemsE = nE * nbE * pb.parts, itemsO = nO * nbO * pb.parts;
+    const int nwaves = ((int)gridDim.x - T) * PP_WAVES;
     const int gw = __builtin_amdgcn_readfirstlane(
-        ((int)blockIdx.x - nres) * PP_WAVES + (int)(threadIdx.x >> 6));
-    for (int q = gw; q < nitems; q += nwaves) {
-        const int p = q % pb.parts;
-        const int kq = q / pb.parts;
-        const int k = kq % nbe;
-        const int s = kq / nbe;
-        pipe_eval_item<D, MODEL>(c, pb, parity, be, s, k, p, lane);
+        ((int)blockIdx.x - T) * PP_WAVES + (int)(threadIdx.x >> 6));
+    for (int q = gw; q < itemsE + itemsO; q += nwaves) {
+        const bool odd = q >= itemsE;
+        const int qq = odd ? q - itemsE : q;
+        const int nb = odd ? nbO : nbE;
+        const int p = qq % pb.parts;
+        const int kq = qq / pb.parts;
+        const int k = kq % nb;
+        const int t = 2 * (kq / nb) + (odd ? 1 : 0);
+        pipe_eval_item<D, MODEL>(c, pb, odd ? beO : beE, t, k, p, lane);
     }
 }
 

@@ -1,5 +1,5 @@
-"""Per-role durations of the pipelined sweep from a rocprofv3 kernel trace: within an
-iteration the k_pipe_step launches come as [eval-only, 15 x fused, resolve-only] per parity.
+"""Durations of the pipelined sweep's launches from a rocprofv3 kernel trace, grouped by
+grid size (resolver-only launches have T workgroups, the others T + evaluators).
 
     python profiles/pipe_roles.py <kernel_trace.csv>
 """
@@ -20,4 +20,5 @@ for g, v in sorted(by_grid.items()):
           (g, len(v), v[len(v) // 2] / 1e3, sum(v) / len(v) / 1e3))
 gaps = [int(b['Start_Timestamp']) - int(a['End_Timestamp']) for a, b in zip(rows, rows[1:])]
 gaps = sorted(g for g in gaps if g < 50000)
-print('gap between consecutive k_pipe_step launches: median %.2f us' % (gaps[len(gaps) // 2] / 1e3))
+if gaps:
+    print('gap between consecutive k_pipe_step launches: median %.2f us' % (gaps[len(gaps) // 2] / 1e3))
