@@ -98,17 +98,20 @@ def sample_tables(n, beta, alpha_init, alpha, kappa, rng):
 
 
 def sample_mbar(m, beta, kappa, alpha, rng):
-    """sample_auxillary.py:31-50 : override variables of the sticky HDP"""
+    """sample_auxillary.py:31-50 : override variables of the sticky HDP.  One
+    ``rng.binomial`` call on the (t, j)-ordered arrays: the legacy sampler walks its
+    arguments element by element, so the draws are those of the reference's loop."""
     T, K, _ = m.shape
-    w = np.zeros((T - 1, K), dtype=np.float64)
     rho = kappa / (alpha + kappa)
-    for t in range(T - 1):
-        for j in range(K):
-            w[t, j] = rng.binomial(m[t + 1, j, j], rho / (rho + beta[j] * (1 - rho)))
-    m_bar = np.zeros((T - 1, K, K), dtype=np.float64)
-    for t in range(T - 1):
-        m_bar[t] = m[t + 1] - np.diag(w[t])
-    return np.sum(m_bar, axis=(0, 1)) + m[0, 0], w
+    idx = np.arange(K)
+    if T > 1:
+        p = rho / (rho + beta * (1 - rho))
+        w = rng.binomial(m[1:, idx, idx], np.broadcast_to(p, (T - 1, K))).astype(np.float64)
+    else:
+        w = np.zeros((0, K))
+    m_bar = m[1:].sum(axis=0).astype(np.float64)
+    m_bar[idx, idx] -= w.sum(axis=0)
+    return np.sum(m_bar, axis=0) + m[0, 0], w
 
 
 def sample_concentration_param(alpha, n_clusters, n_samples, prior_shape, prior_rate, rng):
@@ -133,74 +136,65 @@ def gibbs_updates(X, z, n, nk, mu, sigma, beta, weights, lmbda, hp, rng):
     m_bar, w = sample_mbar(m, beta, hp.kappa, hp.alpha, rng)
     # global transition distribution (:887)
     beta = rng.dirichlet((hp.gamma / K) + m_bar)
-    # initial distribution (:890) and transition distributions (:894-898)
+    # initial distribution (:890) and transition distributions (:894-898).  A legacy
+    # ``dirichlet`` draw is ``standard_gamma`` per component (index order) times the
+    # inverse of their running sum, so all (t, k) rows come from ONE standard_gamma
+    # call on the row-major stack of their parameters.
     weights[0, 0] = sample_dirichlet(hp.alpha_init * beta + nk[0], rng)
-    probas = hp.alpha * beta + hp.kappa * np.eye(K)
-    for t in range(1, T):
-        for k in range(K):
-            weights[t, k] = sample_dirichlet(probas[k] + n[t, k], rng)
-    # cluster means (:901-921); the per-(t, k) sums over the members of a cluster
-    # are label-wise bincounts instead of T*K boolean masks
-    def by_label(V):          # V (T, N, D) -> (T, K, D) sums over nodes with z[t, i] = k
-        out = np.zeros((T, K, D))
-        for t in range(T):
-            for d in range(D):
-                out[t, :, d] = np.bincount(z[t], weights=V[t, :, d], minlength=K)
-        return out
+    if T > 1:
+        al = (hp.alpha * beta + hp.kappa * np.eye(K))[None, :, :] + n[1:]
+        al = np.where(al <= 0., SMALL_EPS, al)
+        g = rng.standard_gamma(al)
+        weights[1:] = g * (1.0 / np.add.accumulate(g, axis=-1)[..., -1:])
+    # cluster means (:901-921); sums over the members of a cluster are label-wise
+    # bincounts on the flattened (t, label) index
+    lm = float(np.ravel(lmbda)[0])
+    tk = (np.arange(T)[:, None] * K + z).ravel()
+
+    def by_label(V):          # V (T, N[, D]) -> (T, K[, D]) sums over nodes with z[t, i] = k
+        if V.ndim == 2:
+            return np.bincount(tk, weights=V.ravel(), minlength=T * K).reshape(T, K)
+        return np.stack([np.bincount(tk, weights=V[:, :, d].ravel(), minlength=T * K)
+                         for d in range(D)], axis=-1).reshape(T, K, D)
     V = X.copy()
-    V[1:] = X[1:] - (1 - lmbda) * X[:-1]
+    V[1:] = X[1:] - (1 - lm) * X[:-1]
     S = by_label(V)
-    for k in range(K):
-        pk = 1 / hp.mean_variance_prior
-        mk = np.zeros(D)
-        for t in range(T):
-            if nk[t, k] > 0:
-                if t == 0:
-                    pk = pk + nk[0, k] / sigma[k]
-                    mk = mk + (1 / sigma[k]) * S[0, k]
-                else:
-                    pk = pk + (lmbda ** 2 / sigma[k]) * nk[t, k]
-                    mk = mk + (lmbda / sigma[k]) * S[t, k]
-        pk = 1 / pk
-        mk = mk * pk
-        mu[k] = rng.multivariate_normal(mean=mk, cov=pk * np.eye(D))
+    has = nk > 0                                                   # (T, K)
+    wt = np.full(T, lm ** 2); wt[0] = 1.0                           # precision weights
+    ws = np.full(T, lm); ws[0] = 1.0
+    pk = 1 / hp.mean_variance_prior + ((wt[:, None] * nk * has).sum(axis=0) / sigma)
+    mk = ((ws[:, None, None] * S * has[:, :, None]).sum(axis=0) / sigma[:, None])
+    pk = 1 / pk
+    mk = mk * pk[:, None]
+    # multivariate_normal(mean, pk I) of the legacy sampler = mean + sqrt(pk) * standard
+    # normals (its SVD of a scaled identity is the identity), drawn in (k, d) order
+    mu[:] = mk + np.sqrt(pk)[:, None] * rng.standard_normal((K, D))
     # cluster variances (:924-938): squared residuals per node, summed by label
     res = X - mu[z]
-    res[1:] = X[1:] - (1 - lmbda) * X[:-1] - lmbda * mu[z[1:]]
-    sq = np.sum(res * res, axis=2)
-    Q = np.zeros((T, K))
-    for t in range(T):
-        Q[t] = np.bincount(z[t], weights=sq[t], minlength=K)
-    for k in range(K):
-        ak = 0.5 * (np.sum(nk[:, k]) * D + hp.a)
-        bk = 0.5 * hp.b
-        for t in range(T):
-            if nk[t, k] > 0:
-                bk = bk + 0.5 * Q[t, k]
-        sigma[k] = 1. / rng.gamma(shape=ak, scale=1. / bk)
+    res[1:] = X[1:] - (1 - lm) * X[:-1] - lm * mu[z[1:]]
+    Q = by_label(np.sum(res * res, axis=2))
+    ak = 0.5 * (nk.sum(axis=0) * D + hp.a)
+    bk = 0.5 * hp.b + 0.5 * (Q * has).sum(axis=0)
+    sigma[:] = 1. / rng.gamma(shape=ak, scale=1. / bk)
     # blending coefficient (:941-954)
-    ml = 0.0
-    sl = 1.0 / hp.lambda_variance_prior
-    for t in range(1, T):
-        ml_diff = (mu[z[t]] - X[t - 1]) / sigma[z[t]].reshape(-1, 1)
-        ml += np.sum(ml_diff * (X[t] - X[t - 1]))
-        ml_diff = (mu[z[t]] - X[t - 1]) / np.sqrt(sigma[z[t]].reshape(-1, 1))
-        sl += np.sum(ml_diff ** 2)
+    if T > 1:
+        dm = mu[z[1:]] - X[:-1]                                    # (T-1, N, D)
+        sz = sigma[z[1:]][:, :, None]
+        ml = np.sum(dm / sz * (X[1:] - X[:-1]))
+        sl = 1.0 / hp.lambda_variance_prior + np.sum(dm * dm / sz)
+    else:
+        ml, sl = 0.0, 1.0 / hp.lambda_variance_prior
     sl = 1. / sl
     ml += hp.lambda_prior / hp.lambda_variance_prior
     ml *= sl
     lmbda = truncated_normal(mean=ml, var=sl, rng=rng)
     # hyper-parameters (:957-972)
     if hp.a0 is not None:
-        b = 0.5 * hp.b0
-        for k in range(K):
-            b += 0.5 * np.sum(mu[k] ** 2)
+        b = 0.5 * hp.b0 + 0.5 * np.sum(mu * mu)
         a = 0.5 * (hp.a0 + K)
         hp.mean_variance_prior = 1 / rng.gamma(shape=a, scale=1. / b, size=1)
     if hp.c0 is not None:
-        scale = 0.5 * hp.d0
-        for k in range(K):
-            scale += 0.5 * (1. / sigma[k])
+        scale = 0.5 * hp.d0 + 0.5 * np.sum(1. / sigma)
         shape = 0.5 * (hp.c0 + K * hp.a)
         hp.b = rng.gamma(shape=shape, scale=1. / scale)
     # concentration parameters (:977-1023)
@@ -248,23 +242,21 @@ def log_posterior_terms(X, intercept, intercept_prior, intercept_variance_prior,
         al = hp.alpha * beta[None, :] + hp.kappa * np.eye(K)          # (K, K)
         lp += _dirichlet_logpdf_rows(weights[1:], al[None, :, :]).sum()
     lp += np.log(weights[0, 0, z[0]]).sum()
-    for t in range(1, T):
-        lp += np.log(weights[t, z[t - 1], z[t]]).sum()
+    if T > 1:
+        lp += np.log(weights[np.arange(1, T)[:, None], z[:-1], z[1:]]).sum()
     diff = intercept - intercept_prior
     if radii is not None:
         lp -= np.sum(0.5 * (diff * diff) / intercept_variance_prior)
     else:
         lp = lp - 0.5 * (diff * diff) / intercept_variance_prior
-    for t in range(T):
-        if t == 0:
-            diff = X[t] - mu[z[t]]
-        else:
-            diff = X[t] - (1 - lmbda) * X[t - 1] - lmbda * mu[z[t]]
-        lp = lp + np.sum(-0.5 * np.log(sigma[z[t]]) -
-                         0.5 * np.sum(diff * diff, axis=1) / sigma[z[t]])
-    for k in range(K):
-        lp = lp - 0.5 * np.sum(mu[k] ** 2) / hp.mean_variance_prior
-    lp = lp + np.sum(-(0.5 * hp.a + 1) * np.log(sigma[z]) - (0.5 * hp.b / sigma[z]))
+    lm = np.ravel(lmbda)[0]
+    res = X - mu[z]
+    res[1:] = X[1:] - (1 - lm) * X[:-1] - lm * mu[z[1:]]
+    sz = sigma[z]
+    lsz = np.log(sz)
+    lp = lp + np.sum(-0.5 * lsz - 0.5 * np.sum(res * res, axis=2) / sz)
+    lp = lp - 0.5 * np.sum(mu * mu) / hp.mean_variance_prior
+    lp = lp + np.sum(-(0.5 * hp.a + 1) * lsz - (0.5 * hp.b / sz))
     lp = lp + truncated_normal_logpdf(lmbda, mean=hp.lambda_prior,
                                       var=hp.lambda_variance_prior)
     if radii is not None:
