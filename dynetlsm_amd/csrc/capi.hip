@@ -933,7 +933,7 @@ int dlsm_sweep_positions(dlsm_chain *h, uint32_t iter, int algo) {
 template <int DD>
 static int launch_post(dlsm_chain *h, const double *d_xref, int n_iter_procrustes,
                        int do_center, LsmDeviceState *lsm, IterRef iter, double *d_R,
-                       bool alloc_only = false) {
+                       bool alloc_only = false, double *trace_X = nullptr) {
     ChainView v = h->view();
     const long rows = (long)h->T * h->N;
     const int nb = (int)std::min<long>(PS_BLOCKS, (rows + PS2_THREADS - 1) / PS2_THREADS);
@@ -948,7 +948,8 @@ static int launch_post(dlsm_chain *h, const double *d_xref, int n_iter_procruste
     hipLaunchKernelGGL((k_post_reduce<DD>), dim3(nb), dim3(PS2_THREADS), 0, h->stream, v,
                        d_xref, n_iter_procrustes, iter, rec);
     hipLaunchKernelGGL((k_post_apply<DD>), dim3(nb), dim3(PS2_THREADS), 0, h->stream, v,
-                       d_xref ? 1 : 0, n_iter_procrustes, do_center, rec, nb, lsm, iter, d_R);
+                       d_xref ? 1 : 0, n_iter_procrustes, do_center, rec, nb, lsm, iter, d_R,
+                       trace_X);
     HIPCHK(h, hipGetLastError());
     return DLSM_OK;
 }
@@ -1116,7 +1117,7 @@ static int enqueue_lsm_iteration(dlsm_chain *h, int it, bool counter, int procru
     rc = enqueue_sweep(h, ir, h->lsm_cfg.sweep_algo, alloc_only); if (rc) return rc;
     const double *xref = procrustes_ref >= 0 ? h->trace_X + row * procrustes_ref : nullptr;
     DISPATCH_D(h, h->D, rc = launch_post<DD>(h, xref, h->lsm_cfg.n_iter_procrustes, 1, h->lsm,
-                                             ir, nullptr, alloc_only));
+                                             ir, nullptr, alloc_only, h->trace_X));
     if (rc) return rc;
     if (alloc_only) return ensure_partials(h, (size_t)ll_blocks(h) * 4);
     int nrec = 0;
@@ -1125,8 +1126,6 @@ static int enqueue_lsm_iteration(dlsm_chain *h, int it, bool counter, int procru
         ProfScope ps(h, DLSM_K_FINALIZE);
         hipLaunchKernelGGL(k_lsm_finalize, dim3(1), dim3(256), 0, h->stream, h->partials, nrec,
                            h->lsm, h->intercept, h->trace_ic, h->trace_logp, ir);
-        hipLaunchKernelGGL(k_trace_copy, dim3(64), dim3(256), 0, h->stream, h->X, h->trace_X,
-                           row, ir);
     }
     HIPCHK(h, hipGetLastError());
     return DLSM_OK;

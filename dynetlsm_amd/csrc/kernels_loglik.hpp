@@ -109,29 +109,69 @@ __global__ __launch_bounds__(LL_THREADS) void k_loglik_undirected(
     for (int k = 1; k < M; ++k) Emax = fmax(Emax, E[k]);
     const double l1p = log1p(Emax);
     const int nflush = !(l1p > 0.0) ? 64 : (600.0 / l1p < 1.0 ? 1 : (600.0 / l1p > 64.0 ? 64 : (int)(600.0 / l1p)));
-    double sy = 0.0, syd = 0.0, S[M], P[M];
+    constexpr int U = 4;          // rows per trip, each with its own product chain
+    double sy = 0.0, syd = 0.0, S[M], P[U][M];
 #pragma unroll
-    for (int k = 0; k < M; ++k) { S[k] = 0.0; P[k] = 1.0; }
+    for (int k = 0; k < M; ++k) {
+        S[k] = 0.0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) P[u][k] = 1.0;
+    }
     if (j < c.N) {
+        // rows i = i0 + r, r in [rbeg, rend): i < j only (also stops at i >= N).  U rows
+        // per trip with independent product chains: the dependent fma / mul chains of one
+        // term are what a lone wavefront would otherwise wait on.
         const int rbeg = half * 64;
+        const int rend = min(rbeg + 64, j - i0);
         int cnt = 0;
-        for (int r = rbeg; r < rbeg + 64; ++r) {
-            const int i = i0 + r;
-            if (i >= j) break;           // i < j only (also stops at i >= N)
-            const double dd = dist_fast<D>(&sXi[r * D], xj, c.squared);
-            const double e = fast_exp(-dd);
-            const int y = (sY[r * 4 + (cj >> 5)] >> (cj & 31)) & 1;
-            if (y) { sy += 1.0; syd += dd; }
+        int r = rbeg;
+        for (; r + U <= rend; r += U) {
+            double dd[U], e[U];
 #pragma unroll
-            for (int k = 0; k < M; ++k) P[k] *= fma(E[k], e, 1.0);
+            for (int u = 0; u < U; ++u) dd[u] = dist_fast<D>(&sXi[(r + u) * D], xj, c.squared);
+#pragma unroll
+            for (int u = 0; u < U; ++u) e[u] = fast_exp(-dd[u]);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int y = (sY[(r + u) * 4 + (cj >> 5)] >> (cj & 31)) & 1;
+                if (y) { sy += 1.0; syd += dd[u]; }
+#pragma unroll
+                for (int k = 0; k < M; ++k) P[u][k] *= fma(E[k], e[u], 1.0);
+            }
             if (++cnt >= nflush) {
 #pragma unroll
-                for (int k = 0; k < M; ++k) { S[k] += log(P[k]); P[k] = 1.0; }
+                for (int k = 0; k < M; ++k)
+#pragma unroll
+                    for (int u = 0; u < U; ++u) { S[k] += log(P[u][k]); P[u][k] = 1.0; }
                 cnt = 0;
             }
         }
+        for (; r < rend; ++r) {                      // < U rows left: chain 0, <= U - 1 more
+            const double d1 = dist_fast<D>(&sXi[r * D], xj, c.squared);
+            const double e1 = fast_exp(-d1);
+            const int y = (sY[r * 4 + (cj >> 5)] >> (cj & 31)) & 1;
+            if (y) { sy += 1.0; syd += d1; }
 #pragma unroll
-        for (int k = 0; k < M; ++k) S[k] += log(P[k]);
+            for (int k = 0; k < M; ++k) {
+                if (P[0][k] > 1e250) { S[k] += log(P[0][k]); P[0][k] = 1.0; }
+                P[0][k] *= fma(E[k], e1, 1.0);
+            }
+        }
+        // nflush == 64: all chains together hold <= 64 factors (1 + E) <= e^(600 / 64) each
+        if (nflush >= 64) {
+#pragma unroll
+            for (int k = 0; k < M; ++k) {
+                double q = P[0][k];
+#pragma unroll
+                for (int u = 1; u < U; ++u) q *= P[u][k];
+                S[k] += log(q);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < M; ++k)
+#pragma unroll
+                for (int u = 0; u < U; ++u) S[k] += log(P[u][k]);
+        }
     }
     double acc[2 + M];
     acc[0] = sy; acc[1] = syd;

@@ -431,7 +431,7 @@ template <int D>
 __global__ __launch_bounds__(PS2_THREADS) void k_post_apply(
     ChainView c, int has_ref, int n_iter_procrustes, int do_center,
     const double *__restrict__ rec, int nrec, LsmDeviceState *lsm, IterRef ir,
-    double *__restrict__ R_out) {
+    double *__restrict__ R_out, double *__restrict__ trace_X) {
     const uint32_t iter = ir.get();
     const int rotate = has_ref && (n_iter_procrustes < 0 || (int)iter > n_iter_procrustes);
     constexpr int W = PostRec<D>::W;
@@ -497,7 +497,9 @@ __global__ __launch_bounds__(PS2_THREADS) void k_post_apply(
         }
     }
     __syncthreads();
-    if (!rotate && !do_center) return;
+    if (!rotate && !do_center && !trace_X) return;
+    // the device-resident loop also files the final positions as row `iter` of its trace
+    double *trow = trace_X ? trace_X + (size_t)iter * rows * D : nullptr;
     for (long r = (long)blockIdx.x * PS2_THREADS + tid; r < rows;
          r += (long)gridDim.x * PS2_THREADS) {
         double x[D], y[D];
@@ -512,6 +514,10 @@ __global__ __launch_bounds__(PS2_THREADS) void k_post_apply(
         }
 #pragma unroll
         for (int b = 0; b < D; ++b) X[r * D + b] = y[b];
+        if (trow) {
+#pragma unroll
+            for (int b = 0; b < D; ++b) trow[r * D + b] = y[b];
+        }
     }
 }
 
@@ -552,15 +558,7 @@ __global__ __launch_bounds__(256) void k_lsm_finalize(
     }
 }
 
-// trace row copy and the iteration counter of the captured-graph path
-__global__ __launch_bounds__(256) void k_trace_copy(const double *__restrict__ X,
-                                                    double *__restrict__ trace_X, size_t row,
-                                                    IterRef ir) {
-    double *dst = trace_X + row * (size_t)ir.get();
-    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < row; q += (size_t)gridDim.x * 256)
-        dst[q] = X[q];
-}
-
+// iteration counter of the captured-graph path
 __global__ void k_advance_iter(uint32_t *p) { *p += 1u; }
 
 }  // namespace dlsm
