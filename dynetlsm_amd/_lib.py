@@ -76,6 +76,8 @@ SIGNATURES = {
     'dlsm_gaussian_likelihood': (C.c_int, [handle_t, C.c_int, C.c_int, c_double_p]),
     'dlsm_sample_labels': (C.c_int, [handle_t, C.c_uint32, c_double_p, c_i64_p,
                                      c_double_p, c_i64_p]),
+    'dlsm_hdp_label_sums': (C.c_int, [handle_t, C.c_int, c_double_p, c_double_p, C.c_double,
+                                      c_double_p, C.c_double, C.c_double, c_double_p]),
     'dlsm_lsm_configure': (C.c_int, [handle_t, C.POINTER(LsmConfig)]),
     'dlsm_lsm_get_config': (C.c_int, [handle_t, C.POINTER(LsmConfig)]),
     'dlsm_trace_alloc': (C.c_int, [handle_t, C.c_int, C.c_double]),

@@ -13,6 +13,7 @@
 #include "chain.hpp"
 #include "device_common.hpp"
 #include "kernels_labels.hpp"
+#include "kernels_hdp.hpp"
 #include "kernels_loglik.hpp"
 #include "kernels_sweep.hpp"
 #include "kernels_spec.hpp"
@@ -1201,6 +1202,50 @@ int dlsm_trace_read(dlsm_chain *h, int first, int count, double *Xs, double *int
     if (intercepts) HIPCHK(h, hipMemcpy(intercepts, h->trace_ic + (size_t)2 * first, sizeof(double) * 2 * count, hipMemcpyDeviceToHost));
     if (logps) HIPCHK(h, hipMemcpy(logps, h->trace_logp + first, sizeof(double) * count, hipMemcpyDeviceToHost));
     return DLSM_OK;
+}
+
+int dlsm_hdp_label_sums(dlsm_chain *h, int stage, const double *mu, const double *sigma,
+                        double lmbda, const double *w, double a, double b, double *out) {
+    NEED(h, h && out, "null argument");
+    NEED(h, stage >= 0 && stage <= 3, "stage must be 0..3");
+    NEED(h, h->have_X && h->prior_kind == DLSM_PRIOR_MIXTURE && h->have_prior,
+         "needs positions and the mixture prior (labels)");
+    NEED(h, stage == HDP_SUMS_MEAN || mu, "mu is NULL");
+    NEED(h, stage < HDP_SUMS_LAMBDA || sigma, "sigma is NULL");
+    NEED(h, stage != HDP_SUMS_LOGP || w, "w is NULL");
+    HIPCHK(h, hipSetDevice(h->device));
+    const int T = h->T, K = h->K, D = h->D;
+    const int nv = stage == HDP_SUMS_MEAN ? D : (stage == HDP_SUMS_LAMBDA ? 2 : 1);
+    const size_t n_out = (size_t)T * K * nv;
+    const size_t n_mu = (size_t)K * D, n_w = (size_t)T * K * K;
+    int rc = ensure_partials(h, n_out + n_mu + K + n_w); if (rc) return rc;
+    double *d_out = h->partials, *d_mu = d_out + n_out, *d_sigma = d_mu + n_mu,
+           *d_w = d_sigma + K;
+    if (mu) HIPCHK(h, hipMemcpyAsync(d_mu, mu, n_mu * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if (sigma) HIPCHK(h, hipMemcpyAsync(d_sigma, sigma, K * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if (stage == HDP_SUMS_LOGP)
+        HIPCHK(h, hipMemcpyAsync(d_w, w, n_w * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    ChainView v = h->view();
+    HdpParams hp{d_mu, d_sigma, d_w, lmbda, a, b};
+    const dim3 grid(K, T), block(HDP_THREADS);
+    {
+        ProfScope ps(h, DLSM_K_LABELS);
+        switch (stage) {
+            case HDP_SUMS_MEAN:
+                DISPATCH_D(h, D, hipLaunchKernelGGL((k_hdp_label_sums<DD, HDP_SUMS_MEAN>), grid, block, 0, h->stream, v, hp, d_out));
+                break;
+            case HDP_SUMS_RESIDUAL:
+                DISPATCH_D(h, D, hipLaunchKernelGGL((k_hdp_label_sums<DD, HDP_SUMS_RESIDUAL>), grid, block, 0, h->stream, v, hp, d_out));
+                break;
+            case HDP_SUMS_LAMBDA:
+                DISPATCH_D(h, D, hipLaunchKernelGGL((k_hdp_label_sums<DD, HDP_SUMS_LAMBDA>), grid, block, 0, h->stream, v, hp, d_out));
+                break;
+            default:
+                DISPATCH_D(h, D, hipLaunchKernelGGL((k_hdp_label_sums<DD, HDP_SUMS_LOGP>), grid, block, 0, h->stream, v, hp, d_out));
+        }
+    }
+    HIPCHK(h, hipGetLastError());
+    return d2h(h, out, d_out, n_out);
 }
 
 // ---------------------------------------------------------------- measurement

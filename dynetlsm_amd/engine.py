@@ -298,6 +298,21 @@ class Chain(object):
         return z, n, nk
 
     # -- device-resident LSM loop -------------------------------------------
+    def hdp_label_sums(self, stage, mu=None, sigma=None, lmbda=0.0, w=None, a=0.0, b=0.0):
+        """Label-wise sums of the HDP-LPCM conjugate updates on the device (stage 0 means,
+        1 residuals, 2 lambda, 3 log-posterior node terms); see ``dlsm_hdp_label_sums``."""
+        K = self.K
+        nv = self.D if stage == 0 else (2 if stage == 2 else 1)
+        out = np.empty((self.T, K, nv) if nv > 1 else (self.T, K))
+        mu = None if mu is None else _f64(mu, (K, self.D), 'mu')
+        sigma = None if sigma is None else _f64(sigma, (K,), 'sigma')
+        w = None if w is None else _f64(w, (self.T, K, K), 'w')
+        self._ck(self._L.dlsm_hdp_label_sums(
+            self._h, int(stage), None if mu is None else _p(mu),
+            None if sigma is None else _p(sigma), float(np.ravel(lmbda)[0]),
+            None if w is None else _p(w), float(a), float(b), _p(out)))
+        return out
+
     def lsm_configure(self, intercept_prior, intercept_variance_prior,
                       step_size_intercept=0.1, tune=None, tune_interval=100,
                       n_iter_procrustes=0, sweep_algo=0, state=None):

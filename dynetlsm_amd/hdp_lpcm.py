@@ -223,10 +223,11 @@ class DynamicNetworkHDPLPCM(object):
             if self.is_directed:
                 self.radiis_[it] = radii
             self.logps_[it] = np.ravel(ll + hu.log_posterior_terms(
-                X, intercept, ip, self.intercept_variance_prior, mu, sigma, z, weights, beta,
+                sums, intercept, ip, self.intercept_variance_prior, mu, sigma, weights, beta,
                 lmbda, hp, radii=radii))[0]
 
         chain.set_prior_mixture(mu, sigma, lmbda, z)
+        sums = hu.DeviceLabelSums(chain)        # label-wise sums at the chain's X and z
         store(0, chain.loglik_full())
         var = self.intercept_variance_prior
         t_loop = time.perf_counter()
@@ -268,8 +269,7 @@ class DynamicNetworkHDPLPCM(object):
             z, n, nk = chain.sample_labels(it, weights)
             X = chain.get_positions()
             mu, sigma, weights = mu.copy(), sigma.copy(), weights.copy()
-            beta, lmbda = hu.gibbs_updates(X, z, n, nk, mu, sigma, beta, weights, lmbda, hp,
-                                           rng)
+            beta, lmbda = hu.gibbs_updates(sums, n, nk, mu, sigma, beta, weights, lmbda, hp, rng)
             store(it, ll)
         self.loop_seconds_ = time.perf_counter() - t_loop     # Gibbs loop only
         chain.get_samplers(self.latent_samplers)

@@ -125,12 +125,36 @@ def sample_concentration_param(alpha, n_clusters, n_samples, prior_shape, prior_
     return rng.gamma(shape=m_shape, scale=1. / m_scale)
 
 
-def gibbs_updates(X, z, n, nk, mu, sigma, beta, weights, lmbda, hp, rng):
+class DeviceLabelSums(object):
+    """The O(T N) sums of the conjugate updates, on the device:
+    ``Chain.hdp_label_sums`` at the chain's current positions and labels."""
+
+    def __init__(self, chain):
+        self.chain = chain
+        self.T, self.N, self.D = chain.T, chain.N, chain.D
+
+    def mean(self, lmbda):
+        return self.chain.hdp_label_sums(0, lmbda=lmbda)
+
+    def residual(self, mu, lmbda):
+        return self.chain.hdp_label_sums(1, mu=mu, lmbda=lmbda)
+
+    def lam(self, mu, sigma):
+        return self.chain.hdp_label_sums(2, mu=mu, sigma=sigma)
+
+    def logp(self, mu, sigma, lmbda, weights, a, b):
+        return self.chain.hdp_label_sums(3, mu=mu, sigma=sigma, lmbda=lmbda, w=weights,
+                                         a=a, b=b)
+
+
+def gibbs_updates(sums, n, nk, mu, sigma, beta, weights, lmbda, hp, rng):
     """hdp_lpcm.py:880-1023.  ``n`` (T,K,K), ``nk`` (T,K) are the label
     update's counts; mu, sigma, weights are updated in place; returns
     (beta, lmbda) and mutates ``hp`` (gamma, alpha_init, alpha, kappa,
-    mean_variance_prior, b)."""
-    T, N, D = X.shape
+    mean_variance_prior, b).  ``sums`` supplies the label-wise sums over the nodes
+    (:901-954): ``DeviceLabelSums`` in the product; the tests inject the numpy
+    restatement of the oracle to pin the draws on a CPU."""
+    T, N, D = sums.T, sums.N, sums.D
     K = hp.n_components
     m = sample_tables(n, beta, hp.alpha_init, hp.alpha, hp.kappa, rng)
     m_bar, w = sample_mbar(m, beta, hp.kappa, hp.alpha, rng)
@@ -146,19 +170,9 @@ def gibbs_updates(X, z, n, nk, mu, sigma, beta, weights, lmbda, hp, rng):
         al = np.where(al <= 0., SMALL_EPS, al)
         g = rng.standard_gamma(al)
         weights[1:] = g * (1.0 / np.add.accumulate(g, axis=-1)[..., -1:])
-    # cluster means (:901-921); sums over the members of a cluster are label-wise
-    # bincounts on the flattened (t, label) index
+    # cluster means (:901-921)
     lm = float(np.ravel(lmbda)[0])
-    tk = (np.arange(T)[:, None] * K + z).ravel()
-
-    def by_label(V):          # V (T, N[, D]) -> (T, K[, D]) sums over nodes with z[t, i] = k
-        if V.ndim == 2:
-            return np.bincount(tk, weights=V.ravel(), minlength=T * K).reshape(T, K)
-        return np.stack([np.bincount(tk, weights=V[:, :, d].ravel(), minlength=T * K)
-                         for d in range(D)], axis=-1).reshape(T, K, D)
-    V = X.copy()
-    V[1:] = X[1:] - (1 - lm) * X[:-1]
-    S = by_label(V)
+    S = sums.mean(lm)                                              # (T, K, D)
     has = nk > 0                                                   # (T, K)
     wt = np.full(T, lm ** 2); wt[0] = 1.0                           # precision weights
     ws = np.full(T, lm); ws[0] = 1.0
@@ -169,19 +183,16 @@ def gibbs_updates(X, z, n, nk, mu, sigma, beta, weights, lmbda, hp, rng):
     # multivariate_normal(mean, pk I) of the legacy sampler = mean + sqrt(pk) * standard
     # normals (its SVD of a scaled identity is the identity), drawn in (k, d) order
     mu[:] = mk + np.sqrt(pk)[:, None] * rng.standard_normal((K, D))
-    # cluster variances (:924-938): squared residuals per node, summed by label
-    res = X - mu[z]
-    res[1:] = X[1:] - (1 - lm) * X[:-1] - lm * mu[z[1:]]
-    Q = by_label(np.sum(res * res, axis=2))
+    # cluster variances (:924-938): squared residuals about the new means, by label
+    Q = sums.residual(mu, lm)                                      # (T, K)
     ak = 0.5 * (nk.sum(axis=0) * D + hp.a)
     bk = 0.5 * hp.b + 0.5 * (Q * has).sum(axis=0)
     sigma[:] = 1. / rng.gamma(shape=ak, scale=1. / bk)
     # blending coefficient (:941-954)
     if T > 1:
-        dm = mu[z[1:]] - X[:-1]                                    # (T-1, N, D)
-        sz = sigma[z[1:]][:, :, None]
-        ml = np.sum(dm / sz * (X[1:] - X[:-1]))
-        sl = 1.0 / hp.lambda_variance_prior + np.sum(dm * dm / sz)
+        L = sums.lam(mu, sigma)                                    # (T, K, 2), row 0 unused
+        ml = np.sum(L[1:, :, 0])
+        sl = 1.0 / hp.lambda_variance_prior + np.sum(L[1:, :, 1])
     else:
         ml, sl = 0.0, 1.0 / hp.lambda_variance_prior
     sl = 1. / sl
@@ -228,35 +239,25 @@ def _dirichlet_logpdf_rows(x, alphas):
             xlogy(alphas - 1, x).sum(axis=-1))
 
 
-def log_posterior_terms(X, intercept, intercept_prior, intercept_variance_prior, mu,
-                        sigma, z, weights, beta, lmbda, hp, radii=None):
+def log_posterior_terms(sums, intercept, intercept_prior, intercept_variance_prior, mu,
+                        sigma, weights, beta, lmbda, hp, radii=None):
     """Everything in DynamicNetworkHDPLPCM.logp (hdp_lpcm.py:1188-1280) except
-    the network log-likelihood, which the device supplies.  The reference's
-    Python loops over nodes / (t, k) rows are vectorised (same terms, numpy
-    summation order)."""
-    T, N, D = X.shape
+    the network log-likelihood, which the device supplies.  The terms that sum over the
+    nodes (label transitions, Gaussian and inverse-gamma terms) come from ``sums``."""
+    T, N, D = sums.T, sums.N, sums.D
     K = hp.n_components
     lp = _dirichlet_logpdf_rows(beta, np.repeat(hp.gamma / K, K))
     lp += _dirichlet_logpdf_rows(weights[0, 0], hp.alpha_init * beta)
     if T > 1:
         al = hp.alpha * beta[None, :] + hp.kappa * np.eye(K)          # (K, K)
         lp += _dirichlet_logpdf_rows(weights[1:], al[None, :, :]).sum()
-    lp += np.log(weights[0, 0, z[0]]).sum()
-    if T > 1:
-        lp += np.log(weights[np.arange(1, T)[:, None], z[:-1], z[1:]]).sum()
     diff = intercept - intercept_prior
     if radii is not None:
         lp -= np.sum(0.5 * (diff * diff) / intercept_variance_prior)
     else:
         lp = lp - 0.5 * (diff * diff) / intercept_variance_prior
-    lm = np.ravel(lmbda)[0]
-    res = X - mu[z]
-    res[1:] = X[1:] - (1 - lm) * X[:-1] - lm * mu[z[1:]]
-    sz = sigma[z]
-    lsz = np.log(sz)
-    lp = lp + np.sum(-0.5 * lsz - 0.5 * np.sum(res * res, axis=2) / sz)
+    lp = lp + np.sum(sums.logp(mu, sigma, np.ravel(lmbda)[0], weights, hp.a, hp.b))
     lp = lp - 0.5 * np.sum(mu * mu) / hp.mean_variance_prior
-    lp = lp + np.sum(-(0.5 * hp.a + 1) * lsz - (0.5 * hp.b / sz))
     lp = lp + truncated_normal_logpdf(lmbda, mean=hp.lambda_prior,
                                       var=hp.lambda_variance_prior)
     if radii is not None:

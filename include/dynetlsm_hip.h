@@ -143,6 +143,20 @@ int dlsm_gaussian_likelihood(dlsm_chain *h, int node, int normalize, double *out
 int dlsm_sample_labels(dlsm_chain *h, uint32_t iter, const double *w, int64_t *z,
                        double *n, int64_t *nk);
 
+/* the O(T N) sums of the HDP-LPCM conjugate updates over the nodes that
+ * carry a label, at the handle's positions and labels (the z of the last
+ * dlsm_sample_labels / dlsm_set_prior_mixture), K = the mixture prior's components:
+ *   stage 0 (hdp_lpcm.py:901-921)  out T*K*D : sum_i V_ti, V_0 = X_0, V_t = X_t - (1-lmbda) X_{t-1}
+ *   stage 1 (:924-938)             out T*K   : sum_i squared residuals about the NEW mu
+ *   stage 2 (:941-954)             out T*K*2 : the two sums of the lambda update per (t, k)
+ *   stage 3 (:1213-1262)           out T*K   : the node terms of DynamicNetworkHDPLPCM.logp
+ *                                              (label transitions w, Gaussian and inverse-gamma
+ *                                              terms; a, b the variance prior's parameters)
+ * mu K*D, sigma K, w T*K*K are the values the update holds at that point (they are not
+ * stored in the handle).  Fixed summation order: bitwise reproducible. */
+int dlsm_hdp_label_sums(dlsm_chain *h, int stage, const double *mu, const double *sigma,
+                        double lmbda, const double *w, double a, double b, double *out);
+
 /* ---- device-resident LSM chain (lsm.py:474-572, fully observed network) -- */
 typedef struct {
     double intercept_prior[2];

@@ -47,13 +47,14 @@ for it in range(1, n_it + 1):
     t0 = time.perf_counter(); X = c.get_positions(); tick('get_positions', t0)
     t0 = time.perf_counter()
     mu, sigma, weights = mu.copy(), sigma.copy(), weights.copy()
-    beta, lmbda = hu.gibbs_updates(X, z, n, nk, mu, sigma, beta, weights, lmbda, hp, rng)
-    tick('host gibbs_updates', t0)
+    sums = hu.DeviceLabelSums(c)
+    beta, lmbda = hu.gibbs_updates(sums, n, nk, mu, sigma, beta, weights, lmbda, hp, rng)
+    tick('gibbs_updates (host draws + 3 device sums)', t0)
     t0 = time.perf_counter()
-    hu.log_posterior_terms(X, np.array([0.1]), np.array([0.1]), 2.0, mu, sigma, z, weights, beta,
+    hu.log_posterior_terms(sums, np.array([0.1]), np.array([0.1]), 2.0, mu, sigma, weights, beta,
                            lmbda, hp)
-    tick('host log_posterior', t0)
+    tick('log_posterior (host + 1 device sum)', t0)
 tot = sum(ph.values())
 for k, v in ph.items():
-    print('%-22s %7.3f ms' % (k, 1e3 * v / n_it))
-print('%-22s %7.3f ms' % ('total', 1e3 * tot / n_it))
+    print('%-44s %7.3f ms' % (k, 1e3 * v / n_it))
+print('%-44s %7.3f ms' % ('total', 1e3 * tot / n_it))

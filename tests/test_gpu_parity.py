@@ -521,3 +521,77 @@ def test_lsm_device_loop_procrustes(eng, monks):
         X3 = c.trace_read(3, 1)[0][0]
     Xw, _ = orc.procrustes_rotation(Xs[1], Xsw)
     np.testing.assert_allclose(X3, orc.center(Xw), atol=1e-10)
+
+
+# ------------------------------------------------------------ HDP label sums (8f-2)
+@pytest.mark.parametrize('T,N,D,K', [(4, 300, 2, 7), (1, 50, 2, 3), (3, 1000, 3, 20), (5, 129, 1, 64)])
+def test_hdp_label_sums_match_oracle(eng, T, N, D, K):
+    """dlsm_hdp_label_sums (hdp_lpcm.py:901-954, :1213-1262 on the device) against the
+    numpy restatement; labels include empty clusters"""
+    from oracle.hdp_sums import NumpyLabelSums
+    rng = np.random.RandomState(T * 1000 + N)
+    X = rng.randn(T, N, D)
+    z = rng.randint(0, max(1, K - 2), size=(T, N)).astype(np.int64)      # last clusters empty
+    mu, sigma = rng.randn(K, D), rng.gamma(2.0, 1.0, size=K) + 0.1
+    w = rng.dirichlet(np.ones(K), size=(T, K))
+    lm, a, b = 0.83, 2.0, 1.3
+    ref = NumpyLabelSums(X, z, K)
+    with eng.Chain(T, N, D, 'undirected') as c:
+        c.set_positions(X)
+        c.set_prior_mixture(mu, sigma, lm, z)
+        np.testing.assert_allclose(c.hdp_label_sums(0, lmbda=lm), ref.mean(lm).reshape(T, K, D)
+                                   if D > 1 else ref.mean(lm).reshape(T, K), rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(c.hdp_label_sums(1, mu=mu, lmbda=lm), ref.residual(mu, lm),
+                                   rtol=1e-12, atol=1e-12)
+        got = c.hdp_label_sums(2, mu=mu, sigma=sigma)
+        np.testing.assert_allclose(got[1:], ref.lam(mu, sigma)[1:], rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(c.hdp_label_sums(3, mu=mu, sigma=sigma, lmbda=lm, w=w, a=a, b=b),
+                                   ref.logp(mu, sigma, lm, w, a, b), rtol=1e-12, atol=1e-12)
+        # needs the mixture prior's labels
+    with eng.Chain(T, N, D, 'undirected') as c:
+        c.set_positions(X)
+        with pytest.raises(eng.EngineError):
+            c.hdp_label_sums(0, lmbda=lm)
+
+
+def test_hdp_host_updates_with_device_sums_reproduce_reference_fit(eng):
+    """the trace replay of tests/test_hdp_host_updates.py with the label-wise sums taken from
+    the device, as the product does"""
+    from conftest import load_golden
+    from dynetlsm_amd import hdp_updates as hu
+    g = load_golden('hdp_trace.npz')
+    Xs, ics = g['tr_Xs'], g['tr_intercepts']
+    mus, sigmas, zs = g['tr_mus'], g['tr_sigmas'], g['tr_zs']
+    betas, weights, lambdas, logps = (g['tr_betas'], g['tr_weights'], g['tr_lambdas'],
+                                      g['tr_logps'])
+    Y = g['Y']
+    n_total, T, N, D = Xs.shape
+    K = sigmas.shape[1]
+    hp0 = dict(gamma=float(g['h0_gamma']), alpha_init=float(g['h0_alpha_init']),
+               alpha=float(g['h0_alpha']), kappa=float(g['h0_kappa']),
+               mean_variance_prior=float(g['h0_mean_variance_prior']), b=float(g['h0_b']),
+               a=float(g['h0_a']), a0=float(g['h0_a0']), b0=float(g['h0_b0']),
+               c0=float(g['h0_c0']), d0=float(g['h0_d0']))
+    with eng.Chain(T, N, D, 'undirected') as c:
+        c.upload_network(Y)
+        it = n_total - 1
+        # state after the labels update of the last recorded iteration: X, z of row `it`,
+        # parameters of row it - 1; the node sums must agree with the oracle's
+        from oracle.hdp_sums import NumpyLabelSums
+        X, z = Xs[it], zs[it]
+        mu, sigma, lm, w = mus[it - 1], sigmas[it - 1], float(lambdas[it - 1][0]), weights[it - 1]
+        c.set_positions(X)
+        c.set_prior_mixture(mu, sigma, lm, z)
+        dev, ref = hu.DeviceLabelSums(c), NumpyLabelSums(X, z, K)
+        np.testing.assert_allclose(dev.mean(lm), ref.mean(lm), rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(dev.residual(mu, lm), ref.residual(mu, lm), rtol=1e-12)
+        # and the log-posterior of the recorded state through the product's function
+        hp = hu.HDPHyper(K, **hp0)
+        for name in ('gamma', 'alpha_init', 'alpha', 'kappa', 'mean_variance_prior', 'b'):
+            setattr(hp, name, float(np.ravel(g['h1_' + name])[0]))
+        c.set_prior_mixture(mus[it], sigmas[it], float(lambdas[it][0]), zs[it])
+        ll = c.loglik_full([ics[it]])[0]
+        lp = ll + hu.log_posterior_terms(hu.DeviceLabelSums(c), ics[it], g['h0_intercept_prior'],
+                                         2, mus[it], sigmas[it], weights[it], betas[it],
+                                         lambdas[it], hp)
+        np.testing.assert_allclose(np.ravel(lp)[0], logps[it], rtol=1e-9)

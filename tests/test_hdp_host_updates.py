@@ -3,13 +3,15 @@ conjugate / auxiliary-variable updates and the log-posterior) against a trace
 recorded from the reference's DynamicNetworkHDPLPCM._fit.  CPU only.
 
 The loop below replays hdp_lpcm.py:823-1069 in the reference's order with its
-MT19937 stream: sweep / labels / log-likelihood come from the (reference-pinned)
-oracle, everything else is the product's host code under test."""
+MT19937 stream: sweep / labels / log-likelihood and the label-wise sums over the nodes
+come from the (reference-pinned) oracle - the product takes those sums from the device,
+tests/test_gpu_models.py - everything else is the product's host code under test."""
 import numpy as np
 import pytest
 
 from conftest import load_golden
 from oracle import oracle as orc
+from oracle.hdp_sums import NumpyLabelSums
 from dynetlsm_amd import hdp_updates as hu
 
 
@@ -53,7 +55,8 @@ def test_hdp_host_updates_reproduce_reference_fit(g):
                     (x[0] - intercept_prior[0]) ** 2 / (2 * 2))
         ic = isamp.step_rw(ic, lp, rng)
         z, n, nk, _ = orc.sample_labels_block_mt(X, mu, sigma, lmbda, w, rng)
-        beta, lmbda = hu.gibbs_updates(X, z, n, nk, mu, sigma, beta, w, lmbda, hp, rng)
+        sums = NumpyLabelSums(X, z, K)
+        beta, lmbda = hu.gibbs_updates(sums, n, nk, mu, sigma, beta, w, lmbda, hp, rng)
         np.testing.assert_allclose(X, Xs[it], atol=1e-9)
         np.testing.assert_allclose(ic, ics[it], atol=1e-10)
         np.testing.assert_array_equal(z, zs[it])
@@ -63,7 +66,7 @@ def test_hdp_host_updates_reproduce_reference_fit(g):
         np.testing.assert_allclose(sigma, sigmas[it], rtol=1e-9)
         np.testing.assert_allclose(lmbda, lambdas[it], rtol=1e-10)
         ll = orc.dynamic_network_loglikelihood_undirected(Y, X, ic[0])
-        lp_it = ll + hu.log_posterior_terms(X, ic, intercept_prior, 2, mu, sigma, z, w,
+        lp_it = ll + hu.log_posterior_terms(sums, ic, intercept_prior, 2, mu, sigma, w,
                                             beta, lmbda, hp)
         np.testing.assert_allclose(np.ravel(lp_it)[0], logps[it], rtol=1e-9)
     for name in ('gamma', 'alpha_init', 'alpha', 'kappa', 'mean_variance_prior', 'b'):
