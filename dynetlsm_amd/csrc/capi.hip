@@ -20,6 +20,7 @@
 #include "kernels_spec_sweep.hpp"
 #include "kernels_spec_pipe.hpp"
 #include "kernels_init.hpp"
+#include "kernels_post.hpp"
 
 using namespace dlsm;
 
@@ -271,7 +272,7 @@ void dlsm_destroy(dlsm_chain *h) {
                     h->radii_alt, h->step, h->nacc, h->nsteps, h->until, h->mu,
                     h->sigma, h->z, h->partials, h->dsmall, h->xref, h->lab_n,
                     h->lab_nk, h->lab_w, h->spec, h->nctrl, h->stamps, h->lsm, h->trace_X, h->trace_ic,
-                    h->trace_logp, h->hops, h->hops_max, h->pipe};
+                    h->trace_logp, h->hops, h->hops_max, h->pipe, h->post_zt, h->post_cooc};
     for (void *p : ptrs) if (p) hipFree(p);
     if (h->hsmall) hipHostFree(h->hsmall);
     if (h->timer0) hipEventDestroy(h->timer0);
@@ -1327,3 +1328,4 @@ int dlsm_timer_stop(dlsm_chain *h, double *ms) {
 }  // extern "C"
 
 #include "capi_init.hpp"
+#include "capi_post.hpp"

@@ -95,6 +95,9 @@ struct dlsm_chain {
     std::vector<std::pair<size_t, size_t>> stamp_launches;   // (first pair, pairs) per launch
     // initialisation pipeline: hop matrices [T][N][N] and the per-slice maximum
     uint16_t *hops = nullptr; int *hops_max = nullptr; bool have_hops = false;
+    // post-loop processing: labels of the kept samples (bytes, [T][N][Spad]) and the
+    // co-occurrence probabilities [T][N][N]
+    uint8_t *post_zt = nullptr; double *post_cooc = nullptr; int post_S = 0, post_Spad = 0;
     // LSM device-resident chain
     dlsm::LsmDeviceState *lsm = nullptr;
     dlsm_lsm_config lsm_cfg{};

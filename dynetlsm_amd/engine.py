@@ -404,6 +404,25 @@ class Chain(object):
     def init_release(self):
         self._ck(self._L.dlsm_init_release(self._h))
 
+    # -- post-loop processing ---------------------------------
+    def post_cooccurrence(self, zs, K, want_matrix=True):
+        """co-occurrence probabilities of the kept samples ``zs`` (S, T, N); returns the
+        (T, N, N) matrices (or None) and keeps them on the device for the VI sums"""
+        zs = _i64(zs, (np.shape(zs)[0], self.T, self.N), 'zs')
+        out = np.empty((self.T, self.N, self.N)) if want_matrix else None
+        self._ck(self._L.dlsm_post_cooccurrence(self._h, _p(zs), zs.shape[0], int(K),
+                                                None if out is None else _p(out)))
+        self._post_S = zs.shape[0]
+        return out
+
+    def post_expected_vi_sums(self):
+        out = np.empty((self.T, self._post_S))
+        self._ck(self._L.dlsm_post_expected_vi_sums(self._h, _p(out)))
+        return out
+
+    def post_release(self):
+        self._ck(self._L.dlsm_post_release(self._h))
+
     def profile_enable(self, on=True):
         self._ck(self._L.dlsm_profile_enable(self._h, int(on)))
 

@@ -6,11 +6,12 @@ prior, centring, intercept (and radii) MH, label block update -- all kernels of
 the engine -- then the O(TN + TK^2) conjugate / auxiliary updates in numpy
 (``hdp_updates``) and the log-posterior trace.
 
-Out of scope: the post-loop model selection by BIC / expected
-VI, co-occurrence matrices, Geweke diagnostics and forecasting.  After the loop
-this class keeps the raw traces, applies thinning, and exposes the maximum
-log-posterior sample as ``X_, z_, mu_, ...`` (``selection_type`` other than
-'map' raises).  Missing edges are rejected.
+After the loop (hdp_lpcm.py:1072-1176; ``posterior``): thinning, model selection by
+minimum posterior expected VI (default), BIC or MAP size - the posterior
+co-occurrence matrices and the VI criterion of every kept sample are computed on
+the device - weight renormalisation, Procrustes alignment of the stored samples,
+posterior means and group counts.  Out of scope: Geweke
+diagnostics and forecasting.  Missing edges are rejected.
 """
 import time
 
@@ -20,6 +21,7 @@ from scipy.stats import dirichlet
 from .engine import Chain, SamplerGrid
 from . import hdp_updates as hu
 from . import initialization as init_mod
+from . import posterior as post
 from .lsm import DynamicNetworkLSM, _ScalarMetropolis, check_random_state
 
 __all__ = ['DynamicNetworkHDPLPCM']
@@ -30,7 +32,7 @@ class DynamicNetworkHDPLPCM(object):
     ``device``, ``chain_id`` and ``sweep_algo``."""
 
     def __init__(self, n_features=2, n_components=10, is_directed=False,
-                 selection_type='map', n_iter=5000, tune=2500, tune_interval=100,
+                 selection_type='vi', n_iter=5000, tune=2500, tune_interval=100,
                  burn=2500, thin=None, gamma=1.0, gamma_prior_shape=1.0,
                  gamma_prior_rate=0.1, alpha_init=1.0, alpha_init_shape=1.,
                  alpha_init_rate=1., alpha=1.0, kappa=4.0, alpha_kappa_shape=5,
@@ -129,10 +131,8 @@ class DynamicNetworkHDPLPCM(object):
         if np.any(Y == -1) or np.any(np.isnan(Y)):
             raise ValueError('missing edges (-1 / nan) are not supported by the '
                              'MI355X engine: impute them first')
-        if self.selection_type != 'map':
-            raise ValueError("selection_type=%r: only 'map' is available (BIC / VI "
-                             "model selection is outside the accelerated hot path)"
-                             % self.selection_type)
+        if self.selection_type not in ('vi', 'bic', 'map'):
+            raise ValueError('Selection type not recognized')
         if self.n_control is not None and not self.is_directed:
             raise ValueError('The case-control likelihood currently only '
                              'supported for directed networks.')
@@ -284,18 +284,14 @@ class DynamicNetworkHDPLPCM(object):
                 setattr(self, name, getattr(self, name)[::self.thin])
             if self.is_directed:
                 self.radiis_ = self.radiis_[::self.thin]
-        # maximum log-posterior sample after burn-in
+        # model selection (hdp_lpcm.py:1085-1139): BIC / MAP size / minimum posterior
+        # expected VI, with the co-occurrence matrices and the VI criterion on the device
         n_burn = min(self.n_burn_ // (self.thin or 1), self.logps_.shape[0] - 1)
-        best = n_burn + int(np.argmax(self.logps_[n_burn:]))
-        self.selected_id_ = best
-        self.logp_ = self.logps_[best]
-        self.X_, self.intercept_ = self.Xs_[best], self.intercepts_[best]
-        self.mu_, self.sigma_, self.z_ = self.mus_[best], self.sigmas_[best], self.zs_[best]
-        self.beta_, self.lambda_ = self.betas_[best], self.lambdas_[best]
-        self.init_weights_ = self.weights_[best][0, 0]
-        self.trans_weights_ = self.weights_[best][1:]
-        if self.is_directed:
-            self.radii_ = self.radiis_[best]
+        post.select_model(self, chain, n_burn)
+        # Procrustes: rotate every stored sample onto the selected one (:1141-1146)
+        post.procrustes_align_samples(self)
+        self.posterior_group_ids_, self.posterior_group_counts_ = post.posterior_group_counts(
+            self, n_burn)
         self.X_mean_ = self.Xs_[n_burn:].mean(axis=0)
         self.lambda_mean_ = self.lambdas_[n_burn:].mean(axis=0)
         self.intercepts_mean_ = self.intercepts_[n_burn:].mean(axis=0)

@@ -215,6 +215,17 @@ int dlsm_init_mle_sums(dlsm_chain *h, double p0, double p1, double *out);
 /* free the hop matrices */
 int dlsm_init_release(dlsm_chain *h);
 
+/* ---- post-loop processing of the stored labels -------- */
+/* _calculate_posterior_cooccurrences (hdp_lpcm.py:1180-1186, label_utils.py:40-62): zs is
+ * the kept part of zs_ (zs_[n_burn:], S*T*N int64, labels < K); cooc_out (T*N*N, may be
+ * NULL) = fraction of the S samples in which nodes i and j share a label at time t.  The
+ * labels and the matrices stay on the device for dlsm_post_expected_vi_sums. */
+int dlsm_post_cooccurrence(dlsm_chain *h, const int64_t *zs, int S, int K, double *cooc_out);
+/* the sample-dependent sum of posterior_expected_vi (model_selection/posterior_vi.py:23-43):
+ * out[t*S + s] = sum_i log2( sum_j cooc[t,i,j] [z_stj == z_sti] ) for every kept sample */
+int dlsm_post_expected_vi_sums(dlsm_chain *h, double *out);
+int dlsm_post_release(dlsm_chain *h);
+
 /* ---- measurement ------------------------------------------------------ */
 enum {
     DLSM_K_LOGLIK = 0, DLSM_K_SWEEP = 1, DLSM_K_CENTER = 2, DLSM_K_LABELS = 3,

@@ -530,10 +530,76 @@ def gen_init(ref):
     print('init.npz')
 
 
+def gen_post(ref):
+    """post-loop processing of DynamicNetworkHDPLPCM: posterior
+    co-occurrence matrices, expected-VI minimisation (with ties), BIC / MAP model
+    selection and weight renormalisation, from the reference's own functions applied to
+    a synthetic stored trace."""
+    from types import SimpleNamespace
+    from dynetlsm.label_utils import (calculate_posterior_cooccurrence, renormalize_weights,
+                                      calculate_posterior_group_counts)
+    from dynetlsm.model_selection.posterior_vi import (
+        minimize_posterior_expected_vi, time_averaged_posterior_expected_vi)
+    from dynetlsm.model_selection.approx_bic import select_bic
+    out = {}
+    for tag, directed in (('u', False), ('d', True)):
+        rng = np.random.RandomState(7 if directed else 5)
+        T, N, K, D, S, n_burn = 3, 30, 6, 2, 40, 8
+        Y = latent_network(31 + directed, T, N, directed)
+        base = rng.randint(0, 3, size=(T, N))
+        zs = np.empty((S, T, N), dtype=np.int64)
+        for s_ in range(S):
+            z = base.copy()
+            flip = rng.rand(T, N) < 0.08 * (1 + (s_ % 3))
+            z[flip] = rng.randint(0, K, size=int(flip.sum()))
+            zs[s_] = z
+        zs[20] = zs[12]; zs[33] = zs[12]          # identical partitions: ties in the VI
+        Xs = rng.randn(S, T, N, D) * (0.05 if directed else 1.0)
+        n_ic = 2 if directed else 1
+        m = SimpleNamespace(
+            Y_fit_=Y, zs_=zs, Xs_=Xs, n_burn_=n_burn, n_components=K, n_features=D,
+            is_directed=directed, case_control_sampler_=None,
+            intercepts_=rng.randn(S, n_ic) * 0.1 + 0.5,
+            radiis_=rng.dirichlet(np.ones(N) * 5, size=S) if directed else None,
+            mus_=rng.randn(S, K, D), sigmas_=rng.gamma(2., 1., size=(S, K)) + 0.1,
+            betas_=rng.dirichlet(np.ones(K), size=S),
+            weights_=rng.dirichlet(np.ones(K), size=(S, T, K)),
+            lambdas_=rng.uniform(0.5, 0.95, size=(S, 1)), logps_=rng.randn(S) * 10)
+        cooc = np.stack([calculate_posterior_cooccurrence(m, t=t) for t in range(T)])
+        m.cooccurrence_probas_ = cooc
+        vis = np.array([time_averaged_posterior_expected_vi(zs[i], cooc)
+                        for i in range(n_burn, S)])
+        best = minimize_posterior_expected_vi(m)
+        bic, models, counts = select_bic(m)
+        z_r, beta_r, init_w, trans_w, mu_r, sigma_r = renormalize_weights(m, sample_id=best)
+        gc = [calculate_posterior_group_counts(m, t=t) for t in range(T)]
+        for k_, v_ in dict(Y=Y, zs=zs, Xs=Xs, intercepts=m.intercepts_, mus=m.mus_,
+                           sigmas=m.sigmas_, betas=m.betas_, weights=m.weights_,
+                           lambdas=m.lambdas_, logps=m.logps_, n_burn=np.array(n_burn),
+                           K=np.array(K), cooc=cooc, vis=vis, best=np.array(best), bic=bic,
+                           counts=counts, z_r=z_r, beta_r=beta_r, init_w=init_w,
+                           trans_w=trans_w, mu_r=mu_r, sigma_r=sigma_r).items():
+            out[tag + '_' + k_] = v_
+        if directed:
+            out['d_radiis'] = m.radiis_
+        for t in range(T):
+            out['%s_gc_index_%d' % (tag, t)] = gc[t][0]
+            out['%s_gc_freq_%d' % (tag, t)] = gc[t][1]
+        for i_, mod in enumerate(models):
+            out['%s_model%d_init_w' % (tag, i_)] = mod.init_weights
+            out['%s_model%d_trans_w' % (tag, i_)] = mod.trans_weights
+            out['%s_model%d_beta' % (tag, i_)] = mod.beta
+    np.savez_compressed(os.path.join(HERE, 'post.npz'), **out)
+    print('post.npz')
+
+
 if __name__ == '__main__':
     ref = import_reference()
     if len(sys.argv) > 1 and sys.argv[1] == 'hdp':
         gen_hdp_trace(ref)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'post':
+        gen_post(ref)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'init':
         gen_init(ref)
@@ -549,3 +615,4 @@ if __name__ == '__main__':
     gen_hdp_trace(ref)
     gen_more_envelopes(ref, Yd)
     gen_init(ref)
+    gen_post(ref)
