@@ -96,6 +96,10 @@ SIGNATURES = {
     'dlsm_post_cooccurrence': (C.c_int, [handle_t, c_i64_p, C.c_int, C.c_int, c_double_p]),
     'dlsm_post_expected_vi_sums': (C.c_int, [handle_t, c_double_p]),
     'dlsm_post_release': (C.c_int, [handle_t]),
+    'dlsm_forecast_mean_probas': (C.c_int, [handle_t, c_double_p, c_double_p, C.c_int, C.c_int,
+                                            c_double_p]),
+    'dlsm_forecast_marginal': (C.c_int, [handle_t, c_double_p, c_double_p, c_double_p, C.c_int,
+                                         c_double_p]),
     'dlsm_profile_enable': (C.c_int, [handle_t, C.c_int]),
     'dlsm_profile_read': (C.c_int, [handle_t, C.c_int, c_double_p, C.POINTER(C.c_int)]),
     'dlsm_profile_read_eval_stamps': (C.c_int, [handle_t, c_double_p, C.POINTER(C.c_int)]),

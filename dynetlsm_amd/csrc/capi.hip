@@ -21,6 +21,7 @@
 #include "kernels_spec_pipe.hpp"
 #include "kernels_init.hpp"
 #include "kernels_post.hpp"
+#include "kernels_forecast.hpp"
 
 using namespace dlsm;
 
@@ -1329,3 +1330,4 @@ int dlsm_timer_stop(dlsm_chain *h, double *ms) {
 
 #include "capi_init.hpp"
 #include "capi_post.hpp"
+#include "capi_forecast.hpp"

@@ -423,6 +423,28 @@ class Chain(object):
     def post_release(self):
         self._ck(self._L.dlsm_post_release(self._h))
 
+    # -- one-step-ahead forecasts ------------------------------
+    def forecast_mean_probas(self, Xs, intercepts, zero_diag=False):
+        Xs = np.ascontiguousarray(Xs, dtype=np.float64)
+        S = Xs.shape[0]
+        Xs = _f64(Xs, (S, self.N, self.D), 'Xs')
+        b = _f64(np.broadcast_to(np.ravel(intercepts), (S,)) if np.size(intercepts) == 1
+                 else np.ravel(intercepts), (S,), 'intercepts')
+        out = np.empty((self.N, self.N))
+        self._ck(self._L.dlsm_forecast_mean_probas(self._h, _p(Xs), _p(b), S, int(zero_diag),
+                                                   _p(out)))
+        return out
+
+    def forecast_marginal(self, x, W, intercepts):
+        W = np.ascontiguousarray(W, dtype=np.float64)
+        S = W.shape[0]
+        x = _f64(x, (self.N, self.D), 'x')
+        W = _f64(W, (S, self.N), 'W')
+        b = _f64(np.ravel(intercepts), (S,), 'intercepts')
+        out = np.empty((self.N, self.N))
+        self._ck(self._L.dlsm_forecast_marginal(self._h, _p(x), _p(W), _p(b), S, _p(out)))
+        return out
+
     def profile_enable(self, on=True):
         self._ck(self._L.dlsm_profile_enable(self._h, int(on)))
 

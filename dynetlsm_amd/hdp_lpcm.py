@@ -22,6 +22,7 @@ from .engine import Chain, SamplerGrid
 from . import hdp_updates as hu
 from . import initialization as init_mod
 from . import posterior as post
+from . import forecast as fc
 from .lsm import DynamicNetworkLSM, _ScalarMetropolis, check_random_state
 
 __all__ = ['DynamicNetworkHDPLPCM']
@@ -84,6 +85,34 @@ class DynamicNetworkHDPLPCM(object):
     @property
     def n_burn_(self):
         return (self.burn or 0) + (self.tune or 0)
+
+    # -- one-step-ahead forecasts (hdp_lpcm.py:496-626; undirected models) ----------
+    def _forecast_ready(self):
+        if not hasattr(self, 'X_'):
+            raise ValueError('Model not fit.')
+        if self.is_directed:
+            raise ValueError('forecasts are implemented for undirected models '
+                             '(as the reference formulas are)')
+        return self.chain_
+
+    @property
+    def forecast_probas_map_(self):
+        return fc.forecast_probas_map(self, self._forecast_ready())
+
+    @property
+    def forecast_probas_plugin_(self):
+        return fc.forecast_probas_plugin(self, self._forecast_ready())
+
+    @property
+    def forecast_probas_marginalized_(self):
+        return fc.forecast_probas_marginalized(self, self._forecast_ready())
+
+    def forecast_probas(self, n_samples=5000):
+        return fc.forecast_probas(self, self._forecast_ready(), n_samples=n_samples)
+
+    @property
+    def forecast_probas_pp_(self):
+        return fc.forecast_probas_pp(self, self._forecast_ready())
 
     # ------------------------------------------------------------------ init
     def _init_sampler(self, Y, rng, init):

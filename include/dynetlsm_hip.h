@@ -226,6 +226,20 @@ int dlsm_post_cooccurrence(dlsm_chain *h, const int64_t *zs, int S, int K, doubl
 int dlsm_post_expected_vi_sums(dlsm_chain *h, double *out);
 int dlsm_post_release(dlsm_chain *h);
 
+/* ---- one-step-ahead forecasts (undirected models) ------ */
+/* the accumulation of forecast_probas / forecast_probas_pp_ (hdp_lpcm.py:555-626):
+ * out[i,j] = (1/S) sum_s expit(intercepts[s] - |Xs[s,i] - Xs[s,j]|), Xs S*N*D the sampled
+ * one-step-ahead positions (drawn by the caller: the draws keep the reference's MT19937
+ * order), out N*N; zero_diag != 0 zeroes the diagonal as forecast_probas does. */
+int dlsm_forecast_mean_probas(dlsm_chain *h, const double *Xs, const double *intercepts, int S,
+                              int zero_diag, double *out);
+/* marginal_forecast (forecast.pyx:79-128): out[i,j] = sum_s W[s,i] W[s,j]
+ * expit(intercepts[s] - |x_i - x_j|) / sum_s W[s,i] W[s,j] for i != j, 0 on the diagonal;
+ * x N*D the plug-in positions, W S*N the per-sample mixture densities of x_i (O(S N K), computed
+ * by the caller: mixture_normal_pdf, forecast.pyx:39-54). */
+int dlsm_forecast_marginal(dlsm_chain *h, const double *x, const double *W, const double *intercepts,
+                           int S, double *out);
+
 /* ---- measurement ------------------------------------------------------ */
 enum {
     DLSM_K_LOGLIK = 0, DLSM_K_SWEEP = 1, DLSM_K_CENTER = 2, DLSM_K_LABELS = 3,

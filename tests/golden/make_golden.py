@@ -593,10 +593,52 @@ def gen_post(ref):
     print('post.npz')
 
 
+def gen_forecast(ref):
+    """one-step-ahead forecasts of DynamicNetworkHDPLPCM from the reference's
+    properties / methods applied to the synthetic stored trace of post.npz (undirected)."""
+    from types import SimpleNamespace
+    import dynetlsm.hdp_lpcm as hm
+    from dynetlsm.label_utils import renormalize_weights
+    from dynetlsm.forecast import marginal_forecast
+    g = np.load(os.path.join(HERE, 'post.npz'))
+    n_burn, best = int(g['u_n_burn']), int(g['u_best'])
+    m = SimpleNamespace(
+        Y_fit_=g['u_Y'], zs_=g['u_zs'], Xs_=g['u_Xs'], n_burn_=n_burn, n_components=int(g['u_K']),
+        n_features=2, is_directed=False, intercepts_=g['u_intercepts'], mus_=g['u_mus'],
+        sigmas_=g['u_sigmas'], betas_=g['u_betas'], weights_=g['u_weights'],
+        lambdas_=g['u_lambdas'], logps_=g['u_logps'], random_state=11)
+    (m.z_, m.beta_, m.init_weights_, m.trans_weights_, m.mu_, m.sigma_) = \
+        renormalize_weights(m, sample_id=best)
+    m.X_, m.intercept_, m.lambda_ = m.Xs_[best], m.intercepts_[best], m.lambdas_[best]
+    m.intercepts_mean_ = m.intercepts_[n_burn:].mean(axis=0)
+    cls = hm.DynamicNetworkHDPLPCM
+    out = {'best': np.array(best)}
+    out['map'] = cls.forecast_probas_map_.fget(m)
+    out['plugin'] = cls.forecast_probas_plugin_.fget(m)
+    out['marginalized'] = cls.forecast_probas_marginalized_.fget(m)
+    out['mc'] = cls.forecast_probas(m, n_samples=25)
+    out['pp'] = cls.forecast_probas_pp_.fget(m)
+    # marginal_forecast on its own, without renormalisation
+    rng = np.random.RandomState(3)
+    S, N, K = 12, 30, 6
+    x = rng.randn(N, 2)
+    out['mf_x'] = x
+    out['mf_probas'] = marginal_forecast(
+        x, np.ascontiguousarray(m.Xs_[:S, -1]), np.ascontiguousarray(m.zs_[:S, -1]),
+        np.ascontiguousarray(m.weights_[:S, -1]), np.ascontiguousarray(m.mus_[:S]),
+        np.ascontiguousarray(m.sigmas_[:S]), m.intercepts_[:S].ravel().copy(),
+        m.lambdas_[:S].ravel().copy(), renormalize=False)
+    np.savez_compressed(os.path.join(HERE, 'forecast.npz'), **out)
+    print('forecast.npz')
+
+
 if __name__ == '__main__':
     ref = import_reference()
     if len(sys.argv) > 1 and sys.argv[1] == 'hdp':
         gen_hdp_trace(ref)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'forecast':
+        gen_forecast(ref)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'post':
         gen_post(ref)
@@ -616,3 +658,4 @@ if __name__ == '__main__':
     gen_more_envelopes(ref, Yd)
     gen_init(ref)
     gen_post(ref)
+    gen_forecast(ref)
