@@ -23,6 +23,7 @@ from . import hdp_updates as hu
 from . import initialization as init_mod
 from . import posterior as post
 from . import forecast as fc
+from .imputer import SimpleNetworkImputer
 from .lsm import DynamicNetworkLSM, _ScalarMetropolis, check_random_state
 
 __all__ = ['DynamicNetworkHDPLPCM']
@@ -157,9 +158,21 @@ class DynamicNetworkHDPLPCM(object):
         Y = np.array(Y, dtype=np.float64, copy=self.copy, order='C')
         if Y.ndim != 3 or Y.shape[1] != Y.shape[2]:
             raise ValueError('Y must have shape (n_time_steps, n_nodes, n_nodes)')
-        if np.any(Y == -1) or np.any(np.isnan(Y)):
-            raise ValueError('missing edges (-1 / nan) are not supported by the '
-                             'MI355X engine: impute them first')
+        if np.any(np.isnan(Y)):
+            raise ValueError('NaN entries are not supported: code missing dyads as -1')
+        # missing dyads (hdp_lpcm.py:669-706): imputed once; undirected models also average
+        # per-iteration Bernoulli draws of them after burn-in into ``missings_``
+        self.nan_mask_, miss = None, None
+        if np.any(Y == -1):
+            if not self.is_directed:
+                miss = np.nonzero(np.triu(Y == -1, 1))            # (t, i, j), row-major
+                iu = np.nonzero(np.triu(np.ones(Y.shape, dtype=bool), 1))
+                self.nan_mask_ = Y[iu] == -1
+                self.missings_ = np.zeros(miss[0].shape[0])
+            else:
+                off = np.nonzero(~np.eye(Y.shape[1], dtype=bool)[None].repeat(Y.shape[0], 0))
+                self.nan_mask_ = Y[off] == -1
+            Y = SimpleNetworkImputer(strategy='random', missing_value=-1).fit_transform(Y)
         if self.selection_type not in ('vi', 'bic', 'map'):
             raise ValueError('Selection type not recognized')
         if self.n_control is not None and not self.is_directed:
@@ -299,8 +312,16 @@ class DynamicNetworkHDPLPCM(object):
             X = chain.get_positions()
             mu, sigma, weights = mu.copy(), sigma.copy(), weights.copy()
             beta, lmbda = hu.gibbs_updates(sums, n, nk, mu, sigma, beta, weights, lmbda, hp, rng)
+            if miss is not None:                  # hdp_lpcm.py:1039-1049
+                dm = X[miss[0], miss[1]] - X[miss[0], miss[2]]
+                eta = intercept[0] - np.sqrt(np.sum(dm * dm, axis=1))
+                y_ij = rng.binomial(1, 1. / (1. + np.exp(-eta)))
+                if it > self.n_burn_:
+                    self.missings_ += y_ij
             store(it, ll)
         self.loop_seconds_ = time.perf_counter() - t_loop     # Gibbs loop only
+        if miss is not None:
+            self.missings_ /= max(1, n_total - self.n_burn_)       # hdp_lpcm.py:1155-1156
         chain.get_samplers(self.latent_samplers)
         self.gamma, self.alpha_init, self.alpha, self.kappa = (hp.gamma, hp.alpha_init,
                                                                hp.alpha, hp.kappa)

@@ -12,7 +12,8 @@ Differences from the reference that a user can see:
   * random numbers: the latent-position sweep uses the engine's Philox streams
     (keyed by a seed drawn from ``random_state``) and the even/odd-t scan order,
     so chains are equal in distribution, not sample for sample;
-  * missing edges (-1 coded dyads) are rejected (imputation is out of scope);
+  * missing edges (-1 coded dyads) are imputed once before the chain, as the reference
+    effectively does (see ``imputer``); NaN entries are rejected;
   * ``fit(Y, init=...)`` accepts starting values and skips the init pipeline.
 """
 import time
@@ -22,6 +23,7 @@ from scipy.stats import dirichlet
 
 from .engine import Chain, SamplerGrid
 from . import initialization as init_mod
+from .imputer import SimpleNetworkImputer
 
 __all__ = ['DynamicNetworkLSM']
 
@@ -146,9 +148,10 @@ class DynamicNetworkLSM(object):
         Y = np.array(Y, dtype=np.float64, copy=self.copy, order='C')
         if Y.ndim != 3 or Y.shape[1] != Y.shape[2]:
             raise ValueError('Y must have shape (n_time_steps, n_nodes, n_nodes)')
-        if np.any(Y == -1) or np.any(np.isnan(Y)):
-            raise ValueError('missing edges (-1 / nan) are not supported by the '
-                             'MI355X engine: impute them first')
+        if np.any(np.isnan(Y)):
+            raise ValueError('NaN entries are not supported: code missing dyads as -1')
+        if np.any(Y == -1):          # lsm.py:345-359
+            Y = SimpleNetworkImputer(strategy='random', missing_value=-1).fit_transform(Y)
         T, N, _ = Y.shape
         D = self.n_features
         rng = check_random_state(self.random_state)

@@ -61,8 +61,8 @@ int dlsm_synchronize(dlsm_chain *h);
 /* ---- network --------------------------------------------------------- */
 /* Y: T*N*N float64 row-major exactly as fit(Y) receives it (lsm.py:341).
  * Packed on device to 1 bit/dyad (+ the transpose for directed models).
- * Entries other than 0.0 / 1.0 -> DLSM_E_DATA (missing-edge imputation,
- * lsm.py:525-545, is out of scope). */
+ * Entries other than 0.0 / 1.0 -> DLSM_E_DATA (the estimators impute -1 coded
+ * dyads before the upload, as imputer.py / lsm.py:345-359 do). */
 int dlsm_upload_network(dlsm_chain *h, const double *Y);
 /* case-control: zero padded edge lists and degrees exactly as
  * DirectedCaseControlSampler.init builds them (case_control_likelihood.py:45-68):

@@ -632,10 +632,34 @@ def gen_forecast(ref):
     print('forecast.npz')
 
 
+def gen_imputer(ref):
+    """SimpleNetworkImputer (imputer.py) on networks with -1 dyads"""
+    from dynetlsm.imputer import SimpleNetworkImputer
+    out = {}
+    for tag, directed in (('u', False), ('d', True)):
+        Y = latent_network(41 + directed, 3, 25, directed)
+        rng = np.random.RandomState(9)
+        mask = rng.rand(*Y.shape) < 0.1
+        if not directed:
+            mask = np.triu(mask, 1); mask = mask | mask.transpose(0, 2, 1)
+        for t in range(Y.shape[0]):
+            np.fill_diagonal(mask[t], False)
+        mask[2] = False                                   # a fully observed slice
+        Ym = Y.copy(); Ym[mask] = -1
+        out[tag + '_Y'] = Ym
+        out[tag + '_random'] = SimpleNetworkImputer(strategy='random',
+                                                    missing_value=-1).fit_transform(Ym)
+    np.savez_compressed(os.path.join(HERE, 'imputer.npz'), **out)
+    print('imputer.npz')
+
+
 if __name__ == '__main__':
     ref = import_reference()
     if len(sys.argv) > 1 and sys.argv[1] == 'hdp':
         gen_hdp_trace(ref)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'imputer':
+        gen_imputer(ref)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'forecast':
         gen_forecast(ref)
@@ -659,3 +683,4 @@ if __name__ == '__main__':
     gen_init(ref)
     gen_post(ref)
     gen_forecast(ref)
+    gen_imputer(ref)

@@ -50,3 +50,14 @@ def test_product_never_imports_the_oracle():
                 txt = open(os.path.join(dirpath, f)).read()
                 assert 'oracle' not in txt.replace('the oracle', '').replace(
                     'CPU oracle', '').replace('oracle (', ''), os.path.join(dirpath, f)
+
+
+def test_imputer_matches_reference():
+    """imputer.py:11-81 (SimpleNetworkImputer, strategy='random'): bit for bit"""
+    import numpy as np
+    from conftest import load_golden
+    from dynetlsm_amd.imputer import SimpleNetworkImputer
+    g = load_golden('imputer.npz')
+    for tag in 'ud':
+        got = SimpleNetworkImputer(strategy='random', missing_value=-1).fit_transform(g[tag + '_Y'])
+        np.testing.assert_array_equal(got, g[tag + '_random'])

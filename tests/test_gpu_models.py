@@ -86,11 +86,21 @@ def test_hdp_directed_smoke(eng):
     assert np.isfinite(m.logps_).all()
 
 
-def test_missing_edges_and_bad_shapes_are_rejected(eng):
+def test_missing_edges_are_imputed_and_bad_shapes_rejected(eng):
     Y, _ = _splitting_network(n_nodes=12)
-    Y[0, 1, 2] = -1
+    Ym = Y.copy()
+    Ym[0, 1, 2] = Ym[0, 2, 1] = -1
+    Ym[1, 3, 7] = Ym[1, 7, 3] = -1
+    lsm = eng.DynamicNetworkLSM(n_iter=5, tune=None, burn=None, random_state=0).fit(Ym)
+    assert set(np.unique(lsm.Y_fit_)) <= {0.0, 1.0}
+    assert np.array_equal(lsm.Y_fit_[Ym != -1], Ym[Ym != -1])
+    hdp = eng.DynamicNetworkHDPLPCM(n_iter=30, tune=10, burn=10, n_components=4,
+                                    random_state=0).fit(Ym)
+    assert hdp.nan_mask_.sum() == 2 and hdp.missings_.shape == (2,)
+    assert ((hdp.missings_ >= 0) & (hdp.missings_ <= 1)).all()
+    Yn = Y.copy(); Yn[0, 1, 2] = np.nan
     with pytest.raises(ValueError):
-        eng.DynamicNetworkLSM(n_iter=5, tune=None, burn=None).fit(Y)
+        eng.DynamicNetworkLSM(n_iter=5, tune=None, burn=None).fit(Yn)
     with pytest.raises(ValueError):
         eng.DynamicNetworkLSM(n_iter=5, tune=None, burn=None).fit(np.zeros((2, 5, 4)))
     with pytest.raises(ValueError):
