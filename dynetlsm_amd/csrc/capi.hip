@@ -769,7 +769,7 @@ static int launch_sweep_spec(dlsm_chain *h, IterRef iter, int S, bool alloc_only
 // workgroup per slice
 static int resolve_sweep_algo(const dlsm_chain *h, int algo) {
     if (algo != 0) return algo;
-    if (h->model == DLSM_DIRECTED_CASE_CONTROL) return h->N >= 256 ? 2 : 1;
+    if (h->model == DLSM_DIRECTED_CASE_CONTROL) return h->N >= 512 ? 4 : (h->N >= 256 ? 2 : 1);
     return h->N >= 512 ? 4 : (h->N >= 256 ? 2 : 1);
 }
 
@@ -788,10 +788,15 @@ template <int DD>
 static int launch_sweep_pipe(dlsm_chain *h, IterRef iter, bool alloc_only = false) {
     const int N = h->N, T = h->T;
     const int nbat = (N + PP_B - 1) / PP_B;
-    const int ne_wg = std::max(h->n_cu / 2, h->n_cu - T);
+    const bool cc = h->model == DLSM_DIRECTED_CASE_CONTROL;
+    int ne_wg = std::max(h->n_cu / 2, h->n_cu - T);
     int parts = (int)((double)ne_wg * PP_WAVES / ((double)T * PP_B) + 0.5);
     if (getenv("DLSM_PIPE_PARTS")) parts = atoi(getenv("DLSM_PIPE_PARTS"));
     parts = std::max(1, std::min(parts, PP_MAXPARTS));
+    if (cc) {           // CC_PARTS wavefronts per node, four nodes per workgroup round
+        parts = CC_PARTS;
+        ne_wg = std::min(ne_wg, (T * PP_B * CC_PARTS + PP_WAVES - 1) / PP_WAVES);
+    }
     auto even2 = [](size_t n) { return (n + 1) / 2 * 2; };
     const size_t n_prop = even2((size_t)T * N * (2 * DD + 2));
     const size_t n_full0 = (size_t)2 * T * PP_B * parts * 2;
@@ -809,12 +814,16 @@ static int launch_sweep_pipe(dlsm_chain *h, IterRef iter, bool alloc_only = fals
     pb.Hx = pb.Hd + n_h; pb.acc = (int32_t *)(pb.Hx + n_h);
     pb.consts = pb.Hx + n_h + n_acc;
     pb.parts = parts; pb.per = (N + parts - 1) / parts; pb.nbat = nbat;
+    pb.nctrl = h->nctrl;
     const size_t lds = (size_t)PP_B * PP_B * sizeof(double);
     auto ku = k_pipe_step<DD, DLSM_UNDIRECTED>;
     auto kd = k_pipe_step<DD, DLSM_DIRECTED>;
+    auto kc = k_pipe_step<DD, DLSM_DIRECTED_CASE_CONTROL>;
     HIPCHK(h, hipFuncSetAttribute((const void *)ku, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds));
     HIPCHK(h, hipFuncSetAttribute((const void *)kd, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds));
+    HIPCHK(h, hipFuncSetAttribute((const void *)kc, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds));
     if (alloc_only) return DLSM_OK;
     ChainView v = h->view();
@@ -828,8 +837,10 @@ static int launch_sweep_pipe(dlsm_chain *h, IterRef iter, bool alloc_only = fals
         const int grid = T + (any_eval ? ne_wg : 0);
         if (h->model == DLSM_UNDIRECTED)
             launch_pipe_step<DD, DLSM_UNDIRECTED>(h, v, pb, grid, lds, l);
-        else
+        else if (h->model == DLSM_DIRECTED)
             launch_pipe_step<DD, DLSM_DIRECTED>(h, v, pb, grid, lds, l);
+        else
+            launch_pipe_step<DD, DLSM_DIRECTED_CASE_CONTROL>(h, v, pb, grid, lds, l);
     }
     HIPCHK(h, hipGetLastError());
     return DLSM_OK;
@@ -853,8 +864,10 @@ static int launch_sweep(dlsm_chain *h, IterRef iter, int algo, bool alloc_only =
         algo = resolve_sweep_algo(h, algo);
         if (alloc_only) {
             hipStreamSynchronize(h->stream);
+            if (algo == 4) return launch_sweep_pipe<DD>(h, iter, true);
             return algo >= 2 ? launch_sweep_spec<DD>(h, iter, 1, true) : DLSM_OK;
         }
+        if (algo == 4) return launch_sweep_pipe<DD>(h, iter);
         if (algo >= 2) return launch_sweep_spec<DD>(h, iter, 1);
         for (int parity = 0; parity < 2; ++parity) {
             int nsl = (h->T - parity + 1) / 2;
@@ -922,8 +935,6 @@ int dlsm_resolve_sweep_algo(dlsm_chain *h, int algo) {
 int dlsm_sweep_positions(dlsm_chain *h, uint32_t iter, int algo) {
     NEED(h, h != nullptr, "null handle");
     NEED(h, algo >= 0 && algo <= 4, "algo must be 0..4");
-    NEED(h, algo != 4 || h->model != DLSM_DIRECTED_CASE_CONTROL,
-         "algo 4 serves the exact likelihoods (case-control: algo 1 or 2)");
     HIPCHK(h, hipSetDevice(h->device));
     int rc = check_ready_sweep(h); if (rc) return rc;
     rc = enqueue_sweep(h, IterRef{iter, nullptr}, algo); if (rc) return rc;

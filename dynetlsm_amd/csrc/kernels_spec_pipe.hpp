@@ -53,6 +53,7 @@ struct PipeBuf {
     double *Hx;      // [2][T][PP_B][PP_B] : Hx[m][k], m in the previous batch
     int32_t *acc;    // [T][PP_B + 1] : count, accepted nodes of the last resolved batch
     double *consts;  // [2] : E = exp(sum of intercepts), flush interval
+    const int32_t *nctrl;   // case-control: valid controls per (t, i, direction)
     int parts, per, nbat;
 };
 
@@ -252,6 +253,109 @@ __device__ __forceinline__ void pipe_eval_item(const ChainView &c, const PipeBuf
     }
 }
 
+
+// Case-control likelihood (a3 inside a9 / a10): the O(deg + 2C) gathered terms of a node
+// as in k_spec_eval_cc, with the snapshot rule for the neighbours' positions, split over
+// the CC_PARTS wavefronts of a group: wavefront `sub` takes the 64-term chunks sub,
+// sub + CC_PARTS, ...  H is non-zero only for the nodes of the window [jprev, jk) that sit in
+// node k's edge / control lists (at most once per direction): their corrections are added into
+// the group's LDS column (two addends at most per entry: order independent) and
+// exponentiated on the way out; every other entry of the column is the factor 1.
+//   term kinds: 0 in-edge, 1 out-edge (eta - softplus(eta)),
+//               2 in-control, 3 out-control (- adj * softplus(eta))
+constexpr int CC_PARTS = 4;
+
+template <int D>
+__device__ __forceinline__ void pipe_cc_accumulate(const ChainView &c, const PipeBuf &pb, int be,
+                                                   int t, int k, int sub, int lane, double *col) {
+    constexpr int PW = 2 * D + 2;
+    const int N = c.N;
+    const int j0 = be * PP_B, jk = j0 + k;
+    const int jprev = max(0, j0 - PP_B);
+    const int bb = be & 1;
+    const size_t node = (size_t)t * N + jk;
+    const double *Xt = c.X + (size_t)t * N * D;
+    const double *props = pb.prop + (size_t)t * N * PW;
+    double xk0[D], xk1[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        xk0[d] = props[(size_t)jk * PW + D + 2 + d];
+        xk1[d] = props[(size_t)jk * PW + d];
+    }
+    const double bin = c.intercept[0], bout = c.intercept[1];
+    const double rj = c.radii[jk];
+    const int in_deg = c.degree[node * 2], out_deg = c.degree[node * 2 + 1];
+    const int nci = pb.nctrl[node * 2], nco = pb.nctrl[node * 2 + 1];
+    const double adj_in = (double)(N - in_deg - 1) / (double)nci;
+    const double adj_out = (double)(N - out_deg - 1) / (double)nco;
+    const int total_terms = in_deg + out_deg + nci + nco;
+    double acc = 0.0;
+    for (int q0 = 64 * sub; q0 < total_terms; q0 += 64 * CC_PARTS) {
+        const int q = q0 + lane;
+        int e = -1, kind = 0;
+        if (q < total_terms) {
+            int r = q;
+            if (r < in_deg) { e = c.in_edges[node * c.Din + r]; kind = 0; }
+            else if ((r -= in_deg) < out_deg) { e = c.out_edges[node * c.Dout + r]; kind = 1; }
+            else if ((r -= out_deg) < nci) { e = c.ctrl_in[node * c.C + r]; kind = 2; }
+            else { r -= nci; e = c.ctrl_out[node * c.C + r]; kind = 3; }
+        }
+        if (e >= 0) {
+            const double *src = e < jprev ? Xt + (size_t)e * D : props + (size_t)e * PW + D + 2;
+            double xe[D];
+#pragma unroll
+            for (int d = 0; d < D; ++d) xe[d] = src[d];
+            const double re = c.radii[e];
+            const bool in_dir = (kind == 0 || kind == 2);
+            const double wsp = kind < 2 ? 1.0 : (kind == 2 ? adj_in : adj_out);
+            // delta of this term when k moves, the neighbour at position xn
+#define DLSM_CC_DELTA(OUT_, XN_, SELF_)                                                        \
+            {                                                                                   \
+                const double d0_ = (SELF_) ? 0.0 : dist_of<D>(XN_, xk0, c.squared);             \
+                const double d1_ = (SELF_) ? 0.0 : dist_of<D>(XN_, xk1, c.squared);             \
+                const double e0_ = in_dir ? bin * (1 - d0_ / rj) + bout * (1 - d0_ / re)        \
+                                          : bin * (1 - d0_ / re) + bout * (1 - d0_ / rj);       \
+                const double e1_ = in_dir ? bin * (1 - d1_ / rj) + bout * (1 - d1_ / re)        \
+                                          : bin * (1 - d1_ / re) + bout * (1 - d1_ / rj);       \
+                const double sp_ = log((1.0 + exp(e1_)) / (1.0 + exp(e0_)));                    \
+                OUT_ = (kind < 2 ? (e1_ - e0_) : 0.0) - wsp * sp_;                              \
+            }
+            double contrib;
+            DLSM_CC_DELTA(contrib, xe, e == jk)
+            acc += contrib;
+            if (e >= jprev && e < jk) {         // a node of the window: its acceptance matters
+                double xe1[D], moved;
+#pragma unroll
+                for (int d = 0; d < D; ++d) xe1[d] = props[(size_t)e * PW + d];
+                DLSM_CC_DELTA(moved, xe1, false)
+                atomicAdd(&col[e - jprev], moved - contrib);
+            }
+#undef DLSM_CC_DELTA
+        }
+    }
+    const double total = wave_sum_all(acc);
+    if (lane == 0) {
+        double2 *f = (double2 *)pb.full0 + (((size_t)bb * c.T + t) * PP_B + k) * pb.parts + sub;
+        *f = make_double2(total, 1.0);
+    }
+}
+
+// the group's column -> factors; wavefront `sub` writes entries [64 sub, 64 sub + 64)
+template <int D>
+__device__ __forceinline__ void pipe_cc_writeout(const ChainView &c, const PipeBuf &pb, int be,
+                                                 int t, int k, int sub, int lane,
+                                                 const double *col) {
+    const int j0 = be * PP_B;
+    const int ncross = j0 - max(0, j0 - PP_B);
+    const int bb = be & 1;
+    const int m = 64 * sub + lane;              // index into [cross block | own batch]
+    if (m >= ncross + k) return;
+    const double v = col[m];
+    const double f = v == 0.0 ? 1.0 : exp(v);
+    if (m < ncross) pb.Hx[(((size_t)bb * c.T + t) * PP_B + m) * PP_B + k] = f;
+    else pb.Hd[(((size_t)bb * c.T + t) * PP_B + (m - ncross)) * PP_B + k] = f;
+}
+
 // Resolve batch b of slice t: the fixed-point solve of k_spec_resolve for one batch,
 // the acceptances of batch b - 1 entering through gathered rows of the cross block.
 template <int D>
@@ -422,6 +526,32 @@ __global__ __launch_bounds__(PP_THREADS) void k_pipe_step(ChainView c, PipeBuf p
     const int beE = l + 1, beO = l;
     const int nbE = (beE >= 0 && beE < pb.nbat) ? min(PP_B, c.N - beE * PP_B) : 0;
     const int nbO = (beO >= 0 && beO < pb.nbat) ? min(PP_B, c.N - beO * PP_B) : 0;
+    if (MODEL == DLSM_DIRECTED_CASE_CONTROL) {
+        // four nodes per workgroup round, CC_PARTS wavefronts each (pb.parts == CC_PARTS)
+        static_assert(CC_PARTS * 64 == 2 * PP_B, "a group's wavefronts cover its LDS column");
+        const int wave = threadIdx.x >> 6, sub = wave & (CC_PARTS - 1), grp = wave / CC_PARTS;
+        constexpr int GROUPS = PP_WAVES / CC_PARTS;
+        double *col = pp_sH + grp * (2 * PP_B);
+        const int nodesE = nE * nbE, nodes = nodesE + nO * nbO;
+        for (int base = ((int)blockIdx.x - T) * GROUPS; base < nodes;
+             base += ((int)gridDim.x - T) * GROUPS) {
+            const int q = base + grp;
+            const bool valid = q < nodes;
+            const bool odd = q >= nodesE;
+            const int qq = odd ? q - nodesE : q;
+            const int nb = max(odd ? nbO : nbE, 1);
+            const int k = qq % nb;
+            const int t = 2 * (qq / nb) + (odd ? 1 : 0);
+            const int be = odd ? beO : beE;
+            col[64 * sub + lane] = 0.0;
+            __syncthreads();
+            if (valid) pipe_cc_accumulate<D>(c, pb, be, t, k, sub, lane, col);
+            __syncthreads();
+            if (valid) pipe_cc_writeout<D>(c, pb, be, t, k, sub, lane, col);
+            __syncthreads();
+        }
+        return;
+    }
     const int itemsE = nE * nbE * pb.parts, itemsO = nO * nbO * pb.parts;
     const int nwaves = ((int)gridDim.x - T) * PP_WAVES;
     const int gw = __builtin_amdgcn_readfirstlane(
@@ -434,7 +564,8 @@ __global__ __launch_bounds__(PP_THREADS) void k_pipe_step(ChainView c, PipeBuf p
         const int kq = qq / pb.parts;
         const int k = kq % nb;
         const int t = 2 * (kq / nb) + (odd ? 1 : 0);
-        pipe_eval_item<D, MODEL>(c, pb, odd ? beO : beE, t, k, p, lane);
+        pipe_eval_item<D, MODEL == DLSM_DIRECTED_CASE_CONTROL ? DLSM_DIRECTED : MODEL>(
+            c, pb, odd ? beO : beE, t, k, p, lane);
     }
 }
 

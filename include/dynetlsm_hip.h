@@ -124,8 +124,8 @@ int dlsm_loglik_partial_all(dlsm_chain *h, int with_prior, double *out);
  * slice; updates X and the sampler grid on device.  algo 0 = auto,
  * 1 = one workgroup per slice, 2 = speculative batches over the whole chip,
  * 3 = speculative batches with one launch pair per two 128-node sub-batches,
- * 4 = pipelined speculative batches (exact likelihoods only): one fused launch
- *     resolves batch b and evaluates batch b + 1. */
+ * 4 = pipelined speculative batches: one fused launch resolves batch b and
+ *     evaluates batch b + 1, both parities in the same launches. */
 int dlsm_sweep_positions(dlsm_chain *h, uint32_t iter, int algo);
 /* the algorithm `algo` resolves to for this handle (what 0 = auto picks): 1..4 */
 int dlsm_resolve_sweep_algo(dlsm_chain *h, int algo);

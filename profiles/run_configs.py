@@ -66,6 +66,22 @@ def c4(n_iter=20):
                 it_per_s=round((n_iter - 1) / m.loop_seconds_, 2))
 
 
+def d2(n_iter=40):
+    """not a BASELINE config: the exact directed model at C2's size (radii / intercept MH
+    host driven, sweep on the device), both sweep algorithms"""
+    net = synthetic_lsm_network(10, 2000, 2, density=0.03, seed=0, directed=True)
+    N = 2000
+    radii = np.full(N, 1.0 / N)
+    out = {}
+    for algo in (3, 4):
+        m = da.DynamicNetworkLSM(n_iter=n_iter, tune=None, burn=None, is_directed=True,
+                                 tau_sq=2.0, sigma_sq=0.1, step_size_X=0.0005, random_state=3,
+                                 sweep_algo=algo)
+        m.fit(net['Y'], init=dict(X=net['X_init'] / N, intercept=[1.0, 1.0], radii=radii))
+        out['algo%d_it_per_s' % algo] = round((n_iter - 1) / m.loop_seconds_, 2)
+    return dict(config='directed exact T=10 N=2000, %d it' % n_iter, **out)
+
+
 if __name__ == '__main__':
     which = sys.argv[1:] or ['c1', 'c3', 'c4']
     for w in which:

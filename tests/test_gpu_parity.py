@@ -321,10 +321,11 @@ def test_sweep_speculative_batches(eng, name, T, N, D, prior, algo):
 @pytest.mark.parametrize('prior', ['rw', 'mix'])
 @pytest.mark.parametrize('T,N,C,density', [(4, 300, 20, 0.05), (3, 10, 3, 0.2),
                                            (2, 150, 40, 0.5), (5, 700, 10, 0.02)])
-def test_sweep_speculative_batches_case_control(eng, T, N, C, density, prior):
+@pytest.mark.parametrize('algo', [2, 4])
+def test_sweep_speculative_batches_case_control(eng, T, N, C, density, prior, algo):
     """sparse H: only the batch nodes that sit in a node's edge / control lists
     interact; density 0.5 with 40 controls makes most of a batch interact"""
-    _sweep_case(eng, 'case_control', prior, T=T, N=N, D=2, n_sweeps=3, algo=2,
+    _sweep_case(eng, 'case_control', prior, T=T, N=N, D=2, n_sweeps=3, algo=algo,
                 scale=0.05, cc_C=C, density=density)
 
 
