@@ -368,6 +368,7 @@ int dlsm_set_controls(dlsm_chain *h, const int64_t *ctrl_in, const int64_t *ctrl
     rc = upload_i64_as_i32(h, &h->ctrl_out, ctrl_out, TN * C); if (rc) return rc;
     h->C = C;
     h->have_controls = true;
+    h->nctrl_valid = false;
     return DLSM_OK;
 }
 
@@ -410,6 +411,7 @@ int dlsm_resample_controls(dlsm_chain *h, uint32_t iter, int n_control) {
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->have_controls = true;
+    h->nctrl_valid = false;
     return DLSM_OK;
 }
 
@@ -858,9 +860,13 @@ static int launch_sweep(dlsm_chain *h, IterRef iter, int algo, bool alloc_only =
             h->nctrl = nullptr; h->nctrl_cap = 0;
             HIPCHK(h, hipMalloc((void **)&h->nctrl, TN * 2 * sizeof(int32_t)));
             h->nctrl_cap = TN * 2;
+            h->nctrl_valid = false;
         }
-        hipLaunchKernelGGL(k_count_controls, dim3((unsigned)((TN + 255) / 256)), dim3(256),
-                           0, h->stream, h->ctrl_in, h->ctrl_out, (long)TN, h->C, h->nctrl);
+        if (!h->nctrl_valid) {      // the control lists change only in set / resample
+            hipLaunchKernelGGL(k_count_controls, dim3((unsigned)((TN + 255) / 256)), dim3(256),
+                               0, h->stream, h->ctrl_in, h->ctrl_out, (long)TN, h->C, h->nctrl);
+            h->nctrl_valid = true;
+        }
         algo = resolve_sweep_algo(h, algo);
         if (alloc_only) {
             hipStreamSynchronize(h->stream);

@@ -90,6 +90,7 @@ struct dlsm_chain {
     double *pipe = nullptr; size_t pipe_cap = 0;        // pipelined sweep (algo 4) buffers
     int n_cu = 256;
     int32_t *nctrl = nullptr; size_t nctrl_cap = 0;     // valid controls per (t, i, dir)
+    bool nctrl_valid = false;
     unsigned long long *stamps = nullptr;               // in-kernel timestamps (profiling)
     size_t stamps_cap = 0, stamps_used = 0;             // in [start, end] pairs
     std::vector<std::pair<size_t, size_t>> stamp_launches;   // (first pair, pairs) per launch
