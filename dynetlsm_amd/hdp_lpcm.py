@@ -16,7 +16,6 @@ diagnostics and forecasting.  Missing edges are rejected.
 import time
 
 import numpy as np
-from scipy.stats import dirichlet
 
 from .engine import Chain, SamplerGrid
 from . import hdp_updates as hu
@@ -24,7 +23,8 @@ from . import initialization as init_mod
 from . import posterior as post
 from . import forecast as fc
 from .imputer import SimpleNetworkImputer
-from .lsm import DynamicNetworkLSM, _ScalarMetropolis, check_random_state
+from .lsm import (DynamicNetworkLSM, _ScalarMetropolis, _dirichlet_logpdf,
+                  check_random_state)
 
 __all__ = ['DynamicNetworkHDPLPCM']
 
@@ -299,8 +299,8 @@ class DynamicNetworkHDPLPCM(object):
                     x /= np.sum(x)
                 ll_cur, ll_prop = chain.loglik_full_radii(x)
                 ratio = (ll_prop - ll_cur +
-                         dirichlet.logpdf(radii, rsamp.step_size * x) -
-                         dirichlet.logpdf(x, rsamp.step_size * radii))
+                         _dirichlet_logpdf(radii, rsamp.step_size * x) -
+                         _dirichlet_logpdf(x, rsamp.step_size * radii))
                 accepted = int(not (np.log(rng.rand()) >= ratio))
                 ll = ll_cur
                 if accepted:

@@ -19,7 +19,7 @@ Differences from the reference that a user can see:
 import time
 
 import numpy as np
-from scipy.stats import dirichlet
+from scipy.special import gammaln, xlogy
 
 from .engine import Chain, SamplerGrid
 from . import initialization as init_mod
@@ -71,11 +71,14 @@ class _ScalarMetropolis(object):
 
 def latent_prior_terms(X, tau_sq, sigma_sq):
     """lsm.py:604-613"""
-    lp = -np.sum(0.5 * np.sum(X[0] * X[0], axis=1) / tau_sq)
-    for t in range(1, X.shape[0]):
-        diff = X[t] - X[t - 1]
-        lp -= np.sum(0.5 * np.sum(diff * diff, axis=1) / sigma_sq)
-    return lp
+    diff = X[1:] - X[:-1]
+    return -(0.5 * np.sum(X[0] * X[0]) / tau_sq + 0.5 * np.sum(diff * diff) / sigma_sq)
+
+
+def _dirichlet_logpdf(x, alpha):
+    """scipy.stats.dirichlet.logpdf(x, alpha) without its input checks (the proposal
+    density ratio of metropolis.py:70-76)"""
+    return gammaln(np.sum(alpha)) - np.sum(gammaln(alpha)) + np.sum(xlogy(alpha - 1.0, x))
 
 
 class DynamicNetworkLSM(object):
@@ -305,8 +308,8 @@ class DynamicNetworkLSM(object):
                 x /= np.sum(x)
             ll_cur, ll_prop = chain.loglik_full_radii(x)
             ratio = ll_prop - ll_cur
-            ratio += (dirichlet.logpdf(radii, rsamp.step_size * x) -
-                      dirichlet.logpdf(x, rsamp.step_size * radii))
+            ratio += (_dirichlet_logpdf(radii, rsamp.step_size * x) -
+                      _dirichlet_logpdf(x, rsamp.step_size * radii))
             accepted = int(not (np.log(rng.rand()) >= ratio))
             ll = ll_cur
             if accepted:
