@@ -132,19 +132,19 @@ __device__ __forceinline__ double fast_exp(double x) {
     const double k = rint(x * 1.4426950408889634074);
     double r = fma(k, -6.93147180369123816490e-01, x);
     r = fma(k, -1.90821492927058770002e-10, r);      // |r| <= ln2 / 2
-    // Taylor to r^13: truncation < 4e-18 relative on |r| <= 0.3466
-    double p = 1.6059043836821613e-10;               // 1/13!
-    p = fma(p, r, 2.08767569878681e-09);             // 1/12!
-    p = fma(p, r, 2.505210838544172e-08);            // 1/11!
-    p = fma(p, r, 2.755731922398589e-07);            // 1/10!
-    p = fma(p, r, 2.7557319223985893e-06);           // 1/9!
-    p = fma(p, r, 2.48015873015873e-05);             // 1/8!
-    p = fma(p, r, 1.984126984126984e-04);            // 1/7!
-    p = fma(p, r, 1.388888888888889e-03);            // 1/6!
-    p = fma(p, r, 8.333333333333333e-03);            // 1/5!
-    p = fma(p, r, 4.1666666666666664e-02);           // 1/4!
-    p = fma(p, r, 1.6666666666666666e-01);           // 1/3!
-    p = fma(p, r, 0.5);
+    // degree-11 interpolant of e^r at the Chebyshev nodes of |r| <= ln2 / 2 (computed in
+    // 80-digit arithmetic, rounded to double): max relative error 1.7e-17 in exact
+    // arithmetic, two fma fewer than the Taylor polynomial of the same accuracy
+    double p = 0x1.af631d0059becp-26;
+    p = fma(p, r, 0x1.28b4057f44145p-22);
+    p = fma(p, r, 0x1.71ddf5749d126p-19);
+    p = fma(p, r, 0x1.a01991ac8730ap-16);
+    p = fma(p, r, 0x1.a01a01b14378fp-13);
+    p = fma(p, r, 0x1.6c16c187fbe02p-10);
+    p = fma(p, r, 0x1.111111110f225p-7);
+    p = fma(p, r, 0x1.555555554f0cfp-5);
+    p = fma(p, r, 0x1.555555555555ap-3);
+    p = fma(p, r, 0x1.0000000000011p-1);
     p = fma(p, r, 1.0);
     p = fma(p, r, 1.0);
     return __builtin_ldexp(p, (int)k);
