@@ -116,13 +116,14 @@ __device__ __forceinline__ double dist_of(const double *a, const double *b,
 // Measured on MI355X (profiles/micro/): v_rsq_f64 / v_sqrt_f64 are good to ~2^-25.6 and
 // issue at a quarter of the fma rate; one Goldschmidt iteration + one residual
 // correction already gives the correctly rounded root on 2^20 samples over
-// [2e-9, 2e4] (the compiler's expansion spends a second correction).
+// [2e-9, 2e4], also with the unrefined h = rsq / 2 in the correction (the compiler's
+// expansion refines h and spends a second correction).
 __device__ __forceinline__ double fast_sqrt(double s) {
     const double y = __builtin_amdgcn_rsq(s);
-    double g = s * y, h = 0.5 * y;
+    double g = s * y;
+    const double h = 0.5 * y;             // ~1 / (2 sqrt(s)): good enough for the correction
     const double r = fma(-h, g, 0.5);
     g = fma(g, r, g);
-    h = fma(h, r, h);
     const double e = fma(-g, g, s);
     g = fma(e, h, g);
     return s > 0.0 ? g : 0.0;             // s == 0: rsq = inf

@@ -21,6 +21,15 @@ __device__ double v_rsq1c(double s) {         // + one residual correction
     const double e = fma(-g, g, s);
     return fma(e, h, g);
 }
+__device__ double v_rsq1c_noh(double s) {     // the correction with the unrefined h = y / 2
+    const double y = __builtin_amdgcn_rsq(s);
+    double g = s * y;
+    const double h = 0.5 * y;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    const double e = fma(-g, g, s);
+    return fma(e, h, g);
+}
 __device__ double v_hwc(double s) {           // hardware sqrt + residual correction via rsq
     const double g = __builtin_amdgcn_sqrt(s);
     const double h = 0.5 * __builtin_amdgcn_rsq(s);
@@ -32,7 +41,7 @@ __global__ void k(const double *x, double *y, int n) {
     int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     double s = x[i];
-    y[i] = V == 0 ? v_hw(s) : V == 1 ? v_rsq0(s) : V == 2 ? v_rsq1(s) : V == 3 ? v_rsq1c(s) : v_hwc(s);
+    y[i] = V == 0 ? v_hw(s) : V == 1 ? v_rsq0(s) : V == 2 ? v_rsq1(s) : V == 3 ? v_rsq1c(s) : V == 4 ? v_hwc(s) : v_rsq1c_noh(s);
 }
 int main() {
     const int n = 1 << 20;
@@ -45,14 +54,15 @@ int main() {
     }
     double *dx, *dy; hipMalloc(&dx, n * 8); hipMalloc(&dy, n * 8);
     hipMemcpy(dx, hx.data(), n * 8, hipMemcpyHostToDevice);
-    const char *names[5] = {"v_sqrt_f64", "s*rsq", "rsq + 1 iteration", "rsq + 1 iteration + correction",
-                            "v_sqrt_f64 + correction(rsq)"};
-    for (int v = 0; v < 5; ++v) {
+    const char *names[6] = {"v_sqrt_f64", "s*rsq", "rsq + 1 iteration", "rsq + 1 iteration + correction",
+                            "v_sqrt_f64 + correction(rsq)", "rsq + 1 iteration + correction (h unrefined)"};
+    for (int v = 0; v < 6; ++v) {
         if (v == 0) hipLaunchKernelGGL(k<0>, dim3(n / 256), dim3(256), 0, 0, dx, dy, n);
         if (v == 1) hipLaunchKernelGGL(k<1>, dim3(n / 256), dim3(256), 0, 0, dx, dy, n);
         if (v == 2) hipLaunchKernelGGL(k<2>, dim3(n / 256), dim3(256), 0, 0, dx, dy, n);
         if (v == 3) hipLaunchKernelGGL(k<3>, dim3(n / 256), dim3(256), 0, 0, dx, dy, n);
         if (v == 4) hipLaunchKernelGGL(k<4>, dim3(n / 256), dim3(256), 0, 0, dx, dy, n);
+        if (v == 5) hipLaunchKernelGGL(k<5>, dim3(n / 256), dim3(256), 0, 0, dx, dy, n);
         hipMemcpy(hy.data(), dy, n * 8, hipMemcpyDeviceToHost);
         double maxulp = 0, sum = 0;
         for (int i = 0; i < n; ++i) {
@@ -62,7 +72,7 @@ int main() {
             if (e > maxulp) maxulp = e;
             sum += e;
         }
-        printf("%-34s max %.3g ulp  mean %.3g ulp\n", names[v], maxulp, sum / n);
+        printf("%-46s max %.3g ulp  mean %.3g ulp\n", names[v], maxulp, sum / n);
     }
     return 0;
 }
