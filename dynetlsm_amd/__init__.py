@@ -9,8 +9,10 @@ from .engine import Chain, SamplerGrid, EngineError  # noqa
 from . import network_likelihoods  # noqa
 from .lsm import DynamicNetworkLSM  # noqa
 from .hdp_lpcm import DynamicNetworkHDPLPCM  # noqa
+from .lpcm import DynamicNetworkLPCM  # noqa
 from .case_control import DirectedCaseControlSampler  # noqa
 
 __version__ = '0.1.0'
 __all__ = ['Chain', 'SamplerGrid', 'EngineError', 'network_likelihoods',
-           'DynamicNetworkLSM', 'DynamicNetworkHDPLPCM', 'DirectedCaseControlSampler']
+           'DynamicNetworkLSM', 'DynamicNetworkHDPLPCM', 'DynamicNetworkLPCM',
+           'DirectedCaseControlSampler']

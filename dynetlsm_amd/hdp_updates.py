@@ -147,29 +147,12 @@ class DeviceLabelSums(object):
                                          a=a, b=b)
 
 
-def gibbs_updates(sums, n, nk, mu, sigma, beta, weights, lmbda, hp, rng):
-    """hdp_lpcm.py:880-1023.  ``n`` (T,K,K), ``nk`` (T,K) are the label
-    update's counts; mu, sigma, weights are updated in place; returns
-    (beta, lmbda) and mutates ``hp`` (gamma, alpha_init, alpha, kappa,
-    mean_variance_prior, b).  ``sums`` supplies the label-wise sums over the nodes
-    (:901-954): ``DeviceLabelSums`` in the product; the tests inject the numpy
-    restatement of the oracle to pin the draws on a CPU."""
+def _cluster_updates(sums, nk, mu, sigma, lmbda, hp, rng):
+    """Cluster means, variances, blending coefficient and the two variance hyper-parameters
+    (hdp_lpcm.py:901-972 = lpcm.py:585-668), in the reference's draw order; mu and sigma are
+    updated in place, hp.mean_variance_prior / hp.b are mutated; returns the new lmbda."""
     T, N, D = sums.T, sums.N, sums.D
     K = hp.n_components
-    m = sample_tables(n, beta, hp.alpha_init, hp.alpha, hp.kappa, rng)
-    m_bar, w = sample_mbar(m, beta, hp.kappa, hp.alpha, rng)
-    # global transition distribution (:887)
-    beta = rng.dirichlet((hp.gamma / K) + m_bar)
-    # initial distribution (:890) and transition distributions (:894-898).  A legacy
-    # ``dirichlet`` draw is ``standard_gamma`` per component (index order) times the
-    # inverse of their running sum, so all (t, k) rows come from ONE standard_gamma
-    # call on the row-major stack of their parameters.
-    weights[0, 0] = sample_dirichlet(hp.alpha_init * beta + nk[0], rng)
-    if T > 1:
-        al = (hp.alpha * beta + hp.kappa * np.eye(K))[None, :, :] + n[1:]
-        al = np.where(al <= 0., SMALL_EPS, al)
-        g = rng.standard_gamma(al)
-        weights[1:] = g * (1.0 / np.add.accumulate(g, axis=-1)[..., -1:])
     # cluster means (:901-921)
     lm = float(np.ravel(lmbda)[0])
     S = sums.mean(lm)                                              # (T, K, D)
@@ -208,6 +191,33 @@ def gibbs_updates(sums, n, nk, mu, sigma, beta, weights, lmbda, hp, rng):
         scale = 0.5 * hp.d0 + 0.5 * np.sum(1. / sigma)
         shape = 0.5 * (hp.c0 + K * hp.a)
         hp.b = rng.gamma(shape=shape, scale=1. / scale)
+    return lmbda
+
+
+def gibbs_updates(sums, n, nk, mu, sigma, beta, weights, lmbda, hp, rng):
+    """hdp_lpcm.py:880-1023.  ``n`` (T,K,K), ``nk`` (T,K) are the label
+    update's counts; mu, sigma, weights are updated in place; returns
+    (beta, lmbda) and mutates ``hp`` (gamma, alpha_init, alpha, kappa,
+    mean_variance_prior, b).  ``sums`` supplies the label-wise sums over the nodes
+    (:901-954): ``DeviceLabelSums`` in the product; the tests inject the numpy
+    restatement of the oracle to pin the draws on a CPU."""
+    T, N, D = sums.T, sums.N, sums.D
+    K = hp.n_components
+    m = sample_tables(n, beta, hp.alpha_init, hp.alpha, hp.kappa, rng)
+    m_bar, w = sample_mbar(m, beta, hp.kappa, hp.alpha, rng)
+    # global transition distribution (:887)
+    beta = rng.dirichlet((hp.gamma / K) + m_bar)
+    # initial distribution (:890) and transition distributions (:894-898).  A legacy
+    # ``dirichlet`` draw is ``standard_gamma`` per component (index order) times the
+    # inverse of their running sum, so all (t, k) rows come from ONE standard_gamma
+    # call on the row-major stack of their parameters.
+    weights[0, 0] = sample_dirichlet(hp.alpha_init * beta + nk[0], rng)
+    if T > 1:
+        al = (hp.alpha * beta + hp.kappa * np.eye(K))[None, :, :] + n[1:]
+        al = np.where(al <= 0., SMALL_EPS, al)
+        g = rng.standard_gamma(al)
+        weights[1:] = g * (1.0 / np.add.accumulate(g, axis=-1)[..., -1:])
+    lmbda = _cluster_updates(sums, nk, mu, sigma, lmbda, hp, rng)
     # concentration parameters (:977-1023)
     hp.gamma = sample_concentration_param(hp.gamma, np.sum(m_bar > 0), np.sum(m_bar),
                                           hp.gamma_prior_shape, hp.gamma_prior_rate, rng)
@@ -257,6 +267,56 @@ def log_posterior_terms(sums, intercept, intercept_prior, intercept_variance_pri
     else:
         lp = lp - 0.5 * (diff * diff) / intercept_variance_prior
     lp = lp + np.sum(sums.logp(mu, sigma, np.ravel(lmbda)[0], weights, hp.a, hp.b))
+    lp = lp - 0.5 * np.sum(mu * mu) / hp.mean_variance_prior
+    lp = lp + truncated_normal_logpdf(lmbda, mean=hp.lambda_prior,
+                                      var=hp.lambda_variance_prior)
+    if radii is not None:
+        lp = lp + dirichlet.logpdf(radii, np.ones(N))
+    if hp.a0 is not None:
+        lp = lp + (-(0.5 * hp.a0 + 1) * np.log(hp.mean_variance_prior) -
+                   (0.5 * hp.b0 / hp.mean_variance_prior))
+    if hp.c0 is not None:
+        lp = lp + (hp.c0 - 1) * np.log(hp.b) - hp.d0 * hp.b
+    return lp
+
+
+
+# ---------------------------------------------------------------------------
+# DynamicNetworkLPCM (finite mixture, time-homogeneous label chain; lpcm.py)
+# ---------------------------------------------------------------------------
+def lpcm_gibbs_updates(sums, n, nk, mu, sigma, init_weights, trans_weights, lmbda, hp, rng,
+                       dirichlet_prior):
+    """lpcm.py:572-668: initial / transition distributions, then the cluster updates shared
+    with the HDP-LPCM.  init_weights (K,), trans_weights (K, K), mu, sigma are updated in
+    place; returns lmbda."""
+    K = hp.n_components
+    init_weights[:] = sample_dirichlet(dirichlet_prior + nk[0], rng)
+    # K legacy dirichlet draws = one standard_gamma call on the row-major stack
+    al = dirichlet_prior + n[1:].sum(axis=0)
+    al = np.where(al <= 0., SMALL_EPS, al)
+    g = rng.standard_gamma(al)
+    trans_weights[:] = g * (1.0 / np.add.accumulate(g, axis=-1)[..., -1:])
+    return _cluster_updates(sums, nk, mu, sigma, lmbda, hp, rng)
+
+
+def lpcm_log_posterior_terms(sums, intercept, intercept_prior, intercept_variance_prior, mu,
+                             sigma, init_weights, trans_weights, lmbda, hp, dirichlet_prior,
+                             radii=None):
+    """DynamicNetworkLPCM.logp (lpcm.py:770-856) without the network log-likelihood."""
+    T, N, D = sums.T, sums.N, sums.D
+    K = hp.n_components
+    prior = dirichlet_prior * np.ones(K)
+    lp = _dirichlet_logpdf_rows(init_weights, prior)
+    lp += _dirichlet_logpdf_rows(trans_weights, prior[None, :]).sum()
+    diff = intercept - intercept_prior
+    if radii is not None:
+        lp -= np.sum(0.5 * (diff * diff) / intercept_variance_prior)
+    else:
+        lp = lp - 0.5 * (diff * diff) / intercept_variance_prior
+    w = np.empty((T, K, K))
+    w[:] = trans_weights[None]
+    w[0, 0] = init_weights
+    lp = lp + np.sum(sums.logp(mu, sigma, np.ravel(lmbda)[0], w, hp.a, hp.b))
     lp = lp - 0.5 * np.sum(mu * mu) / hp.mean_variance_prior
     lp = lp + truncated_normal_logpdf(lmbda, mean=hp.lambda_prior,
                                       var=hp.lambda_variance_prior)

@@ -409,6 +409,75 @@ def gen_hdp_trace(ref):
     print('hdp_trace.npz: %d arrays, %d iterations' % (len(out), cap['traces']['Xs'].shape[0]))
 
 
+def gen_lpcm_trace(ref):
+    """DynamicNetworkLPCM._fit (lpcm.py:504-700): state right after the init pipeline, the
+    numpy RNG state at loop entry, the hyper-parameters, and the raw per-iteration traces
+    (snapshotted before the post-loop selection / Procrustes rewrite them); plus the fitted
+    model's selected sample for both selection types."""
+    import dynetlsm.lpcm as lm
+    rng0 = np.random.RandomState(6)
+    T, N, D, K = 3, 24, 2, 4
+    centers = np.array([[-1.5, 0.0], [1.5, 0.0], [0.0, 2.0]])
+    lab = rng0.randint(0, 3, size=N)
+    X = np.zeros((T, N, D))
+    X[0] = centers[lab] + 0.3 * rng0.randn(N, D)
+    for t in range(1, T):
+        X[t] = 0.8 * centers[lab] + 0.2 * X[t - 1] + 0.2 * rng0.randn(N, D)
+    Y = np.zeros((T, N, N))
+    for t in range(T):
+        d = np.sqrt(((X[t][:, None] - X[t][None]) ** 2).sum(-1))
+        A = (rng0.rand(N, N) < 1 / (1 + np.exp(-(1.0 - d)))).astype(np.float64)
+        A = np.triu(A, 1)
+        Y[t] = A + A.T
+    cap = {}
+    orig_fit = lm.DynamicNetworkLPCM._fit
+    orig_co = lm.DynamicNetworkLPCM._calculate_posterior_cooccurrences
+
+    def spy_fit(self, Y_, random_state):
+        cap['rng'] = random_state.get_state()
+        cap['hyper0'] = dict(
+            mean_variance_prior=self.mean_variance_prior_, b=self.b_, a0=self.a0_,
+            b0=self.b0_, c0=self.c0_, d0=self.d0_, a=self.a, step_size_X=self.step_size_X,
+            dirichlet_prior=self.dirichlet_prior_,
+            intercept_prior=np.asarray(self.intercept_prior, dtype=np.float64).copy())
+        return orig_fit(self, Y_, random_state)
+
+    def spy_co(self):
+        cap['traces'] = dict(
+            Xs=self.Xs_.copy(), intercepts=self.intercepts_.copy(), mus=self.mus_.copy(),
+            sigmas=self.sigmas_.copy(), zs=self.zs_.copy(),
+            init_weights=self.init_weights_.copy(), trans_weights=self.trans_weights_.copy(),
+            lambdas=self.lambdas_.copy(), logps=self.logps_.copy())
+        cap['hyper1'] = dict(mean_variance_prior=self.mean_variance_prior_, b=self.b_)
+        return orig_co(self)
+
+    lm.DynamicNetworkLPCM._fit = spy_fit
+    lm.DynamicNetworkLPCM._calculate_posterior_cooccurrences = spy_co
+    out = {'Y': Y}
+    try:
+        for sel in ('map', 'vi'):
+            m = ref.DynamicNetworkLPCM(n_iter=4, tune=3, burn=2, tune_interval=2,
+                                       n_components=K, selection_type=sel,
+                                       random_state=np.random.RandomState(9)).fit(Y)
+            out['sel_%s_id' % sel] = np.array(m.selected_id_)
+            out['sel_%s_z' % sel] = m.z_
+            out['sel_%s_X' % sel] = m.X_
+    finally:
+        lm.DynamicNetworkLPCM._fit = orig_fit
+        lm.DynamicNetworkLPCM._calculate_posterior_cooccurrences = orig_co
+    st = cap['rng']
+    out.update(rng_keys=st[1], rng_pos=np.int64(st[2]), rng_has_gauss=np.int64(st[3]),
+               rng_cached=np.float64(st[4]))
+    for k, v in cap['hyper0'].items():
+        out['h0_' + k] = np.asarray(v, dtype=np.float64)
+    for k, v in cap['hyper1'].items():
+        out['h1_' + k] = np.asarray(v, dtype=np.float64)
+    for k, v in cap['traces'].items():
+        out['tr_' + k] = v
+    np.savez_compressed(os.path.join(HERE, 'lpcm_trace.npz'), **out)
+    print('lpcm_trace.npz: %d arrays, %d iterations' % (len(out), cap['traces']['Xs'].shape[0]))
+
+
 def gen_more_envelopes(ref, Yd):
     """chain-level summaries of the reference for the directed LSM on monks and
     for the HDP-LPCM on a small synthetic network (several seeds each)."""
@@ -441,6 +510,25 @@ def gen_more_envelopes(ref, Yd):
                                      'sigma_mean']))
     np.savez_compressed(os.path.join(HERE, 'more_envelopes.npz'), **out)
     print('more_envelopes.npz')
+
+
+def gen_lpcm_envelopes(ref):
+    """chain-level summaries of the reference's DynamicNetworkLPCM on the small synthetic
+    network of lpcm_trace.npz (several seeds)"""
+    Y = np.load(os.path.join(HERE, 'lpcm_trace.npz'))['Y']
+    rows = []
+    for s in range(5):
+        m = ref.DynamicNetworkLPCM(n_iter=300, tune=150, burn=150, n_components=4,
+                                   selection_type='map', random_state=s).fit(Y)
+        keep = slice(300, None)
+        nclu = np.array([[len(np.unique(z[t])) for t in range(z.shape[0])]
+                         for z in m.zs_[keep]]).mean()
+        rows.append([m.intercepts_[keep, 0].mean(), m.lambdas_[keep, 0].mean(),
+                     nclu, m.sigmas_[keep].mean()])
+    np.savez_compressed(os.path.join(HERE, 'lpcm_envelopes.npz'), summaries=np.array(rows),
+                        columns=np.array(['intercept_mean', 'lambda_mean', 'mean_n_clusters',
+                                          'sigma_mean']))
+    print('lpcm_envelopes.npz')
 
 
 def latent_network(seed, T, N, directed, intercept=1.0, drift=0.1):
@@ -658,6 +746,10 @@ if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'hdp':
         gen_hdp_trace(ref)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'lpcm':
+        gen_lpcm_trace(ref)
+        gen_lpcm_envelopes(ref)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'imputer':
         gen_imputer(ref)
         sys.exit(0)
@@ -684,3 +776,5 @@ if __name__ == '__main__':
     gen_post(ref)
     gen_forecast(ref)
     gen_imputer(ref)
+    gen_lpcm_trace(ref)
+    gen_lpcm_envelopes(ref)

@@ -184,3 +184,59 @@ def test_hdp_lpcm_posterior_within_mc_error_of_reference(eng):
                     m.sigmas_[keep].mean()])
     _compare_to_envelope(env['hdp_summaries'], cols, np.array(got),
                          ['intercept_mean', 'lambda_mean', 'mean_n_clusters'], 0.05)
+
+
+# ------------------------------------------------------------ DynamicNetworkLPCM
+def test_lpcm_smoke_and_selection(eng):
+    Y, _ = _splitting_network()
+    m = eng.DynamicNetworkLPCM(n_iter=60, burn=30, tune=30, n_components=5,
+                               random_state=5).fit(Y)
+    T, N = Y.shape[:2]
+    assert m.X_.shape == (T, N, 2) and m.z_.shape == (T, N)
+    assert m.trans_weights_.shape == (120, 5, 5) and m.init_weights_.shape == (120, 5)
+    assert np.allclose(m.trans_weights_[1:].sum(-1), 1.0)
+    assert np.allclose(m.init_weights_[1:].sum(-1), 1.0)
+    assert np.isfinite(m.logps_).all() and (m.sigmas_[1:] > 0).all()
+    # lpcm.py:724: the argmax over logps_[n_burn:] is used as an index into the full trace
+    assert m.selected_id_ == int(np.argmax(m.logps_[m.n_burn_:]))
+    assert m.cooccurrence_probas_.shape == (T, N, N)
+    vi = eng.DynamicNetworkLPCM(n_iter=40, burn=20, tune=20, n_components=4,
+                                selection_type='vi', random_state=5).fit(Y)
+    assert vi.n_burn_ <= vi.selected_id_ < 80
+    assert vi.expected_vis_.shape == (80 - vi.n_burn_,)
+    assert vi.expected_vis_.argmin() == vi.selected_id_ - vi.n_burn_ or \
+        (vi.expected_vis_ == vi.expected_vis_.min()).sum() > 1
+
+
+def test_lpcm_directed_and_missing(eng):
+    Yd, _ = _splitting_network(n_nodes=16, directed=True)
+    m = eng.DynamicNetworkLPCM(n_iter=20, burn=10, tune=10, n_components=3, is_directed=True,
+                               random_state=1).fit(Yd)
+    assert m.radiis_.shape == (40, 16) and np.isfinite(m.logps_).all()
+    Yu, _ = _splitting_network(n_nodes=16)
+    Ym = Yu.copy()
+    Ym[0, 1, 2] = Ym[0, 2, 1] = -1
+    m = eng.DynamicNetworkLPCM(n_iter=20, burn=10, tune=10, n_components=3,
+                               random_state=1).fit(Ym)
+    assert m.missings_.shape == (1,) and 0 <= m.missings_[0] <= 1
+    assert set(np.unique(m.Y_fit_)) <= {0.0, 1.0}
+
+
+def test_lpcm_posterior_within_mc_error_of_reference(eng):
+    """DynamicNetworkLPCM on the small synthetic network of the LPCM golden trace (T=3, N=24,
+    K=4): posterior means of the intercept, the blending coefficient and the number of
+    occupied clusters against 5 reference seeds"""
+    env = load_golden('lpcm_envelopes.npz')
+    cols = list(env['columns'])
+    Y = load_golden('lpcm_trace.npz')['Y']
+    got = []
+    for seed in range(5):
+        m = eng.DynamicNetworkLPCM(n_iter=300, tune=150, burn=150, n_components=4,
+                                   random_state=seed, chain_id=seed).fit(Y)
+        keep = slice(300, None)
+        nclu = np.array([[len(np.unique(z[t])) for t in range(z.shape[0])]
+                         for z in m.zs_[keep]]).mean()
+        got.append([m.intercepts_[keep, 0].mean(), m.lambdas_[keep, 0].mean(), nclu,
+                    m.sigmas_[keep].mean()])
+    _compare_to_envelope(env['summaries'], cols, np.array(got),
+                         ['intercept_mean', 'lambda_mean', 'mean_n_clusters'], 0.05)
