@@ -10,7 +10,9 @@ import numpy as np
 from .posterior import renormalize_weights
 
 __all__ = ['forecast_probas_map', 'forecast_probas_plugin', 'forecast_probas_marginalized',
-           'forecast_probas', 'forecast_probas_pp', 'mixture_density']
+           'forecast_probas', 'forecast_probas_pp', 'mixture_density',
+           'lpcm_forecast_probas_map', 'lpcm_forecast_probas_plugin',
+           'lpcm_forecast_probas_marginalized', 'lpcm_forecast_probas']
 
 
 def _kept(model):
@@ -127,4 +129,66 @@ def forecast_probas_pp(model, chain, rng=None, batch=512):
                                       mu.shape[0]))
         probas += (chain.forecast_mean_probas(np.stack(Xs), model.intercepts_[chunk].ravel()) *
                    (chunk.shape[0] / float(ids.shape[0])))
+    return probas
+
+
+# ---------------------------------------------------------------------------
+# DynamicNetworkLPCM (lpcm.py:228-318): time-homogeneous transition matrix
+# ---------------------------------------------------------------------------
+def lpcm_forecast_probas_map(model, chain):
+    """lpcm.py:229-239"""
+    ws = model.trans_weight_[model.z_[-1]]
+    lm = np.ravel(model.lambda_)[0]
+    X_ahead = np.zeros((model.X_.shape[1], model.n_features))
+    for g in range(model.n_components):
+        X_ahead += ws[:, g].reshape(-1, 1) * (lm * model.mu_[g] + (1 - lm) * model.X_[-1])
+    return chain.forecast_mean_probas(X_ahead[None], np.ravel(model.intercept_)[:1])
+
+
+def _lpcm_plugin_positions(model, ids):
+    # lpcm.py:250 / :269 read the LAST stored sample's transition matrix for every
+    # sample (``self.trans_weights_[-1][z]``); kept as it is
+    X_hat = np.zeros((model.Xs_.shape[2], model.n_features))
+    for idx in ids:
+        ws = model.trans_weights_[-1][model.zs_[idx, -1]]
+        lm = np.ravel(model.lambdas_[idx])[0]
+        for g in range(model.n_components):
+            X_hat += (1. / ids.shape[0]) * ws[:, g].reshape(-1, 1) * (
+                lm * model.mus_[idx][g] + (1 - lm) * model.Xs_[idx, -1])
+    return X_hat
+
+
+def lpcm_forecast_probas_plugin(model, chain):
+    """lpcm.py:241-257"""
+    X_hat = _lpcm_plugin_positions(model, _kept(model))
+    return chain.forecast_mean_probas(X_hat[None], np.ravel(model.intercepts_mean_)[:1])
+
+
+def lpcm_forecast_probas_marginalized(model, chain):
+    """lpcm.py:259-283: marginal_forecast with the samples' own transition matrices,
+    renormalize=False"""
+    ids = _kept(model)
+    X_hat = _lpcm_plugin_positions(model, ids)
+    W = np.stack([mixture_density(X_hat, model.Xs_[idx, -1],
+                                  model.trans_weights_[idx][model.zs_[idx, -1]],
+                                  np.ravel(model.lambdas_[idx])[0], model.mus_[idx],
+                                  model.sigmas_[idx]) for idx in ids])
+    return chain.forecast_marginal(X_hat, W, model.intercepts_[ids].ravel())
+
+
+def lpcm_forecast_probas(model, chain, n_samples=5000, rng=None, batch=512):
+    """lpcm.py:285-317"""
+    from .lsm import check_random_state
+    rng = check_random_state(model.random_state) if rng is None else rng
+    n_groups = model.mu_.shape[0]
+    lm = np.ravel(model.lambda_)[0]
+    b = np.ravel(model.intercept_)[:1]
+    N = model.X_.shape[1]
+    probas = np.zeros((N, N))
+    for s0 in range(0, n_samples, batch):
+        ns = min(batch, n_samples - s0)
+        Xs = np.stack([_draw_positions(rng, model.z_[-1], model.trans_weight_, model.mu_,
+                                       model.sigma_, lm, model.X_[-1], n_groups)
+                       for _ in range(ns)])
+        probas += chain.forecast_mean_probas(Xs, b, zero_diag=True) * (ns / float(n_samples))
     return probas

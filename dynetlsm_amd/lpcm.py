@@ -15,6 +15,7 @@ import time
 import numpy as np
 
 from .engine import Chain, SamplerGrid
+from . import forecast as fc
 from . import hdp_updates as hu
 from . import initialization as init_mod
 from . import posterior as post
@@ -71,6 +72,30 @@ class DynamicNetworkLPCM(object):
     def n_burn_(self):
         n_burn = (self.burn or 0) + (self.tune or 0)
         return int(np.ceil(n_burn / self.thin)) if self.thin else n_burn      # lpcm.py:189-197
+
+    # -- one-step-ahead forecasts (lpcm.py:228-318; undirected models) ----------------
+    def _forecast_ready(self):
+        if not hasattr(self, 'X_'):
+            raise ValueError('Model not fit.')
+        if self.is_directed:
+            raise ValueError('forecasts are implemented for undirected models '
+                             '(as the reference formulas are)')
+        return self.chain_
+
+    @property
+    def forecast_probas_map_(self):
+        return fc.lpcm_forecast_probas_map(self, self._forecast_ready())
+
+    @property
+    def forecast_probas_plugin_(self):
+        return fc.lpcm_forecast_probas_plugin(self, self._forecast_ready())
+
+    @property
+    def forecast_probas_marginalized_(self):
+        return fc.lpcm_forecast_probas_marginalized(self, self._forecast_ready())
+
+    def forecast_probas(self, n_samples=5000):
+        return fc.lpcm_forecast_probas(self, self._forecast_ready(), n_samples=n_samples)
 
     # ------------------------------------------------------------------ init
     def _init_sampler(self, Y, Y_raw, rng, init):

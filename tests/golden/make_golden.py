@@ -716,6 +716,24 @@ def gen_forecast(ref):
         np.ascontiguousarray(m.weights_[:S, -1]), np.ascontiguousarray(m.mus_[:S]),
         np.ascontiguousarray(m.sigmas_[:S]), m.intercepts_[:S].ravel().copy(),
         m.lambdas_[:S].ravel().copy(), renormalize=False)
+    # the LPCM's forecasts (lpcm.py:228-318): same stored trace, time-homogeneous weights
+    import dynetlsm.lpcm as lm
+    sid = 17
+    ml = SimpleNamespace(
+        Y_fit_=g['u_Y'], zs_=g['u_zs'], Xs_=g['u_Xs'], n_burn_=n_burn, n_components=int(g['u_K']),
+        n_features=2, is_directed=False, intercepts_=g['u_intercepts'], mus_=g['u_mus'],
+        sigmas_=g['u_sigmas'], trans_weights_=np.ascontiguousarray(g['u_weights'][:, 1]),
+        lambdas_=g['u_lambdas'], random_state=11)
+    ml.z_, ml.trans_weight_ = ml.zs_[sid], ml.trans_weights_[sid]
+    ml.mu_, ml.sigma_, ml.lambda_ = ml.mus_[sid], ml.sigmas_[sid], ml.lambdas_[sid]
+    ml.X_, ml.intercept_ = ml.Xs_[sid], ml.intercepts_[sid]
+    ml.intercepts_mean_ = ml.intercepts_[n_burn:].mean(axis=0)
+    lc = lm.DynamicNetworkLPCM
+    out['lpcm_id'] = np.array(sid)
+    out['lpcm_map'] = lc.forecast_probas_map_.fget(ml)
+    out['lpcm_plugin'] = lc.forecast_probas_plugin_.fget(ml)
+    out['lpcm_marginalized'] = lc.forecast_probas_marginalized_.fget(ml)
+    out['lpcm_mc'] = lc.forecast_probas(ml, n_samples=25)
     np.savez_compressed(os.path.join(HERE, 'forecast.npz'), **out)
     print('forecast.npz')
 

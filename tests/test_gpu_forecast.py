@@ -83,6 +83,32 @@ def test_marginal_forecast_matches_cython(eng, model):
                                    g['mf_probas'], rtol=1e-11, atol=1e-15)
 
 
+def test_lpcm_reference_forecasts(eng):
+    """lpcm.py:228-318 (time-homogeneous weights, its own indexing quirks)"""
+    from dynetlsm_amd import forecast as fc
+    g, p = load_golden('forecast.npz'), load_golden('post.npz')
+    sid, n_burn = int(g['lpcm_id']), int(p['u_n_burn'])
+    m = SimpleNamespace(
+        Y_fit_=p['u_Y'], zs_=p['u_zs'], Xs_=p['u_Xs'], n_burn_=n_burn, thin=None,
+        n_components=int(p['u_K']), n_features=2, is_directed=False,
+        intercepts_=p['u_intercepts'], mus_=p['u_mus'], sigmas_=p['u_sigmas'],
+        trans_weights_=np.ascontiguousarray(p['u_weights'][:, 1]), lambdas_=p['u_lambdas'],
+        random_state=11)
+    m.z_, m.trans_weight_ = m.zs_[sid], m.trans_weights_[sid]
+    m.mu_, m.sigma_, m.lambda_ = m.mus_[sid], m.sigmas_[sid], m.lambdas_[sid]
+    m.X_, m.intercept_ = m.Xs_[sid], m.intercepts_[sid]
+    m.intercepts_mean_ = m.intercepts_[n_burn:].mean(axis=0)
+    T, N, _ = m.Y_fit_.shape
+    with eng.Chain(T, N, 2, 'undirected') as c:
+        np.testing.assert_allclose(fc.lpcm_forecast_probas_map(m, c), g['lpcm_map'], rtol=1e-12)
+        np.testing.assert_allclose(fc.lpcm_forecast_probas_plugin(m, c), g['lpcm_plugin'],
+                                   rtol=1e-12)
+        np.testing.assert_allclose(fc.lpcm_forecast_probas_marginalized(m, c),
+                                   g['lpcm_marginalized'], rtol=1e-11, atol=1e-15)
+        np.testing.assert_allclose(fc.lpcm_forecast_probas(m, c, n_samples=25, batch=9),
+                                   g['lpcm_mc'], rtol=1e-12, atol=1e-15)
+
+
 def test_fitted_model_forecasts(eng):
     rng = np.random.RandomState(0)
     T, N = 3, 40
@@ -92,5 +118,11 @@ def test_fitted_model_forecasts(eng):
                                   random_state=2).fit(Y)
     for P in (m.forecast_probas_map_, m.forecast_probas_plugin_, m.forecast_probas_marginalized_,
               m.forecast_probas(n_samples=20), m.forecast_probas_pp_):
+        assert P.shape == (N, N) and np.isfinite(P).all()
+        assert (P >= 0).all() and (P <= 1).all() and np.allclose(P, P.T)
+    ml = eng.DynamicNetworkLPCM(n_iter=30, burn=15, tune=15, n_components=4,
+                                random_state=2).fit(Y)
+    for P in (ml.forecast_probas_map_, ml.forecast_probas_plugin_,
+              ml.forecast_probas_marginalized_, ml.forecast_probas(n_samples=20)):
         assert P.shape == (N, N) and np.isfinite(P).all()
         assert (P >= 0).all() and (P <= 1).all() and np.allclose(P, P.T)
