@@ -11,6 +11,7 @@ from .lsm import DynamicNetworkLSM  # noqa
 from .hdp_lpcm import DynamicNetworkHDPLPCM  # noqa
 from .lpcm import DynamicNetworkLPCM  # noqa
 from .case_control import DirectedCaseControlSampler  # noqa
+from . import metrics  # noqa
 
 __version__ = '0.1.0'
 __all__ = ['Chain', 'SamplerGrid', 'EngineError', 'network_likelihoods',

@@ -23,13 +23,14 @@ from . import initialization as init_mod
 from . import posterior as post
 from . import forecast as fc
 from .imputer import SimpleNetworkImputer
+from .metrics import FittedQuantities
 from .lsm import (DynamicNetworkLSM, _ScalarMetropolis, _dirichlet_logpdf,
                   check_random_state)
 
 __all__ = ['DynamicNetworkHDPLPCM']
 
 
-class DynamicNetworkHDPLPCM(object):
+class DynamicNetworkHDPLPCM(FittedQuantities):
     """Constructor parameters are the reference's (hdp_lpcm.py:385-455) plus
     ``device``, ``chain_id`` and ``sweep_algo``."""
 

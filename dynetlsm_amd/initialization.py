@@ -61,14 +61,6 @@ def initialize_radii(Y, reg=1e-5):
     return radii
 
 
-def _pairwise(X):
-    """pairwise distances of fitted positions (host; the estimators' ``distances_``
-    / ``probas_`` properties, not part of the sampling path)"""
-    sq = (X * X).sum(-1)
-    d2 = sq[:, :, None] + sq[:, None, :] - 2 * np.einsum('tid,tjd->tij', X, X)
-    return np.sqrt(np.maximum(d2, 0.0))
-
-
 def scale_intercept_mle(chain, X, tol=1e-4):
     """Conditional MLE of (log scale, intercept) of the undirected model by BFGS
     (lsm.py:47-70); objective and gradient (lsm.py:32-44) are one fused pass over

@@ -20,13 +20,14 @@ from . import hdp_updates as hu
 from . import initialization as init_mod
 from . import posterior as post
 from .imputer import SimpleNetworkImputer
+from .metrics import FittedQuantities
 from .lsm import (DynamicNetworkLSM, _ScalarMetropolis, _dirichlet_logpdf,
                   check_random_state)
 
 __all__ = ['DynamicNetworkLPCM']
 
 
-class DynamicNetworkLPCM(object):
+class DynamicNetworkLPCM(FittedQuantities):
     """Constructor parameters are the reference's (lpcm.py:135-187) plus ``device``,
     ``chain_id`` and ``sweep_algo``."""
 

@@ -24,6 +24,7 @@ from scipy.special import gammaln, xlogy
 from .engine import Chain, SamplerGrid
 from . import initialization as init_mod
 from .imputer import SimpleNetworkImputer
+from .metrics import FittedQuantities
 
 __all__ = ['DynamicNetworkLSM']
 
@@ -81,7 +82,7 @@ def _dirichlet_logpdf(x, alpha):
     return gammaln(np.sum(alpha)) - np.sum(gammaln(alpha)) + np.sum(xlogy(alpha - 1.0, x))
 
 
-class DynamicNetworkLSM(object):
+class DynamicNetworkLSM(FittedQuantities):
     """Latent space model for dynamic networks (Sewell & Chen) on MI355X.
 
     Constructor parameters are the reference's (lsm.py:234-268) plus
@@ -118,29 +119,6 @@ class DynamicNetworkLSM(object):
     @property
     def n_burn_(self):
         return (self.burn or 0) + (self.tune or 0)
-
-    # -- fitted quantities the reference exposes as properties ---------------
-    @property
-    def distances_(self):
-        if not hasattr(self, 'X_'):
-            raise ValueError('Model not fit.')
-        return init_mod._pairwise(self.X_)
-
-    @property
-    def probas_(self):
-        """Estimated connection probabilities (lsm.py:291-309)."""
-        if not hasattr(self, 'X_'):
-            raise ValueError('Model not fit.')
-        d = self.distances_
-        if self.is_directed:
-            eta = (self.intercept_[0] * (1 - d / self.radii_[None, None, :]) +
-                   self.intercept_[1] * (1 - d / self.radii_[None, :, None]))
-        else:
-            eta = self.intercept_ - d
-        p = 1 / (1 + np.exp(-eta))
-        idx = np.arange(d.shape[1])
-        p[:, idx, idx] = 0.0
-        return p
 
     # -- fit ------------------------------------------------------------------
     def fit(self, Y, init=None):

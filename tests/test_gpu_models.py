@@ -48,6 +48,7 @@ def test_lsm_smoke(eng):
     acc = lsm.latent_samplers.n_steps
     assert (acc == 749).all()
     assert lsm.probas_.shape == (2, 50, 50)
+    assert 0.5 < lsm.auc_ <= 1.0
 
 
 def test_hdp_lpcm_smoke(eng):
