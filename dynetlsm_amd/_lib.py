@@ -27,7 +27,10 @@ class LsmConfig(C.Structure):
                 ('i_n_accepted', C.c_int32 * 2), ('i_n_steps', C.c_int32 * 2),
                 ('i_steps_until_tune', C.c_int32 * 2),
                 ('i_tune', C.c_int32), ('i_tune_interval', C.c_int32),
-                ('n_iter_procrustes', C.c_int32), ('sweep_algo', C.c_int32)]
+                ('n_iter_procrustes', C.c_int32), ('sweep_algo', C.c_int32),
+                ('r_step_size', C.c_double), ('r_n_accepted', C.c_int32),
+                ('r_n_steps', C.c_int32), ('r_steps_until_tune', C.c_int32),
+                ('r_tune', C.c_int32), ('r_tune_interval', C.c_int32), ('r_pad', C.c_int32)]
 
 
 class EngineError(RuntimeError):
@@ -84,6 +87,7 @@ SIGNATURES = {
     'dlsm_lsm_run': (C.c_int, [handle_t, C.c_int, C.c_int, C.c_int]),
     'dlsm_trace_read': (C.c_int, [handle_t, C.c_int, C.c_int, c_double_p, c_double_p,
                                   c_double_p]),
+    'dlsm_trace_read_radii': (C.c_int, [handle_t, C.c_int, C.c_int, c_double_p]),
     'dlsm_init_shortest_paths': (C.c_int, [handle_t]),
     'dlsm_init_get_dissimilarity': (C.c_int, [handle_t, C.c_int, c_double_p]),
     'dlsm_init_smacof': (C.c_int, [handle_t, C.c_int, C.c_int, c_double_p, C.c_int,

@@ -16,6 +16,7 @@
 #include "kernels_hdp.hpp"
 #include "kernels_loglik.hpp"
 #include "kernels_sweep.hpp"
+#include "kernels_dirloop.hpp"
 #include "kernels_spec.hpp"
 #include "kernels_spec_sweep.hpp"
 #include "kernels_spec_pipe.hpp"
@@ -273,7 +274,8 @@ void dlsm_destroy(dlsm_chain *h) {
                     h->radii_alt, h->step, h->nacc, h->nsteps, h->until, h->mu,
                     h->sigma, h->z, h->partials, h->dsmall, h->xref, h->lab_n,
                     h->lab_nk, h->lab_w, h->spec, h->nctrl, h->stamps, h->lsm, h->trace_X, h->trace_ic,
-                    h->trace_logp, h->hops, h->hops_max, h->pipe, h->post_zt, h->post_cooc};
+                    h->trace_logp, h->hops, h->hops_max, h->pipe, h->post_zt, h->post_cooc,
+                    h->trace_radii};
     for (void *p : ptrs) if (p) hipFree(p);
     if (h->hsmall) hipHostFree(h->hsmall);
     if (h->timer0) hipEventDestroy(h->timer0);
@@ -1075,6 +1077,11 @@ int dlsm_lsm_configure(dlsm_chain *h, const dlsm_lsm_config *cfg) {
     s.intercept_var = cfg->intercept_variance_prior;
     s.i_tune = cfg->i_tune < 0 ? -1 : cfg->i_tune;
     s.i_tune_interval = cfg->i_tune_interval;
+    s.r_step = cfg->r_step_size;
+    s.r_nacc = cfg->r_n_accepted; s.r_nsteps = cfg->r_n_steps;
+    s.r_until = cfg->r_steps_until_tune;
+    s.r_tune = cfg->r_tune < 0 ? -1 : cfg->r_tune;
+    s.r_tune_interval = cfg->r_tune_interval > 0 ? cfg->r_tune_interval : 100;
     HIPCHK(h, hipMemcpy(h->lsm, &s, sizeof(s), hipMemcpyHostToDevice));
     h->lsm_cfg = *cfg;
     h->lsm_configured = true;
@@ -1095,6 +1102,9 @@ int dlsm_lsm_get_config(dlsm_chain *h, dlsm_lsm_config *cfg) {
         cfg->i_n_steps[k] = s.i_nsteps[k];
         cfg->i_steps_until_tune[k] = s.i_until[k];
     }
+    cfg->r_step_size = s.r_step;
+    cfg->r_n_accepted = s.r_nacc; cfg->r_n_steps = s.r_nsteps;
+    cfg->r_steps_until_tune = s.r_until;
     return DLSM_OK;
 }
 
@@ -1104,12 +1114,18 @@ int dlsm_trace_alloc(dlsm_chain *h, int n_total, double logp0) {
     NEED(h, h->have_X, "latent positions not set");
     HIPCHK(h, hipSetDevice(h->device));
     const size_t row = (size_t)h->T * h->N * h->D;
-    void *old[] = {h->trace_X, h->trace_ic, h->trace_logp};
+    void *old[] = {h->trace_X, h->trace_ic, h->trace_logp, h->trace_radii};
     for (void *p : old) if (p) hipFree(p);
-    h->trace_X = h->trace_ic = h->trace_logp = nullptr;
+    h->trace_X = h->trace_ic = h->trace_logp = h->trace_radii = nullptr;
     int rc = dev_alloc(h, &h->trace_X, row * n_total); if (rc) return rc;
     rc = dev_alloc(h, &h->trace_ic, (size_t)2 * n_total); if (rc) return rc;
     rc = dev_alloc(h, &h->trace_logp, n_total); if (rc) return rc;
+    if (h->model != DLSM_UNDIRECTED) {
+        NEED(h, h->have_radii, "radii not set");
+        rc = dev_alloc(h, &h->trace_radii, (size_t)h->N * n_total); if (rc) return rc;
+        HIPCHK(h, hipMemcpyAsync(h->trace_radii, h->radii, h->N * sizeof(double),
+                                 hipMemcpyDeviceToDevice, h->stream));
+    }
     h->trace_n = n_total;
     HIPCHK(h, hipMemsetAsync(h->trace_ic, 0, sizeof(double) * 2 * n_total, h->stream));
     HIPCHK(h, hipMemsetAsync(h->trace_logp, 0, sizeof(double) * n_total, h->stream));
@@ -1141,6 +1157,36 @@ static int enqueue_lsm_iteration(dlsm_chain *h, int it, bool counter, int procru
     if (rc) return rc;
     if (alloc_only) return ensure_partials(h, (size_t)ll_blocks(h) * 4);
     int nrec = 0;
+    if (h->model != DLSM_UNDIRECTED) {
+        // intercept_in, intercept_out, radii: propose -> fused two-candidate pass -> accept
+        ChainView v = h->view();
+        double *ll2 = h->dsmall + 16;
+        ProfScope ps(h, DLSM_K_FINALIZE);
+        for (int which = 0; which < 2; ++which) {
+            hipLaunchKernelGGL(k_dir_propose_intercept, dim3(1), dim3(1), 0, h->stream, v, h->lsm,
+                               h->intercept, which, ir);
+            rc = loglik_records(h, 2, h->lsm->cand, h->radii, h->radii, &nrec); if (rc) return rc;
+            hipLaunchKernelGGL(k_reduce_loglik, dim3(1), dim3(256), 0, h->stream, h->partials, nrec,
+                               h->model, 2, h->lsm->cand, ll2);
+            hipLaunchKernelGGL(k_dir_accept_intercept, dim3(1), dim3(1), 0, h->stream, ll2, h->lsm,
+                               h->intercept, which);
+        }
+        hipLaunchKernelGGL(k_dir_propose_radii, dim3(1), dim3(DR_THREADS), 0, h->stream, v, h->lsm,
+                           h->radii, h->radii_alt, ir);
+        // both candidates at the current intercepts: [b | b] from the handle's intercept
+        HIPCHK(h, hipMemcpyAsync(h->dsmall, h->intercept, 2 * sizeof(double),
+                                 hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->dsmall + 2, h->intercept, 2 * sizeof(double),
+                                 hipMemcpyDeviceToDevice, h->stream));
+        rc = loglik_records(h, 2, h->dsmall, h->radii, h->radii_alt, &nrec); if (rc) return rc;
+        hipLaunchKernelGGL(k_reduce_loglik, dim3(1), dim3(256), 0, h->stream, h->partials, nrec,
+                           h->model, 2, h->dsmall, ll2);
+        hipLaunchKernelGGL(k_dir_accept_radii, dim3(1), dim3(DR_THREADS), 0, h->stream, ll2, v,
+                           h->lsm, h->radii, h->radii_alt, h->intercept, h->trace_ic,
+                           h->trace_radii, h->trace_logp, ir);
+        HIPCHK(h, hipGetLastError());
+        return DLSM_OK;
+    }
     rc = loglik_records(h, 2, h->lsm->cand, nullptr, nullptr, &nrec); if (rc) return rc;
     {
         ProfScope ps(h, DLSM_K_FINALIZE);
@@ -1153,8 +1199,8 @@ static int enqueue_lsm_iteration(dlsm_chain *h, int it, bool counter, int procru
 
 int dlsm_lsm_run(dlsm_chain *h, int first, int count, int procrustes_ref) {
     NEED(h, h != nullptr, "null handle");
-    NEED(h, h->model == DLSM_UNDIRECTED, "the device-resident loop covers the undirected model");
     NEED(h, h->lsm_configured && h->trace_X, "configure the chain and allocate the trace first");
+    NEED(h, h->model == DLSM_UNDIRECTED || h->trace_radii, "no radii trace allocated");
     NEED(h, h->prior_kind == DLSM_PRIOR_RANDOM_WALK, "LSM uses the random-walk prior");
     NEED(h, first >= 1 && count >= 0 && first + count <= h->trace_n, "iteration range out of the trace");
     NEED(h, procrustes_ref < h->trace_n, "procrustes_ref out of the trace");
@@ -1166,7 +1212,8 @@ int dlsm_lsm_run(dlsm_chain *h, int first, int count, int procrustes_ref) {
     // frozen in a graph, hence the device-side iteration counter.  On MI355X the GPU is
     // the limit either way (eager 1874 it/s, replay 1840 it/s at C2), so eager is the
     // default; replay is for hosts that cannot spare a core per chain.
-    const bool want_graph = !h->profiling && !h->graph_failed && count >= 2 &&
+    const bool want_graph = h->model == DLSM_UNDIRECTED && !h->profiling && !h->graph_failed &&
+                            count >= 2 &&
                             getenv("DLSM_GRAPH") && atoi(getenv("DLSM_GRAPH")) == 1;
     if (want_graph) {
         if (!h->graph_exec || h->graph_ref != procrustes_ref ||
@@ -1265,6 +1312,17 @@ int dlsm_hdp_label_sums(dlsm_chain *h, int stage, const double *mu, const double
     }
     HIPCHK(h, hipGetLastError());
     return d2h(h, out, d_out, n_out);
+}
+
+int dlsm_trace_read_radii(dlsm_chain *h, int first, int count, double *radii) {
+    NEED(h, h && radii, "null argument");
+    NEED(h, h->trace_radii, "no radii trace (directed models, after dlsm_trace_alloc)");
+    NEED(h, first >= 0 && count >= 0 && first + count <= h->trace_n, "range out of the trace");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(radii, h->trace_radii + (size_t)h->N * first,
+                        sizeof(double) * h->N * count, hipMemcpyDeviceToHost));
+    return DLSM_OK;
 }
 
 // ---------------------------------------------------------------- measurement

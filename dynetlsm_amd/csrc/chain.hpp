@@ -45,6 +45,11 @@ struct LsmDeviceState {
     double logu;                // log-uniform of the intercept accept test
     uint32_t iter;              // iteration counter of the captured-graph path
     uint32_t pad_;
+    // directed loop: radii sampler (Dirichlet proposal), current log-likelihood, proposal
+    // density ratio of the radii step
+    double r_step;
+    int32_t r_nacc, r_nsteps, r_until, r_tune, r_tune_interval, r_pad_;
+    double ll_cur, dir_q;
 };
 
 struct ProfileSlot {
@@ -104,6 +109,7 @@ struct dlsm_chain {
     dlsm_lsm_config lsm_cfg{};
     bool lsm_configured = false;
     double *trace_X = nullptr, *trace_ic = nullptr, *trace_logp = nullptr;
+    double *trace_radii = nullptr;
     int trace_n = 0;
     // one captured Gibbs iteration (hipGraph), replayed by dlsm_lsm_run
     hipGraph_t graph = nullptr; hipGraphExec_t graph_exec = nullptr;

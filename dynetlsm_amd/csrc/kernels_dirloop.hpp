@@ -1,0 +1,180 @@
+// Device-resident iteration of the directed LSM (lsm.py:474-572, directed branch): the two
+// intercept random-walk MH steps (sample_coefficients.py:12-75) and the radii step with its
+// scaled-Dirichlet proposal (metropolis.py:57-82, sample_coefficients.py:91-121), each around
+// one fused two-candidate log-likelihood pass, without a host round trip.
+// Draws: Philox stream INTERCEPT, counter (which, 0 | 1, iter) for the proposal normal / the
+// accept uniform; stream RADII, counter (i, 2 a | 2 a + 1, iter) for attempt a of node i's
+// gamma variate (Marsaglia-Tsang) and (0xFFFFFFFF, 0, iter) for the accept uniform.
+#pragma once
+#include "chain.hpp"
+#include "device_common.hpp"
+
+namespace dlsm {
+
+constexpr uint32_t STREAM_RADII = 5;
+
+// metropolis.py:23-37 (the Dirichlet proposal's concentration is tuned the other way round)
+__device__ __forceinline__ double tune_dirichlet(double step, double rate) {
+    if (rate < 0.001) step *= 10.0;
+    else if (rate < 0.05) step *= 2.0;
+    else if (rate < 0.25) step *= 1.1;
+    else if (rate > 0.95) step *= 0.1;
+    else if (rate > 0.75) step *= 0.5;
+    else if (rate > 0.4) step *= 0.9;
+    return step;
+}
+
+// cand = [proposal pair | current pair] for intercept `which`
+__global__ void k_dir_propose_intercept(ChainView c, LsmDeviceState *lsm,
+                                        const double *__restrict__ intercept, int which,
+                                        IterRef ir) {
+    const uint32_t iter = ir.get();
+    double u0, u1, z0, z1;
+    philox_uniform2(c.seed, (uint32_t)which, 0, iter, stream_word(c.chain, STREAM_INTERCEPT), u0, u1);
+    box_muller(u0, u1, z0, z1);
+    const double b0 = intercept[0], b1 = intercept[1];
+    lsm->cand[0] = which == 0 ? b0 + lsm->i_step[0] * z0 : b0;
+    lsm->cand[1] = which == 1 ? b1 + lsm->i_step[1] * z0 : b1;
+    lsm->cand[2] = b0;
+    lsm->cand[3] = b1;
+    philox_uniform2(c.seed, (uint32_t)which, 1, iter, stream_word(c.chain, STREAM_INTERCEPT), u0, u1);
+    lsm->logu = log(u0);
+}
+
+// ll[0] at the proposal, ll[1] at the current intercepts
+__global__ void k_dir_accept_intercept(const double *__restrict__ ll, LsmDeviceState *lsm,
+                                       double *__restrict__ intercept, int which) {
+    const double prop = lsm->cand[which], cur = lsm->cand[2 + which];
+    const double pm = lsm->intercept_prior[which], v = lsm->intercept_var;
+    const double ratio = (ll[0] - (prop - pm) * (prop - pm) / (2 * v)) -
+                         (ll[1] - (cur - pm) * (cur - pm) / (2 * v));
+    const int accepted = !(lsm->logu >= ratio);
+    if (accepted) intercept[which] = prop;
+    lsm->ll_cur = accepted ? ll[0] : ll[1];
+    double st = lsm->i_step[which];
+    int32_t na = lsm->i_nacc[which], ns = lsm->i_nsteps[which], un = lsm->i_until[which];
+    metropolis_bookkeeping(st, na, ns, un, lsm->i_tune, lsm->i_tune_interval, accepted);
+    lsm->i_step[which] = st; lsm->i_nacc[which] = na; lsm->i_nsteps[which] = ns;
+    lsm->i_until[which] = un;
+}
+
+// Gamma(a, 1) by Marsaglia & Tsang (2000); a < 1 through Gamma(a + 1) U^(1 / a)
+__device__ __forceinline__ double philox_gamma(uint64_t seed, uint32_t chain, uint32_t i,
+                                               uint32_t iter, double a) {
+    const double aa = a < 1.0 ? a + 1.0 : a;
+    const double d = aa - 1.0 / 3.0, cc = 1.0 / sqrt(9.0 * d);
+    double out = 0.0;
+    for (uint32_t att = 0; att < 4096; ++att) {
+        double u0, u1, z0, z1, w0, w1;
+        philox_uniform2(seed, i, 2 * att, iter, stream_word(chain, STREAM_RADII), u0, u1);
+        box_muller(u0, u1, z0, z1);
+        philox_uniform2(seed, i, 2 * att + 1, iter, stream_word(chain, STREAM_RADII), w0, w1);
+        const double t = 1.0 + cc * z0;
+        if (t <= 0.0) continue;
+        const double v = t * t * t;
+        const double x2 = z0 * z0;
+        if (w0 < 1.0 - 0.0331 * x2 * x2 || log(w0) < 0.5 * x2 + d * (1.0 - v + log(v))) {
+            out = d * v;
+            if (a < 1.0) out *= pow(w1, 1.0 / a);
+            break;
+        }
+    }
+    return out;
+}
+
+constexpr int DR_THREADS = 1024;
+
+// x ~ Dirichlet(step * radii) into radii_alt, and the proposal density ratio
+//   dir_q = log Dir(radii | step x) - log Dir(x | step radii)
+__global__ __launch_bounds__(DR_THREADS) void k_dir_propose_radii(
+    ChainView c, LsmDeviceState *lsm, const double *__restrict__ radii,
+    double *__restrict__ radii_alt, IterRef ir) {
+    __shared__ double buf[8][DR_THREADS / 64];
+    __shared__ int sZero;
+    const uint32_t iter = ir.get();
+    const int tid = threadIdx.x, N = c.N;
+    const double step = lsm->r_step;
+    if (tid == 0) sZero = 0;
+    double s = 0.0;
+    for (int i = tid; i < N; i += DR_THREADS) {
+        const double g = philox_gamma(c.seed, c.chain, (uint32_t)i, iter, step * radii[i]);
+        radii_alt[i] = g;
+        s += g;
+    }
+    s = block_sum_all<DR_THREADS / 64>(s, buf[0], tid);
+    const double inv = 1.0 / s;
+    int zero = 0;
+    for (int i = tid; i < N; i += DR_THREADS) {
+        const double x = radii_alt[i] * inv;
+        radii_alt[i] = x;
+        zero |= x == 0.0;
+    }
+    if (zero) sZero = 1;
+    __syncthreads();
+    if (sZero) {                                   // metropolis.py:65-69
+        double s2 = 0.0;
+        for (int i = tid; i < N; i += DR_THREADS) { radii_alt[i] += 1e-5; s2 += radii_alt[i]; }
+        s2 = block_sum_all<DR_THREADS / 64>(s2, buf[1], tid);
+        for (int i = tid; i < N; i += DR_THREADS) radii_alt[i] /= s2;
+    }
+    double A = 0.0, B = 0.0, C = 0.0, E = 0.0, Sx = 0.0, Sr = 0.0;
+    for (int i = tid; i < N; i += DR_THREADS) {
+        const double x = radii_alt[i], r = radii[i];
+        A += lgamma(step * x);
+        B += (step * x - 1.0) * log(r);
+        C += lgamma(step * r);
+        E += (step * r - 1.0) * log(x);
+        Sx += x; Sr += r;
+    }
+    A = block_sum_all<DR_THREADS / 64>(A, buf[2], tid);
+    B = block_sum_all<DR_THREADS / 64>(B, buf[3], tid);
+    C = block_sum_all<DR_THREADS / 64>(C, buf[4], tid);
+    E = block_sum_all<DR_THREADS / 64>(E, buf[5], tid);
+    Sx = block_sum_all<DR_THREADS / 64>(Sx, buf[6], tid);
+    Sr = block_sum_all<DR_THREADS / 64>(Sr, buf[7], tid);
+    if (tid == 0) {
+        lsm->dir_q = (lgamma(step * Sx) - A + B) - (lgamma(step * Sr) - C + E);
+        double u0, u1;
+        philox_uniform2(c.seed, 0xFFFFFFFFu, 0, iter, stream_word(c.chain, STREAM_RADII), u0, u1);
+        lsm->logu = log(u0);
+    }
+}
+
+// ll[0] at the current radii, ll[1] at radii_alt; then the trace row of this iteration
+__global__ __launch_bounds__(DR_THREADS) void k_dir_accept_radii(
+    const double *__restrict__ ll, ChainView c, LsmDeviceState *lsm, double *__restrict__ radii,
+    const double *__restrict__ radii_alt, const double *__restrict__ intercept,
+    double *__restrict__ trace_ic, double *__restrict__ trace_radii,
+    double *__restrict__ trace_logp, IterRef ir) {
+    const int it = (int)ir.get();
+    const int tid = threadIdx.x, N = c.N;
+    const int accepted = !(lsm->logu >= (ll[1] - ll[0]) + lsm->dir_q);
+    double *row = trace_radii + (size_t)it * N;
+    for (int i = tid; i < N; i += DR_THREADS) {
+        const double r = accepted ? radii_alt[i] : radii[i];
+        if (accepted) radii[i] = r;
+        row[i] = r;
+    }
+    if (tid == 0) {
+        const double llf = accepted ? ll[1] : ll[0];
+        double st = lsm->r_step;
+        int32_t na = lsm->r_nacc, ns = lsm->r_nsteps, un = lsm->r_until;
+        na += accepted; ns += 1;
+        if (lsm->r_tune >= 0) {                    // metropolis.py:110-136, Dirichlet rule
+            if (ns < lsm->r_tune && un == 0) {
+                st = tune_dirichlet(st, (double)na / (double)lsm->r_tune_interval);
+                na = 0; un = lsm->r_tune_interval;
+            } else {
+                un -= 1;
+            }
+        }
+        lsm->r_step = st; lsm->r_nacc = na; lsm->r_nsteps = ns; lsm->r_until = un;
+        const double b0 = intercept[0], b1 = intercept[1], v = lsm->intercept_var;
+        const double d0 = b0 - lsm->intercept_prior[0], d1 = b1 - lsm->intercept_prior[1];
+        trace_ic[(size_t)it * 2] = b0;
+        trace_ic[(size_t)it * 2 + 1] = b1;
+        trace_logp[it] = llf + lsm->prior_x - 0.5 * (d0 * d0 + d1 * d1) / v;   // lsm.py:604-623
+    }
+}
+
+}  // namespace dlsm

@@ -315,7 +315,8 @@ class Chain(object):
 
     def lsm_configure(self, intercept_prior, intercept_variance_prior,
                       step_size_intercept=0.1, tune=None, tune_interval=100,
-                      n_iter_procrustes=0, sweep_algo=0, state=None):
+                      n_iter_procrustes=0, sweep_algo=0, state=None, step_size_radii=175000.,
+                      radii_tune=None, radii_tune_interval=100):
         cfg = LsmConfig()
         ip = np.atleast_1d(np.asarray(intercept_prior, dtype=np.float64)).ravel()
         for k in range(2):
@@ -333,6 +334,11 @@ class Chain(object):
         cfg.i_tune_interval = int(tune_interval)
         cfg.n_iter_procrustes = int(n_iter_procrustes)
         cfg.sweep_algo = int(sweep_algo)
+        cfg.r_step_size = float(step_size_radii)
+        cfg.r_n_accepted, cfg.r_n_steps = 0, 0
+        cfg.r_steps_until_tune = int(radii_tune_interval)
+        cfg.r_tune = -1 if radii_tune is None else int(radii_tune)
+        cfg.r_tune_interval = int(radii_tune_interval)
         self._ck(self._L.dlsm_lsm_configure(self._h, C.byref(cfg)))
 
     def lsm_get_config(self):
@@ -358,7 +364,11 @@ class Chain(object):
                                          _p(lps)))
         return Xs, ics[:, :self.n_intercepts], lps
 
-    # -- measurement ---------------------------------------------------------
+    def trace_read_radii(self, first, count):
+        out = np.zeros((count, self.N))
+        self._ck(self._L.dlsm_trace_read_radii(self._h, int(first), int(count), _p(out)))
+        return out
+
     # -- starting values -----------------------------------
     def init_shortest_paths(self):
         self._ck(self._L.dlsm_init_shortest_paths(self._h))

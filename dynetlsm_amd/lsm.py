@@ -94,7 +94,8 @@ class DynamicNetworkLSM(FittedQuantities):
                  intercept_variance_prior=2.0, tau_sq=2.0, sigma_sq=0.1, step_size_X=0.1,
                  step_size_intercept=0.1, step_size_radii=175000, n_control=None,
                  n_resample_control=100, copy=True, random_state=None, device=0,
-                 chain_id=0, sweep_algo=0):
+                 chain_id=0, sweep_algo=0, directed_loop='device'):
+        self.directed_loop = directed_loop
         self.n_iter = n_iter
         self.is_directed = is_directed
         self.n_features = n_features
@@ -207,6 +208,8 @@ class DynamicNetworkLSM(FittedQuantities):
         t_loop = time.perf_counter()
         if not self.is_directed:
             self._fit_undirected(chain, n_total, n_iter_procrustes, logp0, ip)
+        elif self.directed_loop == 'device':
+            self._fit_directed_device(chain, n_total, n_iter_procrustes, logp0, ip)
         else:
             self._fit_directed(chain, rng, X, intercept, radii, n_total, n_iter_procrustes,
                                logp0, ip)
@@ -241,6 +244,54 @@ class DynamicNetworkLSM(FittedQuantities):
         self.intercept_samplers[0].n_accepted = cfg.i_n_accepted[0]
         self.intercept_samplers[0].n_steps = cfg.i_n_steps[0]
         self.intercept_samplers[0].steps_until_tune = cfg.i_steps_until_tune[0]
+
+    def _fit_directed_device(self, chain, n_total, n_iter_procrustes, logp0, ip):
+        """lsm.py:474-572 for the directed models, iterations enqueued on the device
+        (``dlsm_lsm_run``): sweep, Procrustes / centring, the two intercept steps and the radii
+        step with Philox draws.  The host only keeps the cadence of the control resampling
+        (case_control_likelihood.py:27-33) and picks the Procrustes reference (lsm.py:496)."""
+        chain.lsm_configure(ip, self.intercept_variance_prior,
+                            step_size_intercept=self.step_size_intercept, tune=self.tune,
+                            tune_interval=self.tune_interval, n_iter_procrustes=n_iter_procrustes,
+                            sweep_algo=self.sweep_algo, step_size_radii=self.step_size_radii,
+                            radii_tune=None)
+        chain.trace_alloc(n_total, logp0=float(logp0))
+        ccs = self.case_control_sampler_
+        prev_map = -1
+
+        def run(first, last):                     # iterations first .. last
+            it = first
+            while it <= last:
+                if ccs is not None:
+                    ccs.resample(it)
+                    nxt = it + 1                  # next iteration that resamples
+                    while nxt <= last and ccs.n_iter % ccs.n_resample != 0:
+                        ccs.n_iter += 1
+                        nxt += 1
+                    chain.lsm_run(it, nxt - it, procrustes_ref=prev_map)
+                    it = nxt
+                else:
+                    chain.lsm_run(it, last - it + 1, procrustes_ref=prev_map)
+                    it = last + 1
+        first = min(n_iter_procrustes, n_total - 1)
+        if first > 0:
+            run(1, first)
+        if n_total - 1 > first:
+            _, _, lps = chain.trace_read(0, n_iter_procrustes + 1, positions=False)
+            prev_map = int(np.argmax(lps))          # lsm.py:496
+            run(first + 1, n_total - 1)
+        self.Xs_, self.intercepts_, self.logps_ = chain.trace_read(0, n_total)
+        self.radiis_ = chain.trace_read_radii(0, n_total)
+        cfg = chain.lsm_get_config()
+        self.intercept_samplers = []
+        for k in range(2):
+            sm = _ScalarMetropolis(cfg.i_step_size[k], self.tune, self.tune_interval)
+            sm.n_accepted, sm.n_steps = cfg.i_n_accepted[k], cfg.i_n_steps[k]
+            sm.steps_until_tune = cfg.i_steps_until_tune[k]
+            self.intercept_samplers.append(sm)
+        self.radii_sampler = _ScalarMetropolis(cfg.r_step_size, None, dirichlet=True)
+        self.radii_sampler.n_accepted, self.radii_sampler.n_steps = (cfg.r_n_accepted,
+                                                                     cfg.r_n_steps)
 
     def _fit_directed(self, chain, rng, X, intercept, radii, n_total, n_iter_procrustes,
                       logp0, ip):

@@ -167,18 +167,28 @@ typedef struct {
     int32_t i_tune, i_tune_interval;           /* i_tune < 0 == None */
     int32_t n_iter_procrustes;                 /* lsm.py:362-368 */
     int32_t sweep_algo;                        /* as dlsm_sweep_positions */
+    /* directed models: the radii sampler (scaled-Dirichlet proposal, metropolis.py:57-82;
+     * r_tune < 0 == None, as DynamicNetworkLSM sets it) */
+    double r_step_size;
+    int32_t r_n_accepted, r_n_steps, r_steps_until_tune, r_tune, r_tune_interval, r_pad;
 } dlsm_lsm_config;
 int dlsm_lsm_configure(dlsm_chain *h, const dlsm_lsm_config *cfg);
 int dlsm_lsm_get_config(dlsm_chain *h, dlsm_lsm_config *cfg);
 /* device trace buffers Xs_[n_total,T,N,D], intercepts_[n_total,2],
  * logps_[n_total]; row 0 is filled from the current state, logp0 given */
 int dlsm_trace_alloc(dlsm_chain *h, int n_total, double logp0);
-/* enqueue iterations it = first .. first+count-1 (undirected model): sweep,
- * Procrustes to row `procrustes_ref` of the trace if it > n_iter_procrustes,
- * centring, intercept RW-MH fused with the log-posterior trace; asynchronous */
+/* enqueue iterations it = first .. first+count-1: sweep, Procrustes to row
+ * `procrustes_ref` of the trace if it > n_iter_procrustes, centring, then
+ *   undirected: intercept RW-MH fused with the log-posterior trace;
+ *   directed / case-control: intercept_in, intercept_out (sample_coefficients.py:12-75)
+ *   and radii (:91-121) MH steps, each around one fused two-candidate pass, with Philox
+ *   draws (the caller resamples controls between calls at its own cadence).
+ * Asynchronous. */
 int dlsm_lsm_run(dlsm_chain *h, int first, int count, int procrustes_ref);
 int dlsm_trace_read(dlsm_chain *h, int first, int count, double *Xs,
                     double *intercepts, double *logps);
+/* rows first .. first+count-1 of the radii trace (count*N), directed models */
+int dlsm_trace_read_radii(dlsm_chain *h, int first, int count, double *radii);
 
 /* ---- starting values (generalized_mds + conditional MLEs) -- */
 /* shortest_path_dissimilarity (latent_space.py:36-44) of every time slice, from

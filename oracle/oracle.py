@@ -651,3 +651,110 @@ def lsm_reference_loop(Y, X0, intercept0, rng, n_total, n_iter_procrustes,
         if directed:
             rds[it] = radii
     return Xs, ics, rds, logps
+
+
+# --------------------------------------------------------------------------
+# engine-schedule (Philox) iteration of the DIRECTED LSM: what the device loop of
+# dlsm_lsm_run does for model 1 / 2 (lsm.py:474-572 with the engine's draws):
+# sweep (C oracle), Procrustes / centring, intercept_in, intercept_out, radii.
+# --------------------------------------------------------------------------
+STREAM_RADII = 5
+
+
+def _box_muller(u0, u1):
+    r = np.sqrt(-2.0 * np.log(u0))
+    a = 6.283185307179586476925286766559 * u1
+    return r * np.cos(a), r * np.sin(a)
+
+
+def philox_gamma(seed, chain, i, it, a):
+    """Gamma(a, 1) by Marsaglia & Tsang with the engine's counters: attempt k of node i
+    uses counter (i, 2k, it) for the normal and (i, 2k + 1, it) for the uniforms"""
+    aa = a + 1.0 if a < 1.0 else a
+    d = aa - 1.0 / 3.0
+    cc = 1.0 / np.sqrt(9.0 * d)
+    for att in range(4096):
+        u0, u1 = philox_uniform2(seed, i, 2 * att, it, stream_word(chain, STREAM_RADII))
+        z0, _ = _box_muller(float(u0), float(u1))
+        w0, w1 = philox_uniform2(seed, i, 2 * att + 1, it, stream_word(chain, STREAM_RADII))
+        w0, w1 = float(w0), float(w1)
+        t = 1.0 + cc * z0
+        if t <= 0.0:
+            continue
+        v = t * t * t
+        x2 = z0 * z0
+        if w0 < 1.0 - 0.0331 * x2 * x2 or np.log(w0) < 0.5 * x2 + d * (1.0 - v + np.log(v)):
+            out = d * v
+            if a < 1.0:
+                out *= w1 ** (1.0 / a)
+            return out
+    return 0.0
+
+
+def tune_step_size_dirichlet(step_size, acc_rate):
+    """metropolis.py:23-37"""
+    if acc_rate < 0.001:
+        return step_size * 10.0
+    if acc_rate < 0.05:
+        return step_size * 2.0
+    if acc_rate < 0.25:
+        return step_size * 1.1
+    if acc_rate > 0.95:
+        return step_size * 0.1
+    if acc_rate > 0.75:
+        return step_size * 0.5
+    if acc_rate > 0.4:
+        return step_size * 0.9
+    return step_size
+
+
+def lsm_iteration_directed(state, it, loglik, isamp, rsamp, intercept_prior, intercept_var,
+                           X_ref=None):
+    """One iteration on ``state`` (ChainState, model 1 or 2; its X, intercept and radii are
+    updated in place); ``loglik(X, intercept, radii)`` is the model's network log-likelihood;
+    isamp[2], rsamp are ScalarMetropolis objects.  Returns the log-posterior trace value."""
+    from scipy.special import gammaln
+    seed, chain = state.c.seed, state.c.chain
+    state.c.iter = it
+    state.sweep_c()
+    X = state.X
+    if X_ref is not None:
+        X[:] = procrustes_rotation(X_ref, X)[0]
+    X[:] = center(X)
+    b = state.intercept.copy()
+    radii = state.radii
+    v = intercept_var
+    ll = None
+    for k in range(2):
+        u0, u1 = philox_uniform2(seed, k, 0, it, stream_word(chain, STREAM_INTERCEPT))
+        z0, _ = _box_muller(float(u0), float(u1))
+        prop = b.copy()
+        prop[k] = b[k] + isamp[k].step_size * z0
+        ll_prop, ll_cur = loglik(X, prop, radii), loglik(X, b, radii)
+        ratio = ((ll_prop - (prop[k] - intercept_prior[k]) ** 2 / (2 * v)) -
+                 (ll_cur - (b[k] - intercept_prior[k]) ** 2 / (2 * v)))
+        lu, _ = philox_uniform2(seed, k, 1, it, stream_word(chain, STREAM_INTERCEPT))
+        accepted = int(not (np.log(float(lu)) >= ratio))
+        if accepted:
+            b = prop
+        isamp[k].book(accepted)
+    state.c.intercept[0], state.c.intercept[1] = b[0], b[1]
+    N = radii.shape[0]
+    step = rsamp.step_size
+    g = np.array([philox_gamma(seed, chain, i, it, step * radii[i]) for i in range(N)])
+    x = g * (1.0 / g.sum())
+    if np.any(x == 0.):
+        x = x + 1e-5
+        x = x / np.sum(x)
+    q = ((gammaln(step * x.sum()) - gammaln(step * x).sum() + ((step * x - 1) * np.log(radii)).sum()) -
+         (gammaln(step * radii.sum()) - gammaln(step * radii).sum() +
+          ((step * radii - 1) * np.log(x)).sum()))
+    ll_cur, ll_alt = loglik(X, b, radii), loglik(X, b, x)
+    lu, _ = philox_uniform2(seed, 0xFFFFFFFF, 0, it, stream_word(chain, STREAM_RADII))
+    accepted = int(not (np.log(float(lu)) >= (ll_alt - ll_cur) + q))
+    llf = ll_cur
+    if accepted:
+        radii[:] = x
+        llf = ll_alt
+    rsamp.book(accepted, rule=tune_step_size_dirichlet)
+    return llf + lsm_log_prior(X, state.c.tau_sq, state.c.sigma_sq, b, intercept_prior, v)

@@ -45,7 +45,7 @@ def c3(n_iter=30):
                 n_clusters_used=int(len(np.unique(m.z_))))
 
 
-def c4(n_iter=20):
+def c4(n_iter=100):
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     from test_gpu_full_size import _sparse_directed
     T, N = 5, 10000

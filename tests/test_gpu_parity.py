@@ -596,3 +596,74 @@ def test_hdp_host_updates_with_device_sums_reproduce_reference_fit(eng):
                                          2, mus[it], sigmas[it], weights[it], betas[it],
                                          lambdas[it], hp)
         np.testing.assert_allclose(np.ravel(lp)[0], logps[it], rtol=1e-9)
+
+
+# ------------------------------------------------------------ directed device loop
+@pytest.mark.parametrize('name,N,algo', [('directed', 30, 1), ('directed', 300, 4),
+                                         ('case_control', 300, 4), ('case_control', 40, 1)])
+def test_lsm_directed_device_loop_equals_oracle_iterations(eng, name, N, algo):
+    """dlsm_lsm_run for the directed models (sweep, Procrustes / centring, intercept_in,
+    intercept_out, radii with the scaled-Dirichlet proposal) against the oracle's
+    Philox-driven restatement: same decisions, traces equal to rounding"""
+    T, n_total, n_proc = 3, 8, 4
+    X, Yd, _, radii = _rand_net(31 + N, T, N, scale=0.05, density=0.1)
+    b0 = np.array([0.4, 0.7])
+    prior_b, var_b = np.array([0.3, 0.5]), 2.0
+    og = orc.SamplerGrid(T, N, 0.01, tune=6, tune_interval=2)
+    gg = eng.SamplerGrid(T, N, 0.01, tune=6, tune_interval=2)
+    kw = {}
+    if name == 'case_control':
+        cc = _cc_lists(Yd, 8, 5)
+        deg, ie, oe = cc['degree'], cc['in_edges'], cc['out_edges']
+        ci, co = cc['control_nodes_in'], cc['control_nodes_out']
+        kw = dict(case_control=cc)
+
+        def loglik(Xc, b, r):
+            return orc.approx_directed_network_loglikelihood(Xc, r, ie, oe, deg, co, b[0], b[1])
+    else:
+        kw = dict(Y=Yd)
+
+        def loglik(Xc, b, r):
+            return orc.dynamic_network_loglikelihood_directed(Yd, Xc, b[0], b[1], r)
+    st = orc.ChainState(X, og, model=1 if name == 'directed' else 2, intercept=b0,
+                        radii=radii.copy(), tau_sq=1e-3, sigma_sq=1e-4, seed=23, chain=2, **kw)
+    isamp = [orc.ScalarMetropolis(0.1, 6, 2) for _ in range(2)]
+    rsamp = orc.ScalarMetropolis(175000., 5, 2)
+    step_r = 175000.
+    lp0 = loglik(X, b0, radii) + orc.lsm_log_prior(X, 1e-3, 1e-4, b0, prior_b, var_b)
+    want = dict(X=[X.copy()], b=[b0.copy()], r=[radii.copy()], lp=[lp0])
+    for it in range(1, n_total):
+        ref = None
+        if it > n_proc:
+            ref = want['X'][int(np.argmax(want['lp'][:n_proc + 1]))]
+        lp = orc.lsm_iteration_directed(st, it, loglik, isamp, rsamp, prior_b, var_b, X_ref=ref)
+        want['X'].append(st.X.copy()); want['b'].append(st.intercept.copy())
+        want['r'].append(st.radii.copy()); want['lp'].append(lp)
+    with eng.Chain(T, N, 2, name, seed=23, chain_id=2) as c:
+        if name == 'case_control':
+            c.upload_edges(ie, oe, deg)
+            c.set_controls(ci, co)
+        else:
+            c.upload_network(Yd)
+        c.set_positions(X); c.set_intercepts(b0); c.set_radii(radii)
+        c.set_prior_random_walk(1e-3, 1e-4); c.set_samplers(gg)
+        c.lsm_configure(prior_b, var_b, step_size_intercept=0.1, tune=6, tune_interval=2,
+                        n_iter_procrustes=n_proc, sweep_algo=algo, step_size_radii=step_r,
+                        radii_tune=5, radii_tune_interval=2)
+        c.trace_alloc(n_total, logp0=float(lp0))
+        c.lsm_run(1, n_proc)
+        _, _, lps = c.trace_read(0, n_proc + 1, positions=False)
+        c.lsm_run(n_proc + 1, n_total - 1 - n_proc, procrustes_ref=int(np.argmax(lps)))
+        Xs, ics, lps = c.trace_read(0, n_total)
+        rs = c.trace_read_radii(0, n_total)
+        cfg = c.lsm_get_config()
+    np.testing.assert_allclose(Xs, np.array(want['X']), atol=1e-9)
+    np.testing.assert_allclose(ics, np.array(want['b']), atol=1e-12)
+    np.testing.assert_allclose(rs, np.array(want['r']), rtol=1e-10, atol=1e-16)
+    np.testing.assert_allclose(lps, want['lp'], rtol=1e-10)
+    for k in range(2):
+        assert cfg.i_n_steps[k] == isamp[k].n_steps and cfg.i_n_accepted[k] == isamp[k].n_accepted
+        np.testing.assert_allclose(cfg.i_step_size[k], isamp[k].step_size, rtol=1e-14)
+    assert cfg.r_n_steps == rsamp.n_steps and cfg.r_n_accepted == rsamp.n_accepted
+    np.testing.assert_allclose(cfg.r_step_size, rsamp.step_size, rtol=1e-14)
+    assert 0 < sum(s.n_accepted for s in isamp) + rsamp.n_accepted      # something moved
