@@ -528,7 +528,7 @@ __global__ __launch_bounds__(PP_THREADS) void k_pipe_step(ChainView c, PipeBuf p
     const int nbO = (beO >= 0 && beO < pb.nbat) ? min(PP_B, c.N - beO * PP_B) : 0;
     if (MODEL == DLSM_DIRECTED_CASE_CONTROL) {
         // four nodes per workgroup round, CC_PARTS wavefronts each (pb.parts == CC_PARTS)
-        static_assert(CC_PARTS * 64 == 2 * PP_B, "a group's wavefronts cover its LDS column");
+        static_assert(PP_B == 128 && CC_PARTS * 64 == 2 * PP_B, "a group's wavefronts cover its LDS column");
         const int wave = threadIdx.x >> 6, sub = wave & (CC_PARTS - 1), grp = wave / CC_PARTS;
         constexpr int GROUPS = PP_WAVES / CC_PARTS;
         double *col = pp_sH + grp * (2 * PP_B);
@@ -552,18 +552,22 @@ __global__ __launch_bounds__(PP_THREADS) void k_pipe_step(ChainView c, PipeBuf p
         }
         return;
     }
-    const int itemsE = nE * nbE * pb.parts, itemsO = nO * nbO * pb.parts;
+    // items ordered (part, active slice, k) with 128 k-slots per slice, so that an item id
+    // decodes with a shift, a mask and one small quotient (no integer divisions)
+    const int nslE = nbE > 0 ? nE : 0, nslO = nbO > 0 ? nO : 0, nsl = nslE + nslO;
+    const int nitems = pb.parts * nsl * PP_B;
+    const float inv_nsl = 1.0f / (float)max(nsl, 1);
     const int nwaves = ((int)gridDim.x - T) * PP_WAVES;
     const int gw = __builtin_amdgcn_readfirstlane(
         ((int)blockIdx.x - T) * PP_WAVES + (int)(threadIdx.x >> 6));
-    for (int q = gw; q < itemsE + itemsO; q += nwaves) {
-        const bool odd = q >= itemsE;
-        const int qq = odd ? q - itemsE : q;
-        const int nb = odd ? nbO : nbE;
-        const int p = qq % pb.parts;
-        const int kq = qq / pb.parts;
-        const int k = kq % nb;
-        const int t = 2 * (kq / nb) + (odd ? 1 : 0);
+    for (int q = gw; q < nitems; q += nwaves) {
+        const int k = q & (PP_B - 1);
+        const int r = q >> 7;
+        const int p = (int)(((float)r + 0.5f) * inv_nsl);        // r / nsl (r < 2^20)
+        const int si = r - p * nsl;
+        const bool odd = si >= nslE;
+        if (k >= (odd ? nbO : nbE)) continue;
+        const int t = odd ? 2 * (si - nslE) + 1 : 2 * si;
         pipe_eval_item<D, MODEL == DLSM_DIRECTED_CASE_CONTROL ? DLSM_DIRECTED : MODEL>(
             c, pb, odd ? beO : beE, t, k, p, lane);
     }
