@@ -74,10 +74,32 @@ __device__ __forceinline__ void box_muller(double u0, double u1, double &z0,
 }
 
 // ---- reductions ------------------------------------------------------------
+// All-lanes reductions of a 64-wide wavefront without LDS traffic: four DPP steps inside
+// each row of 16 lanes (quad_perm xor 1, xor 2, row_half_mirror, row_mirror: after them
+// every lane holds its row's total), then the four row totals through v_readlane.
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lane_value(double v, int lane) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane),
+                            __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
 __device__ __forceinline__ double wave_sum_all(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+    v += dpp_move<0xB1>(v);        // quad_perm [1, 0, 3, 2]
+    v += dpp_move<0x4E>(v);        // quad_perm [2, 3, 0, 1]
+    v += dpp_move<0x141>(v);       // row_half_mirror
+    v += dpp_move<0x140>(v);       // row_mirror
+    return (lane_value(v, 0) + lane_value(v, 16)) + (lane_value(v, 32) + lane_value(v, 48));
+}
+__device__ __forceinline__ double wave_prod_all(double v) {
+    v *= dpp_move<0xB1>(v);
+    v *= dpp_move<0x4E>(v);
+    v *= dpp_move<0x141>(v);
+    v *= dpp_move<0x140>(v);
+    return (lane_value(v, 0) * lane_value(v, 16)) * (lane_value(v, 32) * lane_value(v, 48));
 }
 
 // Sum over the workgroup, result in every thread.  `buf` holds NW doubles of LDS

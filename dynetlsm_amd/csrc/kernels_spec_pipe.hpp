@@ -193,14 +193,8 @@ __device__ __forceinline__ void pipe_eval_item(const ChainView &c, const PipeBuf
     double tot_l, tot_r;
     if (MODEL == DLSM_UNDIRECTED && nflush >= hi - lo) {
         // the products of the whole wave stay in range: multiply across lanes
-        double l = ra.lin + ra.lg, q0 = ra.P0, q1 = ra.P1;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            l += __shfl_xor(l, off, 64);
-            q0 *= __shfl_xor(q0, off, 64);
-            q1 *= __shfl_xor(q1, off, 64);
-        }
-        tot_l = l; tot_r = q0 / q1;
+        tot_l = wave_sum_all(ra.lin + ra.lg);
+        tot_r = wave_prod_all(ra.P0) / wave_prod_all(ra.P1);
     } else {
         if (MODEL == DLSM_UNDIRECTED) acc = ra.value();
         tot_l = wave_sum_all(acc); tot_r = 1.0;
