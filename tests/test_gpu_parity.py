@@ -301,6 +301,15 @@ def test_sweep_squared_distances(eng):
 def test_sweep_single_time_step(eng):
     _sweep_case(eng, 'undirected', 'rw', T=1, N=20, D=2, n_sweeps=3, algo=1)
     _sweep_case(eng, 'undirected', 'rw', T=1, N=150, D=2, n_sweeps=3, algo=2)
+    _sweep_case(eng, 'undirected', 'rw', T=1, N=300, D=2, n_sweeps=3, algo=4)     # no odd slices
+
+
+def test_sweep_pipelined_many_slices(eng):
+    """more slices than a launch has evaluator wavefronts per node part: parts clamps to 1 and
+    the resolver workgroups outnumber a handful of CUs (nothing in a launch waits on another
+    workgroup, so over-subscription is harmless)"""
+    _sweep_case(eng, 'undirected', 'mix', T=37, N=140, D=2, n_sweeps=2, algo=4)
+    _sweep_case(eng, 'directed', 'rw', T=300, N=130, D=2, n_sweeps=1, algo=4, scale=0.05)
 
 
 @pytest.mark.parametrize('prior', ['rw', 'mix'])
