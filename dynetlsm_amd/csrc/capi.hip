@@ -1171,8 +1171,18 @@ static int enqueue_lsm_iteration(dlsm_chain *h, int it, bool counter, int procru
             hipLaunchKernelGGL(k_dir_accept_intercept, dim3(1), dim3(1), 0, h->stream, ll2, h->lsm,
                                h->intercept, which);
         }
-        hipLaunchKernelGGL(k_dir_propose_radii, dim3(1), dim3(DR_THREADS), 0, h->stream, v, h->lsm,
-                           h->radii, h->radii_alt, ir);
+        {   // scaled-Dirichlet proposal: records live behind the log-likelihood records
+            const int nblk = (h->N + DP_THREADS - 1) / DP_THREADS;
+            rc = ensure_partials(h, (size_t)ll_blocks(h) * 4 + (size_t)nblk * (1 + DP_COLS));
+            if (rc) return rc;
+            double *rec = h->partials + (size_t)ll_blocks(h) * 4, *rec2 = rec + nblk;
+            hipLaunchKernelGGL(k_dir_radii_gamma, dim3(nblk), dim3(DP_THREADS), 0, h->stream, v,
+                               h->lsm, h->radii, h->radii_alt, rec, ir);
+            hipLaunchKernelGGL(k_dir_radii_terms, dim3(nblk), dim3(DP_THREADS), 0, h->stream, v,
+                               h->lsm, h->radii, h->radii_alt, rec, rec2);
+            hipLaunchKernelGGL(k_dir_radii_finish, dim3(1), dim3(DR_THREADS), 0, h->stream, v,
+                               h->lsm, h->radii, h->radii_alt, rec2, nblk, ir);
+        }
         // both candidates at the current intercepts: [b | b] from the handle's intercept
         HIPCHK(h, hipMemcpyAsync(h->dsmall, h->intercept, 2 * sizeof(double),
                                  hipMemcpyDeviceToDevice, h->stream));

@@ -83,59 +83,99 @@ __device__ __forceinline__ double philox_gamma(uint64_t seed, uint32_t chain, ui
 }
 
 constexpr int DR_THREADS = 1024;
+constexpr int DP_THREADS = 256;
+constexpr int DP_COLS = 7;         // A, B, C, E, sum x, sum r, zero flag
 
-// x ~ Dirichlet(step * radii) into radii_alt, and the proposal density ratio
-//   dir_q = log Dir(radii | step x) - log Dir(x | step radii)
-__global__ __launch_bounds__(DR_THREADS) void k_dir_propose_radii(
-    ChainView c, LsmDeviceState *lsm, const double *__restrict__ radii,
-    double *__restrict__ radii_alt, IterRef ir) {
+// x ~ Dirichlet(step * radii) into radii_alt and the proposal density ratio
+//   dir_q = log Dir(radii | step x) - log Dir(x | step radii),
+// in three launches: gamma variates (one node per thread) + per-workgroup sums; normalise +
+// per-workgroup sums of the density terms; one workgroup puts them together (and repairs an
+// exact zero, metropolis.py:65-69, the slow way: it practically never happens).
+__global__ __launch_bounds__(DP_THREADS) void k_dir_radii_gamma(ChainView c,
+                                                                const LsmDeviceState *lsm,
+                                                                const double *__restrict__ radii,
+                                                                double *__restrict__ radii_alt,
+                                                                double *__restrict__ rec,
+                                                                IterRef ir) {
+    __shared__ double buf[DP_THREADS / 64];
+    const int i = blockIdx.x * DP_THREADS + threadIdx.x;
+    double g = 0.0;
+    if (i < c.N) {
+        g = philox_gamma(c.seed, c.chain, (uint32_t)i, ir.get(), lsm->r_step * radii[i]);
+        radii_alt[i] = g;
+    }
+    g = block_sum_all<DP_THREADS / 64>(g, buf, threadIdx.x);
+    if (threadIdx.x == 0) rec[blockIdx.x] = g;
+}
+
+__global__ __launch_bounds__(DP_THREADS) void k_dir_radii_terms(ChainView c,
+                                                                const LsmDeviceState *lsm,
+                                                                const double *__restrict__ radii,
+                                                                double *__restrict__ radii_alt,
+                                                                const double *__restrict__ rec,
+                                                                double *__restrict__ rec2) {
+    __shared__ double buf[DP_COLS][DP_THREADS / 64];
+    const int tid = threadIdx.x, i = blockIdx.x * DP_THREADS + tid;
+    double total = 0.0;
+    for (int q = 0; q < (int)gridDim.x; ++q) total += rec[q];       // same order in every workgroup
+    const double inv = 1.0 / total, step = lsm->r_step;
+    double v[DP_COLS] = {0, 0, 0, 0, 0, 0, 0};
+    if (i < c.N) {
+        const double x = radii_alt[i] * inv, r = radii[i];
+        radii_alt[i] = x;
+        v[0] = lgamma(step * x);
+        v[1] = (step * x - 1.0) * log(r);
+        v[2] = lgamma(step * r);
+        v[3] = (step * r - 1.0) * log(x);
+        v[4] = x; v[5] = r;
+        v[6] = x == 0.0 ? 1.0 : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < DP_COLS; ++q) {
+        const double sres = block_sum_all<DP_THREADS / 64>(v[q], buf[q], tid);
+        if (tid == 0) rec2[(size_t)blockIdx.x * DP_COLS + q] = sres;
+    }
+}
+
+__global__ __launch_bounds__(DR_THREADS) void k_dir_radii_finish(ChainView c, LsmDeviceState *lsm,
+                                                                 const double *__restrict__ radii,
+                                                                 double *__restrict__ radii_alt,
+                                                                 const double *__restrict__ rec2,
+                                                                 int nblk, IterRef ir) {
     __shared__ double buf[8][DR_THREADS / 64];
-    __shared__ int sZero;
-    const uint32_t iter = ir.get();
+    __shared__ double tot[DP_COLS];
     const int tid = threadIdx.x, N = c.N;
     const double step = lsm->r_step;
-    if (tid == 0) sZero = 0;
-    double s = 0.0;
-    for (int i = tid; i < N; i += DR_THREADS) {
-        const double g = philox_gamma(c.seed, c.chain, (uint32_t)i, iter, step * radii[i]);
-        radii_alt[i] = g;
-        s += g;
+    if (tid < DP_COLS) {
+        double sres = 0.0;
+        for (int q = 0; q < nblk; ++q) sres += rec2[(size_t)q * DP_COLS + tid];
+        tot[tid] = sres;
     }
-    s = block_sum_all<DR_THREADS / 64>(s, buf[0], tid);
-    const double inv = 1.0 / s;
-    int zero = 0;
-    for (int i = tid; i < N; i += DR_THREADS) {
-        const double x = radii_alt[i] * inv;
-        radii_alt[i] = x;
-        zero |= x == 0.0;
-    }
-    if (zero) sZero = 1;
     __syncthreads();
-    if (sZero) {                                   // metropolis.py:65-69
+    double A = tot[0], B = tot[1], Cc = tot[2], E = tot[3], Sx = tot[4], Sr = tot[5];
+    if (tot[6] > 0.0) {                            // an exact zero: regularise and redo the sums
         double s2 = 0.0;
         for (int i = tid; i < N; i += DR_THREADS) { radii_alt[i] += 1e-5; s2 += radii_alt[i]; }
-        s2 = block_sum_all<DR_THREADS / 64>(s2, buf[1], tid);
-        for (int i = tid; i < N; i += DR_THREADS) radii_alt[i] /= s2;
+        s2 = block_sum_all<DR_THREADS / 64>(s2, buf[0], tid);
+        A = B = Cc = E = Sx = Sr = 0.0;
+        for (int i = tid; i < N; i += DR_THREADS) {
+            const double x = radii_alt[i] / s2, r = radii[i];
+            radii_alt[i] = x;
+            A += lgamma(step * x); B += (step * x - 1.0) * log(r);
+            Cc += lgamma(step * r); E += (step * r - 1.0) * log(x);
+            Sx += x; Sr += r;
+        }
+        A = block_sum_all<DR_THREADS / 64>(A, buf[1], tid);
+        B = block_sum_all<DR_THREADS / 64>(B, buf[2], tid);
+        Cc = block_sum_all<DR_THREADS / 64>(Cc, buf[3], tid);
+        E = block_sum_all<DR_THREADS / 64>(E, buf[4], tid);
+        Sx = block_sum_all<DR_THREADS / 64>(Sx, buf[5], tid);
+        Sr = block_sum_all<DR_THREADS / 64>(Sr, buf[6], tid);
     }
-    double A = 0.0, B = 0.0, C = 0.0, E = 0.0, Sx = 0.0, Sr = 0.0;
-    for (int i = tid; i < N; i += DR_THREADS) {
-        const double x = radii_alt[i], r = radii[i];
-        A += lgamma(step * x);
-        B += (step * x - 1.0) * log(r);
-        C += lgamma(step * r);
-        E += (step * r - 1.0) * log(x);
-        Sx += x; Sr += r;
-    }
-    A = block_sum_all<DR_THREADS / 64>(A, buf[2], tid);
-    B = block_sum_all<DR_THREADS / 64>(B, buf[3], tid);
-    C = block_sum_all<DR_THREADS / 64>(C, buf[4], tid);
-    E = block_sum_all<DR_THREADS / 64>(E, buf[5], tid);
-    Sx = block_sum_all<DR_THREADS / 64>(Sx, buf[6], tid);
-    Sr = block_sum_all<DR_THREADS / 64>(Sr, buf[7], tid);
     if (tid == 0) {
-        lsm->dir_q = (lgamma(step * Sx) - A + B) - (lgamma(step * Sr) - C + E);
+        lsm->dir_q = (lgamma(step * Sx) - A + B) - (lgamma(step * Sr) - Cc + E);
         double u0, u1;
-        philox_uniform2(c.seed, 0xFFFFFFFFu, 0, iter, stream_word(c.chain, STREAM_RADII), u0, u1);
+        philox_uniform2(c.seed, 0xFFFFFFFFu, 0, ir.get(), stream_word(c.chain, STREAM_RADII), u0, u1);
         lsm->logu = log(u0);
     }
 }

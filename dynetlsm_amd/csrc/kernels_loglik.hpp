@@ -305,17 +305,27 @@ __global__ __launch_bounds__(256) void k_loglik_casecontrol(
             bout[m] = cand.intercepts[2 * m + 1];
             iri[m] = 1.0 / cand.radii[m][i];
         }
+        // sum log(1 + e^eta) = log prod (1 + e^eta): per-lane running products, flushed
+        // through one log before they could leave the double range (eta is clamped at
+        // +-700 for the exp only; a factor is then at most e^700)
+        double Pe[M], Pc[M];
+#pragma unroll
+        for (int m = 0; m < M; ++m) { Pe[m] = 1.0; Pc[m] = 1.0; }
         // out edges : directed_likelihoods_fast.pyx:236-247
         for (int k = lane; k < out_deg; k += 64) {
             const int e = oe[k];
             const double dd = dist_of<D>(&Xt[(size_t)e * D], xi, c.squared);
 #pragma unroll
             for (int m = 0; m < M; ++m) {
-                double eta = bin[m] * (1.0 - dd / cand.radii[m][e]) +
-                             bout[m] * (1.0 - dd * iri[m]);
-                L[m] += eta - log(1.0 + exp(eta));
+                const double eta = bin[m] * (1.0 - dd / cand.radii[m][e]) +
+                                   bout[m] * (1.0 - dd * iri[m]);
+                L[m] += eta;
+                if (Pe[m] > 1e250) { L[m] -= log(Pe[m]); Pe[m] = 1.0; }
+                Pe[m] *= 1.0 + fast_exp(fmin(fmax(eta, -700.0), 700.0));
             }
         }
+#pragma unroll
+        for (int m = 0; m < M; ++m) L[m] -= log(Pe[m]);
         // control estimate : :250-268 (the list is -1 terminated)
         double ctl[M];
 #pragma unroll
@@ -332,14 +342,17 @@ __global__ __launch_bounds__(256) void k_loglik_casecontrol(
                 const double dd = dist_of<D>(&Xt[(size_t)e * D], xi, c.squared);
 #pragma unroll
                 for (int m = 0; m < M; ++m) {
-                    double eta = bin[m] * (1.0 - dd / cand.radii[m][e]) +
-                                 bout[m] * (1.0 - dd * iri[m]);
-                    ctl[m] += log(1.0 + exp(eta));
+                    const double eta = bin[m] * (1.0 - dd / cand.radii[m][e]) +
+                                       bout[m] * (1.0 - dd * iri[m]);
+                    if (Pc[m] > 1e250) { ctl[m] += log(Pc[m]); Pc[m] = 1.0; }
+                    Pc[m] *= 1.0 + fast_exp(fmin(fmax(eta, -700.0), 700.0));
                 }
             }
             nctl += first_bad;
             if (first_bad < 64) break;
         }
+#pragma unroll
+        for (int m = 0; m < M; ++m) ctl[m] += log(Pc[m]);
         const double adj = (double)(c.N - out_deg - 1) / (double)nctl;
 #pragma unroll
         for (int m = 0; m < M; ++m) L[m] -= adj * ctl[m];
