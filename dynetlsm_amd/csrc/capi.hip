@@ -127,7 +127,7 @@ int ensure_partials(dlsm_chain *h, size_t n) {
 
 int ll_blocks(const dlsm_chain *h) {
     if (h->model == DLSM_DIRECTED_CASE_CONTROL)
-        return (int)(((long)h->T * h->N + 3) / 4);
+        return (int)(((long)h->T * h->N + LLCC_NODES - 1) / LLCC_NODES);
     int nt = (h->N + LL_TILE - 1) / LL_TILE;
     return h->T * (nt * (nt + 1) / 2);
 }

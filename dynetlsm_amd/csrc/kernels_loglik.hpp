@@ -280,15 +280,20 @@ __global__ __launch_bounds__(LL_THREADS) void k_loglik_directed(
 // the node's out-edges and out-controls (gathers of X / radii through L2).
 // Record per workgroup: [L_0 .. L_{M-1}]
 // ---------------------------------------------------------------------------
+constexpr int LLCC_NODES = 16;
+
 template <int D, int M>
 __global__ __launch_bounds__(256) void k_loglik_casecontrol(
     ChainView c, LoglikCand cand, double *__restrict__ partials) {
     __shared__ double sRed[4 * M];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const long node = (long)blockIdx.x * 4 + wave;       // over T*N
+    // LLCC_NODES nodes per workgroup (4 waves x LLCC_NODES / 4 in turn): fewer records for
+    // the single-workgroup reduction that follows
     double L[M];
 #pragma unroll
     for (int m = 0; m < M; ++m) L[m] = 0.0;
+    for (int rep = 0; rep < LLCC_NODES / 4; ++rep) {
+    const long node = ((long)blockIdx.x * (LLCC_NODES / 4) + rep) * 4 + wave;       // over T*N
     if (node < (long)c.T * c.N) {
         const int t = (int)(node / c.N), i = (int)(node % c.N);
         const double *Xt = c.X + (size_t)t * c.N * D;
@@ -356,6 +361,7 @@ __global__ __launch_bounds__(256) void k_loglik_casecontrol(
         const double adj = (double)(c.N - out_deg - 1) / (double)nctl;
 #pragma unroll
         for (int m = 0; m < M; ++m) L[m] -= adj * ctl[m];
+    }
     }
 #pragma unroll
     for (int m = 0; m < M; ++m) {
