@@ -104,6 +104,8 @@ SIGNATURES = {
                                             c_double_p]),
     'dlsm_forecast_marginal': (C.c_int, [handle_t, c_double_p, c_double_p, c_double_p, C.c_int,
                                          c_double_p]),
+    'dlsm_host_sample_tables': (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_double_p, c_double_p,
+                                          C.c_double, C.c_double, C.c_double, c_i64_p]),
     'dlsm_profile_enable': (C.c_int, [handle_t, C.c_int]),
     'dlsm_profile_read': (C.c_int, [handle_t, C.c_int, c_double_p, C.POINTER(C.c_int)]),
     'dlsm_profile_read_eval_stamps': (C.c_int, [handle_t, c_double_p, C.POINTER(C.c_int)]),

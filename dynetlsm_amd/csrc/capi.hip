@@ -23,6 +23,7 @@
 #include "kernels_init.hpp"
 #include "kernels_post.hpp"
 #include "kernels_forecast.hpp"
+#include "host_draws.hpp"
 
 using namespace dlsm;
 
@@ -511,12 +512,14 @@ int dlsm_set_prior_random_walk(dlsm_chain *h, double tau_sq, double sigma_sq) {
 
 int dlsm_set_prior_mixture(dlsm_chain *h, const double *mu, const double *sigma,
                            double lmbda, const int64_t *z, int K) {
-    NEED(h, h && mu && sigma && z, "null argument");
+    NEED(h, h && mu && sigma, "null argument");
     drop_graph(h);
     NEED(h, K >= 1 && K <= 64, "n_components must be in 1..64");
+    NEED(h, z || (h->have_prior && h->prior_kind == DLSM_PRIOR_MIXTURE && h->K == K),
+         "z = NULL keeps the device's labels: none are there for this n_components");
     HIPCHK(h, hipSetDevice(h->device));
     const size_t TN = (size_t)h->T * h->N;
-    for (size_t i = 0; i < TN; ++i)
+    for (size_t i = 0; z && i < TN; ++i)
         if (z[i] < 0 || z[i] >= K) FAIL(h, DLSM_E_DATA, "label out of range at %zu", i);
     if (h->K != K) {
         if (h->mu) hipFree(h->mu);
@@ -528,9 +531,11 @@ int dlsm_set_prior_mixture(dlsm_chain *h, const double *mu, const double *sigma,
     }
     int rc = h2d(h, h->mu, mu, (size_t)K * h->D); if (rc) return rc;
     rc = h2d(h, h->sigma, sigma, K); if (rc) return rc;
-    std::vector<int32_t> zz(TN);
-    for (size_t i = 0; i < TN; ++i) zz[i] = (int32_t)z[i];
-    rc = h2d(h, h->z, zz.data(), TN); if (rc) return rc;
+    if (z) {
+        std::vector<int32_t> zz(TN);
+        for (size_t i = 0; i < TN; ++i) zz[i] = (int32_t)z[i];
+        rc = h2d(h, h->z, zz.data(), TN); if (rc) return rc;
+    }
     h->lmbda = lmbda;
     h->prior_kind = DLSM_PRIOR_MIXTURE;
     h->have_prior = true;
@@ -1030,22 +1035,26 @@ int dlsm_sample_labels(dlsm_chain *h, uint32_t iter, const double *w, int64_t *z
         rc = dev_alloc(h, &h->lab_nk, nnk); if (rc) return rc;
         rc = dev_alloc(h, &h->lab_w, nn); if (rc) return rc;
     }
-    const size_t lds = (size_t)LAB_WAVES * 3 * T * K * sizeof(double);
-    if (lds > 160 * 1024) FAIL(h, DLSM_E_LIMIT, "T*K=%d too large for the label kernel", T * K);
+    const size_t lds_tables = (size_t)LAB_WAVES * 2 * T * K * sizeof(double);
+    const size_t lds_w = (size_t)T * K * lab_row_pad(K) * sizeof(double);
+    if (lds_tables > 160 * 1024)
+        FAIL(h, DLSM_E_LIMIT, "T*K=%d too large for the label kernel", T * K);
+    const bool w_lds = lds_tables + lds_w <= 80 * 1024;     // two workgroups per CU
+    const size_t lds = lds_tables + (w_lds ? lds_w : 0);
     HIPCHK(h, hipMemcpyAsync(h->lab_w, w, nn * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemsetAsync(h->lab_n, 0, nn * sizeof(int32_t), h->stream));
-    HIPCHK(h, hipMemsetAsync(h->lab_nk, 0, nnk * sizeof(int32_t), h->stream));
     ChainView v = h->view();
     {
         ProfScope ps(h, DLSM_K_LABELS);
         DISPATCH_D(h, h->D, {
-            auto kern = k_sample_labels<DD>;
+            auto kern = w_lds ? k_sample_labels<DD, true> : k_sample_labels<DD, false>;
             HIPCHK(h, hipFuncSetAttribute((const void *)kern,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(kern, dim3((N + LAB_WAVES - 1) / LAB_WAVES),
-                               dim3(64 * LAB_WAVES), lds, h->stream, v, h->lab_w, iter,
-                               h->z, h->lab_n, h->lab_nk);
+                               dim3(64 * LAB_WAVES), lds, h->stream, v, h->lab_w, iter, h->z);
         });
+        hipLaunchKernelGGL(k_label_counts, dim3(T), dim3(256),
+                           (size_t)(K * K + K) * sizeof(int32_t), h->stream, h->z, N, K,
+                           (int32_t *)h->lab_n, (int32_t *)h->lab_nk);
     }
     HIPCHK(h, hipGetLastError());
     std::vector<int32_t> zz((size_t)T * N), cn(nn), cnk(nnk);
@@ -1416,3 +1425,11 @@ int dlsm_timer_stop(dlsm_chain *h, double *ms) {
 #include "capi_init.hpp"
 #include "capi_post.hpp"
 #include "capi_forecast.hpp"
+
+extern "C" int dlsm_host_sample_tables(void *numpy_bitgen, int T, int K, const double *n,
+                                       const double *beta, double alpha_init, double alpha,
+                                       double kappa, int64_t *m) {
+    if (!numpy_bitgen || !n || !beta || !m || T < 1 || K < 1) return -1;
+    return dlsm::host_sample_tables((dlsm::NumpyBitGen *)numpy_bitgen, T, K, n, beta, alpha_init,
+                                    alpha, kappa, m);
+}

@@ -52,76 +52,106 @@ __global__ __launch_bounds__(64) void k_gauss_table(ChainView c, int node,
     }
 }
 
-// a12: sample_labels.py:134-190.  Dynamic LDS: per wave 3*T*K doubles
-// (likelihood, backward message, partial marginal).  Sums that decide a draw
-// run in the reference's index order so that the oracle (same Philox uniform)
-// gets the same label.
-constexpr int LAB_WAVES = 4;
+// a12: sample_labels.py:134-190.  Dynamic LDS: the T transition matrices (rows padded
+// to an odd length, shared by the workgroup; WLDS = false reads them from global memory
+// when they do not fit) and per wave 2*T*K doubles (likelihood, partial marginal).  Sums that decide a draw run in the reference's index order so that the
+// oracle (same Philox uniform) gets the same label.
+constexpr int LAB_WAVES = 8;
 
-template <int D>
+__host__ __device__ inline int lab_row_pad(int K) { return K | 1; }
+
+template <int D, bool WLDS>
 __global__ __launch_bounds__(64 * LAB_WAVES) void k_sample_labels(
     ChainView c, const double *__restrict__ w, uint32_t iter,
-    int32_t *__restrict__ z_out, int32_t *__restrict__ n_cnt,
-    int32_t *__restrict__ nk_cnt) {
+    int32_t *__restrict__ z_out) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int T = c.T, K = c.K, N = c.N;
+    const int KP = WLDS ? lab_row_pad(K) : K;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = blockIdx.x * LAB_WAVES + wave;
-    double *L = smem + (size_t)wave * 3 * T * K;
-    double *bm = L + T * K;
-    double *pm = bm + T * K;
-    if (i >= N) return;                       // whole wave leaves together
-    for (int t = 0; t < T; ++t)
-        if (lane < K) L[t * K + lane] = exp(gauss_loglik_tk<D>(c, t, i, lane));
-    if (lane < K) bm[(T - 1) * K + lane] = 1.0;
-    __builtin_amdgcn_wave_barrier();
-    // backward messages :164-170
-    for (int t = T - 1; t > 0; --t) {
-        if (lane < K) pm[t * K + lane] = L[t * K + lane] * bm[t * K + lane];
-        __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): LDS writes landed
-        __builtin_amdgcn_wave_barrier();
-        double s = 0.0;
-        if (lane < K) {
-            const double *wr = w + ((size_t)t * K + lane) * K;
-            for (int k = 0; k < K; ++k) s += wr[k] * pm[t * K + k];
-            bm[(t - 1) * K + lane] = s;
+    const double *wt = w;                     // row (t, j) at wt + (t K + j) KP
+    double *tables = smem;
+    if (WLDS) {
+        for (int q = threadIdx.x; q < T * K * K; q += 64 * LAB_WAVES) {
+            const int r = q / K;
+            smem[(size_t)r * KP + (q - r * K)] = w[q];
         }
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_wave_barrier();
-        double tot = 0.0;
-        for (int r = 0; r < K; ++r) tot += bm[(t - 1) * K + r];
-        __builtin_amdgcn_wave_barrier();
-        if (lane < K) bm[(t - 1) * K + lane] = s / tot;
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_wave_barrier();
+        wt = smem;
+        tables = smem + (size_t)T * K * KP;
     }
-    if (lane < K) pm[lane] = L[lane] * bm[lane];
-    __builtin_amdgcn_s_waitcnt(0xc07f);
+    double *L = tables + (size_t)wave * 2 * T * K;
+    double *pm = L + T * K;
+    const bool live = i < N;                  // a whole wave is live or not
+    if (live)                                 // the T x K table, 64 entries at a time
+        for (int q = lane; q < T * K; q += 64) {
+            const int t = q / K;
+            L[q] = exp(gauss_loglik_tk<D>(c, t, i, q - t * K));
+        }
+    __syncthreads();
+    if (!live) return;
+    // the uniform of time t is drawn by lane t (T <= 64 per pass), all times at once
+    double u_all = 0.0;
+    // Lane k owns component k.  The sums over the components run in index order (as the
+    // reference's do) with the k-th term fetched from lane k's register, not through LDS.
+    // backward messages :164-170
+    double bmk = 1.0;                         // message of component `lane` at time t
+    for (int t = T - 1; t > 0; --t) {
+        const double pmk = lane < K ? L[t * K + lane] * bmk : 0.0;
+        if (lane < K) pm[t * K + lane] = pmk;          // the forward pass needs it again
+        double s = 0.0;
+        const double *wr = wt + ((size_t)t * K + min(lane, K - 1)) * KP;
+#pragma unroll 4
+        for (int k = 0; k < K; ++k) s += wr[k] * lane_value(pmk, k);
+        double tot = 0.0;
+        for (int r = 0; r < K; ++r) tot += lane_value(s, r);
+        bmk = s / tot;
+    }
+    if (lane < K) pm[lane] = L[lane] * bmk;
+    __builtin_amdgcn_s_waitcnt(0xc07f);       // lgkmcnt(0): LDS writes landed
     __builtin_amdgcn_wave_barrier();
-    // forward sampling :173-188 (every lane walks the cdf; lane 0 records)
+    // forward sampling :173-188: the cumulative sum runs in index order and lane k keeps its
+    // k-th value; the label is the number of cumulative values below u * total
     int zprev = 0;
     for (int t = 0; t < T; ++t) {
-        const double *wrow = t == 0 ? w : w + ((size_t)t * K + zprev) * K;
-        double u0, u1;
-        philox_uniform2(c.seed, (uint32_t)i, (uint32_t)t, iter,
-                        stream_word(c.chain, STREAM_LABELS), u0, u1);
-        double total = 0.0;
-        for (int k = 0; k < K; ++k) total += wrow[k] * pm[t * K + k];
-        const double u = u0 * total;
-        double cdf = 0.0;
-        int zt = 0;
+        const double *wrow = wt + (t == 0 ? (size_t)0 : ((size_t)t * K + zprev) * KP);
+        if ((t & 63) == 0) {
+            double u1;
+            philox_uniform2(c.seed, (uint32_t)i, (uint32_t)(t + lane), iter,
+                            stream_word(c.chain, STREAM_LABELS), u_all, u1);
+        }
+        const double u0 = lane_value(u_all, t & 63);
+        const double term = lane < K ? wrow[lane] * pm[t * K + lane] : 0.0;
+        double cdf = 0.0, mine = 0.0;
         for (int k = 0; k < K; ++k) {
-            cdf += wrow[k] * pm[t * K + k];
-            zt += (u > cdf);
+            cdf += lane_value(term, k);
+            mine = k == lane ? cdf : mine;
         }
-        if (lane == 0) {
-            z_out[(size_t)t * N + i] = zt;
-            if (t == 0) atomicAdd(&n_cnt[zt], 1);
-            else atomicAdd(&n_cnt[((size_t)t * K + zprev) * K + zt], 1);
-            atomicAdd(&nk_cnt[t * K + zt], 1);
-        }
+        const double u = u0 * cdf;
+        const int zt = __popcll(__ballot(lane < K && u > mine));
+        if (lane == 0) z_out[(size_t)t * N + i] = zt;
         zprev = zt;
     }
+}
+
+// The counts the conjugate updates need (sample_labels.py:176-188): n[0][0][k] initial labels,
+// n[t][j][k] transitions j -> k into time t, nk[t][k] labels in use.  One workgroup per time
+// step, histogram in LDS (same-address global atomics from 2000 wavefronts cost ~170 ns each).
+__global__ __launch_bounds__(256) void k_label_counts(const int32_t *__restrict__ z, int N, int K,
+                                                      int32_t *__restrict__ n_cnt,
+                                                      int32_t *__restrict__ nk_cnt) {
+    extern __shared__ int32_t hist[];         // K * K + K
+    const int t = blockIdx.x;
+    for (int q = threadIdx.x; q < K * K + K; q += 256) hist[q] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < N; i += 256) {
+        const int zt = z[(size_t)t * N + i];
+        const int zp = t == 0 ? 0 : z[(size_t)(t - 1) * N + i];
+        atomicAdd(&hist[zp * K + zt], 1);
+        atomicAdd(&hist[K * K + zt], 1);
+    }
+    __syncthreads();
+    for (int q = threadIdx.x; q < K * K; q += 256) n_cnt[(size_t)t * K * K + q] = hist[q];
+    for (int q = threadIdx.x; q < K; q += 256) nk_cnt[t * K + q] = hist[K * K + q];
 }
 
 }  // namespace dlsm

@@ -219,12 +219,14 @@ class Chain(object):
                                                     float(sigma_sq)))
 
     def set_prior_mixture(self, mu, sigma, lmbda, z):
+        """``z=None`` keeps the labels the device already holds (those of the last
+        ``sample_labels`` or ``set_prior_mixture``)."""
         sigma = _f64(sigma)
         K = sigma.shape[0]
         mu = _f64(mu, (K, self.D), 'mu')
-        z = _i64(z, (self.T, self.N), 'z')
+        zp = None if z is None else _p(_i64(z, (self.T, self.N), 'z'))
         lm = float(np.asarray(lmbda).ravel()[0])
-        self._ck(self._L.dlsm_set_prior_mixture(self._h, _p(mu), _p(sigma), lm, _p(z), K))
+        self._ck(self._L.dlsm_set_prior_mixture(self._h, _p(mu), _p(sigma), lm, zp, K))
         self.K = K
 
     # -- kernels -----------------------------------------------------------

@@ -277,7 +277,7 @@ class DynamicNetworkHDPLPCM(FittedQuantities):
         for it in range(1, n_total):
             if self.case_control_sampler_ is not None:
                 self.case_control_sampler_.resample(it)
-            chain.set_prior_mixture(mu, sigma, lmbda, z)
+            chain.set_prior_mixture(mu, sigma, lmbda, None)      # z: the device keeps its own
             chain.sweep_positions(it, self.sweep_algo)
             chain.center()
             # intercepts (sample_coefficients.py:12-88), fused two-candidate passes

@@ -6,12 +6,20 @@ the label block update (hdp_lpcm.py:880-1023) and the log-posterior trace
 These are not kernels ("host-side, restated in the build's own
 Python"): small numpy updates driven by a numpy ``RandomState``.  They follow
 the reference's draw order call for call, which tests/test_hdp_host_updates.py
-pins against a trace recorded from the reference.
+pins against a trace recorded from the reference.  The one draw whose count grows
+with N T (the table counts) is made by the engine's native host helper from the same
+RandomState.
 """
+import math
+
 import numpy as np
-from scipy.stats import truncnorm, dirichlet
+from scipy.special import log_ndtr, ndtr, ndtri_exp
+from scipy.stats import dirichlet
+
+from . import _lib
 
 SMALL_EPS = np.finfo('float64').tiny
+_HALF_LOG_2PI = 0.5 * math.log(2.0 * math.pi)
 
 __all__ = ['HDPHyper', 'sample_tables', 'sample_mbar', 'sample_concentration_param',
            'sample_dirichlet', 'gibbs_updates', 'log_posterior_terms']
@@ -52,48 +60,68 @@ def dirichlet_logpdf(x, alphas):
     return dirichlet.logpdf(x, alphas)
 
 
+def _log_gauss_mass(a, b):
+    """log of the standard normal mass of [a, b], computed in the left tail"""
+    if b <= 0:
+        la, lb = log_ndtr(a), log_ndtr(b)
+        return lb + math.log1p(-math.exp(la - lb))
+    if a > 0:
+        return _log_gauss_mass(-b, -a)
+    return math.log1p(-ndtr(a) - ndtr(-b))
+
+
+def _truncnorm_bounds(mean, var, lower, upper):
+    std = math.sqrt(float(np.ravel(var)[0]))
+    mean = float(np.ravel(mean)[0])
+    return mean, std, (lower - mean) / std, (upper - mean) / std
+
+
 def truncated_normal(mean, var, rng, lower=0, upper=1):
-    """distributions.py:68-73"""
-    std = np.sqrt(var)
-    a = (lower - mean) / std
-    b = (upper - mean) / std
-    return truncnorm.rvs(a, b, size=1, loc=mean, scale=std, random_state=rng)
+    """distributions.py:68-73: ``truncnorm.rvs(a, b, size=1, loc, scale, random_state)`` is one
+    ``uniform`` draw pushed through the quantile function; the same log-space formulas as
+    scipy's, on scalars (its generic machinery costs more than the rest of the update)."""
+    mean, std, a, b = _truncnorm_bounds(mean, var, lower, upper)
+    q = float(rng.uniform(size=1)[0])
+    lm = _log_gauss_mass(a, b)
+    with np.errstate(divide='ignore'):
+        if a < 0:
+            x = ndtri_exp(np.logaddexp(log_ndtr(a), np.log(q) + lm))
+        else:
+            x = -ndtri_exp(np.logaddexp(log_ndtr(-b), np.log1p(-q) + lm))
+    return np.array([x * std + mean])
 
 
 def truncated_normal_logpdf(x, mean, var, lower=0, upper=1):
     """distributions.py:76-80"""
-    std = np.sqrt(var)
-    a = (lower - mean) / std
-    b = (upper - mean) / std
-    return truncnorm.logpdf(x, a, b, loc=mean, scale=std)
+    mean, std, a, b = _truncnorm_bounds(mean, var, lower, upper)
+    shape = np.shape(x)
+    y = (float(np.ravel(x)[0]) - mean) / std
+    if y < a or y > b:
+        lp = -np.inf
+    else:
+        lp = -0.5 * y * y - _HALF_LOG_2PI - _log_gauss_mass(a, b) - math.log(std)
+    return np.full(shape, lp) if shape else lp
 
 
 def sample_tables(n, beta, alpha_init, alpha, kappa, rng):
     """sample_auxillary.py:6-28 : number of tables serving each dish.
 
-    The reference draws ``rng.binomial(1, p / (p + arange(n_tjk)))`` cell by cell;
-    the legacy numpy sampler consumes its stream element by element, so ONE call
-    on the concatenation of all cells' probability vectors (same cell order)
-    yields the same draws without T*K*K Python-level calls."""
+    The reference draws ``rng.binomial(1, p / (p + arange(n_tjk)))`` cell by cell
+    (about N T Bernoulli draws per iteration); ``dlsm_host_sample_tables`` makes the
+    same draws, in the same order, from ``rng``'s own MT19937 state through numpy's
+    bit-generator interface, without the T*K*K Python-level calls."""
     T, K, _ = n.shape
+    n = np.ascontiguousarray(n, dtype=np.float64)
+    beta = np.ascontiguousarray(beta, dtype=np.float64)
     m = np.zeros((T, K, K), dtype=np.int64)
-    cnt0 = n[0, 0].astype(np.int64)
-    pr0 = alpha_init * beta
-    cnt1 = n[1:].astype(np.int64).reshape(-1)                  # (t, j, k) order
-    pr1 = np.tile((alpha * beta + kappa * np.eye(K)).reshape(-1), T - 1)
-    counts = np.concatenate([cnt0, cnt1])
-    probas = np.concatenate([pr0, pr1])
-    total = int(counts.sum())
-    if total == 0:
-        return m
-    seg = np.repeat(np.arange(counts.size), counts)
-    starts = np.cumsum(counts) - counts
-    ramp = np.arange(total) - starts[seg]
-    p = probas[seg] / (probas[seg] + ramp)
-    x = rng.binomial(1, p)
-    sums = np.bincount(seg, weights=x, minlength=counts.size).astype(np.int64)
-    m[0, 0] = sums[:K]
-    m[1:] = sums[K:].reshape(T - 1, K, K)
+    bitgen = rng._bit_generator
+    with bitgen.lock:
+        rc = _lib.load().dlsm_host_sample_tables(
+            bitgen.ctypes.bit_generator, T, K, n.ctypes.data_as(_lib.c_double_p),
+            beta.ctypes.data_as(_lib.c_double_p), float(np.ravel(alpha_init)[0]),
+            float(np.ravel(alpha)[0]), float(np.ravel(kappa)[0]), m.ctypes.data_as(_lib.c_i64_p))
+    if rc != 0:
+        raise ValueError('p < 0, p > 1 or p contains NaNs')
     return m
 
 

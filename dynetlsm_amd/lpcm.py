@@ -252,7 +252,7 @@ class DynamicNetworkLPCM(FittedQuantities):
         for it in range(1, n_total):
             if self.case_control_sampler_ is not None:
                 self.case_control_sampler_.resample(it)
-            chain.set_prior_mixture(mu, sigma, lmbda, z)
+            chain.set_prior_mixture(mu, sigma, lmbda, None)      # z: the device keeps its own
             chain.sweep_positions(it, self.sweep_algo)
             chain.center()
             for k in range(n_ic):                    # sample_coefficients.py:12-88

@@ -96,7 +96,8 @@ int dlsm_get_samplers(dlsm_chain *h, double *step_size, int32_t *n_accepted,
 /* prior of sample_latent_positions (sample_latent_positions.py:132-140) */
 int dlsm_set_prior_random_walk(dlsm_chain *h, double tau_sq, double sigma_sq);
 /* prior of sample_latent_positions_mixture (:187-199): mu K*D, sigma K
- * (variances), z T*N int64 */
+ * (variances), z T*N int64; z = NULL keeps the labels already on the device (those of
+ * the last dlsm_sample_labels / dlsm_set_prior_mixture with the same K) */
 int dlsm_set_prior_mixture(dlsm_chain *h, const double *mu, const double *sigma,
                            double lmbda, const int64_t *z, int K);
 
@@ -249,6 +250,15 @@ int dlsm_forecast_mean_probas(dlsm_chain *h, const double *Xs, const double *int
  * by the caller: mixture_normal_pdf, forecast.pyx:39-54). */
 int dlsm_forecast_marginal(dlsm_chain *h, const double *x, const double *W, const double *intercepts,
                            int S, double *out);
+
+/* ---- host-stream auxiliary draws ----------------------- */
+/* sample_tables (sample_auxillary.py:6-28): m T*K*K int64 = tables per (restaurant, dish)
+ * given the transition counts n T*K*K (n[0,0,:] = initial counts) and beta K.  The
+ * Bernoulli draws come from the CALLER's numpy RandomState, in the reference's order:
+ * numpy_bitgen is the address of its bitgen_t (RandomState._bit_generator.ctypes.bit_generator).
+ * Runs on the host; needs no chain.  -1: a probability outside [0, 1] (numpy raises there). */
+int dlsm_host_sample_tables(void *numpy_bitgen, int T, int K, const double *n, const double *beta,
+                            double alpha_init, double alpha, double kappa, int64_t *m);
 
 /* ---- measurement ------------------------------------------------------ */
 enum {

@@ -39,7 +39,7 @@ def tick(name, t0):
 
 n_it = 40
 for it in range(1, n_it + 1):
-    t0 = time.perf_counter(); c.set_prior_mixture(mu, sigma, lmbda, z); tick('set_prior', t0)
+    t0 = time.perf_counter(); c.set_prior_mixture(mu, sigma, lmbda, z if it == 1 else None); tick('set_prior', t0)
     t0 = time.perf_counter(); c.sweep_positions(it, 0); tick('sweep', t0)
     t0 = time.perf_counter(); c.center(); tick('center', t0)
     t0 = time.perf_counter(); c.loglik_full([[0.1], [0.2]]); tick('loglik x1', t0)

@@ -72,3 +72,41 @@ def test_hdp_host_updates_reproduce_reference_fit(g):
     for name in ('gamma', 'alpha_init', 'alpha', 'kappa', 'mean_variance_prior', 'b'):
         np.testing.assert_allclose(np.ravel(getattr(hp, name))[0],
                                    np.ravel(g['h1_' + name])[0], rtol=1e-9)
+
+
+def _tables_cell_by_cell(n, beta, alpha_init, alpha, kappa, rng):
+    """sample_auxillary.py:6-28 as the reference runs it: one binomial call per cell"""
+    T, K, _ = n.shape
+    m = np.zeros((T, K, K), dtype=np.int64)
+    pr0 = alpha_init * beta
+    pr = alpha * beta + kappa * np.eye(K)
+    for t in range(T):
+        for j in range(1 if t == 0 else K):
+            for k in range(K):
+                c = int(n[t, j, k])
+                p = pr0[k] if t == 0 else pr[j, k]
+                if c > 0:
+                    m[t, j, k] = rng.binomial(1, p / (p + np.arange(c))).sum()
+    return m
+
+
+@pytest.mark.parametrize('seed', range(12))
+def test_native_table_draws_consume_the_numpy_stream_like_the_reference(seed):
+    g = np.random.RandomState(seed)
+    T, K = int(g.randint(1, 6)), int(g.randint(1, 9))
+    n = g.poisson(30, size=(T, K, K)).astype(np.float64) * (g.rand(T, K, K) < 0.7)
+    beta = g.dirichlet(np.ones(K))
+    if seed % 4 == 0:
+        beta[0] = 1e-310                      # a dish whose weight has underflowed
+    kappa = 4.0 * (seed % 3)
+    r1, r2 = np.random.RandomState(seed), np.random.RandomState(seed)
+    expect = _tables_cell_by_cell(n, beta, 0.7, 1.3, kappa, r1)
+    got = hu.sample_tables(n, beta, 0.7, 1.3, kappa, r2)
+    np.testing.assert_array_equal(got, expect)
+    assert r1.random_sample() == r2.random_sample()       # same stream position afterwards
+
+
+def test_native_table_draws_reject_invalid_probabilities():
+    n = np.full((2, 2, 2), 3.0)
+    with pytest.raises(ValueError):
+        hu.sample_tables(n, np.array([0.0, 1.0]), 1.0, 1.0, 0.0, np.random.RandomState(0))
