@@ -41,7 +41,7 @@ def parse():
     ap.add_argument('--density', type=float, default=0.03)
     ap.add_argument('--algo', type=int, default=0, help='sweep algorithm (0 auto)')
     ap.add_argument('--profile-steps', type=int, default=20)
-    ap.add_argument('--cpu-iters', type=int, default=3,
+    ap.add_argument('--cpu-iters', type=int, default=8,
                     help='oracle iterations timed for cpu_baseline (0 = skip)')
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--backend', default=None,
@@ -167,7 +167,11 @@ def main():
                     'us_per_launch_in_kernel_stamps': round(st_us, 3) if n_ev > 0 and st_n > 0 else None,
                     'launches_per_sweep': launches,
                     'algorithmic_bytes_per_launch': round(k_bytes, 1),
-                    'sweep_GBps_all_launches': round(sweep_bytes / (sweep_ms * 1e-3) / 1e9, 2)}
+                    'sweep_GBps_all_launches': round(sweep_bytes / (sweep_ms * 1e-3) / 1e9, 2),
+                    # what actually bounds it (network bit-packed: float64 issue, not HBM):
+                    # pairwise terms (distance + exp) evaluated per second over the sweep,
+                    # 2 (proposal, current) x T x N x (N - 1) per sweep
+                    'dyad_terms_per_s': round(2.0 * T * N * (N - 1) / (sweep_ms * 1e-3), 0)}
         extra_r = {'us_resolve_per_launch': round(1e3 * ms_rs / max(n_rs, 1), 3)}
         extra = {'ms_per_loglik_eval': round(ll_ms, 4),
                  'loglik_eval_GBps': round(ll_bytes / (ll_ms * 1e-3) / 1e9, 1),

@@ -141,14 +141,17 @@ __device__ __forceinline__ double dist_of(const double *a, const double *b,
 // [2e-9, 2e4], also with the unrefined h = rsq / 2 in the correction (the compiler's
 // expansion refines h and spends a second correction).
 __device__ __forceinline__ double fast_sqrt(double s) {
+    // s == 0 (coincident points) would give rsq = inf: adding the smallest normal number
+    // leaves every s > 1e-292 unchanged and turns 0 into a root of 1.5e-154, which no sum or
+    // exponential downstream can tell from 0 (one add instead of a compare and two selects)
+    s += 2.2250738585072014e-308;
     const double y = __builtin_amdgcn_rsq(s);
     double g = s * y;
     const double h = 0.5 * y;             // ~1 / (2 sqrt(s)): good enough for the correction
     const double r = fma(-h, g, 0.5);
     g = fma(g, r, g);
     const double e = fma(-g, g, s);
-    g = fma(e, h, g);
-    return s > 0.0 ? g : 0.0;             // s == 0: rsq = inf
+    return fma(e, h, g);
 }
 
 __device__ __forceinline__ double fast_exp(double x) {

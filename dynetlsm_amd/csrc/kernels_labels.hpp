@@ -100,7 +100,6 @@ __global__ __launch_bounds__(64 * LAB_WAVES) void k_sample_labels(
         if (lane < K) pm[t * K + lane] = pmk;          // the forward pass needs it again
         double s = 0.0;
         const double *wr = wt + ((size_t)t * K + min(lane, K - 1)) * KP;
-#pragma unroll 4
         for (int k = 0; k < K; ++k) s += wr[k] * lane_value(pmk, k);
         double tot = 0.0;
         for (int r = 0; r < K; ++r) tot += lane_value(s, r);

@@ -153,7 +153,7 @@ __device__ __forceinline__ void pipe_eval_item(const ChainView &c, const PipeBuf
 
     double acc = 0.0;
     RatioAcc ra;
-#define DLSM_PIPE_TERM(I_, XI_, YB_, YCB_, RI_)                                              \
+#define DLSM_PIPE_TERM(I_, XI_, YB_, YCB_, RI_, FLUSH_)                                      \
     {                                                                                         \
         if (MODEL == DLSM_UNDIRECTED) {                                                       \
             const double d0_ = dist_fast<D>(XI_, xk0, c.squared);                             \
@@ -161,7 +161,7 @@ __device__ __forceinline__ void pipe_eval_item(const ChainView &c, const PipeBuf
             if (YB_) ra.lin += d0_ - d1_;                                                     \
             ra.P0 *= fma(E, fast_exp(-d0_), 1.0);                                             \
             ra.P1 *= fma(E, fast_exp(-d1_), 1.0);                                             \
-            if (++ra.cnt >= nflush) ra.flush();                                               \
+            if (FLUSH_) if (++ra.cnt >= nflush) ra.flush();                                   \
         } else {                                                                              \
             const double d0_ = dist_of<D>(XI_, xk0, c.squared);                               \
             const double d1_ = dist_of<D>(XI_, xk1, c.squared);                               \
@@ -170,28 +170,35 @@ __device__ __forceinline__ void pipe_eval_item(const ChainView &c, const PipeBuf
                                   bin * irk + bout * iri_, E);                                \
         }                                                                                     \
     }
-#pragma unroll
-    for (int u = 0; u < PP_NPRE; ++u) {
-        const int i = lo + lane + 64 * u;
-        const int wi = min((i >> 5) - w0, 63);
-        const uint32_t yw = __shfl(yseg, wi, 64);
-        const uint32_t ycw = MODEL == DLSM_DIRECTED ? __shfl(ycseg, wi, 64) : 0u;
-        if (i < hi && i != jk)
-            DLSM_PIPE_TERM(i, xpre[u], (yw >> (i & 31)) & 1, (ycw >> (i & 31)) & 1,
-                           rpre[MODEL == DLSM_DIRECTED ? u : 0])
+    // the running products of the whole part stay in range without a flush when it has no
+    // more than nflush neighbours (the usual case): that loop carries no flush counter
+    const bool noflush = MODEL == DLSM_UNDIRECTED && nflush >= hi - lo;
+#define DLSM_PIPE_LOOPS(FLUSH_)                                                               \
+    _Pragma("unroll")                                                                         \
+    for (int u = 0; u < PP_NPRE; ++u) {                                                       \
+        const int i = lo + lane + 64 * u;                                                     \
+        const int wi = min((i >> 5) - w0, 63);                                                \
+        const uint32_t yw = __shfl(yseg, wi, 64);                                             \
+        const uint32_t ycw = MODEL == DLSM_DIRECTED ? __shfl(ycseg, wi, 64) : 0u;             \
+        if (i < hi && i != jk)                                                                \
+            DLSM_PIPE_TERM(i, xpre[u], (yw >> (i & 31)) & 1, (ycw >> (i & 31)) & 1,           \
+                           rpre[MODEL == DLSM_DIRECTED ? u : 0], FLUSH_)                      \
+    }                                                                                         \
+    for (int i = lo + lane + 64 * PP_NPRE; i < hi; i += 64) {                                 \
+        if (i == jk) continue;                                                                \
+        const double *src = i < jprev ? Xt + (size_t)i * D : props + (size_t)i * PW + D + 2;  \
+        double xi[D];                                                                         \
+        _Pragma("unroll")                                                                     \
+        for (int d = 0; d < D; ++d) xi[d] = src[d];                                           \
+        const double ri = MODEL == DLSM_DIRECTED ? c.radii[i] : 1.0;                          \
+        DLSM_PIPE_TERM(i, xi, bit_of(yr, i), MODEL == DLSM_DIRECTED ? bit_of(yc, i) : 0, ri,  \
+                       FLUSH_)                                                                \
     }
-    for (int i = lo + lane + 64 * PP_NPRE; i < hi; i += 64) {
-        if (i == jk) continue;
-        const double *src = i < jprev ? Xt + (size_t)i * D : props + (size_t)i * PW + D + 2;
-        double xi[D];
-#pragma unroll
-        for (int d = 0; d < D; ++d) xi[d] = src[d];
-        const double ri = MODEL == DLSM_DIRECTED ? c.radii[i] : 1.0;
-        DLSM_PIPE_TERM(i, xi, bit_of(yr, i), MODEL == DLSM_DIRECTED ? bit_of(yc, i) : 0, ri)
-    }
+    if (noflush) { DLSM_PIPE_LOOPS(false) } else { DLSM_PIPE_LOOPS(true) }
+#undef DLSM_PIPE_LOOPS
 #undef DLSM_PIPE_TERM
     double tot_l, tot_r;
-    if (MODEL == DLSM_UNDIRECTED && nflush >= hi - lo) {
+    if (noflush) {
         // the products of the whole wave stay in range: multiply across lanes
         tot_l = wave_sum_all(ra.lin + ra.lg);
         tot_r = wave_prod_all(ra.P0) / wave_prod_all(ra.P1);
