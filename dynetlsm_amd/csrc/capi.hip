@@ -822,7 +822,8 @@ static int launch_sweep_pipe(dlsm_chain *h, IterRef iter, bool alloc_only = fals
     pb.prop = h->pipe; pb.full0 = pb.prop + n_prop; pb.Hd = pb.full0 + n_full0;
     pb.Hx = pb.Hd + n_h; pb.acc = (int32_t *)(pb.Hx + n_h);
     pb.consts = pb.Hx + n_h + n_acc;
-    pb.parts = parts; pb.per = (N + parts - 1) / parts; pb.nbat = nbat;
+    pb.parts = parts; pb.nbat = nbat;
+    pb.per = ((N + parts - 1) / parts + 63) / 64 * 64;      // parts start on a 64-neighbour boundary
     pb.nctrl = h->nctrl;
     const size_t lds = (size_t)PP_B * PP_B * sizeof(double);
     auto ku = k_pipe_step<DD, DLSM_UNDIRECTED>;

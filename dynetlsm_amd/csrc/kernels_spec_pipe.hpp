@@ -120,9 +120,9 @@ __device__ __forceinline__ void pipe_eval_item(const ChainView &c, const PipeBuf
     // The item is a chain of dependent latencies, so every load it will need is issued
     // before the first use: PP_NPRE neighbours per lane (clamped addresses, no
     // predication) and this lane's first H entry.
-    // The bits of row k for the prefetched neighbours: lane w holds word (lo >> 5) + w of
-    // the row (64 words = 2048 neighbours, more than PP_NPRE * 64), fetched per
-    // neighbour by a lane shuffle instead of a load and a register each.
+    // The bits of row k for the part's neighbours: lane w holds word (lo >> 5) + w of the row
+    // (64 words = 2048 neighbours; a longer part reads the rest from memory), handed to the
+    // trips as scalar lane masks instead of a load and a register per neighbour.
     double xpre[PP_NPRE][D], rpre[MODEL == DLSM_DIRECTED ? PP_NPRE : 1];
     const int w0 = lo >> 5;
     const uint32_t yseg = yr[min(w0 + lane, W - 1)];
@@ -153,11 +153,11 @@ __device__ __forceinline__ void pipe_eval_item(const ChainView &c, const PipeBuf
 
     double acc = 0.0;
     RatioAcc ra;
-#define DLSM_PIPE_TERM(I_, XI_, YB_, YCB_, RI_, FLUSH_)                                      \
+#define DLSM_PIPE_TERM(XI_, YB_, YCB_, RI_, FLUSH_, SQ_)                                      \
     {                                                                                         \
         if (MODEL == DLSM_UNDIRECTED) {                                                       \
-            const double d0_ = dist_fast<D>(XI_, xk0, c.squared);                             \
-            const double d1_ = dist_fast<D>(XI_, xk1, c.squared);                             \
+            const double d0_ = dist_fast<D>(XI_, xk0, SQ_);                                   \
+            const double d1_ = dist_fast<D>(XI_, xk1, SQ_);                                   \
             if (YB_) ra.lin += d0_ - d1_;                                                     \
             ra.P0 *= fma(E, fast_exp(-d0_), 1.0);                                             \
             ra.P1 *= fma(E, fast_exp(-d1_), 1.0);                                             \
@@ -166,36 +166,58 @@ __device__ __forceinline__ void pipe_eval_item(const ChainView &c, const PipeBuf
             const double d0_ = dist_of<D>(XI_, xk0, c.squared);                               \
             const double d1_ = dist_of<D>(XI_, xk1, c.squared);                               \
             const double iri_ = 1.0 / (RI_);                                                  \
-            acc += delta_directed(d0_, d1_, YB_, YCB_, bin * iri_ + bout * irk,               \
+            acc += delta_directed(d0_, d1_, (int)(YB_), (int)(YCB_), bin * iri_ + bout * irk, \
                                   bin * irk + bout * iri_, E);                                \
         }                                                                                     \
     }
     // the running products of the whole part stay in range without a flush when it has no
     // more than nflush neighbours (the usual case): that loop carries no flush counter
-    const bool noflush = MODEL == DLSM_UNDIRECTED && nflush >= hi - lo;
-#define DLSM_PIPE_LOOPS(FLUSH_)                                                               \
+    const bool noflush = MODEL == DLSM_UNDIRECTED && nflush >= hi - lo && !c.squared;
+    // Trip u covers neighbours lo + 64 u + lane (lo is a multiple of 64): their bits of row k
+    // are words 2u, 2u + 1 of the segment held across the lanes, read into a scalar pair that
+    // serves as the lane mask of "y = 1" directly; "i < hi and i != k" is a scalar mask too.
+#define DLSM_PIPE_MASKS(U_)                                                                   \
+        const int base_ = lo + 64 * (U_);                                                     \
+        const int rem_ = hi - base_, self_ = jk - base_;                                      \
+        unsigned long long vm_ = rem_ >= 64 ? ~0ull : (rem_ > 0 ? (1ull << rem_) - 1ull : 0ull); \
+        if (self_ >= 0 && self_ < 64) vm_ &= ~(1ull << self_);                                \
+        const bool in_seg_ = 2 * (U_) + 1 < 64;                                               \
+        const int w_ = in_seg_ ? 2 * (U_) : 0;                                                \
+        const unsigned long long ym_ =                                                        \
+            ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)yseg, w_ + 1) << 32) | \
+            (uint32_t)__builtin_amdgcn_readlane((int)yseg, w_);                               \
+        const unsigned long long ycm_ = MODEL != DLSM_DIRECTED ? 0ull :                       \
+            ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)ycseg, w_ + 1) << 32) | \
+            (uint32_t)__builtin_amdgcn_readlane((int)ycseg, w_);                              \
+        const int i_ = base_ + lane;                                                          \
+        const bool yb_ = in_seg_ ? __builtin_amdgcn_inverse_ballot_w64(ym_)                   \
+                                 : (bool)bit_of(yr, min(i_, N - 1));                          \
+        const bool ycb_ = MODEL != DLSM_DIRECTED ? false :                                    \
+            (in_seg_ ? __builtin_amdgcn_inverse_ballot_w64(ycm_) : (bool)bit_of(yc, min(i_, N - 1)));
+#define DLSM_PIPE_LOOPS(FLUSH_, SQ_)                                                          \
     _Pragma("unroll")                                                                         \
     for (int u = 0; u < PP_NPRE; ++u) {                                                       \
-        const int i = lo + lane + 64 * u;                                                     \
-        const int wi = min((i >> 5) - w0, 63);                                                \
-        const uint32_t yw = __shfl(yseg, wi, 64);                                             \
-        const uint32_t ycw = MODEL == DLSM_DIRECTED ? __shfl(ycseg, wi, 64) : 0u;             \
-        if (i < hi && i != jk)                                                                \
-            DLSM_PIPE_TERM(i, xpre[u], (yw >> (i & 31)) & 1, (ycw >> (i & 31)) & 1,           \
-                           rpre[MODEL == DLSM_DIRECTED ? u : 0], FLUSH_)                      \
+        DLSM_PIPE_MASKS(u)                                                                    \
+        if (__builtin_amdgcn_inverse_ballot_w64(vm_))                                         \
+            DLSM_PIPE_TERM(xpre[u], yb_, ycb_, rpre[MODEL == DLSM_DIRECTED ? u : 0], FLUSH_, SQ_) \
     }                                                                                         \
-    for (int i = lo + lane + 64 * PP_NPRE; i < hi; i += 64) {                                 \
-        if (i == jk) continue;                                                                \
-        const double *src = i < jprev ? Xt + (size_t)i * D : props + (size_t)i * PW + D + 2;  \
-        double xi[D];                                                                         \
-        _Pragma("unroll")                                                                     \
-        for (int d = 0; d < D; ++d) xi[d] = src[d];                                           \
-        const double ri = MODEL == DLSM_DIRECTED ? c.radii[i] : 1.0;                          \
-        DLSM_PIPE_TERM(i, xi, bit_of(yr, i), MODEL == DLSM_DIRECTED ? bit_of(yc, i) : 0, ri,  \
-                       FLUSH_)                                                                \
+    for (int u = PP_NPRE; lo + 64 * u < hi; ++u) {                                            \
+        DLSM_PIPE_MASKS(u)                                                                    \
+        if (__builtin_amdgcn_inverse_ballot_w64(vm_)) {                                       \
+            const double *src = i_ < jprev ? Xt + (size_t)i_ * D                              \
+                                           : props + (size_t)i_ * PW + D + 2;                 \
+            double xi[D];                                                                     \
+            _Pragma("unroll")                                                                 \
+            for (int d = 0; d < D; ++d) xi[d] = src[d];                                       \
+            const double ri = MODEL == DLSM_DIRECTED ? c.radii[i_] : 1.0;                     \
+            DLSM_PIPE_TERM(xi, yb_, ycb_, ri, FLUSH_, SQ_)                                    \
+        }                                                                                     \
     }
-    if (noflush) { DLSM_PIPE_LOOPS(false) } else { DLSM_PIPE_LOOPS(true) }
+    if (noflush) { DLSM_PIPE_LOOPS(false, 0) }
+    else if (c.squared) { DLSM_PIPE_LOOPS(true, 1) }
+    else { DLSM_PIPE_LOOPS(true, 0) }
 #undef DLSM_PIPE_LOOPS
+#undef DLSM_PIPE_MASKS
 #undef DLSM_PIPE_TERM
     double tot_l, tot_r;
     if (noflush) {
