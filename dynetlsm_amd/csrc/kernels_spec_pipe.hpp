@@ -87,10 +87,23 @@ __global__ __launch_bounds__(256) void k_pipe_propose(ChainView c, PipeBuf pb, I
     pr[D + 1] = 0.0;
 }
 
+// flat H index f -> (node kk of the batch, entry e < ncross + kk);
+// prefix(kk) = ncross kk + kk (kk - 1) / 2 (f < 2^16: the float root is off by one at most)
+__device__ __forceinline__ void pipe_h_decode(int f, int ncross, int nb, int &kk, int &e) {
+    const float bq = (float)(2 * ncross - 1);
+    kk = (int)((sqrtf(fmaf(bq, bq, 8.0f * (float)f)) - bq) * 0.5f);
+    kk = min(max(kk, 0), nb - 1);
+    int pre = ncross * kk + ((kk * (kk - 1)) >> 1);
+    if (pre > f) { --kk; pre -= ncross + kk; }
+    else if (pre + ncross + kk <= f) { pre += ncross + kk; ++kk; }
+    kk = min(kk, nb - 1);                 // only when f is not a valid index (clamped prefetch)
+    e = f - pre;
+}
+
 // One wavefront: part p of node k of batch `be` in slice t.
 template <int D, int MODEL>
 __device__ __forceinline__ void pipe_eval_item(const ChainView &c, const PipeBuf &pb, int be,
-                                               int t, int k, int p, int lane) {
+                                               int nb, int t, int k, int p, int lane) {
     constexpr int PW = 2 * D + 2;
     const int N = c.N, W = c.W;
     const int j0 = be * PP_B, jk = j0 + k;
@@ -135,21 +148,33 @@ __device__ __forceinline__ void pipe_eval_item(const ChainView &c, const PipeBuf
         for (int d = 0; d < D; ++d) xpre[u][d] = src[d];
         if (MODEL == DLSM_DIRECTED) rpre[u] = c.radii[ic];
     }
-    const int ne = ncross + k;
-    const int e0 = p + pb.parts * lane;
-    const int e0c = min(e0, max(ne - 1, 0));
-    const bool cross0 = e0c < ncross;
-    const int m0 = cross0 ? e0c : e0c - ncross;
-    const int jm0 = (cross0 ? jprev : j0) + m0;
-    double hm0[D], hm1[D];
+    // H entries of the batch: (node kk, entry e), e < ncross + kk: the previous batch (cross
+    // block) then the earlier nodes of kk's own batch.  They are dealt out evenly over ALL the
+    // lanes working on this (slice, batch) - not to the wavefronts of "their" node, whose
+    // entry counts differ by 2x - through the flat index f = prefix(kk) + e,
+    // prefix(kk) = ncross kk + kk (kk - 1) / 2; one entry per lane when there are >= 3 parts.
+    // The first one's operands are loaded here, ahead of the neighbour loop.
+    const int hround = nb * pb.parts * 64;
+    const int htot = ncross * nb + nb * (nb - 1) / 2;
+    const int hf0 = (k * pb.parts + p) * 64 + lane;
+    int hkk, he;
+    pipe_h_decode(min(hf0, max(htot - 1, 0)), ncross, nb, hkk, he);
+    const bool hcross0 = he < ncross;
+    const int hm_0 = hcross0 ? he : he - ncross;
+    const int jm0 = (hcross0 ? jprev : j0) + hm_0;
+    const int jkk0 = j0 + hkk;
+    double hm0[D], hm1[D], hk0[D], hk1[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) {
         hm0[d] = props[(size_t)jm0 * PW + D + 2 + d];
         hm1[d] = props[(size_t)jm0 * PW + d];
+        hk0[d] = props[(size_t)jkk0 * PW + D + 2 + d];
+        hk1[d] = props[(size_t)jkk0 * PW + d];
     }
-    const uint32_t hw = yr[jm0 >> 5];
-    const uint32_t hwc = MODEL == DLSM_DIRECTED ? yc[jm0 >> 5] : 0u;
+    const uint32_t hw = c.ybits[((size_t)t * N + jkk0) * W + (jm0 >> 5)];
+    const uint32_t hwc = MODEL == DLSM_DIRECTED ? c.ytbits[((size_t)t * N + jkk0) * W + (jm0 >> 5)] : 0u;
     const double hr = MODEL == DLSM_DIRECTED ? c.radii[jm0] : 1.0;
+    const double hrk = MODEL == DLSM_DIRECTED ? c.radii[jkk0] : 1.0;
 
     double acc = 0.0;
     RatioAcc ra;
@@ -232,33 +257,40 @@ __device__ __forceinline__ void pipe_eval_item(const ChainView &c, const PipeBuf
         double2 *f = (double2 *)pb.full0 + (((size_t)bb * c.T + t) * PP_B + k) * pb.parts + p;
         *f = make_double2(tot_l, tot_r);
     }
-    // H entries of node k: the previous batch (cross block) then the earlier nodes of
-    // its own batch; the parts of a node share them round-robin (the first one per lane
-    // was prefetched above)
-    for (int e = e0; e < ne; e += pb.parts * 64) {
-        const bool cross = e < ncross;
-        const int m = cross ? e : e - ncross;
-        const int jm = (cross ? jprev : j0) + m;
-        double xm0[D], xm1[D], rm;
+    // this lane's H entries (see above): the first from the prefetched operands
+    for (int f = hf0; f < htot; f += hround) {
+        int kk, e;
+        double xm0[D], xm1[D], xa0[D], xa1[D], rm, rk;
         int y1, y2;
-        if (e == e0) {
-#pragma unroll
-            for (int d = 0; d < D; ++d) { xm0[d] = hm0[d]; xm1[d] = hm1[d]; }
-            y1 = (hw >> (jm & 31)) & 1; y2 = (hwc >> (jm & 31)) & 1; rm = hr;
-        } else {
+        if (f == hf0) {
+            kk = hkk; e = he;
 #pragma unroll
             for (int d = 0; d < D; ++d) {
-                xm0[d] = props[(size_t)jm * PW + D + 2 + d];
-                xm1[d] = props[(size_t)jm * PW + d];
+                xm0[d] = hm0[d]; xm1[d] = hm1[d]; xa0[d] = hk0[d]; xa1[d] = hk1[d];
             }
-            y1 = bit_of(yr, jm);
-            y2 = MODEL == DLSM_DIRECTED ? bit_of(yc, jm) : 0;
-            rm = MODEL == DLSM_DIRECTED ? c.radii[jm] : 1.0;
+            y1 = (hw >> (jm0 & 31)) & 1; y2 = (hwc >> (jm0 & 31)) & 1; rm = hr; rk = hrk;
+        } else {
+            pipe_h_decode(f, ncross, nb, kk, e);
+            const int jm_ = (e < ncross ? jprev : j0) + (e < ncross ? e : e - ncross);
+            const int jkk = j0 + kk;
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                xm0[d] = props[(size_t)jm_ * PW + D + 2 + d];
+                xm1[d] = props[(size_t)jm_ * PW + d];
+                xa0[d] = props[(size_t)jkk * PW + D + 2 + d];
+                xa1[d] = props[(size_t)jkk * PW + d];
+            }
+            y1 = bit_of(c.ybits + ((size_t)t * N + jkk) * W, jm_);
+            y2 = MODEL == DLSM_DIRECTED ? bit_of(c.ytbits + ((size_t)t * N + jkk) * W, jm_) : 0;
+            rm = MODEL == DLSM_DIRECTED ? c.radii[jm_] : 1.0;
+            rk = MODEL == DLSM_DIRECTED ? c.radii[jkk] : 1.0;
         }
-        const double a0 = dist_fast<D>(xm0, xk0, c.squared);
-        const double a1 = dist_fast<D>(xm0, xk1, c.squared);
-        const double b0 = dist_fast<D>(xm1, xk0, c.squared);
-        const double b1 = dist_fast<D>(xm1, xk1, c.squared);
+        const bool cross = e < ncross;
+        const int m = cross ? e : e - ncross;
+        const double a0 = dist_fast<D>(xm0, xa0, c.squared);
+        const double a1 = dist_fast<D>(xm0, xa1, c.squared);
+        const double b0 = dist_fast<D>(xm1, xa0, c.squared);
+        const double b1 = dist_fast<D>(xm1, xa1, c.squared);
         double h;
         if (MODEL == DLSM_UNDIRECTED) {
             const double num = fma(E, fast_exp(-b0), 1.0) * fma(E, fast_exp(-a1), 1.0);
@@ -266,13 +298,13 @@ __device__ __forceinline__ void pipe_eval_item(const ChainView &c, const PipeBuf
             h = num / den;
             if (y1) h *= fast_exp((b0 - b1) - (a0 - a1));
         } else {
-            const double irm = 1.0 / rm;
-            const double aa = bin * irm + bout * irk, cc = bin * irk + bout * irm;
+            const double irm = 1.0 / rm, irkk = 1.0 / rk;
+            const double aa = bin * irm + bout * irkk, cc = bin * irkk + bout * irm;
             h = exp(delta_directed(b0, b1, y1, y2, aa, cc, E) -
                     delta_directed(a0, a1, y1, y2, aa, cc, E));
         }
         double *dst = cross ? pb.Hx : pb.Hd;
-        dst[(((size_t)bb * c.T + t) * PP_B + m) * PP_B + k] = h;
+        dst[(((size_t)bb * c.T + t) * PP_B + m) * PP_B + kk] = h;
     }
 }
 
@@ -592,7 +624,7 @@ __global__ __launch_bounds__(PP_THREADS) void k_pipe_step(ChainView c, PipeBuf p
         if (k >= (odd ? nbO : nbE)) continue;
         const int t = odd ? 2 * (si - nslE) + 1 : 2 * si;
         pipe_eval_item<D, MODEL == DLSM_DIRECTED_CASE_CONTROL ? DLSM_DIRECTED : MODEL>(
-            c, pb, odd ? beO : beE, t, k, p, lane);
+            c, pb, odd ? beO : beE, odd ? nbO : nbE, t, k, p, lane);
     }
 }
 
