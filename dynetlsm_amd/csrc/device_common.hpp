@@ -140,11 +140,12 @@ __device__ __forceinline__ double dist_of(const double *a, const double *b,
 // correction already gives the correctly rounded root on 2^20 samples over
 // [2e-9, 2e4], also with the unrefined h = rsq / 2 in the correction (the compiler's
 // expansion refines h and spends a second correction).
-__device__ __forceinline__ double fast_sqrt(double s) {
-    // s == 0 (coincident points) would give rsq = inf: adding the smallest normal number
-    // leaves every s > 1e-292 unchanged and turns 0 into a root of 1.5e-154, which no sum or
-    // exponential downstream can tell from 0 (one add instead of a compare and two selects)
-    s += 2.2250738585072014e-308;
+// s == 0 (coincident points) would give rsq = inf: adding the smallest normal number
+// leaves every s > 1e-292 unchanged and turns 0 into a root of 1.5e-154, which no sum or
+// exponential downstream can tell from 0 (one add instead of a compare and two selects;
+// dist_fast folds the add into its first fma)
+constexpr double SQRT_GUARD = 2.2250738585072014e-308;
+__device__ __forceinline__ double fast_sqrt_guarded(double s) {      // s >= SQRT_GUARD
     const double y = __builtin_amdgcn_rsq(s);
     double g = s * y;
     const double h = 0.5 * y;             // ~1 / (2 sqrt(s)): good enough for the correction
@@ -153,6 +154,7 @@ __device__ __forceinline__ double fast_sqrt(double s) {
     const double e = fma(-g, g, s);
     return fma(e, h, g);
 }
+__device__ __forceinline__ double fast_sqrt(double s) { return fast_sqrt_guarded(s + SQRT_GUARD); }
 
 __device__ __forceinline__ double fast_exp(double x) {
     const double k = rint(x * 1.4426950408889634074);
@@ -178,13 +180,13 @@ __device__ __forceinline__ double fast_exp(double x) {
 
 template <int D>
 __device__ __forceinline__ double dist_fast(const double *a, const double *b, int squared) {
-    double s = 0.0;
+    double s = squared ? 0.0 : SQRT_GUARD;
 #pragma unroll
     for (int d = 0; d < D; ++d) {
         double df = a[d] - b[d];
-        s += df * df;
+        s = fma(df, df, s);
     }
-    return squared ? s : fast_sqrt(s);
+    return squared ? s : fast_sqrt_guarded(s);
 }
 
 __device__ __forceinline__ int bit_of(const uint32_t *row, int i) {
