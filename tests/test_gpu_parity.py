@@ -415,6 +415,59 @@ def test_labels_medium_and_distribution(eng):
         np.testing.assert_allclose(lp, st.node_logp(1, 5, X[1, 5]), rtol=1e-12)
 
 
+@pytest.mark.parametrize('T,N,D,K', [
+    (10, 301, 2, 40),     # transition matrices too large for LDS: read from global memory
+    (70, 50, 1, 3),       # more than 64 time steps: the uniforms come in two passes
+    (3, 77, 3, 64),       # every lane owns a component; N not a multiple of the group size
+    (1, 9, 2, 2),         # a single time step: no backward pass
+])
+def test_labels_shapes_against_oracle(eng, T, N, D, K):
+    rng = np.random.RandomState(T * 131 + K)
+    mu = rng.randn(K, D) * 2
+    sg = rng.uniform(0.2, 1.0, K)
+    X = mu[rng.randint(0, K, size=(T, N))] + 0.5 * rng.randn(T, N, D)
+    w = rng.dirichlet(np.ones(K), size=(T, K))
+    with eng.Chain(T, N, D, 'undirected', seed=11, chain_id=2) as c:
+        c.set_positions(X)
+        c.set_prior_mixture(mu, sg, 0.7, np.zeros((T, N), dtype=np.int64))
+        for it in (1, 2):
+            z, n, nk = c.sample_labels(it, w)
+            zo, no, nko = orc.sample_labels_block_philox(X, mu, sg, 0.7, w, 11, 2, it)
+            assert (z != zo).mean() < 2e-3        # identical up to 1-ulp ties
+            # the counts are those of the labels the device drew
+            n_chk = np.zeros((T, K, K)); nk_chk = np.zeros((T, K), dtype=np.int64)
+            np.add.at(n_chk[0, 0], z[0], 1)
+            for t in range(1, T):
+                np.add.at(n_chk[t], (z[t - 1], z[t]), 1)
+            for t in range(T):
+                nk_chk[t] = np.bincount(z[t], minlength=K)
+            np.testing.assert_array_equal(n, n_chk)
+            np.testing.assert_array_equal(nk, nk_chk)
+
+
+def test_set_prior_mixture_keeps_device_labels(eng):
+    rng = np.random.RandomState(8)
+    T, N, D, K = 4, 60, 2, 5
+    X = rng.randn(T, N, D)
+    mu, sg = rng.randn(K, D), rng.uniform(0.3, 1.0, K)
+    w = rng.dirichlet(np.ones(K), size=(T, K))
+    Y = np.zeros((T, N, N))
+    with eng.Chain(T, N, D, 'undirected', seed=2) as c:
+        c.upload_network(Y); c.set_positions(X); c.set_intercepts([0.0])
+        with pytest.raises(eng.EngineError):
+            c.set_prior_mixture(mu, sg, 0.8, None)            # no labels on the device yet
+        c.set_prior_mixture(mu, sg, 0.8, np.zeros((T, N), dtype=np.int64))
+        z, _, _ = c.sample_labels(1, w)
+        mu2, sg2 = mu + 0.1, sg * 1.5
+        c.set_prior_mixture(mu2, sg2, 0.6, None)              # new parameters, same labels
+        a = c.loglik_partial(2, 7, with_prior=True)
+        c.set_prior_mixture(mu2, sg2, 0.6, z)
+        b = c.loglik_partial(2, 7, with_prior=True)
+        assert a == b
+        with pytest.raises(eng.EngineError):
+            c.set_prior_mixture(rng.randn(K + 1, D), np.ones(K + 1), 0.6, None)   # other K
+
+
 # ------------------------------------------------------------ controls
 def test_resample_controls_valid_and_uniform(eng):
     X, Yd, Yu, radii = _rand_net(8, 2, 60, density=0.1)
