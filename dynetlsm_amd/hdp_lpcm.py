@@ -22,12 +22,22 @@ from . import hdp_updates as hu
 from . import initialization as init_mod
 from . import posterior as post
 from . import forecast as fc
+from .diagnostics import geweke_diag
 from .imputer import SimpleNetworkImputer
 from .metrics import FittedQuantities
 from .lsm import (DynamicNetworkLSM, _ScalarMetropolis, _dirichlet_logpdf,
                   check_random_state)
 
 __all__ = ['DynamicNetworkHDPLPCM']
+
+
+
+def _geweke(trace, n_burn):
+    """(z, p) of diagnostics.geweke_diag; (nan, nan) for traces too short for its AR fits"""
+    try:
+        return geweke_diag(trace, n_burn=n_burn)
+    except (ValueError, np.linalg.LinAlgError, ZeroDivisionError):
+        return float('nan'), float('nan')
 
 
 class DynamicNetworkHDPLPCM(FittedQuantities):
@@ -346,4 +356,13 @@ class DynamicNetworkHDPLPCM(FittedQuantities):
         self.X_mean_ = self.Xs_[n_burn:].mean(axis=0)
         self.lambda_mean_ = self.lambdas_[n_burn:].mean(axis=0)
         self.intercepts_mean_ = self.intercepts_[n_burn:].mean(axis=0)
+        # Geweke's diagnostic of the scalar traces (hdp_lpcm.py:1165-1176)
+        with np.errstate(all='ignore'):
+            self.logp_geweke_ = _geweke(self.logps_, n_burn)
+            self.lambda_geweke_ = _geweke(self.lambdas_[:, 0], n_burn)
+            if self.is_directed:
+                self.intercept_in_geweke_ = _geweke(self.intercepts_[:, 0], n_burn)
+                self.intercept_out_geweke_ = _geweke(self.intercepts_[:, 1], n_burn)
+            else:
+                self.intercept_geweke_ = _geweke(self.intercepts_[:, 0], n_burn)
         return self
