@@ -130,7 +130,7 @@ int ll_blocks(const dlsm_chain *h) {
     if (h->model == DLSM_DIRECTED_CASE_CONTROL)
         return (int)(((long)h->T * h->N + LLCC_NODES - 1) / LLCC_NODES);
     int nt = (h->N + LL_TILE - 1) / LL_TILE;
-    return h->T * (nt * (nt + 1) / 2);
+    return h->T * (nt * (nt + 1) / 2) * (h->model == DLSM_UNDIRECTED ? 2 : 1);    // half tiles
 }
 
 int check_ready_loglik(dlsm_chain *h) {
@@ -156,8 +156,8 @@ int launch_loglik_records(dlsm_chain *h, int M, const double *d_ic,
     LoglikCand cand{d_ic, {r0, r1}};
     ProfScope ps(h, DLSM_K_LOGLIK);
     if (h->model == DLSM_UNDIRECTED) {
-        if (M == 1) hipLaunchKernelGGL((k_loglik_undirected<DD, 1>), dim3(nb), dim3(LL_THREADS), 0, h->stream, v, cand, h->partials);
-        else hipLaunchKernelGGL((k_loglik_undirected<DD, 2>), dim3(nb), dim3(LL_THREADS), 0, h->stream, v, cand, h->partials);
+        if (M == 1) hipLaunchKernelGGL((k_loglik_undirected<DD, 1>), dim3(nb), dim3(LLU_THREADS), 0, h->stream, v, cand, h->partials);
+        else hipLaunchKernelGGL((k_loglik_undirected<DD, 2>), dim3(nb), dim3(LLU_THREADS), 0, h->stream, v, cand, h->partials);
     } else if (h->model == DLSM_DIRECTED) {
         if (M == 1) hipLaunchKernelGGL((k_loglik_directed<DD, 1>), dim3(nb), dim3(LL_THREADS), 0, h->stream, v, cand, h->partials);
         else hipLaunchKernelGGL((k_loglik_directed<DD, 2>), dim3(nb), dim3(LL_THREADS), 0, h->stream, v, cand, h->partials);

@@ -38,9 +38,9 @@ __global__ __launch_bounds__(256) void k_pack_bits(const double *__restrict__ Y,
 // ---------------------------------------------------------------------------
 // Full log-likelihood, undirected (a4) and directed (a5).
 //
-// Grid: T x (upper-triangular 128x128 tiles); 256 threads; thread = one column
-// j of the tile x one half (64) of its rows.  X tiles and the tile's Y bits are
-// staged in LDS; X_i is an LDS broadcast, X_j stays in registers.
+// Grid: T x (upper-triangular 128x128 tiles) [x 2 half tiles, undirected]; thread = one
+// column j of the tile x one half (64) of its rows.  X tiles (and, directed, the tile's Y
+// bits) are staged in LDS; X_i is an LDS broadcast, X_j stays in registers.
 // Per-thread accumulators in fp64, wave shuffle -> LDS -> one partial record per
 // workgroup; k_reduce_partials sums the records in a fixed order (deterministic).
 //
@@ -67,41 +67,41 @@ __device__ __forceinline__ void tile_decode(int r, int nt, int &ti, int &tj) {
     tj = ti + r;
 }
 
+// Undirected: one workgroup (2 wavefronts) per HALF tile, 64 rows x 128 columns; thread =
+// one column j (X_j in registers), the rows' X_i an LDS broadcast.  The 64 bits of row i under
+// a wavefront's columns are one aligned 8-byte word of the packed network: read as a SCALAR
+// and used as the lane mask of "y = 1" directly, and counted with a scalar popcount.
+constexpr int LLU_THREADS = 128;
+constexpr int LLU_ROWS = 64;
+
 template <int D, int M>
-__global__ __launch_bounds__(LL_THREADS) void k_loglik_undirected(
+__global__ __launch_bounds__(LLU_THREADS) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_loglik_undirected(
     ChainView c, LoglikCand cand, double *__restrict__ partials) {
-    __shared__ double sXi[LL_TILE * D];
-    __shared__ double sXj[LL_TILE * D];
-    __shared__ uint32_t sY[LL_TILE * 4];
-    __shared__ double sRed[4 * (2 + M)];
+    __shared__ double sXi[LLU_ROWS * D];
+    __shared__ double sRed[2 * (2 + M)];
     const int tid = threadIdx.x;
-    const int nt = (c.N + LL_TILE - 1) / LL_TILE;
+    const int N = c.N;
+    const int nt = (N + LL_TILE - 1) / LL_TILE;
     const int ntri = nt * (nt + 1) / 2;
-    const int t = blockIdx.x / ntri;
+    const int tile = blockIdx.x >> 1;
+    const int t = tile / ntri;
     int ti, tj;
-    tile_decode(blockIdx.x % ntri, nt, ti, tj);
-    const int i0 = ti * LL_TILE, j0 = tj * LL_TILE;
-    const double *Xt = c.X + (size_t)t * c.N * D;
-    for (int k = tid; k < LL_TILE * D; k += LL_THREADS) {
-        int gi = i0 * D + k, gj = j0 * D + k;
-        sXi[k] = gi < c.N * D ? Xt[gi] : 0.0;
-        sXj[k] = gj < c.N * D ? Xt[gj] : 0.0;
+    tile_decode(tile % ntri, nt, ti, tj);
+    const int i0 = ti * LL_TILE + (blockIdx.x & 1) * LLU_ROWS, j0 = tj * LL_TILE;
+    const double *Xt = c.X + (size_t)t * N * D;
+    for (int k = tid; k < LLU_ROWS * D; k += LLU_THREADS) {
+        const int gi = i0 * D + k;
+        sXi[k] = gi < N * D ? Xt[gi] : 0.0;
     }
-    for (int k = tid; k < LL_TILE * 4; k += LL_THREADS) {
-        int r = k >> 2, w = k & 3, gi = i0 + r;
-        sY[k] = gi < c.N ? c.ybits[((size_t)t * c.N + gi) * c.W + (j0 >> 5) + w] : 0u;
-    }
+    const int j = j0 + tid;
+    double xj[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) xj[d] = j < N ? Xt[(size_t)j * D + d] : 0.0;
     double E[M];
 #pragma unroll
     for (int k = 0; k < M; ++k) E[k] = exp(cand.intercepts[k]);
     __syncthreads();
 
-    const int cj = tid & (LL_TILE - 1);
-    const int half = tid >> 7;
-    const int j = j0 + cj;
-    double xj[D];
-#pragma unroll
-    for (int d = 0; d < D; ++d) xj[d] = sXj[cj * D + d];
     // sum_i log(1 + E e^{-d_i}) = log prod_i (1 + E e^{-d_i}): one log per
     // `nflush` dyads (the running product stays far inside the double range)
     double Emax = E[0];
@@ -110,71 +110,75 @@ __global__ __launch_bounds__(LL_THREADS) void k_loglik_undirected(
     const double l1p = log1p(Emax);
     const int nflush = !(l1p > 0.0) ? 64 : (600.0 / l1p < 1.0 ? 1 : (600.0 / l1p > 64.0 ? 64 : (int)(600.0 / l1p)));
     constexpr int U = 4;          // rows per trip, each with its own product chain
-    double sy = 0.0, syd = 0.0, S[M], P[U][M];
+    double syd = 0.0, S[M], P[U][M];
+    int sy = 0;                   // wave-uniform count of the edges seen
 #pragma unroll
     for (int k = 0; k < M; ++k) {
         S[k] = 0.0;
 #pragma unroll
         for (int u = 0; u < U; ++u) P[u][k] = 1.0;
     }
-    if (j < c.N) {
-        // rows i = i0 + r, r in [rbeg, rend): i < j only (also stops at i >= N).  U rows
-        // per trip with independent product chains: the dependent fma / mul chains of one
-        // term are what a lone wavefront would otherwise wait on.
-        const int rbeg = half * 64;
-        const int rend = min(rbeg + 64, j - i0);
-        int cnt = 0;
-        int r = rbeg;
-        for (; r + U <= rend; r += U) {
-            double dd[U], e[U];
+    // rows r < rend of this half tile pair with column j (i < j < N)
+    const int rend = j < N ? min(LLU_ROWS, j - i0) : 0;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t *ywords = c.ybits + ((size_t)t * N) * c.W + (j0 >> 5) + 2 * wave;
+    // a half tile strictly above the diagonal with all its columns inside the network
+    // needs no per-dyad validity test
+    const bool whole = i0 + LLU_ROWS <= j0 && j0 + LL_TILE <= N;
+    int cnt = 0;
+#define DLSM_LLU_TRIPS(WHOLE_, SQ_)                                                            \
+    for (int r = 0; r < LLU_ROWS; r += U) {                                                    \
+        unsigned long long ym[U];                                                              \
+        _Pragma("unroll")                                                                      \
+        for (int u = 0; u < U; ++u)                                                            \
+            ym[u] = *(const unsigned long long *)(ywords + (size_t)min(i0 + r + u, N - 1) * c.W); \
+        double dd[U], e[U];                                                                    \
+        _Pragma("unroll")                                                                      \
+        for (int u = 0; u < U; ++u) dd[u] = dist_fast<D>(&sXi[(r + u) * D], xj, SQ_);          \
+        _Pragma("unroll")                                                                      \
+        for (int u = 0; u < U; ++u) e[u] = fast_exp(-dd[u]);                                   \
+        _Pragma("unroll")                                                                      \
+        for (int u = 0; u < U; ++u) {                                                          \
+            const bool ok = WHOLE_ || r + u < rend;                                            \
+            const unsigned long long live = WHOLE_ ? ym[u] : (ym[u] & __ballot(ok));           \
+            sy += __popcll(live);                                                              \
+            syd = fma(__builtin_amdgcn_inverse_ballot_w64(live) ? 1.0 : 0.0, dd[u], syd);      \
+            if (ok) {                                                                          \
+                _Pragma("unroll")                                                              \
+                for (int k = 0; k < M; ++k) P[u][k] *= fma(E[k], e[u], 1.0);                   \
+            }                                                                                  \
+        }                                                                                      \
+        if (++cnt >= nflush) {                                                                 \
+            _Pragma("unroll")                                                                  \
+            for (int k = 0; k < M; ++k) {                                                      \
+                _Pragma("unroll")                                                              \
+                for (int u = 0; u < U; ++u) { S[k] += log(P[u][k]); P[u][k] = 1.0; }           \
+            }                                                                                  \
+            cnt = 0;                                                                           \
+        }                                                                                      \
+    }
+    if (c.squared) { DLSM_LLU_TRIPS(false, 1) }
+    else if (whole) { DLSM_LLU_TRIPS(true, 0) }
+    else { DLSM_LLU_TRIPS(false, 0) }
+#undef DLSM_LLU_TRIPS
+    // nflush == 64: all chains together hold <= 64 factors (1 + E) <= e^(600 / 64) each
+    if (nflush >= LLU_ROWS) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) dd[u] = dist_fast<D>(&sXi[(r + u) * D], xj, c.squared);
+        for (int k = 0; k < M; ++k) {
+            double q = P[0][k];
 #pragma unroll
-            for (int u = 0; u < U; ++u) e[u] = fast_exp(-dd[u]);
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int y = (sY[(r + u) * 4 + (cj >> 5)] >> (cj & 31)) & 1;
-                if (y) { sy += 1.0; syd += dd[u]; }
-#pragma unroll
-                for (int k = 0; k < M; ++k) P[u][k] *= fma(E[k], e[u], 1.0);
-            }
-            if (++cnt >= nflush) {
-#pragma unroll
-                for (int k = 0; k < M; ++k)
-#pragma unroll
-                    for (int u = 0; u < U; ++u) { S[k] += log(P[u][k]); P[u][k] = 1.0; }
-                cnt = 0;
-            }
+            for (int u = 1; u < U; ++u) q *= P[u][k];
+            S[k] += log(q);
         }
-        for (; r < rend; ++r) {                      // < U rows left: chain 0, <= U - 1 more
-            const double d1 = dist_fast<D>(&sXi[r * D], xj, c.squared);
-            const double e1 = fast_exp(-d1);
-            const int y = (sY[r * 4 + (cj >> 5)] >> (cj & 31)) & 1;
-            if (y) { sy += 1.0; syd += d1; }
+    } else {
 #pragma unroll
-            for (int k = 0; k < M; ++k) {
-                if (P[0][k] > 1e250) { S[k] += log(P[0][k]); P[0][k] = 1.0; }
-                P[0][k] *= fma(E[k], e1, 1.0);
-            }
-        }
-        // nflush == 64: all chains together hold <= 64 factors (1 + E) <= e^(600 / 64) each
-        if (nflush >= 64) {
+        for (int k = 0; k < M; ++k)
 #pragma unroll
-            for (int k = 0; k < M; ++k) {
-                double q = P[0][k];
-#pragma unroll
-                for (int u = 1; u < U; ++u) q *= P[u][k];
-                S[k] += log(q);
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < M; ++k)
-#pragma unroll
-                for (int u = 0; u < U; ++u) S[k] += log(P[u][k]);
-        }
+            for (int u = 0; u < U; ++u) S[k] += log(P[u][k]);
     }
     double acc[2 + M];
-    acc[0] = sy; acc[1] = syd;
+    acc[0] = (tid & 63) == 0 ? (double)sy : 0.0;
+    acc[1] = syd;
 #pragma unroll
     for (int k = 0; k < M; ++k) acc[2 + k] = S[k];
 #pragma unroll
@@ -183,11 +187,8 @@ __global__ __launch_bounds__(LL_THREADS) void k_loglik_undirected(
         if ((tid & 63) == 0) sRed[(tid >> 6) * (2 + M) + q] = v;
     }
     __syncthreads();
-    if (tid < 2 + M) {
-        double s = 0.0;
-        for (int w = 0; w < 4; ++w) s += sRed[w * (2 + M) + tid];
-        partials[(size_t)blockIdx.x * (2 + M) + tid] = s;
-    }
+    if (tid < 2 + M)
+        partials[(size_t)blockIdx.x * (2 + M) + tid] = sRed[tid] + sRed[(2 + M) + tid];
 }
 
 template <int D, int M>
