@@ -241,27 +241,45 @@ __global__ __launch_bounds__(LL_THREADS) void k_loglik_directed(
     double xj[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) xj[d] = sXj[cj * D + d];
-    double L[M];
+    // eta_ij = b_in (1 - d / r_j) + b_out (1 - d / r_i) = B - d a,  a = b_in / r_j + b_out / r_i
+    // eta_ji =                                            B - d g,  g = b_in / r_i + b_out / r_j
+    // sum log((1 + e^eta_ij)(1 + e^eta_ji)) = log of a running product of (1 + E e^{-d a}) factors,
+    // E = e^B, flushed through one log before it could leave the double range; an exponent
+    // above 40 (a negative a at a large distance: the degenerate corner of the parameter space)
+    // takes the term-by-term form instead.
+    double L[M], P[M], Es[M], Bs[M], binrj[M], boutrj[M];
 #pragma unroll
-    for (int m = 0; m < M; ++m) L[m] = 0.0;
+    for (int m = 0; m < M; ++m) {
+        L[m] = 0.0; P[m] = 1.0;
+        Bs[m] = bin[m] + bout[m];
+        Es[m] = exp(Bs[m]);
+        binrj[m] = bin[m] * sRj[m][cj];
+        boutrj[m] = bout[m] * sRj[m][cj];
+    }
     if (j < c.N) {
         const int rbeg = half * 64;
-        for (int r = rbeg; r < rbeg + 64; ++r) {
-            const int i = i0 + r;
-            if (i >= j) break;
-            const double dd = dist_of<D>(&sXi[r * D], xj, c.squared);
+        const int rend = min(rbeg + 64, j - i0);
+        for (int r = rbeg; r < rend; ++r) {
+            const double dd = dist_fast<D>(&sXi[r * D], xj, c.squared);
             const double yij = (double)((sY[r * 4 + (cj >> 5)] >> (cj & 31)) & 1);
             const double yji = (double)((sYT[r * 4 + (cj >> 5)] >> (cj & 31)) & 1);
 #pragma unroll
             for (int m = 0; m < M; ++m) {
-                const double ri = sRi[m][r], rj = sRj[m][cj];
+                const double ri = sRi[m][r];
                 // i -> j : directed_likelihoods_fast.pyx:199-203
-                double eta = bin[m] * (1.0 - dd * rj) + bout[m] * (1.0 - dd * ri);
-                double e2 = bin[m] * (1.0 - dd * ri) + bout[m] * (1.0 - dd * rj);
-                L[m] += yij * eta + yji * e2 -
-                        log((1.0 + exp(eta)) * (1.0 + exp(e2)));
+                const double a = fma(bout[m], ri, binrj[m]), g = fma(bin[m], ri, boutrj[m]);
+                const double xa = -dd * a, xg = -dd * g;
+                L[m] += yij * (Bs[m] + xa) + yji * (Bs[m] + xg);
+                if (fmax(Bs[m] + xa, Bs[m] + xg) > 40.0 || !(Es[m] < 1e17)) {
+                    L[m] -= log((1.0 + exp(Bs[m] + xa)) * (1.0 + exp(Bs[m] + xg)));
+                } else {
+                    if (P[m] > 1e200) { L[m] -= log(P[m]); P[m] = 1.0; }
+                    P[m] *= fma(Es[m], fast_exp(xa), 1.0) * fma(Es[m], fast_exp(xg), 1.0);
+                }
             }
         }
+#pragma unroll
+        for (int m = 0; m < M; ++m) L[m] -= log(P[m]);
     }
 #pragma unroll
     for (int m = 0; m < M; ++m) {

@@ -87,6 +87,28 @@ __global__ __launch_bounds__(256) void k_pipe_propose(ChainView c, PipeBuf pb, I
     pr[D + 1] = 0.0;
 }
 
+// One neighbour of the directed model (both directions of the pair share the distance):
+// delta = log[(1 + E e^{-d0 a})(1 + E e^{-d0 g}) / ((1 + E e^{-d1 a})(1 + E e^{-d1 g}))]
+//         + (d0 - d1)(y_ji a + y_ij g),   E = e^{b_in + b_out}
+// (delta_directed) as factors of the running products of `ra` - no log, no division and the
+// lean exp per neighbour.  An exponent above 40 (negative a at a large distance, the
+// degenerate corner of the parameter space) goes through the exact term-by-term form into
+// `exact` instead; the products are flushed before they could leave the double range.
+__device__ __forceinline__ void pipe_directed_term(RatioAcc &ra, double &exact, double d0, double d1,
+                                                   int y_ji, int y_ij, double a, double g, double E,
+                                                   double lE) {
+    const double x0a = -d0 * a, x0g = -d0 * g, x1a = -d1 * a, x1g = -d1 * g;
+    if (fmax(fmax(x0a, x0g), fmax(x1a, x1g)) + lE > 40.0 || !(E < 1e17)) {
+        exact += delta_directed(d0, d1, y_ji, y_ij, a, g, E);
+        return;
+    }
+    if (y_ji) ra.lin += (d0 - d1) * a;
+    if (y_ij) ra.lin += (d0 - d1) * g;
+    if (fmax(ra.P0, ra.P1) > 1e200) ra.flush();
+    ra.P0 *= fma(E, fast_exp(x0a), 1.0) * fma(E, fast_exp(x0g), 1.0);
+    ra.P1 *= fma(E, fast_exp(x1a), 1.0) * fma(E, fast_exp(x1g), 1.0);
+}
+
 // flat H index f -> (node kk of the batch, entry e < ncross + kk);
 // prefix(kk) = ncross kk + kk (kk - 1) / 2 (f < 2^16: the float root is off by one at most)
 __device__ __forceinline__ void pipe_h_decode(int f, int ncross, int nb, int &kk, int &e) {
@@ -116,6 +138,7 @@ __device__ __forceinline__ void pipe_eval_item(const ChainView &c, const PipeBuf
     const uint32_t *yc = MODEL == DLSM_DIRECTED ? c.ytbits + ((size_t)t * N + jk) * W : nullptr;
     const double E = pb.consts[0];
     const int nflush = (int)pb.consts[1];
+    const double lE = MODEL == DLSM_DIRECTED ? log(E) : 0.0;       // = b_in + b_out
     double xk0[D], xk1[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) {
@@ -188,11 +211,11 @@ __device__ __forceinline__ void pipe_eval_item(const ChainView &c, const PipeBuf
             ra.P1 *= fma(E, fast_exp(-d1_), 1.0);                                             \
             if (FLUSH_) if (++ra.cnt >= nflush) ra.flush();                                   \
         } else {                                                                              \
-            const double d0_ = dist_of<D>(XI_, xk0, c.squared);                               \
-            const double d1_ = dist_of<D>(XI_, xk1, c.squared);                               \
+            const double d0_ = dist_fast<D>(XI_, xk0, c.squared);                             \
+            const double d1_ = dist_fast<D>(XI_, xk1, c.squared);                             \
             const double iri_ = 1.0 / (RI_);                                                  \
-            acc += delta_directed(d0_, d1_, (int)(YB_), (int)(YCB_), bin * iri_ + bout * irk, \
-                                  bin * irk + bout * iri_, E);                                \
+            pipe_directed_term(ra, acc, d0_, d1_, (int)(YB_), (int)(YCB_),                    \
+                               bin * iri_ + bout * irk, bin * irk + bout * iri_, E, lE);      \
         }                                                                                     \
     }
     // the running products of the whole part stay in range without a flush when it has no
@@ -250,7 +273,7 @@ __device__ __forceinline__ void pipe_eval_item(const ChainView &c, const PipeBuf
         tot_l = wave_sum_all(ra.lin + ra.lg);
         tot_r = wave_prod_all(ra.P0) / wave_prod_all(ra.P1);
     } else {
-        if (MODEL == DLSM_UNDIRECTED) acc = ra.value();
+        acc += ra.value();                       // directed: lin / products and the rare exact terms
         tot_l = wave_sum_all(acc); tot_r = 1.0;
     }
     if (lane == 0) {
@@ -300,8 +323,12 @@ __device__ __forceinline__ void pipe_eval_item(const ChainView &c, const PipeBuf
         } else {
             const double irm = 1.0 / rm, irkk = 1.0 / rk;
             const double aa = bin * irm + bout * irkk, cc = bin * irkk + bout * irm;
-            h = exp(delta_directed(b0, b1, y1, y2, aa, cc, E) -
-                    delta_directed(a0, a1, y1, y2, aa, cc, E));
+            RatioAcc rb, rq;
+            double eb = 0.0, eq = 0.0;
+            pipe_directed_term(rb, eb, b0, b1, y1, y2, aa, cc, E, lE);
+            pipe_directed_term(rq, eq, a0, a1, y1, y2, aa, cc, E, lE);
+            // exp(delta(b) - delta(a)) without the logs: the products divide out
+            h = ((rb.P0 * rq.P1) / (rb.P1 * rq.P0)) * exp((rb.lin - rq.lin) + (eb - eq));
         }
         double *dst = cross ? pb.Hx : pb.Hd;
         dst[(((size_t)bb * c.T + t) * PP_B + m) * PP_B + kk] = h;
