@@ -156,6 +156,14 @@ __device__ __forceinline__ double fast_sqrt_guarded(double s) {      // s >= SQR
 }
 __device__ __forceinline__ double fast_sqrt(double s) { return fast_sqrt_guarded(s + SQRT_GUARD); }
 
+// 1 / r for a normal, positive r (radii): v_rcp_f64 (good to 2^-25.6) + two Newton steps,
+// within an ulp of the division at a fifth of its instructions
+__device__ __forceinline__ double fast_rcp(double r) {
+    double x = __builtin_amdgcn_rcp(r);
+    x = fma(fma(-r, x, 1.0), x, x);
+    return fma(fma(-r, x, 1.0), x, x);
+}
+
 __device__ __forceinline__ double fast_exp(double x) {
     const double k = rint(x * 1.4426950408889634074);
     double r = fma(k, -6.93147180369123816490e-01, x);

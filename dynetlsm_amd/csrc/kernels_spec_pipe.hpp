@@ -152,7 +152,7 @@ __device__ __forceinline__ void pipe_eval_item(const ChainView &c, const PipeBuf
     }
     const int lo = p * pb.per, hi = min(N, lo + pb.per);
     // neighbours per lane loaded up front (the directed model carries more per neighbour)
-    constexpr int PP_NPRE = MODEL == DLSM_UNDIRECTED ? (D == 1 ? 11 : D == 2 ? 8 : D == 3 ? 6 : 4) : 3;
+    constexpr int PP_NPRE = MODEL == DLSM_UNDIRECTED ? (D == 1 ? 11 : D == 2 ? 7 : D == 3 ? 5 : 4) : 1;
     // The item is a chain of dependent latencies, so every load it will need is issued
     // before the first use: PP_NPRE neighbours per lane (clamped addresses, no
     // predication) and this lane's first H entry.
@@ -213,7 +213,7 @@ __device__ __forceinline__ void pipe_eval_item(const ChainView &c, const PipeBuf
         } else {                                                                              \
             const double d0_ = dist_fast<D>(XI_, xk0, c.squared);                             \
             const double d1_ = dist_fast<D>(XI_, xk1, c.squared);                             \
-            const double iri_ = 1.0 / (RI_);                                                  \
+            const double iri_ = fast_rcp(RI_);                                                \
             pipe_directed_term(ra, acc, d0_, d1_, (int)(YB_), (int)(YCB_),                    \
                                bin * iri_ + bout * irk, bin * irk + bout * iri_, E, lE);      \
         }                                                                                     \
@@ -242,6 +242,15 @@ __device__ __forceinline__ void pipe_eval_item(const ChainView &c, const PipeBuf
                                  : (bool)bit_of(yr, min(i_, N - 1));                          \
         const bool ycb_ = MODEL != DLSM_DIRECTED ? false :                                    \
             (in_seg_ ? __builtin_amdgcn_inverse_ballot_w64(ycm_) : (bool)bit_of(yc, min(i_, N - 1)));
+#define DLSM_PIPE_REQUEST(U_)                                                                 \
+    {                                                                                         \
+        const int in_ = min(lo + 64 * (U_) + lane, N - 1);                                    \
+        const double *src_ = in_ < jprev ? Xt + (size_t)in_ * D                               \
+                                         : props + (size_t)in_ * PW + D + 2;                  \
+        _Pragma("unroll")                                                                     \
+        for (int d = 0; d < D; ++d) xn[d] = src_[d];                                          \
+        if (MODEL == DLSM_DIRECTED) rn = c.radii[in_];                                        \
+    }
 #define DLSM_PIPE_LOOPS(FLUSH_, SQ_)                                                          \
     _Pragma("unroll")                                                                         \
     for (int u = 0; u < PP_NPRE; ++u) {                                                       \
@@ -249,15 +258,29 @@ __device__ __forceinline__ void pipe_eval_item(const ChainView &c, const PipeBuf
         if (__builtin_amdgcn_inverse_ballot_w64(vm_))                                         \
             DLSM_PIPE_TERM(xpre[u], yb_, ycb_, rpre[MODEL == DLSM_DIRECTED ? u : 0], FLUSH_, SQ_) \
     }                                                                                         \
+    /* the trips beyond the prefetched ones.  Directed model (3 prefetched trips only, a       \
+       radius per neighbour): each trip requests the next one's operands (clamped address, no \
+       predication) before it computes.  Undirected: 8 of the 11 trips at C2 are prefetched   \
+       and the extra registers of the pipelined form cost more than the 3 exposed loads. */   \
+    double xn[D], rn = 1.0;                                                                   \
+    if (MODEL == DLSM_DIRECTED) DLSM_PIPE_REQUEST(PP_NPRE)                                    \
     for (int u = PP_NPRE; lo + 64 * u < hi; ++u) {                                            \
+        double xi[D];                                                                         \
+        double ri = 1.0;                                                                      \
+        if (MODEL == DLSM_DIRECTED) {                                                         \
+            _Pragma("unroll")                                                                 \
+            for (int d = 0; d < D; ++d) xi[d] = xn[d];                                        \
+            ri = rn;                                                                          \
+            DLSM_PIPE_REQUEST(u + 1)                                                          \
+        }                                                                                     \
         DLSM_PIPE_MASKS(u)                                                                    \
         if (__builtin_amdgcn_inverse_ballot_w64(vm_)) {                                       \
-            const double *src = i_ < jprev ? Xt + (size_t)i_ * D                              \
-                                           : props + (size_t)i_ * PW + D + 2;                 \
-            double xi[D];                                                                     \
-            _Pragma("unroll")                                                                 \
-            for (int d = 0; d < D; ++d) xi[d] = src[d];                                       \
-            const double ri = MODEL == DLSM_DIRECTED ? c.radii[i_] : 1.0;                     \
+            if (MODEL != DLSM_DIRECTED) {                                                     \
+                const double *src = i_ < jprev ? Xt + (size_t)i_ * D                          \
+                                               : props + (size_t)i_ * PW + D + 2;             \
+                _Pragma("unroll")                                                             \
+                for (int d = 0; d < D; ++d) xi[d] = src[d];                                   \
+            }                                                                                 \
             DLSM_PIPE_TERM(xi, yb_, ycb_, ri, FLUSH_, SQ_)                                    \
         }                                                                                     \
     }
@@ -265,6 +288,7 @@ __device__ __forceinline__ void pipe_eval_item(const ChainView &c, const PipeBuf
     else if (c.squared) { DLSM_PIPE_LOOPS(true, 1) }
     else { DLSM_PIPE_LOOPS(true, 0) }
 #undef DLSM_PIPE_LOOPS
+#undef DLSM_PIPE_REQUEST
 #undef DLSM_PIPE_MASKS
 #undef DLSM_PIPE_TERM
     double tot_l, tot_r;
