@@ -106,6 +106,42 @@ def test_function_seam_dtype_rules(eng):
         nl.directed_partial_loglikelihood(Yd[0].T, X[0], radii, 0.1, 0.2, 0)
 
 
+def test_directed_large_exponent_corner(eng):
+    """A negative in-intercept with small radii makes a = b_in / r_j + b_out / r_i negative, so
+    eta grows with the distance and passes 40, where the running-product form of the directed
+    kernels (log-likelihood pass, pipelined evaluator and its H entries) hands over to the
+    term-by-term form; both forms within one evaluation here."""
+    T, N, D = 2, 600, 2
+    X, Yd, Yu, radii = _rand_net(123, T, N, D, scale=0.02)
+    b_in, b_out = -2.0, 0.7
+    with eng.Chain(T, N, D, 'directed', seed=5) as c:
+        c.upload_network(Yd); c.set_positions(X); c.set_radii(radii)
+        c.set_intercepts([b_in, b_out])
+        # the corner is really exercised: some exponents above 40, most below
+        d = np.sqrt(((X[0][:, None] - X[0][None]) ** 2).sum(-1))
+        eta = b_in * (1 - d / radii[None, :]) + b_out * (1 - d / radii[:, None])
+        assert (eta > 40).mean() > 0.01 and (eta < 40).mean() > 0.2
+        got = c.loglik_full([[b_in, b_out], [0.2, 0.4]])
+        want = [orc.dynamic_network_loglikelihood_directed(Yd, X, a, b, radii)
+                for a, b in ((b_in, b_out), (0.2, 0.4))]
+        np.testing.assert_allclose(got, want, rtol=RTOL_LL)
+        # a sweep: the pipelined form against the per-slice kernel (same decisions).  One sweep
+        # only: log-ratios of several hundred are outside what the multiplicative accept test
+        # of the pipelined form is specified for (its exponent clamps at +-700, DESIGN 4.4b),
+        # and this corner drives the positions there.
+        c.set_prior_random_walk(2.0, 0.1)
+        c.set_samplers(eng.SamplerGrid(T, N, 0.02, tune=None))
+        c.sweep_positions(1, 4)
+        X4 = c.get_positions()
+        acc4 = c.get_samplers(eng.SamplerGrid(T, N, 0.02, tune=None)).n_accepted.copy()
+        c.set_positions(X)
+        c.set_samplers(eng.SamplerGrid(T, N, 0.02, tune=None))
+        c.sweep_positions(1, 1)
+        acc1 = c.get_samplers(eng.SamplerGrid(T, N, 0.02, tune=None)).n_accepted
+        np.testing.assert_array_equal(acc4, acc1)
+        np.testing.assert_allclose(X4, c.get_positions(), atol=1e-12)
+
+
 # ------------------------------------------------------------ full log-lik
 @pytest.mark.parametrize('N', [7, 128, 129, 300])
 @pytest.mark.parametrize('D', [1, 2, 3, 4])
@@ -276,10 +312,11 @@ def test_sweep_slice_medium(eng, name, N, D):
 
 
 def test_sweep_squared_distances(eng):
-    """squared=True (static_network_fast.pyx:37-38) through both sweep kernels"""
+    """squared=True (static_network_fast.pyx:37-38) through every sweep kernel (the pipelined
+    evaluator and the log-likelihood pass have their own squared-distance loops)"""
     from dynetlsm_amd import Chain, SamplerGrid
     X, Yd, Yu, radii = _rand_net(77, 3, 200, 2)
-    for algo in (1, 2):
+    for algo in (1, 2, 3, 4):
         og = orc.SamplerGrid(3, 200, 0.1, tune=None)
         st = orc.ChainState(X, og, Y=Yu, intercept=[0.5], squared=True, tau_sq=2.0,
                             sigma_sq=0.1, seed=8, chain=0)
