@@ -330,22 +330,27 @@ __global__ __launch_bounds__(256) void k_loglik_casecontrol(
             iri[m] = 1.0 / cand.radii[m][i];
         }
         // sum log(1 + e^eta) = log prod (1 + e^eta): per-lane running products, flushed
-        // through one log before they could leave the double range (eta is clamped at
-        // +-700 for the exp only; a factor is then at most e^700)
+        // through one log before they could leave the double range (a factor is at most
+        // e^130: beyond that log(1 + e^eta) = eta to the last bit and is added as such)
         double Pe[M], Pc[M];
 #pragma unroll
         for (int m = 0; m < M; ++m) { Pe[m] = 1.0; Pc[m] = 1.0; }
         // out edges : directed_likelihoods_fast.pyx:236-247
         for (int k = lane; k < out_deg; k += 64) {
             const int e = oe[k];
-            const double dd = dist_of<D>(&Xt[(size_t)e * D], xi, c.squared);
+            const double dd = dist_fast<D>(&Xt[(size_t)e * D], xi, c.squared);
+            double ire[M];              // 1 / r_e per candidate (one reciprocal when they share radii)
+            ire[0] = fast_rcp(cand.radii[0][e]);
+#pragma unroll
+            for (int m = 1; m < M; ++m)
+                ire[m] = cand.radii[m] == cand.radii[0] ? ire[0] : fast_rcp(cand.radii[m][e]);
 #pragma unroll
             for (int m = 0; m < M; ++m) {
-                const double eta = bin[m] * (1.0 - dd / cand.radii[m][e]) +
-                                   bout[m] * (1.0 - dd * iri[m]);
+                const double eta = bin[m] * (1.0 - dd * ire[m]) + bout[m] * (1.0 - dd * iri[m]);
                 L[m] += eta;
+                if (eta > 130.0) { L[m] -= eta; continue; }      // log(1 + e^eta) = eta there
                 if (Pe[m] > 1e250) { L[m] -= log(Pe[m]); Pe[m] = 1.0; }
-                Pe[m] *= 1.0 + fast_exp(fmin(fmax(eta, -700.0), 700.0));
+                Pe[m] *= 1.0 + fast_exp(fmax(eta, -700.0));
             }
         }
 #pragma unroll
@@ -363,13 +368,18 @@ __global__ __launch_bounds__(256) void k_loglik_casecontrol(
             unsigned long long inv = ~valid;
             int first_bad = inv ? __builtin_ctzll(inv) : 64;
             if (lane < first_bad) {
-                const double dd = dist_of<D>(&Xt[(size_t)e * D], xi, c.squared);
+                const double dd = dist_fast<D>(&Xt[(size_t)e * D], xi, c.squared);
+                double ire[M];
+                ire[0] = fast_rcp(cand.radii[0][e]);
+#pragma unroll
+                for (int m = 1; m < M; ++m)
+                    ire[m] = cand.radii[m] == cand.radii[0] ? ire[0] : fast_rcp(cand.radii[m][e]);
 #pragma unroll
                 for (int m = 0; m < M; ++m) {
-                    const double eta = bin[m] * (1.0 - dd / cand.radii[m][e]) +
-                                       bout[m] * (1.0 - dd * iri[m]);
+                    const double eta = bin[m] * (1.0 - dd * ire[m]) + bout[m] * (1.0 - dd * iri[m]);
+                    if (eta > 130.0) { ctl[m] += eta; continue; }
                     if (Pc[m] > 1e250) { ctl[m] += log(Pc[m]); Pc[m] = 1.0; }
-                    Pc[m] *= 1.0 + fast_exp(fmin(fmax(eta, -700.0), 700.0));
+                    Pc[m] *= 1.0 + fast_exp(fmax(eta, -700.0));
                 }
             }
             nctl += first_bad;
