@@ -146,9 +146,7 @@ def main():
             k_ms = ms_ev / n_ev
             # the eval launches carry their own start/stop events (hipExtLaunchKernelGGL):
             # the dispatch's begin/end timestamps, which is what the rocprofv3 kernel
-            # trace reports.  The in-kernel wall-clock stamps (first workgroup start to
-            # last workgroup end) are reported next to it.
-            st_us, st_n = chain.profile_read_eval_stamps()
+            # trace reports
             k_bytes = sweep_bytes / launches
         else:
             launches = 2.0
@@ -164,7 +162,6 @@ def main():
                     'achieved': round(ach, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                     'frac': round(ach / HBM_PEAK_GBS, 5), 'traffic': traffic,
                     'us_per_launch': round(1e3 * k_ms, 3),
-                    'us_per_launch_in_kernel_stamps': round(st_us, 3) if n_ev > 0 and st_n > 0 else None,
                     'launches_per_sweep': launches,
                     'algorithmic_bytes_per_launch': round(k_bytes, 1),
                     'sweep_GBps_all_launches': round(sweep_bytes / (sweep_ms * 1e-3) / 1e9, 2),
@@ -172,7 +169,8 @@ def main():
                     # pairwise terms (distance + exp) evaluated per second over the sweep,
                     # 2 (proposal, current) x T x N x (N - 1) per sweep
                     'dyad_terms_per_s': round(2.0 * T * N * (N - 1) / (sweep_ms * 1e-3), 0)}
-        extra_r = {'us_resolve_per_launch': round(1e3 * ms_rs / max(n_rs, 1), 3)}
+        # algo 2 / 3 only: their resolve launches (algo 4 resolves inside the fused launch)
+        extra_r = {'us_resolve_per_launch': round(1e3 * ms_rs / n_rs, 3)} if n_rs > 0 else {}
         extra = {'ms_per_loglik_eval': round(ll_ms, 4),
                  'loglik_eval_GBps': round(ll_bytes / (ll_ms * 1e-3) / 1e9, 1),
                  'ms_sweep': round(sweep_ms, 4), 'ms_post_sweep': round(ms_ps / max(n_ps, 1), 4),
