@@ -92,17 +92,47 @@ int dev_alloc(dlsm_chain *h, T **p, size_t n) {
     return DLSM_OK;
 }
 
+// Host <-> device copies of the C-ABI, synchronous at return.  The caller's arrays are
+// pageable memory, for which the runtime's own staging is slow at these sizes
+// (profiles/micro/copy_paths.cpp: 32 KB up 39 us against 10 us from pinned memory, a
+// few bytes down 25 us against 12 us), so small copies go through the handle's pinned buffer.
+constexpr size_t STAGE_BYTES = 256 * 1024;
+constexpr size_t STAGE_D2H_MAX = 64 * 1024;    // beyond it the extra memcpy costs what it saves
+
 template <typename T>
 int h2d(dlsm_chain *h, T *dst, const T *src, size_t n) {
-    HIPCHK(h, hipMemcpyAsync(dst, src, n * sizeof(T), hipMemcpyHostToDevice, h->stream));
+    const size_t bytes = n * sizeof(T);
+    const void *from = src;
+    if (h->stage && bytes <= STAGE_BYTES) { memcpy(h->stage, src, bytes); from = h->stage; }
+    HIPCHK(h, hipMemcpyAsync(dst, from, bytes, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return DLSM_OK;
 }
 
 template <typename T>
 int d2h(dlsm_chain *h, T *dst, const T *src, size_t n) {
-    HIPCHK(h, hipMemcpyAsync(dst, src, n * sizeof(T), hipMemcpyDeviceToHost, h->stream));
+    const size_t bytes = n * sizeof(T);
+    const bool staged = h->stage && bytes <= STAGE_D2H_MAX;
+    HIPCHK(h, hipMemcpyAsync(staged ? h->stage : (void *)dst, src, bytes, hipMemcpyDeviceToHost,
+                             h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (staged) memcpy(dst, h->stage, bytes);
+    return DLSM_OK;
+}
+
+// Several small uploads ahead of a launch: each takes the next slice of the pinned buffer and is
+// only enqueued (the synchronous d2h that ends the call, or the caller, waits for them).
+// `*off` = bytes of the buffer in use; a copy that does not fit goes the runtime's way.
+template <typename T>
+int h2d_enqueue(dlsm_chain *h, T *dst, const T *src, size_t n, size_t *off) {
+    const size_t bytes = n * sizeof(T);
+    const void *from = src;
+    if (h->stage && *off + bytes <= STAGE_BYTES) {
+        from = (char *)h->stage + *off;
+        memcpy((void *)from, src, bytes);
+        *off += (bytes + 255) & ~(size_t)255;
+    }
+    HIPCHK(h, hipMemcpyAsync(dst, from, bytes, hipMemcpyHostToDevice, h->stream));
     return DLSM_OK;
 }
 
@@ -239,6 +269,8 @@ int dlsm_create(int device, int T, int N, int D, int model, uint64_t seed,
     auto bail = [&](int rc) { g_err = h->err; dlsm_destroy(h); return rc; };
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess)
         { h->err = "hipStreamCreate failed"; return bail(DLSM_E_HIP); }
+    if (hipHostMalloc(&h->stage, STAGE_BYTES, hipHostMallocDefault) != hipSuccess)
+        h->stage = nullptr;                     // the copies then take the runtime's path
     const size_t TN = (size_t)T * N;
     int rc = 0;
     rc |= dev_alloc(h, &h->X, TN * D);
@@ -287,6 +319,7 @@ void dlsm_destroy(dlsm_chain *h) {
     if (h->graph_exec) hipGraphExecDestroy(h->graph_exec);
     if (h->graph) hipGraphDestroy(h->graph);
     if (h->stream) hipStreamDestroy(h->stream);
+    if (h->stage) hipHostFree(h->stage);
     delete h;
 }
 
@@ -1042,7 +1075,8 @@ int dlsm_sample_labels(dlsm_chain *h, uint32_t iter, const double *w, int64_t *z
         FAIL(h, DLSM_E_LIMIT, "T*K=%d too large for the label kernel", T * K);
     const bool w_lds = lds_tables + lds_w <= 80 * 1024;     // two workgroups per CU
     const size_t lds = lds_tables + (w_lds ? lds_w : 0);
-    HIPCHK(h, hipMemcpyAsync(h->lab_w, w, nn * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    size_t staged = 0;
+    { int rc = h2d_enqueue(h, h->lab_w, w, nn, &staged); if (rc) return rc; }
     ChainView v = h->view();
     {
         ProfScope ps(h, DLSM_K_LABELS);
@@ -1058,7 +1092,25 @@ int dlsm_sample_labels(dlsm_chain *h, uint32_t iter, const double *w, int64_t *z
                            (int32_t *)h->lab_n, (int32_t *)h->lab_nk);
     }
     HIPCHK(h, hipGetLastError());
-    std::vector<int32_t> zz((size_t)T * N), cn(nn), cnk(nnk);
+    // labels and counts come back as int32 in one batch: into the pinned buffer behind one
+    // synchronisation when they fit, converted from there
+    const size_t ntn = (size_t)T * N;
+    const size_t b_z = ntn * sizeof(int32_t), b_n = nn * sizeof(int32_t), b_nk = nnk * sizeof(int32_t);
+    const size_t o_n = (b_z + 255) & ~(size_t)255, o_nk = o_n + ((b_n + 255) & ~(size_t)255);
+    if (h->stage && o_nk + b_nk <= STAGE_BYTES) {
+        char *st = (char *)h->stage;
+        HIPCHK(h, hipMemcpyAsync(st, h->z, b_z, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipMemcpyAsync(st + o_n, h->lab_n, b_n, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipMemcpyAsync(st + o_nk, h->lab_nk, b_nk, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        const int32_t *zz = (const int32_t *)st, *cn = (const int32_t *)(st + o_n),
+                      *cnk = (const int32_t *)(st + o_nk);
+        for (size_t i = 0; i < ntn; ++i) z[i] = zz[i];
+        for (size_t i = 0; i < nn; ++i) n[i] = (double)cn[i];
+        for (size_t i = 0; i < nnk; ++i) nk[i] = cnk[i];
+        return DLSM_OK;
+    }
+    std::vector<int32_t> zz(ntn), cn(nn), cnk(nnk);
     int rc = d2h(h, zz.data(), h->z, zz.size()); if (rc) return rc;
     rc = d2h(h, cn.data(), h->lab_n, nn); if (rc) return rc;
     rc = d2h(h, cnk.data(), h->lab_nk, nnk); if (rc) return rc;
@@ -1307,10 +1359,10 @@ int dlsm_hdp_label_sums(dlsm_chain *h, int stage, const double *mu, const double
     int rc = ensure_partials(h, n_out + n_mu + K + n_w); if (rc) return rc;
     double *d_out = h->partials, *d_mu = d_out + n_out, *d_sigma = d_mu + n_mu,
            *d_w = d_sigma + K;
-    if (mu) HIPCHK(h, hipMemcpyAsync(d_mu, mu, n_mu * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    if (sigma) HIPCHK(h, hipMemcpyAsync(d_sigma, sigma, K * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    if (stage == HDP_SUMS_LOGP)
-        HIPCHK(h, hipMemcpyAsync(d_w, w, n_w * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    size_t staged = 0;
+    if (mu) { rc = h2d_enqueue(h, d_mu, mu, n_mu, &staged); if (rc) return rc; }
+    if (sigma) { rc = h2d_enqueue(h, d_sigma, sigma, (size_t)K, &staged); if (rc) return rc; }
+    if (stage == HDP_SUMS_LOGP) { rc = h2d_enqueue(h, d_w, w, n_w, &staged); if (rc) return rc; }
     ChainView v = h->view();
     HdpParams hp{d_mu, d_sigma, d_w, lmbda, a, b};
     const dim3 grid(K, T), block(HDP_THREADS);
