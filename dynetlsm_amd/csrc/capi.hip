@@ -562,13 +562,16 @@ int dlsm_set_prior_mixture(dlsm_chain *h, const double *mu, const double *sigma,
         rc = dev_alloc(h, &h->sigma, K); if (rc) return rc;
         h->K = K;
     }
-    int rc = h2d(h, h->mu, mu, (size_t)K * h->D); if (rc) return rc;
-    rc = h2d(h, h->sigma, sigma, K); if (rc) return rc;
+    size_t staged = 0;                          // one synchronisation for the whole upload
+    int rc = h2d_enqueue(h, h->mu, mu, (size_t)K * h->D, &staged); if (rc) return rc;
+    rc = h2d_enqueue(h, h->sigma, sigma, (size_t)K, &staged); if (rc) return rc;
+    std::vector<int32_t> zz;
     if (z) {
-        std::vector<int32_t> zz(TN);
+        zz.resize(TN);
         for (size_t i = 0; i < TN; ++i) zz[i] = (int32_t)z[i];
-        rc = h2d(h, h->z, zz.data(), TN); if (rc) return rc;
+        rc = h2d_enqueue(h, h->z, zz.data(), TN, &staged); if (rc) return rc;
     }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
     h->lmbda = lmbda;
     h->prior_kind = DLSM_PRIOR_MIXTURE;
     h->have_prior = true;
