@@ -138,7 +138,6 @@ __device__ __forceinline__ void pipe_eval_item(const ChainView &c, const PipeBuf
     const uint32_t *yc = MODEL == DLSM_DIRECTED ? c.ytbits + ((size_t)t * N + jk) * W : nullptr;
     const double E = pb.consts[0];
     const int nflush = (int)pb.consts[1];
-    const double lE = MODEL == DLSM_DIRECTED ? log(E) : 0.0;       // = b_in + b_out
     double xk0[D], xk1[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) {
@@ -150,6 +149,7 @@ __device__ __forceinline__ void pipe_eval_item(const ChainView &c, const PipeBuf
         bin = c.intercept[0]; bout = c.intercept[1];
         irk = 1.0 / c.radii[jk];
     }
+    const double lE = bin + bout;              // log E (directed model)
     const int lo = p * pb.per, hi = min(N, lo + pb.per);
     // neighbours per lane loaded up front (the directed model carries more per neighbour)
     constexpr int PP_NPRE = MODEL == DLSM_UNDIRECTED ? (D == 1 ? 11 : D == 2 ? 7 : D == 3 ? 5 : 4) : 1;
