@@ -1227,14 +1227,18 @@ static int enqueue_lsm_iteration(dlsm_chain *h, int it, bool counter, int procru
         ChainView v = h->view();
         double *ll2 = h->dsmall + 16;
         ProfScope ps(h, DLSM_K_FINALIZE);
+        // The sweep moved the positions, so the first step evaluates proposal and current
+        // state; after it the current state's log-likelihood is carried (lsm->ll_cur) and the
+        // later steps evaluate their proposal only: 4 candidate evaluations, not 6.
         for (int which = 0; which < 2; ++which) {
+            const int M = which == 0 ? 2 : 1;
             hipLaunchKernelGGL(k_dir_propose_intercept, dim3(1), dim3(1), 0, h->stream, v, h->lsm,
                                h->intercept, which, ir);
-            rc = loglik_records(h, 2, h->lsm->cand, h->radii, h->radii, &nrec); if (rc) return rc;
+            rc = loglik_records(h, M, h->lsm->cand, h->radii, h->radii, &nrec); if (rc) return rc;
             hipLaunchKernelGGL(k_reduce_loglik, dim3(1), dim3(256), 0, h->stream, h->partials, nrec,
-                               h->model, 2, h->lsm->cand, ll2);
+                               h->model, M, h->lsm->cand, ll2);
             hipLaunchKernelGGL(k_dir_accept_intercept, dim3(1), dim3(1), 0, h->stream, ll2, h->lsm,
-                               h->intercept, which);
+                               h->intercept, which, which);
         }
         {   // scaled-Dirichlet proposal: records live behind the log-likelihood records
             const int nblk = (h->N + DP_THREADS - 1) / DP_THREADS;
@@ -1248,14 +1252,10 @@ static int enqueue_lsm_iteration(dlsm_chain *h, int it, bool counter, int procru
             hipLaunchKernelGGL(k_dir_radii_finish, dim3(1), dim3(DR_THREADS), 0, h->stream, v,
                                h->lsm, h->radii, h->radii_alt, rec2, nblk, ir);
         }
-        // both candidates at the current intercepts: [b | b] from the handle's intercept
-        HIPCHK(h, hipMemcpyAsync(h->dsmall, h->intercept, 2 * sizeof(double),
-                                 hipMemcpyDeviceToDevice, h->stream));
-        HIPCHK(h, hipMemcpyAsync(h->dsmall + 2, h->intercept, 2 * sizeof(double),
-                                 hipMemcpyDeviceToDevice, h->stream));
-        rc = loglik_records(h, 2, h->dsmall, h->radii, h->radii_alt, &nrec); if (rc) return rc;
+        // the proposed radii at the current intercepts (one candidate)
+        rc = loglik_records(h, 1, h->intercept, h->radii_alt, h->radii_alt, &nrec); if (rc) return rc;
         hipLaunchKernelGGL(k_reduce_loglik, dim3(1), dim3(256), 0, h->stream, h->partials, nrec,
-                           h->model, 2, h->dsmall, ll2);
+                           h->model, 1, h->intercept, ll2);
         hipLaunchKernelGGL(k_dir_accept_radii, dim3(1), dim3(DR_THREADS), 0, h->stream, ll2, v,
                            h->lsm, h->radii, h->radii_alt, h->intercept, h->trace_ic,
                            h->trace_radii, h->trace_logp, ir);

@@ -41,16 +41,19 @@ __global__ void k_dir_propose_intercept(ChainView c, LsmDeviceState *lsm,
     lsm->logu = log(u0);
 }
 
-// ll[0] at the proposal, ll[1] at the current intercepts
+// ll[0] at the proposal; at the current intercepts ll[1], or - `carried` - the value the
+// previous step of this iteration left in lsm->ll_cur (same positions, same parameters: the
+// pass that would recompute it is skipped)
 __global__ void k_dir_accept_intercept(const double *__restrict__ ll, LsmDeviceState *lsm,
-                                       double *__restrict__ intercept, int which) {
+                                       double *__restrict__ intercept, int which, int carried) {
     const double prop = lsm->cand[which], cur = lsm->cand[2 + which];
     const double pm = lsm->intercept_prior[which], v = lsm->intercept_var;
+    const double ll_cur = carried ? lsm->ll_cur : ll[1];
     const double ratio = (ll[0] - (prop - pm) * (prop - pm) / (2 * v)) -
-                         (ll[1] - (cur - pm) * (cur - pm) / (2 * v));
+                         (ll_cur - (cur - pm) * (cur - pm) / (2 * v));
     const int accepted = !(lsm->logu >= ratio);
     if (accepted) intercept[which] = prop;
-    lsm->ll_cur = accepted ? ll[0] : ll[1];
+    lsm->ll_cur = accepted ? ll[0] : ll_cur;
     double st = lsm->i_step[which];
     int32_t na = lsm->i_nacc[which], ns = lsm->i_nsteps[which], un = lsm->i_until[which];
     metropolis_bookkeeping(st, na, ns, un, lsm->i_tune, lsm->i_tune_interval, accepted);
@@ -188,7 +191,9 @@ __global__ __launch_bounds__(DR_THREADS) void k_dir_accept_radii(
     double *__restrict__ trace_logp, IterRef ir) {
     const int it = (int)ir.get();
     const int tid = threadIdx.x, N = c.N;
-    const int accepted = !(lsm->logu >= (ll[1] - ll[0]) + lsm->dir_q);
+    // ll[0]: at the proposed radii; at the current ones, the value the intercept steps left
+    const double ll_now = lsm->ll_cur;
+    const int accepted = !(lsm->logu >= (ll[0] - ll_now) + lsm->dir_q);
     double *row = trace_radii + (size_t)it * N;
     for (int i = tid; i < N; i += DR_THREADS) {
         const double r = accepted ? radii_alt[i] : radii[i];
@@ -196,7 +201,7 @@ __global__ __launch_bounds__(DR_THREADS) void k_dir_accept_radii(
         row[i] = r;
     }
     if (tid == 0) {
-        const double llf = accepted ? ll[1] : ll[0];
+        const double llf = accepted ? ll[0] : ll_now;
         double st = lsm->r_step;
         int32_t na = lsm->r_nacc, ns = lsm->r_nsteps, un = lsm->r_until;
         na += accepted; ns += 1;
