@@ -206,3 +206,53 @@ def test_c2_init_pipeline_at_full_size(eng, c2):
         Xo, eo = io.gmds_step(c.init_get_dissimilarity(1), Xp)
         np.testing.assert_allclose(evals, eo, rtol=1e-10)
         assert np.abs(X1 - Xo).max() < 1e-9 * np.abs(Xo).max(), info
+
+
+def test_directed_exact_at_full_size(eng):
+    """T=10, N=2000 exact directed model: the running-product forms of the log-likelihood pass
+    and of the pipelined evaluator against the C oracle and the per-slice kernel, and the
+    device-resident loop's carried log-likelihood against a fresh evaluation of its last state."""
+    from dynetlsm_amd.synthetic import synthetic_lsm_network
+    net = synthetic_lsm_network(T=10, N=2000, D=2, density=0.03, seed=3)
+    T, N, D = 10, 2000, 2
+    rng = np.random.RandomState(7)
+    Yd = (net['Y'] * (rng.rand(T, N, N) < 0.7)).astype(np.float64)      # asymmetric
+    X = net['X_init'] * 0.01
+    radii = rng.dirichlet(np.ones(N) * 5)
+    b = np.array([0.4, 0.9])
+    out = {}
+    for algo in (1, 4):
+        g = eng.SamplerGrid(T, N, 0.002, tune=None)
+        with eng.Chain(T, N, D, 'directed', seed=21, chain_id=1) as c:
+            c.upload_network(Yd); c.set_positions(X); c.set_radii(radii); c.set_intercepts(b)
+            if algo == 1:
+                got = c.loglik_full([b, b + 0.2])
+                want = [orc.dynamic_network_loglikelihood_directed(Yd, X, v[0], v[1], radii)
+                        for v in (b, b + 0.2)]
+                np.testing.assert_allclose(got, want, rtol=1e-10)
+            c.set_prior_random_walk(2.0, 0.1); c.set_samplers(g)
+            for it in (1, 2):
+                c.sweep_positions(it, algo)
+            out[algo] = (c.get_positions(), c.get_samplers(g).n_accepted.copy())
+    np.testing.assert_array_equal(out[1][1], out[4][1])
+    np.testing.assert_allclose(out[1][0], out[4][0], atol=1e-12)
+    assert 0.05 < out[4][1].mean() / 2 < 0.999
+    # the device-resident loop: logp trace = fresh log-likelihood at the stored state + priors
+    n_it = 6
+    with eng.Chain(T, N, D, 'directed', seed=21, chain_id=1) as c:
+        c.upload_network(Yd); c.set_positions(X); c.set_radii(radii); c.set_intercepts(b)
+        c.set_prior_random_walk(2.0, 0.1)
+        c.set_samplers(eng.SamplerGrid(T, N, 0.002, tune=None))
+        c.lsm_configure([0.0, 0.0], 2.0, step_size_intercept=0.05, tune=None, sweep_algo=4)
+        c.trace_alloc(n_it + 1)
+        c.lsm_run(1, n_it)
+        Xs, ics, lps = c.trace_read(0, n_it + 1)
+        rad = c.trace_read_radii(0, n_it + 1)
+        for it in (1, n_it):
+            ll = orc.dynamic_network_loglikelihood_directed(Yd, Xs[it], ics[it, 0], ics[it, 1],
+                                                            rad[it])
+            x = Xs[it]
+            prior = (-0.5 * np.sum(x[0] ** 2) / 2.0 -
+                     0.5 * np.sum((x[1:] - x[:-1]) ** 2) / 0.1 -
+                     0.5 * np.sum(ics[it] ** 2) / 2.0)
+            np.testing.assert_allclose(lps[it], ll + prior, rtol=1e-10)
