@@ -186,18 +186,20 @@ __device__ __forceinline__ void pipe_eval_item(const ChainView &c, const PipeBuf
     const int hm_0 = hcross0 ? he : he - ncross;
     const int jm0 = (hcross0 ? jprev : j0) + hm_0;
     const int jkk0 = j0 + hkk;
+    // (the directed items are short of registers: their H operands are loaded where they are used)
+    constexpr bool HPRE = MODEL == DLSM_UNDIRECTED;
     double hm0[D], hm1[D], hk0[D], hk1[D];
+    uint32_t hw = 0u;
+    if (HPRE) {
 #pragma unroll
-    for (int d = 0; d < D; ++d) {
-        hm0[d] = props[(size_t)jm0 * PW + D + 2 + d];
-        hm1[d] = props[(size_t)jm0 * PW + d];
-        hk0[d] = props[(size_t)jkk0 * PW + D + 2 + d];
-        hk1[d] = props[(size_t)jkk0 * PW + d];
+        for (int d = 0; d < D; ++d) {
+            hm0[d] = props[(size_t)jm0 * PW + D + 2 + d];
+            hm1[d] = props[(size_t)jm0 * PW + d];
+            hk0[d] = props[(size_t)jkk0 * PW + D + 2 + d];
+            hk1[d] = props[(size_t)jkk0 * PW + d];
+        }
+        hw = c.ybits[((size_t)t * N + jkk0) * W + (jm0 >> 5)];
     }
-    const uint32_t hw = c.ybits[((size_t)t * N + jkk0) * W + (jm0 >> 5)];
-    const uint32_t hwc = MODEL == DLSM_DIRECTED ? c.ytbits[((size_t)t * N + jkk0) * W + (jm0 >> 5)] : 0u;
-    const double hr = MODEL == DLSM_DIRECTED ? c.radii[jm0] : 1.0;
-    const double hrk = MODEL == DLSM_DIRECTED ? c.radii[jkk0] : 1.0;
 
     double acc = 0.0;
     RatioAcc ra;
@@ -309,13 +311,13 @@ __device__ __forceinline__ void pipe_eval_item(const ChainView &c, const PipeBuf
         int kk, e;
         double xm0[D], xm1[D], xa0[D], xa1[D], rm, rk;
         int y1, y2;
-        if (f == hf0) {
+        if (HPRE && f == hf0) {
             kk = hkk; e = he;
 #pragma unroll
             for (int d = 0; d < D; ++d) {
                 xm0[d] = hm0[d]; xm1[d] = hm1[d]; xa0[d] = hk0[d]; xa1[d] = hk1[d];
             }
-            y1 = (hw >> (jm0 & 31)) & 1; y2 = (hwc >> (jm0 & 31)) & 1; rm = hr; rk = hrk;
+            y1 = (hw >> (jm0 & 31)) & 1; y2 = 0; rm = 1.0; rk = 1.0;
         } else {
             pipe_h_decode(f, ncross, nb, kk, e);
             const int jm_ = (e < ncross ? jprev : j0) + (e < ncross ? e : e - ncross);
