@@ -152,10 +152,10 @@ __device__ __forceinline__ void pipe_eval_item(const ChainView &c, const PipeBuf
     const double lE = bin + bout;              // log E (directed model)
     const int lo = p * pb.per, hi = min(N, lo + pb.per);
     // neighbours per lane loaded up front (the directed model carries more per neighbour)
-    constexpr int PP_NPRE = MODEL == DLSM_UNDIRECTED ? (D == 1 ? 11 : D == 2 ? 7 : D == 3 ? 5 : 4) : 1;
-    // The item is a chain of dependent latencies, so every load it will need is issued
-    // before the first use: PP_NPRE neighbours per lane (clamped addresses, no
-    // predication) and this lane's first H entry.
+    constexpr int PP_NPRE = MODEL == DLSM_UNDIRECTED ? (D == 1 ? 16 : D == 2 ? 11 : D == 3 ? 7 : 5) : 1;
+    // The item is a chain of dependent latencies, so the neighbours' loads are issued before
+    // the first use: PP_NPRE per lane (clamped addresses, no predication) - all 11 trips of a
+    // part at C2.
     // The bits of row k for the part's neighbours: lane w holds word (lo >> 5) + w of the row
     // (64 words = 2048 neighbours; a longer part reads the rest from memory), handed to the
     // trips as scalar lane masks instead of a load and a register per neighbour.
@@ -176,30 +176,11 @@ __device__ __forceinline__ void pipe_eval_item(const ChainView &c, const PipeBuf
     // lanes working on this (slice, batch) - not to the wavefronts of "their" node, whose
     // entry counts differ by 2x - through the flat index f = prefix(kk) + e,
     // prefix(kk) = ncross kk + kk (kk - 1) / 2; one entry per lane when there are >= 3 parts.
-    // The first one's operands are loaded here, ahead of the neighbour loop.
+    // Their operands are loaded where they are used, after the neighbour loop: the registers
+    // a prefetch would hold are worth more as prefetched neighbours (measured: +6 % at C2).
     const int hround = nb * pb.parts * 64;
     const int htot = ncross * nb + nb * (nb - 1) / 2;
     const int hf0 = (k * pb.parts + p) * 64 + lane;
-    int hkk, he;
-    pipe_h_decode(min(hf0, max(htot - 1, 0)), ncross, nb, hkk, he);
-    const bool hcross0 = he < ncross;
-    const int hm_0 = hcross0 ? he : he - ncross;
-    const int jm0 = (hcross0 ? jprev : j0) + hm_0;
-    const int jkk0 = j0 + hkk;
-    // (the directed items are short of registers: their H operands are loaded where they are used)
-    constexpr bool HPRE = MODEL == DLSM_UNDIRECTED;
-    double hm0[D], hm1[D], hk0[D], hk1[D];
-    uint32_t hw = 0u;
-    if (HPRE) {
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            hm0[d] = props[(size_t)jm0 * PW + D + 2 + d];
-            hm1[d] = props[(size_t)jm0 * PW + d];
-            hk0[d] = props[(size_t)jkk0 * PW + D + 2 + d];
-            hk1[d] = props[(size_t)jkk0 * PW + d];
-        }
-        hw = c.ybits[((size_t)t * N + jkk0) * W + (jm0 >> 5)];
-    }
 
     double acc = 0.0;
     RatioAcc ra;
@@ -306,34 +287,24 @@ __device__ __forceinline__ void pipe_eval_item(const ChainView &c, const PipeBuf
         double2 *f = (double2 *)pb.full0 + (((size_t)bb * c.T + t) * PP_B + k) * pb.parts + p;
         *f = make_double2(tot_l, tot_r);
     }
-    // this lane's H entries (see above): the first from the prefetched operands
+    // this lane's H entries (see above)
     for (int f = hf0; f < htot; f += hround) {
         int kk, e;
-        double xm0[D], xm1[D], xa0[D], xa1[D], rm, rk;
-        int y1, y2;
-        if (HPRE && f == hf0) {
-            kk = hkk; e = he;
+        pipe_h_decode(f, ncross, nb, kk, e);
+        const int jm_ = (e < ncross ? jprev : j0) + (e < ncross ? e : e - ncross);
+        const int jkk = j0 + kk;
+        double xm0[D], xm1[D], xa0[D], xa1[D];
 #pragma unroll
-            for (int d = 0; d < D; ++d) {
-                xm0[d] = hm0[d]; xm1[d] = hm1[d]; xa0[d] = hk0[d]; xa1[d] = hk1[d];
-            }
-            y1 = (hw >> (jm0 & 31)) & 1; y2 = 0; rm = 1.0; rk = 1.0;
-        } else {
-            pipe_h_decode(f, ncross, nb, kk, e);
-            const int jm_ = (e < ncross ? jprev : j0) + (e < ncross ? e : e - ncross);
-            const int jkk = j0 + kk;
-#pragma unroll
-            for (int d = 0; d < D; ++d) {
-                xm0[d] = props[(size_t)jm_ * PW + D + 2 + d];
-                xm1[d] = props[(size_t)jm_ * PW + d];
-                xa0[d] = props[(size_t)jkk * PW + D + 2 + d];
-                xa1[d] = props[(size_t)jkk * PW + d];
-            }
-            y1 = bit_of(c.ybits + ((size_t)t * N + jkk) * W, jm_);
-            y2 = MODEL == DLSM_DIRECTED ? bit_of(c.ytbits + ((size_t)t * N + jkk) * W, jm_) : 0;
-            rm = MODEL == DLSM_DIRECTED ? c.radii[jm_] : 1.0;
-            rk = MODEL == DLSM_DIRECTED ? c.radii[jkk] : 1.0;
+        for (int d = 0; d < D; ++d) {
+            xm0[d] = props[(size_t)jm_ * PW + D + 2 + d];
+            xm1[d] = props[(size_t)jm_ * PW + d];
+            xa0[d] = props[(size_t)jkk * PW + D + 2 + d];
+            xa1[d] = props[(size_t)jkk * PW + d];
         }
+        const int y1 = bit_of(c.ybits + ((size_t)t * N + jkk) * W, jm_);
+        const int y2 = MODEL == DLSM_DIRECTED ? bit_of(c.ytbits + ((size_t)t * N + jkk) * W, jm_) : 0;
+        const double rm = MODEL == DLSM_DIRECTED ? c.radii[jm_] : 1.0;
+        const double rk = MODEL == DLSM_DIRECTED ? c.radii[jkk] : 1.0;
         const bool cross = e < ncross;
         const int m = cross ? e : e - ncross;
         const double a0 = dist_fast<D>(xm0, xa0, c.squared);
