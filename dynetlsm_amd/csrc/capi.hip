@@ -863,9 +863,12 @@ static int launch_sweep_pipe(dlsm_chain *h, IterRef iter, bool alloc_only = fals
     pb.nctrl = h->nctrl;
     const size_t lds = (size_t)PP_B * PP_B * sizeof(double);
     auto ku = k_pipe_step<DD, DLSM_UNDIRECTED>;
+    auto kl = k_pipe_step<DD, PIPE_UNDIRECTED_LONG>;
     auto kd = k_pipe_step<DD, DLSM_DIRECTED>;
     auto kc = k_pipe_step<DD, DLSM_DIRECTED_CASE_CONTROL>;
     HIPCHK(h, hipFuncSetAttribute((const void *)ku, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds));
+    HIPCHK(h, hipFuncSetAttribute((const void *)kl, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds));
     HIPCHK(h, hipFuncSetAttribute((const void *)kd, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds));
@@ -881,7 +884,9 @@ static int launch_sweep_pipe(dlsm_chain *h, IterRef iter, bool alloc_only = fals
     for (int l = -1; l <= last; ++l) {
         const bool any_eval = (l + 1 < nbat) || (T > 1 && l >= 0 && l < nbat);
         const int grid = T + (any_eval ? ne_wg : 0);
-        if (h->model == DLSM_UNDIRECTED)
+        if (h->model == DLSM_UNDIRECTED && pb.per > 64 * pipe_prefetch_trips(DD))
+            launch_pipe_step<DD, PIPE_UNDIRECTED_LONG>(h, v, pb, grid, lds, l);
+        else if (h->model == DLSM_UNDIRECTED)
             launch_pipe_step<DD, DLSM_UNDIRECTED>(h, v, pb, grid, lds, l);
         else if (h->model == DLSM_DIRECTED)
             launch_pipe_step<DD, DLSM_DIRECTED>(h, v, pb, grid, lds, l);

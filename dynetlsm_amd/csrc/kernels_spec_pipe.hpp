@@ -122,8 +122,15 @@ __device__ __forceinline__ void pipe_h_decode(int f, int ncross, int nb, int &kk
     e = f - pre;
 }
 
-// One wavefront: part p of node k of batch `be` in slice t.
-template <int D, int MODEL>
+// trips of 64 neighbours whose operands an undirected item loads up front
+__host__ __device__ constexpr int pipe_prefetch_trips(int D) {
+    return D == 1 ? 16 : D == 2 ? 11 : D == 3 ? 7 : 5;
+}
+
+// One wavefront: part p of node k of batch `be` in slice t.  TP: the trips beyond the
+// prefetched ones are software-pipelined (directed model; undirected parts longer than the
+// prefetch, where it is worth +3 % - at C2, where everything is prefetched, it costs 1 %).
+template <int D, int MODEL, bool TP>
 __device__ __forceinline__ void pipe_eval_item(const ChainView &c, const PipeBuf &pb, int be,
                                                int nb, int t, int k, int p, int lane) {
     constexpr int PW = 2 * D + 2;
@@ -152,7 +159,7 @@ __device__ __forceinline__ void pipe_eval_item(const ChainView &c, const PipeBuf
     const double lE = bin + bout;              // log E (directed model)
     const int lo = p * pb.per, hi = min(N, lo + pb.per);
     // neighbours per lane loaded up front (the directed model carries more per neighbour)
-    constexpr int PP_NPRE = MODEL == DLSM_UNDIRECTED ? (D == 1 ? 16 : D == 2 ? 11 : D == 3 ? 7 : 5) : 1;
+    constexpr int PP_NPRE = MODEL == DLSM_UNDIRECTED ? pipe_prefetch_trips(D) : 1;
     // The item is a chain of dependent latencies, so the neighbours' loads are issued before
     // the first use: PP_NPRE per lane (clamped addresses, no predication) - all 11 trips of a
     // part at C2.
@@ -241,16 +248,14 @@ __device__ __forceinline__ void pipe_eval_item(const ChainView &c, const PipeBuf
         if (__builtin_amdgcn_inverse_ballot_w64(vm_))                                         \
             DLSM_PIPE_TERM(xpre[u], yb_, ycb_, rpre[MODEL == DLSM_DIRECTED ? u : 0], FLUSH_, SQ_) \
     }                                                                                         \
-    /* the trips beyond the prefetched ones.  Directed model (3 prefetched trips only, a       \
-       radius per neighbour): each trip requests the next one's operands (clamped address, no \
-       predication) before it computes.  Undirected: 8 of the 11 trips at C2 are prefetched   \
-       and the extra registers of the pipelined form cost more than the 3 exposed loads. */   \
+    /* the trips beyond the prefetched ones.  TP: each trip requests the next one's operands   \
+       (clamped address, no predication) before it computes. */                               \
     double xn[D], rn = 1.0;                                                                   \
-    if (MODEL == DLSM_DIRECTED) DLSM_PIPE_REQUEST(PP_NPRE)                                    \
+    if (TP && lo + 64 * PP_NPRE < hi) DLSM_PIPE_REQUEST(PP_NPRE)                                    \
     for (int u = PP_NPRE; lo + 64 * u < hi; ++u) {                                            \
         double xi[D];                                                                         \
         double ri = 1.0;                                                                      \
-        if (MODEL == DLSM_DIRECTED) {                                                         \
+        if (TP) {                                                                             \
             _Pragma("unroll")                                                                 \
             for (int d = 0; d < D; ++d) xi[d] = xn[d];                                        \
             ri = rn;                                                                          \
@@ -258,7 +263,7 @@ __device__ __forceinline__ void pipe_eval_item(const ChainView &c, const PipeBuf
         }                                                                                     \
         DLSM_PIPE_MASKS(u)                                                                    \
         if (__builtin_amdgcn_inverse_ballot_w64(vm_)) {                                       \
-            if (MODEL != DLSM_DIRECTED) {                                                     \
+            if (!TP) {                                                     \
                 const double *src = i_ < jprev ? Xt + (size_t)i_ * D                          \
                                                : props + (size_t)i_ * PW + D + 2;             \
                 _Pragma("unroll")                                                             \
@@ -587,8 +592,13 @@ __device__ __forceinline__ void pipe_resolve(const ChainView &c, const PipeBuf &
 // Launch l: even slices resolve batch l and evaluate batch l + 1; odd slices resolve
 // batch l - 1 and evaluate batch l (batches outside [0, nbat) do nothing).
 // Workgroups [0, T) are the resolvers, the rest evaluate one item per wavefront.
-template <int D, int MODEL>
+// MODEL = PIPE_UNDIRECTED_LONG: the undirected model with parts longer than the prefetch
+constexpr int PIPE_UNDIRECTED_LONG = 3;
+
+template <int D, int MODEL_>
 __global__ __launch_bounds__(PP_THREADS) void k_pipe_step(ChainView c, PipeBuf pb, int l) {
+    constexpr int MODEL = MODEL_ == PIPE_UNDIRECTED_LONG ? DLSM_UNDIRECTED : MODEL_;
+    constexpr bool TP = MODEL_ != DLSM_UNDIRECTED;
     extern __shared__ __attribute__((aligned(16))) double pp_sH[];      // 128 x 128
     __shared__ double sPart[PP_WAVES * 64];
     __shared__ unsigned long long sMask[2][2];
@@ -647,7 +657,7 @@ __global__ __launch_bounds__(PP_THREADS) void k_pipe_step(ChainView c, PipeBuf p
         const bool odd = si >= nslE;
         if (k >= (odd ? nbO : nbE)) continue;
         const int t = odd ? 2 * (si - nslE) + 1 : 2 * si;
-        pipe_eval_item<D, MODEL == DLSM_DIRECTED_CASE_CONTROL ? DLSM_DIRECTED : MODEL>(
+        pipe_eval_item<D, MODEL == DLSM_DIRECTED_CASE_CONTROL ? DLSM_DIRECTED : MODEL, TP>(
             c, pb, odd ? beO : beE, odd ? nbO : nbE, t, k, p, lane);
     }
 }

@@ -256,3 +256,25 @@ def test_directed_exact_at_full_size(eng):
                      0.5 * np.sum((x[1:] - x[:-1]) ** 2) / 0.1 -
                      0.5 * np.sum(ics[it] ** 2) / 2.0)
             np.testing.assert_allclose(lps[it], ll + prior, rtol=1e-10)
+
+
+def test_pipelined_sweep_with_parts_longer_than_the_prefetch(eng):
+    """T=12, N=2200: three parts of 768 neighbours per node, more than the 11 prefetched
+    trips, so the pipelined sweep runs its long-part instantiation (software-pipelined tail);
+    same decisions as the two-kernel speculative form."""
+    from dynetlsm_amd.synthetic import synthetic_lsm_network
+    T, N = 12, 2200
+    net = synthetic_lsm_network(T=T, N=N, D=2, density=0.03, seed=5)
+    out = {}
+    for algo in (3, 4):
+        g = eng.SamplerGrid(T, N, 0.1, tune=None)
+        with eng.Chain(T, N, 2, 'undirected', seed=4, chain_id=0) as c:
+            c.upload_network(net['Y']); c.set_positions(net['X_init'])
+            c.set_intercepts([net['intercept']])
+            c.set_prior_random_walk(2.0, 0.1); c.set_samplers(g)
+            for it in (1, 2):
+                c.sweep_positions(it, algo)
+            out[algo] = (c.get_positions(), c.get_samplers(g).n_accepted.copy())
+    np.testing.assert_array_equal(out[3][1], out[4][1])
+    np.testing.assert_allclose(out[3][0], out[4][0], atol=1e-9)
+    assert 0.2 < out[4][1].mean() / 2 < 0.999
