@@ -196,7 +196,7 @@ __device__ __forceinline__ void pipe_eval_item(const ChainView &c, const PipeBuf
         if (MODEL == DLSM_UNDIRECTED) {                                                       \
             const double d0_ = dist_fast<D>(XI_, xk0, SQ_);                                   \
             const double d1_ = dist_fast<D>(XI_, xk1, SQ_);                                   \
-            if (YB_) ra.lin += d0_ - d1_;                                                     \
+            ra.lin = fma((YB_) ? 1.0 : 0.0, d0_ - d1_, ra.lin);                               \
             ra.P0 *= fma(E, fast_exp(-d0_), 1.0);                                             \
             ra.P1 *= fma(E, fast_exp(-d1_), 1.0);                                             \
             if (FLUSH_) if (++ra.cnt >= nflush) ra.flush();                                   \
