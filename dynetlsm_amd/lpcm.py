@@ -258,7 +258,10 @@ class DynamicNetworkLPCM(FittedQuantities):
             for k in range(n_ic):                    # sample_coefficients.py:12-88
                 prop = intercept.copy()
                 prop[k] = intercept[k] + isamp[k].step_size * rng.randn(1)[0]
-                ll_prop, ll_cur = chain.loglik_full([prop, intercept])
+                if k == 0:
+                    ll_prop, ll_cur = chain.loglik_full([prop, intercept])
+                else:       # same positions, and `intercept` is the state the last step left:
+                    ll_prop, ll_cur = chain.loglik_full([prop])[0], ll      # its value is known
                 ratio = ((ll_prop - (prop[k] - ip[k]) ** 2 / (2 * var)) -
                          (ll_cur - (intercept[k] - ip[k]) ** 2 / (2 * var)))
                 accepted = int(not (np.log(rng.rand()) >= ratio))

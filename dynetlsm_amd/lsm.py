@@ -322,12 +322,16 @@ class DynamicNetworkLSM(FittedQuantities):
             for k in range(2):
                 prop = intercept.copy()
                 prop[k] = intercept[k] + isamp[k].step_size * rng.randn(1)[0]
-                ll_prop, ll_cur = chain.loglik_full([prop, intercept])
+                if k == 0:
+                    ll_prop, ll_cur = chain.loglik_full([prop, intercept])
+                else:       # same positions, and `intercept` is the state the last step left
+                    ll_prop, ll_cur = chain.loglik_full([prop])[0], ll_state
                 ratio = ((ll_prop - (prop[k] - ip[k]) ** 2 / (2 * var)) -
                          (ll_cur - (intercept[k] - ip[k]) ** 2 / (2 * var)))
                 accepted = int(not (np.log(rng.rand()) >= ratio))
+                ll_state = ll_cur
                 if accepted:
-                    intercept = prop
+                    intercept, ll_state = prop, ll_prop
                 isamp[k].book(accepted)
             chain.set_intercepts(intercept)
             # sample_coefficients.py:91-121 + metropolis.py:57-82
