@@ -23,7 +23,7 @@ int main() {
     hipStreamCreateWithFlags(&sR, hipStreamNonBlocking);
     hipStreamCreateWithFlags(&sE[0], hipStreamNonBlocking);
     hipStreamCreateWithFlags(&sE[1], hipStreamNonBlocking);
-    std::vector<hipEvent_t> eR(NB + 2), eE(NB + 2);
+    std::vector<hipEvent_t> eR(NB + 3), eE(NB + 3);
     for (auto &e : eR) hipEventCreateWithFlags(&e, hipEventDisableTiming);
     for (auto &e : eE) hipEventCreateWithFlags(&e, hipEventDisableTiming);
     auto now = [] { return std::chrono::steady_clock::now(); };
@@ -77,6 +77,49 @@ int main() {
         hipStreamSynchronize(sR); hipStreamSynchronize(sE[0]); hipStreamSynchronize(sE[1]);
         double us = std::chrono::duration<double, std::micro>(now() - t0).count() / (REPS * NB);
         printf("split roles, empty kernels : %.2f us per batch to enqueue, %.2f us to finish\n", us_host, us);
+    }
+    // (c) the split form captured once as a graph with parallel branches, replayed
+    {
+        hipGraph_t g; hipGraphExec_t ge;
+        hipStreamBeginCapture(sR, hipStreamCaptureModeGlobal);
+        hipEventRecord(eR[NB + 1], sR);                      // fork
+        hipStreamWaitEvent(sE[0], eR[NB + 1], 0);
+        hipStreamWaitEvent(sE[1], eR[NB + 1], 0);
+        for (int l = 0; l < NB; ++l) {
+            hipStream_t se = sE[l & 1];
+            if (l > 0) hipStreamWaitEvent(se, eR[l - 1], 0);
+            hipLaunchKernelGGL(k_spin, dim3(NE), dim3(1024), 0, se, 0, tR, tE);
+            hipEventRecord(eE[l], se);
+            if (l > 0) hipStreamWaitEvent(sR, eE[l - 1], 0);
+            hipLaunchKernelGGL(k_spin, dim3(T), dim3(1024), 0, sR, T, tR, tE);
+            hipEventRecord(eR[l], sR);
+        }
+        hipStreamWaitEvent(sR, eE[NB - 1], 0);               // join
+        hipStreamWaitEvent(sR, eE[NB - 2], 0);
+        hipError_t e1 = hipStreamEndCapture(sR, &g);
+        hipError_t e2 = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+        if (e1 != hipSuccess || e2 != hipSuccess) { printf("graph capture failed: %d %d\n", e1, e2); return 0; }
+        for (int w = 0; w < 2; ++w) {
+            auto t0 = now();
+            for (int r = 0; r < REPS; ++r) hipGraphLaunch(ge, sR);
+            hipStreamSynchronize(sR);
+            double us = std::chrono::duration<double, std::micro>(now() - t0).count() / (REPS * NB);
+            if (w) printf("split roles, graph replay  : %.2f us per batch\n", us);
+        }
+        // and the fused form as a (linear) graph
+        hipGraph_t g2; hipGraphExec_t ge2;
+        hipStreamBeginCapture(sR, hipStreamCaptureModeGlobal);
+        for (int l = 0; l < NB; ++l)
+            hipLaunchKernelGGL(k_spin, dim3(T + NE), dim3(1024), 0, sR, T, tR, tE);
+        hipStreamEndCapture(sR, &g2);
+        hipGraphInstantiate(&ge2, g2, nullptr, nullptr, 0);
+        for (int w = 0; w < 2; ++w) {
+            auto t0 = now();
+            for (int r = 0; r < REPS; ++r) hipGraphLaunch(ge2, sR);
+            hipStreamSynchronize(sR);
+            double us = std::chrono::duration<double, std::micro>(now() - t0).count() / (REPS * NB);
+            if (w) printf("fused, graph replay        : %.2f us per batch\n", us);
+        }
     }
     return 0;
 }
