@@ -1,24 +1,37 @@
 #!/usr/bin/env python
-"""Benchmark of the Gibbs hot path on MI355X: Gibbs iterations/s of
-DynamicNetworkLSM on a synthetic undirected network, T=10 N=2000 d=2
-(BASELINE.json configs[1]), one independent chain per GPU.
+"""Benchmark of the Gibbs hot path on MI355X, one independent chain per GPU.
 
-One "step" = one full Gibbs iteration of lsm.py:474-572 for the fully observed
-undirected model: latent-position sweep (20 000 MH steps), Procrustes rotation
-to the reference sample, centring, intercept MH step and log-posterior trace
-(the three full log-likelihood evaluations of the reference fused into one
-pass), sample stored in the device-resident trace.
+    python bench.py --gpus N --steps K --warmup W [--model lsm|hdp|all]
 
-    python bench.py --gpus N --steps K --warmup W
+Headline (``--model lsm``, BASELINE.json configs[1]): Gibbs iterations/s of
+DynamicNetworkLSM on a synthetic undirected network, T=10 N=2000 d=2.  One "step" =
+one full Gibbs iteration of lsm.py:474-572: latent-position sweep (20 000 MH steps),
+Procrustes rotation, centring, intercept MH step and log-posterior trace (the three
+full log-likelihood evaluations of the reference fused into one pass), sample stored
+in the device-resident trace.
 
-N > 1 is launched by torch.distributed.run (one rank per GPU).  Rank 0 builds
-the network and broadcasts it over RCCL; chains are independent (no
-intra-iteration collective); per-chain summaries are all-gathered at the end.
-Prints ONE JSON line on rank 0.
+``--model hdp`` (configs[2] on one GPU, configs[4] = 8 chains on 8 GPUs): one step =
+one Gibbs iteration of DynamicNetworkHDPLPCM._fit (hdp_lpcm.py:823-1069), K_max = 20:
+sweep with the AR-mixture prior, centring, intercept MH, label block update, the
+HDP's auxiliary / conjugate / hyper-parameter draws and the log-posterior trace.
+
+``--model all`` (the default) prints the LSM line as the headline - the metric of
+BASELINE.json - and attaches the HDP-LPCM measurement of the same run as
+``extra_configs`` (so that the N-GPU runs exercise configs[4] too).
+
+N > 1: when RANK is not set the process spawns the N ranks itself (it makes no GPU
+call before that), relays rank 0's JSON line and exits non-zero if a rank fails;
+under ``torch.distributed.run`` the ranks are the launcher's.  Rank 0 uploads and
+packs the network once and broadcasts the packed words device to device over RCCL;
+chains are independent (no intra-iteration collective); posterior-mean positions,
+log-posterior and intercept traces are all-gathered at the end.  Prints ONE JSON line
+on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,97 +41,141 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# float64 vector peak: v_fma_f64 issues at half the FP32 vector rate (157.3 TFLOP/s spec in
+# MI355X_MICROARCH.md) = 256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz.  A pure fma stream
+# sustains 76 % of it at this occupancy (profiles/micro/f64_rates.cpp): the chip does not
+# hold 2.4 GHz under a dense float64 stream.
+F64_VALU_PEAK_TFLOPS = 78.6
+F64_VALU_SUSTAINED_FRAC = 0.76
+# float64 vector instructions per dyad term (one distance + one exp(-d) + product
+# bookkeeping at ONE position), counted in the disassembly: DESIGN.md 4.1 / 4.4b
+INSTR_PER_TERM_SWEEP = 34       # k_pipe_step neighbour loop: 68 per neighbour, 2 positions
+INSTR_PER_TERM_LOGLIK = 17      # k_loglik_undirected<2,2>: 34 per dyad with 2 candidates
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--model', default='all', choices=['lsm', 'hdp', 'all'])
     ap.add_argument('--T', type=int, default=10)
     ap.add_argument('--N', type=int, default=2000)
     ap.add_argument('--D', type=int, default=2)
+    ap.add_argument('--K', type=int, default=20, help='n_components of the HDP-LPCM')
     ap.add_argument('--density', type=float, default=0.03)
     ap.add_argument('--algo', type=int, default=0, help='sweep algorithm (0 auto)')
     ap.add_argument('--profile-steps', type=int, default=20)
     ap.add_argument('--cpu-iters', type=int, default=8,
                     help='oracle iterations timed for cpu_baseline (0 = skip)')
+    ap.add_argument('--cpu-procs', type=int, default=1,
+                    help='also time this many independent CPU chains in as many processes')
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--backend', default=None,
                     help='collective backend (default nccl = RCCL; gloo for dry runs)')
     ap.add_argument('--share-device0', action='store_true',
                     help='dry run: every rank drives cuda:0 (with --backend gloo)')
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
-def main():
-    args = parse()
-    import torch
+# ------------------------------------------------------------------------------------
+# self-launch: N ranks as child processes (the parent never touches the GPU)
+# ------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
 
-    rank = int(os.environ.get('RANK', '0'))
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world != args.gpus:
+
+def launch_ranks(args):
+    n = args.gpus
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
+                   LOCAL_WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        # rank 0 inherits stdout (its JSON line is the output); the others' go to stderr
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
+                                      env=env, stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    alive = set(range(n))
+    while alive:
+        for r in sorted(alive):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            alive.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                print('bench.py: rank %d exited with %d; stopping the others' % (r, code),
+                      file=sys.stderr)
+                for q in alive:
+                    procs[q].terminate()          # exactly the PIDs started above
+        time.sleep(0.05)
+    return rc
+
+
+# ------------------------------------------------------------------------------------
+# workloads
+# ------------------------------------------------------------------------------------
+class LsmWorkload(object):
+    """configs[1]: DynamicNetworkLSM, undirected, device-resident loop (dlsm_lsm_run)"""
+    name = 'lsm'
+
+    def __init__(self, args, group, local_rank):
+        from dynetlsm_amd import Chain, SamplerGrid
+        from dynetlsm_amd.synthetic import synthetic_lsm_network
+        self.args, self.group = args, group
+        T, N, D = args.T, args.N, args.D
+        rank = group.rank
+        K, W, P = args.steps, args.warmup, args.profile_steps
+        self.chain = chain = Chain(T, N, D, 'undirected', seed=20240229, chain_id=rank,
+                                   device=local_rank)
+        # the network: built, uploaded and packed on rank 0; the packed words are broadcast
+        net = synthetic_lsm_network(T, N, D, density=args.density, seed=0) if rank == 0 else None
+        self.net = net
         if rank == 0:
-            print('bench.py: --gpus %d but WORLD_SIZE=%d; launch with '
-                  'torch.distributed.run --nproc-per-node %d' % (args.gpus, world, args.gpus),
-                  file=sys.stderr)
-        sys.exit(2)
+            chain.upload_network(net['Y'])
+        group.broadcast_chain_network(chain)
+        self.X_init = group.broadcast_array(net['X_init'] if rank == 0 else np.zeros((T, N, D)))
+        self.b_init = float(group.broadcast_array(
+            np.array([net['intercept'], net['Y'].mean()]) if rank == 0 else np.zeros(2))[0])
+        self.density = float(net['Y'].mean()) if rank == 0 else None
+        chain.set_positions(self.X_init)
+        chain.set_intercepts([self.b_init])
+        chain.set_prior_random_walk(2.0, 0.1)
+        chain.set_samplers(SamplerGrid(T, N, step_size=0.1, tune=None))
+        chain.lsm_configure([self.b_init], 2.0, step_size_intercept=0.1, tune=None,
+                            n_iter_procrustes=0, sweep_algo=args.algo)
+        chain.trace_alloc(1 + W + K + P, logp0=0.0)
+        self.next_it = 1
 
-    from dynetlsm_amd import Chain, SamplerGrid
-    from dynetlsm_amd import _lib
-    from dynetlsm_amd.multichain import init_chain_group
-    from dynetlsm_amd.synthetic import synthetic_lsm_network
+    def run(self, count):
+        self.chain.lsm_run(self.next_it, count, procrustes_ref=0)
+        self.next_it += count
 
-    # one process per GPU; collectives over RCCL (backend "nccl") unless told otherwise
-    group = init_chain_group(backend=args.backend or 'nccl') if world > 1 else \
-        init_chain_group(backend='gloo')
-    if args.share_device0:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
+    def synchronize(self):
+        self.chain.synchronize()
 
-    T, N, D = args.T, args.N, args.D
-    K, W, P = args.steps, args.warmup, args.profile_steps
+    def workload(self):
+        a = self.args
+        return ('DynamicNetworkLSM synthetic undirected T=%d N=%d d=%d, 1 chain per GPU'
+                % (a.T, a.N, a.D))
 
-    # ---- the network: built on rank 0, broadcast (uint8 on the wire) -------------
-    net = synthetic_lsm_network(T, N, D, density=args.density, seed=0) if rank == 0 else None
-    Y = group.broadcast_network(net['Y'] if rank == 0 else None)
-    X_init = group.broadcast_array(net['X_init'] if rank == 0 else np.zeros((T, N, D)))
-    b_init = float(group.broadcast_array(np.array([net['intercept']]) if rank == 0
-                                         else np.zeros(1))[0])
-    density = float(Y.mean())
+    def metric(self):
+        a = self.args
+        return 'Gibbs iterations/sec (and ms/log-lik eval), T=%d N=%d d=%d' % (a.T, a.N, a.D)
 
-    # ---- one chain per rank --------------------------------------------------
-    chain = Chain(T, N, D, 'undirected', seed=20240229, chain_id=rank, device=local_rank)
-    chain.upload_network(Y)
-    chain.set_positions(X_init)
-    chain.set_intercepts([b_init])
-    chain.set_prior_random_walk(2.0, 0.1)
-    chain.set_samplers(SamplerGrid(T, N, step_size=0.1, tune=None))
-    chain.lsm_configure([b_init], 2.0, step_size_intercept=0.1, tune=None,
-                        n_iter_procrustes=0, sweep_algo=args.algo)
-    n_total = 1 + W + K + P
-    chain.trace_alloc(n_total, logp0=0.0)
-
-    barrier = group.barrier
-
-    chain.lsm_run(1, W, procrustes_ref=0)
-    chain.synchronize()
-    torch.cuda.synchronize()
-    barrier()
-    t0 = time.perf_counter()
-    chain.lsm_run(1 + W, K, procrustes_ref=0)
-    chain.synchronize()
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = group.max_over_ranks(time.perf_counter() - t0)
-
-    # ---- per-kernel timing by HIP events on the chain's stream --------------
-    roofline = None
-    extra = {}
-    if P > 0:
+    def profile(self):
+        """per-kernel timing by HIP events on the chain's stream -> (roofline, extras)"""
+        from dynetlsm_amd import _lib
+        a, chain = self.args, self.chain
+        T, N, D, P = a.T, a.N, a.D, a.profile_steps
         chain.profile_enable(True)
-        chain.lsm_run(1 + W + K, P, procrustes_ref=0)
+        self.run(P)
         chain.synchronize()
         ms_sw, n_sw = chain.profile_read(_lib.K_SWEEP)
         ms_ll, n_ll = chain.profile_read(_lib.K_LOGLIK)
@@ -129,109 +186,385 @@ def main():
         ms_rs, n_rs = chain.profile_read(_lib.K_SWEEP_RESOLVE)
         sweep_ms = ms_sw / max(n_sw, 1)
         ll_ms = ms_ll / max(n_ll, 1)
-        # algorithmic bytes: a sweep touches every float64 Y entry
-        # once (row j of slice t per MH step) + X[t] once per slice; one fused
-        # eval reads the upper triangle once + X
-        sweep_bytes = 8.0 * T * N * N + 8.0 * T * N * D
-        ll_bytes = 8.0 * T * N * (N - 1) / 2 + 8.0 * T * N * D
-        traffic = None
-        tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
-        if n_ev > 0:
-            # dominant kernel of the sweep: k_spec_eval, (n_ev / P) launches per
-            # sweep, each covering (slices of one parity) x (batch of <= 128 nodes)
-            launches = n_ev / float(P)
-            # algo 4: the fused resolve(b) + eval(b + 1) step; algo 2 / 3: the eval kernel
-            algo_used = chain.resolve_sweep_algo(args.algo)
-            kname = 'k_pipe_step' if algo_used == 4 else 'k_spec_eval'
-            k_ms = ms_ev / n_ev
-            # the eval launches carry their own start/stop events (hipExtLaunchKernelGGL):
-            # the dispatch's begin/end timestamps, which is what the rocprofv3 kernel
-            # trace reports
-            k_bytes = sweep_bytes / launches
-        else:
-            launches = 2.0
-            kname, k_ms = 'k_sweep_slice', sweep_ms / 2.0
-            k_bytes = sweep_bytes / 2.0
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get(kname, {}).get('hbm_bytes_per_launch')
-            except Exception:
-                traffic = None
-        ach = k_bytes / (k_ms * 1e-3) / 1e9
-        roofline = {'bound': 'hbm', 'kernel': kname,
-                    'achieved': round(ach, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                    'frac': round(ach / HBM_PEAK_GBS, 5), 'traffic': traffic,
-                    'us_per_launch': round(1e3 * k_ms, 3),
-                    'launches_per_sweep': launches,
-                    'algorithmic_bytes_per_launch': round(k_bytes, 1),
-                    'sweep_GBps_all_launches': round(sweep_bytes / (sweep_ms * 1e-3) / 1e9, 2),
-                    # what actually bounds it (network bit-packed: float64 issue, not HBM):
-                    # pairwise terms (distance + exp) evaluated per second over the sweep,
-                    # 2 (proposal, current) x T x N x (N - 1) per sweep
-                    'dyad_terms_per_s': round(2.0 * T * N * (N - 1) / (sweep_ms * 1e-3), 0)}
-        # algo 2 / 3 only: their resolve launches (algo 4 resolves inside the fused launch)
-        extra_r = {'us_resolve_per_launch': round(1e3 * ms_rs / n_rs, 3)} if n_rs > 0 else {}
-        extra = {'ms_per_loglik_eval': round(ll_ms, 4),
-                 'loglik_eval_GBps': round(ll_bytes / (ll_ms * 1e-3) / 1e9, 1),
-                 'ms_sweep': round(sweep_ms, 4), 'ms_post_sweep': round(ms_ps / max(n_ps, 1), 4),
-                 'ms_finalize': round(ms_fi / max(n_fi, 1), 4)}
-        extra.update(extra_r)
+        return sweep_rooflines(chain, a, P, sweep_ms, ll_ms, ms_ev, n_ev, ms_rs, n_rs,
+                               ms_ps / max(n_ps, 1), ms_fi / max(n_fi, 1))
 
-    grid_f = chain.get_samplers(SamplerGrid(T, N, 0.1, tune=None))
-    acc_rate = float(grid_f.n_accepted.sum()) / max(float(grid_f.n_steps.sum()), 1.0)
+    def results(self, first, count):
+        """per-chain results for the final gather: posterior-mean positions, traces"""
+        Xs, ics, lps = self.chain.trace_read(first, count, positions=True)
+        return dict(X_mean=Xs.mean(axis=0), logps=lps, intercepts=ics)
 
-    # ---- chain summaries: gather over RCCL ------------------------------------
-    _, ics, lps = chain.trace_read(1 + W, K, positions=False)
-    summaries = [a.tolist() for a in group.gather_arrays(
-        np.array([ics[:, 0].mean(), ics[:, 0].std(), lps.mean(), lps[-1]]))]
+    def acceptance(self):
+        from dynetlsm_amd import SamplerGrid
+        g = self.chain.get_samplers(SamplerGrid(self.args.T, self.args.N, 0.1, tune=None))
+        return float(g.n_accepted.sum()) / max(float(g.n_steps.sum()), 1.0)
 
-    # ---- CPU baseline leg (rank 0): the scalar C oracle timed on this host's cores
-    #      on a bounded sample of the same workload; the same leg checks the engine's
-    #      log-likelihood at the chain's final state against the oracle ---------------
-    cpu = None
-    if rank == 0 and not args.no_cpu and args.cpu_iters > 0:
+    def cpu_baseline(self):
+        """rank 0: the scalar C oracle timed on this host's cores on a bounded sample of the
+        same workload; the same leg checks the engine's log-likelihood at the chain's final
+        state against the oracle"""
         from oracle import oracle as orc
+        a, chain, net = self.args, self.chain, self.net
+        T, N, D = a.T, a.N, a.D
+        Y = net['Y']
         Xf = chain.get_positions()
         bf = chain.get_intercepts()[0]
         g = chain.loglik_full([[bf]])[0]
         o = orc.dynamic_network_loglikelihood_undirected(Y, Xf, bf)
         og = orc.SamplerGrid(T, N, 0.1, tune=None)
-        st = orc.ChainState(X_init, og, Y=Y, intercept=[b_init], tau_sq=2.0,
+        st = orc.ChainState(self.X_init, og, Y=Y, intercept=[self.b_init], tau_sq=2.0,
                             sigma_sq=0.1, seed=20240229, chain=0)
         isamp = orc.ScalarSampler(0.1, 0, 0, 100, -1, 100)
         tc = time.perf_counter()
-        for it in range(1, args.cpu_iters + 1):
+        for it in range(1, a.cpu_iters + 1):
             st.c.iter = it
-            orc.lsm_iteration_undirected(st, isamp, b_init, 2.0)
+            orc.lsm_iteration_undirected(st, isamp, self.b_init, 2.0)
         tc = time.perf_counter() - tc
-        cpu = {'value': round(args.cpu_iters / tc, 5), 'unit': 'Gibbs iterations/s',
+        cpu = {'value': round(a.cpu_iters / tc, 5), 'unit': 'Gibbs iterations/s',
                'cores': 1, 'kind': 'port',
                'sample': '%d iterations of the same T=%d N=%d d=%d workload by the '
                          'scalar C oracle (sweep + 2 full log-lik evals per iteration), '
-                         '%.1f s' % (args.cpu_iters, T, N, D, tc),
+                         '%.1f s' % (a.cpu_iters, T, N, D, tc),
                'engine_loglik_rel_err_vs_oracle': abs(g - o) / abs(o)}
+        if a.cpu_procs > 1:
+            cpu['multi_process'] = cpu_chains_in_processes(a, a.cpu_procs)
+        return cpu
 
+    def close(self):
+        self.chain.close()
+
+
+def cpu_chains_in_processes(a, procs):
+    """`procs` independent CPU chains (the C oracle), one process per host core:
+    the comparator of the N-GPU rows.  Each child builds the same network and times the same
+    iterations; the aggregate is chains x iterations / the slowest child's time."""
+    code = ('import sys, time, json; sys.path.insert(0, %r)\n'
+            'import numpy as np\n'
+            'from oracle import oracle as orc\n'
+            'from dynetlsm_amd.synthetic import synthetic_lsm_network\n'
+            'T, N, D, n, c = %d, %d, %d, %d, int(sys.argv[1])\n'
+            'net = synthetic_lsm_network(T, N, D, density=%r, seed=0)\n'
+            'st = orc.ChainState(net["X_init"], orc.SamplerGrid(T, N, 0.1, tune=None), Y=net["Y"],\n'
+            '                    intercept=[net["intercept"]], tau_sq=2.0, sigma_sq=0.1,\n'
+            '                    seed=20240229, chain=c)\n'
+            'isamp = orc.ScalarSampler(0.1, 0, 0, 100, -1, 100)\n'
+            't0 = time.perf_counter()\n'
+            'for it in range(1, n + 1):\n'
+            '    st.c.iter = it\n'
+            '    orc.lsm_iteration_undirected(st, isamp, net["intercept"], 2.0)\n'
+            'print(json.dumps(time.perf_counter() - t0))\n'
+            % (ROOT, a.T, a.N, a.D, a.cpu_iters, a.density))
+    ps = [subprocess.Popen([sys.executable, '-c', code, str(c)], stdout=subprocess.PIPE)
+          for c in range(procs)]
+    secs = [float(json.loads(p.communicate()[0].decode().strip().splitlines()[-1])) for p in ps]
+    return {'value': round(procs * a.cpu_iters / max(secs), 5), 'unit': 'Gibbs iterations/s',
+            'cores': procs, 'kind': 'port',
+            'sample': '%d chains x %d iterations, one process each, slowest %.1f s; the host '
+                      'has %d cores' % (procs, a.cpu_iters, max(secs), os.cpu_count())}
+
+
+def sweep_rooflines(chain, a, P, sweep_ms, ll_ms, ms_ev, n_ev, ms_rs, n_rs, post_ms, fin_ms,
+                    iteration_ms=None):
+    """roofline blocks of the sweep's dominant kernel and of the log-likelihood pass.
+
+    With the network bit-packed neither kernel is HBM bound (measured traffic is 0.5x / 0.16x
+    the algorithmic float64 bytes): both are bound by float64 vector issue (distance + root,
+    exp).  ``roofline`` therefore prices the dominant kernel against the float64 VALU peak;
+    ``roofline_hbm`` keeps the algorithmic-bytes figure the metric asks for, next to the
+    fraction of the HBM peak that the MEASURED traffic (rocprofv3 PMC, profiles/traffic.json -
+    a stored number of the same kernel, not collected in this run) amounts to."""
+    T, N, D = a.T, a.N, a.D
+    sweep_bytes = 8.0 * T * N * N + 8.0 * T * N * D      # SURVEY.md 8d: row j of Y[t] per MH step
+    ll_bytes = 8.0 * T * N * (N - 1) / 2 + 8.0 * T * N * D
+    sweep_terms = 2.0 * T * N * (N - 1)                  # (proposal, current) x ordered pairs
+    ll_terms = 2.0 * T * N * (N - 1) / 2                 # 2 candidates x unordered pairs
+    algo_used = chain.resolve_sweep_algo(a.algo)
+    if n_ev > 0:
+        launches = n_ev / float(P)
+        kname = 'k_pipe_step' if algo_used == 4 else 'k_spec_eval'
+        k_ms = ms_ev / n_ev        # start/stop events attached to the launch itself
+    else:
+        launches, kname, k_ms = 2.0, 'k_sweep_slice', sweep_ms / 2.0
+    k_bytes, k_terms = sweep_bytes / launches, sweep_terms / launches
+    traffic = None
+    tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
+    ll_traffic = None
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            traffic = tj.get(kname, {}).get('hbm_bytes_per_launch')
+            ll_traffic = tj.get('k_loglik_undirected', {}).get('hbm_bytes_per_launch')
+        except Exception:
+            traffic = None
+
+    def valu(terms, instr, ms):
+        tf = terms * instr * 2.0 / (ms * 1e-3) / 1e12
+        return round(tf, 3), round(tf / F64_VALU_PEAK_TFLOPS, 4)
+
+    ach, frac = valu(k_terms, INSTR_PER_TERM_SWEEP, k_ms)
+    roofline = {
+        'bound': 'fp64_valu', 'kernel': kname, 'achieved': ach, 'peak': F64_VALU_PEAK_TFLOPS,
+        'unit': 'TFLOP/s', 'frac': frac, 'traffic': traffic,
+        'us_per_launch': round(1e3 * k_ms, 3), 'launches_per_sweep': launches,
+        'dyad_terms_per_launch': round(k_terms, 0),
+        'f64_instr_per_term': INSTR_PER_TERM_SWEEP,
+        'peak_note': 'nominal float64 vector peak (fma = 2 flop; every float64 vector '
+                     'instruction priced as one fma slot); a pure fma stream sustains %.2f of it '
+                     'on this chip' % F64_VALU_SUSTAINED_FRAC,
+        'frac_of_sustained': round(frac / F64_VALU_SUSTAINED_FRAC, 4),
+        'dyad_terms_per_s_sweep': round(sweep_terms / (sweep_ms * 1e-3), 0)}
+    ach_b = k_bytes / (k_ms * 1e-3) / 1e9
+    roofline_hbm = {
+        'bound': 'hbm', 'kernel': kname, 'achieved': round(ach_b, 2), 'peak': HBM_PEAK_GBS,
+        'unit': 'GB/s', 'frac': round(ach_b / HBM_PEAK_GBS, 5), 'traffic': traffic,
+        'algorithmic_bytes_per_launch': round(k_bytes, 1),
+        'measured_traffic_GBps': (round(traffic / (k_ms * 1e-3) / 1e9, 2) if traffic else None),
+        'measured_traffic_frac': (round(traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+                                  if traffic else None),
+        'traffic_source': 'profiles/traffic.json (rocprofv3 PMC of this kernel, stored)',
+        'sweep_GBps_all_launches': round(sweep_bytes / (sweep_ms * 1e-3) / 1e9, 2)}
+    ach_l, frac_l = valu(ll_terms, INSTR_PER_TERM_LOGLIK, ll_ms)
+    roofline_ll = {
+        'bound': 'fp64_valu', 'kernel': 'k_loglik_undirected<2,2>', 'achieved': ach_l,
+        'peak': F64_VALU_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': frac_l, 'traffic': ll_traffic,
+        'us_per_launch': round(1e3 * ll_ms, 3),
+        'algorithmic_GBps': round(ll_bytes / (ll_ms * 1e-3) / 1e9, 1),
+        'algorithmic_frac_of_hbm': round(ll_bytes / (ll_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+        'frac_of_sustained': round(frac_l / F64_VALU_SUSTAINED_FRAC, 4)}
+    extra = {'roofline_hbm': roofline_hbm, 'roofline_loglik': roofline_ll,
+             'ms_per_loglik_eval': round(ll_ms, 4),
+             'loglik_eval_GBps': round(ll_bytes / (ll_ms * 1e-3) / 1e9, 1),
+             'ms_sweep': round(sweep_ms, 4), 'ms_post_sweep': round(post_ms, 4),
+             'ms_finalize': round(fin_ms, 4)}
+    if n_rs > 0:
+        extra['us_resolve_per_launch'] = round(1e3 * ms_rs / n_rs, 3)
+    return roofline, extra
+
+
+def iteration_valu_fraction(ms_per_step, a):
+    """the whole iteration against the float64 vector peak: its algorithmic dyad terms
+    (sweep + fused evaluation) x their instruction counts / wall time per iteration"""
+    T, N = a.T, a.N
+    ops = (2.0 * T * N * (N - 1) * INSTR_PER_TERM_SWEEP +
+           2.0 * T * N * (N - 1) / 2 * INSTR_PER_TERM_LOGLIK) * 2.0
+    tf = ops / (ms_per_step * 1e-3) / 1e12
+    return {'achieved_TFLOPs': round(tf, 3), 'frac': round(tf / F64_VALU_PEAK_TFLOPS, 4),
+            'frac_of_sustained': round(tf / F64_VALU_PEAK_TFLOPS / F64_VALU_SUSTAINED_FRAC, 4)}
+
+
+class HdpWorkload(object):
+    """configs[2] / configs[4]: DynamicNetworkHDPLPCM through the estimator facade's
+    prepare / run seam (starting values supplied: the initialisation pipeline is measured
+    separately, profiles/init_timing.py)"""
+    name = 'hdp'
+
+    def __init__(self, args, group, local_rank):
+        from dynetlsm_amd import DynamicNetworkHDPLPCM
+        from dynetlsm_amd.synthetic import synthetic_hdp_network
+        self.args, self.group = args, group
+        T, N, D, Kc = args.T, args.N, args.D, args.K
+        rank = group.rank
+        K, W, P = args.steps, args.warmup, args.profile_steps
+        net = synthetic_hdp_network(T, N, D, density=args.density, seed=0) if rank == 0 else None
+        self.net = net
+        # starting values: the truth plus noise (positions), true labels and centres
+        nc = 6
+        if rank == 0:
+            init_small = np.concatenate([net['X_init'].ravel(), [net['intercept']],
+                                         net['mu_true'].ravel(), net['sigma_true'].ravel(),
+                                         net['z_true'].ravel().astype(np.float64),
+                                         [net['Y'].mean()]])
+        else:
+            init_small = np.zeros(T * N * D + 1 + nc * D + nc + T * N + 1)
+        init_small = group.broadcast_array(init_small)
+        o = 0
+        X0 = init_small[o:o + T * N * D].reshape(T, N, D); o += T * N * D
+        b0 = float(init_small[o]); o += 1
+        mu_t = init_small[o:o + nc * D].reshape(nc, D); o += nc * D
+        sg_t = init_small[o:o + nc]; o += nc
+        z0 = init_small[o:o + T * N].reshape(T, N).astype(np.int64); o += T * N
+        self.density = float(init_small[o])
+        mu0 = np.zeros((Kc, D)); mu0[:nc] = mu_t
+        rs = np.random.RandomState(5)
+        mu0[nc:] = 3.0 * rs.randn(Kc - nc, D)
+        sg0 = np.full(Kc, float(sg_t.mean())); sg0[:nc] = sg_t
+        self.model = m = DynamicNetworkHDPLPCM(
+            n_iter=1 + W + K + P, tune=None, burn=None, n_components=Kc, n_features=D,
+            random_state=1 + rank, device=local_rank, chain_id=rank, sweep_algo=args.algo,
+            selection_type='map')
+        # the facade wants a network argument: rank 0 has the real one; the others get the
+        # packed words from rank 0's chain and only need the shape on the host
+        shell = {}
+
+        def network_from(chain):
+            shell['chain'] = chain
+            if rank == 0:
+                chain.upload_network(net['Y'])
+            group.broadcast_chain_network(chain)
+        Yarg = net['Y'] if rank == 0 else np.zeros((T, N, N))
+        m.copy = False
+        m._prepare(Yarg, init=dict(X=X0, intercept=[b0], mu=mu0, sigma=sg0, z=z0),
+                   network_from=network_from)
+        self.next_it = 1
+
+    def run(self, count):
+        self.model._run(self.next_it, count)
+        self.next_it += count
+
+    def synchronize(self):
+        self.model.chain_.synchronize()
+
+    def workload(self):
+        a = self.args
+        return ('DynamicNetworkHDPLPCM synthetic undirected T=%d N=%d d=%d K_max=%d '
+                '(6 true clusters), 1 chain per GPU' % (a.T, a.N, a.D, a.K))
+
+    def metric(self):
+        a = self.args
+        return 'Gibbs iterations/sec, HDP-LPCM T=%d N=%d d=%d K=%d' % (a.T, a.N, a.D, a.K)
+
+    def profile(self):
+        from dynetlsm_amd import _lib
+        a, chain = self.args, self.model.chain_
+        P = a.profile_steps
+        chain.profile_enable(True)
+        self.run(P)
+        chain.synchronize()
+        ms_sw, n_sw = chain.profile_read(_lib.K_SWEEP)
+        ms_ll, n_ll = chain.profile_read(_lib.K_LOGLIK)
+        ms_ps, n_ps = chain.profile_read(_lib.K_CENTER)
+        ms_lb, n_lb = chain.profile_read(_lib.K_LABELS)
+        chain.profile_enable(False)
+        ms_ev, n_ev = chain.profile_read(_lib.K_SWEEP_EVAL)
+        roofline, extra = sweep_rooflines(chain, a, P, ms_sw / max(n_sw, 1), ms_ll / max(n_ll, 1),
+                                          ms_ev, n_ev, 0.0, 0, ms_ps / max(n_ps, 1), 0.0)
+        extra['ms_label_kernels_per_iteration'] = round(ms_lb / max(P, 1), 4)
+        return roofline, extra
+
+    def results(self, first, count):
+        m = self.model
+        sl = slice(first, first + count)
+        return dict(X_mean=m.Xs_[sl].mean(axis=0), logps=m.logps_[sl].copy(),
+                    intercepts=m.intercepts_[sl].copy(), lambdas=m.lambdas_[sl].copy(),
+                    n_clusters_used=np.array([float(len(np.unique(z))) for z in m.zs_[sl]]))
+
+    def acceptance(self):
+        m = self.model
+        g = m.chain_.get_samplers(m.latent_samplers)
+        return float(g.n_accepted.sum()) / max(float(g.n_steps.sum()), 1.0)
+
+    def cpu_baseline(self):
+        return None
+
+    def close(self):
+        self.model.chain_.close()
+
+
+def measure(wl, args, group):
+    """W untimed warm-up steps, then exactly K steps between barriers + synchronisation,
+    max over ranks; the roofline profile and the final gather follow outside the timed region"""
+    import torch
+    K, W = args.steps, args.warmup
+    wl.run(W)
+    wl.synchronize()
+    torch.cuda.synchronize()
+    group.barrier()
+    t0 = time.perf_counter()
+    wl.run(K)
+    wl.synchronize()
+    torch.cuda.synchronize()
+    group.barrier()
+    elapsed = group.max_over_ranks(time.perf_counter() - t0)
+    roofline, extra = (None, {})
+    if args.profile_steps > 0:
+        roofline, extra = wl.profile()
+    acc = wl.acceptance()
+    gathered = group.gather_results(wl.results(1 + W, K))
+    return elapsed, roofline, extra, acc, gathered
+
+
+def chain_summaries(g):
+    """[intercept mean, intercept sd, logp mean, logp last] per chain + the spread of the
+    gathered posterior-mean positions between chains"""
+    out = []
+    for c in range(g['logps'].shape[0]):
+        out.append([float(g['intercepts'][c, :, 0].mean()), float(g['intercepts'][c, :, 0].std()),
+                    float(g['logps'][c].mean()), float(g['logps'][c, -1])])
+    return out
+
+
+def run_rank(args):
+    import torch
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if rank == 0:
+            print('bench.py: --gpus %d but WORLD_SIZE=%d' % (args.gpus, world), file=sys.stderr)
+        sys.exit(2)
+    from dynetlsm_amd.multichain import init_chain_group
+    if args.share_device0:
+        local_rank = 0
+        os.environ['LOCAL_RANK'] = '0'
+    # one process per GPU; collectives over RCCL (backend "nccl") unless told otherwise
+    group = init_chain_group(backend=(args.backend or 'nccl') if world > 1 else 'gloo')
+    torch.cuda.set_device(local_rank)
+    K, W = args.steps, args.warmup
+    models = ['lsm', 'hdp'] if args.model == 'all' else [args.model]
+    lines = []
+    for name in models:
+        wl = (LsmWorkload if name == 'lsm' else HdpWorkload)(args, group, local_rank)
+        elapsed, roofline, extra, acc, gathered = measure(wl, args, group)
+        cpu = None
+        if rank == 0 and not args.no_cpu and args.cpu_iters > 0:
+            cpu = wl.cpu_baseline()
+        if rank == 0:
+            value = world * K / elapsed
+            xm = gathered['X_mean']
+            line = {
+                'metric': wl.metric(), 'value': round(value, 3), 'unit': 'Gibbs iterations/s',
+                'n_gpus': world, 'steps': K, 'warmup': W,
+                'ms_per_step': round(1e3 * elapsed / K, 4), 'higher_is_better': True,
+                'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+                'config': {'workload': wl.workload(), 'density': round(wl.density, 4),
+                           'chains': world,
+                           'sweep_algo': (wl.chain if name == 'lsm' else wl.model.chain_)
+                           .resolve_sweep_algo(args.algo),
+                           'mh_acceptance_rate': round(acc, 3),
+                           'network_broadcast': ('packed words, device to device (%s)'
+                                                 % group.backend) if world > 1 else 'none'},
+                'roofline': roofline, 'cpu_baseline': cpu,
+                'chain_summaries[intercept_mean,intercept_sd,logp_mean,logp_last]':
+                    chain_summaries(gathered),
+                'gathered': {k: list(v.shape) for k, v in gathered.items()},
+                'X_mean_rms_between_chains': (round(float(np.sqrt(((xm - xm.mean(0)) ** 2).mean())), 5)
+                                              if world > 1 else 0.0)}
+            if name == 'lsm':
+                line['config']['iteration'] = ('sweep + procrustes + centring + intercept MH + '
+                                               'logp trace')
+                line['iteration_fp64_valu'] = iteration_valu_fraction(1e3 * elapsed / K, args)
+            else:
+                line['config']['iteration'] = ('sweep (mixture prior) + centring + intercept MH + '
+                                               'label block update + HDP auxiliary / conjugate / '
+                                               'hyper-parameter draws + logp trace')
+                line['config']['loop'] = getattr(wl.model, 'loop_kind_', 'host-driven')
+                line['n_clusters_used_last'] = [float(v[-1]) for v in gathered['n_clusters_used']]
+            line.update(extra)
+            lines.append(line)
+        wl.close()
     if rank == 0:
-        value = world * K / elapsed
-        line = {
-            'metric': 'Gibbs iterations/sec (and ms/log-lik eval), T=10 N=2000 d=2',
-            'value': round(value, 3), 'unit': 'Gibbs iterations/s', 'n_gpus': world,
-            'steps': K, 'warmup': W, 'ms_per_step': round(1e3 * elapsed / K, 4),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': 'DynamicNetworkLSM synthetic undirected T=%d N=%d d=%d, '
-                                   '1 chain per GPU' % (T, N, D),
-                       'density': round(density, 4), 'chains': world,
-                       'iteration': 'sweep + procrustes + centring + intercept MH + logp trace',
-                       'sweep_algo': chain.resolve_sweep_algo(args.algo),
-                       'mh_acceptance_rate': round(acc_rate, 3)},
-            'roofline': roofline, 'cpu_baseline': cpu,
-            'chain_summaries[intercept_mean,intercept_sd,logp_mean,logp_last]': summaries,
-        }
-        line.update(extra)
-        print(json.dumps(line))
-    chain.close()
+        head = lines[0]
+        if len(lines) > 1:
+            head['extra_configs'] = lines[1:]
+        print(json.dumps(head), flush=True)
     group.close()
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        sys.exit(launch_ranks(args))
+    run_rank(args)
 
 
 if __name__ == '__main__':

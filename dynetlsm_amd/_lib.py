@@ -49,6 +49,9 @@ SIGNATURES = {
     'dlsm_destroy': (None, [handle_t]),
     'dlsm_synchronize': (C.c_int, [handle_t]),
     'dlsm_upload_network': (C.c_int, [handle_t, c_double_p]),
+    'dlsm_network_packed_words': (C.c_int, [handle_t, c_i64_p]),
+    'dlsm_get_network_packed': (C.c_int, [handle_t, C.c_void_p, C.c_int64]),
+    'dlsm_set_network_packed': (C.c_int, [handle_t, C.c_void_p, C.c_int64]),
     'dlsm_upload_edges': (C.c_int, [handle_t, c_i64_p, C.c_int, c_i64_p, C.c_int,
                                     c_i64_p]),
     'dlsm_set_controls': (C.c_int, [handle_t, c_i64_p, c_i64_p, C.c_int]),

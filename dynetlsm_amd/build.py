@@ -2,6 +2,7 @@
 
 hipcc cross-compiles without a GPU; the built library travels with the tree.
 """
+import glob
 import os
 import shutil
 import subprocess
@@ -10,9 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libdynetlsm_hip.so')
 SOURCES = ['capi.hip']
-HEADERS = ['chain.hpp', 'device_common.hpp', 'kernels_loglik.hpp',
-           'kernels_sweep.hpp', 'kernels_labels.hpp', 'kernels_spec.hpp', 'kernels_spec_sweep.hpp',
-           os.path.join('..', '..', 'include', 'dynetlsm_hip.h')]
+INCLUDE = os.path.join(HERE, '..', 'include')
 FLAGS = ['-O3', '--offload-arch=gfx950', '-std=c++17', '-Wno-unused-value',
          '-Wno-unused-result', '-shared', '-fPIC']
 
@@ -24,12 +23,21 @@ def hipcc():
     raise RuntimeError('hipcc not found (set HIPCC or install ROCm under /opt/rocm)')
 
 
+def dependencies():
+    """every file the library is compiled from: all of csrc/ and include/ (capi.hip is a
+    unity build that includes every header, so any of them can change the binary)"""
+    deps = []
+    for pat in (os.path.join(CSRC, '*.hip'), os.path.join(CSRC, '*.hpp'),
+                os.path.join(CSRC, '*.h'), os.path.join(INCLUDE, '*.h')):
+        deps.extend(glob.glob(pat))
+    return sorted(deps)
+
+
 def stale():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
-    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+    return any(os.path.getmtime(d) > t for d in dependencies())
 
 
 def build(force=False, verbose=False):

@@ -136,10 +136,17 @@ int h2d_enqueue(dlsm_chain *h, T *dst, const T *src, size_t n, size_t *off) {
     return DLSM_OK;
 }
 
-// int64 host array -> int32 device array (indices < 2^31 by construction)
-int upload_i64_as_i32(dlsm_chain *h, int32_t **dst, const int64_t *src, size_t n) {
+// int64 host array -> int32 device array; every value must lie in [lo, hi) (node indices
+// index device arrays: a bad one would be an out-of-bounds read in the kernels)
+int upload_i64_as_i32(dlsm_chain *h, int32_t **dst, const int64_t *src, size_t n,
+                      int64_t lo, int64_t hi, const char *what) {
     std::vector<int32_t> tmp(n);
-    for (size_t i = 0; i < n; ++i) tmp[i] = (int32_t)src[i];
+    for (size_t i = 0; i < n; ++i) {
+        if (src[i] < lo || src[i] >= hi)
+            FAIL(h, DLSM_E_DATA, "%s[%zu] = %lld outside [%lld, %lld)", what, i,
+                 (long long)src[i], (long long)lo, (long long)hi);
+        tmp[i] = (int32_t)src[i];
+    }
     if (*dst) { hipFree(*dst); *dst = nullptr; }
     int rc = dev_alloc(h, dst, n);
     if (rc) return rc;
@@ -372,6 +379,65 @@ int dlsm_upload_network(dlsm_chain *h, const double *Y) {
     return DLSM_OK;
 }
 
+static int64_t packed_words(const dlsm_chain *h) {
+    return (int64_t)h->T * h->N * h->W * (h->model == DLSM_DIRECTED ? 2 : 1);
+}
+
+int dlsm_network_packed_words(dlsm_chain *h, int64_t *n_words) {
+    NEED(h, h && n_words, "null argument");
+    NEED(h, h->model != DLSM_DIRECTED_CASE_CONTROL, "case-control chains hold edge lists");
+    *n_words = packed_words(h);
+    return DLSM_OK;
+}
+
+int dlsm_get_network_packed(dlsm_chain *h, uint32_t *buf, int64_t n_words) {
+    NEED(h, h && buf, "null argument");
+    NEED(h, h->model != DLSM_DIRECTED_CASE_CONTROL, "case-control chains hold edge lists");
+    NEED(h, h->have_network, "network not uploaded");
+    NEED(h, n_words == packed_words(h), "buffer must hold %lld words", (long long)packed_words(h));
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t one = (size_t)h->T * h->N * h->W;
+    HIPCHK(h, hipMemcpyAsync(buf, h->ybits, one * sizeof(uint32_t), hipMemcpyDefault, h->stream));
+    if (h->model == DLSM_DIRECTED)
+        HIPCHK(h, hipMemcpyAsync(buf + one, h->ytbits, one * sizeof(uint32_t), hipMemcpyDefault,
+                                 h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return DLSM_OK;
+}
+
+int dlsm_set_network_packed(dlsm_chain *h, const uint32_t *buf, int64_t n_words) {
+    NEED(h, h && buf, "null argument");
+    drop_graph(h);
+    NEED(h, h->model != DLSM_DIRECTED_CASE_CONTROL, "case-control chains hold edge lists");
+    NEED(h, n_words == packed_words(h), "buffer must hold %lld words", (long long)packed_words(h));
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t one = (size_t)h->T * h->N * h->W;
+    if (!h->ybits) { int rc = dev_alloc(h, &h->ybits, one); if (rc) return rc; }
+    if (h->model == DLSM_DIRECTED && !h->ytbits) {
+        int rc = dev_alloc(h, &h->ytbits, one); if (rc) return rc;
+    }
+    HIPCHK(h, hipMemcpyAsync(h->ybits, buf, one * sizeof(uint32_t), hipMemcpyDefault, h->stream));
+    if (h->model == DLSM_DIRECTED)
+        HIPCHK(h, hipMemcpyAsync(h->ytbits, buf + one, one * sizeof(uint32_t), hipMemcpyDefault,
+                                 h->stream));
+    // the layout's invariants, checked on the device: padding bits beyond N and the diagonal
+    // are zero (the kernels rely on both), the undirected network is symmetric
+    int *dflag = (int *)(h->dsmall + 48);
+    HIPCHK(h, hipMemsetAsync(dflag, 0, sizeof(int), h->stream));
+    hipLaunchKernelGGL(k_check_packed, dim3((unsigned)((size_t)h->T * h->N)), dim3(64), 0, h->stream,
+                       h->ybits, h->model == DLSM_DIRECTED ? h->ytbits : h->ybits, h->T, h->N,
+                       h->W, dflag);
+    HIPCHK(h, hipGetLastError());
+    int flag = 0;
+    HIPCHK(h, hipMemcpyAsync(&flag, dflag, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (flag) FAIL(h, DLSM_E_DATA, "packed network violates the layout (code %d: 1 padding bits, "
+                                   "2 diagonal, 4 transpose mismatch)", flag);
+    h->have_network = true;
+    h->have_hops = false;
+    return DLSM_OK;
+}
+
 int dlsm_upload_edges(dlsm_chain *h, const int64_t *in_edges, int Din,
                       const int64_t *out_edges, int Dout, const int64_t *degree) {
     NEED(h, h && in_edges && out_edges && degree, "null argument");
@@ -385,9 +451,12 @@ int dlsm_upload_edges(dlsm_chain *h, const int64_t *in_edges, int Din,
         if (a < 0 || a > Din || b < 0 || b > Dout)
             FAIL(h, DLSM_E_DATA, "degree out of range at node %zu", i);
     }
-    int rc = upload_i64_as_i32(h, &h->in_edges, in_edges, TN * Din); if (rc) return rc;
-    rc = upload_i64_as_i32(h, &h->out_edges, out_edges, TN * Dout); if (rc) return rc;
-    rc = upload_i64_as_i32(h, &h->degree, degree, TN * 2); if (rc) return rc;
+    int rc = upload_i64_as_i32(h, &h->in_edges, in_edges, TN * Din, 0, h->N, "in_edges");
+    if (rc) return rc;
+    rc = upload_i64_as_i32(h, &h->out_edges, out_edges, TN * Dout, 0, h->N, "out_edges");
+    if (rc) return rc;
+    rc = upload_i64_as_i32(h, &h->degree, degree, TN * 2, 0, (int64_t)h->N, "degree");
+    if (rc) return rc;
     h->Din = Din; h->Dout = Dout;
     h->have_edges = true;
     return DLSM_OK;
@@ -400,8 +469,10 @@ int dlsm_set_controls(dlsm_chain *h, const int64_t *ctrl_in, const int64_t *ctrl
     NEED(h, h->model == DLSM_DIRECTED_CASE_CONTROL, "not a case-control chain");
     HIPCHK(h, hipSetDevice(h->device));
     const size_t TN = (size_t)h->T * h->N;
-    int rc = upload_i64_as_i32(h, &h->ctrl_in, ctrl_in, TN * C); if (rc) return rc;
-    rc = upload_i64_as_i32(h, &h->ctrl_out, ctrl_out, TN * C); if (rc) return rc;
+    int rc = upload_i64_as_i32(h, &h->ctrl_in, ctrl_in, TN * C, -1, h->N, "control_nodes_in");
+    if (rc) return rc;                              // -1 = padding
+    rc = upload_i64_as_i32(h, &h->ctrl_out, ctrl_out, TN * C, -1, h->N, "control_nodes_out");
+    if (rc) return rc;
     h->C = C;
     h->have_controls = true;
     h->nctrl_valid = false;
@@ -1072,10 +1143,14 @@ int dlsm_sample_labels(dlsm_chain *h, uint32_t iter, const double *w, int64_t *z
     HIPCHK(h, hipSetDevice(h->device));
     const int T = h->T, K = h->K, N = h->N;
     const size_t nn = (size_t)T * K * K, nnk = (size_t)T * K;
-    if (!h->lab_n) {
+    if (h->lab_cap < nn) {                  // n_components may grow on a live handle
+        void *old[] = {h->lab_n, h->lab_nk, h->lab_w};
+        for (void *p : old) if (p) hipFree(p);
+        h->lab_n = h->lab_nk = nullptr; h->lab_w = nullptr; h->lab_cap = 0;
         int rc = dev_alloc(h, &h->lab_n, nn); if (rc) return rc;
         rc = dev_alloc(h, &h->lab_nk, nnk); if (rc) return rc;
         rc = dev_alloc(h, &h->lab_w, nn); if (rc) return rc;
+        h->lab_cap = nn;
     }
     const size_t lds_tables = (size_t)LAB_WAVES * 2 * T * K * sizeof(double);
     const size_t lds_w = (size_t)T * K * lab_row_pad(K) * sizeof(double);

@@ -91,6 +91,7 @@ struct dlsm_chain {
     double *hsmall = nullptr;      // 64 doubles of pinned host scratch
     double *xref = nullptr;        // T*N*D (procrustes reference staging)
     int32_t *lab_n = nullptr, *lab_nk = nullptr; double *lab_w = nullptr;
+    size_t lab_cap = 0;                                    // T*K*K the three were sized for
     // sweep v2 scratch
     double *spec = nullptr; size_t spec_cap = 0;
     double *pipe = nullptr; size_t pipe_cap = 0;        // pipelined sweep (algo 4) buffers

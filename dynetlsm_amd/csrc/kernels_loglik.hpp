@@ -35,6 +35,34 @@ __global__ __launch_bounds__(256) void k_pack_bits(const double *__restrict__ Y,
     }
 }
 
+// Invariants of a packed network handed in ready-made (dlsm_set_network_packed): bits beyond
+// N and the diagonal are zero, bit i of row j of `bits` equals bit j of row i of `tbits`
+// (tbits = bits for the undirected model: symmetry).  One wavefront per row.
+__global__ __launch_bounds__(64) void k_check_packed(const uint32_t *__restrict__ bits,
+                                                     const uint32_t *__restrict__ tbits, int T,
+                                                     int N, int W, int *__restrict__ flag) {
+    const int lane = threadIdx.x;
+    const size_t row = blockIdx.x;
+    const int t = (int)(row / N), j = (int)(row % N);
+    const uint32_t *r = bits + row * W;
+    int bad = 0;
+    for (int w = lane; w < W; w += 64) {
+        const uint32_t v = r[w];
+        const int lo = 32 * w;
+        if (lo + 32 > N) {
+            const uint32_t keep = lo >= N ? 0u : ((1u << (N - lo)) - 1u);
+            if (v & ~keep) bad |= 1;
+        }
+        if (j >= lo && j < lo + 32 && ((v >> (j - lo)) & 1u)) bad |= 2;
+    }
+    for (int i = lane; i < N; i += 64) {
+        const uint32_t a = (r[i >> 5] >> (i & 31)) & 1u;
+        const uint32_t b = (tbits[((size_t)t * N + i) * W + (j >> 5)] >> (j & 31)) & 1u;
+        if (a != b) bad |= 4;
+    }
+    if (bad) atomicOr(flag, bad);
+}
+
 // ---------------------------------------------------------------------------
 // Full log-likelihood, undirected (a4) and directed (a5).
 //

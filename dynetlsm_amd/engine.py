@@ -139,6 +139,22 @@ class Chain(object):
         Y = _f64(Y, (self.T, self.N, self.N), 'Y')
         self._ck(self._L.dlsm_upload_network(self._h, _p(Y)))
 
+    def network_packed_words(self):
+        """uint32 words of the bit-packed network as the chain holds it"""
+        n = C.c_int64(0)
+        self._ck(self._L.dlsm_network_packed_words(self._h, C.byref(n)))
+        return int(n.value)
+
+    def get_network_packed(self, ptr, n_words):
+        """copy the packed network into ``ptr`` (device or host address, e.g.
+        ``tensor.data_ptr()`` of an int32 tensor of ``n_words`` elements)"""
+        self._ck(self._L.dlsm_get_network_packed(self._h, C.c_void_p(int(ptr)), int(n_words)))
+
+    def set_network_packed(self, ptr, n_words):
+        """take the packed network from ``ptr`` (as written by ``get_network_packed`` of a
+        chain of the same shape and model); the layout's invariants are checked"""
+        self._ck(self._L.dlsm_set_network_packed(self._h, C.c_void_p(int(ptr)), int(n_words)))
+
     def upload_edges(self, in_edges, out_edges, degree):
         ie = _i64(in_edges); oe = _i64(out_edges)
         dg = _i64(degree, (self.T, self.N, 2), 'degree')

@@ -166,6 +166,18 @@ class DynamicNetworkHDPLPCM(FittedQuantities):
     def fit(self, Y, init=None):
         """Sample the posterior of the HDP-LPCM given ``Y`` (T, N, N).  ``init``
         may carry starting values ``X, intercept[, radii][, mu, sigma, z]``."""
+        self._prepare(Y, init)
+        t_loop = time.perf_counter()
+        self._run(1, self._n_total - 1)
+        self.chain_.synchronize()
+        self.loop_seconds_ = time.perf_counter() - t_loop     # Gibbs loop only
+        return self._finish()
+
+    def _prepare(self, Y, init=None, network_from=None):
+        """Everything of ``fit`` before the Gibbs loop (hdp_lpcm.py:628-821): checks,
+        starting values, hyper-priors, the chain handle and the trace arrays.
+        ``network_from``: callable(chain) that loads the network into the chain some other
+        way than the float64 upload (multi-GPU: the packed broadcast of multichain)."""
         Y = np.array(Y, dtype=np.float64, copy=self.copy, order='C')
         if Y.ndim != 3 or Y.shape[1] != Y.shape[2]:
             raise ValueError('Y must have shape (n_time_steps, n_nodes, n_nodes)')
@@ -243,6 +255,8 @@ class DynamicNetworkHDPLPCM(FittedQuantities):
             self.case_control_sampler_ = DirectedCaseControlSampler(
                 n_control=self.n_control, n_resample=self.n_resample_control,
                 chain=chain).init(Y)
+        elif network_from is not None:
+            network_from(chain)
         else:
             chain.upload_network(Y)
         chain.set_positions(X)
@@ -269,22 +283,38 @@ class DynamicNetworkHDPLPCM(FittedQuantities):
         self.radiis_ = np.zeros((n_total, N)) if self.is_directed else None
         self.logps_ = np.zeros(n_total)
 
-        def store(it, ll):
-            self.Xs_[it], self.intercepts_[it] = X, intercept
-            self.mus_[it], self.sigmas_[it], self.zs_[it] = mu, sigma, z
-            self.betas_[it], self.weights_[it], self.lambdas_[it] = beta, weights, lmbda
-            if self.is_directed:
-                self.radiis_[it] = radii
-            self.logps_[it] = np.ravel(ll + hu.log_posterior_terms(
-                sums, intercept, ip, self.intercept_variance_prior, mu, sigma, weights, beta,
-                lmbda, hp, radii=radii))[0]
-
         chain.set_prior_mixture(mu, sigma, lmbda, z)
-        sums = hu.DeviceLabelSums(chain)        # label-wise sums at the chain's X and z
-        store(0, chain.loglik_full())
+        self._n_total, self._rng, self._ip, self._miss = n_total, rng, ip, miss
+        self._sums = hu.DeviceLabelSums(chain)  # label-wise sums at the chain's X and z
+        self._st = dict(X=X, intercept=intercept, mu=mu, sigma=sigma, z=z, beta=beta,
+                        weights=weights, lmbda=lmbda, radii=radii)
+        self._store(0, chain.loglik_full())
+        return self
+
+    def _store(self, it, ll):
+        st, hp = self._st, self.hyper_
+        self.Xs_[it], self.intercepts_[it] = st['X'], st['intercept']
+        self.mus_[it], self.sigmas_[it], self.zs_[it] = st['mu'], st['sigma'], st['z']
+        self.betas_[it], self.weights_[it] = st['beta'], st['weights']
+        self.lambdas_[it] = st['lmbda']
+        if self.is_directed:
+            self.radiis_[it] = st['radii']
+        self.logps_[it] = np.ravel(ll + hu.log_posterior_terms(
+            self._sums, st['intercept'], self._ip, self.intercept_variance_prior, st['mu'],
+            st['sigma'], st['weights'], st['beta'], st['lmbda'], hp, radii=st['radii']))[0]
+
+    def _run(self, first, count):
+        """Gibbs iterations first .. first + count - 1 (hdp_lpcm.py:823-1069), host-driven:
+        the kernels of the engine around numpy draws on the caller's MT19937 stream."""
+        chain, rng, hp, ip = self.chain_, self._rng, self.hyper_, self._ip
+        isamp, rsamp, sums, miss = (self.intercept_samplers, self.radii_sampler, self._sums,
+                                    self._miss)
+        st = self._st
+        X, intercept, mu, sigma, z = st['X'], st['intercept'], st['mu'], st['sigma'], st['z']
+        beta, weights, lmbda, radii = st['beta'], st['weights'], st['lmbda'], st['radii']
+        n_ic = 2 if self.is_directed else 1
         var = self.intercept_variance_prior
-        t_loop = time.perf_counter()
-        for it in range(1, n_total):
+        for it in range(first, first + count):
             if self.case_control_sampler_ is not None:
                 self.case_control_sampler_.resample(it)
             chain.set_prior_mixture(mu, sigma, lmbda, None)      # z: the device keeps its own
@@ -332,9 +362,14 @@ class DynamicNetworkHDPLPCM(FittedQuantities):
                 y_ij = rng.binomial(1, 1. / (1. + np.exp(-eta)))
                 if it > self.n_burn_:
                     self.missings_ += y_ij
-            store(it, ll)
-        self.loop_seconds_ = time.perf_counter() - t_loop     # Gibbs loop only
-        if miss is not None:
+            st.update(X=X, intercept=intercept, mu=mu, sigma=sigma, z=z, beta=beta,
+                      weights=weights, lmbda=lmbda, radii=radii)
+            self._store(it, ll)
+
+    def _finish(self):
+        """Everything of ``fit`` after the Gibbs loop (hdp_lpcm.py:1072-1176)."""
+        chain, hp, n_total = self.chain_, self.hyper_, self._n_total
+        if self._miss is not None:
             self.missings_ /= max(1, n_total - self.n_burn_)       # hdp_lpcm.py:1155-1156
         chain.get_samplers(self.latent_samplers)
         self.gamma, self.alpha_init, self.alpha, self.kappa = (hp.gamma, hp.alpha_init,

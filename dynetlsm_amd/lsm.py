@@ -265,7 +265,9 @@ class DynamicNetworkLSM(FittedQuantities):
                 if ccs is not None:
                     ccs.resample(it)
                     nxt = it + 1                  # next iteration that resamples
-                    while nxt <= last and ccs.n_iter % ccs.n_resample != 0:
+                    # n_resample_control=None: never resample (case_control_likelihood.py:28)
+                    while nxt <= last and (ccs.n_resample is None or
+                                           ccs.n_iter % ccs.n_resample != 0):
                         ccs.n_iter += 1
                         nxt += 1
                     chain.lsm_run(it, nxt - it, procrustes_ref=prev_map)

@@ -3,11 +3,16 @@
 Chains never talk inside an iteration.  Collectives (RCCL over xGMI when the
 backend is ``nccl``; ``gloo`` on CPU for tests) appear only at the edges:
 
-  * ``broadcast_network``  rank 0's network -> every rank, bit-for-byte: the
-    float64 adjacency tensor is sent as uint8 (1/8 of the bytes; 40 MB at
-    T=10, N=2000) and widened locally;
-  * ``gather_arrays``      per-chain summaries / traces -> every rank
-    (all_gather of equally shaped float64 tensors).
+  * ``broadcast_chain_network``  the network of rank 0's chain -> the chains of the
+    other ranks as the engine holds it, 1 bit per dyad (5 MB at T=10, N=2000 instead
+    of 320 MB of float64), device to device: rank 0 uploads and packs once, the
+    packed words travel over xGMI and land in the other chains without touching a
+    host (``dlsm_get/set_network_packed``);
+  * ``broadcast_network``  the float64 tensor itself for host-side consumers
+    (sent as uint8, widened locally);
+  * ``gather_arrays`` / ``gather_results``  per-chain summaries and traces
+    (posterior mean positions, log-posterior and intercept traces ...) -> every
+    rank (all_gather of equally shaped float64 tensors).
 
 Launch with ``python -m torch.distributed.run --nproc-per-node N script.py``;
 rank r drives GPU LOCAL_RANK with Philox chain id r.
@@ -64,6 +69,23 @@ class ChainGroup(object):
         self._dist.broadcast(buf, src)
         return buf.cpu().numpy().astype(np.float64)
 
+    def broadcast_chain_network(self, chain, src=0):
+        """The packed network of rank ``src``'s chain (already uploaded there) into the
+        chain of every other rank; same shape and model on every rank.  With the RCCL
+        backend the words never leave device memory."""
+        if self.world == 1:
+            return
+        t = self._torch
+        n = chain.network_packed_words()
+        buf = t.empty(n, dtype=t.int32, device=self._tensor_device())
+        if self.rank == src:
+            chain.get_network_packed(buf.data_ptr(), n)
+        self._dist.broadcast(buf, src)
+        if self.backend == 'nccl':
+            t.cuda.current_stream().synchronize()      # the chain copies on its own stream
+        if self.rank != src:
+            chain.set_network_packed(buf.data_ptr(), n)
+
     def broadcast_array(self, a, src=0):
         """small float64 array (same shape known on every rank)"""
         if self.world == 1:
@@ -83,6 +105,12 @@ class ChainGroup(object):
         out = [t.empty_like(mine) for _ in range(self.world)]
         self._dist.all_gather(out, mine)
         return [o.cpu().numpy() for o in out]
+
+    def gather_results(self, results):
+        """dict of equally shaped per-chain float arrays (e.g. ``X_mean`` (T, N, D),
+        ``logps`` (n,), ``intercepts`` (n, 1)) -> dict of (world, ...) arrays holding every
+        chain's entry, on every rank: the final gather of SURVEY.md 8e."""
+        return {k: np.stack(self.gather_arrays(results[k])) for k in sorted(results)}
 
     def max_over_ranks(self, x):
         if self.world == 1:

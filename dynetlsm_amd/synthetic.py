@@ -6,7 +6,7 @@ DynamicNetworkLSM); the reference's generator is O(T N^2) Python-side.
 """
 import numpy as np
 
-__all__ = ['synthetic_lsm_network']
+__all__ = ['synthetic_lsm_network', 'synthetic_hdp_network']
 
 
 def _expit(x):
@@ -58,3 +58,55 @@ def synthetic_lsm_network(T=10, N=2000, D=2, density=0.03, seed=0, directed=Fals
         Y[t] = A
     X_init = X + init_noise * rng.randn(T, N, D)
     return dict(Y=Y, X_true=X, intercept=float(b), X_init=X_init)
+
+
+def synthetic_hdp_network(T=10, N=2000, D=2, n_clusters=6, density=0.03, lmbda=0.8,
+                          stay=0.95, seed=0, center_scale=3.0, sigma=0.25, init_noise=0.1):
+    """BASELINE.json configs[2]: a network with the HDP-LPCM's own
+    dynamics.  Labels follow a sticky Markov chain (a node keeps its cluster with
+    probability ``stay``), positions the blended AR(1) walk of the model,
+    x_0 ~ N(mu_z, sigma^2 I), x_t ~ N((1 - lmbda) x_{t-1} + lmbda mu_z, sigma^2 I)
+    (the dynamics of samples_generator.py:701-796 at N = 2000, vectorised), dyads
+    Bernoulli(expit(b - d)) with b solved for the target density.
+
+    Returns dict(Y, X_true, z_true, mu_true, sigma_true, intercept, X_init): the timing
+    runs start at X_init = truth + noise with the true labels / means as the mixture's
+    starting values (the initialisation pipeline is measured separately)."""
+    rng = np.random.RandomState(seed)
+    ang = 2.0 * np.pi * np.arange(n_clusters) / n_clusters
+    mu = np.zeros((n_clusters, D))
+    mu[:, 0] = center_scale * np.cos(ang)
+    if D > 1:
+        mu[:, 1] = center_scale * np.sin(ang)
+    z = np.zeros((T, N), dtype=np.int64)
+    z[0] = rng.randint(0, n_clusters, size=N)
+    for t in range(1, T):
+        move = rng.rand(N) >= stay
+        z[t] = np.where(move, rng.randint(0, n_clusters, size=N), z[t - 1])
+    X = np.zeros((T, N, D))
+    X[0] = mu[z[0]] + sigma * rng.randn(N, D)
+    for t in range(1, T):
+        X[t] = (1 - lmbda) * X[t - 1] + lmbda * mu[z[t]] + sigma * rng.randn(N, D)
+    shift = X.mean(axis=(0, 1))
+    X -= shift
+    mu = mu - shift
+    d0 = _pairwise(X[0])[np.triu_indices(N, 1)]
+    if d0.size > 400000:                      # the bisection needs the mean to 3 digits only
+        d0 = d0[:: d0.size // 400000]
+    lo, hi = -20.0, 20.0
+    for _ in range(40):
+        b = 0.5 * (lo + hi)
+        if _expit(b - d0).mean() < density:
+            lo = b
+        else:
+            hi = b
+    b = 0.5 * (lo + hi)
+    Y = np.zeros((T, N, N))
+    for t in range(T):
+        A = (rng.rand(N, N) < _expit(b - _pairwise(X[t]))).astype(np.float64)
+        np.fill_diagonal(A, 0.0)
+        A = np.triu(A, 1)
+        Y[t] = A + A.T
+    X_init = X + init_noise * rng.randn(T, N, D)
+    return dict(Y=Y, X_true=X, z_true=z, mu_true=mu, sigma_true=np.full(n_clusters, sigma ** 2),
+                intercept=float(b), X_init=X_init)

@@ -64,6 +64,15 @@ int dlsm_synchronize(dlsm_chain *h);
  * Entries other than 0.0 / 1.0 -> DLSM_E_DATA (the estimators impute -1 coded
  * dyads before the upload, as imputer.py / lsm.py:345-359 do). */
 int dlsm_upload_network(dlsm_chain *h, const double *Y);
+/* the network as the chain holds it (1 bit per dyad; [T][N][W] uint32 words,
+ * W = dlsm_network_packed_words / (T N), followed by the transposed copy for the directed
+ * model), so that one chain's upload can be broadcast to the chains on the other GPUs
+ * (RCCL) without a host round trip of the float64 tensor: at T=10, N=2000 5 MB instead of
+ * 320 MB.  `buf` may be a device or a host pointer (hipMemcpyDefault).  The reference has
+ * no counterpart (examples/homogeneous_simulation.py:178-184 refits seeds serially). */
+int dlsm_network_packed_words(dlsm_chain *h, int64_t *n_words);
+int dlsm_get_network_packed(dlsm_chain *h, uint32_t *buf, int64_t n_words);
+int dlsm_set_network_packed(dlsm_chain *h, const uint32_t *buf, int64_t n_words);
 /* case-control: zero padded edge lists and degrees exactly as
  * DirectedCaseControlSampler.init builds them (case_control_likelihood.py:45-68):
  * in_edges T*N*Din, out_edges T*N*Dout, degree T*N*2 (col 0 in, col 1 out). */

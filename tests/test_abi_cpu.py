@@ -26,6 +26,32 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert lib.dlsm_abi_version() == 1
 
 
+def test_stale_tracks_every_source_of_the_library():
+    """build.stale() must notice a change to ANY file the unity build includes
+    (round-1 advice: the headline kernel's header was not watched)"""
+    from dynetlsm_amd import build as b
+    b.build()
+    deps = b.dependencies()
+    names = {os.path.basename(d) for d in deps}
+    for must in ('capi.hip', 'kernels_spec_pipe.hpp', 'kernels_hdp.hpp', 'kernels_dirloop.hpp',
+                 'host_draws.hpp', 'capi_init.hpp', 'dynetlsm_hip.h', 'device_common.hpp'):
+        assert must in names, must
+    # every header the sources include is a dependency
+    inc = set()
+    for d in deps:
+        inc.update(re.findall(r'#include\s+"([^"]+)"', open(d).read()))
+    assert {os.path.basename(i) for i in inc} <= names
+    assert not b.stale()
+    target = [d for d in deps if d.endswith('kernels_spec_pipe.hpp')][0]
+    st = os.stat(target)
+    try:
+        os.utime(target, (st.st_atime, os.path.getmtime(b.LIB) + 10))
+        assert b.stale()
+    finally:
+        os.utime(target, (st.st_atime, st.st_mtime))
+    assert not b.stale()
+
+
 def test_binding_covers_the_header():
     from dynetlsm_amd import _lib
     assert sorted(_lib.SIGNATURES) == _declared_symbols()

@@ -69,8 +69,11 @@ def test_c2_sweep_algorithms_agree_and_match_oracle(eng, c2):
     assert 0.05 < moved < 0.999
 
 
-def test_c3_hdp_pieces_at_full_size(eng, c2):
-    """config 3: T=10, N=2000, K_max=20: mixture-prior sweep and label update"""
+@pytest.mark.parametrize('algo', [0, 2])
+def test_c3_hdp_pieces_at_full_size(eng, c2, algo):
+    """config 3: T=10, N=2000, K_max=20: mixture-prior sweep - with the algorithm fit()
+    picks at this size (algo 0 = auto = the pipelined sweep) and with the two-kernel
+    speculative form - and the label update, against the C oracle"""
     Y, X, b = c2['Y'], c2['X_init'], c2['intercept']
     rng = np.random.RandomState(1)
     K = 20
@@ -84,15 +87,22 @@ def test_c3_hdp_pieces_at_full_size(eng, c2):
     with eng.Chain(10, 2000, 2, 'undirected', seed=5, chain_id=0) as c:
         c.upload_network(Y); c.set_positions(X); c.set_intercepts([b])
         c.set_prior_mixture(mu, sigma, 0.8, z)
-        c.set_samplers(eng.SamplerGrid(10, 2000, 0.1, tune=None))
-        c.sweep_positions(1, 2)
+        g = eng.SamplerGrid(10, 2000, 0.1, tune=None)
+        c.set_samplers(g)
+        if algo == 0:
+            assert c.resolve_sweep_algo(0) == 4
+        c.sweep_positions(1, algo)
         Xg = c.get_positions()
         np.testing.assert_allclose(Xg, st.X, atol=1e-9)
+        np.testing.assert_array_equal(c.get_samplers(g).n_accepted, og.n_accepted)
         t0 = time.perf_counter()
         zg, n, nk = c.sample_labels(1, w)
         dt = time.perf_counter() - t0
-    zo, no, nko = orc.sample_labels_block_philox(st.X, mu, sigma, 0.8, w, 5, 0, 1)
-    assert (zg != zo).mean() < 1e-4          # identical up to 1-ulp position differences
+    # the oracle draws its labels at the DEVICE's positions: every label must agree
+    zo, no, nko = orc.sample_labels_block_philox(Xg, mu, sigma, 0.8, w, 5, 0, 1)
+    np.testing.assert_array_equal(zg, zo)
+    np.testing.assert_array_equal(n, no)
+    np.testing.assert_array_equal(nk, nko)
     assert n.sum() == 20000 and (nk.sum(axis=1) == 2000).all()
     print('labels T=10 N=2000 K=20: %.2f ms incl. transfers' % (1e3 * dt))
 

@@ -78,6 +78,27 @@ def test_lsm_directed_smoke(eng, n_control):
     assert lsm.intercept_samplers[0].n_steps == 99
 
 
+def test_lsm_case_control_never_resample(eng):
+    """n_resample_control=None means the controls of init() are kept for the whole chain
+    (case_control_likelihood.py:27-33); round-1 advice: the device loop raised TypeError"""
+    Y, _ = _splitting_network(n_nodes=40, n_time_steps=3, directed=True)
+    lsm = eng.DynamicNetworkLSM(n_iter=30, burn=10, tune=10, is_directed=True, n_control=10,
+                                n_resample_control=None, random_state=5, tau_sq='auto',
+                                sigma_sq=0.001, step_size_X=0.0075)
+    lsm.fit(Y)
+    assert np.isfinite(lsm.logps_).all()
+    assert lsm.intercept_samplers[0].n_steps == 49
+    ccs = lsm.case_control_sampler_
+    ci, co = ccs.control_nodes_in_, ccs.control_nodes_out_
+    lsm2 = eng.DynamicNetworkLSM(n_iter=3, burn=None, tune=None, is_directed=True, n_control=10,
+                                 n_resample_control=None, random_state=5, tau_sq='auto',
+                                 sigma_sq=0.001, step_size_X=0.0075)
+    lsm2.fit(Y)
+    # same seed, never resampled: the controls are those drawn at init in both fits
+    np.testing.assert_array_equal(ci, lsm2.case_control_sampler_.control_nodes_in_)
+    np.testing.assert_array_equal(co, lsm2.case_control_sampler_.control_nodes_out_)
+
+
 def test_hdp_directed_smoke(eng):
     Y, _ = _splitting_network(n_nodes=30, n_time_steps=2, directed=True)
     m = eng.DynamicNetworkHDPLPCM(n_iter=30, burn=10, tune=10, is_directed=True,

@@ -26,6 +26,30 @@ WORKER = textwrap.dedent('''
     assert np.array_equal(Y, ref)
     x0 = g.broadcast_array(np.arange(4.0) if g.rank == 0 else np.zeros(4))
     assert np.array_equal(x0, np.arange(4.0))
+    # the packed broadcast (dlsm_get/set_network_packed through a stand-in chain that keeps
+    # its words in host memory; with gloo the buffer handed over is a host pointer)
+    import ctypes
+    class FakeChain(object):
+        def __init__(self, words=None):
+            self.words = None if words is None else np.ascontiguousarray(words, dtype=np.uint32)
+            self.n = 3 * 17 * 4
+        def network_packed_words(self):
+            return self.n
+        def get_network_packed(self, ptr, n):
+            assert n == self.n
+            ctypes.memmove(ptr, self.words.ctypes.data, 4 * n)
+        def set_network_packed(self, ptr, n):
+            assert n == self.n
+            self.words = np.zeros(n, dtype=np.uint32)
+            ctypes.memmove(self.words.ctypes.data, ptr, 4 * n)
+    wref = np.random.RandomState(9).randint(0, 2 ** 32, size=3 * 17 * 4, dtype=np.uint64).astype(np.uint32)
+    ch = FakeChain(wref if g.rank == 0 else None)
+    g.broadcast_chain_network(ch)
+    assert np.array_equal(ch.words, wref)
+    res = g.gather_results(dict(X_mean=np.full((3, 17, 2), float(g.rank)),
+                                logps=np.arange(5.0) + g.rank))
+    assert res['X_mean'].shape == (2, 3, 17, 2) and res['logps'].shape == (2, 5)
+    assert res['X_mean'][1].min() == 1.0 and res['logps'][1][0] == 1.0
     # stand-in for a chain: a summary that depends on the chain id
     summ = np.array([g.chain_id, Y.sum() + g.chain_id, 0.5])
     allsum = g.gather_arrays(summ)
@@ -79,3 +103,18 @@ def test_single_process_group_is_a_no_op():
     assert np.array_equal(g.broadcast_network(Y), Y)
     assert g.gather_arrays(np.ones(2))[0].tolist() == [1.0, 1.0]
     assert g.max_over_ranks(3.0) == 3.0
+
+
+def test_bench_self_launch_propagates_rank_failure():
+    """`python bench.py --gpus 2` spawns its ranks itself; on a box without a GPU the ranks
+    fail loudly (no CPU fallback) and the parent exits non-zero instead of hanging"""
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip('a GPU is present: covered by the gpu tests')
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2',
+                        '--backend', 'gloo', '--share-device0', '--steps', '2', '--warmup', '1',
+                        '--model', 'lsm', '--N', '64', '--T', '2', '--no-cpu'],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode != 0
+    assert b'"metric"' not in p.stdout
