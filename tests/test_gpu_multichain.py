@@ -1,0 +1,131 @@
+"""SURVEY.md 8e on an MI355X: the packed-network hand-over between chains
+(dlsm_get/set_network_packed) and `bench.py --gpus 2` launching its own ranks (both ranks on
+cuda:0 with the gloo backend: the box has one GPU; on an 8-GPU node the same code runs one
+rank per GPU over RCCL)."""
+import ctypes
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def eng():
+    import dynetlsm_amd
+    return dynetlsm_amd
+
+
+def _net(T, N, directed, seed):
+    rng = np.random.RandomState(seed)
+    Y = (rng.rand(T, N, N) < 0.15).astype(np.float64)
+    for t in range(T):
+        np.fill_diagonal(Y[t], 0.0)
+    if not directed:
+        Y = np.triu(Y, 1)
+        Y = Y + Y.transpose(0, 2, 1)
+    return Y, rng.randn(T, N, 2), rng.dirichlet(np.ones(N))
+
+
+@pytest.mark.parametrize('model', ['undirected', 'directed'])
+@pytest.mark.parametrize('N', [37, 300])
+def test_packed_network_roundtrip(eng, model, N):
+    T = 3
+    Y, X, radii = _net(T, N, model == 'directed', 4)
+    b = [0.3] if model == 'undirected' else [0.3, 0.6]
+    with eng.Chain(T, N, 2, model) as a, eng.Chain(T, N, 2, model) as c:
+        a.upload_network(Y)
+        n = a.network_packed_words()
+        W = ((N + 31) // 32 + 3) // 4 * 4
+        assert n == T * N * W * (2 if model == 'directed' else 1)
+        buf = np.zeros(n, dtype=np.uint32)
+        a.get_network_packed(buf.ctypes.data, n)              # host pointer
+        # the layout: bit i of row j of slice t is Y[t, j, i]
+        rows = buf[:T * N * W].reshape(T, N, W)
+        for (t, j, i) in [(0, 0, 1), (1, 5, N - 1), (2, N - 1, 0), (1, 7, 7)]:
+            assert ((rows[t, j, i >> 5] >> (i & 31)) & 1) == int(Y[t, j, i])
+        c.set_network_packed(buf.ctypes.data, n)
+        for ch in (a, c):
+            ch.set_positions(X); ch.set_intercepts(b)
+            if model == 'directed':
+                ch.set_radii(radii)
+        assert a.loglik_full() == c.loglik_full()              # bit for bit
+        # through a device buffer (what the RCCL broadcast hands over)
+        import torch
+        dbuf = torch.zeros(n, dtype=torch.int32, device='cuda:0')
+        a.get_network_packed(dbuf.data_ptr(), n)
+        torch.cuda.synchronize()
+        assert np.array_equal(dbuf.cpu().numpy().view(np.uint32), buf)
+        with eng.Chain(T, N, 2, model) as d:
+            d.set_network_packed(dbuf.data_ptr(), n)
+            d.set_positions(X); d.set_intercepts(b)
+            if model == 'directed':
+                d.set_radii(radii)
+            assert d.loglik_full() == a.loglik_full()
+        # a buffer that violates the layout is refused: diagonal, padding, transpose
+        for word, bit in ((0, 0), (W - 1, 31)):
+            bad = buf.copy()
+            bad[word] |= np.uint32(1 << bit)
+            with pytest.raises(eng.EngineError) as e:
+                c.set_network_packed(bad.ctypes.data, n)
+            assert e.value.code == -4
+        bad = buf.copy()
+        bad[0] ^= np.uint32(2)                                  # Y[0, 0, 1] without Y[0, 1, 0]
+        with pytest.raises(eng.EngineError) as e:
+            c.set_network_packed(bad.ctypes.data, n)
+        assert e.value.code == -4
+        with pytest.raises(eng.EngineError):
+            c.set_network_packed(buf.ctypes.data, n - 1)
+
+
+def _run_bench(*extra):
+    env = dict(os.environ)
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + list(extra), env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith('{')]
+    assert len(lines) == 1, p.stdout.decode()[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_launches_two_ranks_by_itself():
+    """`python bench.py --gpus 2` as typed: the parent spawns the ranks, rank 0 broadcasts the
+    packed network, both chains run, the results are gathered; config 5's workload
+    (HDP-LPCM chains) rides along as extra_configs"""
+    line = _run_bench('--gpus', '2', '--backend', 'gloo', '--share-device0', '--steps', '5',
+                      '--warmup', '2', '--profile-steps', '0', '--no-cpu', '--model', 'all')
+    assert line['n_gpus'] == 2 and line['steps'] == 5 and line['scaling'] == 'weak'
+    assert line['config']['chains'] == 2 and 'DynamicNetworkLSM' in line['config']['workload']
+    assert line['value'] > 0 and line['dtype'] == 'f64'
+    assert line['gathered']['X_mean'] == [2, 10, 2000, 2]
+    assert line['gathered']['logps'] == [2, 5]
+    summ = line['chain_summaries[intercept_mean,intercept_sd,logp_mean,logp_last]']
+    assert len(summ) == 2 and summ[0] != summ[1]            # chain id keys the Philox streams
+    assert abs(summ[0][2] - summ[1][2]) < 0.01 * abs(summ[0][2])    # same network, same posterior
+    assert line['X_mean_rms_between_chains'] > 0
+    hdp = line['extra_configs'][0]
+    assert hdp['n_gpus'] == 2 and 'DynamicNetworkHDPLPCM' in hdp['config']['workload']
+    assert hdp['value'] > 0 and hdp['gathered']['X_mean'] == [2, 10, 2000, 2]
+    assert len(hdp['n_clusters_used_last']) == 2
+
+
+def test_bench_single_gpu_line_has_the_contract_fields():
+    line = _run_bench('--steps', '20', '--warmup', '5', '--profile-steps', '5', '--cpu-iters', '1',
+                      '--model', 'lsm')
+    assert line['n_gpus'] == 1 and line['metric'].startswith('Gibbs iterations/sec')
+    r = line['roofline']
+    assert r['bound'] == 'fp64_valu' and r['unit'] == 'TFLOP/s' and 0 < r['frac'] < 1
+    assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3
+    assert line['roofline_hbm']['bound'] == 'hbm' and line['roofline_hbm']['unit'] == 'GB/s'
+    assert line['roofline_loglik']['kernel'].startswith('k_loglik_undirected')
+    c = line['cpu_baseline']
+    assert c['kind'] == 'port' and c['cores'] == 1 and c['value'] > 0
+    assert c['engine_loglik_rel_err_vs_oracle'] < 1e-6          # north_star's tolerance
+    assert 0 < line['iteration_fp64_valu']['frac'] < 1
