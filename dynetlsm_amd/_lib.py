@@ -5,6 +5,7 @@ usable, every entry point raises.
 """
 import ctypes as C
 import os
+import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libdynetlsm_hip.so')
@@ -128,6 +129,19 @@ def load():
                 'dynetlsm_amd: %s is missing. Build it with '
                 '`python -m dynetlsm_amd.build` (needs hipcc); there is no CPU '
                 'fallback.' % LIB_PATH)
+        # PyTorch-ROCm wheels carry their own libamdhip64 / libhsa-runtime64 under the same
+        # sonames as /opt/rocm's, and a process gets ONE copy: the first one loaded.  When the
+        # engine's library came first, torch found no GPU afterwards (measured on the MI355X
+        # box), so if torch is already imported its runtime is initialised before ours binds.
+        # (Processes that use both should import torch first; without torch the engine uses
+        # the system runtime.)
+        if 'torch' in sys.modules:
+            torch = sys.modules['torch']
+            try:
+                if torch.cuda.is_available():
+                    torch.cuda.init()
+            except Exception:       # a torch without a usable device must not mask our own error
+                pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)

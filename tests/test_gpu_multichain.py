@@ -10,6 +10,7 @@ import sys
 
 import numpy as np
 import pytest
+import torch      # before the engine's library: one HIP runtime per process, torch's first
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -56,7 +57,6 @@ def test_packed_network_roundtrip(eng, model, N):
                 ch.set_radii(radii)
         assert a.loglik_full() == c.loglik_full()              # bit for bit
         # through a device buffer (what the RCCL broadcast hands over)
-        import torch
         dbuf = torch.zeros(n, dtype=torch.int32, device='cuda:0')
         a.get_network_packed(dbuf.data_ptr(), n)
         torch.cuda.synchronize()
