@@ -434,15 +434,20 @@ class HdpWorkload(object):
         ms_ll, n_ll = chain.profile_read(_lib.K_LOGLIK)
         ms_ps, n_ps = chain.profile_read(_lib.K_CENTER)
         ms_lb, n_lb = chain.profile_read(_lib.K_LABELS)
+        ms_tl, n_tl = chain.profile_read(_lib.K_HDP_TAIL)
+        ms_fi, n_fi = chain.profile_read(_lib.K_FINALIZE)
         chain.profile_enable(False)
         ms_ev, n_ev = chain.profile_read(_lib.K_SWEEP_EVAL)
         roofline, extra = sweep_rooflines(chain, a, P, ms_sw / max(n_sw, 1), ms_ll / max(n_ll, 1),
                                           ms_ev, n_ev, 0.0, 0, ms_ps / max(n_ps, 1), 0.0)
         extra['ms_label_kernels_per_iteration'] = round(ms_lb / max(P, 1), 4)
+        extra['ms_hdp_draws_and_logp_per_iteration'] = round(ms_tl / max(P, 1), 4)
+        extra['ms_finalize'] = round(ms_fi / max(n_fi, 1), 4)
         return roofline, extra
 
     def results(self, first, count):
         m = self.model
+        m._pull(first, count)
         sl = slice(first, first + count)
         return dict(X_mean=m.Xs_[sl].mean(axis=0), logps=m.logps_[sl].copy(),
                     intercepts=m.intercepts_[sl].copy(), lambdas=m.lambdas_[sl].copy(),

@@ -16,7 +16,7 @@ c_i32_p = C.POINTER(C.c_int32)
 handle_t = C.c_void_p
 
 (K_LOGLIK, K_SWEEP, K_CENTER, K_LABELS, K_FINALIZE, K_SWEEP_EVAL, K_SWEEP_RESOLVE,
- K_INIT) = range(8)
+ K_INIT, K_HDP_TAIL) = range(9)
 UNDIRECTED, DIRECTED, DIRECTED_CASE_CONTROL = 0, 1, 2
 
 
@@ -32,6 +32,23 @@ class LsmConfig(C.Structure):
                 ('r_step_size', C.c_double), ('r_n_accepted', C.c_int32),
                 ('r_n_steps', C.c_int32), ('r_steps_until_tune', C.c_int32),
                 ('r_tune', C.c_int32), ('r_tune_interval', C.c_int32), ('r_pad', C.c_int32)]
+
+
+class HdpConfig(C.Structure):
+    """mirror of ``dlsm_hdp_config``"""
+    _fields_ = [('gamma', C.c_double), ('alpha_init', C.c_double), ('alpha', C.c_double),
+                ('kappa', C.c_double), ('mean_variance_prior', C.c_double), ('b', C.c_double),
+                ('a', C.c_double), ('a0', C.c_double), ('b0', C.c_double), ('c0', C.c_double),
+                ('d0', C.c_double), ('has_a0', C.c_int32), ('has_c0', C.c_int32),
+                ('lambda_prior', C.c_double), ('lambda_variance_prior', C.c_double),
+                ('gamma_prior_shape', C.c_double), ('gamma_prior_rate', C.c_double),
+                ('alpha_init_shape', C.c_double), ('alpha_init_rate', C.c_double),
+                ('alpha_kappa_shape', C.c_double), ('alpha_kappa_rate', C.c_double),
+                ('intercept_prior', C.c_double), ('intercept_variance_prior', C.c_double),
+                ('i_step_size', C.c_double), ('i_n_accepted', C.c_int32),
+                ('i_n_steps', C.c_int32), ('i_steps_until_tune', C.c_int32),
+                ('i_tune', C.c_int32), ('i_tune_interval', C.c_int32),
+                ('sweep_algo', C.c_int32)]
 
 
 class EngineError(RuntimeError):
@@ -92,6 +109,14 @@ SIGNATURES = {
     'dlsm_trace_read': (C.c_int, [handle_t, C.c_int, C.c_int, c_double_p, c_double_p,
                                   c_double_p]),
     'dlsm_trace_read_radii': (C.c_int, [handle_t, C.c_int, C.c_int, c_double_p]),
+    'dlsm_hdp_configure': (C.c_int, [handle_t, C.POINTER(HdpConfig), c_double_p, c_double_p]),
+    'dlsm_hdp_get_config': (C.c_int, [handle_t, C.POINTER(HdpConfig)]),
+    'dlsm_hdp_trace_alloc': (C.c_int, [handle_t, C.c_int, C.c_double]),
+    'dlsm_hdp_run': (C.c_int, [handle_t, C.c_int, C.c_int]),
+    'dlsm_hdp_trace_read': (C.c_int, [handle_t, C.c_int, C.c_int, c_double_p, c_double_p,
+                                      c_double_p, c_double_p, c_double_p, c_i64_p, c_double_p,
+                                      c_double_p, c_double_p, c_double_p]),
+    'dlsm_hdp_get_aux': (C.c_int, [handle_t, c_i64_p, c_double_p, c_i64_p, c_i64_p, c_i64_p]),
     'dlsm_init_shortest_paths': (C.c_int, [handle_t]),
     'dlsm_init_get_dissimilarity': (C.c_int, [handle_t, C.c_int, c_double_p]),
     'dlsm_init_smacof': (C.c_int, [handle_t, C.c_int, C.c_int, c_double_p, C.c_int,

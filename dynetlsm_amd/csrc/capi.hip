@@ -15,6 +15,7 @@
 #include "kernels_labels.hpp"
 #include "kernels_hdp.hpp"
 #include "kernels_loglik.hpp"
+#include "kernels_hdploop.hpp"
 #include "kernels_sweep.hpp"
 #include "kernels_dirloop.hpp"
 #include "kernels_spec.hpp"
@@ -163,6 +164,20 @@ int ensure_partials(dlsm_chain *h, size_t n) {
     return DLSM_OK;
 }
 
+// counts and transition matrices of the label update, sized for the current n_components
+int ensure_label_bufs(dlsm_chain *h) {
+    const size_t nn = (size_t)h->T * h->K * h->K, nnk = (size_t)h->T * h->K;
+    if (h->lab_cap >= nn) return DLSM_OK;   // n_components may grow on a live handle
+    void *old[] = {h->lab_n, h->lab_nk, h->lab_w};
+    for (void *p : old) if (p) hipFree(p);
+    h->lab_n = h->lab_nk = nullptr; h->lab_w = nullptr; h->lab_cap = 0;
+    int rc = dev_alloc(h, &h->lab_n, nn); if (rc) return rc;
+    rc = dev_alloc(h, &h->lab_nk, nnk); if (rc) return rc;
+    rc = dev_alloc(h, &h->lab_w, nn); if (rc) return rc;
+    h->lab_cap = nn;
+    return DLSM_OK;
+}
+
 int ll_blocks(const dlsm_chain *h) {
     if (h->model == DLSM_DIRECTED_CASE_CONTROL)
         return (int)(((long)h->T * h->N + LLCC_NODES - 1) / LLCC_NODES);
@@ -292,11 +307,13 @@ int dlsm_create(int device, int T, int N, int D, int model, uint64_t seed,
     rc |= dev_alloc(h, &h->xref, TN * D);
     rc |= dev_alloc(h, &h->lsm, 1);
     rc |= dev_alloc(h, &h->z, TN);
+    rc |= dev_alloc(h, &h->hdp, 1);
     if (rc) return bail(DLSM_E_HIP);
     if (hipHostMalloc((void **)&h->hsmall, 64 * sizeof(double)) != hipSuccess)
         { h->err = "hipHostMalloc failed"; return bail(DLSM_E_HIP); }
     hipMemsetAsync(h->intercept, 0, 2 * sizeof(double), h->stream);
     hipMemsetAsync(h->lsm, 0, sizeof(LsmDeviceState), h->stream);
+    hipMemsetAsync(h->hdp, 0, sizeof(HdpDeviceState), h->stream);
     hipEventCreate(&h->timer0);
     hipEventCreate(&h->timer1);
     hipStreamSynchronize(h->stream);
@@ -315,7 +332,8 @@ void dlsm_destroy(dlsm_chain *h) {
                     h->sigma, h->z, h->partials, h->dsmall, h->xref, h->lab_n,
                     h->lab_nk, h->lab_w, h->spec, h->nctrl, h->stamps, h->lsm, h->trace_X, h->trace_ic,
                     h->trace_logp, h->hops, h->hops_max, h->pipe, h->post_zt, h->post_cooc,
-                    h->trace_radii};
+                    h->trace_radii, h->hdp, h->hdp_buf, h->htr_mu, h->htr_sigma, h->htr_beta,
+                    h->htr_w, h->htr_lambda, h->htr_hyper, h->htr_z};
     for (void *p : ptrs) if (p) hipFree(p);
     if (h->hsmall) hipHostFree(h->hsmall);
     if (h->timer0) hipEventDestroy(h->timer0);
@@ -636,6 +654,7 @@ int dlsm_set_prior_mixture(dlsm_chain *h, const double *mu, const double *sigma,
     size_t staged = 0;                          // one synchronisation for the whole upload
     int rc = h2d_enqueue(h, h->mu, mu, (size_t)K * h->D, &staged); if (rc) return rc;
     rc = h2d_enqueue(h, h->sigma, sigma, (size_t)K, &staged); if (rc) return rc;
+    rc = h2d_enqueue(h, &h->hdp->lmbda, &lmbda, (size_t)1, &staged); if (rc) return rc;
     std::vector<int32_t> zz;
     if (z) {
         zz.resize(TN);
@@ -1143,15 +1162,7 @@ int dlsm_sample_labels(dlsm_chain *h, uint32_t iter, const double *w, int64_t *z
     HIPCHK(h, hipSetDevice(h->device));
     const int T = h->T, K = h->K, N = h->N;
     const size_t nn = (size_t)T * K * K, nnk = (size_t)T * K;
-    if (h->lab_cap < nn) {                  // n_components may grow on a live handle
-        void *old[] = {h->lab_n, h->lab_nk, h->lab_w};
-        for (void *p : old) if (p) hipFree(p);
-        h->lab_n = h->lab_nk = nullptr; h->lab_w = nullptr; h->lab_cap = 0;
-        int rc = dev_alloc(h, &h->lab_n, nn); if (rc) return rc;
-        rc = dev_alloc(h, &h->lab_nk, nnk); if (rc) return rc;
-        rc = dev_alloc(h, &h->lab_w, nn); if (rc) return rc;
-        h->lab_cap = nn;
-    }
+    { int rc = ensure_label_bufs(h); if (rc) return rc; }
     const size_t lds_tables = (size_t)LAB_WAVES * 2 * T * K * sizeof(double);
     const size_t lds_w = (size_t)T * K * lab_row_pad(K) * sizeof(double);
     if (lds_tables > 160 * 1024)
@@ -1561,6 +1572,7 @@ int dlsm_timer_stop(dlsm_chain *h, double *ms) {
 #include "capi_init.hpp"
 #include "capi_post.hpp"
 #include "capi_forecast.hpp"
+#include "capi_hdp.hpp"
 
 extern "C" int dlsm_host_sample_tables(void *numpy_bitgen, int T, int K, const double *n,
                                        const double *beta, double alpha_init, double alpha,

@@ -1,0 +1,281 @@
+// C-ABI of the device-resident HDP-LPCM loop (included by capi.hip; the FAIL / HIPCHK / NEED
+// macros, the sweep / post / log-likelihood launchers and the copy helpers come from there).
+#pragma once
+
+namespace {
+
+// carve the loop's auxiliary buffers out of one allocation
+HdpLoopBuf hdp_loop_buf(dlsm_chain *h) {
+    const size_t T = h->T, K = h->K, D = h->D;
+    HdpLoopBuf b;
+    double *p = h->hdp_buf;
+    b.beta = p; p += K;
+    b.mbar = p; p += K;
+    b.S = p; p += T * K * D;
+    b.Q = p; p += T * K;
+    b.L = p; p += 2 * T * K;
+    b.LP = p; p += T * K;
+    b.m = (int32_t *)p;
+    b.wover = b.m + T * K * K;
+    b.w = h->lab_w; b.n = h->lab_n; b.nk = h->lab_nk;
+    b.mu = h->mu; b.sigma = h->sigma;
+    b.K = (int)K;
+    return b;
+}
+
+size_t hdp_loop_buf_doubles(const dlsm_chain *h) {
+    const size_t T = h->T, K = h->K, D = h->D;
+    return 2 * K + T * K * D + 4 * T * K + (T * K * K + T * K + 1) / 2 + 2;
+}
+
+void hdp_free_trace(dlsm_chain *h) {
+    void *ptrs[] = {h->htr_mu, h->htr_sigma, h->htr_beta, h->htr_w, h->htr_lambda, h->htr_hyper,
+                    h->htr_z};
+    for (void *p : ptrs) if (p) hipFree(p);
+    h->htr_mu = h->htr_sigma = h->htr_beta = h->htr_w = h->htr_lambda = h->htr_hyper = nullptr;
+    h->htr_z = nullptr; h->htr_n = 0; h->htr_K = 0;
+}
+
+template <int DD>
+int enqueue_hdp_iteration(dlsm_chain *h, int it) {
+    const IterRef ir{(uint32_t)it, nullptr};
+    const int T = h->T, K = h->K, N = h->N;
+    int rc = enqueue_sweep(h, ir, h->hdp_cfg.sweep_algo); if (rc) return rc;
+    // centring; workgroup 0 draws the intercept proposal; the positions' trace row
+    rc = launch_post<DD>(h, nullptr, 0, 1, h->lsm, ir, nullptr, false, h->trace_X); if (rc) return rc;
+    int nrec = 0;
+    rc = loglik_records(h, 2, h->lsm->cand, nullptr, nullptr, &nrec); if (rc) return rc;
+    ChainView v = h->view();
+    HdpLoopBuf hb = hdp_loop_buf(h);
+    {
+        ProfScope ps(h, DLSM_K_FINALIZE);
+        hipLaunchKernelGGL(k_hdp_intercept, dim3(1), dim3(256), 0, h->stream, h->partials, nrec, h->lsm,
+                           h->hdp, h->intercept, h->trace_ic, ir);
+    }
+    {   // label block update (sample_labels.py:134-190) with the transition matrices on the device
+        ProfScope ps(h, DLSM_K_LABELS);
+        const size_t lds_tables = (size_t)LAB_WAVES * 2 * T * K * sizeof(double);
+        const size_t lds_w = (size_t)T * K * lab_row_pad(K) * sizeof(double);
+        const bool w_lds = lds_tables + lds_w <= 80 * 1024;
+        const size_t lds = lds_tables + (w_lds ? lds_w : 0);
+        auto kern = w_lds ? k_sample_labels<DD, true> : k_sample_labels<DD, false>;
+        hipLaunchKernelGGL(kern, dim3((N + LAB_WAVES - 1) / LAB_WAVES), dim3(64 * LAB_WAVES), lds,
+                           h->stream, v, h->lab_w, (uint32_t)it, h->z);
+        hipLaunchKernelGGL(k_label_counts, dim3(T), dim3(256), (size_t)(K * K + K) * sizeof(int32_t),
+                           h->stream, h->z, N, K, (int32_t *)h->lab_n, (int32_t *)h->lab_nk);
+    }
+    ProfScope ps(h, DLSM_K_HDP_TAIL);
+    const long tn = (long)T * N;
+    hipLaunchKernelGGL(k_hdp_trace_labels, dim3((unsigned)((tn + 255) / 256)), dim3(256), 0, h->stream,
+                       h->z, tn, h->htr_z + (size_t)it * tn);
+    hipLaunchKernelGGL(k_hdp_tables, dim3((T * K * K + HT_WAVES - 1) / HT_WAVES), dim3(64 * HT_WAVES), 0,
+                       h->stream, v, hb, h->hdp, ir);
+    hipLaunchKernelGGL(k_hdp_globals, dim3(1), dim3(HG_THREADS), 0, h->stream, v, hb, h->hdp, ir);
+    if (T > 1)
+        hipLaunchKernelGGL(k_hdp_weights, dim3(T - 1), dim3(256), (size_t)(K * K + K) * sizeof(double),
+                           h->stream, v, hb, h->hdp, ir);
+    HdpParams hp{h->mu, h->sigma, h->lab_w, 0.0, h->hdp_cfg.a, 0.0, &h->hdp->lmbda, &h->hdp->b};
+    const dim3 grid(K, T), block(HDP_THREADS);
+    hipLaunchKernelGGL((k_hdp_label_sums<DD, HDP_SUMS_MEAN>), grid, block, 0, h->stream, v, hp, hb.S);
+    hipLaunchKernelGGL((k_hdp_draw_mu<DD>), dim3(1), dim3(64), 0, h->stream, v, hb, h->hdp, ir);
+    hipLaunchKernelGGL((k_hdp_label_sums<DD, HDP_SUMS_RESIDUAL>), grid, block, 0, h->stream, v, hp, hb.Q);
+    hipLaunchKernelGGL(k_hdp_draw_sigma, dim3(1), dim3(64), 0, h->stream, v, hb, h->hdp, ir);
+    hipLaunchKernelGGL((k_hdp_label_sums<DD, HDP_SUMS_LAMBDA>), grid, block, 0, h->stream, v, hp, hb.L);
+    hipLaunchKernelGGL(k_hdp_hypers, dim3(1), dim3(HH_THREADS), 0, h->stream, v, hb, h->hdp, ir);
+    hipLaunchKernelGGL((k_hdp_label_sums<DD, HDP_SUMS_LOGP>), grid, block, 0, h->stream, v, hp, hb.LP);
+    HdpTrace tr{h->trace_ic, h->trace_logp, h->htr_mu, h->htr_sigma, h->htr_beta, h->htr_w,
+                h->htr_lambda, h->htr_hyper};
+    hipLaunchKernelGGL((k_hdp_finalize<DD>), dim3(1), dim3(HF_THREADS), 0, h->stream, v, hb, h->hdp,
+                       h->lsm, tr, ir);
+    HIPCHK(h, hipGetLastError());
+    return DLSM_OK;
+}
+
+int check_ready_hdp(dlsm_chain *h) {
+    NEED(h, h->model == DLSM_UNDIRECTED, "the device-resident HDP-LPCM loop covers the undirected model");
+    NEED(h, h->have_prior && h->prior_kind == DLSM_PRIOR_MIXTURE,
+         "set the mixture prior (mu, sigma, lmbda, z) first");
+    return check_ready_sweep(h);
+}
+
+}  // namespace
+
+extern "C" {
+
+int dlsm_hdp_configure(dlsm_chain *h, const dlsm_hdp_config *cfg, const double *beta,
+                       const double *weights) {
+    NEED(h, h && cfg && beta && weights, "null argument");
+    drop_graph(h);
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc = check_ready_hdp(h); if (rc) return rc;
+    NEED(h, cfg->intercept_variance_prior > 0 && cfg->i_tune_interval > 0 &&
+            cfg->lambda_variance_prior > 0 && cfg->mean_variance_prior > 0 && cfg->b > 0,
+         "variances / tune_interval must be positive");
+    NEED(h, cfg->gamma > 0 && cfg->alpha_init > 0 && cfg->alpha > 0 && cfg->kappa >= 0,
+         "concentration parameters must be positive");
+    const int T = h->T, K = h->K;
+    rc = ensure_label_bufs(h); if (rc) return rc;
+    const size_t need = hdp_loop_buf_doubles(h);
+    if (h->hdp_buf_cap < need) {
+        if (h->hdp_buf) hipFree(h->hdp_buf);
+        h->hdp_buf = nullptr; h->hdp_buf_cap = 0;
+        rc = dev_alloc(h, &h->hdp_buf, need); if (rc) return rc;
+        h->hdp_buf_cap = need;
+    }
+    HIPCHK(h, hipMemsetAsync(h->hdp_buf, 0, need * sizeof(double), h->stream));
+    h->hdp_K = K;
+    // device state: everything but lmbda (dlsm_set_prior_mixture owns it)
+    HdpDeviceState s;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(&s, h->hdp, sizeof(s), hipMemcpyDeviceToHost));
+    s.gamma = cfg->gamma; s.alpha_init = cfg->alpha_init; s.alpha = cfg->alpha; s.kappa = cfg->kappa;
+    s.mvp = cfg->mean_variance_prior; s.b = cfg->b;
+    s.a = cfg->a; s.a0 = cfg->a0; s.b0 = cfg->b0; s.c0 = cfg->c0; s.d0 = cfg->d0;
+    s.has_a0 = cfg->has_a0 ? 1 : 0; s.has_c0 = cfg->has_c0 ? 1 : 0;
+    s.lambda_prior = cfg->lambda_prior; s.lambda_var = cfg->lambda_variance_prior;
+    s.gamma_shape = cfg->gamma_prior_shape; s.gamma_rate = cfg->gamma_prior_rate;
+    s.alpha0_shape = cfg->alpha_init_shape; s.alpha0_rate = cfg->alpha_init_rate;
+    s.ak_shape = cfg->alpha_kappa_shape; s.ak_rate = cfg->alpha_kappa_rate;
+    s.ll = 0.0;
+    s.mbar_total = s.mbar_positive = s.m00_total = s.m_rest_total = s.override_total = 0.0;
+    HIPCHK(h, hipMemcpy(h->hdp, &s, sizeof(s), hipMemcpyHostToDevice));
+    // the intercept's sampler shares the LSM loop's device state
+    LsmDeviceState ls;
+    memset(&ls, 0, sizeof(ls));
+    ls.intercept_prior[0] = cfg->intercept_prior;
+    ls.intercept_var = cfg->intercept_variance_prior;
+    ls.i_step[0] = cfg->i_step_size;
+    ls.i_nacc[0] = cfg->i_n_accepted; ls.i_nsteps[0] = cfg->i_n_steps;
+    ls.i_until[0] = cfg->i_steps_until_tune;
+    ls.i_tune = cfg->i_tune < 0 ? -1 : cfg->i_tune;
+    ls.i_tune_interval = cfg->i_tune_interval;
+    HIPCHK(h, hipMemcpy(h->lsm, &ls, sizeof(ls), hipMemcpyHostToDevice));
+    HdpLoopBuf hb = hdp_loop_buf(h);
+    rc = h2d(h, hb.beta, beta, (size_t)K); if (rc) return rc;
+    rc = h2d(h, h->lab_w, weights, (size_t)T * K * K); if (rc) return rc;
+    // allocations of the sweep / post / log-likelihood launchers (so that the run only enqueues)
+    rc = enqueue_sweep(h, IterRef{0, nullptr}, cfg->sweep_algo, true); if (rc) return rc;
+    DISPATCH_D(h, h->D, rc = launch_post<DD>(h, nullptr, 0, 1, h->lsm, IterRef{0, nullptr}, nullptr, true));
+    if (rc) return rc;
+    h->hdp_cfg = *cfg;
+    h->hdp_configured = true;
+    return DLSM_OK;
+}
+
+int dlsm_hdp_get_config(dlsm_chain *h, dlsm_hdp_config *cfg) {
+    NEED(h, h && cfg, "null argument");
+    NEED(h, h->hdp_configured, "HDP-LPCM loop not configured");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HdpDeviceState s;
+    LsmDeviceState ls;
+    HIPCHK(h, hipMemcpy(&s, h->hdp, sizeof(s), hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(&ls, h->lsm, sizeof(ls), hipMemcpyDeviceToHost));
+    *cfg = h->hdp_cfg;
+    cfg->gamma = s.gamma; cfg->alpha_init = s.alpha_init; cfg->alpha = s.alpha; cfg->kappa = s.kappa;
+    cfg->mean_variance_prior = s.mvp; cfg->b = s.b;
+    cfg->i_step_size = ls.i_step[0]; cfg->i_n_accepted = ls.i_nacc[0];
+    cfg->i_n_steps = ls.i_nsteps[0]; cfg->i_steps_until_tune = ls.i_until[0];
+    return DLSM_OK;
+}
+
+int dlsm_hdp_trace_alloc(dlsm_chain *h, int n_total, double logp0) {
+    NEED(h, h && n_total >= 1, "bad argument");
+    NEED(h, h->hdp_configured, "configure the HDP-LPCM loop first");
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc = dlsm_trace_alloc(h, n_total, logp0); if (rc) return rc;   // Xs_, intercepts_, logps_
+    hdp_free_trace(h);
+    const size_t T = h->T, N = h->N, K = h->K, D = h->D, n = n_total;
+    rc = dev_alloc(h, &h->htr_mu, n * K * D); if (rc) return rc;
+    rc = dev_alloc(h, &h->htr_sigma, n * K); if (rc) return rc;
+    rc = dev_alloc(h, &h->htr_beta, n * K); if (rc) return rc;
+    rc = dev_alloc(h, &h->htr_w, n * T * K * K); if (rc) return rc;
+    rc = dev_alloc(h, &h->htr_lambda, n); if (rc) return rc;
+    rc = dev_alloc(h, &h->htr_hyper, n * 6); if (rc) return rc;
+    rc = dev_alloc(h, &h->htr_z, n * T * N); if (rc) return rc;
+    h->htr_n = n_total; h->htr_K = (int)K;
+    // row 0 = the current state
+    HdpLoopBuf hb = hdp_loop_buf(h);
+    HdpDeviceState s;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(&s, h->hdp, sizeof(s), hipMemcpyDeviceToHost));
+    const double hy[6] = {s.gamma, s.alpha_init, s.alpha, s.kappa, s.mvp, s.b};
+    HIPCHK(h, hipMemcpyAsync(h->htr_mu, h->mu, K * D * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->htr_sigma, h->sigma, K * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->htr_beta, hb.beta, K * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->htr_w, h->lab_w, T * K * K * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->htr_lambda, &h->hdp->lmbda, sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->htr_hyper, hy, sizeof(hy), hipMemcpyHostToDevice, h->stream));
+    const long tn = (long)(T * N);
+    hipLaunchKernelGGL(k_hdp_trace_labels, dim3((unsigned)((tn + 255) / 256)), dim3(256), 0, h->stream,
+                       h->z, tn, h->htr_z);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return DLSM_OK;
+}
+
+int dlsm_hdp_run(dlsm_chain *h, int first, int count) {
+    NEED(h, h != nullptr, "null handle");
+    NEED(h, h->hdp_configured && h->trace_X && h->htr_z, "configure the loop and allocate its trace first");
+    NEED(h, h->hdp_K == h->K && h->htr_K == h->K, "n_components changed since dlsm_hdp_configure");
+    NEED(h, first >= 1 && count >= 0 && first + count <= h->trace_n && first + count <= h->htr_n,
+         "iteration range out of the trace");
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc = check_ready_hdp(h); if (rc) return rc;
+    for (int it = first; it < first + count; ++it) {
+        DISPATCH_D(h, h->D, rc = enqueue_hdp_iteration<DD>(h, it));
+        if (rc) return rc;
+    }
+    return DLSM_OK;
+}
+
+int dlsm_hdp_trace_read(dlsm_chain *h, int first, int count, double *Xs, double *intercepts,
+                        double *logps, double *mus, double *sigmas, int64_t *zs, double *betas,
+                        double *weights, double *lambdas, double *hypers) {
+    NEED(h, h != nullptr, "null handle");
+    NEED(h, h->htr_z, "no HDP-LPCM trace allocated");
+    NEED(h, first >= 0 && count >= 0 && first + count <= h->htr_n, "range out of the trace");
+    int rc = dlsm_trace_read(h, first, count, Xs, intercepts, logps); if (rc) return rc;
+    const size_t T = h->T, N = h->N, K = h->htr_K, D = h->D, f = first, c = count;
+    auto get = [&](double *dst, const double *src, size_t per) -> hipError_t {
+        return dst ? hipMemcpy(dst, src + f * per, c * per * sizeof(double), hipMemcpyDeviceToHost)
+                   : hipSuccess;
+    };
+    HIPCHK(h, get(mus, h->htr_mu, K * D));
+    HIPCHK(h, get(sigmas, h->htr_sigma, K));
+    HIPCHK(h, get(betas, h->htr_beta, K));
+    HIPCHK(h, get(weights, h->htr_w, T * K * K));
+    HIPCHK(h, get(lambdas, h->htr_lambda, 1));
+    HIPCHK(h, get(hypers, h->htr_hyper, 6));
+    if (zs) {
+        std::vector<uint8_t> tmp(c * T * N);
+        HIPCHK(h, hipMemcpy(tmp.data(), h->htr_z + f * T * N, tmp.size(), hipMemcpyDeviceToHost));
+        for (size_t q = 0; q < tmp.size(); ++q) zs[q] = tmp[q];
+    }
+    return DLSM_OK;
+}
+
+int dlsm_hdp_get_aux(dlsm_chain *h, int64_t *m, double *m_bar, int64_t *w_over, int64_t *n,
+                     int64_t *nk) {
+    NEED(h, h != nullptr, "null handle");
+    NEED(h, h->hdp_configured, "HDP-LPCM loop not configured");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const size_t T = h->T, K = h->K;
+    HdpLoopBuf hb = hdp_loop_buf(h);
+    std::vector<int32_t> tmp(T * K * K);
+    auto geti = [&](int64_t *dst, const int32_t *src, size_t cnt) -> hipError_t {
+        if (!dst) return hipSuccess;
+        hipError_t e = hipMemcpy(tmp.data(), src, cnt * sizeof(int32_t), hipMemcpyDeviceToHost);
+        for (size_t q = 0; q < cnt; ++q) dst[q] = tmp[q];
+        return e;
+    };
+    HIPCHK(h, geti(m, hb.m, T * K * K));
+    HIPCHK(h, geti(w_over, hb.wover, (T - 1) * K));
+    HIPCHK(h, geti(n, hb.n, T * K * K));
+    HIPCHK(h, geti(nk, hb.nk, T * K));
+    if (m_bar) HIPCHK(h, hipMemcpy(m_bar, hb.mbar, K * sizeof(double), hipMemcpyDeviceToHost));
+    return DLSM_OK;
+}
+
+}  // extern "C"

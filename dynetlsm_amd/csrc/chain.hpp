@@ -27,7 +27,9 @@ struct ChainView {
     const double *radii;        // device [N]
     int prior_kind;
     double tau_sq, sigma_sq;
-    const double *mu; const double *sigma; double lmbda; const int32_t *z; int K;
+    const double *mu; const double *sigma;
+    const double *lmbda_p;      // device scalar: the blending coefficient (set_prior_mixture / the HDP loop)
+    const int32_t *z; int K;
     double *step; int32_t *nacc; int32_t *nsteps; int32_t *until;
     int tune, tune_interval;
     uint64_t seed; uint32_t chain;
@@ -50,6 +52,21 @@ struct LsmDeviceState {
     double r_step;
     int32_t r_nacc, r_nsteps, r_until, r_tune, r_tune_interval, r_pad_;
     double ll_cur, dir_q;
+};
+
+// Device-resident HDP-LPCM loop (hdp_lpcm.py:823-1069): hyper-parameters the loop resamples,
+// the fixed hyper-priors, the blending coefficient and the carried log-likelihood.  The
+// intercept sampler lives in LsmDeviceState.
+struct HdpDeviceState {
+    double gamma, alpha_init, alpha, kappa, mvp, b;     // resampled (hdp_lpcm.py:957-1023)
+    double a, a0, b0, c0, d0;
+    int32_t has_a0, has_c0;
+    double lambda_prior, lambda_var;
+    double gamma_shape, gamma_rate, alpha0_shape, alpha0_rate, ak_shape, ak_rate;
+    double lmbda;               // current blending coefficient (ChainView::lmbda_p points here)
+    double ll;                  // network log-likelihood after the intercept step
+    // totals of the auxiliary variables of the current iteration (k_hdp_globals)
+    double mbar_total, mbar_positive, m00_total, m_rest_total, override_total;
 };
 
 struct ProfileSlot {
@@ -84,6 +101,15 @@ struct dlsm_chain {
     bool have_samplers = false;
     int prior_kind = 0; double tau_sq = 2.0, sigma_sq = 0.1;
     double *mu = nullptr, *sigma = nullptr; double lmbda = 0.0; int32_t *z = nullptr;
+    dlsm::HdpDeviceState *hdp = nullptr;    // device; always allocated (holds lmbda)
+    // device-resident HDP-LPCM loop: auxiliary buffers and traces
+    double *hdp_buf = nullptr; size_t hdp_buf_cap = 0; int hdp_K = 0;
+    bool hdp_configured = false;
+    dlsm_hdp_config hdp_cfg{};
+    double *htr_mu = nullptr, *htr_sigma = nullptr, *htr_beta = nullptr, *htr_w = nullptr,
+           *htr_lambda = nullptr, *htr_hyper = nullptr;
+    uint8_t *htr_z = nullptr;
+    int htr_n = 0, htr_K = 0;
     int K = 0; bool have_prior = false;
     // scratch
     double *partials = nullptr; size_t partials_cap = 0;   // doubles
@@ -130,7 +156,7 @@ struct dlsm_chain {
         v.degree = degree; v.ctrl_in = ctrl_in; v.ctrl_out = ctrl_out; v.C = C;
         v.X = X; v.intercept = intercept; v.radii = radii;
         v.prior_kind = prior_kind; v.tau_sq = tau_sq; v.sigma_sq = sigma_sq;
-        v.mu = mu; v.sigma = sigma; v.lmbda = lmbda; v.z = z; v.K = K;
+        v.mu = mu; v.sigma = sigma; v.lmbda_p = hdp ? &hdp->lmbda : nullptr; v.z = z; v.K = K;
         v.step = step; v.nacc = nacc; v.nsteps = nsteps; v.until = until;
         v.tune = tune; v.tune_interval = tune_interval;
         v.seed = seed; v.chain = chain;

@@ -25,6 +25,9 @@ struct HdpParams {
     const double *sigma;   // [K]
     const double *w;       // [T][K][K]
     double lmbda, a, b;
+    // device-resident loop: the blending coefficient / the inverse-gamma scale are read from
+    // device memory (they were drawn by the kernels just before); NULL = the values above
+    const double *lmbda_p = nullptr, *b_p = nullptr;
 };
 
 template <int D, int STAGE>
@@ -38,7 +41,8 @@ __global__ __launch_bounds__(HDP_THREADS) void k_hdp_label_sums(ChainView c, Hdp
     const int32_t *zp = t > 0 ? c.z + (size_t)(t - 1) * N : nullptr;
     const double *Xt = c.X + (size_t)t * N * D;
     const double *Xp = t > 0 ? c.X + (size_t)(t - 1) * N * D : nullptr;
-    const double lm = hp.lmbda;
+    const double lm = hp.lmbda_p ? hp.lmbda_p[0] : hp.lmbda;
+    const double hb_ = hp.b_p ? hp.b_p[0] : hp.b;
     double mk[D], sk = 1.0, lsk = 0.0;
 #pragma unroll
     for (int d = 0; d < D; ++d) mk[d] = STAGE == HDP_SUMS_MEAN ? 0.0 : hp.mu[(size_t)k * D + d];
@@ -70,7 +74,7 @@ __global__ __launch_bounds__(HDP_THREADS) void k_hdp_label_sums(ChainView c, Hdp
             } else {
                 const int zprev = t > 0 ? zp[i] : 0;
                 acc[0] += log(hp.w[((size_t)t * K + zprev) * K + k]) - 0.5 * lsk - 0.5 * ss / sk -
-                          (0.5 * hp.a + 1.0) * lsk - 0.5 * hp.b / sk;
+                          (0.5 * hp.a + 1.0) * lsk - 0.5 * hb_ / sk;
             }
         } else {
             if (t > 0) {

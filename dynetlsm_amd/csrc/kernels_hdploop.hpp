@@ -1,0 +1,548 @@
+// Device-resident tail of the HDP-LPCM Gibbs iteration (hdp_lpcm.py:876-1023
+// and the log-posterior of :1188-1280): everything between the label block update and the
+// next sweep, with counter-based draws, so that an iteration never waits for the host.
+//
+// Draws: Philox stream HDP, counter (index, kind | attempt << 8, iteration); the kinds and the
+// index conventions are shared with the CPU oracle (its PhiloxDraws class), which runs the
+// reference's update code with the same draws.
+//   tables     sample_auxillary.py:6-28   m[t,j,k] = sum_{i < n[t,j,k]} Bernoulli(p / (p + i));
+//                                         trial i = uniform i & 1 of attempt i >> 1 of index
+//                                         (t K + j) K + k
+//   override   sample_auxillary.py:31-50  w[t,j] = Binomial(m[t+1,j,j], rho / (rho + beta_j (1 - rho)))
+//                                         as a sum of Bernoullis, index t K + j
+//   Dirichlet  hdp_lpcm.py:887-898        gamma variates (Marsaglia-Tsang, attempt a: normal from
+//                                         attempt 2a, uniforms from 2a + 1) normalised by their sum
+//   mu, sigma, lambda, hyper-parameters, concentration parameters: see each kernel.
+// Launch order per iteration (capi_hdp.hpp): k_hdp_intercept, [labels], k_hdp_tables,
+// k_hdp_globals, k_hdp_weights, sums<MEAN>, k_hdp_draw_mu, sums<RESIDUAL>, k_hdp_draw_sigma,
+// sums<LAMBDA>, k_hdp_hypers, sums<LOGP>, k_hdp_finalize.
+#pragma once
+#include "chain.hpp"
+#include "device_common.hpp"
+#include "kernels_hdp.hpp"
+
+namespace dlsm {
+
+constexpr uint32_t STREAM_HDP = 6;
+enum : uint32_t {
+    HK_TABLES = 0, HK_OVERRIDE, HK_BETA, HK_W0, HK_W, HK_MU, HK_SIGMA, HK_LAMBDA, HK_MVP, HK_B,
+    HK_CONC_GAMMA, HK_CONC_ALPHA0, HK_AK_S, HK_AK_R, HK_AK, HK_RHO
+};
+constexpr double HDP_SMALL_EPS = 2.2250738585072014e-308;     // np.finfo('float64').tiny
+
+struct HdpRng {
+    uint64_t seed; uint32_t sw, iter;
+    __device__ __forceinline__ void u2(uint32_t kind, uint32_t idx, uint32_t att, double &u0,
+                                       double &u1) const {
+        philox_uniform2(seed, idx, kind | (att << 8), iter, sw, u0, u1);
+    }
+};
+__device__ __forceinline__ HdpRng hdp_rng(const ChainView &c, uint32_t iter) {
+    return HdpRng{c.seed, stream_word(c.chain, STREAM_HDP), iter};
+}
+
+// Gamma(a, 1) by Marsaglia & Tsang (2000); a < 1 through Gamma(a + 1) U^(1 / a)
+__device__ inline double hdp_gamma(const HdpRng &g, uint32_t kind, uint32_t idx, double a) {
+    const double aa = a < 1.0 ? a + 1.0 : a;
+    const double d = aa - 1.0 / 3.0, cc = 1.0 / sqrt(9.0 * d);
+    for (uint32_t att = 0; att < 4096; ++att) {
+        double u0, u1, z0, z1, w0, w1;
+        g.u2(kind, idx, 2 * att, u0, u1);
+        box_muller(u0, u1, z0, z1);
+        g.u2(kind, idx, 2 * att + 1, w0, w1);
+        const double t = 1.0 + cc * z0;
+        if (t <= 0.0) continue;
+        const double v = t * t * t;
+        const double x2 = z0 * z0;
+        if (w0 < 1.0 - 0.0331 * x2 * x2 || log(w0) < 0.5 * x2 + d * (1.0 - v + log(v))) {
+            double out = d * v;
+            if (a < 1.0) out *= pow(w1, 1.0 / a);
+            return out;
+        }
+    }
+    return 0.0;
+}
+
+__device__ inline double hdp_beta(const HdpRng &g, uint32_t kind, uint32_t idx, double a, double b) {
+    const double ga = hdp_gamma(g, kind, 2 * idx, a);
+    const double gb = hdp_gamma(g, kind, 2 * idx + 1, b);
+    return ga / (ga + gb);
+}
+
+// successes among n Bernoulli(p) trials; trial i = uniform i & 1 of attempt i >> 1
+__device__ inline int hdp_binomial(const HdpRng &g, uint32_t kind, uint32_t idx, int n, double p) {
+    int cnt = 0;
+    for (int i = 0; i < n; i += 2) {
+        double u0, u1;
+        g.u2(kind, idx, (uint32_t)(i >> 1), u0, u1);
+        cnt += (u0 <= p) + (i + 1 < n && u1 <= p);
+    }
+    return cnt;
+}
+
+// ---- truncated normal on [0, 1] in log space (scipy.stats.truncnorm's formulas) -----------
+__device__ inline double dev_log_ndtr(double x) {
+    if (x > 0.0) return log1p(-0.5 * erfc(x * 0.70710678118654752440));
+    return log(0.5 * erfcx(-x * 0.70710678118654752440)) - 0.5 * x * x;
+}
+__device__ inline double dev_ndtr(double x) { return 0.5 * erfc(-x * 0.70710678118654752440); }
+__device__ inline double dev_logaddexp(double x1, double x2) {
+    if (x1 == x2) return x1 + 0.69314718055994530942;
+    const double d = x1 - x2;
+    return d > 0.0 ? x1 + log1p(exp(-d)) : x2 + log1p(exp(d));
+}
+__device__ inline double dev_log_gauss_mass(double a, double b) {
+    if (a > 0.0) { const double t = a; a = -b; b = -t; }     // mass of [a, b] = mass of [-b, -a]
+    if (b <= 0.0) {
+        const double la = dev_log_ndtr(a), lb = dev_log_ndtr(b);
+        return lb + log1p(-exp(la - lb));
+    }
+    return log1p(-dev_ndtr(a) - dev_ndtr(-b));
+}
+// x with log ndtr(x) = y (y <= 0): a closed-form start, Newton steps on log ndtr
+__device__ inline double dev_ndtri_exp(double y) {
+    double x;
+    int polish = 2;
+    if (y >= -0.69314718055994530942) {
+        x = -normcdfinv(-expm1(y));
+    } else if (y >= -30.0) {
+        x = normcdfinv(exp(y));
+    } else {                        // far tail: log ndtr(x) ~ -x^2/2 - log(-x) - log(2 pi)/2
+        x = -sqrt(-2.0 * (y + 0.91893853320467274178));
+        for (int i = 0; i < 3; ++i) x = -sqrt(-2.0 * (y + 0.91893853320467274178 + log(-x)));
+        polish = 4;
+    }
+    for (int i = 0; i < polish; ++i) {
+        const double l = dev_log_ndtr(x);
+        // d/dx log ndtr = phi / ndtr
+        const double dl = x < 0.0 ? 0.79788456080286535588 / erfcx(-x * 0.70710678118654752440)
+                                  : exp(-0.5 * x * x - 0.91893853320467274178 - l);
+        if (!(dl > 0.0) || !isfinite(dl)) break;
+        x -= (l - y) / dl;
+    }
+    return x;
+}
+__device__ inline double dev_truncnorm_quantile(double q, double mean, double var) {
+    const double sd = sqrt(var);
+    const double a = (0.0 - mean) / sd, b = (1.0 - mean) / sd;
+    const double lm = dev_log_gauss_mass(a, b);
+    double x;
+    if (a < 0.0) x = dev_ndtri_exp(dev_logaddexp(dev_log_ndtr(a), log(q) + lm));
+    else x = -dev_ndtri_exp(dev_logaddexp(dev_log_ndtr(-b), log1p(-q) + lm));
+    return x * sd + mean;
+}
+__device__ inline double dev_truncnorm_logpdf(double x, double mean, double var) {
+    const double sd = sqrt(var);
+    const double a = (0.0 - mean) / sd, b = (1.0 - mean) / sd;
+    const double y = (x - mean) / sd;
+    if (y < a || y > b) return -INFINITY;
+    return -0.5 * y * y - 0.91893853320467274178 - dev_log_gauss_mass(a, b) - log(sd);
+}
+
+// ---- buffers ------------------------------------------------------------------------------
+struct HdpLoopBuf {
+    double *beta;        // [K]
+    double *w;           // [T][K][K]  (the label kernel's transition matrices)
+    const int32_t *n;    // [T][K][K]  label transition counts (k_label_counts)
+    const int32_t *nk;   // [T][K]
+    int32_t *m;          // [T][K][K]  tables
+    int32_t *wover;      // [T-1][K]   override counts
+    double *mbar;        // [K]
+    double *S;           // [T][K][D]  label sums, stage MEAN
+    double *Q;           // [T][K]     stage RESIDUAL
+    double *L;           // [T][K][2]  stage LAMBDA
+    double *LP;          // [T][K]     stage LOGP
+    double *mu, *sigma;  // the mixture prior's (chain->mu, chain->sigma)
+    int K;
+};
+
+struct HdpTrace {
+    double *ic, *logp, *mu, *sigma, *beta, *w, *lambda, *hyper;
+};
+
+// ---- intercept step (sample_coefficients.py:76-86 around one fused two-candidate pass) -----
+__global__ __launch_bounds__(256) void k_hdp_intercept(const double *__restrict__ partials, int nrec,
+                                                       LsmDeviceState *lsm, HdpDeviceState *hs,
+                                                       double *__restrict__ intercept,
+                                                       double *__restrict__ trace_ic, IterRef ir) {
+    const int it = (int)ir.get();
+    __shared__ double scratch[4 * 256];
+    __shared__ double sums[4];
+    reduce_records(partials, nrec, 4, sums, scratch, threadIdx.x);
+    if (threadIdx.x == 0) {
+        const double b0 = lsm->cand[0], b1 = lsm->cand[1];
+        const double ll0 = b0 * sums[0] - sums[1] - sums[2];
+        const double ll1 = b1 * sums[0] - sums[1] - sums[3];
+        const double pm = lsm->intercept_prior[0], v = lsm->intercept_var;
+        const double lp0 = ll0 - (b0 - pm) * (b0 - pm) / (2 * v);
+        const double lp1 = ll1 - (b1 - pm) * (b1 - pm) / (2 * v);
+        const int accepted = !(lsm->logu >= lp1 - lp0);
+        const double b = accepted ? b1 : b0;
+        intercept[0] = b;
+        hs->ll = accepted ? ll1 : ll0;
+        double st = lsm->i_step[0];
+        int32_t na = lsm->i_nacc[0], ns = lsm->i_nsteps[0], un = lsm->i_until[0];
+        metropolis_bookkeeping(st, na, ns, un, lsm->i_tune, lsm->i_tune_interval, accepted);
+        lsm->i_step[0] = st; lsm->i_nacc[0] = na; lsm->i_nsteps[0] = ns; lsm->i_until[0] = un;
+        trace_ic[(size_t)it * 2] = b;
+        trace_ic[(size_t)it * 2 + 1] = 0.0;
+    }
+}
+
+// ---- tables: one wavefront per (t, j, k) cell ------------------------------------------------
+constexpr int HT_WAVES = 4;
+__global__ __launch_bounds__(64 * HT_WAVES) void k_hdp_tables(ChainView c, HdpLoopBuf hb,
+                                                              const HdpDeviceState *hs, IterRef ir) {
+    const int K = hb.K, T = c.T;
+    const int lane = threadIdx.x & 63;
+    const int cell = blockIdx.x * HT_WAVES + (threadIdx.x >> 6);
+    if (cell >= T * K * K) return;
+    const int t = cell / (K * K), r = cell - t * K * K, j = r / K, k = r - j * K;
+    int cnt = 0;
+    if (t > 0 || j == 0) {          // t = 0: only the initial distribution's row (0, 0, :)
+        const int n = hb.n[cell];
+        const double p = t == 0 ? hs->alpha_init * hb.beta[k]
+                                : hs->alpha * hb.beta[k] + (j == k ? hs->kappa : 0.0);
+        const HdpRng g = hdp_rng(c, ir.get());
+        for (int a0 = 0; 2 * a0 < n; a0 += 64) {
+            const int att = a0 + lane, i0 = 2 * att;
+            double u0 = 2.0, u1 = 2.0;
+            if (i0 < n) g.u2(HK_TABLES, (uint32_t)cell, (uint32_t)att, u0, u1);
+            const bool s0 = i0 < n && u0 <= p / (p + (double)i0);
+            const bool s1 = i0 + 1 < n && u1 <= p / (p + (double)(i0 + 1));
+            cnt += __popcll(__ballot(s0)) + __popcll(__ballot(s1));
+        }
+    }
+    if (lane == 0) hb.m[cell] = cnt;
+}
+
+// ---- override variables, m_bar, beta, w0: one workgroup -----------------------------------------
+constexpr int HG_THREADS = 256;
+__global__ __launch_bounds__(HG_THREADS) void k_hdp_globals(ChainView c, HdpLoopBuf hb,
+                                                            HdpDeviceState *hs, IterRef ir) {
+    __shared__ int sMsum[64], sWsum[64], sTot[4];
+    __shared__ double sBeta[64], sG[64];
+    const int K = hb.K, T = c.T, tid = threadIdx.x;
+    const HdpRng g = hdp_rng(c, ir.get());
+    if (tid < 64) { sMsum[tid] = 0; sWsum[tid] = 0; }
+    if (tid < 4) sTot[tid] = 0;
+    if (tid < K) sBeta[tid] = hb.beta[tid];
+    __syncthreads();
+    const double rho = hs->kappa / (hs->alpha + hs->kappa);
+    // override variables (sample_auxillary.py:37-42)
+    int wsum = 0;
+    for (int q = tid; q < (T - 1) * K; q += HG_THREADS) {
+        const int t = q / K, j = q - t * K;
+        const int mjj = hb.m[((size_t)(t + 1) * K + j) * K + j];
+        const double p = rho / (rho + sBeta[j] * (1 - rho));
+        const int w = hdp_binomial(g, HK_OVERRIDE, (uint32_t)q, mjj, p);
+        hb.wover[q] = w;
+        atomicAdd(&sWsum[j], w);
+        wsum += w;
+    }
+    atomicAdd(&sTot[0], wsum);
+    // column sums of the tables: m_bar[k] = sum_{t >= 1, j} m[t, j, k] - sum_t w[t, k] + m[0, 0, k]
+    int mrest = 0;
+    for (int q = tid; q < T * K * K; q += HG_THREADS) {
+        const int t = q / (K * K), r = q - t * K * K, j = r / K, k = r - j * K;
+        if (t == 0 && j != 0) continue;
+        const int v = hb.m[q];
+        atomicAdd(&sMsum[k], v);
+        if (t > 0) mrest += v;
+    }
+    atomicAdd(&sTot[1], mrest);
+    __syncthreads();
+    // global transition distribution beta ~ Dirichlet(gamma / K + m_bar) (hdp_lpcm.py:887)
+    double mb = 0.0;
+    if (tid < K) {
+        mb = (double)(sMsum[tid] - sWsum[tid]);
+        hb.mbar[tid] = mb;
+        sG[tid] = hdp_gamma(g, HK_BETA, (uint32_t)tid, hs->gamma / K + mb);
+    }
+    __syncthreads();
+    double tot = 0.0;
+    for (int k = 0; k < K; ++k) tot += sG[k];
+    const double bnew = tid < K ? sG[tid] * (1.0 / tot) : 0.0;
+    __syncthreads();
+    // initial distribution w0 ~ Dirichlet(alpha_init beta + nk[0]) (hdp_lpcm.py:890)
+    if (tid < K) {
+        hb.beta[tid] = bnew;
+        double al = hs->alpha_init * bnew + (double)hb.nk[tid];
+        if (al <= 0.0) al = HDP_SMALL_EPS;
+        sG[tid] = hdp_gamma(g, HK_W0, (uint32_t)tid, al);
+    }
+    __syncthreads();
+    tot = 0.0;
+    for (int k = 0; k < K; ++k) tot += sG[k];
+    if (tid < K) hb.w[tid] = sG[tid] * (1.0 / tot);
+    if (tid == 0) {
+        double mbt = 0.0, mbp = 0.0, m00 = 0.0;
+        for (int k = 0; k < K; ++k) {
+            const double v = (double)(sMsum[k] - sWsum[k]);
+            mbt += v; mbp += v > 0.0 ? 1.0 : 0.0;
+            m00 += (double)hb.m[k];
+        }
+        hs->mbar_total = mbt; hs->mbar_positive = mbp; hs->m00_total = m00;
+        hs->m_rest_total = (double)sTot[1]; hs->override_total = (double)sTot[0];
+    }
+}
+
+// ---- transition distributions w[t, j, :] ~ Dirichlet(alpha beta + kappa e_j + n[t, j, :]) ---------
+// (hdp_lpcm.py:894-898); workgroup t - 1 draws the K x K gamma variates of time t
+__global__ __launch_bounds__(256) void k_hdp_weights(ChainView c, HdpLoopBuf hb,
+                                                     const HdpDeviceState *hs, IterRef ir) {
+    extern __shared__ double sGam[];            // K * K + K
+    const int K = hb.K, t = blockIdx.x + 1, tid = threadIdx.x;
+    double *sInv = sGam + K * K;
+    const HdpRng g = hdp_rng(c, ir.get());
+    const double alpha = hs->alpha, kappa = hs->kappa;
+    for (int q = tid; q < K * K; q += 256) {
+        const int j = q / K, k = q - j * K;
+        double al = (alpha * hb.beta[k] + (j == k ? kappa : 0.0)) + (double)hb.n[(size_t)t * K * K + q];
+        if (al <= 0.0) al = HDP_SMALL_EPS;
+        sGam[q] = hdp_gamma(g, HK_W, (uint32_t)(t * K * K + q), al);
+    }
+    __syncthreads();
+    if (tid < K) {
+        double tot = 0.0;
+        for (int k = 0; k < K; ++k) tot += sGam[tid * K + k];
+        sInv[tid] = 1.0 / tot;
+    }
+    __syncthreads();
+    for (int q = tid; q < K * K; q += 256) hb.w[(size_t)t * K * K + q] = sGam[q] * sInv[q / K];
+}
+
+// ---- cluster means (hdp_lpcm.py:901-921): thread k ------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(64) void k_hdp_draw_mu(ChainView c, HdpLoopBuf hb,
+                                                    const HdpDeviceState *hs, IterRef ir) {
+    const int K = hb.K, T = c.T, k = threadIdx.x;
+    if (k >= K) return;
+    const HdpRng g = hdp_rng(c, ir.get());
+    const double lm = hs->lmbda, sk = hb.sigma[k];
+    double pk = 1.0 / hs->mvp, mk[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) mk[d] = 0.0;
+    for (int t = 0; t < T; ++t) {
+        const int cnt = hb.nk[t * K + k];
+        if (cnt <= 0) continue;
+        const double *S = hb.S + ((size_t)t * K + k) * D;
+        if (t == 0) {
+            pk += (double)cnt / sk;
+#pragma unroll
+            for (int d = 0; d < D; ++d) mk[d] += (1.0 / sk) * S[d];
+        } else {
+            pk += (lm * lm / sk) * (double)cnt;
+#pragma unroll
+            for (int d = 0; d < D; ++d) mk[d] += (lm / sk) * S[d];
+        }
+    }
+    pk = 1.0 / pk;
+    const double sd = sqrt(pk);
+#pragma unroll
+    for (int d = 0; d < D; d += 2) {
+        double u0, u1, z0, z1;
+        g.u2(HK_MU, (uint32_t)k, (uint32_t)(d >> 1), u0, u1);
+        box_muller(u0, u1, z0, z1);
+        hb.mu[(size_t)k * D + d] = mk[d] * pk + sd * z0;
+        if (d + 1 < D) hb.mu[(size_t)k * D + d + 1] = mk[d + 1] * pk + sd * z1;
+    }
+}
+
+// ---- cluster variances (hdp_lpcm.py:924-938): thread k ---------------------------------------------
+__global__ __launch_bounds__(64) void k_hdp_draw_sigma(ChainView c, HdpLoopBuf hb,
+                                                       const HdpDeviceState *hs, IterRef ir) {
+    const int K = hb.K, T = c.T, D = c.D, k = threadIdx.x;
+    if (k >= K) return;
+    const HdpRng g = hdp_rng(c, ir.get());
+    long cnt = 0;
+    double bk = 0.5 * hs->b;
+    for (int t = 0; t < T; ++t) {
+        const int ntk = hb.nk[t * K + k];
+        cnt += ntk;
+        if (ntk > 0) bk += 0.5 * hb.Q[(size_t)t * K + k];
+    }
+    const double ak = 0.5 * ((double)cnt * D + hs->a);
+    hb.sigma[k] = 1.0 / (hdp_gamma(g, HK_SIGMA, (uint32_t)k, ak) * (1.0 / bk));
+}
+
+// Escobar & West (1995) auxiliary-variable update of a concentration parameter
+// (sample_concentration.py:6-21); one thread
+__device__ inline double hdp_concentration(const HdpRng &g, uint32_t kind, double alpha,
+                                           double n_clusters, double n_samples, double shape0,
+                                           double rate0) {
+    const double eta = hdp_beta(g, kind, 0, alpha + 1.0, n_samples);
+    double m_shape = shape0 + n_clusters - 1.0;
+    const double m_scale = rate0 - log(eta);
+    const double log_odds = (m_shape / m_scale) * (1.0 / n_samples);
+    double u0, u1;
+    g.u2(kind, 2, 0, u0, u1);
+    if (u0 <= log_odds / (1.0 + log_odds)) m_shape += 1.0;
+    return hdp_gamma(g, kind, 3, m_shape) * (1.0 / m_scale);
+}
+
+// ---- blending coefficient, variance hyper-parameters, concentration parameters: one workgroup ------
+// (hdp_lpcm.py:941-1023)
+constexpr int HH_THREADS = 256;
+__global__ __launch_bounds__(HH_THREADS) void k_hdp_hypers(ChainView c, HdpLoopBuf hb,
+                                                           HdpDeviceState *hs, IterRef ir) {
+    __shared__ double red[3][HH_THREADS / 64];
+    const int K = hb.K, T = c.T, D = c.D, tid = threadIdx.x;
+    const HdpRng g = hdp_rng(c, ir.get());
+    // sums of the lambda update over the cells (t >= 1, k) with members
+    double a0 = 0.0, a1 = 0.0;
+    for (int q = K + tid; q < T * K; q += HH_THREADS)
+        if (hb.nk[q] > 0) { a0 += hb.L[2 * (size_t)q]; a1 += hb.L[2 * (size_t)q + 1]; }
+    const double ml_sum = block_sum_all<HH_THREADS / 64>(a0, red[0], tid);
+    const double sl_sum = block_sum_all<HH_THREADS / 64>(a1, red[1], tid);
+    __syncthreads();
+    // alpha + kappa: s ~ Bernoulli(n. / (n. + alpha + kappa)), r ~ Beta(alpha + kappa + 1, n.) for
+    // every (t >= 1, j) with n.[t, j] = sum_k n[t, j, k] > 0 (hdp_lpcm.py:999-1011)
+    const double ak0 = hs->alpha + hs->kappa;
+    double s_sum = 0.0, logr_sum = 0.0, mval_sum = 0.0;
+    for (int q = tid; q < (T - 1) * K; q += HH_THREADS) {
+        const int t = q / K + 1, j = q - (t - 1) * K;
+        long ndot = 0, mrow = 0;
+        for (int k = 0; k < K; ++k) {
+            ndot += hb.n[((size_t)t * K + j) * K + k];
+            mrow += hb.m[((size_t)t * K + j) * K + k];
+        }
+        if (ndot <= 0) continue;
+        double u0, u1;
+        g.u2(HK_AK_S, (uint32_t)q, 0, u0, u1);
+        s_sum += u0 <= (double)ndot / ((double)ndot + ak0) ? 1.0 : 0.0;
+        logr_sum += log(hdp_beta(g, HK_AK_R, (uint32_t)q, ak0 + 1.0, (double)ndot));
+        mval_sum += (double)mrow;
+    }
+    s_sum = block_sum_all<HH_THREADS / 64>(s_sum, red[2], tid);
+    __syncthreads();
+    logr_sum = block_sum_all<HH_THREADS / 64>(logr_sum, red[0], tid);
+    mval_sum = block_sum_all<HH_THREADS / 64>(mval_sum, red[1], tid);
+    if (tid != 0) return;
+    // blending coefficient (hdp_lpcm.py:941-954)
+    double sl = 1.0 / hs->lambda_var + sl_sum;
+    sl = 1.0 / sl;
+    double ml = ml_sum + hs->lambda_prior / hs->lambda_var;
+    ml *= sl;
+    {
+        double u0, u1;
+        g.u2(HK_LAMBDA, 0, 0, u0, u1);
+        hs->lmbda = dev_truncnorm_quantile(u0, ml, sl);
+    }
+    // variance hyper-parameters (hdp_lpcm.py:957-972)
+    if (hs->has_a0) {
+        double b = 0.5 * hs->b0;
+        for (int k = 0; k < K; ++k) {
+            double ss = 0.0;
+            for (int d = 0; d < D; ++d) ss += hb.mu[(size_t)k * D + d] * hb.mu[(size_t)k * D + d];
+            b += 0.5 * ss;
+        }
+        const double a = 0.5 * (hs->a0 + K);
+        hs->mvp = 1.0 / (hdp_gamma(g, HK_MVP, 0, a) * (1.0 / b));
+    }
+    if (hs->has_c0) {
+        double scale = 0.5 * hs->d0;
+        for (int k = 0; k < K; ++k) scale += 0.5 * (1.0 / hb.sigma[k]);
+        const double shape = 0.5 * (hs->c0 + K * hs->a);
+        hs->b = hdp_gamma(g, HK_B, 0, shape) * (1.0 / scale);
+    }
+    // concentration parameters (hdp_lpcm.py:977-996)
+    hs->gamma = hdp_concentration(g, HK_CONC_GAMMA, hs->gamma, hs->mbar_positive, hs->mbar_total,
+                                  hs->gamma_shape, hs->gamma_rate);
+    hs->alpha_init = hdp_concentration(g, HK_CONC_ALPHA0, hs->alpha_init, hs->m00_total,
+                                       (double)c.N, hs->alpha0_shape, hs->alpha0_rate);
+    // alpha + kappa and rho (hdp_lpcm.py:1009-1023)
+    const double shape = hs->ak_shape + mval_sum - s_sum;
+    const double rate = hs->ak_rate - logr_sum;
+    const double ak = hdp_gamma(g, HK_AK, 0, shape) * (1.0 / rate);
+    const double nsucc = hs->override_total;
+    const double rho = hdp_beta(g, HK_RHO, 0, 8.0 + nsucc, hs->m_rest_total - nsucc + 2.0);
+    hs->kappa = ak * rho;
+    hs->alpha = ak - hs->kappa;
+}
+
+// ---- log-posterior trace (hdp_lpcm.py:1188-1280) and the sample's trace rows: one workgroup -----------
+constexpr int HF_THREADS = 256;
+template <int D>
+__global__ __launch_bounds__(HF_THREADS) void k_hdp_finalize(ChainView c, HdpLoopBuf hb,
+                                                             const HdpDeviceState *hs,
+                                                             const LsmDeviceState *lsm,
+                                                             HdpTrace tr, IterRef ir) {
+    __shared__ double red[2][HF_THREADS / 64];
+    const int K = hb.K, T = c.T, tid = threadIdx.x;
+    const int it = (int)ir.get();
+    const double alpha = hs->alpha, kappa = hs->kappa;
+    // Dirichlet log-densities of the T - 1 x K transition rows (distributions.py:95-100: alphas
+    // and x clipped at the smallest normal number) and the node terms of the label sums
+    double acc = 0.0;
+    for (int q = tid; q < (T - 1) * K * K; q += HF_THREADS) {
+        const int r = q / K, k = q - r * K, j = r % K;
+        double al = alpha * hb.beta[k] + (j == k ? kappa : 0.0);
+        if (al <= 0.0) al = HDP_SMALL_EPS;
+        double x = hb.w[(size_t)K * K + q];
+        if (x <= 0.0) x = HDP_SMALL_EPS;
+        acc += (al - 1.0 == 0.0 ? 0.0 : (al - 1.0) * log(x)) - lgamma(al);
+    }
+    for (int r = tid; r < (T - 1) * K; r += HF_THREADS) {
+        const int j = r % K;
+        double tot = 0.0;
+        for (int k = 0; k < K; ++k) {
+            double al = alpha * hb.beta[k] + (j == k ? kappa : 0.0);
+            if (al <= 0.0) al = HDP_SMALL_EPS;
+            tot += al;
+        }
+        acc += lgamma(tot);
+    }
+    for (int q = tid; q < T * K; q += HF_THREADS)
+        if (hb.nk[q] > 0) acc += hb.LP[q];
+    const double body = block_sum_all<HF_THREADS / 64>(acc, red[0], tid);
+    // the trace rows of this sample
+    for (int q = tid; q < K * D; q += HF_THREADS) tr.mu[(size_t)it * K * D + q] = hb.mu[q];
+    for (int q = tid; q < K; q += HF_THREADS) {
+        tr.sigma[(size_t)it * K + q] = hb.sigma[q];
+        tr.beta[(size_t)it * K + q] = hb.beta[q];
+    }
+    for (int q = tid; q < T * K * K; q += HF_THREADS) tr.w[(size_t)it * T * K * K + q] = hb.w[q];
+    if (tid != 0) return;
+    double lp = body + hs->ll;
+    {   // beta ~ Dirichlet(gamma / K) and w0 ~ Dirichlet(alpha_init beta)
+        double al0 = hs->gamma / K, tot0 = 0.0, tot1 = 0.0, s0 = 0.0, s1 = 0.0;
+        if (al0 <= 0.0) al0 = HDP_SMALL_EPS;
+        for (int k = 0; k < K; ++k) {
+            double bk = hb.beta[k];
+            double al1 = hs->alpha_init * bk;
+            if (al1 <= 0.0) al1 = HDP_SMALL_EPS;
+            if (bk <= 0.0) bk = HDP_SMALL_EPS;
+            double x1 = hb.w[k];
+            if (x1 <= 0.0) x1 = HDP_SMALL_EPS;
+            tot0 += al0; tot1 += al1;
+            s0 += (al0 - 1.0 == 0.0 ? 0.0 : (al0 - 1.0) * log(bk)) - lgamma(al0);
+            s1 += (al1 - 1.0 == 0.0 ? 0.0 : (al1 - 1.0) * log(x1)) - lgamma(al1);
+        }
+        lp += lgamma(tot0) + s0 + lgamma(tot1) + s1;
+    }
+    {   // intercept prior, cluster means, blending coefficient, hyper-priors
+        const double b = c.intercept[0], diff = b - lsm->intercept_prior[0];
+        lp -= 0.5 * (diff * diff) / lsm->intercept_var;
+        double ss = 0.0;
+        for (int q = 0; q < K * D; ++q) ss += hb.mu[q] * hb.mu[q];
+        lp -= 0.5 * ss / hs->mvp;
+        lp += dev_truncnorm_logpdf(hs->lmbda, hs->lambda_prior, hs->lambda_var);
+        if (hs->has_a0) lp += -(0.5 * hs->a0 + 1.0) * log(hs->mvp) - (0.5 * hs->b0 / hs->mvp);
+        if (hs->has_c0) lp += (hs->c0 - 1.0) * log(hs->b) - hs->d0 * hs->b;
+    }
+    tr.logp[it] = lp;
+    tr.lambda[it] = hs->lmbda;
+    double *hy = tr.hyper + (size_t)it * 6;
+    hy[0] = hs->gamma; hy[1] = hs->alpha_init; hy[2] = hs->alpha; hy[3] = hs->kappa;
+    hy[4] = hs->mvp; hy[5] = hs->b;
+}
+
+// labels of the sample -> its trace row as bytes (K <= 64)
+__global__ __launch_bounds__(256) void k_hdp_trace_labels(const int32_t *__restrict__ z, long n,
+                                                          uint8_t *__restrict__ row) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) row[i] = (uint8_t)z[i];
+}
+
+}  // namespace dlsm

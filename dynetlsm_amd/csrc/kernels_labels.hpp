@@ -28,9 +28,10 @@ __device__ __forceinline__ double gauss_loglik_tk(const ChainView &c, int t, int
     const double *m = c.mu + (size_t)k * D;
     if (t == 0) return spherical_normal_log_pdf<D>(x, m, c.sigma[k]);
     const double *xp = c.X + ((size_t)(t - 1) * c.N + i) * D;
+    const double lm = c.lmbda_p[0];
     double muk[D];
 #pragma unroll
-    for (int j = 0; j < D; ++j) muk[j] = c.lmbda * m[j] + (1 - c.lmbda) * xp[j];
+    for (int j = 0; j < D; ++j) muk[j] = lm * m[j] + (1 - lm) * xp[j];
     return spherical_normal_log_pdf<D>(x, muk, c.sigma[k]);
 }
 

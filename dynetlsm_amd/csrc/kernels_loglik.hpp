@@ -502,7 +502,7 @@ __device__ __forceinline__ double node_log_prior(const ChainView &c, int t, int 
             lp -= 0.5 * s / c.sigma_sq;
         }
     } else {
-        const double lm = c.lmbda;
+        const double lm = c.lmbda_p[0];
         const int zt = c.z[(size_t)t * N + j];
         const double *m = c.mu + (size_t)zt * D;
         double s = 0.0;

@@ -8,7 +8,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import (EngineError, LsmConfig, c_double_p, c_i32_p, c_i64_p,
+from ._lib import (EngineError, LsmConfig, HdpConfig, c_double_p, c_i32_p, c_i64_p,
                    UNDIRECTED, DIRECTED, DIRECTED_CASE_CONTROL)
 
 __all__ = ['Chain', 'SamplerGrid', 'EngineError']
@@ -381,6 +381,80 @@ class Chain(object):
                                          _p(Xs) if positions else None, _p(ics),
                                          _p(lps)))
         return Xs, ics[:, :self.n_intercepts], lps
+
+    # -- device-resident HDP-LPCM loop -------------------------
+    def hdp_configure(self, hp, beta, weights, intercept_prior, intercept_variance_prior,
+                      step_size_intercept=0.1, tune=None, tune_interval=100, sweep_algo=0,
+                      state=None):
+        """``hp``: an object with the HDP-LPCM's hyper-parameters as attributes (gamma,
+        alpha_init, alpha, kappa, mean_variance_prior, b, a, a0, b0, c0, d0 - None switches an
+        update off -, lambda_prior, lambda_variance_prior, *_prior_shape / *_rate); beta (K,),
+        weights (T, K, K).  The mixture prior (mu, sigma, lmbda, z) must be set."""
+        K = self.K
+        cfg = HdpConfig()
+        for name in ('gamma', 'alpha_init', 'alpha', 'kappa', 'mean_variance_prior', 'b', 'a',
+                     'lambda_prior', 'lambda_variance_prior', 'gamma_prior_shape',
+                     'gamma_prior_rate', 'alpha_init_shape', 'alpha_init_rate',
+                     'alpha_kappa_shape', 'alpha_kappa_rate'):
+            setattr(cfg, name, float(np.ravel(getattr(hp, name))[0]))
+        cfg.has_a0 = int(hp.a0 is not None)
+        cfg.has_c0 = int(hp.c0 is not None)
+        cfg.a0, cfg.b0 = (float(hp.a0), float(hp.b0)) if hp.a0 is not None else (0.0, 0.0)
+        cfg.c0, cfg.d0 = (float(hp.c0), float(hp.d0)) if hp.c0 is not None else (0.0, 0.0)
+        cfg.intercept_prior = float(np.ravel(intercept_prior)[0])
+        cfg.intercept_variance_prior = float(intercept_variance_prior)
+        cfg.i_step_size = float(step_size_intercept)
+        cfg.i_n_accepted, cfg.i_n_steps = 0, 0
+        cfg.i_steps_until_tune = int(tune_interval)
+        if state is not None:       # (step, n_accepted, n_steps, until)
+            cfg.i_step_size, cfg.i_n_accepted = float(state[0]), int(state[1])
+            cfg.i_n_steps, cfg.i_steps_until_tune = int(state[2]), int(state[3])
+        cfg.i_tune = -1 if tune is None else int(tune)
+        cfg.i_tune_interval = int(tune_interval)
+        cfg.sweep_algo = int(sweep_algo)
+        beta = _f64(beta, (K,), 'beta')
+        weights = _f64(weights, (self.T, K, K), 'weights')
+        self._ck(self._L.dlsm_hdp_configure(self._h, C.byref(cfg), _p(beta), _p(weights)))
+
+    def hdp_get_config(self):
+        cfg = HdpConfig()
+        self._ck(self._L.dlsm_hdp_get_config(self._h, C.byref(cfg)))
+        return cfg
+
+    def hdp_trace_alloc(self, n_total, logp0=0.0):
+        self._ck(self._L.dlsm_hdp_trace_alloc(self._h, int(n_total), float(logp0)))
+
+    def hdp_run(self, first, count):
+        """enqueue Gibbs iterations first..first+count-1 of the HDP-LPCM (asynchronous)"""
+        self._ck(self._L.dlsm_hdp_run(self._h, int(first), int(count)))
+
+    def hdp_trace_read(self, first, count, positions=True, labels=True):
+        """dict of the stored samples first..first+count-1"""
+        T, N, D, K = self.T, self.N, self.D, self.K
+        out = dict(intercepts=np.zeros((count, 2)), logps=np.zeros(count),
+                   mus=np.zeros((count, K, D)), sigmas=np.zeros((count, K)),
+                   betas=np.zeros((count, K)), weights=np.zeros((count, T, K, K)),
+                   lambdas=np.zeros((count, 1)), hypers=np.zeros((count, 6)))
+        if positions:
+            out['Xs'] = np.zeros((count, T, N, D))
+        if labels:
+            out['zs'] = np.zeros((count, T, N), dtype=np.int64)
+        self._ck(self._L.dlsm_hdp_trace_read(
+            self._h, int(first), int(count), _p(out['Xs']) if positions else None,
+            _p(out['intercepts']), _p(out['logps']), _p(out['mus']), _p(out['sigmas']),
+            _p(out['zs']) if labels else None, _p(out['betas']), _p(out['weights']),
+            _p(out['lambdas']), _p(out['hypers'])))
+        out['intercepts'] = out['intercepts'][:, :1]
+        return out
+
+    def hdp_get_aux(self):
+        """auxiliary variables of the last iteration: m, m_bar, w_over, n, nk"""
+        T, K = self.T, self.K
+        m = np.zeros((T, K, K), dtype=np.int64); mb = np.zeros(K)
+        wo = np.zeros((max(T - 1, 0), K), dtype=np.int64)
+        n = np.zeros((T, K, K), dtype=np.int64); nk = np.zeros((T, K), dtype=np.int64)
+        self._ck(self._L.dlsm_hdp_get_aux(self._h, _p(m), _p(mb), _p(wo), _p(n), _p(nk)))
+        return dict(m=m, m_bar=mb, w_over=wo, n=n, nk=nk)
 
     def trace_read_radii(self, first, count):
         out = np.zeros((count, self.N))

@@ -42,7 +42,14 @@ def _geweke(trace, n_burn):
 
 class DynamicNetworkHDPLPCM(FittedQuantities):
     """Constructor parameters are the reference's (hdp_lpcm.py:385-455) plus
-    ``device``, ``chain_id`` and ``sweep_algo``."""
+    ``device``, ``chain_id``, ``sweep_algo`` and ``hdp_loop``:
+
+    ``hdp_loop='device'`` runs the whole Gibbs iteration on the GPU (``dlsm_hdp_run``: every
+    draw of hdp_lpcm.py:876-1023 from Philox counters, no host round trip inside an
+    iteration); ``'host'`` keeps the auxiliary / conjugate draws in numpy on the caller's
+    MT19937 stream in the reference's order (the bit-level pin to the reference's ``_fit``
+    trace, and the only form for directed models).  ``'auto'`` = device for undirected
+    models, host otherwise.  The two are equal in distribution."""
 
     def __init__(self, n_features=2, n_components=10, is_directed=False,
                  selection_type='vi', n_iter=5000, tune=2500, tune_interval=100,
@@ -54,8 +61,9 @@ class DynamicNetworkHDPLPCM(FittedQuantities):
                  lambda_variance_prior=0.01, sigma_prior_std=4.0,
                  mean_variance_prior_std=4.0, step_size_X='auto', step_size_intercept=0.1,
                  step_size_radii=175000, n_control=None, n_resample_control=100, copy=True,
-                 random_state=None, device=0, chain_id=0, sweep_algo=0):
+                 random_state=None, device=0, chain_id=0, sweep_algo=0, hdp_loop='auto'):
         self.n_iter = n_iter
+        self.hdp_loop = hdp_loop
         self.is_directed = is_directed
         self.n_features = n_features
         self.n_components = n_components
@@ -284,12 +292,37 @@ class DynamicNetworkHDPLPCM(FittedQuantities):
         self.logps_ = np.zeros(n_total)
 
         chain.set_prior_mixture(mu, sigma, lmbda, z)
+        if self.hdp_loop not in ('auto', 'device', 'host'):
+            raise ValueError("hdp_loop must be 'auto', 'device' or 'host'")
+        if self.hdp_loop == 'device' and self.is_directed:
+            raise ValueError("hdp_loop='device' covers undirected models")
+        self.loop_kind_ = ('host-driven' if (self.is_directed or self.hdp_loop == 'host')
+                           else 'device-resident')
         self._n_total, self._rng, self._ip, self._miss = n_total, rng, ip, miss
         self._sums = hu.DeviceLabelSums(chain)  # label-wise sums at the chain's X and z
         self._st = dict(X=X, intercept=intercept, mu=mu, sigma=sigma, z=z, beta=beta,
                         weights=weights, lmbda=lmbda, radii=radii)
         self._store(0, chain.loglik_full())
+        if self.loop_kind_ == 'device-resident':
+            chain.hdp_configure(hp, beta, weights, ip, self.intercept_variance_prior,
+                                step_size_intercept=self.step_size_intercept, tune=self.tune,
+                                tune_interval=100, sweep_algo=self.sweep_algo)
+            chain.hdp_trace_alloc(n_total, logp0=float(self.logps_[0]))
         return self
+
+    def _pull(self, first, count):
+        """device-resident loop: the stored samples first .. first + count - 1 -> the host
+        trace arrays"""
+        if self.loop_kind_ != 'device-resident' or count <= 0:
+            return
+        tr = self.chain_.hdp_trace_read(first, count)
+        sl = slice(first, first + count)
+        self.Xs_[sl], self.intercepts_[sl], self.logps_[sl] = tr['Xs'], tr['intercepts'], tr['logps']
+        self.mus_[sl], self.sigmas_[sl], self.zs_[sl] = tr['mus'], tr['sigmas'], tr['zs']
+        self.betas_[sl], self.weights_[sl], self.lambdas_[sl] = (tr['betas'], tr['weights'],
+                                                                 tr['lambdas'])
+        self.hypers_ = getattr(self, 'hypers_', np.zeros((self._n_total, 6)))
+        self.hypers_[sl] = tr['hypers']
 
     def _store(self, it, ll):
         st, hp = self._st, self.hyper_
@@ -307,6 +340,9 @@ class DynamicNetworkHDPLPCM(FittedQuantities):
         """Gibbs iterations first .. first + count - 1 (hdp_lpcm.py:823-1069), host-driven:
         the kernels of the engine around numpy draws on the caller's MT19937 stream."""
         chain, rng, hp, ip = self.chain_, self._rng, self.hyper_, self._ip
+        if self.loop_kind_ == 'device-resident':
+            chain.hdp_run(first, count)          # asynchronous: the iterations are enqueued
+            return
         isamp, rsamp, sums, miss = (self.intercept_samplers, self.radii_sampler, self._sums,
                                     self._miss)
         st = self._st
@@ -369,6 +405,27 @@ class DynamicNetworkHDPLPCM(FittedQuantities):
     def _finish(self):
         """Everything of ``fit`` after the Gibbs loop (hdp_lpcm.py:1072-1176)."""
         chain, hp, n_total = self.chain_, self.hyper_, self._n_total
+        if self.loop_kind_ == 'device-resident':
+            self._pull(1, n_total - 1)
+            cfg = chain.hdp_get_config()
+            hp.gamma, hp.alpha_init, hp.alpha, hp.kappa = (cfg.gamma, cfg.alpha_init, cfg.alpha,
+                                                           cfg.kappa)
+            hp.mean_variance_prior, hp.b = cfg.mean_variance_prior, cfg.b
+            sm = self.intercept_samplers[0]
+            sm.step_size, sm.n_accepted = cfg.i_step_size, cfg.i_n_accepted
+            sm.n_steps, sm.steps_until_tune = cfg.i_n_steps, cfg.i_steps_until_tune
+            self._st.update(X=self.Xs_[-1], intercept=self.intercepts_[-1], mu=self.mus_[-1],
+                            sigma=self.sigmas_[-1], z=self.zs_[-1], beta=self.betas_[-1],
+                            weights=self.weights_[-1], lmbda=self.lambdas_[-1])
+            if self._miss is not None:            # hdp_lpcm.py:1039-1049 from the stored samples
+                miss, rng = self._miss, self._rng
+                for it in range(1, n_total):
+                    X = self.Xs_[it]
+                    dm = X[miss[0], miss[1]] - X[miss[0], miss[2]]
+                    eta = self.intercepts_[it, 0] - np.sqrt(np.sum(dm * dm, axis=1))
+                    y_ij = rng.binomial(1, 1. / (1. + np.exp(-eta)))
+                    if it > self.n_burn_:
+                        self.missings_ += y_ij
         if self._miss is not None:
             self.missings_ /= max(1, n_total - self.n_burn_)       # hdp_lpcm.py:1155-1156
         chain.get_samplers(self.latent_samplers)

@@ -200,6 +200,54 @@ int dlsm_trace_read(dlsm_chain *h, int first, int count, double *Xs,
 /* rows first .. first+count-1 of the radii trace (count*N), directed models */
 int dlsm_trace_read_radii(dlsm_chain *h, int first, int count, double *radii);
 
+/* ---- device-resident HDP-LPCM chain (hdp_lpcm.py:823-1069, undirected model) --------
+ * the whole Gibbs iteration of DynamicNetworkHDPLPCM._fit on the device -
+ * sweep with the AR-mixture prior, centring, intercept MH, label block update
+ * (sample_labels.py:134-190), table counts and override variables
+ * (sample_auxillary.py:6-50), beta / w0 / w Dirichlet draws (hdp_lpcm.py:887-898), cluster
+ * means, variances and the blending coefficient (:901-954), the variance hyper-parameters
+ * (:957-972), the concentration parameters (sample_concentration.py:6-21,
+ * hdp_lpcm.py:977-1023) and the log-posterior trace (:1188-1280) - with Philox draws (stream
+ * HDP = 6, counter (index, kind | attempt << 8, iteration)): no host round trip inside an
+ * iteration.  The mixture's state (mu, sigma, lmbda, z) is what dlsm_set_prior_mixture
+ * left on the device. */
+typedef struct {
+    /* resampled by the loop */
+    double gamma, alpha_init, alpha, kappa, mean_variance_prior, b;
+    /* fixed hyper-priors (hdp_lpcm.py:760-793); has_a0 / has_c0 = 0 switch the updates of
+     * mean_variance_prior / b off (mean_variance_prior_std / sigma_prior_std = None) */
+    double a, a0, b0, c0, d0;
+    int32_t has_a0, has_c0;
+    double lambda_prior, lambda_variance_prior;
+    double gamma_prior_shape, gamma_prior_rate, alpha_init_shape, alpha_init_rate,
+           alpha_kappa_shape, alpha_kappa_rate;
+    double intercept_prior, intercept_variance_prior;
+    /* the intercept's random-walk sampler (metropolis.py:85-94); i_tune < 0 == None */
+    double i_step_size;
+    int32_t i_n_accepted, i_n_steps, i_steps_until_tune, i_tune, i_tune_interval;
+    int32_t sweep_algo;                        /* as dlsm_sweep_positions */
+} dlsm_hdp_config;
+/* beta K, weights T*K*K (weights[0,0,:] the initial distribution), K = the mixture prior's */
+int dlsm_hdp_configure(dlsm_chain *h, const dlsm_hdp_config *cfg, const double *beta,
+                       const double *weights);
+/* the current hyper-parameters and sampler state */
+int dlsm_hdp_get_config(dlsm_chain *h, dlsm_hdp_config *cfg);
+/* device trace of n_total samples: Xs_, intercepts_, logps_ (shared with the LSM loop's
+ * buffers), mus_, sigmas_, zs_, betas_, weights_, lambdas_ and the six resampled
+ * hyper-parameters; row 0 = the current state, logp0 given */
+int dlsm_hdp_trace_alloc(dlsm_chain *h, int n_total, double logp0);
+/* enqueue iterations first .. first+count-1.  Asynchronous. */
+int dlsm_hdp_run(dlsm_chain *h, int first, int count);
+/* rows first .. first+count-1; any pointer may be NULL.  zs count*T*N int64, hypers count*6
+ * [gamma, alpha_init, alpha, kappa, mean_variance_prior, b] */
+int dlsm_hdp_trace_read(dlsm_chain *h, int first, int count, double *Xs, double *intercepts,
+                        double *logps, double *mus, double *sigmas, int64_t *zs, double *betas,
+                        double *weights, double *lambdas, double *hypers);
+/* auxiliary variables of the last iteration (tests): m T*K*K tables, m_bar K, w_over (T-1)*K
+ * override counts, n T*K*K and nk T*K label counts */
+int dlsm_hdp_get_aux(dlsm_chain *h, int64_t *m, double *m_bar, int64_t *w_over, int64_t *n,
+                     int64_t *nk);
+
 /* ---- starting values (generalized_mds + conditional MLEs) -- */
 /* shortest_path_dissimilarity (latent_space.py:36-44) of every time slice, from
  * the bit-packed network (symmetrised for directed models, as
@@ -276,7 +324,8 @@ enum {
     DLSM_K_SWEEP_EVAL = 5,     /* k_spec_eval launches of the speculative sweep */
     DLSM_K_SWEEP_RESOLVE = 6,  /* k_spec_resolve launches */
     DLSM_K_INIT = 7,           /* every kernel of the dlsm_init_* calls */
-    DLSM_K_COUNT = 8
+    DLSM_K_HDP_TAIL = 8,       /* dlsm_hdp_run: everything after the label update */
+    DLSM_K_COUNT = 9
 };
 /* when enabled every launch of the kernel classes above is bracketed by HIP
  * events on the handle's stream; read returns accumulated ms and launches */

@@ -1,0 +1,190 @@
+"""The device-resident HDP-LPCM loop (dlsm_hdp_run) against the CPU oracle:
+oracle/hdp_loop_oracle.py runs the reference's own update code (pinned to the reference's
+``_fit`` trace with MT19937 by tests/test_hdp_loop_oracle.py) with the engine's Philox draws;
+the device must reproduce it iteration by iteration - discrete quantities exactly, float
+quantities to rounding.  Through the C-ABI."""
+import numpy as np
+import pytest
+import torch      # noqa: F401  (one HIP runtime per process: torch's first)
+
+from oracle import oracle as orc
+from oracle import hdp_loop_oracle as hlo
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def eng():
+    import dynetlsm_amd
+    return dynetlsm_amd
+
+
+def _case(T, N, K, seed, n_true=3, density_b=1.0):
+    rng = np.random.RandomState(seed)
+    cen = 2.5 * rng.randn(n_true, 2)
+    z = np.zeros((T, N), dtype=np.int64)
+    z[0] = rng.randint(0, n_true, N)
+    for t in range(1, T):
+        mv = rng.rand(N) < 0.15
+        z[t] = np.where(mv, rng.randint(0, n_true, N), z[t - 1])
+    X = np.zeros((T, N, 2))
+    X[0] = cen[z[0]] + 0.5 * rng.randn(N, 2)
+    for t in range(1, T):
+        X[t] = 0.2 * X[t - 1] + 0.8 * cen[z[t]] + 0.5 * rng.randn(N, 2)
+    X -= X.mean(axis=(0, 1))
+    Y = np.zeros((T, N, N))
+    for t in range(T):
+        d = np.sqrt(((X[t][:, None] - X[t][None]) ** 2).sum(-1))
+        A = (rng.rand(N, N) < 1 / (1 + np.exp(-(density_b - d)))).astype(float)
+        A = np.triu(A, 1)
+        Y[t] = A + A.T
+    mu = np.vstack([cen - X.mean(axis=(0, 1)), 2.0 * rng.randn(K - n_true, 2)])[:K]
+    sigma = rng.uniform(0.2, 0.8, K)
+    z0 = z.copy()
+    flip = rng.rand(T, N) < 0.2
+    z0[flip] = rng.randint(0, K, flip.sum())
+    beta = rng.dirichlet(np.ones(K))
+    w = rng.dirichlet(np.ones(K) * 0.7, size=(T, K))
+    return Y, X + 0.1 * rng.randn(T, N, 2), mu, sigma, z0, beta, w
+
+
+def _hyper(a0=True, c0=True):
+    kw = dict(gamma=1.3, alpha_init=0.9, alpha=1.1, kappa=3.5, mean_variance_prior=2.4, b=1.7,
+              a=2.0, lambda_prior=0.9, lambda_variance_prior=0.01, gamma_prior_shape=1.0,
+              gamma_prior_rate=0.1, alpha_init_shape=1.0, alpha_init_rate=1.0,
+              alpha_kappa_shape=5, alpha_kappa_rate=0.1)
+    if a0:
+        kw.update(a0=36.0, b0=9.3)
+    if c0:
+        kw.update(c0=16.0, d0=9.4)
+    return hlo.Hyper(**kw)
+
+
+def _run_both(eng, T, N, K, seed, n_it, tune=None, algo=0, a0=True, c0=True, lmbda=0.8,
+              check_each=True):
+    Y, X, mu, sigma, z, beta, w = _case(T, N, K, seed)
+    b0, ip, var = 0.6, 0.5, 2.0
+    hp = _hyper(a0, c0)
+    og = orc.SamplerGrid(T, N, 0.15, tune=tune, tune_interval=2)
+    isamp = orc.ScalarMetropolis(0.1, tune, 100)
+    oc = hlo.HdpChain(Y, X, [b0], mu, sigma, z, beta, w, lmbda, hp.copy(), og, ip, var, isamp,
+                      seed=77 + seed, chain=2)
+    out = []
+    with eng.Chain(T, N, 2, 'undirected', seed=77 + seed, chain_id=2) as c:
+        c.upload_network(Y); c.set_positions(X); c.set_intercepts([b0])
+        c.set_samplers(eng.SamplerGrid(T, N, 0.15, tune=tune, tune_interval=2))
+        c.set_prior_mixture(mu, sigma, lmbda, z)
+        c.hdp_configure(hp, beta, w, ip, var, step_size_intercept=0.1, tune=tune,
+                        tune_interval=100, sweep_algo=algo)
+        c.hdp_trace_alloc(n_it + 1, logp0=-1.0)
+        for it in range(1, n_it + 1):
+            c.hdp_run(it, 1)
+            c.synchronize()
+            lp = oc.iteration(it)
+            aux = c.hdp_get_aux()
+            tr = c.hdp_trace_read(it, 1)
+            # discrete: labels, counts, tables, override variables
+            np.testing.assert_array_equal(tr['zs'][0], oc.z)
+            np.testing.assert_array_equal(aux['n'], oc.n.astype(np.int64))
+            np.testing.assert_array_equal(aux['nk'], oc.nk)
+            np.testing.assert_array_equal(aux['m'], oc.aux['m'])
+            if T > 1:
+                np.testing.assert_array_equal(aux['w_over'], oc.aux['w'].astype(np.int64))
+            np.testing.assert_allclose(aux['m_bar'], oc.aux['m_bar'], rtol=0, atol=0)
+            # continuous
+            np.testing.assert_allclose(tr['Xs'][0], oc.X, atol=1e-9)
+            np.testing.assert_allclose(tr['intercepts'][0, 0], oc.intercept[0], rtol=1e-11)
+            np.testing.assert_allclose(tr['betas'][0], oc.beta, rtol=1e-9)
+            np.testing.assert_allclose(tr['weights'][0], oc.weights, rtol=1e-8, atol=1e-300)
+            np.testing.assert_allclose(tr['mus'][0], oc.mu, rtol=1e-8, atol=1e-10)
+            np.testing.assert_allclose(tr['sigmas'][0], oc.sigma, rtol=1e-9)
+            np.testing.assert_allclose(tr['lambdas'][0, 0], oc.lmbda[0], rtol=1e-9)
+            h = oc.hp
+            want = [h.gamma, h.alpha_init, h.alpha, h.kappa,
+                    float(np.ravel(h.mean_variance_prior)[0]), h.b]
+            np.testing.assert_allclose(tr['hypers'][0], want, rtol=1e-8)
+            np.testing.assert_allclose(tr['logps'][0], lp, rtol=1e-9)
+            out.append((tr, lp))
+        cfg = c.hdp_get_config()
+        assert cfg.i_n_steps == isamp.n_steps and cfg.i_n_accepted == isamp.n_accepted
+        np.testing.assert_allclose(cfg.i_step_size, isamp.step_size, rtol=1e-13)
+        g = c.get_samplers(eng.SamplerGrid(T, N, 0.15, tune=tune, tune_interval=2))
+        np.testing.assert_array_equal(g.n_accepted, og.n_accepted)
+        np.testing.assert_allclose(g.step_size, og.step_size, rtol=1e-13)
+        tr0 = c.hdp_trace_read(0, 1)
+        np.testing.assert_array_equal(tr0['zs'][0], z)
+        np.testing.assert_allclose(tr0['mus'][0], mu)
+        assert tr0['logps'][0] == -1.0
+    return out
+
+
+@pytest.mark.parametrize('T,N,K,seed', [(3, 60, 4, 0), (4, 150, 6, 1), (2, 33, 3, 2), (5, 70, 9, 3)])
+def test_device_loop_matches_oracle_iteration_by_iteration(eng, T, N, K, seed):
+    _run_both(eng, T, N, K, seed, n_it=5)
+
+
+def test_device_loop_with_tuning_and_without_hyperpriors(eng):
+    _run_both(eng, 3, 80, 5, 5, n_it=6, tune=4)
+    _run_both(eng, 3, 50, 4, 6, n_it=3, a0=False, c0=False)
+    _run_both(eng, 3, 50, 4, 7, n_it=3, a0=True, c0=False)
+
+
+def test_device_loop_single_time_step(eng):
+    """T = 1: no transitions, no override variables (empty sums in hdp_lpcm.py:999-1020)"""
+    _run_both(eng, 1, 60, 4, 8, n_it=4)
+
+
+def test_device_loop_with_the_pipelined_sweep(eng):
+    """N = 600: fit()'s default sweep at this size (algo 4), K = 20 as config 3"""
+    _run_both(eng, 4, 600, 20, 9, n_it=3, algo=0)
+
+
+def test_truncated_normal_far_tails(eng):
+    """the blending coefficient's draw when its conditional sits far outside [0, 1] or is very
+    sharp: the device's log-space quantile against scipy's (through the oracle)"""
+    # exercised through one iteration each with extreme lambda priors
+    for lp, lv in [(5.0, 1e-4), (-3.0, 1e-4), (0.5, 1e-9), (0.999, 1e-6)]:
+        Y, X, mu, sigma, z, beta, w = _case(3, 40, 4, 11)
+        hp = _hyper()
+        hp.lambda_prior, hp.lambda_variance_prior = lp, lv
+        og = orc.SamplerGrid(3, 40, 0.15, tune=None)
+        oc = hlo.HdpChain(Y, X, [0.6], mu, sigma, z, beta, w, 0.8, hp.copy(), og, 0.5, 2.0,
+                          orc.ScalarMetropolis(0.1, None, 100), seed=5, chain=0)
+        with eng.Chain(3, 40, 2, 'undirected', seed=5, chain_id=0) as c:
+            c.upload_network(Y); c.set_positions(X); c.set_intercepts([0.6])
+            c.set_samplers(eng.SamplerGrid(3, 40, 0.15, tune=None))
+            c.set_prior_mixture(mu, sigma, 0.8, z)
+            c.hdp_configure(hp, beta, w, 0.5, 2.0)
+            c.hdp_trace_alloc(3)
+            for it in (1, 2):
+                c.hdp_run(it, 1)
+                want = oc.iteration(it)
+                tr = c.hdp_trace_read(it, 1, positions=False)
+                assert 0.0 <= tr['lambdas'][0, 0] <= 1.0
+                np.testing.assert_allclose(tr['lambdas'][0, 0], oc.lmbda[0], rtol=1e-8, atol=1e-12)
+                np.testing.assert_allclose(tr['logps'][0], want, rtol=1e-9)
+
+
+def test_facade_device_and_host_loops_agree_in_distribution(eng):
+    """the same small network through both loops of DynamicNetworkHDPLPCM: posterior means of
+    the intercept, the blending coefficient and the occupied clusters agree within MC error"""
+    Y = _case(3, 40, 4, 21)[0]
+    res = {}
+    for loop in ('device', 'host'):
+        got = []
+        for seed in range(4):
+            m = eng.DynamicNetworkHDPLPCM(n_iter=300, tune=150, burn=150, n_components=4,
+                                          random_state=seed, chain_id=seed, hdp_loop=loop).fit(Y)
+            assert m.loop_kind_ == ('device-resident' if loop == 'device' else 'host-driven')
+            keep = slice(300, None)
+            nclu = np.array([[len(np.unique(z[t])) for t in range(3)] for z in m.zs_[keep]]).mean()
+            got.append([m.intercepts_[keep, 0].mean(), m.lambdas_[keep, 0].mean(), nclu,
+                        m.logps_[keep].mean()])
+            assert np.isfinite(m.logps_).all() and (m.sigmas_[1:] > 0).all()
+            np.testing.assert_allclose(m.weights_[-1].sum(-1)[1:], 1.0, rtol=1e-12)
+            np.testing.assert_allclose(m.betas_[-1].sum(), 1.0, rtol=1e-12)
+        res[loop] = np.array(got)
+    for k, slack in ((0, 0.05), (1, 0.03), (2, 0.15), (3, 0.02)):
+        a, b = res['device'][:, k], res['host'][:, k]
+        se = np.sqrt(a.var(ddof=1) / 4 + b.var(ddof=1) / 4)
+        assert abs(a.mean() - b.mean()) < 4 * se + slack * abs(b.mean()), (k, a, b)

@@ -188,17 +188,19 @@ def test_monks_directed_posterior_within_mc_error_of_reference(eng):
     assert abs(s_got.mean() - s_ref.mean()) < 4 * se + 0.03
 
 
-def test_hdp_lpcm_posterior_within_mc_error_of_reference(eng):
+@pytest.mark.parametrize('loop', ['device', 'host'])
+def test_hdp_lpcm_posterior_within_mc_error_of_reference(eng, loop):
     """DynamicNetworkHDPLPCM on the small synthetic network of the HDP golden
     trace (T=3, N=24, K=4): posterior means of the intercept, the blending
-    coefficient and the number of occupied clusters against 5 reference seeds"""
+    coefficient and the number of occupied clusters against 5 reference seeds - with the
+    device-resident loop (Philox draws) and with the host-driven one (MT19937 draws)"""
     env = load_golden('more_envelopes.npz')
     cols = list(env['hdp_columns'])
     Y = load_golden('hdp_trace.npz')['Y']
     got = []
     for seed in range(5):
         m = eng.DynamicNetworkHDPLPCM(n_iter=300, tune=150, burn=150, n_components=4,
-                                      random_state=seed, chain_id=seed).fit(Y)
+                                      random_state=seed, chain_id=seed, hdp_loop=loop).fit(Y)
         keep = slice(300, None)
         nclu = np.array([[len(np.unique(z[t])) for t in range(z.shape[0])]
                          for z in m.zs_[keep]]).mean()
