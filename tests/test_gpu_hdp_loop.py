@@ -67,8 +67,9 @@ def _run_both(eng, T, N, K, seed, n_it, tune=None, algo=0, a0=True, c0=True, lmb
     hp = _hyper(a0, c0)
     og = orc.SamplerGrid(T, N, 0.15, tune=tune, tune_interval=2)
     isamp = orc.ScalarMetropolis(0.1, tune, 100)
-    oc = hlo.HdpChain(Y, X, [b0], mu, sigma, z, beta, w, lmbda, hp.copy(), og, ip, var, isamp,
-                      seed=77 + seed, chain=2)
+    # (the oracle updates its arrays in place: hand it copies)
+    oc = hlo.HdpChain(Y, X.copy(), [b0], mu.copy(), sigma.copy(), z.copy(), beta.copy(), w.copy(),
+                      lmbda, hp.copy(), og, ip, var, isamp, seed=77 + seed, chain=2)
     out = []
     with eng.Chain(T, N, 2, 'undirected', seed=77 + seed, chain_id=2) as c:
         c.upload_network(Y); c.set_positions(X); c.set_intercepts([b0])
@@ -148,7 +149,8 @@ def test_truncated_normal_far_tails(eng):
         hp = _hyper()
         hp.lambda_prior, hp.lambda_variance_prior = lp, lv
         og = orc.SamplerGrid(3, 40, 0.15, tune=None)
-        oc = hlo.HdpChain(Y, X, [0.6], mu, sigma, z, beta, w, 0.8, hp.copy(), og, 0.5, 2.0,
+        oc = hlo.HdpChain(Y, X.copy(), [0.6], mu.copy(), sigma.copy(), z.copy(), beta.copy(),
+                          w.copy(), 0.8, hp.copy(), og, 0.5, 2.0,
                           orc.ScalarMetropolis(0.1, None, 100), seed=5, chain=0)
         with eng.Chain(3, 40, 2, 'undirected', seed=5, chain_id=0) as c:
             c.upload_network(Y); c.set_positions(X); c.set_intercepts([0.6])
