@@ -1183,7 +1183,7 @@ int dlsm_sample_labels(dlsm_chain *h, uint32_t iter, const double *w, int64_t *z
         });
         hipLaunchKernelGGL(k_label_counts, dim3(T), dim3(256),
                            (size_t)(K * K + K) * sizeof(int32_t), h->stream, h->z, N, K,
-                           (int32_t *)h->lab_n, (int32_t *)h->lab_nk);
+                           (int32_t *)h->lab_n, (int32_t *)h->lab_nk, (uint8_t *)nullptr);
     }
     HIPCHK(h, hipGetLastError());
     // labels and counts come back as int32 in one batch: into the pinned buffer behind one

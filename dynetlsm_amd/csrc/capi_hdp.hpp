@@ -15,6 +15,7 @@ HdpLoopBuf hdp_loop_buf(dlsm_chain *h) {
     b.Q = p; p += T * K;
     b.L = p; p += 2 * T * K;
     b.LP = p; p += T * K;
+    b.LPD = p; p += T * K;
     b.m = (int32_t *)p;
     b.wover = b.m + T * K * K;
     b.w = h->lab_w; b.n = h->lab_n; b.nk = h->lab_nk;
@@ -25,7 +26,7 @@ HdpLoopBuf hdp_loop_buf(dlsm_chain *h) {
 
 size_t hdp_loop_buf_doubles(const dlsm_chain *h) {
     const size_t T = h->T, K = h->K, D = h->D;
-    return 2 * K + T * K * D + 4 * T * K + (T * K * K + T * K + 1) / 2 + 2;
+    return 2 * K + T * K * D + 5 * T * K + (T * K * K + T * K + 1) / 2 + 2;
 }
 
 void hdp_free_trace(dlsm_chain *h) {
@@ -62,12 +63,10 @@ int enqueue_hdp_iteration(dlsm_chain *h, int it) {
         hipLaunchKernelGGL(kern, dim3((N + LAB_WAVES - 1) / LAB_WAVES), dim3(64 * LAB_WAVES), lds,
                            h->stream, v, h->lab_w, (uint32_t)it, h->z);
         hipLaunchKernelGGL(k_label_counts, dim3(T), dim3(256), (size_t)(K * K + K) * sizeof(int32_t),
-                           h->stream, h->z, N, K, (int32_t *)h->lab_n, (int32_t *)h->lab_nk);
+                           h->stream, h->z, N, K, (int32_t *)h->lab_n, (int32_t *)h->lab_nk,
+                           h->htr_z + (size_t)it * T * N);
     }
     ProfScope ps(h, DLSM_K_HDP_TAIL);
-    const long tn = (long)T * N;
-    hipLaunchKernelGGL(k_hdp_trace_labels, dim3((unsigned)((tn + 255) / 256)), dim3(256), 0, h->stream,
-                       h->z, tn, h->htr_z + (size_t)it * tn);
     hipLaunchKernelGGL(k_hdp_tables, dim3((T * K * K + HT_WAVES - 1) / HT_WAVES), dim3(64 * HT_WAVES), 0,
                        h->stream, v, hb, h->hdp, ir);
     hipLaunchKernelGGL(k_hdp_globals, dim3(1), dim3(HG_THREADS), 0, h->stream, v, hb, h->hdp, ir);
@@ -83,6 +82,7 @@ int enqueue_hdp_iteration(dlsm_chain *h, int it) {
     hipLaunchKernelGGL((k_hdp_label_sums<DD, HDP_SUMS_LAMBDA>), grid, block, 0, h->stream, v, hp, hb.L);
     hipLaunchKernelGGL(k_hdp_hypers, dim3(1), dim3(HH_THREADS), 0, h->stream, v, hb, h->hdp, ir);
     hipLaunchKernelGGL((k_hdp_label_sums<DD, HDP_SUMS_LOGP>), grid, block, 0, h->stream, v, hp, hb.LP);
+    hipLaunchKernelGGL(k_hdp_dirichlet_rows, grid, dim3(64), 0, h->stream, v, hb, h->hdp, hb.LPD);
     HdpTrace tr{h->trace_ic, h->trace_logp, h->htr_mu, h->htr_sigma, h->htr_beta, h->htr_w,
                 h->htr_lambda, h->htr_hyper};
     hipLaunchKernelGGL((k_hdp_finalize<DD>), dim3(1), dim3(HF_THREADS), 0, h->stream, v, hb, h->hdp,

@@ -15,7 +15,7 @@
 //   mu, sigma, lambda, hyper-parameters, concentration parameters: see each kernel.
 // Launch order per iteration (capi_hdp.hpp): k_hdp_intercept, [labels], k_hdp_tables,
 // k_hdp_globals, k_hdp_weights, sums<MEAN>, k_hdp_draw_mu, sums<RESIDUAL>, k_hdp_draw_sigma,
-// sums<LAMBDA>, k_hdp_hypers, sums<LOGP>, k_hdp_finalize.
+// sums<LAMBDA>, k_hdp_hypers, sums<LOGP>, k_hdp_dirichlet_rows, k_hdp_finalize.
 #pragma once
 #include "chain.hpp"
 #include "device_common.hpp"
@@ -152,6 +152,7 @@ struct HdpLoopBuf {
     double *Q;           // [T][K]     stage RESIDUAL
     double *L;           // [T][K][2]  stage LAMBDA
     double *LP;          // [T][K]     stage LOGP
+    double *LPD;         // [T][K]     Dirichlet log-densities of the rows (k_hdp_dirichlet_rows)
     double *mu, *sigma;  // the mixture prior's (chain->mu, chain->sigma)
     int K;
 };
@@ -366,39 +367,31 @@ __global__ __launch_bounds__(64) void k_hdp_draw_sigma(ChainView c, HdpLoopBuf h
     hb.sigma[k] = 1.0 / (hdp_gamma(g, HK_SIGMA, (uint32_t)k, ak) * (1.0 / bk));
 }
 
-// Escobar & West (1995) auxiliary-variable update of a concentration parameter
-// (sample_concentration.py:6-21); one thread
-__device__ inline double hdp_concentration(const HdpRng &g, uint32_t kind, double alpha,
-                                           double n_clusters, double n_samples, double shape0,
-                                           double rate0) {
-    const double eta = hdp_beta(g, kind, 0, alpha + 1.0, n_samples);
-    double m_shape = shape0 + n_clusters - 1.0;
-    const double m_scale = rate0 - log(eta);
-    const double log_odds = (m_shape / m_scale) * (1.0 / n_samples);
-    double u0, u1;
-    g.u2(kind, 2, 0, u0, u1);
-    if (u0 <= log_odds / (1.0 + log_odds)) m_shape += 1.0;
-    return hdp_gamma(g, kind, 3, m_shape) * (1.0 / m_scale);
-}
-
 // ---- blending coefficient, variance hyper-parameters, concentration parameters: one workgroup ------
-// (hdp_lpcm.py:941-1023)
+// (hdp_lpcm.py:941-1023).  A float64 gamma variate costs a lone lane ~2 us of dependent
+// transcendental latency, so the draws that do not depend on each other run side by side: the
+// (t, j) grid of the alpha + kappa update over all threads, eight gamma variates on the lanes of
+// the last wavefront and the truncated-normal quantile on another one at the same time, then the
+// three gamma variates whose shapes depend on those (Escobar & West's mixture indicator, the
+// alpha + kappa shape) on three lanes.  Counters are fixed per draw, so the values do not depend
+// on which lane makes them.
 constexpr int HH_THREADS = 256;
 __global__ __launch_bounds__(HH_THREADS) void k_hdp_hypers(ChainView c, HdpLoopBuf hb,
                                                            HdpDeviceState *hs, IterRef ir) {
     __shared__ double red[3][HH_THREADS / 64];
-    const int K = hb.K, T = c.T, D = c.D, tid = threadIdx.x;
+    __shared__ double sB[8], sC[3], sLam;
+    const int K = hb.K, T = c.T, D = c.D, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const HdpRng g = hdp_rng(c, ir.get());
-    // sums of the lambda update over the cells (t >= 1, k) with members
+    // sums of the lambda update over the cells (t >= 1, k) with members (hdp_lpcm.py:941-950)
     double a0 = 0.0, a1 = 0.0;
     for (int q = K + tid; q < T * K; q += HH_THREADS)
         if (hb.nk[q] > 0) { a0 += hb.L[2 * (size_t)q]; a1 += hb.L[2 * (size_t)q + 1]; }
     const double ml_sum = block_sum_all<HH_THREADS / 64>(a0, red[0], tid);
     const double sl_sum = block_sum_all<HH_THREADS / 64>(a1, red[1], tid);
-    __syncthreads();
     // alpha + kappa: s ~ Bernoulli(n. / (n. + alpha + kappa)), r ~ Beta(alpha + kappa + 1, n.) for
     // every (t >= 1, j) with n.[t, j] = sum_k n[t, j, k] > 0 (hdp_lpcm.py:999-1011)
     const double ak0 = hs->alpha + hs->kappa;
+    const double nsucc = hs->override_total;
     double s_sum = 0.0, logr_sum = 0.0, mval_sum = 0.0;
     for (int q = tid; q < (T - 1) * K; q += HH_THREADS) {
         const int t = q / K + 1, j = q - (t - 1) * K;
@@ -414,22 +407,56 @@ __global__ __launch_bounds__(HH_THREADS) void k_hdp_hypers(ChainView c, HdpLoopB
         logr_sum += log(hdp_beta(g, HK_AK_R, (uint32_t)q, ak0 + 1.0, (double)ndot));
         mval_sum += (double)mrow;
     }
+    if (wave == HH_THREADS / 64 - 1 && lane < 8) {
+        // gamma variates with known shapes: the two Beta draws of Escobar & West's eta
+        // (sample_concentration.py:11), the two variance hyper-parameters (hdp_lpcm.py:957-972),
+        // rho's Beta draw (:1017-1020)
+        uint32_t kind = HK_CONC_GAMMA, idx = (uint32_t)(lane & 1);
+        double shape = lane == 0 ? hs->gamma + 1.0 : hs->mbar_total;
+        if (lane == 2 || lane == 3) { kind = HK_CONC_ALPHA0; shape = lane == 2 ? hs->alpha_init + 1.0 : (double)c.N; }
+        if (lane == 4) { kind = HK_MVP; idx = 0; shape = 0.5 * (hs->a0 + K); }
+        if (lane == 5) { kind = HK_B; idx = 0; shape = 0.5 * (hs->c0 + K * hs->a); }
+        if (lane == 6 || lane == 7) { kind = HK_RHO; shape = lane == 6 ? 8.0 + nsucc : hs->m_rest_total - nsucc + 2.0; }
+        sB[lane] = hdp_gamma(g, kind, idx, shape);
+    }
+    if (wave == HH_THREADS / 64 - 2 && lane == 0) {
+        // blending coefficient (hdp_lpcm.py:951-954)
+        double sl = 1.0 / hs->lambda_var + sl_sum;
+        sl = 1.0 / sl;
+        double ml = ml_sum + hs->lambda_prior / hs->lambda_var;
+        ml *= sl;
+        double u0, u1;
+        g.u2(HK_LAMBDA, 0, 0, u0, u1);
+        sLam = dev_truncnorm_quantile(u0, ml, sl);
+    }
     s_sum = block_sum_all<HH_THREADS / 64>(s_sum, red[2], tid);
     __syncthreads();
     logr_sum = block_sum_all<HH_THREADS / 64>(logr_sum, red[0], tid);
     mval_sum = block_sum_all<HH_THREADS / 64>(mval_sum, red[1], tid);
-    if (tid != 0) return;
-    // blending coefficient (hdp_lpcm.py:941-954)
-    double sl = 1.0 / hs->lambda_var + sl_sum;
-    sl = 1.0 / sl;
-    double ml = ml_sum + hs->lambda_prior / hs->lambda_var;
-    ml *= sl;
-    {
-        double u0, u1;
-        g.u2(HK_LAMBDA, 0, 0, u0, u1);
-        hs->lmbda = dev_truncnorm_quantile(u0, ml, sl);
+    // second round: Escobar & West's gamma draws (sample_concentration.py:13-21) and alpha + kappa
+    double m_scale = 1.0;
+    if (tid < 3) {
+        uint32_t kind = HK_AK, idx = 0;
+        double shape = hs->ak_shape + mval_sum - s_sum;
+        m_scale = hs->ak_rate - logr_sum;
+        if (tid < 2) {
+            kind = tid == 0 ? HK_CONC_GAMMA : HK_CONC_ALPHA0;
+            idx = 3;
+            const double eta = sB[2 * tid] / (sB[2 * tid] + sB[2 * tid + 1]);
+            const double n_clusters = tid == 0 ? hs->mbar_positive : hs->m00_total;
+            const double n_samples = tid == 0 ? hs->mbar_total : (double)c.N;
+            shape = (tid == 0 ? hs->gamma_shape : hs->alpha0_shape) + n_clusters - 1.0;
+            m_scale = (tid == 0 ? hs->gamma_rate : hs->alpha0_rate) - log(eta);
+            const double log_odds = (shape / m_scale) * (1.0 / n_samples);
+            double u0, u1;
+            g.u2(kind, 2, 0, u0, u1);
+            if (u0 <= log_odds / (1.0 + log_odds)) shape += 1.0;
+        }
+        sC[tid] = hdp_gamma(g, kind, idx, shape) * (1.0 / m_scale);
     }
-    // variance hyper-parameters (hdp_lpcm.py:957-972)
+    __syncthreads();
+    if (tid != 0) return;
+    hs->lmbda = sLam;
     if (hs->has_a0) {
         double b = 0.5 * hs->b0;
         for (int k = 0; k < K; ++k) {
@@ -437,28 +464,57 @@ __global__ __launch_bounds__(HH_THREADS) void k_hdp_hypers(ChainView c, HdpLoopB
             for (int d = 0; d < D; ++d) ss += hb.mu[(size_t)k * D + d] * hb.mu[(size_t)k * D + d];
             b += 0.5 * ss;
         }
-        const double a = 0.5 * (hs->a0 + K);
-        hs->mvp = 1.0 / (hdp_gamma(g, HK_MVP, 0, a) * (1.0 / b));
+        hs->mvp = 1.0 / (sB[4] * (1.0 / b));
     }
     if (hs->has_c0) {
         double scale = 0.5 * hs->d0;
         for (int k = 0; k < K; ++k) scale += 0.5 * (1.0 / hb.sigma[k]);
-        const double shape = 0.5 * (hs->c0 + K * hs->a);
-        hs->b = hdp_gamma(g, HK_B, 0, shape) * (1.0 / scale);
+        hs->b = sB[5] * (1.0 / scale);
     }
-    // concentration parameters (hdp_lpcm.py:977-996)
-    hs->gamma = hdp_concentration(g, HK_CONC_GAMMA, hs->gamma, hs->mbar_positive, hs->mbar_total,
-                                  hs->gamma_shape, hs->gamma_rate);
-    hs->alpha_init = hdp_concentration(g, HK_CONC_ALPHA0, hs->alpha_init, hs->m00_total,
-                                       (double)c.N, hs->alpha0_shape, hs->alpha0_rate);
-    // alpha + kappa and rho (hdp_lpcm.py:1009-1023)
-    const double shape = hs->ak_shape + mval_sum - s_sum;
-    const double rate = hs->ak_rate - logr_sum;
-    const double ak = hdp_gamma(g, HK_AK, 0, shape) * (1.0 / rate);
-    const double nsucc = hs->override_total;
-    const double rho = hdp_beta(g, HK_RHO, 0, 8.0 + nsucc, hs->m_rest_total - nsucc + 2.0);
+    hs->gamma = sC[0];
+    hs->alpha_init = sC[1];
+    const double ak = sC[2];
+    const double rho = sB[6] / (sB[6] + sB[7]);
     hs->kappa = ak * rho;
     hs->alpha = ak - hs->kappa;
+}
+
+// ---- Dirichlet log-densities of the log-posterior (hdp_lpcm.py:1193-1203), spread over the
+// workgroups of the LOGP label sums' grid: workgroup (k, t >= 1) takes row (t, j = k) of the
+// transition matrices, workgroup (0, 0) the two rows at t = 0 (beta and w0).
+// distributions.py:95-100: alphas and x are clipped at the smallest normal number.
+__device__ __forceinline__ double dirichlet_term(double al, double x) {
+    if (al <= 0.0) al = HDP_SMALL_EPS;
+    if (x <= 0.0) x = HDP_SMALL_EPS;
+    return (al - 1.0 == 0.0 ? 0.0 : (al - 1.0) * log(x)) - lgamma(al);
+}
+__global__ __launch_bounds__(64) void k_hdp_dirichlet_rows(ChainView c, HdpLoopBuf hb,
+                                                           const HdpDeviceState *hs,
+                                                           double *__restrict__ out) {
+    const int K = hb.K, j = blockIdx.x, t = blockIdx.y, lane = threadIdx.x;
+    double total = 0.0;
+    if (t >= 1) {
+        double al = 0.0, v = 0.0;
+        if (lane < K) {
+            al = hs->alpha * hb.beta[lane] + (j == lane ? hs->kappa : 0.0);
+            if (al <= 0.0) al = HDP_SMALL_EPS;
+            v = dirichlet_term(al, hb.w[((size_t)t * K + j) * K + lane]);
+        }
+        total = lgamma(wave_sum_all(al)) + wave_sum_all(v);
+    } else if (j == 0) {
+        double al0 = 0.0, al1 = 0.0, v0 = 0.0, v1 = 0.0;
+        if (lane < K) {
+            al0 = hs->gamma / K;
+            al1 = hs->alpha_init * hb.beta[lane];
+            if (al0 <= 0.0) al0 = HDP_SMALL_EPS;
+            if (al1 <= 0.0) al1 = HDP_SMALL_EPS;
+            v0 = dirichlet_term(al0, hb.beta[lane]);
+            v1 = dirichlet_term(al1, hb.w[lane]);
+        }
+        total = (lgamma(wave_sum_all(al0)) + wave_sum_all(v0)) +
+                (lgamma(wave_sum_all(al1)) + wave_sum_all(v1));
+    }
+    if (lane == 0) out[(size_t)t * K + j] = total;
 }
 
 // ---- log-posterior trace (hdp_lpcm.py:1188-1280) and the sample's trace rows: one workgroup -----------
@@ -471,30 +527,10 @@ __global__ __launch_bounds__(HF_THREADS) void k_hdp_finalize(ChainView c, HdpLoo
     __shared__ double red[2][HF_THREADS / 64];
     const int K = hb.K, T = c.T, tid = threadIdx.x;
     const int it = (int)ir.get();
-    const double alpha = hs->alpha, kappa = hs->kappa;
-    // Dirichlet log-densities of the T - 1 x K transition rows (distributions.py:95-100: alphas
-    // and x clipped at the smallest normal number) and the node terms of the label sums
+    // node terms of the label sums + the Dirichlet rows
     double acc = 0.0;
-    for (int q = tid; q < (T - 1) * K * K; q += HF_THREADS) {
-        const int r = q / K, k = q - r * K, j = r % K;
-        double al = alpha * hb.beta[k] + (j == k ? kappa : 0.0);
-        if (al <= 0.0) al = HDP_SMALL_EPS;
-        double x = hb.w[(size_t)K * K + q];
-        if (x <= 0.0) x = HDP_SMALL_EPS;
-        acc += (al - 1.0 == 0.0 ? 0.0 : (al - 1.0) * log(x)) - lgamma(al);
-    }
-    for (int r = tid; r < (T - 1) * K; r += HF_THREADS) {
-        const int j = r % K;
-        double tot = 0.0;
-        for (int k = 0; k < K; ++k) {
-            double al = alpha * hb.beta[k] + (j == k ? kappa : 0.0);
-            if (al <= 0.0) al = HDP_SMALL_EPS;
-            tot += al;
-        }
-        acc += lgamma(tot);
-    }
     for (int q = tid; q < T * K; q += HF_THREADS)
-        if (hb.nk[q] > 0) acc += hb.LP[q];
+        acc += (hb.nk[q] > 0 ? hb.LP[q] : 0.0) + hb.LPD[q];
     const double body = block_sum_all<HF_THREADS / 64>(acc, red[0], tid);
     // the trace rows of this sample
     for (int q = tid; q < K * D; q += HF_THREADS) tr.mu[(size_t)it * K * D + q] = hb.mu[q];
@@ -505,22 +541,6 @@ __global__ __launch_bounds__(HF_THREADS) void k_hdp_finalize(ChainView c, HdpLoo
     for (int q = tid; q < T * K * K; q += HF_THREADS) tr.w[(size_t)it * T * K * K + q] = hb.w[q];
     if (tid != 0) return;
     double lp = body + hs->ll;
-    {   // beta ~ Dirichlet(gamma / K) and w0 ~ Dirichlet(alpha_init beta)
-        double al0 = hs->gamma / K, tot0 = 0.0, tot1 = 0.0, s0 = 0.0, s1 = 0.0;
-        if (al0 <= 0.0) al0 = HDP_SMALL_EPS;
-        for (int k = 0; k < K; ++k) {
-            double bk = hb.beta[k];
-            double al1 = hs->alpha_init * bk;
-            if (al1 <= 0.0) al1 = HDP_SMALL_EPS;
-            if (bk <= 0.0) bk = HDP_SMALL_EPS;
-            double x1 = hb.w[k];
-            if (x1 <= 0.0) x1 = HDP_SMALL_EPS;
-            tot0 += al0; tot1 += al1;
-            s0 += (al0 - 1.0 == 0.0 ? 0.0 : (al0 - 1.0) * log(bk)) - lgamma(al0);
-            s1 += (al1 - 1.0 == 0.0 ? 0.0 : (al1 - 1.0) * log(x1)) - lgamma(al1);
-        }
-        lp += lgamma(tot0) + s0 + lgamma(tot1) + s1;
-    }
     {   // intercept prior, cluster means, blending coefficient, hyper-priors
         const double b = c.intercept[0], diff = b - lsm->intercept_prior[0];
         lp -= 0.5 * (diff * diff) / lsm->intercept_var;

@@ -136,9 +136,12 @@ __global__ __launch_bounds__(64 * LAB_WAVES) void k_sample_labels(
 // The counts the conjugate updates need (sample_labels.py:176-188): n[0][0][k] initial labels,
 // n[t][j][k] transitions j -> k into time t, nk[t][k] labels in use.  One workgroup per time
 // step, histogram in LDS (same-address global atomics from 2000 wavefronts cost ~170 ns each).
+// `trace_row` (may be NULL): the labels are also filed as bytes, [T][N], the device-resident
+// HDP-LPCM loop's trace row of this sample.
 __global__ __launch_bounds__(256) void k_label_counts(const int32_t *__restrict__ z, int N, int K,
                                                       int32_t *__restrict__ n_cnt,
-                                                      int32_t *__restrict__ nk_cnt) {
+                                                      int32_t *__restrict__ nk_cnt,
+                                                      uint8_t *__restrict__ trace_row) {
     extern __shared__ int32_t hist[];         // K * K + K
     const int t = blockIdx.x;
     for (int q = threadIdx.x; q < K * K + K; q += 256) hist[q] = 0;
@@ -148,6 +151,7 @@ __global__ __launch_bounds__(256) void k_label_counts(const int32_t *__restrict_
         const int zp = t == 0 ? 0 : z[(size_t)(t - 1) * N + i];
         atomicAdd(&hist[zp * K + zt], 1);
         atomicAdd(&hist[K * K + zt], 1);
+        if (trace_row) trace_row[(size_t)t * N + i] = (uint8_t)zt;
     }
     __syncthreads();
     for (int q = threadIdx.x; q < K * K; q += 256) n_cnt[(size_t)t * K * K + q] = hist[q];
