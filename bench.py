@@ -64,6 +64,9 @@ def parse(argv=None):
     ap.add_argument('--D', type=int, default=2)
     ap.add_argument('--K', type=int, default=20, help='n_components of the HDP-LPCM')
     ap.add_argument('--density', type=float, default=0.03)
+    ap.add_argument('--chains-per-gpu', type=int, default=1,
+                    help='independent chains per GPU, each on its own handle and stream, '
+                         'enqueued by its own host thread (aggregate throughput)')
     ap.add_argument('--algo', type=int, default=0, help='sweep algorithm (0 auto)')
     ap.add_argument('--profile-steps', type=int, default=20)
     ap.add_argument('--cpu-iters', type=int, default=8,
@@ -121,6 +124,40 @@ def launch_ranks(args):
 # ------------------------------------------------------------------------------------
 # workloads
 # ------------------------------------------------------------------------------------
+def in_threads(calls):
+    """run the zero-argument callables side by side, one host thread each (the engine's
+    enqueue calls are C calls that release the GIL); re-raises the first failure"""
+    if len(calls) == 1:
+        calls[0]()
+        return
+    import threading
+    errs = []
+
+    def wrap(f):
+        try:
+            f()
+        except BaseException as e:       # noqa: B902
+            errs.append(e)
+    ths = [threading.Thread(target=wrap, args=(f,)) for f in calls]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    if errs:
+        raise errs[0]
+
+
+def share_network(src, others):
+    """the packed network of chain `src` into the other chains of this GPU (device to device)"""
+    if not others:
+        return
+    import torch
+    n = src.network_packed_words()
+    buf = torch.empty(n, dtype=torch.int32, device='cuda')
+    src.get_network_packed(buf.data_ptr(), n)
+    for c in others:
+        c.set_network_packed(buf.data_ptr(), n)
+
 class LsmWorkload(object):
     """configs[1]: DynamicNetworkLSM, undirected, device-resident loop (dlsm_lsm_run)"""
     name = 'lsm'
@@ -132,38 +169,44 @@ class LsmWorkload(object):
         T, N, D = args.T, args.N, args.D
         rank = group.rank
         K, W, P = args.steps, args.warmup, args.profile_steps
-        self.chain = chain = Chain(T, N, D, 'undirected', seed=20240229, chain_id=rank,
-                                   device=local_rank)
+        C = args.chains_per_gpu
+        self.chains = [Chain(T, N, D, 'undirected', seed=20240229, chain_id=rank * C + c,
+                             device=local_rank) for c in range(C)]
+        self.chain = chain = self.chains[0]
         # the network: built, uploaded and packed on rank 0; the packed words are broadcast
         net = synthetic_lsm_network(T, N, D, density=args.density, seed=0) if rank == 0 else None
         self.net = net
         if rank == 0:
             chain.upload_network(net['Y'])
         group.broadcast_chain_network(chain)
+        share_network(chain, self.chains[1:])
         self.X_init = group.broadcast_array(net['X_init'] if rank == 0 else np.zeros((T, N, D)))
         self.b_init = float(group.broadcast_array(
             np.array([net['intercept'], net['Y'].mean()]) if rank == 0 else np.zeros(2))[0])
         self.density = float(net['Y'].mean()) if rank == 0 else None
-        chain.set_positions(self.X_init)
-        chain.set_intercepts([self.b_init])
-        chain.set_prior_random_walk(2.0, 0.1)
-        chain.set_samplers(SamplerGrid(T, N, step_size=0.1, tune=None))
-        chain.lsm_configure([self.b_init], 2.0, step_size_intercept=0.1, tune=None,
-                            n_iter_procrustes=0, sweep_algo=args.algo)
-        chain.trace_alloc(1 + W + K + P, logp0=0.0)
+        for ch in self.chains:
+            ch.set_positions(self.X_init)
+            ch.set_intercepts([self.b_init])
+            ch.set_prior_random_walk(2.0, 0.1)
+            ch.set_samplers(SamplerGrid(T, N, step_size=0.1, tune=None))
+            ch.lsm_configure([self.b_init], 2.0, step_size_intercept=0.1, tune=None,
+                             n_iter_procrustes=0, sweep_algo=args.algo)
+            ch.trace_alloc(1 + W + K + P, logp0=0.0)
         self.next_it = 1
 
     def run(self, count):
-        self.chain.lsm_run(self.next_it, count, procrustes_ref=0)
+        it = self.next_it
+        in_threads([(lambda ch=ch: ch.lsm_run(it, count, procrustes_ref=0)) for ch in self.chains])
         self.next_it += count
 
     def synchronize(self):
-        self.chain.synchronize()
+        for ch in self.chains:
+            ch.synchronize()
 
     def workload(self):
         a = self.args
-        return ('DynamicNetworkLSM synthetic undirected T=%d N=%d d=%d, 1 chain per GPU'
-                % (a.T, a.N, a.D))
+        return ('DynamicNetworkLSM synthetic undirected T=%d N=%d d=%d, %d chain%s per GPU'
+                % (a.T, a.N, a.D, a.chains_per_gpu, '' if a.chains_per_gpu == 1 else 's'))
 
     def metric(self):
         a = self.args
@@ -175,7 +218,8 @@ class LsmWorkload(object):
         a, chain = self.args, self.chain
         T, N, D, P = a.T, a.N, a.D, a.profile_steps
         chain.profile_enable(True)
-        self.run(P)
+        chain.lsm_run(self.next_it, P, procrustes_ref=0)      # the first chain alone
+        self.next_it += P
         chain.synchronize()
         ms_sw, n_sw = chain.profile_read(_lib.K_SWEEP)
         ms_ll, n_ll = chain.profile_read(_lib.K_LOGLIK)
@@ -191,8 +235,11 @@ class LsmWorkload(object):
 
     def results(self, first, count):
         """per-chain results for the final gather: posterior-mean positions, traces"""
-        Xs, ics, lps = self.chain.trace_read(first, count, positions=True)
-        return dict(X_mean=Xs.mean(axis=0), logps=lps, intercepts=ics)
+        out = []
+        for ch in self.chains:
+            Xs, ics, lps = ch.trace_read(first, count, positions=True)
+            out.append(dict(X_mean=Xs.mean(axis=0), logps=lps, intercepts=ics))
+        return {k: np.stack([o[k] for o in out]) for k in out[0]}
 
     def acceptance(self):
         from dynetlsm_amd import SamplerGrid
@@ -231,7 +278,8 @@ class LsmWorkload(object):
         return cpu
 
     def close(self):
-        self.chain.close()
+        for ch in self.chains:
+            ch.close()
 
 
 def cpu_chains_in_processes(a, procs):
@@ -365,6 +413,7 @@ class HdpWorkload(object):
         T, N, D, Kc = args.T, args.N, args.D, args.K
         rank = group.rank
         K, W, P = args.steps, args.warmup, args.profile_steps
+        C = args.chains_per_gpu
         net = synthetic_hdp_network(T, N, D, density=args.density, seed=0) if rank == 0 else None
         self.net = net
         # starting values: the truth plus noise (positions), true labels and centres
@@ -388,36 +437,45 @@ class HdpWorkload(object):
         rs = np.random.RandomState(5)
         mu0[nc:] = 3.0 * rs.randn(Kc - nc, D)
         sg0 = np.full(Kc, float(sg_t.mean())); sg0[:nc] = sg_t
-        self.model = m = DynamicNetworkHDPLPCM(
-            n_iter=1 + W + K + P, tune=None, burn=None, n_components=Kc, n_features=D,
-            random_state=1 + rank, device=local_rank, chain_id=rank, sweep_algo=args.algo,
-            selection_type='map')
-        # the facade wants a network argument: rank 0 has the real one; the others get the
-        # packed words from rank 0's chain and only need the shape on the host
-        shell = {}
-
-        def network_from(chain):
-            shell['chain'] = chain
-            if rank == 0:
-                chain.upload_network(net['Y'])
-            group.broadcast_chain_network(chain)
+        # the facade wants a network argument: rank 0 has the real one; the other ranks (and
+        # the other chains of this GPU) get the packed words and only need the shape
         Yarg = net['Y'] if rank == 0 else np.zeros((T, N, N))
-        m.copy = False
-        m._prepare(Yarg, init=dict(X=X0, intercept=[b0], mu=mu0, sigma=sg0, z=z0),
-                   network_from=network_from)
+        self.models = []
+        for c in range(C):
+            m = DynamicNetworkHDPLPCM(
+                n_iter=1 + W + K + P, tune=None, burn=None, n_components=Kc, n_features=D,
+                random_state=1 + rank * C + c, device=local_rank, chain_id=rank * C + c,
+                sweep_algo=args.algo, selection_type='map')
+            first = self.models[0].chain_ if self.models else None
+
+            def network_from(chain, first=first):
+                if first is not None:
+                    share_network(first, [chain])
+                    return
+                if rank == 0:
+                    chain.upload_network(net['Y'])
+                group.broadcast_chain_network(chain)
+            m.copy = False
+            m._prepare(Yarg, init=dict(X=X0, intercept=[b0], mu=mu0, sigma=sg0, z=z0),
+                       network_from=network_from)
+            self.models.append(m)
+        self.model = self.models[0]
         self.next_it = 1
 
     def run(self, count):
-        self.model._run(self.next_it, count)
+        it = self.next_it
+        in_threads([(lambda m=m: m._run(it, count)) for m in self.models])
         self.next_it += count
 
     def synchronize(self):
-        self.model.chain_.synchronize()
+        for m in self.models:
+            m.chain_.synchronize()
 
     def workload(self):
         a = self.args
         return ('DynamicNetworkHDPLPCM synthetic undirected T=%d N=%d d=%d K_max=%d '
-                '(6 true clusters), 1 chain per GPU' % (a.T, a.N, a.D, a.K))
+                '(6 true clusters), %d chain%s per GPU'
+                % (a.T, a.N, a.D, a.K, a.chains_per_gpu, '' if a.chains_per_gpu == 1 else 's'))
 
     def metric(self):
         a = self.args
@@ -428,7 +486,8 @@ class HdpWorkload(object):
         a, chain = self.args, self.model.chain_
         P = a.profile_steps
         chain.profile_enable(True)
-        self.run(P)
+        self.model._run(self.next_it, P)                      # the first chain alone
+        self.next_it += P
         chain.synchronize()
         ms_sw, n_sw = chain.profile_read(_lib.K_SWEEP)
         ms_ll, n_ll = chain.profile_read(_lib.K_LOGLIK)
@@ -446,12 +505,15 @@ class HdpWorkload(object):
         return roofline, extra
 
     def results(self, first, count):
-        m = self.model
-        m._pull(first, count)
+        out = []
         sl = slice(first, first + count)
-        return dict(X_mean=m.Xs_[sl].mean(axis=0), logps=m.logps_[sl].copy(),
-                    intercepts=m.intercepts_[sl].copy(), lambdas=m.lambdas_[sl].copy(),
-                    n_clusters_used=np.array([float(len(np.unique(z))) for z in m.zs_[sl]]))
+        for m in self.models:
+            m._pull(first, count)
+            out.append(dict(X_mean=m.Xs_[sl].mean(axis=0), logps=m.logps_[sl].copy(),
+                            intercepts=m.intercepts_[sl].copy(), lambdas=m.lambdas_[sl].copy(),
+                            n_clusters_used=np.array([float(len(np.unique(z)))
+                                                      for z in m.zs_[sl]])))
+        return {k: np.stack([o[k] for o in out]) for k in out[0]}
 
     def acceptance(self):
         m = self.model
@@ -462,7 +524,8 @@ class HdpWorkload(object):
         return None
 
     def close(self):
-        self.model.chain_.close()
+        for m in self.models:
+            m.chain_.close()
 
 
 def measure(wl, args, group):
@@ -485,6 +548,8 @@ def measure(wl, args, group):
         roofline, extra = wl.profile()
     acc = wl.acceptance()
     gathered = group.gather_results(wl.results(1 + W, K))
+    # (ranks, chains per GPU, ...) -> (chains, ...)
+    gathered = {k: v.reshape((-1,) + v.shape[2:]) for k, v in gathered.items()}
     return elapsed, roofline, extra, acc, gathered
 
 
@@ -524,7 +589,8 @@ def run_rank(args):
         if rank == 0 and not args.no_cpu and args.cpu_iters > 0:
             cpu = wl.cpu_baseline()
         if rank == 0:
-            value = world * K / elapsed
+            C = args.chains_per_gpu
+            value = world * C * K / elapsed
             xm = gathered['X_mean']
             line = {
                 'metric': wl.metric(), 'value': round(value, 3), 'unit': 'Gibbs iterations/s',
@@ -532,7 +598,7 @@ def run_rank(args):
                 'ms_per_step': round(1e3 * elapsed / K, 4), 'higher_is_better': True,
                 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
                 'config': {'workload': wl.workload(), 'density': round(wl.density, 4),
-                           'chains': world,
+                           'chains': world * C, 'chains_per_gpu': C,
                            'sweep_algo': (wl.chain if name == 'lsm' else wl.model.chain_)
                            .resolve_sweep_algo(args.algo),
                            'mh_acceptance_rate': round(acc, 3),
@@ -543,7 +609,7 @@ def run_rank(args):
                     chain_summaries(gathered),
                 'gathered': {k: list(v.shape) for k, v in gathered.items()},
                 'X_mean_rms_between_chains': (round(float(np.sqrt(((xm - xm.mean(0)) ** 2).mean())), 5)
-                                              if world > 1 else 0.0)}
+                                              if world * C > 1 else 0.0)}
             if name == 'lsm':
                 line['config']['iteration'] = ('sweep + procrustes + centring + intercept MH + '
                                                'logp trace')
