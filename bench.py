@@ -15,9 +15,14 @@ one Gibbs iteration of DynamicNetworkHDPLPCM._fit (hdp_lpcm.py:823-1069), K_max 
 sweep with the AR-mixture prior, centring, intercept MH, label block update, the
 HDP's auxiliary / conjugate / hyper-parameter draws and the log-posterior trace.
 
+``--model cc`` (configs[3]): one step = one Gibbs iteration of the directed case-control
+DynamicNetworkLSM (T=5 N=10 000, 100 controls): sweep over the case-control partial
+likelihoods, centring, the two intercept steps and the radii step.
+
 ``--model all`` (the default) prints the LSM line as the headline - the metric of
-BASELINE.json - and attaches the HDP-LPCM measurement of the same run as
-``extra_configs`` (so that the N-GPU runs exercise configs[4] too).
+BASELINE.json - and attaches the HDP-LPCM and case-control measurements of the same run as
+``extra_configs`` (so that the N-GPU runs exercise configs[4] too).  ``--chains-per-gpu C``
+runs C independent chains per GPU, each on its own handle, stream and host thread.
 
 N > 1: when RANK is not set the process spawns the N ranks itself (it makes no GPU
 call before that), relays rank 0's JSON line and exits non-zero if a rank fails;
@@ -58,12 +63,15 @@ def parse(argv=None):
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=20)
-    ap.add_argument('--model', default='all', choices=['lsm', 'hdp', 'all'])
+    ap.add_argument('--model', default='all', choices=['lsm', 'hdp', 'cc', 'all'])
     ap.add_argument('--T', type=int, default=10)
     ap.add_argument('--N', type=int, default=2000)
     ap.add_argument('--D', type=int, default=2)
     ap.add_argument('--K', type=int, default=20, help='n_components of the HDP-LPCM')
     ap.add_argument('--density', type=float, default=0.03)
+    ap.add_argument('--cc-T', type=int, default=5, help='--model cc: time steps')
+    ap.add_argument('--cc-N', type=int, default=10000, help='--model cc: nodes')
+    ap.add_argument('--cc-controls', type=int, default=100, help='--model cc: n_control')
     ap.add_argument('--chains-per-gpu', type=int, default=1,
                     help='independent chains per GPU, each on its own handle and stream, '
                          'enqueued by its own host thread (aggregate throughput)')
@@ -528,6 +536,144 @@ class HdpWorkload(object):
             m.chain_.close()
 
 
+class CcWorkload(object):
+    """configs[3]: directed case-control DynamicNetworkLSM, T=5 N=10 000 d=2, n_control=100,
+    device-resident loop (dlsm_lsm_run: sweep, centring, two intercept steps and the radii
+    step around case-control log-likelihood passes); controls redrawn on the device every
+    n_resample_control = 100 iterations (case_control_likelihood.py:27-33).  The network is
+    given as edge tables (the dense tensor would be 4 GB)."""
+    name = 'cc'
+
+    def __init__(self, args, group, local_rank):
+        from dynetlsm_amd import Chain, SamplerGrid
+        from dynetlsm_amd.synthetic import synthetic_sparse_directed
+        self.args, self.group = args, group
+        T, N, C = args.cc_T, args.cc_N, args.cc_controls
+        self.T, self.N, self.C = T, N, C
+        rank = group.rank
+        K, W, P = args.steps, args.warmup, args.profile_steps
+        if rank == 0:
+            X, radii, degree, in_edges, out_edges = synthetic_sparse_directed(T, N, 20, 0)
+            shp = np.array([in_edges.shape[2], out_edges.shape[2]], dtype=np.float64)
+        else:
+            shp = np.zeros(2)
+        shp = group.broadcast_array(shp)
+        Din, Dout = int(shp[0]), int(shp[1])
+        if rank != 0:
+            X, radii = np.zeros((T, N, 2)), np.zeros(N)
+            degree = np.zeros((T, N, 2)); in_edges = np.zeros((T, N, Din))
+            out_edges = np.zeros((T, N, Dout))
+        X = group.broadcast_array(X); radii = group.broadcast_array(radii)
+        degree = group.broadcast_array(degree).astype(np.int64)
+        in_edges = group.broadcast_array(in_edges).astype(np.int64)
+        out_edges = group.broadcast_array(out_edges).astype(np.int64)
+        self.density = float(degree[:, :, 1].mean() / (N - 1))
+        self.mean_terms = float(degree.sum(axis=2).mean() + 2 * C)
+        self.chains = []
+        for c in range(args.chains_per_gpu):
+            ch = Chain(T, N, 2, 'case_control', seed=20240229, chain_id=rank * args.chains_per_gpu + c,
+                       device=local_rank)
+            ch.upload_edges(in_edges, out_edges, degree)
+            ch.resample_controls(0, C)
+            ch.set_positions(X); ch.set_radii(radii); ch.set_intercepts([1.0, 0.5])
+            ch.set_prior_random_walk(1e-4, 1e-5)
+            ch.set_samplers(SamplerGrid(T, N, step_size=0.002, tune=None))
+            ch.lsm_configure([1.0, 0.5], 2.0, step_size_intercept=0.1, tune=None,
+                             n_iter_procrustes=0, sweep_algo=args.algo, step_size_radii=175000.,
+                             radii_tune=None)
+            ch.trace_alloc(1 + W + K + P, logp0=0.0)
+            self.chains.append(ch)
+        self.chain = self.chains[0]
+        self.next_it = 1
+        self.n_resample = 100
+
+    def _run_chain(self, ch, first, count):
+        it, last = first, first + count - 1
+        while it <= last:
+            if it % self.n_resample == 0:
+                ch.resample_controls(it, self.C)
+            nxt = min(last + 1, (it // self.n_resample + 1) * self.n_resample)
+            ch.lsm_run(it, nxt - it, procrustes_ref=0)
+            it = nxt
+
+    def run(self, count):
+        it = self.next_it
+        in_threads([(lambda ch=ch: self._run_chain(ch, it, count)) for ch in self.chains])
+        self.next_it += count
+
+    def synchronize(self):
+        for ch in self.chains:
+            ch.synchronize()
+
+    def workload(self):
+        return ('DynamicNetworkLSM directed case-control T=%d N=%d d=2, n_control=%d, mean degree '
+                '%.1f, %d chain%s per GPU' % (self.T, self.N, self.C, self.density * (self.N - 1),
+                                              len(self.chains), '' if len(self.chains) == 1 else 's'))
+
+    def metric(self):
+        return ('Gibbs iterations/sec, directed case-control T=%d N=%d d=2 n_control=%d'
+                % (self.T, self.N, self.C))
+
+    def profile(self):
+        from dynetlsm_amd import _lib
+        a, chain = self.args, self.chain
+        P = a.profile_steps
+        chain.profile_enable(True)
+        self._run_chain(chain, self.next_it, P)
+        self.next_it += P
+        chain.synchronize()
+        ms_sw, n_sw = chain.profile_read(_lib.K_SWEEP)
+        ms_ll, n_ll = chain.profile_read(_lib.K_LOGLIK)
+        ms_ps, n_ps = chain.profile_read(_lib.K_CENTER)
+        chain.profile_enable(False)
+        ms_ev, n_ev = chain.profile_read(_lib.K_SWEEP_EVAL)
+        T, N = self.T, self.N
+        sweep_ms = ms_sw / max(n_sw, 1)
+        launches = n_ev / float(max(P, 1))
+        k_ms = ms_ev / max(n_ev, 1)
+        algo = chain.resolve_sweep_algo(a.algo)
+        kname = {5: 'k_ccpipe_step', 4: 'k_pipe_step<case-control>'}.get(algo, 'k_spec_eval_cc')
+        # algorithmic bytes (SURVEY.md 8a, a3): every MH step evaluates the partial log-likelihood
+        # at the proposal and at the current position; each evaluation walks the node's edge
+        # and control lists (int64 index 8 B) and gathers X[e] (16 B at d = 2) and radii[e] (8 B)
+        sweep_bytes = 2.0 * T * N * self.mean_terms * (8 + 16 + 8)
+        k_bytes = sweep_bytes / max(launches, 1)
+        ach = k_bytes / (k_ms * 1e-3) / 1e9
+        roofline = {'bound': 'hbm', 'kernel': kname, 'achieved': round(ach, 2), 'peak': HBM_PEAK_GBS,
+                    'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 5), 'traffic': None,
+                    'us_per_launch': round(1e3 * k_ms, 3), 'launches_per_sweep': launches,
+                    'algorithmic_bytes_per_launch': round(k_bytes, 1),
+                    'gathered_terms_per_s_sweep': round(2.0 * T * N * self.mean_terms /
+                                                        (sweep_ms * 1e-3), 0),
+                    'note': 'gather-latency bound: each term is a dependent chain list index -> '
+                            'X[e], radii[e] through L2 (the working set, 2.4 MB, is cache '
+                            'resident: HBM traffic is far below the algorithmic bytes)'}
+        extra = {'ms_sweep': round(sweep_ms, 4),
+                 'ms_per_loglik_pass': round(ms_ll / max(n_ll, 1), 4),
+                 'loglik_passes_per_iteration': round(n_ll / float(max(P, 1)), 2),
+                 'ms_post_sweep': round(ms_ps / max(n_ps, 1), 4)}
+        return roofline, extra
+
+    def results(self, first, count):
+        out = []
+        for ch in self.chains:
+            Xs, ics, lps = ch.trace_read(first, count, positions=True)
+            out.append(dict(X_mean=Xs.mean(axis=0), logps=lps, intercepts=ics))
+        return {k: np.stack([o[k] for o in out]) for k in out[0]}
+
+    def acceptance(self):
+        from dynetlsm_amd import SamplerGrid
+        g = self.chain.get_samplers(SamplerGrid(self.T, self.N, 0.002, tune=None))
+        return float(g.n_accepted.sum()) / max(float(g.n_steps.sum()), 1.0)
+
+    def cpu_baseline(self):
+        return None
+
+    def close(self):
+        for ch in self.chains:
+            ch.close()
+
+
 def measure(wl, args, group):
     """W untimed warm-up steps, then exactly K steps between barriers + synchronisation,
     max over ranks; the roofline profile and the final gather follow outside the timed region"""
@@ -580,10 +726,10 @@ def run_rank(args):
     group = init_chain_group(backend=(args.backend or 'nccl') if world > 1 else 'gloo')
     torch.cuda.set_device(local_rank)
     K, W = args.steps, args.warmup
-    models = ['lsm', 'hdp'] if args.model == 'all' else [args.model]
+    models = ['lsm', 'hdp', 'cc'] if args.model == 'all' else [args.model]
     lines = []
     for name in models:
-        wl = (LsmWorkload if name == 'lsm' else HdpWorkload)(args, group, local_rank)
+        wl = {'lsm': LsmWorkload, 'hdp': HdpWorkload, 'cc': CcWorkload}[name](args, group, local_rank)
         elapsed, roofline, extra, acc, gathered = measure(wl, args, group)
         cpu = None
         if rank == 0 and not args.no_cpu and args.cpu_iters > 0:
@@ -599,7 +745,7 @@ def run_rank(args):
                 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
                 'config': {'workload': wl.workload(), 'density': round(wl.density, 4),
                            'chains': world * C, 'chains_per_gpu': C,
-                           'sweep_algo': (wl.chain if name == 'lsm' else wl.model.chain_)
+                           'sweep_algo': (wl.model.chain_ if name == 'hdp' else wl.chain)
                            .resolve_sweep_algo(args.algo),
                            'mh_acceptance_rate': round(acc, 3),
                            'network_broadcast': ('packed words, device to device (%s)'
@@ -614,6 +760,11 @@ def run_rank(args):
                 line['config']['iteration'] = ('sweep + procrustes + centring + intercept MH + '
                                                'logp trace')
                 line['iteration_fp64_valu'] = iteration_valu_fraction(1e3 * elapsed / K, args)
+            elif name == 'cc':
+                line['config']['iteration'] = ('sweep (case-control partial likelihoods) + centring + '
+                                               'intercept_in / intercept_out / radii MH around '
+                                               'case-control log-likelihood passes + logp trace; '
+                                               'controls redrawn every 100 iterations')
             else:
                 line['config']['iteration'] = ('sweep (mixture prior) + centring + intercept MH + '
                                                'label block update + HDP auxiliary / conjugate / '

@@ -21,6 +21,7 @@
 #include "kernels_spec.hpp"
 #include "kernels_spec_sweep.hpp"
 #include "kernels_spec_pipe.hpp"
+#include "kernels_ccpipe.hpp"
 #include "kernels_init.hpp"
 #include "kernels_post.hpp"
 #include "kernels_forecast.hpp"
@@ -904,7 +905,9 @@ static int launch_sweep_spec(dlsm_chain *h, IterRef iter, int S, bool alloc_only
 // workgroup per slice
 static int resolve_sweep_algo(const dlsm_chain *h, int algo) {
     if (algo != 0) return algo;
-    if (h->model == DLSM_DIRECTED_CASE_CONTROL) return h->N >= 512 ? 4 : (h->N >= 256 ? 2 : 1);
+    // case-control: sparse correction lists once a slice has several batches of 1024
+    if (h->model == DLSM_DIRECTED_CASE_CONTROL)
+        return h->N >= 2048 ? 5 : (h->N >= 512 ? 4 : (h->N >= 256 ? 2 : 1));
     return h->N >= 512 ? 4 : (h->N >= 256 ? 2 : 1);
 }
 
@@ -987,6 +990,58 @@ static int launch_sweep_pipe(dlsm_chain *h, IterRef iter, bool alloc_only = fals
     return DLSM_OK;
 }
 
+// algo 5: the case-control likelihood with sparse correction lists, batches of 1024 nodes
+// (kernels_ccpipe.hpp)
+template <int DD>
+static int launch_sweep_ccpipe(dlsm_chain *h, IterRef iter, bool alloc_only = false) {
+    const int N = h->N, T = h->T;
+    const int nbat = (N + CP_B - 1) / CP_B;
+    const int total_max = h->Din + h->Dout + 2 * h->C;
+    const int chunks = (total_max + 63) / 64;
+    const int cap = 64 * std::max(1, (chunks + CP_SUBS - 1) / CP_SUBS);
+    auto even2 = [](size_t n) { return (n + 1) / 2 * 2; };
+    const size_t n_prop = even2((size_t)T * N * (2 * DD + 2));
+    const size_t n_slot = (size_t)2 * T * CP_B * CP_SUBS;
+    const size_t n_ent = n_slot * cap;
+    // doubles: prop | tot | hval | consts(2) ; then int32 hidx, hcnt ; then uint64 accmask
+    const size_t need = (n_prop + n_slot + n_ent + 2) * sizeof(double) +
+                        even2(n_ent + n_slot) * sizeof(int32_t) +
+                        (size_t)T * CP_WAVES * sizeof(unsigned long long);
+    if (h->pipe_cap < need) {
+        if (h->pipe) hipFree(h->pipe);
+        h->pipe = nullptr; h->pipe_cap = 0;
+        HIPCHK(h, hipMalloc((void **)&h->pipe, need));
+        h->pipe_cap = need;
+    }
+    if (alloc_only) return DLSM_OK;
+    CcPipeBuf pb;
+    pb.prop = h->pipe; pb.tot = pb.prop + n_prop; pb.hval = pb.tot + n_slot;
+    double *consts = pb.hval + n_ent;
+    pb.hidx = (int32_t *)(consts + 2); pb.hcnt = pb.hidx + n_ent;
+    pb.accmask = (unsigned long long *)(pb.hidx + even2(n_ent + n_slot));
+    pb.nctrl = h->nctrl; pb.cap = cap; pb.nbat = nbat;
+    PipeBuf pp{};                   // the proposal kernel's view: proposals + its two constants
+    pp.prop = pb.prop; pp.consts = consts;
+    ChainView v = h->view();
+    hipLaunchKernelGGL((k_pipe_propose<DD>), dim3((N + 255) / 256, T), dim3(256), 0, h->stream, v,
+                       pp, iter);
+    const int nodes_max = ((T + 1) / 2 + T / 2) * std::min(CP_B, N);
+    const int ne_wg = std::max(1, std::min(std::max(h->n_cu / 2, h->n_cu - T),
+                                           (nodes_max * CP_SUBS + CP_WAVES - 1) / CP_WAVES));
+    const int last = T > 1 ? nbat : nbat - 1;
+    for (int l = -1; l <= last; ++l) {
+        const bool any_eval = (l + 1 < nbat) || (T > 1 && l >= 0 && l < nbat);
+        const int grid = T + (any_eval ? ne_wg : 0);
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (h->profiling) { hipEventCreate(&e0); hipEventCreate(&e1); }
+        hipExtLaunchKernelGGL((k_ccpipe_step<DD>), dim3(grid), dim3(CP_THREADS), 0, h->stream, e0, e1,
+                              0, v, pb, l);
+        if (h->profiling) h->prof[DLSM_K_SWEEP_EVAL].pending.emplace_back(e0, e1);
+    }
+    HIPCHK(h, hipGetLastError());
+    return DLSM_OK;
+}
+
 template <int DD>
 static int launch_sweep(dlsm_chain *h, IterRef iter, int algo, bool alloc_only = false) {
     ChainView v = h->view();
@@ -1009,9 +1064,11 @@ static int launch_sweep(dlsm_chain *h, IterRef iter, int algo, bool alloc_only =
         algo = resolve_sweep_algo(h, algo);
         if (alloc_only) {
             hipStreamSynchronize(h->stream);
+            if (algo == 5) return launch_sweep_ccpipe<DD>(h, iter, true);
             if (algo == 4) return launch_sweep_pipe<DD>(h, iter, true);
             return algo >= 2 ? launch_sweep_spec<DD>(h, iter, 1, true) : DLSM_OK;
         }
+        if (algo == 5) return launch_sweep_ccpipe<DD>(h, iter);
         if (algo == 4) return launch_sweep_pipe<DD>(h, iter);
         if (algo >= 2) return launch_sweep_spec<DD>(h, iter, 1);
         for (int parity = 0; parity < 2; ++parity) {
@@ -1073,13 +1130,15 @@ extern "C" {
 
 int dlsm_resolve_sweep_algo(dlsm_chain *h, int algo) {
     NEED(h, h != nullptr, "null handle");
-    NEED(h, algo >= 0 && algo <= 4, "algo must be 0..4");
+    NEED(h, algo >= 0 && algo <= 5, "algo must be 0..5");
+    NEED(h, algo != 5 || h->model == DLSM_DIRECTED_CASE_CONTROL, "algo 5 is the case-control sweep");
     return resolve_sweep_algo(h, algo);
 }
 
 int dlsm_sweep_positions(dlsm_chain *h, uint32_t iter, int algo) {
     NEED(h, h != nullptr, "null handle");
-    NEED(h, algo >= 0 && algo <= 4, "algo must be 0..4");
+    NEED(h, algo >= 0 && algo <= 5, "algo must be 0..5");
+    NEED(h, algo != 5 || h->model == DLSM_DIRECTED_CASE_CONTROL, "algo 5 is the case-control sweep");
     HIPCHK(h, hipSetDevice(h->device));
     int rc = check_ready_sweep(h); if (rc) return rc;
     rc = enqueue_sweep(h, IterRef{iter, nullptr}, algo); if (rc) return rc;

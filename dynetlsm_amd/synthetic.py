@@ -6,7 +6,7 @@ DynamicNetworkLSM); the reference's generator is O(T N^2) Python-side.
 """
 import numpy as np
 
-__all__ = ['synthetic_lsm_network', 'synthetic_hdp_network']
+__all__ = ['synthetic_lsm_network', 'synthetic_hdp_network', 'synthetic_sparse_directed']
 
 
 def _expit(x):
@@ -110,3 +110,35 @@ def synthetic_hdp_network(T=10, N=2000, D=2, n_clusters=6, density=0.03, lmbda=0
     X_init = X + init_noise * rng.randn(T, N, D)
     return dict(Y=Y, X_true=X, z_true=z, mu_true=mu, sigma_true=np.full(n_clusters, sigma ** 2),
                 intercept=float(b), X_init=X_init)
+
+
+def synthetic_sparse_directed(T=5, N=10000, deg=20, seed=0):
+    """BASELINE.json configs[3]: a sparse directed network given directly
+    as the case-control sampler's tables - the dense T x N x N tensor (4 GB at T = 5,
+    N = 10 000) is never formed.  Every node draws ``deg`` out-neighbours uniformly (duplicates
+    and self-loops dropped: mean out-degree just under ``deg``); positions ~ N(0, 0.01^2 I) and
+    radii ~ Dirichlet(10) as in the reference's directed generators
+    (samples_generator.py:123-131, 249-253).
+
+    Returns (X, radii, degree[T, N, 2], in_edges, out_edges) in the layouts of
+    case_control_likelihood.py:45-68 (zero padded, sources in increasing order)."""
+    rng = np.random.RandomState(seed)
+    X = 0.01 * rng.randn(T, N, 2)
+    radii = rng.dirichlet(np.ones(N) * 10)
+    out = rng.randint(0, N, size=(T, N, deg))
+    out_lists = [[np.setdiff1d(np.unique(out[t, i]), [i]) for i in range(N)] for t in range(T)]
+    degree = np.zeros((T, N, 2), dtype=np.int64)
+    for t in range(T):
+        for i in range(N):
+            degree[t, i, 1] = out_lists[t][i].size
+            np.add.at(degree[t, :, 0], out_lists[t][i], 1)
+    out_edges = np.zeros((T, N, degree[:, :, 1].max()), dtype=np.int64)
+    in_edges = np.zeros((T, N, degree[:, :, 0].max()), dtype=np.int64)
+    fill = np.zeros((T, N), dtype=np.int64)
+    for t in range(T):
+        for i in range(N):
+            e = out_lists[t][i]
+            out_edges[t, i, :e.size] = e
+            in_edges[t, e, fill[t, e]] = i       # sources arrive in increasing i
+            fill[t, e] += 1
+    return X, radii, degree, in_edges, out_edges

@@ -135,9 +135,11 @@ int dlsm_loglik_partial_all(dlsm_chain *h, int with_prior, double *out);
  * 1 = one workgroup per slice, 2 = speculative batches over the whole chip,
  * 3 = speculative batches with one launch pair per two 128-node sub-batches,
  * 4 = pipelined speculative batches: one fused launch resolves batch b and
- *     evaluates batch b + 1, both parities in the same launches. */
+ *     evaluates batch b + 1, both parities in the same launches,
+ * 5 = (case-control model) the pipelined form with sparse correction lists and batches
+ *     of 1024 nodes. */
 int dlsm_sweep_positions(dlsm_chain *h, uint32_t iter, int algo);
-/* the algorithm `algo` resolves to for this handle (what 0 = auto picks): 1..4 */
+/* the algorithm `algo` resolves to for this handle (what 0 = auto picks): 1..5 */
 int dlsm_resolve_sweep_algo(dlsm_chain *h, int algo);
 /* lsm.py:501 / hdp_lpcm.py:852 */
 int dlsm_center(dlsm_chain *h);

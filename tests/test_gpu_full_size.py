@@ -109,26 +109,8 @@ def test_c3_hdp_pieces_at_full_size(eng, c2, algo):
 
 def _sparse_directed(T, N, deg, seed):
     """directed edge lists built without a dense network (config 4 is sparse)"""
-    rng = np.random.RandomState(seed)
-    X = 0.01 * rng.randn(T, N, 2)
-    radii = rng.dirichlet(np.ones(N) * 10)
-    out = rng.randint(0, N, size=(T, N, deg))
-    out_lists = [[np.setdiff1d(np.unique(out[t, i]), [i]) for i in range(N)] for t in range(T)]
-    degree = np.zeros((T, N, 2), dtype=np.int64)
-    for t in range(T):
-        for i in range(N):
-            degree[t, i, 1] = out_lists[t][i].size
-            np.add.at(degree[t, :, 0], out_lists[t][i], 1)
-    out_edges = np.zeros((T, N, degree[:, :, 1].max()), dtype=np.int64)
-    in_edges = np.zeros((T, N, degree[:, :, 0].max()), dtype=np.int64)
-    fill = np.zeros((T, N), dtype=np.int64)
-    for t in range(T):
-        for i in range(N):
-            e = out_lists[t][i]
-            out_edges[t, i, :e.size] = e
-            in_edges[t, e, fill[t, e]] = i       # sources arrive in increasing i
-            fill[t, e] += 1
-    return X, radii, degree, in_edges, out_edges
+    from dynetlsm_amd.synthetic import synthetic_sparse_directed
+    return synthetic_sparse_directed(T, N, deg, seed)
 
 
 def test_c4_case_control_at_full_size(eng):
@@ -166,12 +148,18 @@ def test_c4_case_control_at_full_size(eng):
                     b[0], b[1], j), rtol=1e-11)
         c.set_prior_random_walk(1e-4, 1e-5)
         c.set_samplers(eng.SamplerGrid(T, N, 0.002, tune=None))
+        assert c.resolve_sweep_algo(0) == 5             # sparse correction lists at this size
         t0 = time.perf_counter()
         c.sweep_positions(1, 0)
         t_sw = time.perf_counter() - t0
         st.sweep_c()
-        np.testing.assert_allclose(c.get_positions(), st.X, atol=1e-12)
+        Xg = c.get_positions()
+        np.testing.assert_allclose(Xg, st.X, atol=1e-12)
         assert 0.02 < og.n_accepted.mean() < 0.98
+        # the dense-block form of the pipelined sweep (algo 4) makes the same decisions
+        c.set_positions(X); c.set_samplers(eng.SamplerGrid(T, N, 0.002, tune=None))
+        c.sweep_positions(1, 4)
+        np.testing.assert_allclose(c.get_positions(), Xg, atol=1e-12)
     print('C4: resample %.1f ms, sweep %.1f ms' % (1e3 * t_res, 1e3 * t_sw))
 
 

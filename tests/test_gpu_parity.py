@@ -367,11 +367,21 @@ def test_sweep_speculative_batches(eng, name, T, N, D, prior, algo):
 @pytest.mark.parametrize('prior', ['rw', 'mix'])
 @pytest.mark.parametrize('T,N,C,density', [(4, 300, 20, 0.05), (3, 10, 3, 0.2),
                                            (2, 150, 40, 0.5), (5, 700, 10, 0.02)])
-@pytest.mark.parametrize('algo', [2, 4])
+@pytest.mark.parametrize('algo', [2, 4, 5])
 def test_sweep_speculative_batches_case_control(eng, T, N, C, density, prior, algo):
     """sparse H: only the batch nodes that sit in a node's edge / control lists
-    interact; density 0.5 with 40 controls makes most of a batch interact"""
+    interact; density 0.5 with 40 controls makes most of a batch interact.  algo 5 keeps the
+    corrections as per-node lists (batches of 1024: one batch at these sizes)"""
     _sweep_case(eng, 'case_control', prior, T=T, N=N, D=2, n_sweeps=3, algo=algo,
+                scale=0.05, cc_C=C, density=density)
+
+
+@pytest.mark.parametrize('T,N,C,density,prior', [(3, 2300, 12, 0.004, 'rw'), (2, 1025, 30, 0.01, 'mix'),
+                                                 (4, 3100, 6, 0.003, 'rw'), (1, 2100, 8, 0.004, 'rw')])
+def test_sweep_case_control_sparse_lists_over_several_batches(eng, T, N, C, density, prior):
+    """algo 5 with 2 - 4 batches of 1024 nodes per slice (ragged last batch, a single slice,
+    both priors): cross-batch corrections through the lists, same decisions as the oracle"""
+    _sweep_case(eng, 'case_control', prior, T=T, N=N, D=2, n_sweeps=2, algo=5,
                 scale=0.05, cc_C=C, density=density)
 
 
