@@ -996,16 +996,15 @@ template <int DD>
 static int launch_sweep_ccpipe(dlsm_chain *h, IterRef iter, bool alloc_only = false) {
     const int N = h->N, T = h->T;
     const int nbat = (N + CP_B - 1) / CP_B;
-    const int total_max = h->Din + h->Dout + 2 * h->C;
-    const int chunks = (total_max + 63) / 64;
-    const int cap = 64 * std::max(1, (chunks + CP_SUBS - 1) / CP_SUBS);
+    const int cap = std::max(1, h->Din + h->Dout + 2 * h->C);   // either list may hold every term
     auto even2 = [](size_t n) { return (n + 1) / 2 * 2; };
     const size_t n_prop = even2((size_t)T * N * (2 * DD + 2));
-    const size_t n_slot = (size_t)2 * T * CP_B * CP_SUBS;
-    const size_t n_ent = n_slot * cap;
-    // doubles: prop | tot | hval | consts(2) ; then int32 hidx, hcnt ; then uint64 accmask
-    const size_t need = (n_prop + n_slot + n_ent + 2) * sizeof(double) +
-                        even2(n_ent + n_slot) * sizeof(int32_t) +
+    const size_t n_tot = (size_t)2 * T * CP_B * CP_SUBS;
+    const size_t n_ent = (size_t)2 * T * cap * CP_B;
+    const size_t n_cnt = (size_t)2 * T * CP_B * 2;
+    // doubles: prop | tot | xval | oval | consts(2) ; int32: xidx | oidx | cnt ; uint64: accmask
+    const size_t need = (n_prop + n_tot + 2 * n_ent + 2) * sizeof(double) +
+                        even2(2 * n_ent + n_cnt) * sizeof(int32_t) +
                         (size_t)T * CP_WAVES * sizeof(unsigned long long);
     if (h->pipe_cap < need) {
         if (h->pipe) hipFree(h->pipe);
@@ -1015,10 +1014,10 @@ static int launch_sweep_ccpipe(dlsm_chain *h, IterRef iter, bool alloc_only = fa
     }
     if (alloc_only) return DLSM_OK;
     CcPipeBuf pb;
-    pb.prop = h->pipe; pb.tot = pb.prop + n_prop; pb.hval = pb.tot + n_slot;
-    double *consts = pb.hval + n_ent;
-    pb.hidx = (int32_t *)(consts + 2); pb.hcnt = pb.hidx + n_ent;
-    pb.accmask = (unsigned long long *)(pb.hidx + even2(n_ent + n_slot));
+    pb.prop = h->pipe; pb.tot = pb.prop + n_prop; pb.xval = pb.tot + n_tot; pb.oval = pb.xval + n_ent;
+    double *consts = pb.oval + n_ent;
+    pb.xidx = (int32_t *)(consts + 2); pb.oidx = pb.xidx + n_ent; pb.cnt = pb.oidx + n_ent;
+    pb.accmask = (unsigned long long *)(pb.xidx + even2(2 * n_ent + n_cnt));
     pb.nctrl = h->nctrl; pb.cap = cap; pb.nbat = nbat;
     PipeBuf pp{};                   // the proposal kernel's view: proposals + its two constants
     pp.prop = pb.prop; pp.consts = consts;
@@ -1027,7 +1026,7 @@ static int launch_sweep_ccpipe(dlsm_chain *h, IterRef iter, bool alloc_only = fa
                        pp, iter);
     const int nodes_max = ((T + 1) / 2 + T / 2) * std::min(CP_B, N);
     const int ne_wg = std::max(1, std::min(std::max(h->n_cu / 2, h->n_cu - T),
-                                           (nodes_max * CP_SUBS + CP_WAVES - 1) / CP_WAVES));
+                                           (nodes_max + CP_GROUPS - 1) / CP_GROUPS));
     const int last = T > 1 ? nbat : nbat - 1;
     for (int l = -1; l <= last; ++l) {
         const bool any_eval = (l + 1 < nbat) || (T > 1 && l >= 0 && l < nbat);

@@ -8,17 +8,20 @@
 // ratio only depends on the O(deg + 2C) nodes in its edge / control lists, so of the nodes not
 // yet resolved when k is evaluated (the window: the previous batch and the earlier nodes of
 // k's own batch) only a few matter: ~40 of 2048 at C4 with batches of 1024.  Here the
-// evaluator files exactly those as a LIST per node, (window index, correction) pairs in term
-// order, and the resolver runs the same fixed-point solve of the in-order accept / reject
+// evaluator files exactly those as two LISTS per node - corrections for nodes of the previous
+// batch (whose acceptances are final when k's batch is resolved) and for earlier nodes of k's
+// own batch - and the resolver runs the same fixed-point solve of the in-order accept / reject
 // rule over the lists:
 //
-//     a_k = [ log u_k < r_k + sum_{(m, h) in list_k, m accepted} h ]
+//     a_k = [ log u_k < r_k + sum_{(m, h) in own_k, m accepted} h ]
 //
 // A fixed point of a -> F(a) satisfies the triangular system, whose solution is unique, so it
 // is the sequential scan's result.  Batches of 1024 nodes: ceil(N / 1024) + 2 launches per
-// sweep (12 at C4), each with T resolver workgroups beside ~250 evaluator workgroups (one
-// wavefront per (node, quarter of its terms)).  Same snapshot rule, same one-batch lag of the odd
-// slices, same decisions as the dense form and the scalar oracle.
+// sweep (12 at C4), each with T resolver workgroups (thread = node) beside ~250 evaluator
+// workgroups (four wavefronts per node).  The lists are stored entry-major ([entry][node]) so
+// that the resolver's thread-per-node walks are coalesced; a node's first CP_OWN_REGS own
+// entries stay in registers across the passes of the solve.  Same snapshot rule, same
+// one-batch lag of the odd slices, same decisions as the dense form and the scalar oracle.
 #pragma once
 #include "kernels_spec_pipe.hpp"
 
@@ -28,17 +31,45 @@ constexpr int CP_B = 1024;              // nodes per batch = threads of the reso
 constexpr int CP_THREADS = 1024;
 constexpr int CP_WAVES = CP_THREADS / 64;
 constexpr int CP_SUBS = 4;              // wavefronts per node in the evaluator
+constexpr int CP_GROUPS = CP_WAVES / CP_SUBS;   // nodes per evaluator workgroup round
+constexpr int CP_OWN_REGS = 16;         // own entries a resolver thread keeps in registers
 
 struct CcPipeBuf {
     double *prop;            // [T][N][2D + 2] : x1[D], u, (unused), x0[D] (snapshot)
     double *tot;             // [2][T][CP_B][CP_SUBS] : partial log-ratio of node k (snapshot neighbours)
-    double *hval;            // [2][T][CP_B][CP_SUBS][cap] : corrections, in term order
-    int32_t *hidx;           // same shape: window index m in [0, 2 CP_B): previous batch, then own
-    int32_t *hcnt;           // [2][T][CP_B][CP_SUBS]
+    double *xval, *oval;     // [2][T][cap][CP_B] : cross / own corrections, entry-major
+    int32_t *xidx, *oidx;    // same shape: index of the node inside its batch
+    int32_t *cnt;            // [2][T][CP_B][2] : entries of the two lists
     unsigned long long *accmask;   // [T][CP_WAVES] : accepted nodes of the last resolved batch
     const int32_t *nctrl;    // valid controls per (t, i, direction)
     int cap, nbat;
 };
+
+// terms of the four lists of a node in one order: in-edges, out-edges, in-controls,
+// out-controls (kinds 0..3)
+struct CcNode {
+    size_t node;
+    int in_deg, out_deg, nci, nco, total;
+    double adj_in, adj_out;
+};
+__device__ __forceinline__ CcNode cc_node(const ChainView &c, const int32_t *nctrl, int t, int jk) {
+    CcNode n;
+    n.node = (size_t)t * c.N + jk;
+    n.in_deg = c.degree[n.node * 2]; n.out_deg = c.degree[n.node * 2 + 1];
+    n.nci = nctrl[n.node * 2]; n.nco = nctrl[n.node * 2 + 1];
+    n.adj_in = (double)(c.N - n.in_deg - 1) / (double)n.nci;
+    n.adj_out = (double)(c.N - n.out_deg - 1) / (double)n.nco;
+    n.total = n.in_deg + n.out_deg + n.nci + n.nco;
+    return n;
+}
+__device__ __forceinline__ int cc_term(const ChainView &c, const CcNode &n, int q, int &kind) {
+    int r = q;
+    if (r < n.in_deg) { kind = 0; return c.in_edges[n.node * c.Din + r]; }
+    if ((r -= n.in_deg) < n.out_deg) { kind = 1; return c.out_edges[n.node * c.Dout + r]; }
+    if ((r -= n.out_deg) < n.nci) { kind = 2; return c.ctrl_in[n.node * c.C + r]; }
+    kind = 3;
+    return c.ctrl_out[n.node * c.C + (r - n.nci)];
+}
 
 // log-ratio contribution of one gathered term of node k when k moves x0 -> x1, its partner
 // at xn (directed_likelihoods_fast.pyx:107-180):
@@ -59,82 +90,101 @@ __device__ __forceinline__ double cc_term_delta(const double *xn, const double *
     return (edge ? (e1 - e0) : 0.0) - wsp * sp;
 }
 
-// One wavefront: quarter `sub` of the terms of node k of batch `be` in slice t.
+// One wavefront: quarter `sub` of the terms of node k of batch `be` in slice t; the four
+// wavefronts of a node are consecutive wavefronts of one workgroup (group `grp`) and agree on
+// the positions of their entries in the node's two lists through `sCnt`.  All wavefronts of
+// the workgroup call this together (barriers inside); `valid` = the group has a node.
 template <int D>
-__device__ __forceinline__ void ccpipe_eval_item(const ChainView &c, const CcPipeBuf &pb, int be,
-                                                 int t, int k, int sub, int lane) {
+__device__ __forceinline__ void ccpipe_eval_item(const ChainView &c, const CcPipeBuf &pb, bool valid,
+                                                 int be, int t, int k, int sub, int grp, int lane,
+                                                 int (*sCnt)[CP_SUBS][2]) {
     constexpr int PW = 2 * D + 2;
     const int N = c.N;
     const int j0 = be * CP_B, jk = j0 + k;
     const int jprev = max(0, j0 - CP_B);       // nodes >= jprev: snapshot positions
     const int bb = be & 1;
-    const size_t node = (size_t)t * N + jk;
-    const double *Xt = c.X + (size_t)t * N * D;
-    const double *props = pb.prop + (size_t)t * N * PW;
-    double xk0[D], xk1[D];
-#pragma unroll
-    for (int d = 0; d < D; ++d) {
-        xk0[d] = props[(size_t)jk * PW + D + 2 + d];
-        xk1[d] = props[(size_t)jk * PW + d];
-    }
-    const double bin = c.intercept[0], bout = c.intercept[1];
-    const double rj = c.radii[jk];
-    const int in_deg = c.degree[node * 2], out_deg = c.degree[node * 2 + 1];
-    const int nci = pb.nctrl[node * 2], nco = pb.nctrl[node * 2 + 1];
-    const double adj_in = (double)(N - in_deg - 1) / (double)nci;
-    const double adj_out = (double)(N - out_deg - 1) / (double)nco;
-    const int total_terms = in_deg + out_deg + nci + nco;
-    const size_t slot = (((size_t)bb * c.T + t) * CP_B + k) * CP_SUBS + sub;
-    double *hval = pb.hval + slot * pb.cap;
-    int32_t *hidx = pb.hidx + slot * pb.cap;
-    const unsigned long long below = (1ull << lane) - 1ull;
-    double acc = 0.0;
-    int cnt = 0;
-    for (int q0 = 64 * sub; q0 < total_terms; q0 += 64 * CP_SUBS) {
-        const int q = q0 + lane;
-        int e = -1, kind = 0;
-        if (q < total_terms) {
-            int r = q;
-            if (r < in_deg) { e = c.in_edges[node * c.Din + r]; kind = 0; }
-            else if ((r -= in_deg) < out_deg) { e = c.out_edges[node * c.Dout + r]; kind = 1; }
-            else if ((r -= out_deg) < nci) { e = c.ctrl_in[node * c.C + r]; kind = 2; }
-            else { r -= nci; e = c.ctrl_out[node * c.C + r]; kind = 3; }
+    CcNode nd{};
+    if (valid) nd = cc_node(c, pb.nctrl, t, jk);
+    // pass A: how many of this quarter's terms point into the window
+    int ncx = 0, nco_ = 0;
+    if (valid) {
+        for (int q0 = 64 * sub; q0 < nd.total; q0 += 64 * CP_SUBS) {
+            const int q = q0 + lane;
+            int kind, e = -1;
+            if (q < nd.total) e = cc_term(c, nd, q, kind);
+            ncx += __popcll(__ballot(e >= jprev && e < j0));
+            nco_ += __popcll(__ballot(e >= j0 && e < jk));
         }
-        bool inwin = false;
-        double h = 0.0;
-        if (e >= 0) {
-            const double *src = e < jprev ? Xt + (size_t)e * D : props + (size_t)e * PW + D + 2;
-            double xe[D];
+        if (lane == 0) { sCnt[grp][sub][0] = ncx; sCnt[grp][sub][1] = nco_; }
+    }
+    __syncthreads();
+    if (valid) {
+        int bx = 0, bo = 0, tx = 0, to = 0;
 #pragma unroll
-            for (int d = 0; d < D; ++d) xe[d] = src[d];
-            const double re = c.radii[e];
-            const bool in_dir = (kind == 0 || kind == 2);
-            const double wsp = kind < 2 ? 1.0 : (kind == 2 ? adj_in : adj_out);
-            const double contrib = cc_term_delta<D>(xe, xk0, xk1, e == jk, in_dir, kind < 2, wsp,
-                                                    bin, bout, rj, re, c.squared);
-            acc += contrib;
-            inwin = e >= jprev && e < jk;
-            if (inwin) {            // a node of the window: its acceptance changes this term
-                double xe1[D];
+        for (int s = 0; s < CP_SUBS; ++s) {
+            const int a = sCnt[grp][s][0], b = sCnt[grp][s][1];
+            if (s < sub) { bx += a; bo += b; }
+            tx += a; to += b;
+        }
+        const double *Xt = c.X + (size_t)t * N * D;
+        const double *props = pb.prop + (size_t)t * N * PW;
+        double xk0[D], xk1[D];
 #pragma unroll
-                for (int d = 0; d < D; ++d) xe1[d] = props[(size_t)e * PW + d];
-                h = cc_term_delta<D>(xe1, xk0, xk1, false, in_dir, kind < 2, wsp, bin, bout, rj,
-                                     re, c.squared) - contrib;
+        for (int d = 0; d < D; ++d) {
+            xk0[d] = props[(size_t)jk * PW + D + 2 + d];
+            xk1[d] = props[(size_t)jk * PW + d];
+        }
+        const double bin = c.intercept[0], bout = c.intercept[1];
+        const double rj = c.radii[jk];
+        const size_t lbase = ((size_t)bb * c.T + t) * pb.cap * CP_B + k;      // + entry * CP_B
+        const unsigned long long below = (1ull << lane) - 1ull;
+        double acc = 0.0;
+        for (int q0 = 64 * sub; q0 < nd.total; q0 += 64 * CP_SUBS) {
+            const int q = q0 + lane;
+            int kind = 0, e = -1;
+            if (q < nd.total) e = cc_term(c, nd, q, kind);
+            bool isx = false, iso = false;
+            double h = 0.0;
+            if (e >= 0) {
+                const double *src = e < jprev ? Xt + (size_t)e * D : props + (size_t)e * PW + D + 2;
+                double xe[D];
+#pragma unroll
+                for (int d = 0; d < D; ++d) xe[d] = src[d];
+                const double re = c.radii[e];
+                const bool in_dir = (kind == 0 || kind == 2);
+                const double wsp = kind < 2 ? 1.0 : (kind == 2 ? nd.adj_in : nd.adj_out);
+                const double contrib = cc_term_delta<D>(xe, xk0, xk1, e == jk, in_dir, kind < 2, wsp,
+                                                        bin, bout, rj, re, c.squared);
+                acc += contrib;
+                isx = e >= jprev && e < j0;
+                iso = e >= j0 && e < jk;
+                if (isx || iso) {       // a node of the window: its acceptance changes this term
+                    double xe1[D];
+#pragma unroll
+                    for (int d = 0; d < D; ++d) xe1[d] = props[(size_t)e * PW + d];
+                    h = cc_term_delta<D>(xe1, xk0, xk1, false, in_dir, kind < 2, wsp, bin, bout, rj,
+                                         re, c.squared) - contrib;
+                }
             }
+            const unsigned long long mx = __ballot(isx), mo = __ballot(iso);
+            if (isx) {
+                const size_t p = lbase + (size_t)(bx + __popcll(mx & below)) * CP_B;
+                pb.xidx[p] = e - jprev; pb.xval[p] = h;
+            }
+            if (iso) {
+                const size_t p = lbase + (size_t)(bo + __popcll(mo & below)) * CP_B;
+                pb.oidx[p] = e - j0; pb.oval[p] = h;
+            }
+            bx += __popcll(mx); bo += __popcll(mo);
         }
-        const unsigned long long m = __ballot(inwin);
-        if (inwin) {
-            const int pos = cnt + __popcll(m & below);
-            hidx[pos] = e - jprev;
-            hval[pos] = h;
+        const double total = wave_sum_all(acc);
+        if (lane == 0) {
+            const size_t slot = ((size_t)bb * c.T + t) * CP_B + k;
+            pb.tot[slot * CP_SUBS + sub] = total;
+            if (sub == 0) { pb.cnt[slot * 2] = tx; pb.cnt[slot * 2 + 1] = to; }
         }
-        cnt += __popcll(m);
     }
-    const double total = wave_sum_all(acc);
-    if (lane == 0) {
-        pb.tot[slot] = total;
-        pb.hcnt[slot] = cnt;
-    }
+    __syncthreads();                        // sCnt is reused by the next round
 }
 
 // Resolve batch b of slice t: thread k owns node k of the batch.
@@ -147,18 +197,27 @@ __device__ __forceinline__ void ccpipe_resolve(const ChainView &c, const CcPipeB
     const int N = c.N;
     const int j0 = b * CP_B;
     const int nb = min(CP_B, N - j0);
-    const int ncross = j0 - max(0, j0 - CP_B);
     const int bb = b & 1;
     const int k = tid;
     const bool valid = k < nb;
     const int kc = min(k, nb - 1);
     unsigned long long *accg = pb.accmask + (size_t)t * CP_WAVES;
     if (tid < CP_WAVES) sPrev[tid] = b > 0 ? accg[tid] : 0ull;
-    const size_t slot0 = (((size_t)bb * c.T + t) * CP_B + kc) * CP_SUBS;
-    double r = 0.0;
-    int cnts[CP_SUBS];
+    const size_t slot = ((size_t)bb * c.T + t) * CP_B + kc;
+    const size_t lbase = ((size_t)bb * c.T + t) * pb.cap * CP_B + kc;
+    const int ncx = pb.cnt[slot * 2], nown = pb.cnt[slot * 2 + 1];
+    // the node's first own entries: into registers, all loads in flight at once
+    double ov[CP_OWN_REGS];
+    int oi[CP_OWN_REGS];
 #pragma unroll
-    for (int s = 0; s < CP_SUBS; ++s) { r += pb.tot[slot0 + s]; cnts[s] = pb.hcnt[slot0 + s]; }
+    for (int e = 0; e < CP_OWN_REGS; ++e) {
+        const size_t p = lbase + (size_t)min(e, max(nown - 1, 0)) * CP_B;
+        oi[e] = e < nown ? pb.oidx[p] : 0;
+        ov[e] = pb.oval[p];
+    }
+    double r = 0.0;
+#pragma unroll
+    for (int s = 0; s < CP_SUBS; ++s) r += pb.tot[slot * CP_SUBS + s];
     const double *pr = pb.prop + ((size_t)t * N + j0 + kc) * PW;
     double x0[D], x1[D];
 #pragma unroll
@@ -172,19 +231,11 @@ __device__ __forceinline__ void ccpipe_resolve(const ChainView &c, const CcPipeB
     int32_t na = c.nacc[tjc], ns = c.nsteps[tjc], un = c.until[tjc];
     __syncthreads();                                   // sPrev visible
     // the previous batch's acceptances, final by now: cross entries in list order
-    int nown = 0;
-#pragma unroll
-    for (int s = 0; s < CP_SUBS; ++s) {
-        const double *hv = pb.hval + (slot0 + s) * pb.cap;
-        const int32_t *hi = pb.hidx + (slot0 + s) * pb.cap;
-        for (int e = 0; e < cnts[s]; ++e) {
-            const int m = hi[e];
-            if (m < ncross) {
-                if ((sPrev[m >> 6] >> (m & 63)) & 1ull) r += hv[e];
-            } else {
-                ++nown;
-            }
-        }
+    for (int e = 0; e < ncx; ++e) {
+        const size_t p = lbase + (size_t)e * CP_B;
+        const int m = pb.xidx[p];
+        const double h = pb.xval[p];
+        if ((sPrev[m >> 6] >> (m & 63)) & 1ull) r += h;
     }
     {
         const unsigned long long g = __ballot(valid && !(lu >= r));
@@ -195,16 +246,13 @@ __device__ __forceinline__ void ccpipe_resolve(const ChainView &c, const CcPipeB
     int cur = 0;
     for (int pass = 0; pass < CP_B + 2; ++pass) {
         double s_own = 0.0;
-        if (nown > 0) {
 #pragma unroll
-            for (int s = 0; s < CP_SUBS; ++s) {
-                const double *hv = pb.hval + (slot0 + s) * pb.cap;
-                const int32_t *hi = pb.hidx + (slot0 + s) * pb.cap;
-                for (int e = 0; e < cnts[s]; ++e) {
-                    const int m = hi[e] - ncross;
-                    if (m >= 0 && ((sMask[cur][m >> 6] >> (m & 63)) & 1ull)) s_own += hv[e];
-                }
-            }
+        for (int e = 0; e < CP_OWN_REGS; ++e)
+            if (e < nown && ((sMask[cur][oi[e] >> 6] >> (oi[e] & 63)) & 1ull)) s_own += ov[e];
+        for (int e = CP_OWN_REGS; e < nown; ++e) {          // the rare long list: from memory
+            const size_t p = lbase + (size_t)e * CP_B;
+            const int m = pb.oidx[p];
+            if ((sMask[cur][m >> 6] >> (m & 63)) & 1ull) s_own += pb.oval[p];
         }
         const unsigned long long g = __ballot(valid && !(lu >= r + s_own));
         if (lane == 0) {
@@ -240,6 +288,7 @@ __global__ __launch_bounds__(CP_THREADS) void k_ccpipe_step(ChainView c, CcPipeB
     __shared__ unsigned long long sMask[2][CP_WAVES];
     __shared__ unsigned long long sPrev[CP_WAVES];
     __shared__ int sChanged;
+    __shared__ int sCnt[CP_GROUPS][CP_SUBS][2];
     const int T = c.T;
     if ((int)blockIdx.x < T) {
         const int t = blockIdx.x;
@@ -247,23 +296,24 @@ __global__ __launch_bounds__(CP_THREADS) void k_ccpipe_step(ChainView c, CcPipeB
         if (b >= 0 && b < pb.nbat) ccpipe_resolve<D>(c, pb, b, t, sMask, sPrev, &sChanged);
         return;
     }
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = wave & (CP_SUBS - 1), grp = wave / CP_SUBS;
     const int nE = (T + 1) / 2, nO = T / 2;
     const int beE = l + 1, beO = l;
     const int nbE = (beE >= 0 && beE < pb.nbat) ? min(CP_B, c.N - beE * CP_B) : 0;
     const int nbO = (beO >= 0 && beO < pb.nbat) ? min(CP_B, c.N - beO * CP_B) : 0;
     const int nodesE = nE * nbE, nodes = nodesE + nO * nbO;
-    const int nwaves = ((int)gridDim.x - T) * CP_WAVES;
-    const int gw = __builtin_amdgcn_readfirstlane(
-        ((int)blockIdx.x - T) * CP_WAVES + (int)(threadIdx.x >> 6));
-    for (int item = gw; item < nodes * CP_SUBS; item += nwaves) {
-        const int q = item / CP_SUBS, sub = item - q * CP_SUBS;
+    // every wavefront of the workgroup runs the same number of rounds (barriers inside)
+    for (int base = ((int)blockIdx.x - T) * CP_GROUPS; base < nodes;
+         base += ((int)gridDim.x - T) * CP_GROUPS) {
+        const int q = base + grp;
+        const bool valid = q < nodes;
         const bool odd = q >= nodesE;
         const int qq = odd ? q - nodesE : q;
-        const int nb = odd ? nbO : nbE;
+        const int nb = max(odd ? nbO : nbE, 1);
         const int k = qq % nb;
         const int t = 2 * (qq / nb) + (odd ? 1 : 0);
-        ccpipe_eval_item<D>(c, pb, odd ? beO : beE, t, k, sub, lane);
+        ccpipe_eval_item<D>(c, pb, valid, odd ? beO : beE, t, k, sub, grp, lane, sCnt);
     }
 }
 
