@@ -90,6 +90,25 @@ __device__ __forceinline__ double cc_term_delta(const double *xn, const double *
     return (edge ? (e1 - e0) : 0.0) - wsp * sp;
 }
 
+// The same with the lean forms of device_common.hpp: eta = B - d a with B = b_in + b_out and
+// a = b_in / r + b_out / r' from reciprocals (irj = 1 / r_k is the caller's, 1 / r_e a
+// v_rcp_f64 + two Newton steps), the correctly rounded lean root, the ~1 ulp lean exp and one
+// reciprocal instead of the division: a third of the instructions, equal to rounding.
+template <int D>
+__device__ __forceinline__ double cc_term_delta_fast(const double *xn, const double *xk0,
+                                                     const double *xk1, bool self, bool in_dir,
+                                                     bool edge, double wsp, double bin, double bout,
+                                                     double irj, double re, int squared) {
+    const double d0 = self ? 0.0 : dist_fast<D>(xn, xk0, squared);
+    const double d1 = self ? 0.0 : dist_fast<D>(xn, xk1, squared);
+    const double ire = fast_rcp(re);
+    const double a = in_dir ? fma(bin, irj, bout * ire) : fma(bin, ire, bout * irj);
+    const double B = bin + bout;
+    const double e0 = fma(-d0, a, B), e1 = fma(-d1, a, B);
+    const double sp = log(fma(1.0, fast_exp(e1), 1.0) * fast_rcp(1.0 + fast_exp(e0)));
+    return (edge ? (e1 - e0) : 0.0) - wsp * sp;
+}
+
 // One wavefront: quarter `sub` of the terms of node k of batch `be` in slice t; the four
 // wavefronts of a node are consecutive wavefronts of one workgroup (group `grp`) and agree on
 // the positions of their entries in the node's two lists through `sCnt`.  All wavefronts of
@@ -135,7 +154,7 @@ __device__ __forceinline__ void ccpipe_eval_item(const ChainView &c, const CcPip
             xk1[d] = props[(size_t)jk * PW + d];
         }
         const double bin = c.intercept[0], bout = c.intercept[1];
-        const double rj = c.radii[jk];
+        const double irj = 1.0 / c.radii[jk];
         const size_t lbase = ((size_t)bb * c.T + t) * pb.cap * CP_B + k;      // + entry * CP_B
         const unsigned long long below = (1ull << lane) - 1ull;
         double acc = 0.0;
@@ -153,8 +172,8 @@ __device__ __forceinline__ void ccpipe_eval_item(const ChainView &c, const CcPip
                 const double re = c.radii[e];
                 const bool in_dir = (kind == 0 || kind == 2);
                 const double wsp = kind < 2 ? 1.0 : (kind == 2 ? nd.adj_in : nd.adj_out);
-                const double contrib = cc_term_delta<D>(xe, xk0, xk1, e == jk, in_dir, kind < 2, wsp,
-                                                        bin, bout, rj, re, c.squared);
+                const double contrib = cc_term_delta_fast<D>(xe, xk0, xk1, e == jk, in_dir, kind < 2,
+                                                             wsp, bin, bout, irj, re, c.squared);
                 acc += contrib;
                 isx = e >= jprev && e < j0;
                 iso = e >= j0 && e < jk;
@@ -162,8 +181,8 @@ __device__ __forceinline__ void ccpipe_eval_item(const ChainView &c, const CcPip
                     double xe1[D];
 #pragma unroll
                     for (int d = 0; d < D; ++d) xe1[d] = props[(size_t)e * PW + d];
-                    h = cc_term_delta<D>(xe1, xk0, xk1, false, in_dir, kind < 2, wsp, bin, bout, rj,
-                                         re, c.squared) - contrib;
+                    h = cc_term_delta_fast<D>(xe1, xk0, xk1, false, in_dir, kind < 2, wsp, bin, bout,
+                                              irj, re, c.squared) - contrib;
                 }
             }
             const unsigned long long mx = __ballot(isx), mo = __ballot(iso);
@@ -231,11 +250,20 @@ __device__ __forceinline__ void ccpipe_resolve(const ChainView &c, const CcPipeB
     int32_t na = c.nacc[tjc], ns = c.nsteps[tjc], un = c.until[tjc];
     __syncthreads();                                   // sPrev visible
     // the previous batch's acceptances, final by now: cross entries in list order
-    for (int e = 0; e < ncx; ++e) {
-        const size_t p = lbase + (size_t)e * CP_B;
-        const int m = pb.xidx[p];
-        const double h = pb.xval[p];
-        if ((sPrev[m >> 6] >> (m & 63)) & 1ull) r += h;
+    // (eight entries per trip, their loads issued together: a one-entry loop is a chain of
+    // ~1 us memory latencies)
+    for (int e0 = 0; e0 < ncx; e0 += 8) {
+        int m[8];
+        double h[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const size_t p = lbase + (size_t)min(e0 + u, ncx - 1) * CP_B;
+            m[u] = pb.xidx[p];
+            h[u] = pb.xval[p];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (e0 + u < ncx && ((sPrev[m[u] >> 6] >> (m[u] & 63)) & 1ull)) r += h[u];
     }
     {
         const unsigned long long g = __ballot(valid && !(lu >= r));
