@@ -215,7 +215,11 @@ int launch_loglik_records(dlsm_chain *h, int M, const double *d_ic,
         if (M == 1) hipLaunchKernelGGL((k_loglik_directed<DD, 1>), dim3(nb), dim3(LL_THREADS), 0, h->stream, v, cand, h->partials);
         else hipLaunchKernelGGL((k_loglik_directed<DD, 2>), dim3(nb), dim3(LL_THREADS), 0, h->stream, v, cand, h->partials);
     } else {
-        if (M == 1) hipLaunchKernelGGL((k_loglik_casecontrol<DD, 1>), dim3(nb), dim3(256), 0, h->stream, v, cand, h->partials);
+        // every load up front when a node's out-edges fit one trip and its controls two
+        const bool pf = h->Dout <= 64 && h->C <= 128 && !getenv("DLSM_CC_LOGLIK_PLAIN");
+        if (pf && M == 1) hipLaunchKernelGGL((k_loglik_casecontrol_pf<DD, 1>), dim3(nb), dim3(256), 0, h->stream, v, cand, h->partials);
+        else if (pf) hipLaunchKernelGGL((k_loglik_casecontrol_pf<DD, 2>), dim3(nb), dim3(256), 0, h->stream, v, cand, h->partials);
+        else if (M == 1) hipLaunchKernelGGL((k_loglik_casecontrol<DD, 1>), dim3(nb), dim3(256), 0, h->stream, v, cand, h->partials);
         else hipLaunchKernelGGL((k_loglik_casecontrol<DD, 2>), dim3(nb), dim3(256), 0, h->stream, v, cand, h->partials);
     }
     HIPCHK(h, hipGetLastError());

@@ -433,6 +433,117 @@ __global__ __launch_bounds__(256) void k_loglik_casecontrol(
     }
 }
 
+// The same with every load of a wavefront's LLCC_NODES / 4 nodes issued before the first
+// use (degrees, then the out-edge and control indices, then the gathered positions and
+// radii): the kernel is a chain of gather latencies, and four nodes in turn are four chains.
+// For out-degrees <= 64 and at most 128 controls (the launcher checks); same record layout
+// and the same arithmetic per term.
+template <int D, int M>
+__global__ __launch_bounds__(256) void k_loglik_casecontrol_pf(
+    ChainView c, LoglikCand cand, double *__restrict__ partials) {
+    constexpr int NPW = LLCC_NODES / 4;
+    __shared__ double sRed[4 * M];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long nodes = (long)c.T * c.N;
+    const bool two_radii = M > 1 && cand.radii[M - 1] != cand.radii[0];
+    long node[NPW];
+    int outdeg[NPW], e[NPW][3], nctl[NPW];
+#pragma unroll
+    for (int r = 0; r < NPW; ++r) {
+        node[r] = ((long)blockIdx.x * NPW + r) * 4 + wave;
+        outdeg[r] = node[r] < nodes ? c.degree[node[r] * 2 + 1] : 0;
+    }
+#pragma unroll
+    for (int r = 0; r < NPW; ++r) {
+        const bool live = node[r] < nodes;
+        const long nn = live ? node[r] : 0;
+        e[r][0] = live && lane < outdeg[r] ? c.out_edges[nn * c.Dout + lane] : -1;
+        e[r][1] = live && lane < c.C ? c.ctrl_out[nn * c.C + lane] : -1;
+        e[r][2] = live && 64 + lane < c.C ? c.ctrl_out[nn * c.C + 64 + lane] : -1;
+    }
+#pragma unroll
+    for (int r = 0; r < NPW; ++r) {     // the control list ends at its first -1
+        const unsigned long long bad1 = ~__ballot(e[r][1] >= 0);
+        const int fb1 = bad1 ? __builtin_ctzll(bad1) : 64;
+        if (lane >= fb1) e[r][1] = -1;
+        const unsigned long long bad2 = ~__ballot(e[r][2] >= 0);
+        const int fb2 = fb1 < 64 ? 0 : (bad2 ? __builtin_ctzll(bad2) : 64);
+        if (lane >= fb2) e[r][2] = -1;
+        nctl[r] = fb1 + fb2;
+    }
+    double xi[NPW][D], xe[NPW][3][D], re0[NPW][3], re1[NPW][3], ri0[NPW], ri1[NPW];
+#pragma unroll
+    for (int r = 0; r < NPW; ++r) {
+        const long nn = node[r] < nodes ? node[r] : 0;
+        const int t = (int)(nn / c.N), i = (int)(nn % c.N);
+        const double *Xt = c.X + (size_t)t * c.N * D;
+#pragma unroll
+        for (int d = 0; d < D; ++d) xi[r][d] = Xt[(size_t)i * D + d];
+        ri0[r] = cand.radii[0][i];
+        ri1[r] = two_radii ? cand.radii[M - 1][i] : ri0[r];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const int ee = max(e[r][s], 0);
+#pragma unroll
+            for (int d = 0; d < D; ++d) xe[r][s][d] = Xt[(size_t)ee * D + d];
+            re0[r][s] = cand.radii[0][ee];
+            re1[r][s] = two_radii ? cand.radii[M - 1][ee] : re0[r][s];
+        }
+    }
+    double bin[M], bout[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) { bin[m] = cand.intercepts[2 * m]; bout[m] = cand.intercepts[2 * m + 1]; }
+    double L[M], Pe[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) { L[m] = 0.0; Pe[m] = 1.0; }
+#pragma unroll
+    for (int r = 0; r < NPW; ++r) {
+        if (node[r] >= nodes) continue;                   // wave-uniform
+        double iri[M], Pc[M], ctl[M];
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            iri[m] = 1.0 / (m == 0 ? ri0[r] : ri1[r]);
+            Pc[m] = 1.0; ctl[m] = 0.0;
+        }
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            if (e[r][s] < 0) continue;
+            const double dd = dist_fast<D>(xe[r][s], xi[r], c.squared);
+            const double ire0 = fast_rcp(re0[r][s]);
+            const double ire1 = two_radii ? fast_rcp(re1[r][s]) : ire0;
+#pragma unroll
+            for (int m = 0; m < M; ++m) {
+                const double ire = m == 0 ? ire0 : ire1;
+                const double eta = bin[m] * (1.0 - dd * ire) + bout[m] * (1.0 - dd * iri[m]);
+                if (s == 0) {               // out edge : directed_likelihoods_fast.pyx:236-247
+                    L[m] += eta;
+                    if (eta > 130.0) { L[m] -= eta; continue; }       // log(1 + e^eta) = eta there
+                    if (Pe[m] > 1e250) { L[m] -= log(Pe[m]); Pe[m] = 1.0; }
+                    Pe[m] *= 1.0 + fast_exp(fmax(eta, -700.0));
+                } else {                    // control : :250-268
+                    if (eta > 130.0) { ctl[m] += eta; continue; }
+                    Pc[m] *= 1.0 + fast_exp(fmax(eta, -700.0));
+                }
+            }
+        }
+        const double adj = (double)(c.N - outdeg[r] - 1) / (double)nctl[r];
+#pragma unroll
+        for (int m = 0; m < M; ++m) L[m] -= adj * (ctl[m] + log(Pc[m]));
+    }
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+        L[m] -= log(Pe[m]);
+        double v = wave_sum_all(L[m]);
+        if (lane == 0) sRed[wave * M + m] = v;
+    }
+    __syncthreads();
+    if (tid < M) {
+        double s = 0.0;
+        for (int w = 0; w < 4; ++w) s += sRed[w * M + tid];
+        partials[(size_t)blockIdx.x * M + tid] = s;
+    }
+}
+
 // Deterministic final reduction of `nrec` records of `width` doubles: one
 // workgroup, fixed strided order + fixed tree.  out[q] = sum_r rec[r][q].
 __device__ __forceinline__ void reduce_records(const double *__restrict__ rec,
