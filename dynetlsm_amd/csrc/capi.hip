@@ -217,8 +217,20 @@ int launch_loglik_records(dlsm_chain *h, int M, const double *d_ic,
     } else {
         // every load up front when a node's out-edges fit one trip and its controls two
         const bool pf = h->Dout <= 64 && h->C <= 128 && !getenv("DLSM_CC_LOGLIK_PLAIN");
-        if (pf && M == 1) hipLaunchKernelGGL((k_loglik_casecontrol_pf<DD, 1>), dim3(nb), dim3(256), 0, h->stream, v, cand, h->partials);
-        else if (pf) hipLaunchKernelGGL((k_loglik_casecontrol_pf<DD, 2>), dim3(nb), dim3(256), 0, h->stream, v, cand, h->partials);
+        if (pf) {       // positions and both candidates' radii as one record per node
+            const size_t nodes = (size_t)h->T * h->N;
+            const size_t need = nodes * llcc_record_width(DD);
+            if (h->xr_cap < need) {
+                if (h->xr) hipFree(h->xr);
+                h->xr = nullptr; h->xr_cap = 0;
+                HIPCHK(h, hipMalloc((void **)&h->xr, need * sizeof(double)));
+                h->xr_cap = need;
+            }
+            hipLaunchKernelGGL((k_pack_xr<DD>), dim3((unsigned)((nodes + 255) / 256)), dim3(256), 0,
+                               h->stream, h->X, r0, M > 1 ? r1 : r0, (long)nodes, h->N, h->xr);
+        }
+        if (pf && M == 1) hipLaunchKernelGGL((k_loglik_casecontrol_pf<DD, 1>), dim3(nb), dim3(256), 0, h->stream, v, cand, h->xr, h->partials);
+        else if (pf) hipLaunchKernelGGL((k_loglik_casecontrol_pf<DD, 2>), dim3(nb), dim3(256), 0, h->stream, v, cand, h->xr, h->partials);
         else if (M == 1) hipLaunchKernelGGL((k_loglik_casecontrol<DD, 1>), dim3(nb), dim3(256), 0, h->stream, v, cand, h->partials);
         else hipLaunchKernelGGL((k_loglik_casecontrol<DD, 2>), dim3(nb), dim3(256), 0, h->stream, v, cand, h->partials);
     }
@@ -338,7 +350,7 @@ void dlsm_destroy(dlsm_chain *h) {
                     h->lab_nk, h->lab_w, h->spec, h->nctrl, h->stamps, h->lsm, h->trace_X, h->trace_ic,
                     h->trace_logp, h->hops, h->hops_max, h->pipe, h->post_zt, h->post_cooc,
                     h->trace_radii, h->hdp, h->hdp_buf, h->htr_mu, h->htr_sigma, h->htr_beta,
-                    h->htr_w, h->htr_lambda, h->htr_hyper, h->htr_z};
+                    h->htr_w, h->htr_lambda, h->htr_hyper, h->htr_z, h->xr};
     for (void *p : ptrs) if (p) hipFree(p);
     if (h->hsmall) hipHostFree(h->hsmall);
     if (h->timer0) hipEventDestroy(h->timer0);
@@ -1006,8 +1018,10 @@ static int launch_sweep_ccpipe(dlsm_chain *h, IterRef iter, bool alloc_only = fa
     const size_t n_tot = (size_t)2 * T * CP_B * CP_SUBS;
     const size_t n_ent = (size_t)2 * T * cap * CP_B;
     const size_t n_cnt = (size_t)2 * T * CP_B * 2;
-    // doubles: prop | tot | xval | oval | consts(2) ; int32: xidx | oidx | cnt ; uint64: accmask
-    const size_t need = (n_prop + n_tot + 2 * n_ent + 2) * sizeof(double) +
+    const size_t n_rec = (size_t)T * N * cp_record_width(DD);
+    // doubles: prop | tot | xval | oval | consts(2) | cur | snap ; int32: xidx | oidx | cnt ;
+    // uint64: accmask
+    const size_t need = (n_prop + n_tot + 2 * n_ent + 2 + 2 * n_rec) * sizeof(double) +
                         even2(2 * n_ent + n_cnt) * sizeof(int32_t) +
                         (size_t)T * CP_WAVES * sizeof(unsigned long long);
     if (h->pipe_cap < need) {
@@ -1020,7 +1034,8 @@ static int launch_sweep_ccpipe(dlsm_chain *h, IterRef iter, bool alloc_only = fa
     CcPipeBuf pb;
     pb.prop = h->pipe; pb.tot = pb.prop + n_prop; pb.xval = pb.tot + n_tot; pb.oval = pb.xval + n_ent;
     double *consts = pb.oval + n_ent;
-    pb.xidx = (int32_t *)(consts + 2); pb.oidx = pb.xidx + n_ent; pb.cnt = pb.oidx + n_ent;
+    pb.cur = consts + 2; pb.snap = pb.cur + n_rec;
+    pb.xidx = (int32_t *)(pb.snap + n_rec); pb.oidx = pb.xidx + n_ent; pb.cnt = pb.oidx + n_ent;
     pb.accmask = (unsigned long long *)(pb.xidx + even2(2 * n_ent + n_cnt));
     pb.nctrl = h->nctrl; pb.cap = cap; pb.nbat = nbat;
     PipeBuf pp{};                   // the proposal kernel's view: proposals + its two constants
@@ -1028,6 +1043,8 @@ static int launch_sweep_ccpipe(dlsm_chain *h, IterRef iter, bool alloc_only = fa
     ChainView v = h->view();
     hipLaunchKernelGGL((k_pipe_propose<DD>), dim3((N + 255) / 256, T), dim3(256), 0, h->stream, v,
                        pp, iter);
+    hipLaunchKernelGGL((k_ccpipe_pack<DD>), dim3((unsigned)(((size_t)T * N + 255) / 256)), dim3(256), 0,
+                       h->stream, v, pb);
     const int nodes_max = ((T + 1) / 2 + T / 2) * std::min(CP_B, N);
     const int ne_wg = std::max(1, std::min(std::max(h->n_cu / 2, h->n_cu - T),
                                            (nodes_max + CP_GROUPS - 1) / CP_GROUPS));

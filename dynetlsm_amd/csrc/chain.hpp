@@ -113,6 +113,7 @@ struct dlsm_chain {
     int K = 0; bool have_prior = false;
     // scratch
     double *partials = nullptr; size_t partials_cap = 0;   // doubles
+    double *xr = nullptr; size_t xr_cap = 0;               // packed (x, r, r') records (case-control)
     double *dsmall = nullptr;      // 64 doubles of device scratch
     double *hsmall = nullptr;      // 64 doubles of pinned host scratch
     double *xref = nullptr;        // T*N*D (procrustes reference staging)

@@ -40,10 +40,34 @@ struct CcPipeBuf {
     double *xval, *oval;     // [2][T][cap][CP_B] : cross / own corrections, entry-major
     int32_t *xidx, *oidx;    // same shape: index of the node inside its batch
     int32_t *cnt;            // [2][T][CP_B][2] : entries of the two lists
+    double *cur, *snap;      // [T][N][RW] : (x[D], r) records of the current / the snapshot positions
     unsigned long long *accmask;   // [T][CP_WAVES] : accepted nodes of the last resolved batch
     const int32_t *nctrl;    // valid controls per (t, i, direction)
     int cap, nbat;
 };
+
+// A gathered term needs its partner's position and radius: one record (32 bytes up to d = 3)
+// instead of two arrays halves the cache-line requests the evaluator is bound by.  `cur` follows
+// the chain (the resolver writes accepted positions into it), `snap` keeps the positions of
+// the sweep's start for the nodes that are not resolved yet.
+__host__ __device__ constexpr int cp_record_width(int D) { return D + 1 <= 4 ? 4 : 8; }
+template <int D>
+__global__ __launch_bounds__(256) void k_ccpipe_pack(ChainView c, CcPipeBuf pb) {
+    constexpr int RW = cp_record_width(D);
+    const long q = (long)blockIdx.x * 256 + threadIdx.x;
+    if (q >= (long)c.T * c.N) return;
+    double rec[RW];
+#pragma unroll
+    for (int d = 0; d < RW; ++d) rec[d] = 0.0;
+#pragma unroll
+    for (int d = 0; d < D; ++d) rec[d] = c.X[q * D + d];
+    rec[D] = c.radii[q % c.N];
+#pragma unroll
+    for (int d = 0; d < RW; d += 2) {
+        *(double2 *)(pb.cur + q * RW + d) = make_double2(rec[d], rec[d + 1]);
+        *(double2 *)(pb.snap + q * RW + d) = make_double2(rec[d], rec[d + 1]);
+    }
+}
 
 // terms of the four lists of a node in one order: in-edges, out-edges, in-controls,
 // out-controls (kinds 0..3)
@@ -145,7 +169,8 @@ __device__ __forceinline__ void ccpipe_eval_item(const ChainView &c, const CcPip
             if (s < sub) { bx += a; bo += b; }
             tx += a; to += b;
         }
-        const double *Xt = c.X + (size_t)t * N * D;
+        constexpr int RW = cp_record_width(D);
+        const double *cur = pb.cur + (size_t)t * N * RW, *snap = pb.snap + (size_t)t * N * RW;
         const double *props = pb.prop + (size_t)t * N * PW;
         double xk0[D], xk1[D];
 #pragma unroll
@@ -165,11 +190,11 @@ __device__ __forceinline__ void ccpipe_eval_item(const ChainView &c, const CcPip
             bool isx = false, iso = false;
             double h = 0.0;
             if (e >= 0) {
-                const double *src = e < jprev ? Xt + (size_t)e * D : props + (size_t)e * PW + D + 2;
+                const double *src = (e < jprev ? cur : snap) + (size_t)e * RW;
                 double xe[D];
 #pragma unroll
                 for (int d = 0; d < D; ++d) xe[d] = src[d];
-                const double re = c.radii[e];
+                const double re = src[D];
                 const bool in_dir = (kind == 0 || kind == 2);
                 const double wsp = kind < 2 ? 1.0 : (kind == 2 ? nd.adj_in : nd.adj_out);
                 const double contrib = cc_term_delta_fast<D>(xe, xk0, xk1, e == jk, in_dir, kind < 2,
@@ -301,7 +326,10 @@ __device__ __forceinline__ void ccpipe_resolve(const ChainView &c, const CcPipeB
         const size_t tj = (size_t)t * N + j0 + k;
         if (accepted) {
 #pragma unroll
-            for (int d = 0; d < D; ++d) c.X[tj * D + d] = x1[d];
+            for (int d = 0; d < D; ++d) {
+                c.X[tj * D + d] = x1[d];
+                pb.cur[tj * cp_record_width(D) + d] = x1[d];
+            }
         }
         metropolis_bookkeeping(st, na, ns, un, c.tune, c.tune_interval, accepted);
         c.step[tj] = st; c.nacc[tj] = na; c.nsteps[tj] = ns; c.until[tj] = un;

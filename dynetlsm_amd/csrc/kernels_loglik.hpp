@@ -433,6 +433,33 @@ __global__ __launch_bounds__(256) void k_loglik_casecontrol(
     }
 }
 
+// Packed records for the gathers of the case-control log-likelihood: [T][N][RW] doubles
+// (x[D], r, r') with r / r' the radii of the two candidates.  A term gathers the position and
+// the radius of a random node: from separate arrays those are two cache-line requests for 16 +
+// 8 useful bytes, and the kernel is bound by exactly that request rate (6 M terms per pass at
+// C4); from one 32-byte record (64 at d > 2) it is one.
+__host__ __device__ constexpr int llcc_record_width(int D) { return D + 2 <= 4 ? 4 : 8; }
+template <int D>
+__global__ __launch_bounds__(256) void k_pack_xr(const double *__restrict__ X,
+                                                 const double *__restrict__ r0,
+                                                 const double *__restrict__ r1, long nodes, int N,
+                                                 double *__restrict__ XR) {
+    constexpr int RW = llcc_record_width(D);
+    const long q = (long)blockIdx.x * 256 + threadIdx.x;
+    if (q >= nodes) return;
+    const int i = (int)(q % N);
+    double rec[RW];
+#pragma unroll
+    for (int d = 0; d < RW; ++d) rec[d] = 0.0;
+#pragma unroll
+    for (int d = 0; d < D; ++d) rec[d] = X[q * D + d];
+    rec[D] = r0[i];
+    rec[D + 1] = r1[i];
+#pragma unroll
+    for (int d = 0; d < RW; d += 2)
+        *(double2 *)(XR + q * RW + d) = make_double2(rec[d], rec[d + 1]);
+}
+
 // The same with every load of a wavefront's LLCC_NODES / 4 nodes issued before the first
 // use (degrees, then the out-edge and control indices, then the gathered positions and
 // radii): the kernel is a chain of gather latencies, and four nodes in turn are four chains.
@@ -440,8 +467,9 @@ __global__ __launch_bounds__(256) void k_loglik_casecontrol(
 // and the same arithmetic per term.
 template <int D, int M>
 __global__ __launch_bounds__(256) void k_loglik_casecontrol_pf(
-    ChainView c, LoglikCand cand, double *__restrict__ partials) {
+    ChainView c, LoglikCand cand, const double *__restrict__ XR, double *__restrict__ partials) {
     constexpr int NPW = LLCC_NODES / 4;
+    constexpr int RW = llcc_record_width(D);
     __shared__ double sRed[4 * M];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long nodes = (long)c.T * c.N;
@@ -475,19 +503,22 @@ __global__ __launch_bounds__(256) void k_loglik_casecontrol_pf(
 #pragma unroll
     for (int r = 0; r < NPW; ++r) {
         const long nn = node[r] < nodes ? node[r] : 0;
-        const int t = (int)(nn / c.N), i = (int)(nn % c.N);
-        const double *Xt = c.X + (size_t)t * c.N * D;
+        const int t = (int)(nn / c.N);
+        const double *Rt = XR + (size_t)t * c.N * RW;
+        {
+            const double *rec = XR + (size_t)nn * RW;
 #pragma unroll
-        for (int d = 0; d < D; ++d) xi[r][d] = Xt[(size_t)i * D + d];
-        ri0[r] = cand.radii[0][i];
-        ri1[r] = two_radii ? cand.radii[M - 1][i] : ri0[r];
+            for (int d = 0; d < D; ++d) xi[r][d] = rec[d];
+            ri0[r] = rec[D];
+            ri1[r] = rec[D + 1];
+        }
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
-            const int ee = max(e[r][s], 0);
+            const double *rec = Rt + (size_t)max(e[r][s], 0) * RW;
 #pragma unroll
-            for (int d = 0; d < D; ++d) xe[r][s][d] = Xt[(size_t)ee * D + d];
-            re0[r][s] = cand.radii[0][ee];
-            re1[r][s] = two_radii ? cand.radii[M - 1][ee] : re0[r][s];
+            for (int d = 0; d < D; ++d) xe[r][s][d] = rec[d];
+            re0[r][s] = rec[D];
+            re1[r][s] = rec[D + 1];
         }
     }
     double bin[M], bout[M];
