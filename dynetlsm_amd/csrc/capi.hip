@@ -1015,7 +1015,7 @@ static int launch_sweep_ccpipe(dlsm_chain *h, IterRef iter, bool alloc_only = fa
     const int cap = std::max(1, h->Din + h->Dout + 2 * h->C);   // either list may hold every term
     auto even2 = [](size_t n) { return (n + 1) / 2 * 2; };
     const size_t n_prop = even2((size_t)T * N * (2 * DD + 2));
-    const size_t n_tot = (size_t)2 * T * CP_B * CP_SUBS;
+    const size_t n_tot = (size_t)2 * T * CP_B;
     const size_t n_ent = (size_t)2 * T * cap * CP_B;
     const size_t n_cnt = (size_t)2 * T * CP_B * 2;
     const size_t n_rec = (size_t)T * N * cp_record_width(DD);
@@ -1047,7 +1047,7 @@ static int launch_sweep_ccpipe(dlsm_chain *h, IterRef iter, bool alloc_only = fa
                        h->stream, v, pb);
     const int nodes_max = ((T + 1) / 2 + T / 2) * std::min(CP_B, N);
     const int ne_wg = std::max(1, std::min(std::max(h->n_cu / 2, h->n_cu - T),
-                                           (nodes_max + CP_GROUPS - 1) / CP_GROUPS));
+                                           (nodes_max + CP_WAVES - 1) / CP_WAVES));
     const int last = T > 1 ? nbat : nbat - 1;
     for (int l = -1; l <= last; ++l) {
         const bool any_eval = (l + 1 < nbat) || (T > 1 && l >= 0 && l < nbat);

@@ -18,7 +18,7 @@
 // A fixed point of a -> F(a) satisfies the triangular system, whose solution is unique, so it
 // is the sequential scan's result.  Batches of 1024 nodes: ceil(N / 1024) + 2 launches per
 // sweep (12 at C4), each with T resolver workgroups (thread = node) beside ~250 evaluator
-// workgroups (four wavefronts per node).  The lists are stored entry-major ([entry][node]) so
+// workgroups (one wavefront per node, every load of a gather level in flight together).  The lists are stored entry-major ([entry][node]) so
 // that the resolver's thread-per-node walks are coalesced; a node's first CP_OWN_REGS own
 // entries stay in registers across the passes of the solve.  Same snapshot rule, same
 // one-batch lag of the odd slices, same decisions as the dense form and the scalar oracle.
@@ -30,13 +30,11 @@ namespace dlsm {
 constexpr int CP_B = 1024;              // nodes per batch = threads of the resolver
 constexpr int CP_THREADS = 1024;
 constexpr int CP_WAVES = CP_THREADS / 64;
-constexpr int CP_SUBS = 4;              // wavefronts per node in the evaluator
-constexpr int CP_GROUPS = CP_WAVES / CP_SUBS;   // nodes per evaluator workgroup round
 constexpr int CP_OWN_REGS = 16;         // own entries a resolver thread keeps in registers
 
 struct CcPipeBuf {
     double *prop;            // [T][N][2D + 2] : x1[D], u, (unused), x0[D] (snapshot)
-    double *tot;             // [2][T][CP_B][CP_SUBS] : partial log-ratio of node k (snapshot neighbours)
+    double *tot;             // [2][T][CP_B] : log-ratio of node k with its partners at their snapshot / final positions
     double *xval, *oval;     // [2][T][cap][CP_B] : cross / own corrections, entry-major
     int32_t *xidx, *oidx;    // same shape: index of the node inside its batch
     int32_t *cnt;            // [2][T][CP_B][2] : entries of the two lists
@@ -133,102 +131,96 @@ __device__ __forceinline__ double cc_term_delta_fast(const double *xn, const dou
     return (edge ? (e1 - e0) : 0.0) - wsp * sp;
 }
 
-// One wavefront: quarter `sub` of the terms of node k of batch `be` in slice t; the four
-// wavefronts of a node are consecutive wavefronts of one workgroup (group `grp`) and agree on
-// the positions of their entries in the node's two lists through `sCnt`.  All wavefronts of
-// the workgroup call this together (barriers inside); `valid` = the group has a node.
+// One wavefront: node k of batch `be` in slice t, its terms four 64-term chunks at a time with
+// every load of a level issued together (list indices, then the partners' records, then the
+// window partners' proposals): the item is a chain of gather latencies, and a wavefront that owns
+// the whole node needs neither a second pass over the indices nor a barrier to place its entries
+// in the node's two lists.
 template <int D>
-__device__ __forceinline__ void ccpipe_eval_item(const ChainView &c, const CcPipeBuf &pb, bool valid,
-                                                 int be, int t, int k, int sub, int grp, int lane,
-                                                 int (*sCnt)[CP_SUBS][2]) {
+__device__ __forceinline__ void ccpipe_eval_item(const ChainView &c, const CcPipeBuf &pb, int be,
+                                                 int t, int k, int lane) {
     constexpr int PW = 2 * D + 2;
+    constexpr int RW = cp_record_width(D);
+    constexpr int NCH = 4;
     const int N = c.N;
     const int j0 = be * CP_B, jk = j0 + k;
     const int jprev = max(0, j0 - CP_B);       // nodes >= jprev: snapshot positions
     const int bb = be & 1;
-    CcNode nd{};
-    if (valid) nd = cc_node(c, pb.nctrl, t, jk);
-    // pass A: how many of this quarter's terms point into the window
-    int ncx = 0, nco_ = 0;
-    if (valid) {
-        for (int q0 = 64 * sub; q0 < nd.total; q0 += 64 * CP_SUBS) {
-            const int q = q0 + lane;
-            int kind, e = -1;
-            if (q < nd.total) e = cc_term(c, nd, q, kind);
-            ncx += __popcll(__ballot(e >= jprev && e < j0));
-            nco_ += __popcll(__ballot(e >= j0 && e < jk));
-        }
-        if (lane == 0) { sCnt[grp][sub][0] = ncx; sCnt[grp][sub][1] = nco_; }
+    const CcNode nd = cc_node(c, pb.nctrl, t, jk);
+    const double *cur = pb.cur + (size_t)t * N * RW, *snap = pb.snap + (size_t)t * N * RW;
+    const double *props = pb.prop + (size_t)t * N * PW;
+    double xk0[D], xk1[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        xk0[d] = props[(size_t)jk * PW + D + 2 + d];
+        xk1[d] = props[(size_t)jk * PW + d];
     }
-    __syncthreads();
-    if (valid) {
-        int bx = 0, bo = 0, tx = 0, to = 0;
+    const double bin = c.intercept[0], bout = c.intercept[1];
+    const double irj = 1.0 / c.radii[jk];
+    const size_t lbase = ((size_t)bb * c.T + t) * pb.cap * CP_B + k;      // + entry * CP_B
+    const unsigned long long below = (1ull << lane) - 1ull;
+    double acc = 0.0;
+    int bx = 0, bo = 0;
+    for (int q0 = 0; q0 < nd.total; q0 += 64 * NCH) {
+        int e[NCH], kind[NCH];
 #pragma unroll
-        for (int s = 0; s < CP_SUBS; ++s) {
-            const int a = sCnt[grp][s][0], b = sCnt[grp][s][1];
-            if (s < sub) { bx += a; bo += b; }
-            tx += a; to += b;
+        for (int u = 0; u < NCH; ++u) {
+            const int q = q0 + 64 * u + lane;
+            kind[u] = 0;
+            e[u] = q < nd.total ? cc_term(c, nd, q, kind[u]) : -1;
         }
-        constexpr int RW = cp_record_width(D);
-        const double *cur = pb.cur + (size_t)t * N * RW, *snap = pb.snap + (size_t)t * N * RW;
-        const double *props = pb.prop + (size_t)t * N * PW;
-        double xk0[D], xk1[D];
+        double xe[NCH][D], re[NCH];
 #pragma unroll
-        for (int d = 0; d < D; ++d) {
-            xk0[d] = props[(size_t)jk * PW + D + 2 + d];
-            xk1[d] = props[(size_t)jk * PW + d];
+        for (int u = 0; u < NCH; ++u) {
+            const int ee = max(e[u], 0);
+            const double *src = (ee < jprev ? cur : snap) + (size_t)ee * RW;
+#pragma unroll
+            for (int d = 0; d < D; ++d) xe[u][d] = src[d];
+            re[u] = src[D];
         }
-        const double bin = c.intercept[0], bout = c.intercept[1];
-        const double irj = 1.0 / c.radii[jk];
-        const size_t lbase = ((size_t)bb * c.T + t) * pb.cap * CP_B + k;      // + entry * CP_B
-        const unsigned long long below = (1ull << lane) - 1ull;
-        double acc = 0.0;
-        for (int q0 = 64 * sub; q0 < nd.total; q0 += 64 * CP_SUBS) {
-            const int q = q0 + lane;
-            int kind = 0, e = -1;
-            if (q < nd.total) e = cc_term(c, nd, q, kind);
-            bool isx = false, iso = false;
+        bool win[NCH];
+        double xe1[NCH][D];
+#pragma unroll
+        for (int u = 0; u < NCH; ++u) {     // window partners: their proposals too
+            win[u] = e[u] >= jprev && e[u] < jk;
+            const int ee = win[u] ? e[u] : jk;
+#pragma unroll
+            for (int d = 0; d < D; ++d) xe1[u][d] = props[(size_t)ee * PW + d];
+        }
+#pragma unroll
+        for (int u = 0; u < NCH; ++u) {
+            if (q0 + 64 * u >= nd.total) break;             // wave-uniform
             double h = 0.0;
-            if (e >= 0) {
-                const double *src = (e < jprev ? cur : snap) + (size_t)e * RW;
-                double xe[D];
-#pragma unroll
-                for (int d = 0; d < D; ++d) xe[d] = src[d];
-                const double re = src[D];
-                const bool in_dir = (kind == 0 || kind == 2);
-                const double wsp = kind < 2 ? 1.0 : (kind == 2 ? nd.adj_in : nd.adj_out);
-                const double contrib = cc_term_delta_fast<D>(xe, xk0, xk1, e == jk, in_dir, kind < 2,
-                                                             wsp, bin, bout, irj, re, c.squared);
+            if (e[u] >= 0) {
+                const bool in_dir = (kind[u] == 0 || kind[u] == 2);
+                const double wsp = kind[u] < 2 ? 1.0 : (kind[u] == 2 ? nd.adj_in : nd.adj_out);
+                const double contrib = cc_term_delta_fast<D>(xe[u], xk0, xk1, e[u] == jk, in_dir,
+                                                             kind[u] < 2, wsp, bin, bout, irj, re[u],
+                                                             c.squared);
                 acc += contrib;
-                isx = e >= jprev && e < j0;
-                iso = e >= j0 && e < jk;
-                if (isx || iso) {       // a node of the window: its acceptance changes this term
-                    double xe1[D];
-#pragma unroll
-                    for (int d = 0; d < D; ++d) xe1[d] = props[(size_t)e * PW + d];
-                    h = cc_term_delta_fast<D>(xe1, xk0, xk1, false, in_dir, kind < 2, wsp, bin, bout,
-                                              irj, re, c.squared) - contrib;
-                }
+                if (win[u])             // its acceptance changes this term
+                    h = cc_term_delta_fast<D>(xe1[u], xk0, xk1, false, in_dir, kind[u] < 2, wsp, bin,
+                                              bout, irj, re[u], c.squared) - contrib;
             }
+            const bool isx = win[u] && e[u] < j0, iso = win[u] && e[u] >= j0;
             const unsigned long long mx = __ballot(isx), mo = __ballot(iso);
             if (isx) {
                 const size_t p = lbase + (size_t)(bx + __popcll(mx & below)) * CP_B;
-                pb.xidx[p] = e - jprev; pb.xval[p] = h;
+                pb.xidx[p] = e[u] - jprev; pb.xval[p] = h;
             }
             if (iso) {
                 const size_t p = lbase + (size_t)(bo + __popcll(mo & below)) * CP_B;
-                pb.oidx[p] = e - j0; pb.oval[p] = h;
+                pb.oidx[p] = e[u] - j0; pb.oval[p] = h;
             }
             bx += __popcll(mx); bo += __popcll(mo);
         }
-        const double total = wave_sum_all(acc);
-        if (lane == 0) {
-            const size_t slot = ((size_t)bb * c.T + t) * CP_B + k;
-            pb.tot[slot * CP_SUBS + sub] = total;
-            if (sub == 0) { pb.cnt[slot * 2] = tx; pb.cnt[slot * 2 + 1] = to; }
-        }
     }
-    __syncthreads();                        // sCnt is reused by the next round
+    const double total = wave_sum_all(acc);
+    if (lane == 0) {
+        const size_t slot = ((size_t)bb * c.T + t) * CP_B + k;
+        pb.tot[slot] = total;
+        pb.cnt[slot * 2] = bx; pb.cnt[slot * 2 + 1] = bo;
+    }
 }
 
 // Resolve batch b of slice t: thread k owns node k of the batch.
@@ -259,9 +251,7 @@ __device__ __forceinline__ void ccpipe_resolve(const ChainView &c, const CcPipeB
         oi[e] = e < nown ? pb.oidx[p] : 0;
         ov[e] = pb.oval[p];
     }
-    double r = 0.0;
-#pragma unroll
-    for (int s = 0; s < CP_SUBS; ++s) r += pb.tot[slot * CP_SUBS + s];
+    double r = pb.tot[slot];
     const double *pr = pb.prop + ((size_t)t * N + j0 + kc) * PW;
     double x0[D], x1[D];
 #pragma unroll
@@ -344,7 +334,6 @@ __global__ __launch_bounds__(CP_THREADS) void k_ccpipe_step(ChainView c, CcPipeB
     __shared__ unsigned long long sMask[2][CP_WAVES];
     __shared__ unsigned long long sPrev[CP_WAVES];
     __shared__ int sChanged;
-    __shared__ int sCnt[CP_GROUPS][CP_SUBS][2];
     const int T = c.T;
     if ((int)blockIdx.x < T) {
         const int t = blockIdx.x;
@@ -352,24 +341,22 @@ __global__ __launch_bounds__(CP_THREADS) void k_ccpipe_step(ChainView c, CcPipeB
         if (b >= 0 && b < pb.nbat) ccpipe_resolve<D>(c, pb, b, t, sMask, sPrev, &sChanged);
         return;
     }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int sub = wave & (CP_SUBS - 1), grp = wave / CP_SUBS;
+    const int lane = threadIdx.x & 63;
     const int nE = (T + 1) / 2, nO = T / 2;
     const int beE = l + 1, beO = l;
     const int nbE = (beE >= 0 && beE < pb.nbat) ? min(CP_B, c.N - beE * CP_B) : 0;
     const int nbO = (beO >= 0 && beO < pb.nbat) ? min(CP_B, c.N - beO * CP_B) : 0;
     const int nodesE = nE * nbE, nodes = nodesE + nO * nbO;
-    // every wavefront of the workgroup runs the same number of rounds (barriers inside)
-    for (int base = ((int)blockIdx.x - T) * CP_GROUPS; base < nodes;
-         base += ((int)gridDim.x - T) * CP_GROUPS) {
-        const int q = base + grp;
-        const bool valid = q < nodes;
+    const int nwaves = ((int)gridDim.x - T) * CP_WAVES;
+    const int gw = __builtin_amdgcn_readfirstlane(
+        ((int)blockIdx.x - T) * CP_WAVES + (int)(threadIdx.x >> 6));
+    for (int q = gw; q < nodes; q += nwaves) {
         const bool odd = q >= nodesE;
         const int qq = odd ? q - nodesE : q;
-        const int nb = max(odd ? nbO : nbE, 1);
+        const int nb = odd ? nbO : nbE;
         const int k = qq % nb;
         const int t = 2 * (qq / nb) + (odd ? 1 : 0);
-        ccpipe_eval_item<D>(c, pb, valid, odd ? beO : beE, t, k, sub, grp, lane, sCnt);
+        ccpipe_eval_item<D>(c, pb, odd ? beO : beE, t, k, lane);
     }
 }
 
