@@ -276,3 +276,44 @@ def test_pipelined_sweep_with_parts_longer_than_the_prefetch(eng):
     np.testing.assert_array_equal(out[3][1], out[4][1])
     np.testing.assert_allclose(out[3][0], out[4][0], atol=1e-9)
     assert 0.2 < out[4][1].mean() / 2 < 0.999
+
+
+@pytest.mark.parametrize('loop', ['device', 'host'])
+def test_c3_facade_fit_logps_recomputed_by_the_oracle(eng, loop):
+    """config 3 through the estimator facade: DynamicNetworkHDPLPCM(...).fit at T=10, N=2000,
+    K_max=20 for a few iterations; the log-posterior trace is recomputed by the oracle
+    (hdp_lpcm.py:1188-1280 restated) from the stored samples"""
+    import torch  # noqa: F401
+    from oracle import hdp_loop_oracle as hlo
+    from dynetlsm_amd.synthetic import synthetic_hdp_network
+    net = synthetic_hdp_network(T=10, N=2000, D=2, density=0.03, seed=0)
+    K = 20
+    rs = np.random.RandomState(5)
+    mu0 = np.zeros((K, 2)); mu0[:6] = net['mu_true']; mu0[6:] = 3.0 * rs.randn(K - 6, 2)
+    sg0 = np.full(K, float(net['sigma_true'].mean()))
+    n_iter = 5
+    m = eng.DynamicNetworkHDPLPCM(n_iter=n_iter, tune=None, burn=None, n_components=K,
+                                  random_state=3, selection_type='map', hdp_loop=loop)
+    m.fit(net['Y'], init=dict(X=net['X_init'], intercept=[net['intercept']], mu=mu0, sigma=sg0,
+                              z=net['z_true']))
+    assert m.loop_kind_ == ('device-resident' if loop == 'device' else 'host-driven')
+    assert m.chain_.resolve_sweep_algo(0) == 4
+    ip = np.atleast_1d(m.intercept_prior)
+    its = range(1, n_iter) if loop == 'device' else [n_iter - 1]
+    for it in its:
+        hp = m.hyper_
+        h = hlo.Hyper(a=hp.a, a0=hp.a0, b0=hp.b0, c0=hp.c0, d0=hp.d0, lambda_prior=hp.lambda_prior,
+                      lambda_variance_prior=hp.lambda_variance_prior)
+        if loop == 'device':            # the hyper-parameters of that iteration
+            (h.gamma, h.alpha_init, h.alpha, h.kappa, h.mean_variance_prior, h.b) = m.hypers_[it]
+        else:                           # the host loop keeps the last ones
+            (h.gamma, h.alpha_init, h.alpha, h.kappa, h.mean_variance_prior, h.b) = (
+                hp.gamma, hp.alpha_init, hp.alpha, hp.kappa,
+                float(np.ravel(hp.mean_variance_prior)[0]), hp.b)
+        ll = orc.dynamic_network_loglikelihood_undirected(net['Y'], m.Xs_[it], m.intercepts_[it, 0])
+        want = hlo.log_posterior(ll, m.Xs_[it], m.intercepts_[it], m.mus_[it], m.sigmas_[it],
+                                 m.zs_[it], m.weights_[it], m.betas_[it], m.lambdas_[it], h, ip,
+                                 m.intercept_variance_prior)
+        np.testing.assert_allclose(m.logps_[it], want, rtol=1e-9)
+    assert (m.zs_[-1] != m.zs_[0]).any() and np.isfinite(m.logps_).all()
+    np.testing.assert_allclose(m.weights_[-1].sum(-1)[1:], 1.0, rtol=1e-12)
