@@ -48,11 +48,6 @@ int enqueue_hdp_iteration(dlsm_chain *h, int it) {
     rc = loglik_records(h, 2, h->lsm->cand, nullptr, nullptr, &nrec); if (rc) return rc;
     ChainView v = h->view();
     HdpLoopBuf hb = hdp_loop_buf(h);
-    {
-        ProfScope ps(h, DLSM_K_FINALIZE);
-        hipLaunchKernelGGL(k_hdp_intercept, dim3(1), dim3(256), 0, h->stream, h->partials, nrec, h->lsm,
-                           h->hdp, h->intercept, h->trace_ic, ir);
-    }
     {   // label block update (sample_labels.py:134-190) with the transition matrices on the device
         ProfScope ps(h, DLSM_K_LABELS);
         const size_t lds_tables = (size_t)LAB_WAVES * 2 * T * K * sizeof(double);
@@ -76,17 +71,14 @@ int enqueue_hdp_iteration(dlsm_chain *h, int it) {
     HdpParams hp{h->mu, h->sigma, h->lab_w, 0.0, h->hdp_cfg.a, 0.0, &h->hdp->lmbda, &h->hdp->b};
     const dim3 grid(K, T), block(HDP_THREADS);
     hipLaunchKernelGGL((k_hdp_label_sums<DD, HDP_SUMS_MEAN>), grid, block, 0, h->stream, v, hp, hb.S);
-    hipLaunchKernelGGL((k_hdp_draw_mu<DD>), dim3(1), dim3(64), 0, h->stream, v, hb, h->hdp, ir);
-    hipLaunchKernelGGL((k_hdp_label_sums<DD, HDP_SUMS_RESIDUAL>), grid, block, 0, h->stream, v, hp, hb.Q);
-    hipLaunchKernelGGL(k_hdp_draw_sigma, dim3(1), dim3(64), 0, h->stream, v, hb, h->hdp, ir);
-    hipLaunchKernelGGL((k_hdp_label_sums<DD, HDP_SUMS_LAMBDA>), grid, block, 0, h->stream, v, hp, hb.L);
+    hipLaunchKernelGGL((k_hdp_mu_residual<DD>), grid, block, 0, h->stream, v, hb, h->hdp, ir);
+    hipLaunchKernelGGL((k_hdp_sigma_lambda<DD>), grid, block, 0, h->stream, v, hb, h->hdp, ir);
     hipLaunchKernelGGL(k_hdp_hypers, dim3(1), dim3(HH_THREADS), 0, h->stream, v, hb, h->hdp, ir);
-    hipLaunchKernelGGL((k_hdp_label_sums<DD, HDP_SUMS_LOGP>), grid, block, 0, h->stream, v, hp, hb.LP);
-    hipLaunchKernelGGL(k_hdp_dirichlet_rows, grid, dim3(64), 0, h->stream, v, hb, h->hdp, hb.LPD);
+    hipLaunchKernelGGL((k_hdp_logp_sums<DD>), grid, block, 0, h->stream, v, hb, h->hdp);
     HdpTrace tr{h->trace_ic, h->trace_logp, h->htr_mu, h->htr_sigma, h->htr_beta, h->htr_w,
                 h->htr_lambda, h->htr_hyper};
     hipLaunchKernelGGL((k_hdp_finalize<DD>), dim3(1), dim3(HF_THREADS), 0, h->stream, v, hb, h->hdp,
-                       h->lsm, tr, ir);
+                       h->lsm, h->partials, nrec, h->intercept, tr, ir);
     HIPCHK(h, hipGetLastError());
     return DLSM_OK;
 }

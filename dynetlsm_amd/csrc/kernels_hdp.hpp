@@ -30,9 +30,12 @@ struct HdpParams {
     const double *lmbda_p = nullptr, *b_p = nullptr;
 };
 
+// the sums of workgroup (k, t) given cluster k's mean `mk`, variance `sk` and the scalars
 template <int D, int STAGE>
-__global__ __launch_bounds__(HDP_THREADS) void k_hdp_label_sums(ChainView c, HdpParams hp,
-                                                                double *__restrict__ out) {
+__device__ __forceinline__ void hdp_label_sums_wg(const ChainView &c, const double (&mk)[D], double sk,
+                                                  double lm, double a_, double hb_,
+                                                  const double *__restrict__ w,
+                                                  double *__restrict__ out) {
     constexpr int NV = STAGE == HDP_SUMS_MEAN ? D : (STAGE == HDP_SUMS_LAMBDA ? 2 : 1);
     __shared__ double buf[NV][HDP_THREADS / 64];
     const int k = blockIdx.x, t = blockIdx.y, tid = threadIdx.x;
@@ -41,13 +44,7 @@ __global__ __launch_bounds__(HDP_THREADS) void k_hdp_label_sums(ChainView c, Hdp
     const int32_t *zp = t > 0 ? c.z + (size_t)(t - 1) * N : nullptr;
     const double *Xt = c.X + (size_t)t * N * D;
     const double *Xp = t > 0 ? c.X + (size_t)(t - 1) * N * D : nullptr;
-    const double lm = hp.lmbda_p ? hp.lmbda_p[0] : hp.lmbda;
-    const double hb_ = hp.b_p ? hp.b_p[0] : hp.b;
-    double mk[D], sk = 1.0, lsk = 0.0;
-#pragma unroll
-    for (int d = 0; d < D; ++d) mk[d] = STAGE == HDP_SUMS_MEAN ? 0.0 : hp.mu[(size_t)k * D + d];
-    if (STAGE == HDP_SUMS_LAMBDA || STAGE == HDP_SUMS_LOGP) sk = hp.sigma[k];
-    if (STAGE == HDP_SUMS_LOGP) lsk = log(sk);
+    const double lsk = STAGE == HDP_SUMS_LOGP ? log(sk) : 0.0;
     double acc[NV];
 #pragma unroll
     for (int v = 0; v < NV; ++v) acc[v] = 0.0;
@@ -73,8 +70,8 @@ __global__ __launch_bounds__(HDP_THREADS) void k_hdp_label_sums(ChainView c, Hdp
                 acc[0] += ss;
             } else {
                 const int zprev = t > 0 ? zp[i] : 0;
-                acc[0] += log(hp.w[((size_t)t * K + zprev) * K + k]) - 0.5 * lsk - 0.5 * ss / sk -
-                          (0.5 * hp.a + 1.0) * lsk - 0.5 * hb_ / sk;
+                acc[0] += log(w[((size_t)t * K + zprev) * K + k]) - 0.5 * lsk - 0.5 * ss / sk -
+                          (0.5 * a_ + 1.0) * lsk - 0.5 * hb_ / sk;
             }
         } else {
             if (t > 0) {
@@ -95,6 +92,19 @@ __global__ __launch_bounds__(HDP_THREADS) void k_hdp_label_sums(ChainView c, Hdp
         const double s = block_sum_all<HDP_THREADS / 64>(acc[v], buf[v], tid);
         if (tid == 0) out[((size_t)t * K + k) * NV + v] = s;
     }
+}
+
+template <int D, int STAGE>
+__global__ __launch_bounds__(HDP_THREADS) void k_hdp_label_sums(ChainView c, HdpParams hp,
+                                                                double *__restrict__ out) {
+    const int k = blockIdx.x;
+    const double lm = hp.lmbda_p ? hp.lmbda_p[0] : hp.lmbda;
+    const double hb_ = hp.b_p ? hp.b_p[0] : hp.b;
+    double mk[D], sk = 1.0;
+#pragma unroll
+    for (int d = 0; d < D; ++d) mk[d] = STAGE == HDP_SUMS_MEAN ? 0.0 : hp.mu[(size_t)k * D + d];
+    if (STAGE == HDP_SUMS_LAMBDA || STAGE == HDP_SUMS_LOGP) sk = hp.sigma[k];
+    hdp_label_sums_wg<D, STAGE>(c, mk, sk, lm, hp.a, hb_, hp.w, out);
 }
 
 }  // namespace dlsm

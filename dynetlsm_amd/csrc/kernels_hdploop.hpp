@@ -13,9 +13,10 @@
 //   Dirichlet  hdp_lpcm.py:887-898        gamma variates (Marsaglia-Tsang, attempt a: normal from
 //                                         attempt 2a, uniforms from 2a + 1) normalised by their sum
 //   mu, sigma, lambda, hyper-parameters, concentration parameters: see each kernel.
-// Launch order per iteration (capi_hdp.hpp): k_hdp_intercept, [labels], k_hdp_tables,
-// k_hdp_globals, k_hdp_weights, sums<MEAN>, k_hdp_draw_mu, sums<RESIDUAL>, k_hdp_draw_sigma,
-// sums<LAMBDA>, k_hdp_hypers, sums<LOGP>, k_hdp_dirichlet_rows, k_hdp_finalize.
+// Launch order per iteration (capi_hdp.hpp): [labels], k_hdp_tables, k_hdp_globals,
+// k_hdp_weights, sums<MEAN>, k_hdp_mu_residual (mu drawn in the prologue), k_hdp_sigma_lambda
+// (sigma likewise), k_hdp_hypers, k_hdp_logp_sums (+ the Dirichlet rows), k_hdp_finalize (+ the
+// intercept's accept / reject).
 #pragma once
 #include "chain.hpp"
 #include "device_common.hpp"
@@ -161,35 +162,6 @@ struct HdpTrace {
     double *ic, *logp, *mu, *sigma, *beta, *w, *lambda, *hyper;
 };
 
-// ---- intercept step (sample_coefficients.py:76-86 around one fused two-candidate pass) -----
-__global__ __launch_bounds__(256) void k_hdp_intercept(const double *__restrict__ partials, int nrec,
-                                                       LsmDeviceState *lsm, HdpDeviceState *hs,
-                                                       double *__restrict__ intercept,
-                                                       double *__restrict__ trace_ic, IterRef ir) {
-    const int it = (int)ir.get();
-    __shared__ double scratch[4 * 256];
-    __shared__ double sums[4];
-    reduce_records(partials, nrec, 4, sums, scratch, threadIdx.x);
-    if (threadIdx.x == 0) {
-        const double b0 = lsm->cand[0], b1 = lsm->cand[1];
-        const double ll0 = b0 * sums[0] - sums[1] - sums[2];
-        const double ll1 = b1 * sums[0] - sums[1] - sums[3];
-        const double pm = lsm->intercept_prior[0], v = lsm->intercept_var;
-        const double lp0 = ll0 - (b0 - pm) * (b0 - pm) / (2 * v);
-        const double lp1 = ll1 - (b1 - pm) * (b1 - pm) / (2 * v);
-        const int accepted = !(lsm->logu >= lp1 - lp0);
-        const double b = accepted ? b1 : b0;
-        intercept[0] = b;
-        hs->ll = accepted ? ll1 : ll0;
-        double st = lsm->i_step[0];
-        int32_t na = lsm->i_nacc[0], ns = lsm->i_nsteps[0], un = lsm->i_until[0];
-        metropolis_bookkeeping(st, na, ns, un, lsm->i_tune, lsm->i_tune_interval, accepted);
-        lsm->i_step[0] = st; lsm->i_nacc[0] = na; lsm->i_nsteps[0] = ns; lsm->i_until[0] = un;
-        trace_ic[(size_t)it * 2] = b;
-        trace_ic[(size_t)it * 2 + 1] = 0.0;
-    }
-}
-
 // ---- tables: one wavefront per (t, j, k) cell ------------------------------------------------
 constexpr int HT_WAVES = 4;
 __global__ __launch_bounds__(64 * HT_WAVES) void k_hdp_tables(ChainView c, HdpLoopBuf hb,
@@ -313,13 +285,16 @@ __global__ __launch_bounds__(256) void k_hdp_weights(ChainView c, HdpLoopBuf hb,
     for (int q = tid; q < K * K; q += 256) hb.w[(size_t)t * K * K + q] = sGam[q] * sInv[q / K];
 }
 
-// ---- cluster means (hdp_lpcm.py:901-921): thread k ------------------------------------------------
+// ---- cluster means (hdp_lpcm.py:901-921) and variances (:924-938) -----------------------------------
+// The draw of cluster k needs T label sums and one Philox call: every workgroup (k, t) of the
+// label-sum pass that follows redoes it for its own k (same counters, same value) instead of
+// waiting for a launch of its own; the workgroup t = 0 files the value.
 template <int D>
-__global__ __launch_bounds__(64) void k_hdp_draw_mu(ChainView c, HdpLoopBuf hb,
-                                                    const HdpDeviceState *hs, IterRef ir) {
-    const int K = hb.K, T = c.T, k = threadIdx.x;
-    if (k >= K) return;
-    const HdpRng g = hdp_rng(c, ir.get());
+__device__ __forceinline__ void hdp_mu_of(const ChainView &c, const HdpLoopBuf &hb,
+                                          const HdpDeviceState *hs, uint32_t iter, int k,
+                                          double (&mu)[D]) {
+    const int K = hb.K, T = c.T;
+    const HdpRng g = hdp_rng(c, iter);
     const double lm = hs->lmbda, sk = hb.sigma[k];
     double pk = 1.0 / hs->mvp, mk[D];
 #pragma unroll
@@ -345,17 +320,15 @@ __global__ __launch_bounds__(64) void k_hdp_draw_mu(ChainView c, HdpLoopBuf hb,
         double u0, u1, z0, z1;
         g.u2(HK_MU, (uint32_t)k, (uint32_t)(d >> 1), u0, u1);
         box_muller(u0, u1, z0, z1);
-        hb.mu[(size_t)k * D + d] = mk[d] * pk + sd * z0;
-        if (d + 1 < D) hb.mu[(size_t)k * D + d + 1] = mk[d + 1] * pk + sd * z1;
+        mu[d] = mk[d] * pk + sd * z0;
+        if (d + 1 < D) mu[d + 1] = mk[d + 1] * pk + sd * z1;
     }
 }
 
-// ---- cluster variances (hdp_lpcm.py:924-938): thread k ---------------------------------------------
-__global__ __launch_bounds__(64) void k_hdp_draw_sigma(ChainView c, HdpLoopBuf hb,
-                                                       const HdpDeviceState *hs, IterRef ir) {
-    const int K = hb.K, T = c.T, D = c.D, k = threadIdx.x;
-    if (k >= K) return;
-    const HdpRng g = hdp_rng(c, ir.get());
+__device__ __forceinline__ double hdp_sigma_of(const ChainView &c, const HdpLoopBuf &hb,
+                                               const HdpDeviceState *hs, uint32_t iter, int k) {
+    const int K = hb.K, T = c.T;
+    const HdpRng g = hdp_rng(c, iter);
     long cnt = 0;
     double bk = 0.5 * hs->b;
     for (int t = 0; t < T; ++t) {
@@ -363,8 +336,40 @@ __global__ __launch_bounds__(64) void k_hdp_draw_sigma(ChainView c, HdpLoopBuf h
         cnt += ntk;
         if (ntk > 0) bk += 0.5 * hb.Q[(size_t)t * K + k];
     }
-    const double ak = 0.5 * ((double)cnt * D + hs->a);
-    hb.sigma[k] = 1.0 / (hdp_gamma(g, HK_SIGMA, (uint32_t)k, ak) * (1.0 / bk));
+    const double ak = 0.5 * ((double)cnt * c.D + hs->a);
+    return 1.0 / (hdp_gamma(g, HK_SIGMA, (uint32_t)k, ak) * (1.0 / bk));
+}
+
+// mu_k drawn in the prologue, then the squared residuals about it (stage RESIDUAL)
+template <int D>
+__global__ __launch_bounds__(HDP_THREADS) void k_hdp_mu_residual(ChainView c, HdpLoopBuf hb,
+                                                                 const HdpDeviceState *hs, IterRef ir) {
+    const int k = blockIdx.x;
+    double mk[D];
+    hdp_mu_of<D>(c, hb, hs, ir.get(), k, mk);
+    if (blockIdx.y == 0 && threadIdx.x == 0) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) hb.mu[(size_t)k * D + d] = mk[d];
+    }
+    hdp_label_sums_wg<D, HDP_SUMS_RESIDUAL>(c, mk, 1.0, hs->lmbda, 0.0, 0.0, nullptr, hb.Q);
+}
+
+// sigma_k drawn in the prologue (one lane per workgroup: a gamma variate), then the sums of the
+// blending coefficient's conditional (stage LAMBDA)
+template <int D>
+__global__ __launch_bounds__(HDP_THREADS) void k_hdp_sigma_lambda(ChainView c, HdpLoopBuf hb,
+                                                                  const HdpDeviceState *hs, IterRef ir) {
+    __shared__ double sSig;
+    const int k = blockIdx.x;
+    if (threadIdx.x == 0) {
+        sSig = hdp_sigma_of(c, hb, hs, ir.get(), k);
+        if (blockIdx.y == 0) hb.sigma[k] = sSig;
+    }
+    __syncthreads();
+    double mk[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) mk[d] = hb.mu[(size_t)k * D + d];
+    hdp_label_sums_wg<D, HDP_SUMS_LAMBDA>(c, mk, sSig, hs->lmbda, 0.0, 0.0, nullptr, hb.L);
 }
 
 // ---- blending coefficient, variance hyper-parameters, concentration parameters: one workgroup ------
@@ -488,10 +493,10 @@ __device__ __forceinline__ double dirichlet_term(double al, double x) {
     if (x <= 0.0) x = HDP_SMALL_EPS;
     return (al - 1.0 == 0.0 ? 0.0 : (al - 1.0) * log(x)) - lgamma(al);
 }
-__global__ __launch_bounds__(64) void k_hdp_dirichlet_rows(ChainView c, HdpLoopBuf hb,
-                                                           const HdpDeviceState *hs,
-                                                           double *__restrict__ out) {
-    const int K = hb.K, j = blockIdx.x, t = blockIdx.y, lane = threadIdx.x;
+// Dirichlet log-density of the row that workgroup (j, t) owns; first wavefront, lanes = components
+__device__ __forceinline__ double hdp_dirichlet_row(const HdpLoopBuf &hb, const HdpDeviceState *hs,
+                                                    int j, int t, int lane) {
+    const int K = hb.K;
     double total = 0.0;
     if (t >= 1) {
         double al = 0.0, v = 0.0;
@@ -514,19 +519,60 @@ __global__ __launch_bounds__(64) void k_hdp_dirichlet_rows(ChainView c, HdpLoopB
         total = (lgamma(wave_sum_all(al0)) + wave_sum_all(v0)) +
                 (lgamma(wave_sum_all(al1)) + wave_sum_all(v1));
     }
-    if (lane == 0) out[(size_t)t * K + j] = total;
+    return total;
+}
+
+// the node terms of the log-posterior (stage LOGP) and, on the workgroup's first wavefront, the
+// Dirichlet row (k, t)
+template <int D>
+__global__ __launch_bounds__(HDP_THREADS) void k_hdp_logp_sums(ChainView c, HdpLoopBuf hb,
+                                                               const HdpDeviceState *hs) {
+    const int k = blockIdx.x, t = blockIdx.y;
+    if (threadIdx.x < 64) {
+        const double v = hdp_dirichlet_row(hb, hs, k, t, threadIdx.x);
+        if (threadIdx.x == 0) hb.LPD[(size_t)t * hb.K + k] = v;
+    }
+    double mk[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) mk[d] = hb.mu[(size_t)k * D + d];
+    hdp_label_sums_wg<D, HDP_SUMS_LOGP>(c, mk, hb.sigma[k], hs->lmbda, hs->a, hs->b, hb.w, hb.LP);
 }
 
 // ---- log-posterior trace (hdp_lpcm.py:1188-1280) and the sample's trace rows: one workgroup -----------
 constexpr int HF_THREADS = 256;
+// (the intercept's accept / reject - sample_coefficients.py:76-86 around the fused two-candidate
+// pass whose records are still in `partials` - happens here too: nothing between the label
+// update and this kernel reads the intercept)
 template <int D>
 __global__ __launch_bounds__(HF_THREADS) void k_hdp_finalize(ChainView c, HdpLoopBuf hb,
-                                                             const HdpDeviceState *hs,
-                                                             const LsmDeviceState *lsm,
+                                                             HdpDeviceState *hs, LsmDeviceState *lsm,
+                                                             const double *__restrict__ partials,
+                                                             int nrec, double *__restrict__ intercept,
                                                              HdpTrace tr, IterRef ir) {
     __shared__ double red[2][HF_THREADS / 64];
+    __shared__ double scratch[4 * 256];
+    __shared__ double sums[4];
     const int K = hb.K, T = c.T, tid = threadIdx.x;
     const int it = (int)ir.get();
+    reduce_records(partials, nrec, 4, sums, scratch, tid);
+    if (tid == 0) {
+        const double b0 = lsm->cand[0], b1 = lsm->cand[1];
+        const double ll0 = b0 * sums[0] - sums[1] - sums[2];
+        const double ll1 = b1 * sums[0] - sums[1] - sums[3];
+        const double pm = lsm->intercept_prior[0], v = lsm->intercept_var;
+        const double lp0 = ll0 - (b0 - pm) * (b0 - pm) / (2 * v);
+        const double lp1 = ll1 - (b1 - pm) * (b1 - pm) / (2 * v);
+        const int accepted = !(lsm->logu >= lp1 - lp0);
+        intercept[0] = accepted ? b1 : b0;
+        hs->ll = accepted ? ll1 : ll0;
+        double st = lsm->i_step[0];
+        int32_t na = lsm->i_nacc[0], ns = lsm->i_nsteps[0], un = lsm->i_until[0];
+        metropolis_bookkeeping(st, na, ns, un, lsm->i_tune, lsm->i_tune_interval, accepted);
+        lsm->i_step[0] = st; lsm->i_nacc[0] = na; lsm->i_nsteps[0] = ns; lsm->i_until[0] = un;
+        tr.ic[(size_t)it * 2] = intercept[0];
+        tr.ic[(size_t)it * 2 + 1] = 0.0;
+    }
+    __syncthreads();
     // node terms of the label sums + the Dirichlet rows
     double acc = 0.0;
     for (int q = tid; q < T * K; q += HF_THREADS)
@@ -542,7 +588,7 @@ __global__ __launch_bounds__(HF_THREADS) void k_hdp_finalize(ChainView c, HdpLoo
     if (tid != 0) return;
     double lp = body + hs->ll;
     {   // intercept prior, cluster means, blending coefficient, hyper-priors
-        const double b = c.intercept[0], diff = b - lsm->intercept_prior[0];
+        const double b = intercept[0], diff = b - lsm->intercept_prior[0];
         lp -= 0.5 * (diff * diff) / lsm->intercept_var;
         double ss = 0.0;
         for (int q = 0; q < K * D; ++q) ss += hb.mu[q] * hb.mu[q];
