@@ -34,9 +34,11 @@ __all__ = ['DynamicNetworkHDPLPCM']
 
 def _geweke(trace, n_burn):
     """(z, p) of diagnostics.geweke_diag; (nan, nan) for traces too short for its AR fits"""
+    if not np.all(np.isfinite(np.asarray(trace)[n_burn:])):     # e.g. a -inf log-posterior at the start
+        return float('nan'), float('nan')
     try:
         return geweke_diag(trace, n_burn=n_burn)
-    except (ValueError, np.linalg.LinAlgError, ZeroDivisionError):
+    except (ValueError, TypeError, np.linalg.LinAlgError, ZeroDivisionError):
         return float('nan'), float('nan')
 
 
