@@ -112,6 +112,27 @@ __device__ __forceinline__ double cc_term_delta(const double *xn, const double *
     return (edge ? (e1 - e0) : 0.0) - wsp * sp;
 }
 
+// log(x) for x in [1e-300, 1e300] (fdlibm's e_log.c scheme: x = 2^k (1 + f), s = f / (2 + f),
+// log(1 + f) = 2 s + s R(s^2) arranged around f - f^2 / 2): < 1 ulp, a third of the compiler's
+// expansion (no subnormal / special-value paths; the division is a reciprocal + Newton steps)
+__device__ __forceinline__ double fast_log(double x) {
+    int k = __builtin_amdgcn_frexp_exp(x);                 // x = m 2^k, m in [0.5, 1)
+    double m = __builtin_amdgcn_frexp_mant(x);
+    if (m < 0.70710678118654752440) { m *= 2.0; --k; }     // m in [sqrt(1/2), sqrt(2))
+    const double f = m - 1.0;
+    const double s = f * fast_rcp(2.0 + f);
+    const double z = s * s, w = z * z;
+    const double t1 = w * fma(w, fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01),
+                              3.999999999940941908e-01);
+    const double t2 = z * fma(w, fma(w, fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01),
+                                     2.857142874366239149e-01), 6.666666666666735130e-01);
+    const double R = t1 + t2;
+    const double hfsq = 0.5 * f * f;
+    const double dk = (double)k;
+    return dk * 6.93147180369123816490e-01 -
+           ((hfsq - (s * (hfsq + R) + dk * 1.90821492927058770002e-10)) - f);
+}
+
 // The same with the lean forms of device_common.hpp: eta = B - d a with B = b_in + b_out and
 // a = b_in / r + b_out / r' from reciprocals (irj = 1 / r_k is the caller's, 1 / r_e a
 // v_rcp_f64 + two Newton steps), the correctly rounded lean root, the ~1 ulp lean exp and one
@@ -127,18 +148,28 @@ __device__ __forceinline__ double cc_term_delta_fast(const double *xn, const dou
     const double a = in_dir ? fma(bin, irj, bout * ire) : fma(bin, ire, bout * irj);
     const double B = bin + bout;
     const double e0 = fma(-d0, a, B), e1 = fma(-d1, a, B);
-    const double sp = log(fma(1.0, fast_exp(e1), 1.0) * fast_rcp(1.0 + fast_exp(e0)));
+    const double sp = fast_log((1.0 + fast_exp(e1)) * fast_rcp(1.0 + fast_exp(e0)));
     return (edge ? (e1 - e0) : 0.0) - wsp * sp;
 }
 
+// per-wavefront scratch of the evaluator: the window terms of a node, compacted in term order
+constexpr int CP_WCAP = 128;
+struct CcWin {
+    int e[CP_WCAP];            // partner | kind << 28
+    double contrib[CP_WCAP];   // the term with the partner at its snapshot position
+    double re[CP_WCAP];        // the partner's radius
+};
+
 // One wavefront: node k of batch `be` in slice t, its terms four 64-term chunks at a time with
-// every load of a level issued together (list indices, then the partners' records, then the
-// window partners' proposals): the item is a chain of gather latencies, and a wavefront that owns
-// the whole node needs neither a second pass over the indices nor a barrier to place its entries
-// in the node's two lists.
+// every load of a level issued together (list indices, then the partners' records): the item
+// is a chain of gather latencies, and a wavefront that owns the whole node needs neither a second
+// pass over the indices nor a barrier to place its entries in the node's two lists.  The terms
+// whose partner sits in the window (~15 % at C4) are collected in LDS and get their second
+// evaluation - the partner at its proposal - together, a full wavefront at a time, instead of one
+// mostly idle evaluation per chunk.
 template <int D>
 __device__ __forceinline__ void ccpipe_eval_item(const ChainView &c, const CcPipeBuf &pb, int be,
-                                                 int t, int k, int lane) {
+                                                 int t, int k, int lane, CcWin &sw) {
     constexpr int PW = 2 * D + 2;
     constexpr int RW = cp_record_width(D);
     constexpr int NCH = 4;
@@ -160,7 +191,40 @@ __device__ __forceinline__ void ccpipe_eval_item(const ChainView &c, const CcPip
     const size_t lbase = ((size_t)bb * c.T + t) * pb.cap * CP_B + k;      // + entry * CP_B
     const unsigned long long below = (1ull << lane) - 1ull;
     double acc = 0.0;
-    int bx = 0, bo = 0;
+    int bx = 0, bo = 0, wcnt = 0;
+    // second evaluation of the collected window terms: lane i takes the i-th of them
+    auto flush = [&]() {
+        __builtin_amdgcn_wave_barrier();
+        for (int i0 = 0; i0 < wcnt; i0 += 64) {
+            const int i = i0 + lane;
+            const bool live = i < wcnt;
+            const int packed = live ? sw.e[i] : 0;
+            const int e = packed & 0x0FFFFFFF, kind = (packed >> 28) & 3;
+            double h = 0.0;
+            if (live) {
+                double xe1[D];
+#pragma unroll
+                for (int d = 0; d < D; ++d) xe1[d] = props[(size_t)e * PW + d];
+                const bool in_dir = (kind == 0 || kind == 2);
+                const double wsp = kind < 2 ? 1.0 : (kind == 2 ? nd.adj_in : nd.adj_out);
+                h = cc_term_delta_fast<D>(xe1, xk0, xk1, false, in_dir, kind < 2, wsp, bin, bout, irj,
+                                          sw.re[i], c.squared) - sw.contrib[i];
+            }
+            const bool isx = live && e < j0, iso = live && e >= j0;
+            const unsigned long long mx = __ballot(isx), mo = __ballot(iso);
+            if (isx) {
+                const size_t p = lbase + (size_t)(bx + __popcll(mx & below)) * CP_B;
+                pb.xidx[p] = e - jprev; pb.xval[p] = h;
+            }
+            if (iso) {
+                const size_t p = lbase + (size_t)(bo + __popcll(mo & below)) * CP_B;
+                pb.oidx[p] = e - j0; pb.oval[p] = h;
+            }
+            bx += __popcll(mx); bo += __popcll(mo);
+        }
+        wcnt = 0;
+        __builtin_amdgcn_wave_barrier();
+    };
     for (int q0 = 0; q0 < nd.total; q0 += 64 * NCH) {
         int e[NCH], kind[NCH];
 #pragma unroll
@@ -178,43 +242,31 @@ __device__ __forceinline__ void ccpipe_eval_item(const ChainView &c, const CcPip
             for (int d = 0; d < D; ++d) xe[u][d] = src[d];
             re[u] = src[D];
         }
-        bool win[NCH];
-        double xe1[NCH][D];
-#pragma unroll
-        for (int u = 0; u < NCH; ++u) {     // window partners: their proposals too
-            win[u] = e[u] >= jprev && e[u] < jk;
-            const int ee = win[u] ? e[u] : jk;
-#pragma unroll
-            for (int d = 0; d < D; ++d) xe1[u][d] = props[(size_t)ee * PW + d];
-        }
 #pragma unroll
         for (int u = 0; u < NCH; ++u) {
             if (q0 + 64 * u >= nd.total) break;             // wave-uniform
-            double h = 0.0;
+            double contrib = 0.0;
             if (e[u] >= 0) {
                 const bool in_dir = (kind[u] == 0 || kind[u] == 2);
                 const double wsp = kind[u] < 2 ? 1.0 : (kind[u] == 2 ? nd.adj_in : nd.adj_out);
-                const double contrib = cc_term_delta_fast<D>(xe[u], xk0, xk1, e[u] == jk, in_dir,
-                                                             kind[u] < 2, wsp, bin, bout, irj, re[u],
-                                                             c.squared);
+                contrib = cc_term_delta_fast<D>(xe[u], xk0, xk1, e[u] == jk, in_dir, kind[u] < 2, wsp,
+                                                bin, bout, irj, re[u], c.squared);
                 acc += contrib;
-                if (win[u])             // its acceptance changes this term
-                    h = cc_term_delta_fast<D>(xe1[u], xk0, xk1, false, in_dir, kind[u] < 2, wsp, bin,
-                                              bout, irj, re[u], c.squared) - contrib;
             }
-            const bool isx = win[u] && e[u] < j0, iso = win[u] && e[u] >= j0;
-            const unsigned long long mx = __ballot(isx), mo = __ballot(iso);
-            if (isx) {
-                const size_t p = lbase + (size_t)(bx + __popcll(mx & below)) * CP_B;
-                pb.xidx[p] = e[u] - jprev; pb.xval[p] = h;
+            const bool win = e[u] >= jprev && e[u] < jk;    // its acceptance changes this term
+            const unsigned long long mw = __ballot(win);
+            const int nw = __popcll(mw);
+            if (wcnt + nw > CP_WCAP) flush();
+            if (win) {
+                const int pos = wcnt + __popcll(mw & below);
+                sw.e[pos] = e[u] | (kind[u] << 28);
+                sw.contrib[pos] = contrib;
+                sw.re[pos] = re[u];
             }
-            if (iso) {
-                const size_t p = lbase + (size_t)(bo + __popcll(mo & below)) * CP_B;
-                pb.oidx[p] = e[u] - j0; pb.oval[p] = h;
-            }
-            bx += __popcll(mx); bo += __popcll(mo);
+            wcnt += nw;
         }
     }
+    flush();
     const double total = wave_sum_all(acc);
     if (lane == 0) {
         const size_t slot = ((size_t)bb * c.T + t) * CP_B + k;
@@ -242,15 +294,6 @@ __device__ __forceinline__ void ccpipe_resolve(const ChainView &c, const CcPipeB
     const size_t slot = ((size_t)bb * c.T + t) * CP_B + kc;
     const size_t lbase = ((size_t)bb * c.T + t) * pb.cap * CP_B + kc;
     const int ncx = pb.cnt[slot * 2], nown = pb.cnt[slot * 2 + 1];
-    // the node's first own entries: into registers, all loads in flight at once
-    double ov[CP_OWN_REGS];
-    int oi[CP_OWN_REGS];
-#pragma unroll
-    for (int e = 0; e < CP_OWN_REGS; ++e) {
-        const size_t p = lbase + (size_t)min(e, max(nown - 1, 0)) * CP_B;
-        oi[e] = e < nown ? pb.oidx[p] : 0;
-        ov[e] = pb.oval[p];
-    }
     double r = pb.tot[slot];
     const double *pr = pb.prop + ((size_t)t * N + j0 + kc) * PW;
     double x0[D], x1[D];
@@ -265,27 +308,39 @@ __device__ __forceinline__ void ccpipe_resolve(const ChainView &c, const CcPipeB
     int32_t na = c.nacc[tjc], ns = c.nsteps[tjc], un = c.until[tjc];
     __syncthreads();                                   // sPrev visible
     // the previous batch's acceptances, final by now: cross entries in list order
-    // (eight entries per trip, their loads issued together: a one-entry loop is a chain of
+    // (sixteen entries per trip, their loads issued together: a one-entry loop is a chain of
     // ~1 us memory latencies)
-    for (int e0 = 0; e0 < ncx; e0 += 8) {
-        int m[8];
-        double h[8];
+    constexpr int XCH = 16;
+    for (int e0 = 0; e0 < ncx; e0 += XCH) {
+        int m[XCH];
+        double h[XCH];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < XCH; ++u) {
             const size_t p = lbase + (size_t)min(e0 + u, ncx - 1) * CP_B;
             m[u] = pb.xidx[p];
             h[u] = pb.xval[p];
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
+        for (int u = 0; u < XCH; ++u)
             if (e0 + u < ncx && ((sPrev[m[u] >> 6] >> (m[u] & 63)) & 1ull)) r += h[u];
+    }
+    // the node's first own entries: into registers, all loads in flight at once
+    double ov[CP_OWN_REGS];
+    int oi[CP_OWN_REGS];
+#pragma unroll
+    for (int e = 0; e < CP_OWN_REGS; ++e) {
+        const size_t p = lbase + (size_t)min(e, max(nown - 1, 0)) * CP_B;
+        oi[e] = e < nown ? pb.oidx[p] : 0;
+        ov[e] = pb.oval[p];
     }
     {
         const unsigned long long g = __ballot(valid && !(lu >= r));
         if (lane == 0) sMask[0][wave] = g;
     }
-    if (tid == 0) *sChanged = 0;
+    if (tid < 3) sChanged[tid] = 0;
     __syncthreads();
+    // fixed point of a -> F(a); one barrier per pass: pass p raises flag p % 3 and clears flag
+    // (p + 1) % 3, whose last readers (pass p - 2) are two barriers behind
     int cur = 0;
     for (int pass = 0; pass < CP_B + 2; ++pass) {
         double s_own = 0.0;
@@ -300,15 +355,12 @@ __device__ __forceinline__ void ccpipe_resolve(const ChainView &c, const CcPipeB
         const unsigned long long g = __ballot(valid && !(lu >= r + s_own));
         if (lane == 0) {
             sMask[cur ^ 1][wave] = g;
-            if (g != sMask[cur][wave]) atomicOr(sChanged, 1);
+            if (g != sMask[cur][wave]) atomicOr(&sChanged[pass % 3], 1);
         }
+        if (tid == 0) sChanged[(pass + 1) % 3] = 0;
         __syncthreads();
-        const int changed = *sChanged;
         cur ^= 1;
-        __syncthreads();
-        if (!changed) break;
-        if (tid == 0) *sChanged = 0;
-        __syncthreads();
+        if (!sChanged[pass % 3]) break;
     }
     const unsigned long long mine = sMask[cur][wave];
     const int accepted = (int)((mine >> lane) & 1ull);
@@ -333,12 +385,13 @@ template <int D>
 __global__ __launch_bounds__(CP_THREADS) void k_ccpipe_step(ChainView c, CcPipeBuf pb, int l) {
     __shared__ unsigned long long sMask[2][CP_WAVES];
     __shared__ unsigned long long sPrev[CP_WAVES];
-    __shared__ int sChanged;
+    __shared__ int sChanged[3];
+    __shared__ CcWin sWin[CP_WAVES];
     const int T = c.T;
     if ((int)blockIdx.x < T) {
         const int t = blockIdx.x;
         const int b = l - (t & 1);
-        if (b >= 0 && b < pb.nbat) ccpipe_resolve<D>(c, pb, b, t, sMask, sPrev, &sChanged);
+        if (b >= 0 && b < pb.nbat) ccpipe_resolve<D>(c, pb, b, t, sMask, sPrev, sChanged);
         return;
     }
     const int lane = threadIdx.x & 63;
@@ -356,7 +409,7 @@ __global__ __launch_bounds__(CP_THREADS) void k_ccpipe_step(ChainView c, CcPipeB
         const int nb = odd ? nbO : nbE;
         const int k = qq % nb;
         const int t = 2 * (qq / nb) + (odd ? 1 : 0);
-        ccpipe_eval_item<D>(c, pb, odd ? beO : beE, t, k, lane);
+        ccpipe_eval_item<D>(c, pb, odd ? beO : beE, t, k, lane, sWin[threadIdx.x >> 6]);
     }
 }
 
