@@ -7,7 +7,7 @@
 // batch at 128 nodes: 81 latency-bound launches per sweep at T = 5, N = 10 000.  But node k's
 // ratio only depends on the O(deg + 2C) nodes in its edge / control lists, so of the nodes not
 // yet resolved when k is evaluated (the window: the previous batch and the earlier nodes of
-// k's own batch) only a few matter: ~40 of 2048 at C4 with batches of 1024.  Here the
+// k's own batch) only a few matter: ~18 of 1024 at C4 with batches of 512.  Here the
 // evaluator files exactly those as two LISTS per node - corrections for nodes of the previous
 // batch (whose acceptances are final when k's batch is resolved) and for earlier nodes of k's
 // own batch - and the resolver runs the same fixed-point solve of the in-order accept / reject
@@ -16,8 +16,10 @@
 //     a_k = [ log u_k < r_k + sum_{(m, h) in own_k, m accepted} h ]
 //
 // A fixed point of a -> F(a) satisfies the triangular system, whose solution is unique, so it
-// is the sequential scan's result.  Batches of 1024 nodes: ceil(N / 1024) + 2 launches per
-// sweep (12 at C4), each with T resolver workgroups (thread = node) beside ~250 evaluator
+// is the sequential scan's result.  Batches of CP_B = 512 nodes: ceil(N / 512) + 2 launches per
+// sweep (22 at C4; measured 1517 it/s against 1506 / 1475 / 1471 for batches of 640 / 768 / 1024
+// and 1359 for 384: larger batches lengthen the lists and the resolver, smaller ones pay the
+// launch floor more often), each with T resolver workgroups (thread = node) beside ~250 evaluator
 // workgroups (one wavefront per node, every load of a gather level in flight together).  The lists are stored entry-major ([entry][node]) so
 // that the resolver's thread-per-node walks are coalesced; a node's first CP_OWN_REGS own
 // entries stay in registers across the passes of the solve.  Same snapshot rule, same
@@ -27,7 +29,7 @@
 
 namespace dlsm {
 
-constexpr int CP_B = 1024;              // nodes per batch = threads of the resolver
+constexpr int CP_B = 512;               // nodes per batch (<= CP_THREADS: the resolver's thread = node)
 constexpr int CP_THREADS = 1024;
 constexpr int CP_WAVES = CP_THREADS / 64;
 constexpr int CP_OWN_REGS = 16;         // own entries a resolver thread keeps in registers
@@ -347,10 +349,18 @@ __device__ __forceinline__ void ccpipe_resolve(const ChainView &c, const CcPipeB
 #pragma unroll
         for (int e = 0; e < CP_OWN_REGS; ++e)
             if (e < nown && ((sMask[cur][oi[e] >> 6] >> (oi[e] & 63)) & 1ull)) s_own += ov[e];
-        for (int e = CP_OWN_REGS; e < nown; ++e) {          // the rare long list: from memory
-            const size_t p = lbase + (size_t)e * CP_B;
-            const int m = pb.oidx[p];
-            if ((sMask[cur][m >> 6] >> (m & 63)) & 1ull) s_own += pb.oval[p];
+        for (int e0 = CP_OWN_REGS; e0 < nown; e0 += 8) {    // the long list: from memory, eight
+            int m[8];                                       // loads in flight per trip
+            double h[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const size_t p = lbase + (size_t)min(e0 + u, nown - 1) * CP_B;
+                m[u] = pb.oidx[p];
+                h[u] = pb.oval[p];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (e0 + u < nown && ((sMask[cur][m[u] >> 6] >> (m[u] & 63)) & 1ull)) s_own += h[u];
         }
         const unsigned long long g = __ballot(valid && !(lu >= r + s_own));
         if (lane == 0) {

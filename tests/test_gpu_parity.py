@@ -371,7 +371,7 @@ def test_sweep_speculative_batches(eng, name, T, N, D, prior, algo):
 def test_sweep_speculative_batches_case_control(eng, T, N, C, density, prior, algo):
     """sparse H: only the batch nodes that sit in a node's edge / control lists
     interact; density 0.5 with 40 controls makes most of a batch interact.  algo 5 keeps the
-    corrections as per-node lists (batches of 1024: one batch at these sizes)"""
+    corrections as per-node lists (batches of 512: one or two batches at these sizes)"""
     _sweep_case(eng, 'case_control', prior, T=T, N=N, D=2, n_sweeps=3, algo=algo,
                 scale=0.05, cc_C=C, density=density)
 
@@ -379,7 +379,7 @@ def test_sweep_speculative_batches_case_control(eng, T, N, C, density, prior, al
 @pytest.mark.parametrize('T,N,C,density,prior', [(3, 2300, 12, 0.004, 'rw'), (2, 1025, 30, 0.01, 'mix'),
                                                  (4, 3100, 6, 0.003, 'rw'), (1, 2100, 8, 0.004, 'rw')])
 def test_sweep_case_control_sparse_lists_over_several_batches(eng, T, N, C, density, prior):
-    """algo 5 with 2 - 4 batches of 1024 nodes per slice (ragged last batch, a single slice,
+    """algo 5 with 3 - 7 batches of 512 nodes per slice (ragged last batch, a single slice,
     both priors): cross-batch corrections through the lists, same decisions as the oracle"""
     _sweep_case(eng, 'case_control', prior, T=T, N=N, D=2, n_sweeps=2, algo=5,
                 scale=0.05, cc_C=C, density=density)
