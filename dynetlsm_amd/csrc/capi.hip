@@ -921,7 +921,7 @@ static int launch_sweep_spec(dlsm_chain *h, IterRef iter, int S, bool alloc_only
 // workgroup per slice
 static int resolve_sweep_algo(const dlsm_chain *h, int algo) {
     if (algo != 0) return algo;
-    // case-control: sparse correction lists once a slice has several batches of 1024
+    // case-control: sparse correction lists once a slice has several batches of 512
     if (h->model == DLSM_DIRECTED_CASE_CONTROL)
         return h->N >= 2048 ? 5 : (h->N >= 512 ? 4 : (h->N >= 256 ? 2 : 1));
     return h->N >= 512 ? 4 : (h->N >= 256 ? 2 : 1);
@@ -1006,7 +1006,7 @@ static int launch_sweep_pipe(dlsm_chain *h, IterRef iter, bool alloc_only = fals
     return DLSM_OK;
 }
 
-// algo 5: the case-control likelihood with sparse correction lists, batches of 1024 nodes
+// algo 5: the case-control likelihood with sparse correction lists, batches of CP_B = 512 nodes
 // (kernels_ccpipe.hpp)
 template <int DD>
 static int launch_sweep_ccpipe(dlsm_chain *h, IterRef iter, bool alloc_only = false) {
