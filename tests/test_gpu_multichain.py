@@ -129,3 +129,40 @@ def test_bench_single_gpu_line_has_the_contract_fields():
     assert c['kind'] == 'port' and c['cores'] == 1 and c['value'] > 0
     assert c['engine_loglik_rel_err_vs_oracle'] < 1e-6          # north_star's tolerance
     assert 0 < line['iteration_fp64_valu']['frac'] < 1
+
+
+def test_chains_sharing_a_gpu_are_bitwise_the_single_chain_runs(eng):
+    """several chains per GPU (bench.py --chains-per-gpu): each chain is its own handle and
+    stream, enqueued from its own host thread; what a chain computes does not depend on its
+    neighbours - traces bitwise equal to the same chains run one after the other"""
+    import threading
+    from dynetlsm_amd.synthetic import synthetic_lsm_network
+    T, N, n_it = 4, 700, 12
+    net = synthetic_lsm_network(T, N, 2, density=0.05, seed=2)
+
+    def make(cid):
+        c = eng.Chain(T, N, 2, 'undirected', seed=99, chain_id=cid)
+        c.upload_network(net['Y']); c.set_positions(net['X_init'])
+        c.set_intercepts([net['intercept']])
+        c.set_prior_random_walk(2.0, 0.1)
+        c.set_samplers(eng.SamplerGrid(T, N, 0.1, tune=6, tune_interval=2))
+        c.lsm_configure([net['intercept']], 2.0, tune=6, n_iter_procrustes=0)
+        c.trace_alloc(n_it + 1)
+        return c
+    alone = []
+    for cid in range(3):
+        with make(cid) as c:
+            c.lsm_run(1, n_it, procrustes_ref=0)
+            alone.append(c.trace_read(0, n_it + 1))
+    chains = [make(cid) for cid in range(3)]
+    ths = [threading.Thread(target=c.lsm_run, args=(1, n_it, 0)) for c in chains]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    for c, ref in zip(chains, alone):
+        got = c.trace_read(0, n_it + 1)
+        for a, b in zip(got, ref):
+            np.testing.assert_array_equal(a, b)
+        c.close()
+    assert not np.array_equal(alone[0][0][-1], alone[1][0][-1])     # chain id keys the draws
