@@ -34,7 +34,8 @@
 // the evaluators hand over products of (1 + E e^{-d}) factors as they accumulate
 // them, so a wavefront spends one division where the additive form needs a
 // float64 log per node part and per H entry (each executed by all 64 lanes); the
-// resolver pays one exp per node instead.
+// resolver pays one exp per node instead.  (A node whose log-ratio is beyond +-700 - exp would
+// saturate - is resolved in the log domain, with the logs of its H factors: pipe_resolve.)
 #pragma once
 #include "kernels_spec_sweep.hpp"
 
@@ -445,7 +446,8 @@ __device__ __forceinline__ void pipe_cc_writeout(const ChainView &c, const PipeB
 template <int D>
 __device__ __forceinline__ void pipe_resolve(const ChainView &c, const PipeBuf &pb, int b, int t,
                                              double *sH, double *sPart,
-                                             unsigned long long (*sMask)[2], int *sPrev) {
+                                             unsigned long long (*sMask)[2], int *sPrev,
+                                             unsigned char *sSat) {
     constexpr int PW = 2 * D + 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int N = c.N;
@@ -468,8 +470,12 @@ __device__ __forceinline__ void pipe_resolve(const ChainView &c, const PipeBuf &
     }
     const int nprev = b > 0 ? accg[0] : 0;
     for (int a = tid; a < nprev; a += PP_THREADS) sPrev[a] = accg[1 + a];
-    // multiplicative domain: r = exp(log-ratio of node k), lu = its uniform draw
-    double r = 0.0, lu = 0.0, st = 0.0, x1[D];
+    // multiplicative domain: r = exp(log-ratio of node k), lu = its uniform draw.  A node whose
+    // log-ratio is beyond +-700 (exp would saturate) is resolved in the log domain instead -
+    // log u against lr + the LOGS of its H factors - so that the decision is the sequential
+    // scan's for every chain, not only for those whose single-node moves stay below 700 nats.
+    double r = 0.0, lu = 0.0, st = 0.0, x1[D], lr = 0.0;
+    bool sat = false;
     int32_t na = 0, ns = 0, un = 0;
 #pragma unroll
     for (int d = 0; d < D; ++d) x1[d] = 0.0;
@@ -495,9 +501,12 @@ __device__ __forceinline__ void pipe_resolve(const ChainView &c, const PipeBuf &
         // are now (see the header: the odd slices run one batch behind)
         const double prior = node_log_prior<D>(c, t, j0 + kc, x1) -
                              node_log_prior<D>(c, t, j0 + kc, x0);
-        // exp(r_k): |arguments| beyond 700 decide the test on their own
-        r = exp(fmin(fmax(tot + prior, -700.0), 700.0)) * pr_;
+        const double ek = tot + prior;
+        sat = !(fabs(ek) <= 700.0);
+        r = sat ? 1.0 : exp(ek) * pr_;
         lu = pr[D];
+        if (sat) { lr = ek + log(pr_); lu = log(lu); }
+        sSat[k] = sat ? 1 : 0;
         const size_t tjc = (size_t)t * N + j0 + kc;
         st = c.step[tjc]; na = c.nacc[tjc]; ns = c.nsteps[tjc]; un = c.until[tjc];
     }
@@ -505,28 +514,42 @@ __device__ __forceinline__ void pipe_resolve(const ChainView &c, const PipeBuf &
     for (int u = 0; u < 8; ++u)
         ((double2 *)sH)[min(u * PP_THREADS + tid, nb * (PP_B / 2) - 1)] = blk[u];
     __syncthreads();                                   // sPrev, sH visible
+    const bool satk = sSat[k] != 0;                    // column k is resolved in the log domain
+    const bool anysat = __ballot(satk) != 0ull;        // (practically never: wave-uniform slow path)
     if (nprev > 0) {
         const double *colp = Hx + min(k, PP_B - 1);
         double prod = 1.0;
         int a = part;
-        for (; a + 24 < nprev; a += 32) {
-            const double h0 = colp[(size_t)sPrev[a] * PP_B];
-            const double h1 = colp[(size_t)sPrev[a + 8] * PP_B];
-            const double h2 = colp[(size_t)sPrev[a + 16] * PP_B];
-            const double h3 = colp[(size_t)sPrev[a + 24] * PP_B];
-            prod *= h0; prod *= h1; prod *= h2; prod *= h3;
+        if (!anysat) {
+            for (; a + 24 < nprev; a += 32) {
+                const double h0 = colp[(size_t)sPrev[a] * PP_B];
+                const double h1 = colp[(size_t)sPrev[a + 8] * PP_B];
+                const double h2 = colp[(size_t)sPrev[a + 16] * PP_B];
+                const double h3 = colp[(size_t)sPrev[a + 24] * PP_B];
+                prod *= h0; prod *= h1; prod *= h2; prod *= h3;
+            }
+            for (; a < nprev; a += 8) prod *= colp[(size_t)sPrev[a] * PP_B];
+        } else {
+            double lsum = 0.0;
+            for (; a < nprev; a += 8) {
+                const double h = colp[(size_t)sPrev[a] * PP_B];
+                if (satk) lsum += log(h); else prod *= h;
+            }
+            if (satk) prod = lsum;
         }
-        for (; a < nprev; a += 8) prod *= colp[(size_t)sPrev[a] * PP_B];
         sPart[wave * 64 + lane] = prod;
         __syncthreads();
         if (owner) {
 #pragma unroll
-            for (int p = 0; p < 8; ++p) r *= sPart[(2 * p + half) * 64 + lane];
+            for (int p = 0; p < 8; ++p) {
+                const double v = sPart[(2 * p + half) * 64 + lane];
+                if (sat) lr += v; else r *= v;
+            }
         }
         __syncthreads();
     }
     if (owner) {
-        const unsigned long long g = __ballot(valid && !(lu >= r));
+        const unsigned long long g = __ballot(valid && !(sat ? lu >= lr : lu >= r));
         if (lane == 0) sMask[0][half] = g;
     }
     __syncthreads();
@@ -535,7 +558,7 @@ __device__ __forceinline__ void pipe_resolve(const ChainView &c, const PipeBuf &
         const unsigned long long gm = sMask[cur][part >> 2];
         unsigned int bits = (unsigned int)(gm >> (16 * (part & 3))) & 0xFFFFu;
         const int mbase = 16 * part;
-        double sum = 1.0;
+        double sum = 1.0, lsum = 0.0;
         if (half == 1 || part < 4) {                   // rows >= 64 never touch half 0
             const double *col = sH + k;
             while (bits) {
@@ -548,16 +571,25 @@ __device__ __forceinline__ void pipe_resolve(const ChainView &c, const PipeBuf &
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) h[u] = col[(f[u] < (1 << 20) ? f[u] : 0) * PP_B];
+                if (!anysat) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) sum *= k > f[u] ? h[u] : 1.0;
+                    for (int u = 0; u < 4; ++u) sum *= k > f[u] ? h[u] : 1.0;
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (k > f[u]) { if (satk) lsum += log(h[u]); else sum *= h[u]; }
+                }
             }
         }
-        sPart[wave * 64 + lane] = sum;
+        sPart[wave * 64 + lane] = satk ? lsum : sum;
         __syncthreads();
         if (owner) {
-            double q = r;
+            double q = sat ? lr : r;
 #pragma unroll
-            for (int p = 0; p < 8; ++p) q *= sPart[(2 * p + half) * 64 + lane];
+            for (int p = 0; p < 8; ++p) {
+                const double v = sPart[(2 * p + half) * 64 + lane];
+                if (sat) q += v; else q *= v;
+            }
             const unsigned long long g = __ballot(valid && !(lu >= q));
             if (lane == 0) sMask[cur ^ 1][half] = g;
         }
@@ -603,11 +635,12 @@ __global__ __launch_bounds__(PP_THREADS) void k_pipe_step(ChainView c, PipeBuf p
     __shared__ double sPart[PP_WAVES * 64];
     __shared__ unsigned long long sMask[2][2];
     __shared__ int sPrev[PP_B];
+    __shared__ unsigned char sSat[PP_B];
     const int T = c.T;
     if ((int)blockIdx.x < T) {
         const int t = blockIdx.x;
         const int b = l - (t & 1);
-        if (b >= 0 && b < pb.nbat) pipe_resolve<D>(c, pb, b, t, pp_sH, sPart, sMask, sPrev);
+        if (b >= 0 && b < pb.nbat) pipe_resolve<D>(c, pb, b, t, pp_sH, sPart, sMask, sPrev, sSat);
         return;
     }
     const int lane = threadIdx.x & 63;

@@ -125,21 +125,30 @@ def test_directed_large_exponent_corner(eng):
         want = [orc.dynamic_network_loglikelihood_directed(Yd, X, a, b, radii)
                 for a, b in ((b_in, b_out), (0.2, 0.4))]
         np.testing.assert_allclose(got, want, rtol=RTOL_LL)
-        # a sweep: the pipelined form against the per-slice kernel (same decisions).  One sweep
-        # only: log-ratios of several hundred are outside what the multiplicative accept test
-        # of the pipelined form is specified for (its exponent clamps at +-700),
-        # and this corner drives the positions there.
+        # sweeps: the pipelined form against the per-slice kernel (same decisions).  This corner
+        # drives log-ratios of single-node moves beyond +-700, where exp() of the pipelined form's
+        # multiplicative accept test would saturate: those nodes are resolved in the log domain
+        # (pipe_resolve), so the two forms keep agreeing sweep after sweep.
         c.set_prior_random_walk(2.0, 0.1)
-        c.set_samplers(eng.SamplerGrid(T, N, 0.02, tune=None))
-        c.sweep_positions(1, 4)
-        X4 = c.get_positions()
-        acc4 = c.get_samplers(eng.SamplerGrid(T, N, 0.02, tune=None)).n_accepted.copy()
-        c.set_positions(X)
-        c.set_samplers(eng.SamplerGrid(T, N, 0.02, tune=None))
-        c.sweep_positions(1, 1)
-        acc1 = c.get_samplers(eng.SamplerGrid(T, N, 0.02, tune=None)).n_accepted
-        np.testing.assert_array_equal(acc4, acc1)
-        np.testing.assert_allclose(X4, c.get_positions(), atol=1e-12)
+        big = 0
+        for algo in (4, 1):
+            c.set_positions(X)
+            c.set_samplers(eng.SamplerGrid(T, N, 0.02, tune=None))
+            res = []
+            for it in (1, 2, 3, 4):
+                if algo == 1:
+                    pa = c.loglik_partial_all(with_prior=True)
+                c.sweep_positions(it, algo)
+                res.append((c.get_positions(),
+                            c.get_samplers(eng.SamplerGrid(T, N, 0.02, tune=None)).n_accepted.copy()))
+                if algo == 1:       # how large do single-node log-ratios get here?
+                    big = max(big, float(np.abs(c.loglik_partial_all(with_prior=True) - pa).max()))
+            if algo == 4:
+                res4 = res
+        for (X4, a4), (X1, a1) in zip(res4, res):
+            np.testing.assert_array_equal(a4, a1)
+            np.testing.assert_allclose(X4, X1, atol=1e-12)
+        assert big > 700.0, big         # the corner really is beyond the exponent's range
 
 
 # ------------------------------------------------------------ full log-lik
