@@ -16,6 +16,7 @@ HdpLoopBuf hdp_loop_buf(dlsm_chain *h) {
     b.L = p; p += 2 * T * K;
     b.LP = p; p += T * K;
     b.LPD = p; p += T * K;
+    b.scr = p; p += HS_COUNT;
     b.m = (int32_t *)p;
     b.wover = b.m + T * K * K;
     b.w = h->lab_w; b.n = h->lab_n; b.nk = h->lab_nk;
@@ -26,7 +27,7 @@ HdpLoopBuf hdp_loop_buf(dlsm_chain *h) {
 
 size_t hdp_loop_buf_doubles(const dlsm_chain *h) {
     const size_t T = h->T, K = h->K, D = h->D;
-    return 2 * K + T * K * D + 5 * T * K + (T * K * K + T * K + 1) / 2 + 2;
+    return 2 * K + T * K * D + 5 * T * K + HS_COUNT + (T * K * K + T * K + 1) / 2 + 2;
 }
 
 void hdp_free_trace(dlsm_chain *h) {
@@ -62,17 +63,14 @@ int enqueue_hdp_iteration(dlsm_chain *h, int it) {
                            h->htr_z + (size_t)it * T * N);
     }
     ProfScope ps(h, DLSM_K_HDP_TAIL);
-    hipLaunchKernelGGL(k_hdp_tables, dim3((T * K * K + HT_WAVES - 1) / HT_WAVES), dim3(64 * HT_WAVES), 0,
-                       h->stream, v, hb, h->hdp, ir);
-    hipLaunchKernelGGL(k_hdp_globals, dim3(1), dim3(HG_THREADS), 0, h->stream, v, hb, h->hdp, ir);
-    if (T > 1)
-        hipLaunchKernelGGL(k_hdp_weights, dim3(T - 1), dim3(256), (size_t)(K * K + K) * sizeof(double),
-                           h->stream, v, hb, h->hdp, ir);
-    HdpParams hp{h->mu, h->sigma, h->lab_w, 0.0, h->hdp_cfg.a, 0.0, &h->hdp->lmbda, &h->hdp->b};
+    const int n_tab = (T * K * K + HT_WAVES - 1) / HT_WAVES;
+    hipLaunchKernelGGL((k_hdp_stage1<DD>), dim3(n_tab + K * T), dim3(HDP_THREADS), 0, h->stream, v, hb,
+                       h->hdp, ir);
+    hipLaunchKernelGGL((k_hdp_stage2<DD>), dim3(2 + K * T), dim3(HDP_THREADS), 0, h->stream, v, hb,
+                       h->hdp, ir);
+    hipLaunchKernelGGL((k_hdp_stage3<DD>), dim3(T + K * T), dim3(HDP_THREADS),
+                       (size_t)(K * K + K) * sizeof(double), h->stream, v, hb, h->hdp, ir);
     const dim3 grid(K, T), block(HDP_THREADS);
-    hipLaunchKernelGGL((k_hdp_label_sums<DD, HDP_SUMS_MEAN>), grid, block, 0, h->stream, v, hp, hb.S);
-    hipLaunchKernelGGL((k_hdp_mu_residual<DD>), grid, block, 0, h->stream, v, hb, h->hdp, ir);
-    hipLaunchKernelGGL((k_hdp_sigma_lambda<DD>), grid, block, 0, h->stream, v, hb, h->hdp, ir);
     hipLaunchKernelGGL(k_hdp_hypers, dim3(1), dim3(HH_THREADS), 0, h->stream, v, hb, h->hdp, ir);
     hipLaunchKernelGGL((k_hdp_logp_sums<DD>), grid, block, 0, h->stream, v, hb, h->hdp);
     HdpTrace tr{h->trace_ic, h->trace_logp, h->htr_mu, h->htr_sigma, h->htr_beta, h->htr_w,

@@ -32,13 +32,14 @@ struct HdpParams {
 
 // the sums of workgroup (k, t) given cluster k's mean `mk`, variance `sk` and the scalars
 template <int D, int STAGE>
-__device__ __forceinline__ void hdp_label_sums_wg(const ChainView &c, const double (&mk)[D], double sk,
+__device__ __forceinline__ void hdp_label_sums_wg(const ChainView &c, int k, int t,
+                                                  const double (&mk)[D], double sk,
                                                   double lm, double a_, double hb_,
                                                   const double *__restrict__ w,
                                                   double *__restrict__ out) {
     constexpr int NV = STAGE == HDP_SUMS_MEAN ? D : (STAGE == HDP_SUMS_LAMBDA ? 2 : 1);
     __shared__ double buf[NV][HDP_THREADS / 64];
-    const int k = blockIdx.x, t = blockIdx.y, tid = threadIdx.x;
+    const int tid = threadIdx.x;
     const int N = c.N, K = c.K;
     const int32_t *zt = c.z + (size_t)t * N;
     const int32_t *zp = t > 0 ? c.z + (size_t)(t - 1) * N : nullptr;
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(HDP_THREADS) void k_hdp_label_sums(ChainView c, Hdp
 #pragma unroll
     for (int d = 0; d < D; ++d) mk[d] = STAGE == HDP_SUMS_MEAN ? 0.0 : hp.mu[(size_t)k * D + d];
     if (STAGE == HDP_SUMS_LAMBDA || STAGE == HDP_SUMS_LOGP) sk = hp.sigma[k];
-    hdp_label_sums_wg<D, STAGE>(c, mk, sk, lm, hp.a, hb_, hp.w, out);
+    hdp_label_sums_wg<D, STAGE>(c, k, (int)blockIdx.y, mk, sk, lm, hp.a, hb_, hp.w, out);
 }
 
 }  // namespace dlsm
