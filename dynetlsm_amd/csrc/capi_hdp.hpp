@@ -64,8 +64,8 @@ int enqueue_hdp_iteration(dlsm_chain *h, int it) {
     }
     ProfScope ps(h, DLSM_K_HDP_TAIL);
     const int n_tab = (T * K * K + HT_WAVES - 1) / HT_WAVES;
-    hipLaunchKernelGGL((k_hdp_stage1<DD>), dim3(n_tab + K * T), dim3(HDP_THREADS), 0, h->stream, v, hb,
-                       h->hdp, ir);
+    hipLaunchKernelGGL((k_hdp_stage1<DD>), dim3(n_tab + K * T + 1), dim3(HDP_THREADS), 0, h->stream, v,
+                       hb, h->hdp, h->lsm, h->partials, nrec, h->intercept, h->trace_ic, ir);
     hipLaunchKernelGGL((k_hdp_stage2<DD>), dim3(2 + K * T), dim3(HDP_THREADS), 0, h->stream, v, hb,
                        h->hdp, ir);
     hipLaunchKernelGGL((k_hdp_stage3<DD>), dim3(T + K * T), dim3(HDP_THREADS),
@@ -76,7 +76,7 @@ int enqueue_hdp_iteration(dlsm_chain *h, int it) {
     HdpTrace tr{h->trace_ic, h->trace_logp, h->htr_mu, h->htr_sigma, h->htr_beta, h->htr_w,
                 h->htr_lambda, h->htr_hyper};
     hipLaunchKernelGGL((k_hdp_finalize<DD>), dim3(1), dim3(HF_THREADS), 0, h->stream, v, hb, h->hdp,
-                       h->lsm, h->partials, nrec, h->intercept, tr, ir);
+                       h->lsm, h->intercept, tr, ir);
     HIPCHK(h, hipGetLastError());
     return DLSM_OK;
 }

@@ -16,7 +16,7 @@
 // Launch order per iteration (capi_hdp.hpp): [labels], k_hdp_stage1 (tables | MEAN sums),
 // k_hdp_stage2 (override variables, m_bar, beta, w0 | the alpha + kappa grid | mu + RESIDUAL sums),
 // k_hdp_stage3 (w | eight gamma variates | sigma + LAMBDA sums), k_hdp_hypers, k_hdp_logp_sums
-// (+ the Dirichlet rows), k_hdp_finalize (+ the intercept's accept / reject).
+// (+ the Dirichlet rows), k_hdp_finalize; the intercept's accept / reject is one more role of stage 1.
 #pragma once
 #include "chain.hpp"
 #include "device_common.hpp"
@@ -503,6 +503,34 @@ __global__ __launch_bounds__(HH_THREADS) void k_hdp_hypers(ChainView c, HdpLoopB
     hs->alpha = ak - hs->kappa;
 }
 
+// intercept step (sample_coefficients.py:76-86 around the fused two-candidate pass whose records
+// are in `partials`): one workgroup; nothing before k_hdp_finalize reads its results
+__device__ __forceinline__ void hdp_intercept_wg(const double *__restrict__ partials, int nrec,
+                                                 LsmDeviceState *lsm, HdpDeviceState *hs,
+                                                 double *__restrict__ intercept,
+                                                 double *__restrict__ trace_ic, int it) {
+    __shared__ double scratch[4 * 256];
+    __shared__ double sums[4];
+    reduce_records(partials, nrec, 4, sums, scratch, threadIdx.x);
+    if (threadIdx.x == 0) {
+        const double b0 = lsm->cand[0], b1 = lsm->cand[1];
+        const double ll0 = b0 * sums[0] - sums[1] - sums[2];
+        const double ll1 = b1 * sums[0] - sums[1] - sums[3];
+        const double pm = lsm->intercept_prior[0], v = lsm->intercept_var;
+        const double lp0 = ll0 - (b0 - pm) * (b0 - pm) / (2 * v);
+        const double lp1 = ll1 - (b1 - pm) * (b1 - pm) / (2 * v);
+        const int accepted = !(lsm->logu >= lp1 - lp0);
+        intercept[0] = accepted ? b1 : b0;
+        hs->ll = accepted ? ll1 : ll0;
+        double st = lsm->i_step[0];
+        int32_t na = lsm->i_nacc[0], ns = lsm->i_nsteps[0], un = lsm->i_until[0];
+        metropolis_bookkeeping(st, na, ns, un, lsm->i_tune, lsm->i_tune_interval, accepted);
+        lsm->i_step[0] = st; lsm->i_nacc[0] = na; lsm->i_nsteps[0] = ns; lsm->i_until[0] = un;
+        trace_ic[(size_t)it * 2] = intercept[0];
+        trace_ic[(size_t)it * 2 + 1] = 0.0;
+    }
+}
+
 // ---- the three multi-role launches between the label counts and k_hdp_hypers -------------------------
 // Two chains of work follow the label update and meet only in k_hdp_hypers: tables -> override
 // variables, m_bar, beta, w0 -> w  and  MEAN sums -> mu + RESIDUAL sums -> sigma + LAMBDA sums.
@@ -510,10 +538,17 @@ __global__ __launch_bounds__(HH_THREADS) void k_hdp_hypers(ChainView c, HdpLoopB
 // draws that are ready by then: 3 launches of ~5 / 20 / 15 us instead of 6.
 template <int D>
 __global__ __launch_bounds__(HDP_THREADS) void k_hdp_stage1(ChainView c, HdpLoopBuf hb,
-                                                            const HdpDeviceState *hs, IterRef ir) {
+                                                            HdpDeviceState *hs, LsmDeviceState *lsm,
+                                                            const double *__restrict__ partials,
+                                                            int nrec, double *__restrict__ intercept,
+                                                            double *__restrict__ trace_ic, IterRef ir) {
     const int K = hb.K, T = c.T;
     const int n_tab = (T * K * K + HT_WAVES - 1) / HT_WAVES;
     if ((int)blockIdx.x < n_tab) { hdp_tables_wg(c, hb, hs, ir.get(), blockIdx.x); return; }
+    if ((int)blockIdx.x == n_tab + K * T) {
+        hdp_intercept_wg(partials, nrec, lsm, hs, intercept, trace_ic, (int)ir.get());
+        return;
+    }
     const int q = (int)blockIdx.x - n_tab, k = q % K, t = q / K;
     double mk[D];
 #pragma unroll
@@ -598,39 +633,15 @@ __global__ __launch_bounds__(HDP_THREADS) void k_hdp_logp_sums(ChainView c, HdpL
 
 // ---- log-posterior trace (hdp_lpcm.py:1188-1280) and the sample's trace rows: one workgroup -----------
 constexpr int HF_THREADS = 256;
-// (the intercept's accept / reject - sample_coefficients.py:76-86 around the fused two-candidate
-// pass whose records are still in `partials` - happens here too: nothing between the label
-// update and this kernel reads the intercept)
 template <int D>
 __global__ __launch_bounds__(HF_THREADS) void k_hdp_finalize(ChainView c, HdpLoopBuf hb,
-                                                             HdpDeviceState *hs, LsmDeviceState *lsm,
-                                                             const double *__restrict__ partials,
-                                                             int nrec, double *__restrict__ intercept,
+                                                             const HdpDeviceState *hs,
+                                                             const LsmDeviceState *lsm,
+                                                             const double *__restrict__ intercept,
                                                              HdpTrace tr, IterRef ir) {
     __shared__ double red[2][HF_THREADS / 64];
-    __shared__ double scratch[4 * 256];
-    __shared__ double sums[4];
     const int K = hb.K, T = c.T, tid = threadIdx.x;
     const int it = (int)ir.get();
-    reduce_records(partials, nrec, 4, sums, scratch, tid);
-    if (tid == 0) {
-        const double b0 = lsm->cand[0], b1 = lsm->cand[1];
-        const double ll0 = b0 * sums[0] - sums[1] - sums[2];
-        const double ll1 = b1 * sums[0] - sums[1] - sums[3];
-        const double pm = lsm->intercept_prior[0], v = lsm->intercept_var;
-        const double lp0 = ll0 - (b0 - pm) * (b0 - pm) / (2 * v);
-        const double lp1 = ll1 - (b1 - pm) * (b1 - pm) / (2 * v);
-        const int accepted = !(lsm->logu >= lp1 - lp0);
-        intercept[0] = accepted ? b1 : b0;
-        hs->ll = accepted ? ll1 : ll0;
-        double st = lsm->i_step[0];
-        int32_t na = lsm->i_nacc[0], ns = lsm->i_nsteps[0], un = lsm->i_until[0];
-        metropolis_bookkeeping(st, na, ns, un, lsm->i_tune, lsm->i_tune_interval, accepted);
-        lsm->i_step[0] = st; lsm->i_nacc[0] = na; lsm->i_nsteps[0] = ns; lsm->i_until[0] = un;
-        tr.ic[(size_t)it * 2] = intercept[0];
-        tr.ic[(size_t)it * 2 + 1] = 0.0;
-    }
-    __syncthreads();
     // node terms of the label sums + the Dirichlet rows
     double acc = 0.0;
     for (int q = tid; q < T * K; q += HF_THREADS)
