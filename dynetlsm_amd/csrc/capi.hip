@@ -956,12 +956,7 @@ static int launch_sweep_pipe(dlsm_chain *h, IterRef iter, bool alloc_only = fals
     const size_t n_full0 = (size_t)2 * T * PP_B * parts * 2;
     const size_t n_h = (size_t)2 * T * PP_B * PP_B;
     const size_t n_acc = even2(((size_t)T * (PP_B + 1) + 1) / 2);           // int32 pairs
-    // exact likelihoods: the snapshot part of every node's sum is computed up front (k_pipe_late)
-    const bool late = !cc && !(getenv("DLSM_PIPE_LATE") && atoi(getenv("DLSM_PIPE_LATE")) == 0);
-    const int lparts = std::max(1, std::min(PP_MAXPARTS, (N + 64 * pipe_prefetch_trips(DD) - 1) /
-                                                             (64 * pipe_prefetch_trips(DD))));
-    const size_t n_late = late ? (size_t)T * N * lparts * 2 : 0;
-    const size_t need = (n_prop + n_full0 + 2 * n_h + n_acc + 2 + n_late) * sizeof(double);
+    const size_t need = (n_prop + n_full0 + 2 * n_h + n_acc + 2) * sizeof(double);
     if (h->pipe_cap < need) {
         if (h->pipe) hipFree(h->pipe);
         h->pipe = nullptr; h->pipe_cap = 0;
@@ -972,7 +967,6 @@ static int launch_sweep_pipe(dlsm_chain *h, IterRef iter, bool alloc_only = fals
     pb.prop = h->pipe; pb.full0 = pb.prop + n_prop; pb.Hd = pb.full0 + n_full0;
     pb.Hx = pb.Hd + n_h; pb.acc = (int32_t *)(pb.Hx + n_h);
     pb.consts = pb.Hx + n_h + n_acc;
-    pb.late = late ? pb.consts + 2 : nullptr; pb.lparts = lparts;
     pb.parts = parts; pb.nbat = nbat;
     pb.per = ((N + parts - 1) / parts + 63) / 64 * 64;      // parts start on a 64-neighbour boundary
     pb.nctrl = h->nctrl;
@@ -993,27 +987,13 @@ static int launch_sweep_pipe(dlsm_chain *h, IterRef iter, bool alloc_only = fals
     ChainView v = h->view();
     hipLaunchKernelGGL((k_pipe_propose<DD>), dim3((N + 255) / 256, T), dim3(256), 0, h->stream, v,
                        pb, iter);
-    const int lper = ((N + lparts - 1) / lparts + 63) / 64 * 64;
-    const bool long_parts = h->model == DLSM_UNDIRECTED &&
-                            (late ? std::max(lper, ((std::max(N - 2 * PP_B, 0) + parts - 1) / parts + 63) / 64 * 64)
-                                  : pb.per) > 64 * pipe_prefetch_trips(DD);
-    if (late) {
-        const int nitems = T * N * lparts;
-        const dim3 lg((unsigned)((nitems + PP_WAVES - 1) / PP_WAVES));
-        if (h->model == DLSM_DIRECTED)
-            hipLaunchKernelGGL((k_pipe_late<DD, DLSM_DIRECTED>), lg, dim3(PP_THREADS), 0, h->stream, v, pb, 0, nbat);
-        else if (long_parts)
-            hipLaunchKernelGGL((k_pipe_late<DD, PIPE_UNDIRECTED_LONG>), lg, dim3(PP_THREADS), 0, h->stream, v, pb, 0, nbat);
-        else
-            hipLaunchKernelGGL((k_pipe_late<DD, DLSM_UNDIRECTED>), lg, dim3(PP_THREADS), 0, h->stream, v, pb, 0, nbat);
-    }
     // launch l: even slices resolve batch l / evaluate l + 1, odd slices resolve l - 1 /
     // evaluate l; with a single slice (T == 1) the trailing odd-only launch is empty
     const int last = T > 1 ? nbat : nbat - 1;
     for (int l = -1; l <= last; ++l) {
         const bool any_eval = (l + 1 < nbat) || (T > 1 && l >= 0 && l < nbat);
         const int grid = T + (any_eval ? ne_wg : 0);
-        if (h->model == DLSM_UNDIRECTED && long_parts)
+        if (h->model == DLSM_UNDIRECTED && pb.per > 64 * pipe_prefetch_trips(DD))
             launch_pipe_step<DD, PIPE_UNDIRECTED_LONG>(h, v, pb, grid, lds, l);
         else if (h->model == DLSM_UNDIRECTED)
             launch_pipe_step<DD, DLSM_UNDIRECTED>(h, v, pb, grid, lds, l);

@@ -56,10 +56,6 @@ struct PipeBuf {
     double *consts;  // [2] : E = exp(sum of intercepts), flush interval
     const int32_t *nctrl;   // case-control: valid controls per (t, i, direction)
     int parts, per, nbat;
-    // exact likelihoods: the part of every node's sum that only involves snapshot positions
-    // (neighbours i >= jprev) is pipeline independent and computed up front by k_pipe_late
-    double *late;    // [T][N][lparts][2] : (sum of linear terms, ratio of products), or NULL
-    int lparts;
 };
 
 template <int D>
@@ -135,12 +131,9 @@ __host__ __device__ constexpr int pipe_prefetch_trips(int D) {
 // One wavefront: part p of node k of batch `be` in slice t.  TP: the trips beyond the
 // prefetched ones are software-pipelined (directed model; undirected parts longer than the
 // prefetch, where it is worth +3 % - at C2, where everything is prefetched, it costs 1 %).
-// Neighbours [lo, hi) (lo a multiple of 64); the record goes to `rec`; `with_h`: the item also
-// takes its share of the batch's H entries (the pipelined launches' items do, k_pipe_late's don't).
 template <int D, int MODEL, bool TP>
 __device__ __forceinline__ void pipe_eval_item(const ChainView &c, const PipeBuf &pb, int be,
-                                               int nb, int t, int k, int p, int lane, int lo, int hi,
-                                               bool with_h, double2 *rec) {
+                                               int nb, int t, int k, int p, int lane) {
     constexpr int PW = 2 * D + 2;
     const int N = c.N, W = c.W;
     const int j0 = be * PP_B, jk = j0 + k;
@@ -165,6 +158,7 @@ __device__ __forceinline__ void pipe_eval_item(const ChainView &c, const PipeBuf
         irk = 1.0 / c.radii[jk];
     }
     const double lE = bin + bout;              // log E (directed model)
+    const int lo = p * pb.per, hi = min(N, lo + pb.per);
     // neighbours per lane loaded up front (the directed model carries more per neighbour)
     constexpr int PP_NPRE = MODEL == DLSM_UNDIRECTED ? pipe_prefetch_trips(D) : 1;
     // The item is a chain of dependent latencies, so the neighbours' loads are issued before
@@ -295,9 +289,12 @@ __device__ __forceinline__ void pipe_eval_item(const ChainView &c, const PipeBuf
         acc += ra.value();                       // directed: lin / products and the rare exact terms
         tot_l = wave_sum_all(acc); tot_r = 1.0;
     }
-    if (lane == 0) *rec = make_double2(tot_l, tot_r);
+    if (lane == 0) {
+        double2 *f = (double2 *)pb.full0 + (((size_t)bb * c.T + t) * PP_B + k) * pb.parts + p;
+        *f = make_double2(tot_l, tot_r);
+    }
     // this lane's H entries (see above)
-    for (int f = hf0; with_h && f < htot; f += hround) {
+    for (int f = hf0; f < htot; f += hround) {
         int kk, e;
         pipe_h_decode(f, ncross, nb, kk, e);
         const int jm_ = (e < ncross ? jprev : j0) + (e < ncross ? e : e - ncross);
@@ -496,10 +493,6 @@ __device__ __forceinline__ void pipe_resolve(const ChainView &c, const PipeBuf &
             tot += u < p1 ? tv[u].x : 0.0;
             pr_ *= u < p1 ? tv[u].y : 1.0;
         }
-        if (pb.late) {          // the snapshot part of the sum (k_pipe_late)
-            const double2 *lt = (const double2 *)pb.late + ((size_t)t * N + j0 + kc) * pb.lparts;
-            for (int u = 0; u < pb.lparts; ++u) { const double2 v = lt[u]; tot += v.x; pr_ *= v.y; }
-        }
         const double *pr = pb.prop + ((size_t)t * N + j0 + kc) * PW;
         double x0[D];
 #pragma unroll
@@ -697,45 +690,8 @@ __global__ __launch_bounds__(PP_THREADS) void k_pipe_step(ChainView c, PipeBuf p
         const bool odd = si >= nslE;
         if (k >= (odd ? nbO : nbE)) continue;
         const int t = odd ? 2 * (si - nslE) + 1 : 2 * si;
-        const int be = odd ? beO : beE;
-        const int bb = be & 1;
-        // with the late part precomputed only the neighbours with final positions are left
-        const int nend = pb.late ? max(0, be * PP_B - PP_B) : c.N;
-        const int per = pb.late ? ((nend + pb.parts - 1) / pb.parts + 63) / 64 * 64 : pb.per;
-        const int lo = p * per, hi = min(nend, lo + per);
-        double2 *rec = (double2 *)pb.full0 + (((size_t)bb * c.T + t) * PP_B + k) * pb.parts + p;
         pipe_eval_item<D, MODEL == DLSM_DIRECTED_CASE_CONTROL ? DLSM_DIRECTED : MODEL, TP>(
-            c, pb, be, odd ? nbO : nbE, t, k, p, lane, lo, max(hi, lo), true, rec);
-    }
-}
-
-// The pipeline-independent part of the sweep's sums: for node (t, j) the neighbours i >= jprev
-// (its previous batch and everything after it) sit at their snapshot positions whenever j is
-// evaluated, so their contribution - 59 % of all neighbour terms at N = 2000 - is computed once
-// per sweep, up front, in one chip-wide launch; the pipelined launches keep the neighbours whose
-// positions become final on the way (and the H entries).  One wavefront per (node, part).
-template <int D, int MODEL_>
-__global__ __launch_bounds__(PP_THREADS) void k_pipe_late(ChainView c, PipeBuf pb, int tb0, int tb1) {
-    constexpr int MODEL = MODEL_ == PIPE_UNDIRECTED_LONG ? DLSM_UNDIRECTED : MODEL_;
-    constexpr bool TP = MODEL_ != DLSM_UNDIRECTED;
-    const int lane = threadIdx.x & 63;
-    const int N = c.N, T = c.T;
-    // target batches [tb0, tb1) of every slice
-    const int j_lo = tb0 * PP_B, j_hi = min(N, tb1 * PP_B);
-    const int nn = max(0, j_hi - j_lo);
-    const int nitems = T * nn * pb.lparts;
-    const int nwaves = (int)gridDim.x * PP_WAVES;
-    const int gw = __builtin_amdgcn_readfirstlane((int)blockIdx.x * PP_WAVES + (int)(threadIdx.x >> 6));
-    for (int q = gw; q < nitems; q += nwaves) {
-        const int p = q % pb.lparts, r = q / pb.lparts;
-        const int j = j_lo + r % nn, t = r / nn;
-        const int be = j / PP_B, k = j - be * PP_B;
-        const int start = max(0, be * PP_B - PP_B);                 // jprev of this node's batch
-        const int per = ((N - start + pb.lparts - 1) / pb.lparts + 63) / 64 * 64;
-        const int lo = start + p * per, hi = min(N, lo + per);
-        double2 *rec = (double2 *)pb.late + ((size_t)t * N + j) * pb.lparts + p;
-        pipe_eval_item<D, MODEL, TP>(c, pb, be, min(PP_B, N - be * PP_B), t, k, p, lane, lo, max(hi, lo),
-                                     false, rec);
+            c, pb, odd ? beO : beE, odd ? nbO : nbE, t, k, p, lane);
     }
 }
 
