@@ -728,52 +728,63 @@ def run_rank(args):
     K, W = args.steps, args.warmup
     models = ['lsm', 'hdp', 'cc'] if args.model == 'all' else [args.model]
     lines = []
-    for name in models:
-        wl = {'lsm': LsmWorkload, 'hdp': HdpWorkload, 'cc': CcWorkload}[name](args, group, local_rank)
-        elapsed, roofline, extra, acc, gathered = measure(wl, args, group)
-        cpu = None
-        if rank == 0 and not args.no_cpu and args.cpu_iters > 0:
-            cpu = wl.cpu_baseline()
-        if rank == 0:
-            C = args.chains_per_gpu
-            value = world * C * K / elapsed
-            xm = gathered['X_mean']
-            line = {
-                'metric': wl.metric(), 'value': round(value, 3), 'unit': 'Gibbs iterations/s',
-                'n_gpus': world, 'steps': K, 'warmup': W,
-                'ms_per_step': round(1e3 * elapsed / K, 4), 'higher_is_better': True,
-                'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-                'config': {'workload': wl.workload(), 'density': round(wl.density, 4),
-                           'chains': world * C, 'chains_per_gpu': C,
-                           'sweep_algo': (wl.model.chain_ if name == 'hdp' else wl.chain)
-                           .resolve_sweep_algo(args.algo),
-                           'mh_acceptance_rate': round(acc, 3),
-                           'network_broadcast': ('packed words, device to device (%s)'
-                                                 % group.backend) if world > 1 else 'none'},
-                'roofline': roofline, 'cpu_baseline': cpu,
-                'chain_summaries[intercept_mean,intercept_sd,logp_mean,logp_last]':
-                    chain_summaries(gathered),
-                'gathered': {k: list(v.shape) for k, v in gathered.items()},
-                'X_mean_rms_between_chains': (round(float(np.sqrt(((xm - xm.mean(0)) ** 2).mean())), 5)
-                                              if world * C > 1 else 0.0)}
-            if name == 'lsm':
-                line['config']['iteration'] = ('sweep + procrustes + centring + intercept MH + '
-                                               'logp trace')
-                line['iteration_fp64_valu'] = iteration_valu_fraction(1e3 * elapsed / K, args)
-            elif name == 'cc':
-                line['config']['iteration'] = ('sweep (case-control partial likelihoods) + centring + '
-                                               'intercept_in / intercept_out / radii MH around '
-                                               'case-control log-likelihood passes + logp trace; '
-                                               'controls redrawn every 100 iterations')
-            else:
-                line['config']['iteration'] = ('sweep (mixture prior) + centring + intercept MH + '
-                                               'label block update + HDP auxiliary / conjugate / '
-                                               'hyper-parameter draws + logp trace')
-                line['config']['loop'] = getattr(wl.model, 'loop_kind_', 'host-driven')
-                line['n_clusters_used_last'] = [float(v[-1]) for v in gathered['n_clusters_used']]
-            line.update(extra)
-            lines.append(line)
-        wl.close()
+    def run_model(name):
+            wl = {'lsm': LsmWorkload, 'hdp': HdpWorkload, 'cc': CcWorkload}[name](args, group, local_rank)
+            elapsed, roofline, extra, acc, gathered = measure(wl, args, group)
+            cpu = None
+            if rank == 0 and not args.no_cpu and args.cpu_iters > 0:
+                cpu = wl.cpu_baseline()
+            if rank == 0:
+                C = args.chains_per_gpu
+                value = world * C * K / elapsed
+                xm = gathered['X_mean']
+                line = {
+                    'metric': wl.metric(), 'value': round(value, 3), 'unit': 'Gibbs iterations/s',
+                    'n_gpus': world, 'steps': K, 'warmup': W,
+                    'ms_per_step': round(1e3 * elapsed / K, 4), 'higher_is_better': True,
+                    'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+                    'config': {'workload': wl.workload(), 'density': round(wl.density, 4),
+                               'chains': world * C, 'chains_per_gpu': C,
+                               'sweep_algo': (wl.model.chain_ if name == 'hdp' else wl.chain)
+                               .resolve_sweep_algo(args.algo),
+                               'mh_acceptance_rate': round(acc, 3),
+                               'network_broadcast': ('packed words, device to device (%s)'
+                                                     % group.backend) if world > 1 else 'none'},
+                    'roofline': roofline, 'cpu_baseline': cpu,
+                    'chain_summaries[intercept_mean,intercept_sd,logp_mean,logp_last]':
+                        chain_summaries(gathered),
+                    'gathered': {k: list(v.shape) for k, v in gathered.items()},
+                    'X_mean_rms_between_chains': (round(float(np.sqrt(((xm - xm.mean(0)) ** 2).mean())), 5)
+                                                  if world * C > 1 else 0.0)}
+                if name == 'lsm':
+                    line['config']['iteration'] = ('sweep + procrustes + centring + intercept MH + '
+                                                   'logp trace')
+                    line['iteration_fp64_valu'] = iteration_valu_fraction(1e3 * elapsed / K, args)
+                elif name == 'cc':
+                    line['config']['iteration'] = ('sweep (case-control partial likelihoods) + centring + '
+                                                   'intercept_in / intercept_out / radii MH around '
+                                                   'case-control log-likelihood passes + logp trace; '
+                                                   'controls redrawn every 100 iterations')
+                else:
+                    line['config']['iteration'] = ('sweep (mixture prior) + centring + intercept MH + '
+                                                   'label block update + HDP auxiliary / conjugate / '
+                                                   'hyper-parameter draws + logp trace')
+                    line['config']['loop'] = getattr(wl.model, 'loop_kind_', 'host-driven')
+                    line['n_clusters_used_last'] = [float(v[-1]) for v in gathered['n_clusters_used']]
+                line.update(extra)
+                lines.append(line)
+            wl.close()
+
+    for i, name in enumerate(models):
+        if i == 0 or world > 1:
+            run_model(name)         # ranks must stay in step: a failure ends the job
+            continue
+        try:                        # single process: an attached config may fail without
+            run_model(name)         # taking the headline line with it
+        except Exception as e:      # noqa: BLE001
+            import traceback
+            traceback.print_exc(file=sys.stderr)
+            lines.append({'metric': name, 'error': '%s: %s' % (type(e).__name__, e)})
     if rank == 0:
         head = lines[0]
         if len(lines) > 1:
