@@ -521,14 +521,14 @@ __device__ __forceinline__ void pipe_resolve(const ChainView &c, const PipeBuf &
         double prod = 1.0;
         int a = part;
         if (!anysat) {
-            for (; a + 24 < nprev; a += 32) {
-                const double h0 = colp[(size_t)sPrev[a] * PP_B];
-                const double h1 = colp[(size_t)sPrev[a + 8] * PP_B];
-                const double h2 = colp[(size_t)sPrev[a + 16] * PP_B];
-                const double h3 = colp[(size_t)sPrev[a + 24] * PP_B];
-                prod *= h0; prod *= h1; prod *= h2; prod *= h3;
-            }
-            for (; a < nprev; a += 8) prod *= colp[(size_t)sPrev[a] * PP_B];
+            // at most PP_B / 8 = 16 rows per thread: all their loads in flight together (clamped
+            // addresses, the factor of a row that is not there replaced by 1)
+            double hh[PP_B / 8];
+#pragma unroll
+            for (int u = 0; u < PP_B / 8; ++u)
+                hh[u] = colp[(size_t)sPrev[min(a + 8 * u, nprev - 1)] * PP_B];
+#pragma unroll
+            for (int u = 0; u < PP_B / 8; ++u) prod *= a + 8 * u < nprev ? hh[u] : 1.0;
         } else {
             double lsum = 0.0;
             for (; a < nprev; a += 8) {
