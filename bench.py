@@ -639,8 +639,16 @@ class CcWorkload(object):
         sweep_bytes = 2.0 * T * N * self.mean_terms * (8 + 16 + 8)
         k_bytes = sweep_bytes / max(launches, 1)
         ach = k_bytes / (k_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(kname, {}).get('hbm_bytes_per_launch')
+            except Exception:
+                traffic = None
         roofline = {'bound': 'hbm', 'kernel': kname, 'achieved': round(ach, 2), 'peak': HBM_PEAK_GBS,
-                    'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 5), 'traffic': None,
+                    'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 5), 'traffic': traffic,
+                    'traffic_source': 'profiles/traffic.json (rocprofv3 PMC of this kernel, stored)',
                     'us_per_launch': round(1e3 * k_ms, 3), 'launches_per_sweep': launches,
                     'algorithmic_bytes_per_launch': round(k_bytes, 1),
                     'gathered_terms_per_s_sweep': round(2.0 * T * N * self.mean_terms /
