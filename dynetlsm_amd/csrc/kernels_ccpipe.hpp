@@ -23,7 +23,7 @@
 // workgroups (one wavefront per node, every load of a gather level in flight together).  The lists are stored entry-major ([entry][node]) so
 // that the resolver's thread-per-node walks are coalesced; a node's first CP_OWN_REGS own
 // entries stay in registers across the passes of the solve.  Same snapshot rule, same
-// one-batch lag of the odd slices, same decisions as the dense form and the scalar oracle.
+// one-batch lag of the odd slices, same decisions as the dense form and the CPU oracle.
 #pragma once
 #include "kernels_spec_pipe.hpp"
 
