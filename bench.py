@@ -448,6 +448,7 @@ class HdpWorkload(object):
         # the facade wants a network argument: rank 0 has the real one; the other ranks (and
         # the other chains of this GPU) get the packed words and only need the shape
         Yarg = net['Y'] if rank == 0 else np.zeros((T, N, N))
+        self.start = dict(X=X0, b=b0, mu=mu0, sigma=sg0, z=z0)
         self.models = []
         for c in range(C):
             m = DynamicNetworkHDPLPCM(
@@ -466,6 +467,9 @@ class HdpWorkload(object):
             m.copy = False
             m._prepare(Yarg, init=dict(X=X0, intercept=[b0], mu=mu0, sigma=sg0, z=z0),
                        network_from=network_from)
+            if c == 0:              # the state the chain starts from (for the CPU leg)
+                self.start.update(beta=m._st['beta'].copy(), weights=m._st['weights'].copy(),
+                                  hyper=dict(m.hyper_.__dict__))
             self.models.append(m)
         self.model = self.models[0]
         self.next_it = 1
@@ -529,7 +533,27 @@ class HdpWorkload(object):
         return float(g.n_accepted.sum()) / max(float(g.n_steps.sum()), 1.0)
 
     def cpu_baseline(self):
-        return None
+        """rank 0: the oracle's restatement of the same iteration (C sweep, log-likelihoods and
+        label update; the O(T K^2) draws in numpy) from the same starting state, 1 core"""
+        from oracle import oracle as orc
+        from oracle import hdp_loop_oracle as hlo
+        a, st, m = self.args, self.start, self.model
+        T, N = a.T, a.N
+        hy = {k: v for k, v in st['hyper'].items() if k != 'n_components'}
+        n_it = max(2, a.cpu_iters // 2)
+        oc = hlo.HdpChain(self.net['Y'], st['X'].copy(), [st['b']], st['mu'].copy(), st['sigma'].copy(),
+                          st['z'].copy(), st['beta'].copy(), st['weights'].copy(), m.lambda_prior,
+                          hlo.Hyper(**hy), orc.SamplerGrid(T, N, 0.1, tune=None), st['b'],
+                          m.intercept_variance_prior, orc.ScalarMetropolis(0.1, None, 100),
+                          seed=1, chain=0)
+        tc = time.perf_counter()
+        for it in range(1, n_it + 1):
+            oc.iteration(it)
+        tc = time.perf_counter() - tc
+        return {'value': round(n_it / tc, 5), 'unit': 'Gibbs iterations/s', 'cores': 1, 'kind': 'port',
+                'sample': '%d iterations of the same T=%d N=%d K=%d workload by the oracle (scalar C '
+                          'sweep, two log-likelihood evaluations and label update; numpy draws), '
+                          '%.1f s' % (n_it, T, N, a.K, tc)}
 
     def close(self):
         for m in self.models:
@@ -569,6 +593,7 @@ class CcWorkload(object):
         out_edges = group.broadcast_array(out_edges).astype(np.int64)
         self.density = float(degree[:, :, 1].mean() / (N - 1))
         self.mean_terms = float(degree.sum(axis=2).mean() + 2 * C)
+        self.tables = (X, radii, degree, in_edges, out_edges) if rank == 0 else None
         self.chains = []
         for c in range(args.chains_per_gpu):
             ch = Chain(T, N, 2, 'case_control', seed=20240229, chain_id=rank * args.chains_per_gpu + c,
@@ -675,7 +700,32 @@ class CcWorkload(object):
         return float(g.n_accepted.sum()) / max(float(g.n_steps.sum()), 1.0)
 
     def cpu_baseline(self):
-        return None
+        """rank 0: the oracle's restatement of the same iteration (scalar C sweep and case-control
+        log-likelihoods; the radii's Dirichlet proposal in numpy) with the chain's controls"""
+        from oracle import oracle as orc
+        X, radii, degree, in_edges, out_edges = self.tables
+        T, N = self.T, self.N
+        ci, co = self.chain.get_controls()
+        cc = dict(in_edges=in_edges, out_edges=out_edges, degree=degree, control_nodes_in=ci,
+                  control_nodes_out=co)
+        st = orc.ChainState(X, orc.SamplerGrid(T, N, 0.002, tune=None), model=2, intercept=[1.0, 0.5],
+                            radii=radii.copy(), case_control=cc, tau_sq=1e-4, sigma_sq=1e-5,
+                            seed=20240229, chain=0)
+
+        def loglik(Xc, b, r):
+            return orc.approx_directed_network_loglikelihood(Xc, r, in_edges, out_edges, degree, co,
+                                                             b[0], b[1])
+        isamp = [orc.ScalarMetropolis(0.1, None, 100) for _ in range(2)]
+        rsamp = orc.ScalarMetropolis(175000., None, 100)
+        n_it = max(2, self.args.cpu_iters // 4)
+        tc = time.perf_counter()
+        for it in range(1, n_it + 1):
+            orc.lsm_iteration_directed(st, it, loglik, isamp, rsamp, np.array([1.0, 0.5]), 2.0)
+        tc = time.perf_counter() - tc
+        return {'value': round(n_it / tc, 5), 'unit': 'Gibbs iterations/s', 'cores': 1, 'kind': 'port',
+                'sample': '%d iterations of the same T=%d N=%d n_control=%d workload by the oracle '
+                          '(scalar C sweep, six case-control log-likelihood evaluations; the radii '
+                          'proposal in numpy), %.1f s' % (n_it, T, N, self.C, tc)}
 
     def close(self):
         for ch in self.chains:

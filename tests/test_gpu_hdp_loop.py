@@ -19,18 +19,19 @@ def eng():
     return dynetlsm_amd
 
 
-def _case(T, N, K, seed, n_true=3, density_b=1.0):
+def _case(T, N, K, seed, n_true=3, density_b=1.0, D=2):
     rng = np.random.RandomState(seed)
-    cen = 2.5 * rng.randn(n_true, 2)
+    n_true = min(n_true, K)
+    cen = 2.5 * rng.randn(n_true, D)
     z = np.zeros((T, N), dtype=np.int64)
     z[0] = rng.randint(0, n_true, N)
     for t in range(1, T):
         mv = rng.rand(N) < 0.15
         z[t] = np.where(mv, rng.randint(0, n_true, N), z[t - 1])
-    X = np.zeros((T, N, 2))
-    X[0] = cen[z[0]] + 0.5 * rng.randn(N, 2)
+    X = np.zeros((T, N, D))
+    X[0] = cen[z[0]] + 0.5 * rng.randn(N, D)
     for t in range(1, T):
-        X[t] = 0.2 * X[t - 1] + 0.8 * cen[z[t]] + 0.5 * rng.randn(N, 2)
+        X[t] = 0.2 * X[t - 1] + 0.8 * cen[z[t]] + 0.5 * rng.randn(N, D)
     X -= X.mean(axis=(0, 1))
     Y = np.zeros((T, N, N))
     for t in range(T):
@@ -38,14 +39,14 @@ def _case(T, N, K, seed, n_true=3, density_b=1.0):
         A = (rng.rand(N, N) < 1 / (1 + np.exp(-(density_b - d)))).astype(float)
         A = np.triu(A, 1)
         Y[t] = A + A.T
-    mu = np.vstack([cen - X.mean(axis=(0, 1)), 2.0 * rng.randn(K - n_true, 2)])[:K]
+    mu = np.vstack([cen - X.mean(axis=(0, 1)), 2.0 * rng.randn(K - n_true, D)])[:K]
     sigma = rng.uniform(0.2, 0.8, K)
     z0 = z.copy()
     flip = rng.rand(T, N) < 0.2
     z0[flip] = rng.randint(0, K, flip.sum())
     beta = rng.dirichlet(np.ones(K))
     w = rng.dirichlet(np.ones(K) * 0.7, size=(T, K))
-    return Y, X + 0.1 * rng.randn(T, N, 2), mu, sigma, z0, beta, w
+    return Y, X + 0.1 * rng.randn(T, N, D), mu, sigma, z0, beta, w
 
 
 def _hyper(a0=True, c0=True):
@@ -61,8 +62,8 @@ def _hyper(a0=True, c0=True):
 
 
 def _run_both(eng, T, N, K, seed, n_it, tune=None, algo=0, a0=True, c0=True, lmbda=0.8,
-              check_each=True):
-    Y, X, mu, sigma, z, beta, w = _case(T, N, K, seed)
+              check_each=True, D=2):
+    Y, X, mu, sigma, z, beta, w = _case(T, N, K, seed, D=D)
     b0, ip, var = 0.6, 0.5, 2.0
     hp = _hyper(a0, c0)
     og = orc.SamplerGrid(T, N, 0.15, tune=tune, tune_interval=2)
@@ -71,7 +72,7 @@ def _run_both(eng, T, N, K, seed, n_it, tune=None, algo=0, a0=True, c0=True, lmb
     oc = hlo.HdpChain(Y, X.copy(), [b0], mu.copy(), sigma.copy(), z.copy(), beta.copy(), w.copy(),
                       lmbda, hp.copy(), og, ip, var, isamp, seed=77 + seed, chain=2)
     out = []
-    with eng.Chain(T, N, 2, 'undirected', seed=77 + seed, chain_id=2) as c:
+    with eng.Chain(T, N, D, 'undirected', seed=77 + seed, chain_id=2) as c:
         c.upload_network(Y); c.set_positions(X); c.set_intercepts([b0])
         c.set_samplers(eng.SamplerGrid(T, N, 0.15, tune=tune, tune_interval=2))
         c.set_prior_mixture(mu, sigma, lmbda, z)
@@ -128,6 +129,14 @@ def test_device_loop_with_tuning_and_without_hyperpriors(eng):
     _run_both(eng, 3, 80, 5, 5, n_it=6, tune=4)
     _run_both(eng, 3, 50, 4, 6, n_it=3, a0=False, c0=False)
     _run_both(eng, 3, 50, 4, 7, n_it=3, a0=True, c0=False)
+
+
+@pytest.mark.parametrize('T,N,K,D,seed', [(3, 45, 5, 1, 12), (2, 50, 33, 3, 13), (3, 40, 1, 2, 14),
+                                          (2, 36, 64, 4, 15)])
+def test_device_loop_other_dimensions_and_component_counts(eng, T, N, K, D, seed):
+    """d = 1, 3, 4; a single component (every Dirichlet draw is 1); more components than half a
+    wavefront; the 64-component limit"""
+    _run_both(eng, T, N, K, seed, n_it=3, D=D)
 
 
 def test_device_loop_single_time_step(eng):
