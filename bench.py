@@ -540,7 +540,7 @@ class HdpWorkload(object):
         a, st, m = self.args, self.start, self.model
         T, N = a.T, a.N
         hy = {k: v for k, v in st['hyper'].items() if k != 'n_components'}
-        n_it = max(2, a.cpu_iters // 2)
+        n_it = max(2, a.cpu_iters)
         oc = hlo.HdpChain(self.net['Y'], st['X'].copy(), [st['b']], st['mu'].copy(), st['sigma'].copy(),
                           st['z'].copy(), st['beta'].copy(), st['weights'].copy(), m.lambda_prior,
                           hlo.Hyper(**hy), orc.SamplerGrid(T, N, 0.1, tune=None), st['b'],
@@ -717,7 +717,7 @@ class CcWorkload(object):
                                                              b[0], b[1])
         isamp = [orc.ScalarMetropolis(0.1, None, 100) for _ in range(2)]
         rsamp = orc.ScalarMetropolis(175000., None, 100)
-        n_it = max(2, self.args.cpu_iters // 4)
+        n_it = max(2, self.args.cpu_iters)
         tc = time.perf_counter()
         for it in range(1, n_it + 1):
             orc.lsm_iteration_directed(st, it, loglik, isamp, rsamp, np.array([1.0, 0.5]), 2.0)
