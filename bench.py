@@ -84,6 +84,9 @@ def parse(argv=None):
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--backend', default=None,
                     help='collective backend (default nccl = RCCL; gloo for dry runs)')
+    ap.add_argument('--force-collectives', action='store_true',
+                    help='with --gpus 1: initialise the backend anyway and route the broadcast / '
+                         'gather / barrier through it (exercises RCCL on a single-GPU box)')
     ap.add_argument('--share-device0', action='store_true',
                     help='dry run: every rank drives cuda:0 (with --backend gloo)')
     return ap.parse_args(argv)
@@ -781,7 +784,8 @@ def run_rank(args):
         local_rank = 0
         os.environ['LOCAL_RANK'] = '0'
     # one process per GPU; collectives over RCCL (backend "nccl") unless told otherwise
-    group = init_chain_group(backend=(args.backend or 'nccl') if world > 1 else 'gloo')
+    group = init_chain_group(backend=(args.backend or 'nccl') if (world > 1 or args.force_collectives)
+                             else 'gloo', force=args.force_collectives)
     torch.cuda.set_device(local_rank)
     K, W = args.steps, args.warmup
     models = ['lsm', 'hdp', 'cc'] if args.model == 'all' else [args.model]

@@ -27,10 +27,13 @@ __all__ = ['ChainGroup', 'init_chain_group']
 class ChainGroup(object):
     """Rank / device bookkeeping of one process of the chain group."""
 
-    def __init__(self, rank, world, local_rank, backend, dist=None, torch=None):
+    def __init__(self, rank, world, local_rank, backend, dist=None, torch=None, force=False):
         self.rank, self.world, self.local_rank = rank, world, local_rank
         self.backend = backend
         self._dist, self._torch = dist, torch
+        # force: go through the collectives even in a group of one (a single-GPU box can then
+        # exercise the RCCL path: device tensors, stream ordering, library initialisation)
+        self._solo = world == 1 and not force
 
     @property
     def chain_id(self):
@@ -45,12 +48,12 @@ class ChainGroup(object):
         return t.device('cuda', self.local_rank) if self.backend == 'nccl' else t.device('cpu')
 
     def barrier(self):
-        if self.world > 1:
+        if not self._solo:
             self._dist.barrier()
 
     def broadcast_network(self, Y, shape=None, src=0):
         """Y (T, N, N) float64 on ``src`` (None elsewhere) -> float64 on all."""
-        if self.world == 1:
+        if self._solo:
             return np.ascontiguousarray(Y, dtype=np.float64)
         t = self._torch
         dev = self._tensor_device()
@@ -73,7 +76,7 @@ class ChainGroup(object):
         """The packed network of rank ``src``'s chain (already uploaded there) into the
         chain of every other rank; same shape and model on every rank.  With the RCCL
         backend the words never leave device memory."""
-        if self.world == 1:
+        if self._solo:
             return
         t = self._torch
         n = chain.network_packed_words()
@@ -88,7 +91,7 @@ class ChainGroup(object):
 
     def broadcast_array(self, a, src=0):
         """small float64 array (same shape known on every rank)"""
-        if self.world == 1:
+        if self._solo:
             return np.asarray(a, dtype=np.float64)
         t = self._torch
         buf = t.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(self._tensor_device())
@@ -98,7 +101,7 @@ class ChainGroup(object):
     def gather_arrays(self, a):
         """list (one per rank) of equally shaped float64 arrays, on every rank"""
         a = np.ascontiguousarray(a, dtype=np.float64)
-        if self.world == 1:
+        if self._solo:
             return [a]
         t = self._torch
         mine = t.from_numpy(a).to(self._tensor_device())
@@ -113,7 +116,7 @@ class ChainGroup(object):
         return {k: np.stack(self.gather_arrays(results[k])) for k in sorted(results)}
 
     def max_over_ranks(self, x):
-        if self.world == 1:
+        if self._solo:
             return float(x)
         t = self._torch
         v = t.tensor([float(x)], dtype=t.float64, device=self._tensor_device())
@@ -121,13 +124,14 @@ class ChainGroup(object):
         return float(v.cpu()[0])
 
     def close(self):
-        if self.world > 1 and self._dist.is_initialized():
+        if not self._solo and self._dist.is_initialized():
             self._dist.destroy_process_group()
 
 
-def init_chain_group(backend=None):
+def init_chain_group(backend=None, force=False):
     """Join the process group described by RANK / WORLD_SIZE / LOCAL_RANK /
-    MASTER_ADDR / MASTER_PORT (torch.distributed.run sets them)."""
+    MASTER_ADDR / MASTER_PORT (torch.distributed.run sets them).  ``force``: initialise the
+    backend and route through its collectives even when WORLD_SIZE is 1."""
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -137,9 +141,11 @@ def init_chain_group(backend=None):
         backend = 'nccl' if torch.cuda.is_available() else 'gloo'
     if backend == 'nccl':
         torch.cuda.set_device(local_rank)
-    if world > 1:
+    if world > 1 or force:
         kw = {}
         if backend == 'nccl':
             kw['device_id'] = torch.device('cuda', local_rank)
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29511')
         dist.init_process_group(backend, rank=rank, world_size=world, **kw)
-    return ChainGroup(rank, world, local_rank, backend, dist, torch)
+    return ChainGroup(rank, world, local_rank, backend, dist, torch, force=force)

@@ -166,3 +166,14 @@ def test_chains_sharing_a_gpu_are_bitwise_the_single_chain_runs(eng):
             np.testing.assert_array_equal(a, b)
         c.close()
     assert not np.array_equal(alone[0][0][-1], alone[1][0][-1])     # chain id keys the draws
+
+
+def test_bench_through_rccl_in_a_group_of_one():
+    """the RCCL code path on a single-GPU box: `--force-collectives` initialises the nccl
+    backend with world size 1 and sends the packed network, the starting values, the timing
+    reduction and the final gather through it (device tensors, stream ordering)"""
+    line = _run_bench('--gpus', '1', '--force-collectives', '--backend', 'nccl', '--model', 'lsm',
+                      '--steps', '10', '--warmup', '3', '--profile-steps', '0', '--no-cpu')
+    assert line['n_gpus'] == 1 and line['value'] > 0
+    assert 'nccl' in line['config']['network_broadcast']
+    assert line['gathered']['X_mean'] == [1, 10, 2000, 2]
