@@ -811,7 +811,8 @@ def run_rank(args):
                                .resolve_sweep_algo(args.algo),
                                'mh_acceptance_rate': round(acc, 3),
                                'network_broadcast': ('packed words, device to device (%s)'
-                                                     % group.backend) if world > 1 else 'none'},
+                                                     % group.backend)
+                               if (world > 1 or args.force_collectives) else 'none'},
                     'roofline': roofline, 'cpu_baseline': cpu,
                     'chain_summaries[intercept_mean,intercept_sd,logp_mean,logp_last]':
                         chain_summaries(gathered),
