@@ -794,7 +794,7 @@ def run_rank(args):
             wl = {'lsm': LsmWorkload, 'hdp': HdpWorkload, 'cc': CcWorkload}[name](args, group, local_rank)
             elapsed, roofline, extra, acc, gathered = measure(wl, args, group)
             cpu = None
-            if rank == 0 and not args.no_cpu and args.cpu_iters > 0:
+            if rank == 0 and world == 1 and not args.no_cpu and args.cpu_iters > 0:      # at N = 1 only
                 cpu = wl.cpu_baseline()
             if rank == 0:
                 C = args.chains_per_gpu
