@@ -101,7 +101,16 @@ __global__ __launch_bounds__(64 * LAB_WAVES) void k_sample_labels(
         if (lane < K) pm[t * K + lane] = pmk;          // the forward pass needs it again
         double s = 0.0;
         const double *wr = wt + ((size_t)t * K + min(lane, K - 1)) * KP;
-        for (int k = 0; k < K; ++k) s += wr[k] * lane_value(pmk, k);
+        // the lane's row of w, eight LDS reads in flight per trip (one read per term of the
+        // chain would pay the LDS latency K times per step); same terms, same order
+        for (int k0 = 0; k0 < K; k0 += 8) {
+            double wv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) wv[u] = wr[min(k0 + u, K - 1)];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (k0 + u < K) s += wv[u] * lane_value(pmk, k0 + u);
+        }
         double tot = 0.0;
         for (int r = 0; r < K; ++r) tot += lane_value(s, r);
         bmk = s / tot;
