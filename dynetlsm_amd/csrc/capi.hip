@@ -217,20 +217,6 @@ int launch_loglik_records(dlsm_chain *h, int M, const double *d_ic,
     } else {
         // every load up front when a node's out-edges fit one trip and its controls two
         const bool pf = h->Dout <= 64 && h->C <= 128 && !getenv("DLSM_CC_LOGLIK_PLAIN");
-        // candidates that share their radii, and the radii fit in LDS: one gather per term
-        if (pf && (M == 1 || r0 == r1) && h->N <= LLCC_LDS_MAX_N && !getenv("DLSM_CC_LOGLIK_NOLDS")) {
-            const size_t lds = (size_t)h->N * sizeof(double);
-            const int grid = std::min(h->n_cu, (int)(((size_t)h->T * h->N + 63) / 64));
-            auto k1 = k_loglik_casecontrol_lds<DD, 1>;
-            auto k2 = k_loglik_casecontrol_lds<DD, 2>;
-            HIPCHK(h, hipFuncSetAttribute((const void *)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            HIPCHK(h, hipFuncSetAttribute((const void *)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            if (M == 1) hipLaunchKernelGGL(k1, dim3(grid), dim3(LLCC_LDS_THREADS), lds, h->stream, v, cand, h->partials);
-            else hipLaunchKernelGGL(k2, dim3(grid), dim3(LLCC_LDS_THREADS), lds, h->stream, v, cand, h->partials);
-            HIPCHK(h, hipGetLastError());
-            *nrec_out = grid;
-            return DLSM_OK;
-        }
         if (pf) {       // positions and both candidates' radii as one record per node
             const size_t nodes = (size_t)h->T * h->N;
             const size_t need = nodes * llcc_record_width(DD);

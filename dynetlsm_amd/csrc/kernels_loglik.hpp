@@ -575,119 +575,6 @@ __global__ __launch_bounds__(256) void k_loglik_casecontrol_pf(
     }
 }
 
-// The same for candidates that share their radii (every pass of the device-resident loop: two
-// intercept candidates at the chain's radii, or one candidate at the proposed radii) when the
-// radii fit in LDS (N <= 10 240 at 80 KB): persistent 1024-thread workgroups stage the N radii
-// once and read r_e from LDS, so a term is ONE scattered 16-byte gather (the position) instead of
-// two - the kernel is bound by the rate of those gather instructions (section 4.15 of DESIGN.md).
-constexpr int LLCC_LDS_THREADS = 1024;
-constexpr int LLCC_LDS_MAX_N = 10240;
-template <int D, int M>
-__global__ __launch_bounds__(LLCC_LDS_THREADS) void k_loglik_casecontrol_lds(
-    ChainView c, LoglikCand cand, double *__restrict__ partials) {
-    constexpr int NPW = 4;
-    constexpr int WAVES = LLCC_LDS_THREADS / 64;
-    extern __shared__ double sRad[];                  // N radii
-    __shared__ double sRed[WAVES * M];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const long nodes = (long)c.T * c.N;
-    for (int i = tid; i < c.N; i += LLCC_LDS_THREADS) sRad[i] = cand.radii[0][i];
-    double bin[M], bout[M];
-#pragma unroll
-    for (int m = 0; m < M; ++m) { bin[m] = cand.intercepts[2 * m]; bout[m] = cand.intercepts[2 * m + 1]; }
-    __syncthreads();
-    double L[M], Pe[M];
-#pragma unroll
-    for (int m = 0; m < M; ++m) { L[m] = 0.0; Pe[m] = 1.0; }
-    for (long base = ((long)blockIdx.x * WAVES + wave) * NPW; base < nodes;
-         base += (long)gridDim.x * WAVES * NPW) {
-        long node[NPW];
-        int outdeg[NPW], e[NPW][3], nctl[NPW];
-#pragma unroll
-        for (int r = 0; r < NPW; ++r) {
-            node[r] = base + r;
-            outdeg[r] = node[r] < nodes ? c.degree[node[r] * 2 + 1] : 0;
-        }
-#pragma unroll
-        for (int r = 0; r < NPW; ++r) {
-            const bool live = node[r] < nodes;
-            const long nn = live ? node[r] : 0;
-            e[r][0] = live && lane < outdeg[r] ? c.out_edges[nn * c.Dout + lane] : -1;
-            e[r][1] = live && lane < c.C ? c.ctrl_out[nn * c.C + lane] : -1;
-            e[r][2] = live && 64 + lane < c.C ? c.ctrl_out[nn * c.C + 64 + lane] : -1;
-        }
-#pragma unroll
-        for (int r = 0; r < NPW; ++r) {     // the control list ends at its first -1
-            const unsigned long long bad1 = ~__ballot(e[r][1] >= 0);
-            const int fb1 = bad1 ? __builtin_ctzll(bad1) : 64;
-            if (lane >= fb1) e[r][1] = -1;
-            const unsigned long long bad2 = ~__ballot(e[r][2] >= 0);
-            const int fb2 = fb1 < 64 ? 0 : (bad2 ? __builtin_ctzll(bad2) : 64);
-            if (lane >= fb2) e[r][2] = -1;
-            nctl[r] = fb1 + fb2;
-        }
-        double xi[NPW][D], xe[NPW][3][D];
-        int ii[NPW];
-#pragma unroll
-        for (int r = 0; r < NPW; ++r) {
-            const long nn = node[r] < nodes ? node[r] : 0;
-            const int t = (int)(nn / c.N);
-            ii[r] = (int)(nn % c.N);
-            const double *Xt = c.X + (size_t)t * c.N * D;
-#pragma unroll
-            for (int d = 0; d < D; ++d) xi[r][d] = Xt[(size_t)ii[r] * D + d];
-#pragma unroll
-            for (int s = 0; s < 3; ++s) {
-                const int ee = max(e[r][s], 0);
-#pragma unroll
-                for (int d = 0; d < D; ++d) xe[r][s][d] = Xt[(size_t)ee * D + d];
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < NPW; ++r) {
-            if (node[r] >= nodes) continue;                   // wave-uniform
-            const double iri = 1.0 / sRad[ii[r]];
-            double Pc[M], ctl[M];
-#pragma unroll
-            for (int m = 0; m < M; ++m) { Pc[m] = 1.0; ctl[m] = 0.0; }
-#pragma unroll
-            for (int s = 0; s < 3; ++s) {
-                if (e[r][s] < 0) continue;
-                const double dd = dist_fast<D>(xe[r][s], xi[r], c.squared);
-                const double ire = fast_rcp(sRad[e[r][s]]);
-#pragma unroll
-                for (int m = 0; m < M; ++m) {
-                    const double eta = bin[m] * (1.0 - dd * ire) + bout[m] * (1.0 - dd * iri);
-                    if (s == 0) {               // out edge : directed_likelihoods_fast.pyx:236-247
-                        L[m] += eta;
-                        if (eta > 130.0) { L[m] -= eta; continue; }       // log(1 + e^eta) = eta there
-                        if (Pe[m] > 1e250) { L[m] -= log(Pe[m]); Pe[m] = 1.0; }
-                        Pe[m] *= 1.0 + fast_exp(fmax(eta, -700.0));
-                    } else {                    // control : :250-268
-                        if (eta > 130.0) { ctl[m] += eta; continue; }
-                        Pc[m] *= 1.0 + fast_exp(fmax(eta, -700.0));
-                    }
-                }
-            }
-            const double adj = (double)(c.N - outdeg[r] - 1) / (double)nctl[r];
-#pragma unroll
-            for (int m = 0; m < M; ++m) L[m] -= adj * (ctl[m] + log(Pc[m]));
-        }
-    }
-#pragma unroll
-    for (int m = 0; m < M; ++m) {
-        L[m] -= log(Pe[m]);
-        double v = wave_sum_all(L[m]);
-        if (lane == 0) sRed[wave * M + m] = v;
-    }
-    __syncthreads();
-    if (tid < M) {
-        double s = 0.0;
-        for (int w = 0; w < WAVES; ++w) s += sRed[w * M + tid];
-        partials[(size_t)blockIdx.x * M + tid] = s;
-    }
-}
-
 // Deterministic final reduction of `nrec` records of `width` doubles: one
 // workgroup, fixed strided order + fixed tree.  out[q] = sum_r rec[r][q].
 __device__ __forceinline__ void reduce_records(const double *__restrict__ rec,
