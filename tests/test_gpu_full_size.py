@@ -317,3 +317,49 @@ def test_c3_facade_fit_logps_recomputed_by_the_oracle(eng, loop):
         np.testing.assert_allclose(m.logps_[it], want, rtol=1e-9)
     assert (m.zs_[-1] != m.zs_[0]).any() and np.isfinite(m.logps_[1:]).all()
     np.testing.assert_allclose(m.weights_[-1].sum(-1)[1:], 1.0, rtol=1e-12)
+
+
+def test_c3_device_loop_invariants_at_full_size(eng):
+    """size-independent properties of the device-resident HDP-LPCM iteration at T=10, N=2000,
+    K_max=20 (sample_auxillary.py / hdp_lpcm.py:876-1023): table counts between 1 and the
+    customer counts, override counts below the diagonal tables, m_bar as defined, label counts
+    that add up, distributions that are normalised, parameters in their supports"""
+    from dynetlsm_amd import hdp_updates as hu
+    from dynetlsm_amd.synthetic import synthetic_hdp_network
+    T, N, K = 10, 2000, 20
+    net = synthetic_hdp_network(T=T, N=N, D=2, density=0.03, seed=0)
+    rs = np.random.RandomState(5)
+    mu0 = np.zeros((K, 2)); mu0[:6] = net['mu_true']; mu0[6:] = 3.0 * rs.randn(K - 6, 2)
+    sg0 = np.full(K, float(net['sigma_true'].mean()))
+    beta = rs.dirichlet(np.ones(K))
+    w = rs.dirichlet(np.ones(K), size=(T, K))
+    hp = hu.HDPHyper(K, mean_variance_prior=40.0, b=160.0, a0=36.0, b0=2720.0, c0=16.0, d0=0.1)
+    with eng.Chain(T, N, 2, 'undirected', seed=8, chain_id=1) as c:
+        c.upload_network(net['Y']); c.set_positions(net['X_init'])
+        c.set_intercepts([net['intercept']])
+        c.set_samplers(eng.SamplerGrid(T, N, 0.1, tune=None))
+        c.set_prior_mixture(mu0, sg0, 0.9, net['z_true'])
+        c.hdp_configure(hp, beta, w, net['intercept'], 2.0)
+        n_it = 4
+        c.hdp_trace_alloc(n_it + 1)
+        for it in range(1, n_it + 1):
+            c.hdp_run(it, 1)
+            a = c.hdp_get_aux()
+            tr = c.hdp_trace_read(it, 1, positions=False)
+            n, m, nk = a['n'], a['m'], a['nk']
+            assert (nk.sum(axis=1) == N).all() and n[0, 0].sum() == N and (n[0, 1:] == 0).all()
+            assert (n[1:].sum(axis=(1, 2)) == N).all()
+            np.testing.assert_array_equal(n[1:].sum(axis=1), nk[1:])          # arrivals per label
+            np.testing.assert_array_equal(n[1:].sum(axis=2), nk[:-1])         # departures per label
+            assert (m <= n).all() and (m[n > 0] >= 1).all() and (m[n == 0] == 0).all()
+            idx = np.arange(K)
+            assert (a['w_over'] <= m[1:, idx, idx]).all() and (a['w_over'] >= 0).all()
+            want = m[1:].sum(axis=(0, 1)) - a['w_over'].sum(axis=0) + m[0, 0]
+            np.testing.assert_array_equal(a['m_bar'], want)
+            np.testing.assert_allclose(tr['betas'][0].sum(), 1.0, rtol=1e-12)
+            np.testing.assert_allclose(tr['weights'][0, 0, 0].sum(), 1.0, rtol=1e-12)
+            np.testing.assert_allclose(tr['weights'][0, 1:].sum(axis=-1), 1.0, rtol=1e-12)
+            assert (tr['sigmas'][0] > 0).all() and 0.0 < tr['lambdas'][0, 0] < 1.0
+            assert (tr['hypers'][0] > 0).all() and np.isfinite(tr['logps'][0])
+            np.testing.assert_array_equal(np.bincount(tr['zs'][0].ravel(), minlength=K),
+                                          nk.sum(axis=0))
