@@ -736,10 +736,16 @@ class CcWorkload(object):
 
 
 def measure(wl, args, group):
-    """W untimed warm-up steps, then exactly K steps between barriers + synchronisation,
-    max over ranks; the roofline profile and the final gather follow outside the timed region"""
+    """the roofline profile (P steps), W untimed warm-up steps, then exactly K steps between
+    barriers + synchronisation, max over ranks; the final gather follows outside the timed region"""
     import torch
     K, W = args.steps, args.warmup
+    # the per-kernel profile (P steps with HIP events around every launch) comes first: it is
+    # part of every run anyway, and placed here the timed steps do not start on a device that has
+    # just sat idle through the host-side generation of the network
+    roofline, extra = (None, {})
+    if args.profile_steps > 0:
+        roofline, extra = wl.profile()
     wl.run(W)
     wl.synchronize()
     torch.cuda.synchronize()
@@ -750,11 +756,9 @@ def measure(wl, args, group):
     torch.cuda.synchronize()
     group.barrier()
     elapsed = group.max_over_ranks(time.perf_counter() - t0)
-    roofline, extra = (None, {})
-    if args.profile_steps > 0:
-        roofline, extra = wl.profile()
     acc = wl.acceptance()
-    gathered = group.gather_results(wl.results(1 + W, K))
+    P = args.profile_steps if args.profile_steps > 0 else 0
+    gathered = group.gather_results(wl.results(1 + P + W, K))
     # (ranks, chains per GPU, ...) -> (chains, ...)
     gathered = {k: v.reshape((-1,) + v.shape[2:]) for k, v in gathered.items()}
     return elapsed, roofline, extra, acc, gathered
