@@ -394,6 +394,13 @@ def test_sweep_case_control_sparse_lists_over_several_batches(eng, T, N, C, dens
                 scale=0.05, cc_C=C, density=density)
 
 
+@pytest.mark.parametrize('D', [1, 3, 4])
+def test_sweep_case_control_sparse_lists_other_dimensions(eng, D):
+    """algo 5 with d = 1, 3, 4 (packed records of 4 / 4 / 8 doubles), two batches"""
+    _sweep_case(eng, 'case_control', 'rw', T=2, N=700, D=D, n_sweeps=2, algo=5, scale=0.05, cc_C=8,
+                density=0.01)
+
+
 def test_sweep_auto_picks_a_valid_algorithm(eng):
     _sweep_case(eng, 'undirected', 'rw', T=3, N=400, D=2, n_sweeps=2, algo=0)
     _sweep_case(eng, 'undirected', 'rw', T=3, N=40, D=2, n_sweeps=2, algo=0)
