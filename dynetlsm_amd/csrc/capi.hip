@@ -1660,3 +1660,12 @@ extern "C" int dlsm_host_sample_tables(void *numpy_bitgen, int T, int K, const d
     return dlsm::host_sample_tables((dlsm::NumpyBitGen *)numpy_bitgen, T, K, n, beta, alpha_init,
                                     alpha, kappa, m);
 }
+
+#ifdef DLSM_PIPE_TIMING
+extern "C" int dlsm_debug_pipe_timing(unsigned long long *items, unsigned long long *res) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(items, HIP_SYMBOL(dlsm::g_pipe_item_t), sizeof(dlsm::g_pipe_item_t)) != hipSuccess) return -2;
+    if (hipMemcpyFromSymbol(res, HIP_SYMBOL(dlsm::g_pipe_res_t), sizeof(dlsm::g_pipe_res_t)) != hipSuccess) return -3;
+    return 0;
+}
+#endif

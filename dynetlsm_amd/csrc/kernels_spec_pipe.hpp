@@ -114,13 +114,69 @@ __device__ __forceinline__ void pipe_directed_term(RatioAcc &ra, double &exact, 
 // prefix(kk) = ncross kk + kk (kk - 1) / 2 (f < 2^16: the float root is off by one at most)
 __device__ __forceinline__ void pipe_h_decode(int f, int ncross, int nb, int &kk, int &e) {
     const float bq = (float)(2 * ncross - 1);
-    kk = (int)((sqrtf(fmaf(bq, bq, 8.0f * (float)f)) - bq) * 0.5f);
+    kk = (int)((__builtin_amdgcn_sqrtf(fmaf(bq, bq, 8.0f * (float)f)) - bq) * 0.5f);
     kk = min(max(kk, 0), nb - 1);
     int pre = ncross * kk + ((kk * (kk - 1)) >> 1);
     if (pre > f) { --kk; pre -= ncross + kk; }
     else if (pre + ncross + kk <= f) { pre += ncross + kk; ++kk; }
     kk = min(kk, nb - 1);                 // only when f is not a valid index (clamped prefetch)
     e = f - pre;
+}
+
+#ifdef DLSM_PIPE_TIMING
+// phase stamps (100 MHz constant clock) of every evaluator wavefront and every resolver
+// workgroup of the last sweep: profiles/pipe_timing.py reads them
+__device__ unsigned long long g_pipe_item_t[24][4096][6];
+__device__ unsigned long long g_pipe_res_t[24][32][5];
+__device__ __forceinline__ unsigned long long pipe_clock(double dep) {
+    unsigned long long t;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : "v"(dep));
+    return t;
+}
+#define DLSM_STAMP(I_, DEP_) ts[I_] = pipe_clock(DEP_);
+#else
+#define DLSM_STAMP(I_, DEP_)
+#endif
+
+// ---- the item's wavefront reductions -------------------------------------------------------
+// An evaluator launch is bound by float64 VALU issue (profiles/pipe_timing.py: the four
+// wavefronts of a SIMD run one after the other, the SIMD is busy from the first operand's
+// arrival to the launch's end), so what is not a neighbour term is overhead to be counted in
+// instructions.  Only lane 0 stores the record: the sum and the two products are reduced
+// towards it with DPP moves that need no "old" value (every lane of these patterns is valid),
+// the two products share one tree from the second step on (even lanes carry P0, odd lanes
+// P1: quad_perm xor 2 and the row rotations keep the parity), and the rows are combined
+// through the LDS crossbar (ds_bpermute: no VALU cycles) instead of v_readlane.
+template <int CTRL>
+__device__ __forceinline__ double dpp_get(double v) {
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lane_get(double v, int byte_addr) {      // 4 * source lane
+    return __hiloint2double(__builtin_amdgcn_ds_bpermute(byte_addr, __double2hiint(v)),
+                            __builtin_amdgcn_ds_bpermute(byte_addr, __double2loint(v)));
+}
+// lane 0: sum = sum over the wavefront of s, ratio = prod a / prod b
+__device__ __forceinline__ void pipe_reduce(double s, double a, double b, int lane, double &sum,
+                                            double &ratio) {
+    const int x16 = (lane ^ 16) << 2, x32 = (lane ^ 32) << 2;
+    s += dpp_get<0xB1>(s);         // quad_perm [1, 0, 3, 2]
+    a *= dpp_get<0xB1>(a);
+    b *= dpp_get<0xB1>(b);
+    double q = (lane & 1) ? b : a;
+    s += dpp_get<0x4E>(s);         // quad_perm [2, 3, 0, 1]
+    q *= dpp_get<0x4E>(q);
+    s += dpp_get<0x124>(s);        // row_ror:4
+    q *= dpp_get<0x124>(q);
+    s += dpp_get<0x128>(s);        // row_ror:8
+    q *= dpp_get<0x128>(q);
+    s += lane_get(s, x16);
+    q *= lane_get(q, x16);
+    s += lane_get(s, x32);
+    q *= lane_get(q, x32);
+    sum = s;
+    ratio = q / dpp_get<0xB1>(q);  // lane 0: prod a / prod b
 }
 
 // trips of 64 neighbours whose operands an undirected item loads up front
@@ -133,9 +189,18 @@ __host__ __device__ constexpr int pipe_prefetch_trips(int D) {
 // prefetch, where it is worth +3 % - at C2, where everything is prefetched, it costs 1 %).
 template <int D, int MODEL, bool TP>
 __device__ __forceinline__ void pipe_eval_item(const ChainView &c, const PipeBuf &pb, int be,
-                                               int nb, int t, int k, int p, int lane) {
+                                               int nb, int t, int k, int p, int lane,
+                                               const double *etab
+#ifdef DLSM_PIPE_TIMING
+                                               , int tl, int tgw
+#endif
+                                               ) {
     constexpr int PW = 2 * D + 2;
     const int N = c.N, W = c.W;
+#ifdef DLSM_PIPE_TIMING
+    unsigned long long ts[6] = {0, 0, 0, 0, 0, 0};
+#endif
+    DLSM_STAMP(0, (double)lane)
     const int j0 = be * PP_B, jk = j0 + k;
     const int jprev = max(0, j0 - PP_B);       // nodes >= jprev: snapshot positions
     const int ncross = j0 - jprev;
@@ -171,10 +236,20 @@ __device__ __forceinline__ void pipe_eval_item(const ChainView &c, const PipeBuf
     const int w0 = lo >> 5;
     const uint32_t yseg = yr[min(w0 + lane, W - 1)];
     const uint32_t ycseg = MODEL == DLSM_DIRECTED ? yc[min(w0 + lane, W - 1)] : 0u;
+    // lo and jprev are multiples of 64, so a trip's 64 neighbours are all on one side of jprev
+    // (the clamped ones included: N - 1 >= jprev): the array and its row stride are scalar
+    // choices and a lane's address is a 32-bit offset from a scalar base
+    auto x_source = [&](int first, int ic, uint32_t &off) -> const char * {
+        const bool snap = first >= jprev;
+        off = __umul24((uint32_t)ic, (uint32_t)((snap ? PW : D) * sizeof(double)));    // N < 2^24
+        return snap ? (const char *)(props + D + 2) : (const char *)Xt;
+    };
 #pragma unroll
     for (int u = 0; u < PP_NPRE; ++u) {
         const int ic = min(lo + lane + 64 * u, N - 1);
-        const double *src = ic < jprev ? Xt + (size_t)ic * D : props + (size_t)ic * PW + D + 2;
+        uint32_t off;
+        const char *base = x_source(lo + 64 * u, ic, off);
+        const double *src = (const double *)(base + off);
 #pragma unroll
         for (int d = 0; d < D; ++d) xpre[u][d] = src[d];
         if (MODEL == DLSM_DIRECTED) rpre[u] = c.radii[ic];
@@ -198,8 +273,8 @@ __device__ __forceinline__ void pipe_eval_item(const ChainView &c, const PipeBuf
             const double d0_ = dist_fast<D>(XI_, xk0, SQ_);                                   \
             const double d1_ = dist_fast<D>(XI_, xk1, SQ_);                                   \
             ra.lin = fma((YB_) ? 1.0 : 0.0, d0_ - d1_, ra.lin);                               \
-            ra.P0 *= fma(E, fast_exp(-d0_), 1.0);                                             \
-            ra.P1 *= fma(E, fast_exp(-d1_), 1.0);                                             \
+            ra.P0 *= fma(E, tab_exp(-d0_, etab), 1.0);                                        \
+            ra.P1 *= fma(E, tab_exp(-d1_, etab), 1.0);                                        \
             if (FLUSH_) if (++ra.cnt >= nflush) ra.flush();                                   \
         } else {                                                                              \
             const double d0_ = dist_fast<D>(XI_, xk0, c.squared);                             \
@@ -236,8 +311,9 @@ __device__ __forceinline__ void pipe_eval_item(const ChainView &c, const PipeBuf
 #define DLSM_PIPE_REQUEST(U_)                                                                 \
     {                                                                                         \
         const int in_ = min(lo + 64 * (U_) + lane, N - 1);                                    \
-        const double *src_ = in_ < jprev ? Xt + (size_t)in_ * D                               \
-                                         : props + (size_t)in_ * PW + D + 2;                  \
+        uint32_t off_;                                                                        \
+        const char *base_src_ = x_source(lo + 64 * (U_), in_, off_);                          \
+        const double *src_ = (const double *)(base_src_ + off_);                              \
         _Pragma("unroll")                                                                     \
         for (int d = 0; d < D; ++d) xn[d] = src_[d];                                          \
         if (MODEL == DLSM_DIRECTED) rn = c.radii[in_];                                        \
@@ -248,6 +324,8 @@ __device__ __forceinline__ void pipe_eval_item(const ChainView &c, const PipeBuf
         DLSM_PIPE_MASKS(u)                                                                    \
         if (__builtin_amdgcn_inverse_ballot_w64(vm_))                                         \
             DLSM_PIPE_TERM(xpre[u], yb_, ycb_, rpre[MODEL == DLSM_DIRECTED ? u : 0], FLUSH_, SQ_) \
+        if (u == 0) { DLSM_STAMP(1, ra.P0) }                                                  \
+        if (u == PP_NPRE - 1) { DLSM_STAMP(2, ra.P0) }                                        \
     }                                                                                         \
     /* the trips beyond the prefetched ones.  TP: each trip requests the next one's operands   \
        (clamped address, no predication) before it computes. */                               \
@@ -264,9 +342,10 @@ __device__ __forceinline__ void pipe_eval_item(const ChainView &c, const PipeBuf
         }                                                                                     \
         DLSM_PIPE_MASKS(u)                                                                    \
         if (__builtin_amdgcn_inverse_ballot_w64(vm_)) {                                       \
-            if (!TP) {                                                     \
-                const double *src = i_ < jprev ? Xt + (size_t)i_ * D                          \
-                                               : props + (size_t)i_ * PW + D + 2;             \
+            if (!TP) {                                                                        \
+                uint32_t off_;                                                                \
+                const char *base_src_ = x_source(base_, i_, off_);                            \
+                const double *src = (const double *)(base_src_ + off_);                       \
                 _Pragma("unroll")                                                             \
                 for (int d = 0; d < D; ++d) xi[d] = src[d];                                   \
             }                                                                                 \
@@ -283,8 +362,7 @@ __device__ __forceinline__ void pipe_eval_item(const ChainView &c, const PipeBuf
     double tot_l, tot_r;
     if (noflush) {
         // the products of the whole wave stay in range: multiply across lanes
-        tot_l = wave_sum_all(ra.lin + ra.lg);
-        tot_r = wave_prod_all(ra.P0) / wave_prod_all(ra.P1);
+        pipe_reduce(ra.lin + ra.lg, ra.P0, ra.P1, lane, tot_l, tot_r);
     } else {
         acc += ra.value();                       // directed: lin / products and the rare exact terms
         tot_l = wave_sum_all(acc); tot_r = 1.0;
@@ -293,38 +371,55 @@ __device__ __forceinline__ void pipe_eval_item(const ChainView &c, const PipeBuf
         double2 *f = (double2 *)pb.full0 + (((size_t)bb * c.T + t) * PP_B + k) * pb.parts + p;
         *f = make_double2(tot_l, tot_r);
     }
-    // this lane's H entries (see above)
+    DLSM_STAMP(3, tot_r)
+    // this lane's H entries (see above).  Rows of `props`, the bits and the H blocks are
+    // addressed as 32-bit offsets from scalar bases.
+    const char *yrows = (const char *)(c.ybits + (size_t)t * N * W);
+    const char *ytrows = MODEL == DLSM_DIRECTED ? (const char *)(c.ytbits + (size_t)t * N * W) : nullptr;
+    char *hbase = (char *)(pb.Hd + ((size_t)bb * c.T + t) * PP_B * PP_B);
+    const uint32_t hx_off = (uint32_t)((const char *)pb.Hx - (const char *)pb.Hd);   // one allocation
     for (int f = hf0; f < htot; f += hround) {
         int kk, e;
         pipe_h_decode(f, ncross, nb, kk, e);
-        const int jm_ = (e < ncross ? jprev : j0) + (e < ncross ? e : e - ncross);
+        const int jm_ = jprev + e;                 // jprev + ncross == j0
         const int jkk = j0 + kk;
+        const double *rowm = (const double *)((const char *)props + __umul24((uint32_t)jm_, (uint32_t)(PW * sizeof(double))));
+        const double *rowk = (const double *)((const char *)props + __umul24((uint32_t)jkk, (uint32_t)(PW * sizeof(double))));
         double xm0[D], xm1[D], xa0[D], xa1[D];
 #pragma unroll
         for (int d = 0; d < D; ++d) {
-            xm0[d] = props[(size_t)jm_ * PW + D + 2 + d];
-            xm1[d] = props[(size_t)jm_ * PW + d];
-            xa0[d] = props[(size_t)jkk * PW + D + 2 + d];
-            xa1[d] = props[(size_t)jkk * PW + d];
+            xm0[d] = rowm[D + 2 + d];
+            xm1[d] = rowm[d];
+            xa0[d] = rowk[D + 2 + d];
+            xa1[d] = rowk[d];
         }
-        const int y1 = bit_of(c.ybits + ((size_t)t * N + jkk) * W, jm_);
-        const int y2 = MODEL == DLSM_DIRECTED ? bit_of(c.ytbits + ((size_t)t * N + jkk) * W, jm_) : 0;
-        const double rm = MODEL == DLSM_DIRECTED ? c.radii[jm_] : 1.0;
-        const double rk = MODEL == DLSM_DIRECTED ? c.radii[jkk] : 1.0;
+        const uint32_t woff = ((uint32_t)jkk * (uint32_t)W + ((uint32_t)jm_ >> 5)) * 4u;
+        const int y1 = (int)((*(const uint32_t *)(yrows + woff) >> (jm_ & 31)) & 1u);
         const bool cross = e < ncross;
         const int m = cross ? e : e - ncross;
         const double a0 = dist_fast<D>(xm0, xa0, c.squared);
         const double a1 = dist_fast<D>(xm0, xa1, c.squared);
         const double b0 = dist_fast<D>(xm1, xa0, c.squared);
         const double b1 = dist_fast<D>(xm1, xa1, c.squared);
+#ifdef DLSM_PIPE_TIMING
+        if (f == hf0) { DLSM_STAMP(4, a0 + b1) }
+#endif
         double h;
         if (MODEL == DLSM_UNDIRECTED) {
-            const double num = fma(E, fast_exp(-b0), 1.0) * fma(E, fast_exp(-a1), 1.0);
-            const double den = fma(E, fast_exp(-b1), 1.0) * fma(E, fast_exp(-a0), 1.0);
+            const double eb0 = tab_exp(-b0, etab), ea1 = tab_exp(-a1, etab);
+            const double eb1 = tab_exp(-b1, etab), ea0 = tab_exp(-a0, etab);
+            double num = fma(E, eb0, 1.0) * fma(E, ea1, 1.0);
+            double den = fma(E, eb1, 1.0) * fma(E, ea0, 1.0);
+            // the edge's factor e^{(b0 - b1) - (a0 - a1)} from the four exponentials at hand;
+            // a fifth one only when their product left the normal range (distances > 300)
+            const double fn = eb1 * ea0, fd = eb0 * ea1;
+            const bool tiny = y1 && !(fd > 1e-290);
+            if (y1 && !tiny) { num *= fn; den *= fd; }
             h = num / den;
-            if (y1) h *= fast_exp((b0 - b1) - (a0 - a1));
+            if (__builtin_amdgcn_ballot_w64(tiny)) { if (tiny) h *= fast_exp((b0 - b1) - (a0 - a1)); }
         } else {
-            const double irm = 1.0 / rm, irkk = 1.0 / rk;
+            const int y2 = (int)((*(const uint32_t *)(ytrows + woff) >> (jm_ & 31)) & 1u);
+            const double irm = 1.0 / c.radii[jm_], irkk = 1.0 / c.radii[jkk];
             const double aa = bin * irm + bout * irkk, cc = bin * irkk + bout * irm;
             RatioAcc rb, rq;
             double eb = 0.0, eq = 0.0;
@@ -333,9 +428,13 @@ __device__ __forceinline__ void pipe_eval_item(const ChainView &c, const PipeBuf
             // exp(delta(b) - delta(a)) without the logs: the products divide out
             h = ((rb.P0 * rq.P1) / (rb.P1 * rq.P0)) * exp((rb.lin - rq.lin) + (eb - eq));
         }
-        double *dst = cross ? pb.Hx : pb.Hd;
-        dst[(((size_t)bb * c.T + t) * PP_B + m) * PP_B + kk] = h;
+        *(double *)(hbase + ((cross ? hx_off : 0u) + (uint32_t)(m * PP_B + kk) * 8u)) = h;
     }
+#ifdef DLSM_PIPE_TIMING
+    DLSM_STAMP(5, acc)
+    if (lane == 0 && tl >= 0 && tl < 24 && tgw < 4096)
+        for (int i = 0; i < 6; ++i) g_pipe_item_t[tl][tgw][i] = ts[i];
+#endif
 }
 
 
@@ -447,9 +546,17 @@ template <int D>
 __device__ __forceinline__ void pipe_resolve(const ChainView &c, const PipeBuf &pb, int b, int t,
                                              double *sH, double *sPart,
                                              unsigned long long (*sMask)[2], int *sPrev,
-                                             unsigned char *sSat) {
+                                             unsigned char *sSat
+#ifdef DLSM_PIPE_TIMING
+                                             , int tl
+#endif
+                                             ) {
     constexpr int PW = 2 * D + 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef DLSM_PIPE_TIMING
+    unsigned long long ts[5] = {0, 0, 0, 0, 0};
+#endif
+    DLSM_STAMP(0, (double)tid)
     const int N = c.N;
     const int j0 = b * PP_B;
     const int nb = min(PP_B, N - j0);
@@ -514,6 +621,7 @@ __device__ __forceinline__ void pipe_resolve(const ChainView &c, const PipeBuf &
     for (int u = 0; u < 8; ++u)
         ((double2 *)sH)[min(u * PP_THREADS + tid, nb * (PP_B / 2) - 1)] = blk[u];
     __syncthreads();                                   // sPrev, sH visible
+    DLSM_STAMP(1, (double)tid)
     const bool satk = sSat[k] != 0;                    // column k is resolved in the log domain
     const bool anysat = __ballot(satk) != 0ull;        // (practically never: wave-uniform slow path)
     if (nprev > 0) {
@@ -553,6 +661,7 @@ __device__ __forceinline__ void pipe_resolve(const ChainView &c, const PipeBuf &
         if (lane == 0) sMask[0][half] = g;
     }
     __syncthreads();
+    DLSM_STAMP(2, (double)tid)
     int cur = 0;
     for (int pass = 0; pass < 2 * PP_B + 2; ++pass) {
         const unsigned long long gm = sMask[cur][part >> 2];
@@ -599,6 +708,7 @@ __device__ __forceinline__ void pipe_resolve(const ChainView &c, const PipeBuf &
         cur ^= 1;
         if (same) break;
     }
+    DLSM_STAMP(3, (double)cur)
     if (owner) {
         const unsigned long long m0 = sMask[cur][0], m1 = sMask[cur][1];
         const unsigned long long mine = half == 0 ? m0 : m1;
@@ -619,6 +729,11 @@ __device__ __forceinline__ void pipe_resolve(const ChainView &c, const PipeBuf &
         }
         if (tid == 0) accg[0] = __popcll(m0) + __popcll(m1);
     }
+#ifdef DLSM_PIPE_TIMING
+    DLSM_STAMP(4, (double)cur)
+    if (tid == 0 && tl >= 0 && tl < 24 && t < 32)
+        for (int i = 0; i < 5; ++i) g_pipe_res_t[tl][t][i] = ts[i];
+#endif
 }
 
 // Launch l: even slices resolve batch l and evaluate batch l + 1; odd slices resolve
@@ -640,7 +755,11 @@ __global__ __launch_bounds__(PP_THREADS) void k_pipe_step(ChainView c, PipeBuf p
     if ((int)blockIdx.x < T) {
         const int t = blockIdx.x;
         const int b = l - (t & 1);
-        if (b >= 0 && b < pb.nbat) pipe_resolve<D>(c, pb, b, t, pp_sH, sPart, sMask, sPrev, sSat);
+        if (b >= 0 && b < pb.nbat) pipe_resolve<D>(c, pb, b, t, pp_sH, sPart, sMask, sPrev, sSat
+#ifdef DLSM_PIPE_TIMING
+                                                   , l + 1
+#endif
+                                                   );
         return;
     }
     const int lane = threadIdx.x & 63;
@@ -679,6 +798,11 @@ __global__ __launch_bounds__(PP_THREADS) void k_pipe_step(ChainView c, PipeBuf p
     const int nslE = nbE > 0 ? nE : 0, nslO = nbO > 0 ? nO : 0, nsl = nslE + nslO;
     const int nitems = pb.parts * nsl * PP_B;
     const float inv_nsl = 1.0f / (float)max(nsl, 1);
+    // the evaluators' table of 2^(j / 256) (tab_exp) in the dynamic LDS the resolvers use for H
+    if (MODEL == DLSM_UNDIRECTED) {
+        exp_table_fill(pp_sH, threadIdx.x);
+        __syncthreads();
+    }
     const int nwaves = ((int)gridDim.x - T) * PP_WAVES;
     const int gw = __builtin_amdgcn_readfirstlane(
         ((int)blockIdx.x - T) * PP_WAVES + (int)(threadIdx.x >> 6));
@@ -691,7 +815,11 @@ __global__ __launch_bounds__(PP_THREADS) void k_pipe_step(ChainView c, PipeBuf p
         if (k >= (odd ? nbO : nbE)) continue;
         const int t = odd ? 2 * (si - nslE) + 1 : 2 * si;
         pipe_eval_item<D, MODEL == DLSM_DIRECTED_CASE_CONTROL ? DLSM_DIRECTED : MODEL, TP>(
-            c, pb, odd ? beO : beE, odd ? nbO : nbE, t, k, p, lane);
+            c, pb, odd ? beO : beE, odd ? nbO : nbE, t, k, p, lane, pp_sH
+#ifdef DLSM_PIPE_TIMING
+            , l + 1, gw
+#endif
+            );
     }
 }
 

@@ -36,12 +36,18 @@ __device__ double v_hwc(double s) {           // hardware sqrt + residual correc
     const double e = fma(-g, g, s);
     return fma(e, h, g);
 }
+__device__ double v_rsqc(double s) {          // the residual correction alone (no iteration)
+    const double y = __builtin_amdgcn_rsq(s);
+    const double g = s * y, h = 0.5 * y;
+    const double e = fma(-g, g, s);
+    return fma(e, h, g);
+}
 template <int V>
 __global__ void k(const double *x, double *y, int n) {
     int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     double s = x[i];
-    y[i] = V == 0 ? v_hw(s) : V == 1 ? v_rsq0(s) : V == 2 ? v_rsq1(s) : V == 3 ? v_rsq1c(s) : V == 4 ? v_hwc(s) : v_rsq1c_noh(s);
+    y[i] = V == 0 ? v_hw(s) : V == 1 ? v_rsq0(s) : V == 2 ? v_rsq1(s) : V == 3 ? v_rsq1c(s) : V == 4 ? v_hwc(s) : V == 5 ? v_rsq1c_noh(s) : v_rsqc(s);
 }
 int main() {
     const int n = 1 << 20;
@@ -54,15 +60,17 @@ int main() {
     }
     double *dx, *dy; hipMalloc(&dx, n * 8); hipMalloc(&dy, n * 8);
     hipMemcpy(dx, hx.data(), n * 8, hipMemcpyHostToDevice);
-    const char *names[6] = {"v_sqrt_f64", "s*rsq", "rsq + 1 iteration", "rsq + 1 iteration + correction",
-                            "v_sqrt_f64 + correction(rsq)", "rsq + 1 iteration + correction (h unrefined)"};
-    for (int v = 0; v < 6; ++v) {
+    const char *names[7] = {"v_sqrt_f64", "s*rsq", "rsq + 1 iteration", "rsq + 1 iteration + correction",
+                            "v_sqrt_f64 + correction(rsq)", "rsq + 1 iteration + correction (h unrefined)",
+                            "rsq + correction only"};
+    for (int v = 0; v < 7; ++v) {
         if (v == 0) hipLaunchKernelGGL(k<0>, dim3(n / 256), dim3(256), 0, 0, dx, dy, n);
         if (v == 1) hipLaunchKernelGGL(k<1>, dim3(n / 256), dim3(256), 0, 0, dx, dy, n);
         if (v == 2) hipLaunchKernelGGL(k<2>, dim3(n / 256), dim3(256), 0, 0, dx, dy, n);
         if (v == 3) hipLaunchKernelGGL(k<3>, dim3(n / 256), dim3(256), 0, 0, dx, dy, n);
         if (v == 4) hipLaunchKernelGGL(k<4>, dim3(n / 256), dim3(256), 0, 0, dx, dy, n);
         if (v == 5) hipLaunchKernelGGL(k<5>, dim3(n / 256), dim3(256), 0, 0, dx, dy, n);
+        if (v == 6) hipLaunchKernelGGL(k<6>, dim3(n / 256), dim3(256), 0, 0, dx, dy, n);
         hipMemcpy(hy.data(), dy, n * 8, hipMemcpyDeviceToHost);
         double maxulp = 0, sum = 0;
         for (int i = 0; i < n; ++i) {
