@@ -47,15 +47,16 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # float64 vector peak: v_fma_f64 issues at half the FP32 vector rate (157.3 TFLOP/s spec in
-# MI355X_MICROARCH.md) = 256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz.  A pure fma stream
-# sustains 76 % of it at this occupancy (profiles/micro/f64_rates.cpp): the chip does not
-# hold 2.4 GHz under a dense float64 stream.
+# MI355X_MICROARCH.md) = 256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz.  A pure fma stream at
+# the sweep's occupancy (4 wavefronts per SIMD) issues one wavefront-instruction per 4.15
+# cycles at the 2.05 GHz the chip holds under it = 82 % of nominal
+# (profiles/micro/valu_rates.hip; one wavefront per SIMD: 4.57 cycles, the 76 % of round 1).
 F64_VALU_PEAK_TFLOPS = 78.6
-F64_VALU_SUSTAINED_FRAC = 0.76
+F64_VALU_SUSTAINED_FRAC = 0.82
 # float64 vector instructions per dyad term (one distance + one exp(-d) + product
 # bookkeeping at ONE position), counted in the disassembly: DESIGN.md 4.1 / 4.4b
-INSTR_PER_TERM_SWEEP = 34       # k_pipe_step neighbour loop: 68 per neighbour, 2 positions
-INSTR_PER_TERM_LOGLIK = 17      # k_loglik_undirected<2,2>: 34 per dyad with 2 candidates
+INSTR_PER_TERM_SWEEP = 29       # k_pipe_step neighbour loop: 58 per neighbour, 2 positions
+INSTR_PER_TERM_LOGLIK = 15      # k_loglik_undirected<2,2>: 30 per dyad with 2 candidates
 
 
 def parse(argv=None):

@@ -4,6 +4,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "exp2_table.hpp"
 
 namespace dlsm {
 
@@ -193,8 +194,9 @@ __device__ __forceinline__ double fast_exp(double x) {
 // ln2) is read from the low word of x 256 / ln2 + 1.5 * 2^52 (|x| < 5e6).  1 ulp against the
 // correctly rounded exponential on 2e4 samples of [-60, 0] (emulated without fma: 1.5 ulp).
 constexpr int EXPTAB_N = 256;
+// the workgroup's table, by its first 256 threads (callers put a barrier behind it)
 __device__ __forceinline__ void exp_table_fill(double *tab, int tid) {
-    if (tid < EXPTAB_N) tab[tid] = fast_exp((double)tid * (0.693147180559945309417 / EXPTAB_N));
+    if (tid < EXPTAB_N) tab[tid] = c_exp2_tab[tid];
 }
 __device__ __forceinline__ double tab_exp(double x, const double *tab) {
     const double magic = 6755399441055744.0;                     // 1.5 * 2^52

@@ -107,8 +107,12 @@ __global__ __launch_bounds__(LLU_THREADS) __attribute__((amdgpu_waves_per_eu(6, 
     ChainView c, LoglikCand cand, double *__restrict__ partials) {
     __shared__ double sXi[LLU_ROWS * D];
     __shared__ double sRed[2 * (2 + M)];
+    __shared__ __attribute__((aligned(16))) double sTab[EXPTAB_N];      // tab_exp (device_common.hpp)
     const int tid = threadIdx.x;
     const int N = c.N;
+    static_assert(2 * LLU_THREADS == EXPTAB_N, "two table entries per thread");
+    sTab[tid] = c_exp2_tab[tid];                   // visible after the staging barrier below
+    sTab[tid + LLU_THREADS] = c_exp2_tab[tid + LLU_THREADS];
     const int nt = (N + LL_TILE - 1) / LL_TILE;
     const int ntri = nt * (nt + 1) / 2;
     const int tile = blockIdx.x >> 1;
@@ -164,7 +168,7 @@ __global__ __launch_bounds__(LLU_THREADS) __attribute__((amdgpu_waves_per_eu(6, 
         _Pragma("unroll")                                                                      \
         for (int u = 0; u < U; ++u) dd[u] = dist_fast<D>(&sXi[(r + u) * D], xj, SQ_);          \
         _Pragma("unroll")                                                                      \
-        for (int u = 0; u < U; ++u) e[u] = fast_exp(-dd[u]);                                   \
+        for (int u = 0; u < U; ++u) e[u] = tab_exp(-dd[u], sTab);                              \
         _Pragma("unroll")                                                                      \
         for (int u = 0; u < U; ++u) {                                                          \
             const bool ok = WHOLE_ || r + u < rend;                                            \

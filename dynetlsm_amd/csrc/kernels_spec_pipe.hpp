@@ -799,6 +799,7 @@ __global__ __launch_bounds__(PP_THREADS) void k_pipe_step(ChainView c, PipeBuf p
     const int nitems = pb.parts * nsl * PP_B;
     const float inv_nsl = 1.0f / (float)max(nsl, 1);
     // the evaluators' table of 2^(j / 256) (tab_exp) in the dynamic LDS the resolvers use for H
+    // (the barrier-free fill of exp_table_fill_wave measured no better: 3614 against 3638 it/s)
     if (MODEL == DLSM_UNDIRECTED) {
         exp_table_fill(pp_sH, threadIdx.x);
         __syncthreads();
