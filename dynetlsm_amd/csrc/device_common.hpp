@@ -78,10 +78,12 @@ __device__ __forceinline__ void box_muller(double u0, double u1, double &z0,
 // All-lanes reductions of a 64-wide wavefront without LDS traffic: four DPP steps inside
 // each row of 16 lanes (quad_perm xor 1, xor 2, row_half_mirror, row_mirror: after them
 // every lane holds its row's total), then the four row totals through v_readlane.
+// (every lane of these patterns has a valid source, so the move needs no "old" value: the
+// update_dpp form cost an extra v_mov per word to provide one)
 template <int CTRL>
 __device__ __forceinline__ double dpp_move(double v) {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xF, 0xF, false);
     return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double lane_value(double v, int lane) {
@@ -94,6 +96,23 @@ __device__ __forceinline__ double wave_sum_all(double v) {
     v += dpp_move<0x141>(v);       // row_half_mirror
     v += dpp_move<0x140>(v);       // row_mirror
     return (lane_value(v, 0) + lane_value(v, 16)) + (lane_value(v, 32) + lane_value(v, 48));
+}
+// The same sum, bit for bit (butterflies commute and the rows combine in the same order), with
+// the rows exchanged through the LDS crossbar (ds_bpermute) instead of eight v_readlane: 14
+// vector instructions against 27, for kernels bound by VALU issue; a lone wavefront waiting on
+// its own result is better served by wave_sum_all (two ds_bpermute round trips are slower than
+// the readlanes).
+__device__ __forceinline__ double wave_sum_all_tp(double v, int lane) {
+    v += dpp_move<0xB1>(v);
+    v += dpp_move<0x4E>(v);
+    v += dpp_move<0x141>(v);
+    v += dpp_move<0x140>(v);
+    const int a16 = (lane ^ 16) << 2, a32 = (lane ^ 32) << 2;
+    v += __hiloint2double(__builtin_amdgcn_ds_bpermute(a16, __double2hiint(v)),
+                          __builtin_amdgcn_ds_bpermute(a16, __double2loint(v)));
+    v += __hiloint2double(__builtin_amdgcn_ds_bpermute(a32, __double2hiint(v)),
+                          __builtin_amdgcn_ds_bpermute(a32, __double2loint(v)));
+    return v;
 }
 __device__ __forceinline__ double wave_prod_all(double v) {
     v *= dpp_move<0xB1>(v);
@@ -185,6 +204,27 @@ __device__ __forceinline__ double fast_exp(double x) {
     p = fma(p, r, 1.0);
     p = fma(p, r, 1.0);
     return __builtin_ldexp(p, (int)k);
+}
+
+// log(x) for x in [1e-300, 1e300] (fdlibm's e_log.c scheme: x = 2^k (1 + f), s = f / (2 + f),
+// log(1 + f) = 2 s + s R(s^2) arranged around f - f^2 / 2): < 1 ulp, a third of the compiler's
+// expansion (no subnormal / special-value paths; the division is a reciprocal + Newton steps)
+__device__ __forceinline__ double fast_log(double x) {
+    int k = __builtin_amdgcn_frexp_exp(x);                 // x = m 2^k, m in [0.5, 1)
+    double m = __builtin_amdgcn_frexp_mant(x);
+    if (m < 0.70710678118654752440) { m *= 2.0; --k; }     // m in [sqrt(1/2), sqrt(2))
+    const double f = m - 1.0;
+    const double s = f * fast_rcp(2.0 + f);
+    const double z = s * s, w = z * z;
+    const double t1 = w * fma(w, fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01),
+                              3.999999999940941908e-01);
+    const double t2 = z * fma(w, fma(w, fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01),
+                                     2.857142874366239149e-01), 6.666666666666735130e-01);
+    const double R = t1 + t2;
+    const double hfsq = 0.5 * f * f;
+    const double dk = (double)k;
+    return dk * 6.93147180369123816490e-01 -
+           ((hfsq - (s * (hfsq + R) + dk * 1.90821492927058770002e-10)) - f);
 }
 
 // e^x through a 256-entry table of 2^(j / 256) held in LDS: x = (256 n + j) ln2 / 256 + r with

@@ -114,27 +114,6 @@ __device__ __forceinline__ double cc_term_delta(const double *xn, const double *
     return (edge ? (e1 - e0) : 0.0) - wsp * sp;
 }
 
-// log(x) for x in [1e-300, 1e300] (fdlibm's e_log.c scheme: x = 2^k (1 + f), s = f / (2 + f),
-// log(1 + f) = 2 s + s R(s^2) arranged around f - f^2 / 2): < 1 ulp, a third of the compiler's
-// expansion (no subnormal / special-value paths; the division is a reciprocal + Newton steps)
-__device__ __forceinline__ double fast_log(double x) {
-    int k = __builtin_amdgcn_frexp_exp(x);                 // x = m 2^k, m in [0.5, 1)
-    double m = __builtin_amdgcn_frexp_mant(x);
-    if (m < 0.70710678118654752440) { m *= 2.0; --k; }     // m in [sqrt(1/2), sqrt(2))
-    const double f = m - 1.0;
-    const double s = f * fast_rcp(2.0 + f);
-    const double z = s * s, w = z * z;
-    const double t1 = w * fma(w, fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01),
-                              3.999999999940941908e-01);
-    const double t2 = z * fma(w, fma(w, fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01),
-                                     2.857142874366239149e-01), 6.666666666666735130e-01);
-    const double R = t1 + t2;
-    const double hfsq = 0.5 * f * f;
-    const double dk = (double)k;
-    return dk * 6.93147180369123816490e-01 -
-           ((hfsq - (s * (hfsq + R) + dk * 1.90821492927058770002e-10)) - f);
-}
-
 // The same with the lean forms of device_common.hpp: eta = B - d a with B = b_in + b_out and
 // a = b_in / r + b_out / r' from reciprocals (irj = 1 / r_k is the caller's, 1 / r_e a
 // v_rcp_f64 + two Newton steps), the correctly rounded lean root, the ~1 ulp lean exp and one

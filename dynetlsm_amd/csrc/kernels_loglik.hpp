@@ -131,7 +131,7 @@ __global__ __launch_bounds__(LLU_THREADS) __attribute__((amdgpu_waves_per_eu(6, 
     for (int d = 0; d < D; ++d) xj[d] = j < N ? Xt[(size_t)j * D + d] : 0.0;
     double E[M];
 #pragma unroll
-    for (int k = 0; k < M; ++k) E[k] = exp(cand.intercepts[k]);
+    for (int k = 0; k < M; ++k) E[k] = fast_exp(cand.intercepts[k]);
     __syncthreads();
 
     // sum_i log(1 + E e^{-d_i}) = log prod_i (1 + E e^{-d_i}): one log per
@@ -139,8 +139,9 @@ __global__ __launch_bounds__(LLU_THREADS) __attribute__((amdgpu_waves_per_eu(6, 
     double Emax = E[0];
 #pragma unroll
     for (int k = 1; k < M; ++k) Emax = fmax(Emax, E[k]);
-    const double l1p = log1p(Emax);
-    const int nflush = !(l1p > 0.0) ? 64 : (600.0 / l1p < 1.0 ? 1 : (600.0 / l1p > 64.0 ? 64 : (int)(600.0 / l1p)));
+    // (float precision is plenty for a flush interval with a margin of e^109)
+    const float l1p = __logf(1.0f + (float)Emax);
+    const int nflush = !(l1p > 0.0f) ? 64 : (600.0f / l1p < 1.0f ? 1 : (600.0f / l1p > 64.0f ? 64 : (int)(600.0f / l1p)));
     constexpr int U = 4;          // rows per trip, each with its own product chain
     double syd = 0.0, S[M], P[U][M];
     int sy = 0;                   // wave-uniform count of the edges seen
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(LLU_THREADS) __attribute__((amdgpu_waves_per_eu(6, 
             _Pragma("unroll")                                                                  \
             for (int k = 0; k < M; ++k) {                                                      \
                 _Pragma("unroll")                                                              \
-                for (int u = 0; u < U; ++u) { S[k] += log(P[u][k]); P[u][k] = 1.0; }           \
+                for (int u = 0; u < U; ++u) { S[k] += fast_log(P[u][k]); P[u][k] = 1.0; }           \
             }                                                                                  \
             cnt = 0;                                                                           \
         }                                                                                      \
@@ -200,13 +201,13 @@ __global__ __launch_bounds__(LLU_THREADS) __attribute__((amdgpu_waves_per_eu(6, 
             double q = P[0][k];
 #pragma unroll
             for (int u = 1; u < U; ++u) q *= P[u][k];
-            S[k] += log(q);
+            S[k] += fast_log(q);
         }
     } else {
 #pragma unroll
         for (int k = 0; k < M; ++k)
 #pragma unroll
-            for (int u = 0; u < U; ++u) S[k] += log(P[u][k]);
+            for (int u = 0; u < U; ++u) S[k] += fast_log(P[u][k]);
     }
     double acc[2 + M];
     acc[0] = (tid & 63) == 0 ? (double)sy : 0.0;
@@ -215,7 +216,7 @@ __global__ __launch_bounds__(LLU_THREADS) __attribute__((amdgpu_waves_per_eu(6, 
     for (int k = 0; k < M; ++k) acc[2 + k] = S[k];
 #pragma unroll
     for (int q = 0; q < 2 + M; ++q) {
-        double v = wave_sum_all(acc[q]);
+        double v = wave_sum_all_tp(acc[q], tid & 63);
         if ((tid & 63) == 0) sRed[(tid >> 6) * (2 + M) + q] = v;
     }
     __syncthreads();

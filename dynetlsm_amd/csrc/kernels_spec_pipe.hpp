@@ -143,16 +143,9 @@ __device__ __forceinline__ unsigned long long pipe_clock(double dep) {
 // wavefronts of a SIMD run one after the other, the SIMD is busy from the first operand's
 // arrival to the launch's end), so what is not a neighbour term is overhead to be counted in
 // instructions.  Only lane 0 stores the record: the sum and the two products are reduced
-// towards it with DPP moves that need no "old" value (every lane of these patterns is valid),
-// the two products share one tree from the second step on (even lanes carry P0, odd lanes
+// towards it, the two products share one tree from the second step on (even lanes carry P0, odd lanes
 // P1: quad_perm xor 2 and the row rotations keep the parity), and the rows are combined
 // through the LDS crossbar (ds_bpermute: no VALU cycles) instead of v_readlane.
-template <int CTRL>
-__device__ __forceinline__ double dpp_get(double v) {
-    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xF, 0xF, false);
-    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xF, 0xF, false);
-    return __hiloint2double(hi, lo);
-}
 __device__ __forceinline__ double lane_get(double v, int byte_addr) {      // 4 * source lane
     return __hiloint2double(__builtin_amdgcn_ds_bpermute(byte_addr, __double2hiint(v)),
                             __builtin_amdgcn_ds_bpermute(byte_addr, __double2loint(v)));
@@ -161,22 +154,22 @@ __device__ __forceinline__ double lane_get(double v, int byte_addr) {      // 4 
 __device__ __forceinline__ void pipe_reduce(double s, double a, double b, int lane, double &sum,
                                             double &ratio) {
     const int x16 = (lane ^ 16) << 2, x32 = (lane ^ 32) << 2;
-    s += dpp_get<0xB1>(s);         // quad_perm [1, 0, 3, 2]
-    a *= dpp_get<0xB1>(a);
-    b *= dpp_get<0xB1>(b);
+    s += dpp_move<0xB1>(s);         // quad_perm [1, 0, 3, 2]
+    a *= dpp_move<0xB1>(a);
+    b *= dpp_move<0xB1>(b);
     double q = (lane & 1) ? b : a;
-    s += dpp_get<0x4E>(s);         // quad_perm [2, 3, 0, 1]
-    q *= dpp_get<0x4E>(q);
-    s += dpp_get<0x124>(s);        // row_ror:4
-    q *= dpp_get<0x124>(q);
-    s += dpp_get<0x128>(s);        // row_ror:8
-    q *= dpp_get<0x128>(q);
+    s += dpp_move<0x4E>(s);         // quad_perm [2, 3, 0, 1]
+    q *= dpp_move<0x4E>(q);
+    s += dpp_move<0x124>(s);        // row_ror:4
+    q *= dpp_move<0x124>(q);
+    s += dpp_move<0x128>(s);        // row_ror:8
+    q *= dpp_move<0x128>(q);
     s += lane_get(s, x16);
     q *= lane_get(q, x16);
     s += lane_get(s, x32);
     q *= lane_get(q, x32);
     sum = s;
-    ratio = q / dpp_get<0xB1>(q);  // lane 0: prod a / prod b
+    ratio = q / dpp_move<0xB1>(q);  // lane 0: prod a / prod b
 }
 
 // trips of 64 neighbours whose operands an undirected item loads up front
