@@ -102,6 +102,9 @@ __device__ __forceinline__ void tile_decode(int r, int nt, int &ti, int &tj) {
 constexpr int LLU_THREADS = 128;
 constexpr int LLU_ROWS = 64;
 
+#ifdef DLSM_PIPE_TIMING
+__device__ unsigned long long g_ll_t[8192][3];     // per wavefront: entry, exit (100 MHz), HW_ID
+#endif
 template <int D, int M>
 __global__ __launch_bounds__(LLU_THREADS) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_loglik_undirected(
     ChainView c, LoglikCand cand, double *__restrict__ partials) {
@@ -110,6 +113,11 @@ __global__ __launch_bounds__(LLU_THREADS) __attribute__((amdgpu_waves_per_eu(6, 
     __shared__ __attribute__((aligned(16))) double sTab[EXPTAB_N];      // tab_exp (device_common.hpp)
     const int tid = threadIdx.x;
     const int N = c.N;
+#ifdef DLSM_PIPE_TIMING
+    unsigned long long tl0;
+    unsigned int hwid, xccid;
+    asm volatile("s_memrealtime %0\n\ts_getreg_b32 %1, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %2, hwreg(HW_REG_XCC_ID)\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl0), "=s"(hwid), "=s"(xccid));
+#endif
     static_assert(2 * LLU_THREADS == EXPTAB_N, "two table entries per thread");
     sTab[tid] = c_exp2_tab[tid];                   // visible after the staging barrier below
     sTab[tid + LLU_THREADS] = c_exp2_tab[tid + LLU_THREADS];
@@ -222,6 +230,14 @@ __global__ __launch_bounds__(LLU_THREADS) __attribute__((amdgpu_waves_per_eu(6, 
     __syncthreads();
     if (tid < 2 + M)
         partials[(size_t)blockIdx.x * (2 + M) + tid] = sRed[tid] + sRed[(2 + M) + tid];
+#ifdef DLSM_PIPE_TIMING
+    {
+        unsigned long long tl1;
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl1) : "v"(acc[1]));
+        const unsigned w = blockIdx.x * 2 + (tid >> 6);
+        if ((tid & 63) == 0 && w < 8192) { g_ll_t[w][0] = tl0; g_ll_t[w][1] = tl1; g_ll_t[w][2] = (unsigned long long)hwid | ((unsigned long long)xccid << 32); }
+    }
+#endif
 }
 
 template <int D, int M>
