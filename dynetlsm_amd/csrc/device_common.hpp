@@ -231,8 +231,10 @@ __device__ __forceinline__ double fast_log(double x) {
 // |r| <= ln2 / 512, e^x = 2^n * tab[j] * p(r), p the degree-4 Taylor polynomial (truncation
 // 3.8e-17 relative).  13 vector instructions and one LDS read against fast_exp's 18 - the LDS
 // pipe is idle in the kernels that are bound by float64 VALU issue.  The integer round(x 256 /
-// ln2) is read from the low word of x 256 / ln2 + 1.5 * 2^52 (|x| < 5e6).  1 ulp against the
-// correctly rounded exponential on 2e4 samples of [-60, 0] (emulated without fma: 1.5 ulp).
+// ln2) is read from the low word of x 256 / ln2 + 1.5 * 2^52: VALID FOR |x| < 5.8e6 only (beyond
+// it the word wraps) - minus a Euclidean distance between latent positions is inside by any
+// margin; minus a SQUARED distance goes through tab_exp_clamped.  1 ulp against the correctly
+// rounded exponential on 2e4 samples of [-60, 0] (emulated without fma: 1.5 ulp).
 constexpr int EXPTAB_N = 256;
 // the workgroup's table, by its first 256 threads (callers put a barrier behind it)
 __device__ __forceinline__ void exp_table_fill(double *tab, int tid) {
@@ -250,6 +252,11 @@ __device__ __forceinline__ double tab_exp(double x, const double *tab) {
     p = fma(p, r, 1.0);
     p = fma(p, r, 1.0);
     return __builtin_ldexp(tab[ki & (EXPTAB_N - 1)] * p, ki >> 8);
+}
+
+// any x <= 0: e^x is 0 in double below -745.2
+__device__ __forceinline__ double tab_exp_clamped(double x, const double *tab) {
+    return tab_exp(fmax(x, -1000.0), tab);
 }
 
 template <int D>

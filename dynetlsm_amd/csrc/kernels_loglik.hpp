@@ -177,7 +177,8 @@ __global__ __launch_bounds__(LLU_THREADS) __attribute__((amdgpu_waves_per_eu(6, 
         _Pragma("unroll")                                                                      \
         for (int u = 0; u < U; ++u) dd[u] = dist_fast<D>(&sXi[(r + u) * D], xj, SQ_);          \
         _Pragma("unroll")                                                                      \
-        for (int u = 0; u < U; ++u) e[u] = tab_exp(-dd[u], sTab);                              \
+        for (int u = 0; u < U; ++u)                                                            \
+            e[u] = (SQ_) ? tab_exp_clamped(-dd[u], sTab) : tab_exp(-dd[u], sTab);              \
         _Pragma("unroll")                                                                      \
         for (int u = 0; u < U; ++u) {                                                          \
             const bool ok = WHOLE_ || r + u < rend;                                            \

@@ -266,8 +266,8 @@ __device__ __forceinline__ void pipe_eval_item(const ChainView &c, const PipeBuf
             const double d0_ = dist_fast<D>(XI_, xk0, SQ_);                                   \
             const double d1_ = dist_fast<D>(XI_, xk1, SQ_);                                   \
             ra.lin = fma((YB_) ? 1.0 : 0.0, d0_ - d1_, ra.lin);                               \
-            ra.P0 *= fma(E, tab_exp(-d0_, etab), 1.0);                                        \
-            ra.P1 *= fma(E, tab_exp(-d1_, etab), 1.0);                                        \
+            ra.P0 *= fma(E, (SQ_) ? tab_exp_clamped(-d0_, etab) : tab_exp(-d0_, etab), 1.0);  \
+            ra.P1 *= fma(E, (SQ_) ? tab_exp_clamped(-d1_, etab) : tab_exp(-d1_, etab), 1.0);  \
             if (FLUSH_) if (++ra.cnt >= nflush) ra.flush();                                   \
         } else {                                                                              \
             const double d0_ = dist_fast<D>(XI_, xk0, c.squared);                             \
@@ -399,8 +399,8 @@ __device__ __forceinline__ void pipe_eval_item(const ChainView &c, const PipeBuf
 #endif
         double h;
         if (MODEL == DLSM_UNDIRECTED) {
-            const double eb0 = tab_exp(-b0, etab), ea1 = tab_exp(-a1, etab);
-            const double eb1 = tab_exp(-b1, etab), ea0 = tab_exp(-a0, etab);
+            const double eb0 = tab_exp_clamped(-b0, etab), ea1 = tab_exp_clamped(-a1, etab);
+            const double eb1 = tab_exp_clamped(-b1, etab), ea0 = tab_exp_clamped(-a0, etab);
             double num = fma(E, eb0, 1.0) * fma(E, ea1, 1.0);
             double den = fma(E, eb1, 1.0) * fma(E, ea0, 1.0);
             // the edge's factor e^{(b0 - b1) - (a0 - a1)} from the four exponentials at hand;

@@ -344,6 +344,33 @@ def test_sweep_squared_distances(eng):
                 rtol=1e-10)
 
 
+def test_squared_distances_far_apart(eng):
+    """positions thousands of units apart under squared=True: -d^2 is far below the range in which
+    the table exponential reads its integer part (device_common.hpp: tab_exp_clamped); e^{-d^2}
+    must come out as 0, not as a wrapped power of two - log-likelihood and pipelined sweep"""
+    from dynetlsm_amd import Chain, SamplerGrid
+    X, Yd, Yu, radii = _rand_net(5, 2, 150, 2)
+    X = X.copy()
+    X[:, 75:] += 4000.0            # two groups 5.6e3 apart: squared distances of 3e7
+    with Chain(2, 150, 2, 'undirected', seed=3) as c:
+        c.upload_network(Yu); c.set_positions(X); c.set_intercepts([0.5]); c.set_squared(True)
+        got = c.loglik_full([[0.5], [1.5]])
+        want = [orc.dynamic_network_loglikelihood_undirected(Yu, X, b, squared=True) for b in (0.5, 1.5)]
+        assert np.all(np.isfinite(got))
+        np.testing.assert_allclose(got, want, rtol=RTOL_LL)
+        c.set_prior_random_walk(2.0, 0.1)
+        c.set_samplers(SamplerGrid(2, 150, 0.1, tune=None))
+        og = orc.SamplerGrid(2, 150, 0.1, tune=None)
+        st = orc.ChainState(X, og, Y=Yu, intercept=[0.5], squared=True, tau_sq=2.0, sigma_sq=0.1,
+                            seed=3, chain=0)
+        for it in (1, 2):
+            c.sweep_positions(it, 4)
+            st.c.iter = it
+            st.sweep_c()
+        assert np.all(np.isfinite(c.get_positions()))
+        np.testing.assert_allclose(c.get_positions(), st.X, atol=1e-9)
+
+
 def test_sweep_single_time_step(eng):
     _sweep_case(eng, 'undirected', 'rw', T=1, N=20, D=2, n_sweeps=3, algo=1)
     _sweep_case(eng, 'undirected', 'rw', T=1, N=150, D=2, n_sweeps=3, algo=2)
