@@ -100,7 +100,11 @@ __device__ __forceinline__ void tile_decode(int r, int nt, int &ti, int &tj) {
 // a wavefront's columns are one aligned 8-byte word of the packed network: read as a SCALAR
 // and used as the lane mask of "y = 1" directly, and counted with a scalar popcount.
 constexpr int LLU_THREADS = 128;
-constexpr int LLU_ROWS = 64;
+#ifndef LLU_ROWS_V
+#define LLU_ROWS_V 64
+#endif
+constexpr int LLU_ROWS = LLU_ROWS_V;
+constexpr int LLU_SPLIT = 128 / LLU_ROWS;         // workgroups per tile
 
 #ifdef DLSM_PIPE_TIMING
 __device__ unsigned long long g_ll_t[8192][3];     // per wavefront: entry, exit (100 MHz), HW_ID
@@ -123,11 +127,11 @@ __global__ __launch_bounds__(LLU_THREADS) __attribute__((amdgpu_waves_per_eu(6, 
     sTab[tid + LLU_THREADS] = c_exp2_tab[tid + LLU_THREADS];
     const int nt = (N + LL_TILE - 1) / LL_TILE;
     const int ntri = nt * (nt + 1) / 2;
-    const int tile = blockIdx.x >> 1;
+    const int tile = blockIdx.x / LLU_SPLIT;
     const int t = tile / ntri;
     int ti, tj;
     tile_decode(tile % ntri, nt, ti, tj);
-    const int i0 = ti * LL_TILE + (blockIdx.x & 1) * LLU_ROWS, j0 = tj * LL_TILE;
+    const int i0 = ti * LL_TILE + (blockIdx.x % LLU_SPLIT) * LLU_ROWS, j0 = tj * LL_TILE;
     const double *Xt = c.X + (size_t)t * N * D;
     for (int k = tid; k < LLU_ROWS * D; k += LLU_THREADS) {
         const int gi = i0 * D + k;
