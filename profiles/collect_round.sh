@@ -1,0 +1,25 @@
+#!/bin/bash
+# Everything profiles/README.md lists for a round, in one call on the GPU box (from the repo root,
+# through gpurun; ~12 minutes).  tmp_timing/libtiming.so = the engine built with -DDLSM_PIPE_TIMING.
+#   bash profiles/collect_round.sh <tag>      -> gpurun_out/<tag>/
+TAG=${1:-round}
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p $OUT
+for m in lsm hdp cc; do bash $ROOT/profiles/collect.sh $TAG $m all > $OUT/collect_$m.log 2>&1; done
+cd $ROOT
+python3 bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
+python3 bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver_args.json 2> $OUT/bench_driver_args.err
+: > $OUT/chains_per_gpu.jsonl
+for C in 2 3 4; do python3 bench.py --chains-per-gpu $C --no-cpu >> $OUT/chains_per_gpu.jsonl 2>> $OUT/chains_per_gpu.err; done
+python3 bench.py --gpus 2 --backend gloo --share-device0 --no-cpu > $OUT/bench_2ranks_one_gpu.json 2> $OUT/bench_2ranks.err
+python3 bench.py --model lsm --cpu-procs 8 > $OUT/bench_lsm_cpu8.json 2> $OUT/bench_lsm_cpu8.err
+if [ -f tmp_timing/libtiming.so ]; then
+  python3 profiles/pipe_timing.py tmp_timing/libtiming.so $OUT/pipe_timing.json > $OUT/pipe_timing.log 2>&1
+  python3 profiles/loglik_timing.py tmp_timing/libtiming.so $OUT/loglik_timing.json > $OUT/loglik_timing.log 2>&1
+fi
+[ -x tmp_timing/valu_rates ] && ./tmp_timing/valu_rates > $OUT/valu_rates.txt 2>&1
+[ -x tmp_timing/sqrt_acc ] && ./tmp_timing/sqrt_acc > $OUT/sqrt_acc.txt 2>&1
+python3 profiles/end_to_end_fit.py 1000 > $OUT/end_to_end_fit.jsonl 2> $OUT/end_to_end_fit.err
+python3 profiles/end_to_end_fit.py 5000 >> $OUT/end_to_end_fit.jsonl 2>> $OUT/end_to_end_fit.err
+ls -la $OUT | head -60
