@@ -928,18 +928,19 @@ static int resolve_sweep_algo(const dlsm_chain *h, int algo) {
 }
 
 // algo 4: one fused launch per batch, resolve(b) beside eval(b + 1) (kernels_spec_pipe.hpp)
-template <int DD, int MODEL>
+template <int DD, int MODEL, int G = 1>
 static void launch_pipe_step(dlsm_chain *h, const ChainView &v, const PipeBuf &pb, int grid,
                              size_t lds, int l) {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (h->profiling) { hipEventCreate(&e0); hipEventCreate(&e1); }
-    hipExtLaunchKernelGGL((k_pipe_step<DD, MODEL>), dim3(grid), dim3(PP_THREADS), lds, h->stream,
+    hipExtLaunchKernelGGL((k_pipe_step<DD, MODEL, G>), dim3(grid), dim3(PP_THREADS), lds, h->stream,
                           e0, e1, 0, v, pb, l);
     if (h->profiling) h->prof[DLSM_K_SWEEP_EVAL].pending.emplace_back(e0, e1);
 }
 
+// G = batches resolved (and evaluated) per launch: algo 4: 1, algo 6: 2
 template <int DD>
-static int launch_sweep_pipe(dlsm_chain *h, IterRef iter, bool alloc_only = false) {
+static int launch_sweep_pipe(dlsm_chain *h, IterRef iter, bool alloc_only = false, int G = 1) {
     const int N = h->N, T = h->T;
     const int nbat = (N + PP_B - 1) / PP_B;
     const bool cc = h->model == DLSM_DIRECTED_CASE_CONTROL;
@@ -953,10 +954,13 @@ static int launch_sweep_pipe(dlsm_chain *h, IterRef iter, bool alloc_only = fals
     }
     auto even2 = [](size_t n) { return (n + 1) / 2 * 2; };
     const size_t n_prop = even2((size_t)T * N * (2 * DD + 2));
-    const size_t n_full0 = (size_t)2 * T * PP_B * parts * 2;
-    const size_t n_h = (size_t)2 * T * PP_B * PP_B;
-    const size_t n_acc = even2(((size_t)T * (PP_B + 1) + 1) / 2);           // int32 pairs
-    const size_t need = (n_prop + n_full0 + 2 * n_h + n_acc + 2) * sizeof(double);
+    if (cc) G = 1;      // its correction columns are sized for a window of one batch
+    const int xr = (2 * G - 1) * PP_B;
+    const size_t n_full0 = (size_t)2 * G * T * PP_B * parts * 2;
+    const size_t n_h = (size_t)2 * G * T * PP_B * PP_B;
+    const size_t n_hx = (size_t)2 * G * T * xr * PP_B;
+    const size_t n_acc = even2(((size_t)T * 2 * G * (PP_B + 1) + 1) / 2);   // int32 pairs
+    const size_t need = (n_prop + n_full0 + n_h + n_hx + n_acc + 2) * sizeof(double);
     if (h->pipe_cap < need) {
         if (h->pipe) hipFree(h->pipe);
         h->pipe = nullptr; h->pipe_cap = 0;
@@ -965,9 +969,10 @@ static int launch_sweep_pipe(dlsm_chain *h, IterRef iter, bool alloc_only = fals
     }
     PipeBuf pb;
     pb.prop = h->pipe; pb.full0 = pb.prop + n_prop; pb.Hd = pb.full0 + n_full0;
-    pb.Hx = pb.Hd + n_h; pb.acc = (int32_t *)(pb.Hx + n_h);
-    pb.consts = pb.Hx + n_h + n_acc;
+    pb.Hx = pb.Hd + n_h; pb.acc = (int32_t *)(pb.Hx + n_hx);
+    pb.consts = pb.Hx + n_hx + n_acc;
     pb.parts = parts; pb.nbat = nbat;
+    pb.G = G; pb.xr = xr;
     pb.per = ((N + parts - 1) / parts + 63) / 64 * 64;      // parts start on a 64-neighbour boundary
     pb.nctrl = h->nctrl;
     const size_t lds = (size_t)PP_B * PP_B * sizeof(double);
@@ -975,6 +980,15 @@ static int launch_sweep_pipe(dlsm_chain *h, IterRef iter, bool alloc_only = fals
     auto kl = k_pipe_step<DD, PIPE_UNDIRECTED_LONG>;
     auto kd = k_pipe_step<DD, DLSM_DIRECTED>;
     auto kc = k_pipe_step<DD, DLSM_DIRECTED_CASE_CONTROL>;
+    auto ku2 = k_pipe_step<DD, DLSM_UNDIRECTED, 2>;
+    auto kl2 = k_pipe_step<DD, PIPE_UNDIRECTED_LONG, 2>;
+    auto kd2 = k_pipe_step<DD, DLSM_DIRECTED, 2>;
+    HIPCHK(h, hipFuncSetAttribute((const void *)ku2, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds));
+    HIPCHK(h, hipFuncSetAttribute((const void *)kl2, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds));
+    HIPCHK(h, hipFuncSetAttribute((const void *)kd2, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds));
     HIPCHK(h, hipFuncSetAttribute((const void *)ku, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds));
     HIPCHK(h, hipFuncSetAttribute((const void *)kl, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -987,16 +1001,24 @@ static int launch_sweep_pipe(dlsm_chain *h, IterRef iter, bool alloc_only = fals
     ChainView v = h->view();
     hipLaunchKernelGGL((k_pipe_propose<DD>), dim3((N + 255) / 256, T), dim3(256), 0, h->stream, v,
                        pb, iter);
-    // launch l: even slices resolve batch l / evaluate l + 1, odd slices resolve l - 1 /
-    // evaluate l; with a single slice (T == 1) the trailing odd-only launch is empty
-    const int last = T > 1 ? nbat : nbat - 1;
+    // launch l: even slices resolve batches G l .. / evaluate G (l + 1) .., odd slices one launch
+    // behind; with a single slice (T == 1) the trailing odd-only launch is empty
+    const int nlaunch = (nbat + G - 1) / G;
+    const int last = T > 1 ? nlaunch : nlaunch - 1;
     for (int l = -1; l <= last; ++l) {
-        const bool any_eval = (l + 1 < nbat) || (T > 1 && l >= 0 && l < nbat);
+        const bool any_eval = (G * (l + 1) < nbat) || (T > 1 && l >= 0 && G * l < nbat);
         const int grid = T + (any_eval ? ne_wg : 0);
-        if (h->model == DLSM_UNDIRECTED && pb.per > 64 * pipe_prefetch_trips(DD))
+        const bool lng = pb.per > 64 * pipe_prefetch_trips(DD);
+        if (h->model == DLSM_UNDIRECTED && lng && G == 2)
+            launch_pipe_step<DD, PIPE_UNDIRECTED_LONG, 2>(h, v, pb, grid, lds, l);
+        else if (h->model == DLSM_UNDIRECTED && lng)
             launch_pipe_step<DD, PIPE_UNDIRECTED_LONG>(h, v, pb, grid, lds, l);
+        else if (h->model == DLSM_UNDIRECTED && G == 2)
+            launch_pipe_step<DD, DLSM_UNDIRECTED, 2>(h, v, pb, grid, lds, l);
         else if (h->model == DLSM_UNDIRECTED)
             launch_pipe_step<DD, DLSM_UNDIRECTED>(h, v, pb, grid, lds, l);
+        else if (h->model == DLSM_DIRECTED && G == 2)
+            launch_pipe_step<DD, DLSM_DIRECTED, 2>(h, v, pb, grid, lds, l);
         else if (h->model == DLSM_DIRECTED)
             launch_pipe_step<DD, DLSM_DIRECTED>(h, v, pb, grid, lds, l);
         else
@@ -1102,6 +1124,7 @@ static int launch_sweep(dlsm_chain *h, IterRef iter, int algo, bool alloc_only =
     }
     algo = resolve_sweep_algo(h, algo);
     if (algo == 4) return launch_sweep_pipe<DD>(h, iter, alloc_only);
+    if (algo == 6) return launch_sweep_pipe<DD>(h, iter, alloc_only, 2);
     if (algo == 2) return launch_sweep_spec<DD>(h, iter, 1, alloc_only);
     if (algo == 3)
         return launch_sweep_spec<DD>(h, iter, getenv("DLSM_SPEC_S") ? atoi(getenv("DLSM_SPEC_S")) : 2,
@@ -1150,15 +1173,17 @@ extern "C" {
 
 int dlsm_resolve_sweep_algo(dlsm_chain *h, int algo) {
     NEED(h, h != nullptr, "null handle");
-    NEED(h, algo >= 0 && algo <= 5, "algo must be 0..5");
+    NEED(h, algo >= 0 && algo <= 6, "algo must be 0..6");
     NEED(h, algo != 5 || h->model == DLSM_DIRECTED_CASE_CONTROL, "algo 5 is the case-control sweep");
+    NEED(h, algo != 6 || h->model != DLSM_DIRECTED_CASE_CONTROL, "algo 6 is for the exact likelihoods");
     return resolve_sweep_algo(h, algo);
 }
 
 int dlsm_sweep_positions(dlsm_chain *h, uint32_t iter, int algo) {
     NEED(h, h != nullptr, "null handle");
-    NEED(h, algo >= 0 && algo <= 5, "algo must be 0..5");
+    NEED(h, algo >= 0 && algo <= 6, "algo must be 0..6");
     NEED(h, algo != 5 || h->model == DLSM_DIRECTED_CASE_CONTROL, "algo 5 is the case-control sweep");
+    NEED(h, algo != 6 || h->model != DLSM_DIRECTED_CASE_CONTROL, "algo 6 is for the exact likelihoods");
     HIPCHK(h, hipSetDevice(h->device));
     int rc = check_ready_sweep(h); if (rc) return rc;
     rc = enqueue_sweep(h, IterRef{iter, nullptr}, algo); if (rc) return rc;

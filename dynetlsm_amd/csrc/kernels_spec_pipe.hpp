@@ -46,17 +46,26 @@ constexpr int PP_WAVES = PP_THREADS / 64;
 constexpr int PP_B = 128;               // nodes per batch (two 64-lane halves)
 constexpr int PP_MAXPARTS = 8;
 
+// G batches are resolved (and G evaluated) per launch.  Batch b is evaluated while the batches
+// from ws(b) = G (b / G - 1) on are still unresolved - its WINDOW: G = 1: the previous batch;
+// G = 2: two or three batches - and everything produced per batch lives in slot b mod 2G.
 struct PipeBuf {
     double *prop;    // [T][N][2D + 2] : x1[D], u, (unused), x0[D] (snapshot)
-    double *full0;   // [2][T][PP_B][parts][2] : (sum of linear terms, ratio of products)
-    double *Hd;      // [2][T][PP_B][PP_B] : Hd[m][k], k > m, both in the batch: the FACTOR
-                     //                     exp(H[k][m]) of node m's acceptance
-    double *Hx;      // [2][T][PP_B][PP_B] : Hx[m][k], m in the previous batch
-    int32_t *acc;    // [T][PP_B + 1] : count, accepted nodes of the last resolved batch
+    double *full0;   // [2G][T][PP_B][parts][2] : (sum of linear terms, ratio of products)
+    double *Hd;      // [2G][T][PP_B][PP_B] : Hd[m][k], k > m, both in the batch: the FACTOR
+                     //                      exp(H[k][m]) of node m's acceptance
+    double *Hx;      // [2G][T][xr][PP_B] : Hx[m][k], m the m-th node of the window's earlier batches
+    int32_t *acc;    // [T][2G][PP_B + 1] : count, accepted nodes of the batch in that slot
     double *consts;  // [2] : E = exp(sum of intercepts), flush interval
     const int32_t *nctrl;   // case-control: valid controls per (t, i, direction)
     int parts, per, nbat;
+    int G, xr;       // batches per launch; rows of an Hx block = (2G - 1) PP_B
 };
+// first batch of the window of batch b
+__host__ __device__ __forceinline__ int pipe_window_start(int b, int G) {
+    const int ws = G * (b / G - 1);
+    return ws > 0 ? ws : 0;
+}
 
 template <int D>
 __global__ __launch_bounds__(256) void k_pipe_propose(ChainView c, PipeBuf pb, IterRef ir) {
@@ -180,7 +189,7 @@ __host__ __device__ constexpr int pipe_prefetch_trips(int D) {
 // One wavefront: part p of node k of batch `be` in slice t.  TP: the trips beyond the
 // prefetched ones are software-pipelined (directed model; undirected parts longer than the
 // prefetch, where it is worth +3 % - at C2, where everything is prefetched, it costs 1 %).
-template <int D, int MODEL, bool TP>
+template <int D, int MODEL, bool TP, int G>
 __device__ __forceinline__ void pipe_eval_item(const ChainView &c, const PipeBuf &pb, int be,
                                                int nb, int t, int k, int p, int lane,
                                                const double *etab
@@ -195,9 +204,9 @@ __device__ __forceinline__ void pipe_eval_item(const ChainView &c, const PipeBuf
 #endif
     DLSM_STAMP(0, (double)lane)
     const int j0 = be * PP_B, jk = j0 + k;
-    const int jprev = max(0, j0 - PP_B);       // nodes >= jprev: snapshot positions
+    const int jprev = pipe_window_start(be, G) * PP_B;      // nodes >= jprev: snapshot positions
     const int ncross = j0 - jprev;
-    const int bb = be & 1;
+    const int bb = be & (2 * G - 1);
     const double *Xt = c.X + (size_t)t * N * D;
     const double *props = pb.prop + (size_t)t * N * PW;
     const uint32_t *yr = c.ybits + ((size_t)t * N + jk) * W;
@@ -370,7 +379,8 @@ __device__ __forceinline__ void pipe_eval_item(const ChainView &c, const PipeBuf
     const char *yrows = (const char *)(c.ybits + (size_t)t * N * W);
     const char *ytrows = MODEL == DLSM_DIRECTED ? (const char *)(c.ytbits + (size_t)t * N * W) : nullptr;
     char *hbase = (char *)(pb.Hd + ((size_t)bb * c.T + t) * PP_B * PP_B);
-    const uint32_t hx_off = (uint32_t)((const char *)pb.Hx - (const char *)pb.Hd);   // one allocation
+    const uint32_t hx_off = (uint32_t)((const char *)(pb.Hx + ((size_t)bb * c.T + t) * ((2 * G - 1) * PP_B) * PP_B) -
+                                       (const char *)hbase);                          // one allocation
     for (int f = hf0; f < htot; f += hround) {
         int kk, e;
         pipe_h_decode(f, ncross, nb, kk, e);
@@ -529,17 +539,19 @@ __device__ __forceinline__ void pipe_cc_writeout(const ChainView &c, const PipeB
     if (m >= ncross + k) return;
     const double v = col[m];
     const double f = v == 0.0 ? 1.0 : exp(v);
-    if (m < ncross) pb.Hx[(((size_t)bb * c.T + t) * PP_B + m) * PP_B + k] = f;
+    if (m < ncross) pb.Hx[(((size_t)bb * c.T + t) * PP_B + m) * PP_B + k] = f;    // G = 1
     else pb.Hd[(((size_t)bb * c.T + t) * PP_B + (m - ncross)) * PP_B + k] = f;
 }
 
-// Resolve batch b of slice t: the fixed-point solve of k_spec_resolve for one batch,
-// the acceptances of batch b - 1 entering through gathered rows of the cross block.
-template <int D>
+// Resolve batch b of slice t: the fixed-point solve of k_spec_resolve for one batch, the
+// acceptances of its window's earlier batches (pipe_window_start) entering through gathered rows
+// of the cross block.  With G > 1 a workgroup resolves G batches one after the other; the list
+// of the batch it has just resolved is in sOwn (own_prev), the others come from memory.
+template <int D, int G>
 __device__ __forceinline__ void pipe_resolve(const ChainView &c, const PipeBuf &pb, int b, int t,
                                              double *sH, double *sPart,
                                              unsigned long long (*sMask)[2], int *sPrev,
-                                             unsigned char *sSat
+                                             unsigned char *sSat, int *sOwn, bool own_prev
 #ifdef DLSM_PIPE_TIMING
                                              , int tl
 #endif
@@ -553,14 +565,18 @@ __device__ __forceinline__ void pipe_resolve(const ChainView &c, const PipeBuf &
     const int N = c.N;
     const int j0 = b * PP_B;
     const int nb = min(PP_B, N - j0);
-    const int bb = b & 1;
+    constexpr int G2 = 2 * G;
+    const int bb = b & (G2 - 1);
     const int half = wave & 1, part = wave >> 1;
     const int k = 64 * half + lane;
     const bool owner = wave < 2;
     const bool valid = k < nb;
     const double *Hd = pb.Hd + ((size_t)bb * c.T + t) * PP_B * PP_B;
-    const double *Hx = pb.Hx + ((size_t)bb * c.T + t) * PP_B * PP_B;
-    int32_t *accg = pb.acc + (size_t)t * (PP_B + 1);
+    const double *Hx = pb.Hx + ((size_t)bb * c.T + t) * ((G2 - 1) * PP_B) * PP_B;
+    int32_t *acct = pb.acc + (size_t)t * G2 * (PP_B + 1);
+    int32_t *accg = acct + (size_t)bb * (PP_B + 1);            // this batch's list
+    const int ws = pipe_window_start(b, G);
+    const int nwin = b - ws;                                    // earlier batches of the window: <= 3
     // diagonal block -> LDS (unconditional clamped loads, see k_spec_resolve)
     double2 blk[8];
 #pragma unroll
@@ -568,8 +584,23 @@ __device__ __forceinline__ void pipe_resolve(const ChainView &c, const PipeBuf &
         const int q = min(u * PP_THREADS + tid, nb * (PP_B / 2) - 1);
         blk[u] = *(const double2 *)(Hd + (size_t)(q >> 6) * PP_B + 2 * (q & 63));
     }
-    const int nprev = b > 0 ? accg[0] : 0;
-    for (int a = tid; a < nprev; a += PP_THREADS) sPrev[a] = accg[1 + a];
+    // their accepted nodes as rows of the cross block: row = 128 (batch - ws) + node
+    int cntw[3] = {0, 0, 0};
+#pragma unroll
+    for (int w = 0; w < G2 - 1; ++w)
+        if (w < nwin) {
+            const bool own = own_prev && ws + w == b - 1;
+            cntw[w] = own ? sOwn[0] : acct[(size_t)((ws + w) & (G2 - 1)) * (PP_B + 1)];
+        }
+    const int nprev = cntw[0] + cntw[1] + cntw[2];
+#pragma unroll
+    for (int w = 0; w < G2 - 1; ++w)
+        if (w < nwin) {
+            const bool own = own_prev && ws + w == b - 1;
+            const int32_t *lst = own ? sOwn : acct + (size_t)((ws + w) & (G2 - 1)) * (PP_B + 1);
+            const int off = w == 0 ? 0 : (w == 1 ? cntw[0] : cntw[0] + cntw[1]);
+            for (int a = tid; a < cntw[w]; a += PP_THREADS) sPrev[off + a] = w * PP_B + lst[1 + a];
+        }
     // multiplicative domain: r = exp(log-ratio of node k), lu = its uniform draw.  A node whose
     // log-ratio is beyond +-700 (exp would saturate) is resolved in the log domain instead -
     // log u against lr + the LOGS of its H factors - so that the decision is the sequential
@@ -622,14 +653,17 @@ __device__ __forceinline__ void pipe_resolve(const ChainView &c, const PipeBuf &
         double prod = 1.0;
         int a = part;
         if (!anysat) {
-            // at most PP_B / 8 = 16 rows per thread: all their loads in flight together (clamped
-            // addresses, the factor of a row that is not there replaced by 1)
-            double hh[PP_B / 8];
+            // PP_B / 8 = 16 rows per thread and trip (one trip per 128 accepted nodes): all their
+            // loads in flight together (clamped addresses, the factor of a row that is not there
+            // replaced by 1)
+            for (int base = 0; base < nprev; base += PP_B) {
+                double hh[PP_B / 8];
 #pragma unroll
-            for (int u = 0; u < PP_B / 8; ++u)
-                hh[u] = colp[(size_t)sPrev[min(a + 8 * u, nprev - 1)] * PP_B];
+                for (int u = 0; u < PP_B / 8; ++u)
+                    hh[u] = colp[(size_t)sPrev[min(base + a + 8 * u, nprev - 1)] * PP_B];
 #pragma unroll
-            for (int u = 0; u < PP_B / 8; ++u) prod *= a + 8 * u < nprev ? hh[u] : 1.0;
+                for (int u = 0; u < PP_B / 8; ++u) prod *= base + a + 8 * u < nprev ? hh[u] : 1.0;
+            }
         } else {
             double lsum = 0.0;
             for (; a < nprev; a += 8) {
@@ -715,12 +749,15 @@ __device__ __forceinline__ void pipe_resolve(const ChainView &c, const PipeBuf &
             metropolis_bookkeeping(st, na, ns, un, c.tune, c.tune_interval, accepted);
             c.step[tj] = st; c.nacc[tj] = na; c.nsteps[tj] = ns; c.until[tj] = un;
         }
-        // accepted nodes of this batch (ascending) for the next batch's cross term
+        // accepted nodes of this batch (ascending) for the cross terms of the batches that have it
+        // in their window: in memory for the launches to come, in LDS for this workgroup's next batch
         if (accepted) {
             const int base = half == 0 ? 0 : __popcll(m0);
-            accg[1 + base + __popcll(mine & ((1ull << lane) - 1ull))] = k;
+            const int at = 1 + base + __popcll(mine & ((1ull << lane) - 1ull));
+            accg[at] = k;
+            sOwn[at] = k;
         }
-        if (tid == 0) accg[0] = __popcll(m0) + __popcll(m1);
+        if (tid == 0) { const int cnt = __popcll(m0) + __popcll(m1); accg[0] = cnt; sOwn[0] = cnt; }
     }
 #ifdef DLSM_PIPE_TIMING
     DLSM_STAMP(4, (double)cur)
@@ -729,35 +766,42 @@ __device__ __forceinline__ void pipe_resolve(const ChainView &c, const PipeBuf &
 #endif
 }
 
-// Launch l: even slices resolve batch l and evaluate batch l + 1; odd slices resolve
-// batch l - 1 and evaluate batch l (batches outside [0, nbat) do nothing).
-// Workgroups [0, T) are the resolvers, the rest evaluate one item per wavefront.
+// Launch l: even slices resolve batches G l .. G l + G - 1 and evaluate batches G (l + 1) ..;
+// odd slices run one launch behind (batches outside [0, nbat) do nothing).
+// Workgroups [0, T) are the resolvers, the rest evaluate one item per wavefront and round.
 // MODEL = PIPE_UNDIRECTED_LONG: the undirected model with parts longer than the prefetch
 constexpr int PIPE_UNDIRECTED_LONG = 3;
 
-template <int D, int MODEL_>
+template <int D, int MODEL_, int G = 1>
 __global__ __launch_bounds__(PP_THREADS) void k_pipe_step(ChainView c, PipeBuf pb, int l) {
     constexpr int MODEL = MODEL_ == PIPE_UNDIRECTED_LONG ? DLSM_UNDIRECTED : MODEL_;
     constexpr bool TP = MODEL_ != DLSM_UNDIRECTED;
     extern __shared__ __attribute__((aligned(16))) double pp_sH[];      // 128 x 128
     __shared__ double sPart[PP_WAVES * 64];
     __shared__ unsigned long long sMask[2][2];
-    __shared__ int sPrev[PP_B];
+    __shared__ int sPrev[3 * PP_B];
+    __shared__ int sOwn[PP_B + 1];
     __shared__ unsigned char sSat[PP_B];
     const int T = c.T;
     if ((int)blockIdx.x < T) {
         const int t = blockIdx.x;
-        const int b = l - (t & 1);
-        if (b >= 0 && b < pb.nbat) pipe_resolve<D>(c, pb, b, t, pp_sH, sPart, sMask, sPrev, sSat
+        bool own_prev = false;
+        for (int g = 0; g < G; ++g) {
+            const int b = G * (l - (t & 1)) + g;
+            if (b < 0 || b >= pb.nbat) continue;
+            if (own_prev) __syncthreads();          // the LDS of the batch before is free again
+            pipe_resolve<D, G>(c, pb, b, t, pp_sH, sPart, sMask, sPrev, sSat, sOwn, own_prev
 #ifdef DLSM_PIPE_TIMING
-                                                   , l + 1
+                            , l + 1
 #endif
-                                                   );
+                            );
+            own_prev = true;
+        }
         return;
     }
     const int lane = threadIdx.x & 63;
     const int nE = (T + 1) / 2, nO = T / 2;
-    const int beE = l + 1, beO = l;
+    const int beE = G * (l + 1), beO = G * l;        // first batch evaluated (even / odd slices)
     const int nbE = (beE >= 0 && beE < pb.nbat) ? min(PP_B, c.N - beE * PP_B) : 0;
     const int nbO = (beO >= 0 && beO < pb.nbat) ? min(PP_B, c.N - beO * PP_B) : 0;
     if (MODEL == DLSM_DIRECTED_CASE_CONTROL) {
@@ -788,8 +832,10 @@ __global__ __launch_bounds__(PP_THREADS) void k_pipe_step(ChainView c, PipeBuf p
     }
     // items ordered (part, active slice, k) with 128 k-slots per slice, so that an item id
     // decodes with a shift, a mask and one small quotient (no integer divisions)
+    // (a launch's first batch exists whenever any of its G batches does)
+    constexpr int gsh = G == 2 ? 8 : 7;                // k-slots per slice: G * 128
     const int nslE = nbE > 0 ? nE : 0, nslO = nbO > 0 ? nO : 0, nsl = nslE + nslO;
-    const int nitems = pb.parts * nsl * PP_B;
+    const int nitems = (pb.parts * nsl) << gsh;
     const float inv_nsl = 1.0f / (float)max(nsl, 1);
     // the evaluators' table of 2^(j / 256) (tab_exp) in the dynamic LDS the resolvers use for H
     // (the barrier-free fill of exp_table_fill_wave measured no better: 3614 against 3638 it/s)
@@ -802,14 +848,17 @@ __global__ __launch_bounds__(PP_THREADS) void k_pipe_step(ChainView c, PipeBuf p
         ((int)blockIdx.x - T) * PP_WAVES + (int)(threadIdx.x >> 6));
     for (int q = gw; q < nitems; q += nwaves) {
         const int k = q & (PP_B - 1);
-        const int r = q >> 7;
+        const int g = (q >> 7) & (G - 1);
+        const int r = q >> gsh;
         const int p = (int)(((float)r + 0.5f) * inv_nsl);        // r / nsl (r < 2^20)
         const int si = r - p * nsl;
         const bool odd = si >= nslE;
-        if (k >= (odd ? nbO : nbE)) continue;
+        const int be = (odd ? beO : beE) + g;
+        const int nb = be < pb.nbat ? min(PP_B, c.N - be * PP_B) : 0;
+        if (k >= nb) continue;
         const int t = odd ? 2 * (si - nslE) + 1 : 2 * si;
-        pipe_eval_item<D, MODEL == DLSM_DIRECTED_CASE_CONTROL ? DLSM_DIRECTED : MODEL, TP>(
-            c, pb, odd ? beO : beE, odd ? nbO : nbE, t, k, p, lane, pp_sH
+        pipe_eval_item<D, MODEL == DLSM_DIRECTED_CASE_CONTROL ? DLSM_DIRECTED : MODEL, TP, G>(
+            c, pb, be, nb, t, k, p, lane, pp_sH
 #ifdef DLSM_PIPE_TIMING
             , l + 1, gw
 #endif

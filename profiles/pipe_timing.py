@@ -6,7 +6,7 @@ wavefronts relative to the launch's earliest stamp.
 
     hipcc -O3 --offload-arch=gfx950 -std=c++17 -shared -fPIC -DDLSM_PIPE_TIMING \
           -o tmp_timing/libtiming.so dynetlsm_amd/csrc/capi.hip
-    python profiles/pipe_timing.py tmp_timing/libtiming.so [out.json]
+    python profiles/pipe_timing.py tmp_timing/libtiming.so [out.json [sweep algo: 4 | 6]]
 
 Evaluator stamps: 0 entry, 1 first trip of 64 neighbours done (its operands have arrived),
 2 last prefetched trip done, 3 wavefront reductions + record stored, 4 first H entry's operands
@@ -37,7 +37,7 @@ ch.set_intercepts([float(net['intercept'])])
 ch.set_prior_random_walk(2.0, 0.1)
 ch.set_samplers(SamplerGrid(T, N, step_size=0.1, tune=None))
 ch.lsm_configure([float(net['intercept'])], 2.0, step_size_intercept=0.1, tune=None,
-                 n_iter_procrustes=0, sweep_algo=4)
+                 n_iter_procrustes=0, sweep_algo=int(sys.argv[3]) if len(sys.argv) > 3 else 4)
 ch.trace_alloc(64, logp0=0.0)
 ch.lsm_run(1, 40, procrustes_ref=0)
 ch.synchronize()

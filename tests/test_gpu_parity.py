@@ -325,7 +325,7 @@ def test_sweep_squared_distances(eng):
     evaluator and the log-likelihood pass have their own squared-distance loops)"""
     from dynetlsm_amd import Chain, SamplerGrid
     X, Yd, Yu, radii = _rand_net(77, 3, 200, 2)
-    for algo in (1, 2, 3, 4):
+    for algo in (1, 2, 3, 4, 6):
         og = orc.SamplerGrid(3, 200, 0.1, tune=None)
         st = orc.ChainState(X, og, Y=Yu, intercept=[0.5], squared=True, tau_sq=2.0,
                             sigma_sq=0.1, seed=8, chain=0)
@@ -390,10 +390,11 @@ def test_sweep_pipelined_many_slices(eng):
                                         ('undirected', 3, 1100, 2), ('directed', 4, 260, 2),
                                         ('directed', 3, 128, 3), ('undirected', 5, 129, 1),
                                         ('undirected', 2, 257, 4)])
-@pytest.mark.parametrize('algo', [2, 3, 4])
+@pytest.mark.parametrize('algo', [2, 3, 4, 6])
 def test_sweep_speculative_batches(eng, name, T, N, D, prior, algo):
-    """algo 2 / 3 (chip-wide speculative batches) and 4 (the pipelined form: batch b + 1
-    evaluated beside the resolve of batch b) are the same Gauss-Seidel scan:
+    """algo 2 / 3 (chip-wide speculative batches), 4 (the pipelined form: batch b + 1
+    evaluated beside the resolve of batch b) and 6 (two batches resolved and two evaluated
+    per launch: windows of two and three batches) are the same Gauss-Seidel scan:
     identical decisions, positions equal to rounding.  N = 10 < one batch,
     129 / 257 / 300 leave ragged last batches."""
     _sweep_case(eng, name, prior, T=T, N=N, D=D, n_sweeps=3, algo=algo,
@@ -426,6 +427,17 @@ def test_sweep_case_control_sparse_lists_other_dimensions(eng, D):
     """algo 5 with d = 1, 3, 4 (packed records of 4 / 4 / 8 doubles), two batches"""
     _sweep_case(eng, 'case_control', 'rw', T=2, N=700, D=D, n_sweeps=2, algo=5, scale=0.05, cc_C=8,
                 density=0.01)
+
+
+@pytest.mark.parametrize('name,T,N,D,prior', [('undirected', 3, 1290, 2, 'mix'), ('undirected', 2, 640, 3, 'rw'),
+                                              ('undirected', 1, 770, 2, 'rw'), ('directed', 3, 520, 2, 'rw'),
+                                              ('undirected', 5, 385, 1, 'mix')])
+def test_sweep_two_batches_per_launch(eng, name, T, N, D, prior):
+    """algo 6 over odd and even batch counts (11, 5, 7, 5, 4 batches; the last one ragged or a
+    single node), a single slice, both exact models: the windows of two and three batches, the
+    workgroup's second fixed point fed from the first's list in LDS"""
+    _sweep_case(eng, name, prior, T=T, N=N, D=D, n_sweeps=3, algo=6,
+                scale=1.0 if name == 'undirected' else 0.05)
 
 
 def test_sweep_auto_picks_a_valid_algorithm(eng):
