@@ -137,7 +137,9 @@ int dlsm_loglik_partial_all(dlsm_chain *h, int with_prior, double *out);
  * 4 = pipelined speculative batches: one fused launch resolves batch b and
  *     evaluates batch b + 1, both parities in the same launches,
  * 5 = (case-control model) the pipelined form with sparse correction lists and batches
- *     of 512 nodes. */
+ *     of 512 nodes,
+ * 6 = (exact likelihoods) the pipelined form with two batches resolved and two evaluated
+ *     per launch: half the launches, larger correction blocks (measured slower than 4). */
 int dlsm_sweep_positions(dlsm_chain *h, uint32_t iter, int algo);
 /* the algorithm `algo` resolves to for this handle (what 0 = auto picks): 1..5 */
 int dlsm_resolve_sweep_algo(dlsm_chain *h, int algo);
