@@ -77,7 +77,10 @@ def parse(argv=None):
                     help='independent chains per GPU, each on its own handle and stream, '
                          'enqueued by its own host thread (aggregate throughput)')
     ap.add_argument('--algo', type=int, default=0, help='sweep algorithm (0 auto)')
-    ap.add_argument('--profile-steps', type=int, default=20)
+    ap.add_argument('--profile-steps', type=int, default=100,
+                    help='iterations of the per-kernel event phase that precedes the warm-up steps '
+                         '(averages over 100 x 18 sweep launches; it also leaves the device in its '
+                         'running state: a short timed window right after an idle device reads 3-5 %% low)')
     ap.add_argument('--cpu-iters', type=int, default=8,
                     help='oracle iterations timed for cpu_baseline (0 = skip)')
     ap.add_argument('--cpu-procs', type=int, default=1,
