@@ -838,7 +838,8 @@ __global__ __launch_bounds__(PP_THREADS) void k_pipe_step(ChainView c, PipeBuf p
     const int nitems = (pb.parts * nsl) << gsh;
     const float inv_nsl = 1.0f / (float)max(nsl, 1);
     // the evaluators' table of 2^(j / 256) (tab_exp) in the dynamic LDS the resolvers use for H
-    // (the barrier-free fill of exp_table_fill_wave measured no better: 3614 against 3638 it/s)
+    // (a barrier-free fill - every wavefront copying the table itself with global_load_lds_dwordx4 -
+    // measured no better: 3614 against 3638 it/s; nor did the barrier behind the item's loads: 3615)
     if (MODEL == DLSM_UNDIRECTED) {
         exp_table_fill(pp_sH, threadIdx.x);
         __syncthreads();

@@ -1,6 +1,8 @@
 #!/bin/bash
 # Everything profiles/README.md lists for a round, in one call on the GPU box (from the repo root,
-# through gpurun; ~12 minutes).  tmp_timing/libtiming.so = the engine built with -DDLSM_PIPE_TIMING.
+# through gpurun; ~5 minutes).  Optional inputs under tmp_timing/ (untracked, built in the container first):
+#   libtiming.so = the engine with -DDLSM_PIPE_TIMING (see profiles/pipe_timing.py),
+#   valu_rates, sqrt_acc = hipcc -O3 --offload-arch=gfx950 of profiles/micro/valu_rates.hip, sqrt_acc.cpp
 #   bash profiles/collect_round.sh <tag>      -> gpurun_out/<tag>/
 TAG=${1:-round}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
