@@ -1693,6 +1693,12 @@ extern "C" int dlsm_debug_pipe_timing(unsigned long long *items, unsigned long l
     if (hipMemcpyFromSymbol(res, HIP_SYMBOL(dlsm::g_pipe_res_t), sizeof(dlsm::g_pipe_res_t)) != hipSuccess) return -3;
     return 0;
 }
+extern "C" int dlsm_debug_ccpipe_timing(unsigned long long *res, unsigned long long *items) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(res, HIP_SYMBOL(dlsm::g_cc_res_t), sizeof(dlsm::g_cc_res_t)) != hipSuccess) return -2;
+    if (hipMemcpyFromSymbol(items, HIP_SYMBOL(dlsm::g_cc_item_t), sizeof(dlsm::g_cc_item_t)) != hipSuccess) return -3;
+    return 0;
+}
 extern "C" int dlsm_debug_loglik_timing(unsigned long long *waves) {
     if (hipDeviceSynchronize() != hipSuccess) return -1;
     if (hipMemcpyFromSymbol(waves, HIP_SYMBOL(dlsm::g_ll_t), sizeof(dlsm::g_ll_t)) != hipSuccess) return -2;

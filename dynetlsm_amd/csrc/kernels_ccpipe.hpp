@@ -257,69 +257,129 @@ __device__ __forceinline__ void ccpipe_eval_item(const ChainView &c, const CcPip
 }
 
 // Resolve batch b of slice t: thread k owns node k of the batch.
+#ifdef DLSM_PIPE_TIMING
+// resolver phase stamps and evaluator entry / exit of the last sweep (profiles/ccpipe_timing.py)
+__device__ unsigned long long g_cc_res_t[32][16][8];
+__device__ unsigned long long g_cc_item_t[32][4096][2];
+#define DLSM_CC_STAMP(I_, DEP_) { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) : "v"(DEP_)); cts[I_] = t_; }
+#else
+#define DLSM_CC_STAMP(I_, DEP_)
+#endif
 template <int D>
 __device__ __forceinline__ void ccpipe_resolve(const ChainView &c, const CcPipeBuf &pb, int b, int t,
                                                unsigned long long (*sMask)[CP_WAVES],
-                                               unsigned long long *sPrev, int *sChanged) {
+                                               unsigned long long *sPrev, int *sChanged,
+                                               double *sCross
+#ifdef DLSM_PIPE_TIMING
+                                               , int tl
+#endif
+                                               ) {
     constexpr int PW = 2 * D + 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef DLSM_PIPE_TIMING
+    unsigned long long cts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    DLSM_CC_STAMP(0, (double)tid)
     const int N = c.N;
     const int j0 = b * CP_B;
     const int nb = min(CP_B, N - j0);
     const int bb = b & 1;
-    const int k = tid;
-    const bool valid = k < nb;
+    // Two threads per node, half a workgroup apart: thread k carries the node's state and its
+    // own entries, thread CP_B + k its cross entries - so that everything a node needs from
+    // memory leaves in ONE go without either thread holding both lists in registers
+    // (profiles/ccpipe_timing.py: the resolver is the launch's critical path, and was four
+    // memory round trips of 3 - 4 us in sequence - state, cross entries, own entries, each behind
+    // a count).  The first XCH cross / CP_OWN_REGS own entries are requested whatever the counts
+    // will turn out to be (the lists are entry-major with room for `cap` entries; what lies
+    // beyond a count is ignored).
+    static_assert(CP_THREADS == 2 * CP_B, "two threads per node");
+    const bool upper = tid >= CP_B;
+    const int k = upper ? tid - CP_B : tid;
+    const bool valid = !upper && k < nb;
     const int kc = min(k, nb - 1);
     unsigned long long *accg = pb.accmask + (size_t)t * CP_WAVES;
     if (tid < CP_WAVES) sPrev[tid] = b > 0 ? accg[tid] : 0ull;
     const size_t slot = ((size_t)bb * c.T + t) * CP_B + kc;
     const size_t lbase = ((size_t)bb * c.T + t) * pb.cap * CP_B + kc;
-    const int ncx = pb.cnt[slot * 2], nown = pb.cnt[slot * 2 + 1];
-    double r = pb.tot[slot];
-    const double *pr = pb.prop + ((size_t)t * N + j0 + kc) * PW;
-    double x0[D], x1[D];
+    // Cross entries up front: 32 (a node of config 4 has 12 on average, more than 16 in one of
+    // eight cases, and a second trip to memory for the few costs every wavefront 3.6 us); the two
+    // halves are separate code paths, so neither holds the other's registers.
+    constexpr int XCH = 32;
+    const int nlist = pb.cnt[slot * 2 + (upper ? 0 : 1)];
+    const int ncx = upper ? nlist : 0, nown = upper ? 0 : nlist;
+    int oi[CP_OWN_REGS];
+    double ov[CP_OWN_REGS];
+    double r = 0.0, lu = 0.0, st = 0.0, x1[D];
+    int32_t na = 0, ns = 0, un = 0;
 #pragma unroll
-    for (int d = 0; d < D; ++d) { x1[d] = pr[d]; x0[d] = pr[D + 2 + d]; }
-    // prior terms of the step's logp closure, with the neighbouring slices as they are now
-    // (the odd slices run one batch behind: kernels_spec_pipe.hpp)
-    r += node_log_prior<D>(c, t, j0 + kc, x1) - node_log_prior<D>(c, t, j0 + kc, x0);
-    const double lu = log(pr[D]);
-    const size_t tjc = (size_t)t * N + j0 + kc;
-    double st = c.step[tjc];
-    int32_t na = c.nacc[tjc], ns = c.nsteps[tjc], un = c.until[tjc];
-    __syncthreads();                                   // sPrev visible
-    // the previous batch's acceptances, final by now: cross entries in list order
-    // (sixteen entries per trip, their loads issued together: a one-entry loop is a chain of
-    // ~1 us memory latencies)
-    constexpr int XCH = 16;
-    for (int e0 = 0; e0 < ncx; e0 += XCH) {
-        int m[XCH];
-        double h[XCH];
+    for (int d = 0; d < D; ++d) x1[d] = 0.0;
+#pragma unroll
+    for (int e = 0; e < CP_OWN_REGS; ++e) { oi[e] = 0; ov[e] = 0.0; }
+    if (upper) {
+        int xm[XCH];
+        double xh[XCH];
 #pragma unroll
         for (int u = 0; u < XCH; ++u) {
-            const size_t p = lbase + (size_t)min(e0 + u, ncx - 1) * CP_B;
-            m[u] = pb.xidx[p];
-            h[u] = pb.xval[p];
+            const size_t p = lbase + (size_t)min(u, pb.cap - 1) * CP_B;
+            xm[u] = pb.xidx[p];
+            xh[u] = pb.xval[p];
         }
+        __syncthreads();                               // sPrev visible
+        // the previous batch's acceptances, final by now: the node's cross entries in list order
+        // (a list longer than the 32 at hand comes sixteen entries per trip, their loads issued
+        // together), handed over through LDS
+        double xs = 0.0;
 #pragma unroll
         for (int u = 0; u < XCH; ++u)
-            if (e0 + u < ncx && ((sPrev[m[u] >> 6] >> (m[u] & 63)) & 1ull)) r += h[u];
-    }
-    // the node's first own entries: into registers, all loads in flight at once
-    double ov[CP_OWN_REGS];
-    int oi[CP_OWN_REGS];
+            if (u < ncx && ((sPrev[xm[u] >> 6] >> (xm[u] & 63)) & 1ull)) xs += xh[u];
+        for (int e0 = XCH; e0 < ncx; e0 += 16) {
+            int m[16];
+            double h[16];
 #pragma unroll
-    for (int e = 0; e < CP_OWN_REGS; ++e) {
-        const size_t p = lbase + (size_t)min(e, max(nown - 1, 0)) * CP_B;
-        oi[e] = e < nown ? pb.oidx[p] : 0;
-        ov[e] = pb.oval[p];
+            for (int u = 0; u < 16; ++u) {
+                const size_t p = lbase + (size_t)min(e0 + u, ncx - 1) * CP_B;
+                m[u] = pb.xidx[p];
+                h[u] = pb.xval[p];
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                if (e0 + u < ncx && ((sPrev[m[u] >> 6] >> (m[u] & 63)) & 1ull)) xs += h[u];
+        }
+        sCross[k] = xs;
+    } else {
+#pragma unroll
+        for (int e = 0; e < CP_OWN_REGS; ++e) {
+            const size_t p = lbase + (size_t)min(e, pb.cap - 1) * CP_B;
+            oi[e] = pb.oidx[p];
+            ov[e] = pb.oval[p];
+        }
+        r = pb.tot[slot];
+        const double *pr = pb.prop + ((size_t)t * N + j0 + kc) * PW;
+        double x0[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) { x1[d] = pr[d]; x0[d] = pr[D + 2 + d]; }
+        // prior terms of the step's logp closure, with the neighbouring slices as they are now
+        // (the odd slices run one batch behind: kernels_spec_pipe.hpp)
+        r += node_log_prior<D>(c, t, j0 + kc, x1) - node_log_prior<D>(c, t, j0 + kc, x0);
+        lu = log(pr[D]);
+        const size_t tjc = (size_t)t * N + j0 + kc;
+        st = c.step[tjc];
+        na = c.nacc[tjc]; ns = c.nsteps[tjc]; un = c.until[tjc];
+        __syncthreads();                               // (the upper half's barrier)
     }
+    DLSM_CC_STAMP(2, r)
+    // the node's first own entries stay in registers through the passes
+#pragma unroll
+    for (int e = 0; e < CP_OWN_REGS; ++e) oi[e] = e < nown ? oi[e] : 0;
+    __syncthreads();                                   // sCross visible
+    if (!upper) r += sCross[k];
     {
         const unsigned long long g = __ballot(valid && !(lu >= r));
         if (lane == 0) sMask[0][wave] = g;
     }
     if (tid < 3) sChanged[tid] = 0;
     __syncthreads();
+    DLSM_CC_STAMP(3, ov[0])
     // fixed point of a -> F(a); one barrier per pass: pass p raises flag p % 3 and clears flag
     // (p + 1) % 3, whose last readers (pass p - 2) are two barriers behind
     int cur = 0;
@@ -351,6 +411,7 @@ __device__ __forceinline__ void ccpipe_resolve(const ChainView &c, const CcPipeB
         cur ^= 1;
         if (!sChanged[pass % 3]) break;
     }
+    DLSM_CC_STAMP(4, (double)cur)
     const unsigned long long mine = sMask[cur][wave];
     const int accepted = (int)((mine >> lane) & 1ull);
     if (valid) {
@@ -366,6 +427,10 @@ __device__ __forceinline__ void ccpipe_resolve(const ChainView &c, const CcPipeB
         c.step[tj] = st; c.nacc[tj] = na; c.nsteps[tj] = ns; c.until[tj] = un;
     }
     if (lane == 0) accg[wave] = mine;
+#ifdef DLSM_PIPE_TIMING
+    DLSM_CC_STAMP(5, (double)cur)
+    if (tid == 0 && tl >= 0 && tl < 32 && t < 16) for (int i = 0; i < 6; ++i) g_cc_res_t[tl][t][i] = cts[i];
+#endif
 }
 
 // Launch l: even slices resolve batch l and evaluate batch l + 1; odd slices resolve batch
@@ -375,12 +440,17 @@ __global__ __launch_bounds__(CP_THREADS) void k_ccpipe_step(ChainView c, CcPipeB
     __shared__ unsigned long long sMask[2][CP_WAVES];
     __shared__ unsigned long long sPrev[CP_WAVES];
     __shared__ int sChanged[3];
+    __shared__ double sCross[CP_B];
     __shared__ CcWin sWin[CP_WAVES];
     const int T = c.T;
     if ((int)blockIdx.x < T) {
         const int t = blockIdx.x;
         const int b = l - (t & 1);
-        if (b >= 0 && b < pb.nbat) ccpipe_resolve<D>(c, pb, b, t, sMask, sPrev, sChanged);
+        if (b >= 0 && b < pb.nbat) ccpipe_resolve<D>(c, pb, b, t, sMask, sPrev, sChanged, sCross
+#ifdef DLSM_PIPE_TIMING
+                                                     , l + 1
+#endif
+                                                     );
         return;
     }
     const int lane = threadIdx.x & 63;
@@ -398,7 +468,15 @@ __global__ __launch_bounds__(CP_THREADS) void k_ccpipe_step(ChainView c, CcPipeB
         const int nb = odd ? nbO : nbE;
         const int k = qq % nb;
         const int t = 2 * (qq / nb) + (odd ? 1 : 0);
+#ifdef DLSM_PIPE_TIMING
+        unsigned long long cts[2];
+        DLSM_CC_STAMP(0, (double)lane)
+#endif
         ccpipe_eval_item<D>(c, pb, odd ? beO : beE, t, k, lane, sWin[threadIdx.x >> 6]);
+#ifdef DLSM_PIPE_TIMING
+        DLSM_CC_STAMP(1, (double)lane)
+        if (lane == 0 && l + 1 >= 0 && l + 1 < 32 && gw < 4096) { g_cc_item_t[l + 1][gw][0] = cts[0]; g_cc_item_t[l + 1][gw][1] = cts[1]; }
+#endif
     }
 }
 
