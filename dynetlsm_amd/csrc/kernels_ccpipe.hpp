@@ -32,7 +32,9 @@ namespace dlsm {
 constexpr int CP_B = 512;               // nodes per batch (<= CP_THREADS: the resolver's thread = node)
 constexpr int CP_THREADS = 1024;
 constexpr int CP_WAVES = CP_THREADS / 64;
-constexpr int CP_OWN_REGS = 16;         // own entries a resolver thread keeps in registers
+// (12 / 24 up front measured best at config 4: 8 / 16 1637, 10 / 20 1679, 12 / 24 1731-1744,
+// 14 / 24 1739, 12 / 32 1700, 16 / 32 1557 it/s - every own entry is an LDS read per pass)
+constexpr int CP_OWN_REGS = 12;         // own entries a resolver thread keeps in registers
 
 struct CcPipeBuf {
     double *prop;            // [T][N][2D + 2] : x1[D], u, (unused), x0[D] (snapshot)
@@ -301,10 +303,10 @@ __device__ __forceinline__ void ccpipe_resolve(const ChainView &c, const CcPipeB
     if (tid < CP_WAVES) sPrev[tid] = b > 0 ? accg[tid] : 0ull;
     const size_t slot = ((size_t)bb * c.T + t) * CP_B + kc;
     const size_t lbase = ((size_t)bb * c.T + t) * pb.cap * CP_B + kc;
-    // Cross entries up front: 32 (a node of config 4 has 12 on average, more than 16 in one of
+    // Cross entries up front: 24 (a node of config 4 has 12 on average, more than 16 in one of
     // eight cases, and a second trip to memory for the few costs every wavefront 3.6 us); the two
     // halves are separate code paths, so neither holds the other's registers.
-    constexpr int XCH = 32;
+    constexpr int XCH = 24;
     const int nlist = pb.cnt[slot * 2 + (upper ? 0 : 1)];
     const int ncx = upper ? nlist : 0, nown = upper ? 0 : nlist;
     int oi[CP_OWN_REGS];
@@ -326,7 +328,7 @@ __device__ __forceinline__ void ccpipe_resolve(const ChainView &c, const CcPipeB
         }
         __syncthreads();                               // sPrev visible
         // the previous batch's acceptances, final by now: the node's cross entries in list order
-        // (a list longer than the 32 at hand comes sixteen entries per trip, their loads issued
+        // (a list longer than the 24 at hand comes sixteen entries per trip, their loads issued
         // together), handed over through LDS
         double xs = 0.0;
 #pragma unroll
