@@ -19,6 +19,7 @@ python3 bench.py --model lsm --cpu-procs 8 > $OUT/bench_lsm_cpu8.json 2> $OUT/be
 if [ -f tmp_timing/libtiming.so ]; then
   python3 profiles/pipe_timing.py tmp_timing/libtiming.so $OUT/pipe_timing.json > $OUT/pipe_timing.log 2>&1
   python3 profiles/loglik_timing.py tmp_timing/libtiming.so $OUT/loglik_timing.json > $OUT/loglik_timing.log 2>&1
+  python3 profiles/ccpipe_timing.py tmp_timing/libtiming.so $OUT/ccpipe_timing.json > $OUT/ccpipe_timing.log 2>&1
 fi
 [ -x tmp_timing/valu_rates ] && ./tmp_timing/valu_rates > $OUT/valu_rates.txt 2>&1
 [ -x tmp_timing/sqrt_acc ] && ./tmp_timing/sqrt_acc > $OUT/sqrt_acc.txt 2>&1
