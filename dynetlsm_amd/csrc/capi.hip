@@ -1699,6 +1699,11 @@ extern "C" int dlsm_debug_ccpipe_timing(unsigned long long *res, unsigned long l
     if (hipMemcpyFromSymbol(items, HIP_SYMBOL(dlsm::g_cc_item_t), sizeof(dlsm::g_cc_item_t)) != hipSuccess) return -3;
     return 0;
 }
+extern "C" int dlsm_debug_labels_timing(unsigned long long *waves) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(waves, HIP_SYMBOL(dlsm::g_lab_t), sizeof(dlsm::g_lab_t)) != hipSuccess) return -2;
+    return 0;
+}
 extern "C" int dlsm_debug_loglik_timing(unsigned long long *waves) {
     if (hipDeviceSynchronize() != hipSuccess) return -1;
     if (hipMemcpyFromSymbol(waves, HIP_SYMBOL(dlsm::g_ll_t), sizeof(dlsm::g_ll_t)) != hipSuccess) return -2;

@@ -61,6 +61,12 @@ constexpr int LAB_WAVES = 8;
 
 __host__ __device__ inline int lab_row_pad(int K) { return K | 1; }
 
+#ifdef DLSM_PIPE_TIMING
+__device__ unsigned long long g_lab_t[4096][6];    // per wavefront: phase stamps (profiles/labels_phases.py)
+#define DLSM_LAB_STAMP(I_, DEP_) { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) : "v"(DEP_)); lts[I_] = t_; }
+#else
+#define DLSM_LAB_STAMP(I_, DEP_)
+#endif
 template <int D, bool WLDS>
 __global__ __launch_bounds__(64 * LAB_WAVES) void k_sample_labels(
     ChainView c, const double *__restrict__ w, uint32_t iter,
@@ -70,6 +76,10 @@ __global__ __launch_bounds__(64 * LAB_WAVES) void k_sample_labels(
     const int KP = WLDS ? lab_row_pad(K) : K;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = blockIdx.x * LAB_WAVES + wave;
+#ifdef DLSM_PIPE_TIMING
+    unsigned long long lts[6] = {0, 0, 0, 0, 0, 0};
+#endif
+    DLSM_LAB_STAMP(0, (double)lane)
     const double *wt = w;                     // row (t, j) at wt + (t K + j) KP
     double *tables = smem;
     if (WLDS) {
@@ -80,6 +90,7 @@ __global__ __launch_bounds__(64 * LAB_WAVES) void k_sample_labels(
         wt = smem;
         tables = smem + (size_t)T * K * KP;
     }
+    DLSM_LAB_STAMP(1, (double)lane)
     double *L = tables + (size_t)wave * 2 * T * K;
     double *pm = L + T * K;
     const bool live = i < N;                  // a whole wave is live or not
@@ -90,6 +101,7 @@ __global__ __launch_bounds__(64 * LAB_WAVES) void k_sample_labels(
         }
     __syncthreads();
     if (!live) return;
+    DLSM_LAB_STAMP(2, (double)lane)
     // the uniform of time t is drawn by lane t (T <= 64 per pass), all times at once
     double u_all = 0.0;
     // Lane k owns component k.  The sums over the components run in index order (as the
@@ -103,19 +115,28 @@ __global__ __launch_bounds__(64 * LAB_WAVES) void k_sample_labels(
         const double *wr = wt + ((size_t)t * K + min(lane, K - 1)) * KP;
         // the lane's row of w, eight LDS reads in flight per trip (one read per term of the
         // chain would pay the LDS latency K times per step); same terms, same order
+        // (no test of k0 + u < K inside a trip: lanes >= K hold pmk = 0, the clamped read is a
+        // finite weight, and adding their product, +0, changes nothing - a branch per term was
+        // most of a step's 1.5 us, profiles/labels_phases.py)
         for (int k0 = 0; k0 < K; k0 += 8) {
             double wv[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) wv[u] = wr[min(k0 + u, K - 1)];
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (k0 + u < K) s += wv[u] * lane_value(pmk, k0 + u);
+            for (int u = 0; u < 8; ++u) s += wv[u] * lane_value(pmk, (k0 + u) & 63);
         }
         double tot = 0.0;
-        for (int r = 0; r < K; ++r) tot += lane_value(s, r);
+        for (int r0 = 0; r0 < K; r0 += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const double v = lane_value(s, (r0 + u) & 63);
+                tot += r0 + u < K ? v : 0.0;
+            }
+        }
         bmk = s / tot;
     }
     if (lane < K) pm[lane] = L[lane] * bmk;
+    DLSM_LAB_STAMP(3, bmk)
     __builtin_amdgcn_s_waitcnt(0xc07f);       // lgkmcnt(0): LDS writes landed
     __builtin_amdgcn_wave_barrier();
     // forward sampling :173-188: the cumulative sum runs in index order and lane k keeps its
@@ -131,15 +152,22 @@ __global__ __launch_bounds__(64 * LAB_WAVES) void k_sample_labels(
         const double u0 = lane_value(u_all, t & 63);
         const double term = lane < K ? wrow[lane] * pm[t * K + lane] : 0.0;
         double cdf = 0.0, mine = 0.0;
-        for (int k = 0; k < K; ++k) {
-            cdf += lane_value(term, k);
-            mine = k == lane ? cdf : mine;
+        for (int k0 = 0; k0 < K; k0 += 8) {            // lanes >= K hold term = 0: no test per k
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                cdf += lane_value(term, (k0 + u) & 63);
+                mine = k0 + u == lane ? cdf : mine;
+            }
         }
         const double u = u0 * cdf;
         const int zt = __popcll(__ballot(lane < K && u > mine));
         if (lane == 0) z_out[(size_t)t * N + i] = zt;
         zprev = zt;
     }
+#ifdef DLSM_PIPE_TIMING
+    DLSM_LAB_STAMP(4, (double)zprev)
+    if (lane == 0 && i < 4096) for (int q = 0; q < 5; ++q) g_lab_t[i][q] = lts[q];
+#endif
 }
 
 // The counts the conjugate updates need (sample_labels.py:176-188): n[0][0][k] initial labels,
