@@ -53,10 +53,16 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # (profiles/micro/valu_rates.hip; one wavefront per SIMD: 4.57 cycles, the 76 % of round 1).
 F64_VALU_PEAK_TFLOPS = 78.6
 F64_VALU_SUSTAINED_FRAC = 0.82
-# float64 vector instructions per dyad term (one distance + one exp(-d) + product
-# bookkeeping at ONE position), counted in the disassembly: DESIGN.md 4.1 / 4.4b
-INSTR_PER_TERM_SWEEP = 29       # k_pipe_step neighbour loop: 58 per neighbour, 2 positions
-INSTR_PER_TERM_LOGLIK = 15      # k_loglik_undirected<2,2>: 30 per dyad with 2 candidates
+# ALGORITHMIC float64 operations per dyad term (one distance + one exp(-d) + product
+# bookkeeping at ONE position): squared distance 4, root to the last bit 7, exp to 1 ulp 17,
+# product update 4, edge sum 2 = 34 (the log-likelihood pass shares the distance and the
+# exponential between its two candidates: 17 per candidate).  FIXED since round 1 so that
+# `roofline.frac` compares between rounds; what the kernels spend today is reported beside it
+# (the table exponential of round 2 brought the neighbour loop to 29, the pass to 15).
+OPS_PER_TERM_SWEEP = 34
+OPS_PER_TERM_LOGLIK = 17
+INSTR_PER_TERM_SWEEP = 29       # k_pipe_step neighbour loop today: 58 per neighbour, 2 positions
+INSTR_PER_TERM_LOGLIK = 15      # k_loglik_undirected<2,2> today: 30 per dyad with 2 candidates
 
 
 def parse(argv=None):
@@ -364,16 +370,20 @@ def sweep_rooflines(chain, a, P, sweep_ms, ll_ms, ms_ev, n_ev, ms_rs, n_rs, post
         tf = terms * instr * 2.0 / (ms * 1e-3) / 1e12
         return round(tf, 3), round(tf / F64_VALU_PEAK_TFLOPS, 4)
 
-    ach, frac = valu(k_terms, INSTR_PER_TERM_SWEEP, k_ms)
+    ach, frac = valu(k_terms, OPS_PER_TERM_SWEEP, k_ms)
+    ach_i, frac_i = valu(k_terms, INSTR_PER_TERM_SWEEP, k_ms)
     roofline = {
         'bound': 'fp64_valu', 'kernel': kname, 'achieved': ach, 'peak': F64_VALU_PEAK_TFLOPS,
         'unit': 'TFLOP/s', 'frac': frac, 'traffic': traffic,
         'us_per_launch': round(1e3 * k_ms, 3), 'launches_per_sweep': launches,
         'dyad_terms_per_launch': round(k_terms, 0),
-        'f64_instr_per_term': INSTR_PER_TERM_SWEEP,
-        'peak_note': 'nominal float64 vector peak (fma = 2 flop; every float64 vector '
-                     'instruction priced as one fma slot); a pure fma stream sustains %.2f of it '
-                     'on this chip' % F64_VALU_SUSTAINED_FRAC,
+        'f64_ops_per_term': OPS_PER_TERM_SWEEP,
+        'f64_instr_per_term_in_kernel': INSTR_PER_TERM_SWEEP,
+        'frac_by_kernel_instructions': frac_i,
+        'peak_note': 'nominal float64 vector peak (fma = 2 flop; the algorithmic operations of a '
+                     'dyad term priced as fma slots: 34, fixed since round 1; the kernel spends '
+                     '29 since the table exponential); a pure fma stream sustains %.2f of the '
+                     'peak at 4 wavefronts per SIMD' % F64_VALU_SUSTAINED_FRAC,
         'frac_of_sustained': round(frac / F64_VALU_SUSTAINED_FRAC, 4),
         'dyad_terms_per_s_sweep': round(sweep_terms / (sweep_ms * 1e-3), 0)}
     ach_b = k_bytes / (k_ms * 1e-3) / 1e9
@@ -386,11 +396,13 @@ def sweep_rooflines(chain, a, P, sweep_ms, ll_ms, ms_ev, n_ev, ms_rs, n_rs, post
                                   if traffic else None),
         'traffic_source': 'profiles/traffic.json (rocprofv3 PMC of this kernel, stored)',
         'sweep_GBps_all_launches': round(sweep_bytes / (sweep_ms * 1e-3) / 1e9, 2)}
-    ach_l, frac_l = valu(ll_terms, INSTR_PER_TERM_LOGLIK, ll_ms)
+    ach_l, frac_l = valu(ll_terms, OPS_PER_TERM_LOGLIK, ll_ms)
     roofline_ll = {
         'bound': 'fp64_valu', 'kernel': 'k_loglik_undirected<2,2>', 'achieved': ach_l,
         'peak': F64_VALU_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': frac_l, 'traffic': ll_traffic,
         'us_per_launch': round(1e3 * ll_ms, 3),
+        'f64_ops_per_term': OPS_PER_TERM_LOGLIK,
+        'f64_instr_per_term_in_kernel': INSTR_PER_TERM_LOGLIK,
         'algorithmic_GBps': round(ll_bytes / (ll_ms * 1e-3) / 1e9, 1),
         'algorithmic_frac_of_hbm': round(ll_bytes / (ll_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
         'frac_of_sustained': round(frac_l / F64_VALU_SUSTAINED_FRAC, 4)}
@@ -408,8 +420,8 @@ def iteration_valu_fraction(ms_per_step, a):
     """the whole iteration against the float64 vector peak: its algorithmic dyad terms
     (sweep + fused evaluation) x their instruction counts / wall time per iteration"""
     T, N = a.T, a.N
-    ops = (2.0 * T * N * (N - 1) * INSTR_PER_TERM_SWEEP +
-           2.0 * T * N * (N - 1) / 2 * INSTR_PER_TERM_LOGLIK) * 2.0
+    ops = (2.0 * T * N * (N - 1) * OPS_PER_TERM_SWEEP +
+           2.0 * T * N * (N - 1) / 2 * OPS_PER_TERM_LOGLIK) * 2.0
     tf = ops / (ms_per_step * 1e-3) / 1e12
     return {'achieved_TFLOPs': round(tf, 3), 'frac': round(tf / F64_VALU_PEAK_TFLOPS, 4),
             'frac_of_sustained': round(tf / F64_VALU_PEAK_TFLOPS / F64_VALU_SUSTAINED_FRAC, 4)}
