@@ -497,7 +497,9 @@ __global__ __launch_bounds__(256) void k_loglik_casecontrol_pf(
     constexpr int NPW = LLCC_NODES / 4;
     constexpr int RW = llcc_record_width(D);
     __shared__ double sRed[4 * M];
+    __shared__ __attribute__((aligned(16))) double sTab[EXPTAB_N];       // tab_exp (device_common.hpp)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    exp_table_fill(sTab, tid);                 // 256 threads: one entry each; barrier below
     const long nodes = (long)c.T * c.N;
     const bool two_radii = M > 1 && cand.radii[M - 1] != cand.radii[0];
     long node[NPW];
@@ -507,14 +509,20 @@ __global__ __launch_bounds__(256) void k_loglik_casecontrol_pf(
         node[r] = ((long)blockIdx.x * NPW + r) * 4 + wave;
         outdeg[r] = node[r] < nodes ? c.degree[node[r] * 2 + 1] : 0;
     }
+    // (the edge row is requested whatever the degree turns out to be - Dout <= 64 slots - and cut
+    // to the degree afterwards: the index loads do not wait for the degree's round trip)
 #pragma unroll
     for (int r = 0; r < NPW; ++r) {
         const bool live = node[r] < nodes;
         const long nn = live ? node[r] : 0;
-        e[r][0] = live && lane < outdeg[r] ? c.out_edges[nn * c.Dout + lane] : -1;
+        e[r][0] = live && lane < c.Dout ? c.out_edges[nn * c.Dout + lane] : -1;
         e[r][1] = live && lane < c.C ? c.ctrl_out[nn * c.C + lane] : -1;
         e[r][2] = live && 64 + lane < c.C ? c.ctrl_out[nn * c.C + 64 + lane] : -1;
     }
+#pragma unroll
+    for (int r = 0; r < NPW; ++r)
+        if (lane >= outdeg[r]) e[r][0] = -1;
+    __syncthreads();                           // sTab visible
 #pragma unroll
     for (int r = 0; r < NPW; ++r) {     // the control list ends at its first -1
         const unsigned long long bad1 = ~__ballot(e[r][1] >= 0);
@@ -575,21 +583,21 @@ __global__ __launch_bounds__(256) void k_loglik_casecontrol_pf(
                 if (s == 0) {               // out edge : directed_likelihoods_fast.pyx:236-247
                     L[m] += eta;
                     if (eta > 130.0) { L[m] -= eta; continue; }       // log(1 + e^eta) = eta there
-                    if (Pe[m] > 1e250) { L[m] -= log(Pe[m]); Pe[m] = 1.0; }
-                    Pe[m] *= 1.0 + fast_exp(fmax(eta, -700.0));
+                    if (Pe[m] > 1e250) { L[m] -= fast_log(Pe[m]); Pe[m] = 1.0; }
+                    Pe[m] *= 1.0 + tab_exp(fmax(eta, -700.0), sTab);
                 } else {                    // control : :250-268
                     if (eta > 130.0) { ctl[m] += eta; continue; }
-                    Pc[m] *= 1.0 + fast_exp(fmax(eta, -700.0));
+                    Pc[m] *= 1.0 + tab_exp(fmax(eta, -700.0), sTab);
                 }
             }
         }
         const double adj = (double)(c.N - outdeg[r] - 1) / (double)nctl[r];
 #pragma unroll
-        for (int m = 0; m < M; ++m) L[m] -= adj * (ctl[m] + log(Pc[m]));
+        for (int m = 0; m < M; ++m) L[m] -= adj * (ctl[m] + fast_log(Pc[m]));
     }
 #pragma unroll
     for (int m = 0; m < M; ++m) {
-        L[m] -= log(Pe[m]);
+        L[m] -= fast_log(Pe[m]);
         double v = wave_sum_all(L[m]);
         if (lane == 0) sRed[wave * M + m] = v;
     }
