@@ -201,7 +201,8 @@ int check_ready_loglik(dlsm_chain *h) {
 // are at device address `d_ic` (and radii r0 / r1); returns the record count.
 template <int DD>
 int launch_loglik_records(dlsm_chain *h, int M, const double *d_ic,
-                          const double *r0, const double *r1, int *nrec_out) {
+                          const double *r0, const double *r1, int *nrec_out,
+                          bool reuse_pack = false) {
     const int nb = ll_blocks(h);
     int rc = ensure_partials(h, (size_t)nb * 4);
     if (rc) return rc;
@@ -226,8 +227,10 @@ int launch_loglik_records(dlsm_chain *h, int M, const double *d_ic,
                 HIPCHK(h, hipMalloc((void **)&h->xr, need * sizeof(double)));
                 h->xr_cap = need;
             }
-            hipLaunchKernelGGL((k_pack_xr<DD>), dim3((unsigned)((nodes + 255) / 256)), dim3(256), 0,
-                               h->stream, h->X, r0, M > 1 ? r1 : r0, (long)nodes, h->N, h->xr);
+            // (reuse_pack: the caller knows positions and radii are those of the pass before)
+            if (!reuse_pack)
+                hipLaunchKernelGGL((k_pack_xr<DD>), dim3((unsigned)((nodes + 255) / 256)), dim3(256), 0,
+                                   h->stream, h->X, r0, M > 1 ? r1 : r0, (long)nodes, h->N, h->xr);
         }
         if (pf && M == 1) hipLaunchKernelGGL((k_loglik_casecontrol_pf<DD, 1>), dim3(nb), dim3(256), 0, h->stream, v, cand, h->xr, h->partials);
         else if (pf) hipLaunchKernelGGL((k_loglik_casecontrol_pf<DD, 2>), dim3(nb), dim3(256), 0, h->stream, v, cand, h->xr, h->partials);
@@ -240,8 +243,8 @@ int launch_loglik_records(dlsm_chain *h, int M, const double *d_ic,
 }
 
 int loglik_records(dlsm_chain *h, int M, const double *d_ic, const double *r0,
-                   const double *r1, int *nrec) {
-    DISPATCH_D(h, h->D, return launch_loglik_records<DD>(h, M, d_ic, r0, r1, nrec));
+                   const double *r1, int *nrec, bool reuse_pack = false) {
+    DISPATCH_D(h, h->D, return launch_loglik_records<DD>(h, M, d_ic, r0, r1, nrec, reuse_pack));
     return DLSM_OK;
 }
 
@@ -1425,15 +1428,17 @@ static int enqueue_lsm_iteration(dlsm_chain *h, int it, bool counter, int procru
         // The sweep moved the positions, so the first step evaluates proposal and current
         // state; after it the current state's log-likelihood is carried (lsm->ll_cur) and the
         // later steps evaluate their proposal only: 4 candidate evaluations, not 6.
+        // (the sum of a pass's records, the accept / reject and the next step's proposal share a
+        // launch; the second pass reuses the packed records of the first: same positions and radii)
+        hipLaunchKernelGGL(k_dir_propose_intercept, dim3(1), dim3(1), 0, h->stream, v, h->lsm,
+                           h->intercept, 0, ir);
         for (int which = 0; which < 2; ++which) {
             const int M = which == 0 ? 2 : 1;
-            hipLaunchKernelGGL(k_dir_propose_intercept, dim3(1), dim3(1), 0, h->stream, v, h->lsm,
-                               h->intercept, which, ir);
-            rc = loglik_records(h, M, h->lsm->cand, h->radii, h->radii, &nrec); if (rc) return rc;
-            hipLaunchKernelGGL(k_reduce_loglik, dim3(1), dim3(256), 0, h->stream, h->partials, nrec,
-                               h->model, M, h->lsm->cand, ll2);
-            hipLaunchKernelGGL(k_dir_accept_intercept, dim3(1), dim3(1), 0, h->stream, ll2, h->lsm,
-                               h->intercept, which, which);
+            rc = loglik_records(h, M, h->lsm->cand, h->radii, h->radii, &nrec, which == 1);
+            if (rc) return rc;
+            hipLaunchKernelGGL(k_dir_reduce_accept_intercept, dim3(1), dim3(256), 0, h->stream,
+                               h->partials, nrec, M, ll2, v, h->lsm, h->intercept, which, which,
+                               which == 0 ? 1 : -1, ir);
         }
         {   // scaled-Dirichlet proposal: records live behind the log-likelihood records
             const int nblk = (h->N + DP_THREADS - 1) / DP_THREADS;

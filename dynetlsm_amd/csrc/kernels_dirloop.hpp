@@ -24,11 +24,10 @@ __device__ __forceinline__ double tune_dirichlet(double step, double rate) {
     return step;
 }
 
-// cand = [proposal pair | current pair] for intercept `which`
-__global__ void k_dir_propose_intercept(ChainView c, LsmDeviceState *lsm,
-                                        const double *__restrict__ intercept, int which,
-                                        IterRef ir) {
-    const uint32_t iter = ir.get();
+// cand = [proposal pair | current pair] for intercept `which` (one thread)
+__device__ __forceinline__ void dir_propose_intercept(const ChainView &c, LsmDeviceState *lsm,
+                                                      const double *__restrict__ intercept,
+                                                      int which, uint32_t iter) {
     double u0, u1, z0, z1;
     philox_uniform2(c.seed, (uint32_t)which, 0, iter, stream_word(c.chain, STREAM_INTERCEPT), u0, u1);
     box_muller(u0, u1, z0, z1);
@@ -40,12 +39,15 @@ __global__ void k_dir_propose_intercept(ChainView c, LsmDeviceState *lsm,
     philox_uniform2(c.seed, (uint32_t)which, 1, iter, stream_word(c.chain, STREAM_INTERCEPT), u0, u1);
     lsm->logu = log(u0);
 }
-
-// ll[0] at the proposal; at the current intercepts ll[1], or - `carried` - the value the
-// previous step of this iteration left in lsm->ll_cur (same positions, same parameters: the
-// pass that would recompute it is skipped)
-__global__ void k_dir_accept_intercept(const double *__restrict__ ll, LsmDeviceState *lsm,
-                                       double *__restrict__ intercept, int which, int carried) {
+__global__ void k_dir_propose_intercept(ChainView c, LsmDeviceState *lsm,
+                                        const double *__restrict__ intercept, int which,
+                                        IterRef ir) {
+    dir_propose_intercept(c, lsm, intercept, which, ir.get());
+}
+// accept / reject of intercept `which` from ll = [at the proposal, at the current pair] (one thread)
+__device__ __forceinline__ void dir_accept_intercept(const double *ll, LsmDeviceState *lsm,
+                                                     double *__restrict__ intercept, int which,
+                                                     int carried) {
     const double prop = lsm->cand[which], cur = lsm->cand[2 + which];
     const double pm = lsm->intercept_prior[which], v = lsm->intercept_var;
     const double ll_cur = carried ? lsm->ll_cur : ll[1];
@@ -59,6 +61,28 @@ __global__ void k_dir_accept_intercept(const double *__restrict__ ll, LsmDeviceS
     metropolis_bookkeeping(st, na, ns, un, lsm->i_tune, lsm->i_tune_interval, accepted);
     lsm->i_step[which] = st; lsm->i_nacc[which] = na; lsm->i_nsteps[which] = ns;
     lsm->i_until[which] = un;
+}
+__global__ void k_dir_accept_intercept(const double *__restrict__ ll, LsmDeviceState *lsm,
+                                       double *__restrict__ intercept, int which, int carried) {
+    dir_accept_intercept(ll, lsm, intercept, which, carried);
+}
+// The iteration's chain around a log-likelihood pass in ONE single-workgroup launch instead of
+// three: the fixed-order sum of the pass's records (k_reduce_loglik), the accept / reject of
+// intercept `which`, and - next_which >= 0 - the proposal of the next intercept step.
+// (kernels_loglik.hpp's reduce_records is in scope: capi.hip includes it first.)
+__global__ __launch_bounds__(256) void k_dir_reduce_accept_intercept(
+    const double *__restrict__ partials, int nrec, int M, double *__restrict__ ll_out, ChainView c,
+    LsmDeviceState *lsm, double *__restrict__ intercept, int which, int carried, int next_which,
+    IterRef ir) {
+    __shared__ double scratch[4 * 256];
+    __shared__ double sums[8];
+    reduce_records(partials, nrec, M, sums, scratch, threadIdx.x);
+    if (threadIdx.x != 0) return;
+    double ll[2] = {sums[0], M > 1 ? sums[1] : 0.0};
+    ll_out[0] = ll[0];
+    if (M > 1) ll_out[1] = ll[1];
+    dir_accept_intercept(ll, lsm, intercept, which, carried);
+    if (next_which >= 0) dir_propose_intercept(c, lsm, intercept, next_which, ir.get());
 }
 
 // Gamma(a, 1) by Marsaglia & Tsang (2000); a < 1 through Gamma(a + 1) U^(1 / a)
