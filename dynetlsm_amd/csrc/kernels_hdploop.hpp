@@ -433,10 +433,37 @@ __device__ __forceinline__ void hdp_gam8_wg(const ChainView &c, const HdpLoopBuf
     hb.scr[HS_GAM8 + lane] = hdp_gamma(g, kind, idx, shape);
 }
 
+#ifdef DLSM_PIPE_TIMING
+// entry / exit stamps (100 MHz) of every workgroup of the six launches behind the label update
+// (profiles/hdp_tail_timing.py)
+__device__ unsigned long long g_hdp_t[6][512][2];
+struct HdpStamp {
+    int kid, blk;
+    __device__ HdpStamp(int kid_) : kid(kid_), blk((int)(blockIdx.x + gridDim.x * blockIdx.y)) {
+        if (threadIdx.x == 0 && blk < 512) {
+            unsigned long long t;
+            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t));
+            g_hdp_t[kid][blk][0] = t;
+        }
+    }
+    __device__ ~HdpStamp() {
+        if (threadIdx.x == 0 && blk < 512) {
+            unsigned long long t;
+            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t));
+            g_hdp_t[kid][blk][1] = t;
+        }
+    }
+};
+#define DLSM_HDP_STAMP(K_) HdpStamp hdp_stamp_(K_);
+#else
+#define DLSM_HDP_STAMP(K_)
+#endif
+
 // what is left for the launch of its own: the blending coefficient (needs the LAMBDA sums), the
 // three gamma variates whose shapes depend on the draws above, the new values
 __global__ __launch_bounds__(HH_THREADS) void k_hdp_hypers(ChainView c, HdpLoopBuf hb,
                                                            HdpDeviceState *hs, IterRef ir) {
+    DLSM_HDP_STAMP(3)
     __shared__ double red[2][HH_THREADS / 64];
     __shared__ double sC[3], sLam;
     const int K = hb.K, T = c.T, D = c.D, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -542,6 +569,7 @@ __global__ __launch_bounds__(HDP_THREADS) void k_hdp_stage1(ChainView c, HdpLoop
                                                             const double *__restrict__ partials,
                                                             int nrec, double *__restrict__ intercept,
                                                             double *__restrict__ trace_ic, IterRef ir) {
+    DLSM_HDP_STAMP(0)
     const int K = hb.K, T = c.T;
     const int n_tab = (T * K * K + HT_WAVES - 1) / HT_WAVES;
     if ((int)blockIdx.x < n_tab) { hdp_tables_wg(c, hb, hs, ir.get(), blockIdx.x); return; }
@@ -559,6 +587,7 @@ __global__ __launch_bounds__(HDP_THREADS) void k_hdp_stage1(ChainView c, HdpLoop
 template <int D>
 __global__ __launch_bounds__(HDP_THREADS) void k_hdp_stage2(ChainView c, HdpLoopBuf hb,
                                                             HdpDeviceState *hs, IterRef ir) {
+    DLSM_HDP_STAMP(1)
     const int K = hb.K;
     if (blockIdx.x == 0) { hdp_globals_wg(c, hb, hs, ir.get()); return; }
     if (blockIdx.x == 1) { hdp_akgrid_wg(c, hb, hs, ir.get()); return; }
@@ -569,6 +598,7 @@ __global__ __launch_bounds__(HDP_THREADS) void k_hdp_stage2(ChainView c, HdpLoop
 template <int D>
 __global__ __launch_bounds__(HDP_THREADS) void k_hdp_stage3(ChainView c, HdpLoopBuf hb,
                                                             const HdpDeviceState *hs, IterRef ir) {
+    DLSM_HDP_STAMP(2)
     extern __shared__ double sGam[];            // K * K + K (the weights' role)
     const int K = hb.K, T = c.T;
     if ((int)blockIdx.x < T - 1) { hdp_weights_wg(c, hb, hs, ir.get(), blockIdx.x + 1, sGam); return; }
@@ -620,6 +650,7 @@ __device__ __forceinline__ double hdp_dirichlet_row(const HdpLoopBuf &hb, const 
 template <int D>
 __global__ __launch_bounds__(HDP_THREADS) void k_hdp_logp_sums(ChainView c, HdpLoopBuf hb,
                                                                const HdpDeviceState *hs) {
+    DLSM_HDP_STAMP(4)
     const int k = blockIdx.x, t = blockIdx.y;
     if (threadIdx.x < 64) {
         const double v = hdp_dirichlet_row(hb, hs, k, t, threadIdx.x);
@@ -639,6 +670,7 @@ __global__ __launch_bounds__(HF_THREADS) void k_hdp_finalize(ChainView c, HdpLoo
                                                              const LsmDeviceState *lsm,
                                                              const double *__restrict__ intercept,
                                                              HdpTrace tr, IterRef ir) {
+    DLSM_HDP_STAMP(5)
     __shared__ double red[2][HF_THREADS / 64];
     const int K = hb.K, T = c.T, tid = threadIdx.x;
     const int it = (int)ir.get();
