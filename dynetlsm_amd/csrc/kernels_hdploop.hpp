@@ -237,18 +237,9 @@ __device__ __forceinline__ void hdp_globals_wg(const ChainView &c, const HdpLoop
     double tot = 0.0;
     for (int k = 0; k < K; ++k) tot += sG[k];
     const double bnew = tid < K ? sG[tid] * (1.0 / tot) : 0.0;
-    __syncthreads();
-    // initial distribution w0 ~ Dirichlet(alpha_init beta + nk[0]) (hdp_lpcm.py:890)
-    if (tid < K) {
-        hb.beta[tid] = bnew;
-        double al = hs->alpha_init * bnew + (double)hb.nk[tid];
-        if (al <= 0.0) al = HDP_SMALL_EPS;
-        sG[tid] = hdp_gamma(g, HK_W0, (uint32_t)tid, al);
-    }
-    __syncthreads();
-    tot = 0.0;
-    for (int k = 0; k < K; ++k) tot += sG[k];
-    if (tid < K) hb.w[tid] = sG[tid] * (1.0 / tot);
+    // (the initial distribution w0, whose gamma draws wait for beta, is drawn in stage 3 beside
+    // the other rows of w: this workgroup is stage 2's long pole, profiles/hdp_tail_timing.py)
+    if (tid < K) hb.beta[tid] = bnew;
     if (tid == 0) {
         double mbt = 0.0, mbp = 0.0, m00 = 0.0;
         for (int k = 0; k < K; ++k) {
@@ -421,8 +412,24 @@ __device__ __forceinline__ void hdp_akgrid_wg(const ChainView &c, const HdpLoopB
 __device__ __forceinline__ void hdp_gam8_wg(const ChainView &c, const HdpLoopBuf &hb,
                                             const HdpDeviceState *hs, uint32_t iter) {
     const int K = hb.K, lane = threadIdx.x;
-    if (lane >= 8) return;
     const HdpRng g = hdp_rng(c, iter);
+    {   // second wavefront: initial distribution w0 ~ Dirichlet(alpha_init beta + nk[0])
+        // (hdp_lpcm.py:890), beta being stage 2's
+        __shared__ double sG0[64];
+        const int j = lane - 64;
+        if (j >= 0 && j < K) {
+            double al = hs->alpha_init * hb.beta[j] + (double)hb.nk[j];
+            if (al <= 0.0) al = HDP_SMALL_EPS;
+            sG0[j] = hdp_gamma(g, HK_W0, (uint32_t)j, al);
+        }
+        __syncthreads();
+        if (j >= 0 && j < K) {
+            double tot = 0.0;
+            for (int k = 0; k < K; ++k) tot += sG0[k];
+            hb.w[j] = sG0[j] * (1.0 / tot);
+        }
+    }
+    if (lane >= 8) return;
     const double nsucc = hs->override_total;
     uint32_t kind = HK_CONC_GAMMA, idx = (uint32_t)(lane & 1);
     double shape = lane == 0 ? hs->gamma + 1.0 : hs->mbar_total;
