@@ -21,6 +21,7 @@
 #include "kernels_spec.hpp"
 #include "kernels_spec_sweep.hpp"
 #include "kernels_spec_pipe.hpp"
+#include "kernels_pipe_persist.hpp"
 #include "kernels_ccpipe.hpp"
 #include "kernels_init.hpp"
 #include "kernels_post.hpp"
@@ -64,6 +65,9 @@ static thread_local std::string g_err;
 
 // A captured iteration freezes pointers and scalars of the chain: anything that changes
 // them drops the graph (it is rebuilt by the next dlsm_lsm_run).
+static int check_pipe_err(dlsm_chain *h);
+static int check_sweep_algo(dlsm_chain *h, int algo);
+
 static void drop_graph(dlsm_chain *h) {
     if (h->graph_exec) hipGraphExecDestroy(h->graph_exec);
     if (h->graph) hipGraphDestroy(h->graph);
@@ -353,7 +357,7 @@ void dlsm_destroy(dlsm_chain *h) {
                     h->lab_nk, h->lab_w, h->spec, h->nctrl, h->stamps, h->lsm, h->trace_X, h->trace_ic,
                     h->trace_logp, h->hops, h->hops_max, h->pipe, h->post_zt, h->post_cooc,
                     h->trace_radii, h->hdp, h->hdp_buf, h->htr_mu, h->htr_sigma, h->htr_beta,
-                    h->htr_w, h->htr_lambda, h->htr_hyper, h->htr_z, h->xr};
+                    h->htr_w, h->htr_lambda, h->htr_hyper, h->htr_z, h->xr, h->pipe_err};
     for (void *p : ptrs) if (p) hipFree(p);
     if (h->hsmall) hipHostFree(h->hsmall);
     if (h->timer0) hipEventDestroy(h->timer0);
@@ -372,7 +376,7 @@ int dlsm_synchronize(dlsm_chain *h) {
     NEED(h, h != nullptr, "null handle");
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    return DLSM_OK;
+    return check_pipe_err(h);
 }
 
 // ---------------------------------------------------------------- network
@@ -941,9 +945,33 @@ static void launch_pipe_step(dlsm_chain *h, const ChainView &v, const PipeBuf &p
     if (h->profiling) h->prof[DLSM_K_SWEEP_EVAL].pending.emplace_back(e0, e1);
 }
 
-// G = batches resolved (and evaluated) per launch: algo 4: 1, algo 6: 2
+// the sticky error word of the persistent sweep (algo 7): a bounded wait ran out of its budget
+static int check_pipe_err(dlsm_chain *h) {
+    if (!h->pipe_err || !h->pipe_err_armed) return DLSM_OK;
+    int32_t e = 0;
+    HIPCHK(h, hipMemcpy(&e, h->pipe_err, sizeof(e), hipMemcpyDeviceToHost));
+    if (e != 0)
+        FAIL(h, DLSM_E_HIP, "persistent sweep (algo 7): a wait inside the launch ran out of its poll "
+             "budget - the chain's state is undefined (device shared with a long-running kernel?); "
+             "use sweep_algo 4");
+    return DLSM_OK;
+}
+
+// algo 7: the whole sweep in one launch (kernels_pipe_persist.hpp); shares algo 4's buffers
+template <int DD, int MODEL>
+static void launch_pipe_persist(dlsm_chain *h, const ChainView &v, const PipeBuf &pb,
+                                const PipeSync &ps, int grid, size_t lds) {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (h->profiling) { hipEventCreate(&e0); hipEventCreate(&e1); }
+    hipExtLaunchKernelGGL((k_pipe_persist<DD, MODEL>), dim3(grid), dim3(PP_THREADS), lds, h->stream,
+                          e0, e1, 0, v, pb, ps);
+    if (h->profiling) h->prof[DLSM_K_SWEEP_EVAL].pending.emplace_back(e0, e1);
+}
+
+// G = batches resolved (and evaluated) per launch: algo 4: 1, algo 6: 2; persist: algo 7 (G = 1)
 template <int DD>
-static int launch_sweep_pipe(dlsm_chain *h, IterRef iter, bool alloc_only = false, int G = 1) {
+static int launch_sweep_pipe(dlsm_chain *h, IterRef iter, bool alloc_only = false, int G = 1,
+                             bool persist = false) {
     const int N = h->N, T = h->T;
     const int nbat = (N + PP_B - 1) / PP_B;
     const bool cc = h->model == DLSM_DIRECTED_CASE_CONTROL;
@@ -963,7 +991,18 @@ static int launch_sweep_pipe(dlsm_chain *h, IterRef iter, bool alloc_only = fals
     const size_t n_h = (size_t)2 * G * T * PP_B * PP_B;
     const size_t n_hx = (size_t)2 * G * T * xr * PP_B;
     const size_t n_acc = even2(((size_t)T * 2 * G * (PP_B + 1) + 1) / 2);   // int32 pairs
-    const size_t need = (n_prop + n_full0 + n_h + n_hx + n_acc + 2) * sizeof(double);
+    // persistent form: ticket counter, resolved[t], done[t][b], one 64-byte line each
+    const int n_sync = persist ? 1 + T + T * nbat : 0;
+    const size_t n_syncd = (size_t)n_sync * PS_STRIDE * sizeof(int32_t) / sizeof(double);
+    const size_t need = (n_prop + n_full0 + n_h + n_hx + n_acc + 2 + n_syncd) * sizeof(double);
+    if (persist) {
+        NEED(h, !cc, "algo 7 is for the exact likelihoods");
+        NEED(h, T + 1 <= h->n_cu, "algo 7 needs a compute unit per slice and one to evaluate");
+        if (!h->pipe_err) {
+            HIPCHK(h, hipMalloc((void **)&h->pipe_err, 64));
+            HIPCHK(h, hipMemset(h->pipe_err, 0, 64));
+        }
+    }
     if (h->pipe_cap < need) {
         if (h->pipe) hipFree(h->pipe);
         h->pipe = nullptr; h->pipe_cap = 0;
@@ -974,11 +1013,18 @@ static int launch_sweep_pipe(dlsm_chain *h, IterRef iter, bool alloc_only = fals
     pb.prop = h->pipe; pb.full0 = pb.prop + n_prop; pb.Hd = pb.full0 + n_full0;
     pb.Hx = pb.Hd + n_h; pb.acc = (int32_t *)(pb.Hx + n_hx);
     pb.consts = pb.Hx + n_hx + n_acc;
+    pb.sync = persist ? (int32_t *)(pb.consts + 2) : nullptr;
+    pb.nsync = n_sync; pb.queue0 = ne_wg;
     pb.parts = parts; pb.nbat = nbat;
     pb.G = G; pb.xr = xr;
     pb.per = ((N + parts - 1) / parts + 63) / 64 * 64;      // parts start on a 64-neighbour boundary
     pb.nctrl = h->nctrl;
     const size_t lds = (size_t)PP_B * PP_B * sizeof(double);
+    // persistent form: the resolvers' diagonal block by rows of PR_LD, the evaluators' exp table
+    // and staged neighbour rows
+    const size_t lds_persist = (size_t)PP_B * PR_LD * sizeof(double);
+    if (persist && ((size_t)EXPTAB_N + (size_t)pb.per * DD) * sizeof(double) > lds_persist)
+        FAIL(h, DLSM_E_LIMIT, "algo 7: a part of %d neighbours does not fit the evaluators' LDS", pb.per);
     auto ku = k_pipe_step<DD, DLSM_UNDIRECTED>;
     auto kl = k_pipe_step<DD, PIPE_UNDIRECTED_LONG>;
     auto kd = k_pipe_step<DD, DLSM_DIRECTED>;
@@ -986,6 +1032,12 @@ static int launch_sweep_pipe(dlsm_chain *h, IterRef iter, bool alloc_only = fals
     auto ku2 = k_pipe_step<DD, DLSM_UNDIRECTED, 2>;
     auto kl2 = k_pipe_step<DD, PIPE_UNDIRECTED_LONG, 2>;
     auto kd2 = k_pipe_step<DD, DLSM_DIRECTED, 2>;
+    auto pu = k_pipe_persist<DD, DLSM_UNDIRECTED>;
+    auto pd = k_pipe_persist<DD, DLSM_DIRECTED>;
+    HIPCHK(h, hipFuncSetAttribute((const void *)pu, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds_persist));
+    HIPCHK(h, hipFuncSetAttribute((const void *)pd, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds_persist));
     HIPCHK(h, hipFuncSetAttribute((const void *)ku2, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds));
     HIPCHK(h, hipFuncSetAttribute((const void *)kl2, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1004,6 +1056,19 @@ static int launch_sweep_pipe(dlsm_chain *h, IterRef iter, bool alloc_only = fals
     ChainView v = h->view();
     hipLaunchKernelGGL((k_pipe_propose<DD>), dim3((N + 255) / 256, T), dim3(256), 0, h->stream, v,
                        pb, iter);
+    if (persist) {
+        PipeSync ps;
+        ps.words = pb.sync; ps.err = h->pipe_err;
+        ps.spin_budget = getenv("DLSM_PERSIST_BUDGET") ? atoi(getenv("DLSM_PERSIST_BUDGET")) : (1 << 20);
+        const int grid = T + ne_wg;
+        if (h->model == DLSM_UNDIRECTED)
+            launch_pipe_persist<DD, DLSM_UNDIRECTED>(h, v, pb, ps, grid, lds_persist);
+        else
+            launch_pipe_persist<DD, DLSM_DIRECTED>(h, v, pb, ps, grid, lds_persist);
+        h->pipe_err_armed = true;
+        HIPCHK(h, hipGetLastError());
+        return DLSM_OK;
+    }
     // launch l: even slices resolve batches G l .. / evaluate G (l + 1) .., odd slices one launch
     // behind; with a single slice (T == 1) the trailing odd-only launch is empty
     const int nlaunch = (nbat + G - 1) / G;
@@ -1128,6 +1193,7 @@ static int launch_sweep(dlsm_chain *h, IterRef iter, int algo, bool alloc_only =
     algo = resolve_sweep_algo(h, algo);
     if (algo == 4) return launch_sweep_pipe<DD>(h, iter, alloc_only);
     if (algo == 6) return launch_sweep_pipe<DD>(h, iter, alloc_only, 2);
+    if (algo == 7) return launch_sweep_pipe<DD>(h, iter, alloc_only, 1, true);
     if (algo == 2) return launch_sweep_spec<DD>(h, iter, 1, alloc_only);
     if (algo == 3)
         return launch_sweep_spec<DD>(h, iter, getenv("DLSM_SPEC_S") ? atoi(getenv("DLSM_SPEC_S")) : 2,
@@ -1159,6 +1225,15 @@ static int launch_sweep(dlsm_chain *h, IterRef iter, int algo, bool alloc_only =
     return DLSM_OK;
 }
 
+// the sweep algorithms a caller may name (dlsm_sweep_positions, the loops' configurations)
+static int check_sweep_algo(dlsm_chain *h, int algo) {
+    NEED(h, algo >= 0 && algo <= 7, "algo must be 0..7");
+    NEED(h, algo != 5 || h->model == DLSM_DIRECTED_CASE_CONTROL, "algo 5 is the case-control sweep");
+    NEED(h, (algo != 6 && algo != 7) || h->model != DLSM_DIRECTED_CASE_CONTROL,
+         "algo 6 and 7 are for the exact likelihoods");
+    return DLSM_OK;
+}
+
 static int check_ready_sweep(dlsm_chain *h) {
     int rc = check_ready_loglik(h); if (rc) return rc;
     NEED(h, h->have_samplers, "samplers not set");
@@ -1176,22 +1251,18 @@ extern "C" {
 
 int dlsm_resolve_sweep_algo(dlsm_chain *h, int algo) {
     NEED(h, h != nullptr, "null handle");
-    NEED(h, algo >= 0 && algo <= 6, "algo must be 0..6");
-    NEED(h, algo != 5 || h->model == DLSM_DIRECTED_CASE_CONTROL, "algo 5 is the case-control sweep");
-    NEED(h, algo != 6 || h->model != DLSM_DIRECTED_CASE_CONTROL, "algo 6 is for the exact likelihoods");
+    int rc = check_sweep_algo(h, algo); if (rc) return rc;
     return resolve_sweep_algo(h, algo);
 }
 
 int dlsm_sweep_positions(dlsm_chain *h, uint32_t iter, int algo) {
     NEED(h, h != nullptr, "null handle");
-    NEED(h, algo >= 0 && algo <= 6, "algo must be 0..6");
-    NEED(h, algo != 5 || h->model == DLSM_DIRECTED_CASE_CONTROL, "algo 5 is the case-control sweep");
-    NEED(h, algo != 6 || h->model != DLSM_DIRECTED_CASE_CONTROL, "algo 6 is for the exact likelihoods");
+    int rc = check_sweep_algo(h, algo); if (rc) return rc;
     HIPCHK(h, hipSetDevice(h->device));
-    int rc = check_ready_sweep(h); if (rc) return rc;
+    rc = check_ready_sweep(h); if (rc) return rc;
     rc = enqueue_sweep(h, IterRef{iter, nullptr}, algo); if (rc) return rc;
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    return DLSM_OK;
+    return check_pipe_err(h);
 }
 
 }  // extern "C"
@@ -1327,6 +1398,7 @@ int dlsm_lsm_configure(dlsm_chain *h, const dlsm_lsm_config *cfg) {
     drop_graph(h);
     NEED(h, cfg->intercept_variance_prior > 0, "intercept_variance_prior must be positive");
     NEED(h, cfg->i_tune_interval > 0, "tune_interval must be positive");
+    { int rc_ = check_sweep_algo(h, cfg->sweep_algo); if (rc_) return rc_; }
     HIPCHK(h, hipSetDevice(h->device));
     LsmDeviceState s;
     memset(&s, 0, sizeof(s));
@@ -1538,6 +1610,7 @@ int dlsm_trace_read(dlsm_chain *h, int first, int count, double *Xs, double *int
     NEED(h, first >= 0 && count >= 0 && first + count <= h->trace_n, "range out of the trace");
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    { int rc_ = check_pipe_err(h); if (rc_) return rc_; }
     const size_t row = (size_t)h->T * h->N * h->D;
     if (Xs) HIPCHK(h, hipMemcpy(Xs, h->trace_X + row * first, row * count * sizeof(double), hipMemcpyDeviceToHost));
     if (intercepts) HIPCHK(h, hipMemcpy(intercepts, h->trace_ic + (size_t)2 * first, sizeof(double) * 2 * count, hipMemcpyDeviceToHost));
@@ -1696,6 +1769,12 @@ extern "C" int dlsm_debug_pipe_timing(unsigned long long *items, unsigned long l
     if (hipDeviceSynchronize() != hipSuccess) return -1;
     if (hipMemcpyFromSymbol(items, HIP_SYMBOL(dlsm::g_pipe_item_t), sizeof(dlsm::g_pipe_item_t)) != hipSuccess) return -2;
     if (hipMemcpyFromSymbol(res, HIP_SYMBOL(dlsm::g_pipe_res_t), sizeof(dlsm::g_pipe_res_t)) != hipSuccess) return -3;
+    return 0;
+}
+extern "C" int dlsm_debug_persist_timing(unsigned long long *res, unsigned long long *ev) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(res, HIP_SYMBOL(dlsm::g_persist_res_t), sizeof(dlsm::g_persist_res_t)) != hipSuccess) return -2;
+    if (hipMemcpyFromSymbol(ev, HIP_SYMBOL(dlsm::g_persist_ev_t), sizeof(dlsm::g_persist_ev_t)) != hipSuccess) return -3;
     return 0;
 }
 extern "C" int dlsm_debug_ccpipe_timing(unsigned long long *res, unsigned long long *items) {

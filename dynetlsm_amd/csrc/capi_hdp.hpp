@@ -103,6 +103,7 @@ int dlsm_hdp_configure(dlsm_chain *h, const dlsm_hdp_config *cfg, const double *
          "variances / tune_interval must be positive");
     NEED(h, cfg->gamma > 0 && cfg->alpha_init > 0 && cfg->alpha > 0 && cfg->kappa >= 0,
          "concentration parameters must be positive");
+    rc = check_sweep_algo(h, cfg->sweep_algo); if (rc) return rc;
     const int T = h->T, K = h->K;
     rc = ensure_label_bufs(h); if (rc) return rc;
     const size_t need = hdp_loop_buf_doubles(h);

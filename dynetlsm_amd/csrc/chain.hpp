@@ -122,6 +122,7 @@ struct dlsm_chain {
     // sweep v2 scratch
     double *spec = nullptr; size_t spec_cap = 0;
     double *pipe = nullptr; size_t pipe_cap = 0;        // pipelined sweep (algo 4) buffers
+    int32_t *pipe_err = nullptr; bool pipe_err_armed = false;   // persistent sweep (algo 7): sticky error word
     int n_cu = 256;
     int32_t *nctrl = nullptr; size_t nctrl_cap = 0;     // valid controls per (t, i, dir)
     bool nctrl_valid = false;

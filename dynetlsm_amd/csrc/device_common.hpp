@@ -74,6 +74,89 @@ __device__ __forceinline__ void box_muller(double u0, double u1, double &z0,
     z1 = r * s;
 }
 
+// ---- cross-workgroup hand-offs inside one launch -----------------------------------------
+// A CU's vector L1 is never refreshed by another CU's stores, and a kernel boundary is the only
+// implicit write-back / invalidate.  Bytes that one workgroup of a persistent launch hands to
+// another are therefore stored write-through and loaded past the L1 (`sc1` on gfx950: agent
+// scope), every one of them, on both sides; the flag or counter that announces them is written
+// after every storing wavefront has drained its stores (s_waitcnt vmcnt(0)) and read by a
+// relaxed sc1 poll (MI355X guide, "inter-workgroup visibility": the sc1 / sc1 hand-off).
+// COH = false gives the plain accesses of the launch-per-batch kernels.
+typedef unsigned int dlsm_u4 __attribute__((ext_vector_type(4)));
+typedef unsigned int dlsm_u2 __attribute__((ext_vector_type(2)));
+constexpr int DLSM_AUX_SC1 = 16;                 // cache-policy bit of the buffer builtins
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t coh_rsrc(const void *base) {
+    // wave-uniform base (forced into scalar registers), byte offsets from the lanes
+    const uint64_t a = (uint64_t)base;
+    const uint64_t u = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) |
+                       (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a);
+    return __builtin_amdgcn_make_buffer_rsrc((void *)u, 0, 0x7fffffff, 0x00020000);
+}
+template <bool COH>
+__device__ __forceinline__ double coh_load(const double *p) {
+    if (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return *p;
+}
+template <bool COH>
+__device__ __forceinline__ void coh_store(double *p, double v) {
+    if (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+__device__ __forceinline__ int32_t coh_load_i32(const int32_t *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void coh_store_i32(int32_t *p, int32_t v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// 16 bytes at base + off (base wave-uniform, off a multiple of 16)
+// (`soff`: a wave-uniform addend that travels in a scalar register, so that the loads of an
+// unrolled loop share ONE per-lane offset register)
+template <bool COH>
+__device__ __forceinline__ double2 coh_load2(const void *base, uint32_t off, uint32_t soff = 0u) {
+    if (COH) {
+        const dlsm_u4 v = __builtin_amdgcn_raw_buffer_load_b128(coh_rsrc(base), (int)off, (int)soff, DLSM_AUX_SC1);
+        return make_double2(__hiloint2double((int)v.y, (int)v.x), __hiloint2double((int)v.w, (int)v.z));
+    }
+    return *(const double2 *)((const char *)base + off + soff);
+}
+template <bool COH>
+__device__ __forceinline__ void coh_store2(void *base, uint32_t off, double2 v) {
+    if (COH) {
+        dlsm_u4 w;
+        w.x = (unsigned)__double2loint(v.x); w.y = (unsigned)__double2hiint(v.x);
+        w.z = (unsigned)__double2loint(v.y); w.w = (unsigned)__double2hiint(v.y);
+        __builtin_amdgcn_raw_buffer_store_b128(w, coh_rsrc(base), (int)off, 0, DLSM_AUX_SC1);
+    } else {
+        *(double2 *)((char *)base + off) = v;
+    }
+}
+// D doubles of one row at base + off (one 16-byte access per pair)
+template <int D, bool COH>
+__device__ __forceinline__ void coh_load_row(const void *base, uint32_t off, double *out) {
+    if (!COH) {
+        const double *src = (const double *)((const char *)base + off);
+#pragma unroll
+        for (int d = 0; d < D; ++d) out[d] = src[d];
+        return;
+    }
+    const __amdgpu_buffer_rsrc_t r = coh_rsrc(base);
+    if (D % 2 == 0) {                   // rows of an even D are 16-byte aligned
+#pragma unroll
+        for (int d = 0; d + 1 < D; d += 2) {
+            const dlsm_u4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(off + 8u * d), 0, DLSM_AUX_SC1);
+            out[d] = __hiloint2double((int)v.y, (int)v.x);
+            out[d + 1] = __hiloint2double((int)v.w, (int)v.z);
+        }
+    } else {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const dlsm_u2 v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)(off + 8u * d), 0, DLSM_AUX_SC1);
+            out[d] = __hiloint2double((int)v.y, (int)v.x);
+        }
+    }
+}
+__device__ __forceinline__ void drain_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 // ---- reductions ------------------------------------------------------------
 // All-lanes reductions of a 64-wide wavefront without LDS traffic: four DPP steps inside
 // each row of 16 lanes (quad_perm xor 1, xor 2, row_half_mirror, row_mirror: after them

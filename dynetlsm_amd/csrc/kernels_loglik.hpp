@@ -653,7 +653,9 @@ __global__ __launch_bounds__(256) void k_reduce_loglik(
 //   random walk : sample_latent_positions.py:132-140
 //   AR mixture  : sample_latent_positions.py:187-199
 // ---------------------------------------------------------------------------
-template <int D>
+// COH: the neighbouring slices' positions were written by other workgroups of the SAME launch
+// (persistent sweep): loaded past the L1 (device_common.hpp)
+template <int D, bool COH = false>
 __device__ __forceinline__ double node_log_prior(const ChainView &c, int t, int j,
                                                  const double *x) {
     const int N = c.N;
@@ -667,14 +669,14 @@ __device__ __forceinline__ double node_log_prior(const ChainView &c, int t, int 
         } else {
             const double *xp = c.X + ((size_t)(t - 1) * N + j) * D;
 #pragma unroll
-            for (int d = 0; d < D; ++d) s += (x[d] - xp[d]) * (x[d] - xp[d]);
+            for (int d = 0; d < D; ++d) { const double df = x[d] - coh_load<COH>(xp + d); s += df * df; }
             lp -= 0.5 * s / c.sigma_sq;
         }
         if (t < c.T - 1) {
             const double *xn = c.X + ((size_t)(t + 1) * N + j) * D;
             s = 0.0;
 #pragma unroll
-            for (int d = 0; d < D; ++d) s += (xn[d] - x[d]) * (xn[d] - x[d]);
+            for (int d = 0; d < D; ++d) { const double df = coh_load<COH>(xn + d) - x[d]; s += df * df; }
             lp -= 0.5 * s / c.sigma_sq;
         }
     } else {
@@ -689,7 +691,7 @@ __device__ __forceinline__ double node_log_prior(const ChainView &c, int t, int 
             const double *xp = c.X + ((size_t)(t - 1) * N + j) * D;
 #pragma unroll
             for (int d = 0; d < D; ++d) {
-                double df = x[d] - (1 - lm) * xp[d] - lm * m[d];
+                double df = x[d] - (1 - lm) * coh_load<COH>(xp + d) - lm * m[d];
                 s += df * df;
             }
         }
@@ -701,7 +703,7 @@ __device__ __forceinline__ double node_log_prior(const ChainView &c, int t, int 
             s = 0.0;
 #pragma unroll
             for (int d = 0; d < D; ++d) {
-                double df = xn[d] - (1 - lm) * x[d] - lm * mn[d];
+                double df = coh_load<COH>(xn + d) - (1 - lm) * x[d] - lm * mn[d];
                 s += df * df;
             }
             lp -= 0.5 * s / c.sigma[zn];

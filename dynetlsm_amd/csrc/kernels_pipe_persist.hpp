@@ -1,0 +1,625 @@
+// Pipelined speculative sweep in ONE launch (algo 7): the roles of k_pipe_step
+// (kernels_spec_pipe.hpp) kept alive for the whole sweep, the kernel boundary between two batches
+// replaced by per-slice flags.
+//
+// The launch-per-batch form pays, 18 times per sweep at T = 10, N = 2000, a dispatch floor and a
+// cold start (wavefront launch, scalar loads, first trip to memory behind the boundary's cache
+// invalidation) - about a third of its 12 us period - and makes every slice wait for the slowest
+// role of every batch.  Here
+//
+//     workgroup t < T          resolves batches 0, 1, .. of slice t, one after the other;
+//     workgroups >= T          evaluate (slice, batch, 16 nodes, part) groups, one item per
+//                              wavefront, drawn in batch order from a ticket counter;
+//
+// and the only waits are the true dependencies of the scheme (header of kernels_spec_pipe.hpp):
+//
+//     eval(t, b)      needs  resolve(t, b - 2)     the positions of batches <= b - 2 are final
+//     resolve(t, b)   needs  eval(t, b) complete   and resolve(t, b - 1): program order
+//     resolve(odd t, b) needs resolve(t +- 1, b)   even-then-odd order of the prior's neighbours
+//
+// Even slices never wait for odd ones, tickets are handed out in dependency order and only to
+// workgroups that are running, so the lowest unfinished ticket always belongs to a running
+// workgroup whose dependencies are complete: the launch makes progress with ANY number of
+// resident evaluator workgroups (a shared device only slows it down).  Every wait is bounded all
+// the same: a poll budget, then a sticky error word that makes every role leave, reported by the
+// host as DLSM_E_HIP.
+//
+// Hand-offs (MI355X guide, inter-workgroup visibility; helpers in device_common.hpp): handed-off
+// bytes are stored and loaded `sc1` on both sides - final positions (resolver -> evaluators and
+// the neighbouring slices' resolvers), (sum, product) records and H factors (evaluators ->
+// resolver).  A resolver announces batch b with one sc1 flag store behind a workgroup barrier that
+// follows every storing wavefront's s_waitcnt vmcnt(0); an evaluator wavefront drains its stores,
+// bumps a counter in LDS, and the wavefront whose bump completes the group adds the group's items
+// to the slice's per-batch counter (agent-scope atomic).  Consumers poll with relaxed sc1 loads
+// from ONE wavefront, the others start behind a workgroup barrier.
+//
+// Decisions are those of algo 4 bit for bit: the items and the fixed-point solve are the same
+// code (pipe_eval_item / pipe_resolve with COH = true), only their scheduling differs.
+#pragma once
+#include "kernels_spec_pipe.hpp"
+
+namespace dlsm {
+
+constexpr int PS_STRIDE = 16;            // int32 words between two flags: one 64-byte line each
+constexpr int PS_KGROUP = PP_WAVES;      // nodes of a ticket: one per wavefront
+constexpr int PS_GROUPS = PP_B / PS_KGROUP;
+
+struct PipeSync {
+    int32_t *words;      // [1 + T + T nbat][PS_STRIDE] : ticket counter, resolved[t], done[t][b]
+    int32_t *err;        // sticky: a wait ran out of its budget
+    int spin_budget;     // polls per wait
+    __device__ __forceinline__ int32_t *queue() const { return words; }
+    __device__ __forceinline__ int32_t *resolved(int t) const { return words + (size_t)(1 + t) * PS_STRIDE; }
+    __device__ __forceinline__ int32_t *done(int T, int nbat, int t, int b) const {
+        return words + (size_t)(1 + T + t * nbat + b) * PS_STRIDE;
+    }
+};
+
+// Called by a whole wavefront: lane i waits for *word >= want (word == nullptr: nothing to wait
+// for).  Relaxed sc1 polls with a sleep in between, bounded.  false = the budget ran out here or
+// elsewhere (the error word is set): the caller leaves the kernel.
+__device__ __forceinline__ bool pipe_wait(const int32_t *word, int want, const PipeSync &ps) {
+    bool ok = word == nullptr;
+    for (int spins = 0;; ++spins) {
+        if (!ok) ok = coh_load_i32(word) >= want;
+        if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) return true;
+        if (spins >= ps.spin_budget) {
+            if (!ok) coh_store_i32(ps.err, 1);
+            return false;
+        }
+        if ((spins & 255) == 255 && coh_load_i32(ps.err) != 0) return false;
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+
+#ifdef DLSM_PIPE_TIMING
+// phase stamps of the persistent launch: resolver t, batch b: {wait start, wait end, resolve end,
+// published}; evaluator workgroup w, round r (its wavefront 0): {round start, poll matched +
+// barrier, item done and drained, ticket, items of the group}
+__device__ unsigned long long g_persist_res_t[32][24][4];
+__device__ unsigned long long g_persist_ev_t[256][24][5];
+__device__ __forceinline__ unsigned long long persist_clock() {
+    unsigned long long t;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t));
+    return t;
+}
+#endif
+
+// ---- the resolver of the persistent launch ------------------------------------------------------
+// pipe_resolve's fixed-point solve (same system, same passes) with its memory side rebuilt for a
+// workgroup that stays on its CU:
+//   * the evaluators file the H factors of batch b as one row of 2 PP_B doubles per node k -
+//     [window nodes | own batch's nodes] - so their stores are contiguous (write-through 8-byte
+//     stores down a column were 245 000 partial-line writes per step) and every load here is a
+//     coalesced 16-byte one;
+//   * the WHOLE cross block comes in with the first burst of loads (16 factors per thread, thread
+//     = (node k, eighth of the window)) and the previous batch's acceptances select among them as
+//     a bit mask held in LDS: no list, and no gather that could only start once that list existed;
+//   * the diagonal block sits in LDS by rows of k with an odd stride, so that the passes' reads
+//     (lane = k, row f fixed) fall into different banks.
+// Decisions are pipe_resolve's up to the order in which a node's cross factors are multiplied.
+constexpr int PR_LD = PP_B + 1;          // LDS row stride of the diagonal block (doubles)
+
+// the product (or, for a node resolved in the log domain, the sum) over the 8 adjacent lanes
+// that share a node: quad_perm xor 1, xor 2, then the half-row mirror
+__device__ __forceinline__ double group8_prod(double v) {
+    v *= dpp_move<0xB1>(v);
+    v *= dpp_move<0x4E>(v);
+    v *= dpp_move<0x141>(v);
+    return v;
+}
+__device__ __forceinline__ double group8_sum(double v) {
+    v += dpp_move<0xB1>(v);
+    v += dpp_move<0x4E>(v);
+    v += dpp_move<0x141>(v);
+    return v;
+}
+
+template <int D>
+__device__ __forceinline__ void persist_resolve(const ChainView &c, const PipeBuf &pb, int b, int t,
+                                                double *sD, double *sPart,
+                                                unsigned long long (*sMask)[2],
+                                                unsigned long long *sMaskPrev, double *sCross,
+                                                unsigned char *sSat
+#ifdef DLSM_PIPE_TIMING
+                                                , int tl
+#endif
+                                                ) {
+    constexpr int PW = 2 * D + 2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef DLSM_PIPE_TIMING
+    unsigned long long ts[5] = {0, 0, 0, 0, 0};
+#endif
+    DLSM_STAMP(0, (double)tid)
+    const int N = c.N;
+    const int j0 = b * PP_B;
+    const int nb = min(PP_B, N - j0);
+    const int bb = b & 1;
+    const int half = wave & 1, part = wave >> 1;
+    const int k = 64 * half + lane;
+    const bool owner = wave < 2;
+    const bool valid = k < nb;
+    const double *H = pb.Hd + ((size_t)bb * c.T + t) * PP_B * (2 * PP_B);
+    // ---- every load of the batch, at once ------------------------------------------------------
+    // cross factors: node kx = tid / 8; trip u: window nodes 16 u + 2 jx, + 1 - the 8 lanes of a
+    // node read one 128-byte line per trip
+    const int kx = tid >> 3, jx = tid & 7;
+    double cr[16];
+    const uint32_t cr_off = (uint32_t)((kx * (2 * PP_B) + 2 * jx) * sizeof(double));
+    if (b > 0) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const double2 v = coh_load2<true>(H, cr_off, (uint32_t)(16 * u * sizeof(double)));
+            cr[2 * u] = v.x; cr[2 * u + 1] = v.y;
+        }
+    }
+    // diagonal block: 16 bytes per thread and trip, a wavefront per row (rows >= nb and columns
+    // >= the row's node were never written: never read either)
+    // (trip u: row 16 u + wave, columns 2 lane, 2 lane + 1)
+    double2 blk[8];
+    const uint32_t blk_off = (uint32_t)((wave * (2 * PP_B) + PP_B + 2 * lane) * sizeof(double));
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+        blk[u] = coh_load2<true>(H, blk_off, (uint32_t)(u * PP_WAVES * (2 * PP_B) * sizeof(double)));
+    double r = 0.0, lu = 0.0, st = 0.0, x1[D], lr = 0.0;
+    bool sat = false;
+    int32_t na = 0, ns = 0, un = 0;
+#pragma unroll
+    for (int d = 0; d < D; ++d) x1[d] = 0.0;
+    if (owner) {
+        const int kc = min(k, nb - 1);
+        const double2 *f = (const double2 *)pb.full0 + ((size_t)bb * c.T + t) * PP_B * pb.parts;
+        const int p1 = pb.parts;
+        // the node's parts, four records in flight at a time (same order of sums and products as
+        // pipe_resolve)
+        double tot = 0.0, pr_ = 1.0;
+        for (int u0 = 0; u0 < p1; u0 += 4) {
+            double2 tv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                tv[u] = coh_load2<true>(f, (uint32_t)((kc * p1 + min(u0 + u, p1 - 1)) * sizeof(double2)));
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (u0 + u == 0) { tot = tv[0].x; pr_ = tv[0].y; }
+                else if (u0 + u < p1) { tot += tv[u].x; pr_ *= tv[u].y; }
+            }
+        }
+        const double *pr = pb.prop + ((size_t)t * N + j0 + kc) * PW;
+        double x0[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) { x1[d] = pr[d]; x0[d] = pr[D + 2 + d]; }
+        // prior terms of the step's logp closure, the neighbouring slices as they are now (the
+        // odd slices wait for the even ones: header)
+        const double prior = node_log_prior<D, true>(c, t, j0 + kc, x1) -
+                             node_log_prior<D, true>(c, t, j0 + kc, x0);
+        const double ek = tot + prior;
+        sat = !(fabs(ek) <= 700.0);
+        r = sat ? 1.0 : exp(ek) * pr_;
+        lu = pr[D];
+        if (sat) { lr = ek + log(pr_); lu = log(lu); }
+        sSat[k] = sat ? 1 : 0;
+        const size_t tjc = (size_t)t * N + j0 + kc;
+        st = c.step[tjc]; na = c.nacc[tjc]; ns = c.nsteps[tjc]; un = c.until[tjc];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        double *dst = sD + (u * PP_WAVES + wave) * PR_LD + 2 * lane;
+        dst[0] = blk[u].x; dst[1] = blk[u].y;
+    }
+    __syncthreads();                                   // sD, sSat (and the previous batch's mask) visible
+    DLSM_STAMP(1, (double)tid)
+    const bool satk = sSat[k] != 0;                    // column k is resolved in the log domain
+    const bool anysat = __ballot(satk) != 0ull;        // (practically never: wave-uniform slow path)
+    if (b > 0) {
+        // the window's accepted nodes among this thread's 16 factors: cr[2 u + i] belongs to node
+        // 16 u + 2 jx + i -> bit 2 u + i of mp
+        const unsigned long long mlo = sMaskPrev[0] >> (2 * jx), mhi = sMaskPrev[1] >> (2 * jx);
+        unsigned int mp = 0u;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            mp |= ((unsigned int)((u < 4 ? mlo : mhi) >> (16 * (u & 3))) & 3u) << (2 * u);
+        const bool satx = sSat[kx] != 0;
+        double v;
+        if (__ballot(satx) == 0ull) {
+            double prod = 1.0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) prod *= (mp >> i) & 1u ? cr[i] : 1.0;
+            v = group8_prod(prod);
+        } else {
+            double prod = 1.0, lsum = 0.0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                if ((mp >> i) & 1u) { if (satx) lsum += log(cr[i]); else prod *= cr[i]; }
+            const double vp = group8_prod(prod), vs = group8_sum(lsum);
+            v = satx ? vs : vp;
+        }
+        if (jx == 0) sCross[kx] = v;
+        __syncthreads();
+        if (owner) { const double vk = sCross[k]; if (sat) lr += vk; else r *= vk; }
+    }
+    if (owner) {
+        const unsigned long long g = __ballot(valid && !(sat ? lu >= lr : lu >= r));
+        if (lane == 0) sMask[0][half] = g;
+    }
+    __syncthreads();
+    DLSM_STAMP(2, (double)tid)
+    int cur = 0;
+    for (int pass = 0; pass < 2 * PP_B + 2; ++pass) {
+        const unsigned long long gm = sMask[cur][part >> 2];
+        unsigned int bits = (unsigned int)(gm >> (16 * (part & 3))) & 0xFFFFu;
+        const int mbase = 16 * part;
+        double sum = 1.0, lsum = 0.0;
+        if (half == 1 || part < 4) {                   // rows >= 64 never touch half 0
+            const double *rowk = sD + k * PR_LD;
+            while (bits) {
+                int f[4];
+                double h[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    f[u] = bits ? mbase + __builtin_ctz(bits) : 1 << 20;
+                    bits &= bits - 1u;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) h[u] = rowk[f[u] < (1 << 20) ? f[u] : 0];
+                if (!anysat) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) sum *= k > f[u] ? h[u] : 1.0;
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (k > f[u]) { if (satk) lsum += log(h[u]); else sum *= h[u]; }
+                }
+            }
+        }
+        sPart[wave * 64 + lane] = satk ? lsum : sum;
+        __syncthreads();
+        if (owner) {
+            double q = sat ? lr : r;
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const double v = sPart[(2 * p + half) * 64 + lane];
+                if (sat) q += v; else q *= v;
+            }
+            const unsigned long long g = __ballot(valid && !(lu >= q));
+            if (lane == 0) sMask[cur ^ 1][half] = g;
+        }
+        __syncthreads();
+        const bool same = sMask[cur ^ 1][0] == sMask[cur][0] &&
+                          sMask[cur ^ 1][1] == sMask[cur][1];
+        cur ^= 1;
+        if (same) break;
+    }
+    DLSM_STAMP(3, (double)cur)
+    if (owner) {
+        const unsigned long long m0 = sMask[cur][0], m1 = sMask[cur][1];
+        const unsigned long long mine = half == 0 ? m0 : m1;
+        const int accepted = (int)((mine >> lane) & 1ull);
+        if (valid) {
+            const size_t tj = (size_t)t * N + j0 + k;
+            if (accepted) {
+#pragma unroll
+                for (int d = 0; d < D; ++d) coh_store<true>(&c.X[tj * D + d], x1[d]);
+            }
+            metropolis_bookkeeping(st, na, ns, un, c.tune, c.tune_interval, accepted);
+            c.step[tj] = st; c.nacc[tj] = na; c.nsteps[tj] = ns; c.until[tj] = un;
+        }
+        // the next batch's window: this batch's acceptances, as a mask
+        if (tid == 0) { sMaskPrev[0] = m0; sMaskPrev[1] = m1; }
+    }
+#ifdef DLSM_PIPE_TIMING
+    DLSM_STAMP(4, (double)cur)
+    if (tid == 0 && tl >= 0 && tl < 24 && t < 32)
+        for (int i = 0; i < 5; ++i) g_pipe_res_t[tl][t][i] = ts[i];
+#endif
+}
+
+// ticket -> (slice t, evaluated batch be, its size nb, group of 16 nodes kg, part p); false when
+// the ticket is past the end or its slice has no batch at that step.  Wave-uniform; quotients
+// through float reciprocals and one fix-up (tickets < 2^20).
+__device__ __forceinline__ bool persist_decode(int ticket, int total, int gps, float inv_gps, int T,
+                                               float inv_T, int nE, int nbat, int N, int &t, int &be,
+                                               int &nb, int &kg, int &p) {
+    int s = (int)(((float)ticket + 0.5f) * inv_gps);
+    s -= (s * gps > ticket); s += ((s + 1) * gps <= ticket);
+    const int g = ticket - s * gps;
+    const int r = g / PS_GROUPS;
+    kg = g - r * PS_GROUPS;
+    p = (int)(((float)r + 0.5f) * inv_T);
+    p -= (p * T > r); p += ((p + 1) * T <= r);
+    const int si = r - p * T;
+    t = si < nE ? 2 * si : 2 * (si - nE) + 1;
+    const int l = s - 1;
+    be = (t & 1) ? l : l + 1;
+    const bool live = ticket < total && be >= 0 && be < nbat;
+    nb = live ? min(PP_B, N - be * PP_B) : 0;
+    return live;
+}
+
+// ---- the evaluator's item with its neighbours staged in LDS ---------------------------------
+// The 16 wavefronts of a round work on 16 nodes of ONE (slice, part): they all need the same
+// `per` neighbour rows.  Read past the L1 by every wavefront (the final positions are handed over
+// inside the launch) those rows cost 16 trips to the L2 each - 3.7 us before the first operands
+// of an item arrived, against 1.3 us in the launch-per-batch kernel, whose wavefronts share them
+// through the L1.  So the workgroup stages them once per round: thread r loads row lo + r - its
+// final position (sc1) when the node's batch is resolved, else the snapshot the propose kernel
+// took (plain) - and the items read them from LDS, one ds_read_b128 per trip at d = 2, with no
+// register prefetch to carry.
+template <int D>
+__device__ __forceinline__ void persist_stage_rows(const ChainView &c, const PipeBuf &pb, int t,
+                                                   int be, int p, double *sX, int tid) {
+    constexpr int PW = 2 * D + 2;
+    const int N = c.N;
+    const int jprev = pipe_window_start(be, 1) * PP_B;       // nodes >= jprev: snapshot positions
+    const int lo = p * pb.per;
+    const int n = min(pb.per, N - lo);
+    const double *Xt = c.X + (size_t)t * N * D;
+    const double *props = pb.prop + (size_t)t * N * PW;
+    // lo and jprev are multiples of 64: a wavefront's 64 rows lie on one side of jprev
+    for (int r = tid; r < n; r += PP_THREADS) {
+        const int i = lo + r;
+        double x[D];
+        if (i >= jprev) {
+            const double *src = props + (size_t)i * PW + D + 2;
+#pragma unroll
+            for (int d = 0; d < D; ++d) x[d] = src[d];
+        } else {
+            coh_load_row<D, true>(Xt, (uint32_t)i * (uint32_t)(D * sizeof(double)), x);
+        }
+#pragma unroll
+        for (int d = 0; d < D; ++d) sX[r * D + d] = x[d];
+    }
+}
+
+template <int D, int MODEL, bool FLUSH, int SQ>
+__device__ __forceinline__ void persist_item_loop(const ChainView &c, int N, int lo, int hi, int jk,
+                                                  int lane, uint32_t yseg, uint32_t ycseg,
+                                                  const uint32_t *yr, const uint32_t *yc,
+                                                  const double *xk0, const double *xk1,
+                                                  const double *sX, const double *etab, double E,
+                                                  double lE, double bin, double bout, double irk,
+                                                  int nflush, double &acc, RatioAcc &ra) {
+    for (int u = 0; lo + 64 * u < hi; ++u) {
+        // trip u: neighbours lo + 64 u + lane; their bits of row jk are words 2u, 2u + 1 of the
+        // segment held across the lanes, read into a scalar pair that is the lane mask of "y = 1"
+        const int base = lo + 64 * u;
+        const int rem = hi - base, self = jk - base;
+        unsigned long long vm = rem >= 64 ? ~0ull : (1ull << rem) - 1ull;
+        if (self >= 0 && self < 64) vm &= ~(1ull << self);
+        const bool in_seg = 2 * u + 1 < 64;
+        const int w = in_seg ? 2 * u : 0;
+        const unsigned long long ym =
+            ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)yseg, w + 1) << 32) |
+            (uint32_t)__builtin_amdgcn_readlane((int)yseg, w);
+        const unsigned long long ycm = MODEL != DLSM_DIRECTED ? 0ull :
+            ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)ycseg, w + 1) << 32) |
+            (uint32_t)__builtin_amdgcn_readlane((int)ycseg, w);
+        const int i = base + lane;
+        const bool yb = in_seg ? __builtin_amdgcn_inverse_ballot_w64(ym) : (bool)bit_of(yr, min(i, N - 1));
+        const bool ycb = MODEL != DLSM_DIRECTED ? false :
+            (in_seg ? __builtin_amdgcn_inverse_ballot_w64(ycm) : (bool)bit_of(yc, min(i, N - 1)));
+        double xi[D];
+        const double *row = sX + (size_t)(64 * u + lane) * D;       // staged up to hi: lanes beyond read
+#pragma unroll                                                         // the table's slack, masked below
+        for (int d = 0; d < D; ++d) xi[d] = row[d];
+        double ri = 1.0;
+        if (MODEL == DLSM_DIRECTED) ri = c.radii[min(i, N - 1)];
+        if (__builtin_amdgcn_inverse_ballot_w64(vm)) {
+            if (MODEL == DLSM_UNDIRECTED) {
+                const double d0 = dist_fast<D>(xi, xk0, SQ);
+                const double d1 = dist_fast<D>(xi, xk1, SQ);
+                ra.lin = fma(yb ? 1.0 : 0.0, d0 - d1, ra.lin);
+                ra.P0 *= fma(E, SQ ? tab_exp_clamped(-d0, etab) : tab_exp(-d0, etab), 1.0);
+                ra.P1 *= fma(E, SQ ? tab_exp_clamped(-d1, etab) : tab_exp(-d1, etab), 1.0);
+                if (FLUSH) if (++ra.cnt >= nflush) ra.flush();
+            } else {
+                const double d0 = dist_fast<D>(xi, xk0, c.squared);
+                const double d1 = dist_fast<D>(xi, xk1, c.squared);
+                const double iri = fast_rcp(ri);
+                pipe_directed_term(ra, acc, d0, d1, (int)yb, (int)ycb, bin * iri + bout * irk,
+                                   bin * irk + bout * iri, E, lE);
+            }
+        }
+    }
+}
+
+// One wavefront: part p of node k of batch `be` in slice t - pipe_eval_item's terms in
+// pipe_eval_item's order (same sums, same products, bit for bit), neighbours from `sX`.
+template <int D, int MODEL>
+__device__ __forceinline__ void persist_eval_item(const ChainView &c, const PipeBuf &pb, int be, int nb,
+                                                  int t, int k, int p, int lane, const double *etab,
+                                                  const double *sX
+#ifdef DLSM_PIPE_TIMING
+                                                  , int tl, int tgw
+#endif
+                                                  ) {
+    constexpr int PW = 2 * D + 2;
+    const int N = c.N, W = c.W;
+#ifdef DLSM_PIPE_TIMING
+    unsigned long long ts[6] = {0, 0, 0, 0, 0, 0};
+#endif
+    DLSM_STAMP(0, (double)lane)
+    const int jk = be * PP_B + k;
+    const double *props = pb.prop + (size_t)t * N * PW;
+    const uint32_t *yr = c.ybits + ((size_t)t * N + jk) * W;
+    const uint32_t *yc = MODEL == DLSM_DIRECTED ? c.ytbits + ((size_t)t * N + jk) * W : nullptr;
+    const double E = pb.consts[0];
+    const int nflush = (int)pb.consts[1];
+    double xk0[D], xk1[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        xk0[d] = props[(size_t)jk * PW + D + 2 + d];
+        xk1[d] = props[(size_t)jk * PW + d];
+    }
+    double bin = 0.0, bout = 0.0, irk = 0.0;
+    if (MODEL == DLSM_DIRECTED) {
+        bin = c.intercept[0]; bout = c.intercept[1];
+        irk = 1.0 / c.radii[jk];
+    }
+    const double lE = bin + bout;
+    const int lo = p * pb.per, hi = min(N, lo + pb.per);
+    const int w0 = lo >> 5;
+    const uint32_t yseg = yr[min(w0 + lane, W - 1)];
+    const uint32_t ycseg = MODEL == DLSM_DIRECTED ? yc[min(w0 + lane, W - 1)] : 0u;
+    double acc = 0.0;
+    RatioAcc ra;
+    const bool noflush = MODEL == DLSM_UNDIRECTED && nflush >= hi - lo && !c.squared;
+    DLSM_STAMP(1, xk0[0])
+    if (noflush)
+        persist_item_loop<D, MODEL, false, 0>(c, N, lo, hi, jk, lane, yseg, ycseg, yr, yc, xk0, xk1, sX,
+                                              etab, E, lE, bin, bout, irk, nflush, acc, ra);
+    else if (c.squared)
+        persist_item_loop<D, MODEL, true, 1>(c, N, lo, hi, jk, lane, yseg, ycseg, yr, yc, xk0, xk1, sX,
+                                             etab, E, lE, bin, bout, irk, nflush, acc, ra);
+    else
+        persist_item_loop<D, MODEL, true, 0>(c, N, lo, hi, jk, lane, yseg, ycseg, yr, yc, xk0, xk1, sX,
+                                             etab, E, lE, bin, bout, irk, nflush, acc, ra);
+    DLSM_STAMP(2, ra.P0)
+    pipe_item_finish<D, MODEL, 1, true>(c, pb, be, nb, t, k, p, lane, etab, acc, ra, noflush
+#ifdef DLSM_PIPE_TIMING
+                                        , ts
+#endif
+                                        );
+#ifdef DLSM_PIPE_TIMING
+    if (lane == 0 && tl >= 0 && tl < 24 && tgw < 4096)
+        for (int i = 0; i < 6; ++i) g_pipe_item_t[tl][tgw][i] = ts[i];
+#endif
+}
+
+template <int D, int MODEL_>
+__global__ __launch_bounds__(PP_THREADS) void k_pipe_persist(ChainView c, PipeBuf pb, PipeSync ps) {
+    constexpr int MODEL = MODEL_ == PIPE_UNDIRECTED_LONG ? DLSM_UNDIRECTED : MODEL_;
+    // resolvers: the diagonal block, PP_B rows of PR_LD; evaluators: exp table + the round's rows
+    extern __shared__ __attribute__((aligned(16))) double pp_sH[];
+    __shared__ double sPart[PP_WAVES * 64];
+    __shared__ double sCross[PP_B];
+    __shared__ unsigned long long sMask[2][2];
+    __shared__ unsigned long long sMaskPrev[2];
+    __shared__ unsigned char sSat[PP_B];
+    __shared__ int sGo[2], sTicket[2], sCnt;
+    const int T = c.T, N = c.N, nbat = pb.nbat;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int last = T > 1 ? nbat : nbat - 1;      // steps l = -1 .. last, as the launches of algo 4
+    // an earlier sweep of this chain gave up: leave (one load per workgroup, so that its
+    // wavefronts agree)
+    if (tid == 0) sGo[1] = coh_load_i32(ps.err) == 0 ? 1 : 0;
+    if (tid == 0) sCnt = 0;
+    __syncthreads();
+    if (!sGo[1]) return;
+    if ((int)blockIdx.x < T) {
+        // ---- resolver of slice t -------------------------------------------------------------
+        const int t = blockIdx.x;
+        for (int l = -1; l <= last; ++l) {
+            const int b = l - (t & 1);
+            if (b < 0 || b >= nbat) continue;
+            const int nb = min(PP_B, N - b * PP_B);
+#ifdef DLSM_PIPE_TIMING
+            unsigned long long ts0 = persist_clock(), ts1 = 0, ts2 = 0;
+#endif
+            if (wave == 0) {
+                const int32_t *word = nullptr;
+                int want = 0;
+                if (lane == 0) { word = ps.done(T, nbat, t, b); want = nb * pb.parts; }
+                else if ((t & 1) && lane == 1) { word = ps.resolved(t - 1); want = b + 1; }
+                else if ((t & 1) && lane == 2 && t + 1 < T) { word = ps.resolved(t + 1); want = b + 1; }
+                const bool ok = pipe_wait(word, want, ps);
+                if (lane == 0) sGo[0] = ok ? 1 : 0;
+            }
+            __syncthreads();
+            if (!sGo[0]) return;
+#ifdef DLSM_PIPE_TIMING
+            ts1 = persist_clock();
+#endif
+            persist_resolve<D>(c, pb, b, t, pp_sH, sPart, sMask, sMaskPrev, sCross, sSat
+#ifdef DLSM_PIPE_TIMING
+                               , b
+#endif
+                               );
+            drain_vmem();                      // this wavefront's position stores have left
+#ifdef DLSM_PIPE_TIMING
+            ts2 = persist_clock();
+#endif
+            __syncthreads();                   // ... every wavefront's; the LDS of this batch is free
+            if (tid == 0) {
+                coh_store_i32(ps.resolved(t), b + 1);
+#ifdef DLSM_PIPE_TIMING
+                if (t < 32 && b < 24) {
+                    g_persist_res_t[t][b][0] = ts0; g_persist_res_t[t][b][1] = ts1;
+                    g_persist_res_t[t][b][2] = ts2; g_persist_res_t[t][b][3] = persist_clock();
+                }
+#endif
+            }
+        }
+        return;
+    }
+    // ---- evaluators ------------------------------------------------------------------------------
+    // ticket -> (step s = l + 1, part p, slice, group of 16 nodes); slices in the order evens, odds
+    if (MODEL == DLSM_UNDIRECTED) exp_table_fill(pp_sH, tid);     // visible behind the first round's barrier
+    const int nE = (T + 1) / 2;
+    const int gps = pb.parts * T * PS_GROUPS;             // tickets per step
+    const int total = (last + 2) * gps;
+    const float inv_gps = 1.0f / (float)gps, inv_T = 1.0f / (float)T;
+    // One barrier per round: wavefront 0 decodes its ticket, requests the next one (it travels
+    // while this one is worked on), polls the slice's flag and posts (ticket, go) in LDS; the
+    // others pick both up behind the barrier.  Slots alternate by round parity.
+    int tk0 = (int)blockIdx.x - T;                         // wavefront 0's copy; the counter starts behind these
+    for (int round = 0;; ++round) {
+        const int par = round & 1;
+        int next = 0;
+#ifdef DLSM_PIPE_TIMING
+        const unsigned long long tsr = persist_clock();
+#endif
+        if (wave == 0) {
+            int t_, be_, nb_, kg_, p_;
+            const bool live = persist_decode(tk0, total, gps, inv_gps, T, inv_T, nE, nbat, N, t_, be_, nb_, kg_, p_);
+            if (lane == 0 && tk0 < total)
+                next = __hip_atomic_fetch_add(ps.queue(), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            bool ok = true;
+            if (live && nb_ > kg_ * PS_KGROUP && be_ >= 2)
+                ok = pipe_wait(lane == 0 ? ps.resolved(t_) : nullptr, be_ - 1, ps);
+            if (lane == 0) { sGo[par] = ok ? 1 : 0; sTicket[par] = tk0; }
+        }
+        __syncthreads();                       // the poll has matched: everyone may load
+        const int ticket = sTicket[par];
+        if (ticket >= total || !sGo[par]) return;
+        int t, be, nb, kg, p;
+        persist_decode(ticket, total, gps, inv_gps, T, inv_T, nE, nbat, N, t, be, nb, kg, p);
+        const int k = kg * PS_KGROUP + wave;
+        const int nvalid = min(max(nb - kg * PS_KGROUP, 0), PS_KGROUP);
+#ifdef DLSM_PIPE_TIMING
+        const unsigned long long ts0 = persist_clock();
+#endif
+        double *sX = pp_sH + EXPTAB_N;         // the round's neighbour rows, behind the exp table
+        if (nvalid > 0) persist_stage_rows<D>(c, pb, t, be, p, sX, tid);
+        __syncthreads();
+        if (k < nb)
+            persist_eval_item<D, MODEL == DLSM_DIRECTED_CASE_CONTROL ? DLSM_DIRECTED : MODEL>(
+                c, pb, be, nb, t, k, p, lane, pp_sH, sX
+#ifdef DLSM_PIPE_TIMING
+                , round, ((int)blockIdx.x - T) * PP_WAVES + wave
+#endif
+                );
+        if (nvalid > 0) {
+            drain_vmem();                      // records and H factors of this wavefront have left
+            if (lane == 0) {
+                const int old = atomicAdd(&sCnt, 1);
+                if ((old & (PP_WAVES - 1)) == PP_WAVES - 1)        // the group's last wavefront
+                    __hip_atomic_fetch_add(ps.done(T, nbat, t, be), nvalid, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+#ifdef DLSM_PIPE_TIMING
+        if (tid == 0 && round < 24) {
+            const int w = (int)blockIdx.x - T;
+            if (w < 256) {
+                g_persist_ev_t[w][round][0] = tsr; g_persist_ev_t[w][round][1] = ts0;
+                g_persist_ev_t[w][round][2] = persist_clock();
+                g_persist_ev_t[w][round][3] = (unsigned long long)ticket;
+                g_persist_ev_t[w][round][4] = (unsigned long long)nvalid;
+            }
+        }
+#endif
+        if (wave == 0) tk0 = __builtin_amdgcn_readfirstlane(next);
+    }
+}
+
+}  // namespace dlsm

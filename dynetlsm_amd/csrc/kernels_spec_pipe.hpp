@@ -60,6 +60,9 @@ struct PipeBuf {
     const int32_t *nctrl;   // case-control: valid controls per (t, i, direction)
     int parts, per, nbat;
     int G, xr;       // batches per launch; rows of an Hx block = (2G - 1) PP_B
+    // persistent form (kernels_pipe_persist.hpp): nsync flag words, one per 64-byte line, zeroed
+    // by the propose kernel; word 0 (the ticket counter) starts at queue0
+    int32_t *sync; int nsync, queue0;
 };
 // first batch of the window of batch b
 __host__ __device__ __forceinline__ int pipe_window_start(int b, int G) {
@@ -78,6 +81,10 @@ __global__ __launch_bounds__(256) void k_pipe_propose(ChainView c, PipeBuf pb, I
                                                     : exp(c.intercept[0] + c.intercept[1]);
         pb.consts[0] = E;
         pb.consts[1] = (double)flush_interval(E);
+    }
+    if (pb.sync) {
+        const int flat = ((int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x) * 256 + (int)threadIdx.x;
+        if (flat < pb.nsync) pb.sync[(size_t)flat * 16] = flat == 0 ? pb.queue0 : 0;
     }
     if (j >= N) return;
     // valid for the whole sweep: X[t, j] and its step size change only at step (t, j)
@@ -181,6 +188,110 @@ __device__ __forceinline__ void pipe_reduce(double s, double a, double b, int la
     ratio = q / dpp_move<0xB1>(q);  // lane 0: prod a / prod b
 }
 
+// The item's tail: wavefront reductions, the (sum, ratio) record, and this lane's share of the
+// batch's H entries.  Shared by the launch-per-batch item (neighbours prefetched from memory) and
+// the persistent launch's item (neighbours staged in LDS, kernels_pipe_persist.hpp).
+template <int D, int MODEL, int G, bool COH>
+__device__ __forceinline__ void pipe_item_finish(const ChainView &c, const PipeBuf &pb, int be, int nb,
+                                                 int t, int k, int p, int lane, const double *etab,
+                                                 double acc, RatioAcc &ra, bool noflush
+#ifdef DLSM_PIPE_TIMING
+                                                 , unsigned long long *ts
+#endif
+                                                 ) {
+    constexpr int PW = 2 * D + 2;
+    const int N = c.N, W = c.W;
+    const int j0 = be * PP_B;
+    const int jprev = pipe_window_start(be, G) * PP_B;
+    const int ncross = j0 - jprev;
+    const int bb = be & (2 * G - 1);
+    const double *props = pb.prop + (size_t)t * N * PW;
+    const double E = pb.consts[0];
+    double bin = 0.0, bout = 0.0;
+    if (MODEL == DLSM_DIRECTED) { bin = c.intercept[0]; bout = c.intercept[1]; }
+    const double lE = bin + bout;
+    const int hround = nb * pb.parts * 64;
+    const int htot = ncross * nb + nb * (nb - 1) / 2;
+    const int hf0 = (k * pb.parts + p) * 64 + lane;
+    double tot_l, tot_r;
+    if (noflush) {
+        // the products of the whole wave stay in range: multiply across lanes
+        pipe_reduce(ra.lin + ra.lg, ra.P0, ra.P1, lane, tot_l, tot_r);
+    } else {
+        acc += ra.value();                       // directed: lin / products and the rare exact terms
+        tot_l = wave_sum_all(acc); tot_r = 1.0;
+    }
+    if (lane == 0) {
+        double2 *f = (double2 *)pb.full0 + (((size_t)bb * c.T + t) * PP_B + k) * pb.parts + p;
+        coh_store2<COH>(f, 0u, make_double2(tot_l, tot_r));
+    }
+    DLSM_STAMP(3, tot_r)
+    // this lane's H entries (see above).  Rows of `props`, the bits and the H blocks are
+    // addressed as 32-bit offsets from scalar bases.
+    const char *yrows = (const char *)(c.ybits + (size_t)t * N * W);
+    const char *ytrows = MODEL == DLSM_DIRECTED ? (const char *)(c.ytbits + (size_t)t * N * W) : nullptr;
+    char *hbase = (char *)(pb.Hd + ((size_t)bb * c.T + t) * PP_B * (COH ? 2 * PP_B : PP_B));
+    const uint32_t hx_off = (uint32_t)((const char *)(pb.Hx + ((size_t)bb * c.T + t) * ((2 * G - 1) * PP_B) * PP_B) -
+                                       (const char *)hbase);                          // one allocation
+    for (int f = hf0; f < htot; f += hround) {
+        int kk, e;
+        pipe_h_decode(f, ncross, nb, kk, e);
+        const int jm_ = jprev + e;                 // jprev + ncross == j0
+        const int jkk = j0 + kk;
+        const double *rowm = (const double *)((const char *)props + __umul24((uint32_t)jm_, (uint32_t)(PW * sizeof(double))));
+        const double *rowk = (const double *)((const char *)props + __umul24((uint32_t)jkk, (uint32_t)(PW * sizeof(double))));
+        double xm0[D], xm1[D], xa0[D], xa1[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            xm0[d] = rowm[D + 2 + d];
+            xm1[d] = rowm[d];
+            xa0[d] = rowk[D + 2 + d];
+            xa1[d] = rowk[d];
+        }
+        const uint32_t woff = ((uint32_t)jkk * (uint32_t)W + ((uint32_t)jm_ >> 5)) * 4u;
+        const int y1 = (int)((*(const uint32_t *)(yrows + woff) >> (jm_ & 31)) & 1u);
+        const bool cross = e < ncross;
+        const int m = cross ? e : e - ncross;
+        const double a0 = dist_fast<D>(xm0, xa0, c.squared);
+        const double a1 = dist_fast<D>(xm0, xa1, c.squared);
+        const double b0 = dist_fast<D>(xm1, xa0, c.squared);
+        const double b1 = dist_fast<D>(xm1, xa1, c.squared);
+#ifdef DLSM_PIPE_TIMING
+        if (f == hf0) { DLSM_STAMP(4, a0 + b1) }
+#endif
+        double h;
+        if (MODEL == DLSM_UNDIRECTED) {
+            const double eb0 = tab_exp_clamped(-b0, etab), ea1 = tab_exp_clamped(-a1, etab);
+            const double eb1 = tab_exp_clamped(-b1, etab), ea0 = tab_exp_clamped(-a0, etab);
+            double num = fma(E, eb0, 1.0) * fma(E, ea1, 1.0);
+            double den = fma(E, eb1, 1.0) * fma(E, ea0, 1.0);
+            // the edge's factor e^{(b0 - b1) - (a0 - a1)} from the four exponentials at hand;
+            // a fifth one only when their product left the normal range (distances > 300)
+            const double fn = eb1 * ea0, fd = eb0 * ea1;
+            const bool tiny = y1 && !(fd > 1e-290);
+            if (y1 && !tiny) { num *= fn; den *= fd; }
+            h = num / den;
+            if (__builtin_amdgcn_ballot_w64(tiny)) { if (tiny) h *= fast_exp((b0 - b1) - (a0 - a1)); }
+        } else {
+            const int y2 = (int)((*(const uint32_t *)(ytrows + woff) >> (jm_ & 31)) & 1u);
+            const double irm = 1.0 / c.radii[jm_], irkk = 1.0 / c.radii[jkk];
+            const double aa = bin * irm + bout * irkk, cc = bin * irkk + bout * irm;
+            RatioAcc rb, rq;
+            double eb = 0.0, eq = 0.0;
+            pipe_directed_term(rb, eb, b0, b1, y1, y2, aa, cc, E, lE);
+            pipe_directed_term(rq, eq, a0, a1, y1, y2, aa, cc, E, lE);
+            // exp(delta(b) - delta(a)) without the logs: the products divide out
+            h = ((rb.P0 * rq.P1) / (rb.P1 * rq.P0)) * exp((rb.lin - rq.lin) + (eb - eq));
+        }
+        if (COH)        // persistent launch: one row of 2 PP_B factors per later node kk - its window's
+                        // nodes, then its own batch's - so that a wavefront's entries are contiguous
+            coh_store<true>((double *)(hbase + (uint32_t)(kk * (2 * PP_B) + (cross ? e : PP_B + m)) * 8u), h);
+        else
+            coh_store<false>((double *)(hbase + ((cross ? hx_off : 0u) + (uint32_t)(m * PP_B + kk) * 8u)), h);
+    }
+    DLSM_STAMP(5, acc)
+}
+
 // trips of 64 neighbours whose operands an undirected item loads up front
 __host__ __device__ constexpr int pipe_prefetch_trips(int D) {
     return D == 1 ? 16 : D == 2 ? 11 : D == 3 ? 7 : 5;
@@ -189,7 +300,9 @@ __host__ __device__ constexpr int pipe_prefetch_trips(int D) {
 // One wavefront: part p of node k of batch `be` in slice t.  TP: the trips beyond the
 // prefetched ones are software-pipelined (directed model; undirected parts longer than the
 // prefetch, where it is worth +3 % - at C2, where everything is prefetched, it costs 1 %).
-template <int D, int MODEL, bool TP, int G>
+// COH: the item runs inside the persistent launch (kernels_pipe_persist.hpp): final positions come
+// from resolver workgroups of the same launch and its records go to them - sc1 accesses.
+template <int D, int MODEL, bool TP, int G, bool COH = false>
 __device__ __forceinline__ void pipe_eval_item(const ChainView &c, const PipeBuf &pb, int be,
                                                int nb, int t, int k, int p, int lane,
                                                const double *etab
@@ -251,9 +364,7 @@ __device__ __forceinline__ void pipe_eval_item(const ChainView &c, const PipeBuf
         const int ic = min(lo + lane + 64 * u, N - 1);
         uint32_t off;
         const char *base = x_source(lo + 64 * u, ic, off);
-        const double *src = (const double *)(base + off);
-#pragma unroll
-        for (int d = 0; d < D; ++d) xpre[u][d] = src[d];
+        coh_load_row<D, COH>(base, off, xpre[u]);
         if (MODEL == DLSM_DIRECTED) rpre[u] = c.radii[ic];
     }
     // H entries of the batch: (node kk, entry e), e < ncross + kk: the previous batch (cross
@@ -315,9 +426,7 @@ __device__ __forceinline__ void pipe_eval_item(const ChainView &c, const PipeBuf
         const int in_ = min(lo + 64 * (U_) + lane, N - 1);                                    \
         uint32_t off_;                                                                        \
         const char *base_src_ = x_source(lo + 64 * (U_), in_, off_);                          \
-        const double *src_ = (const double *)(base_src_ + off_);                              \
-        _Pragma("unroll")                                                                     \
-        for (int d = 0; d < D; ++d) xn[d] = src_[d];                                          \
+        coh_load_row<D, COH>(base_src_, off_, xn);                                            \
         if (MODEL == DLSM_DIRECTED) rn = c.radii[in_];                                        \
     }
 #define DLSM_PIPE_LOOPS(FLUSH_, SQ_)                                                          \
@@ -347,9 +456,7 @@ __device__ __forceinline__ void pipe_eval_item(const ChainView &c, const PipeBuf
             if (!TP) {                                                                        \
                 uint32_t off_;                                                                \
                 const char *base_src_ = x_source(base_, i_, off_);                            \
-                const double *src = (const double *)(base_src_ + off_);                       \
-                _Pragma("unroll")                                                             \
-                for (int d = 0; d < D; ++d) xi[d] = src[d];                                   \
+                coh_load_row<D, COH>(base_src_, off_, xi);                                    \
             }                                                                                 \
             DLSM_PIPE_TERM(xi, yb_, ycb_, ri, FLUSH_, SQ_)                                    \
         }                                                                                     \
@@ -361,80 +468,12 @@ __device__ __forceinline__ void pipe_eval_item(const ChainView &c, const PipeBuf
 #undef DLSM_PIPE_REQUEST
 #undef DLSM_PIPE_MASKS
 #undef DLSM_PIPE_TERM
-    double tot_l, tot_r;
-    if (noflush) {
-        // the products of the whole wave stay in range: multiply across lanes
-        pipe_reduce(ra.lin + ra.lg, ra.P0, ra.P1, lane, tot_l, tot_r);
-    } else {
-        acc += ra.value();                       // directed: lin / products and the rare exact terms
-        tot_l = wave_sum_all(acc); tot_r = 1.0;
-    }
-    if (lane == 0) {
-        double2 *f = (double2 *)pb.full0 + (((size_t)bb * c.T + t) * PP_B + k) * pb.parts + p;
-        *f = make_double2(tot_l, tot_r);
-    }
-    DLSM_STAMP(3, tot_r)
-    // this lane's H entries (see above).  Rows of `props`, the bits and the H blocks are
-    // addressed as 32-bit offsets from scalar bases.
-    const char *yrows = (const char *)(c.ybits + (size_t)t * N * W);
-    const char *ytrows = MODEL == DLSM_DIRECTED ? (const char *)(c.ytbits + (size_t)t * N * W) : nullptr;
-    char *hbase = (char *)(pb.Hd + ((size_t)bb * c.T + t) * PP_B * PP_B);
-    const uint32_t hx_off = (uint32_t)((const char *)(pb.Hx + ((size_t)bb * c.T + t) * ((2 * G - 1) * PP_B) * PP_B) -
-                                       (const char *)hbase);                          // one allocation
-    for (int f = hf0; f < htot; f += hround) {
-        int kk, e;
-        pipe_h_decode(f, ncross, nb, kk, e);
-        const int jm_ = jprev + e;                 // jprev + ncross == j0
-        const int jkk = j0 + kk;
-        const double *rowm = (const double *)((const char *)props + __umul24((uint32_t)jm_, (uint32_t)(PW * sizeof(double))));
-        const double *rowk = (const double *)((const char *)props + __umul24((uint32_t)jkk, (uint32_t)(PW * sizeof(double))));
-        double xm0[D], xm1[D], xa0[D], xa1[D];
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            xm0[d] = rowm[D + 2 + d];
-            xm1[d] = rowm[d];
-            xa0[d] = rowk[D + 2 + d];
-            xa1[d] = rowk[d];
-        }
-        const uint32_t woff = ((uint32_t)jkk * (uint32_t)W + ((uint32_t)jm_ >> 5)) * 4u;
-        const int y1 = (int)((*(const uint32_t *)(yrows + woff) >> (jm_ & 31)) & 1u);
-        const bool cross = e < ncross;
-        const int m = cross ? e : e - ncross;
-        const double a0 = dist_fast<D>(xm0, xa0, c.squared);
-        const double a1 = dist_fast<D>(xm0, xa1, c.squared);
-        const double b0 = dist_fast<D>(xm1, xa0, c.squared);
-        const double b1 = dist_fast<D>(xm1, xa1, c.squared);
+    pipe_item_finish<D, MODEL, G, COH>(c, pb, be, nb, t, k, p, lane, etab, acc, ra, noflush
 #ifdef DLSM_PIPE_TIMING
-        if (f == hf0) { DLSM_STAMP(4, a0 + b1) }
+                                       , ts
 #endif
-        double h;
-        if (MODEL == DLSM_UNDIRECTED) {
-            const double eb0 = tab_exp_clamped(-b0, etab), ea1 = tab_exp_clamped(-a1, etab);
-            const double eb1 = tab_exp_clamped(-b1, etab), ea0 = tab_exp_clamped(-a0, etab);
-            double num = fma(E, eb0, 1.0) * fma(E, ea1, 1.0);
-            double den = fma(E, eb1, 1.0) * fma(E, ea0, 1.0);
-            // the edge's factor e^{(b0 - b1) - (a0 - a1)} from the four exponentials at hand;
-            // a fifth one only when their product left the normal range (distances > 300)
-            const double fn = eb1 * ea0, fd = eb0 * ea1;
-            const bool tiny = y1 && !(fd > 1e-290);
-            if (y1 && !tiny) { num *= fn; den *= fd; }
-            h = num / den;
-            if (__builtin_amdgcn_ballot_w64(tiny)) { if (tiny) h *= fast_exp((b0 - b1) - (a0 - a1)); }
-        } else {
-            const int y2 = (int)((*(const uint32_t *)(ytrows + woff) >> (jm_ & 31)) & 1u);
-            const double irm = 1.0 / c.radii[jm_], irkk = 1.0 / c.radii[jkk];
-            const double aa = bin * irm + bout * irkk, cc = bin * irkk + bout * irm;
-            RatioAcc rb, rq;
-            double eb = 0.0, eq = 0.0;
-            pipe_directed_term(rb, eb, b0, b1, y1, y2, aa, cc, E, lE);
-            pipe_directed_term(rq, eq, a0, a1, y1, y2, aa, cc, E, lE);
-            // exp(delta(b) - delta(a)) without the logs: the products divide out
-            h = ((rb.P0 * rq.P1) / (rb.P1 * rq.P0)) * exp((rb.lin - rq.lin) + (eb - eq));
-        }
-        *(double *)(hbase + ((cross ? hx_off : 0u) + (uint32_t)(m * PP_B + kk) * 8u)) = h;
-    }
+                                       );
 #ifdef DLSM_PIPE_TIMING
-    DLSM_STAMP(5, acc)
     if (lane == 0 && tl >= 0 && tl < 24 && tgw < 4096)
         for (int i = 0; i < 6; ++i) g_pipe_item_t[tl][tgw][i] = ts[i];
 #endif
@@ -547,7 +586,10 @@ __device__ __forceinline__ void pipe_cc_writeout(const ChainView &c, const PipeB
 // acceptances of its window's earlier batches (pipe_window_start) entering through gathered rows
 // of the cross block.  With G > 1 a workgroup resolves G batches one after the other; the list
 // of the batch it has just resolved is in sOwn (own_prev), the others come from memory.
-template <int D, int G>
+// COH: inside the persistent launch - evaluator records and the neighbouring slices' positions
+// are read past the L1, the positions are stored write-through, the previous batch's list lives
+// in LDS only (own_prev).
+template <int D, int G, bool COH = false>
 __device__ __forceinline__ void pipe_resolve(const ChainView &c, const PipeBuf &pb, int b, int t,
                                              double *sH, double *sPart,
                                              unsigned long long (*sMask)[2], int *sPrev,
@@ -582,21 +624,21 @@ __device__ __forceinline__ void pipe_resolve(const ChainView &c, const PipeBuf &
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
         const int q = min(u * PP_THREADS + tid, nb * (PP_B / 2) - 1);
-        blk[u] = *(const double2 *)(Hd + (size_t)(q >> 6) * PP_B + 2 * (q & 63));
+        blk[u] = coh_load2<COH>(Hd, (uint32_t)(((q >> 6) * PP_B + 2 * (q & 63)) * sizeof(double)));
     }
     // their accepted nodes as rows of the cross block: row = 128 (batch - ws) + node
     int cntw[3] = {0, 0, 0};
 #pragma unroll
     for (int w = 0; w < G2 - 1; ++w)
         if (w < nwin) {
-            const bool own = own_prev && ws + w == b - 1;
+            const bool own = COH || (own_prev && ws + w == b - 1);
             cntw[w] = own ? sOwn[0] : acct[(size_t)((ws + w) & (G2 - 1)) * (PP_B + 1)];
         }
     const int nprev = cntw[0] + cntw[1] + cntw[2];
 #pragma unroll
     for (int w = 0; w < G2 - 1; ++w)
         if (w < nwin) {
-            const bool own = own_prev && ws + w == b - 1;
+            const bool own = COH || (own_prev && ws + w == b - 1);
             const int32_t *lst = own ? sOwn : acct + (size_t)((ws + w) & (G2 - 1)) * (PP_B + 1);
             const int off = w == 0 ? 0 : (w == 1 ? cntw[0] : cntw[0] + cntw[1]);
             for (int a = tid; a < cntw[w]; a += PP_THREADS) sPrev[off + a] = w * PP_B + lst[1 + a];
@@ -612,12 +654,12 @@ __device__ __forceinline__ void pipe_resolve(const ChainView &c, const PipeBuf &
     for (int d = 0; d < D; ++d) x1[d] = 0.0;
     if (owner) {
         const int kc = min(k, nb - 1);
-        const double2 *f = (const double2 *)pb.full0 +
-                           (((size_t)bb * c.T + t) * PP_B + kc) * pb.parts;
+        const double2 *f = (const double2 *)pb.full0 + ((size_t)bb * c.T + t) * PP_B * pb.parts;
         const int p1 = pb.parts;
         double2 tv[PP_MAXPARTS];
 #pragma unroll
-        for (int u = 0; u < PP_MAXPARTS; ++u) tv[u] = f[min(u, p1 - 1)];
+        for (int u = 0; u < PP_MAXPARTS; ++u)
+            tv[u] = coh_load2<COH>(f, (uint32_t)((kc * p1 + min(u, p1 - 1)) * sizeof(double2)));
         double tot = tv[0].x, pr_ = tv[0].y;
 #pragma unroll
         for (int u = 1; u < PP_MAXPARTS; ++u) {
@@ -630,8 +672,8 @@ __device__ __forceinline__ void pipe_resolve(const ChainView &c, const PipeBuf &
         for (int d = 0; d < D; ++d) { x1[d] = pr[d]; x0[d] = pr[D + 2 + d]; }
         // prior terms of the step's logp closure, with the neighbouring slices as they
         // are now (see the header: the odd slices run one batch behind)
-        const double prior = node_log_prior<D>(c, t, j0 + kc, x1) -
-                             node_log_prior<D>(c, t, j0 + kc, x0);
+        const double prior = node_log_prior<D, COH>(c, t, j0 + kc, x1) -
+                             node_log_prior<D, COH>(c, t, j0 + kc, x0);
         const double ek = tot + prior;
         sat = !(fabs(ek) <= 700.0);
         r = sat ? 1.0 : exp(ek) * pr_;
@@ -660,14 +702,14 @@ __device__ __forceinline__ void pipe_resolve(const ChainView &c, const PipeBuf &
                 double hh[PP_B / 8];
 #pragma unroll
                 for (int u = 0; u < PP_B / 8; ++u)
-                    hh[u] = colp[(size_t)sPrev[min(base + a + 8 * u, nprev - 1)] * PP_B];
+                    hh[u] = coh_load<COH>(colp + (size_t)sPrev[min(base + a + 8 * u, nprev - 1)] * PP_B);
 #pragma unroll
                 for (int u = 0; u < PP_B / 8; ++u) prod *= base + a + 8 * u < nprev ? hh[u] : 1.0;
             }
         } else {
             double lsum = 0.0;
             for (; a < nprev; a += 8) {
-                const double h = colp[(size_t)sPrev[a] * PP_B];
+                const double h = coh_load<COH>(colp + (size_t)sPrev[a] * PP_B);
                 if (satk) lsum += log(h); else prod *= h;
             }
             if (satk) prod = lsum;
@@ -744,7 +786,7 @@ __device__ __forceinline__ void pipe_resolve(const ChainView &c, const PipeBuf &
             const size_t tj = (size_t)t * N + j0 + k;
             if (accepted) {
 #pragma unroll
-                for (int d = 0; d < D; ++d) c.X[tj * D + d] = x1[d];
+                for (int d = 0; d < D; ++d) coh_store<COH>(&c.X[tj * D + d], x1[d]);
             }
             metropolis_bookkeeping(st, na, ns, un, c.tune, c.tune_interval, accepted);
             c.step[tj] = st; c.nacc[tj] = na; c.nsteps[tj] = ns; c.until[tj] = un;
@@ -754,10 +796,14 @@ __device__ __forceinline__ void pipe_resolve(const ChainView &c, const PipeBuf &
         if (accepted) {
             const int base = half == 0 ? 0 : __popcll(m0);
             const int at = 1 + base + __popcll(mine & ((1ull << lane) - 1ull));
-            accg[at] = k;
+            if (!COH) accg[at] = k;
             sOwn[at] = k;
         }
-        if (tid == 0) { const int cnt = __popcll(m0) + __popcll(m1); accg[0] = cnt; sOwn[0] = cnt; }
+        if (tid == 0) {
+            const int cnt = __popcll(m0) + __popcll(m1);
+            if (!COH) accg[0] = cnt;
+            sOwn[0] = cnt;
+        }
     }
 #ifdef DLSM_PIPE_TIMING
     DLSM_STAMP(4, (double)cur)
