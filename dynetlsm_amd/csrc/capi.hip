@@ -493,6 +493,9 @@ int dlsm_upload_edges(dlsm_chain *h, const int64_t *in_edges, int Din,
         if (a < 0 || a > Din || b < 0 || b > Dout)
             FAIL(h, DLSM_E_DATA, "degree out of range at node %zu", i);
     }
+    // a failed re-upload must not leave new lists behind old strides: the chain has no edges
+    // until all three arrays are in
+    h->have_edges = false;
     int rc = upload_i64_as_i32(h, &h->in_edges, in_edges, TN * Din, 0, h->N, "in_edges");
     if (rc) return rc;
     rc = upload_i64_as_i32(h, &h->out_edges, out_edges, TN * Dout, 0, h->N, "out_edges");
@@ -511,6 +514,8 @@ int dlsm_set_controls(dlsm_chain *h, const int64_t *ctrl_in, const int64_t *ctrl
     NEED(h, h->model == DLSM_DIRECTED_CASE_CONTROL, "not a case-control chain");
     HIPCHK(h, hipSetDevice(h->device));
     const size_t TN = (size_t)h->T * h->N;
+    h->have_controls = false;                       // (as dlsm_upload_edges)
+    h->nctrl_valid = false;
     int rc = upload_i64_as_i32(h, &h->ctrl_in, ctrl_in, TN * C, -1, h->N, "control_nodes_in");
     if (rc) return rc;                              // -1 = padding
     rc = upload_i64_as_i32(h, &h->ctrl_out, ctrl_out, TN * C, -1, h->N, "control_nodes_out");

@@ -156,6 +156,7 @@ int dlsm_hdp_configure(dlsm_chain *h, const dlsm_hdp_config *cfg, const double *
 int dlsm_hdp_get_config(dlsm_chain *h, dlsm_hdp_config *cfg) {
     NEED(h, h && cfg, "null argument");
     NEED(h, h->hdp_configured, "HDP-LPCM loop not configured");
+    NEED(h, h->hdp_K == h->K, "n_components changed since dlsm_hdp_configure: configure again");
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HdpDeviceState s;
@@ -173,6 +174,7 @@ int dlsm_hdp_get_config(dlsm_chain *h, dlsm_hdp_config *cfg) {
 int dlsm_hdp_trace_alloc(dlsm_chain *h, int n_total, double logp0) {
     NEED(h, h && n_total >= 1, "bad argument");
     NEED(h, h->hdp_configured, "configure the HDP-LPCM loop first");
+    NEED(h, h->hdp_K == h->K, "n_components changed since dlsm_hdp_configure: configure again");
     HIPCHK(h, hipSetDevice(h->device));
     int rc = dlsm_trace_alloc(h, n_total, logp0); if (rc) return rc;   // Xs_, intercepts_, logps_
     hdp_free_trace(h);
@@ -250,6 +252,7 @@ int dlsm_hdp_get_aux(dlsm_chain *h, int64_t *m, double *m_bar, int64_t *w_over, 
                      int64_t *nk) {
     NEED(h, h != nullptr, "null handle");
     NEED(h, h->hdp_configured, "HDP-LPCM loop not configured");
+    NEED(h, h->hdp_K == h->K, "n_components changed since dlsm_hdp_configure: configure again");
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     const size_t T = h->T, K = h->K;

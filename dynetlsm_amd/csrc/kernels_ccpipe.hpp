@@ -326,6 +326,12 @@ __device__ __forceinline__ void ccpipe_resolve(const ChainView &c, const CcPipeB
             xm[u] = pb.xidx[p];
             xh[u] = pb.xval[p];
         }
+        // (Each half of the workgroup meets the other at its OWN s_barrier: the halves are whole
+        // wavefronts - `upper` is wave-uniform - and gfx950 counts arrivals per workgroup, not per
+        // instruction address.  One barrier behind the if / else was built: both halves' operands
+        // are then live at one program point, 119 -> 128 VGPRs and 14 spilled, on the kernel's
+        // critical path.  If a compiler ever merges or moves these two, parity tests of algo 5
+        // hang or fail at once.)
         __syncthreads();                               // sPrev visible
         // the previous batch's acceptances, final by now: the node's cross entries in list order
         // (a list longer than the 24 at hand comes sixteen entries per trip, their loads issued

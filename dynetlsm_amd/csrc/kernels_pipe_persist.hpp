@@ -120,7 +120,7 @@ __device__ __forceinline__ void persist_resolve(const ChainView &c, const PipeBu
                                                 double *sD, double *sPart,
                                                 unsigned long long (*sMask)[2],
                                                 unsigned long long *sMaskPrev, double *sCross,
-                                                unsigned char *sSat
+                                                unsigned long long *sSatMask, const double *sTab
 #ifdef DLSM_PIPE_TIMING
                                                 , int tl
 #endif
@@ -161,43 +161,25 @@ __device__ __forceinline__ void persist_resolve(const ChainView &c, const PipeBu
 #pragma unroll
     for (int u = 0; u < 8; ++u)
         blk[u] = coh_load2<true>(H, blk_off, (uint32_t)(u * PP_WAVES * (2 * PP_B) * sizeof(double)));
-    double r = 0.0, lu = 0.0, st = 0.0, x1[D], lr = 0.0;
-    bool sat = false;
+    // the owners' inputs (requested now, used once the blocks above have left their registers)
+    double2 tv[4];
+    double x1[D], x0[D], uk = 1.0, st = 0.0;
     int32_t na = 0, ns = 0, un = 0;
+    const int kc = min(k, nb - 1);
+    const int p1 = pb.parts;
+    const double2 *frec = (const double2 *)pb.full0 + ((size_t)bb * c.T + t) * PP_B * pb.parts;
 #pragma unroll
-    for (int d = 0; d < D; ++d) x1[d] = 0.0;
+    for (int d = 0; d < D; ++d) { x1[d] = 0.0; x0[d] = 0.0; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) tv[u] = make_double2(0.0, 1.0);
     if (owner) {
-        const int kc = min(k, nb - 1);
-        const double2 *f = (const double2 *)pb.full0 + ((size_t)bb * c.T + t) * PP_B * pb.parts;
-        const int p1 = pb.parts;
-        // the node's parts, four records in flight at a time (same order of sums and products as
-        // pipe_resolve)
-        double tot = 0.0, pr_ = 1.0;
-        for (int u0 = 0; u0 < p1; u0 += 4) {
-            double2 tv[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-                tv[u] = coh_load2<true>(f, (uint32_t)((kc * p1 + min(u0 + u, p1 - 1)) * sizeof(double2)));
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (u0 + u == 0) { tot = tv[0].x; pr_ = tv[0].y; }
-                else if (u0 + u < p1) { tot += tv[u].x; pr_ *= tv[u].y; }
-            }
-        }
+        for (int u = 0; u < 4; ++u)
+            tv[u] = coh_load2<true>(frec, (uint32_t)((kc * p1 + min(u, p1 - 1)) * sizeof(double2)));
         const double *pr = pb.prop + ((size_t)t * N + j0 + kc) * PW;
-        double x0[D];
 #pragma unroll
         for (int d = 0; d < D; ++d) { x1[d] = pr[d]; x0[d] = pr[D + 2 + d]; }
-        // prior terms of the step's logp closure, the neighbouring slices as they are now (the
-        // odd slices wait for the even ones: header)
-        const double prior = node_log_prior<D, true>(c, t, j0 + kc, x1) -
-                             node_log_prior<D, true>(c, t, j0 + kc, x0);
-        const double ek = tot + prior;
-        sat = !(fabs(ek) <= 700.0);
-        r = sat ? 1.0 : exp(ek) * pr_;
-        lu = pr[D];
-        if (sat) { lr = ek + log(pr_); lu = log(lu); }
-        sSat[k] = sat ? 1 : 0;
+        uk = pr[D];
         const size_t tjc = (size_t)t * N + j0 + kc;
         st = c.step[tjc]; na = c.nacc[tjc]; ns = c.nsteps[tjc]; un = c.until[tjc];
     }
@@ -206,38 +188,72 @@ __device__ __forceinline__ void persist_resolve(const ChainView &c, const PipeBu
         double *dst = sD + (u * PP_WAVES + wave) * PR_LD + 2 * lane;
         dst[0] = blk[u].x; dst[1] = blk[u].y;
     }
-    __syncthreads();                                   // sD, sSat (and the previous batch's mask) visible
-    DLSM_STAMP(1, (double)tid)
-    const bool satk = sSat[k] != 0;                    // column k is resolved in the log domain
-    const bool anysat = __ballot(satk) != 0ull;        // (practically never: wave-uniform slow path)
+    // the window's accepted nodes among this thread's 16 factors: cr[2 u + i] belongs to node
+    // 16 u + 2 jx + i -> bit 2 u + i of mp.  Multiplicative domain; a node that turns out to be
+    // resolved in the log domain (below) redoes its part from memory.
+    unsigned int mp = 0u;
     if (b > 0) {
-        // the window's accepted nodes among this thread's 16 factors: cr[2 u + i] belongs to node
-        // 16 u + 2 jx + i -> bit 2 u + i of mp
         const unsigned long long mlo = sMaskPrev[0] >> (2 * jx), mhi = sMaskPrev[1] >> (2 * jx);
-        unsigned int mp = 0u;
 #pragma unroll
         for (int u = 0; u < 8; ++u)
             mp |= ((unsigned int)((u < 4 ? mlo : mhi) >> (16 * (u & 3))) & 3u) << (2 * u);
-        const bool satx = sSat[kx] != 0;
-        double v;
-        if (__ballot(satx) == 0ull) {
-            double prod = 1.0;
+        double prod = 1.0;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) prod *= (mp >> i) & 1u ? cr[i] : 1.0;
-            v = group8_prod(prod);
-        } else {
-            double prod = 1.0, lsum = 0.0;
-#pragma unroll
-            for (int i = 0; i < 16; ++i)
-                if ((mp >> i) & 1u) { if (satx) lsum += log(cr[i]); else prod *= cr[i]; }
-            const double vp = group8_prod(prod), vs = group8_sum(lsum);
-            v = satx ? vs : vp;
-        }
+        for (int i = 0; i < 16; ++i) prod *= (mp >> i) & 1u ? cr[i] : 1.0;
+        const double v = group8_prod(prod);
         if (jx == 0) sCross[kx] = v;
+    }
+    // multiplicative domain: r = exp(log-ratio of node k), lu = its uniform draw.  A node whose
+    // log-ratio is beyond +-700 (exp would saturate) is resolved in the log domain instead
+    // (pipe_resolve)
+    double r = 0.0, lu = 0.0, lr = 0.0;
+    bool sat = false;
+    if (owner) {
+        double tot = tv[0].x, pr_ = tv[0].y;
+#pragma unroll
+        for (int u = 1; u < 4; ++u)
+            if (u < p1) { tot += tv[u].x; pr_ *= tv[u].y; }
+        for (int u = 4; u < p1; ++u) {                 // more than four parts (short slices, many CUs)
+            const double2 w = coh_load2<true>(frec, (uint32_t)((kc * p1 + u) * sizeof(double2)));
+            tot += w.x; pr_ *= w.y;
+        }
+        // prior terms of the step's logp closure, the neighbouring slices as they are now (the
+        // odd slices wait for the even ones: header)
+        const double prior = node_log_prior<D, true>(c, t, j0 + kc, x1) -
+                             node_log_prior<D, true>(c, t, j0 + kc, x0);
+        const double ek = tot + prior;
+        sat = !(fabs(ek) <= 700.0);
+        // (the table exponential: the compiler's exp() keeps a dozen float64 constants alive through
+        // the whole batch loop, in registers the blocks above need - it spilled them)
+        r = sat ? 1.0 : tab_exp(sat ? 0.0 : ek, sTab) * pr_;
+        lu = uk;
+        if (sat) { lr = ek + log(pr_); lu = log(lu); }
+        const unsigned long long sm = __ballot(sat);
+        if (lane == 0) sSatMask[half] = sm;
+    }
+    __syncthreads();                                   // sD, sCross, sSatMask visible
+    DLSM_STAMP(1, (double)tid)
+    const unsigned long long sat0 = sSatMask[0], sat1 = sSatMask[1];
+    const bool anysat = (sat0 | sat1) != 0ull;         // workgroup-uniform; practically never
+    const bool satk = (((half ? sat1 : sat0) >> lane) & 1ull) != 0ull;
+    if (anysat && b > 0) {
+        // slow path: the log-domain nodes' cross terms as sums of logs
+        const bool satx = ((((kx >> 6) ? sat1 : sat0) >> (kx & 63)) & 1ull) != 0ull;
+        if (__ballot(satx) != 0ull) {
+            double lsum = 0.0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const double2 v = coh_load2<true>(H, cr_off, (uint32_t)(16 * u * sizeof(double)));
+                if (satx && ((mp >> (2 * u)) & 1u)) lsum += log(v.x);
+                if (satx && ((mp >> (2 * u + 1)) & 1u)) lsum += log(v.y);
+            }
+            const double vs = group8_sum(lsum);
+            if (satx && jx == 0) sCross[kx] = vs;
+        }
         __syncthreads();
-        if (owner) { const double vk = sCross[k]; if (sat) lr += vk; else r *= vk; }
     }
     if (owner) {
+        if (b > 0) { const double vk = sCross[k]; if (sat) lr += vk; else r *= vk; }
         const unsigned long long g = __ballot(valid && !(sat ? lu >= lr : lu >= r));
         if (lane == 0) sMask[0][half] = g;
     }
@@ -342,8 +358,8 @@ __device__ __forceinline__ bool persist_decode(int ticket, int total, int gps, f
 // of an item arrived, against 1.3 us in the launch-per-batch kernel, whose wavefronts share them
 // through the L1.  So the workgroup stages them once per round: thread r loads row lo + r - its
 // final position (sc1) when the node's batch is resolved, else the snapshot the propose kernel
-// took (plain) - and the items read them from LDS, one ds_read_b128 per trip at d = 2, with no
-// register prefetch to carry.
+// took (plain) - and the items (pipe_eval_item with LDSX) read them from LDS, one ds_read_b128 per
+// trip at d = 2.
 template <int D>
 __device__ __forceinline__ void persist_stage_rows(const ChainView &c, const PipeBuf &pb, int t,
                                                    int be, int p, double *sX, int tid) {
@@ -370,121 +386,6 @@ __device__ __forceinline__ void persist_stage_rows(const ChainView &c, const Pip
     }
 }
 
-template <int D, int MODEL, bool FLUSH, int SQ>
-__device__ __forceinline__ void persist_item_loop(const ChainView &c, int N, int lo, int hi, int jk,
-                                                  int lane, uint32_t yseg, uint32_t ycseg,
-                                                  const uint32_t *yr, const uint32_t *yc,
-                                                  const double *xk0, const double *xk1,
-                                                  const double *sX, const double *etab, double E,
-                                                  double lE, double bin, double bout, double irk,
-                                                  int nflush, double &acc, RatioAcc &ra) {
-    for (int u = 0; lo + 64 * u < hi; ++u) {
-        // trip u: neighbours lo + 64 u + lane; their bits of row jk are words 2u, 2u + 1 of the
-        // segment held across the lanes, read into a scalar pair that is the lane mask of "y = 1"
-        const int base = lo + 64 * u;
-        const int rem = hi - base, self = jk - base;
-        unsigned long long vm = rem >= 64 ? ~0ull : (1ull << rem) - 1ull;
-        if (self >= 0 && self < 64) vm &= ~(1ull << self);
-        const bool in_seg = 2 * u + 1 < 64;
-        const int w = in_seg ? 2 * u : 0;
-        const unsigned long long ym =
-            ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)yseg, w + 1) << 32) |
-            (uint32_t)__builtin_amdgcn_readlane((int)yseg, w);
-        const unsigned long long ycm = MODEL != DLSM_DIRECTED ? 0ull :
-            ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)ycseg, w + 1) << 32) |
-            (uint32_t)__builtin_amdgcn_readlane((int)ycseg, w);
-        const int i = base + lane;
-        const bool yb = in_seg ? __builtin_amdgcn_inverse_ballot_w64(ym) : (bool)bit_of(yr, min(i, N - 1));
-        const bool ycb = MODEL != DLSM_DIRECTED ? false :
-            (in_seg ? __builtin_amdgcn_inverse_ballot_w64(ycm) : (bool)bit_of(yc, min(i, N - 1)));
-        double xi[D];
-        const double *row = sX + (size_t)(64 * u + lane) * D;       // staged up to hi: lanes beyond read
-#pragma unroll                                                         // the table's slack, masked below
-        for (int d = 0; d < D; ++d) xi[d] = row[d];
-        double ri = 1.0;
-        if (MODEL == DLSM_DIRECTED) ri = c.radii[min(i, N - 1)];
-        if (__builtin_amdgcn_inverse_ballot_w64(vm)) {
-            if (MODEL == DLSM_UNDIRECTED) {
-                const double d0 = dist_fast<D>(xi, xk0, SQ);
-                const double d1 = dist_fast<D>(xi, xk1, SQ);
-                ra.lin = fma(yb ? 1.0 : 0.0, d0 - d1, ra.lin);
-                ra.P0 *= fma(E, SQ ? tab_exp_clamped(-d0, etab) : tab_exp(-d0, etab), 1.0);
-                ra.P1 *= fma(E, SQ ? tab_exp_clamped(-d1, etab) : tab_exp(-d1, etab), 1.0);
-                if (FLUSH) if (++ra.cnt >= nflush) ra.flush();
-            } else {
-                const double d0 = dist_fast<D>(xi, xk0, c.squared);
-                const double d1 = dist_fast<D>(xi, xk1, c.squared);
-                const double iri = fast_rcp(ri);
-                pipe_directed_term(ra, acc, d0, d1, (int)yb, (int)ycb, bin * iri + bout * irk,
-                                   bin * irk + bout * iri, E, lE);
-            }
-        }
-    }
-}
-
-// One wavefront: part p of node k of batch `be` in slice t - pipe_eval_item's terms in
-// pipe_eval_item's order (same sums, same products, bit for bit), neighbours from `sX`.
-template <int D, int MODEL>
-__device__ __forceinline__ void persist_eval_item(const ChainView &c, const PipeBuf &pb, int be, int nb,
-                                                  int t, int k, int p, int lane, const double *etab,
-                                                  const double *sX
-#ifdef DLSM_PIPE_TIMING
-                                                  , int tl, int tgw
-#endif
-                                                  ) {
-    constexpr int PW = 2 * D + 2;
-    const int N = c.N, W = c.W;
-#ifdef DLSM_PIPE_TIMING
-    unsigned long long ts[6] = {0, 0, 0, 0, 0, 0};
-#endif
-    DLSM_STAMP(0, (double)lane)
-    const int jk = be * PP_B + k;
-    const double *props = pb.prop + (size_t)t * N * PW;
-    const uint32_t *yr = c.ybits + ((size_t)t * N + jk) * W;
-    const uint32_t *yc = MODEL == DLSM_DIRECTED ? c.ytbits + ((size_t)t * N + jk) * W : nullptr;
-    const double E = pb.consts[0];
-    const int nflush = (int)pb.consts[1];
-    double xk0[D], xk1[D];
-#pragma unroll
-    for (int d = 0; d < D; ++d) {
-        xk0[d] = props[(size_t)jk * PW + D + 2 + d];
-        xk1[d] = props[(size_t)jk * PW + d];
-    }
-    double bin = 0.0, bout = 0.0, irk = 0.0;
-    if (MODEL == DLSM_DIRECTED) {
-        bin = c.intercept[0]; bout = c.intercept[1];
-        irk = 1.0 / c.radii[jk];
-    }
-    const double lE = bin + bout;
-    const int lo = p * pb.per, hi = min(N, lo + pb.per);
-    const int w0 = lo >> 5;
-    const uint32_t yseg = yr[min(w0 + lane, W - 1)];
-    const uint32_t ycseg = MODEL == DLSM_DIRECTED ? yc[min(w0 + lane, W - 1)] : 0u;
-    double acc = 0.0;
-    RatioAcc ra;
-    const bool noflush = MODEL == DLSM_UNDIRECTED && nflush >= hi - lo && !c.squared;
-    DLSM_STAMP(1, xk0[0])
-    if (noflush)
-        persist_item_loop<D, MODEL, false, 0>(c, N, lo, hi, jk, lane, yseg, ycseg, yr, yc, xk0, xk1, sX,
-                                              etab, E, lE, bin, bout, irk, nflush, acc, ra);
-    else if (c.squared)
-        persist_item_loop<D, MODEL, true, 1>(c, N, lo, hi, jk, lane, yseg, ycseg, yr, yc, xk0, xk1, sX,
-                                             etab, E, lE, bin, bout, irk, nflush, acc, ra);
-    else
-        persist_item_loop<D, MODEL, true, 0>(c, N, lo, hi, jk, lane, yseg, ycseg, yr, yc, xk0, xk1, sX,
-                                             etab, E, lE, bin, bout, irk, nflush, acc, ra);
-    DLSM_STAMP(2, ra.P0)
-    pipe_item_finish<D, MODEL, 1, true>(c, pb, be, nb, t, k, p, lane, etab, acc, ra, noflush
-#ifdef DLSM_PIPE_TIMING
-                                        , ts
-#endif
-                                        );
-#ifdef DLSM_PIPE_TIMING
-    if (lane == 0 && tl >= 0 && tl < 24 && tgw < 4096)
-        for (int i = 0; i < 6; ++i) g_pipe_item_t[tl][tgw][i] = ts[i];
-#endif
-}
-
 template <int D, int MODEL_>
 __global__ __launch_bounds__(PP_THREADS) void k_pipe_persist(ChainView c, PipeBuf pb, PipeSync ps) {
     constexpr int MODEL = MODEL_ == PIPE_UNDIRECTED_LONG ? DLSM_UNDIRECTED : MODEL_;
@@ -494,7 +395,8 @@ __global__ __launch_bounds__(PP_THREADS) void k_pipe_persist(ChainView c, PipeBu
     __shared__ double sCross[PP_B];
     __shared__ unsigned long long sMask[2][2];
     __shared__ unsigned long long sMaskPrev[2];
-    __shared__ unsigned char sSat[PP_B];
+    __shared__ unsigned long long sSatMask[2];
+    __shared__ double sTab[EXPTAB_N];                  // the resolvers' exp table (the evaluators' is in pp_sH)
     __shared__ int sGo[2], sTicket[2], sCnt;
     const int T = c.T, N = c.N, nbat = pb.nbat;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -503,6 +405,7 @@ __global__ __launch_bounds__(PP_THREADS) void k_pipe_persist(ChainView c, PipeBu
     // wavefronts agree)
     if (tid == 0) sGo[1] = coh_load_i32(ps.err) == 0 ? 1 : 0;
     if (tid == 0) sCnt = 0;
+    if ((int)blockIdx.x < T) exp_table_fill(sTab, tid);
     __syncthreads();
     if (!sGo[1]) return;
     if ((int)blockIdx.x < T) {
@@ -529,7 +432,7 @@ __global__ __launch_bounds__(PP_THREADS) void k_pipe_persist(ChainView c, PipeBu
 #ifdef DLSM_PIPE_TIMING
             ts1 = persist_clock();
 #endif
-            persist_resolve<D>(c, pb, b, t, pp_sH, sPart, sMask, sMaskPrev, sCross, sSat
+            persist_resolve<D>(c, pb, b, t, pp_sH, sPart, sMask, sMaskPrev, sCross, sSatMask, sTab
 #ifdef DLSM_PIPE_TIMING
                                , b
 #endif
@@ -558,9 +461,16 @@ __global__ __launch_bounds__(PP_THREADS) void k_pipe_persist(ChainView c, PipeBu
     const int gps = pb.parts * T * PS_GROUPS;             // tickets per step
     const int total = (last + 2) * gps;
     const float inv_gps = 1.0f / (float)gps, inv_T = 1.0f / (float)T;
-    // One barrier per round: wavefront 0 decodes its ticket, requests the next one (it travels
-    // while this one is worked on), polls the slice's flag and posts (ticket, go) in LDS; the
-    // others pick both up behind the barrier.  Slots alternate by round parity.
+    // A round: wavefront 0 decodes its ticket, requests the next one (it travels while this one is
+    // worked on), polls the slice's flag and posts (ticket, go) in LDS; behind the barrier the
+    // workgroup stages the part's neighbour rows, behind a second one the items run.  Slots
+    // alternate by round parity.
+    // (Requesting everything that does not depend on the awaited batch - the item's prologue, the
+    // operands of its first H entry, the rows of the other batches - BEFORE the poll matched was
+    // built and measured: it puts those loads on top of the resolvers' bandwidth-bound block loads
+    // and lost 10 %: profiles/r03_persist_notes.md.)
+    double *sX = pp_sH + EXPTAB_N;                         // the round's neighbour rows, behind the exp table
+    constexpr int IM = MODEL == DLSM_DIRECTED_CASE_CONTROL ? DLSM_DIRECTED : MODEL;
     int tk0 = (int)blockIdx.x - T;                         // wavefront 0's copy; the counter starts behind these
     for (int round = 0;; ++round) {
         const int par = round & 1;
@@ -588,16 +498,18 @@ __global__ __launch_bounds__(PP_THREADS) void k_pipe_persist(ChainView c, PipeBu
 #ifdef DLSM_PIPE_TIMING
         const unsigned long long ts0 = persist_clock();
 #endif
-        double *sX = pp_sH + EXPTAB_N;         // the round's neighbour rows, behind the exp table
         if (nvalid > 0) persist_stage_rows<D>(c, pb, t, be, p, sX, tid);
         __syncthreads();
-        if (k < nb)
-            persist_eval_item<D, MODEL == DLSM_DIRECTED_CASE_CONTROL ? DLSM_DIRECTED : MODEL>(
-                c, pb, be, nb, t, k, p, lane, pp_sH, sX
+        if (k < nb) {
+            PipeItemPre<D> pre;
+            PipeHPre<D> nohp;                  // (unused: HPF = false)
+            pipe_item_prologue<D, IM>(c, pb, be, t, k, p, lane, pre);
+            pipe_eval_item<D, IM, false, 1, true, true>(c, pb, be, nb, t, k, p, lane, pp_sH, sX, pre, nohp
 #ifdef DLSM_PIPE_TIMING
                 , round, ((int)blockIdx.x - T) * PP_WAVES + wave
 #endif
                 );
+        }
         if (nvalid > 0) {
             drain_vmem();                      // records and H factors of this wavefront have left
             if (lane == 0) {

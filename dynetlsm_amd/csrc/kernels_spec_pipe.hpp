@@ -188,13 +188,65 @@ __device__ __forceinline__ void pipe_reduce(double s, double a, double b, int la
     ratio = q / dpp_move<0xB1>(q);  // lane 0: prod a / prod b
 }
 
+// Operands of a lane's FIRST H entry (proposal / snapshot rows of the two nodes, the edge's bit,
+// the directed model's radii): static too - the persistent launch requests them early.
+template <int D>
+struct PipeHPre {
+    double xm0[D], xm1[D], xa0[D], xa1[D], rm, rkk;
+    uint32_t yw, yw2;
+};
+template <int D, int MODEL>
+__device__ __forceinline__ void pipe_h_operands(const ChainView &c, const double *props,
+                                                const char *yrows, const char *ytrows, int jm_,
+                                                int jkk, PipeHPre<D> &o) {
+    constexpr int PW = 2 * D + 2;
+    const double *rowm = (const double *)((const char *)props + __umul24((uint32_t)jm_, (uint32_t)(PW * sizeof(double))));
+    const double *rowk = (const double *)((const char *)props + __umul24((uint32_t)jkk, (uint32_t)(PW * sizeof(double))));
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        o.xm0[d] = rowm[D + 2 + d];
+        o.xm1[d] = rowm[d];
+        o.xa0[d] = rowk[D + 2 + d];
+        o.xa1[d] = rowk[d];
+    }
+    const uint32_t woff = ((uint32_t)jkk * (uint32_t)c.W + ((uint32_t)jm_ >> 5)) * 4u;
+    o.yw = *(const uint32_t *)(yrows + woff);
+    o.yw2 = 0u; o.rm = 1.0; o.rkk = 1.0;
+    if (MODEL == DLSM_DIRECTED) {
+        o.yw2 = *(const uint32_t *)(ytrows + woff);
+        o.rm = c.radii[jm_]; o.rkk = c.radii[jkk];
+    }
+}
+// the lane's first entry of batch `be` (flat index hf0; false: the lane has none)
+template <int D, int MODEL, int G>
+__device__ __forceinline__ bool pipe_h_prefetch(const ChainView &c, const PipeBuf &pb, int be, int nb,
+                                                int t, int k, int p, int lane, PipeHPre<D> &o) {
+    constexpr int PW = 2 * D + 2;
+    const int N = c.N, W = c.W;
+    const int j0 = be * PP_B;
+    const int jprev = pipe_window_start(be, G) * PP_B;
+    const int ncross = j0 - jprev;
+    const int htot = ncross * nb + nb * (nb - 1) / 2;
+    const int hf0 = (k * pb.parts + p) * 64 + lane;
+    int kk, e;
+    pipe_h_decode(min(hf0, max(htot - 1, 0)), ncross, nb, kk, e);
+    const double *props = pb.prop + (size_t)t * N * PW;
+    const char *yrows = (const char *)(c.ybits + (size_t)t * N * W);
+    const char *ytrows = MODEL == DLSM_DIRECTED ? (const char *)(c.ytbits + (size_t)t * N * W) : nullptr;
+    pipe_h_operands<D, MODEL>(c, props, yrows, ytrows, jprev + e, j0 + kk, o);
+    return hf0 < htot;
+}
+
 // The item's tail: wavefront reductions, the (sum, ratio) record, and this lane's share of the
 // batch's H entries.  Shared by the launch-per-batch item (neighbours prefetched from memory) and
 // the persistent launch's item (neighbours staged in LDS, kernels_pipe_persist.hpp).
-template <int D, int MODEL, int G, bool COH>
+// HPF: `hpre` holds the operands of the lane's first H entry (by reference and under a template
+// flag: a pointer that may be null kept the structure in scratch memory)
+template <int D, int MODEL, int G, bool COH, bool HPF>
 __device__ __forceinline__ void pipe_item_finish(const ChainView &c, const PipeBuf &pb, int be, int nb,
                                                  int t, int k, int p, int lane, const double *etab,
-                                                 double acc, RatioAcc &ra, bool noflush
+                                                 double acc, RatioAcc &ra, bool noflush,
+                                                 const PipeHPre<D> &hpre
 #ifdef DLSM_PIPE_TIMING
                                                  , unsigned long long *ts
 #endif
@@ -233,23 +285,15 @@ __device__ __forceinline__ void pipe_item_finish(const ChainView &c, const PipeB
     char *hbase = (char *)(pb.Hd + ((size_t)bb * c.T + t) * PP_B * (COH ? 2 * PP_B : PP_B));
     const uint32_t hx_off = (uint32_t)((const char *)(pb.Hx + ((size_t)bb * c.T + t) * ((2 * G - 1) * PP_B) * PP_B) -
                                        (const char *)hbase);                          // one allocation
-    for (int f = hf0; f < htot; f += hround) {
+    // one entry: flat index f, operands o
+    auto h_entry = [&](int f, const PipeHPre<D> &o) {
         int kk, e;
         pipe_h_decode(f, ncross, nb, kk, e);
         const int jm_ = jprev + e;                 // jprev + ncross == j0
-        const int jkk = j0 + kk;
-        const double *rowm = (const double *)((const char *)props + __umul24((uint32_t)jm_, (uint32_t)(PW * sizeof(double))));
-        const double *rowk = (const double *)((const char *)props + __umul24((uint32_t)jkk, (uint32_t)(PW * sizeof(double))));
         double xm0[D], xm1[D], xa0[D], xa1[D];
 #pragma unroll
-        for (int d = 0; d < D; ++d) {
-            xm0[d] = rowm[D + 2 + d];
-            xm1[d] = rowm[d];
-            xa0[d] = rowk[D + 2 + d];
-            xa1[d] = rowk[d];
-        }
-        const uint32_t woff = ((uint32_t)jkk * (uint32_t)W + ((uint32_t)jm_ >> 5)) * 4u;
-        const int y1 = (int)((*(const uint32_t *)(yrows + woff) >> (jm_ & 31)) & 1u);
+        for (int d = 0; d < D; ++d) { xm0[d] = o.xm0[d]; xm1[d] = o.xm1[d]; xa0[d] = o.xa0[d]; xa1[d] = o.xa1[d]; }
+        const int y1 = (int)((o.yw >> (jm_ & 31)) & 1u);
         const bool cross = e < ncross;
         const int m = cross ? e : e - ncross;
         const double a0 = dist_fast<D>(xm0, xa0, c.squared);
@@ -268,13 +312,13 @@ __device__ __forceinline__ void pipe_item_finish(const ChainView &c, const PipeB
             // the edge's factor e^{(b0 - b1) - (a0 - a1)} from the four exponentials at hand;
             // a fifth one only when their product left the normal range (distances > 300)
             const double fn = eb1 * ea0, fd = eb0 * ea1;
-            const bool tiny = y1 && !(fd > 1e-290);
+            const bool tiny = y1 && !(fd > 1e-290 && fn > 1e-290);      // both products normal
             if (y1 && !tiny) { num *= fn; den *= fd; }
             h = num / den;
             if (__builtin_amdgcn_ballot_w64(tiny)) { if (tiny) h *= fast_exp((b0 - b1) - (a0 - a1)); }
         } else {
-            const int y2 = (int)((*(const uint32_t *)(ytrows + woff) >> (jm_ & 31)) & 1u);
-            const double irm = 1.0 / c.radii[jm_], irkk = 1.0 / c.radii[jkk];
+            const int y2 = (int)((o.yw2 >> (jm_ & 31)) & 1u);
+            const double irm = 1.0 / o.rm, irkk = 1.0 / o.rkk;
             const double aa = bin * irm + bout * irkk, cc = bin * irkk + bout * irm;
             RatioAcc rb, rq;
             double eb = 0.0, eq = 0.0;
@@ -288,8 +332,57 @@ __device__ __forceinline__ void pipe_item_finish(const ChainView &c, const PipeB
             coh_store<true>((double *)(hbase + (uint32_t)(kk * (2 * PP_B) + (cross ? e : PP_B + m)) * 8u), h);
         else
             coh_store<false>((double *)(hbase + ((cross ? hx_off : 0u) + (uint32_t)(m * PP_B + kk) * 8u)), h);
+    };
+    int f = hf0;
+    if (HPF) {          // the first entry's operands were requested before the batch was released (its own
+                        // copy of the code: selecting between `hpre` and fresh loads inside ONE loop left
+                        // the structure in scratch memory)
+        if (f < htot) { h_entry(f, hpre); f += hround; }
+    }
+    for (; f < htot; f += hround) {
+        int kk, e;
+        pipe_h_decode(f, ncross, nb, kk, e);
+        PipeHPre<D> o;
+        pipe_h_operands<D, MODEL>(c, props, yrows, ytrows, jprev + e, j0 + kk, o);
+        h_entry(f, o);
     }
     DLSM_STAMP(5, acc)
+}
+
+// What an item reads about its OWN node before the first neighbour: static for the whole sweep
+// (proposal and snapshot from the propose kernel, the node's row of the network), so the
+// persistent launch requests it while it still waits for the batch it depends on.
+template <int D>
+struct PipeItemPre {
+    double xk0[D], xk1[D], E, bin, bout, irk;
+    int nflush;
+    uint32_t yseg, ycseg;
+};
+template <int D, int MODEL>
+__device__ __forceinline__ void pipe_item_prologue(const ChainView &c, const PipeBuf &pb, int be, int t,
+                                                   int k, int p, int lane, PipeItemPre<D> &q) {
+    constexpr int PW = 2 * D + 2;
+    const int N = c.N, W = c.W;
+    const int jk = be * PP_B + k;
+    const double *props = pb.prop + (size_t)t * N * PW;
+    const uint32_t *yr = c.ybits + ((size_t)t * N + jk) * W;
+    const uint32_t *yc = MODEL == DLSM_DIRECTED ? c.ytbits + ((size_t)t * N + jk) * W : nullptr;
+    q.E = pb.consts[0];
+    q.nflush = (int)pb.consts[1];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        q.xk0[d] = props[(size_t)jk * PW + D + 2 + d];
+        q.xk1[d] = props[(size_t)jk * PW + d];
+    }
+    q.bin = 0.0; q.bout = 0.0; q.irk = 0.0;
+    if (MODEL == DLSM_DIRECTED) {
+        q.bin = c.intercept[0]; q.bout = c.intercept[1];
+        q.irk = 1.0 / c.radii[jk];
+    }
+    // the bits of row k for the part's neighbours: lane w holds word (lo >> 5) + w of the row
+    const int w0 = (p * pb.per) >> 5;
+    q.yseg = yr[min(w0 + lane, W - 1)];
+    q.ycseg = MODEL == DLSM_DIRECTED ? yc[min(w0 + lane, W - 1)] : 0u;
 }
 
 // trips of 64 neighbours whose operands an undirected item loads up front
@@ -302,10 +395,13 @@ __host__ __device__ constexpr int pipe_prefetch_trips(int D) {
 // prefetch, where it is worth +3 % - at C2, where everything is prefetched, it costs 1 %).
 // COH: the item runs inside the persistent launch (kernels_pipe_persist.hpp): final positions come
 // from resolver workgroups of the same launch and its records go to them - sc1 accesses.
-template <int D, int MODEL, bool TP, int G, bool COH = false>
+// LDSX: the part's neighbour rows were staged in LDS by the workgroup (sX[row - lo][D]): the
+// "prefetch" is LDS reads and the trips beyond it read LDS as they go.
+template <int D, int MODEL, bool TP, int G, bool COH = false, bool LDSX = false, bool HPF = false>
 __device__ __forceinline__ void pipe_eval_item(const ChainView &c, const PipeBuf &pb, int be,
                                                int nb, int t, int k, int p, int lane,
-                                               const double *etab
+                                               const double *etab, const double *sX,
+                                               const PipeItemPre<D> &pre, const PipeHPre<D> &hpre
 #ifdef DLSM_PIPE_TIMING
                                                , int tl, int tgw
 #endif
@@ -324,19 +420,12 @@ __device__ __forceinline__ void pipe_eval_item(const ChainView &c, const PipeBuf
     const double *props = pb.prop + (size_t)t * N * PW;
     const uint32_t *yr = c.ybits + ((size_t)t * N + jk) * W;
     const uint32_t *yc = MODEL == DLSM_DIRECTED ? c.ytbits + ((size_t)t * N + jk) * W : nullptr;
-    const double E = pb.consts[0];
-    const int nflush = (int)pb.consts[1];
+    const double E = pre.E;
+    const int nflush = pre.nflush;
     double xk0[D], xk1[D];
 #pragma unroll
-    for (int d = 0; d < D; ++d) {
-        xk0[d] = props[(size_t)jk * PW + D + 2 + d];
-        xk1[d] = props[(size_t)jk * PW + d];
-    }
-    double bin = 0.0, bout = 0.0, irk = 0.0;
-    if (MODEL == DLSM_DIRECTED) {
-        bin = c.intercept[0]; bout = c.intercept[1];
-        irk = 1.0 / c.radii[jk];
-    }
+    for (int d = 0; d < D; ++d) { xk0[d] = pre.xk0[d]; xk1[d] = pre.xk1[d]; }
+    const double bin = pre.bin, bout = pre.bout, irk = pre.irk;
     const double lE = bin + bout;              // log E (directed model)
     const int lo = p * pb.per, hi = min(N, lo + pb.per);
     // neighbours per lane loaded up front (the directed model carries more per neighbour)
@@ -348,9 +437,7 @@ __device__ __forceinline__ void pipe_eval_item(const ChainView &c, const PipeBuf
     // (64 words = 2048 neighbours; a longer part reads the rest from memory), handed to the
     // trips as scalar lane masks instead of a load and a register per neighbour.
     double xpre[PP_NPRE][D], rpre[MODEL == DLSM_DIRECTED ? PP_NPRE : 1];
-    const int w0 = lo >> 5;
-    const uint32_t yseg = yr[min(w0 + lane, W - 1)];
-    const uint32_t ycseg = MODEL == DLSM_DIRECTED ? yc[min(w0 + lane, W - 1)] : 0u;
+    const uint32_t yseg = pre.yseg, ycseg = pre.ycseg;
     // lo and jprev are multiples of 64, so a trip's 64 neighbours are all on one side of jprev
     // (the clamped ones included: N - 1 >= jprev): the array and its row stride are scalar
     // choices and a lane's address is a 32-bit offset from a scalar base
@@ -362,9 +449,11 @@ __device__ __forceinline__ void pipe_eval_item(const ChainView &c, const PipeBuf
 #pragma unroll
     for (int u = 0; u < PP_NPRE; ++u) {
         const int ic = min(lo + lane + 64 * u, N - 1);
-        uint32_t off;
-        const char *base = x_source(lo + 64 * u, ic, off);
-        coh_load_row<D, COH>(base, off, xpre[u]);
+        if (!LDSX) {            // (LDSX: the trip reads its row where it uses it - LDS is near)
+            uint32_t off;
+            const char *base = x_source(lo + 64 * u, ic, off);
+            coh_load_row<D, COH>(base, off, xpre[u]);
+        }
         if (MODEL == DLSM_DIRECTED) rpre[u] = c.radii[ic];
     }
     // H entries of the batch: (node kk, entry e), e < ncross + kk: the previous batch (cross
@@ -433,6 +522,11 @@ __device__ __forceinline__ void pipe_eval_item(const ChainView &c, const PipeBuf
     _Pragma("unroll")                                                                         \
     for (int u = 0; u < PP_NPRE; ++u) {                                                       \
         DLSM_PIPE_MASKS(u)                                                                    \
+        if (LDSX) {     /* rows are staged up to the part's end; a clamped lane is masked */  \
+            const double *row_ = sX + (size_t)min(64 * u + lane, pb.per - 1) * D;             \
+            _Pragma("unroll")                                                                 \
+            for (int d = 0; d < D; ++d) xpre[u][d] = row_[d];                                 \
+        }                                                                                     \
         if (__builtin_amdgcn_inverse_ballot_w64(vm_))                                         \
             DLSM_PIPE_TERM(xpre[u], yb_, ycb_, rpre[MODEL == DLSM_DIRECTED ? u : 0], FLUSH_, SQ_) \
         if (u == 0) { DLSM_STAMP(1, ra.P0) }                                                  \
@@ -454,9 +548,16 @@ __device__ __forceinline__ void pipe_eval_item(const ChainView &c, const PipeBuf
         DLSM_PIPE_MASKS(u)                                                                    \
         if (__builtin_amdgcn_inverse_ballot_w64(vm_)) {                                       \
             if (!TP) {                                                                        \
-                uint32_t off_;                                                                \
-                const char *base_src_ = x_source(base_, i_, off_);                            \
-                coh_load_row<D, COH>(base_src_, off_, xi);                                    \
+                if (LDSX) {                                                                   \
+                    const double *row_ = sX + (size_t)(64 * u + lane) * D;                    \
+                    _Pragma("unroll")                                                         \
+                    for (int d = 0; d < D; ++d) xi[d] = row_[d];                              \
+                } else {                                                                      \
+                    uint32_t off_;                                                            \
+                    const char *base_src_ = x_source(base_, i_, off_);                        \
+                    coh_load_row<D, COH>(base_src_, off_, xi);                                \
+                }                                                                             \
+                if (MODEL == DLSM_DIRECTED) ri = c.radii[min(i_, N - 1)];                     \
             }                                                                                 \
             DLSM_PIPE_TERM(xi, yb_, ycb_, ri, FLUSH_, SQ_)                                    \
         }                                                                                     \
@@ -468,7 +569,7 @@ __device__ __forceinline__ void pipe_eval_item(const ChainView &c, const PipeBuf
 #undef DLSM_PIPE_REQUEST
 #undef DLSM_PIPE_MASKS
 #undef DLSM_PIPE_TERM
-    pipe_item_finish<D, MODEL, G, COH>(c, pb, be, nb, t, k, p, lane, etab, acc, ra, noflush
+    pipe_item_finish<D, MODEL, G, COH, HPF>(c, pb, be, nb, t, k, p, lane, etab, acc, ra, noflush, hpre
 #ifdef DLSM_PIPE_TIMING
                                        , ts
 #endif
@@ -904,8 +1005,12 @@ __global__ __launch_bounds__(PP_THREADS) void k_pipe_step(ChainView c, PipeBuf p
         const int nb = be < pb.nbat ? min(PP_B, c.N - be * PP_B) : 0;
         if (k >= nb) continue;
         const int t = odd ? 2 * (si - nslE) + 1 : 2 * si;
-        pipe_eval_item<D, MODEL == DLSM_DIRECTED_CASE_CONTROL ? DLSM_DIRECTED : MODEL, TP, G>(
-            c, pb, be, nb, t, k, p, lane, pp_sH
+        constexpr int IM = MODEL == DLSM_DIRECTED_CASE_CONTROL ? DLSM_DIRECTED : MODEL;
+        PipeItemPre<D> pre;
+        PipeHPre<D> nohp;                   // (unused: HPF = false)
+        pipe_item_prologue<D, IM>(c, pb, be, t, k, p, lane, pre);
+        pipe_eval_item<D, IM, TP, G>(
+            c, pb, be, nb, t, k, p, lane, pp_sH, nullptr, pre, nohp
 #ifdef DLSM_PIPE_TIMING
             , l + 1, gw
 #endif

@@ -139,9 +139,16 @@ int dlsm_loglik_partial_all(dlsm_chain *h, int with_prior, double *out);
  * 5 = (case-control model) the pipelined form with sparse correction lists and batches
  *     of 512 nodes,
  * 6 = (exact likelihoods) the pipelined form with two batches resolved and two evaluated
- *     per launch: half the launches, larger correction blocks (measured slower than 4). */
+ *     per launch: half the launches, larger correction blocks (measured slower than 4),
+ * 7 = (exact likelihoods) algo 4's roles in ONE persistent launch per sweep: per-slice flags
+ *     instead of kernel boundaries, evaluator work drawn from a ticket counter (progress with
+ *     any number of resident workgroups), every wait bounded by a poll budget - a wait that
+ *     runs out sets a sticky error word and the next synchronising call returns DLSM_E_HIP.
+ *     Needs a compute unit per time slice.  Decisions identical to algo 4; measured slower
+ *     (the flag hand-offs cost more than the boundaries they replace), never picked by auto. */
 int dlsm_sweep_positions(dlsm_chain *h, uint32_t iter, int algo);
-/* the algorithm `algo` resolves to for this handle (what 0 = auto picks): 1..5 */
+/* the algorithm `algo` resolves to for this handle (what 0 = auto picks): 1, 2, 4 or 5; a
+ * non-zero `algo` is returned as it is after the same checks as dlsm_sweep_positions */
 int dlsm_resolve_sweep_algo(dlsm_chain *h, int algo);
 /* lsm.py:501 / hdp_lpcm.py:852 */
 int dlsm_center(dlsm_chain *h);
