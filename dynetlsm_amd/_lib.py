@@ -116,6 +116,9 @@ SIGNATURES = {
     'dlsm_hdp_trace_read': (C.c_int, [handle_t, C.c_int, C.c_int, c_double_p, c_double_p,
                                       c_double_p, c_double_p, c_double_p, c_i64_p, c_double_p,
                                       c_double_p, c_double_p, c_double_p]),
+    'dlsm_hdp_trace_write': (C.c_int, [handle_t, C.c_int, C.c_int, c_double_p, c_double_p, c_double_p,
+                                       c_double_p, c_double_p, c_i64_p, c_double_p, c_double_p,
+                                       c_double_p]),
     'dlsm_hdp_get_aux': (C.c_int, [handle_t, c_i64_p, c_double_p, c_i64_p, c_i64_p, c_i64_p]),
     'dlsm_init_shortest_paths': (C.c_int, [handle_t]),
     'dlsm_init_get_dissimilarity': (C.c_int, [handle_t, C.c_int, c_double_p]),
@@ -129,6 +132,14 @@ SIGNATURES = {
     'dlsm_post_cooccurrence': (C.c_int, [handle_t, c_i64_p, C.c_int, C.c_int, c_double_p]),
     'dlsm_post_expected_vi_sums': (C.c_int, [handle_t, c_double_p]),
     'dlsm_post_release': (C.c_int, [handle_t]),
+    'dlsm_post_trace_label_counts': (C.c_int, [handle_t, C.c_int, C.c_int, c_i32_p]),
+    'dlsm_post_trace_cooccurrence': (C.c_int, [handle_t, C.c_int, C.c_int, c_double_p, c_double_p]),
+    'dlsm_post_get_cooccurrence': (C.c_int, [handle_t, c_double_p]),
+    'dlsm_post_trace_align': (C.c_int, [handle_t, C.c_int, C.c_int, C.c_int]),
+    'dlsm_post_trace_mean': (C.c_int, [handle_t, C.c_int, C.c_int, c_double_p]),
+    'dlsm_post_latent_marginal_loglik': (C.c_int, [handle_t, C.c_int, c_double_p, c_double_p,
+                                                   c_double_p, c_double_p, C.c_double, C.c_int,
+                                                   c_double_p]),
     'dlsm_forecast_mean_probas': (C.c_int, [handle_t, c_double_p, c_double_p, C.c_int, C.c_int,
                                             c_double_p]),
     'dlsm_forecast_marginal': (C.c_int, [handle_t, c_double_p, c_double_p, c_double_p, C.c_int,

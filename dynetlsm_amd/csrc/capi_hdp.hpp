@@ -199,6 +199,10 @@ int dlsm_hdp_trace_alloc(dlsm_chain *h, int n_total, double logp0) {
     HIPCHK(h, hipMemcpyAsync(h->htr_w, h->lab_w, T * K * K * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->htr_lambda, &h->hdp->lmbda, sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->htr_hyper, hy, sizeof(hy), hipMemcpyHostToDevice, h->stream));
+    {   // row 0's network log-likelihood is not known here (NaN: "evaluate it if you need it")
+        const double nanv = std::nan("");
+        HIPCHK(h, hipMemcpyAsync(h->trace_ic + 1, &nanv, sizeof(double), hipMemcpyHostToDevice, h->stream));
+    }
     const long tn = (long)(T * N);
     hipLaunchKernelGGL(k_hdp_trace_labels, dim3((unsigned)((tn + 255) / 256)), dim3(256), 0, h->stream,
                        h->z, tn, h->htr_z);
@@ -244,6 +248,45 @@ int dlsm_hdp_trace_read(dlsm_chain *h, int first, int count, double *Xs, double 
         std::vector<uint8_t> tmp(c * T * N);
         HIPCHK(h, hipMemcpy(tmp.data(), h->htr_z + f * T * N, tmp.size(), hipMemcpyDeviceToHost));
         for (size_t q = 0; q < tmp.size(); ++q) zs[q] = tmp[q];
+    }
+    return DLSM_OK;
+}
+
+int dlsm_hdp_trace_write(dlsm_chain *h, int first, int count, const double *Xs,
+                         const double *intercepts, const double *logps, const double *mus,
+                         const double *sigmas, const int64_t *zs, const double *betas,
+                         const double *weights, const double *lambdas) {
+    NEED(h, h != nullptr, "null handle");
+    NEED(h, h->htr_z && h->trace_X, "no HDP-LPCM trace allocated");
+    NEED(h, first >= 0 && count >= 0 && first + count <= h->htr_n && first + count <= h->trace_n,
+         "range out of the trace");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const size_t T = h->T, N = h->N, K = h->htr_K, D = h->D, f = first, c = count;
+    auto put = [&](double *dst, const double *src, size_t per) -> hipError_t {
+        return src ? hipMemcpy(dst + f * per, src, c * per * sizeof(double), hipMemcpyHostToDevice)
+                   : hipSuccess;
+    };
+    HIPCHK(h, put(h->trace_X, Xs, T * N * D));
+    HIPCHK(h, put(h->trace_logp, logps, 1));
+    HIPCHK(h, put(h->htr_mu, mus, K * D));
+    HIPCHK(h, put(h->htr_sigma, sigmas, K));
+    HIPCHK(h, put(h->htr_beta, betas, K));
+    HIPCHK(h, put(h->htr_w, weights, T * K * K));
+    HIPCHK(h, put(h->htr_lambda, lambdas, 1));
+    if (intercepts) {                       // the device keeps two per row (undirected: the second unused)
+        std::vector<double> tmp(c * 2, std::nan(""));    // (second slot: network log-likelihood, unknown)
+        for (size_t q = 0; q < c; ++q) tmp[2 * q] = intercepts[q];
+        HIPCHK(h, hipMemcpy(h->trace_ic + 2 * f, tmp.data(), tmp.size() * sizeof(double),
+                            hipMemcpyHostToDevice));
+    }
+    if (zs) {
+        std::vector<uint8_t> tmp(c * T * N);
+        for (size_t q = 0; q < tmp.size(); ++q) {
+            if (zs[q] < 0 || zs[q] >= (int64_t)K) FAIL(h, DLSM_E_DATA, "label out of range at %zu", q);
+            tmp[q] = (uint8_t)zs[q];
+        }
+        HIPCHK(h, hipMemcpy(h->htr_z + f * T * N, tmp.data(), tmp.size(), hipMemcpyHostToDevice));
     }
     return DLSM_OK;
 }

@@ -706,6 +706,10 @@ __global__ __launch_bounds__(HF_THREADS) void k_hdp_finalize(ChainView c, HdpLoo
         if (hs->has_c0) lp += (hs->c0 - 1.0) * log(hs->b) - hs->d0 * hs->b;
     }
     tr.logp[it] = lp;
+    // the network log-likelihood of the stored state rides in the undirected model's unused second
+    // intercept slot: the tie-break of posterior_vi.py:62-80 (often thousands of identical
+    // partitions) then needs no pass over the stored positions
+    tr.ic[(size_t)it * 2 + 1] = hs->ll;
     tr.lambda[it] = hs->lmbda;
     double *hy = tr.hyper + (size_t)it * 6;
     hy[0] = hs->gamma; hy[1] = hs->alpha_init; hy[2] = hs->alpha; hy[3] = hs->kappa;

@@ -10,8 +10,10 @@
 
 namespace dlsm {
 
-// int64 [S][T][N] (a chunk of samples s0 .. s0 + ns) -> uint8 [T][N][Spad]
-__global__ __launch_bounds__(256) void k_post_pack_labels(const int64_t *__restrict__ zs, int ns,
+// int64 (the caller's zs_) or uint8 (the device-resident trace) [S][T][N] (a chunk of samples
+// s0 .. s0 + ns) -> uint8 [T][N][Spad]
+template <typename ZT>
+__global__ __launch_bounds__(256) void k_post_pack_labels(const ZT *__restrict__ zs, int ns,
                                                           int s0, int T, int N, int Spad,
                                                           uint8_t *__restrict__ zt) {
     const size_t total = (size_t)ns * T * N;
@@ -135,6 +137,181 @@ __global__ __launch_bounds__(256) void k_post_vi_reduce(const double *__restrict
     double v = 0.0;
     for (int g = 0; g < ngroups; ++g) v += part[((size_t)t * ngroups + g) * Spad + s];
     out[(size_t)t * S + s] = v;
+}
+
+// ---- post-loop processing on the device-resident trace (hdp_lpcm.py:1085-1162) ------------------
+// nk[s][t][k] = nodes carrying label k at time t of stored sample s (approx_bic.py:26-51,
+// posterior_vi.py:31-36 and label_utils.py:73-81 all start from these counts)
+__global__ __launch_bounds__(256) void k_post_label_counts(const uint8_t *__restrict__ z, int N, int K,
+                                                           int32_t *__restrict__ nk) {
+    __shared__ int hist[256];
+    const int t = blockIdx.x, s = blockIdx.y, T = gridDim.x;
+    hist[threadIdx.x] = 0;
+    __syncthreads();
+    const uint8_t *row = z + ((size_t)s * T + t) * N;
+    for (int i = threadIdx.x; i < N; i += 256) atomicAdd(&hist[row[i]], 1);      // integers: order free
+    __syncthreads();
+    if ((int)threadIdx.x < K) nk[((size_t)s * T + t) * K + threadIdx.x] = hist[threadIdx.x];
+}
+
+// out[r] = sum_j cooc[r][j], one wavefront per row, fixed order
+__global__ __launch_bounds__(256) void k_post_row_sums(const double *__restrict__ cooc, size_t rows,
+                                                       int N, double *__restrict__ out) {
+    const size_t r = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const int lane = threadIdx.x & 63;
+    double v = 0.0;
+    for (int j = lane; j < N; j += 64) v += cooc[r * N + j];
+    v = wave_sum_all(v);
+    if (lane == 0) out[r] = v;
+}
+
+// Procrustes alignment of every stored sample onto a reference configuration
+// (hdp_lpcm.py:1141-1146 -> procrustes.py:20-35 -> scipy.linalg.orthogonal_procrustes):
+// M = X_s^T X_ref over the T N rows, R = U V^T of its SVD, X_s <- X_s R, mu_s <- mu_s R.
+// One workgroup per sample: pass 1 reduces M in a fixed order, every thread then holds R (the
+// d x d one-sided Jacobi of the sweep's own Procrustes step), pass 2 rotates the rows.
+template <int D>
+__device__ void jacobi_polar(const double (&M)[D][D], double (&R)[D][D]);   // kernels_sweep.hpp
+template <int D>
+__global__ __launch_bounds__(256) void k_post_align(double *__restrict__ Xs, double *__restrict__ mus,
+                                                    const double *__restrict__ ref, int rows, int K) {
+    __shared__ double sM[4][D * D];
+    __shared__ double sR[D * D];
+    const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double *X = Xs + (size_t)s * rows * D;
+    double m[D][D];
+#pragma unroll
+    for (int a = 0; a < D; ++a)
+#pragma unroll
+        for (int b = 0; b < D; ++b) m[a][b] = 0.0;
+    for (int r = tid; r < rows; r += 256) {
+        double x[D], y[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) { x[d] = X[(size_t)r * D + d]; y[d] = ref[(size_t)r * D + d]; }
+#pragma unroll
+        for (int a = 0; a < D; ++a)
+#pragma unroll
+            for (int b = 0; b < D; ++b) m[a][b] = fma(x[a], y[b], m[a][b]);
+    }
+#pragma unroll
+    for (int a = 0; a < D; ++a)
+#pragma unroll
+        for (int b = 0; b < D; ++b) {
+            const double v = wave_sum_all(m[a][b]);
+            if (lane == 0) sM[wave][a * D + b] = v;
+        }
+    __syncthreads();
+    if (tid == 0) {
+        double M[D][D], R[D][D];
+#pragma unroll
+        for (int a = 0; a < D; ++a)
+#pragma unroll
+            for (int b = 0; b < D; ++b)
+                M[a][b] = (sM[0][a * D + b] + sM[1][a * D + b]) + (sM[2][a * D + b] + sM[3][a * D + b]);
+        jacobi_polar<D>(M, R);
+#pragma unroll
+        for (int a = 0; a < D; ++a)
+#pragma unroll
+            for (int b = 0; b < D; ++b) sR[a * D + b] = R[a][b];
+    }
+    __syncthreads();
+    double R[D][D];
+#pragma unroll
+    for (int a = 0; a < D; ++a)
+#pragma unroll
+        for (int b = 0; b < D; ++b) R[a][b] = sR[a * D + b];
+    auto rotate = [&](double *row) {
+        double x[D], y[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) x[d] = row[d];
+#pragma unroll
+        for (int b = 0; b < D; ++b) {
+            double acc = 0.0;
+#pragma unroll
+            for (int a = 0; a < D; ++a) acc = fma(x[a], R[a][b], acc);
+            y[b] = acc;
+        }
+#pragma unroll
+        for (int d = 0; d < D; ++d) row[d] = y[d];
+    };
+    for (int r = tid; r < rows; r += 256) rotate(X + (size_t)r * D);
+    if (mus != nullptr && tid < K) rotate(mus + ((size_t)s * K + tid) * D);
+}
+
+// partial[c][e] = sum over the samples s = c, c + C, .. of Xs[s][e]; then mean[e] = sum_c / S
+constexpr int PM_CHUNKS = 64;
+__global__ __launch_bounds__(256) void k_post_mean_partial(const double *__restrict__ Xs, size_t len,
+                                                           int S, double *__restrict__ partial) {
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int c = blockIdx.y;
+    if (e >= len) return;
+    double v = 0.0;
+    for (int s = c; s < S; s += PM_CHUNKS) v += Xs[(size_t)s * len + e];
+    partial[(size_t)c * len + e] = v;
+}
+__global__ __launch_bounds__(256) void k_post_mean_final(const double *__restrict__ partial, size_t len,
+                                                         int S, double *__restrict__ out) {
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= len) return;
+    double v = 0.0;
+    for (int c = 0; c < PM_CHUNKS; ++c) v += partial[(size_t)c * len + e];
+    out[e] = v / (double)S;
+}
+
+// latent_marginal_loglikelihood (model_selection/approx_bic.py:54-76): the forward algorithm over
+// the label chain of every node at positions X, one wavefront per node, lane k = component k
+// (K <= 64); spherical_normal_log_pdf of gaussian_likelihood_fast.pyx:17-27 for the densities.
+// part[workgroup] = sum over its 4 nodes of sum_t log c_t.
+template <int D>
+__global__ __launch_bounds__(256) void k_post_forward_loglik(const double *__restrict__ X, int T, int N,
+                                                             const double *__restrict__ init_w,
+                                                             const double *__restrict__ trans_w,
+                                                             const double *__restrict__ mu,
+                                                             const double *__restrict__ sigma,
+                                                             double lmbda, int K,
+                                                             double *__restrict__ part) {
+    __shared__ double sW[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = blockIdx.x * 4 + wave;
+    double ll = 0.0;
+    if (i < N) {
+        const bool on = lane < K;
+        const int kc = min(lane, K - 1);
+        double m[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) m[d] = mu[(size_t)kc * D + d];
+        const double var = sigma[kc];
+        const double lognorm = -0.5 * D * log(2.0 * 3.14159265358979323846 * var);
+        double f = 0.0, xprev[D];
+        for (int t = 0; t < T; ++t) {
+            double x[D], ss = 0.0;
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                x[d] = X[((size_t)t * N + i) * D + d];
+                const double mean = t == 0 ? m[d] : lmbda * m[d] + (1.0 - lmbda) * xprev[d];
+                const double df = x[d] - mean;
+                ss += df * df;
+            }
+            const double g = on ? exp(lognorm - 0.5 * ss / var) : 0.0;
+            if (t == 0) {
+                f = on ? init_w[kc] * g : 0.0;
+            } else {
+                double acc = 0.0;            // sum_j f_j trans_w[t][j][k], j ascending
+                for (int j = 0; j < K; ++j)
+                    acc = fma(lane_value(f, j), on ? trans_w[((size_t)t * K + j) * K + kc] : 0.0, acc);
+                f = g * acc;
+            }
+            const double c = wave_sum_all(f);
+            ll += log(c);
+            f /= c;
+#pragma unroll
+            for (int d = 0; d < D; ++d) xprev[d] = x[d];
+        }
+    }
+    if (lane == 0) sW[wave] = ll;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (sW[0] + sW[1]) + (sW[2] + sW[3]);
 }
 
 }  // namespace dlsm

@@ -428,24 +428,52 @@ class Chain(object):
         """enqueue Gibbs iterations first..first+count-1 of the HDP-LPCM (asynchronous)"""
         self._ck(self._L.dlsm_hdp_run(self._h, int(first), int(count)))
 
-    def hdp_trace_read(self, first, count, positions=True, labels=True):
-        """dict of the stored samples first..first+count-1"""
+    def hdp_trace_read(self, first, count, positions=True, labels=True, weights=True, small=True):
+        """dict of the stored samples first..first+count-1: ``Xs`` (positions), ``zs`` (labels),
+        ``weights`` - the three large arrays, each optional - and the small ones (``small``)"""
         T, N, D, K = self.T, self.N, self.D, self.K
-        out = dict(intercepts=np.zeros((count, 2)), logps=np.zeros(count),
-                   mus=np.zeros((count, K, D)), sigmas=np.zeros((count, K)),
-                   betas=np.zeros((count, K)), weights=np.zeros((count, T, K, K)),
-                   lambdas=np.zeros((count, 1)), hypers=np.zeros((count, 6)))
+        out = {}
+        if small:
+            out.update(intercepts=np.zeros((count, 2)), logps=np.zeros(count),
+                       mus=np.zeros((count, K, D)), sigmas=np.zeros((count, K)),
+                       betas=np.zeros((count, K)), lambdas=np.zeros((count, 1)),
+                       hypers=np.zeros((count, 6)))
+        if weights:
+            out['weights'] = np.zeros((count, T, K, K))
         if positions:
             out['Xs'] = np.zeros((count, T, N, D))
         if labels:
             out['zs'] = np.zeros((count, T, N), dtype=np.int64)
+
+        def ptr(name):
+            return _p(out[name]) if name in out else None
         self._ck(self._L.dlsm_hdp_trace_read(
-            self._h, int(first), int(count), _p(out['Xs']) if positions else None,
-            _p(out['intercepts']), _p(out['logps']), _p(out['mus']), _p(out['sigmas']),
-            _p(out['zs']) if labels else None, _p(out['betas']), _p(out['weights']),
-            _p(out['lambdas']), _p(out['hypers'])))
-        out['intercepts'] = out['intercepts'][:, :1]
+            self._h, int(first), int(count), ptr('Xs'), ptr('intercepts'), ptr('logps'), ptr('mus'),
+            ptr('sigmas'), ptr('zs'), ptr('betas'), ptr('weights'), ptr('lambdas'), ptr('hypers')))
+        if small:
+            # (undirected device loop: the second slot carries the network log-likelihood of the
+            # stored state, NaN where it is not known)
+            out['logliks'] = out['intercepts'][:, 1].copy()
+            out['intercepts'] = out['intercepts'][:, :1]
         return out
+
+    def hdp_trace_write(self, first, Xs=None, intercepts=None, logps=None, mus=None, sigmas=None,
+                        zs=None, betas=None, weights=None, lambdas=None):
+        """rows first .. of the device-resident trace from host arrays (the mirror of
+        ``hdp_trace_read``); every given array has the same leading length"""
+        T, N, D, K = self.T, self.N, self.D, self.K
+        given = [a for a in (Xs, intercepts, logps, mus, sigmas, zs, betas, weights, lambdas)
+                 if a is not None]
+        count = int(np.shape(given[0])[0])
+
+        def f(a, shape):
+            return None if a is None else _p(_f64(np.reshape(a, (count,) + shape), (count,) + shape))
+        zz = None if zs is None else _i64(zs, (count, T, N), 'zs')
+        self._ck(self._L.dlsm_hdp_trace_write(
+            self._h, int(first), count, f(Xs, (T, N, D)),
+            None if intercepts is None else _p(_f64(np.reshape(intercepts, (count, -1))[:, 0].copy())),
+            f(logps, ()), f(mus, (K, D)), f(sigmas, (K,)), None if zz is None else _p(zz),
+            f(betas, (K,)), f(weights, (T, K, K)), f(lambdas, ())))
 
     def hdp_get_aux(self):
         """auxiliary variables of the last iteration: m, m_bar, w_over, n, nk"""
@@ -524,6 +552,51 @@ class Chain(object):
 
     def post_release(self):
         self._ck(self._L.dlsm_post_release(self._h))
+
+    # the same on the device-resident trace of hdp_run (rows first .. first + count - 1)
+    def post_trace_label_counts(self, first, count):
+        """(count, T, K) int32: nodes per label, time and stored sample"""
+        nk = np.empty((count, self.T, self.K), dtype=np.int32)
+        self._ck(self._L.dlsm_post_trace_label_counts(self._h, int(first), int(count),
+                                                      nk.ctypes.data_as(c_i32_p)))
+        return nk
+
+    def post_trace_cooccurrence(self, first, count, want_matrix=False):
+        """co-occurrence probabilities of the stored samples: returns (matrix or None, row sums
+        (T, N)); the matrices stay on the device for the VI sums / ``post_get_cooccurrence``"""
+        out = np.empty((self.T, self.N, self.N)) if want_matrix else None
+        rs = np.empty((self.T, self.N))
+        self._ck(self._L.dlsm_post_trace_cooccurrence(self._h, int(first), int(count),
+                                                      None if out is None else _p(out), _p(rs)))
+        self._post_S = int(count)
+        return out, rs
+
+    def post_get_cooccurrence(self):
+        out = np.empty((self.T, self.N, self.N))
+        self._ck(self._L.dlsm_post_get_cooccurrence(self._h, _p(out)))
+        return out
+
+    def post_trace_align(self, first, count, ref_row):
+        """rotate the stored positions and cluster means of the rows onto row ``ref_row``"""
+        self._ck(self._L.dlsm_post_trace_align(self._h, int(first), int(count), int(ref_row)))
+
+    def post_trace_mean(self, first, count):
+        out = np.empty((self.T, self.N, self.D))
+        self._ck(self._L.dlsm_post_trace_mean(self._h, int(first), int(count), _p(out)))
+        return out
+
+    def post_latent_marginal_loglik(self, init_w, trans_w, mu, sigma, lmbda, row=-1):
+        """approx_bic.py:54-76 at trace row ``row`` (-1: the chain's current positions)"""
+        Ka = int(np.shape(sigma)[0])
+        init_w = _f64(init_w, (Ka,), 'init_w')
+        trans_w = _f64(trans_w, (self.T, Ka, Ka), 'trans_w')
+        mu = _f64(mu, (Ka, self.D), 'mu')
+        sigma = _f64(sigma, (Ka,), 'sigma')
+        out = np.zeros(1)
+        self._ck(self._L.dlsm_post_latent_marginal_loglik(
+            self._h, int(row), _p(init_w), _p(trans_w), _p(mu), _p(sigma),
+            float(np.ravel(lmbda)[0]), Ka, _p(out)))
+        return float(out[0])
 
     # -- one-step-ahead forecasts (SURVEY.md 8f-4) ------------------------------
     def forecast_mean_probas(self, Xs, intercepts, zero_diag=False):

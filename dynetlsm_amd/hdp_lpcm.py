@@ -51,7 +51,14 @@ class DynamicNetworkHDPLPCM(FittedQuantities):
     iteration); ``'host'`` keeps the auxiliary / conjugate draws in numpy on the caller's
     MT19937 stream in the reference's order (the bit-level pin to the reference's ``_fit``
     trace, and the only form for directed models).  ``'auto'`` = device for undirected
-    models, host otherwise.  The two are equal in distribution."""
+    models, host otherwise.  The two are equal in distribution.
+
+    After a device-resident loop the post-loop processing (hdp_lpcm.py:1085-1162: model selection,
+    Procrustes alignment of every stored sample, posterior means) runs on the trace where it lies,
+    and ``Xs_``, ``zs_``, ``weights_`` and ``cooccurrence_probas_`` are copied to the host when they
+    are first read (320 KB per stored sample of positions at T=10, N=2000);
+    ``post_processing='host'`` copies the whole trace first and processes it in numpy, as thinning
+    and missing dyads always do."""
 
     def __init__(self, n_features=2, n_components=10, is_directed=False,
                  selection_type='vi', n_iter=5000, tune=2500, tune_interval=100,
@@ -63,7 +70,8 @@ class DynamicNetworkHDPLPCM(FittedQuantities):
                  lambda_variance_prior=0.01, sigma_prior_std=4.0,
                  mean_variance_prior_std=4.0, step_size_X='auto', step_size_intercept=0.1,
                  step_size_radii=175000, n_control=None, n_resample_control=100, copy=True,
-                 random_state=None, device=0, chain_id=0, sweep_algo=0, hdp_loop='auto'):
+                 random_state=None, device=0, chain_id=0, sweep_algo=0, hdp_loop='auto',
+                 post_processing='auto'):
         self.n_iter = n_iter
         self.hdp_loop = hdp_loop
         self.is_directed = is_directed
@@ -103,6 +111,7 @@ class DynamicNetworkHDPLPCM(FittedQuantities):
         self.device = device
         self.chain_id = chain_id
         self.sweep_algo = sweep_algo
+        self.post_processing = post_processing
 
     @property
     def n_burn_(self):
@@ -282,24 +291,31 @@ class DynamicNetworkHDPLPCM(FittedQuantities):
         rsamp = _ScalarMetropolis(self.step_size_radii, self.tune, dirichlet=True)
         self.intercept_samplers, self.radii_sampler = isamp, rsamp
 
-        self.Xs_ = np.zeros((n_total, T, N, D))
-        self.intercepts_ = np.zeros((n_total, n_ic))
-        self.mus_ = np.zeros((n_total, K, D))
-        self.sigmas_ = np.zeros((n_total, K))
-        self.zs_ = np.zeros((n_total, T, N), dtype=np.int64)
-        self.betas_ = np.zeros((n_total, K))
-        self.weights_ = np.zeros((n_total, T, K, K))
-        self.lambdas_ = np.zeros((n_total, 1))
-        self.radiis_ = np.zeros((n_total, N)) if self.is_directed else None
-        self.logps_ = np.zeros(n_total)
-
-        chain.set_prior_mixture(mu, sigma, lmbda, z)
         if self.hdp_loop not in ('auto', 'device', 'host'):
             raise ValueError("hdp_loop must be 'auto', 'device' or 'host'")
         if self.hdp_loop == 'device' and self.is_directed:
             raise ValueError("hdp_loop='device' covers undirected models")
         self.loop_kind_ = ('host-driven' if (self.is_directed or self.hdp_loop == 'host')
                            else 'device-resident')
+        # The device-resident loop keeps its trace in HBM; the three large arrays - Xs_
+        # (320 KB per sample at T=10, N=2000), zs_, weights_ - reach the host only when somebody
+        # reads them (__getattr__), and the post-loop processing runs where they lie.
+        self._lazy_trace = False
+        for name in ('Xs_', 'zs_', 'weights_', 'cooccurrence_probas_'):
+            self.__dict__.pop(name, None)
+        if self.loop_kind_ == 'host-driven':
+            self.Xs_ = np.zeros((n_total, T, N, D))
+            self.zs_ = np.zeros((n_total, T, N), dtype=np.int64)
+            self.weights_ = np.zeros((n_total, T, K, K))
+        self.intercepts_ = np.zeros((n_total, n_ic))
+        self.mus_ = np.zeros((n_total, K, D))
+        self.sigmas_ = np.zeros((n_total, K))
+        self.betas_ = np.zeros((n_total, K))
+        self.lambdas_ = np.zeros((n_total, 1))
+        self.radiis_ = np.zeros((n_total, N)) if self.is_directed else None
+        self.logps_ = np.zeros(n_total)
+
+        chain.set_prior_mixture(mu, sigma, lmbda, z)
         self._n_total, self._rng, self._ip, self._miss = n_total, rng, ip, miss
         self._sums = hu.DeviceLabelSums(chain)  # label-wise sums at the chain's X and z
         self._st = dict(X=X, intercept=intercept, mu=mu, sigma=sigma, z=z, beta=beta,
@@ -317,6 +333,14 @@ class DynamicNetworkHDPLPCM(FittedQuantities):
         trace arrays"""
         if self.loop_kind_ != 'device-resident' or count <= 0:
             return
+        n_total, T, N = self._n_total, self.chain_.T, self.chain_.N
+        K, D = self.n_components, self.n_features
+        if 'Xs_' not in self.__dict__:      # the eager path: every array on the host
+            self.Xs_ = np.zeros((n_total, T, N, D))
+            self.zs_ = np.zeros((n_total, T, N), dtype=np.int64)
+            self.weights_ = np.zeros((n_total, T, K, K))
+            tr0 = self.chain_.hdp_trace_read(0, 1)
+            self.Xs_[0], self.zs_[0], self.weights_[0] = tr0['Xs'][0], tr0['zs'][0], tr0['weights'][0]
         tr = self.chain_.hdp_trace_read(first, count)
         sl = slice(first, first + count)
         self.Xs_[sl], self.intercepts_[sl], self.logps_[sl] = tr['Xs'], tr['intercepts'], tr['logps']
@@ -328,9 +352,11 @@ class DynamicNetworkHDPLPCM(FittedQuantities):
 
     def _store(self, it, ll):
         st, hp = self._st, self.hyper_
-        self.Xs_[it], self.intercepts_[it] = st['X'], st['intercept']
-        self.mus_[it], self.sigmas_[it], self.zs_[it] = st['mu'], st['sigma'], st['z']
-        self.betas_[it], self.weights_[it] = st['beta'], st['weights']
+        self.intercepts_[it] = st['intercept']
+        self.mus_[it], self.sigmas_[it] = st['mu'], st['sigma']
+        self.betas_[it] = st['beta']
+        if 'Xs_' in self.__dict__:          # (device-resident loop: row 0 of its trace is the device's)
+            self.Xs_[it], self.zs_[it], self.weights_[it] = st['X'], st['z'], st['weights']
         self.lambdas_[it] = st['lmbda']
         if self.is_directed:
             self.radiis_[it] = st['radii']
@@ -404,9 +430,71 @@ class DynamicNetworkHDPLPCM(FittedQuantities):
                       weights=weights, lmbda=lmbda, radii=radii)
             self._store(it, ll)
 
+    # ---- the large arrays of a device-resident trace, on demand --------------------------------
+    def __getattr__(self, name):            # reached only when the attribute is not there
+        d = self.__dict__
+        if name in ('Xs_', 'zs_', 'weights_') and d.get('_lazy_trace') and d.get('chain_') is not None:
+            key = {'Xs_': 'Xs', 'zs_': 'zs', 'weights_': 'weights'}[name]
+            tr = d['chain_'].hdp_trace_read(0, d['_n_total'], positions=name == 'Xs_',
+                                            labels=name == 'zs_', weights=name == 'weights_',
+                                            small=False)
+            d[name] = tr[key]
+            return d[name]
+        if name == 'cooccurrence_probas_' and d.get('_lazy_cooc') and d.get('chain_') is not None:
+            d[name] = d['chain_'].post_get_cooccurrence()
+            d['chain_'].post_release()
+            d['_lazy_cooc'] = False
+            return d[name]
+        raise AttributeError(name)
+
+    def _finish_on_device(self):
+        """``_finish`` for the device-resident loop without thinning or missing dyads: model
+        selection, Procrustes alignment and the posterior means run on the trace in HBM
+        (hdp_lpcm.py:1085-1162); the host receives the scalar traces, the cluster parameters and
+        the selected sample."""
+        chain, hp, n_total = self.chain_, self.hyper_, self._n_total
+        tr = chain.hdp_trace_read(0, n_total, positions=False, labels=False, weights=False)
+        self.intercepts_, self.logps_ = tr['intercepts'], tr['logps']
+        self.mus_, self.sigmas_, self.betas_ = tr['mus'], tr['sigmas'], tr['betas']
+        self.lambdas_, self.hypers_ = tr['lambdas'], tr['hypers']
+        self._trace_logliks = tr['logliks']
+        self._lazy_trace = True
+        cfg = chain.hdp_get_config()
+        hp.gamma, hp.alpha_init, hp.alpha, hp.kappa = cfg.gamma, cfg.alpha_init, cfg.alpha, cfg.kappa
+        hp.mean_variance_prior, hp.b = cfg.mean_variance_prior, cfg.b
+        sm = self.intercept_samplers[0]
+        sm.step_size, sm.n_accepted = cfg.i_step_size, cfg.i_n_accepted
+        sm.n_steps, sm.steps_until_tune = cfg.i_n_steps, cfg.i_steps_until_tune
+        last = post._trace_row(chain, n_total - 1)
+        self._st.update(X=last['X'], intercept=last['intercept'], mu=last['mu'], sigma=last['sigma'],
+                        z=last['z'], beta=last['beta'], weights=last['weights'], lmbda=last['lmbda'])
+        chain.get_samplers(self.latent_samplers)
+        self.gamma, self.alpha_init, self.alpha, self.kappa = (hp.gamma, hp.alpha_init,
+                                                               hp.alpha, hp.kappa)
+        self.mean_variance_prior_, self.b_ = hp.mean_variance_prior, hp.b
+        n_burn = min(self.n_burn_, n_total - 1)
+        post.select_model_device(self, chain, n_burn)
+        # Procrustes: every stored sample (and its cluster means) onto the selected one (:1141-1146)
+        chain.post_trace_align(0, n_total, self.selected_id_)
+        self.mus_ = chain.hdp_trace_read(0, n_total, positions=False, labels=False,
+                                         weights=False)['mus']
+        self.posterior_group_ids_, self.posterior_group_counts_ = post.posterior_group_counts_from(
+            self._counts_t)
+        self.X_mean_ = chain.post_trace_mean(n_burn, n_total - n_burn)
+        self.lambda_mean_ = self.lambdas_[n_burn:].mean(axis=0)
+        self.intercepts_mean_ = self.intercepts_[n_burn:].mean(axis=0)
+        with np.errstate(all='ignore'):
+            self.logp_geweke_ = _geweke(self.logps_, n_burn)
+            self.lambda_geweke_ = _geweke(self.lambdas_[:, 0], n_burn)
+            self.intercept_geweke_ = _geweke(self.intercepts_[:, 0], n_burn)
+        return self
+
     def _finish(self):
         """Everything of ``fit`` after the Gibbs loop (hdp_lpcm.py:1072-1176)."""
         chain, hp, n_total = self.chain_, self.hyper_, self._n_total
+        if (self.loop_kind_ == 'device-resident' and self.thin is None and self._miss is None
+                and self.post_processing != 'host'):
+            return self._finish_on_device()
         if self.loop_kind_ == 'device-resident':
             self._pull(1, n_total - 1)
             cfg = chain.hdp_get_config()

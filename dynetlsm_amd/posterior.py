@@ -15,7 +15,8 @@ import numpy as np
 __all__ = ['cluster_counts', 'cluster_counts_t', 'renormalize_weights',
            'latent_marginal_loglikelihood', 'select_bic', 'posterior_cooccurrences',
            'expected_vi', 'minimize_posterior_expected_vi', 'procrustes_align_samples',
-           'posterior_group_counts', 'select_model']
+           'posterior_group_counts', 'select_model', 'select_model_device',
+           'posterior_group_counts_from']
 
 
 def _presence(zs, K):
@@ -162,6 +163,127 @@ def procrustes_align_samples(model):
         R, _ = orthogonal_procrustes(flat, ref)
         model.Xs_[idx] = flat.dot(R).reshape(model.Xs_[idx].shape)
         model.mus_[idx] = model.mus_[idx].dot(R)
+
+
+def _renormalize_row(row, T, N):
+    """label_utils.py:10-37 for one stored sample given as a dict (z, beta, weights, mu, sigma)"""
+    active = np.unique(row['z'].ravel())
+    beta = row['beta'][active]
+    beta = beta / beta.sum()
+    init_w = row['weights'][0, 0, active]
+    init_w = init_w / init_w.sum()
+    trans_w = np.zeros((T, active.shape[0], active.shape[0]))
+    for t in range(1, T):
+        trans_w[t] = row['weights'][t, active][:, active]
+        trans_w[t] /= np.sum(trans_w[t], axis=1).reshape(-1, 1)
+    _, z = np.unique(row['z'].ravel(), return_inverse=True)
+    return z.reshape(T, N), beta, init_w, trans_w, row['mu'][active], row['sigma'][active]
+
+
+def _trace_row(chain, sid):
+    """one stored sample of the device-resident trace as a dict"""
+    tr = chain.hdp_trace_read(int(sid), 1)
+    return dict(X=tr['Xs'][0], z=tr['zs'][0], weights=tr['weights'][0], beta=tr['betas'][0],
+                mu=tr['mus'][0], sigma=tr['sigmas'][0], intercept=tr['intercepts'][0],
+                lmbda=tr['lambdas'][0])
+
+
+def select_model_device(model, chain, n_burn):
+    """``select_model`` for the undirected model's device-resident trace: the label counts, the
+    co-occurrence matrices, the VI sums, the network log-likelihoods and the forward-algorithm
+    marginal likelihood (approx_bic.py:54-76) come from kernels over the trace where it lies; the
+    host sees (S, T, K) counts, (T, S) sums and the handful of samples it selects - never the
+    positions or labels of all samples.  Same attributes as ``select_model``;
+    ``cooccurrence_probas_`` is left on the device (the estimator pulls it when it is asked for)."""
+    n_total = model.logps_.shape[0]
+    S = n_total - n_burn
+    T, N = chain.T, chain.N
+    nk = chain.post_trace_label_counts(n_burn, S)                  # (S, T, K)
+    present = nk > 0
+    counts = present.any(axis=1).sum(axis=1)                       # approx_bic.py:40-51
+    model._counts_t = present.sum(axis=2).T                        # approx_bic.py:26-37: (T, S)
+    Y = model.Y_fit_
+    off_diag_sum = np.sum(Y) - np.einsum('ikk', Y).sum()
+
+    def network_loglik(row):
+        chain.set_positions(row['X'])
+        return chain.loglik_full([row['intercept']])[0]
+
+    # approx_bic.py:79-162
+    bic, models = [], []
+    for k in np.unique(counts):
+        lp = np.where(counts == k, model.logps_[n_burn:], -np.inf)
+        map_id = int(np.argmax(lp)) + n_burn
+        row = _trace_row(chain, map_id)
+        z, beta, init_w, trans_w, mu, sigma = _renormalize_row(row, T, N)
+        loglik_k = network_loglik(row)
+        bic_k = -2 * loglik_k + np.log(0.5 * off_diag_sum)
+        bic_k -= 2 * chain.post_latent_marginal_loglik(init_w, trans_w, mu, sigma, row['lmbda'],
+                                                       row=map_id)
+        n_params = ((model.n_features + 1) * k + (k - 1) + (k - 1) + (T - 1) * k * (k - 1))
+        bic_k += n_params * np.log(N * T)
+        models.append(SimpleNamespace(beta=beta, init_weights=init_w, trans_weights=trans_w,
+                                      X=row['X'], mu=mu, sigma=sigma, lmbda=row['lmbda'], z=row['z'],
+                                      intercept=row['intercept'], radii=None))
+        bic.append([k, bic_k, loglik_k, map_id])
+    model.bic_, model.models_, model.counts_ = np.array(bic), models, counts
+    # hdp_lpcm.py:1180-1186 (the matrices stay on the device)
+    _, row_sums = chain.post_trace_cooccurrence(n_burn, S, want_matrix=False)
+    model._lazy_cooc = True
+    if model.selection_type == 'vi':
+        sums = chain.post_expected_vi_sums()                       # (T, S)
+        nkf = nk.astype(np.float64)
+        with np.errstate(divide='ignore', invalid='ignore'):
+            t1 = np.where(nk > 0, nkf * np.log2(nkf), 0.0).sum(axis=2)     # posterior_vi.py:31-36
+        t3 = np.log2(row_sums).sum(axis=1)
+        vis = ((t1 - 2 * sums.T + t3[None, :]) / N).mean(axis=1)
+        mins = np.where(vis == vis.min())[0]
+        best = int(mins[0]) + n_burn
+        if mins.shape[0] > 1:                                      # posterior_vi.py:62-80
+            # ties (identical partitions: thousands once the chain has settled) go to the highest
+            # network log-likelihood, first one on equality; the loop stored it with every sample
+            lls = np.array(getattr(model, '_trace_logliks', np.full(n_total, np.nan)))[mins + n_burn]
+            for q in np.where(np.isnan(lls))[0]:
+                lls[q] = network_loglik(_trace_row(chain, int(mins[q]) + n_burn))
+            best = int(mins[int(np.argmax(lls))]) + n_burn
+        model.expected_vis_ = vis
+        row = _trace_row(chain, best)
+        model.logp_ = model.logps_[best]
+        model.X_, model.intercept_ = row['X'].copy(), row['intercept']
+        model.lambda_ = row['lmbda']
+        (model.z_, model.beta_, model.init_weights_, model.trans_weights_, model.mu_,
+         model.sigma_) = _renormalize_row(row, T, N)
+        model.selected_id_ = best
+    else:
+        if model.selection_type == 'bic':
+            mid = int(np.argmin(model.bic_[:, 1]))
+            model.best_k_ = int(model.bic_[mid, 0])
+        elif model.selection_type == 'map':
+            model.best_k_ = int(np.argmax(np.bincount(model.counts_)))
+            mid = int(np.argwhere(model.bic_[:, 0] == model.best_k_)[0, 0])
+        else:
+            raise ValueError('Selection type not recognized')
+        m = model.models_[mid]
+        model.selected_id_ = int(model.bic_[mid, 3])
+        model.logp_ = model.logps_[model.selected_id_]
+        model.X_, model.intercept_ = m.X.copy(), m.intercept
+        model.mu_, model.sigma_ = m.mu, m.sigma
+        _, z = np.unique(m.z.ravel(), return_inverse=True)
+        model.z_ = z.reshape(T, N)
+        model.beta_, model.init_weights_ = m.beta, m.init_weights
+        model.trans_weights_, model.lambda_ = m.trans_weights, m.lmbda
+    return model
+
+
+def posterior_group_counts_from(counts_t):
+    """label_utils.py:73-81 for every t, from the (T, S) numbers of labels in use"""
+    ids, freqs = [], []
+    for row in counts_t:
+        freq = np.bincount(row)
+        index = np.where(freq != 0)[0]
+        ids.append(index)
+        freqs.append(freq[index])
+    return ids, freqs
 
 
 def posterior_group_counts(model, n_burn):

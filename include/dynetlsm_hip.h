@@ -254,6 +254,14 @@ int dlsm_hdp_run(dlsm_chain *h, int first, int count);
 int dlsm_hdp_trace_read(dlsm_chain *h, int first, int count, double *Xs, double *intercepts,
                         double *logps, double *mus, double *sigmas, int64_t *zs, double *betas,
                         double *weights, double *lambdas, double *hypers);
+/* the mirror of dlsm_hdp_trace_read (undirected model: one intercept per row): rows first ..
+ * first+count-1 of the device-resident trace from host arrays; any pointer may be NULL.  Lets a
+ * caller continue or post-process on the device a trace it holds on the host (the reference
+ * keeps Xs_, zs_, ... as attributes of the fitted estimator, hdp_lpcm.py:691-747). */
+int dlsm_hdp_trace_write(dlsm_chain *h, int first, int count, const double *Xs,
+                         const double *intercepts, const double *logps, const double *mus,
+                         const double *sigmas, const int64_t *zs, const double *betas,
+                         const double *weights, const double *lambdas);
 /* auxiliary variables of the last iteration (tests): m T*K*K tables, m_bar K, w_over (T-1)*K
  * override counts, n T*K*K and nk T*K label counts */
 int dlsm_hdp_get_aux(dlsm_chain *h, int64_t *m, double *m_bar, int64_t *w_over, int64_t *n,
@@ -304,6 +312,31 @@ int dlsm_post_cooccurrence(dlsm_chain *h, const int64_t *zs, int S, int K, doubl
  * out[t*S + s] = sum_i log2( sum_j cooc[t,i,j] [z_stj == z_sti] ) for every kept sample */
 int dlsm_post_expected_vi_sums(dlsm_chain *h, double *out);
 int dlsm_post_release(dlsm_chain *h);
+/* The same processing straight from the device-resident trace of dlsm_hdp_run (rows
+ * first .. first + count - 1 = the kept samples), so that fit() does not move the trace to the host
+ * and back (hdp_lpcm.py:1085-1162):
+ *   label_counts: nk count*T*K int32, nodes per label, time and sample - what approx_bic.py:26-51
+ *     (models' sizes), posterior_vi.py:31-36 (the n_k log2 n_k term) and label_utils.py:73-81
+ *     (posterior group counts) are computed from;
+ *   cooccurrence: as dlsm_post_cooccurrence; cooc_out (T*N*N) and row_sums (T*N: sum_j C_t[i][j],
+ *     posterior_vi.py:43) may be NULL; the matrices stay on the device for the VI sums and
+ *     dlsm_post_get_cooccurrence;
+ *   align: hdp_lpcm.py:1141-1146 - every row (positions and cluster means) rotated onto row
+ *     `ref_row` by the orthogonal Procrustes rotation over all T N positions (procrustes.py:20-35,
+ *     scipy.linalg.orthogonal_procrustes), in place on the device;
+ *   mean: X_mean_ (T*N*D) = mean of the rows (hdp_lpcm.py:1149). */
+int dlsm_post_trace_label_counts(dlsm_chain *h, int first, int count, int32_t *nk);
+int dlsm_post_trace_cooccurrence(dlsm_chain *h, int first, int count, double *cooc_out,
+                                 double *row_sums);
+int dlsm_post_get_cooccurrence(dlsm_chain *h, double *cooc_out);
+int dlsm_post_trace_align(dlsm_chain *h, int first, int count, int ref_row);
+int dlsm_post_trace_mean(dlsm_chain *h, int first, int count, double *X_mean);
+/* latent_marginal_loglikelihood (model_selection/approx_bic.py:54-76): forward algorithm over
+ * the label chain of every node, at trace row `row` (row < 0: the handle's current positions);
+ * init_w K, trans_w T*K*K (trans_w[0] unused), mu K*D, sigma K (variances), K <= 64 */
+int dlsm_post_latent_marginal_loglik(dlsm_chain *h, int row, const double *init_w,
+                                     const double *trans_w, const double *mu, const double *sigma,
+                                     double lmbda, int K, double *out);
 
 /* ---- one-step-ahead forecasts (undirected models) ------ */
 /* the accumulation of forecast_probas / forecast_probas_pp_ (hdp_lpcm.py:555-626):

@@ -661,6 +661,20 @@ def gen_post(ref):
         bic, models, counts = select_bic(m)
         z_r, beta_r, init_w, trans_w, mu_r, sigma_r = renormalize_weights(m, sample_id=best)
         gc = [calculate_posterior_group_counts(m, t=t) for t in range(T)]
+        # hdp_lpcm.py:1141-1149: every stored sample (and its means) rotated onto the selected
+        # one by the reference's own procrustes.py, the posterior mean of the aligned positions;
+        # approx_bic.py:54-76 at the selected sample
+        from dynetlsm.procrustes import longitudinal_procrustes_rotation
+        from dynetlsm.model_selection.approx_bic import latent_marginal_loglikelihood
+        X_al, mus_al = Xs.copy(), m.mus_.copy()
+        for s_ in range(S):
+            X_al[s_], R_ = longitudinal_procrustes_rotation(Xs[best], Xs[s_])
+            mus_al[s_] = np.dot(m.mus_[s_], R_)
+        out[tag + '_Xs_aligned'] = X_al
+        out[tag + '_mus_aligned'] = mus_al
+        out[tag + '_X_mean'] = X_al[n_burn:].mean(axis=0)
+        out[tag + '_latent_marginal'] = np.array(latent_marginal_loglikelihood(
+            Xs[best], init_w, trans_w, mu_r, sigma_r, m.lambdas_[best]))
         for k_, v_ in dict(Y=Y, zs=zs, Xs=Xs, intercepts=m.intercepts_, mus=m.mus_,
                            sigmas=m.sigmas_, betas=m.betas_, weights=m.weights_,
                            lambdas=m.lambdas_, logps=m.logps_, n_burn=np.array(n_burn),
