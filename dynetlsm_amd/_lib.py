@@ -128,6 +128,8 @@ SIGNATURES = {
                                       C.c_double, c_double_p, c_double_p, c_i32_p,
                                       c_double_p]),
     'dlsm_init_mle_sums': (C.c_int, [handle_t, C.c_double, C.c_double, c_double_p]),
+    'dlsm_init_kmeans_lloyd': (C.c_int, [handle_t, c_double_p, C.c_int, C.c_int, C.c_int, c_double_p,
+                                         C.c_int, C.c_double, c_double_p, c_i32_p, c_i32_p, c_i32_p]),
     'dlsm_init_release': (C.c_int, [handle_t]),
     'dlsm_post_cooccurrence': (C.c_int, [handle_t, c_i64_p, C.c_int, C.c_int, c_double_p]),
     'dlsm_post_expected_vi_sums': (C.c_int, [handle_t, c_double_p]),

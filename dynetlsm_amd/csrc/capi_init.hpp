@@ -252,4 +252,67 @@ int dlsm_init_release(dlsm_chain *h) {
     return DLSM_OK;
 }
 
+int dlsm_init_kmeans_lloyd(dlsm_chain *h, const double *X, int N, int F, int K,
+                           const double *centers_init, int max_iter, double tol, double *centers_out,
+                           int32_t *labels_out, int32_t *n_iter_out, int32_t *empty_out) {
+    NEED(h, h && X && centers_init && centers_out && labels_out && n_iter_out && empty_out, "null argument");
+    NEED(h, N >= 1 && F >= 1 && K >= 1 && K <= N && max_iter >= 1, "bad sizes");
+    const size_t lds = ((size_t)K * F + K) * sizeof(double);
+    NEED(h, lds <= 64 * 1024, "the centres (n_clusters x T d doubles) do not fit the assignment kernel's LDS");
+    HIPCHK(h, hipSetDevice(h->device));
+    DevBuf dX, dC, dL, dS;
+    HIPCHK(h, hipMalloc(&dX.p, (size_t)N * F * sizeof(double)));
+    HIPCHK(h, hipMalloc(&dC.p, (size_t)2 * K * F * sizeof(double)));
+    HIPCHK(h, hipMalloc(&dL.p, (size_t)N * sizeof(int32_t)));
+    HIPCHK(h, hipMalloc(&dS.p, (size_t)K * (sizeof(double) + sizeof(int32_t)) + 16));
+    double *cen[2] = {dC.as<double>(), dC.as<double>() + (size_t)K * F};
+    double *d_shift = dS.as<double>();
+    int32_t *d_counts = (int32_t *)(d_shift + K), *d_changed = d_counts + K;
+    HIPCHK(h, hipMemcpyAsync(dX.p, X, (size_t)N * F * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(cen[0], centers_init, (size_t)K * F * sizeof(double), hipMemcpyHostToDevice,
+                             h->stream));
+    HIPCHK(h, hipMemsetAsync(dL.p, 0xFF, (size_t)N * sizeof(int32_t), h->stream));      // labels = -1
+    std::vector<double> shift(K);
+    std::vector<int32_t> counts(K + 1);
+    const int nb = (N + 255) / 256;
+    int cur = 0, it = 0;
+    bool strict = false;
+    *empty_out = 0;
+    ProfScope ps(h, DLSM_K_INIT);
+    // _kmeans_single_lloyd (sklearn/cluster/_kmeans.py): E + M step, then "labels unchanged"
+    // (strict convergence) or the squared centre shift within tol; when the loop ends otherwise,
+    // one more E-step so that the labels match the returned centres
+    for (it = 0; it < max_iter; ++it) {
+        HIPCHK(h, hipMemsetAsync(d_changed, 0, sizeof(int32_t), h->stream));
+        hipLaunchKernelGGL(k_kmeans_assign, dim3(nb), dim3(256), lds, h->stream, dX.as<double>(), N, F, K,
+                           cen[cur], dL.as<int32_t>(), d_changed);
+        hipLaunchKernelGGL(k_kmeans_update, dim3(K), dim3(256), 0, h->stream, dX.as<double>(), N, F,
+                           dL.as<int32_t>(), cen[cur], cen[cur ^ 1], d_counts, d_shift);
+        HIPCHK(h, hipGetLastError());
+        HIPCHK(h, hipMemcpyAsync(shift.data(), d_shift, K * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipMemcpyAsync(counts.data(), d_counts, (K + 1) * sizeof(int32_t), hipMemcpyDeviceToHost,
+                                 h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        for (int k = 0; k < K; ++k)
+            if (counts[k] == 0) { *empty_out = 1; *n_iter_out = it + 1; return DLSM_OK; }   // relocation: the caller's
+        cur ^= 1;
+        if (counts[K] == 0) { strict = true; ++it; break; }
+        double tot = 0.0;
+        for (int k = 0; k < K; ++k) tot += shift[k];
+        if (tot <= tol) { ++it; break; }
+    }
+    if (!strict) {
+        HIPCHK(h, hipMemsetAsync(d_changed, 0, sizeof(int32_t), h->stream));
+        hipLaunchKernelGGL(k_kmeans_assign, dim3(nb), dim3(256), lds, h->stream, dX.as<double>(), N, F, K,
+                           cen[cur], dL.as<int32_t>(), d_changed);
+        HIPCHK(h, hipGetLastError());
+    }
+    *n_iter_out = std::min(it, max_iter);
+    HIPCHK(h, hipMemcpyAsync(centers_out, cen[cur], (size_t)K * F * sizeof(double), hipMemcpyDeviceToHost,
+                             h->stream));
+    HIPCHK(h, hipMemcpyAsync(labels_out, dL.p, (size_t)N * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return DLSM_OK;
+}
+
 }  // extern "C"

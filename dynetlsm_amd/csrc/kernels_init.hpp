@@ -473,4 +473,75 @@ __global__ __launch_bounds__(1024) void k_sum_records(const double *__restrict__
     }
 }
 
+// ---- longitudinal k-means (latent_space.py:98-137 -> sklearn.cluster.KMeans, Lloyd) ------------
+// scikit-learn's lloyd_iter_chunked_dense on the centred N x F matrix of time-stacked
+// trajectories (F = T d): the E-step assigns a sample to argmin_k |c_k|^2 - 2 x.c_k (first
+// minimum), the M-step averages the members.  The seeding (k-means++) draws from the caller's
+// RandomState and stays on the host, as the BFGS driver of the conditional MLEs does.
+// labels[i], changed (a count) by the first kernel; centres, member counts, squared shift by the
+// second (one workgroup per cluster, members summed in index order: reproducible).
+__global__ __launch_bounds__(256) void k_kmeans_assign(const double *__restrict__ X, int N, int F, int K,
+                                                       const double *__restrict__ centers,
+                                                       int32_t *__restrict__ labels,
+                                                       int32_t *__restrict__ changed) {
+    extern __shared__ double km_sC[];              // K x F centres, K squared norms
+    double *sN = km_sC + (size_t)K * F;
+    for (int q = threadIdx.x; q < K * F; q += 256) km_sC[q] = centers[q];
+    __syncthreads();
+    for (int k = threadIdx.x; k < K; k += 256) {
+        double n2 = 0.0;
+        for (int f = 0; f < F; ++f) n2 = fma(km_sC[k * F + f], km_sC[k * F + f], n2);
+        sN[k] = n2;
+    }
+    __syncthreads();
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const double *x = X + (size_t)i * F;
+    int best = 0;
+    double bestv = 0.0;
+    for (int k = 0; k < K; ++k) {
+        double dot = 0.0;
+        for (int f = 0; f < F; ++f) dot = fma(x[f], km_sC[k * F + f], dot);
+        const double v = fma(-2.0, dot, sN[k]);
+        if (k == 0 || v < bestv) { bestv = v; best = k; }
+    }
+    if (labels[i] != best) atomicAdd(changed, 1);
+    labels[i] = best;
+}
+
+__global__ __launch_bounds__(256) void k_kmeans_update(const double *__restrict__ X, int N, int F,
+                                                       const int32_t *__restrict__ labels,
+                                                       const double *__restrict__ centers_old,
+                                                       double *__restrict__ centers_new,
+                                                       int32_t *__restrict__ counts,
+                                                       double *__restrict__ shift_sq) {
+    __shared__ double sRed[4];
+    __shared__ int sCnt[4];
+    const int k = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int cnt = 0;
+    for (int i = tid; i < N; i += 256) cnt += labels[i] == k;
+    {
+        double c = wave_sum_all((double)cnt);
+        if (lane == 0) sCnt[wave] = (int)c;
+    }
+    __syncthreads();
+    const int total = (sCnt[0] + sCnt[1]) + (sCnt[2] + sCnt[3]);
+    __syncthreads();
+    double sh = 0.0;
+    for (int f = 0; f < F; ++f) {
+        double v = 0.0;
+        for (int i = tid; i < N; i += 256) v += labels[i] == k ? X[(size_t)i * F + f] : 0.0;
+        v = wave_sum_all(v);
+        if (lane == 0) sRed[wave] = v;
+        __syncthreads();
+        const double sum = (sRed[0] + sRed[1]) + (sRed[2] + sRed[3]);
+        __syncthreads();
+        const double cn = total > 0 ? sum / (double)total : centers_old[k * F + f];
+        if (tid == 0) centers_new[k * F + f] = cn;
+        const double df = cn - centers_old[k * F + f];
+        sh = fma(df, df, sh);
+    }
+    if (tid == 0) { counts[k] = total; shift_sq[k] = sh; }
+}
+
 }  // namespace dlsm

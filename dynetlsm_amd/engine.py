@@ -535,6 +535,21 @@ class Chain(object):
         self._ck(self._L.dlsm_init_release(self._h))
 
     # -- post-loop processing ---------------------------------
+    def init_kmeans_lloyd(self, Xc, centers_init, max_iter=300, tol=0.0):
+        """scikit-learn's Lloyd loop on the centred (N, F) matrix from the given seeding; returns
+        (centers, labels, n_iter) or None when a cluster emptied (the caller finishes on the host)"""
+        Xc = _f64(Xc)
+        N, F = Xc.shape
+        K = int(np.shape(centers_init)[0])
+        c0 = _f64(centers_init, (K, F), 'centers_init')
+        cen = np.empty((K, F)); lab = np.empty(N, dtype=np.int32)
+        nit = np.zeros(1, dtype=np.int32); empty = np.zeros(1, dtype=np.int32)
+        self._ck(self._L.dlsm_init_kmeans_lloyd(self._h, _p(Xc), N, F, K, _p(c0), int(max_iter),
+                                                float(tol), _p(cen), _p(lab), _p(nit), _p(empty)))
+        if empty[0]:
+            return None
+        return cen, lab, int(nit[0])
+
     def post_cooccurrence(self, zs, K, want_matrix=True):
         """co-occurrence probabilities of the kept samples ``zs`` (S, T, N); returns the
         (T, N, N) matrices (or None) and keeps them on the device for the VI sums"""

@@ -170,7 +170,10 @@ class DynamicNetworkHDPLPCM(FittedQuantities):
             sigma = np.array(init['sigma'], dtype=np.float64)
             z = np.array(init['z'], dtype=np.int64)
         else:
-            mu, sigma, z = init_mod.longitudinal_kmeans(X, n_clusters=K, random_state=rng)
+            # the Lloyd iterations of longitudinal_kmeans run on the device (any handle will do)
+            with Chain(1, N, D, 'undirected', device=self.device) as tmp:
+                mu, sigma, z = init_mod.longitudinal_kmeans(X, n_clusters=K, random_state=rng,
+                                                            chain=tmp)
             z = z.astype(np.int64)
         weights = np.zeros((T, K, K))
         weights[0, 0] = np.bincount(z[0], minlength=K) / N

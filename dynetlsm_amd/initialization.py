@@ -13,7 +13,7 @@ than the chain itself.  Here the O(N^2)-and-up parts are kernels of the engine
 
 The host keeps what is O(1) or O(N): the 2-parameter BFGS driver
 (scipy.optimize.minimize, as the reference), the radii (a degree count) and
-longitudinal k-means on the N x (T D) trajectories.
+seeding of longitudinal k-means (its Lloyd iterations run on the device).
 """
 import warnings
 
@@ -88,17 +88,82 @@ def directed_intercept_mle(chain, X, radii, tol=1e-4):
     return res.x[0], res.x[1]
 
 
-def longitudinal_kmeans(X, n_clusters=5, var_reg=1e-3, random_state=None):
+def kmeans_plusplus_seeds(Xc, n_clusters, rs):
+    """scikit-learn 1.7's ``_kmeans_plusplus`` (Arthur & Vassilvitskii with 2 + log k local
+    trials) restated in numpy - the same draws from ``rs`` in the same order (``choice``, then one
+    ``uniform(size=n_local_trials)`` per centre), the same distance expression
+    (|x|^2 - 2 x.y + |y|^2 through the same BLAS product, clipped at 0), the same cumulative sums -
+    so that the seeds, and with them labels and centres, are the library's bit for bit
+    (tests/test_init_oracle_golden.py against ``sklearn.cluster.kmeans_plusplus`` itself) without
+    importing ``sklearn.cluster`` (half a second, half of what ``fit`` spends before its loop)."""
+    n, _ = Xc.shape
+    x2 = np.einsum('ij,ij->i', Xc, Xc)          # sklearn.utils.extmath.row_norms(squared=True)
+    w = np.ones(n)
+
+    def dist_sq(C):                              # sklearn.metrics.pairwise._euclidean_distances
+        d = -2 * (C @ Xc.T)
+        d += np.einsum('ij,ij->i', C, C)[:, np.newaxis]
+        d += x2[np.newaxis, :]
+        np.maximum(d, 0, out=d)
+        return d
+    centers = np.empty((n_clusters, Xc.shape[1]))
+    n_local_trials = 2 + int(np.log(n_clusters))
+    center_id = rs.choice(n, p=w / w.sum())
+    centers[0] = Xc[center_id]
+    closest = dist_sq(centers[0, np.newaxis])
+    current_pot = closest @ w
+    for c in range(1, n_clusters):
+        rand_vals = rs.uniform(size=n_local_trials) * current_pot
+        cand = np.searchsorted(np.cumsum(w * closest, dtype=np.float64).ravel(), rand_vals)
+        np.clip(cand, None, closest.size - 1, out=cand)
+        d = dist_sq(Xc[cand])
+        np.minimum(closest, d, out=d)
+        pots = d @ w.reshape(-1, 1)
+        best = np.argmin(pots)
+        current_pot = pots[best]
+        closest = d[best]
+        centers[c] = Xc[cand[best]]
+    return centers
+
+
+def _kmeans(X_vec, n_clusters, random_state, chain):
+    """``KMeans(n_clusters, random_state=random_state).fit(X_vec)`` (scikit-learn >= 1.4 defaults:
+    k-means++ seeding, one start, Lloyd, tol 1e-4, 300 iterations) with the Lloyd iterations on
+    the device: the data are centred and seeded exactly as ``KMeans.fit`` does - ``kmeans_plusplus``
+    draws from the caller's RandomState, so the stream ends where the library's would - and
+    ``Chain.init_kmeans_lloyd`` runs _kmeans_single_lloyd's loop.  Returns (labels, centers)."""
+    if chain is None:
+        from sklearn.cluster import KMeans
+        km = KMeans(n_clusters=n_clusters, random_state=random_state).fit(X_vec)
+        return km.labels_, km.cluster_centers_
+    from .lsm import check_random_state                    # sklearn.utils.check_random_state's rules
+    rs = check_random_state(random_state)
+    Xc = np.array(X_vec, dtype=np.float64, order='C')
+    mean = Xc.mean(axis=0)
+    Xc -= mean
+    seeds = kmeans_plusplus_seeds(Xc, n_clusters, rs)
+    tol = np.mean(np.var(Xc, axis=0)) * 1e-4
+    res = chain.init_kmeans_lloyd(Xc, seeds, max_iter=300, tol=tol)
+    if res is None:         # a cluster emptied: scikit-learn's relocation rule, on the host
+        from sklearn.cluster._kmeans import _kmeans_single_lloyd
+        labels, _, centers, _ = _kmeans_single_lloyd(Xc, np.ones(Xc.shape[0]), seeds.copy(),
+                                                     max_iter=300, tol=tol)
+    else:
+        centers, labels, _ = res
+    return labels, centers + mean
+
+
+def longitudinal_kmeans(X, n_clusters=5, var_reg=1e-3, random_state=None, chain=None):
     """Genolini & Falissard (2010): k-means on the time-stacked trajectories;
-    returns (centers[K, D], variances[K], labels[T, N])."""
-    from sklearn.cluster import KMeans
+    returns (centers[K, D], variances[K], labels[T, N]).  ``chain``: any chain handle of the
+    device the Lloyd iterations should run on (None: scikit-learn on the host)."""
     T, N, D = X.shape
     X_vec = np.moveaxis(X, 0, -1).reshape(N, T * D)
-    km = KMeans(n_clusters=n_clusters, random_state=random_state).fit(X_vec)
-    labels = np.tile(km.labels_.reshape(1, -1), (T, 1))
+    km_labels, km_centers = _kmeans(X_vec, n_clusters, random_state, chain)
+    labels = np.tile(np.asarray(km_labels).reshape(1, -1), (T, 1))
     centers = np.empty((n_clusters, D))
     for k in range(n_clusters):
-        centers[k] = km.cluster_centers_[k].reshape(-1, T).T.mean(axis=0)
+        centers[k] = km_centers[k].reshape(-1, T).T.mean(axis=0)
     variances = np.zeros(n_clusters)
     for k in range(n_clusters):
         for t in range(T):

@@ -299,6 +299,16 @@ int dlsm_init_gmds_step(dlsm_chain *h, int t, const double *X_prev, double lmbda
  *   out = [loglik, directed_intercept_grad in, out]
  *   (directed_likelihoods_fast.pyx:20-43). */
 int dlsm_init_mle_sums(dlsm_chain *h, double p0, double p1, double *out);
+/* the Lloyd iterations of longitudinal_kmeans (latent_space.py:98-137: sklearn.cluster.KMeans on
+ * the N x F matrix of time-stacked trajectories, F = T d), scikit-learn's _kmeans_single_lloyd:
+ * X N*F (centred by the caller, as KMeans.fit does), centers_init K*F (k-means++ seeding, drawn by
+ * the caller from its RandomState), tol the absolute tolerance (KMeans' tol x mean feature
+ * variance).  centers_out K*F, labels_out N, n_iter_out.  empty_out != 0: a cluster lost all its
+ * members at iteration n_iter_out (scikit-learn then relocates it to the farthest sample): the
+ * outputs are not set and the caller finishes with the library. */
+int dlsm_init_kmeans_lloyd(dlsm_chain *h, const double *X, int N, int F, int K,
+                           const double *centers_init, int max_iter, double tol, double *centers_out,
+                           int32_t *labels_out, int32_t *n_iter_out, int32_t *empty_out);
 /* free the hop matrices */
 int dlsm_init_release(dlsm_chain *h);
 

@@ -618,6 +618,32 @@ def gen_init(ref):
     print('init.npz')
 
 
+def gen_kmeans(ref):
+    """longitudinal_kmeans (latent_space.py:98-137; scikit-learn's KMeans underneath): centres,
+    variances, labels and the NEXT draw of the RandomState it consumed, for clustered and
+    unclustered trajectories."""
+    import sklearn
+    from dynetlsm.latent_space import longitudinal_kmeans
+    out = {'sklearn_version': np.array(sklearn.__version__)}
+    for tag, (T, N, D, K, seed, clustered) in dict(a=(4, 300, 2, 6, 3, True), b=(3, 57, 3, 4, 11, False),
+                                                   c=(10, 500, 2, 20, 5, True), d=(2, 40, 1, 3, 2, False)).items():
+        rng = np.random.RandomState(seed)
+        if clustered:
+            cen = rng.randn(max(K // 2, 2), D) * 3
+            g_ = rng.randint(0, cen.shape[0], size=N)
+            X0 = cen[g_] + rng.randn(N, D) * 0.7
+        else:
+            X0 = rng.randn(N, D)
+        X = np.stack([X0 + 0.3 * t * rng.randn(N, D) for t in range(T)])
+        rs = np.random.RandomState(seed + 100)
+        centers, variances, labels = longitudinal_kmeans(X, n_clusters=K, random_state=rs)
+        out.update({tag + '_X': X, tag + '_K': np.array(K), tag + '_seed': np.array(seed + 100),
+                    tag + '_centers': centers, tag + '_variances': variances, tag + '_labels': labels,
+                    tag + '_next_draw': np.array(rs.rand())})
+    np.savez_compressed(os.path.join(HERE, 'kmeans.npz'), **out)
+    print('kmeans.npz')
+
+
 def gen_post(ref):
     """post-loop processing of DynamicNetworkHDPLPCM: posterior
     co-occurrence matrices, expected-VI minimisation (with ties), BIC / MAP model
@@ -788,6 +814,9 @@ if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'forecast':
         gen_forecast(ref)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'kmeans':
+        gen_kmeans(ref)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'post':
         gen_post(ref)
         sys.exit(0)
@@ -806,6 +835,7 @@ if __name__ == '__main__':
     gen_more_envelopes(ref, Yd)
     gen_init(ref)
     gen_post(ref)
+    gen_kmeans(ref)
     gen_forecast(ref)
     gen_imputer(ref)
     gen_lpcm_trace(ref)

@@ -10,6 +10,7 @@ numpy's: 1e-8 of the configuration scale against the oracle on the same inputs;
 import numpy as np
 import pytest
 
+from conftest import load_golden
 from oracle import init_oracle as io
 
 pytestmark = pytest.mark.gpu
@@ -179,3 +180,38 @@ def test_fit_without_init_runs_device_pipeline(eng, golden_init):
     m = eng.DynamicNetworkLSM(n_iter=20, tune=10, burn=10, random_state=4).fit(Y)
     assert np.isfinite(m.logps_).all()
     assert m.X_.shape == (Y.shape[0], Y.shape[1], 2)
+
+
+@pytest.mark.parametrize('tag', ['a', 'b', 'c', 'd'])
+def test_longitudinal_kmeans_lloyd_on_device_matches_reference(tag):
+    """latent_space.py:98-137 with the Lloyd iterations on the device (k_kmeans_assign /
+    k_kmeans_update, scikit-learn's _kmeans_single_lloyd loop) against the reference's own outputs
+    (tests/golden/kmeans.npz): same labels, centres and variances, and the caller's RandomState
+    ends where scikit-learn's KMeans would leave it"""
+    import dynetlsm_amd as eng
+    from dynetlsm_amd import initialization as im
+    g = load_golden('kmeans.npz')
+    X, K = g[tag + '_X'], int(g[tag + '_K'])
+    T, N, D = X.shape
+    rs = np.random.RandomState(int(g[tag + '_seed']))
+    with eng.Chain(1, N, D, 'undirected') as c:
+        centers, variances, labels = im.longitudinal_kmeans(X, n_clusters=K, random_state=rs, chain=c)
+    np.testing.assert_array_equal(labels, g[tag + '_labels'])
+    np.testing.assert_allclose(centers, g[tag + '_centers'], rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(variances, g[tag + '_variances'], rtol=1e-12)
+    assert rs.rand() == float(g[tag + '_next_draw'])
+
+
+def test_kmeans_lloyd_reports_an_emptied_cluster():
+    """a seeding that starves a cluster: the device loop stops and says so (scikit-learn's
+    relocation rule is then applied on the host by the caller)"""
+    import dynetlsm_amd as eng
+    rng = np.random.RandomState(0)
+    Xc = np.vstack([rng.randn(50, 4) * 0.1 - 3.0, rng.randn(50, 4) * 0.1 + 3.0])
+    Xc -= Xc.mean(axis=0)
+    seeds = np.vstack([Xc[0], Xc[60], Xc[60] + 40.0])           # nobody is nearest to the third
+    with eng.Chain(1, 100, 2, 'undirected') as c:
+        assert c.init_kmeans_lloyd(Xc, seeds, max_iter=50, tol=0.0) is None
+        cen, lab, nit = c.init_kmeans_lloyd(Xc, seeds[:2], max_iter=50, tol=0.0)
+    assert (lab[:50] == 0).all() and (lab[50:] == 1).all() and nit == 2
+    np.testing.assert_allclose(cen[0], Xc[:50].mean(axis=0), rtol=1e-13)

@@ -78,3 +78,39 @@ def test_conditional_mles(golden_init):
         np.testing.assert_allclose(got, g[tag + '_mle'], rtol=1e-5, atol=1e-6)
     got = io.directed_intercept_mle(g['d_Y'], g['d_X'], g['d_radii'])
     np.testing.assert_allclose(got, g['d_mle'], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize('tag', ['a', 'b', 'c', 'd'])
+def test_longitudinal_kmeans_host_path_matches_reference(tag):
+    """the host form of longitudinal_kmeans (chain=None: scikit-learn's KMeans, as the reference)
+    and the seeding / centring the device form shares, against tests/golden/kmeans.npz"""
+    from conftest import load_golden
+    from dynetlsm_amd import initialization as im
+    g = load_golden('kmeans.npz')
+    rs = np.random.RandomState(int(g[tag + '_seed']))
+    centers, variances, labels = im.longitudinal_kmeans(g[tag + '_X'], n_clusters=int(g[tag + '_K']),
+                                                        random_state=rs)
+    np.testing.assert_array_equal(labels, g[tag + '_labels'])
+    np.testing.assert_allclose(centers, g[tag + '_centers'], rtol=1e-12)
+    np.testing.assert_allclose(variances, g[tag + '_variances'], rtol=1e-12)
+    assert rs.rand() == float(g[tag + '_next_draw'])
+
+
+def test_kmeans_plusplus_restatement_is_the_library_bit_for_bit():
+    """``initialization.kmeans_plusplus_seeds`` (numpy, no ``sklearn.cluster`` import in fit) against
+    ``sklearn.cluster.kmeans_plusplus`` of this image: same seeds, same RandomState position"""
+    from sklearn.cluster import kmeans_plusplus
+    from dynetlsm_amd import initialization as im
+    for seed in range(12):
+        rng = np.random.RandomState(seed)
+        N, F = rng.randint(20, 700), rng.randint(1, 25)
+        K = rng.randint(2, min(25, N))
+        X = rng.randn(N, F) * (1 + rng.rand(F) * 3)
+        if seed % 3 == 0:
+            X[:N // 2] += 5
+        Xc = X - X.mean(axis=0)
+        r1, r2 = np.random.RandomState(seed + 7), np.random.RandomState(seed + 7)
+        a = im.kmeans_plusplus_seeds(Xc, K, r1)
+        b, _ = kmeans_plusplus(Xc, K, x_squared_norms=np.einsum('ij,ij->i', Xc, Xc), random_state=r2)
+        np.testing.assert_array_equal(a, b)
+        assert r1.rand() == r2.rand()
