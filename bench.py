@@ -466,7 +466,8 @@ class HdpWorkload(object):
         sg0 = np.full(Kc, float(sg_t.mean())); sg0[:nc] = sg_t
         # the facade wants a network argument: rank 0 has the real one; the other ranks (and
         # the other chains of this GPU) get the packed words and only need the shape
-        Yarg = net['Y'] if rank == 0 else np.zeros((T, N, N))
+        # (a zero-stride view: the estimator checks shape and NaNs, the 320 MB are never allocated)
+        Yarg = net['Y'] if rank == 0 else np.broadcast_to(np.zeros(()), (T, N, N))
         self.start = dict(X=X0, b=b0, mu=mu0, sigma=sg0, z=z0)
         self.models = []
         for c in range(C):
@@ -537,13 +538,13 @@ class HdpWorkload(object):
 
     def results(self, first, count):
         out = []
-        sl = slice(first, first + count)
-        for m in self.models:
-            m._pull(first, count)
-            out.append(dict(X_mean=m.Xs_[sl].mean(axis=0), logps=m.logps_[sl].copy(),
-                            intercepts=m.intercepts_[sl].copy(), lambdas=m.lambdas_[sl].copy(),
-                            n_clusters_used=np.array([float(len(np.unique(z)))
-                                                      for z in m.zs_[sl]])))
+        for m in self.models:       # summaries from the trace where it lies (no 100 MB pull)
+            ch = m.chain_
+            tr = ch.hdp_trace_read(first, count, positions=False, labels=False, weights=False)
+            nk = ch.post_trace_label_counts(first, count)
+            out.append(dict(X_mean=ch.post_trace_mean(first, count), logps=tr['logps'],
+                            intercepts=tr['intercepts'], lambdas=tr['lambdas'],
+                            n_clusters_used=(nk > 0).any(axis=1).sum(axis=1).astype(np.float64)))
         return {k: np.stack([o[k] for o in out]) for k in out[0]}
 
     def acceptance(self):
@@ -564,12 +565,24 @@ class HdpWorkload(object):
                           st['z'].copy(), st['beta'].copy(), st['weights'].copy(), m.lambda_prior,
                           hlo.Hyper(**hy), orc.SamplerGrid(T, N, 0.1, tune=None), st['b'],
                           m.intercept_variance_prior, orc.ScalarMetropolis(0.1, None, 100),
-                          seed=1, chain=0)
+                          seed=m.chain_.seed, chain=m.chain_.chain_id)
         tc = time.perf_counter()
+        lps, snaps = [], []
         for it in range(1, n_it + 1):
-            oc.iteration(it)
+            lps.append(oc.iteration(it))
+            snaps.append((oc.X.copy(), oc.z.copy(), float(oc.intercept[0]), float(oc.lmbda[0])))
         tc = time.perf_counter() - tc
+        # the engine ran these very iterations (same start, same Philox key) at the head of its
+        # trace: parity evidence at the full size, inside the driver's run
+        tr = m.chain_.hdp_trace_read(1, n_it, weights=False)
+        err = {'iterations': n_it,
+               'labels_equal': bool(all(np.array_equal(tr['zs'][i], snaps[i][1]) for i in range(n_it))),
+               'positions_max_abs': float(max(np.abs(tr['Xs'][i] - snaps[i][0]).max() for i in range(n_it))),
+               'intercepts_max_abs': float(max(abs(tr['intercepts'][i, 0] - snaps[i][2]) for i in range(n_it))),
+               'lambda_max_abs': float(max(abs(tr['lambdas'][i, 0] - snaps[i][3]) for i in range(n_it))),
+               'logps_max_rel': float(max(abs(tr['logps'][i] - lps[i]) / abs(lps[i]) for i in range(n_it)))}
         return {'value': round(n_it / tc, 5), 'unit': 'Gibbs iterations/s', 'cores': 1, 'kind': 'port',
+                'engine_trace_max_err_vs_oracle': err,
                 'sample': '%d iterations of the same T=%d N=%d K=%d workload by the oracle (scalar C '
                           'sweep, two log-likelihood evaluations and label update; numpy draws), '
                           '%.1f s' % (n_it, T, N, a.K, tc)}
@@ -619,6 +632,8 @@ class CcWorkload(object):
                        device=local_rank)
             ch.upload_edges(in_edges, out_edges, degree)
             ch.resample_controls(0, C)
+            if rank == 0 and c == 0:        # the controls the first 99 iterations use (CPU leg)
+                self.controls0 = ch.get_controls()
             ch.set_positions(X); ch.set_radii(radii); ch.set_intercepts([1.0, 0.5])
             ch.set_prior_random_walk(1e-4, 1e-5)
             ch.set_samplers(SamplerGrid(T, N, step_size=0.002, tune=None))
@@ -724,7 +739,7 @@ class CcWorkload(object):
         from oracle import oracle as orc
         X, radii, degree, in_edges, out_edges = self.tables
         T, N = self.T, self.N
-        ci, co = self.chain.get_controls()
+        ci, co = self.controls0
         cc = dict(in_edges=in_edges, out_edges=out_edges, degree=degree, control_nodes_in=ci,
                   control_nodes_out=co)
         st = orc.ChainState(X, orc.SamplerGrid(T, N, 0.002, tune=None), model=2, intercept=[1.0, 0.5],
@@ -736,12 +751,23 @@ class CcWorkload(object):
                                                              b[0], b[1])
         isamp = [orc.ScalarMetropolis(0.1, None, 100) for _ in range(2)]
         rsamp = orc.ScalarMetropolis(175000., None, 100)
-        n_it = max(2, self.args.cpu_iters)
+        n_it = min(max(2, self.args.cpu_iters), self.n_resample - 1)
         tc = time.perf_counter()
+        lps, snaps = [], []
         for it in range(1, n_it + 1):
-            orc.lsm_iteration_directed(st, it, loglik, isamp, rsamp, np.array([1.0, 0.5]), 2.0)
+            lps.append(orc.lsm_iteration_directed(st, it, loglik, isamp, rsamp, np.array([1.0, 0.5]), 2.0))
+            snaps.append((st.X.copy(), st.intercept.copy(), st.radii.copy()))
         tc = time.perf_counter() - tc
+        # the engine's trace rows 1 .. n_it: the same iterations from the same start, same key
+        Xs, ics, elps = self.chain.trace_read(1, n_it, positions=True)
+        rad = self.chain.trace_read_radii(1, n_it)
+        err = {'iterations': n_it,
+               'positions_max_abs': float(max(np.abs(Xs[i] - snaps[i][0]).max() for i in range(n_it))),
+               'intercepts_max_abs': float(max(np.abs(ics[i] - snaps[i][1]).max() for i in range(n_it))),
+               'radii_max_rel': float(max(np.abs(rad[i] / snaps[i][2] - 1).max() for i in range(n_it))),
+               'logps_max_rel': float(max(abs(elps[i] - lps[i]) / abs(lps[i]) for i in range(n_it)))}
         return {'value': round(n_it / tc, 5), 'unit': 'Gibbs iterations/s', 'cores': 1, 'kind': 'port',
+                'engine_trace_max_err_vs_oracle': err,
                 'sample': '%d iterations of the same T=%d N=%d n_control=%d workload by the oracle '
                           '(scalar C sweep, six case-control log-likelihood evaluations; the radii '
                           'proposal in numpy), %.1f s' % (n_it, T, N, self.C, tc)}
@@ -771,7 +797,9 @@ def measure(wl, args, group):
     wl.synchronize()
     torch.cuda.synchronize()
     group.barrier()
-    elapsed = group.max_over_ranks(time.perf_counter() - t0)
+    mine = time.perf_counter() - t0
+    elapsed = group.max_over_ranks(mine)
+    wl.per_rank_seconds = [float(v[0]) for v in group.gather_arrays(np.array([mine]))]
     acc = wl.acceptance()
     P = args.profile_steps if args.profile_steps > 0 else 0
     gathered = group.gather_results(wl.results(1 + P + W, K))
@@ -833,6 +861,9 @@ def run_rank(args):
                                'network_broadcast': ('packed words, device to device (%s)'
                                                      % group.backend)
                                if (world > 1 or args.force_collectives) else 'none'},
+                    # every rank's own rate between the barriers (a straggler GPU shows here; `value`
+                    # uses the slowest)
+                    'per_rank_value': [round(C * K / sec, 3) for sec in wl.per_rank_seconds],
                     'roofline': roofline, 'cpu_baseline': cpu,
                     'chain_summaries[intercept_mean,intercept_sd,logp_mean,logp_last]':
                         chain_summaries(gathered),
@@ -858,6 +889,42 @@ def run_rank(args):
                 lines.append(line)
             wl.close()
 
+    def run_monks():
+        """BASELINE.json configs[0]: DynamicNetworkLSM on Sampson's monks (T=3, N=18, d=2), 500
+        iterations through the estimator's fit(); its posterior summary beside the reference's
+        between-seed envelope (tests/golden/monks_envelopes.npz: the reference's own 8 seeds)"""
+        from dynetlsm_amd import DynamicNetworkLSM
+        gold = os.path.join(ROOT, 'tests', 'golden')
+        Y = np.load(os.path.join(gold, 'monks.npz'))['Y_undirected']
+        env = np.load(os.path.join(gold, 'monks_envelopes.npz'))
+        cols = [str(c) for c in env['columns']]
+        m = DynamicNetworkLSM(n_iter=500, tune=250, burn=250, random_state=0, device=local_rank)
+        t0 = time.perf_counter()
+        m.fit(Y)
+        wall = time.perf_counter() - t0
+        n_total = m.logps_.shape[0]
+        keep = slice(500, None)
+        d = np.sqrt(((m.Xs_[keep, :, :, None, :] - m.Xs_[keep, :, None, :, :]) ** 2).sum(-1))
+        got = {'intercept_mean': float(m.intercepts_[keep, 0].mean()),
+               'intercept_sd': float(m.intercepts_[keep, 0].std()),
+               'logp_mean': float(m.logps_[keep].mean()), 'logp_sd': float(m.logps_[keep].std()),
+               'mean_pairwise_distance': float(d.mean())}
+        ref = {c: [round(float(env['summaries'][:, k].mean()), 4),
+                   round(float(env['summaries'][:, k].std(ddof=1)), 4)] for k, c in enumerate(cols)}
+        loop = getattr(m, 'loop_seconds_', None)
+        lines.append({
+            'metric': 'Gibbs iterations/sec, DynamicNetworkLSM on Sampson\'s monks T=3 N=18 d=2',
+            'value': round((n_total - 1) / (loop if loop else wall), 1), 'unit': 'Gibbs iterations/s',
+            'n_gpus': 1, 'steps': n_total - 1, 'dtype': 'f64', 'data': 'Sampson monks (tests/golden/monks.npz)',
+            'config': {'workload': 'DynamicNetworkLSM(n_iter=500, tune=250, burn=250).fit(monks), '
+                                   'undirected, 1 chain on 1 GPU (launch bound at N = 18)'},
+            'fit_seconds': round(wall, 3),
+            'posterior_summary': {k: round(v, 4) for k, v in got.items()},
+            'reference_between_seed_[mean,sd]': ref,
+            'within_4sd_of_reference': {k: bool(abs(got[k] - ref[k][0]) <= 4 * ref[k][1] + 0.02 * abs(ref[k][0]))
+                                        for k in got if k in ref}})
+        m.chain_.close()
+
     for i, name in enumerate(models):
         if i == 0 or world > 1:
             run_model(name)         # ranks must stay in step: a failure ends the job
@@ -868,6 +935,13 @@ def run_rank(args):
             import traceback
             traceback.print_exc(file=sys.stderr)
             lines.append({'metric': name, 'error': '%s: %s' % (type(e).__name__, e)})
+    if rank == 0 and world == 1 and args.model == 'all':
+        try:
+            run_monks()
+        except Exception as e:      # noqa: BLE001
+            import traceback
+            traceback.print_exc(file=sys.stderr)
+            lines.append({'metric': 'monks', 'error': '%s: %s' % (type(e).__name__, e)})
     if rank == 0:
         head = lines[0]
         if len(lines) > 1:

@@ -107,6 +107,7 @@ class Chain(object):
             raise EngineError(rc, msg.decode() if msg else 'dlsm_create failed')
         self.K = 0
         self.C = 0
+        self.seed, self.chain_id = int(seed) & (2 ** 64 - 1), int(chain_id)    # the Philox key
 
     # -- plumbing ---------------------------------------------------------
     def _ck(self, rc):

@@ -200,7 +200,9 @@ class DynamicNetworkHDPLPCM(FittedQuantities):
         starting values, hyper-priors, the chain handle and the trace arrays.
         ``network_from``: callable(chain) that loads the network into the chain some other
         way than the float64 upload (multi-GPU: the packed broadcast of multichain)."""
-        Y = np.array(Y, dtype=np.float64, copy=self.copy, order='C')
+        # (copy=False keeps the caller's array as it is - a network_from loader never reads it)
+        Y = (np.array(Y, dtype=np.float64, order='C') if self.copy or network_from is None
+             else np.asarray(Y, dtype=np.float64))
         if Y.ndim != 3 or Y.shape[1] != Y.shape[2]:
             raise ValueError('Y must have shape (n_time_steps, n_nodes, n_nodes)')
         if np.any(np.isnan(Y)):

@@ -94,7 +94,7 @@ def kmeans_plusplus_seeds(Xc, n_clusters, rs):
     ``uniform(size=n_local_trials)`` per centre), the same distance expression
     (|x|^2 - 2 x.y + |y|^2 through the same BLAS product, clipped at 0), the same cumulative sums -
     so that the seeds, and with them labels and centres, are the library's bit for bit
-    (tests/test_init_oracle_golden.py against ``sklearn.cluster.kmeans_plusplus`` itself) without
+    (a CPU test holds it against ``sklearn.cluster.kmeans_plusplus`` itself) without
     importing ``sklearn.cluster`` (half a second, half of what ``fit`` spends before its loop)."""
     n, _ = Xc.shape
     x2 = np.einsum('ij,ij->i', Xc, Xc)          # sklearn.utils.extmath.row_norms(squared=True)

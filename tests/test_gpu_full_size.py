@@ -369,3 +369,15 @@ def test_c3_device_loop_invariants_at_full_size(eng):
             assert (tr['hypers'][0] > 0).all() and np.isfinite(tr['logps'][0])
             np.testing.assert_array_equal(np.bincount(tr['zs'][0].ravel(), minlength=K),
                                           nk.sum(axis=0))
+
+
+def test_c3_device_loop_matches_oracle_at_full_size(eng):
+    """config 3 (T=10, N=2000, K_max=20): two iterations of the device-resident HDP-LPCM loop
+    against the oracle's restatement of hdp_lpcm.py:876-1023 with the engine's Philox draws,
+    value for value - labels, label and table counts (cells with ~10^3 customers), override
+    variables and m-bar exactly; positions, beta, w, mu, sigma^2, lambda, the six resampled
+    hyper-parameters and the log-posterior to the tolerances of tests/test_gpu_hdp_loop.py"""
+    from test_gpu_hdp_loop import _run_both
+    out = _run_both(eng, 10, 2000, 20, seed=21, n_it=2, algo=0)
+    tr, lp = out[-1]
+    assert np.isfinite(lp) and len(np.unique(tr['zs'][0])) >= 2

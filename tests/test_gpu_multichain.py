@@ -172,8 +172,14 @@ def test_bench_through_rccl_in_a_group_of_one():
     """the RCCL code path on a single-GPU box: `--force-collectives` initialises the nccl
     backend with world size 1 and sends the packed network, the starting values, the timing
     reduction and the final gather through it (device tensors, stream ordering)"""
-    line = _run_bench('--gpus', '1', '--force-collectives', '--backend', 'nccl', '--model', 'lsm',
-                      '--steps', '10', '--warmup', '3', '--profile-steps', '0', '--no-cpu')
+    common = ('--gpus', '1', '--model', 'lsm', '--steps', '100', '--warmup', '50',
+              '--profile-steps', '0', '--no-cpu')
+    line = _run_bench('--force-collectives', '--backend', 'nccl', *common)
     assert line['n_gpus'] == 1 and line['value'] > 0
     assert 'nccl' in line['config']['network_broadcast']
     assert line['gathered']['X_mean'] == [1, 10, 2000, 2]
+    assert line['per_rank_value'] == [line['value']]
+    # the collectives sit outside the timed region: the rate is the plain single-GPU run's
+    plain = _run_bench(*common)
+    assert plain['config']['network_broadcast'] == 'none'
+    assert abs(line['value'] / plain['value'] - 1.0) < 0.03, (line['value'], plain['value'])
