@@ -752,10 +752,12 @@ class CcWorkload(object):
         isamp = [orc.ScalarMetropolis(0.1, None, 100) for _ in range(2)]
         rsamp = orc.ScalarMetropolis(175000., None, 100)
         n_it = min(max(2, self.args.cpu_iters), self.n_resample - 1)
+        X_ref = X.copy()            # the engine rotates every iteration onto its trace row 0 (lsm.py:495-498)
         tc = time.perf_counter()
         lps, snaps = [], []
         for it in range(1, n_it + 1):
-            lps.append(orc.lsm_iteration_directed(st, it, loglik, isamp, rsamp, np.array([1.0, 0.5]), 2.0))
+            lps.append(orc.lsm_iteration_directed(st, it, loglik, isamp, rsamp, np.array([1.0, 0.5]), 2.0,
+                                                  X_ref=X_ref))
             snaps.append((st.X.copy(), st.intercept.copy(), st.radii.copy()))
         tc = time.perf_counter() - tc
         # the engine's trace rows 1 .. n_it: the same iterations from the same start, same key
@@ -799,6 +801,9 @@ def measure(wl, args, group):
     group.barrier()
     mine = time.perf_counter() - t0
     elapsed = group.max_over_ranks(mine)
+    tb = time.perf_counter()
+    group.barrier()                 # what the closing barrier of the timed region costs by itself
+    wl.barrier_ms = 1e3 * (time.perf_counter() - tb)
     wl.per_rank_seconds = [float(v[0]) for v in group.gather_arrays(np.array([mine]))]
     acc = wl.acceptance()
     P = args.profile_steps if args.profile_steps > 0 else 0
@@ -864,6 +869,7 @@ def run_rank(args):
                     # every rank's own rate between the barriers (a straggler GPU shows here; `value`
                     # uses the slowest)
                     'per_rank_value': [round(C * K / sec, 3) for sec in wl.per_rank_seconds],
+                    'barrier_ms': round(wl.barrier_ms, 4),
                     'roofline': roofline, 'cpu_baseline': cpu,
                     'chain_summaries[intercept_mean,intercept_sd,logp_mean,logp_last]':
                         chain_summaries(gathered),

@@ -34,6 +34,14 @@ class ChainGroup(object):
         # force: go through the collectives even in a group of one (a single-GPU box can then
         # exercise the RCCL path: device tensors, stream ordering, library initialisation)
         self._solo = world == 1 and not force
+        # Control traffic - barriers and the timing reduction around a timed region - goes
+        # through a gloo group of the same ranks when the data backend is RCCL: a device
+        # barrier is an all-reduce launch plus a device synchronisation (about a millisecond,
+        # 3 - 4 % of a 100-iteration window), a host barrier over loopback a few tens of
+        # microseconds.  The network broadcast and the final gather stay on the data backend.
+        self._ctl = None
+        if not self._solo and backend == 'nccl':
+            self._ctl = dist.new_group(backend='gloo')
 
     @property
     def chain_id(self):
@@ -49,7 +57,10 @@ class ChainGroup(object):
 
     def barrier(self):
         if not self._solo:
-            self._dist.barrier()
+            if self._ctl is not None:
+                self._dist.barrier(group=self._ctl)
+            else:
+                self._dist.barrier()
 
     def broadcast_network(self, Y, shape=None, src=0):
         """Y (T, N, N) float64 on ``src`` (None elsewhere) -> float64 on all."""
@@ -119,6 +130,10 @@ class ChainGroup(object):
         if self._solo:
             return float(x)
         t = self._torch
+        if self._ctl is not None:
+            v = t.tensor([float(x)], dtype=t.float64)
+            self._dist.all_reduce(v, op=self._dist.ReduceOp.MAX, group=self._ctl)
+            return float(v[0])
         v = t.tensor([float(x)], dtype=t.float64, device=self._tensor_device())
         self._dist.all_reduce(v, op=self._dist.ReduceOp.MAX)
         return float(v.cpu()[0])

@@ -90,7 +90,7 @@ def _run_bench(*extra):
     p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + list(extra), env=env,
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500)
     assert p.returncode == 0, p.stderr.decode()[-3000:]
-    lines = [l for l in p.stdout.decode().splitlines() if l.startswith('{')]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith('{"metric"')]
     assert len(lines) == 1, p.stdout.decode()[-2000:]
     return json.loads(lines[0])
 
@@ -172,7 +172,7 @@ def test_bench_through_rccl_in_a_group_of_one():
     """the RCCL code path on a single-GPU box: `--force-collectives` initialises the nccl
     backend with world size 1 and sends the packed network, the starting values, the timing
     reduction and the final gather through it (device tensors, stream ordering)"""
-    common = ('--gpus', '1', '--model', 'lsm', '--steps', '100', '--warmup', '50',
+    common = ('--gpus', '1', '--model', 'lsm', '--steps', '200', '--warmup', '50',
               '--profile-steps', '0', '--no-cpu')
     line = _run_bench('--force-collectives', '--backend', 'nccl', *common)
     assert line['n_gpus'] == 1 and line['value'] > 0
