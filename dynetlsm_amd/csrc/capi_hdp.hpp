@@ -70,13 +70,34 @@ int enqueue_hdp_iteration(dlsm_chain *h, int it) {
                        h->hdp, ir);
     hipLaunchKernelGGL((k_hdp_stage3<DD>), dim3(T + K * T), dim3(HDP_THREADS),
                        (size_t)(K * K + K) * sizeof(double), h->stream, v, hb, h->hdp, ir);
-    const dim3 grid(K, T), block(HDP_THREADS);
-    hipLaunchKernelGGL(k_hdp_hypers, dim3(1), dim3(HH_THREADS), 0, h->stream, v, hb, h->hdp, ir);
-    hipLaunchKernelGGL((k_hdp_logp_sums<DD>), grid, block, 0, h->stream, v, hb, h->hdp);
     HdpTrace tr{h->trace_ic, h->trace_logp, h->htr_mu, h->htr_sigma, h->htr_beta, h->htr_w,
                 h->htr_lambda, h->htr_hyper};
-    hipLaunchKernelGGL((k_hdp_finalize<DD>), dim3(1), dim3(HF_THREADS), 0, h->stream, v, hb, h->hdp,
-                       h->lsm, h->intercept, tr, ir);
+    hipLaunchKernelGGL(k_hdp_hypers, dim3(1), dim3(HH_THREADS), 0, h->stream, v, hb, h->hdp, tr, ir);
+    HIPCHK(h, hipGetLastError());
+    return DLSM_OK;
+}
+
+// the log-posterior of the stored samples first .. first + count - 1, in chunks of samples
+template <int DD>
+int enqueue_hdp_logp_batch(dlsm_chain *h, int first, int count) {
+    const int T = h->T, K = h->K;
+    constexpr int CHUNK = 512;
+    const size_t per = (size_t)T * K;
+    const size_t need = (size_t)std::min(count, CHUNK) * per;           // doubles + int32
+    int rc = ensure_partials(h, need + (need + 1) / 2); if (rc) return rc;
+    double *LP = h->partials;
+    int32_t *cnt = (int32_t *)(h->partials + need);
+    ChainView v = h->view();
+    HdpTraceView tv{h->trace_X, h->htr_z, h->trace_ic, h->htr_mu, h->htr_sigma, h->htr_beta, h->htr_w,
+                    h->htr_lambda, h->htr_hyper, h->trace_logp};
+    ProfScope ps(h, DLSM_K_HDP_TAIL);
+    for (int s0 = first; s0 < first + count; s0 += CHUNK) {
+        const int ns = std::min(CHUNK, first + count - s0);
+        hipLaunchKernelGGL((k_hdp_logp_batch_sums<DD>), dim3(K, T, ns), dim3(HDP_THREADS), 0, h->stream,
+                           v, tv, s0, h->hdp_cfg.a, LP, cnt);
+        hipLaunchKernelGGL((k_hdp_logp_batch_finish<DD>), dim3(ns), dim3(HF_THREADS),
+                           per * sizeof(double), h->stream, v, tv, s0, h->hdp, h->lsm, LP, cnt);
+    }
     HIPCHK(h, hipGetLastError());
     return DLSM_OK;
 }
@@ -223,7 +244,9 @@ int dlsm_hdp_run(dlsm_chain *h, int first, int count) {
         DISPATCH_D(h, h->D, rc = enqueue_hdp_iteration<DD>(h, it));
         if (rc) return rc;
     }
-    return DLSM_OK;
+    // the log-posterior trace of these rows: one batched pass over the trace, behind the iterations
+    if (count > 0) DISPATCH_D(h, h->D, rc = enqueue_hdp_logp_batch<DD>(h, first, count));
+    return rc;
 }
 
 int dlsm_hdp_trace_read(dlsm_chain *h, int first, int count, double *Xs, double *intercepts,

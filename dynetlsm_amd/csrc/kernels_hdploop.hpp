@@ -15,8 +15,9 @@
 //   mu, sigma, lambda, hyper-parameters, concentration parameters: see each kernel.
 // Launch order per iteration (capi_hdp.hpp): [labels], k_hdp_stage1 (tables | MEAN sums),
 // k_hdp_stage2 (override variables, m_bar, beta, w0 | the alpha + kappa grid | mu + RESIDUAL sums),
-// k_hdp_stage3 (w | eight gamma variates | sigma + LAMBDA sums), k_hdp_hypers, k_hdp_logp_sums
-// (+ the Dirichlet rows), k_hdp_finalize; the intercept's accept / reject is one more role of stage 1.
+// k_hdp_stage3 (w | eight gamma variates | sigma + LAMBDA sums), k_hdp_hypers (+ the sample's trace
+// rows); the intercept's accept / reject is one more role of stage 1.  The log-posterior trace is
+// computed afterwards, batched over the rows a run produced (k_hdp_logp_batch_sums / _finish).
 #pragma once
 #include "chain.hpp"
 #include "device_common.hpp"
@@ -468,8 +469,12 @@ struct HdpStamp {
 
 // what is left for the launch of its own: the blending coefficient (needs the LAMBDA sums), the
 // three gamma variates whose shapes depend on the draws above, the new values
+// ... and the sample's trace rows (mu, sigma, beta, w are final by now; lambda and the six
+// hyper-parameters as thread 0 sets them).  The log-posterior of the sample is NOT computed here:
+// dlsm_hdp_run evaluates it for all the rows it produced in one batched pass over the trace
+// (k_hdp_logp_batch_*), off the iteration's critical path.
 __global__ __launch_bounds__(HH_THREADS) void k_hdp_hypers(ChainView c, HdpLoopBuf hb,
-                                                           HdpDeviceState *hs, IterRef ir) {
+                                                           HdpDeviceState *hs, HdpTrace tr, IterRef ir) {
     DLSM_HDP_STAMP(3)
     __shared__ double red[2][HH_THREADS / 64];
     __shared__ double sC[3], sLam;
@@ -512,6 +517,15 @@ __global__ __launch_bounds__(HH_THREADS) void k_hdp_hypers(ChainView c, HdpLoopB
         }
         sC[tid] = hdp_gamma(g, kind, idx, shape) * (1.0 / m_scale);
     }
+    {   // the sample's trace rows, by the threads that have no draw to make
+        const size_t it = ir.get();
+        for (int q = tid; q < K * D; q += HH_THREADS) tr.mu[it * K * D + q] = hb.mu[q];
+        for (int q = tid; q < K; q += HH_THREADS) {
+            tr.sigma[it * K + q] = hb.sigma[q];
+            tr.beta[it * K + q] = hb.beta[q];
+        }
+        for (int q = tid; q < T * K * K; q += HH_THREADS) tr.w[it * T * K * K + q] = hb.w[q];
+    }
     __syncthreads();
     if (tid != 0) return;
     hs->lmbda = sLam;
@@ -535,10 +549,15 @@ __global__ __launch_bounds__(HH_THREADS) void k_hdp_hypers(ChainView c, HdpLoopB
     const double rho = sB[6] / (sB[6] + sB[7]);
     hs->kappa = ak * rho;
     hs->alpha = ak - hs->kappa;
+    const size_t it = ir.get();
+    tr.lambda[it] = hs->lmbda;
+    double *hy = tr.hyper + it * 6;
+    hy[0] = hs->gamma; hy[1] = hs->alpha_init; hy[2] = hs->alpha; hy[3] = hs->kappa;
+    hy[4] = hs->mvp; hy[5] = hs->b;
 }
 
 // intercept step (sample_coefficients.py:76-86 around the fused two-candidate pass whose records
-// are in `partials`): one workgroup; nothing before k_hdp_finalize reads its results
+// are in `partials`): one workgroup; nothing inside the iteration reads its results
 __device__ __forceinline__ void hdp_intercept_wg(const double *__restrict__ partials, int nrec,
                                                  LsmDeviceState *lsm, HdpDeviceState *hs,
                                                  double *__restrict__ intercept,
@@ -561,7 +580,11 @@ __device__ __forceinline__ void hdp_intercept_wg(const double *__restrict__ part
         metropolis_bookkeeping(st, na, ns, un, lsm->i_tune, lsm->i_tune_interval, accepted);
         lsm->i_step[0] = st; lsm->i_nacc[0] = na; lsm->i_nsteps[0] = ns; lsm->i_until[0] = un;
         trace_ic[(size_t)it * 2] = intercept[0];
-        trace_ic[(size_t)it * 2 + 1] = 0.0;
+        // the network log-likelihood of the stored state rides in the undirected model's unused
+        // second intercept slot: the batched log-posterior pass reads it there, and the tie-break
+        // of posterior_vi.py:62-80 (often thousands of identical partitions) needs no pass over
+        // the stored positions
+        trace_ic[(size_t)it * 2 + 1] = hs->ll;
     }
 }
 
@@ -614,37 +637,102 @@ __global__ __launch_bounds__(HDP_THREADS) void k_hdp_stage3(ChainView c, HdpLoop
     hdp_sigma_lambda_wg<D>(c, hb, hs, ir.get(), q % K, q / K);
 }
 
-// ---- Dirichlet log-densities of the log-posterior (hdp_lpcm.py:1193-1203), spread over the
-// workgroups of the LOGP label sums' grid: workgroup (k, t >= 1) takes row (t, j = k) of the
-// transition matrices, workgroup (0, 0) the two rows at t = 0 (beta and w0).
-// distributions.py:95-100: alphas and x are clipped at the smallest normal number.
+// one term of a Dirichlet log-density (hdp_lpcm.py:1193-1203; distributions.py:95-100: alphas and
+// x are clipped at the smallest normal number)
 __device__ __forceinline__ double dirichlet_term(double al, double x) {
     if (al <= 0.0) al = HDP_SMALL_EPS;
     if (x <= 0.0) x = HDP_SMALL_EPS;
     return (al - 1.0 == 0.0 ? 0.0 : (al - 1.0) * log(x)) - lgamma(al);
 }
-// Dirichlet log-density of the row that workgroup (j, t) owns; first wavefront, lanes = components
-__device__ __forceinline__ double hdp_dirichlet_row(const HdpLoopBuf &hb, const HdpDeviceState *hs,
-                                                    int j, int t, int lane) {
-    const int K = hb.K;
+
+// ---- log-posterior trace (hdp_lpcm.py:1188-1280), batched over the stored samples ---------------
+// Nothing in an iteration needs the sample's log-posterior, and everything it is computed from is
+// in the trace (positions, labels as bytes, mu, sigma, beta, w, lambda, the six resampled
+// hyper-parameters, the intercept and - second intercept slot - the network log-likelihood).  So
+// dlsm_hdp_run computes it afterwards for all the rows it produced: the two launches that did it
+// inside the iteration (label sums + Dirichlet rows, then a single-workgroup reduction: 23 us of
+// the 114 us tail at config 3) become chip-wide passes over the trace.  Same terms, same order of
+// summation per sample as the per-iteration kernels had (hdp_label_sums_wg<LOGP>, the reduction
+// of k_hdp_finalize): the values are bit for bit the old ones.
+struct HdpTraceView {
+    const double *X;       // [n][T][N][D]
+    const uint8_t *z;      // [n][T][N]
+    const double *ic, *mu, *sigma, *beta, *w, *lambda, *hyper;
+    double *logp;
+};
+
+// grid (K, T, samples): LP[s][t][k] = the node terms of cluster k at time t of sample s0 + s;
+// cnt = its members
+template <int D>
+__global__ __launch_bounds__(HDP_THREADS) void k_hdp_logp_batch_sums(ChainView c, HdpTraceView tv,
+                                                                     int s0, double a_,
+                                                                     double *__restrict__ LP,
+                                                                     int32_t *__restrict__ cnt) {
+    __shared__ double buf[HDP_THREADS / 64];
+    __shared__ int sC[HDP_THREADS / 64];
+    const int k = blockIdx.x, t = blockIdx.y, tid = threadIdx.x;
+    const size_t s = (size_t)s0 + blockIdx.z;
+    const int N = c.N, K = c.K, T = c.T;
+    const uint8_t *zt = tv.z + (s * T + t) * N;
+    const uint8_t *zp = t > 0 ? tv.z + (s * T + t - 1) * N : nullptr;
+    const double *Xt = tv.X + (s * T + t) * (size_t)N * D;
+    const double *Xp = t > 0 ? tv.X + (s * T + t - 1) * (size_t)N * D : nullptr;
+    const double *w = tv.w + s * T * K * K;
+    double mk[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) mk[d] = tv.mu[(s * K + k) * D + d];
+    const double sk = tv.sigma[s * K + k], lm = tv.lambda[s], hb_ = tv.hyper[s * 6 + 5];
+    const double lsk = log(sk);
+    double acc = 0.0;
+    int members = 0;
+    for (int i = tid; i < N; i += HDP_THREADS) {
+        if (zt[i] != k) continue;
+        ++members;
+        double ss = 0.0;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const double x = Xt[(size_t)i * D + d];
+            const double xp = t > 0 ? Xp[(size_t)i * D + d] : 0.0;
+            const double r = t > 0 ? x - (1 - lm) * xp - lm * mk[d] : x - mk[d];
+            ss += r * r;
+        }
+        const int zprev = t > 0 ? zp[i] : 0;
+        acc += log(w[((size_t)t * K + zprev) * K + k]) - 0.5 * lsk - 0.5 * ss / sk -
+               (0.5 * a_ + 1.0) * lsk - 0.5 * hb_ / sk;
+    }
+    const double v = block_sum_all<HDP_THREADS / 64>(acc, buf, tid);
+    const double m = wave_sum_all((double)members);
+    if ((tid & 63) == 0) sC[tid >> 6] = (int)m;
+    __syncthreads();
+    if (tid == 0) {
+        const size_t q = ((size_t)blockIdx.z * T + t) * K + k;
+        LP[q] = v;
+        cnt[q] = (sC[0] + sC[1]) + (sC[2] + sC[3]);
+    }
+}
+
+// Dirichlet log-density of row (j, t) of sample s (hdp_lpcm.py:1193-1203; distributions.py:95-100:
+// alphas and x clipped at the smallest normal number): one wavefront, lanes = components
+__device__ __forceinline__ double hdp_dirichlet_row_at(const double *beta, const double *w,
+                                                       const double *hy, int K, int j, int t, int lane) {
     double total = 0.0;
     if (t >= 1) {
         double al = 0.0, v = 0.0;
         if (lane < K) {
-            al = hs->alpha * hb.beta[lane] + (j == lane ? hs->kappa : 0.0);
+            al = hy[2] * beta[lane] + (j == lane ? hy[3] : 0.0);       // alpha beta + kappa delta
             if (al <= 0.0) al = HDP_SMALL_EPS;
-            v = dirichlet_term(al, hb.w[((size_t)t * K + j) * K + lane]);
+            v = dirichlet_term(al, w[((size_t)t * K + j) * K + lane]);
         }
         total = lgamma(wave_sum_all(al)) + wave_sum_all(v);
     } else if (j == 0) {
         double al0 = 0.0, al1 = 0.0, v0 = 0.0, v1 = 0.0;
         if (lane < K) {
-            al0 = hs->gamma / K;
-            al1 = hs->alpha_init * hb.beta[lane];
+            al0 = hy[0] / K;                                           // gamma / K
+            al1 = hy[1] * beta[lane];                                  // alpha_init beta
             if (al0 <= 0.0) al0 = HDP_SMALL_EPS;
             if (al1 <= 0.0) al1 = HDP_SMALL_EPS;
-            v0 = dirichlet_term(al0, hb.beta[lane]);
-            v1 = dirichlet_term(al1, hb.w[lane]);
+            v0 = dirichlet_term(al0, beta[lane]);
+            v1 = dirichlet_term(al1, w[lane]);
         }
         total = (lgamma(wave_sum_all(al0)) + wave_sum_all(v0)) +
                 (lgamma(wave_sum_all(al1)) + wave_sum_all(v1));
@@ -652,68 +740,45 @@ __device__ __forceinline__ double hdp_dirichlet_row(const HdpLoopBuf &hb, const 
     return total;
 }
 
-// the node terms of the log-posterior (stage LOGP) and, on the workgroup's first wavefront, the
-// Dirichlet row (k, t)
-template <int D>
-__global__ __launch_bounds__(HDP_THREADS) void k_hdp_logp_sums(ChainView c, HdpLoopBuf hb,
-                                                               const HdpDeviceState *hs) {
-    DLSM_HDP_STAMP(4)
-    const int k = blockIdx.x, t = blockIdx.y;
-    if (threadIdx.x < 64) {
-        const double v = hdp_dirichlet_row(hb, hs, k, t, threadIdx.x);
-        if (threadIdx.x == 0) hb.LPD[(size_t)t * hb.K + k] = v;
-    }
-    double mk[D];
-#pragma unroll
-    for (int d = 0; d < D; ++d) mk[d] = hb.mu[(size_t)k * D + d];
-    hdp_label_sums_wg<D, HDP_SUMS_LOGP>(c, k, t, mk, hb.sigma[k], hs->lmbda, hs->a, hs->b, hb.w, hb.LP);
-}
-
-// ---- log-posterior trace (hdp_lpcm.py:1188-1280) and the sample's trace rows: one workgroup -----------
+// grid (samples): the Dirichlet rows of the sample, then k_hdp_finalize's reduction and scalars
 constexpr int HF_THREADS = 256;
 template <int D>
-__global__ __launch_bounds__(HF_THREADS) void k_hdp_finalize(ChainView c, HdpLoopBuf hb,
-                                                             const HdpDeviceState *hs,
-                                                             const LsmDeviceState *lsm,
-                                                             const double *__restrict__ intercept,
-                                                             HdpTrace tr, IterRef ir) {
-    DLSM_HDP_STAMP(5)
-    __shared__ double red[2][HF_THREADS / 64];
-    const int K = hb.K, T = c.T, tid = threadIdx.x;
-    const int it = (int)ir.get();
-    // node terms of the label sums + the Dirichlet rows
-    double acc = 0.0;
-    for (int q = tid; q < T * K; q += HF_THREADS)
-        acc += (hb.nk[q] > 0 ? hb.LP[q] : 0.0) + hb.LPD[q];
-    const double body = block_sum_all<HF_THREADS / 64>(acc, red[0], tid);
-    // the trace rows of this sample
-    for (int q = tid; q < K * D; q += HF_THREADS) tr.mu[(size_t)it * K * D + q] = hb.mu[q];
-    for (int q = tid; q < K; q += HF_THREADS) {
-        tr.sigma[(size_t)it * K + q] = hb.sigma[q];
-        tr.beta[(size_t)it * K + q] = hb.beta[q];
+__global__ __launch_bounds__(HF_THREADS) void k_hdp_logp_batch_finish(ChainView c, HdpTraceView tv,
+                                                                      int s0, const HdpDeviceState *hs,
+                                                                      const LsmDeviceState *lsm,
+                                                                      const double *__restrict__ LP,
+                                                                      const int32_t *__restrict__ cnt) {
+    extern __shared__ double sLPD[];            // T * K
+    __shared__ double red[HF_THREADS / 64];
+    const int K = c.K, T = c.T, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const size_t s = (size_t)s0 + blockIdx.x;
+    const double *beta = tv.beta + s * K, *w = tv.w + s * T * K * K, *hy = tv.hyper + s * 6;
+    for (int q = wave; q < T * K; q += HF_THREADS / 64) {
+        const int t = q / K, j = q - t * K;
+        const double v = hdp_dirichlet_row_at(beta, w, hy, K, j, t, lane);
+        if (lane == 0) sLPD[q] = v;
     }
-    for (int q = tid; q < T * K * K; q += HF_THREADS) tr.w[(size_t)it * T * K * K + q] = hb.w[q];
+    __syncthreads();
+    double acc = 0.0;
+    for (int q = tid; q < T * K; q += HF_THREADS) {
+        const size_t g = (size_t)blockIdx.x * T * K + q;
+        acc += (cnt[g] > 0 ? LP[g] : 0.0) + sLPD[q];
+    }
+    const double body = block_sum_all<HF_THREADS / 64>(acc, red, tid);
     if (tid != 0) return;
-    double lp = body + hs->ll;
+    double lp = body + tv.ic[s * 2 + 1];                        // + the network log-likelihood
     {   // intercept prior, cluster means, blending coefficient, hyper-priors
-        const double b = intercept[0], diff = b - lsm->intercept_prior[0];
+        const double b = tv.ic[s * 2], diff = b - lsm->intercept_prior[0];
         lp -= 0.5 * (diff * diff) / lsm->intercept_var;
         double ss = 0.0;
-        for (int q = 0; q < K * D; ++q) ss += hb.mu[q] * hb.mu[q];
-        lp -= 0.5 * ss / hs->mvp;
-        lp += dev_truncnorm_logpdf(hs->lmbda, hs->lambda_prior, hs->lambda_var);
-        if (hs->has_a0) lp += -(0.5 * hs->a0 + 1.0) * log(hs->mvp) - (0.5 * hs->b0 / hs->mvp);
-        if (hs->has_c0) lp += (hs->c0 - 1.0) * log(hs->b) - hs->d0 * hs->b;
+        for (int q = 0; q < K * D; ++q) ss += tv.mu[s * K * D + q] * tv.mu[s * K * D + q];
+        const double mvp = hy[4], hb_ = hy[5];
+        lp -= 0.5 * ss / mvp;
+        lp += dev_truncnorm_logpdf(tv.lambda[s], hs->lambda_prior, hs->lambda_var);
+        if (hs->has_a0) lp += -(0.5 * hs->a0 + 1.0) * log(mvp) - (0.5 * hs->b0 / mvp);
+        if (hs->has_c0) lp += (hs->c0 - 1.0) * log(hb_) - hs->d0 * hb_;
     }
-    tr.logp[it] = lp;
-    // the network log-likelihood of the stored state rides in the undirected model's unused second
-    // intercept slot: the tie-break of posterior_vi.py:62-80 (often thousands of identical
-    // partitions) then needs no pass over the stored positions
-    tr.ic[(size_t)it * 2 + 1] = hs->ll;
-    tr.lambda[it] = hs->lmbda;
-    double *hy = tr.hyper + (size_t)it * 6;
-    hy[0] = hs->gamma; hy[1] = hs->alpha_init; hy[2] = hs->alpha; hy[3] = hs->kappa;
-    hy[4] = hs->mvp; hy[5] = hs->b;
+    tv.logp[s] = lp;
 }
 
 // labels of the sample -> its trace row as bytes (K <= 64)
