@@ -61,8 +61,20 @@ F64_VALU_SUSTAINED_FRAC = 0.82
 # (the table exponential of round 2 brought the neighbour loop to 29, the pass to 15).
 OPS_PER_TERM_SWEEP = 34
 OPS_PER_TERM_LOGLIK = 17
-INSTR_PER_TERM_SWEEP = 29       # k_pipe_step neighbour loop today: 58 per neighbour, 2 positions
-INSTR_PER_TERM_LOGLIK = 15      # k_loglik_undirected<2,2> today: 30 per dyad with 2 candidates
+
+
+def kernel_instr_per_term():
+    """vector instructions the built kernels spend per dyad term, counted in the library's own
+    code object (profiles/instr_counts.py: disassembly of the hot loops); None where the
+    disassembler is not at hand"""
+    try:
+        sys.path.insert(0, os.path.join(ROOT, 'profiles'))
+        import instr_counts
+        c = instr_counts.counts()
+        return (c.get('k_pipe_step<2,0,1>', {}).get('valu_per_term'),
+                c.get('k_loglik_undirected<2,2>', {}).get('valu_per_candidate_term'))
+    except Exception:       # noqa: BLE001
+        return None, None
 
 
 def parse(argv=None):
@@ -371,19 +383,21 @@ def sweep_rooflines(chain, a, P, sweep_ms, ll_ms, ms_ev, n_ev, ms_rs, n_rs, post
         return round(tf, 3), round(tf / F64_VALU_PEAK_TFLOPS, 4)
 
     ach, frac = valu(k_terms, OPS_PER_TERM_SWEEP, k_ms)
-    ach_i, frac_i = valu(k_terms, INSTR_PER_TERM_SWEEP, k_ms)
+    ipt_sweep, ipt_ll = kernel_instr_per_term()
+    frac_i = valu(k_terms, ipt_sweep, k_ms)[1] if ipt_sweep else None
     roofline = {
         'bound': 'fp64_valu', 'kernel': kname, 'achieved': ach, 'peak': F64_VALU_PEAK_TFLOPS,
         'unit': 'TFLOP/s', 'frac': frac, 'traffic': traffic,
         'us_per_launch': round(1e3 * k_ms, 3), 'launches_per_sweep': launches,
         'dyad_terms_per_launch': round(k_terms, 0),
         'f64_ops_per_term': OPS_PER_TERM_SWEEP,
-        'f64_instr_per_term_in_kernel': INSTR_PER_TERM_SWEEP,
+        'valu_instr_per_term_in_kernel': ipt_sweep,
         'frac_by_kernel_instructions': frac_i,
+        'instr_source': 'profiles/instr_counts.py on the built library (llvm-objdump of the hot loop)',
         'peak_note': 'nominal float64 vector peak (fma = 2 flop; the algorithmic operations of a '
-                     'dyad term priced as fma slots: 34, fixed since round 1; the kernel spends '
-                     '29 since the table exponential); a pure fma stream sustains %.2f of the '
-                     'peak at 4 wavefronts per SIMD' % F64_VALU_SUSTAINED_FRAC,
+                     'dyad term priced as fma slots: 34, fixed since round 1; what the kernel '
+                     'spends per term is counted in its code object); a pure fma stream sustains '
+                     '%.2f of the peak at 4 wavefronts per SIMD' % F64_VALU_SUSTAINED_FRAC,
         'frac_of_sustained': round(frac / F64_VALU_SUSTAINED_FRAC, 4),
         'dyad_terms_per_s_sweep': round(sweep_terms / (sweep_ms * 1e-3), 0)}
     ach_b = k_bytes / (k_ms * 1e-3) / 1e9
@@ -402,7 +416,8 @@ def sweep_rooflines(chain, a, P, sweep_ms, ll_ms, ms_ev, n_ev, ms_rs, n_rs, post
         'peak': F64_VALU_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': frac_l, 'traffic': ll_traffic,
         'us_per_launch': round(1e3 * ll_ms, 3),
         'f64_ops_per_term': OPS_PER_TERM_LOGLIK,
-        'f64_instr_per_term_in_kernel': INSTR_PER_TERM_LOGLIK,
+        'valu_instr_per_candidate_term_in_kernel': ipt_ll,
+        'frac_by_kernel_instructions': (valu(ll_terms, ipt_ll, ll_ms)[1] if ipt_ll else None),
         'algorithmic_GBps': round(ll_bytes / (ll_ms * 1e-3) / 1e9, 1),
         'algorithmic_frac_of_hbm': round(ll_bytes / (ll_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
         'frac_of_sustained': round(frac_l / F64_VALU_SUSTAINED_FRAC, 4)}

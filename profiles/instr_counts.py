@@ -1,0 +1,128 @@
+"""Vector instructions per dyad term of the two hot loops, read from the BUILT library's code object
+(bench.py's `f64_instr_per_term_in_kernel` / `frac_by_kernel_instructions` used hand-kept constants).
+
+    python profiles/instr_counts.py [dynetlsm_amd/libdynetlsm_hip.so]
+
+The gfx950 code object is cut out of the library's clang offload bundle and disassembled with
+llvm-objdump; inside a kernel the neighbour trips are found by their v_rsq_f64 instructions
+(one root per distance):
+  * k_pipe_step<2, undirected, 1>: the fully unrolled no-flush loop - the run of equally long
+    trips with two roots each (two positions of the moving node against 64 neighbours);
+    per term = VALU instructions of a trip / 2;
+  * k_loglik_undirected<2, 2>: the whole-tile loop - trips of four rows (four roots), two candidate
+    intercepts sharing distance and exponential; per candidate-term = VALU of a trip / (4 * 2).
+"""
+import json
+import os
+import re
+import struct
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OBJDUMP = '/opt/rocm/lib/llvm/bin/llvm-objdump'
+
+
+def extract_code_object(lib_path, arch='gfx950'):
+    data = open(lib_path, 'rb').read()
+    i = data.find(b'__CLANG_OFFLOAD_BUNDLE__')
+    if i < 0:
+        raise RuntimeError('no offload bundle in %s' % lib_path)
+    n = struct.unpack_from('<Q', data, i + 24)[0]
+    off = i + 32
+    for _ in range(n):
+        o, sz, tl = struct.unpack_from('<QQQ', data, off)
+        off += 24
+        triple = data[off:off + tl].decode()
+        off += tl
+        if arch in triple:
+            return data[i + o:i + o + sz]
+    raise RuntimeError('no %s code object in %s' % (arch, lib_path))
+
+
+def disassemble(lib_path):
+    co = extract_code_object(lib_path)
+    with tempfile.NamedTemporaryFile(suffix='.co', delete=False) as f:
+        f.write(co)
+        path = f.name
+    try:
+        txt = subprocess.run([OBJDUMP, '-d', '--mcpu=gfx950', '--no-show-raw-insn', path],
+                             stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout.decode()
+    finally:
+        os.unlink(path)
+    funcs, name, cur = {}, None, []
+    for line in txt.splitlines():
+        m = re.match(r'^[0-9a-f]+ <([^>]+)>:$', line)
+        if m:
+            if name:
+                funcs[name] = cur
+            name, cur = m.group(1), []
+        elif name and line.strip() and not line.startswith('Disassembly'):
+            ins = line.strip().split('//')[0].strip()
+            if ins:
+                cur.append(ins)
+    if name:
+        funcs[name] = cur
+    return funcs
+
+
+def _trips(ins, roots_per_trip):
+    """(VALU count, length) of every stretch between two consecutive groups of roots"""
+    pos = [k for k, l in enumerate(ins) if l.startswith('v_rsq_f64')]
+    starts = pos[::roots_per_trip]
+    out = []
+    for a, b in zip(starts[:-1], starts[1:]):
+        seg = ins[a:b]
+        if sum(1 for l in seg if l.startswith('v_rsq_f64')) != roots_per_trip:
+            continue
+        out.append((sum(1 for l in seg if l.startswith('v_')), b - a))
+    return out
+
+
+def _modal_run(trips, min_run):
+    """the VALU count of the longest run of equally long trips (the unrolled steady state)"""
+    best, i = None, 0
+    while i < len(trips):
+        j = i
+        while j + 1 < len(trips) and abs(trips[j + 1][1] - trips[i][1]) <= 2:
+            j += 1
+        if j - i + 1 >= min_run and (best is None or trips[i][0] < best[0]):
+            best = (trips[i][0], j - i + 1)
+        i = j + 1
+    return best
+
+
+def counts(lib_path=None):
+    lib_path = lib_path or os.path.join(ROOT, 'dynetlsm_amd', 'libdynetlsm_hip.so')
+    funcs = disassemble(lib_path)
+    sweep = next(v for k, v in funcs.items() if re.match(r'_ZN4dlsm11k_pipe_stepILi2ELi0ELi1E', k))
+    ll = next(v for k, v in funcs.items() if re.match(r'_ZN4dlsm19k_loglik_undirectedILi2ELi2E', k))
+    s = _modal_run(_trips(sweep, 2), 8)
+    # the log-likelihood loops are rolled, one per variant (whole tile / ragged tile; the squared-
+    # distance one has no root): a trip runs from the loop's head (behind the previous branch) to the
+    # flush test behind its four roots (s_cmp_ge: the logarithms behind it run once per `nflush`
+    # trips); the variant with the fewest vector instructions is the whole-tile one
+    pos = [k for k, l in enumerate(ll) if l.startswith('v_rsq_f64')]
+    bodies = []
+    for g in range(0, len(pos) - 3, 4):
+        a = pos[g]
+        while a > 0 and not (ll[a - 1].startswith('s_cbranch') or ll[a - 1].startswith('s_branch')):
+            a -= 1
+        e = pos[g + 3]
+        while e < len(ll) and not ll[e].startswith('s_cmp_ge'):
+            e += 1
+        bodies.append((sum(1 for l in ll[a:e] if l.startswith('v_')), e - a))
+    body = min(bodies) if bodies else None
+    out = {'library': os.path.relpath(lib_path, ROOT)}
+    if s:
+        out['k_pipe_step<2,0,1>'] = {'valu_per_trip_of_64_neighbours_2_positions': s[0],
+                                    'unrolled_trips_found': s[1], 'valu_per_term': round(s[0] / 2.0, 1)}
+    if body:
+        out['k_loglik_undirected<2,2>'] = {'valu_per_trip_of_4_rows_2_candidates': body[0],
+                                           'valu_per_candidate_term': round(body[0] / 8.0, 1)}
+    return out
+
+
+if __name__ == '__main__':
+    print(json.dumps(counts(sys.argv[1] if len(sys.argv) > 1 else None), indent=1))
