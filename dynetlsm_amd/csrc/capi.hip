@@ -1296,6 +1296,65 @@ static int launch_post(dlsm_chain *h, const double *d_xref, int n_iter_procruste
     return DLSM_OK;
 }
 
+namespace {
+// The label block update's two launches.  16 nodes per workgroup on the f64 matrix cores when the
+// transition matrices and the 16 nodes' tables fit in LDS together (config 3: 82 KB); the
+// wavefront-per-node kernel otherwise (DLSM_LABELS_KERNEL=wave forces it, for measurements).
+static bool labels_wave_forced() {
+    static const bool v = [] { const char *e = getenv("DLSM_LABELS_KERNEL"); return e && !strcmp(e, "wave"); }();
+    return v;
+}
+
+template <int KS>
+int launch_labels_mfma(dlsm_chain *h, const ChainView &v, uint32_t iter, hipStream_t q) {
+    auto kern = k_sample_labels_mfma<KS>;
+    const size_t lds = lm_lds_bytes(h->T, h->K, h->D);
+    static size_t armed = 0;                    // per instantiation: the largest size asked for
+    if (lds > armed) {
+        HIPCHK(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)lds));
+        armed = lds;
+    }
+    hipLaunchKernelGGL(kern, dim3((h->N + 15) / 16), dim3(LM_THREADS), lds, q, v, h->lab_w, iter, h->z);
+    return DLSM_OK;
+}
+
+template <int DD>
+int launch_sample_labels(dlsm_chain *h, const ChainView &v, uint32_t iter, uint8_t *trace_row,
+                         hipStream_t q) {
+    const int T = h->T, K = h->K, N = h->N;
+    if (K <= 64 && lm_lds_bytes(T, K, h->D) <= 150 * 1024 && !labels_wave_forced()) {
+        int rc;
+        switch (lm_ksteps(K)) {
+#define DLSM_LM_CASE(KS_) case KS_: rc = launch_labels_mfma<KS_>(h, v, iter, q); break;
+            DLSM_LM_CASE(1) DLSM_LM_CASE(2) DLSM_LM_CASE(3) DLSM_LM_CASE(4) DLSM_LM_CASE(5)
+            DLSM_LM_CASE(6) DLSM_LM_CASE(7) DLSM_LM_CASE(8) DLSM_LM_CASE(9) DLSM_LM_CASE(10)
+            DLSM_LM_CASE(11) DLSM_LM_CASE(12) DLSM_LM_CASE(13) DLSM_LM_CASE(14) DLSM_LM_CASE(15)
+            default: rc = launch_labels_mfma<16>(h, v, iter, q); break;
+#undef DLSM_LM_CASE
+        }
+        if (rc) return rc;
+    } else {
+        const size_t lds_tables = (size_t)LAB_WAVES * 2 * T * K * sizeof(double);
+        const size_t lds_w = (size_t)T * K * lab_row_pad(K) * sizeof(double);
+        if (lds_tables > 160 * 1024)
+            FAIL(h, DLSM_E_LIMIT, "T*K=%d too large for the label kernel", T * K);
+        const bool w_lds = lds_tables + lds_w <= 80 * 1024;     // two workgroups per CU
+        const size_t lds = lds_tables + (w_lds ? lds_w : 0);
+        auto kern = w_lds ? k_sample_labels<DD, true> : k_sample_labels<DD, false>;
+        if (lds > 64 * 1024)
+            HIPCHK(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)lds));
+        hipLaunchKernelGGL(kern, dim3((N + LAB_WAVES - 1) / LAB_WAVES), dim3(64 * LAB_WAVES), lds, q, v,
+                           h->lab_w, iter, h->z);
+    }
+    hipLaunchKernelGGL(k_label_counts, dim3(T), dim3(256), (size_t)(K * K + K) * sizeof(int32_t), q,
+                       h->z, N, K, (int32_t *)h->lab_n, (int32_t *)h->lab_nk, trace_row);
+    return DLSM_OK;
+}
+
+}  // namespace
+
 extern "C" {
 
 int dlsm_center(dlsm_chain *h) {
@@ -1346,27 +1405,14 @@ int dlsm_sample_labels(dlsm_chain *h, uint32_t iter, const double *w, int64_t *z
     const int T = h->T, K = h->K, N = h->N;
     const size_t nn = (size_t)T * K * K, nnk = (size_t)T * K;
     { int rc = ensure_label_bufs(h); if (rc) return rc; }
-    const size_t lds_tables = (size_t)LAB_WAVES * 2 * T * K * sizeof(double);
-    const size_t lds_w = (size_t)T * K * lab_row_pad(K) * sizeof(double);
-    if (lds_tables > 160 * 1024)
-        FAIL(h, DLSM_E_LIMIT, "T*K=%d too large for the label kernel", T * K);
-    const bool w_lds = lds_tables + lds_w <= 80 * 1024;     // two workgroups per CU
-    const size_t lds = lds_tables + (w_lds ? lds_w : 0);
     size_t staged = 0;
     { int rc = h2d_enqueue(h, h->lab_w, w, nn, &staged); if (rc) return rc; }
     ChainView v = h->view();
     {
         ProfScope ps(h, DLSM_K_LABELS);
         DISPATCH_D(h, h->D, {
-            auto kern = w_lds ? k_sample_labels<DD, true> : k_sample_labels<DD, false>;
-            HIPCHK(h, hipFuncSetAttribute((const void *)kern,
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(kern, dim3((N + LAB_WAVES - 1) / LAB_WAVES),
-                               dim3(64 * LAB_WAVES), lds, h->stream, v, h->lab_w, iter, h->z);
+            int rc = launch_sample_labels<DD>(h, v, iter, nullptr, h->stream); if (rc) return rc;
         });
-        hipLaunchKernelGGL(k_label_counts, dim3(T), dim3(256),
-                           (size_t)(K * K + K) * sizeof(int32_t), h->stream, h->z, N, K,
-                           (int32_t *)h->lab_n, (int32_t *)h->lab_nk, (uint8_t *)nullptr);
     }
     HIPCHK(h, hipGetLastError());
     // labels and counts come back as int32 in one batch: into the pinned buffer behind one

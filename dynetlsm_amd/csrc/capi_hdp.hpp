@@ -45,23 +45,34 @@ int enqueue_hdp_iteration(dlsm_chain *h, int it) {
     int rc = enqueue_sweep(h, ir, h->hdp_cfg.sweep_algo); if (rc) return rc;
     // centring; workgroup 0 draws the intercept proposal; the positions' trace row
     rc = launch_post<DD>(h, nullptr, 0, 1, h->lsm, ir, nullptr, false, h->trace_X); if (rc) return rc;
-    int nrec = 0;
-    rc = loglik_records(h, 2, h->lsm->cand, nullptr, nullptr, &nrec); if (rc) return rc;
+    // The label block update needs the centred positions and last iteration's mixture, not the
+    // intercept's likelihood records (33 us at config 3), and those do not need the labels: with
+    // DLSM_HDP_QUEUES=2 the labels go to a second queue beside them.  Opt-in: on MI355X the two
+    // event hand-overs between the queues cost more than the 20 us they hide (C3 2836 -> 2609 it/s,
+    // profiles/r03_labels_notes.md).
+    static const bool one_queue = [] { const char *e = getenv("DLSM_HDP_QUEUES"); return !(e && atoi(e) == 2); }();
+    const bool fork = !one_queue && !h->profiling;
+    if (fork && !h->stream2) {
+        HIPCHK(h, hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+        HIPCHK(h, hipEventCreateWithFlags(&h->ev_a, hipEventDisableTiming));
+        HIPCHK(h, hipEventCreateWithFlags(&h->ev_b, hipEventDisableTiming));
+    }
     ChainView v = h->view();
     HdpLoopBuf hb = hdp_loop_buf(h);
     {   // label block update (sample_labels.py:134-190) with the transition matrices on the device
         ProfScope ps(h, DLSM_K_LABELS);
-        const size_t lds_tables = (size_t)LAB_WAVES * 2 * T * K * sizeof(double);
-        const size_t lds_w = (size_t)T * K * lab_row_pad(K) * sizeof(double);
-        const bool w_lds = lds_tables + lds_w <= 80 * 1024;
-        const size_t lds = lds_tables + (w_lds ? lds_w : 0);
-        auto kern = w_lds ? k_sample_labels<DD, true> : k_sample_labels<DD, false>;
-        hipLaunchKernelGGL(kern, dim3((N + LAB_WAVES - 1) / LAB_WAVES), dim3(64 * LAB_WAVES), lds,
-                           h->stream, v, h->lab_w, (uint32_t)it, h->z);
-        hipLaunchKernelGGL(k_label_counts, dim3(T), dim3(256), (size_t)(K * K + K) * sizeof(int32_t),
-                           h->stream, h->z, N, K, (int32_t *)h->lab_n, (int32_t *)h->lab_nk,
-                           h->htr_z + (size_t)it * T * N);
+        if (fork) {
+            HIPCHK(h, hipEventRecord(h->ev_a, h->stream));
+            HIPCHK(h, hipStreamWaitEvent(h->stream2, h->ev_a, 0));
+        }
+        rc = launch_sample_labels<DD>(h, v, (uint32_t)it, h->htr_z + (size_t)it * T * N,
+                                      fork ? h->stream2 : h->stream);
+        if (rc) return rc;
+        if (fork) HIPCHK(h, hipEventRecord(h->ev_b, h->stream2));
     }
+    int nrec = 0;
+    rc = loglik_records(h, 2, h->lsm->cand, nullptr, nullptr, &nrec); if (rc) return rc;
+    if (fork) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_b, 0));
     ProfScope ps(h, DLSM_K_HDP_TAIL);
     const int n_tab = (T * K * K + HT_WAVES - 1) / HT_WAVES;
     hipLaunchKernelGGL((k_hdp_stage1<DD>), dim3(n_tab + K * T + 1), dim3(HDP_THREADS), 0, h->stream, v,

@@ -171,6 +171,231 @@ __global__ __launch_bounds__(64 * LAB_WAVES) void k_sample_labels(
 #endif
 }
 
+// ---- a12 on the f64 matrix cores: 16 nodes per workgroup ----
+// The backward recursion of one node is a chain of T - 1 matrix-vector products with the same
+// matrices for every node: for 16 nodes at once a step is  S[n][j] = sum_k P[n][k] w[t][j][k],
+// a (16 x K)(K x K) product, ceil(K/4) x ceil(K/16) v_mfma_f64_16x16x4_f64 per step (operand
+// placement probed on the hardware, profiles/micro/mfma_f64_layout.hip: A[i = lane % 16][k =
+// lane / 16], B[k = lane / 16][j = lane % 16], D[i = 4 r + lane / 16][j = lane % 16]).  The
+// wavefront-per-node kernel above spends 1.4 us per step on a K-term chain of register fetches;
+// here a step of 16 nodes is one burst of LDS reads, ten matrix instructions, a rescale and one
+// trip through LDS that turns the result's placement into the next step's A operand.
+//   * KS = ceil(K / 4) is a template parameter: every loop over components is unrolled without a
+//     guard, the rows in LDS are padded with zeros up to 4 KS components instead;
+//   * the whole workgroup builds the 16 nodes' T x K likelihood table (same expression as
+//     gauss_loglik_tk, the -d/2 log(2 pi sigma_k) term computed once per component) and the
+//     Philox uniforms (counter = (node, t, iteration), as above); wavefront 0 then runs the
+//     recursion and the draws;
+//   * the messages are rescaled by a power of two per node and step (the largest exponent of the
+//     row) instead of divided by the row's sum: the scale cancels in the draw (u * total against
+//     the cumulative sums), a power of two rounds nothing, and the row maximum - unlike a sum -
+//     is the same number in every lane whatever the order of the reduction;
+//   * forward draws: four lanes per node, each the cumulative sums of KS components in index
+//     order; the quarters' offsets are (c0), (c0 + c1), ((c0 + c1) + c2).
+// The sums over k run inside the matrix instruction and over quarters here, the reference's and
+// the kernel above's in one chain: the messages and cumulative sums differ from theirs in the
+// last bits, so a label can differ when u * total lies within a few ulp of a cumulative sum
+// (about K 1e-16 per draw; the parity tests compare labels exactly over thousands of draws).
+constexpr int LM_THREADS = 1024;
+typedef double lm_v4d __attribute__((ext_vector_type(4)));
+__host__ __device__ inline int lm_ksteps(int K) { return (K + 3) / 4; }
+__host__ __device__ inline int lm_wstride(int K) { return (4 * lm_ksteps(K)) | 1; }
+__host__ __device__ inline int lm_stride(int K) { return 16 * ((lm_ksteps(K) + 3) / 4) + 1; }
+__host__ __device__ inline size_t lm_lds_bytes(int T, int K) {
+    return ((size_t)T * K * lm_wstride(K) + (size_t)(T + 1) * 16 * lm_stride(K) + 16 * (size_t)T + 2 * K) *
+           sizeof(double);
+}
+__host__ __device__ inline size_t lm_lds_bytes(int T, int K, int D) {
+    return lm_lds_bytes(T, K) + ((size_t)T * 16 + K) * D * sizeof(double);
+}
+
+template <int KS>
+__global__ __launch_bounds__(LM_THREADS) void k_sample_labels_mfma(
+    ChainView c, const double *__restrict__ w, uint32_t iter, int32_t *__restrict__ z_out) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    constexpr int KT = (KS + 3) / 4, S = 16 * KT + 1, WS = (4 * KS) | 1;
+    const int T = c.T, K = c.K, N = c.N, D = c.D;
+    double *wt = smem;                                  // [T][K][WS] transition matrices, zero padded
+    double *tab = wt + (size_t)T * K * WS;              // [T][16][S] likelihood, then partial marginal
+    double *Mb = tab + (size_t)T * 16 * S;              // [16][S] the step's messages
+    double *U = Mb + 16 * S;                            // [16][T] uniforms
+    double *lognorm = U + 16 * T;                       // [K]
+    double *hiv = lognorm + K;                          // [K] 0.5 / sigma_k
+    double *sx = hiv + K;                               // [T][16][D] the nodes' positions
+    double *smu = sx + (size_t)T * 16 * D;              // [K][D]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int node0 = blockIdx.x * 16;
+#ifdef DLSM_PIPE_TIMING
+    unsigned long long lts[6] = {0, 0, 0, 0, 0, 0};
+#endif
+    DLSM_LAB_STAMP(0, (double)lane)
+    for (int q = tid; q < T * 16 * D; q += LM_THREADS) {
+        const int tn = q / D, j = q - tn * D;
+        sx[q] = c.X[((size_t)(tn >> 4) * N + min(node0 + (tn & 15), N - 1)) * D + j];
+    }
+    for (int q = tid; q < K * D; q += LM_THREADS) smu[q] = c.mu[q];
+    for (int q = tid; q < T * K * WS; q += LM_THREADS) {
+        const int r = q / WS, k = q - r * WS;
+        wt[q] = k < K ? w[(size_t)r * K + k] : 0.0;
+    }
+    for (int k = tid; k < K; k += LM_THREADS) {
+        const double var = c.sigma[k];
+        lognorm[k] = -0.5 * D * log(2 * 3.14159265358979323846 * var);
+        hiv[k] = 0.5 * (1. / var);
+    }
+    for (int q = tid; q < 16 * T; q += LM_THREADS) {
+        const int n = q / T, t = q - n * T;
+        double u0, u1;
+        philox_uniform2(c.seed, (uint32_t)min(node0 + n, N - 1), (uint32_t)t, iter,
+                        stream_word(c.chain, STREAM_LABELS), u0, u1);
+        U[q] = u0;
+    }
+    for (int q = tid; q < 16 * S; q += LM_THREADS) Mb[q] = 1.0;     // the message of time T - 1
+    __syncthreads();
+    DLSM_LAB_STAMP(1, (double)lane)
+    {
+        const double lm = c.lmbda_p[0];
+        for (int q = tid; q < T * 16 * 4 * KS; q += LM_THREADS) {
+            const int tn = q / (4 * KS), k = q - tn * (4 * KS), t = tn >> 4;
+            double v = 0.0;                             // components K .. 4 KS - 1: padding
+            if (k < K) {
+                const double *x = sx + (size_t)tn * D;
+                const double *m = smu + (size_t)k * D;
+                double ss = 0.0;
+                if (t == 0) {
+                    for (int j = 0; j < D; ++j) ss += (x[j] - m[j]) * (x[j] - m[j]);
+                } else {
+                    const double *xp = x - (size_t)16 * D;
+                    for (int j = 0; j < D; ++j) {
+                        const double mk = lm * m[j] + (1 - lm) * xp[j];
+                        ss += (x[j] - mk) * (x[j] - mk);
+                    }
+                }
+                ss *= hiv[k];
+                v = exp(lognorm[k] - ss);
+            }
+            tab[(size_t)tn * S + k] = v;
+        }
+    }
+    __syncthreads();
+    if (tid >= 64) return;                              // wavefront 0 carries on alone
+    DLSM_LAB_STAMP(2, (double)lane)
+    // backward messages (sample_labels.py:164-170)
+    const int an = lane & 15, g = lane >> 4;            // A operand: node an, component 4 s + g
+    // operands of a step that do not wait for the step before it (likelihood column, B operand)
+    // are requested a step ahead, while the matrix instructions run
+    double lk[KS], b[KS][KT];
+    auto request = [&](int t) {
+        const double *trow = tab + ((size_t)t * 16 + an) * S + g;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) lk[s] = trow[4 * s];
+#pragma unroll
+        for (int ct = 0; ct < KT; ++ct) {               // B operand: w[t][j][k], rows past K are zero
+            const int j = 16 * ct + an;
+            const double *wrow = wt + ((size_t)t * K + min(j, K - 1)) * WS + g;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const double wv = wrow[4 * s];
+                b[s][ct] = j < K ? wv : 0.0;
+            }
+        }
+    };
+    if (T > 1) request(T - 1);
+    for (int t = T - 1; t > 0; --t) {
+        double *trow = tab + ((size_t)t * 16 + an) * S + g;
+        const double *mrow = Mb + an * S + g;
+        double a[KS], bb[KS][KT];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) a[s] = lk[s] * mrow[4 * s];
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int ct = 0; ct < KT; ++ct) bb[s][ct] = b[s][ct];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) trow[4 * s] = a[s];            // the forward pass needs it again
+        if (t > 1) request(t - 1);
+        lm_v4d acc[KT];
+#pragma unroll
+        for (int ct = 0; ct < KT; ++ct) acc[ct] = lm_v4d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int ct = 0; ct < KT; ++ct)
+                acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], bb[s][ct], acc[ct], 0, 0, 0);
+        // lane holds nodes 4 r + g, components 16 ct + an: one power of two per node, from the
+        // largest biased exponent of the row (the sums are >= 0: the high word orders them; the
+        // four nodes' reductions are written side by side so that their DPP waits interleave)
+        int e[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            e[r] = __double2hiint(acc[0][r]);
+#pragma unroll
+            for (int ct = 1; ct < KT; ++ct) e[r] = max(e[r], __double2hiint(acc[ct][r]));
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) e[r] = max(e[r], __builtin_amdgcn_mov_dpp(e[r], 0x128, 0xF, 0xF, false));   // row_ror:8
+#pragma unroll
+        for (int r = 0; r < 4; ++r) e[r] = max(e[r], __builtin_amdgcn_mov_dpp(e[r], 0x124, 0xF, 0xF, false));   // row_ror:4
+#pragma unroll
+        for (int r = 0; r < 4; ++r) e[r] = max(e[r], __builtin_amdgcn_mov_dpp(e[r], 0x122, 0xF, 0xF, false));   // row_ror:2
+#pragma unroll
+        for (int r = 0; r < 4; ++r) e[r] = max(e[r], __builtin_amdgcn_mov_dpp(e[r], 0x121, 0xF, 0xF, false));   // row_ror:1
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int sh = 1023 - (e[r] >> 20);         // the row's largest entry lands in [1, 2)
+#pragma unroll
+            for (int ct = 0; ct < KT; ++ct)
+                Mb[(4 * r + g) * S + 16 * ct + an] = ldexp(acc[ct][r], sh);
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < KS; ++s) tab[(size_t)an * S + g + 4 * s] *= Mb[an * S + g + 4 * s];
+    DLSM_LAB_STAMP(3, (double)lane)
+    __builtin_amdgcn_s_waitcnt(0xc07f);                 // lgkmcnt(0): LDS writes landed
+    __builtin_amdgcn_wave_barrier();
+    // forward sampling (:173-188): four lanes per node, KS components each
+    const int fn = lane >> 2, q = lane & 3, node = node0 + fn;
+    int zprev = 0;
+    double pv[KS];
+#pragma unroll
+    for (int e = 0; e < KS; ++e) pv[e] = tab[(size_t)fn * S + q * KS + e];
+    double un = U[fn * T];
+    for (int t = 0; t < T; ++t) {
+        const double *wrow = wt + (t == 0 ? (size_t)0 : ((size_t)t * K + zprev) * WS) + q * KS;
+        double pl[KS], run = 0.0;
+#pragma unroll
+        for (int e = 0; e < KS; ++e) pl[e] = wrow[e];
+#pragma unroll
+        for (int e = 0; e < KS; ++e) {
+            run += pl[e] * pv[e];
+            pl[e] = run;
+        }
+        const double ut0 = un;
+        if (t + 1 < T) {                                // the next step's operands that do not wait for the label
+#pragma unroll
+            for (int e = 0; e < KS; ++e) pv[e] = tab[((size_t)(t + 1) * 16 + fn) * S + q * KS + e];
+            un = U[fn * T + t + 1];
+        }
+        const double c0 = dpp_move<0x00>(run), c1 = dpp_move<0x55>(run), c2 = dpp_move<0xAA>(run),
+                     c3 = dpp_move<0xFF>(run);
+        const double o2 = c0 + c1, o3 = o2 + c2, total = o3 + c3;
+        const double off = q == 0 ? 0.0 : q == 1 ? c0 : q == 2 ? o2 : o3;
+        const double ut = ut0 * total;
+        int cnt = 0;                                    // padding repeats the quarter's last sum: never below u * total
+#pragma unroll
+        for (int e = 0; e < KS; ++e) cnt += ut > off + pl[e] ? 1 : 0;
+        cnt += __builtin_amdgcn_mov_dpp(cnt, 0xB1, 0xF, 0xF, false);             // quad_perm [1, 0, 3, 2]
+        cnt += __builtin_amdgcn_mov_dpp(cnt, 0x4E, 0xF, 0xF, false);             // quad_perm [2, 3, 0, 1]
+        const int zt = min(cnt, K - 1);
+        if (q == 0 && node < N) z_out[(size_t)t * N + node] = zt;
+        zprev = zt;
+    }
+#ifdef DLSM_PIPE_TIMING
+    DLSM_LAB_STAMP(4, (double)zprev)
+    if (lane == 0 && blockIdx.x < 4096) for (int qq = 0; qq < 5; ++qq) g_lab_t[blockIdx.x][qq] = lts[qq];
+#endif
+}
+
 // The counts the conjugate updates need (sample_labels.py:176-188): n[0][0][k] initial labels,
 // n[t][j][k] transitions j -> k into time t, nk[t][k] labels in use.  One workgroup per time
 // step, histogram in LDS (same-address global atomics from 2000 wavefronts cost ~170 ns each).

@@ -1,4 +1,4 @@
-"""Phase stamps of k_sample_labels at config 3 (engine built with -DDLSM_PIPE_TIMING): per
+"""Phase stamps of the label kernel (k_sample_labels_mfma; DLSM_LABELS_KERNEL=wave: k_sample_labels) at config 3 (engine built with -DDLSM_PIPE_TIMING): per
 wavefront (= node) entry, transition matrices staged in LDS, the T x K table built, backward
 messages done, forward sampling done.
     python profiles/labels_phases.py tmp_timing/libtiming.so [out.json]
@@ -34,12 +34,14 @@ w = np.zeros((4096, 6), dtype=np.uint64)
 L.dlsm_debug_labels_timing.restype = C.c_int
 L.dlsm_debug_labels_timing.argtypes = [C.c_void_p]
 assert L.dlsm_debug_labels_timing(w.ctypes.data) == 0
-w = w[:N, :5].astype(np.int64)
+w = w[:, :5].astype(np.int64)
+w = w[w[:, 0] != 0]          # one row per wavefront (per node) or per workgroup (16 nodes)
 t0 = w[:, 0].min()
 rel = (w - t0) * 0.01
 names = ['entry', 'w staged', 'table built', 'backward done', 'forward done']
 out = {n: {'p50': round(float(np.median(rel[:, i])), 2), 'max': round(float(rel[:, i].max()), 2)}
        for i, n in enumerate(names)}
+out['rows'] = int(len(w))
 print(json.dumps(out))
 if len(sys.argv) > 2:
     json.dump(out, open(sys.argv[2], 'w'), indent=1)

@@ -607,6 +607,10 @@ def test_labels_medium_and_distribution(eng):
     (70, 50, 1, 3),       # more than 64 time steps: the uniforms come in two passes
     (3, 77, 3, 64),       # every lane owns a component; N not a multiple of the group size
     (1, 9, 2, 2),         # a single time step: no backward pass
+    (5, 203, 2, 17),      # matrix-core kernel, 5 k-steps with three padded components, 2 column tiles
+    (4, 100, 3, 33),      # 9 k-steps, 3 column tiles
+    (6, 45, 2, 7),        # 2 k-steps, one column tile
+    (12, 16, 4, 48),      # 12 k-steps, exactly one group of 16 nodes
 ])
 def test_labels_shapes_against_oracle(eng, T, N, D, K):
     rng = np.random.RandomState(T * 131 + K)
