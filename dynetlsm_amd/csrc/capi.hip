@@ -1315,7 +1315,8 @@ int launch_labels_mfma(dlsm_chain *h, const ChainView &v, uint32_t iter, hipStre
                                       (int)lds));
         armed = lds;
     }
-    hipLaunchKernelGGL(kern, dim3((h->N + 15) / 16), dim3(LM_THREADS), lds, q, v, h->lab_w, iter, h->z);
+    hipLaunchKernelGGL(kern, dim3((h->N + LM_NODES - 1) / LM_NODES), dim3(LM_THREADS), lds, q, v, h->lab_w, iter,
+                       h->z);
     return DLSM_OK;
 }
 
@@ -1348,7 +1349,7 @@ int launch_sample_labels(dlsm_chain *h, const ChainView &v, uint32_t iter, uint8
         hipLaunchKernelGGL(kern, dim3((N + LAB_WAVES - 1) / LAB_WAVES), dim3(64 * LAB_WAVES), lds, q, v,
                            h->lab_w, iter, h->z);
     }
-    hipLaunchKernelGGL(k_label_counts, dim3(T), dim3(256), (size_t)(K * K + K) * sizeof(int32_t), q,
+    hipLaunchKernelGGL(k_label_counts, dim3(T), dim3(LC_THREADS), (size_t)(K * K + K) * sizeof(int32_t), q,
                        h->z, N, K, (int32_t *)h->lab_n, (int32_t *)h->lab_nk, trace_row);
     return DLSM_OK;
 }

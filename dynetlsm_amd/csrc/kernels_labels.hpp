@@ -197,16 +197,17 @@ __global__ __launch_bounds__(64 * LAB_WAVES) void k_sample_labels(
 // last bits, so a label can differ when u * total lies within a few ulp of a cumulative sum
 // (about K 1e-16 per draw; the parity tests compare labels exactly over thousands of draws).
 constexpr int LM_THREADS = 1024;
+constexpr int LM_NODES = 8;             // nodes per workgroup: rows 8-15 of the A operand repeat rows 0-7
 typedef double lm_v4d __attribute__((ext_vector_type(4)));
 __host__ __device__ inline int lm_ksteps(int K) { return (K + 3) / 4; }
 __host__ __device__ inline int lm_wstride(int K) { return (4 * lm_ksteps(K)) | 1; }
 __host__ __device__ inline int lm_stride(int K) { return 16 * ((lm_ksteps(K) + 3) / 4) + 1; }
 __host__ __device__ inline size_t lm_lds_bytes(int T, int K) {
-    return ((size_t)T * K * lm_wstride(K) + (size_t)(T + 1) * 16 * lm_stride(K) + 16 * (size_t)T + 2 * K) *
+    return ((size_t)T * K * lm_wstride(K) + (size_t)(T + 1) * LM_NODES * lm_stride(K) + LM_NODES * (size_t)T + 2 * K) *
            sizeof(double);
 }
 __host__ __device__ inline size_t lm_lds_bytes(int T, int K, int D) {
-    return lm_lds_bytes(T, K) + ((size_t)T * 16 + K) * D * sizeof(double);
+    return lm_lds_bytes(T, K) + ((size_t)T * LM_NODES + K) * D * sizeof(double);
 }
 
 template <int KS>
@@ -216,25 +217,40 @@ __global__ __launch_bounds__(LM_THREADS) void k_sample_labels_mfma(
     constexpr int KT = (KS + 3) / 4, S = 16 * KT + 1, WS = (4 * KS) | 1;
     const int T = c.T, K = c.K, N = c.N, D = c.D;
     double *wt = smem;                                  // [T][K][WS] transition matrices, zero padded
-    double *tab = wt + (size_t)T * K * WS;              // [T][16][S] likelihood, then partial marginal
-    double *Mb = tab + (size_t)T * 16 * S;              // [16][S] the step's messages
-    double *U = Mb + 16 * S;                            // [16][T] uniforms
-    double *lognorm = U + 16 * T;                       // [K]
+    constexpr int NN = LM_NODES;
+    double *tab = wt + (size_t)T * K * WS;              // [T][NN][S] likelihood, then partial marginal
+    double *Mb = tab + (size_t)T * NN * S;              // [NN][S] the step's messages
+    double *U = Mb + NN * S;                            // [NN][T] uniforms
+    double *lognorm = U + NN * T;                       // [K]
     double *hiv = lognorm + K;                          // [K] 0.5 / sigma_k
-    double *sx = hiv + K;                               // [T][16][D] the nodes' positions
-    double *smu = sx + (size_t)T * 16 * D;              // [K][D]
+    double *sx = hiv + K;                               // [T][NN][D] the nodes' positions
+    double *smu = sx + (size_t)T * NN * D;              // [K][D]
     const int tid = threadIdx.x, lane = tid & 63;
-    const int node0 = blockIdx.x * 16;
+    const int node0 = blockIdx.x * NN;
 #ifdef DLSM_PIPE_TIMING
     unsigned long long lts[6] = {0, 0, 0, 0, 0, 0};
 #endif
     DLSM_LAB_STAMP(0, (double)lane)
-    for (int q = tid; q < T * 16 * D; q += LM_THREADS) {
+    // the transition matrices' first passes are requested before anything waits on a load
+    constexpr int WPRE = 6;
+    const int TKW = T * K * WS;
+    double wv[WPRE];
+#pragma unroll
+    for (int u = 0; u < WPRE; ++u) {
+        const int q = tid + u * LM_THREADS, r = q / WS, k = q - r * WS;
+        wv[u] = q < TKW && k < K ? w[(size_t)r * K + k] : 0.0;
+    }
+    for (int q = tid; q < T * NN * D; q += LM_THREADS) {
         const int tn = q / D, j = q - tn * D;
-        sx[q] = c.X[((size_t)(tn >> 4) * N + min(node0 + (tn & 15), N - 1)) * D + j];
+        sx[q] = c.X[((size_t)(tn / NN) * N + min(node0 + (tn % NN), N - 1)) * D + j];
     }
     for (int q = tid; q < K * D; q += LM_THREADS) smu[q] = c.mu[q];
-    for (int q = tid; q < T * K * WS; q += LM_THREADS) {
+#pragma unroll
+    for (int u = 0; u < WPRE; ++u) {
+        const int q = tid + u * LM_THREADS;
+        if (q < TKW) wt[q] = wv[u];
+    }
+    for (int q = tid + WPRE * LM_THREADS; q < TKW; q += LM_THREADS) {
         const int r = q / WS, k = q - r * WS;
         wt[q] = k < K ? w[(size_t)r * K + k] : 0.0;
     }
@@ -243,20 +259,20 @@ __global__ __launch_bounds__(LM_THREADS) void k_sample_labels_mfma(
         lognorm[k] = -0.5 * D * log(2 * 3.14159265358979323846 * var);
         hiv[k] = 0.5 * (1. / var);
     }
-    for (int q = tid; q < 16 * T; q += LM_THREADS) {
+    for (int q = tid; q < NN * T; q += LM_THREADS) {
         const int n = q / T, t = q - n * T;
         double u0, u1;
         philox_uniform2(c.seed, (uint32_t)min(node0 + n, N - 1), (uint32_t)t, iter,
                         stream_word(c.chain, STREAM_LABELS), u0, u1);
         U[q] = u0;
     }
-    for (int q = tid; q < 16 * S; q += LM_THREADS) Mb[q] = 1.0;     // the message of time T - 1
+    for (int q = tid; q < NN * S; q += LM_THREADS) Mb[q] = 1.0;     // the message of time T - 1
     __syncthreads();
     DLSM_LAB_STAMP(1, (double)lane)
     {
         const double lm = c.lmbda_p[0];
-        for (int q = tid; q < T * 16 * 4 * KS; q += LM_THREADS) {
-            const int tn = q / (4 * KS), k = q - tn * (4 * KS), t = tn >> 4;
+        for (int q = tid; q < T * NN * 4 * KS; q += LM_THREADS) {
+            const int tn = q / (4 * KS), k = q - tn * (4 * KS), t = tn / NN;
             double v = 0.0;                             // components K .. 4 KS - 1: padding
             if (k < K) {
                 const double *x = sx + (size_t)tn * D;
@@ -265,7 +281,7 @@ __global__ __launch_bounds__(LM_THREADS) void k_sample_labels_mfma(
                 if (t == 0) {
                     for (int j = 0; j < D; ++j) ss += (x[j] - m[j]) * (x[j] - m[j]);
                 } else {
-                    const double *xp = x - (size_t)16 * D;
+                    const double *xp = x - (size_t)NN * D;
                     for (int j = 0; j < D; ++j) {
                         const double mk = lm * m[j] + (1 - lm) * xp[j];
                         ss += (x[j] - mk) * (x[j] - mk);
@@ -281,12 +297,14 @@ __global__ __launch_bounds__(LM_THREADS) void k_sample_labels_mfma(
     if (tid >= 64) return;                              // wavefront 0 carries on alone
     DLSM_LAB_STAMP(2, (double)lane)
     // backward messages (sample_labels.py:164-170)
-    const int an = lane & 15, g = lane >> 4;            // A operand: node an, component 4 s + g
+    const int an = lane & 15, g = lane >> 4;            // A operand: node an % NN, component 4 s + g
+    const int ar = an % NN;
+    const bool own = an < NN;                           // the lanes that file what they compute
     // operands of a step that do not wait for the step before it (likelihood column, B operand)
     // are requested a step ahead, while the matrix instructions run
     double lk[KS], b[KS][KT];
     auto request = [&](int t) {
-        const double *trow = tab + ((size_t)t * 16 + an) * S + g;
+        const double *trow = tab + ((size_t)t * NN + ar) * S + g;
 #pragma unroll
         for (int s = 0; s < KS; ++s) lk[s] = trow[4 * s];
 #pragma unroll
@@ -302,8 +320,8 @@ __global__ __launch_bounds__(LM_THREADS) void k_sample_labels_mfma(
     };
     if (T > 1) request(T - 1);
     for (int t = T - 1; t > 0; --t) {
-        double *trow = tab + ((size_t)t * 16 + an) * S + g;
-        const double *mrow = Mb + an * S + g;
+        double *trow = tab + ((size_t)t * NN + ar) * S + g;
+        const double *mrow = Mb + ar * S + g;
         double a[KS], bb[KS][KT];
 #pragma unroll
         for (int s = 0; s < KS; ++s) a[s] = lk[s] * mrow[4 * s];
@@ -312,7 +330,8 @@ __global__ __launch_bounds__(LM_THREADS) void k_sample_labels_mfma(
 #pragma unroll
             for (int ct = 0; ct < KT; ++ct) bb[s][ct] = b[s][ct];
 #pragma unroll
-        for (int s = 0; s < KS; ++s) trow[4 * s] = a[s];            // the forward pass needs it again
+        for (int s = 0; s < KS; ++s)
+            if (own) trow[4 * s] = a[s];                            // the forward pass needs it again
         if (t > 1) request(t - 1);
         lm_v4d acc[KT];
 #pragma unroll
@@ -325,23 +344,24 @@ __global__ __launch_bounds__(LM_THREADS) void k_sample_labels_mfma(
         // lane holds nodes 4 r + g, components 16 ct + an: one power of two per node, from the
         // largest biased exponent of the row (the sums are >= 0: the high word orders them; the
         // four nodes' reductions are written side by side so that their DPP waits interleave)
-        int e[4];
+        constexpr int NR = NN / 4;                      // result registers that hold real nodes
+        int e[NR];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < NR; ++r) {
             e[r] = __double2hiint(acc[0][r]);
 #pragma unroll
             for (int ct = 1; ct < KT; ++ct) e[r] = max(e[r], __double2hiint(acc[ct][r]));
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) e[r] = max(e[r], __builtin_amdgcn_mov_dpp(e[r], 0x128, 0xF, 0xF, false));   // row_ror:8
+        for (int r = 0; r < NR; ++r) e[r] = max(e[r], __builtin_amdgcn_mov_dpp(e[r], 0x128, 0xF, 0xF, false));  // row_ror:8
 #pragma unroll
-        for (int r = 0; r < 4; ++r) e[r] = max(e[r], __builtin_amdgcn_mov_dpp(e[r], 0x124, 0xF, 0xF, false));   // row_ror:4
+        for (int r = 0; r < NR; ++r) e[r] = max(e[r], __builtin_amdgcn_mov_dpp(e[r], 0x124, 0xF, 0xF, false));  // row_ror:4
 #pragma unroll
-        for (int r = 0; r < 4; ++r) e[r] = max(e[r], __builtin_amdgcn_mov_dpp(e[r], 0x122, 0xF, 0xF, false));   // row_ror:2
+        for (int r = 0; r < NR; ++r) e[r] = max(e[r], __builtin_amdgcn_mov_dpp(e[r], 0x122, 0xF, 0xF, false));  // row_ror:2
 #pragma unroll
-        for (int r = 0; r < 4; ++r) e[r] = max(e[r], __builtin_amdgcn_mov_dpp(e[r], 0x121, 0xF, 0xF, false));   // row_ror:1
+        for (int r = 0; r < NR; ++r) e[r] = max(e[r], __builtin_amdgcn_mov_dpp(e[r], 0x121, 0xF, 0xF, false));  // row_ror:1
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < NR; ++r) {
             const int sh = 1023 - (e[r] >> 20);         // the row's largest entry lands in [1, 2)
 #pragma unroll
             for (int ct = 0; ct < KT; ++ct)
@@ -349,12 +369,13 @@ __global__ __launch_bounds__(LM_THREADS) void k_sample_labels_mfma(
         }
     }
 #pragma unroll
-    for (int s = 0; s < KS; ++s) tab[(size_t)an * S + g + 4 * s] *= Mb[an * S + g + 4 * s];
+    for (int s = 0; s < KS; ++s)
+        if (own) tab[(size_t)ar * S + g + 4 * s] *= Mb[ar * S + g + 4 * s];
     DLSM_LAB_STAMP(3, (double)lane)
     __builtin_amdgcn_s_waitcnt(0xc07f);                 // lgkmcnt(0): LDS writes landed
     __builtin_amdgcn_wave_barrier();
     // forward sampling (:173-188): four lanes per node, KS components each
-    const int fn = lane >> 2, q = lane & 3, node = node0 + fn;
+    const int fl = lane >> 2, fn = fl % NN, q = lane & 3, node = node0 + fn;   // lanes 4 NN .. 63 shadow the first
     int zprev = 0;
     double pv[KS];
 #pragma unroll
@@ -373,7 +394,7 @@ __global__ __launch_bounds__(LM_THREADS) void k_sample_labels_mfma(
         const double ut0 = un;
         if (t + 1 < T) {                                // the next step's operands that do not wait for the label
 #pragma unroll
-            for (int e = 0; e < KS; ++e) pv[e] = tab[((size_t)(t + 1) * 16 + fn) * S + q * KS + e];
+            for (int e = 0; e < KS; ++e) pv[e] = tab[((size_t)(t + 1) * NN + fn) * S + q * KS + e];
             un = U[fn * T + t + 1];
         }
         const double c0 = dpp_move<0x00>(run), c1 = dpp_move<0x55>(run), c2 = dpp_move<0xAA>(run),
@@ -387,7 +408,7 @@ __global__ __launch_bounds__(LM_THREADS) void k_sample_labels_mfma(
         cnt += __builtin_amdgcn_mov_dpp(cnt, 0xB1, 0xF, 0xF, false);             // quad_perm [1, 0, 3, 2]
         cnt += __builtin_amdgcn_mov_dpp(cnt, 0x4E, 0xF, 0xF, false);             // quad_perm [2, 3, 0, 1]
         const int zt = min(cnt, K - 1);
-        if (q == 0 && node < N) z_out[(size_t)t * N + node] = zt;
+        if (q == 0 && fl < NN && node < N) z_out[(size_t)t * N + node] = zt;
         zprev = zt;
     }
 #ifdef DLSM_PIPE_TIMING
@@ -401,24 +422,44 @@ __global__ __launch_bounds__(LM_THREADS) void k_sample_labels_mfma(
 // step, histogram in LDS (same-address global atomics from 2000 wavefronts cost ~170 ns each).
 // `trace_row` (may be NULL): the labels are also filed as bytes, [T][N], the device-resident
 // HDP-LPCM loop's trace row of this sample.
-__global__ __launch_bounds__(256) void k_label_counts(const int32_t *__restrict__ z, int N, int K,
-                                                      int32_t *__restrict__ n_cnt,
-                                                      int32_t *__restrict__ nk_cnt,
-                                                      uint8_t *__restrict__ trace_row) {
+constexpr int LC_THREADS = 1024;
+__global__ __launch_bounds__(LC_THREADS) void k_label_counts(const int32_t *__restrict__ z, int N, int K,
+                                                             int32_t *__restrict__ n_cnt,
+                                                             int32_t *__restrict__ nk_cnt,
+                                                             uint8_t *__restrict__ trace_row) {
     extern __shared__ int32_t hist[];         // K * K + K
     const int t = blockIdx.x;
-    for (int q = threadIdx.x; q < K * K + K; q += 256) hist[q] = 0;
+    // the first two passes' labels are requested before the histogram is cleared (a pass is one
+    // memory round trip: 2 of them at N = 2000 instead of 8 with 256 threads)
+    constexpr int PRE = 2;
+    int zt[PRE], zp[PRE];
+#pragma unroll
+    for (int u = 0; u < PRE; ++u) {
+        const int i = threadIdx.x + u * LC_THREADS;
+        zt[u] = i < N ? z[(size_t)t * N + i] : 0;
+        zp[u] = i < N && t > 0 ? z[(size_t)(t - 1) * N + i] : 0;
+    }
+    for (int q = threadIdx.x; q < K * K + K; q += LC_THREADS) hist[q] = 0;
     __syncthreads();
-    for (int i = threadIdx.x; i < N; i += 256) {
-        const int zt = z[(size_t)t * N + i];
-        const int zp = t == 0 ? 0 : z[(size_t)(t - 1) * N + i];
-        atomicAdd(&hist[zp * K + zt], 1);
-        atomicAdd(&hist[K * K + zt], 1);
-        if (trace_row) trace_row[(size_t)t * N + i] = (uint8_t)zt;
+#pragma unroll
+    for (int u = 0; u < PRE; ++u) {
+        const int i = threadIdx.x + u * LC_THREADS;
+        if (i < N) {
+            atomicAdd(&hist[zp[u] * K + zt[u]], 1);
+            atomicAdd(&hist[K * K + zt[u]], 1);
+            if (trace_row) trace_row[(size_t)t * N + i] = (uint8_t)zt[u];
+        }
+    }
+    for (int i = threadIdx.x + PRE * LC_THREADS; i < N; i += LC_THREADS) {
+        const int a = z[(size_t)t * N + i];
+        const int b = t == 0 ? 0 : z[(size_t)(t - 1) * N + i];
+        atomicAdd(&hist[b * K + a], 1);
+        atomicAdd(&hist[K * K + a], 1);
+        if (trace_row) trace_row[(size_t)t * N + i] = (uint8_t)a;
     }
     __syncthreads();
-    for (int q = threadIdx.x; q < K * K; q += 256) n_cnt[(size_t)t * K * K + q] = hist[q];
-    for (int q = threadIdx.x; q < K; q += 256) nk_cnt[t * K + q] = hist[K * K + q];
+    for (int q = threadIdx.x; q < K * K; q += LC_THREADS) n_cnt[(size_t)t * K * K + q] = hist[q];
+    for (int q = threadIdx.x; q < K; q += LC_THREADS) nk_cnt[t * K + q] = hist[K * K + q];
 }
 
 }  // namespace dlsm
