@@ -22,6 +22,7 @@
 #include "kernels_spec_sweep.hpp"
 #include "kernels_spec_pipe.hpp"
 #include "kernels_pipe_persist.hpp"
+#include "kernels_tail_propose.hpp"
 #include "kernels_ccpipe.hpp"
 #include "kernels_init.hpp"
 #include "kernels_post.hpp"
@@ -1059,8 +1060,16 @@ static int launch_sweep_pipe(dlsm_chain *h, IterRef iter, bool alloc_only = fals
                                   (int)lds));
     if (alloc_only) return DLSM_OK;
     ChainView v = h->view();
-    hipLaunchKernelGGL((k_pipe_propose<DD>), dim3((N + 255) / 256, T), dim3(256), 0, h->stream, v,
-                       pb, iter);
+    {   // the proposal pass, unless the previous iteration's last launch carried it
+        const ProposeBuf nb{pb.prop, pb.consts, pb.sync, pb.nsync, pb.queue0};
+        const bool drawn = !iter.ptr && h->prop_drawn_for == (long)iter.value && h->next_prop_ok &&
+                           h->next_prop.prop == nb.prop && h->next_prop.sync == nb.sync &&
+                           h->next_prop.queue0 == nb.queue0;
+        if (!drawn)
+            hipLaunchKernelGGL((k_pipe_propose<DD>), dim3((N + 255) / 256, T), dim3(256), 0, h->stream, v,
+                               pb, iter);
+        h->next_prop = nb; h->next_prop_ok = true; h->prop_drawn_for = -1; h->pipe_touched = true;
+    }
     if (persist) {
         PipeSync ps;
         ps.words = pb.sync; ps.err = h->pipe_err;
@@ -1248,7 +1257,12 @@ static int check_ready_sweep(dlsm_chain *h) {
 
 static int enqueue_sweep(dlsm_chain *h, IterRef iter, int algo, bool alloc_only = false) {
     int rc = DLSM_OK;
+    if (!alloc_only) h->pipe_touched = false;
     DISPATCH_D(h, h->D, rc = launch_sweep<DD>(h, iter, algo, alloc_only));
+    if (!alloc_only) {              // only a pipelined sweep leaves proposal buffers a tail can fill
+        if (!h->pipe_touched) h->next_prop_ok = false;
+        h->prop_drawn_for = -1;
+    }
     return rc;
 }
 
@@ -1265,6 +1279,7 @@ int dlsm_sweep_positions(dlsm_chain *h, uint32_t iter, int algo) {
     int rc = check_sweep_algo(h, algo); if (rc) return rc;
     HIPCHK(h, hipSetDevice(h->device));
     rc = check_ready_sweep(h); if (rc) return rc;
+    h->prop_drawn_for = -1;
     rc = enqueue_sweep(h, IterRef{iter, nullptr}, algo); if (rc) return rc;
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return check_pipe_err(h);
@@ -1531,7 +1546,7 @@ int dlsm_trace_alloc(dlsm_chain *h, int n_total, double logp0) {
 // With `counter` the iteration index is read from device memory (captured graph: the
 // first kernel advances it), otherwise it is the value `it`.
 static int enqueue_lsm_iteration(dlsm_chain *h, int it, bool counter, int procrustes_ref,
-                                 bool alloc_only = false) {
+                                 bool alloc_only = false, bool draw_next = false) {
     const size_t row = (size_t)h->T * h->N * h->D;
     const IterRef ir{(uint32_t)it, counter ? &h->lsm->iter : nullptr};
     int rc = DLSM_OK;
@@ -1589,8 +1604,17 @@ static int enqueue_lsm_iteration(dlsm_chain *h, int it, bool counter, int procru
     rc = loglik_records(h, 2, h->lsm->cand, nullptr, nullptr, &nrec); if (rc) return rc;
     {
         ProfScope ps(h, DLSM_K_FINALIZE);
-        hipLaunchKernelGGL(k_lsm_finalize, dim3(1), dim3(256), 0, h->stream, h->partials, nrec,
-                           h->lsm, h->intercept, h->trace_ic, h->trace_logp, ir);
+        if (draw_next && !counter && h->next_prop_ok) {
+            // the next sweep's proposal pass rides along (kernels_tail_propose.hpp)
+            ChainView v = h->view();
+            DISPATCH_D(h, h->D, hipLaunchKernelGGL((k_lsm_finalize_propose<DD>),
+                                                   dim3(1 + propose_blocks(h->T, h->N)), dim3(256), 0,
+                                                   h->stream, h->partials, nrec, h->lsm, h->intercept,
+                                                   h->trace_ic, h->trace_logp, ir, v, h->next_prop));
+            h->prop_drawn_for = (long)it + 1;
+        } else
+            hipLaunchKernelGGL(k_lsm_finalize, dim3(1), dim3(256), 0, h->stream, h->partials, nrec,
+                               h->lsm, h->intercept, h->trace_ic, h->trace_logp, ir);
     }
     HIPCHK(h, hipGetLastError());
     return DLSM_OK;
@@ -1647,11 +1671,16 @@ int dlsm_lsm_run(dlsm_chain *h, int first, int count, int procrustes_ref) {
             return DLSM_OK;
         }
     }
+    // (read per call: the tests switch it inside one process)
+    const bool ride = !(getenv("DLSM_TAIL_PROPOSE") && atoi(getenv("DLSM_TAIL_PROPOSE")) == 0);
+    h->prop_drawn_for = -1;
     for (int it = first; it < first + count; ++it) {
         rc = enqueue_lsm_iteration(h, it, false,
-                                   it > h->lsm_cfg.n_iter_procrustes ? procrustes_ref : -1);
+                                   it > h->lsm_cfg.n_iter_procrustes ? procrustes_ref : -1, false,
+                                   ride && it + 1 < first + count);
         if (rc) return rc;
     }
+    h->prop_drawn_for = -1;
     return DLSM_OK;
 }
 

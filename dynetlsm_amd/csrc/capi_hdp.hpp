@@ -39,7 +39,7 @@ void hdp_free_trace(dlsm_chain *h) {
 }
 
 template <int DD>
-int enqueue_hdp_iteration(dlsm_chain *h, int it) {
+int enqueue_hdp_iteration(dlsm_chain *h, int it, bool draw_next) {
     const IterRef ir{(uint32_t)it, nullptr};
     const int T = h->T, K = h->K, N = h->N;
     int rc = enqueue_sweep(h, ir, h->hdp_cfg.sweep_algo); if (rc) return rc;
@@ -83,7 +83,12 @@ int enqueue_hdp_iteration(dlsm_chain *h, int it) {
                        (size_t)(K * K + K) * sizeof(double), h->stream, v, hb, h->hdp, ir);
     HdpTrace tr{h->trace_ic, h->trace_logp, h->htr_mu, h->htr_sigma, h->htr_beta, h->htr_w,
                 h->htr_lambda, h->htr_hyper};
-    hipLaunchKernelGGL(k_hdp_hypers, dim3(1), dim3(HH_THREADS), 0, h->stream, v, hb, h->hdp, tr, ir);
+    if (draw_next && h->next_prop_ok) {     // with the next sweep's proposal pass (kernels_tail_propose.hpp)
+        hipLaunchKernelGGL((k_hdp_hypers_propose<DD>), dim3(1 + propose_blocks(T, N)), dim3(HH_THREADS), 0,
+                           h->stream, v, hb, h->hdp, tr, ir, h->next_prop);
+        h->prop_drawn_for = (long)it + 1;
+    } else
+        hipLaunchKernelGGL(k_hdp_hypers, dim3(1), dim3(HH_THREADS), 0, h->stream, v, hb, h->hdp, tr, ir);
     HIPCHK(h, hipGetLastError());
     return DLSM_OK;
 }
@@ -251,10 +256,14 @@ int dlsm_hdp_run(dlsm_chain *h, int first, int count) {
          "iteration range out of the trace");
     HIPCHK(h, hipSetDevice(h->device));
     int rc = check_ready_hdp(h); if (rc) return rc;
+    // (read per call: the tests switch it inside one process)
+    const bool ride = !(getenv("DLSM_TAIL_PROPOSE") && atoi(getenv("DLSM_TAIL_PROPOSE")) == 0);
+    h->prop_drawn_for = -1;
     for (int it = first; it < first + count; ++it) {
-        DISPATCH_D(h, h->D, rc = enqueue_hdp_iteration<DD>(h, it));
+        DISPATCH_D(h, h->D, rc = enqueue_hdp_iteration<DD>(h, it, ride && it + 1 < first + count));
         if (rc) return rc;
     }
+    h->prop_drawn_for = -1;
     // the log-posterior trace of these rows: one batched pass over the trace, behind the iterations
     if (count > 0) DISPATCH_D(h, h->D, rc = enqueue_hdp_logp_batch<DD>(h, first, count));
     return rc;

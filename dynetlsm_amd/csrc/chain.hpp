@@ -35,6 +35,13 @@ struct ChainView {
     uint64_t seed; uint32_t chain;
 };
 
+// What the proposal pass of the pipelined sweeps writes (kernels_spec_pipe.hpp): the iteration's
+// last launch can carry the next sweep's pass (kernels_tail_propose.hpp)
+struct ProposeBuf {
+    double *prop, *consts;
+    int32_t *sync; int nsync, queue0;
+};
+
 // intercept sampler + LSM bookkeeping that lives on the device
 struct LsmDeviceState {
     double intercept_prior[2];
@@ -122,6 +129,9 @@ struct dlsm_chain {
     // sweep v2 scratch
     double *spec = nullptr; size_t spec_cap = 0;
     double *pipe = nullptr; size_t pipe_cap = 0;        // pipelined sweep (algo 4) buffers
+    // the proposal buffers of the sweep enqueued last (valid for a pipelined sweep only) and the
+    // iteration whose proposals the previous iteration's last launch has already drawn into them
+    dlsm::ProposeBuf next_prop{}; bool next_prop_ok = false, pipe_touched = false; long prop_drawn_for = -1;
     int32_t *pipe_err = nullptr; bool pipe_err_armed = false;   // persistent sweep (algo 7): sticky error word
     int n_cu = 256;
     int32_t *nctrl = nullptr; size_t nctrl_cap = 0;     // valid controls per (t, i, dir)

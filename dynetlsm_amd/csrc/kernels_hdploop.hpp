@@ -473,8 +473,8 @@ struct HdpStamp {
 // hyper-parameters as thread 0 sets them).  The log-posterior of the sample is NOT computed here:
 // dlsm_hdp_run evaluates it for all the rows it produced in one batched pass over the trace
 // (k_hdp_logp_batch_*), off the iteration's critical path.
-__global__ __launch_bounds__(HH_THREADS) void k_hdp_hypers(ChainView c, HdpLoopBuf hb,
-                                                           HdpDeviceState *hs, HdpTrace tr, IterRef ir) {
+__device__ __forceinline__ void hdp_hypers_wg(const ChainView &c, const HdpLoopBuf &hb,
+                                              HdpDeviceState *hs, const HdpTrace &tr, IterRef ir) {
     DLSM_HDP_STAMP(3)
     __shared__ double red[2][HH_THREADS / 64];
     __shared__ double sC[3], sLam;
@@ -554,6 +554,11 @@ __global__ __launch_bounds__(HH_THREADS) void k_hdp_hypers(ChainView c, HdpLoopB
     double *hy = tr.hyper + it * 6;
     hy[0] = hs->gamma; hy[1] = hs->alpha_init; hy[2] = hs->alpha; hy[3] = hs->kappa;
     hy[4] = hs->mvp; hy[5] = hs->b;
+}
+
+__global__ __launch_bounds__(HH_THREADS) void k_hdp_hypers(ChainView c, HdpLoopBuf hb,
+                                                           HdpDeviceState *hs, HdpTrace tr, IterRef ir) {
+    hdp_hypers_wg(c, hb, hs, tr, ir);
 }
 
 // intercept step (sample_coefficients.py:76-86 around the fused two-candidate pass whose records

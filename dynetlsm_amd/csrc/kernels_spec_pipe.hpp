@@ -70,20 +70,25 @@ __host__ __device__ __forceinline__ int pipe_window_start(int b, int G) {
     return ws > 0 ? ws : 0;
 }
 
+// The proposal pass of a sweep, as pieces: it runs as its own launch (k_pipe_propose) or, inside
+// the device-resident loops, as extra workgroups of the previous iteration's last launch
+// (kernels_tail_propose.hpp) - everything it reads is final by then.
+__device__ __forceinline__ void pipe_propose_consts(const ChainView &c, double *consts,
+                                                    const double *intercept) {
+    const double E = c.model == DLSM_UNDIRECTED ? exp(intercept[0]) : exp(intercept[0] + intercept[1]);
+    consts[0] = E;
+    consts[1] = (double)flush_interval(E);
+}
+
+// workgroup `fb` of ceil(N / 256) T, 256 threads
 template <int D>
-__global__ __launch_bounds__(256) void k_pipe_propose(ChainView c, PipeBuf pb, IterRef ir) {
-    const uint32_t iter = ir.get();
-    const int N = c.N;
-    const int t = blockIdx.y;
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
-        const double E = c.model == DLSM_UNDIRECTED ? exp(c.intercept[0])
-                                                    : exp(c.intercept[0] + c.intercept[1]);
-        pb.consts[0] = E;
-        pb.consts[1] = (double)flush_interval(E);
-    }
+__device__ __forceinline__ void pipe_propose_rows(const ChainView &c, const ProposeBuf &pb, uint32_t iter,
+                                                  int fb, int tid) {
+    const int N = c.N, nbx = (N + 255) / 256;
+    const int t = fb / nbx;
+    const int j = (fb - t * nbx) * 256 + tid;
     if (pb.sync) {
-        const int flat = ((int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x) * 256 + (int)threadIdx.x;
+        const int flat = fb * 256 + tid;
         if (flat < pb.nsync) pb.sync[(size_t)flat * 16] = flat == 0 ? pb.queue0 : 0;
     }
     if (j >= N) return;
@@ -102,6 +107,14 @@ __global__ __launch_bounds__(256) void k_pipe_propose(ChainView c, PipeBuf pb, I
         pr[D] = u0;
     }
     pr[D + 1] = 0.0;
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void k_pipe_propose(ChainView c, PipeBuf pb, IterRef ir) {
+    const int fb = (int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x;
+    if (fb == 0 && threadIdx.x == 0) pipe_propose_consts(c, pb.consts, c.intercept);
+    const ProposeBuf nb{pb.prop, pb.consts, pb.sync, pb.nsync, pb.queue0};
+    pipe_propose_rows<D>(c, nb, ir.get(), fb, (int)threadIdx.x);
 }
 
 // One neighbour of the directed model (both directions of the pair share the distance):

@@ -527,7 +527,7 @@ __global__ __launch_bounds__(PS2_THREADS) void k_post_apply(
 // (sample_coefficients.py:76-86, metropolis.py:96-136), log-posterior trace
 // (lsm.py:576-625).  One workgroup.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_lsm_finalize(
+__device__ __forceinline__ void lsm_finalize_wg(
     const double *__restrict__ partials, int nrec, LsmDeviceState *lsm,
     double *__restrict__ intercept, double *__restrict__ trace_ic,
     double *__restrict__ trace_logp, IterRef ir) {
@@ -556,6 +556,13 @@ __global__ __launch_bounds__(256) void k_lsm_finalize(
         trace_ic[(size_t)it * 2 + 1] = 0.0;
         trace_logp[it] = ll + lsm->prior_x - 0.5 * (b - pm) * (b - pm) / v;
     }
+}
+
+__global__ __launch_bounds__(256) void k_lsm_finalize(
+    const double *__restrict__ partials, int nrec, LsmDeviceState *lsm,
+    double *__restrict__ intercept, double *__restrict__ trace_ic,
+    double *__restrict__ trace_logp, IterRef ir) {
+    lsm_finalize_wg(partials, nrec, lsm, intercept, trace_ic, trace_logp, ir);
 }
 
 // iteration counter of the captured-graph path

@@ -149,6 +149,30 @@ def test_device_loop_with_the_pipelined_sweep(eng):
     _run_both(eng, 4, 600, 20, 9, n_it=3, algo=0)
 
 
+def test_device_loop_proposals_drawn_by_the_previous_iteration(eng, monkeypatch):
+    """several iterations per dlsm_hdp_run call: the sweep's proposal pass rides in the launch of
+    the hyper-parameters (kernels_tail_propose.hpp); DLSM_TAIL_PROPOSE=0 keeps it a launch of its
+    own - bit for bit the same trace"""
+    T, N, K = 4, 600, 20
+    Y, X, mu, sigma, z, beta, w = _case(T, N, K, 21)
+    hp = _hyper()
+    out = {}
+    for mode in ('0', '1'):
+        monkeypatch.setenv('DLSM_TAIL_PROPOSE', mode)
+        with eng.Chain(T, N, 2, 'undirected', seed=5, chain_id=3) as c:
+            c.upload_network(Y); c.set_positions(X); c.set_intercepts([0.6])
+            c.set_samplers(eng.SamplerGrid(T, N, 0.15, tune=4, tune_interval=2))
+            c.set_prior_mixture(mu, sigma, 0.8, z)
+            c.hdp_configure(hp, beta, w, 0.5, 2.0, step_size_intercept=0.1, tune=4,
+                            tune_interval=100, sweep_algo=4)
+            c.hdp_trace_alloc(9)
+            c.hdp_run(1, 5); c.hdp_run(6, 3)
+            out[mode] = c.hdp_trace_read(0, 9)
+    for key in out['0']:
+        np.testing.assert_array_equal(out['0'][key], out['1'][key], err_msg=key)
+    assert not np.array_equal(out['1']['Xs'][8], out['1']['Xs'][4])
+
+
 def test_truncated_normal_far_tails(eng):
     """the blending coefficient's draw when its conditional sits far outside [0, 1] or is very
     sharp: the device's log-space quantile against scipy's (through the oracle)"""

@@ -730,6 +730,32 @@ def test_lsm_device_loop_equals_oracle_iterations(eng, monks, N, algo):
     np.testing.assert_allclose(cfg.i_step_size[0], isamp.step_size, rtol=1e-14)
 
 
+@pytest.mark.parametrize('algo', [4, 6, 7])
+def test_lsm_device_loop_proposals_drawn_by_the_previous_iteration(eng, algo, monkeypatch):
+    """inside dlsm_lsm_run the sweep's proposal pass rides in the previous iteration's last
+    launch (kernels_tail_propose.hpp; DLSM_TAIL_PROPOSE=0: its own launch): same trace bit for
+    bit, across two calls, with step-size tuning under way"""
+    X, _, Y, _ = _rand_net(33, 4, 600, scale=0.05)
+    T, N = Y.shape[:2]
+    out = {}
+    for mode in ('0', '1'):
+        monkeypatch.setenv('DLSM_TAIL_PROPOSE', mode)
+        gg = eng.SamplerGrid(T, N, 0.1, tune=6, tune_interval=2)
+        with eng.Chain(T, N, 2, 'undirected', seed=23, chain_id=1) as c:
+            c.upload_network(Y); c.set_positions(X); c.set_intercepts([0.2])
+            c.set_prior_random_walk(2.0, 0.1); c.set_samplers(gg)
+            c.lsm_configure([0.2], 2.0, step_size_intercept=0.1, tune=6, tune_interval=3,
+                            n_iter_procrustes=10 ** 6, sweep_algo=algo)
+            c.trace_alloc(10)
+            c.lsm_run(1, 5)
+            c.sweep_positions(77, algo=algo)          # a lone sweep in between draws for itself
+            c.lsm_run(6, 4)
+            out[mode] = c.trace_read(0, 10) + (c.get_positions(),)
+    for a, b in zip(out['0'], out['1']):
+        np.testing.assert_array_equal(a, b)
+    assert not np.array_equal(out['1'][0][9], out['1'][0][5])
+
+
 def test_lsm_device_loop_graph_replay_equals_eager(eng, monks, monkeypatch):
     """DLSM_GRAPH=1: the captured iteration (device-side iteration counter, rotation
     decided in-kernel) replays to the same trace as eager launches, including across
