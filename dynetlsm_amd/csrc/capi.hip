@@ -202,12 +202,33 @@ int check_ready_loglik(dlsm_chain *h) {
     return DLSM_OK;
 }
 
+// the case-control pass with every load up front (k_loglik_casecontrol_pf): when a node's
+// out-edges fit one trip and its controls two
+static bool cc_prefetch_form(const dlsm_chain *h) {
+    return h->model == DLSM_DIRECTED_CASE_CONTROL && h->Dout <= 64 && h->C <= 128 &&
+           !getenv("DLSM_CC_LOGLIK_PLAIN");
+}
+// its gather records (positions and both candidates' radii, one record per node)
+template <int DD>
+int ensure_xr(dlsm_chain *h) {
+    const size_t need = (size_t)h->T * h->N * llcc_record_width(DD);
+    if (h->xr_cap < need) {
+        if (h->xr) hipFree(h->xr);
+        h->xr = nullptr; h->xr_cap = 0;
+        HIPCHK(h, hipMalloc((void **)&h->xr, need * sizeof(double)));
+        h->xr_cap = need;
+    }
+    return DLSM_OK;
+}
+
 // Enqueue the log-likelihood record kernel for M candidates whose intercepts
 // are at device address `d_ic` (and radii r0 / r1); returns the record count.
+// reuse_pack: the records are those this pass needs already (the caller knows); rslot: which of
+// a record's two radii a single candidate reads
 template <int DD>
 int launch_loglik_records(dlsm_chain *h, int M, const double *d_ic,
                           const double *r0, const double *r1, int *nrec_out,
-                          bool reuse_pack = false) {
+                          bool reuse_pack = false, int rslot = 0) {
     const int nb = ll_blocks(h);
     int rc = ensure_partials(h, (size_t)nb * 4);
     if (rc) return rc;
@@ -221,24 +242,16 @@ int launch_loglik_records(dlsm_chain *h, int M, const double *d_ic,
         if (M == 1) hipLaunchKernelGGL((k_loglik_directed<DD, 1>), dim3(nb), dim3(LL_THREADS), 0, h->stream, v, cand, h->partials);
         else hipLaunchKernelGGL((k_loglik_directed<DD, 2>), dim3(nb), dim3(LL_THREADS), 0, h->stream, v, cand, h->partials);
     } else {
-        // every load up front when a node's out-edges fit one trip and its controls two
-        const bool pf = h->Dout <= 64 && h->C <= 128 && !getenv("DLSM_CC_LOGLIK_PLAIN");
+        const bool pf = cc_prefetch_form(h);
         if (pf) {       // positions and both candidates' radii as one record per node
             const size_t nodes = (size_t)h->T * h->N;
-            const size_t need = nodes * llcc_record_width(DD);
-            if (h->xr_cap < need) {
-                if (h->xr) hipFree(h->xr);
-                h->xr = nullptr; h->xr_cap = 0;
-                HIPCHK(h, hipMalloc((void **)&h->xr, need * sizeof(double)));
-                h->xr_cap = need;
-            }
-            // (reuse_pack: the caller knows positions and radii are those of the pass before)
+            int rc2 = ensure_xr<DD>(h); if (rc2) return rc2;
             if (!reuse_pack)
                 hipLaunchKernelGGL((k_pack_xr<DD>), dim3((unsigned)((nodes + 255) / 256)), dim3(256), 0,
                                    h->stream, h->X, r0, M > 1 ? r1 : r0, (long)nodes, h->N, h->xr);
         }
-        if (pf && M == 1) hipLaunchKernelGGL((k_loglik_casecontrol_pf<DD, 1>), dim3(nb), dim3(256), 0, h->stream, v, cand, h->xr, h->partials);
-        else if (pf) hipLaunchKernelGGL((k_loglik_casecontrol_pf<DD, 2>), dim3(nb), dim3(256), 0, h->stream, v, cand, h->xr, h->partials);
+        if (pf && M == 1) hipLaunchKernelGGL((k_loglik_casecontrol_pf<DD, 1>), dim3(nb), dim3(256), 0, h->stream, v, cand, h->xr, h->partials, rslot);
+        else if (pf) hipLaunchKernelGGL((k_loglik_casecontrol_pf<DD, 2>), dim3(nb), dim3(256), 0, h->stream, v, cand, h->xr, h->partials, 0);
         else if (M == 1) hipLaunchKernelGGL((k_loglik_casecontrol<DD, 1>), dim3(nb), dim3(256), 0, h->stream, v, cand, h->partials);
         else hipLaunchKernelGGL((k_loglik_casecontrol<DD, 2>), dim3(nb), dim3(256), 0, h->stream, v, cand, h->partials);
     }
@@ -248,8 +261,8 @@ int launch_loglik_records(dlsm_chain *h, int M, const double *d_ic,
 }
 
 int loglik_records(dlsm_chain *h, int M, const double *d_ic, const double *r0,
-                   const double *r1, int *nrec, bool reuse_pack = false) {
-    DISPATCH_D(h, h->D, return launch_loglik_records<DD>(h, M, d_ic, r0, r1, nrec, reuse_pack));
+                   const double *r1, int *nrec, bool reuse_pack = false, int rslot = 0) {
+    DISPATCH_D(h, h->D, return launch_loglik_records<DD>(h, M, d_ic, r0, r1, nrec, reuse_pack, rslot));
     return DLSM_OK;
 }
 
@@ -1145,8 +1158,15 @@ static int launch_sweep_ccpipe(dlsm_chain *h, IterRef iter, bool alloc_only = fa
     PipeBuf pp{};                   // the proposal kernel's view: proposals + its two constants
     pp.prop = pb.prop; pp.consts = consts;
     ChainView v = h->view();
-    hipLaunchKernelGGL((k_pipe_propose<DD>), dim3((N + 255) / 256, T), dim3(256), 0, h->stream, v,
-                       pp, iter);
+    {   // the proposal pass, unless the previous iteration's last launch carried it
+        const ProposeBuf nb{pp.prop, pp.consts, nullptr, 0, 0};
+        const bool drawn = !iter.ptr && h->prop_drawn_for == (long)iter.value && h->next_prop_ok &&
+                           h->next_prop.prop == nb.prop && h->next_prop.sync == nullptr;
+        if (!drawn)
+            hipLaunchKernelGGL((k_pipe_propose<DD>), dim3((N + 255) / 256, T), dim3(256), 0, h->stream, v,
+                               pp, iter);
+        h->next_prop = nb; h->next_prop_ok = true; h->prop_drawn_for = -1; h->pipe_touched = true;
+    }
     hipLaunchKernelGGL((k_ccpipe_pack<DD>), dim3((unsigned)(((size_t)T * N + 255) / 256)), dim3(256), 0,
                        h->stream, v, pb);
     const int nodes_max = ((T + 1) / 2 + T / 2) * std::min(CP_B, N);
@@ -1290,7 +1310,7 @@ int dlsm_sweep_positions(dlsm_chain *h, uint32_t iter, int algo) {
 template <int DD>
 static int launch_post(dlsm_chain *h, const double *d_xref, int n_iter_procrustes,
                        int do_center, LsmDeviceState *lsm, IterRef iter, double *d_R,
-                       bool alloc_only = false, double *trace_X = nullptr) {
+                       bool alloc_only = false, double *trace_X = nullptr, double *xr = nullptr) {
     ChainView v = h->view();
     const long rows = (long)h->T * h->N;
     const int nb = (int)std::min<long>(PS_BLOCKS, (rows + PS2_THREADS - 1) / PS2_THREADS);
@@ -1306,7 +1326,7 @@ static int launch_post(dlsm_chain *h, const double *d_xref, int n_iter_procruste
                        d_xref, n_iter_procrustes, iter, rec);
     hipLaunchKernelGGL((k_post_apply<DD>), dim3(nb), dim3(PS2_THREADS), 0, h->stream, v,
                        d_xref ? 1 : 0, n_iter_procrustes, do_center, rec, nb, lsm, iter, d_R,
-                       trace_X);
+                       trace_X, xr);
     HIPCHK(h, hipGetLastError());
     return DLSM_OK;
 }
@@ -1554,8 +1574,11 @@ static int enqueue_lsm_iteration(dlsm_chain *h, int it, bool counter, int procru
         hipLaunchKernelGGL(k_advance_iter, dim3(1), dim3(1), 0, h->stream, &h->lsm->iter);
     rc = enqueue_sweep(h, ir, h->lsm_cfg.sweep_algo, alloc_only); if (rc) return rc;
     const double *xref = procrustes_ref >= 0 ? h->trace_X + row * procrustes_ref : nullptr;
+    // case-control: the centring pass also writes the log-likelihood's gather records
+    const bool pf = cc_prefetch_form(h);
+    if (pf) { DISPATCH_D(h, h->D, rc = ensure_xr<DD>(h)); if (rc) return rc; }
     DISPATCH_D(h, h->D, rc = launch_post<DD>(h, xref, h->lsm_cfg.n_iter_procrustes, 1, h->lsm,
-                                             ir, nullptr, alloc_only, h->trace_X));
+                                             ir, nullptr, alloc_only, h->trace_X, pf ? h->xr : nullptr));
     if (rc) return rc;
     if (alloc_only) return ensure_partials(h, (size_t)ll_blocks(h) * 4);
     int nrec = 0;
@@ -1567,37 +1590,42 @@ static int enqueue_lsm_iteration(dlsm_chain *h, int it, bool counter, int procru
         // The sweep moved the positions, so the first step evaluates proposal and current
         // state; after it the current state's log-likelihood is carried (lsm->ll_cur) and the
         // later steps evaluate their proposal only: 4 candidate evaluations, not 6.
-        // (the sum of a pass's records, the accept / reject and the next step's proposal share a
-        // launch; the second pass reuses the packed records of the first: same positions and radii)
-        hipLaunchKernelGGL(k_dir_propose_intercept, dim3(1), dim3(1), 0, h->stream, v, h->lsm,
-                           h->intercept, 0, ir);
+        // Launches besides the three passes: 4 (round 2: eleven).  The first intercept proposal is
+        // drawn by the centring pass, which also writes the passes' gather records; the sum of a
+        // pass's records, the accept / reject and the next step's proposal share a launch, and
+        // the radii proposal's gamma variates and density terms ride in those two launches (they
+        // file the proposal in the records' second radius slot); its closing workgroup is a
+        // launch; the last pass's sum, the radii's accept / reject and the trace row share the
+        // last launch, which can carry the next sweep's proposal pass.
+        // scaled-Dirichlet proposal of the radii: its records live behind the log-likelihood records
+        const int nblk = (h->N + DP_THREADS - 1) / DP_THREADS;
+        rc = ensure_partials(h, (size_t)ll_blocks(h) * 4 + (size_t)nblk * (1 + DP_COLS));
+        if (rc) return rc;
+        double *rrec = h->partials + (size_t)ll_blocks(h) * 4, *rrec2 = rrec + nblk;
+        double *xr = pf ? h->xr : nullptr;
         for (int which = 0; which < 2; ++which) {
             const int M = which == 0 ? 2 : 1;
-            rc = loglik_records(h, M, h->lsm->cand, h->radii, h->radii, &nrec, which == 1);
+            rc = loglik_records(h, M, h->lsm->cand, h->radii, h->radii, &nrec, pf || which == 1);
             if (rc) return rc;
-            hipLaunchKernelGGL(k_dir_reduce_accept_intercept, dim3(1), dim3(256), 0, h->stream,
-                               h->partials, nrec, M, ll2, v, h->lsm, h->intercept, which, which,
-                               which == 0 ? 1 : -1, ir);
+            const DirRider rd{which + 1, nblk, h->radii, h->radii_alt, rrec, rrec2, xr};
+            DISPATCH_D(h, h->D, hipLaunchKernelGGL((k_dir_reduce_accept_intercept<DD>), dim3(1 + nblk),
+                                                   dim3(256), 0, h->stream, h->partials, nrec, M, ll2, v,
+                                                   h->lsm, h->intercept, which, which,
+                                                   which == 0 ? 1 : -1, ir, rd));
         }
-        {   // scaled-Dirichlet proposal: records live behind the log-likelihood records
-            const int nblk = (h->N + DP_THREADS - 1) / DP_THREADS;
-            rc = ensure_partials(h, (size_t)ll_blocks(h) * 4 + (size_t)nblk * (1 + DP_COLS));
-            if (rc) return rc;
-            double *rec = h->partials + (size_t)ll_blocks(h) * 4, *rec2 = rec + nblk;
-            hipLaunchKernelGGL(k_dir_radii_gamma, dim3(nblk), dim3(DP_THREADS), 0, h->stream, v,
-                               h->lsm, h->radii, h->radii_alt, rec, ir);
-            hipLaunchKernelGGL(k_dir_radii_terms, dim3(nblk), dim3(DP_THREADS), 0, h->stream, v,
-                               h->lsm, h->radii, h->radii_alt, rec, rec2);
-            hipLaunchKernelGGL(k_dir_radii_finish, dim3(1), dim3(DR_THREADS), 0, h->stream, v,
-                               h->lsm, h->radii, h->radii_alt, rec2, nblk, ir);
-        }
+        DISPATCH_D(h, h->D, hipLaunchKernelGGL((k_dir_radii_finish<DD>), dim3(1), dim3(DR_THREADS), 0,
+                                               h->stream, v, h->lsm, h->radii, h->radii_alt, rrec2, nblk,
+                                               xr, ir));
         // the proposed radii at the current intercepts (one candidate)
-        rc = loglik_records(h, 1, h->intercept, h->radii_alt, h->radii_alt, &nrec); if (rc) return rc;
-        hipLaunchKernelGGL(k_reduce_loglik, dim3(1), dim3(256), 0, h->stream, h->partials, nrec,
-                           h->model, 1, h->intercept, ll2);
-        hipLaunchKernelGGL(k_dir_accept_radii, dim3(1), dim3(DR_THREADS), 0, h->stream, ll2, v,
-                           h->lsm, h->radii, h->radii_alt, h->intercept, h->trace_ic,
-                           h->trace_radii, h->trace_logp, ir);
+        rc = loglik_records(h, 1, h->intercept, h->radii_alt, h->radii_alt, &nrec, pf, 1);
+        if (rc) return rc;
+        const bool ride = draw_next && !counter && h->next_prop_ok;
+        const int grid = 1 + (ride ? (propose_blocks(h->T, h->N) + DR_THREADS / 256 - 1) / (DR_THREADS / 256) : 0);
+        DISPATCH_D(h, h->D, hipLaunchKernelGGL((k_dir_tail<DD>), dim3(grid), dim3(DR_THREADS), 0, h->stream,
+                                               h->partials, nrec, ll2, v, h->lsm, h->radii, h->radii_alt,
+                                               h->intercept, h->trace_ic, h->trace_radii, h->trace_logp,
+                                               ir, h->next_prop, ride ? 1 : 0));
+        if (ride) h->prop_drawn_for = (long)it + 1;
         HIPCHK(h, hipGetLastError());
         return DLSM_OK;
     }

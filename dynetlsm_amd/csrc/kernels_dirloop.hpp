@@ -8,6 +8,8 @@
 #pragma once
 #include "chain.hpp"
 #include "device_common.hpp"
+#include "kernels_sweep.hpp"      // dir_propose_intercept, reduce_records
+#include "kernels_spec_pipe.hpp"  // the sweep's proposal pass
 
 namespace dlsm {
 
@@ -24,26 +26,6 @@ __device__ __forceinline__ double tune_dirichlet(double step, double rate) {
     return step;
 }
 
-// cand = [proposal pair | current pair] for intercept `which` (one thread)
-__device__ __forceinline__ void dir_propose_intercept(const ChainView &c, LsmDeviceState *lsm,
-                                                      const double *__restrict__ intercept,
-                                                      int which, uint32_t iter) {
-    double u0, u1, z0, z1;
-    philox_uniform2(c.seed, (uint32_t)which, 0, iter, stream_word(c.chain, STREAM_INTERCEPT), u0, u1);
-    box_muller(u0, u1, z0, z1);
-    const double b0 = intercept[0], b1 = intercept[1];
-    lsm->cand[0] = which == 0 ? b0 + lsm->i_step[0] * z0 : b0;
-    lsm->cand[1] = which == 1 ? b1 + lsm->i_step[1] * z0 : b1;
-    lsm->cand[2] = b0;
-    lsm->cand[3] = b1;
-    philox_uniform2(c.seed, (uint32_t)which, 1, iter, stream_word(c.chain, STREAM_INTERCEPT), u0, u1);
-    lsm->logu = log(u0);
-}
-__global__ void k_dir_propose_intercept(ChainView c, LsmDeviceState *lsm,
-                                        const double *__restrict__ intercept, int which,
-                                        IterRef ir) {
-    dir_propose_intercept(c, lsm, intercept, which, ir.get());
-}
 // accept / reject of intercept `which` from ll = [at the proposal, at the current pair] (one thread)
 __device__ __forceinline__ void dir_accept_intercept(const double *ll, LsmDeviceState *lsm,
                                                      double *__restrict__ intercept, int which,
@@ -66,25 +48,6 @@ __global__ void k_dir_accept_intercept(const double *__restrict__ ll, LsmDeviceS
                                        double *__restrict__ intercept, int which, int carried) {
     dir_accept_intercept(ll, lsm, intercept, which, carried);
 }
-// The iteration's chain around a log-likelihood pass in ONE single-workgroup launch instead of
-// three: the fixed-order sum of the pass's records (k_reduce_loglik), the accept / reject of
-// intercept `which`, and - next_which >= 0 - the proposal of the next intercept step.
-// (kernels_loglik.hpp's reduce_records is in scope: capi.hip includes it first.)
-__global__ __launch_bounds__(256) void k_dir_reduce_accept_intercept(
-    const double *__restrict__ partials, int nrec, int M, double *__restrict__ ll_out, ChainView c,
-    LsmDeviceState *lsm, double *__restrict__ intercept, int which, int carried, int next_which,
-    IterRef ir) {
-    __shared__ double scratch[4 * 256];
-    __shared__ double sums[8];
-    reduce_records(partials, nrec, M, sums, scratch, threadIdx.x);
-    if (threadIdx.x != 0) return;
-    double ll[2] = {sums[0], M > 1 ? sums[1] : 0.0};
-    ll_out[0] = ll[0];
-    if (M > 1) ll_out[1] = ll[1];
-    dir_accept_intercept(ll, lsm, intercept, which, carried);
-    if (next_which >= 0) dir_propose_intercept(c, lsm, intercept, next_which, ir.get());
-}
-
 // Gamma(a, 1) by Marsaglia & Tsang (2000); a < 1 through Gamma(a + 1) U^(1 / a)
 __device__ __forceinline__ double philox_gamma(uint64_t seed, uint32_t chain, uint32_t i,
                                                uint32_t iter, double a) {
@@ -115,41 +78,46 @@ constexpr int DP_COLS = 7;         // A, B, C, E, sum x, sum r, zero flag
 
 // x ~ Dirichlet(step * radii) into radii_alt and the proposal density ratio
 //   dir_q = log Dir(radii | step x) - log Dir(x | step radii),
-// in three launches: gamma variates (one node per thread) + per-workgroup sums; normalise +
+// in three steps: gamma variates (one node per thread) + per-workgroup sums; normalise +
 // per-workgroup sums of the density terms; one workgroup puts them together (and repairs an
 // exact zero, metropolis.py:65-69, the slow way: it practically never happens).
-__global__ __launch_bounds__(DP_THREADS) void k_dir_radii_gamma(ChainView c,
-                                                                const LsmDeviceState *lsm,
-                                                                const double *__restrict__ radii,
-                                                                double *__restrict__ radii_alt,
-                                                                double *__restrict__ rec,
-                                                                IterRef ir) {
+__device__ __forceinline__ void dir_radii_gamma_wg(const ChainView &c, const LsmDeviceState *lsm,
+                                                   const double *__restrict__ radii,
+                                                   double *__restrict__ radii_alt,
+                                                   double *__restrict__ rec, IterRef ir, int wg) {
     __shared__ double buf[DP_THREADS / 64];
-    const int i = blockIdx.x * DP_THREADS + threadIdx.x;
+    const int i = wg * DP_THREADS + threadIdx.x;
     double g = 0.0;
     if (i < c.N) {
         g = philox_gamma(c.seed, c.chain, (uint32_t)i, ir.get(), lsm->r_step * radii[i]);
         radii_alt[i] = g;
     }
     g = block_sum_all<DP_THREADS / 64>(g, buf, threadIdx.x);
-    if (threadIdx.x == 0) rec[blockIdx.x] = g;
+    if (threadIdx.x == 0) rec[wg] = g;
 }
 
-__global__ __launch_bounds__(DP_THREADS) void k_dir_radii_terms(ChainView c,
-                                                                const LsmDeviceState *lsm,
-                                                                const double *__restrict__ radii,
-                                                                double *__restrict__ radii_alt,
-                                                                const double *__restrict__ rec,
-                                                                double *__restrict__ rec2) {
+// xr (may be NULL): the case-control log-likelihood's gather records [T][N][RW]: the proposal goes
+// into their second radius slot, so the pass at the proposed radii needs no packing launch
+template <int D>
+__device__ __forceinline__ void dir_radii_terms_wg(const ChainView &c, const LsmDeviceState *lsm,
+                                                   const double *__restrict__ radii,
+                                                   double *__restrict__ radii_alt,
+                                                   const double *__restrict__ rec,
+                                                   double *__restrict__ rec2, double *__restrict__ xr,
+                                                   int wg, int nwg) {
     __shared__ double buf[DP_COLS][DP_THREADS / 64];
-    const int tid = threadIdx.x, i = blockIdx.x * DP_THREADS + tid;
+    const int tid = threadIdx.x, i = wg * DP_THREADS + tid;
     double total = 0.0;
-    for (int q = 0; q < (int)gridDim.x; ++q) total += rec[q];       // same order in every workgroup
+    for (int q = 0; q < nwg; ++q) total += rec[q];                  // same order in every workgroup
     const double inv = 1.0 / total, step = lsm->r_step;
     double v[DP_COLS] = {0, 0, 0, 0, 0, 0, 0};
     if (i < c.N) {
         const double x = radii_alt[i] * inv, r = radii[i];
         radii_alt[i] = x;
+        if (xr) {
+            constexpr int RW = llcc_record_width(D);
+            for (int t = 0; t < c.T; ++t) xr[((size_t)t * c.N + i) * RW + D + 1] = x;
+        }
         v[0] = lgamma(step * x);
         v[1] = (step * x - 1.0) * log(r);
         v[2] = lgamma(step * r);
@@ -160,15 +128,17 @@ __global__ __launch_bounds__(DP_THREADS) void k_dir_radii_terms(ChainView c,
 #pragma unroll
     for (int q = 0; q < DP_COLS; ++q) {
         const double sres = block_sum_all<DP_THREADS / 64>(v[q], buf[q], tid);
-        if (tid == 0) rec2[(size_t)blockIdx.x * DP_COLS + q] = sres;
+        if (tid == 0) rec2[(size_t)wg * DP_COLS + q] = sres;
     }
 }
 
+template <int D>
 __global__ __launch_bounds__(DR_THREADS) void k_dir_radii_finish(ChainView c, LsmDeviceState *lsm,
                                                                  const double *__restrict__ radii,
                                                                  double *__restrict__ radii_alt,
                                                                  const double *__restrict__ rec2,
-                                                                 int nblk, IterRef ir) {
+                                                                 int nblk, double *__restrict__ xr,
+                                                                 IterRef ir) {
     __shared__ double buf[8][DR_THREADS / 64];
     __shared__ double tot[DP_COLS];
     const int tid = threadIdx.x, N = c.N;
@@ -188,6 +158,10 @@ __global__ __launch_bounds__(DR_THREADS) void k_dir_radii_finish(ChainView c, Ls
         for (int i = tid; i < N; i += DR_THREADS) {
             const double x = radii_alt[i] / s2, r = radii[i];
             radii_alt[i] = x;
+            if (xr) {
+                constexpr int RW = llcc_record_width(D);
+                for (int t = 0; t < c.T; ++t) xr[((size_t)t * N + i) * RW + D + 1] = x;
+            }
             A += lgamma(step * x); B += (step * x - 1.0) * log(r);
             Cc += lgamma(step * r); E += (step * r - 1.0) * log(x);
             Sx += x; Sr += r;
@@ -207,25 +181,74 @@ __global__ __launch_bounds__(DR_THREADS) void k_dir_radii_finish(ChainView c, Ls
     }
 }
 
-// ll[0] at the current radii, ll[1] at radii_alt; then the trace row of this iteration
-__global__ __launch_bounds__(DR_THREADS) void k_dir_accept_radii(
-    const double *__restrict__ ll, ChainView c, LsmDeviceState *lsm, double *__restrict__ radii,
-    const double *__restrict__ radii_alt, const double *__restrict__ intercept,
-    double *__restrict__ trace_ic, double *__restrict__ trace_radii,
-    double *__restrict__ trace_logp, IterRef ir) {
-    const int it = (int)ir.get();
+// The iteration's chain around a log-likelihood pass in ONE launch instead of three: workgroup 0
+// does the fixed-order sum of the pass's records (k_reduce_loglik), the accept / reject of
+// intercept `which`, and - next_which >= 0 - the proposal of the next intercept step.  The chip
+// is idle meanwhile, and the radii proposal needs nothing the intercept steps produce: its gamma
+// variates (rider == 1) and its normalisation + density terms (rider == 2) ride along as
+// workgroups 1 .. nblk (DP_THREADS = 256 threads, as workgroup 0).
+struct DirRider {
+    int kind, nblk;
+    const double *radii; double *radii_alt; double *rec; double *rec2; double *xr;
+};
+static_assert(DP_THREADS == 256, "riders share the launch of a 256-thread workgroup");
+template <int D>
+__global__ __launch_bounds__(256) void k_dir_reduce_accept_intercept(
+    const double *__restrict__ partials, int nrec, int M, double *__restrict__ ll_out, ChainView c,
+    LsmDeviceState *lsm, double *__restrict__ intercept, int which, int carried, int next_which,
+    IterRef ir, DirRider rd) {
+    if (blockIdx.x > 0) {
+        const int wg = (int)blockIdx.x - 1;
+        if (rd.kind == 1) dir_radii_gamma_wg(c, lsm, rd.radii, rd.radii_alt, rd.rec, ir, wg);
+        else dir_radii_terms_wg<D>(c, lsm, rd.radii, rd.radii_alt, rd.rec, rd.rec2, rd.xr, wg, rd.nblk);
+        return;
+    }
+    __shared__ double scratch[4 * 256];
+    __shared__ double sums[8];
+    reduce_records(partials, nrec, M, sums, scratch, threadIdx.x);
+    if (threadIdx.x != 0) return;
+    double ll[2] = {sums[0], M > 1 ? sums[1] : 0.0};
+    ll_out[0] = ll[0];
+    if (M > 1) ll_out[1] = ll[1];
+    dir_accept_intercept(ll, lsm, intercept, which, carried);
+    if (next_which >= 0) dir_propose_intercept(c, lsm, intercept, next_which, ir.get());
+}
+
+// The last launch of a directed iteration.  Workgroup 0: the fixed-order sum of the records of
+// the pass at the proposed radii (k_reduce_loglik's), the radii's accept / reject, the trace
+// row (lsm.py:604-623).  The other workgroups, when `ride`: the next sweep's proposal pass
+// (kernels_spec_pipe.hpp: nothing it reads is written here; workgroup 0 leaves its two constants).
+template <int D>
+__global__ __launch_bounds__(DR_THREADS) void k_dir_tail(
+    const double *__restrict__ partials, int nrec, double *__restrict__ ll_out, ChainView c,
+    LsmDeviceState *lsm, double *__restrict__ radii, const double *__restrict__ radii_alt,
+    const double *__restrict__ intercept, double *__restrict__ trace_ic,
+    double *__restrict__ trace_radii, double *__restrict__ trace_logp, IterRef ir, ProposeBuf nb,
+    int ride) {
     const int tid = threadIdx.x, N = c.N;
-    // ll[0]: at the proposed radii; at the current ones, the value the intercept steps left
+    if (blockIdx.x > 0) {
+        const int fb = ((int)blockIdx.x - 1) * (DR_THREADS / 256) + (tid >> 8);
+        if (fb < ((N + 255) / 256) * c.T) pipe_propose_rows<D>(c, nb, ir.get() + 1u, fb, tid & 255);
+        return;
+    }
+    __shared__ double scratch[4 * 256];
+    __shared__ double sums[8];
+    reduce_records(partials, nrec, 1, sums, scratch, tid);
+    const double ll0 = sums[0];                     // at the proposed radii
+    const int it = (int)ir.get();
+    // at the current ones: the value the intercept steps left
     const double ll_now = lsm->ll_cur;
-    const int accepted = !(lsm->logu >= (ll[0] - ll_now) + lsm->dir_q);
+    const int accepted = !(lsm->logu >= (ll0 - ll_now) + lsm->dir_q);
     double *row = trace_radii + (size_t)it * N;
     for (int i = tid; i < N; i += DR_THREADS) {
         const double r = accepted ? radii_alt[i] : radii[i];
         if (accepted) radii[i] = r;
         row[i] = r;
     }
+    __syncthreads();                                // every thread has read lsm->ll_cur / logu
     if (tid == 0) {
-        const double llf = accepted ? ll[0] : ll_now;
+        ll_out[0] = ll0;
+        const double llf = accepted ? ll0 : ll_now;
         double st = lsm->r_step;
         int32_t na = lsm->r_nacc, ns = lsm->r_nsteps, un = lsm->r_until;
         na += accepted; ns += 1;
@@ -243,6 +266,7 @@ __global__ __launch_bounds__(DR_THREADS) void k_dir_accept_radii(
         trace_ic[(size_t)it * 2] = b0;
         trace_ic[(size_t)it * 2 + 1] = b1;
         trace_logp[it] = llf + lsm->prior_x - 0.5 * (d0 * d0 + d1 * d1) / v;   // lsm.py:604-623
+        if (ride) pipe_propose_consts(c, nb.consts, intercept);
     }
 }
 

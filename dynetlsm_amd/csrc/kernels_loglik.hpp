@@ -491,9 +491,11 @@ __global__ __launch_bounds__(256) void k_pack_xr(const double *__restrict__ X,
 // radii): the kernel is a chain of gather latencies, and four nodes in turn are four chains.
 // For out-degrees <= 64 and at most 128 controls (the launcher checks); same record layout
 // and the same arithmetic per term.
+// rslot: which of the record's two radii a single candidate (M == 1) reads
 template <int D, int M>
 __global__ __launch_bounds__(256) void k_loglik_casecontrol_pf(
-    ChainView c, LoglikCand cand, const double *__restrict__ XR, double *__restrict__ partials) {
+    ChainView c, LoglikCand cand, const double *__restrict__ XR, double *__restrict__ partials,
+    int rslot) {
     constexpr int NPW = LLCC_NODES / 4;
     constexpr int RW = llcc_record_width(D);
     __shared__ double sRed[4 * M];
@@ -543,7 +545,7 @@ __global__ __launch_bounds__(256) void k_loglik_casecontrol_pf(
             const double *rec = XR + (size_t)nn * RW;
 #pragma unroll
             for (int d = 0; d < D; ++d) xi[r][d] = rec[d];
-            ri0[r] = rec[D];
+            ri0[r] = rec[D + (M == 1 ? rslot : 0)];
             ri1[r] = rec[D + 1];
         }
 #pragma unroll
@@ -551,7 +553,7 @@ __global__ __launch_bounds__(256) void k_loglik_casecontrol_pf(
             const double *rec = Rt + (size_t)max(e[r][s], 0) * RW;
 #pragma unroll
             for (int d = 0; d < D; ++d) xe[r][s][d] = rec[d];
-            re0[r][s] = rec[D];
+            re0[r][s] = rec[D + (M == 1 ? rslot : 0)];
             re1[r][s] = rec[D + 1];
         }
     }
@@ -614,13 +616,16 @@ __global__ __launch_bounds__(256) void k_loglik_casecontrol_pf(
 __device__ __forceinline__ void reduce_records(const double *__restrict__ rec,
                                                int nrec, int width, double *sums,
                                                double *scratch /*4 * 256*/, int tid) {
-    // up to 4 columns at a time share one tree (and its barriers)
+    // up to 4 columns at a time share one tree (and its barriers); in a wider workgroup the
+    // threads past 255 only keep the barriers company (same order of the sums for any width)
     for (int q0 = 0; q0 < width; q0 += 4) {
         const int nq = min(4, width - q0);
         double s[4] = {0.0, 0.0, 0.0, 0.0};
-        for (int r = tid; r < nrec; r += 256)
-            for (int q = 0; q < nq; ++q) s[q] += rec[(size_t)r * width + q0 + q];
-        for (int q = 0; q < 4; ++q) scratch[q * 256 + tid] = s[q];
+        if (tid < 256) {
+            for (int r = tid; r < nrec; r += 256)
+                for (int q = 0; q < nq; ++q) s[q] += rec[(size_t)r * width + q0 + q];
+            for (int q = 0; q < 4; ++q) scratch[q * 256 + tid] = s[q];
+        }
         __syncthreads();
         for (int off = 128; off > 0; off >>= 1) {
             if (tid < off)

@@ -424,6 +424,22 @@ __global__ __launch_bounds__(PS2_THREADS) void k_post_reduce(
     }
 }
 
+// directed models: cand = [proposal pair | current pair] for intercept `which` (one thread;
+// sample_coefficients.py:12-75)
+__device__ __forceinline__ void dir_propose_intercept(const ChainView &c, LsmDeviceState *lsm,
+                                                      const double *__restrict__ intercept,
+                                                      int which, uint32_t iter) {
+    double u0, u1, z0, z1;
+    philox_uniform2(c.seed, (uint32_t)which, 0, iter, stream_word(c.chain, STREAM_INTERCEPT), u0, u1);
+    box_muller(u0, u1, z0, z1);
+    const double b0 = intercept[0], b1 = intercept[1];
+    lsm->cand[0] = which == 0 ? b0 + lsm->i_step[0] * z0 : b0;
+    lsm->cand[1] = which == 1 ? b1 + lsm->i_step[1] * z0 : b1;
+    lsm->cand[2] = b0;
+    lsm->cand[3] = b1;
+    philox_uniform2(c.seed, (uint32_t)which, 1, iter, stream_word(c.chain, STREAM_INTERCEPT), u0, u1);
+    lsm->logu = log(u0);
+}
 // Pass 2 (many workgroups): every workgroup sums the records in the same fixed
 // order, gets R (one-sided Jacobi polar factor of M) and the mean, and applies
 // x <- x R - mean R to its rows.  Workgroup 0 also leaves the LSM bookkeeping.
@@ -431,7 +447,7 @@ template <int D>
 __global__ __launch_bounds__(PS2_THREADS) void k_post_apply(
     ChainView c, int has_ref, int n_iter_procrustes, int do_center,
     const double *__restrict__ rec, int nrec, LsmDeviceState *lsm, IterRef ir,
-    double *__restrict__ R_out, double *__restrict__ trace_X) {
+    double *__restrict__ R_out, double *__restrict__ trace_X, double *__restrict__ xr = nullptr) {
     const uint32_t iter = ir.get();
     const int rotate = has_ref && (n_iter_procrustes < 0 || (int)iter > n_iter_procrustes);
     constexpr int W = PostRec<D>::W;
@@ -483,21 +499,26 @@ __global__ __launch_bounds__(PS2_THREADS) void k_post_apply(
                 q0 = q0 - 2.0 * ms + (double)c.N * mm;
                 lsm->prior_x = -(0.5 * q0 / c.tau_sq +
                                  0.5 * sSum[2 * D + D * D + 1] / c.sigma_sq);
-                double u0, u1, z0, z1;
-                philox_uniform2(c.seed, 0, 0, iter, stream_word(c.chain, STREAM_INTERCEPT),
-                                u0, u1);
-                box_muller(u0, u1, z0, z1);
-                const double b0 = c.intercept[0];
-                lsm->cand[0] = b0;
-                lsm->cand[1] = b0 + lsm->i_step[0] * z0;
-                philox_uniform2(c.seed, 0, 1, iter, stream_word(c.chain, STREAM_INTERCEPT),
-                                u0, u1);
-                lsm->logu = log(u0);
+                if (c.model != DLSM_UNDIRECTED) {
+                    // the first of the two intercept steps of the directed loops
+                    dir_propose_intercept(c, lsm, c.intercept, 0, iter);
+                } else {
+                    double u0, u1, z0, z1;
+                    philox_uniform2(c.seed, 0, 0, iter, stream_word(c.chain, STREAM_INTERCEPT),
+                                    u0, u1);
+                    box_muller(u0, u1, z0, z1);
+                    const double b0 = c.intercept[0];
+                    lsm->cand[0] = b0;
+                    lsm->cand[1] = b0 + lsm->i_step[0] * z0;
+                    philox_uniform2(c.seed, 0, 1, iter, stream_word(c.chain, STREAM_INTERCEPT),
+                                    u0, u1);
+                    lsm->logu = log(u0);
+                }
             }
         }
     }
     __syncthreads();
-    if (!rotate && !do_center && !trace_X) return;
+    if (!rotate && !do_center && !trace_X && !xr) return;
     // the device-resident loop also files the final positions as row `iter` of its trace
     double *trow = trace_X ? trace_X + (size_t)iter * rows * D : nullptr;
     for (long r = (long)blockIdx.x * PS2_THREADS + tid; r < rows;
@@ -517,6 +538,18 @@ __global__ __launch_bounds__(PS2_THREADS) void k_post_apply(
         if (trow) {
 #pragma unroll
             for (int b = 0; b < D; ++b) trow[r * D + b] = y[b];
+        }
+        if (xr) {       // the case-control log-likelihood's gather records (k_pack_xr's): [x | r | r]
+            constexpr int RW = llcc_record_width(D);
+            double rc[RW];
+#pragma unroll
+            for (int d = 0; d < RW; ++d) rc[d] = 0.0;
+#pragma unroll
+            for (int d = 0; d < D; ++d) rc[d] = y[d];
+            rc[D] = rc[D + 1] = c.radii[r % c.N];
+#pragma unroll
+            for (int d = 0; d < RW; d += 2)
+                *(double2 *)(xr + r * RW + d) = make_double2(rc[d], rc[d + 1]);
         }
     }
 }

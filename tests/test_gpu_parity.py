@@ -878,8 +878,40 @@ def test_hdp_host_updates_with_device_sums_reproduce_reference_fit(eng):
 
 
 # ------------------------------------------------------------ directed device loop
+@pytest.mark.parametrize('name,algo', [('directed', 4), ('case_control', 4), ('case_control', 5)])
+def test_lsm_directed_device_loop_proposals_drawn_by_the_previous_iteration(eng, name, algo,
+                                                                            monkeypatch):
+    """the directed loops' last launch (radii accept / reject, trace row) carries the next sweep's
+    proposal pass; DLSM_TAIL_PROPOSE=0 keeps it a launch of its own: same traces bit for bit"""
+    T, N = 3, 700
+    X, Yd, _, radii = _rand_net(57, T, N, scale=0.05, density=0.05)
+    out = {}
+    for mode in ('0', '1'):
+        monkeypatch.setenv('DLSM_TAIL_PROPOSE', mode)
+        gg = eng.SamplerGrid(T, N, 0.01, tune=6, tune_interval=2)
+        with eng.Chain(T, N, 2, name, seed=29, chain_id=1) as c:
+            if name == 'case_control':
+                cc = _cc_lists(Yd, 8, 5)
+                c.upload_edges(cc['in_edges'], cc['out_edges'], cc['degree'])
+                c.set_controls(cc['control_nodes_in'], cc['control_nodes_out'])
+            else:
+                c.upload_network(Yd)
+            c.set_positions(X); c.set_intercepts([0.4, 0.7]); c.set_radii(radii)
+            c.set_prior_random_walk(1e-3, 1e-4); c.set_samplers(gg)
+            c.lsm_configure([0.3, 0.5], 2.0, step_size_intercept=0.1, tune=6, tune_interval=2,
+                            n_iter_procrustes=10 ** 6, sweep_algo=algo, step_size_radii=175000.,
+                            radii_tune=5, radii_tune_interval=2)
+            c.trace_alloc(9)
+            c.lsm_run(1, 5); c.lsm_run(6, 3)
+            out[mode] = c.trace_read(0, 9) + (c.trace_read_radii(0, 9),)
+    for a, b in zip(out['0'], out['1']):
+        np.testing.assert_array_equal(a, b)
+    assert not np.array_equal(out['1'][0][8], out['1'][0][4])
+
+
 @pytest.mark.parametrize('name,N,algo', [('directed', 30, 1), ('directed', 300, 4),
-                                         ('case_control', 300, 4), ('case_control', 40, 1)])
+                                         ('case_control', 300, 4), ('case_control', 40, 1),
+                                         ('case_control', 700, 5)])
 def test_lsm_directed_device_loop_equals_oracle_iterations(eng, name, N, algo):
     """dlsm_lsm_run for the directed models (sweep, Procrustes / centring, intercept_in,
     intercept_out, radii with the scaled-Dirichlet proposal) against the oracle's
