@@ -52,6 +52,12 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # cycles at the 2.05 GHz the chip holds under it = 82 % of nominal
 # (profiles/micro/valu_rates.hip; one wavefront per SIMD: 4.57 cycles, the 76 % of round 1).
 F64_VALU_PEAK_TFLOPS = 78.6
+# the f64 matrix instructions run at the vector rate on this part (v_mfma_f64_16x16x4_f64:
+# 2048 flop in 64 cycles per SIMD)
+FP64_MATRIX_PEAK_TFLOPS = 78.6
+# gathers of records that stay in L2: a CU's vector L1 looks up one cache line per clock, so a
+# wavefront load that touches 64 lines occupies it for 64 clocks: 256 CUs x 2.4 GHz
+GATHER_PEAK_GRECS = 256 * 2.4
 F64_VALU_SUSTAINED_FRAC = 0.82
 # ALGORITHMIC float64 operations per dyad term (one distance + one exp(-d) + product
 # bookkeeping at ONE position): squared distance 4, root to the last bit 7, exp to 1 ulp 17,
@@ -549,6 +555,27 @@ class HdpWorkload(object):
         extra['ms_label_kernels_per_iteration'] = round(ms_lb / max(P, 1), 4)
         extra['ms_hdp_draws_and_logp_per_iteration'] = round(ms_tl / max(P, 1), 4)
         extra['ms_finalize'] = round(ms_fi / max(n_fi, 1), 4)
+        # what follows the likelihood pass: the label block update (two launches) and the HDP's
+        # conjugate draws (four).  Neither bandwidth nor arithmetic bounds it: 6 dependent
+        # launches of 1 .. 250 workgroups, each a chain of dependent draws (phase
+        # stamps in profiles/r03_labels_notes.md and profiles/hdp_tail_timing.py).  `achieved` is
+        # the label update's algorithmic rate (backward messages 2 (T-1) N K^2 flop + forward
+        # draws 2 T N K) against the f64 matrix peak, for the record: 1-2 % of it.
+        T, N, K = a.T, a.N, a.K
+        lab_flop = 2.0 * (T - 1) * N * K * K + 2.0 * T * N * K
+        lab_s = max(ms_lb / max(P, 1), 1e-9) * 1e-3
+        tail_us = 1e3 * (ms_lb + ms_tl) / max(P, 1)
+        extra['roofline_tail'] = {
+            'bound': 'latency', 'kernels': ['k_sample_labels_mfma', 'k_label_counts', 'k_hdp_stage1',
+                                            'k_hdp_stage2', 'k_hdp_stage3', 'k_hdp_hypers(+proposal pass)'],
+            'launches': 6, 'us_per_iteration': round(tail_us, 2),
+            'us_label_update': round(1e3 * ms_lb / max(P, 1), 2),
+            'us_conjugate_draws': round(1e3 * ms_tl / max(P, 1), 2),
+            'us_floor_launch_boundaries': round(6 * 1.7, 1),
+            'achieved': round(lab_flop / lab_s / 1e12, 4), 'peak': FP64_MATRIX_PEAK_TFLOPS,
+            'unit': 'TFLOP/s', 'frac': round(lab_flop / lab_s / 1e12 / FP64_MATRIX_PEAK_TFLOPS, 5),
+            'note': 'label update only in achieved / peak; the draws are scalar chains (gamma, beta, '
+                    'truncated normal variates) whose launches are bounded by their longest chain'}
         return roofline, extra
 
     def results(self, first, count):
@@ -640,6 +667,7 @@ class CcWorkload(object):
         out_edges = group.broadcast_array(out_edges).astype(np.int64)
         self.density = float(degree[:, :, 1].mean() / (N - 1))
         self.mean_terms = float(degree.sum(axis=2).mean() + 2 * C)
+        self.mean_out = float(degree[:, :, 1].mean())
         self.tables = (X, radii, degree, in_edges, out_edges) if rank == 0 else None
         self.chains = []
         for c in range(args.chains_per_gpu):
@@ -730,7 +758,30 @@ class CcWorkload(object):
                     'note': 'gather-latency bound: each term is a dependent chain list index -> '
                             'X[e], radii[e] through L2 (the working set, 2.4 MB, is cache '
                             'resident: HBM traffic is far below the algorithmic bytes)'}
-        extra = {'ms_sweep': round(sweep_ms, 4),
+        # The bound that fits both kernels: a gathered term is one 32-byte record from a random
+        # node of the slice, and a CU's vector L1 looks up one cache line per clock, whatever
+        # the hit rate (the records are L2 resident): 256 CUs x 2.4 GHz records per second.
+        rec_sweep = float(T) * N * self.mean_terms          # one record per term, both candidates share it
+        roofline_gather = {
+            'bound': 'gather rate (one cache-line look-up per CU per clock)', 'kernel': kname,
+            'achieved': round(rec_sweep / (sweep_ms * 1e-3) / 1e9, 2), 'peak': GATHER_PEAK_GRECS,
+            'unit': 'G records/s', 'frac': round(rec_sweep / (sweep_ms * 1e-3) / 1e9 / GATHER_PEAK_GRECS, 4),
+            'records_per_sweep': rec_sweep}
+        ll_ms = ms_ll / max(n_ll, 1)
+        rec_ll = float(T) * N * (float(self.mean_out) + self.C)     # out-edges + out-controls
+        roofline_ll = {
+            'bound': 'gather rate (one cache-line look-up per CU per clock)',
+            'kernel': 'k_loglik_casecontrol_pf',
+            'achieved': round(rec_ll / (ll_ms * 1e-3) / 1e9, 2), 'peak': GATHER_PEAK_GRECS,
+            'unit': 'G records/s', 'frac': round(rec_ll / (ll_ms * 1e-3) / 1e9 / GATHER_PEAK_GRECS, 4),
+            'records_per_pass': rec_ll, 'us_per_pass': round(1e3 * ll_ms, 2),
+            'algorithmic_bytes_per_pass': rec_ll * (4 + 32),
+            'hbm_equivalent_GBs': round(rec_ll * 36 / (ll_ms * 1e-3) / 1e9, 1),
+            'note': 'average over the iteration\'s three passes (one of two candidates, two of one); '
+                    'index 4 B + record 32 B per term; every load of a wavefront\'s four nodes is '
+                    'issued before the first use'}
+        extra = {'roofline_gather': roofline_gather, 'roofline_loglik': roofline_ll,
+                 'ms_sweep': round(sweep_ms, 4),
                  'ms_per_loglik_pass': round(ms_ll / max(n_ll, 1), 4),
                  'loglik_passes_per_iteration': round(n_ll / float(max(P, 1)), 2),
                  'ms_post_sweep': round(ms_ps / max(n_ps, 1), 4)}
