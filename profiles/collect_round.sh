@@ -10,7 +10,7 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 for m in lsm hdp cc; do bash $ROOT/profiles/collect.sh $TAG $m all > $OUT/collect_$m.log 2>&1; done
 cd $ROOT
-python3 bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
+python3 bench.py < /dev/null > $OUT/bench_default.json 2> $OUT/bench_default.err
 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver_args.json 2> $OUT/bench_driver_args.err
 : > $OUT/chains_per_gpu.jsonl
 for C in 2 3 4; do python3 bench.py --chains-per-gpu $C --no-cpu >> $OUT/chains_per_gpu.jsonl 2>> $OUT/chains_per_gpu.err; done
@@ -20,6 +20,9 @@ if [ -f tmp_timing/libtiming.so ]; then
   python3 profiles/pipe_timing.py tmp_timing/libtiming.so $OUT/pipe_timing.json > $OUT/pipe_timing.log 2>&1
   python3 profiles/loglik_timing.py tmp_timing/libtiming.so $OUT/loglik_timing.json > $OUT/loglik_timing.log 2>&1
   python3 profiles/ccpipe_timing.py tmp_timing/libtiming.so $OUT/ccpipe_timing.json > $OUT/ccpipe_timing.log 2>&1
+  python3 profiles/labels_phases.py tmp_timing/libtiming.so $OUT/labels_phases.json > $OUT/labels_phases.log 2>&1
+  python3 profiles/hdp_tail_timing.py tmp_timing/libtiming.so $OUT/hdp_tail_timing.json > $OUT/hdp_tail_timing.log 2>&1
+  python3 profiles/persist_timing.py tmp_timing/libtiming.so $OUT/persist_timing.json > $OUT/persist_timing.log 2>&1
 fi
 [ -x tmp_timing/valu_rates ] && ./tmp_timing/valu_rates > $OUT/valu_rates.txt 2>&1
 [ -x tmp_timing/sqrt_acc ] && ./tmp_timing/sqrt_acc > $OUT/sqrt_acc.txt 2>&1
