@@ -1332,8 +1332,8 @@ static int launch_post(dlsm_chain *h, const double *d_xref, int n_iter_procruste
 }
 
 namespace {
-// The label block update's two launches.  16 nodes per workgroup on the f64 matrix cores when the
-// transition matrices and the 16 nodes' tables fit in LDS together (config 3: 82 KB); the
+// The label block update's two launches.  LM_NODES nodes per workgroup on the f64 matrix cores when
+// the transition matrices and the nodes' tables fit in LDS together (config 3: 58 KB); the
 // wavefront-per-node kernel otherwise (DLSM_LABELS_KERNEL=wave forces it, for measurements).
 static bool labels_wave_forced() {
     static const bool v = [] { const char *e = getenv("DLSM_LABELS_KERNEL"); return e && !strcmp(e, "wave"); }();
