@@ -69,10 +69,23 @@ OPS_PER_TERM_SWEEP = 34
 OPS_PER_TERM_LOGLIK = 17
 
 
+_INSTR_CACHE = []
+
+
 def kernel_instr_per_term():
     """vector instructions the built kernels spend per dyad term, counted in the library's own
     code object (profiles/instr_counts.py: disassembly of the hot loops); None where the
-    disassembler is not at hand"""
+    disassembler is not at hand.  Disassembling takes a second or two of host time: run_rank calls
+    this once BEFORE any device work, so that the profile phase, the warm-up and the timed steps
+    follow each other without an idle device in between (a short timed window behind an idle
+    device reads 3-5 % low)."""
+    if _INSTR_CACHE:
+        return _INSTR_CACHE[0]
+    _INSTR_CACHE.append(_kernel_instr_per_term())
+    return _INSTR_CACHE[0]
+
+
+def _kernel_instr_per_term():
     try:
         sys.path.insert(0, os.path.join(ROOT, 'profiles'))
         import instr_counts
@@ -907,6 +920,8 @@ def run_rank(args):
                              else 'gloo', force=args.force_collectives)
     torch.cuda.set_device(local_rank)
     K, W = args.steps, args.warmup
+    if args.profile_steps > 0:
+        kernel_instr_per_term()         # host-only, cached: not between the profile phase and the timed steps
     models = ['lsm', 'hdp', 'cc'] if args.model == 'all' else [args.model]
     lines = []
     def run_model(name):
