@@ -118,6 +118,11 @@ def parse(argv=None):
                     help='iterations of the per-kernel event phase that precedes the warm-up steps '
                          '(averages over 100 x 18 sweep launches; it also leaves the device in its '
                          'running state: a short timed window right after an idle device reads 3-5 %% low)')
+    ap.add_argument('--settle-steps', type=int, default=0,
+                    help='plain iterations of every chain between the event-instrumented profile phase '
+                         'and the W warm-up steps (untimed, reported in the line).  Measured on MI355X: '
+                         '0 / 100 / 300 read 3850 / 3790-3825 / 3821-3836 it/s on --steps 20 --warmup 5: '
+                         'no gain, so off by default (the profile phase already precedes the warm-up)')
     ap.add_argument('--cpu-iters', type=int, default=8,
                     help='oracle iterations timed for cpu_baseline (0 = skip)')
     ap.add_argument('--cpu-procs', type=int, default=1,
@@ -243,7 +248,7 @@ class LsmWorkload(object):
             ch.set_samplers(SamplerGrid(T, N, step_size=0.1, tune=None))
             ch.lsm_configure([self.b_init], 2.0, step_size_intercept=0.1, tune=None,
                              n_iter_procrustes=0, sweep_algo=args.algo)
-            ch.trace_alloc(1 + W + K + P, logp0=0.0)
+            ch.trace_alloc(1 + W + K + P + args.settle_steps, logp0=0.0)
         self.next_it = 1
 
     def run(self, count):
@@ -506,7 +511,7 @@ class HdpWorkload(object):
         self.models = []
         for c in range(C):
             m = DynamicNetworkHDPLPCM(
-                n_iter=1 + W + K + P, tune=None, burn=None, n_components=Kc, n_features=D,
+                n_iter=1 + W + K + P + args.settle_steps, tune=None, burn=None, n_components=Kc, n_features=D,
                 random_state=1 + rank * C + c, device=local_rank, chain_id=rank * C + c,
                 sweep_algo=args.algo, selection_type='map')
             first = self.models[0].chain_ if self.models else None
@@ -696,7 +701,7 @@ class CcWorkload(object):
             ch.lsm_configure([1.0, 0.5], 2.0, step_size_intercept=0.1, tune=None,
                              n_iter_procrustes=0, sweep_algo=args.algo, step_size_radii=175000.,
                              radii_tune=None)
-            ch.trace_alloc(1 + W + K + P, logp0=0.0)
+            ch.trace_alloc(1 + W + K + P + args.settle_steps, logp0=0.0)
             self.chains.append(ch)
         self.chain = self.chains[0]
         self.next_it = 1
@@ -869,6 +874,8 @@ def measure(wl, args, group):
     roofline, extra = (None, {})
     if args.profile_steps > 0:
         roofline, extra = wl.profile()
+    if args.settle_steps > 0:
+        wl.run(args.settle_steps)
     wl.run(W)
     wl.synchronize()
     torch.cuda.synchronize()
@@ -886,7 +893,7 @@ def measure(wl, args, group):
     wl.per_rank_seconds = [float(v[0]) for v in group.gather_arrays(np.array([mine]))]
     acc = wl.acceptance()
     P = args.profile_steps if args.profile_steps > 0 else 0
-    gathered = group.gather_results(wl.results(1 + P + W, K))
+    gathered = group.gather_results(wl.results(1 + P + args.settle_steps + W, K))
     # (ranks, chains per GPU, ...) -> (chains, ...)
     gathered = {k: v.reshape((-1,) + v.shape[2:]) for k, v in gathered.items()}
     return elapsed, roofline, extra, acc, gathered
@@ -937,6 +944,8 @@ def run_rank(args):
                 line = {
                     'metric': wl.metric(), 'value': round(value, 3), 'unit': 'Gibbs iterations/s',
                     'n_gpus': world, 'steps': K, 'warmup': W,
+                    'untimed_steps_before_warmup': {'profile_steps': max(args.profile_steps, 0),
+                                                    'settle_steps': args.settle_steps},
                     'ms_per_step': round(1e3 * elapsed / K, 4), 'higher_is_better': True,
                     'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
                     'config': {'workload': wl.workload(), 'density': round(wl.density, 4),
