@@ -517,14 +517,17 @@ __device__ __forceinline__ void hdp_hypers_wg(const ChainView &c, const HdpLoopB
         }
         sC[tid] = hdp_gamma(g, kind, idx, shape) * (1.0 / m_scale);
     }
-    {   // the sample's trace rows, by the threads that have no draw to make
+    if (wave >= 2) {    // the sample's trace rows, by the WAVEFRONTS that have no draw to make (lanes of
+                        // the drawing wavefronts would run their stores in turn with the draws)
+        constexpr int NS = HH_THREADS - 128;
+        const int st = tid - 128;
         const size_t it = ir.get();
-        for (int q = tid; q < K * D; q += HH_THREADS) tr.mu[it * K * D + q] = hb.mu[q];
-        for (int q = tid; q < K; q += HH_THREADS) {
+        for (int q = st; q < K * D; q += NS) tr.mu[it * K * D + q] = hb.mu[q];
+        for (int q = st; q < K; q += NS) {
             tr.sigma[it * K + q] = hb.sigma[q];
             tr.beta[it * K + q] = hb.beta[q];
         }
-        for (int q = tid; q < T * K * K; q += HH_THREADS) tr.w[it * T * K * K + q] = hb.w[q];
+        for (int q = st; q < T * K * K; q += NS) tr.w[it * T * K * K + q] = hb.w[q];
     }
     __syncthreads();
     if (tid != 0) return;
