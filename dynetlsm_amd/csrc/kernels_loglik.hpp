@@ -582,14 +582,20 @@ __global__ __launch_bounds__(256) void k_loglik_casecontrol_pf(
             for (int m = 0; m < M; ++m) {
                 const double ire = m == 0 ? ire0 : ire1;
                 const double eta = bin[m] * (1.0 - dd * ire) + bout[m] * (1.0 - dd * iri[m]);
+                // log(1 + e^eta) = eta beyond 130: such a term adds nothing to an edge's sum and eta to
+                // a control's.  Selects, not branches: the exponential is computed for every lane
+                // anyway, and a lane-wise branch costs an exec-mask round trip per candidate; the
+                // flush test is one wavefront-wide question
+                const bool big = eta > 130.0;
+                const double f = 1.0 + tab_exp(fmin(fmax(eta, -700.0), 130.0), sTab);
                 if (s == 0) {               // out edge : directed_likelihoods_fast.pyx:236-247
-                    L[m] += eta;
-                    if (eta > 130.0) { L[m] -= eta; continue; }       // log(1 + e^eta) = eta there
-                    if (Pe[m] > 1e250) { L[m] -= fast_log(Pe[m]); Pe[m] = 1.0; }
-                    Pe[m] *= 1.0 + tab_exp(fmax(eta, -700.0), sTab);
+                    L[m] += big ? 0.0 : eta;
+                    if (__builtin_amdgcn_ballot_w64(Pe[m] > 1e250))
+                        if (Pe[m] > 1e250) { L[m] -= fast_log(Pe[m]); Pe[m] = 1.0; }
+                    Pe[m] *= big ? 1.0 : f;
                 } else {                    // control : :250-268
-                    if (eta > 130.0) { ctl[m] += eta; continue; }
-                    Pc[m] *= 1.0 + tab_exp(fmax(eta, -700.0), sTab);
+                    ctl[m] += big ? eta : 0.0;
+                    Pc[m] *= big ? 1.0 : f;
                 }
             }
         }
