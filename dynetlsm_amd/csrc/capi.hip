@@ -1577,45 +1577,61 @@ static int enqueue_lsm_iteration(dlsm_chain *h, int it, bool counter, int procru
     // case-control: the centring pass also writes the log-likelihood's gather records
     const bool pf = cc_prefetch_form(h);
     if (pf) { DISPATCH_D(h, h->D, rc = ensure_xr<DD>(h)); if (rc) return rc; }
-    DISPATCH_D(h, h->D, rc = launch_post<DD>(h, xref, h->lsm_cfg.n_iter_procrustes, 1, h->lsm,
-                                             ir, nullptr, alloc_only, h->trace_X, pf ? h->xr : nullptr));
-    if (rc) return rc;
-    if (alloc_only) return ensure_partials(h, (size_t)ll_blocks(h) * 4);
+    if (h->model == DLSM_UNDIRECTED) {
+        DISPATCH_D(h, h->D, rc = launch_post<DD>(h, xref, h->lsm_cfg.n_iter_procrustes, 1, h->lsm,
+                                                 ir, nullptr, alloc_only, h->trace_X, nullptr));
+        if (rc) return rc;
+    }
+    if (alloc_only)     // (the directed loops' records: likelihood | centring | radii proposal)
+        return ensure_partials(h, (size_t)ll_blocks(h) * 4 + (size_t)PS_BLOCKS * 26 +
+                                  (size_t)((h->N + DP_THREADS - 1) / DP_THREADS) * (1 + DP_COLS));
     int nrec = 0;
     if (h->model != DLSM_UNDIRECTED) {
         // intercept_in, intercept_out, radii: propose -> fused two-candidate pass -> accept
         ChainView v = h->view();
         double *ll2 = h->dsmall + 16;
-        ProfScope ps(h, DLSM_K_FINALIZE);
         // The sweep moved the positions, so the first step evaluates proposal and current
         // state; after it the current state's log-likelihood is carried (lsm->ll_cur) and the
         // later steps evaluate their proposal only: 4 candidate evaluations, not 6.
-        // Launches besides the three passes: 4 (round 2: eleven).  The first intercept proposal is
-        // drawn by the centring pass, which also writes the passes' gather records; the sum of a
-        // pass's records, the accept / reject and the next step's proposal share a launch, and
-        // the radii proposal's gamma variates and density terms ride in those two launches (they
-        // file the proposal in the records' second radius slot); its closing workgroup is a
-        // launch; the last pass's sum, the radii's accept / reject and the trace row share the
-        // last launch, which can carry the next sweep's proposal pass.
-        // scaled-Dirichlet proposal of the radii: its records live behind the log-likelihood records
+        // Launches besides the three passes: 5, none of them the radii proposal's own (round 2:
+        // eleven).  The centring launches draw the first intercept proposal, write the passes'
+        // gather records and carry the radii proposal's gamma variates (pass 1) and its
+        // normalisation + density terms (pass 2: they file the proposal in the records' second
+        // radius slot); the sum of a pass's records, the accept / reject and the next step's
+        // proposal share a launch, the first of which carries the proposal's closing workgroup;
+        // the last pass's sum, the radii's accept / reject and the trace row share the last
+        // launch, which can carry the next sweep's proposal pass.
         const int nblk = (h->N + DP_THREADS - 1) / DP_THREADS;
-        rc = ensure_partials(h, (size_t)ll_blocks(h) * 4 + (size_t)nblk * (1 + DP_COLS));
+        constexpr int PW_MAX = 2 * 4 + 4 * 4 + 2;           // PostRec<4>::W
+        const size_t n_post = (size_t)PS_BLOCKS * PW_MAX;
+        rc = ensure_partials(h, (size_t)ll_blocks(h) * 4 + n_post + (size_t)nblk * (1 + DP_COLS));
         if (rc) return rc;
-        double *rrec = h->partials + (size_t)ll_blocks(h) * 4, *rrec2 = rrec + nblk;
+        double *prec = h->partials + (size_t)ll_blocks(h) * 4;
+        double *rrec = prec + n_post, *rrec2 = rrec + nblk;
         double *xr = pf ? h->xr : nullptr;
+        const long rows = (long)h->T * h->N;
+        const int nbp = (int)std::min<long>(PS_BLOCKS, (rows + PS2_THREADS - 1) / PS2_THREADS);
+        {
+            ProfScope psc(h, DLSM_K_CENTER);
+            const DirRider rg{1, nblk, h->radii, h->radii_alt, rrec, rrec2, xr};
+            DISPATCH_D(h, h->D, hipLaunchKernelGGL((k_post_reduce_dir<DD>), dim3(nbp + nblk), dim3(PS2_THREADS), 0,
+                                                   h->stream, v, xref, h->lsm_cfg.n_iter_procrustes, ir, prec,
+                                                   nbp, h->lsm, rg));
+            DISPATCH_D(h, h->D, hipLaunchKernelGGL((k_post_apply_dir<DD>), dim3(nbp + nblk), dim3(PS2_THREADS), 0,
+                                                   h->stream, v, xref ? 1 : 0, h->lsm_cfg.n_iter_procrustes, 1,
+                                                   prec, nbp, h->lsm, ir, h->trace_X, xr, nbp, rg));
+        }
+        ProfScope ps(h, DLSM_K_FINALIZE);
         for (int which = 0; which < 2; ++which) {
             const int M = which == 0 ? 2 : 1;
             rc = loglik_records(h, M, h->lsm->cand, h->radii, h->radii, &nrec, pf || which == 1);
             if (rc) return rc;
-            const DirRider rd{which + 1, nblk, h->radii, h->radii_alt, rrec, rrec2, xr};
-            DISPATCH_D(h, h->D, hipLaunchKernelGGL((k_dir_reduce_accept_intercept<DD>), dim3(1 + nblk),
-                                                   dim3(256), 0, h->stream, h->partials, nrec, M, ll2, v,
-                                                   h->lsm, h->intercept, which, which,
-                                                   which == 0 ? 1 : -1, ir, rd));
+            const DirRider rd{which == 0 ? 3 : 0, nblk, h->radii, h->radii_alt, rrec, rrec2, xr};
+            DISPATCH_D(h, h->D, hipLaunchKernelGGL((k_dir_reduce_accept_intercept<DD>),
+                                                   dim3(1 + (which == 0 ? 1 : 0)), dim3(256), 0, h->stream,
+                                                   h->partials, nrec, M, ll2, v, h->lsm, h->intercept, which,
+                                                   which, which == 0 ? 1 : -1, ir, rd));
         }
-        DISPATCH_D(h, h->D, hipLaunchKernelGGL((k_dir_radii_finish<DD>), dim3(1), dim3(DR_THREADS), 0,
-                                               h->stream, v, h->lsm, h->radii, h->radii_alt, rrec2, nblk,
-                                               xr, ir));
         // the proposed radii at the current intercepts (one candidate)
         rc = loglik_records(h, 1, h->intercept, h->radii_alt, h->radii_alt, &nrec, pf, 1);
         if (rc) return rc;

@@ -59,6 +59,8 @@ struct LsmDeviceState {
     double r_step;
     int32_t r_nacc, r_nsteps, r_until, r_tune, r_tune_interval, r_pad_;
     double ll_cur, dir_q;
+    double r_logu;              // log-uniform of the radii step's accept test (its own word: the proposal
+                                // is closed while the intercept steps still use `logu`)
 };
 
 // Device-resident HDP-LPCM loop (hdp_lpcm.py:823-1069): hyper-parameters the loop resamples,

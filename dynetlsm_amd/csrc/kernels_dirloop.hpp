@@ -132,14 +132,14 @@ __device__ __forceinline__ void dir_radii_terms_wg(const ChainView &c, const Lsm
     }
 }
 
-template <int D>
-__global__ __launch_bounds__(DR_THREADS) void k_dir_radii_finish(ChainView c, LsmDeviceState *lsm,
-                                                                 const double *__restrict__ radii,
-                                                                 double *__restrict__ radii_alt,
-                                                                 const double *__restrict__ rec2,
-                                                                 int nblk, double *__restrict__ xr,
-                                                                 IterRef ir) {
-    __shared__ double buf[8][DR_THREADS / 64];
+template <int D, int NT>
+__device__ __forceinline__ void dir_radii_finish_wg(const ChainView &c, LsmDeviceState *lsm,
+                                                    const double *__restrict__ radii,
+                                                    double *__restrict__ radii_alt,
+                                                    const double *__restrict__ rec2,
+                                                    int nblk, double *__restrict__ xr,
+                                                    IterRef ir) {
+    __shared__ double buf[8][NT / 64];
     __shared__ double tot[DP_COLS];
     const int tid = threadIdx.x, N = c.N;
     const double step = lsm->r_step;
@@ -152,10 +152,10 @@ __global__ __launch_bounds__(DR_THREADS) void k_dir_radii_finish(ChainView c, Ls
     double A = tot[0], B = tot[1], Cc = tot[2], E = tot[3], Sx = tot[4], Sr = tot[5];
     if (tot[6] > 0.0) {                            // an exact zero: regularise and redo the sums
         double s2 = 0.0;
-        for (int i = tid; i < N; i += DR_THREADS) { radii_alt[i] += 1e-5; s2 += radii_alt[i]; }
-        s2 = block_sum_all<DR_THREADS / 64>(s2, buf[0], tid);
+        for (int i = tid; i < N; i += NT) { radii_alt[i] += 1e-5; s2 += radii_alt[i]; }
+        s2 = block_sum_all<NT / 64>(s2, buf[0], tid);
         A = B = Cc = E = Sx = Sr = 0.0;
-        for (int i = tid; i < N; i += DR_THREADS) {
+        for (int i = tid; i < N; i += NT) {
             const double x = radii_alt[i] / s2, r = radii[i];
             radii_alt[i] = x;
             if (xr) {
@@ -166,27 +166,29 @@ __global__ __launch_bounds__(DR_THREADS) void k_dir_radii_finish(ChainView c, Ls
             Cc += lgamma(step * r); E += (step * r - 1.0) * log(x);
             Sx += x; Sr += r;
         }
-        A = block_sum_all<DR_THREADS / 64>(A, buf[1], tid);
-        B = block_sum_all<DR_THREADS / 64>(B, buf[2], tid);
-        Cc = block_sum_all<DR_THREADS / 64>(Cc, buf[3], tid);
-        E = block_sum_all<DR_THREADS / 64>(E, buf[4], tid);
-        Sx = block_sum_all<DR_THREADS / 64>(Sx, buf[5], tid);
-        Sr = block_sum_all<DR_THREADS / 64>(Sr, buf[6], tid);
+        A = block_sum_all<NT / 64>(A, buf[1], tid);
+        B = block_sum_all<NT / 64>(B, buf[2], tid);
+        Cc = block_sum_all<NT / 64>(Cc, buf[3], tid);
+        E = block_sum_all<NT / 64>(E, buf[4], tid);
+        Sx = block_sum_all<NT / 64>(Sx, buf[5], tid);
+        Sr = block_sum_all<NT / 64>(Sr, buf[6], tid);
     }
     if (tid == 0) {
         lsm->dir_q = (lgamma(step * Sx) - A + B) - (lgamma(step * Sr) - Cc + E);
         double u0, u1;
         philox_uniform2(c.seed, 0xFFFFFFFFu, 0, ir.get(), stream_word(c.chain, STREAM_RADII), u0, u1);
-        lsm->logu = log(u0);
+        lsm->r_logu = log(u0);
     }
 }
 
 // The iteration's chain around a log-likelihood pass in ONE launch instead of three: workgroup 0
 // does the fixed-order sum of the pass's records (k_reduce_loglik), the accept / reject of
 // intercept `which`, and - next_which >= 0 - the proposal of the next intercept step.  The chip
-// is idle meanwhile, and the radii proposal needs nothing the intercept steps produce: its gamma
-// variates (rider == 1) and its normalisation + density terms (rider == 2) ride along as
-// workgroups 1 .. nblk (DP_THREADS = 256 threads, as workgroup 0).
+// is idle meanwhile, and the radii proposal needs nothing the intercept steps produce: its steps
+// ride along as workgroups 1 .. (DP_THREADS = 256 threads, as workgroup 0) - kind 1 the gamma
+// variates, 2 the normalisation + density terms, 3 (one workgroup) the closing sums.  In the
+// device loop the first two ride in the centring launches below and the first reduce / accept
+// launch carries the third.
 struct DirRider {
     int kind, nblk;
     const double *radii; double *radii_alt; double *rec; double *rec2; double *xr;
@@ -200,7 +202,8 @@ __global__ __launch_bounds__(256) void k_dir_reduce_accept_intercept(
     if (blockIdx.x > 0) {
         const int wg = (int)blockIdx.x - 1;
         if (rd.kind == 1) dir_radii_gamma_wg(c, lsm, rd.radii, rd.radii_alt, rd.rec, ir, wg);
-        else dir_radii_terms_wg<D>(c, lsm, rd.radii, rd.radii_alt, rd.rec, rd.rec2, rd.xr, wg, rd.nblk);
+        else if (rd.kind == 2) dir_radii_terms_wg<D>(c, lsm, rd.radii, rd.radii_alt, rd.rec, rd.rec2, rd.xr, wg, rd.nblk);
+        else dir_radii_finish_wg<D, 256>(c, lsm, rd.radii, rd.radii_alt, rd.rec2, rd.nblk, rd.xr, ir);
         return;
     }
     __shared__ double scratch[4 * 256];
@@ -212,6 +215,34 @@ __global__ __launch_bounds__(256) void k_dir_reduce_accept_intercept(
     if (M > 1) ll_out[1] = ll[1];
     dir_accept_intercept(ll, lsm, intercept, which, carried);
     if (next_which >= 0) dir_propose_intercept(c, lsm, intercept, next_which, ir.get());
+}
+
+// The centring launches of the directed loops with the radii proposal riding in them: the gamma
+// variates beside the sums (pass 1), normalisation + density terms beside the rotation / shift
+// (pass 2: it leaves the records' second radius slot to the riders).  Neither reads what the other
+// writes: the proposal depends on the current radii and its step size only.
+template <int D>
+__global__ __launch_bounds__(PS2_THREADS) void k_post_reduce_dir(
+    ChainView c, const double *__restrict__ xref_in, int n_iter_procrustes, IterRef ir,
+    double *__restrict__ rec, int nb_post, const LsmDeviceState *lsm, DirRider rd) {
+    if ((int)blockIdx.x < nb_post) {
+        post_reduce_wg<D>(c, xref_in, n_iter_procrustes, ir, rec, (int)blockIdx.x, nb_post);
+        return;
+    }
+    dir_radii_gamma_wg(c, lsm, rd.radii, rd.radii_alt, rd.rec, ir, (int)blockIdx.x - nb_post);
+}
+template <int D>
+__global__ __launch_bounds__(PS2_THREADS) void k_post_apply_dir(
+    ChainView c, int has_ref, int n_iter_procrustes, int do_center,
+    const double *__restrict__ rec, int nrec, LsmDeviceState *lsm, IterRef ir,
+    double *__restrict__ trace_X, double *__restrict__ xr, int nb_post, DirRider rd) {
+    if ((int)blockIdx.x < nb_post) {
+        post_apply_wg<D>(c, has_ref, n_iter_procrustes, do_center, rec, nrec, lsm, ir, nullptr, trace_X, xr,
+                         1, (int)blockIdx.x, nb_post);
+        return;
+    }
+    dir_radii_terms_wg<D>(c, lsm, rd.radii, rd.radii_alt, rd.rec, rd.rec2, rd.xr, (int)blockIdx.x - nb_post,
+                          rd.nblk);
 }
 
 // The last launch of a directed iteration.  Workgroup 0: the fixed-order sum of the records of
@@ -238,7 +269,7 @@ __global__ __launch_bounds__(DR_THREADS) void k_dir_tail(
     const int it = (int)ir.get();
     // at the current ones: the value the intercept steps left
     const double ll_now = lsm->ll_cur;
-    const int accepted = !(lsm->logu >= (ll0 - ll_now) + lsm->dir_q);
+    const int accepted = !(lsm->r_logu >= (ll0 - ll_now) + lsm->dir_q);
     double *row = trace_radii + (size_t)it * N;
     for (int i = tid; i < N; i += DR_THREADS) {
         const double r = accepted ? radii_alt[i] : radii[i];

@@ -569,7 +569,7 @@ __global__ __launch_bounds__(256) void k_loglik_casecontrol_pf(
         double iri[M], Pc[M], ctl[M];
 #pragma unroll
         for (int m = 0; m < M; ++m) {
-            iri[m] = 1.0 / (m == 0 ? ri0[r] : ri1[r]);
+            iri[m] = 1.0 / (m == 0 || !two_radii ? ri0[r] : ri1[r]);   // (same radii: slot 1 may hold a proposal)
             Pc[m] = 1.0; ctl[m] = 0.0;
         }
 #pragma unroll

@@ -376,9 +376,9 @@ constexpr int PS2_THREADS = 256;
 template <int D> struct PostRec { static constexpr int W = 2 * D + D * D + 2; };
 
 template <int D>
-__global__ __launch_bounds__(PS2_THREADS) void k_post_reduce(
-    ChainView c, const double *__restrict__ xref_in, int n_iter_procrustes, IterRef ir,
-    double *__restrict__ rec) {
+__device__ __forceinline__ void post_reduce_wg(
+    const ChainView &c, const double *__restrict__ xref_in, int n_iter_procrustes, IterRef ir,
+    double *__restrict__ rec, int wg, int nwg) {
     // lsm.py:495: rotate only once it > tune + burn (n_iter_procrustes < 0: always)
     const double *xref = (xref_in && (n_iter_procrustes < 0 ||
                                       (int)ir.get() > n_iter_procrustes)) ? xref_in : nullptr;
@@ -390,8 +390,8 @@ __global__ __launch_bounds__(PS2_THREADS) void k_post_reduce(
     double acc[W];
 #pragma unroll
     for (int q = 0; q < W; ++q) acc[q] = 0.0;
-    for (long r = (long)blockIdx.x * PS2_THREADS + tid; r < rows;
-         r += (long)gridDim.x * PS2_THREADS) {
+    for (long r = (long)wg * PS2_THREADS + tid; r < rows;
+         r += (long)nwg * PS2_THREADS) {
         double x[D];
 #pragma unroll
         for (int d = 0; d < D; ++d) { x[d] = X[r * D + d]; acc[d] += x[d]; }
@@ -420,9 +420,17 @@ __global__ __launch_bounds__(PS2_THREADS) void k_post_reduce(
     for (int q = 0; q < W; ++q) {
         const double v = block_sum_all<PS2_THREADS / 64>(
             acc[q], sRed + (q & 1) * (PS2_THREADS / 64), tid);
-        if (tid == 0) rec[(size_t)blockIdx.x * W + q] = v;
+        if (tid == 0) rec[(size_t)wg * W + q] = v;
     }
 }
+
+template <int D>
+__global__ __launch_bounds__(PS2_THREADS) void k_post_reduce(
+    ChainView c, const double *__restrict__ xref_in, int n_iter_procrustes, IterRef ir,
+    double *__restrict__ rec) {
+    post_reduce_wg<D>(c, xref_in, n_iter_procrustes, ir, rec, (int)blockIdx.x, (int)gridDim.x);
+}
+
 
 // directed models: cand = [proposal pair | current pair] for intercept `which` (one thread;
 // sample_coefficients.py:12-75)
@@ -443,11 +451,14 @@ __device__ __forceinline__ void dir_propose_intercept(const ChainView &c, LsmDev
 // Pass 2 (many workgroups): every workgroup sums the records in the same fixed
 // order, gets R (one-sided Jacobi polar factor of M) and the mean, and applies
 // x <- x R - mean R to its rows.  Workgroup 0 also leaves the LSM bookkeeping.
+// xr_keep_alt: leave the records' second radius slot alone (the radii proposal, riding in the same
+// launch, files itself there)
 template <int D>
-__global__ __launch_bounds__(PS2_THREADS) void k_post_apply(
-    ChainView c, int has_ref, int n_iter_procrustes, int do_center,
+__device__ __forceinline__ void post_apply_wg(
+    const ChainView &c, int has_ref, int n_iter_procrustes, int do_center,
     const double *__restrict__ rec, int nrec, LsmDeviceState *lsm, IterRef ir,
-    double *__restrict__ R_out, double *__restrict__ trace_X, double *__restrict__ xr = nullptr) {
+    double *__restrict__ R_out, double *__restrict__ trace_X, double *__restrict__ xr, int xr_keep_alt,
+    int wg, int nwg) {
     const uint32_t iter = ir.get();
     const int rotate = has_ref && (n_iter_procrustes < 0 || (int)iter > n_iter_procrustes);
     constexpr int W = PostRec<D>::W;
@@ -485,7 +496,7 @@ __global__ __launch_bounds__(PS2_THREADS) void k_post_apply(
             for (int a = 0; a < D; ++a) { sh += mean[a] * R[a][b]; sR[a * D + b] = R[a][b]; }
             sShift[b] = sh;
         }
-        if (blockIdx.x == 0) {
+        if (wg == 0) {
             if (R_out)
                 for (int a = 0; a < D * D; ++a) R_out[a] = sR[a];
             if (lsm) {
@@ -521,8 +532,8 @@ __global__ __launch_bounds__(PS2_THREADS) void k_post_apply(
     if (!rotate && !do_center && !trace_X && !xr) return;
     // the device-resident loop also files the final positions as row `iter` of its trace
     double *trow = trace_X ? trace_X + (size_t)iter * rows * D : nullptr;
-    for (long r = (long)blockIdx.x * PS2_THREADS + tid; r < rows;
-         r += (long)gridDim.x * PS2_THREADS) {
+    for (long r = (long)wg * PS2_THREADS + tid; r < rows;
+         r += (long)nwg * PS2_THREADS) {
         double x[D], y[D];
 #pragma unroll
         for (int a = 0; a < D; ++a) x[a] = X[r * D + a];
@@ -547,12 +558,28 @@ __global__ __launch_bounds__(PS2_THREADS) void k_post_apply(
 #pragma unroll
             for (int d = 0; d < D; ++d) rc[d] = y[d];
             rc[D] = rc[D + 1] = c.radii[r % c.N];
+            if (xr_keep_alt) {
 #pragma unroll
-            for (int d = 0; d < RW; d += 2)
-                *(double2 *)(xr + r * RW + d) = make_double2(rc[d], rc[d + 1]);
+                for (int d = 0; d < RW; ++d)
+                    if (d != D + 1) xr[r * RW + d] = rc[d];
+            } else {
+#pragma unroll
+                for (int d = 0; d < RW; d += 2)
+                    *(double2 *)(xr + r * RW + d) = make_double2(rc[d], rc[d + 1]);
+            }
         }
     }
 }
+
+template <int D>
+__global__ __launch_bounds__(PS2_THREADS) void k_post_apply(
+    ChainView c, int has_ref, int n_iter_procrustes, int do_center,
+    const double *__restrict__ rec, int nrec, LsmDeviceState *lsm, IterRef ir,
+    double *__restrict__ R_out, double *__restrict__ trace_X, double *__restrict__ xr = nullptr) {
+    post_apply_wg<D>(c, has_ref, n_iter_procrustes, do_center, rec, nrec, lsm, ir, R_out, trace_X, xr, 0,
+                     (int)blockIdx.x, (int)gridDim.x);
+}
+
 
 // ---------------------------------------------------------------------------
 // End of an undirected LSM iteration: fixed-order reduction of the fused
