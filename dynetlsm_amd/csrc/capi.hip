@@ -1913,6 +1913,11 @@ extern "C" int dlsm_debug_labels_timing(unsigned long long *waves) {
     if (hipMemcpyFromSymbol(waves, HIP_SYMBOL(dlsm::g_lab_t), sizeof(dlsm::g_lab_t)) != hipSuccess) return -2;
     return 0;
 }
+extern "C" int dlsm_debug_hdp_globals_phases(unsigned long long *out) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(dlsm::g_hdp_phase), sizeof(dlsm::g_hdp_phase)) != hipSuccess) return -2;
+    return 0;
+}
 extern "C" int dlsm_debug_hdp_tail_timing(unsigned long long *out) {
     if (hipDeviceSynchronize() != hipSuccess) return -1;
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(dlsm::g_hdp_t), sizeof(dlsm::g_hdp_t)) != hipSuccess) return -2;

@@ -65,11 +65,58 @@ __device__ inline double hdp_gamma(const HdpRng &g, uint32_t kind, uint32_t idx,
     return 0.0;
 }
 
+// The first attempt's normal and uniforms do not depend on the shape: a lane can draw them while
+// the shape is still being summed elsewhere, and finish with hdp_gamma_with (same arithmetic on
+// the same numbers as hdp_gamma: the same variate, bit for bit).
+struct HdpGammaPre { double z0, w0, w1, lw0; };
+__device__ inline HdpGammaPre hdp_gamma_pre(const HdpRng &g, uint32_t kind, uint32_t idx) {
+    HdpGammaPre p;
+    double u0, u1, z1;
+    g.u2(kind, idx, 0, u0, u1);
+    box_muller(u0, u1, p.z0, z1);
+    g.u2(kind, idx, 1, p.w0, p.w1);
+    p.lw0 = log(p.w0);
+    return p;
+}
+__device__ inline double hdp_gamma_with(const HdpRng &g, uint32_t kind, uint32_t idx, double a,
+                                        const HdpGammaPre &p) {
+    const double aa = a < 1.0 ? a + 1.0 : a;
+    const double d = aa - 1.0 / 3.0, cc = 1.0 / sqrt(9.0 * d);
+    for (uint32_t att = 0; att < 4096; ++att) {
+        double u0, u1, z0, z1, w0, w1, lw0;
+        if (att == 0) { z0 = p.z0; w0 = p.w0; w1 = p.w1; lw0 = p.lw0; }
+        else {
+            g.u2(kind, idx, 2 * att, u0, u1);
+            box_muller(u0, u1, z0, z1);
+            g.u2(kind, idx, 2 * att + 1, w0, w1);
+            lw0 = log(w0);
+        }
+        const double t = 1.0 + cc * z0;
+        if (t <= 0.0) continue;
+        const double v = t * t * t;
+        const double x2 = z0 * z0;
+        if (w0 < 1.0 - 0.0331 * x2 * x2 || lw0 < 0.5 * x2 + d * (1.0 - v + log(v))) {
+            double out = d * v;
+            if (a < 1.0) out *= pow(w1, 1.0 / a);
+            return out;
+        }
+    }
+    return 0.0;
+}
+
 __device__ inline double hdp_beta(const HdpRng &g, uint32_t kind, uint32_t idx, double a, double b) {
     const double ga = hdp_gamma(g, kind, 2 * idx, a);
     const double gb = hdp_gamma(g, kind, 2 * idx + 1, b);
     return ga / (ga + gb);
 }
+
+#ifdef DLSM_PIPE_TIMING
+// phases of the globals' workgroup (stage 2's long pole), rows [4][phase]: profiles/hdp_tail_timing.py
+__device__ unsigned long long g_hdp_phase[16][2];
+#define DLSM_HDP_PHASE(I_) { __syncthreads(); if (threadIdx.x == 0) { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)); g_hdp_phase[I_][0] = t_; g_hdp_phase[I_][1] = t_; } }
+#else
+#define DLSM_HDP_PHASE(I_)
+#endif
 
 // successes among n Bernoulli(p) trials; trial i = uniform i & 1 of attempt i >> 1
 __device__ inline int hdp_binomial(const HdpRng &g, uint32_t kind, uint32_t idx, int n, double p) {
@@ -193,53 +240,110 @@ __device__ __forceinline__ void hdp_tables_wg(const ChainView &c, const HdpLoopB
 
 // ---- override variables, m_bar, beta, w0: one workgroup -----------------------------------------
 constexpr int HG_THREADS = 256;
+constexpr int HG_MCAP = 8192;           // table cells the globals' workgroup stages in LDS (32 KB)
 __device__ __forceinline__ void hdp_globals_wg(const ChainView &c, const HdpLoopBuf &hb,
                                                HdpDeviceState *hs, uint32_t iter) {
+    // This workgroup is stage 2's long pole (profiles/hdp_tail_timing.py: 17 us against 9 for the
+    // other roles), and its three chains ran one after the other: a lane per override binomial
+    // (6.6 us), the tables' column sums a cell per trip through an LDS atomic (4.8 us), a lane per
+    // gamma variate of beta (4.0 us).  Now wavefronts 0-2 draw the binomials while wavefront 3
+    // stages the tables in LDS, sums their columns from there and draws the shape-independent
+    // part of beta's variates; what is left behind the barrier is the variates' shape-dependent
+    // part.  Same draws, integer sums: the same values (17.4 -> 11.7 us).
+    // (Built and measured slower: the binomials' trials dealt out over all threads - 1800 pairs
+    // at config 3 - through a scan and a pair -> cell search: 7.8 us; a column's rows read from
+    // global memory by nine threads: 9.2 us.)
     __shared__ int sMsum[64], sWsum[64], sTot[4];
     __shared__ double sBeta[64], sG[64];
-    const int K = hb.K, T = c.T, tid = threadIdx.x;
+    __shared__ int sMt[HG_MCAP];
+    __shared__ int sReady;
+    const int K = hb.K, T = c.T, tid = threadIdx.x, wave = tid >> 6;
+    const int TKK = T * K * K;
+    const bool mlds = TKK <= HG_MCAP;
     const HdpRng g = hdp_rng(c, iter);
     if (tid < 64) { sMsum[tid] = 0; sWsum[tid] = 0; }
     if (tid < 4) sTot[tid] = 0;
     if (tid < K) sBeta[tid] = hb.beta[tid];
+    if (tid == 0) sReady = 0;
     __syncthreads();
+    DLSM_HDP_PHASE(0)
+    // every thread stages its share of the tables (one burst of loads); only wavefront 3 reads
+    // them, so only wavefront 3 waits for the others' shares - on a counter in LDS, the binomials'
+    // wavefronts go on at once
+    if (mlds) {
+        for (int q0 = tid; q0 < TKK; q0 += 8 * HG_THREADS) {
+            int v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = q0 + u * HG_THREADS < TKK ? hb.m[q0 + u * HG_THREADS] : 0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (q0 + u * HG_THREADS < TKK) sMt[q0 + u * HG_THREADS] = v[u];
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);         // lgkmcnt(0): this wavefront's LDS writes landed
+        __builtin_amdgcn_wave_barrier();
+        if ((tid & 63) == 0) atomicAdd(&sReady, 1);
+    }
     const double rho = hs->kappa / (hs->alpha + hs->kappa);
-    // override variables (sample_auxillary.py:37-42)
-    int wsum = 0;
-    for (int q = tid; q < (T - 1) * K; q += HG_THREADS) {
-        const int t = q / K, j = q - t * K;
-        const int mjj = hb.m[((size_t)(t + 1) * K + j) * K + j];
-        const double p = rho / (rho + sBeta[j] * (1 - rho));
-        const int w = hdp_binomial(g, HK_OVERRIDE, (uint32_t)q, mjj, p);
-        hb.wover[q] = w;
-        atomicAdd(&sWsum[j], w);
-        wsum += w;
+    HdpGammaPre gp{0.0, 0.0, 0.0, 0.0};
+    const int l3 = tid - 3 * 64;                    // lane of wavefront 3 = component
+    if (wave < 3) {
+        // override variables (sample_auxillary.py:37-42)
+        int wsum = 0;
+        for (int q = tid; q < (T - 1) * K; q += 3 * 64) {
+            const int t = q / K, j = q - t * K;
+            const int mjj = hb.m[((size_t)(t + 1) * K + j) * K + j];
+            const double p = rho / (rho + sBeta[j] * (1 - rho));
+            const int w = hdp_binomial(g, HK_OVERRIDE, (uint32_t)q, mjj, p);
+            hb.wover[q] = w;
+            atomicAdd(&sWsum[j], w);
+            wsum += w;
+        }
+        atomicAdd(&sTot[0], wsum);
+    } else {
+        // column sums of the tables: m_bar[k] = sum_{t >= 1, j} m[t, j, k] - sum_t w[t, k] + m[0, 0, k]
+        // (nsub lanes per column, four rows requested per trip: a row per trip is an LDS round trip
+        // per row, 200 in a row at config 3)
+        if (mlds)
+            while (*(volatile int *)&sReady < HG_THREADS / 64) __builtin_amdgcn_s_sleep(1);
+        const int nsub = max(1, 64 / K);
+        for (int k0 = 0; k0 < K; k0 += 64) {
+            const int k = k0 + l3 % min(K, 64), sub = l3 / min(K, 64);
+            if (k >= K || sub >= nsub) continue;
+            int acc = 0, rest = 0;
+            for (int r0 = sub; r0 < T * K; r0 += 4 * nsub) {        // row r = (t, j)
+                int v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int r = min(r0 + u * nsub, T * K - 1);
+                    v[u] = mlds ? sMt[r * K + k] : hb.m[(size_t)r * K + k];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int r = r0 + u * nsub;
+                    if (r >= T * K || (r < K && r != 0)) continue;  // t = 0: only j = 0
+                    acc += v[u];
+                    if (r >= K) rest += v[u];
+                }
+            }
+            atomicAdd(&sMsum[k], acc);
+            atomicAdd(&sTot[1], rest);
+        }
+        if (l3 < K) gp = hdp_gamma_pre(g, HK_BETA, (uint32_t)l3);
     }
-    atomicAdd(&sTot[0], wsum);
-    // column sums of the tables: m_bar[k] = sum_{t >= 1, j} m[t, j, k] - sum_t w[t, k] + m[0, 0, k]
-    int mrest = 0;
-    for (int q = tid; q < T * K * K; q += HG_THREADS) {
-        const int t = q / (K * K), r = q - t * K * K, j = r / K, k = r - j * K;
-        if (t == 0 && j != 0) continue;
-        const int v = hb.m[q];
-        atomicAdd(&sMsum[k], v);
-        if (t > 0) mrest += v;
-    }
-    atomicAdd(&sTot[1], mrest);
     __syncthreads();
+    DLSM_HDP_PHASE(2)
     // global transition distribution beta ~ Dirichlet(gamma / K + m_bar) (hdp_lpcm.py:887)
-    double mb = 0.0;
-    if (tid < K) {
-        mb = (double)(sMsum[tid] - sWsum[tid]);
-        hb.mbar[tid] = mb;
-        sG[tid] = hdp_gamma(g, HK_BETA, (uint32_t)tid, hs->gamma / K + mb);
+    if (l3 >= 0 && l3 < K) {
+        const double mb = (double)(sMsum[l3] - sWsum[l3]);
+        hb.mbar[l3] = mb;
+        sG[l3] = hdp_gamma_with(g, HK_BETA, (uint32_t)l3, hs->gamma / K + mb, gp);
     }
     __syncthreads();
+    DLSM_HDP_PHASE(3)
     double tot = 0.0;
     for (int k = 0; k < K; ++k) tot += sG[k];
     const double bnew = tid < K ? sG[tid] * (1.0 / tot) : 0.0;
     // (the initial distribution w0, whose gamma draws wait for beta, is drawn in stage 3 beside
-    // the other rows of w: this workgroup is stage 2's long pole, profiles/hdp_tail_timing.py)
+    // the other rows of w)
     if (tid < K) hb.beta[tid] = bnew;
     if (tid == 0) {
         double mbt = 0.0, mbp = 0.0, m00 = 0.0;
@@ -251,6 +355,7 @@ __device__ __forceinline__ void hdp_globals_wg(const ChainView &c, const HdpLoop
         hs->mbar_total = mbt; hs->mbar_positive = mbp; hs->m00_total = m00;
         hs->m_rest_total = (double)sTot[1]; hs->override_total = (double)sTot[0];
     }
+    DLSM_HDP_PHASE(4)
 }
 
 // ---- transition distributions w[t, j, :] ~ Dirichlet(alpha beta + kappa e_j + n[t, j, :]) ---------
