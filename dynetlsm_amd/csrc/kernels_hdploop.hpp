@@ -581,26 +581,32 @@ struct HdpStamp {
 __device__ __forceinline__ void hdp_hypers_wg(const ChainView &c, const HdpLoopBuf &hb,
                                               HdpDeviceState *hs, const HdpTrace &tr, IterRef ir) {
     DLSM_HDP_STAMP(3)
-    __shared__ double red[2][HH_THREADS / 64];
-    __shared__ double sC[3], sLam;
+    __shared__ double sC[3], sLam, sEp[2];
     const int K = hb.K, T = c.T, D = c.D, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const HdpRng g = hdp_rng(c, ir.get());
     const double *sB = hb.scr + HS_GAM8;
-    // sums of the lambda update over the cells (t >= 1, k) with members (hdp_lpcm.py:941-950)
-    double a0 = 0.0, a1 = 0.0;
-    for (int q = K + tid; q < T * K; q += HH_THREADS)
-        if (hb.nk[q] > 0) { a0 += hb.L[2 * (size_t)q]; a1 += hb.L[2 * (size_t)q + 1]; }
-    const double ml_sum = block_sum_all<HH_THREADS / 64>(a0, red[0], tid);
-    const double sl_sum = block_sum_all<HH_THREADS / 64>(a1, red[1], tid);
-    if (wave == 1 && lane == 0) {
-        // blending coefficient (hdp_lpcm.py:951-954)
-        double sl = 1.0 / hs->lambda_var + sl_sum;
-        sl = 1.0 / sl;
-        double ml = ml_sum + hs->lambda_prior / hs->lambda_var;
-        ml *= sl;
-        double u0, u1;
-        g.u2(HK_LAMBDA, 0, 0, u0, u1);
-        sLam = dev_truncnorm_quantile(u0, ml, sl);
+    // Three chains that do not wait for each other, each on wavefronts of its own and with one
+    // barrier behind all of them: wavefront 1 the blending coefficient (its sums by the wavefront
+    // alone: no workgroup barrier in front of the quantile), wavefront 0 the gamma variates (from
+    // the first instruction: they need nothing summed here), wavefronts 2-3 the trace rows and
+    // the two sums of the variance hyper-parameters.
+    if (wave == 1) {
+        // sums of the lambda update over the cells (t >= 1, k) with members (hdp_lpcm.py:941-950)
+        double a0 = 0.0, a1 = 0.0;
+        for (int q = K + lane; q < T * K; q += 64)
+            if (hb.nk[q] > 0) { a0 += hb.L[2 * (size_t)q]; a1 += hb.L[2 * (size_t)q + 1]; }
+        const double ml_sum = wave_sum_all(a0);
+        const double sl_sum = wave_sum_all(a1);
+        if (lane == 0) {
+            // blending coefficient (hdp_lpcm.py:951-954)
+            double sl = 1.0 / hs->lambda_var + sl_sum;
+            sl = 1.0 / sl;
+            double ml = ml_sum + hs->lambda_prior / hs->lambda_var;
+            ml *= sl;
+            double u0, u1;
+            g.u2(HK_LAMBDA, 0, 0, u0, u1);
+            sLam = dev_truncnorm_quantile(u0, ml, sl);
+        }
     }
     // Escobar & West's gamma draws (sample_concentration.py:13-21) and alpha + kappa
     if (tid < 3) {
@@ -633,24 +639,26 @@ __device__ __forceinline__ void hdp_hypers_wg(const ChainView &c, const HdpLoopB
             tr.beta[it * K + q] = hb.beta[q];
         }
         for (int q = st; q < T * K * K; q += NS) tr.w[it * T * K * K + q] = hb.w[q];
+        if (tid == 128 && hs->has_a0) {             // (the order of the sums is the reference's)
+            double b = 0.5 * hs->b0;
+            for (int k = 0; k < K; ++k) {
+                double ss = 0.0;
+                for (int d = 0; d < D; ++d) ss += hb.mu[(size_t)k * D + d] * hb.mu[(size_t)k * D + d];
+                b += 0.5 * ss;
+            }
+            sEp[0] = b;
+        }
+        if (tid == 192 && hs->has_c0) {
+            double scale = 0.5 * hs->d0;
+            for (int k = 0; k < K; ++k) scale += 0.5 * (1.0 / hb.sigma[k]);
+            sEp[1] = scale;
+        }
     }
     __syncthreads();
     if (tid != 0) return;
     hs->lmbda = sLam;
-    if (hs->has_a0) {
-        double b = 0.5 * hs->b0;
-        for (int k = 0; k < K; ++k) {
-            double ss = 0.0;
-            for (int d = 0; d < D; ++d) ss += hb.mu[(size_t)k * D + d] * hb.mu[(size_t)k * D + d];
-            b += 0.5 * ss;
-        }
-        hs->mvp = 1.0 / (sB[4] * (1.0 / b));
-    }
-    if (hs->has_c0) {
-        double scale = 0.5 * hs->d0;
-        for (int k = 0; k < K; ++k) scale += 0.5 * (1.0 / hb.sigma[k]);
-        hs->b = sB[5] * (1.0 / scale);
-    }
+    if (hs->has_a0) hs->mvp = 1.0 / (sB[4] * (1.0 / sEp[0]));
+    if (hs->has_c0) hs->b = sB[5] * (1.0 / sEp[1]);
     hs->gamma = sC[0];
     hs->alpha_init = sC[1];
     const double ak = sC[2];
