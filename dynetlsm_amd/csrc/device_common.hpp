@@ -321,8 +321,9 @@ __device__ __forceinline__ double fast_log(double x) {
 // pipe is idle in the kernels that are bound by float64 VALU issue.  The integer round(x 256 /
 // ln2) is read from the low word of x 256 / ln2 + 1.5 * 2^52: VALID FOR |x| < 5.8e6 only (beyond
 // it the word wraps) - minus a Euclidean distance between latent positions is inside by any
-// margin; minus a SQUARED distance goes through tab_exp_clamped.  1 ulp against the correctly
-// rounded exponential on 2e4 samples of [-60, 0] (emulated without fma: 1.5 ulp).
+// margin; minus a SQUARED distance goes through tab_exp_clamped.  Against the correctly rounded
+// exponential (tests/test_exp_table_cpu.py): 2 ulp + |x| / 2 ulp with the one-step argument
+// reduction below (the two-step form, 1 ulp everywhere, is kept under DLSM_EXP_TWO_STEP).
 constexpr int EXPTAB_N = 256;
 // the workgroup's table, by its first 256 threads (callers put a barrier behind it)
 __device__ __forceinline__ void exp_table_fill(double *tab, int tid) {
@@ -333,8 +334,15 @@ __device__ __forceinline__ double tab_exp(double x, const double *tab) {
     const double t = fma(x, 369.3299304675746, magic);           // 256 / ln2
     const double kf = t - magic;
     const int ki = __double2loint(t);
+#ifdef DLSM_EXP_TWO_STEP
     double r = fma(kf, -0x1.62e42fee00000p-9, x);                // ln2 / 256, high 32 bits
     r = fma(kf, -0x1.a39ef35793c76p-41, r);
+#else
+    // one step with ln2 / 256 rounded to double: the product is exact inside the fma, so the only
+    // error is the constant's rounding, |x| 1.1e-16 on the reduced argument = on e^x relatively
+    // (1e-15 at a distance of 10, 9e-15 at 80, where e^x is 1e-35) - one instruction of twelve
+    const double r = fma(kf, -0x1.62e42fefa39efp-9, x);
+#endif
     double p = fma(r, 1.0 / 24.0, 1.0 / 6.0);
     p = fma(p, r, 0.5);
     p = fma(p, r, 1.0);

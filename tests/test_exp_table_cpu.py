@@ -29,6 +29,32 @@ def test_table_entries_are_correctly_rounded():
     assert tab[0] == 1.0 and np.all(np.diff(tab) > 0) and tab[-1] < 2.0
 
 
+def test_table_exponential_one_step_reduction_error_grows_with_the_argument():
+    """the kernels' default: ONE reduction step with ln2 / 256 rounded to double (the product is exact
+    inside the fma, here emulated in longdouble) - the constant's rounding error, |x| 1.1e-16, is the
+    whole price: within 2 ulp + |x| / 2 ulp of the correctly rounded exponential"""
+    tab = _table()
+    getcontext().prec = 50
+    magic = 6755399441055744.0
+    c = float.fromhex('0x1.62e42fefa39efp-9')
+    assert c == 0.6931471805599453 / 256
+    x = -np.random.RandomState(1).uniform(0.0, 80.0, 20000)
+    t = x * 369.3299304675746 + magic
+    kf = t - magic
+    ki = kf.astype(np.int64)
+    r = (x.astype(np.longdouble) - kf.astype(np.longdouble) * np.longdouble(c)).astype(np.float64)
+    p = r * (1.0 / 24.0) + 1.0 / 6.0
+    p = p * r + 0.5
+    p = p * r + 1.0
+    p = p * r + 1.0
+    got = np.ldexp(tab[ki & 255] * p, (ki >> 8).astype(np.int32))
+    want = np.array([float(Decimal(float(v)).exp()) for v in x])
+    err = np.abs(got - want) / np.spacing(want)
+    assert np.all(err <= 2.0 + 0.5 * np.abs(x))
+    near = np.abs(x) < 10.0
+    assert np.max(err[near]) <= 7.0
+
+
 def test_table_exponential_within_two_ulp():
     tab = _table()
     getcontext().prec = 50
