@@ -198,7 +198,9 @@ __device__ __forceinline__ void pipe_reduce(double s, double a, double b, int la
     s += lane_get(s, x32);
     q *= lane_get(q, x32);
     sum = s;
-    ratio = q / dpp_move<0xB1>(q);  // lane 0: prod a / prod b
+    // lane 0: prod a / prod b (products of factors >= 1 that the caller keeps inside the double
+    // range: the reciprocal's Newton form, within 2 ulp of the division at a fifth of it)
+    ratio = q * fast_rcp(dpp_move<0xB1>(q));
 }
 
 // Operands of a lane's FIRST H entry (proposal / snapshot rows of the two nodes, the edge's bit,
