@@ -79,7 +79,7 @@ int enqueue_hdp_iteration(dlsm_chain *h, int it, bool draw_next) {
                        hb, h->hdp, h->lsm, h->partials, nrec, h->intercept, h->trace_ic, ir);
     hipLaunchKernelGGL((k_hdp_stage2<DD>), dim3(2 + K * T), dim3(HDP_THREADS), 0, h->stream, v, hb,
                        h->hdp, ir);
-    hipLaunchKernelGGL((k_hdp_stage3<DD>), dim3(T + K * T), dim3(HDP_THREADS),
+    hipLaunchKernelGGL((k_hdp_stage3<DD>), dim3(HW_SPLIT * (T - 1) + 1 + K * T), dim3(HDP_THREADS),
                        (size_t)(K * K + K) * sizeof(double), h->stream, v, hb, h->hdp, ir);
     HdpTrace tr{h->trace_ic, h->trace_logp, h->htr_mu, h->htr_sigma, h->htr_beta, h->htr_w,
                 h->htr_lambda, h->htr_hyper};

@@ -360,27 +360,31 @@ __device__ __forceinline__ void hdp_globals_wg(const ChainView &c, const HdpLoop
 
 // ---- transition distributions w[t, j, :] ~ Dirichlet(alpha beta + kappa e_j + n[t, j, :]) ---------
 // (hdp_lpcm.py:894-898); workgroup t - 1 draws the K x K gamma variates of time t
+// HW_SPLIT workgroups per time step, each a band of rows (a row is normalised by itself): one
+// gamma variate per thread at K = 20 instead of two in a row (the role was stage 3's long pole)
+constexpr int HW_SPLIT = 2;
 __device__ __forceinline__ void hdp_weights_wg(const ChainView &c, const HdpLoopBuf &hb,
-                                               const HdpDeviceState *hs, uint32_t iter, int t,
+                                               const HdpDeviceState *hs, uint32_t iter, int t, int part,
                                                double *sGam /* K * K + K */) {
     const int K = hb.K, tid = threadIdx.x;
+    const int jb = (K + HW_SPLIT - 1) / HW_SPLIT, j0 = part * jb, j1 = min(K, j0 + jb);
     double *sInv = sGam + K * K;
     const HdpRng g = hdp_rng(c, iter);
     const double alpha = hs->alpha, kappa = hs->kappa;
-    for (int q = tid; q < K * K; q += 256) {
+    for (int q = j0 * K + tid; q < j1 * K; q += 256) {
         const int j = q / K, k = q - j * K;
         double al = (alpha * hb.beta[k] + (j == k ? kappa : 0.0)) + (double)hb.n[(size_t)t * K * K + q];
         if (al <= 0.0) al = HDP_SMALL_EPS;
         sGam[q] = hdp_gamma(g, HK_W, (uint32_t)(t * K * K + q), al);
     }
     __syncthreads();
-    if (tid < K) {
+    if (tid >= j0 && tid < j1) {
         double tot = 0.0;
         for (int k = 0; k < K; ++k) tot += sGam[tid * K + k];
         sInv[tid] = 1.0 / tot;
     }
     __syncthreads();
-    for (int q = tid; q < K * K; q += 256) hb.w[(size_t)t * K * K + q] = sGam[q] * sInv[q / K];
+    for (int q = j0 * K + tid; q < j1 * K; q += 256) hb.w[(size_t)t * K * K + q] = sGam[q] * sInv[q / K];
 }
 
 // ---- cluster means (hdp_lpcm.py:901-921) and variances (:924-938) -----------------------------------
@@ -752,9 +756,13 @@ __global__ __launch_bounds__(HDP_THREADS) void k_hdp_stage3(ChainView c, HdpLoop
     DLSM_HDP_STAMP(2)
     extern __shared__ double sGam[];            // K * K + K (the weights' role)
     const int K = hb.K, T = c.T;
-    if ((int)blockIdx.x < T - 1) { hdp_weights_wg(c, hb, hs, ir.get(), blockIdx.x + 1, sGam); return; }
-    if ((int)blockIdx.x == T - 1) { hdp_gam8_wg(c, hb, hs, ir.get()); return; }
-    const int q = (int)blockIdx.x - T;
+    const int nw = HW_SPLIT * (T - 1);
+    if ((int)blockIdx.x < nw) {
+        hdp_weights_wg(c, hb, hs, ir.get(), (int)blockIdx.x / HW_SPLIT + 1, (int)blockIdx.x % HW_SPLIT, sGam);
+        return;
+    }
+    if ((int)blockIdx.x == nw) { hdp_gam8_wg(c, hb, hs, ir.get()); return; }
+    const int q = (int)blockIdx.x - nw - 1;
     hdp_sigma_lambda_wg<D>(c, hb, hs, ir.get(), q % K, q / K);
 }
 
