@@ -52,17 +52,16 @@ for i, nm in enumerate(names):
                'exit_us_p50': round(float(np.median(ext)), 2),
                'slowest_workgroups[(blockIdx, entry, exit)]': [(int(idx[j]), round(float(ent[j]), 2), round(float(ext[j]), 2)) for j in order]}
     print(nm, json.dumps(out[nm]))
-# phases of the globals' workgroup of stage 2 (entry, override binomials, column sums, beta's gamma
-# variates, exit), relative to its entry
+# phases of the globals' workgroup of stage 2, relative to its entry
 ph = np.zeros((16, 2), dtype=np.uint64)
 try:
     L.dlsm_debug_hdp_globals_phases.restype = C.c_int
     L.dlsm_debug_hdp_globals_phases.argtypes = [C.c_void_p]
     if L.dlsm_debug_hdp_globals_phases(ph.ctypes.data) == 0:
-        p0 = ph[:5, 0].astype(np.int64)
-        out['stage2_globals_phases_us[entry, binomials, column sums, beta gammas, exit]'] = \
-            [round(float(v - p0[0]) * 0.01, 2) for v in p0]
-        print('globals phases', out['stage2_globals_phases_us[entry, binomials, column sums, beta gammas, exit]'])
+        p0 = ph[[0, 2, 3, 4], 0].astype(np.int64)
+        key = 'stage2_globals_phases_us[entry, binomials + column sums + pre-drawn variates done, beta drawn, exit]'
+        out[key] = [round(float(v - p0[0]) * 0.01, 2) for v in p0]
+        print('globals phases', out[key])
 except AttributeError:
     pass
 if len(sys.argv) > 2:
