@@ -49,14 +49,37 @@ __device__ __forceinline__ void hdp_label_sums_wg(const ChainView &c, int k, int
     double acc[NV];
 #pragma unroll
     for (int v = 0; v < NV; ++v) acc[v] = 0.0;
-    for (int i = tid; i < N; i += HDP_THREADS) {
-        if (zt[i] != k) continue;
+    // Four nodes per thread and trip: their labels are requested together, then the positions of
+    // the cluster's members together (a node per trip was two memory round trips per node, one
+    // behind the other, eight nodes in a row at config 3); a thread still adds its nodes in
+    // ascending order: the sums are the same numbers.
+    constexpr int NU = 4;
+    for (int i0 = tid; i0 < N; i0 += NU * HDP_THREADS) {
+      int zz[NU];
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+          const int i = i0 + u * HDP_THREADS;
+          zz[u] = i < N ? zt[i] : -1;
+      }
+      double xs[NU][D], xps[NU][D];
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+          const int i = i0 + u * HDP_THREADS;
+          if (zz[u] == k) {
+#pragma unroll
+              for (int d = 0; d < D; ++d) {
+                  xs[u][d] = Xt[(size_t)i * D + d];
+                  xps[u][d] = t > 0 ? Xp[(size_t)i * D + d] : 0.0;
+              }
+          }
+      }
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        const int i = i0 + u * HDP_THREADS;
+        if (zz[u] != k) continue;
         double x[D], xp[D];
 #pragma unroll
-        for (int d = 0; d < D; ++d) {
-            x[d] = Xt[(size_t)i * D + d];
-            xp[d] = t > 0 ? Xp[(size_t)i * D + d] : 0.0;
-        }
+        for (int d = 0; d < D; ++d) { x[d] = xs[u][d]; xp[d] = xps[u][d]; }
         if (STAGE == HDP_SUMS_MEAN) {
 #pragma unroll
             for (int d = 0; d < D; ++d) acc[d] += t > 0 ? x[d] - (1 - lm) * xp[d] : x[d];
@@ -87,6 +110,7 @@ __device__ __forceinline__ void hdp_label_sums_wg(const ChainView &c, int k, int
                 acc[1] += a1 / sk;
             }
         }
+      }
     }
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
