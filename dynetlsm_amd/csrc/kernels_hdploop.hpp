@@ -814,20 +814,43 @@ __global__ __launch_bounds__(HDP_THREADS) void k_hdp_logp_batch_sums(ChainView c
     const double lsk = log(sk);
     double acc = 0.0;
     int members = 0;
-    for (int i = tid; i < N; i += HDP_THREADS) {
-        if (zt[i] != k) continue;
-        ++members;
-        double ss = 0.0;
+    // (four nodes per thread and trip, labels then positions requested together; a thread adds its
+    // nodes in ascending order as before)
+    constexpr int NU = 4;
+    for (int i0 = tid; i0 < N; i0 += NU * HDP_THREADS) {
+        int zz[NU], zq[NU];
 #pragma unroll
-        for (int d = 0; d < D; ++d) {
-            const double x = Xt[(size_t)i * D + d];
-            const double xp = t > 0 ? Xp[(size_t)i * D + d] : 0.0;
-            const double r = t > 0 ? x - (1 - lm) * xp - lm * mk[d] : x - mk[d];
-            ss += r * r;
+        for (int u = 0; u < NU; ++u) {
+            const int i = i0 + u * HDP_THREADS;
+            zz[u] = i < N ? (int)zt[i] : -1;
+            zq[u] = i < N && t > 0 ? (int)zp[i] : 0;
         }
-        const int zprev = t > 0 ? zp[i] : 0;
-        acc += log(w[((size_t)t * K + zprev) * K + k]) - 0.5 * lsk - 0.5 * ss / sk -
-               (0.5 * a_ + 1.0) * lsk - 0.5 * hb_ / sk;
+        double xs[NU][D], xps[NU][D], lw[NU];
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int i = i0 + u * HDP_THREADS;
+            if (zz[u] == k) {
+#pragma unroll
+                for (int d = 0; d < D; ++d) {
+                    xs[u][d] = Xt[(size_t)i * D + d];
+                    xps[u][d] = t > 0 ? Xp[(size_t)i * D + d] : 0.0;
+                }
+                lw[u] = w[((size_t)t * K + zq[u]) * K + k];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            if (zz[u] != k) continue;
+            ++members;
+            double ss = 0.0;
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const double x = xs[u][d], xp = xps[u][d];
+                const double r = t > 0 ? x - (1 - lm) * xp - lm * mk[d] : x - mk[d];
+                ss += r * r;
+            }
+            acc += log(lw[u]) - 0.5 * lsk - 0.5 * ss / sk - (0.5 * a_ + 1.0) * lsk - 0.5 * hb_ / sk;
+        }
     }
     const double v = block_sum_all<HDP_THREADS / 64>(acc, buf, tid);
     const double m = wave_sum_all((double)members);
@@ -870,7 +893,10 @@ __device__ __forceinline__ double hdp_dirichlet_row_at(const double *beta, const
 }
 
 // grid (samples): the Dirichlet rows of the sample, then k_hdp_finalize's reduction and scalars
-constexpr int HF_THREADS = 256;
+// (1024 threads: a row per wavefront, 16 rows at a time - with four wavefronts the (T - 1) K + 1 rows
+// of a sample, each a handful of lgamma, were 125 us in a row; the sums keep their order: the first
+// 256 threads add exactly what the 256 threads of the four-wavefront form added, the others zeros)
+constexpr int HF_THREADS = 1024;
 template <int D>
 __global__ __launch_bounds__(HF_THREADS) void k_hdp_logp_batch_finish(ChainView c, HdpTraceView tv,
                                                                       int s0, const HdpDeviceState *hs,
@@ -889,10 +915,11 @@ __global__ __launch_bounds__(HF_THREADS) void k_hdp_logp_batch_finish(ChainView 
     }
     __syncthreads();
     double acc = 0.0;
-    for (int q = tid; q < T * K; q += HF_THREADS) {
-        const size_t g = (size_t)blockIdx.x * T * K + q;
-        acc += (cnt[g] > 0 ? LP[g] : 0.0) + sLPD[q];
-    }
+    if (tid < 256)
+        for (int q = tid; q < T * K; q += 256) {
+            const size_t g = (size_t)blockIdx.x * T * K + q;
+            acc += (cnt[g] > 0 ? LP[g] : 0.0) + sLPD[q];
+        }
     const double body = block_sum_all<HF_THREADS / 64>(acc, red, tid);
     if (tid != 0) return;
     double lp = body + tv.ic[s * 2 + 1];                        // + the network log-likelihood
