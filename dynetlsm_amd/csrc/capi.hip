@@ -1071,6 +1071,8 @@ static int launch_sweep_pipe(dlsm_chain *h, IterRef iter, bool alloc_only = fals
                                   (int)lds));
     HIPCHK(h, hipFuncSetAttribute((const void *)kc, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds));
+    HIPCHK(h, hipFuncSetAttribute((const void *)k_pipe_last_ride<DD>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (alloc_only) return DLSM_OK;
     ChainView v = h->view();
     {   // the proposal pass, unless the previous iteration's last launch carried it
@@ -1104,6 +1106,18 @@ static int launch_sweep_pipe(dlsm_chain *h, IterRef iter, bool alloc_only = fals
         const bool any_eval = (G * (l + 1) < nbat) || (T > 1 && l >= 0 && G * l < nbat);
         const int grid = T + (any_eval ? ne_wg : 0);
         const bool lng = pb.per > 64 * pipe_prefetch_trips(DD);
+        if (l == last && !any_eval && h->post_ride_want && G == 1 && h->model == DLSM_UNDIRECTED &&
+            !h->profiling && l >= 0) {
+            // the centring sums ride in the resolve-only launch (kernels_spec_pipe.hpp)
+            const long rows = (long)T * N;
+            const int nwg = (int)std::min<long>(PS_BLOCKS, (rows + PP_THREADS - 1) / PP_THREADS);
+            PipePostRide pr{h->post_ride_xref, iter, h->partials + (size_t)ll_blocks(h) * 4, nwg,
+                            (nbat - 1) * PP_B, T > 1 ? 1 : 0};
+            hipLaunchKernelGGL((k_pipe_last_ride<DD>), dim3(T + nwg), dim3(PP_THREADS), lds, h->stream, v, pb,
+                               l, pr);
+            h->post_ride_done = true; h->post_ride_nwg = nwg; h->post_ride_jl = pr.jl; h->post_ride_par = pr.par;
+            continue;
+        }
         if (h->model == DLSM_UNDIRECTED && lng && G == 2)
             launch_pipe_step<DD, PIPE_UNDIRECTED_LONG, 2>(h, v, pb, grid, lds, l);
         else if (h->model == DLSM_UNDIRECTED && lng)
@@ -1310,7 +1324,8 @@ int dlsm_sweep_positions(dlsm_chain *h, uint32_t iter, int algo) {
 template <int DD>
 static int launch_post(dlsm_chain *h, const double *d_xref, int n_iter_procrustes,
                        int do_center, LsmDeviceState *lsm, IterRef iter, double *d_R,
-                       bool alloc_only = false, double *trace_X = nullptr, double *xr = nullptr) {
+                       bool alloc_only = false, double *trace_X = nullptr, double *xr = nullptr,
+                       int ride_nwg = 0, int ride_jl = -1, int ride_par = 0) {
     ChainView v = h->view();
     const long rows = (long)h->T * h->N;
     const int nb = (int)std::min<long>(PS_BLOCKS, (rows + PS2_THREADS - 1) / PS2_THREADS);
@@ -1322,6 +1337,13 @@ static int launch_post(dlsm_chain *h, const double *d_xref, int n_iter_procruste
     if (alloc_only) return DLSM_OK;
     double *rec = h->partials + (size_t)ll_blocks(h) * 4;
     ProfScope ps(h, DLSM_K_CENTER);
+    if (ride_nwg > 0) {     // the sums rode in the sweep's last launch, but for the rows it was still moving
+        hipLaunchKernelGGL((k_post_apply<DD>), dim3(nb), dim3(PS2_THREADS), 0, h->stream, v,
+                           d_xref ? 1 : 0, n_iter_procrustes, do_center, rec, ride_nwg, lsm, iter, d_R,
+                           trace_X, xr, ride_jl, ride_par, d_xref);
+        HIPCHK(h, hipGetLastError());
+        return DLSM_OK;
+    }
     hipLaunchKernelGGL((k_post_reduce<DD>), dim3(nb), dim3(PS2_THREADS), 0, h->stream, v,
                        d_xref, n_iter_procrustes, iter, rec);
     hipLaunchKernelGGL((k_post_apply<DD>), dim3(nb), dim3(PS2_THREADS), 0, h->stream, v,
@@ -1572,14 +1594,29 @@ static int enqueue_lsm_iteration(dlsm_chain *h, int it, bool counter, int procru
     int rc = DLSM_OK;
     if (counter && !alloc_only)
         hipLaunchKernelGGL(k_advance_iter, dim3(1), dim3(1), 0, h->stream, &h->lsm->iter);
-    rc = enqueue_sweep(h, ir, h->lsm_cfg.sweep_algo, alloc_only); if (rc) return rc;
     const double *xref = procrustes_ref >= 0 ? h->trace_X + row * procrustes_ref : nullptr;
+    // undirected loop: the centring sums ride in the pipelined sweep's last launch when there is one
+    // (DLSM_POST_RIDE=0: a launch of their own); whether the rotation is on is decided here
+    h->post_ride_want = h->model == DLSM_UNDIRECTED && !counter && !alloc_only &&
+                        !(getenv("DLSM_POST_RIDE") && atoi(getenv("DLSM_POST_RIDE")) == 0);
+    h->post_ride_done = false;
+    if (h->post_ride_want) {
+        rc = ensure_partials(h, (size_t)ll_blocks(h) * 4 + (size_t)PS_BLOCKS * 26); if (rc) return rc;
+        const int nip = h->lsm_cfg.n_iter_procrustes;
+        h->post_ride_xref = (xref && (nip < 0 || it > nip)) ? xref : nullptr;
+    }
+    rc = enqueue_sweep(h, ir, h->lsm_cfg.sweep_algo, alloc_only);
+    h->post_ride_want = false;
+    if (rc) return rc;
+    const bool rode = h->post_ride_done;
+    h->post_ride_done = false;
     // case-control: the centring pass also writes the log-likelihood's gather records
     const bool pf = cc_prefetch_form(h);
     if (pf) { DISPATCH_D(h, h->D, rc = ensure_xr<DD>(h)); if (rc) return rc; }
     if (h->model == DLSM_UNDIRECTED) {
         DISPATCH_D(h, h->D, rc = launch_post<DD>(h, xref, h->lsm_cfg.n_iter_procrustes, 1, h->lsm,
-                                                 ir, nullptr, alloc_only, h->trace_X, nullptr));
+                                                 ir, nullptr, alloc_only, h->trace_X, nullptr,
+                                                 rode ? h->post_ride_nwg : 0, h->post_ride_jl, h->post_ride_par));
         if (rc) return rc;
     }
     if (alloc_only)     // (the directed loops' records: likelihood | centring | radii proposal)

@@ -42,9 +42,21 @@ template <int DD>
 int enqueue_hdp_iteration(dlsm_chain *h, int it, bool draw_next) {
     const IterRef ir{(uint32_t)it, nullptr};
     const int T = h->T, K = h->K, N = h->N;
-    int rc = enqueue_sweep(h, ir, h->hdp_cfg.sweep_algo); if (rc) return rc;
+    // (the centring sums ride in the pipelined sweep's last launch when there is one)
+    h->post_ride_want = h->model == DLSM_UNDIRECTED &&
+                        !(getenv("DLSM_POST_RIDE") && atoi(getenv("DLSM_POST_RIDE")) == 0);
+    h->post_ride_done = false; h->post_ride_xref = nullptr;
+    int rc = DLSM_OK;
+    if (h->post_ride_want) { rc = ensure_partials(h, (size_t)ll_blocks(h) * 4 + (size_t)PS_BLOCKS * 26); if (rc) return rc; }
+    rc = enqueue_sweep(h, ir, h->hdp_cfg.sweep_algo);
+    h->post_ride_want = false;
+    if (rc) return rc;
+    const bool rode = h->post_ride_done;
+    h->post_ride_done = false;
     // centring; workgroup 0 draws the intercept proposal; the positions' trace row
-    rc = launch_post<DD>(h, nullptr, 0, 1, h->lsm, ir, nullptr, false, h->trace_X); if (rc) return rc;
+    rc = launch_post<DD>(h, nullptr, 0, 1, h->lsm, ir, nullptr, false, h->trace_X, nullptr,
+                         rode ? h->post_ride_nwg : 0, h->post_ride_jl, h->post_ride_par);
+    if (rc) return rc;
     // The label block update needs the centred positions and last iteration's mixture, not the
     // intercept's likelihood records (33 us at config 3), and those do not need the labels: with
     // DLSM_HDP_QUEUES=2 the labels go to a second queue beside them.  Opt-in: on MI355X the two

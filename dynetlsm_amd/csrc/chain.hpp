@@ -133,6 +133,11 @@ struct dlsm_chain {
     double *pipe = nullptr; size_t pipe_cap = 0;        // pipelined sweep (algo 4) buffers
     // the proposal buffers of the sweep enqueued last (valid for a pipelined sweep only) and the
     // iteration whose proposals the previous iteration's last launch has already drawn into them
+    // the centring sums riding in the pipelined sweep's last launch (k_pipe_last_ride): asked for by
+    // the undirected loops before they enqueue the sweep, granted (done) by launch_sweep_pipe
+    bool post_ride_want = false, post_ride_done = false;
+    const double *post_ride_xref = nullptr;
+    int post_ride_jl = -1, post_ride_par = 0, post_ride_nwg = 0;
     dlsm::ProposeBuf next_prop{}; bool next_prop_ok = false, pipe_touched = false; long prop_drawn_for = -1;
     int32_t *pipe_err = nullptr; bool pipe_err_armed = false;   // persistent sweep (algo 7): sticky error word
     int n_cu = 256;

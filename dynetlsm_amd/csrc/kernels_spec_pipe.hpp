@@ -1035,4 +1035,34 @@ __global__ __launch_bounds__(PP_THREADS) void k_pipe_step(ChainView c, PipeBuf p
     }
 }
 
+// The sweep's LAST launch only resolves (the last batch of the odd slices; of the even ones when
+// T = 1): a handful of workgroups busy for 9 us and the chip idle - while the centring sums, the next
+// launch, need nothing but the positions that are final already.  Here they ride in that launch as
+// workgroups T ..: every row except the nodes i >= jl of the slices that are still being resolved
+// (and the difference terms that touch them: post_row_own_left / post_row_diff_left); the centring
+// pass adds those rows itself.  The resolver workgroups run exactly what k_pipe_step runs for them.
+struct PipePostRide { const double *xref; IterRef ir; double *rec; int nwg, jl, par; };
+template <int D>
+__global__ __launch_bounds__(PP_THREADS) void k_pipe_last_ride(ChainView c, PipeBuf pb, int l, PipePostRide pr) {
+    extern __shared__ __attribute__((aligned(16))) double pp_sH[];      // 128 x 128
+    __shared__ double sPart[PP_WAVES * 64];
+    __shared__ unsigned long long sMask[2][2];
+    __shared__ int sPrev[3 * PP_B];
+    __shared__ int sOwn[PP_B + 1];
+    __shared__ unsigned char sSat[PP_B];
+    const int T = c.T;
+    if ((int)blockIdx.x < T) {
+        const int t = blockIdx.x;
+        const int b = l - (t & 1);
+        if (b < 0 || b >= pb.nbat) return;
+        pipe_resolve<D, 1>(c, pb, b, t, pp_sH, sPart, sMask, sPrev, sSat, sOwn, false
+#ifdef DLSM_PIPE_TIMING
+                           , l + 1
+#endif
+                           );
+        return;
+    }
+    post_reduce_wg<D, PP_THREADS>(c, pr.xref, -1, pr.ir, pr.rec, (int)blockIdx.x - T, pr.nwg, pr.jl, pr.par);
+}
+
 }  // namespace dlsm

@@ -375,51 +375,73 @@ constexpr int PS_BLOCKS = 64;
 constexpr int PS2_THREADS = 256;
 template <int D> struct PostRec { static constexpr int W = 2 * D + D * D + 2; };
 
+// one row's contributions to the W sums.  own: everything that needs the row itself (sum x, M, the
+// t = 0 sums); diff: the row's |x_t - x_{t-1}|^2 (rows of t >= 1)
 template <int D>
-__device__ __forceinline__ void post_reduce_wg(
-    const ChainView &c, const double *__restrict__ xref_in, int n_iter_procrustes, IterRef ir,
-    double *__restrict__ rec, int wg, int nwg) {
-    // lsm.py:495: rotate only once it > tune + burn (n_iter_procrustes < 0: always)
-    const double *xref = (xref_in && (n_iter_procrustes < 0 ||
-                                      (int)ir.get() > n_iter_procrustes)) ? xref_in : nullptr;
-    constexpr int W = PostRec<D>::W;
-    __shared__ double sRed[2 * (PS2_THREADS / 64)];
-    const int tid = threadIdx.x;
-    const long rows = (long)c.T * c.N;
+__device__ __forceinline__ void post_row_terms(const ChainView &c, const double *__restrict__ xref,
+                                               long r, bool own, bool diff, double (&acc)[PostRec<D>::W]) {
     const double *X = c.X;
-    double acc[W];
+    double x[D];
 #pragma unroll
-    for (int q = 0; q < W; ++q) acc[q] = 0.0;
-    for (long r = (long)wg * PS2_THREADS + tid; r < rows;
-         r += (long)nwg * PS2_THREADS) {
-        double x[D];
+    for (int d = 0; d < D; ++d) x[d] = X[r * D + d];
+    if (own) {
 #pragma unroll
-        for (int d = 0; d < D; ++d) { x[d] = X[r * D + d]; acc[d] += x[d]; }
+        for (int d = 0; d < D; ++d) acc[d] += x[d];
         if (xref) {
 #pragma unroll
             for (int a = 0; a < D; ++a)
 #pragma unroll
                 for (int b = 0; b < D; ++b) acc[D + a * D + b] += x[a] * xref[r * D + b];
         }
-        if (r < c.N) {
+    }
+    if (r < c.N) {
+        if (own) {
             double q = 0.0;
 #pragma unroll
             for (int d = 0; d < D; ++d) { acc[D + D * D + d] += x[d]; q += x[d] * x[d]; }
             acc[2 * D + D * D] += q;
-        } else {
-            double q = 0.0;
-#pragma unroll
-            for (int d = 0; d < D; ++d) {
-                const double df = x[d] - X[(r - c.N) * D + d];
-                q += df * df;
-            }
-            acc[2 * D + D * D + 1] += q;
         }
+    } else if (diff) {
+        double q = 0.0;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const double df = x[d] - X[(r - c.N) * D + d];
+            q += df * df;
+        }
+        acc[2 * D + D * D + 1] += q;
+    }
+}
+
+// Rows a pass over "what is final" leaves to the centring pass (k_pipe_last_ride: the sums ride in the
+// sweep's last launch, which still moves the nodes i >= jl of the slices of parity `par`): such a
+// row's own terms, and the difference terms of every row i >= jl of t >= 1 (one of t, t - 1 has that
+// parity).  jl < 0: nothing is left out.
+__device__ __forceinline__ bool post_row_own_left(int t, int i, int jl, int par) {
+    return jl >= 0 && i >= jl && (t & 1) == par;
+}
+__device__ __forceinline__ bool post_row_diff_left(int t, int i, int jl) { return jl >= 0 && i >= jl && t >= 1; }
+
+template <int D, int NT = PS2_THREADS>
+__device__ __forceinline__ void post_reduce_wg(
+    const ChainView &c, const double *__restrict__ xref_in, int n_iter_procrustes, IterRef ir,
+    double *__restrict__ rec, int wg, int nwg, int jl = -1, int par = 0) {
+    // lsm.py:495: rotate only once it > tune + burn (n_iter_procrustes < 0: always)
+    const double *xref = (xref_in && (n_iter_procrustes < 0 ||
+                                      (int)ir.get() > n_iter_procrustes)) ? xref_in : nullptr;
+    constexpr int W = PostRec<D>::W;
+    __shared__ double sRed[2 * (NT / 64)];
+    const int tid = threadIdx.x;
+    const long rows = (long)c.T * c.N;
+    double acc[W];
+#pragma unroll
+    for (int q = 0; q < W; ++q) acc[q] = 0.0;
+    for (long r = (long)wg * NT + tid; r < rows; r += (long)nwg * NT) {
+        const int t = (int)(r / c.N), i = (int)(r - (long)t * c.N);
+        post_row_terms<D>(c, xref, r, !post_row_own_left(t, i, jl, par), !post_row_diff_left(t, i, jl), acc);
     }
 #pragma unroll
     for (int q = 0; q < W; ++q) {
-        const double v = block_sum_all<PS2_THREADS / 64>(
-            acc[q], sRed + (q & 1) * (PS2_THREADS / 64), tid);
+        const double v = block_sum_all<NT / 64>(acc[q], sRed + (q & 1) * (NT / 64), tid);
         if (tid == 0) rec[(size_t)wg * W + q] = v;
     }
 }
@@ -458,7 +480,7 @@ __device__ __forceinline__ void post_apply_wg(
     const ChainView &c, int has_ref, int n_iter_procrustes, int do_center,
     const double *__restrict__ rec, int nrec, LsmDeviceState *lsm, IterRef ir,
     double *__restrict__ R_out, double *__restrict__ trace_X, double *__restrict__ xr, int xr_keep_alt,
-    int wg, int nwg) {
+    int wg, int nwg, int jl = -1, int par = 0, const double *__restrict__ xref_rows = nullptr) {
     const uint32_t iter = ir.get();
     const int rotate = has_ref && (n_iter_procrustes < 0 || (int)iter > n_iter_procrustes);
     constexpr int W = PostRec<D>::W;
@@ -476,6 +498,34 @@ __device__ __forceinline__ void post_apply_wg(
         double s = 0.0;
         for (int b = 0; b < nrec; ++b) s += sRec[b * W + tid];
         sSum[tid] = s;
+    }
+    if (jl >= 0) {
+        // the rows the riding sums left out (see post_row_own_left): T (N - jl) candidates, every
+        // workgroup adds them itself, in the same order
+        __shared__ double sRedL[W][PS2_THREADS / 64];
+        const double *xref_l = rotate ? xref_rows : nullptr;
+        double acc[W];
+#pragma unroll
+        for (int q = 0; q < W; ++q) acc[q] = 0.0;
+        const int nl = c.N - jl;
+        for (int q = tid; q < c.T * nl; q += PS2_THREADS) {
+            const int t = q / nl, i = jl + (q - t * nl);
+            post_row_terms<D>(c, xref_l, (long)t * c.N + i, post_row_own_left(t, i, jl, par),
+                              post_row_diff_left(t, i, jl), acc);
+        }
+        // one barrier for the W sums (a barrier per sum was a microsecond of the launch)
+#pragma unroll
+        for (int q = 0; q < W; ++q) {
+            const double v = wave_sum_all(acc[q]);
+            if ((tid & 63) == 0) sRedL[q][tid >> 6] = v;
+        }
+        __syncthreads();
+        if (tid < W) {                              // thread q wrote sSum[q] above
+            double v = 0.0;
+#pragma unroll
+            for (int w = 0; w < PS2_THREADS / 64; ++w) v += sRedL[tid][w];
+            sSum[tid] += v;
+        }
     }
     __syncthreads();
     if (tid == 0) {
@@ -575,9 +625,10 @@ template <int D>
 __global__ __launch_bounds__(PS2_THREADS) void k_post_apply(
     ChainView c, int has_ref, int n_iter_procrustes, int do_center,
     const double *__restrict__ rec, int nrec, LsmDeviceState *lsm, IterRef ir,
-    double *__restrict__ R_out, double *__restrict__ trace_X, double *__restrict__ xr = nullptr) {
+    double *__restrict__ R_out, double *__restrict__ trace_X, double *__restrict__ xr = nullptr,
+    int jl = -1, int par = 0, const double *__restrict__ xref_rows = nullptr) {
     post_apply_wg<D>(c, has_ref, n_iter_procrustes, do_center, rec, nrec, lsm, ir, R_out, trace_X, xr, 0,
-                     (int)blockIdx.x, (int)gridDim.x);
+                     (int)blockIdx.x, (int)gridDim.x, jl, par, xref_rows);
 }
 
 

@@ -756,6 +756,35 @@ def test_lsm_device_loop_proposals_drawn_by_the_previous_iteration(eng, algo, mo
     assert not np.array_equal(out['1'][0][9], out['1'][0][5])
 
 
+@pytest.mark.parametrize('T,N', [(4, 600), (1, 700), (3, 1500)])
+def test_lsm_device_loop_centring_sums_riding_in_the_last_sweep_launch(eng, T, N, monkeypatch):
+    """behind a pipelined sweep the centring sums ride in the sweep's last, resolve-only launch
+    (k_pipe_last_ride) for every row that is final by then; the centring pass adds the rows the launch
+    is still moving (the last batch of the odd slices - of the even one when T = 1 - and the
+    difference terms that touch them).  DLSM_POST_RIDE=0: the sums as a launch of their own.  Same
+    sums in another order: the same chain to rounding, with the Procrustes rotation switching on at
+    iteration 4 and across two calls"""
+    X, _, Y, _ = _rand_net(35, T, N, scale=0.05)
+    out = {}
+    for mode in ('0', '1'):
+        monkeypatch.setenv('DLSM_POST_RIDE', mode)
+        gg = eng.SamplerGrid(T, N, 0.1, tune=6, tune_interval=2)
+        with eng.Chain(T, N, 2, 'undirected', seed=31, chain_id=2) as c:
+            c.upload_network(Y); c.set_positions(X); c.set_intercepts([0.2])
+            c.set_prior_random_walk(2.0, 0.1); c.set_samplers(gg)
+            c.lsm_configure([0.2], 2.0, step_size_intercept=0.1, tune=6, tune_interval=3,
+                            n_iter_procrustes=3, sweep_algo=4)
+            c.trace_alloc(10)
+            c.lsm_run(1, 3)
+            c.lsm_run(4, 6, procrustes_ref=2)
+            out[mode] = c.trace_read(0, 10)
+    assert np.isfinite(out['1'][0]).all() and np.isfinite(out['1'][2]).all()
+    np.testing.assert_allclose(out['1'][0], out['0'][0], atol=1e-9)
+    np.testing.assert_allclose(out['1'][1], out['0'][1], atol=1e-12)
+    np.testing.assert_allclose(out['1'][2], out['0'][2], rtol=1e-11)
+    assert np.abs(out['1'][0][9].mean(axis=(0, 1))).max() < 1e-12      # centred
+
+
 def test_lsm_device_loop_graph_replay_equals_eager(eng, monks, monkeypatch):
     """DLSM_GRAPH=1: the captured iteration (device-side iteration counter, rotation
     decided in-kernel) replays to the same trace as eager launches, including across
