@@ -375,26 +375,24 @@ constexpr int PS_BLOCKS = 64;
 constexpr int PS2_THREADS = 256;
 template <int D> struct PostRec { static constexpr int W = 2 * D + D * D + 2; };
 
-// one row's contributions to the W sums.  own: everything that needs the row itself (sum x, M, the
-// t = 0 sums); diff: the row's |x_t - x_{t-1}|^2 (rows of t >= 1)
+// one row's contributions to the W sums from its operands (x, the row of the slice before, the
+// reference's row).  own: everything that needs the row itself (sum x, M, the t = 0 sums); diff: the
+// row's |x_t - x_{t-1}|^2 (rows of t >= 1)
 template <int D>
-__device__ __forceinline__ void post_row_terms(const ChainView &c, const double *__restrict__ xref,
-                                               long r, bool own, bool diff, double (&acc)[PostRec<D>::W]) {
-    const double *X = c.X;
-    double x[D];
-#pragma unroll
-    for (int d = 0; d < D; ++d) x[d] = X[r * D + d];
+__device__ __forceinline__ void post_row_accumulate(const double (&x)[D], const double (&xp)[D],
+                                                    const double (&xr)[D], bool t0, bool own, bool diff,
+                                                    bool has_ref, double (&acc)[PostRec<D>::W]) {
     if (own) {
 #pragma unroll
         for (int d = 0; d < D; ++d) acc[d] += x[d];
-        if (xref) {
+        if (has_ref) {
 #pragma unroll
             for (int a = 0; a < D; ++a)
 #pragma unroll
-                for (int b = 0; b < D; ++b) acc[D + a * D + b] += x[a] * xref[r * D + b];
+                for (int b = 0; b < D; ++b) acc[D + a * D + b] += x[a] * xr[b];
         }
     }
-    if (r < c.N) {
+    if (t0) {
         if (own) {
             double q = 0.0;
 #pragma unroll
@@ -405,11 +403,30 @@ __device__ __forceinline__ void post_row_terms(const ChainView &c, const double 
         double q = 0.0;
 #pragma unroll
         for (int d = 0; d < D; ++d) {
-            const double df = x[d] - X[(r - c.N) * D + d];
+            const double df = x[d] - xp[d];
             q += df * df;
         }
         acc[2 * D + D * D + 1] += q;
     }
+}
+template <int D>
+__device__ __forceinline__ void post_row_load(const ChainView &c, const double *__restrict__ xref, long r,
+                                              bool own, bool diff, double (&x)[D], double (&xp)[D],
+                                              double (&xr)[D]) {
+    const double *X = c.X;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        x[d] = X[r * D + d];
+        xp[d] = r >= c.N && diff ? X[(r - c.N) * D + d] : 0.0;
+        xr[d] = own && xref ? xref[r * D + d] : 0.0;
+    }
+}
+template <int D>
+__device__ __forceinline__ void post_row_terms(const ChainView &c, const double *__restrict__ xref,
+                                               long r, bool own, bool diff, double (&acc)[PostRec<D>::W]) {
+    double x[D], xp[D], xr[D];
+    post_row_load<D>(c, xref, r, own, diff, x, xp, xr);
+    post_row_accumulate<D>(x, xp, xr, r < c.N, own, diff, xref != nullptr, acc);
 }
 
 // Rows a pass over "what is final" leaves to the centring pass (k_pipe_last_ride: the sums ride in the
@@ -508,10 +525,24 @@ __device__ __forceinline__ void post_apply_wg(
 #pragma unroll
         for (int q = 0; q < W; ++q) acc[q] = 0.0;
         const int nl = c.N - jl;
-        for (int q = tid; q < c.T * nl; q += PS2_THREADS) {
-            const int t = q / nl, i = jl + (q - t * nl);
-            post_row_terms<D>(c, xref_l, (long)t * c.N + i, post_row_own_left(t, i, jl, par),
-                              post_row_diff_left(t, i, jl), acc);
+        constexpr int LU = 4;               // rows per thread requested together
+        for (int q0 = tid; q0 < c.T * nl; q0 += LU * PS2_THREADS) {
+            double x[LU][D], xp[LU][D], xr[LU][D];
+            long rr[LU];
+            bool own[LU], df[LU];
+#pragma unroll
+            for (int u = 0; u < LU; ++u) {
+                const int q = min(q0 + u * PS2_THREADS, c.T * nl - 1);
+                const int t = q / nl, i = jl + (q - t * nl);
+                const bool val = q0 + u * PS2_THREADS < c.T * nl;
+                rr[u] = (long)t * c.N + i;
+                own[u] = val && post_row_own_left(t, i, jl, par);
+                df[u] = val && post_row_diff_left(t, i, jl);
+                post_row_load<D>(c, xref_l, rr[u], own[u], df[u], x[u], xp[u], xr[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < LU; ++u)
+                post_row_accumulate<D>(x[u], xp[u], xr[u], rr[u] < c.N, own[u], df[u], xref_l != nullptr, acc);
         }
         // one barrier for the W sums (a barrier per sum was a microsecond of the launch)
 #pragma unroll
