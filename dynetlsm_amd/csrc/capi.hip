@@ -1034,6 +1034,7 @@ static int launch_sweep_pipe(dlsm_chain *h, IterRef iter, bool alloc_only = fals
     pb.consts = pb.Hx + n_hx + n_acc;
     pb.sync = persist ? (int32_t *)(pb.consts + 2) : nullptr;
     pb.nsync = n_sync; pb.queue0 = ne_wg;
+    pb.lsm_draw = h->loop_draws_intercept ? h->lsm : nullptr;
     pb.parts = parts; pb.nbat = nbat;
     pb.G = G; pb.xr = xr;
     pb.per = ((N + parts - 1) / parts + 63) / 64 * 64;      // parts start on a 64-neighbour boundary
@@ -1076,10 +1077,10 @@ static int launch_sweep_pipe(dlsm_chain *h, IterRef iter, bool alloc_only = fals
     if (alloc_only) return DLSM_OK;
     ChainView v = h->view();
     {   // the proposal pass, unless the previous iteration's last launch carried it
-        const ProposeBuf nb{pb.prop, pb.consts, pb.sync, pb.nsync, pb.queue0};
+        const ProposeBuf nb{pb.prop, pb.consts, pb.sync, pb.nsync, pb.queue0, pb.lsm_draw};
         const bool drawn = !iter.ptr && h->prop_drawn_for == (long)iter.value && h->next_prop_ok &&
                            h->next_prop.prop == nb.prop && h->next_prop.sync == nb.sync &&
-                           h->next_prop.queue0 == nb.queue0;
+                           h->next_prop.queue0 == nb.queue0 && h->next_prop.lsm_draw == nb.lsm_draw;
         if (!drawn)
             hipLaunchKernelGGL((k_pipe_propose<DD>), dim3((N + 255) / 256, T), dim3(256), 0, h->stream, v,
                                pb, iter);
@@ -1173,7 +1174,7 @@ static int launch_sweep_ccpipe(dlsm_chain *h, IterRef iter, bool alloc_only = fa
     pp.prop = pb.prop; pp.consts = consts;
     ChainView v = h->view();
     {   // the proposal pass, unless the previous iteration's last launch carried it
-        const ProposeBuf nb{pp.prop, pp.consts, nullptr, 0, 0};
+        const ProposeBuf nb{pp.prop, pp.consts, nullptr, 0, 0, nullptr};
         const bool drawn = !iter.ptr && h->prop_drawn_for == (long)iter.value && h->next_prop_ok &&
                            h->next_prop.prop == nb.prop && h->next_prop.sync == nullptr;
         if (!drawn)
@@ -1605,11 +1606,33 @@ static int enqueue_lsm_iteration(dlsm_chain *h, int it, bool counter, int procru
         const int nip = h->lsm_cfg.n_iter_procrustes;
         h->post_ride_xref = (xref && (nip < 0 || it > nip)) ? xref : nullptr;
     }
+    h->loop_draws_intercept = h->post_ride_want;     // the proposal pass also draws the intercept proposal
     rc = enqueue_sweep(h, ir, h->lsm_cfg.sweep_algo, alloc_only);
-    h->post_ride_want = false;
+    h->post_ride_want = false; h->loop_draws_intercept = false;
     if (rc) return rc;
     const bool rode = h->post_ride_done;
     h->post_ride_done = false;
+    if (rode && draw_next && h->next_prop_ok && h->next_prop.lsm_draw &&
+        !(getenv("DLSM_POST_FUSE") && atoi(getenv("DLSM_POST_FUSE")) == 0)) {
+        // The likelihood pass on the positions as the sweep left them (distances do not change under
+        // the centring pass's rotation and shift; its intercept proposal came with the sweep's
+        // proposals), then ONE launch for the rest of the iteration: centring, accept / reject, trace
+        // row, the next sweep's proposal pass (k_lsm_finalize_apply_propose).
+        int nrec_f = 0;
+        rc = loglik_records(h, 2, h->lsm->cand, nullptr, nullptr, &nrec_f); if (rc) return rc;
+        ProfScope ps(h, DLSM_K_FINALIZE);
+        ChainView v = h->view();
+        const PostFusedArgs pa{xref ? 1 : 0, h->lsm_cfg.n_iter_procrustes,
+                               h->partials + (size_t)ll_blocks(h) * 4, h->post_ride_nwg, h->post_ride_jl,
+                               h->post_ride_par, xref, h->trace_X};
+        DISPATCH_D(h, h->D, hipLaunchKernelGGL((k_lsm_finalize_apply_propose<DD>),
+                                               dim3(1 + propose_blocks(h->T, h->N)), dim3(256), 0, h->stream,
+                                               h->partials, nrec_f, h->lsm, h->intercept, h->trace_ic,
+                                               h->trace_logp, ir, v, h->next_prop, pa));
+        h->prop_drawn_for = (long)it + 1;
+        HIPCHK(h, hipGetLastError());
+        return DLSM_OK;
+    }
     // case-control: the centring pass also writes the log-likelihood's gather records
     const bool pf = cc_prefetch_form(h);
     if (pf) { DISPATCH_D(h, h->D, rc = ensure_xr<DD>(h)); if (rc) return rc; }

@@ -37,9 +37,11 @@ struct ChainView {
 
 // What the proposal pass of the pipelined sweeps writes (kernels_spec_pipe.hpp): the iteration's
 // last launch can carry the next sweep's pass (kernels_tail_propose.hpp)
+struct LsmDeviceState;
 struct ProposeBuf {
     double *prop, *consts;
     int32_t *sync; int nsync, queue0;
+    LsmDeviceState *lsm_draw;   // not NULL: the pass also draws the undirected loop's intercept proposal
 };
 
 // intercept sampler + LSM bookkeeping that lives on the device
@@ -136,6 +138,7 @@ struct dlsm_chain {
     // the centring sums riding in the pipelined sweep's last launch (k_pipe_last_ride): asked for by
     // the undirected loops before they enqueue the sweep, granted (done) by launch_sweep_pipe
     bool post_ride_want = false, post_ride_done = false;
+    bool loop_draws_intercept = false;      // set by the undirected LSM loop around its sweep
     const double *post_ride_xref = nullptr;
     int post_ride_jl = -1, post_ride_par = 0, post_ride_nwg = 0;
     dlsm::ProposeBuf next_prop{}; bool next_prop_ok = false, pipe_touched = false; long prop_drawn_for = -1;

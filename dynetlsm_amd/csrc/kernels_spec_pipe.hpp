@@ -63,6 +63,7 @@ struct PipeBuf {
     // persistent form (kernels_pipe_persist.hpp): nsync flag words, one per 64-byte line, zeroed
     // by the propose kernel; word 0 (the ticket counter) starts at queue0
     int32_t *sync; int nsync, queue0;
+    LsmDeviceState *lsm_draw;   // not NULL: the proposal pass also draws the intercept proposal
 };
 // first batch of the window of batch b
 __host__ __device__ __forceinline__ int pipe_window_start(int b, int G) {
@@ -78,6 +79,42 @@ __device__ __forceinline__ void pipe_propose_consts(const ChainView &c, double *
     const double E = c.model == DLSM_UNDIRECTED ? exp(intercept[0]) : exp(intercept[0] + intercept[1]);
     consts[0] = E;
     consts[1] = (double)flush_interval(E);
+}
+
+// The undirected loop's intercept proposal and the log-uniform of its accept test
+// (sample_coefficients.py:76-86; Philox stream INTERCEPT, counters (0, 0 | 1, iter)) - what the
+// centring pass draws (k_post_apply), from the same counters and the same intercept and step size,
+// which are settled when the previous iteration ends: drawn with the sweep's proposals, the
+// likelihood pass can run before the centring pass (kernels_tail_propose.hpp).
+__device__ __forceinline__ void pipe_propose_intercept(const ChainView &c, LsmDeviceState *lsm,
+                                                       const double *intercept, uint32_t iter) {
+    double u0, u1, z0, z1;
+    philox_uniform2(c.seed, 0, 0, iter, stream_word(c.chain, STREAM_INTERCEPT), u0, u1);
+    box_muller(u0, u1, z0, z1);
+    const double b0 = intercept[0];
+    lsm->cand[0] = b0;
+    lsm->cand[1] = b0 + lsm->i_step[0] * z0;
+    philox_uniform2(c.seed, 0, 1, iter, stream_word(c.chain, STREAM_INTERCEPT), u0, u1);
+    lsm->logu = log(u0);
+}
+
+// the proposal of node (t, j) from its position x0
+template <int D>
+__device__ __forceinline__ void pipe_propose_row_from(const ChainView &c, const ProposeBuf &pb, uint32_t iter,
+                                                      int t, int j, const double (&x0)[D]) {
+    const int N = c.N;
+    double x1[D], logu;
+    make_proposal<D>(c, iter, t, j, x0, c.step[(size_t)t * N + j], x1, logu);
+    double *pr = pb.prop + ((size_t)t * N + j) * (2 * D + 2);
+#pragma unroll
+    for (int d = 0; d < D; ++d) { pr[d] = x1[d]; pr[D + 2 + d] = x0[d]; }
+    {   // the uniform itself (same draw as make_proposal's log u)
+        double u0, u1;
+        philox_uniform2(c.seed, (uint32_t)j, (uint32_t)t, iter,
+                        stream_word(c.chain, STREAM_SWEEP_UNIFORM), u0, u1);
+        pr[D] = u0;
+    }
+    pr[D + 1] = 0.0;
 }
 
 // workgroup `fb` of ceil(N / 256) T, 256 threads
@@ -112,8 +149,11 @@ __device__ __forceinline__ void pipe_propose_rows(const ChainView &c, const Prop
 template <int D>
 __global__ __launch_bounds__(256) void k_pipe_propose(ChainView c, PipeBuf pb, IterRef ir) {
     const int fb = (int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x;
-    if (fb == 0 && threadIdx.x == 0) pipe_propose_consts(c, pb.consts, c.intercept);
-    const ProposeBuf nb{pb.prop, pb.consts, pb.sync, pb.nsync, pb.queue0};
+    if (fb == 0 && threadIdx.x == 0) {
+        pipe_propose_consts(c, pb.consts, c.intercept);
+        if (pb.lsm_draw) pipe_propose_intercept(c, pb.lsm_draw, c.intercept, ir.get());
+    }
+    const ProposeBuf nb{pb.prop, pb.consts, pb.sync, pb.nsync, pb.queue0, pb.lsm_draw};
     pipe_propose_rows<D>(c, nb, ir.get(), fb, (int)threadIdx.x);
 }
 

@@ -492,12 +492,17 @@ __device__ __forceinline__ void dir_propose_intercept(const ChainView &c, LsmDev
 // x <- x R - mean R to its rows.  Workgroup 0 also leaves the LSM bookkeeping.
 // xr_keep_alt: leave the records' second radius slot alone (the radii proposal, riding in the same
 // launch, files itself there)
-template <int D>
+struct PostNoHook { __device__ __forceinline__ void operator()(long, const double *) const {} };
+// hook(r, y): called with every row this workgroup has just centred (the fused last launch of the
+// undirected loop draws the next sweep's proposal from it); do_rows = false: the sums, R, the
+// shift and workgroup 0's bookkeeping only; draw_intercept = 0: the intercept proposal is not drawn
+template <int D, class RowHook = PostNoHook>
 __device__ __forceinline__ void post_apply_wg(
     const ChainView &c, int has_ref, int n_iter_procrustes, int do_center,
     const double *__restrict__ rec, int nrec, LsmDeviceState *lsm, IterRef ir,
     double *__restrict__ R_out, double *__restrict__ trace_X, double *__restrict__ xr, int xr_keep_alt,
-    int wg, int nwg, int jl = -1, int par = 0, const double *__restrict__ xref_rows = nullptr) {
+    int wg, int nwg, int jl = -1, int par = 0, const double *__restrict__ xref_rows = nullptr,
+    bool do_rows = true, int draw_intercept = 1, RowHook hook = RowHook()) {
     const uint32_t iter = ir.get();
     const int rotate = has_ref && (n_iter_procrustes < 0 || (int)iter > n_iter_procrustes);
     constexpr int W = PostRec<D>::W;
@@ -591,7 +596,9 @@ __device__ __forceinline__ void post_apply_wg(
                 q0 = q0 - 2.0 * ms + (double)c.N * mm;
                 lsm->prior_x = -(0.5 * q0 / c.tau_sq +
                                  0.5 * sSum[2 * D + D * D + 1] / c.sigma_sq);
-                if (c.model != DLSM_UNDIRECTED) {
+                if (!draw_intercept) {
+                    // (drawn with the sweep's proposals: pipe_propose_intercept)
+                } else if (c.model != DLSM_UNDIRECTED) {
                     // the first of the two intercept steps of the directed loops
                     dir_propose_intercept(c, lsm, c.intercept, 0, iter);
                 } else {
@@ -610,7 +617,7 @@ __device__ __forceinline__ void post_apply_wg(
         }
     }
     __syncthreads();
-    if (!rotate && !do_center && !trace_X && !xr) return;
+    if (!do_rows || (!rotate && !do_center && !trace_X && !xr)) return;
     // the device-resident loop also files the final positions as row `iter` of its trace
     double *trow = trace_X ? trace_X + (size_t)iter * rows * D : nullptr;
     for (long r = (long)wg * PS2_THREADS + tid; r < rows;
@@ -631,6 +638,7 @@ __device__ __forceinline__ void post_apply_wg(
 #pragma unroll
             for (int b = 0; b < D; ++b) trow[r * D + b] = y[b];
         }
+        hook(r, y);
         if (xr) {       // the case-control log-likelihood's gather records (k_pack_xr's): [x | r | r]
             constexpr int RW = llcc_record_width(D);
             double rc[RW];

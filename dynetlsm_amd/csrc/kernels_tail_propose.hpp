@@ -22,10 +22,57 @@ __global__ __launch_bounds__(256) void k_lsm_finalize_propose(
     double *__restrict__ trace_logp, IterRef ir, ChainView c, ProposeBuf nb) {
     if (blockIdx.x == 0) {
         lsm_finalize_wg(partials, nrec, lsm, intercept, trace_ic, trace_logp, ir);
-        if (threadIdx.x == 0) pipe_propose_consts(c, nb.consts, intercept);     // its own store above
+        if (threadIdx.x == 0) {                 // behind its own stores above
+            pipe_propose_consts(c, nb.consts, intercept);
+            if (nb.lsm_draw) pipe_propose_intercept(c, nb.lsm_draw, intercept, ir.get() + 1u);
+        }
         return;
     }
     pipe_propose_rows<D>(c, nb, ir.get() + 1u, (int)blockIdx.x - 1, (int)threadIdx.x);
+}
+
+// The undirected LSM loop's last TWO launches in one.  Distances do not change under the rotation
+// and the shift of the centring pass, so the likelihood pass can read the positions as the sweep
+// left them (its intercept proposal was drawn with the sweep's proposals), and what is left - centre
+// and rotate the positions, the intercept's accept / reject, the trace row, the next sweep's
+// proposal pass - needs one launch: every workgroup redoes the centring pass's prologue (the riding
+// sums' records + the rows they left out -> R, shift); workgroup 0 takes the latent prior terms from
+// it and finishes the iteration; workgroup 1 + w centres its rows (a node per thread), files them in
+// X and in the trace, and draws the node's proposal for the next sweep from the centred row.
+struct PostFusedArgs {
+    int has_ref, n_iter_procrustes;
+    const double *rec; int nrec, jl, par;
+    const double *xref_rows;
+    double *trace_X;
+};
+static_assert(PS2_THREADS == 256, "the proposal pass is laid out for 256 threads");
+template <int D>
+__global__ __launch_bounds__(256) void k_lsm_finalize_apply_propose(
+    const double *__restrict__ partials, int nrec, LsmDeviceState *lsm,
+    double *__restrict__ intercept, double *__restrict__ trace_ic,
+    double *__restrict__ trace_logp, IterRef ir, ChainView c, ProposeBuf nb, PostFusedArgs pa) {
+    if (blockIdx.x == 0) {
+        // sums, R, shift and the latent prior terms (lsm->prior_x); no rows, no intercept draw
+        post_apply_wg<D>(c, pa.has_ref, pa.n_iter_procrustes, 1, pa.rec, pa.nrec, lsm, ir, nullptr, nullptr,
+                         nullptr, 0, 0, 1, pa.jl, pa.par, pa.xref_rows, false, 0);
+        lsm_finalize_wg(partials, nrec, lsm, intercept, trace_ic, trace_logp, ir);
+        if (threadIdx.x == 0) {
+            pipe_propose_consts(c, nb.consts, intercept);
+            if (nb.lsm_draw) pipe_propose_intercept(c, nb.lsm_draw, intercept, ir.get() + 1u);
+        }
+        return;
+    }
+    const uint32_t next = ir.get() + 1u;
+    auto hook = [&](long r, const double *y) {
+        const int t = (int)(r / c.N), j = (int)(r - (long)t * c.N);
+        double x0[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) x0[d] = y[d];
+        pipe_propose_row_from<D>(c, nb, next, t, j, x0);
+    };
+    post_apply_wg<D>(c, pa.has_ref, pa.n_iter_procrustes, 1, pa.rec, pa.nrec, nullptr, ir, nullptr, pa.trace_X,
+                     nullptr, 0, (int)blockIdx.x - 1, (int)gridDim.x - 1, pa.jl, pa.par, pa.xref_rows, true, 0,
+                     hook);
 }
 
 static_assert(HH_THREADS == 256, "the proposal pass is laid out for 256 threads");
@@ -35,7 +82,7 @@ __global__ __launch_bounds__(HH_THREADS) void k_hdp_hypers_propose(ChainView c, 
                                                                    IterRef ir, ProposeBuf nb) {
     if (blockIdx.x == 0) {
         // the intercept of the next sweep was settled in stage 1
-        if (threadIdx.x == 0) pipe_propose_consts(c, nb.consts, c.intercept);
+        if (threadIdx.x == 0) pipe_propose_consts(c, nb.consts, c.intercept);   // (nb.lsm_draw is NULL here)
         hdp_hypers_wg(c, hb, hs, tr, ir);
         return;
     }

@@ -738,6 +738,9 @@ def test_lsm_device_loop_proposals_drawn_by_the_previous_iteration(eng, algo, mo
     X, _, Y, _ = _rand_net(33, 4, 600, scale=0.05)
     T, N = Y.shape[:2]
     out = {}
+    # (without the fused last launch, whose likelihood pass reads the positions before they are
+    # centred: equal to rounding only - test_lsm_device_loop_centring_sums_riding_... covers it)
+    monkeypatch.setenv('DLSM_POST_FUSE', '0')
     for mode in ('0', '1'):
         monkeypatch.setenv('DLSM_TAIL_PROPOSE', mode)
         gg = eng.SamplerGrid(T, N, 0.1, tune=6, tune_interval=2)
@@ -763,7 +766,9 @@ def test_lsm_device_loop_centring_sums_riding_in_the_last_sweep_launch(eng, T, N
     is still moving (the last batch of the odd slices - of the even one when T = 1 - and the
     difference terms that touch them).  DLSM_POST_RIDE=0: the sums as a launch of their own.  Same
     sums in another order: the same chain to rounding, with the Procrustes rotation switching on at
-    iteration 4 and across two calls"""
+    iteration 4 and across two calls.  With the sums riding, every iteration but a call's last also
+    ends in the fused launch (k_lsm_finalize_apply_propose: likelihood pass on the uncentred
+    positions, then centring + accept / reject + trace row + next proposal pass in one launch)"""
     X, _, Y, _ = _rand_net(35, T, N, scale=0.05)
     out = {}
     for mode in ('0', '1'):
