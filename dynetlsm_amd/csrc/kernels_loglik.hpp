@@ -628,7 +628,21 @@ __device__ __forceinline__ void reduce_records(const double *__restrict__ rec,
         const int nq = min(4, width - q0);
         double s[4] = {0.0, 0.0, 0.0, 0.0};
         if (tid < 256) {
-            for (int r = tid; r < nrec; r += 256)
+            // (four records per thread requested together; they are added in the same order)
+            int r = tid;
+            for (; r + 3 * 256 < nrec; r += 4 * 256) {
+                double v[4][4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        v[u][q] = q < nq ? rec[(size_t)(r + u * 256) * width + q0 + q] : 0.0;
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) if (q < nq) s[q] += v[u][q];
+            }
+            for (; r < nrec; r += 256)
                 for (int q = 0; q < nq; ++q) s[q] += rec[(size_t)r * width + q0 + q];
             for (int q = 0; q < 4; ++q) scratch[q * 256 + tid] = s[q];
         }

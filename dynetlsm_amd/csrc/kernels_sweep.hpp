@@ -566,7 +566,7 @@ __device__ __forceinline__ void post_apply_wg(
     __syncthreads();
     if (tid == 0) {
         double R[D][D];
-        if (rotate) {
+        if (rotate && do_rows) {        // (a workgroup that centres no rows needs the mean only)
             double M[D][D];
             for (int a = 0; a < D; ++a)
                 for (int b = 0; b < D; ++b) M[a][b] = sSum[D + a * D + b];
