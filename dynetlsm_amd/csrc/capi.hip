@@ -1108,15 +1108,16 @@ static int launch_sweep_pipe(dlsm_chain *h, IterRef iter, bool alloc_only = fals
         const int grid = T + (any_eval ? ne_wg : 0);
         const bool lng = pb.per > 64 * pipe_prefetch_trips(DD);
         if (l == last && !any_eval && h->post_ride_want && G == 1 && h->model == DLSM_UNDIRECTED &&
-            !h->profiling && l >= 0) {
-            // the centring sums ride in the resolve-only launch (kernels_spec_pipe.hpp)
+            !h->profiling && l >= 0 && T + 4 <= PS_BLOCKS) {
+            // the centring sums ride in the resolve-only launch (kernels_spec_pipe.hpp): nwg rider
+            // records + one per slice from the resolvers
             const long rows = (long)T * N;
-            const int nwg = (int)std::min<long>(PS_BLOCKS, (rows + PP_THREADS - 1) / PP_THREADS);
+            const int nwg = (int)std::min<long>(PS_BLOCKS - T, (rows + PP_THREADS - 1) / PP_THREADS);
             PipePostRide pr{h->post_ride_xref, iter, h->partials + (size_t)ll_blocks(h) * 4, nwg,
                             (nbat - 1) * PP_B, T > 1 ? 1 : 0};
             hipLaunchKernelGGL((k_pipe_last_ride<DD>), dim3(T + nwg), dim3(PP_THREADS), lds, h->stream, v, pb,
                                l, pr);
-            h->post_ride_done = true; h->post_ride_nwg = nwg; h->post_ride_jl = pr.jl; h->post_ride_par = pr.par;
+            h->post_ride_done = true; h->post_ride_nwg = nwg + T; h->post_ride_jl = pr.jl; h->post_ride_par = pr.par;
             continue;
         }
         if (h->model == DLSM_UNDIRECTED && lng && G == 2)

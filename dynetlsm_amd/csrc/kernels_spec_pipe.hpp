@@ -1079,8 +1079,9 @@ __global__ __launch_bounds__(PP_THREADS) void k_pipe_step(ChainView c, PipeBuf p
 // T = 1): a handful of workgroups busy for 9 us and the chip idle - while the centring sums, the next
 // launch, need nothing but the positions that are final already.  Here they ride in that launch as
 // workgroups T ..: every row except the nodes i >= jl of the slices that are still being resolved
-// (and the difference terms that touch them: post_row_own_left / post_row_diff_left); the centring
-// pass adds those rows itself.  The resolver workgroups run exactly what k_pipe_step runs for them.
+// (and the difference terms that touch them: post_row_own_left / post_row_diff_left), which the
+// resolver workgroups sum themselves once they have settled them (records nwg .. nwg + T - 1).
+// The resolver workgroups run exactly what k_pipe_step runs for them before that.
 struct PipePostRide { const double *xref; IterRef ir; double *rec; int nwg, jl, par; };
 template <int D>
 __global__ __launch_bounds__(PP_THREADS) void k_pipe_last_ride(ChainView c, PipeBuf pb, int l, PipePostRide pr) {
@@ -1092,14 +1093,46 @@ __global__ __launch_bounds__(PP_THREADS) void k_pipe_last_ride(ChainView c, Pipe
     __shared__ unsigned char sSat[PP_B];
     const int T = c.T;
     if ((int)blockIdx.x < T) {
-        const int t = blockIdx.x;
+        // The rows this launch is still moving (nodes i >= jl of this slice) and the difference terms
+        // that touch them are summed HERE, by the workgroup that has just settled them, into record
+        // nwg + t: nobody else may read those rows while the launch runs, and the centring pass may
+        // not read any position at all once its workgroups have begun to rewrite them in place.
+        constexpr int W = PostRec<D>::W;
+        __shared__ double sRedL[W][PP_WAVES];
+        const int t = blockIdx.x, tid = threadIdx.x;
         const int b = l - (t & 1);
-        if (b < 0 || b >= pb.nbat) return;
-        pipe_resolve<D, 1>(c, pb, b, t, pp_sH, sPart, sMask, sPrev, sSat, sOwn, false
+        const bool mine = b >= 0 && b < pb.nbat;
+        if (mine)
+            pipe_resolve<D, 1>(c, pb, b, t, pp_sH, sPart, sMask, sPrev, sSat, sOwn, false
 #ifdef DLSM_PIPE_TIMING
-                           , l + 1
+                               , l + 1
 #endif
-                           );
+                               );
+        __syncthreads();                    // the accepted positions of this workgroup are in memory
+        double acc[W];
+#pragma unroll
+        for (int q = 0; q < W; ++q) acc[q] = 0.0;
+        if (mine && (t & 1) == pr.par) {
+            const int nl = c.N - pr.jl;
+            for (int q = tid; q < 2 * nl; q += PP_THREADS) {
+                const bool nxt = q >= nl;                   // the difference term of the slice behind
+                const int i = pr.jl + (nxt ? q - nl : q), tt = nxt ? t + 1 : t;
+                if (tt >= T) continue;
+                post_row_terms<D>(c, pr.xref, (long)tt * c.N + i, !nxt, tt >= 1, acc);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < W; ++q) {
+            const double v = wave_sum_all(acc[q]);
+            if ((tid & 63) == 0) sRedL[q][tid >> 6] = v;
+        }
+        __syncthreads();
+        if (tid < W) {
+            double v = 0.0;
+#pragma unroll
+            for (int w = 0; w < PP_WAVES; ++w) v += sRedL[tid][w];
+            pr.rec[(size_t)(pr.nwg + t) * W + tid] = v;
+        }
         return;
     }
     post_reduce_wg<D, PP_THREADS>(c, pr.xref, -1, pr.ir, pr.rec, (int)blockIdx.x - T, pr.nwg, pr.jl, pr.par);

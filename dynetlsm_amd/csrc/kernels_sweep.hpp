@@ -429,10 +429,10 @@ __device__ __forceinline__ void post_row_terms(const ChainView &c, const double 
     post_row_accumulate<D>(x, xp, xr, r < c.N, own, diff, xref != nullptr, acc);
 }
 
-// Rows a pass over "what is final" leaves to the centring pass (k_pipe_last_ride: the sums ride in the
-// sweep's last launch, which still moves the nodes i >= jl of the slices of parity `par`): such a
-// row's own terms, and the difference terms of every row i >= jl of t >= 1 (one of t, t - 1 has that
-// parity).  jl < 0: nothing is left out.
+// Rows a pass over "what is final" leaves out (k_pipe_last_ride: the sums ride in the sweep's last
+// launch, which still moves the nodes i >= jl of the slices of parity `par`): such a row's own terms,
+// and the difference terms of every row i >= jl of t >= 1 (one of t, t - 1 has that parity); the
+// launch's resolver workgroups add them.  jl < 0: nothing is left out.
 __device__ __forceinline__ bool post_row_own_left(int t, int i, int jl, int par) {
     return jl >= 0 && i >= jl && (t & 1) == par;
 }
@@ -520,48 +520,6 @@ __device__ __forceinline__ void post_apply_wg(
         double s = 0.0;
         for (int b = 0; b < nrec; ++b) s += sRec[b * W + tid];
         sSum[tid] = s;
-    }
-    if (jl >= 0) {
-        // the rows the riding sums left out (see post_row_own_left): T (N - jl) candidates, every
-        // workgroup adds them itself, in the same order
-        __shared__ double sRedL[W][PS2_THREADS / 64];
-        const double *xref_l = rotate ? xref_rows : nullptr;
-        double acc[W];
-#pragma unroll
-        for (int q = 0; q < W; ++q) acc[q] = 0.0;
-        const int nl = c.N - jl;
-        constexpr int LU = 4;               // rows per thread requested together
-        for (int q0 = tid; q0 < c.T * nl; q0 += LU * PS2_THREADS) {
-            double x[LU][D], xp[LU][D], xr[LU][D];
-            long rr[LU];
-            bool own[LU], df[LU];
-#pragma unroll
-            for (int u = 0; u < LU; ++u) {
-                const int q = min(q0 + u * PS2_THREADS, c.T * nl - 1);
-                const int t = q / nl, i = jl + (q - t * nl);
-                const bool val = q0 + u * PS2_THREADS < c.T * nl;
-                rr[u] = (long)t * c.N + i;
-                own[u] = val && post_row_own_left(t, i, jl, par);
-                df[u] = val && post_row_diff_left(t, i, jl);
-                post_row_load<D>(c, xref_l, rr[u], own[u], df[u], x[u], xp[u], xr[u]);
-            }
-#pragma unroll
-            for (int u = 0; u < LU; ++u)
-                post_row_accumulate<D>(x[u], xp[u], xr[u], rr[u] < c.N, own[u], df[u], xref_l != nullptr, acc);
-        }
-        // one barrier for the W sums (a barrier per sum was a microsecond of the launch)
-#pragma unroll
-        for (int q = 0; q < W; ++q) {
-            const double v = wave_sum_all(acc[q]);
-            if ((tid & 63) == 0) sRedL[q][tid >> 6] = v;
-        }
-        __syncthreads();
-        if (tid < W) {                              // thread q wrote sSum[q] above
-            double v = 0.0;
-#pragma unroll
-            for (int w = 0; w < PS2_THREADS / 64; ++w) v += sRedL[tid][w];
-            sSum[tid] += v;
-        }
     }
     __syncthreads();
     if (tid == 0) {

@@ -762,9 +762,9 @@ def test_lsm_device_loop_proposals_drawn_by_the_previous_iteration(eng, algo, mo
 @pytest.mark.parametrize('T,N', [(4, 600), (1, 700), (3, 1500)])
 def test_lsm_device_loop_centring_sums_riding_in_the_last_sweep_launch(eng, T, N, monkeypatch):
     """behind a pipelined sweep the centring sums ride in the sweep's last, resolve-only launch
-    (k_pipe_last_ride) for every row that is final by then; the centring pass adds the rows the launch
-    is still moving (the last batch of the odd slices - of the even one when T = 1 - and the
-    difference terms that touch them).  DLSM_POST_RIDE=0: the sums as a launch of their own.  Same
+    (k_pipe_last_ride) for every row that is final by then; the resolver workgroups add the rows the
+    launch is still moving (the last batch of the odd slices - of the even one when T = 1 - and the
+    difference terms that touch them) once they have settled them.  DLSM_POST_RIDE=0: the sums as a launch of their own.  Same
     sums in another order: the same chain to rounding, with the Procrustes rotation switching on at
     iteration 4 and across two calls.  With the sums riding, every iteration but a call's last also
     ends in the fused launch (k_lsm_finalize_apply_propose: likelihood pass on the uncentred
