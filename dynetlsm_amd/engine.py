@@ -11,7 +11,21 @@ from . import _lib
 from ._lib import (EngineError, LsmConfig, HdpConfig, c_double_p, c_i32_p, c_i64_p,
                    UNDIRECTED, DIRECTED, DIRECTED_CASE_CONTROL)
 
-__all__ = ['Chain', 'SamplerGrid', 'EngineError']
+__all__ = ['Chain', 'SamplerGrid', 'EngineError', 'MAX_FEATURES', 'check_n_features']
+
+# The kernels take the latent dimension as a template parameter, instantiated for 1..4 (the
+# reference takes any n_features, lsm.py:235,254; its examples and the paper use 2).
+MAX_FEATURES = 4
+
+
+def check_n_features(n_features):
+    """ValueError naming the limit, before any device call (capi.hip's DISPATCH_D would answer
+    DLSM_E_LIMIT from the first kernel launch only)"""
+    d = int(n_features)
+    if d != n_features or not 1 <= d <= MAX_FEATURES:
+        raise ValueError('n_features=%r is not supported by the MI355X engine: its kernels are '
+                         'compiled for 1 <= n_features <= %d latent dimensions' % (n_features, MAX_FEATURES))
+    return d
 
 
 def _f64(a, shape=None, name='array'):
@@ -93,6 +107,7 @@ class Chain(object):
               'case_control': DIRECTED_CASE_CONTROL}
 
     def __init__(self, T, N, D=2, model='undirected', seed=0, chain_id=0, device=0):
+        check_n_features(D)
         self._L = _lib.load()
         self._h = _lib.handle_t()
         self.T, self.N, self.D = int(T), int(N), int(D)

@@ -17,7 +17,7 @@ import time
 
 import numpy as np
 
-from .engine import Chain, SamplerGrid
+from .engine import Chain, SamplerGrid, check_n_features
 from . import hdp_updates as hu
 from . import initialization as init_mod
 from . import posterior as post
@@ -149,7 +149,7 @@ class DynamicNetworkHDPLPCM(FittedQuantities):
     def _init_sampler(self, Y, rng, init):
         """hdp_lpcm.py:48-141 : LSM warm start, longitudinal k-means, weights"""
         T, N, _ = Y.shape
-        K, D = self.n_components, self.n_features
+        K, D = self.n_components, check_n_features(self.n_features)
         if init is not None and 'X' in init:
             X = np.array(init['X'], dtype=np.float64)
             intercept = np.atleast_1d(np.asarray(init['intercept'], dtype=np.float64)).copy()
@@ -226,7 +226,7 @@ class DynamicNetworkHDPLPCM(FittedQuantities):
             raise ValueError('The case-control likelihood currently only '
                              'supported for directed networks.')
         T, N, _ = Y.shape
-        K, D = self.n_components, self.n_features
+        K, D = self.n_components, check_n_features(self.n_features)
         rng = check_random_state(self.random_state)
         self.Y_fit_ = Y
         if self.burn is not None:

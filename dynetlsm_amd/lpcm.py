@@ -14,7 +14,7 @@ import time
 
 import numpy as np
 
-from .engine import Chain, SamplerGrid
+from .engine import Chain, SamplerGrid, check_n_features
 from . import forecast as fc
 from . import hdp_updates as hu
 from . import initialization as init_mod
@@ -104,7 +104,7 @@ class DynamicNetworkLPCM(FittedQuantities):
         distribution, uniform transition matrix; missing dyads are re-imputed by
         thresholding the warm start's edge probabilities (:77-81)"""
         T, N, _ = Y.shape
-        K, D = self.n_components, self.n_features
+        K, D = self.n_components, check_n_features(self.n_features)
         if init is not None and 'X' in init:
             X = np.array(init['X'], dtype=np.float64)
             intercept = np.atleast_1d(np.asarray(init['intercept'], dtype=np.float64)).copy()
@@ -154,7 +154,7 @@ class DynamicNetworkLPCM(FittedQuantities):
             raise ValueError('The case-control likelihood currently only '
                              'supported for directed networks.')
         T, N, _ = Y_raw.shape
-        K, D = self.n_components, self.n_features
+        K, D = self.n_components, check_n_features(self.n_features)
         rng = check_random_state(self.random_state)
         self.nan_mask_, miss = None, None
         Y = Y_raw

@@ -21,7 +21,7 @@ import time
 import numpy as np
 from scipy.special import gammaln, xlogy
 
-from .engine import Chain, SamplerGrid
+from .engine import Chain, SamplerGrid, check_n_features
 from . import initialization as init_mod
 from .imputer import SimpleNetworkImputer
 from .metrics import FittedQuantities
@@ -135,7 +135,7 @@ class DynamicNetworkLSM(FittedQuantities):
         if np.any(Y == -1):          # lsm.py:345-359
             Y = SimpleNetworkImputer(strategy='random', missing_value=-1).fit_transform(Y)
         T, N, _ = Y.shape
-        D = self.n_features
+        D = check_n_features(self.n_features)
         rng = check_random_state(self.random_state)
         self.Y_fit_ = Y
         if self.n_control is not None and not self.is_directed:
