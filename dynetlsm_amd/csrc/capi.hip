@@ -969,10 +969,18 @@ static int check_pipe_err(dlsm_chain *h) {
     if (!h->pipe_err || !h->pipe_err_armed) return DLSM_OK;
     int32_t e = 0;
     HIPCHK(h, hipMemcpy(&e, h->pipe_err, sizeof(e), hipMemcpyDeviceToHost));
-    if (e != 0)
+    if (e != 0) {
+        // reported ONCE: the word is cleared on the handle's own stream (a non-blocking stream
+        // does not order against the null stream) and disarmed, so that a caller who re-uploads
+        // the state and switches to sweep_algo 4 - what the message recommends - can go on with
+        // this handle
+        HIPCHK(h, hipMemsetAsync(h->pipe_err, 0, 64, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        h->pipe_err_armed = false;
         FAIL(h, DLSM_E_HIP, "persistent sweep (algo 7): a wait inside the launch ran out of its poll "
              "budget - the chain's state is undefined (device shared with a long-running kernel?); "
-             "use sweep_algo 4");
+             "set the state again and use sweep_algo 4");
+    }
     return DLSM_OK;
 }
 

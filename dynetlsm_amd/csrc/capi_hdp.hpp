@@ -242,16 +242,15 @@ int dlsm_hdp_trace_alloc(dlsm_chain *h, int n_total, double logp0) {
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipMemcpy(&s, h->hdp, sizeof(s), hipMemcpyDeviceToHost));
     const double hy[6] = {s.gamma, s.alpha_init, s.alpha, s.kappa, s.mvp, s.b};
+    const double nanv = std::nan("");     // (both live until the synchronisation that ends the copies)
     HIPCHK(h, hipMemcpyAsync(h->htr_mu, h->mu, K * D * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->htr_sigma, h->sigma, K * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->htr_beta, hb.beta, K * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->htr_w, h->lab_w, T * K * K * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->htr_lambda, &h->hdp->lmbda, sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->htr_hyper, hy, sizeof(hy), hipMemcpyHostToDevice, h->stream));
-    {   // row 0's network log-likelihood is not known here (NaN: "evaluate it if you need it")
-        const double nanv = std::nan("");
-        HIPCHK(h, hipMemcpyAsync(h->trace_ic + 1, &nanv, sizeof(double), hipMemcpyHostToDevice, h->stream));
-    }
+    // row 0's network log-likelihood is not known here (NaN: "evaluate it if you need it")
+    HIPCHK(h, hipMemcpyAsync(h->trace_ic + 1, &nanv, sizeof(double), hipMemcpyHostToDevice, h->stream));
     const long tn = (long)(T * N);
     hipLaunchKernelGGL(k_hdp_trace_labels, dim3((unsigned)((tn + 255) / 256)), dim3(256), 0, h->stream,
                        h->z, tn, h->htr_z);

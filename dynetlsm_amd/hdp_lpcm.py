@@ -58,7 +58,10 @@ class DynamicNetworkHDPLPCM(FittedQuantities):
     and ``Xs_``, ``zs_``, ``weights_`` and ``cooccurrence_probas_`` are copied to the host when they
     are first read (320 KB per stored sample of positions at T=10, N=2000);
     ``post_processing='host'`` copies the whole trace first and processes it in numpy, as thinning
-    and missing dyads always do."""
+    and missing dyads always do.  Until they are read the four arrays are not in ``vars(model)``:
+    ``materialize()`` reads them all (before copying or pickling the estimator),
+    ``release_device_trace()`` then frees the chain's device memory; a read that fails raises
+    ``AttributeError`` (chained to the engine's error), so ``hasattr`` / ``getattr`` defaults work."""
 
     def __init__(self, n_features=2, n_components=10, is_directed=False,
                  selection_type='vi', n_iter=5000, tune=2500, tune_interval=100,
@@ -306,6 +309,7 @@ class DynamicNetworkHDPLPCM(FittedQuantities):
         # (320 KB per sample at T=10, N=2000), zs_, weights_ - reach the host only when somebody
         # reads them (__getattr__), and the post-loop processing runs where they lie.
         self._lazy_trace = False
+        self._lazy_cooc = False
         for name in ('Xs_', 'zs_', 'weights_', 'cooccurrence_probas_'):
             self.__dict__.pop(name, None)
         if self.loop_kind_ == 'host-driven':
@@ -436,21 +440,56 @@ class DynamicNetworkHDPLPCM(FittedQuantities):
             self._store(it, ll)
 
     # ---- the large arrays of a device-resident trace, on demand --------------------------------
+    _LAZY = ('Xs_', 'zs_', 'weights_', 'cooccurrence_probas_')
+
     def __getattr__(self, name):            # reached only when the attribute is not there
         d = self.__dict__
-        if name in ('Xs_', 'zs_', 'weights_') and d.get('_lazy_trace') and d.get('chain_') is not None:
-            key = {'Xs_': 'Xs', 'zs_': 'zs', 'weights_': 'weights'}[name]
-            tr = d['chain_'].hdp_trace_read(0, d['_n_total'], positions=name == 'Xs_',
-                                            labels=name == 'zs_', weights=name == 'weights_',
-                                            small=False)
-            d[name] = tr[key]
-            return d[name]
-        if name == 'cooccurrence_probas_' and d.get('_lazy_cooc') and d.get('chain_') is not None:
-            d[name] = d['chain_'].post_get_cooccurrence()
-            d['chain_'].post_release()
-            d['_lazy_cooc'] = False
-            return d[name]
+        try:
+            if name in ('Xs_', 'zs_', 'weights_') and d.get('_lazy_trace') and d.get('chain_') is not None:
+                key = {'Xs_': 'Xs', 'zs_': 'zs', 'weights_': 'weights'}[name]
+                tr = d['chain_'].hdp_trace_read(0, d['_n_total'], positions=name == 'Xs_',
+                                                labels=name == 'zs_', weights=name == 'weights_',
+                                                small=False)
+                d[name] = tr[key]
+                return d[name]
+            if name == 'cooccurrence_probas_' and d.get('_lazy_cooc') and d.get('chain_') is not None:
+                d[name] = d['chain_'].post_get_cooccurrence()
+                d['chain_'].post_release()
+                d['_lazy_cooc'] = False
+                return d[name]
+        except Exception as e:              # noqa: BLE001  (a closed handle, a failing copy)
+            # hasattr / getattr(obj, name, default) rely on AttributeError
+            raise AttributeError('%s could not be read from the device-resident trace: %s'
+                                 % (name, e)) from e
         raise AttributeError(name)
+
+    def materialize(self):
+        """Read every array that still lives in the device-resident trace (``Xs_``, ``zs_``,
+        ``weights_``, ``cooccurrence_probas_``: at T=10, N=2000 320 KB per sample and a 320 MB
+        co-occurrence tensor) into the estimator's ``__dict__`` - what ``vars()``, ``copy`` and
+        ``pickle`` see.  The reference holds them as plain attributes (hdp_lpcm.py:795-818); here
+        they are fetched on first access, or all at once by this call.  Returns self."""
+        for name in self._LAZY:
+            if name not in self.__dict__:
+                try:
+                    getattr(self, name)
+                except AttributeError:
+                    pass
+        return self
+
+    def release_device_trace(self, materialize=True):
+        """Free the chain handle - the trace and every other device buffer of this fit (about
+        2 GB per 5000 samples at T=10, N=2000) - after reading the lazy arrays (``materialize=False``
+        drops them instead).  Forecasts and further post-processing on the device are not possible
+        afterwards."""
+        if materialize:
+            self.materialize()
+        self._lazy_trace = False
+        self._lazy_cooc = False
+        ch = self.__dict__.get('chain_')
+        if ch is not None:
+            ch.close()
+        return self
 
     def _finish_on_device(self):
         """``_finish`` for the device-resident loop without thinning or missing dyads: model

@@ -132,17 +132,19 @@ def _kmeans(X_vec, n_clusters, random_state, chain):
     the device: the data are centred and seeded exactly as ``KMeans.fit`` does - ``kmeans_plusplus``
     draws from the caller's RandomState, so the stream ends where the library's would - and
     ``Chain.init_kmeans_lloyd`` runs _kmeans_single_lloyd's loop.  Returns (labels, centers)."""
-    if chain is None:
+    if chain is None or not _sklearn_kmeans_restated():
         from sklearn.cluster import KMeans
         km = KMeans(n_clusters=n_clusters, random_state=random_state).fit(X_vec)
         return km.labels_, km.cluster_centers_
     from .lsm import check_random_state                    # sklearn.utils.check_random_state's rules
     rs = check_random_state(random_state)
     Xc = np.array(X_vec, dtype=np.float64, order='C')
+    # KMeans._check_params_vs_input computes its absolute tolerance from the data BEFORE fit()
+    # subtracts the mean (sklearn/cluster/_kmeans.py: _tolerance): same bits at the stopping test
+    tol = np.mean(np.var(Xc, axis=0)) * 1e-4
     mean = Xc.mean(axis=0)
     Xc -= mean
     seeds = kmeans_plusplus_seeds(Xc, n_clusters, rs)
-    tol = np.mean(np.var(Xc, axis=0)) * 1e-4
     res = chain.init_kmeans_lloyd(Xc, seeds, max_iter=300, tol=tol)
     if res is None:         # a cluster emptied: scikit-learn's relocation rule, on the host
         from sklearn.cluster._kmeans import _kmeans_single_lloyd
@@ -151,6 +153,22 @@ def _kmeans(X_vec, n_clusters, random_state, chain):
     else:
         centers, labels, _ = res
     return labels, centers + mean
+
+
+# scikit-learn releases whose KMeans internals (k-means++ draw order with `choice(p=w)` for the
+# first centre, n_init='auto' = one start, _kmeans_single_lloyd's signature) the restatement above
+# was pinned against (tests/golden/kmeans.npz, tests/test_init_oracle_golden.py); any other release
+# runs the library itself on the host
+_KMEANS_RESTATED_FOR = ((1, 4), (1, 5), (1, 6), (1, 7))
+
+
+def _sklearn_kmeans_restated():
+    try:
+        import sklearn
+        ver = tuple(int(p) for p in sklearn.__version__.split('.')[:2])
+    except Exception:       # noqa: BLE001
+        return False
+    return ver in _KMEANS_RESTATED_FOR
 
 
 def longitudinal_kmeans(X, n_clusters=5, var_reg=1e-3, random_state=None, chain=None):

@@ -147,7 +147,7 @@ def test_monks_posterior_within_mc_error_of_reference(eng):
         got.append([m.intercepts_[keep, 0].mean(), m.intercepts_[keep, 0].std(),
                     m.logps_[keep].mean(), m.logps_[keep].std(), d.mean()])
     got = np.array(got)
-    for name in ('intercept_mean', 'mean_pairwise_distance', 'intercept_sd', 'logp_sd'):
+    for name in ('intercept_mean', 'mean_pairwise_distance', 'intercept_sd', 'logp_mean', 'logp_sd'):
         k = cols.index(name)
         mu_r, sd_r = ref[:, k].mean(), ref[:, k].std(ddof=1)
         mu_g, sd_g = got[:, k].mean(), got[:, k].std(ddof=1)

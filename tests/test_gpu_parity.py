@@ -508,8 +508,16 @@ def test_sweep_persistent_launch_waits_are_bounded(eng, monkeypatch):
         with pytest.raises(RuntimeError, match='poll budget'):
             c.sweep_positions(2, algo=7)
         monkeypatch.delenv('DLSM_PERSIST_BUDGET')
-        with pytest.raises(RuntimeError, match='poll budget'):   # sticky: the state is undefined
-            c.sweep_positions(3, algo=7)
+        # reported once: the caller sets the state again and goes on with the same handle, as the
+        # message says (round-3 advice: the word used to stay set for the handle's lifetime)
+        c.set_positions(X)
+        c.set_samplers(eng.SamplerGrid(4, 600, 0.2, tune=None))
+        c.sweep_positions(3, algo=4)
+        Xa = c.get_positions()
+        c.set_positions(X)
+        c.set_samplers(eng.SamplerGrid(4, 600, 0.2, tune=None))
+        c.sweep_positions(3, algo=7)                       # and the persistent form works again
+        np.testing.assert_array_equal(c.get_positions(), Xa)
 
 
 def test_sweep_persistent_launch_refuses_what_it_cannot_place(eng):

@@ -322,3 +322,38 @@ def test_fit_post_processing_on_device_equals_host(eng, selection_type):
     np.testing.assert_array_equal(a.weights_, b.weights_)
     np.testing.assert_array_equal(a.cooccurrence_probas_, b.cooccurrence_probas_)
     assert 'Xs_' in a.__dict__ and 'cooccurrence_probas_' in a.__dict__
+
+
+def test_lazy_trace_arrays_materialize_release_and_fail_as_attribute_errors(eng):
+    """round-3 advice: vars() / copies see the lazily read arrays after materialize(); a read that
+    cannot be served raises AttributeError (hasattr / getattr defaults keep working);
+    release_device_trace() frees the handle and keeps what was read"""
+    import copy
+    rng = np.random.RandomState(2)
+    T, N = 3, 40
+    Y = (rng.rand(T, N, N) < 0.15).astype(np.float64)
+    Y = np.triu(Y, 1); Y = Y + Y.transpose(0, 2, 1)
+    kw = dict(n_iter=20, burn=10, tune=10, n_components=4, selection_type='map', random_state=3)
+    m = eng.DynamicNetworkHDPLPCM(**kw).fit(Y)
+    assert 'zs_' not in vars(m)
+    m.materialize()
+    for name in ('Xs_', 'zs_', 'weights_', 'cooccurrence_probas_'):
+        assert name in vars(m), name
+    zs = m.zs_.copy()
+    m.release_device_trace()
+    np.testing.assert_array_equal(m.zs_, zs)
+    c = copy.copy(m)
+    np.testing.assert_array_equal(c.zs_, zs)
+    # a second fit that is released WITHOUT reading: the arrays are gone, and say so politely
+    m2 = eng.DynamicNetworkHDPLPCM(**kw).fit(Y)
+    m2.chain_.close()
+    assert not hasattr(m2, 'zs_')
+    assert getattr(m2, 'Xs_', None) is None
+    with pytest.raises(AttributeError, match='device-resident trace'):
+        m2.weights_
+    # refitting resets the lazy co-occurrence flag
+    m3 = eng.DynamicNetworkHDPLPCM(**kw)
+    m3.fit(Y)
+    assert m3._lazy_cooc
+    m3._prepare(Y)
+    assert not m3._lazy_cooc and not m3._lazy_trace

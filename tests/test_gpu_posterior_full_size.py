@@ -1,0 +1,263 @@
+"""Posterior summaries at BASELINE.json's sizes (configs 2 and 3: T=10, N=2000, d=2), inside the
+`-m gpu` suite: north_star asks for "posterior summaries within MC error".
+
+Every other full-size check of the suite pins the arithmetic and the decisions of a handful of
+iterations against the oracle replaying the engine's Philox stream.  These tests ask what that
+cannot: do chains of thousands of iterations at N = 2000 - with the 35-ulp root and the table
+exponential in every one of their 10^11 dyad terms - mix to the right place?
+
+  * two chains with different Philox chain ids, >= 3000 kept iterations each: split R-hat of the
+    scalar traces, and the generating intercept / blending coefficient / number of clusters /
+    partition recovered (Monte Carlo error from the autocorrelations, tests/mcmc_diag.py =
+    trace_utils.py:11-45);
+  * the scalar C / numpy oracle, started from the state the engine reached at the END of such a
+    chain, must reproduce the engine's next iterations value for value - at equilibrium, far from
+    the synthetic starting point - so the oracle (pinned to the reference) does not drift away
+    from where the engine went.
+"""
+import time
+
+import numpy as np
+import pytest
+
+from mcmc_diag import effective_n, mcse, pooled_mean_and_se, split_rhat
+
+pytestmark = pytest.mark.gpu
+
+T, N, D = 10, 2000, 2
+N_BURN, N_KEEP, N_REPLAY = 600, 3000, 6
+SEED = 20240229
+
+
+@pytest.fixture(scope='module')
+def eng():
+    import dynetlsm_amd
+    return dynetlsm_amd
+
+
+def _share_network(src, dst):
+    """the packed network of one chain into another (5 MB through a host buffer)"""
+    n = src.network_packed_words()
+    buf = np.zeros(n, dtype=np.uint32)
+    src.get_network_packed(buf.ctypes.data, n)
+    dst.set_network_packed(buf.ctypes.data, n)
+
+
+# ---------------------------------------------------------------------------------------------
+# config 2: DynamicNetworkLSM, device-resident loop (lsm.py:474-572)
+# ---------------------------------------------------------------------------------------------
+@pytest.fixture(scope='module')
+def c2_chains(eng):
+    from dynetlsm_amd.synthetic import synthetic_lsm_network
+    net = synthetic_lsm_network(T=T, N=N, D=D, density=0.03, seed=0)
+    n_total = 1 + N_BURN + N_KEEP + N_REPLAY
+    chains, out = [], []
+    t0 = time.perf_counter()
+    for cid in (0, 1):
+        c = eng.Chain(T, N, D, 'undirected', seed=SEED, chain_id=cid)
+        if chains:
+            _share_network(chains[0], c)
+        else:
+            c.upload_network(net['Y'])
+        c.set_positions(net['X_init']); c.set_intercepts([net['intercept']])
+        c.set_prior_random_walk(2.0, 0.1)
+        c.set_samplers(eng.SamplerGrid(T, N, step_size=0.1, tune=None))
+        c.lsm_configure([net['intercept']], 2.0, step_size_intercept=0.1, tune=None,
+                        n_iter_procrustes=0, sweep_algo=0)
+        c.trace_alloc(n_total, logp0=0.0)
+        c.lsm_run(1, N_BURN + N_KEEP, procrustes_ref=-1)   # (the C oracle's iteration has no rotation)
+        chains.append(c)
+    for c in chains:
+        c.synchronize()
+    secs = time.perf_counter() - t0
+    for c in chains:
+        _, ics, lps = c.trace_read(1 + N_BURN, N_KEEP, positions=False)
+        out.append(dict(intercepts=ics[:, 0].copy(), logps=lps.copy()))
+    print('C2: 2 chains x %d iterations in %.2f s' % (N_BURN + N_KEEP, secs))
+    yield net, chains, out
+    for c in chains:
+        c.close()
+
+
+def test_c2_two_chains_agree_and_recover_the_generating_intercept(c2_chains):
+    net, chains, out = c2_chains
+    ic = np.stack([o['intercepts'] for o in out])
+    lp = np.stack([o['logps'] for o in out])
+    assert np.isfinite(ic).all() and np.isfinite(lp).all()
+    r_ic, r_lp = split_rhat(ic), split_rhat(lp)
+    ess_ic = [effective_n(x) for x in ic]
+    m_ic, se_ic = pooled_mean_and_se(ic)
+    sd_ic = float(ic.std())
+    print('C2 split R-hat: intercept %.4f logp %.4f; ESS(intercept) %s; intercept %.5f +- %.5f (MC), '
+          'posterior sd %.5f, generating %.5f; logp means %s'
+          % (r_ic, r_lp, np.round(ess_ic, 0), m_ic, se_ic, sd_ic, net['intercept'], lp.mean(axis=1)))
+    assert r_ic < 1.05, r_ic
+    assert r_lp < 1.05, r_lp
+    # the two chains' means agree within their Monte Carlo errors
+    d = abs(ic[0].mean() - ic[1].mean())
+    assert d < 4 * np.hypot(mcse(ic[0]), mcse(ic[1])), (d, mcse(ic[0]), mcse(ic[1]))
+    # The generating value lies where the posterior puts its mass: within 4 (posterior sd + MC
+    # error) of the posterior mean, plus the shrinkage of the positions' Gaussian random-walk
+    # prior (tau^2 = 2, sigma^2 = 0.1 against the generator's 1.5^2 and 0.3^2), which pulls the
+    # distances - and with them the intercept - down by a few per cent.
+    assert abs(m_ic - net['intercept']) < 4 * (sd_ic + se_ic) + 0.05 * abs(net['intercept']), \
+        (m_ic, net['intercept'], sd_ic, se_ic)
+    # acceptance rate of the position sweeps: inside the range the step-size rule aims for
+    g = chains[0].get_samplers(__import__('dynetlsm_amd').SamplerGrid(T, N, 0.1, tune=None))
+    acc = float(g.n_accepted.sum()) / float(g.n_steps.sum())
+    assert 0.2 < acc < 0.9, acc
+
+
+def test_c2_oracle_continues_the_equilibrium_chain_value_for_value(c2_chains):
+    """the C oracle, started at the state the engine holds after N_BURN + N_KEEP iterations,
+    reproduces the engine's next N_REPLAY iterations (same Philox key and iteration numbers):
+    intercepts, log-posteriors and positions - and so stays inside the chain's stationary range"""
+    from oracle import oracle as orc
+    net, chains, out = c2_chains
+    c = chains[1]
+    first = 1 + N_BURN + N_KEEP
+    X0 = c.get_positions()
+    b0 = float(c.get_intercepts()[0])
+    og = orc.SamplerGrid(T, N, 0.1, tune=None)
+    g = c.get_samplers(__import__('dynetlsm_amd').SamplerGrid(T, N, 0.1, tune=None))
+    og.n_accepted[:] = g.n_accepted; og.n_steps[:] = g.n_steps
+    c.lsm_run(first, N_REPLAY, procrustes_ref=-1)
+    Xs, ics, lps = c.trace_read(first, N_REPLAY, positions=True)
+    st = orc.ChainState(X0, og, Y=net['Y'], intercept=[b0], tau_sq=2.0, sigma_sq=0.1, seed=SEED,
+                        chain=1)
+    cfg = c.lsm_get_config()
+    isamp = orc.ScalarSampler(0.1, int(cfg.i_n_accepted[0]), int(cfg.i_n_steps[0]), 100, -1, 100)
+    lp_o, ic_o = [], []
+    for k in range(N_REPLAY):
+        st.c.iter = first + k
+        lp_o.append(orc.lsm_iteration_undirected(st, isamp, net['intercept'], 2.0))
+        ic_o.append(float(st.intercept[0]))
+        np.testing.assert_allclose(Xs[k], st.X, atol=1e-9)
+    np.testing.assert_allclose(ics[:, 0], ic_o, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(lps, lp_o, rtol=1e-10)
+    # no drift: the oracle's values stay inside the stationary range of the kept trace
+    kept = out[1]
+    for got, tr in ((np.array(lp_o), kept['logps']), (np.array(ic_o), kept['intercepts'])):
+        assert abs(got.mean() - tr.mean()) < 5 * tr.std(), (got.mean(), tr.mean(), tr.std())
+
+
+# ---------------------------------------------------------------------------------------------
+# config 3: DynamicNetworkHDPLPCM through fit() (hdp_lpcm.py:641-1176), device-resident loop
+# ---------------------------------------------------------------------------------------------
+K_MAX, N_TRUE = 20, 6
+
+
+@pytest.fixture(scope='module')
+def c3_fits(eng):
+    from dynetlsm_amd.synthetic import synthetic_hdp_network
+    net = synthetic_hdp_network(T=T, N=N, D=D, density=0.03, seed=0)
+    rs = np.random.RandomState(5)
+    mu0 = np.zeros((K_MAX, D)); mu0[:N_TRUE] = net['mu_true']
+    mu0[N_TRUE:] = 3.0 * rs.randn(K_MAX - N_TRUE, D)
+    sg0 = np.full(K_MAX, float(net['sigma_true'].mean()))
+    fits = []
+    t0 = time.perf_counter()
+    for cid in (0, 1):
+        m = eng.DynamicNetworkHDPLPCM(n_iter=N_KEEP, tune=N_BURN // 2, burn=N_BURN - N_BURN // 2,
+                                      n_components=K_MAX, n_features=D, random_state=11 + cid,
+                                      chain_id=cid, selection_type='vi')
+        m.fit(net['Y'], init=dict(X=net['X_init'], intercept=[net['intercept']], mu=mu0, sigma=sg0,
+                                  z=net['z_true']))
+        fits.append(m)
+    print('C3: 2 x fit() of %d iterations in %.2f s (loops %.2f / %.2f s)'
+          % (N_BURN + N_KEEP, time.perf_counter() - t0, fits[0].loop_seconds_, fits[1].loop_seconds_))
+    yield net, fits
+    for m in fits:
+        m.chain_.close()
+
+
+def _clusters_in_use(m, first, count):
+    nk = m.chain_.post_trace_label_counts(first, count)          # (S, T, K)
+    return (nk > 0).any(axis=1).sum(axis=1).astype(np.float64)
+
+
+def test_c3_two_chains_agree_and_recover_the_generating_structure(c3_fits):
+    from sklearn.metrics import adjusted_rand_score
+    net, fits = c3_fits
+    nb = fits[0].n_burn_
+    assert fits[0].loop_kind_ == 'device-resident' and nb == N_BURN
+    lam = np.stack([m.lambdas_[nb:, 0] for m in fits])
+    ic = np.stack([m.intercepts_[nb:, 0] for m in fits])
+    lp = np.stack([m.logps_[nb:] for m in fits])
+    ncl = np.stack([_clusters_in_use(m, nb, m.logps_.shape[0] - nb) for m in fits])
+    assert np.isfinite(lp).all() and lam.shape[1] >= 3000
+    r = {k: split_rhat(v) for k, v in (('lambda', lam), ('intercept', ic), ('logp', lp))}
+    m_lam, se_lam = pooled_mean_and_se(lam)
+    m_ic, se_ic = pooled_mean_and_se(ic)
+    print('C3 split R-hat %s; lambda %.5f +- %.5f (sd %.5f; generating 0.8); intercept %.5f +- %.5f '
+          '(sd %.5f; generating %.5f); clusters in use: mean %.3f min %d max %d; selected: %s'
+          % ({k: round(v, 4) for k, v in r.items()}, m_lam, se_lam, lam.std(), m_ic, se_ic, ic.std(),
+             net['intercept'], ncl.mean(), ncl.min(), ncl.max(),
+             [len(np.unique(m.z_)) for m in fits]))
+    for k, v in r.items():
+        assert v < 1.05, (k, v)
+    # the generating values inside the posterior's mass (4 posterior sd + MC error; the
+    # intercept with the same few per cent of prior shrinkage as in the LSM)
+    assert abs(m_lam - 0.8) < 4 * (lam.std() + se_lam), (m_lam, lam.std(), se_lam)
+    assert abs(m_ic - net['intercept']) < 4 * (ic.std() + se_ic) + 0.05 * abs(net['intercept'])
+    # six generating clusters: every kept sample uses at least six components; the posterior
+    # mean number in use stays within one of it (the HDP opens and closes small extra clusters)
+    assert ncl.min() >= N_TRUE and abs(ncl.mean() - N_TRUE) < 1.0, (ncl.min(), ncl.mean())
+    for m in fits:
+        # the partition fit() selects (minimum posterior expected VI, hdp_lpcm.py:1085-1139)
+        ari = adjusted_rand_score(net['z_true'].ravel(), m.z_.ravel())
+        assert ari >= 0.95, ari
+        big = np.bincount(m.z_.ravel(), minlength=K_MAX) >= 0.01 * T * N
+        assert big.sum() == N_TRUE, np.bincount(m.z_.ravel(), minlength=K_MAX)
+    # both chains select (almost) the same partition
+    assert adjusted_rand_score(fits[0].z_.ravel(), fits[1].z_.ravel()) >= 0.95
+
+
+def test_c3_oracle_continues_the_equilibrium_chain_value_for_value(c3_fits):
+    """hdp_lpcm.py:876-1023 restated in the oracle, started from the LAST stored sample of a
+    3600-iteration fit, against the engine continuing from the same sample: labels exactly,
+    positions, lambda, intercept, log-posterior"""
+    from oracle import oracle as orc
+    from oracle import hdp_loop_oracle as hlo
+    import dynetlsm_amd as da
+    net, fits = c3_fits
+    m = fits[1]
+    ch, n_total = m.chain_, m.logps_.shape[0]
+    tr = ch.hdp_trace_read(n_total - 1, 1)
+    hy = tr['hypers'][0]
+    hp_o = {k: v for k, v in m.hyper_.__dict__.items() if k != 'n_components'}
+    hp_o.update(gamma=hy[0], alpha_init=hy[1], alpha=hy[2], kappa=hy[3], mean_variance_prior=hy[4],
+                b=hy[5])
+    n_it = 3
+    # the engine: a fresh chain at that state, same key, iterations numbered on from n_total
+    with da.Chain(T, N, D, 'undirected', seed=ch.seed, chain_id=ch.chain_id) as c:
+        _share_network(ch, c)
+        c.set_positions(tr['Xs'][0]); c.set_intercepts(tr['intercepts'][0][:1])
+        c.set_samplers(m.latent_samplers)        # step sizes as the tuning phase left them
+        c.set_prior_mixture(tr['mus'][0], tr['sigmas'][0], float(tr['lambdas'][0, 0]), tr['zs'][0])
+        hp_e = hlo.Hyper(**hp_o)
+        cfg = ch.hdp_get_config()
+        c.hdp_configure(hp_e, tr['betas'][0], tr['weights'][0], m._ip, m.intercept_variance_prior,
+                        step_size_intercept=cfg.i_step_size, tune=None)
+        c.hdp_trace_alloc(n_total + n_it)
+        # (rows are indexed by iteration number: the Philox counters carry it)
+        c.hdp_run(n_total, n_it)
+        got = c.hdp_trace_read(n_total, n_it)
+    lg = m.latent_samplers
+    og = orc.SamplerGrid(T, N, 0.1, tune=lg.tune, tune_interval=lg.tune_interval)
+    og.step_size[:] = lg.step_size; og.n_accepted[:] = lg.n_accepted
+    og.n_steps[:] = lg.n_steps; og.steps_until_tune[:] = lg.steps_until_tune
+    oc = hlo.HdpChain(net['Y'], tr['Xs'][0].copy(), tr['intercepts'][0][:1].copy(), tr['mus'][0].copy(),
+                      tr['sigmas'][0].copy(), tr['zs'][0].copy(), tr['betas'][0].copy(),
+                      tr['weights'][0].copy(), float(tr['lambdas'][0, 0]), hlo.Hyper(**hp_o),
+                      og, m._ip, m.intercept_variance_prior,
+                      orc.ScalarMetropolis(cfg.i_step_size, None, 100), seed=ch.seed, chain=ch.chain_id)
+    kept_lp = m.logps_[m.n_burn_:]
+    for k in range(n_it):
+        lp = oc.iteration(n_total + k)
+        np.testing.assert_array_equal(got['zs'][k], oc.z)
+        np.testing.assert_allclose(got['Xs'][k], oc.X, atol=1e-9)
+        np.testing.assert_allclose(got['lambdas'][k, 0], oc.lmbda[0], rtol=1e-9)
+        np.testing.assert_allclose(got['intercepts'][k, 0], oc.intercept[0], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(got['logps'][k], lp, rtol=1e-9)
+        assert abs(lp - kept_lp.mean()) < 6 * kept_lp.std(), (lp, kept_lp.mean(), kept_lp.std())
