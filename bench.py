@@ -35,7 +35,6 @@ on rank 0.
 import argparse
 import json
 import os
-import socket
 import subprocess
 import sys
 import time
@@ -141,41 +140,11 @@ def parse(argv=None):
 # ------------------------------------------------------------------------------------
 # self-launch: N ranks as child processes (the parent never touches the GPU)
 # ------------------------------------------------------------------------------------
-def _free_port():
-    s = socket.socket()
-    s.bind(('127.0.0.1', 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
-
-
 def launch_ranks(args):
-    n = args.gpus
-    port = _free_port()
-    procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
-                   LOCAL_WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
-        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        # rank 0 inherits stdout (its JSON line is the output); the others' go to stderr
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
-                                      env=env, stdout=None if r == 0 else sys.stderr))
-    rc = 0
-    alive = set(range(n))
-    while alive:
-        for r in sorted(alive):
-            code = procs[r].poll()
-            if code is None:
-                continue
-            alive.discard(r)
-            if code != 0 and rc == 0:
-                rc = code if code > 0 else 1
-                print('bench.py: rank %d exited with %d; stopping the others' % (r, code),
-                      file=sys.stderr)
-                for q in alive:
-                    procs[q].terminate()          # exactly the PIDs started above
-        time.sleep(0.05)
-    return rc
+    """N ranks as child processes through the package's own launcher (the one
+    ``dynetlsm_amd.multichain.fit_chains`` uses): rank 0's JSON line is the output"""
+    from dynetlsm_amd.multichain import launch_ranks as launch
+    return launch([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus)
 
 
 # ------------------------------------------------------------------------------------
@@ -368,6 +337,30 @@ def cpu_chains_in_processes(a, procs):
                       'has %d cores' % (procs, a.cpu_iters, max(secs), os.cpu_count())}
 
 
+_DUR_CACHE = []
+
+
+def stored_kernel_us(kname, model):
+    """the rocprofv3 average of a kernel from profiles/kernel_durations.json (None if absent):
+    the longest-running instantiation whose name starts with `kname` in that model's profile"""
+    if not _DUR_CACHE:
+        try:
+            _DUR_CACHE.append(json.load(open(os.path.join(ROOT, 'profiles', 'kernel_durations.json'))))
+        except Exception:       # noqa: BLE001
+            _DUR_CACHE.append({})
+    rows = _DUR_CACHE[0].get(model, {})
+    best = None
+    for name, r in rows.items():
+        if name.split('<')[0] == kname.split('<')[0] and (best is None or r['calls'] > best[1]['calls']):
+            best = (name, r)
+    if best is None:
+        return None
+    return {'avg_us': best[1]['avg_us'], 'calls': best[1]['calls'],
+            'source': 'rocprofv3 --kernel-trace --stats average of %s over %d calls (profiles/'
+                      'kernel_durations.json <- %s)' % (best[0], best[1]['calls'],
+                                                        _DUR_CACHE[0].get('_source', '').split(' (')[0])}
+
+
 def sweep_rooflines(chain, a, P, sweep_ms, ll_ms, ms_ev, n_ev, ms_rs, n_rs, post_ms, fin_ms,
                     iteration_ms=None):
     """roofline blocks of the sweep's dominant kernel and of the log-likelihood pass.
@@ -406,42 +399,65 @@ def sweep_rooflines(chain, a, P, sweep_ms, ll_ms, ms_ev, n_ev, ms_rs, n_rs, post
         tf = terms * instr * 2.0 / (ms * 1e-3) / 1e12
         return round(tf, 3), round(tf / F64_VALU_PEAK_TFLOPS, 4)
 
-    ach, frac = valu(k_terms, OPS_PER_TERM_SWEEP, k_ms)
+    # The duration `frac` divides by is the rocprofv3 average of this kernel stored under
+    # profiles/ (kernel_durations.json <- rNN_kernel_stats_*.csv, the same command under the
+    # profiler), so that the fraction follows from the committed files; the duration THIS run
+    # measured - begin / end timestamps of the dispatches, events attached to the launches -
+    # rides beside it (`us_per_launch_events`, `frac_events`; it reads ~7 % shorter: the
+    # profiler serialises the dispatches and keeps their ramps from overlapping).
+    stored = stored_kernel_us(kname, getattr(a, 'model_tag', 'lsm'))
+    prof_ms = stored['avg_us'] * 1e-3 if stored else k_ms
+    ach, frac = valu(k_terms, OPS_PER_TERM_SWEEP, prof_ms)
+    ach_ev, frac_ev = valu(k_terms, OPS_PER_TERM_SWEEP, k_ms)
     ipt_sweep, ipt_ll = kernel_instr_per_term()
-    frac_i = valu(k_terms, ipt_sweep, k_ms)[1] if ipt_sweep else None
+    frac_x = valu(k_terms, ipt_sweep, prof_ms)[1] if ipt_sweep else None
     roofline = {
         'bound': 'fp64_valu', 'kernel': kname, 'achieved': ach, 'peak': F64_VALU_PEAK_TFLOPS,
         'unit': 'TFLOP/s', 'frac': frac, 'traffic': traffic,
-        'us_per_launch': round(1e3 * k_ms, 3), 'launches_per_sweep': launches,
+        'us_per_launch': round(1e3 * prof_ms, 3),
+        'us_per_launch_source': (stored['source'] if stored else
+                                 'events attached to the launches of this run (no stored profile)'),
+        'us_per_launch_events': round(1e3 * k_ms, 3), 'achieved_events': ach_ev, 'frac_events': frac_ev,
+        'launches_per_sweep': launches,
         'dyad_terms_per_launch': round(k_terms, 0),
         'f64_ops_per_term': OPS_PER_TERM_SWEEP,
+        # the same duration priced by the vector instructions the kernel EXECUTES per term
+        # (its code object, profiles/instr_counts.py): issue utilisation of the neighbour loop
         'valu_instr_per_term_in_kernel': ipt_sweep,
-        'frac_by_kernel_instructions': frac_i,
+        'frac_executed': frac_x,
         'instr_source': 'profiles/instr_counts.py on the built library (llvm-objdump of the hot loop)',
-        'peak_note': 'nominal float64 vector peak (fma = 2 flop; the algorithmic operations of a '
-                     'dyad term priced as fma slots: 34, fixed since round 1; what the kernel '
-                     'spends per term is counted in its code object); a pure fma stream sustains '
-                     '%.2f of the peak at 4 wavefronts per SIMD' % F64_VALU_SUSTAINED_FRAC,
+        'peak_note': 'nominal float64 vector peak (fma = 2 flop).  `frac` prices the ALGORITHMIC '
+                     'operations of a dyad term as fma slots - 34, fixed since round 1 so that '
+                     'rounds compare; the kernel itself executes %s vector instructions per term '
+                     'since the table exponential, i.e. 34 > executed: `frac` overstates issue '
+                     'utilisation by that ratio and `frac_executed` is the utilisation figure; a '
+                     'pure fma stream sustains %.2f of the peak at 4 wavefronts per SIMD'
+                     % (ipt_sweep, F64_VALU_SUSTAINED_FRAC),
         'frac_of_sustained': round(frac / F64_VALU_SUSTAINED_FRAC, 4),
         'dyad_terms_per_s_sweep': round(sweep_terms / (sweep_ms * 1e-3), 0)}
-    ach_b = k_bytes / (k_ms * 1e-3) / 1e9
+    ach_b = k_bytes / (prof_ms * 1e-3) / 1e9
     roofline_hbm = {
         'bound': 'hbm', 'kernel': kname, 'achieved': round(ach_b, 2), 'peak': HBM_PEAK_GBS,
         'unit': 'GB/s', 'frac': round(ach_b / HBM_PEAK_GBS, 5), 'traffic': traffic,
         'algorithmic_bytes_per_launch': round(k_bytes, 1),
-        'measured_traffic_GBps': (round(traffic / (k_ms * 1e-3) / 1e9, 2) if traffic else None),
-        'measured_traffic_frac': (round(traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+        'measured_traffic_GBps': (round(traffic / (prof_ms * 1e-3) / 1e9, 2) if traffic else None),
+        'measured_traffic_frac': (round(traffic / (prof_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
                                   if traffic else None),
         'traffic_source': 'profiles/traffic.json (rocprofv3 PMC of this kernel, stored)',
         'sweep_GBps_all_launches': round(sweep_bytes / (sweep_ms * 1e-3) / 1e9, 2)}
-    ach_l, frac_l = valu(ll_terms, OPS_PER_TERM_LOGLIK, ll_ms)
+    stored_ll = stored_kernel_us('k_loglik_undirected', getattr(a, 'model_tag', 'lsm'))
+    ll_prof_ms = stored_ll['avg_us'] * 1e-3 if stored_ll else ll_ms
+    ach_l, frac_l = valu(ll_terms, OPS_PER_TERM_LOGLIK, ll_prof_ms)
     roofline_ll = {
         'bound': 'fp64_valu', 'kernel': 'k_loglik_undirected<2,2>', 'achieved': ach_l,
         'peak': F64_VALU_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': frac_l, 'traffic': ll_traffic,
-        'us_per_launch': round(1e3 * ll_ms, 3),
+        'us_per_launch': round(1e3 * ll_prof_ms, 3),
+        'us_per_launch_source': stored_ll['source'] if stored_ll else 'events of this run',
+        'us_per_launch_events': round(1e3 * ll_ms, 3),
+        'frac_events': valu(ll_terms, OPS_PER_TERM_LOGLIK, ll_ms)[1],
         'f64_ops_per_term': OPS_PER_TERM_LOGLIK,
         'valu_instr_per_candidate_term_in_kernel': ipt_ll,
-        'frac_by_kernel_instructions': (valu(ll_terms, ipt_ll, ll_ms)[1] if ipt_ll else None),
+        'frac_executed': (valu(ll_terms, ipt_ll, ll_prof_ms)[1] if ipt_ll else None),
         'algorithmic_GBps': round(ll_bytes / (ll_ms * 1e-3) / 1e9, 1),
         'algorithmic_frac_of_hbm': round(ll_bytes / (ll_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
         'frac_of_sustained': round(frac_l / F64_VALU_SUSTAINED_FRAC, 4)}
@@ -568,7 +584,9 @@ class HdpWorkload(object):
         ms_fi, n_fi = chain.profile_read(_lib.K_FINALIZE)
         chain.profile_enable(False)
         ms_ev, n_ev = chain.profile_read(_lib.K_SWEEP_EVAL)
-        roofline, extra = sweep_rooflines(chain, a, P, ms_sw / max(n_sw, 1), ms_ll / max(n_ll, 1),
+        import copy
+        a_h = copy.copy(a); a_h.model_tag = 'hdp'          # (the stored profile of THIS model)
+        roofline, extra = sweep_rooflines(chain, a_h, P, ms_sw / max(n_sw, 1), ms_ll / max(n_ll, 1),
                                           ms_ev, n_ev, 0.0, 0, ms_ps / max(n_ps, 1), 0.0)
         extra['ms_label_kernels_per_iteration'] = round(ms_lb / max(P, 1), 4)
         extra['ms_hdp_draws_and_logp_per_iteration'] = round(ms_tl / max(P, 1), 4)
@@ -758,6 +776,10 @@ class CcWorkload(object):
         # and control lists (int64 index 8 B) and gathers X[e] (16 B at d = 2) and radii[e] (8 B)
         sweep_bytes = 2.0 * T * N * self.mean_terms * (8 + 16 + 8)
         k_bytes = sweep_bytes / max(launches, 1)
+        k_ms_events = k_ms
+        stored = stored_kernel_us(kname, 'cc')      # the rocprofv3 average under profiles/, as in the headline
+        if stored:
+            k_ms = stored['avg_us'] * 1e-3
         ach = k_bytes / (k_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
@@ -769,7 +791,10 @@ class CcWorkload(object):
         roofline = {'bound': 'hbm', 'kernel': kname, 'achieved': round(ach, 2), 'peak': HBM_PEAK_GBS,
                     'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 5), 'traffic': traffic,
                     'traffic_source': 'profiles/traffic.json (rocprofv3 PMC of this kernel, stored)',
-                    'us_per_launch': round(1e3 * k_ms, 3), 'launches_per_sweep': launches,
+                    'us_per_launch': round(1e3 * k_ms, 3),
+                    'us_per_launch_source': stored['source'] if stored else 'events of this run',
+                    'us_per_launch_events': round(1e3 * k_ms_events, 3),
+                    'launches_per_sweep': launches,
                     'algorithmic_bytes_per_launch': round(k_bytes, 1),
                     'gathered_terms_per_s_sweep': round(2.0 * T * N * self.mean_terms /
                                                         (sweep_ms * 1e-3), 0),

@@ -1051,7 +1051,7 @@ static int launch_sweep_pipe(dlsm_chain *h, IterRef iter, bool alloc_only = fals
     // persistent form: the resolvers' diagonal block by rows of PR_LD, the evaluators' exp table
     // and staged neighbour rows
     const size_t lds_persist = (size_t)PP_B * PR_LD * sizeof(double);
-    if (persist && ((size_t)EXPTAB_N + (size_t)pb.per * DD) * sizeof(double) > lds_persist)
+    if (persist && ((size_t)EXPTAB11_N + (size_t)pb.per * DD) * sizeof(double) > lds_persist)
         FAIL(h, DLSM_E_LIMIT, "algo 7: a part of %d neighbours does not fit the evaluators' LDS", pb.per);
     auto ku = k_pipe_step<DD, DLSM_UNDIRECTED>;
     auto kl = k_pipe_step<DD, PIPE_UNDIRECTED_LONG>;

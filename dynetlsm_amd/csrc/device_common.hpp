@@ -355,6 +355,35 @@ __device__ __forceinline__ double tab_exp_clamped(double x, const double *tab) {
     return tab_exp(fmax(x, -1000.0), tab);
 }
 
+// The same scheme on a 2048-entry table of 2^(j / 2048) (16 KB of LDS): |r| <= ln2 / 4096 = 1.7e-4,
+// so the degree-3 Taylor polynomial is enough (truncation r^4 / 24 = 3.4e-17 relative) and its first
+// step, r / 6 + 1 / 2, has one literal and one inline constant - the degree-4 form's r / 24 + 1 / 6
+// needs a register for its second literal: 11 vector instructions + one LDS read against 13.  For the
+// kernels that own a CU's LDS (the pipelined sweeps' evaluators: one workgroup per CU); the
+// log-likelihood passes keep the 2 KB table (six wavefronts per SIMD need the LDS).
+// VALID FOR |x| < 7.2e5; error as tab_exp: 2 ulp + |x| / 2 ulp (tests/test_exp_table_cpu.py).
+constexpr int EXPTAB11_N = 2048;
+// the workgroup's table (callers put a barrier behind it): NT threads, two entries per load
+template <int NT>
+__device__ __forceinline__ void exp_table11_fill(double *tab, int tid) {
+    for (int i = tid; i < EXPTAB11_N / 2; i += NT)
+        ((double2 *)tab)[i] = ((const double2 *)c_exp2_tab11)[i];
+}
+__device__ __forceinline__ double tab_exp11(double x, const double *tab) {
+    const double magic = 6755399441055744.0;                     // 1.5 * 2^52
+    const double t = fma(x, 2954.639443740597, magic);           // 2048 / ln2
+    const double kf = t - magic;
+    const int ki = __double2loint(t);
+    const double r = fma(kf, -0x1.62e42fefa39efp-12, x);         // ln2 / 2048 rounded to double
+    double p = fma(r, 1.0 / 6.0, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return __builtin_ldexp(tab[ki & (EXPTAB11_N - 1)] * p, ki >> 11);
+}
+__device__ __forceinline__ double tab_exp11_clamped(double x, const double *tab) {
+    return tab_exp11(fmax(x, -1000.0), tab);
+}
+
 template <int D>
 __device__ __forceinline__ double dist_fast(const double *a, const double *b, int squared) {
     double s = squared ? 0.0 : SQRT_GUARD;

@@ -456,7 +456,7 @@ __global__ __launch_bounds__(PP_THREADS) void k_pipe_persist(ChainView c, PipeBu
     }
     // ---- evaluators ------------------------------------------------------------------------------
     // ticket -> (step s = l + 1, part p, slice, group of 16 nodes); slices in the order evens, odds
-    if (MODEL == DLSM_UNDIRECTED) exp_table_fill(pp_sH, tid);     // visible behind the first round's barrier
+    if (MODEL == DLSM_UNDIRECTED) exp_table11_fill<PP_THREADS>(pp_sH, tid);     // visible behind the first round's barrier
     const int nE = (T + 1) / 2;
     const int gps = pb.parts * T * PS_GROUPS;             // tickets per step
     const int total = (last + 2) * gps;
@@ -469,7 +469,7 @@ __global__ __launch_bounds__(PP_THREADS) void k_pipe_persist(ChainView c, PipeBu
     // operands of its first H entry, the rows of the other batches - BEFORE the poll matched was
     // built and measured: it puts those loads on top of the resolvers' bandwidth-bound block loads
     // and lost 10 %: profiles/r03_persist_notes.md.)
-    double *sX = pp_sH + EXPTAB_N;                         // the round's neighbour rows, behind the exp table
+    double *sX = pp_sH + EXPTAB11_N;                       // the round's neighbour rows, behind the exp table
     constexpr int IM = MODEL == DLSM_DIRECTED_CASE_CONTROL ? DLSM_DIRECTED : MODEL;
     int tk0 = (int)blockIdx.x - T;                         // wavefront 0's copy; the counter starts behind these
     for (int round = 0;; ++round) {

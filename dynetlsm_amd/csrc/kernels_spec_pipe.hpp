@@ -360,8 +360,8 @@ __device__ __forceinline__ void pipe_item_finish(const ChainView &c, const PipeB
 #endif
         double h;
         if (MODEL == DLSM_UNDIRECTED) {
-            const double eb0 = tab_exp_clamped(-b0, etab), ea1 = tab_exp_clamped(-a1, etab);
-            const double eb1 = tab_exp_clamped(-b1, etab), ea0 = tab_exp_clamped(-a0, etab);
+            const double eb0 = tab_exp11_clamped(-b0, etab), ea1 = tab_exp11_clamped(-a1, etab);
+            const double eb1 = tab_exp11_clamped(-b1, etab), ea0 = tab_exp11_clamped(-a0, etab);
             double num = fma(E, eb0, 1.0) * fma(E, ea1, 1.0);
             double den = fma(E, eb1, 1.0) * fma(E, ea0, 1.0);
             // the edge's factor e^{(b0 - b1) - (a0 - a1)} from the four exponentials at hand;
@@ -532,8 +532,8 @@ __device__ __forceinline__ void pipe_eval_item(const ChainView &c, const PipeBuf
             const double d0_ = dist_fast<D>(XI_, xk0, SQ_);                                   \
             const double d1_ = dist_fast<D>(XI_, xk1, SQ_);                                   \
             ra.lin = fma((YB_) ? 1.0 : 0.0, d0_ - d1_, ra.lin);                               \
-            ra.P0 *= fma(E, (SQ_) ? tab_exp_clamped(-d0_, etab) : tab_exp(-d0_, etab), 1.0);  \
-            ra.P1 *= fma(E, (SQ_) ? tab_exp_clamped(-d1_, etab) : tab_exp(-d1_, etab), 1.0);  \
+            ra.P0 *= fma(E, (SQ_) ? tab_exp11_clamped(-d0_, etab) : tab_exp11(-d0_, etab), 1.0);  \
+            ra.P1 *= fma(E, (SQ_) ? tab_exp11_clamped(-d1_, etab) : tab_exp11(-d1_, etab), 1.0);  \
             if (FLUSH_) if (++ra.cnt >= nflush) ra.flush();                                   \
         } else {                                                                              \
             const double d0_ = dist_fast<D>(XI_, xk0, c.squared);                             \
@@ -1041,11 +1041,11 @@ __global__ __launch_bounds__(PP_THREADS) void k_pipe_step(ChainView c, PipeBuf p
     const int nslE = nbE > 0 ? nE : 0, nslO = nbO > 0 ? nO : 0, nsl = nslE + nslO;
     const int nitems = (pb.parts * nsl) << gsh;
     const float inv_nsl = 1.0f / (float)max(nsl, 1);
-    // the evaluators' table of 2^(j / 256) (tab_exp) in the dynamic LDS the resolvers use for H
+    // the evaluators' table of 2^(j / 2048) (tab_exp11) in the dynamic LDS the resolvers use for H
     // (a barrier-free fill - every wavefront copying the table itself with global_load_lds_dwordx4 -
     // measured no better: 3614 against 3638 it/s; nor did the barrier behind the item's loads: 3615)
     if (MODEL == DLSM_UNDIRECTED) {
-        exp_table_fill(pp_sH, threadIdx.x);
+        exp_table11_fill<PP_THREADS>(pp_sH, threadIdx.x);
         __syncthreads();
     }
     const int nwaves = ((int)gridDim.x - T) * PP_WAVES;

@@ -157,7 +157,7 @@ def _kmeans(X_vec, n_clusters, random_state, chain):
 
 # scikit-learn releases whose KMeans internals (k-means++ draw order with `choice(p=w)` for the
 # first centre, n_init='auto' = one start, _kmeans_single_lloyd's signature) the restatement above
-# was pinned against (tests/golden/kmeans.npz, tests/test_init_oracle_golden.py); any other release
+# was pinned against (tests/golden/kmeans.npz and the k-means++ test beside it); any other release
 # runs the library itself on the host
 _KMEANS_RESTATED_FOR = ((1, 4), (1, 5), (1, 6), (1, 7))
 

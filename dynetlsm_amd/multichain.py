@@ -16,12 +16,28 @@ backend is ``nccl``; ``gloo`` on CPU for tests) appear only at the edges:
 
 Launch with ``python -m torch.distributed.run --nproc-per-node N script.py``;
 rank r drives GPU LOCAL_RANK with Philox chain id r.
+
+``fit_chains(estimator, Y, n_chains)`` is the estimator-level call: N chains of one model,
+one per GPU, in one call - what the reference does serially with ``for i in range(n_reps):
+... random_state=i`` (examples/homogeneous_simulation.py:177-184).  It joins the ranks of a
+launcher when there is one (RANK set), and otherwise spawns one child process per chain itself
+BEFORE any GPU call of its own (``launch_ranks``: the parent never touches the device); rank 0's
+network is broadcast over RCCL, every rank runs ``estimator.fit`` with Philox chain id and
+``random_state`` offset by its rank, the scalar traces / posterior means / selected partitions
+are all-gathered, and the result carries the split R-hat of the scalar traces across chains.
 """
 import os
+import pickle
+import socket
+import subprocess
+import sys
+import tempfile
+import time
 
 import numpy as np
 
-__all__ = ['ChainGroup', 'init_chain_group']
+__all__ = ['ChainGroup', 'init_chain_group', 'fit_chains', 'ChainsResult', 'launch_ranks',
+           'split_rhat']
 
 
 class ChainGroup(object):
@@ -71,15 +87,15 @@ class ChainGroup(object):
         hdr = t.zeros(3, dtype=t.int64, device=dev)
         if self.rank == src:
             Y = np.ascontiguousarray(Y, dtype=np.float64)
-            if not np.all((Y == 0) | (Y == 1)):
-                raise ValueError('network entries must be 0 / 1')
+            if not np.all((Y == 0) | (Y == 1) | (Y == -1)):      # -1: the reference's missing code
+                raise ValueError('network entries must be 0 / 1 (or -1 for a missing dyad)')
             hdr = t.tensor(Y.shape, dtype=t.int64, device=dev)
         self._dist.broadcast(hdr, src)
         shp = tuple(int(v) for v in hdr.cpu())
         if self.rank == src:
-            buf = t.from_numpy(Y.astype(np.uint8)).to(dev)
+            buf = t.from_numpy(Y.astype(np.int8)).to(dev)
         else:
-            buf = t.empty(shp, dtype=t.uint8, device=dev)
+            buf = t.empty(shp, dtype=t.int8, device=dev)
         self._dist.broadcast(buf, src)
         return buf.cpu().numpy().astype(np.float64)
 
@@ -164,3 +180,213 @@ def init_chain_group(backend=None, force=False):
         os.environ.setdefault('MASTER_PORT', '29511')
         dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     return ChainGroup(rank, world, local_rank, backend, dist, torch, force=force)
+
+
+# ------------------------------------------------------------------------------------
+# N chains of one estimator, one per GPU
+# ------------------------------------------------------------------------------------
+def split_rhat(chains):
+    """split R-hat (Gelman et al., BDA3 11.4) of a scalar trace over chains (m, n): every chain
+    cut in two halves, between- against within-sequence variance"""
+    c = np.asarray(chains, dtype=np.float64)
+    if c.ndim != 2 or c.shape[1] < 4:
+        return float('nan')
+    half = c.shape[1] // 2
+    q = np.concatenate([c[:, :half], c[:, half:2 * half]], axis=0)
+    n = q.shape[1]
+    W = q.var(axis=1, ddof=1).mean()
+    B = n * q.mean(axis=1).var(ddof=1)
+    if not W > 0.0:
+        return 1.0 if B == 0.0 else float('inf')
+    return float(np.sqrt(((n - 1.0) / n * W + B / n) / W))
+
+
+def _free_port():
+    sk = socket.socket()
+    sk.bind(('127.0.0.1', 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    return port
+
+
+def launch_ranks(argv, n, env_extra=None, relay_rank0=True, local_ranks=None):
+    """Start ``argv`` n times as child processes with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*
+    set (one rank per GPU) and wait for them: the caller makes no GPU call, so nothing is
+    inherited.  Rank 0 inherits stdout when ``relay_rank0`` (its output is the job's), the
+    others' goes to stderr.  When a rank fails the others are terminated - exactly the PIDs
+    started here - and the first non-zero exit code is returned."""
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        lr = r if local_ranks is None else local_ranks[r]
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(lr), WORLD_SIZE=str(n),
+                   LOCAL_WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        if env_extra:
+            env.update(env_extra)
+        procs.append(subprocess.Popen(list(argv), env=env,
+                                      stdout=None if (r == 0 and relay_rank0) else sys.stderr))
+    rc = 0
+    alive = set(range(n))
+    while alive:
+        for r in sorted(alive):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            alive.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                print('rank %d exited with %d; stopping the others' % (r, code), file=sys.stderr)
+                for q in alive:
+                    procs[q].terminate()
+        time.sleep(0.05)
+    return rc
+
+
+class ChainsResult(object):
+    """What ``fit_chains`` returns, the same on every rank:
+
+    ``n_chains``; ``traces`` - dict of (n_chains, n_total[, k]) arrays (``logps``, ``intercepts``,
+    ``lambdas`` when the model has them); ``X_mean`` (n_chains, T, N, D) posterior-mean (or
+    selected) positions; ``z`` (n_chains, T, N) selected partitions when the model has labels;
+    ``n_burn``; ``rhat`` - split R-hat of every scalar trace over the chains' kept iterations;
+    ``logp_mean`` per chain and ``best_chain`` (the highest); ``seconds`` per chain;
+    ``estimator`` - the fitted estimator of THIS rank (rank 0's when the chains were spawned:
+    with its large traces dropped unless ``keep_traces``)."""
+
+    def __init__(self, gathered, n_burn, estimator=None):
+        self.traces = {k: gathered[k] for k in ('logps', 'intercepts', 'lambdas') if k in gathered}
+        self.X_mean = gathered.get('X_mean')
+        self.z = gathered['z'].astype(np.int64) if 'z' in gathered else None
+        self.seconds = gathered['seconds'][:, 0]
+        self.n_chains = int(self.seconds.shape[0])
+        self.n_burn = int(n_burn)
+        self.estimator = estimator
+        self.rhat = {}
+        kept = slice(self.n_burn, None)
+        for name, tr in self.traces.items():
+            tr = tr[:, kept]
+            if tr.ndim == 2:
+                self.rhat[name] = split_rhat(tr)
+            else:
+                for j in range(tr.shape[2]):
+                    self.rhat['%s[%d]' % (name, j)] = split_rhat(tr[:, :, j])
+        self.logp_mean = self.traces['logps'][:, kept].mean(axis=1)
+        self.best_chain = int(np.argmax(self.logp_mean))
+
+    def summary(self):
+        return {'n_chains': self.n_chains, 'n_burn': self.n_burn,
+                'rhat': {k: round(v, 4) for k, v in self.rhat.items()},
+                'logp_mean': [round(float(v), 3) for v in self.logp_mean],
+                'best_chain': self.best_chain, 'seconds': [round(float(v), 3) for v in self.seconds]}
+
+
+def _chain_results(est, seconds):
+    """the per-chain arrays that travel in the final gather (float64, equal shapes on every rank)"""
+    out = {'logps': np.asarray(est.logps_, dtype=np.float64),
+           'intercepts': np.asarray(est.intercepts_, dtype=np.float64),
+           'seconds': np.array([float(seconds)])}
+    if getattr(est, 'lambdas_', None) is not None:
+        out['lambdas'] = np.asarray(est.lambdas_, dtype=np.float64)
+    xm = getattr(est, 'X_mean_', None)
+    out['X_mean'] = np.asarray(xm if xm is not None else est.X_, dtype=np.float64)
+    if getattr(est, 'z_', None) is not None:
+        out['z'] = np.asarray(est.z_, dtype=np.float64)
+    return out
+
+
+def _fit_as_rank(estimator, Y, init, group, seed_stride=1):
+    """this rank's part of ``fit_chains``: network from rank 0, fit with the rank's chain id and
+    seed, final gather"""
+    Y = group.broadcast_network(Y if group.rank == 0 else None)      # (shape header + int8 entries)
+    est = estimator
+    est.chain_id = int(getattr(est, 'chain_id', 0) or 0) + group.rank
+    est.device = group.device
+    rs = getattr(est, 'random_state', None)
+    if rs is None or isinstance(rs, (int, np.integer)):
+        est.random_state = (0 if rs is None else int(rs)) + seed_stride * group.rank
+    t0 = time.perf_counter()
+    est.fit(Y, init=init) if init is not None else est.fit(Y)
+    secs = time.perf_counter() - t0
+    gathered = group.gather_results(_chain_results(est, secs))
+    n_burn = getattr(est, 'n_burn_', 0)
+    return ChainsResult(gathered, n_burn, est)
+
+
+def fit_chains(estimator, Y, n_chains=None, init=None, backend=None, share_device0=False,
+               keep_traces=False, timeout=None):
+    """Fit ``n_chains`` independent chains of ``estimator`` (an unfitted DynamicNetworkLSM /
+    DynamicNetworkHDPLPCM / DynamicNetworkLPCM) to the network ``Y``, one chain per GPU of this
+    node, and gather them: returns a ``ChainsResult``.
+
+    * Under a launcher (``RANK`` is set: ``torch.distributed.run`` or ``launch_ranks``) every rank
+      calls this; only rank 0 needs ``Y`` (the others may pass None): it reaches them as one RCCL
+      broadcast.  Chain r uses Philox chain id ``estimator.chain_id + r`` and ``random_state + r``.
+    * Otherwise the call spawns its ranks itself, one child process per chain, before making any
+      GPU call (``n_chains=None``: one per visible device), hands them the estimator, ``init`` and
+      ``Y`` through a temporary directory, and returns rank 0's gathered result.
+      ``share_device0`` puts every rank on GPU 0 over gloo (a single-GPU box; tests).
+
+    ``backend``: 'nccl' (= RCCL; the default on a GPU box) or 'gloo'."""
+    if 'RANK' in os.environ:
+        if share_device0:
+            os.environ['LOCAL_RANK'] = '0'
+        group = init_chain_group(backend=backend)
+        try:
+            return _fit_as_rank(estimator, Y, init, group)
+        finally:
+            group.close()
+    if n_chains is None:
+        import torch
+        n_chains = max(1, torch.cuda.device_count())      # (counting devices initialises nothing)
+    n_chains = int(n_chains)
+    if backend is None:
+        backend = 'gloo' if share_device0 else 'nccl'
+    with tempfile.TemporaryDirectory(prefix='dlsm_chains_') as job:
+        Yarr = np.ascontiguousarray(Y, dtype=np.float64)
+        np.save(os.path.join(job, 'Y.npy'), Yarr.astype(np.int8))      # 0 / 1 / -1 (missing)
+        with open(os.path.join(job, 'job.pkl'), 'wb') as f:
+            pickle.dump(dict(estimator=estimator, init=init, backend=backend,
+                             share_device0=bool(share_device0), keep_traces=bool(keep_traces)), f)
+        env = {'PYTHONPATH': os.pathsep.join([p for p in sys.path if p] +
+                                             [os.environ.get('PYTHONPATH', '')])}
+        # (the module is imported, not run as __main__: the pickled result must name
+        # dynetlsm_amd.multichain.ChainsResult)
+        code = 'import sys; from dynetlsm_amd.multichain import _rank_main; _rank_main(sys.argv[1])'
+        rc = launch_ranks([sys.executable, '-c', code, job], n_chains,
+                          env_extra=env, relay_rank0=False,
+                          local_ranks=[0] * n_chains if share_device0 else None)
+        if rc != 0:
+            raise RuntimeError('fit_chains: a rank exited with code %d (its messages are on stderr)' % rc)
+        with open(os.path.join(job, 'result.pkl'), 'rb') as f:
+            return pickle.load(f)
+
+
+def _rank_main(job):
+    """entry point of a rank spawned by ``fit_chains``"""
+    with open(os.path.join(job, 'job.pkl'), 'rb') as f:
+        spec = pickle.load(f)
+    group = init_chain_group(backend=spec['backend'])
+    try:
+        Y = None
+        if group.rank == 0:
+            Y = np.load(os.path.join(job, 'Y.npy')).astype(np.float64)
+        res = _fit_as_rank(spec['estimator'], Y, spec['init'], group)
+        if group.rank == 0:
+            est = res.estimator
+            if est is not None:
+                ch = getattr(est, 'chain_', None)
+                if hasattr(est, 'release_device_trace'):
+                    est.release_device_trace(materialize=spec['keep_traces'])
+                elif ch is not None:
+                    ch.close()
+                for name in ('chain_', '_sums', 'case_control_sampler_'):
+                    est.__dict__.pop(name, None)           # device handles do not travel
+                if not spec['keep_traces']:
+                    for name in ('Xs_', 'zs_', 'weights_', 'cooccurrence_probas_', 'Y_fit_'):
+                        est.__dict__.pop(name, None)
+            with open(os.path.join(job, 'result.pkl'), 'wb') as f:
+                pickle.dump(res, f)
+    finally:
+        group.close()
+

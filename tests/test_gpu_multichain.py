@@ -187,3 +187,35 @@ def test_bench_through_rccl_in_a_group_of_one():
     # 50 ms window)
     assert abs(line['value'] / plain['value'] - 1.0) < 0.10, (line['value'], plain['value'])
     assert line['barrier_ms'] < 5.0, line['barrier_ms']
+
+
+def test_fit_chains_two_ranks_on_one_gpu_are_the_single_chain_fits(eng):
+    """config 5 as ONE call (multichain.fit_chains, the estimator-level entry point): two ranks,
+    both on cuda:0 over gloo (the box has one GPU; on an 8-GPU node the same call runs one rank per
+    GPU over RCCL).  Every chain's trace is bit for bit what a single fit with that chain id and
+    seed produces; the result carries the split R-hat over the chains."""
+    from dynetlsm_amd.multichain import fit_chains
+    rng = np.random.RandomState(3)
+    T, N = 3, 150
+    Y = (rng.rand(T, N, N) < 0.08).astype(np.float64)
+    Y = np.triu(Y, 1); Y = Y + Y.transpose(0, 2, 1)
+    kw = dict(n_iter=60, tune=20, burn=20, n_components=5, selection_type='map')
+    res = fit_chains(eng.DynamicNetworkHDPLPCM(random_state=4, chain_id=0, **kw), Y, n_chains=2,
+                     share_device0=True)
+    assert res.n_chains == 2 and res.n_burn == 40
+    assert res.traces['logps'].shape == (2, 100) and res.traces['lambdas'].shape == (2, 100, 1)
+    assert res.X_mean.shape == (2, T, N, 2) and res.z.shape == (2, T, N)
+    for r in range(2):
+        m = eng.DynamicNetworkHDPLPCM(random_state=4 + r, chain_id=r, **kw).fit(Y)
+        np.testing.assert_array_equal(res.traces['logps'][r], m.logps_)
+        np.testing.assert_array_equal(res.traces['lambdas'][r], m.lambdas_)
+        np.testing.assert_array_equal(res.z[r], m.z_)
+        np.testing.assert_array_equal(res.X_mean[r], m.X_mean_)
+        m.chain_.close()
+    assert np.isfinite(res.rhat['logps']) and 'lambdas[0]' in res.rhat
+    assert res.estimator.selected_id_ >= 40 and 'chain_' not in vars(res.estimator)
+    # the LSM through the same call
+    res = fit_chains(eng.DynamicNetworkLSM(n_iter=40, tune=10, burn=10, random_state=1), Y, n_chains=2,
+                     share_device0=True)
+    assert res.traces['logps'].shape == (2, 60) and res.z is None and res.X_mean.shape == (2, T, N, 2)
+    assert not np.array_equal(res.traces['logps'][0], res.traces['logps'][1])

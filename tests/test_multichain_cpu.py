@@ -118,3 +118,45 @@ def test_bench_self_launch_propagates_rank_failure():
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert p.returncode != 0
     assert b'"metric"' not in p.stdout
+
+
+def test_fit_chains_spawns_its_ranks_and_gathers(tmp_path):
+    """multichain.fit_chains from a plain process: one child per chain (gloo, world size 2), the
+    network from rank 0 (a missing dyad included), chain ids and seeds offset by the rank, traces and
+    selected partitions gathered, split R-hat over the chains"""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import numpy as np
+    from dynetlsm_amd.multichain import fit_chains, split_rhat
+    from standin_estimator import StandInEstimator
+    rng = np.random.RandomState(0)
+    Y = (rng.rand(3, 9, 9) < 0.3).astype(np.float64)
+    Y[1, 2, 3] = -1
+    res = fit_chains(StandInEstimator(n_iter=60, random_state=5, chain_id=2), Y, n_chains=2,
+                     init=dict(shift=0.25), backend='gloo')
+    assert res.n_chains == 2 and res.n_burn == 10
+    assert res.traces['logps'].shape == (2, 60) and res.traces['intercepts'].shape == (2, 60, 1)
+    assert res.X_mean.shape == (2, 3, 9, 2) and res.z.shape == (2, 3, 9) and res.z.dtype == np.int64
+    # every rank ran ITS chain: id and seed offset by the rank, the same network and init everywhere
+    for r in range(2):
+        want = StandInEstimator(n_iter=60, random_state=5 + r, chain_id=2 + r).fit(Y, init=dict(shift=0.25))
+        np.testing.assert_array_equal(res.traces['logps'][r], want.logps_)
+        np.testing.assert_array_equal(res.z[r], want.z_)
+    assert not np.array_equal(res.traces['logps'][0], res.traces['logps'][1])
+    assert res.rhat['logps'] == split_rhat(res.traces['logps'][:, 10:])
+    assert 0.9 < res.rhat['logps'] < 1.5 and 'intercepts[0]' in res.rhat
+    assert res.best_chain == int(np.argmax(res.traces['logps'][:, 10:].mean(axis=1)))
+    assert res.estimator.chain_id == 2 and res.estimator.seen_missing_ == 1      # rank 0's
+    assert set(res.summary()) >= {'n_chains', 'rhat', 'best_chain'}
+
+
+def test_fit_chains_reports_a_failing_rank():
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import numpy as np
+    import pytest
+    from dynetlsm_amd.multichain import fit_chains
+    from standin_estimator import StandInEstimator
+    with pytest.raises(RuntimeError, match='rank exited'):
+        fit_chains(StandInEstimator(n_iter=20, fail_on_chain=1), np.zeros((2, 5, 5)), n_chains=2,
+                   backend='gloo')
