@@ -248,8 +248,8 @@ def test_bad_inputs_fail_loudly(eng):
         c.upload_network(Yu); c.set_positions(X)
         with pytest.raises(eng.EngineError):
             c.sweep_positions(1)                   # samplers / prior missing
-    with pytest.raises(eng.EngineError):
-        eng.Chain(2, 10, 9, 'undirected')          # unsupported n_features
+    with pytest.raises(ValueError, match='1 <= n_features <= 4'):
+        eng.Chain(2, 10, 9, 'undirected')          # unsupported n_features: named before any device call
 
 
 # ------------------------------------------------------------ sweep
