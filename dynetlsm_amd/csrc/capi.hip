@@ -27,6 +27,7 @@
 #include "kernels_init.hpp"
 #include "kernels_post.hpp"
 #include "kernels_forecast.hpp"
+#include "kernels_batch.hpp"
 #include "host_draws.hpp"
 
 using namespace dlsm;
@@ -68,6 +69,7 @@ static thread_local std::string g_err;
 // them drops the graph (it is rebuilt by the next dlsm_lsm_run).
 static int check_pipe_err(dlsm_chain *h);
 static int check_sweep_algo(dlsm_chain *h, int algo);
+static void batch_forget(dlsm_chain *h);
 
 static void drop_graph(dlsm_chain *h) {
     if (h->graph_exec) hipGraphExecDestroy(h->graph_exec);
@@ -363,6 +365,10 @@ void dlsm_destroy(dlsm_chain *h) {
     if (!h) return;
     hipSetDevice(h->device);
     if (h->stream) hipStreamSynchronize(h->stream);
+    if (h->batch) {                 // still in a batch: its stream is the batch's, not this chain's to destroy
+        batch_forget(h);
+        h->stream = h->own_stream; h->own_stream = nullptr; h->batch = nullptr;
+    }
     drain_profile(h);
     void *ptrs[] = {h->ybits, h->ytbits, h->in_edges, h->out_edges, h->degree,
                     h->ctrl_in, h->ctrl_out, h->X, h->intercept, h->radii,
@@ -998,7 +1004,7 @@ static void launch_pipe_persist(dlsm_chain *h, const ChainView &v, const PipeBuf
 // G = batches resolved (and evaluated) per launch: algo 4: 1, algo 6: 2; persist: algo 7 (G = 1)
 template <int DD>
 static int launch_sweep_pipe(dlsm_chain *h, IterRef iter, bool alloc_only = false, int G = 1,
-                             bool persist = false) {
+                             bool persist = false, PipeBuf *pb_out = nullptr) {
     const int N = h->N, T = h->T;
     const int nbat = (N + PP_B - 1) / PP_B;
     const bool cc = h->model == DLSM_DIRECTED_CASE_CONTROL;
@@ -1082,6 +1088,7 @@ static int launch_sweep_pipe(dlsm_chain *h, IterRef iter, bool alloc_only = fals
                                   (int)lds));
     HIPCHK(h, hipFuncSetAttribute((const void *)k_pipe_last_ride<DD>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (pb_out) { *pb_out = pb; return DLSM_OK; }      // (the batch form launches its own kernels)
     if (alloc_only) return DLSM_OK;
     ChainView v = h->view();
     {   // the proposal pass, unless the previous iteration's last launch carried it
@@ -1949,6 +1956,7 @@ int dlsm_timer_stop(dlsm_chain *h, double *ms) {
 #include "capi_post.hpp"
 #include "capi_forecast.hpp"
 #include "capi_hdp.hpp"
+#include "capi_batch.hpp"
 
 extern "C" int dlsm_host_sample_tables(void *numpy_bitgen, int T, int K, const double *n,
                                        const double *beta, double alpha_init, double alpha,

@@ -94,6 +94,8 @@ struct dlsm_chain {
     uint64_t seed = 0; uint32_t chain = 0;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;          // second queue of the speculative sweep
+    // member of a dlsm_batch: `stream` is the batch's shared stream, the chain's own is parked here
+    hipStream_t own_stream = nullptr; void *batch = nullptr;
     void *stage = nullptr;                  // pinned host staging for the small copies of the C-ABI
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
     // network

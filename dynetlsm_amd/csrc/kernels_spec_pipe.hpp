@@ -1083,23 +1083,21 @@ __global__ __launch_bounds__(PP_THREADS) void k_pipe_step(ChainView c, PipeBuf p
 // resolver workgroups sum themselves once they have settled them (records nwg .. nwg + T - 1).
 // The resolver workgroups run exactly what k_pipe_step runs for them before that.
 struct PipePostRide { const double *xref; IterRef ir; double *rec; int nwg, jl, par; };
+// workgroup `bx` of T + nwg (the LDS of k_pipe_step's resolvers is the caller's)
 template <int D>
-__global__ __launch_bounds__(PP_THREADS) void k_pipe_last_ride(ChainView c, PipeBuf pb, int l, PipePostRide pr) {
-    extern __shared__ __attribute__((aligned(16))) double pp_sH[];      // 128 x 128
-    __shared__ double sPart[PP_WAVES * 64];
-    __shared__ unsigned long long sMask[2][2];
-    __shared__ int sPrev[3 * PP_B];
-    __shared__ int sOwn[PP_B + 1];
-    __shared__ unsigned char sSat[PP_B];
+__device__ __forceinline__ void pipe_last_ride_wg(const ChainView &c, const PipeBuf &pb, int l,
+                                                  const PipePostRide &pr, int bx, double *pp_sH,
+                                                  double *sPart, unsigned long long (*sMask)[2],
+                                                  int *sPrev, int *sOwn, unsigned char *sSat) {
     const int T = c.T;
-    if ((int)blockIdx.x < T) {
+    if (bx < T) {
         // The rows this launch is still moving (nodes i >= jl of this slice) and the difference terms
         // that touch them are summed HERE, by the workgroup that has just settled them, into record
         // nwg + t: nobody else may read those rows while the launch runs, and the centring pass may
         // not read any position at all once its workgroups have begun to rewrite them in place.
         constexpr int W = PostRec<D>::W;
         __shared__ double sRedL[W][PP_WAVES];
-        const int t = blockIdx.x, tid = threadIdx.x;
+        const int t = bx, tid = threadIdx.x;
         const int b = l - (t & 1);
         const bool mine = b >= 0 && b < pb.nbat;
         if (mine)
@@ -1135,7 +1133,18 @@ __global__ __launch_bounds__(PP_THREADS) void k_pipe_last_ride(ChainView c, Pipe
         }
         return;
     }
-    post_reduce_wg<D, PP_THREADS>(c, pr.xref, -1, pr.ir, pr.rec, (int)blockIdx.x - T, pr.nwg, pr.jl, pr.par);
+    post_reduce_wg<D, PP_THREADS>(c, pr.xref, -1, pr.ir, pr.rec, bx - T, pr.nwg, pr.jl, pr.par);
+}
+
+template <int D>
+__global__ __launch_bounds__(PP_THREADS) void k_pipe_last_ride(ChainView c, PipeBuf pb, int l, PipePostRide pr) {
+    extern __shared__ __attribute__((aligned(16))) double pp_sH[];      // 128 x 128
+    __shared__ double sPart[PP_WAVES * 64];
+    __shared__ unsigned long long sMask[2][2];
+    __shared__ int sPrev[3 * PP_B];
+    __shared__ int sOwn[PP_B + 1];
+    __shared__ unsigned char sSat[PP_B];
+    pipe_last_ride_wg<D>(c, pb, l, pr, (int)blockIdx.x, pp_sH, sPart, sMask, sPrev, sOwn, sSat);
 }
 
 }  // namespace dlsm

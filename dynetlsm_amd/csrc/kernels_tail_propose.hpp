@@ -46,12 +46,14 @@ struct PostFusedArgs {
     double *trace_X;
 };
 static_assert(PS2_THREADS == 256, "the proposal pass is laid out for 256 threads");
+// workgroup `bx` of 1 + nblk (nblk = the proposal pass's workgroups)
 template <int D>
-__global__ __launch_bounds__(256) void k_lsm_finalize_apply_propose(
+__device__ __forceinline__ void lsm_finalize_apply_propose_wg(
     const double *__restrict__ partials, int nrec, LsmDeviceState *lsm,
     double *__restrict__ intercept, double *__restrict__ trace_ic,
-    double *__restrict__ trace_logp, IterRef ir, ChainView c, ProposeBuf nb, PostFusedArgs pa) {
-    if (blockIdx.x == 0) {
+    double *__restrict__ trace_logp, IterRef ir, const ChainView &c, const ProposeBuf &nb,
+    const PostFusedArgs &pa, int bx, int nblk) {
+    if (bx == 0) {
         // sums, R, shift and the latent prior terms (lsm->prior_x); no rows, no intercept draw
         post_apply_wg<D>(c, pa.has_ref, pa.n_iter_procrustes, 1, pa.rec, pa.nrec, lsm, ir, nullptr, nullptr,
                          nullptr, 0, 0, 1, pa.jl, pa.par, pa.xref_rows, false, 0);
@@ -71,8 +73,16 @@ __global__ __launch_bounds__(256) void k_lsm_finalize_apply_propose(
         pipe_propose_row_from<D>(c, nb, next, t, j, x0);
     };
     post_apply_wg<D>(c, pa.has_ref, pa.n_iter_procrustes, 1, pa.rec, pa.nrec, nullptr, ir, nullptr, pa.trace_X,
-                     nullptr, 0, (int)blockIdx.x - 1, (int)gridDim.x - 1, pa.jl, pa.par, pa.xref_rows, true, 0,
-                     hook);
+                     nullptr, 0, bx - 1, nblk, pa.jl, pa.par, pa.xref_rows, true, 0, hook);
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void k_lsm_finalize_apply_propose(
+    const double *__restrict__ partials, int nrec, LsmDeviceState *lsm,
+    double *__restrict__ intercept, double *__restrict__ trace_ic,
+    double *__restrict__ trace_logp, IterRef ir, ChainView c, ProposeBuf nb, PostFusedArgs pa) {
+    lsm_finalize_apply_propose_wg<D>(partials, nrec, lsm, intercept, trace_ic, trace_logp, ir, c, nb, pa,
+                                     (int)blockIdx.x, (int)gridDim.x - 1);
 }
 
 static_assert(HH_THREADS == 256, "the proposal pass is laid out for 256 threads");

@@ -211,6 +211,28 @@ int dlsm_trace_read(dlsm_chain *h, int first, int count, double *Xs,
 /* rows first .. first+count-1 of the radii trace (count*N), directed models */
 int dlsm_trace_read_radii(dlsm_chain *h, int first, int count, double *radii);
 
+/* ---- several chains of one network in shared launches ------------------------------------
+ * The reference refits seeds one after the other (examples/homogeneous_simulation.py:177-184:
+ * `for i in range(n_reps): ... random_state=i`).  A batch drives up to 8 chains of the SAME
+ * network on one GPU (undirected model; same device, shape and `squared`; the networks are
+ * compared word for word at creation) through shared launches of the pipelined sweep: the
+ * chains' resolver workgroups side by side, ONE pool of evaluator items over all chains, the
+ * launch floors paid once per batch instead of once per chain.  Every chain keeps its own state,
+ * configuration, trace and Philox chain id, and every other entry point of this header keeps
+ * working on a member chain (its calls order on the batch's stream); a chain's trace is bit for
+ * bit the one dlsm_lsm_run produces for it alone.  Destroy the batch before its chains. */
+typedef struct dlsm_batch dlsm_batch;
+int dlsm_batch_create(dlsm_chain *const *chains, int n, dlsm_batch **out);
+void dlsm_batch_destroy(dlsm_batch *b);
+/* dlsm_lsm_run(first, count, procrustes_ref) for every chain of the batch.  Asynchronous. */
+int dlsm_batch_lsm_run(dlsm_batch *b, int first, int count, int procrustes_ref);
+int dlsm_batch_synchronize(dlsm_batch *b);
+/* iterations that ran through shared launches / chain by chain so far (the first and the last
+ * iteration of a call run chain by chain, as in dlsm_lsm_run; so does every iteration when the
+ * chains are configured differently or use another sweep than algo 4) */
+int dlsm_batch_stats(dlsm_batch *b, int64_t *merged, int64_t *single);
+const char *dlsm_batch_last_error(const dlsm_batch *b);
+
 /* ---- device-resident HDP-LPCM chain (hdp_lpcm.py:823-1069, undirected model) --------
  * the whole Gibbs iteration of DynamicNetworkHDPLPCM._fit on the device -
  * sweep with the AR-mixture prior, centring, intercept MH, label block update
