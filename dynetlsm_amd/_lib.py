@@ -48,7 +48,13 @@ class HdpConfig(C.Structure):
                 ('i_step_size', C.c_double), ('i_n_accepted', C.c_int32),
                 ('i_n_steps', C.c_int32), ('i_steps_until_tune', C.c_int32),
                 ('i_tune', C.c_int32), ('i_tune_interval', C.c_int32),
-                ('sweep_algo', C.c_int32)]
+                ('sweep_algo', C.c_int32),
+                # directed models: intercept_out and the radii sampler
+                ('intercept_prior_out', C.c_double), ('i_step_size_out', C.c_double),
+                ('i_n_accepted_out', C.c_int32), ('i_n_steps_out', C.c_int32),
+                ('i_steps_until_tune_out', C.c_int32), ('r_tune', C.c_int32),
+                ('r_step_size', C.c_double), ('r_n_accepted', C.c_int32), ('r_n_steps', C.c_int32),
+                ('r_steps_until_tune', C.c_int32), ('r_tune_interval', C.c_int32)]
 
 
 class EngineError(RuntimeError):

@@ -53,10 +53,60 @@ int enqueue_hdp_iteration(dlsm_chain *h, int it, bool draw_next) {
     if (rc) return rc;
     const bool rode = h->post_ride_done;
     h->post_ride_done = false;
+    const bool directed = h->model != DLSM_UNDIRECTED;
+    if (directed) {
+        // hdp_lpcm.py:855-874 with is_directed: centring, intercept_in, intercept_out and the radii
+        // step around three likelihood passes - the launches of dlsm_lsm_run's directed loop
+        // (enqueue_lsm_iteration, kernels_dirloop.hpp), without a Procrustes reference and with the
+        // last launch leaving the network log-likelihood of the stored state in the row's
+        // log-posterior slot (the batched pass behind the run turns it into the log-posterior)
+        const bool pf = cc_prefetch_form(h);
+        if (pf) { rc = ensure_xr<DD>(h); if (rc) return rc; }
+        ChainView vd = h->view();
+        double *ll2 = h->dsmall + 16;
+        const int nblk = (h->N + DP_THREADS - 1) / DP_THREADS;
+        constexpr int PW_MAX = 2 * 4 + 4 * 4 + 2;           // PostRec<4>::W
+        const size_t n_post = (size_t)PS_BLOCKS * PW_MAX;
+        rc = ensure_partials(h, (size_t)ll_blocks(h) * 4 + n_post + (size_t)nblk * (1 + DP_COLS));
+        if (rc) return rc;
+        double *prec = h->partials + (size_t)ll_blocks(h) * 4;
+        double *rrec = prec + n_post, *rrec2 = rrec + nblk;
+        double *xr = pf ? h->xr : nullptr;
+        const long rows = (long)h->T * h->N;
+        const int nbp = (int)std::min<long>(PS_BLOCKS, (rows + PS2_THREADS - 1) / PS2_THREADS);
+        {
+            ProfScope psc(h, DLSM_K_CENTER);
+            const DirRider rg{1, nblk, h->radii, h->radii_alt, rrec, rrec2, xr};
+            hipLaunchKernelGGL((k_post_reduce_dir<DD>), dim3(nbp + nblk), dim3(PS2_THREADS), 0, h->stream, vd,
+                               (const double *)nullptr, 0, ir, prec, nbp, h->lsm, rg);
+            hipLaunchKernelGGL((k_post_apply_dir<DD>), dim3(nbp + nblk), dim3(PS2_THREADS), 0, h->stream, vd, 0, 0,
+                               1, prec, nbp, h->lsm, ir, h->trace_X, xr, nbp, rg);
+        }
+        {
+            ProfScope psf(h, DLSM_K_FINALIZE);
+            int nrec_d = 0;
+            for (int which = 0; which < 2; ++which) {
+                const int M = which == 0 ? 2 : 1;
+                rc = loglik_records(h, M, h->lsm->cand, h->radii, h->radii, &nrec_d, pf || which == 1);
+                if (rc) return rc;
+                const DirRider rd{which == 0 ? 3 : 0, nblk, h->radii, h->radii_alt, rrec, rrec2, xr};
+                hipLaunchKernelGGL((k_dir_reduce_accept_intercept<DD>), dim3(1 + (which == 0 ? 1 : 0)), dim3(256), 0,
+                                   h->stream, h->partials, nrec_d, M, ll2, vd, h->lsm, h->intercept, which, which,
+                                   which == 0 ? 1 : -1, ir, rd);
+            }
+            rc = loglik_records(h, 1, h->intercept, h->radii_alt, h->radii_alt, &nrec_d, pf, 1);
+            if (rc) return rc;
+            hipLaunchKernelGGL((k_dir_tail<DD>), dim3(1), dim3(DR_THREADS), 0, h->stream, h->partials, nrec_d, ll2,
+                               vd, h->lsm, h->radii, h->radii_alt, h->intercept, h->trace_ic, h->trace_radii,
+                               h->trace_logp, ir, h->next_prop, 0, 1);
+        }
+        HIPCHK(h, hipGetLastError());
+    } else {
     // centring; workgroup 0 draws the intercept proposal; the positions' trace row
     rc = launch_post<DD>(h, nullptr, 0, 1, h->lsm, ir, nullptr, false, h->trace_X, nullptr,
                          rode ? h->post_ride_nwg : 0, h->post_ride_jl, h->post_ride_par);
     if (rc) return rc;
+    }
     // The label block update needs the centred positions and last iteration's mixture, not the
     // intercept's likelihood records (33 us at config 3), and those do not need the labels: with
     // DLSM_HDP_QUEUES=2 the labels go to a second queue beside them.  Opt-in: on MI355X the two
@@ -83,12 +133,13 @@ int enqueue_hdp_iteration(dlsm_chain *h, int it, bool draw_next) {
         if (fork) HIPCHK(h, hipEventRecord(h->ev_b, h->stream2));
     }
     int nrec = 0;
-    rc = loglik_records(h, 2, h->lsm->cand, nullptr, nullptr, &nrec); if (rc) return rc;
+    if (!directed) { rc = loglik_records(h, 2, h->lsm->cand, nullptr, nullptr, &nrec); if (rc) return rc; }
     if (fork) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_b, 0));
     ProfScope ps(h, DLSM_K_HDP_TAIL);
     const int n_tab = (T * K * K + HT_WAVES - 1) / HT_WAVES;
-    hipLaunchKernelGGL((k_hdp_stage1<DD>), dim3(n_tab + K * T + 1), dim3(HDP_THREADS), 0, h->stream, v,
-                       hb, h->hdp, h->lsm, h->partials, nrec, h->intercept, h->trace_ic, ir);
+    // (directed models: the intercepts were settled above - the launch goes without the role's workgroup)
+    hipLaunchKernelGGL((k_hdp_stage1<DD>), dim3(n_tab + K * T + (directed ? 0 : 1)), dim3(HDP_THREADS), 0,
+                       h->stream, v, hb, h->hdp, h->lsm, h->partials, nrec, h->intercept, h->trace_ic, ir);
     hipLaunchKernelGGL((k_hdp_stage2<DD>), dim3(2 + K * T), dim3(HDP_THREADS), 0, h->stream, v, hb,
                        h->hdp, ir);
     hipLaunchKernelGGL((k_hdp_stage3<DD>), dim3(HW_SPLIT * (T - 1) + 1 + K * T), dim3(HDP_THREADS),
@@ -131,7 +182,7 @@ int enqueue_hdp_logp_batch(dlsm_chain *h, int first, int count) {
 }
 
 int check_ready_hdp(dlsm_chain *h) {
-    NEED(h, h->model == DLSM_UNDIRECTED, "the device-resident HDP-LPCM loop covers the undirected model");
+    NEED(h, h->model == DLSM_UNDIRECTED || h->have_radii, "radii not set");
     NEED(h, h->have_prior && h->prior_kind == DLSM_PRIOR_MIXTURE,
          "set the mixture prior (mu, sigma, lmbda, z) first");
     return check_ready_sweep(h);
@@ -189,14 +240,27 @@ int dlsm_hdp_configure(dlsm_chain *h, const dlsm_hdp_config *cfg, const double *
     ls.i_until[0] = cfg->i_steps_until_tune;
     ls.i_tune = cfg->i_tune < 0 ? -1 : cfg->i_tune;
     ls.i_tune_interval = cfg->i_tune_interval;
+    if (h->model != DLSM_UNDIRECTED) {      // intercept_out and the radii sampler
+        NEED(h, cfg->i_step_size_out > 0 && cfg->r_step_size > 0, "directed models: step sizes must be positive");
+        ls.intercept_prior[1] = cfg->intercept_prior_out;
+        ls.i_step[1] = cfg->i_step_size_out;
+        ls.i_nacc[1] = cfg->i_n_accepted_out; ls.i_nsteps[1] = cfg->i_n_steps_out;
+        ls.i_until[1] = cfg->i_steps_until_tune_out;
+        ls.r_step = cfg->r_step_size;
+        ls.r_nacc = cfg->r_n_accepted; ls.r_nsteps = cfg->r_n_steps; ls.r_until = cfg->r_steps_until_tune;
+        ls.r_tune = cfg->r_tune < 0 ? -1 : cfg->r_tune;
+        ls.r_tune_interval = cfg->r_tune_interval > 0 ? cfg->r_tune_interval : 100;
+    }
     HIPCHK(h, hipMemcpy(h->lsm, &ls, sizeof(ls), hipMemcpyHostToDevice));
     HdpLoopBuf hb = hdp_loop_buf(h);
     rc = h2d(h, hb.beta, beta, (size_t)K); if (rc) return rc;
     rc = h2d(h, h->lab_w, weights, (size_t)T * K * K); if (rc) return rc;
     // allocations of the sweep / post / log-likelihood launchers (so that the run only enqueues)
     rc = enqueue_sweep(h, IterRef{0, nullptr}, cfg->sweep_algo, true); if (rc) return rc;
-    DISPATCH_D(h, h->D, rc = launch_post<DD>(h, nullptr, 0, 1, h->lsm, IterRef{0, nullptr}, nullptr, true));
-    if (rc) return rc;
+    if (h->model == DLSM_UNDIRECTED) {
+        DISPATCH_D(h, h->D, rc = launch_post<DD>(h, nullptr, 0, 1, h->lsm, IterRef{0, nullptr}, nullptr, true));
+        if (rc) return rc;
+    }
     h->hdp_cfg = *cfg;
     h->hdp_configured = true;
     return DLSM_OK;
@@ -217,6 +281,12 @@ int dlsm_hdp_get_config(dlsm_chain *h, dlsm_hdp_config *cfg) {
     cfg->mean_variance_prior = s.mvp; cfg->b = s.b;
     cfg->i_step_size = ls.i_step[0]; cfg->i_n_accepted = ls.i_nacc[0];
     cfg->i_n_steps = ls.i_nsteps[0]; cfg->i_steps_until_tune = ls.i_until[0];
+    if (h->model != DLSM_UNDIRECTED) {
+        cfg->i_step_size_out = ls.i_step[1]; cfg->i_n_accepted_out = ls.i_nacc[1];
+        cfg->i_n_steps_out = ls.i_nsteps[1]; cfg->i_steps_until_tune_out = ls.i_until[1];
+        cfg->r_step_size = ls.r_step; cfg->r_n_accepted = ls.r_nacc; cfg->r_n_steps = ls.r_nsteps;
+        cfg->r_steps_until_tune = ls.r_until;
+    }
     return DLSM_OK;
 }
 
@@ -249,8 +319,10 @@ int dlsm_hdp_trace_alloc(dlsm_chain *h, int n_total, double logp0) {
     HIPCHK(h, hipMemcpyAsync(h->htr_w, h->lab_w, T * K * K * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->htr_lambda, &h->hdp->lmbda, sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->htr_hyper, hy, sizeof(hy), hipMemcpyHostToDevice, h->stream));
-    // row 0's network log-likelihood is not known here (NaN: "evaluate it if you need it")
-    HIPCHK(h, hipMemcpyAsync(h->trace_ic + 1, &nanv, sizeof(double), hipMemcpyHostToDevice, h->stream));
+    // row 0's network log-likelihood is not known here (NaN: "evaluate it if you need it"); the
+    // directed models keep intercept_out in that slot
+    if (h->model == DLSM_UNDIRECTED)
+        HIPCHK(h, hipMemcpyAsync(h->trace_ic + 1, &nanv, sizeof(double), hipMemcpyHostToDevice, h->stream));
     const long tn = (long)(T * N);
     hipLaunchKernelGGL(k_hdp_trace_labels, dim3((unsigned)((tn + 255) / 256)), dim3(256), 0, h->stream,
                        h->z, tn, h->htr_z);
@@ -328,7 +400,9 @@ int dlsm_hdp_trace_write(dlsm_chain *h, int first, int count, const double *Xs,
     HIPCHK(h, put(h->htr_beta, betas, K));
     HIPCHK(h, put(h->htr_w, weights, T * K * K));
     HIPCHK(h, put(h->htr_lambda, lambdas, 1));
-    if (intercepts) {                       // the device keeps two per row (undirected: the second unused)
+    if (intercepts && h->model != DLSM_UNDIRECTED) {
+        HIPCHK(h, hipMemcpy(h->trace_ic + 2 * f, intercepts, c * 2 * sizeof(double), hipMemcpyHostToDevice));
+    } else if (intercepts) {                // the device keeps two per row (undirected: the second unused)
         std::vector<double> tmp(c * 2, std::nan(""));    // (second slot: network log-likelihood, unknown)
         for (size_t q = 0; q < c; ++q) tmp[2 * q] = intercepts[q];
         HIPCHK(h, hipMemcpy(h->trace_ic + 2 * f, tmp.data(), tmp.size() * sizeof(double),

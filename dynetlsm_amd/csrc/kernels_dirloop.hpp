@@ -255,7 +255,7 @@ __global__ __launch_bounds__(DR_THREADS) void k_dir_tail(
     LsmDeviceState *lsm, double *__restrict__ radii, const double *__restrict__ radii_alt,
     const double *__restrict__ intercept, double *__restrict__ trace_ic,
     double *__restrict__ trace_radii, double *__restrict__ trace_logp, IterRef ir, ProposeBuf nb,
-    int ride) {
+    int ride, int hdp_mode = 0) {
     const int tid = threadIdx.x, N = c.N;
     if (blockIdx.x > 0) {
         const int fb = ((int)blockIdx.x - 1) * (DR_THREADS / 256) + (tid >> 8);
@@ -296,7 +296,9 @@ __global__ __launch_bounds__(DR_THREADS) void k_dir_tail(
         const double d0 = b0 - lsm->intercept_prior[0], d1 = b1 - lsm->intercept_prior[1];
         trace_ic[(size_t)it * 2] = b0;
         trace_ic[(size_t)it * 2 + 1] = b1;
-        trace_logp[it] = llf + lsm->prior_x - 0.5 * (d0 * d0 + d1 * d1) / v;   // lsm.py:604-623
+        // (HDP-LPCM loop: the row's log-posterior is computed after the run from the trace; until
+        // then the slot carries the network log-likelihood of the stored state)
+        trace_logp[it] = hdp_mode ? llf : llf + lsm->prior_x - 0.5 * (d0 * d0 + d1 * d1) / v;   // lsm.py:604-623
         if (ride) pipe_propose_consts(c, nb.consts, intercept);
     }
 }

@@ -922,9 +922,17 @@ __global__ __launch_bounds__(HF_THREADS) void k_hdp_logp_batch_finish(ChainView 
         }
     const double body = block_sum_all<HF_THREADS / 64>(acc, red, tid);
     if (tid != 0) return;
-    double lp = body + tv.ic[s * 2 + 1];                        // + the network log-likelihood
+    // + the network log-likelihood: the undirected model's second intercept slot; the directed
+    // models use both slots and park it in the row's log-posterior slot (k_dir_tail)
+    const bool directed = c.model != DLSM_UNDIRECTED;
+    double lp = body + (directed ? tv.logp[s] : tv.ic[s * 2 + 1]);
     {   // intercept prior, cluster means, blending coefficient, hyper-priors
         const double b = tv.ic[s * 2], diff = b - lsm->intercept_prior[0];
+        if (directed) {                 // hdp_lpcm.py:1234-1237, :1268-1269 (flat Dirichlet: log Gamma(N))
+            const double diff1 = tv.ic[s * 2 + 1] - lsm->intercept_prior[1];
+            lp -= (0.5 * (diff * diff) / lsm->intercept_var + 0.5 * (diff1 * diff1) / lsm->intercept_var);
+            lp += lgamma((double)c.N);
+        } else
         lp -= 0.5 * (diff * diff) / lsm->intercept_var;
         double ss = 0.0;
         for (int q = 0; q < K * D; ++q) ss += tv.mu[s * K * D + q] * tv.mu[s * K * D + q];

@@ -401,7 +401,7 @@ class Chain(object):
     # -- device-resident HDP-LPCM loop -------------------------
     def hdp_configure(self, hp, beta, weights, intercept_prior, intercept_variance_prior,
                       step_size_intercept=0.1, tune=None, tune_interval=100, sweep_algo=0,
-                      state=None):
+                      state=None, step_size_radii=175000., radii_tune=None, radii_tune_interval=100):
         """``hp``: an object with the HDP-LPCM's hyper-parameters as attributes (gamma,
         alpha_init, alpha, kappa, mean_variance_prior, b, a, a0, b0, c0, d0 - None switches an
         update off -, lambda_prior, lambda_variance_prior, *_prior_shape / *_rate); beta (K,),
@@ -428,6 +428,17 @@ class Chain(object):
         cfg.i_tune = -1 if tune is None else int(tune)
         cfg.i_tune_interval = int(tune_interval)
         cfg.sweep_algo = int(sweep_algo)
+        if self.model != UNDIRECTED:        # intercept_out and the radii sampler (hdp_lpcm.py:731-747)
+            ip = np.ravel(np.asarray(intercept_prior, dtype=np.float64))
+            cfg.intercept_prior_out = float(ip[1] if ip.size > 1 else ip[0])
+            cfg.i_step_size_out = float(step_size_intercept)
+            cfg.i_n_accepted_out, cfg.i_n_steps_out = 0, 0
+            cfg.i_steps_until_tune_out = int(tune_interval)
+            cfg.r_step_size = float(step_size_radii)
+            cfg.r_n_accepted, cfg.r_n_steps = 0, 0
+            cfg.r_steps_until_tune = int(radii_tune_interval)
+            cfg.r_tune = -1 if radii_tune is None else int(radii_tune)
+            cfg.r_tune_interval = int(radii_tune_interval)
         beta = _f64(beta, (K,), 'beta')
         weights = _f64(weights, (self.T, K, K), 'weights')
         self._ck(self._L.dlsm_hdp_configure(self._h, C.byref(cfg), _p(beta), _p(weights)))
@@ -466,11 +477,13 @@ class Chain(object):
         self._ck(self._L.dlsm_hdp_trace_read(
             self._h, int(first), int(count), ptr('Xs'), ptr('intercepts'), ptr('logps'), ptr('mus'),
             ptr('sigmas'), ptr('zs'), ptr('betas'), ptr('weights'), ptr('lambdas'), ptr('hypers')))
-        if small:
+        if small and self.model == UNDIRECTED:
             # (undirected device loop: the second slot carries the network log-likelihood of the
             # stored state, NaN where it is not known)
             out['logliks'] = out['intercepts'][:, 1].copy()
             out['intercepts'] = out['intercepts'][:, :1]
+        elif small:
+            out['logliks'] = np.full(count, np.nan)
         return out
 
     def hdp_trace_write(self, first, Xs=None, intercepts=None, logps=None, mus=None, sigmas=None,
@@ -487,7 +500,8 @@ class Chain(object):
         zz = None if zs is None else _i64(zs, (count, T, N), 'zs')
         self._ck(self._L.dlsm_hdp_trace_write(
             self._h, int(first), count, f(Xs, (T, N, D)),
-            None if intercepts is None else _p(_f64(np.reshape(intercepts, (count, -1))[:, 0].copy())),
+            None if intercepts is None else _p(_f64(
+                np.reshape(intercepts, (count, -1))[:, :self.n_intercepts].copy())),
             f(logps, ()), f(mus, (K, D)), f(sigmas, (K,)), None if zz is None else _p(zz),
             f(betas, (K,)), f(weights, (T, K, K)), f(lambdas, ())))
 

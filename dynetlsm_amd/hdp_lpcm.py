@@ -48,10 +48,11 @@ class DynamicNetworkHDPLPCM(FittedQuantities):
 
     ``hdp_loop='device'`` runs the whole Gibbs iteration on the GPU (``dlsm_hdp_run``: every
     draw of hdp_lpcm.py:876-1023 from Philox counters, no host round trip inside an
-    iteration); ``'host'`` keeps the auxiliary / conjugate draws in numpy on the caller's
-    MT19937 stream in the reference's order (the bit-level pin to the reference's ``_fit``
-    trace, and the only form for directed models).  ``'auto'`` = device for undirected
-    models, host otherwise.  The two are equal in distribution.
+    iteration; directed and case-control models too: their two intercept steps and the radii
+    step run as in the directed LSM's device loop); ``'host'`` keeps the auxiliary / conjugate
+    draws in numpy on the caller's MT19937 stream in the reference's order (the bit-level pin to
+    the reference's ``_fit`` trace).  ``'auto'`` = device for undirected models, host for the
+    directed ones.  The two are equal in distribution.
 
     After a device-resident loop the post-loop processing (hdp_lpcm.py:1085-1162: model selection,
     Procrustes alignment of every stored sample, posterior means) runs on the trace where it lies,
@@ -301,10 +302,12 @@ class DynamicNetworkHDPLPCM(FittedQuantities):
 
         if self.hdp_loop not in ('auto', 'device', 'host'):
             raise ValueError("hdp_loop must be 'auto', 'device' or 'host'")
-        if self.hdp_loop == 'device' and self.is_directed:
-            raise ValueError("hdp_loop='device' covers undirected models")
-        self.loop_kind_ = ('host-driven' if (self.is_directed or self.hdp_loop == 'host')
-                           else 'device-resident')
+        # 'auto': the undirected model's loop runs on the device; the directed models' does when
+        # it is asked for (their default stays the host-driven loop with the reference's MT19937
+        # draw order, which the recorded reference traces pin)
+        self.loop_kind_ = ('device-resident' if (self.hdp_loop == 'device' or
+                                                 (self.hdp_loop == 'auto' and not self.is_directed))
+                           else 'host-driven')
         # The device-resident loop keeps its trace in HBM; the three large arrays - Xs_
         # (320 KB per sample at T=10, N=2000), zs_, weights_ - reach the host only when somebody
         # reads them (__getattr__), and the post-loop processing runs where they lie.
@@ -333,7 +336,8 @@ class DynamicNetworkHDPLPCM(FittedQuantities):
         if self.loop_kind_ == 'device-resident':
             chain.hdp_configure(hp, beta, weights, ip, self.intercept_variance_prior,
                                 step_size_intercept=self.step_size_intercept, tune=self.tune,
-                                tune_interval=100, sweep_algo=self.sweep_algo)
+                                tune_interval=100, sweep_algo=self.sweep_algo,
+                                step_size_radii=self.step_size_radii, radii_tune=self.tune)
             chain.hdp_trace_alloc(n_total, logp0=float(self.logps_[0]))
         return self
 
@@ -358,6 +362,8 @@ class DynamicNetworkHDPLPCM(FittedQuantities):
                                                                  tr['lambdas'])
         self.hypers_ = getattr(self, 'hypers_', np.zeros((self._n_total, 6)))
         self.hypers_[sl] = tr['hypers']
+        if self.is_directed:
+            self.radiis_[sl] = self.chain_.trace_read_radii(first, count)
 
     def _store(self, it, ll):
         st, hp = self._st, self.hyper_
@@ -378,7 +384,20 @@ class DynamicNetworkHDPLPCM(FittedQuantities):
         the kernels of the engine around numpy draws on the caller's MT19937 stream."""
         chain, rng, hp, ip = self.chain_, self._rng, self.hyper_, self._ip
         if self.loop_kind_ == 'device-resident':
-            chain.hdp_run(first, count)          # asynchronous: the iterations are enqueued
+            ccs = self.case_control_sampler_
+            if ccs is None:
+                chain.hdp_run(first, count)      # asynchronous: the iterations are enqueued
+                return
+            # the host keeps the cadence of the control resampling (case_control_likelihood.py:27-33)
+            it, last = first, first + count - 1
+            while it <= last:
+                ccs.resample(it)
+                nxt = it + 1
+                while nxt <= last and (ccs.n_resample is None or ccs.n_iter % ccs.n_resample != 0):
+                    ccs.n_iter += 1
+                    nxt += 1
+                chain.hdp_run(it, nxt - it)
+                it = nxt
             return
         isamp, rsamp, sums, miss = (self.intercept_samplers, self.radii_sampler, self._sums,
                                     self._miss)
@@ -537,7 +556,7 @@ class DynamicNetworkHDPLPCM(FittedQuantities):
         """Everything of ``fit`` after the Gibbs loop (hdp_lpcm.py:1072-1176)."""
         chain, hp, n_total = self.chain_, self.hyper_, self._n_total
         if (self.loop_kind_ == 'device-resident' and self.thin is None and self._miss is None
-                and self.post_processing != 'host'):
+                and self.post_processing != 'host' and not self.is_directed):
             return self._finish_on_device()
         if self.loop_kind_ == 'device-resident':
             self._pull(1, n_total - 1)
@@ -551,6 +570,13 @@ class DynamicNetworkHDPLPCM(FittedQuantities):
             self._st.update(X=self.Xs_[-1], intercept=self.intercepts_[-1], mu=self.mus_[-1],
                             sigma=self.sigmas_[-1], z=self.zs_[-1], beta=self.betas_[-1],
                             weights=self.weights_[-1], lmbda=self.lambdas_[-1])
+            if self.is_directed:
+                so, rs = self.intercept_samplers[1], self.radii_sampler
+                so.step_size, so.n_accepted = cfg.i_step_size_out, cfg.i_n_accepted_out
+                so.n_steps, so.steps_until_tune = cfg.i_n_steps_out, cfg.i_steps_until_tune_out
+                rs.step_size, rs.n_accepted = cfg.r_step_size, cfg.r_n_accepted
+                rs.n_steps, rs.steps_until_tune = cfg.r_n_steps, cfg.r_steps_until_tune
+                self._st.update(radii=self.radiis_[-1])
             if self._miss is not None:            # hdp_lpcm.py:1039-1049 from the stored samples
                 miss, rng = self._miss, self._rng
                 for it in range(1, n_total):

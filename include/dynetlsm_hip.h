@@ -233,7 +233,7 @@ int dlsm_batch_synchronize(dlsm_batch *b);
 int dlsm_batch_stats(dlsm_batch *b, int64_t *merged, int64_t *single);
 const char *dlsm_batch_last_error(const dlsm_batch *b);
 
-/* ---- device-resident HDP-LPCM chain (hdp_lpcm.py:823-1069, undirected model) --------
+/* ---- device-resident HDP-LPCM chain (hdp_lpcm.py:823-1069) --------------------------
  * the whole Gibbs iteration of DynamicNetworkHDPLPCM._fit on the device -
  * sweep with the AR-mixture prior, centring, intercept MH, label block update
  * (sample_labels.py:134-190), table counts and override variables
@@ -243,7 +243,10 @@ const char *dlsm_batch_last_error(const dlsm_batch *b);
  * hdp_lpcm.py:977-1023) and the log-posterior trace (:1188-1280) - with Philox draws (stream
  * HDP = 6, counter (index, kind | attempt << 8, iteration)): no host round trip inside an
  * iteration.  The mixture's state (mu, sigma, lmbda, z) is what dlsm_set_prior_mixture
- * left on the device. */
+ * left on the device.  Directed and case-control models: the intercept step is the two steps of
+ * sample_coefficients.py:12-75 followed by the radii step (:91-121), as in dlsm_lsm_run's
+ * directed loop (the caller resamples the controls between calls at its own cadence); the radii
+ * trace is read with dlsm_trace_read_radii. */
 typedef struct {
     /* resampled by the loop */
     double gamma, alpha_init, alpha, kappa, mean_variance_prior, b;
@@ -259,6 +262,13 @@ typedef struct {
     double i_step_size;
     int32_t i_n_accepted, i_n_steps, i_steps_until_tune, i_tune, i_tune_interval;
     int32_t sweep_algo;                        /* as dlsm_sweep_positions */
+    /* directed models (hdp_lpcm.py:731-747, sample_coefficients.py:12-121): the fields above
+     * describe intercept_in, these intercept_out and the radii sampler (scaled-Dirichlet
+     * proposal, metropolis.py:57-82; r_tune < 0 == None) */
+    double intercept_prior_out, i_step_size_out;
+    int32_t i_n_accepted_out, i_n_steps_out, i_steps_until_tune_out, r_tune;
+    double r_step_size;
+    int32_t r_n_accepted, r_n_steps, r_steps_until_tune, r_tune_interval;
 } dlsm_hdp_config;
 /* beta K, weights T*K*K (weights[0,0,:] the initial distribution), K = the mixture prior's */
 int dlsm_hdp_configure(dlsm_chain *h, const dlsm_hdp_config *cfg, const double *beta,
@@ -272,11 +282,13 @@ int dlsm_hdp_trace_alloc(dlsm_chain *h, int n_total, double logp0);
 /* enqueue iterations first .. first+count-1.  Asynchronous. */
 int dlsm_hdp_run(dlsm_chain *h, int first, int count);
 /* rows first .. first+count-1; any pointer may be NULL.  zs count*T*N int64, hypers count*6
- * [gamma, alpha_init, alpha, kappa, mean_variance_prior, b] */
+ * [gamma, alpha_init, alpha, kappa, mean_variance_prior, b]; intercepts count*2 (undirected
+ * model: the second column carries the network log-likelihood of the stored state) */
 int dlsm_hdp_trace_read(dlsm_chain *h, int first, int count, double *Xs, double *intercepts,
                         double *logps, double *mus, double *sigmas, int64_t *zs, double *betas,
                         double *weights, double *lambdas, double *hypers);
-/* the mirror of dlsm_hdp_trace_read (undirected model: one intercept per row): rows first ..
+/* the mirror of dlsm_hdp_trace_read (intercepts: count*1 for the undirected model, count*2 for
+ * the directed ones): rows first ..
  * first+count-1 of the device-resident trace from host arrays; any pointer may be NULL.  Lets a
  * caller continue or post-process on the device a trace it holds on the host (the reference
  * keeps Xs_, zs_, ... as attributes of the fitted estimator, hdp_lpcm.py:691-747). */

@@ -395,9 +395,9 @@ def _dirichlet_logpdf(x, alphas):
 
 
 def log_posterior(loglik, X, intercept, mu, sigma, z, weights, beta, lmbda, hp, intercept_prior,
-                  intercept_variance_prior):
-    """DynamicNetworkHDPLPCM.logp (hdp_lpcm.py:1188-1280), undirected model; ``loglik`` is the
-    network log-likelihood at (X, intercept)"""
+                  intercept_variance_prior, n_radii=None):
+    """DynamicNetworkHDPLPCM.logp (hdp_lpcm.py:1188-1280); ``loglik`` is the network
+    log-likelihood at (X, intercept[, radii]); ``n_radii`` = N for the directed models"""
     T, N, D = X.shape
     K = sigma.shape[0]
     lm = float(np.ravel(lmbda)[0])
@@ -412,8 +412,13 @@ def log_posterior(loglik, X, intercept, mu, sigma, z, weights, beta, lmbda, hp, 
         for t in range(1, T):
             lp += np.sum(np.log(weights[t, z[t - 1], z[t]]))
     lp += loglik
-    diff = np.ravel(intercept)[0] - np.ravel(intercept_prior)[0]
-    lp -= 0.5 * (diff * diff) / intercept_variance_prior
+    if n_radii is not None:             # directed models: both intercepts (hdp_lpcm.py:1234-1237)
+        diff = np.ravel(intercept)[:2] - np.ravel(intercept_prior)[:2]
+        lp -= np.sum(0.5 * (diff * diff) / intercept_variance_prior)
+        lp += gammaln(float(n_radii))   # stats.dirichlet.logpdf(radii, ones(N)), hdp_lpcm.py:1268-1269
+    else:
+        diff = np.ravel(intercept)[0] - np.ravel(intercept_prior)[0]
+        lp -= 0.5 * (diff * diff) / intercept_variance_prior
     for t in range(T):
         if t == 0:
             df = X[t] - mu[z[t]]
@@ -510,3 +515,60 @@ class HdpChain(object):
         self.n, self.nk = n, nk
         return log_posterior(ll, st.X, st.c.intercept[0], st.mu, st.sigma, st.z, self.weights,
                              self.beta, self.lmbda, self.hp, self.ip, self.var)
+
+
+class HdpChainDirected(HdpChain):
+    """The directed (exact or case-control) HDP-LPCM chain in the engine's order
+    (hdp_lpcm.py:823-1069 with is_directed): sweep with the directed partial likelihoods, centring,
+    the two intercept steps and the radii step (oracle.directed_coefficient_steps = the steps of
+    the directed LSM loop), then the label update and the conjugate draws of the undirected chain."""
+
+    def __init__(self, Y, X, intercept, radii, mu, sigma, z, beta, weights, lmbda, hp, grid,
+                 intercept_prior, intercept_variance_prior, isamps, rsamp, seed, chain, case_control=None):
+        self.Y = None if Y is None else np.ascontiguousarray(Y, dtype=np.float64)
+        self.cc = case_control
+        self.st = orc.ChainState(X, grid, Y=self.Y, intercept=np.ravel(intercept), radii=np.array(radii),
+                                 model=2 if case_control is not None else 1, case_control=case_control,
+                                 mu=mu, sigma=sigma, lmbda=lmbda, z=z, seed=seed, chain=chain)
+        self.beta = np.array(beta, dtype=np.float64)
+        self.weights = np.array(weights, dtype=np.float64)
+        self.lmbda = np.array(np.ravel(lmbda)[:1], dtype=np.float64)
+        self.hp = hp
+        self.ip = np.array(np.ravel(intercept_prior)[:2], dtype=np.float64)
+        self.var = float(intercept_variance_prior)
+        self.isamps, self.rsamp = isamps, rsamp
+        self.seed, self.chain = seed, chain
+        self.aux = None
+
+    @property
+    def intercept(self):
+        return self.st.intercept[:2]
+
+    @property
+    def radii(self):
+        return self.st.radii
+
+    def loglik_at(self, X, b, r):
+        if self.cc is not None:
+            return orc.approx_directed_network_loglikelihood(
+                X, r, self.cc['in_edges'], self.cc['out_edges'], self.cc['degree'],
+                self.cc['control_nodes_out'], b[0], b[1])
+        return orc.dynamic_network_loglikelihood_directed(self.Y, X, b[0], b[1], r)
+
+    def iteration(self, it):
+        st = self.st
+        st.c.iter = it
+        st.c.lmbda = float(self.lmbda[0])
+        st.sweep_c()
+        st.X[:] = orc.center(st.X)
+        ll = orc.directed_coefficient_steps(st, it, self.loglik_at, self.isamps, self.rsamp, self.ip, self.var)
+        z, n, nk = orc.sample_labels_block_philox(st.X, st.mu, st.sigma, self.lmbda, self.weights,
+                                                  self.seed, self.chain, it)
+        st.z[:] = z
+        self.beta, self.lmbda, self.aux = gibbs_updates(
+            st.X, st.z, n, nk, st.mu, st.sigma, self.beta, self.weights, self.lmbda, self.hp,
+            PhiloxDraws(self.seed, self.chain, it))
+        self.lmbda = np.array(np.ravel(self.lmbda)[:1], dtype=np.float64)
+        self.n, self.nk = n, nk
+        return log_posterior(ll, st.X, self.intercept, st.mu, st.sigma, st.z, self.weights, self.beta,
+                             self.lmbda, self.hp, self.ip, self.var, n_radii=st.radii.shape[0])

@@ -708,23 +708,16 @@ def tune_step_size_dirichlet(step_size, acc_rate):
     return step_size
 
 
-def lsm_iteration_directed(state, it, loglik, isamp, rsamp, intercept_prior, intercept_var,
-                           X_ref=None):
-    """One iteration on ``state`` (ChainState, model 1 or 2; its X, intercept and radii are
-    updated in place); ``loglik(X, intercept, radii)`` is the model's network log-likelihood;
-    isamp[2], rsamp are ScalarMetropolis objects.  Returns the log-posterior trace value."""
+def directed_coefficient_steps(state, it, loglik, isamp, rsamp, intercept_prior, intercept_var):
+    """intercept_in, intercept_out (sample_coefficients.py:12-75) and radii (:91-121) steps of one
+    directed iteration at ``state``'s positions, with the engine's Philox draws; updates the
+    state's intercepts and radii in place and returns the network log-likelihood of the new state"""
     from scipy.special import gammaln
     seed, chain = state.c.seed, state.c.chain
-    state.c.iter = it
-    state.sweep_c()
     X = state.X
-    if X_ref is not None:
-        X[:] = procrustes_rotation(X_ref, X)[0]
-    X[:] = center(X)
     b = state.intercept.copy()
     radii = state.radii
     v = intercept_var
-    ll = None
     for k in range(2):
         u0, u1 = philox_uniform2(seed, k, 0, it, stream_word(chain, STREAM_INTERCEPT))
         z0, _ = _box_muller(float(u0), float(u1))
@@ -757,4 +750,20 @@ def lsm_iteration_directed(state, it, loglik, isamp, rsamp, intercept_prior, int
         radii[:] = x
         llf = ll_alt
     rsamp.book(accepted, rule=tune_step_size_dirichlet)
-    return llf + lsm_log_prior(X, state.c.tau_sq, state.c.sigma_sq, b, intercept_prior, v)
+    return llf
+
+
+def lsm_iteration_directed(state, it, loglik, isamp, rsamp, intercept_prior, intercept_var,
+                           X_ref=None):
+    """One iteration on ``state`` (ChainState, model 1 or 2; its X, intercept and radii are
+    updated in place); ``loglik(X, intercept, radii)`` is the model's network log-likelihood;
+    isamp[2], rsamp are ScalarMetropolis objects.  Returns the log-posterior trace value."""
+    state.c.iter = it
+    state.sweep_c()
+    X = state.X
+    if X_ref is not None:
+        X[:] = procrustes_rotation(X_ref, X)[0]
+    X[:] = center(X)
+    llf = directed_coefficient_steps(state, it, loglik, isamp, rsamp, intercept_prior, intercept_var)
+    return llf + lsm_log_prior(X, state.c.tau_sq, state.c.sigma_sq, state.intercept, intercept_prior,
+                               intercept_var)

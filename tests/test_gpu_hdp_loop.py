@@ -223,3 +223,106 @@ def test_facade_device_and_host_loops_agree_in_distribution(eng):
         a, b = res['device'][:, k], res['host'][:, k]
         se = np.sqrt(a.var(ddof=1) / 4 + b.var(ddof=1) / 4)
         assert abs(a.mean() - b.mean()) < 4 * se + slack * abs(b.mean()), (k, a, b)
+
+
+# ---------------------------------------------------------------- directed models on the device
+def _directed_case(T, N, K, seed):
+    """a directed network with the case's positions, radii ~ Dirichlet, intercepts (0.8, 0.4)"""
+    Y, X, mu, sigma, z, beta, w = _case(T, N, K, seed)
+    rng = np.random.RandomState(100 + seed)
+    radii = rng.dirichlet(np.ones(N) * 8.0)
+    Xs = 0.02 * X                                       # the directed model's scale (radii ~ 1 / N)
+    mu, sigma = 0.02 * mu, (0.02 ** 2) * sigma
+    b = np.array([0.8, 0.4])
+    Yd = np.zeros((T, N, N))
+    for t in range(T):
+        d = np.sqrt(((Xs[t][:, None] - Xs[t][None]) ** 2).sum(-1))
+        eta = b[0] * (1 - d / radii[None, :]) + b[1] * (1 - d / radii[:, None])
+        A = (rng.rand(N, N) < 1 / (1 + np.exp(-eta))).astype(float)
+        np.fill_diagonal(A, 0.0)
+        Yd[t] = A
+    return Yd, Xs, radii, b, mu, sigma, z, beta, w
+
+
+@pytest.mark.parametrize('T,N,K,seed,model,tune', [(3, 60, 4, 0, 'directed', None), (2, 90, 5, 1, 'directed', 3),
+                                                   (3, 70, 4, 2, 'case_control', None),
+                                                   (2, 600, 5, 3, 'directed', None)])
+def test_directed_device_loop_matches_oracle_iteration_by_iteration(eng, T, N, K, seed, model, tune):
+    """hdp_lpcm.py:823-1069 with is_directed on the device (dlsm_hdp_run): sweep with the directed
+    (or case-control) partial likelihoods and the mixture prior, centring, intercept_in,
+    intercept_out, radii (sample_coefficients.py:12-121), label update, conjugate draws and the
+    log-posterior of hdp_lpcm.py:1188-1280 with its directed terms - against the oracle's
+    restatement with the engine's draws, iteration by iteration (N = 600: the pipelined sweep)"""
+    Y, X, radii, b, mu, sigma, z, beta, w = _directed_case(T, N, K, seed)
+    ip, var = np.array([0.7, 0.5]), 2.0
+    hp = _hyper()
+    og = orc.SamplerGrid(T, N, 0.004, tune=tune, tune_interval=2)
+    isamps = [orc.ScalarMetropolis(0.1, tune, 100) for _ in range(2)]
+    rsamp = orc.ScalarMetropolis(20000., tune, 100)
+    cc = None
+    n_it = 4
+    with eng.Chain(T, N, 2, model, seed=31 + seed, chain_id=1) as c:
+        if model == 'case_control':
+            from dynetlsm_amd.case_control import build_edge_lists
+            dg, ie, oe = build_edge_lists(Y)
+            c.upload_edges(ie, oe, dg)
+            c.resample_controls(0, 12)
+            ci, co = c.get_controls()
+            cc = dict(in_edges=ie, out_edges=oe, degree=dg, control_nodes_in=ci, control_nodes_out=co)
+        else:
+            c.upload_network(Y)
+        c.set_positions(X); c.set_intercepts(b); c.set_radii(radii)
+        c.set_samplers(eng.SamplerGrid(T, N, 0.004, tune=tune, tune_interval=2))
+        c.set_prior_mixture(mu, sigma, 0.8, z)
+        c.hdp_configure(hp, beta, w, ip, var, step_size_intercept=0.1, tune=tune, tune_interval=100,
+                        step_size_radii=20000., radii_tune=tune)
+        c.hdp_trace_alloc(n_it + 1, logp0=-1.0)
+        oc = hlo.HdpChainDirected(None if cc else Y, X.copy(), b.copy(), radii.copy(), mu.copy(), sigma.copy(),
+                                  z.copy(), beta.copy(), w.copy(), 0.8, hp.copy(), og, ip, var, isamps, rsamp,
+                                  seed=31 + seed, chain=1, case_control=cc)
+        for it in range(1, n_it + 1):
+            c.hdp_run(it, 1)
+            c.synchronize()
+            lp = oc.iteration(it)
+            tr = c.hdp_trace_read(it, 1)
+            rad = c.trace_read_radii(it, 1)[0]
+            np.testing.assert_array_equal(tr['zs'][0], oc.z)
+            np.testing.assert_allclose(tr['Xs'][0], oc.X, atol=1e-11)
+            np.testing.assert_allclose(tr['intercepts'][0], oc.intercept, rtol=1e-11)
+            np.testing.assert_allclose(rad, oc.radii, rtol=1e-9)
+            np.testing.assert_allclose(tr['betas'][0], oc.beta, rtol=1e-9)
+            np.testing.assert_allclose(tr['mus'][0], oc.mu, rtol=1e-8, atol=1e-12)
+            np.testing.assert_allclose(tr['sigmas'][0], oc.sigma, rtol=1e-9)
+            np.testing.assert_allclose(tr['lambdas'][0, 0], oc.lmbda[0], rtol=1e-9)
+            np.testing.assert_allclose(tr['logps'][0], lp, rtol=1e-9)
+            np.testing.assert_allclose(c.get_radii(), oc.radii, rtol=1e-9)
+        cfg = c.hdp_get_config()
+        assert (cfg.i_n_steps, cfg.i_n_steps_out, cfg.r_n_steps) == (n_it, n_it, n_it)
+        assert cfg.i_n_accepted == isamps[0].n_accepted and cfg.i_n_accepted_out == isamps[1].n_accepted
+        assert cfg.r_n_accepted == rsamp.n_accepted
+        np.testing.assert_allclose([cfg.i_step_size, cfg.i_step_size_out, cfg.r_step_size],
+                                   [isamps[0].step_size, isamps[1].step_size, rsamp.step_size], rtol=1e-13)
+        tr0 = c.hdp_trace_read(0, 1)
+        np.testing.assert_allclose(tr0['intercepts'][0], b)          # row 0 keeps BOTH intercepts
+
+
+def test_directed_facade_device_loop_runs_and_lands_where_the_host_loop_does(eng):
+    """DynamicNetworkHDPLPCM(is_directed=True, hdp_loop='device'): the estimator's surface (radii trace,
+    selected model) and a posterior level comparable to the host-driven loop's on the same network"""
+    Y, X, radii, b, mu, sigma, z, beta, w = _directed_case(3, 40, 4, 5)
+    out = {}
+    for loop in ('device', 'host'):
+        lp = []
+        for seed in range(3):
+            m = eng.DynamicNetworkHDPLPCM(n_iter=120, tune=60, burn=60, is_directed=True, n_components=4,
+                                          random_state=seed, chain_id=seed, hdp_loop=loop, selection_type='map')
+            m.fit(Y)
+            assert m.loop_kind_ == ('device-resident' if loop == 'device' else 'host-driven')
+            assert m.radiis_.shape == (240, 40) and np.allclose(m.radiis_[1:].sum(axis=1), 1.0)
+            assert m.intercepts_.shape == (240, 2) and np.isfinite(m.logps_).all()
+            assert m.X_.shape == (3, 40, 2) and m.radii_.shape == (40,)
+            lp.append(m.logps_[120:].mean())
+            m.chain_.close()
+        out[loop] = np.array(lp)
+    se = np.sqrt(out['device'].var(ddof=1) / 3 + out['host'].var(ddof=1) / 3)
+    assert abs(out['device'].mean() - out['host'].mean()) < 5 * se + 0.05 * abs(out['host'].mean()), out
