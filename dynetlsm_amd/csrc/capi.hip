@@ -70,6 +70,7 @@ static thread_local std::string g_err;
 static int check_pipe_err(dlsm_chain *h);
 static int check_sweep_algo(dlsm_chain *h, int algo);
 static void batch_forget(dlsm_chain *h);
+static int build_colmajor(dlsm_chain *h);
 
 static void drop_graph(dlsm_chain *h) {
     if (h->graph_exec) hipGraphExecDestroy(h->graph_exec);
@@ -370,7 +371,7 @@ void dlsm_destroy(dlsm_chain *h) {
         h->stream = h->own_stream; h->own_stream = nullptr; h->batch = nullptr;
     }
     drain_profile(h);
-    void *ptrs[] = {h->ybits, h->ytbits, h->in_edges, h->out_edges, h->degree,
+    void *ptrs[] = {h->ycm, h->ybits, h->ytbits, h->in_edges, h->out_edges, h->degree,
                     h->ctrl_in, h->ctrl_out, h->X, h->intercept, h->radii,
                     h->radii_alt, h->step, h->nacc, h->nsteps, h->until, h->mu,
                     h->sigma, h->z, h->partials, h->dsmall, h->xref, h->lab_n,
@@ -436,8 +437,22 @@ int dlsm_upload_network(dlsm_chain *h, const double *Y) {
     HIPCHK(h, hipGetLastError());
     if (flag) FAIL(h, DLSM_E_DATA, "network has entries other than 0.0 / 1.0 "
                                    "(missing-edge sampling is not supported)");
+    { int rc = build_colmajor(h); if (rc) return rc; }
     h->have_network = true;
     h->have_hops = false;
+    return DLSM_OK;
+}
+
+// the undirected model's column-block-major copy of the packed words (ChainView::ycm)
+static int build_colmajor(dlsm_chain *h) {
+    if (h->model != DLSM_UNDIRECTED) return DLSM_OK;
+    const int Ncm = (h->N + 127) / 128 * 128;       // = ChainView::Ncm
+    const size_t n = (size_t)h->T * (h->W / 2) * Ncm;
+    if (!h->ycm) { int rc = dev_alloc(h, &h->ycm, n); if (rc) return rc; }
+    hipLaunchKernelGGL(k_pack_colmajor, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->ybits,
+                       h->T, h->N, h->W, Ncm, h->ycm);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipStreamSynchronize(h->stream));
     return DLSM_OK;
 }
 
@@ -495,6 +510,7 @@ int dlsm_set_network_packed(dlsm_chain *h, const uint32_t *buf, int64_t n_words)
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (flag) FAIL(h, DLSM_E_DATA, "packed network violates the layout (code %d: 1 padding bits, "
                                    "2 diagonal, 4 transpose mismatch)", flag);
+    { int rc = build_colmajor(h); if (rc) return rc; }
     h->have_network = true;
     h->have_hops = false;
     return DLSM_OK;

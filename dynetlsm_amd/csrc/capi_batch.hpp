@@ -54,7 +54,7 @@ int batch_enqueue_iteration(dlsm_batch *b, int it, int procrustes_ref) {
         h->loop_draws_intercept = false;
         if (rc) { b->err = h->err; return rc; }
         ChainView v = h->view();
-        v.ybits = h0->ybits;                 // one copy of the network serves the whole batch
+        v.ybits = h0->ybits; v.ycm = h0->ycm;        // one copy of the network serves the whole batch
         pa.c[c] = v; pa.pb[c] = pb;
         ra.c[c] = v; ra.pb[c] = pb;
         ra.pr[c] = PipePostRide{ride_xref, ir, h->partials + (size_t)ll_blocks(h) * 4, nwg, (nbat - 1) * PP_B,
@@ -96,10 +96,11 @@ int batch_enqueue_iteration(dlsm_batch *b, int it, int procrustes_ref) {
     for (int c = 0; c < nc; ++c) {
         dlsm_chain *h = b->ch[c];
         int nrec = 0;
-        const uint32_t *own = h->ybits;
-        h->ybits = h0->ybits;
+        uint32_t *own = h->ybits;
+        unsigned long long *own_cm = h->ycm;
+        h->ybits = h0->ybits; h->ycm = h0->ycm;
         int rc = loglik_records(h, 2, h->lsm->cand, nullptr, nullptr, &nrec);
-        h->ybits = const_cast<uint32_t *>(own);
+        h->ybits = own; h->ycm = own_cm;
         if (rc) { b->err = h->err; return rc; }
     }
     hipLaunchKernelGGL((k_lsm_finalize_apply_propose_batch<DD>), dim3(1 + propose_blocks(T, N), nc), dim3(256), 0,

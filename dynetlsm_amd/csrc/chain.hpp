@@ -16,6 +16,10 @@ struct ChainView {
     int W;                      // uint32 words per bit row (multiple of 4)
     const uint32_t *ybits;      // [T][N][W]  bit i of row j = Y[t, j, i]
     const uint32_t *ytbits;     // [T][N][W]  bit i of row j = Y[t, i, j] (directed)
+    // undirected: the same words column-block-major, [T][W / 2][Ncm] of 8 bytes - word (i, cb)
+    // = bits 64 cb .. 64 cb + 63 of row i - so that the rows of one 64-column block are contiguous
+    // (the log-likelihood pass reads a tile's row words as whole lines); Ncm = N rounded up to its 128-row tiles
+    const unsigned long long *ycm; int Ncm;
     // case-control (int32 on device)
     const int32_t *in_edges;  int Din;
     const int32_t *out_edges; int Dout;
@@ -101,6 +105,7 @@ struct dlsm_chain {
     // network
     int W = 0;
     uint32_t *ybits = nullptr, *ytbits = nullptr;
+    unsigned long long *ycm = nullptr;      // undirected: column-block-major copy of ybits
     bool have_network = false;
     int Din = 0, Dout = 0, C = 0;
     int32_t *in_edges = nullptr, *out_edges = nullptr, *degree = nullptr;
@@ -176,6 +181,7 @@ struct dlsm_chain {
         dlsm::ChainView v;
         v.T = T; v.N = N; v.D = D; v.model = model; v.squared = squared; v.W = W;
         v.ybits = ybits; v.ytbits = ytbits;
+        v.ycm = ycm; v.Ncm = (N + 127) / 128 * 128;
         v.in_edges = in_edges; v.Din = Din; v.out_edges = out_edges; v.Dout = Dout;
         v.degree = degree; v.ctrl_in = ctrl_in; v.ctrl_out = ctrl_out; v.C = C;
         v.X = X; v.intercept = intercept; v.radii = radii;

@@ -35,6 +35,22 @@ __global__ __launch_bounds__(256) void k_pack_bits(const double *__restrict__ Y,
     }
 }
 
+// The undirected network's words column-block-major (ChainView::ycm): thread = (row i, 64-column
+// block cb); a wavefront reads 64 rows' words (stride W) and writes 512 contiguous bytes.
+__global__ __launch_bounds__(256) void k_pack_colmajor(const uint32_t *__restrict__ bits, int T, int N,
+                                                       int W, int Ncm,
+                                                       unsigned long long *__restrict__ ycm) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long per_t = (long)(W / 2) * Ncm;
+    if (idx >= (long)T * per_t) return;
+    const int t = (int)(idx / per_t);
+    const long r = idx - (long)t * per_t;
+    const int cb = (int)(r / Ncm), i = (int)(r - (long)cb * Ncm);
+    unsigned long long v = 0ull;
+    if (i < N) v = *(const unsigned long long *)(bits + ((size_t)t * N + i) * W + 2 * cb);
+    ycm[idx] = v;
+}
+
 // Invariants of a packed network handed in ready-made (dlsm_set_network_packed): bits beyond
 // N and the diagonal are zero, bit i of row j of `bits` equals bit j of row i of `tbits`
 // (tbits = bits for the undirected model: symmetry).  One wavefront per row.
@@ -166,7 +182,10 @@ __global__ __launch_bounds__(LLU_THREADS) __attribute__((amdgpu_waves_per_eu(6, 
     // rows r < rend of this half tile pair with column j (i < j < N)
     const int rend = j < N ? min(LLU_ROWS, j - i0) : 0;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t *ywords = c.ybits + ((size_t)t * N) * c.W + (j0 >> 5) + 2 * wave;
+    // the row words of this wavefront's 64 columns, rows i0 .. : contiguous in the column-block-major
+    // copy (row-major they are W words apart: every 8-byte scalar load dragged a 128-byte line in,
+    // 25 MB of traffic per pass for 5 MB of bits; rows beyond N are zero there)
+    const unsigned long long *ywords = c.ycm + ((size_t)t * (c.W >> 1) + (j0 >> 6) + wave) * c.Ncm + i0;
     // a half tile strictly above the diagonal with all its columns inside the network
     // needs no per-dyad validity test
     const bool whole = i0 + LLU_ROWS <= j0 && j0 + LL_TILE <= N;
@@ -176,7 +195,7 @@ __global__ __launch_bounds__(LLU_THREADS) __attribute__((amdgpu_waves_per_eu(6, 
         unsigned long long ym[U];                                                              \
         _Pragma("unroll")                                                                      \
         for (int u = 0; u < U; ++u)                                                            \
-            ym[u] = *(const unsigned long long *)(ywords + (size_t)min(i0 + r + u, N - 1) * c.W); \
+            ym[u] = ywords[r + u];                                                             \
         double dd[U], e[U];                                                                    \
         _Pragma("unroll")                                                                      \
         for (int u = 0; u < U; ++u) dd[u] = dist_fast<D>(&sXi[(r + u) * D], xj, SQ_);          \
