@@ -1414,14 +1414,16 @@ template <int DD>
 int launch_sample_labels(dlsm_chain *h, const ChainView &v, uint32_t iter, uint8_t *trace_row,
                          hipStream_t q) {
     const int T = h->T, K = h->K, N = h->N;
-    if (K <= 64 && lm_lds_bytes(T, K, h->D) <= 150 * 1024 && !labels_wave_forced()) {
+    // The matrix-core kernel up to 32 components (KS = K / 4 <= 8 unrolled steps: no scratch memory;
+    // above that its unrolled tiles spill - 44 to 303 scratch instructions at KS = 9 .. 16 - and the
+    // wavefront-per-node kernel, which has no such limit, takes over)
+    if (K <= 4 * LM_MAX_KS && lm_lds_bytes(T, K, h->D) <= 150 * 1024 && !labels_wave_forced()) {
         int rc;
         switch (lm_ksteps(K)) {
 #define DLSM_LM_CASE(KS_) case KS_: rc = launch_labels_mfma<KS_>(h, v, iter, q); break;
             DLSM_LM_CASE(1) DLSM_LM_CASE(2) DLSM_LM_CASE(3) DLSM_LM_CASE(4) DLSM_LM_CASE(5)
-            DLSM_LM_CASE(6) DLSM_LM_CASE(7) DLSM_LM_CASE(8) DLSM_LM_CASE(9) DLSM_LM_CASE(10)
-            DLSM_LM_CASE(11) DLSM_LM_CASE(12) DLSM_LM_CASE(13) DLSM_LM_CASE(14) DLSM_LM_CASE(15)
-            default: rc = launch_labels_mfma<16>(h, v, iter, q); break;
+            DLSM_LM_CASE(6) DLSM_LM_CASE(7)
+            default: rc = launch_labels_mfma<LM_MAX_KS>(h, v, iter, q); break;
 #undef DLSM_LM_CASE
         }
         if (rc) return rc;

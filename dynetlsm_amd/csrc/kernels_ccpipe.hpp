@@ -267,6 +267,15 @@ __device__ unsigned long long g_cc_item_t[32][4096][2];
 #else
 #define DLSM_CC_STAMP(I_, DEP_)
 #endif
+// One wavefront's arrival at its workgroup's barrier, as the instruction (see ccpipe_resolve): the
+// "memory" clobber keeps the compiler from moving LDS / global accesses across it; loads already
+// requested stay in flight (gfx950 needs no drained counters at s_barrier).
+__device__ __forceinline__ void cc_barrier_arrive() { asm volatile("s_barrier" ::: "memory"); }
+// ... with this wavefront's LDS stores completed first (what the other side reads behind the barrier)
+__device__ __forceinline__ void cc_barrier_arrive_after_lds_stores() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 template <int D>
 __device__ __forceinline__ void ccpipe_resolve(const ChainView &c, const CcPipeBuf &pb, int b, int t,
                                                unsigned long long (*sMask)[CP_WAVES],
@@ -326,13 +335,16 @@ __device__ __forceinline__ void ccpipe_resolve(const ChainView &c, const CcPipeB
             xm[u] = pb.xidx[p];
             xh[u] = pb.xval[p];
         }
-        // (Each half of the workgroup meets the other at its OWN s_barrier: the halves are whole
-        // wavefronts - `upper` is wave-uniform - and gfx950 counts arrivals per workgroup, not per
-        // instruction address.  One barrier behind the if / else was built: both halves' operands
-        // are then live at one program point, 119 -> 128 VGPRs and 14 spilled, on the kernel's
-        // critical path.  If a compiler ever merges or moves these two, parity tests of algo 5
-        // hang or fail at once.)
-        __syncthreads();                               // sPrev visible
+        // Each half of the workgroup meets the other at its OWN s_barrier: the halves are whole
+        // wavefronts - `upper` is wave-uniform - and the hardware counts a workgroup's ARRIVALS,
+        // whatever the instruction address (gfx950 ISA: s_barrier).  That is a contract of the
+        // instruction set, not of HIP's __syncthreads() (undefined in divergent code), so the two
+        // arrivals are written as what they are: the instruction itself behind exactly the wait
+        // its side needs (cc_barrier_*: a compiler barrier too).  This side has stored nothing
+        // the other reads and keeps its 48 loads in flight across the barrier.
+        // (One barrier behind the if / else was built: both halves' operands are then live at one
+        // program point, 119 -> 128 VGPRs and 14 spilled, on the kernel's critical path.)
+        cc_barrier_arrive();                           // sPrev visible
         // the previous batch's acceptances, final by now: the node's cross entries in list order
         // (a list longer than the 24 at hand comes sixteen entries per trip, their loads issued
         // together), handed over through LDS
@@ -373,7 +385,7 @@ __device__ __forceinline__ void ccpipe_resolve(const ChainView &c, const CcPipeB
         const size_t tjc = (size_t)t * N + j0 + kc;
         st = c.step[tjc];
         na = c.nacc[tjc]; ns = c.nsteps[tjc]; un = c.until[tjc];
-        __syncthreads();                               // (the upper half's barrier)
+        cc_barrier_arrive_after_lds_stores();          // (the upper half's barrier; sPrev is this half's store)
     }
     DLSM_CC_STAMP(2, r)
     // the node's first own entries stay in registers through the passes

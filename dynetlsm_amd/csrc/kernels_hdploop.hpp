@@ -896,7 +896,10 @@ __device__ __forceinline__ double hdp_dirichlet_row_at(const double *beta, const
 // (1024 threads: a row per wavefront, 16 rows at a time - with four wavefronts the (T - 1) K + 1 rows
 // of a sample, each a handful of lgamma, were 125 us in a row; the sums keep their order: the first
 // 256 threads add exactly what the 256 threads of the four-wavefront form added, the others zeros)
-constexpr int HF_THREADS = 1024;
+// (512 threads since round 4: at 1024 the six inlined lgamma expansions did not fit 128 registers -
+// 62 spilled; the post-run pass has one workgroup per stored sample, so the width of a workgroup is
+// not what fills the chip)
+constexpr int HF_THREADS = 512;
 template <int D>
 __global__ __launch_bounds__(HF_THREADS) void k_hdp_logp_batch_finish(ChainView c, HdpTraceView tv,
                                                                       int s0, const HdpDeviceState *hs,

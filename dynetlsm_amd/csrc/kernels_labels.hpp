@@ -199,6 +199,7 @@ __global__ __launch_bounds__(64 * LAB_WAVES) void k_sample_labels(
 constexpr int LM_THREADS = 1024;
 constexpr int LM_NODES = 8;             // nodes per workgroup: rows 8-15 of the A operand repeat rows 0-7
 typedef double lm_v4d __attribute__((ext_vector_type(4)));
+constexpr int LM_MAX_KS = 8;          // K <= 32: the unrolled forms that stay in registers (capi.hip)
 __host__ __device__ inline int lm_ksteps(int K) { return (K + 3) / 4; }
 __host__ __device__ inline int lm_wstride(int K) { return (4 * lm_ksteps(K)) | 1; }
 __host__ __device__ inline int lm_stride(int K) { return 16 * ((lm_ksteps(K) + 3) / 4) + 1; }

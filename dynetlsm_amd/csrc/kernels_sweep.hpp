@@ -392,22 +392,24 @@ __device__ __forceinline__ void post_row_accumulate(const double (&x)[D], const 
                 for (int b = 0; b < D; ++b) acc[D + a * D + b] += x[a] * xr[b];
         }
     }
+    // (the last two sums get their addend - or an exact 0.0 - by name: written as `acc[..] += q` in
+    // the two branches the compiler merged the updates into ONE access with a selected index, and the
+    // pair lived in scratch memory: 12 scratch instructions in k_pipe_last_ride, once per iteration)
+    double q0 = 0.0, q1 = 0.0;
     if (t0) {
         if (own) {
-            double q = 0.0;
 #pragma unroll
-            for (int d = 0; d < D; ++d) { acc[D + D * D + d] += x[d]; q += x[d] * x[d]; }
-            acc[2 * D + D * D] += q;
+            for (int d = 0; d < D; ++d) { acc[D + D * D + d] += x[d]; q0 += x[d] * x[d]; }
         }
     } else if (diff) {
-        double q = 0.0;
 #pragma unroll
         for (int d = 0; d < D; ++d) {
             const double df = x[d] - xp[d];
-            q += df * df;
+            q1 += df * df;
         }
-        acc[2 * D + D * D + 1] += q;
     }
+    acc[2 * D + D * D] += q0;
+    acc[2 * D + D * D + 1] += q1;
 }
 template <int D>
 __device__ __forceinline__ void post_row_load(const ChainView &c, const double *__restrict__ xref, long r,

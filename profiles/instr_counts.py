@@ -124,5 +124,63 @@ def counts(lib_path=None):
     return out
 
 
+def kernel_metadata(lib_path=None):
+    """{demangled-ish kernel name: dict(vgpr, sgpr, vgpr_spill, sgpr_spill, scratch_bytes, lds, kernarg)}
+    from the code object's notes (llvm-readelf --notes)"""
+    lib_path = lib_path or os.path.join(ROOT, 'dynetlsm_amd', 'libdynetlsm_hip.so')
+    co = extract_code_object(lib_path)
+    with tempfile.NamedTemporaryFile(suffix='.co', delete=False) as f:
+        f.write(co)
+        path = f.name
+    try:
+        out = subprocess.run([os.path.join(os.path.dirname(OBJDUMP), 'llvm-readelf'), '--notes', path],
+                             stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout.decode()
+        names = subprocess.run(['c++filt'],
+                               input='\n'.join(re.findall(r'\.name:\s+(\S+)', out)).encode(),
+                               stdout=subprocess.PIPE, check=True).stdout.decode().splitlines()
+    finally:
+        os.unlink(path)
+    res = {}
+    blocks = out.split('- .agpr_count')[1:]
+    mangled = re.findall(r'\.name:\s+(\S+)', out)
+    demangle = dict(zip(mangled, names))
+    for b in blocks:
+        m = re.search(r'\.name:\s+(\S+)', b)
+        if not m:
+            continue
+
+        def g(k):
+            q = re.search(r'\.%s:\s+(\d+)' % k, b)
+            return int(q.group(1)) if q else 0
+        nm = demangle.get(m.group(1), m.group(1))
+        nm = nm.split('(')[0].replace('void ', '').replace('dlsm::', '').replace(' ', '')
+        res[nm] = dict(vgpr=g('vgpr_count'), sgpr=g('sgpr_count'), vgpr_spill=g('vgpr_spill_count'),
+                       sgpr_spill=g('sgpr_spill_count'), scratch_bytes=g('private_segment_fixed_size'),
+                       lds=g('group_segment_fixed_size'), kernarg=g('kernarg_segment_size'))
+    return res
+
+
+# the kernels an iteration of the three benchmark configurations launches (D = 2): none of them
+# may touch scratch memory (round-3 verdict: k_pipe_last_ride<2> had 12 scratch instructions)
+HOT_KERNELS = [
+    'k_pipe_step<2,0,1>', 'k_pipe_last_ride<2>', 'k_loglik_undirected<2,2>',
+    'k_lsm_finalize_apply_propose<2>', 'k_pipe_step_batch<2,0>', 'k_pipe_last_ride_batch<2>',
+    'k_lsm_finalize_apply_propose_batch<2>',
+    'k_post_apply<2>', 'k_sample_labels_mfma<5>', 'k_label_counts', 'k_hdp_stage1<2>', 'k_hdp_stage2<2>',
+    'k_hdp_stage3<2>', 'k_hdp_hypers_propose<2>', 'k_hdp_logp_batch_sums<2>', 'k_hdp_logp_batch_finish<2>',
+    'k_ccpipe_step<2>', 'k_ccpipe_pack<2>', 'k_loglik_casecontrol_pf<2,1>', 'k_loglik_casecontrol_pf<2,2>',
+    'k_post_reduce_dir<2>', 'k_post_apply_dir<2>', 'k_dir_reduce_accept_intercept<2>', 'k_dir_tail<2>',
+]
+
+
+def hot_scratch_report(lib_path=None):
+    md = kernel_metadata(lib_path)
+    return {k: md.get(k) for k in HOT_KERNELS}
+
+
 if __name__ == '__main__':
-    print(json.dumps(counts(sys.argv[1] if len(sys.argv) > 1 else None), indent=1))
+    if len(sys.argv) > 1 and sys.argv[-1] == 'scratch':         # python profiles/instr_counts.py scratch
+        for k, v in hot_scratch_report().items():
+            print('%-44s %s' % (k, v))
+    else:
+        print(json.dumps(counts(sys.argv[1] if len(sys.argv) > 1 else None), indent=1))
