@@ -8,7 +8,9 @@ import os
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'libdynetlsm_hip.so')
+# (DLSM_LIB: another build of the same sources - a profiling build with in-kernel stamps, an A / B
+# experiment under tmp_timing/ - for the measurement scripts; the product loads the in-tree library)
+LIB_PATH = os.environ.get('DLSM_LIB') or os.path.join(HERE, 'libdynetlsm_hip.so')
 
 c_double_p = C.POINTER(C.c_double)
 c_i64_p = C.POINTER(C.c_int64)

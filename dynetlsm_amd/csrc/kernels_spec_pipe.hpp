@@ -391,6 +391,9 @@ __device__ __forceinline__ void pipe_item_finish(const ChainView &c, const PipeB
             coh_store<false>((double *)(hbase + ((cross ? hx_off : 0u) + (uint32_t)(m * PP_B + kk) * 8u)), h);
     };
     int f = hf0;
+#ifdef DLSM_X_NOH       // measurement only (wrong results): what the launches cost without any H entry
+    f = htot;
+#endif
     if (HPF) {          // the first entry's operands were requested before the batch was released (its own
                         // copy of the code: selecting between `hpre` and fresh loads inside ONE loop left
                         // the structure in scratch memory)
