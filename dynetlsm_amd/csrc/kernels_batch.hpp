@@ -95,9 +95,13 @@ __global__ __launch_bounds__(PP_THREADS) void k_pipe_step_batch(PipeBatchArgs a,
         if (k >= nb) continue;
         const int t = odd ? 2 * (si - nslE) + 1 : 2 * si;
         PipeItemPre<D> pre;
-        PipeHPre<D> nohp;                   // (unused: HPF = false)
+        PipeHPre<D> hp;
         pipe_item_prologue<D, MODEL>(a.c[ci], a.pb[ci], be, t, k, p, lane, pre);
-        pipe_eval_item<D, MODEL, TP, 1>(a.c[ci], a.pb[ci], be, nb, t, k, p, lane, pp_sH, nullptr, pre, nohp
+#if DLSM_H_FIRST
+        pipe_h_prefetch<D, MODEL, 1>(a.c[ci], a.pb[ci], be, nb, t, k, p, lane, hp);
+#endif
+        pipe_eval_item<D, MODEL, TP, 1, false, false, DLSM_H_FIRST != 0, DLSM_H_FIRST != 0>(
+            a.c[ci], a.pb[ci], be, nb, t, k, p, lane, pp_sH, nullptr, pre, hp
 #ifdef DLSM_PIPE_TIMING
                                         , -1, 0
 #endif

@@ -41,6 +41,20 @@
 
 namespace dlsm {
 
+// 1: the lane's H entry at the head of the item (operands requested ahead of the neighbour rows);
+// 0: at its tail.  Measured in round 4 (profiles/r04_h_entry_ablation.md): the head form is no faster
+// (11.2 against 10.9 us per launch) and costs two spilled registers - the tail form stays.
+#ifndef DLSM_H_FIRST
+#define DLSM_H_FIRST 0
+#endif
+// > 0: the operands of the lane's H entry are requested that many trips before the last prefetched
+// trip of the item (into registers the finished trips have released); 0: behind the record's store.
+// Measured in round 4: wherever the request sits (1 or 3 trips early, with scheduling barriers around
+// it) the allocator answers with 20 spilled registers, three prefetched rows and a constant that every
+// trip reloads among them - the 11-trip prefetch already uses all 128 registers.  Off.
+#ifndef DLSM_H_MID
+#define DLSM_H_MID 0
+#endif
 constexpr int PP_THREADS = 1024;
 constexpr int PP_WAVES = PP_THREADS / 64;
 constexpr int PP_B = 128;               // nodes per batch (two 64-lane halves)
@@ -179,17 +193,35 @@ __device__ __forceinline__ void pipe_directed_term(RatioAcc &ra, double &exact, 
     ra.P1 *= fma(E, fast_exp(x1a), 1.0) * fma(E, fast_exp(x1g), 1.0);
 }
 
-// flat H index f -> (node kk of the batch, entry e < ncross + kk);
-// prefix(kk) = ncross kk + kk (kk - 1) / 2 (f < 2^16: the float root is off by one at most)
-__device__ __forceinline__ void pipe_h_decode(int f, int ncross, int nb, int &kk, int &e) {
-    const float bq = (float)(2 * ncross - 1);
-    kk = (int)((__builtin_amdgcn_sqrtf(fmaf(bq, bq, 8.0f * (float)f)) - bq) * 0.5f);
-    kk = min(max(kk, 0), nb - 1);
-    int pre = ncross * kk + ((kk * (kk - 1)) >> 1);
-    if (pre > f) { --kk; pre -= ncross + kk; }
-    else if (pre + ncross + kk <= f) { pre += ncross + kk; ++kk; }
-    kk = min(kk, nb - 1);                 // only when f is not a valid index (clamped prefetch)
-    e = f - pre;
+// The H entries of a (slice, batch) - node kk has ncross + kk of them: the window's earlier batches
+// (cross block), then the earlier nodes of its own batch - as ONE flat list dealt out over the lanes
+// working on the (slice, batch).  Rows are listed in PAIRS (r, nb - 1 - r), r < ceil(nb / 2): a pair
+// holds L = 2 ncross + nb - 1 entries whatever r, so f -> (pair, offset) is one quotient by a launch
+// constant and the pair's two rows are told apart by a compare - 15 vector instructions where the
+// triangular prefix of round 3 (prefix(kk) = ncross kk + kk (kk - 1) / 2, inverted by a float root
+// and a two-branch fix-up) took 28 and was evaluated twice per entry.  Which lane computes an entry
+// does not change its value: the blocks are bit for bit the same.  (nb odd: the middle row is a
+// pair of its own whose second member is empty - its slots beyond ncross + (nb - 1) / 2 are idle.)
+struct PipeHList { int L, npairs, nslots; float invL; };
+__device__ __forceinline__ PipeHList pipe_h_list(int ncross, int nb) {
+    PipeHList h;
+    h.L = max(2 * ncross + nb - 1, 1);
+    h.npairs = (nb + 1) >> 1;
+    h.nslots = h.npairs * h.L;
+    h.invL = 1.0f / (float)h.L;
+    return h;
+}
+// slot f < nslots -> (kk, e); false: the slot is idle (second half of an odd batch's middle pair)
+__device__ __forceinline__ bool pipe_h_decode(int f, const PipeHList &hl, int ncross, int nb, int &kk, int &e) {
+    int r = (int)(((float)f + 0.5f) * hl.invL);            // f / L (f < 2^17: off by one at most)
+    int rem = f - r * hl.L;
+    if (rem < 0) { --r; rem += hl.L; } else if (rem >= hl.L) { ++r; rem -= hl.L; }
+    r = min(r, hl.npairs - 1);                              // only for a clamped prefetch index
+    const int len0 = ncross + r;                            // entries of row r
+    const bool second = rem >= len0;
+    kk = second ? nb - 1 - r : r;
+    e = second ? rem - len0 : rem;
+    return !(second && kk == r);                            // the middle row has no partner
 }
 
 #ifdef DLSM_PIPE_TIMING
@@ -264,6 +296,15 @@ __device__ __forceinline__ void pipe_h_operands(const ChainView &c, const double
         o.xa0[d] = rowk[D + 2 + d];
         o.xa1[d] = rowk[d];
     }
+#if defined(DLSM_X_H) && (DLSM_X_H == 4 || DLSM_X_H == 7)     // measurement only: no operand loads (arithmetic on constants of the lane)
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        o.xm0[d] = 0.001 * (double)jm_; o.xm1[d] = 0.002 * (double)jm_ + d;
+        o.xa0[d] = 0.003 * (double)jkk; o.xa1[d] = 0.004 * (double)jkk + d;
+    }
+    o.yw = (uint32_t)jm_; o.yw2 = 0u; o.rm = 1.0; o.rkk = 1.0;
+    return;
+#endif
     const uint32_t woff = ((uint32_t)jkk * (uint32_t)c.W + ((uint32_t)jm_ >> 5)) * 4u;
     o.yw = *(const uint32_t *)(yrows + woff);
     o.yw2 = 0u; o.rm = 1.0; o.rkk = 1.0;
@@ -281,15 +322,95 @@ __device__ __forceinline__ bool pipe_h_prefetch(const ChainView &c, const PipeBu
     const int j0 = be * PP_B;
     const int jprev = pipe_window_start(be, G) * PP_B;
     const int ncross = j0 - jprev;
-    const int htot = ncross * nb + nb * (nb - 1) / 2;
+    const PipeHList hl = pipe_h_list(ncross, nb);
     const int hf0 = (k * pb.parts + p) * 64 + lane;
     int kk, e;
-    pipe_h_decode(min(hf0, max(htot - 1, 0)), ncross, nb, kk, e);
+    const bool live = pipe_h_decode(min(hf0, max(hl.nslots - 1, 0)), hl, ncross, nb, kk, e);
+    e = min(e, max(ncross + kk - 1, 0));                    // (an idle slot: clamped, its entry is not stored)
     const double *props = pb.prop + (size_t)t * N * PW;
     const char *yrows = (const char *)(c.ybits + (size_t)t * N * W);
     const char *ytrows = MODEL == DLSM_DIRECTED ? (const char *)(c.ytbits + (size_t)t * N * W) : nullptr;
     pipe_h_operands<D, MODEL>(c, props, yrows, ytrows, jprev + e, j0 + kk, o);
-    return hf0 < htot;
+    return hf0 < hl.nslots && live && ncross + kk > 0;
+}
+
+// One H entry: flat index f of (slice t, batch be), operands o.  Rows of the H blocks are addressed as
+// 32-bit offsets from a scalar base.
+template <int D, int MODEL, int G, bool COH, bool SQ>
+__device__ __forceinline__ void pipe_h_entry(const ChainView &c, const PipeBuf &pb, int be, int nb, int t,
+                                             const double *etab, int kk, int e, const PipeHPre<D> &o, bool stamp
+#ifdef DLSM_PIPE_TIMING
+                                             , unsigned long long *ts
+#endif
+                                             ) {
+    const int j0 = be * PP_B;
+    const int jprev = pipe_window_start(be, G) * PP_B;
+    const int ncross = j0 - jprev;
+    const int bb = be & (2 * G - 1);
+    const double E = pb.consts[0];
+    char *hbase = (char *)(pb.Hd + ((size_t)bb * c.T + t) * PP_B * (COH ? 2 * PP_B : PP_B));
+    const uint32_t hx_off = (uint32_t)((const char *)(pb.Hx + ((size_t)bb * c.T + t) * ((2 * G - 1) * PP_B) * PP_B) -
+                                       (const char *)hbase);                          // one allocation
+    const int jm_ = jprev + e;                 // jprev + ncross == j0
+    double xm0[D], xm1[D], xa0[D], xa1[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) { xm0[d] = o.xm0[d]; xm1[d] = o.xm1[d]; xa0[d] = o.xa0[d]; xa1[d] = o.xa1[d]; }
+    const int y1 = (int)((o.yw >> (jm_ & 31)) & 1u);
+    const bool cross = e < ncross;
+    const int m = cross ? e : e - ncross;
+    // (SQ: the squared-distance model, a template flag here as in the trips: as a run-time flag it
+    // cost two selects per distance and a clamp per exponential on every entry)
+    const double a0 = dist_fast<D>(xm0, xa0, SQ ? 1 : 0);
+    const double a1 = dist_fast<D>(xm0, xa1, SQ ? 1 : 0);
+    const double b0 = dist_fast<D>(xm1, xa0, SQ ? 1 : 0);
+    const double b1 = dist_fast<D>(xm1, xa1, SQ ? 1 : 0);
+#ifdef DLSM_PIPE_TIMING
+    if (stamp) { DLSM_STAMP(4, a0 + b1) }
+#endif
+    double h;
+    if (MODEL == DLSM_UNDIRECTED) {
+        const double eb0 = SQ ? tab_exp11_clamped(-b0, etab) : tab_exp11(-b0, etab);
+        const double ea1 = SQ ? tab_exp11_clamped(-a1, etab) : tab_exp11(-a1, etab);
+        const double eb1 = SQ ? tab_exp11_clamped(-b1, etab) : tab_exp11(-b1, etab);
+        const double ea0 = SQ ? tab_exp11_clamped(-a0, etab) : tab_exp11(-a0, etab);
+        double num = fma(E, eb0, 1.0) * fma(E, ea1, 1.0);
+        double den = fma(E, eb1, 1.0) * fma(E, ea0, 1.0);
+        // the edge's factor e^{(b0 - b1) - (a0 - a1)} from the four exponentials at hand;
+        // a fifth one only when their product left the normal range (distances > 300)
+        const double fn = eb1 * ea0, fd = eb0 * ea1;
+        const bool tiny = y1 && !(fd > 1e-290 && fn > 1e-290);      // both products normal
+        if (y1 && !tiny) { num *= fn; den *= fd; }
+        // (den is a product of factors >= 1 and, with an edge, of fd > 1e-290: normal, so the
+        // reciprocal's Newton form applies - within 2 ulp of the division at a fifth of it)
+        h = num * fast_rcp(den);
+        if (__builtin_amdgcn_ballot_w64(tiny)) { if (tiny) h *= fast_exp((b0 - b1) - (a0 - a1)); }
+    } else {
+        double bin = c.intercept[0], bout = c.intercept[1];
+        const double lE = bin + bout;
+        const int y2 = (int)((o.yw2 >> (jm_ & 31)) & 1u);
+        const double irm = 1.0 / o.rm, irkk = 1.0 / o.rkk;
+        const double aa = bin * irm + bout * irkk, cc = bin * irkk + bout * irm;
+        RatioAcc rb, rq;
+        double eb = 0.0, eq = 0.0;
+        pipe_directed_term(rb, eb, b0, b1, y1, y2, aa, cc, E, lE);
+        pipe_directed_term(rq, eq, a0, a1, y1, y2, aa, cc, E, lE);
+        // exp(delta(b) - delta(a)) without the logs: the products divide out
+        h = ((rb.P0 * rq.P1) / (rb.P1 * rq.P0)) * exp((rb.lin - rq.lin) + (eb - eq));
+    }
+#if defined(DLSM_X_H) && DLSM_X_H == 6     // measurement only: operands loaded, no arithmetic, the neutral factor stored
+    h = fma(0.0, (xm0[0] + xm1[0]) + (xa0[0] + xa1[0]) + (double)y1, 1.0);
+#endif
+#if defined(DLSM_X_H) && (DLSM_X_H == 7 || DLSM_X_H == 8)     // measurement only: full arithmetic, the neutral factor stored
+    h = h != 123.456 ? 1.0 : h;
+#endif
+#if defined(DLSM_X_H) && DLSM_X_H == 3     // measurement only: arithmetic, no store
+    if (h != 123.456) return;
+#endif
+    if (COH)        // persistent launch: one row of 2 PP_B factors per later node kk - its window's
+                    // nodes, then its own batch's - so that a wavefront's entries are contiguous
+        coh_store<true>((double *)(hbase + (uint32_t)(kk * (2 * PP_B) + (cross ? e : PP_B + m)) * 8u), h);
+    else
+        coh_store<false>((double *)(hbase + ((cross ? hx_off : 0u) + (uint32_t)(m * PP_B + kk) * 8u)), h);
 }
 
 // The item's tail: wavefront reductions, the (sum, ratio) record, and this lane's share of the
@@ -297,7 +418,7 @@ __device__ __forceinline__ bool pipe_h_prefetch(const ChainView &c, const PipeBu
 // the persistent launch's item (neighbours staged in LDS, kernels_pipe_persist.hpp).
 // HPF: `hpre` holds the operands of the lane's first H entry (by reference and under a template
 // flag: a pointer that may be null kept the structure in scratch memory)
-template <int D, int MODEL, int G, bool COH, bool HPF>
+template <int D, int MODEL, int G, bool COH, bool HPF, bool HDONE = false>
 __device__ __forceinline__ void pipe_item_finish(const ChainView &c, const PipeBuf &pb, int be, int nb,
                                                  int t, int k, int p, int lane, const double *etab,
                                                  double acc, RatioAcc &ra, bool noflush,
@@ -313,12 +434,8 @@ __device__ __forceinline__ void pipe_item_finish(const ChainView &c, const PipeB
     const int ncross = j0 - jprev;
     const int bb = be & (2 * G - 1);
     const double *props = pb.prop + (size_t)t * N * PW;
-    const double E = pb.consts[0];
-    double bin = 0.0, bout = 0.0;
-    if (MODEL == DLSM_DIRECTED) { bin = c.intercept[0]; bout = c.intercept[1]; }
-    const double lE = bin + bout;
     const int hround = nb * pb.parts * 64;
-    const int htot = ncross * nb + nb * (nb - 1) / 2;
+    const PipeHList hl = pipe_h_list(ncross, nb);
     const int hf0 = (k * pb.parts + p) * 64 + lane;
     double tot_l, tot_r;
     if (noflush) {
@@ -333,79 +450,44 @@ __device__ __forceinline__ void pipe_item_finish(const ChainView &c, const PipeB
         coh_store2<COH>(f, 0u, make_double2(tot_l, tot_r));
     }
     DLSM_STAMP(3, tot_r)
-    // this lane's H entries (see above).  Rows of `props`, the bits and the H blocks are
-    // addressed as 32-bit offsets from scalar bases.
+    // this lane's H entries (pipe_h_decode).  Rows of `props` and the bits are addressed as
+    // 32-bit offsets from scalar bases.
     const char *yrows = (const char *)(c.ybits + (size_t)t * N * W);
     const char *ytrows = MODEL == DLSM_DIRECTED ? (const char *)(c.ytbits + (size_t)t * N * W) : nullptr;
-    char *hbase = (char *)(pb.Hd + ((size_t)bb * c.T + t) * PP_B * (COH ? 2 * PP_B : PP_B));
-    const uint32_t hx_off = (uint32_t)((const char *)(pb.Hx + ((size_t)bb * c.T + t) * ((2 * G - 1) * PP_B) * PP_B) -
-                                       (const char *)hbase);                          // one allocation
-    // one entry: flat index f, operands o
-    auto h_entry = [&](int f, const PipeHPre<D> &o) {
-        int kk, e;
-        pipe_h_decode(f, ncross, nb, kk, e);
-        const int jm_ = jprev + e;                 // jprev + ncross == j0
-        double xm0[D], xm1[D], xa0[D], xa1[D];
-#pragma unroll
-        for (int d = 0; d < D; ++d) { xm0[d] = o.xm0[d]; xm1[d] = o.xm1[d]; xa0[d] = o.xa0[d]; xa1[d] = o.xa1[d]; }
-        const int y1 = (int)((o.yw >> (jm_ & 31)) & 1u);
-        const bool cross = e < ncross;
-        const int m = cross ? e : e - ncross;
-        const double a0 = dist_fast<D>(xm0, xa0, c.squared);
-        const double a1 = dist_fast<D>(xm0, xa1, c.squared);
-        const double b0 = dist_fast<D>(xm1, xa0, c.squared);
-        const double b1 = dist_fast<D>(xm1, xa1, c.squared);
-#ifdef DLSM_PIPE_TIMING
-        if (f == hf0) { DLSM_STAMP(4, a0 + b1) }
-#endif
-        double h;
-        if (MODEL == DLSM_UNDIRECTED) {
-            const double eb0 = tab_exp11_clamped(-b0, etab), ea1 = tab_exp11_clamped(-a1, etab);
-            const double eb1 = tab_exp11_clamped(-b1, etab), ea0 = tab_exp11_clamped(-a0, etab);
-            double num = fma(E, eb0, 1.0) * fma(E, ea1, 1.0);
-            double den = fma(E, eb1, 1.0) * fma(E, ea0, 1.0);
-            // the edge's factor e^{(b0 - b1) - (a0 - a1)} from the four exponentials at hand;
-            // a fifth one only when their product left the normal range (distances > 300)
-            const double fn = eb1 * ea0, fd = eb0 * ea1;
-            const bool tiny = y1 && !(fd > 1e-290 && fn > 1e-290);      // both products normal
-            if (y1 && !tiny) { num *= fn; den *= fd; }
-            // (den is a product of factors >= 1 and, with an edge, of fd > 1e-290: normal, so the
-            // reciprocal's Newton form applies - within 2 ulp of the division at a fifth of it)
-            h = num * fast_rcp(den);
-            if (__builtin_amdgcn_ballot_w64(tiny)) { if (tiny) h *= fast_exp((b0 - b1) - (a0 - a1)); }
-        } else {
-            const int y2 = (int)((o.yw2 >> (jm_ & 31)) & 1u);
-            const double irm = 1.0 / o.rm, irkk = 1.0 / o.rkk;
-            const double aa = bin * irm + bout * irkk, cc = bin * irkk + bout * irm;
-            RatioAcc rb, rq;
-            double eb = 0.0, eq = 0.0;
-            pipe_directed_term(rb, eb, b0, b1, y1, y2, aa, cc, E, lE);
-            pipe_directed_term(rq, eq, a0, a1, y1, y2, aa, cc, E, lE);
-            // exp(delta(b) - delta(a)) without the logs: the products divide out
-            h = ((rb.P0 * rq.P1) / (rb.P1 * rq.P0)) * exp((rb.lin - rq.lin) + (eb - eq));
-        }
-        if (COH)        // persistent launch: one row of 2 PP_B factors per later node kk - its window's
-                        // nodes, then its own batch's - so that a wavefront's entries are contiguous
-            coh_store<true>((double *)(hbase + (uint32_t)(kk * (2 * PP_B) + (cross ? e : PP_B + m)) * 8u), h);
-        else
-            coh_store<false>((double *)(hbase + ((cross ? hx_off : 0u) + (uint32_t)(m * PP_B + kk) * 8u)), h);
-    };
     int f = hf0;
 #ifdef DLSM_X_NOH       // measurement only (wrong results): what the launches cost without any H entry
-    f = htot;
+    f = hl.nslots;
 #endif
-    if (HPF) {          // the first entry's operands were requested before the batch was released (its own
+#define DLSM_H_CALL(SQ_, KK_, E_, O_, STAMP_)                                                         \
+    pipe_h_entry<D, MODEL, G, COH, SQ_>(c, pb, be, nb, t, etab, KK_, E_, O_, STAMP_ DLSM_H_TS)
+#ifdef DLSM_PIPE_TIMING
+#define DLSM_H_TS , ts
+#else
+#define DLSM_H_TS
+#endif
+    if (HDONE) {        // the lane's first entry was computed at the head of the item (pipe_eval_item)
+        f += hround;
+    } else if (HPF) {   // the first entry's operands were requested before the batch was released (its own
                         // copy of the code: selecting between `hpre` and fresh loads inside ONE loop left
                         // the structure in scratch memory)
-        if (f < htot) { h_entry(f, hpre); f += hround; }
+        if (f < hl.nslots) {
+            int kk, e;
+            if (pipe_h_decode(f, hl, ncross, nb, kk, e)) {
+                if (c.squared) DLSM_H_CALL(true, kk, e, hpre, true); else DLSM_H_CALL(false, kk, e, hpre, true);
+            }
+            f += hround;
+        }
     }
-    for (; f < htot; f += hround) {
+    for (; f < hl.nslots; f += hround) {
         int kk, e;
-        pipe_h_decode(f, ncross, nb, kk, e);
+        if (!pipe_h_decode(f, hl, ncross, nb, kk, e)) continue;
         PipeHPre<D> o;
         pipe_h_operands<D, MODEL>(c, props, yrows, ytrows, jprev + e, j0 + kk, o);
-        h_entry(f, o);
+        if (c.squared) DLSM_H_CALL(true, kk, e, o, !HPF && !HDONE && f == hf0);
+        else DLSM_H_CALL(false, kk, e, o, !HPF && !HDONE && f == hf0);
     }
+#undef DLSM_H_CALL
+#undef DLSM_H_TS
     DLSM_STAMP(5, acc)
 }
 
@@ -457,7 +539,11 @@ __host__ __device__ constexpr int pipe_prefetch_trips(int D) {
 // from resolver workgroups of the same launch and its records go to them - sc1 accesses.
 // LDSX: the part's neighbour rows were staged in LDS by the workgroup (sX[row - lo][D]): the
 // "prefetch" is LDS reads and the trips beyond it read LDS as they go.
-template <int D, int MODEL, bool TP, int G, bool COH = false, bool LDSX = false, bool HPF = false>
+// HFIRST (with HPF): the lane's first H entry is computed at the HEAD of the item - its operands were
+// requested before the neighbours', so they arrive first and the entry's arithmetic runs under the
+// neighbour rows' flight instead of behind a round trip of its own at the item's tail
+template <int D, int MODEL, bool TP, int G, bool COH = false, bool LDSX = false, bool HPF = false,
+          bool HFIRST = false>
 __device__ __forceinline__ void pipe_eval_item(const ChainView &c, const PipeBuf &pb, int be,
                                                int nb, int t, int k, int p, int lane,
                                                const double *etab, const double *sX,
@@ -519,14 +605,36 @@ __device__ __forceinline__ void pipe_eval_item(const ChainView &c, const PipeBuf
     // H entries of the batch: (node kk, entry e), e < ncross + kk: the previous batch (cross
     // block) then the earlier nodes of kk's own batch.  They are dealt out evenly over ALL the
     // lanes working on this (slice, batch) - not to the wavefronts of "their" node, whose
-    // entry counts differ by 2x - through the flat index f = prefix(kk) + e,
-    // prefix(kk) = ncross kk + kk (kk - 1) / 2; one entry per lane when there are >= 3 parts.
-    // Their operands are loaded where they are used, after the neighbour loop: the registers
-    // a prefetch would hold are worth more as prefetched neighbours (measured: +6 % at C2).
-    const int hround = nb * pb.parts * 64;
-    const int htot = ncross * nb + nb * (nb - 1) / 2;
-    const int hf0 = (k * pb.parts + p) * 64 + lane;
+    // entry counts differ by 2x - through the flat list of pipe_h_decode; one entry per lane when
+    // there are >= 3 parts.  Their operands are loaded where they are used, after the neighbour
+    // loop: the registers a prefetch would hold are worth more as prefetched neighbours
+    // (measured: +6 % at C2; computing the entry at the head of the item instead, DLSM_H_FIRST,
+    // measured no better in round 4).
+    if (HFIRST && HPF) {
+#ifndef DLSM_X_NOH
+        const PipeHList hl = pipe_h_list(ncross, nb);
+        const int hf0 = (k * pb.parts + p) * 64 + lane;
+        int kk, e;
+        if (hf0 < hl.nslots && pipe_h_decode(hf0, hl, ncross, nb, kk, e)) {
+            if (c.squared)
+                pipe_h_entry<D, MODEL, G, COH, true>(c, pb, be, nb, t, etab, kk, e, hpre, true
+#ifdef DLSM_PIPE_TIMING
+                                                     , ts
+#endif
+                                                     );
+            else
+                pipe_h_entry<D, MODEL, G, COH, false>(c, pb, be, nb, t, etab, kk, e, hpre, true
+#ifdef DLSM_PIPE_TIMING
+                                                      , ts
+#endif
+                                                      );
+        }
+#endif
+    }
 
+    // HMID: request the first H entry's operands DLSM_H_MID trips before the last prefetched one
+    constexpr bool HMID = DLSM_H_MID > 0 && !COH && !LDSX && !HPF && PP_NPRE >= DLSM_H_MID + 3;
+    PipeHPre<D> hmid;
     double acc = 0.0;
     RatioAcc ra;
 #define DLSM_PIPE_TERM(XI_, YB_, YCB_, RI_, FLUSH_, SQ_)                                      \
@@ -591,6 +699,13 @@ __device__ __forceinline__ void pipe_eval_item(const ChainView &c, const PipeBuf
             DLSM_PIPE_TERM(xpre[u], yb_, ycb_, rpre[MODEL == DLSM_DIRECTED ? u : 0], FLUSH_, SQ_) \
         if (u == 0) { DLSM_STAMP(1, ra.P0) }                                                  \
         if (u == PP_NPRE - 1) { DLSM_STAMP(2, ra.P0) }                                        \
+        if (HMID && u == PP_NPRE - 1 - DLSM_H_MID) {                                          \
+            /* the lane's H entry: operands requested HERE, into the registers the trips     \
+               behind us have released, so that they are at hand when the record is stored */ \
+            __builtin_amdgcn_sched_barrier(0);   /* not hoisted among the prologue's loads */ \
+            pipe_h_prefetch<D, MODEL, G>(c, pb, be, nb, t, k, p, lane, hmid);                 \
+            __builtin_amdgcn_sched_barrier(0);                                                \
+        }                                                                                     \
     }                                                                                         \
     /* the trips beyond the prefetched ones.  TP: each trip requests the next one's operands   \
        (clamped address, no predication) before it computes. */                               \
@@ -629,7 +744,8 @@ __device__ __forceinline__ void pipe_eval_item(const ChainView &c, const PipeBuf
 #undef DLSM_PIPE_REQUEST
 #undef DLSM_PIPE_MASKS
 #undef DLSM_PIPE_TERM
-    pipe_item_finish<D, MODEL, G, COH, HPF>(c, pb, be, nb, t, k, p, lane, etab, acc, ra, noflush, hpre
+    pipe_item_finish<D, MODEL, G, COH, HPF || HMID, HFIRST && HPF>(c, pb, be, nb, t, k, p, lane, etab, acc, ra, noflush,
+                                                                   HMID ? hmid : hpre
 #ifdef DLSM_PIPE_TIMING
                                        , ts
 #endif
@@ -1067,10 +1183,16 @@ __global__ __launch_bounds__(PP_THREADS) void k_pipe_step(ChainView c, PipeBuf p
         const int t = odd ? 2 * (si - nslE) + 1 : 2 * si;
         constexpr int IM = MODEL == DLSM_DIRECTED_CASE_CONTROL ? DLSM_DIRECTED : MODEL;
         PipeItemPre<D> pre;
-        PipeHPre<D> nohp;                   // (unused: HPF = false)
+        PipeHPre<D> hp;
         pipe_item_prologue<D, IM>(c, pb, be, t, k, p, lane, pre);
-        pipe_eval_item<D, IM, TP, G>(
-            c, pb, be, nb, t, k, p, lane, pp_sH, nullptr, pre, nohp
+        // the lane's H entry: operands requested here, ahead of the neighbour rows, and the entry
+        // computed at the head of the item (round 4: at the item's tail its loads were a round trip of
+        // their own that every wavefront of the SIMD sat out - 2.5 of a launch's 10.9 us went to H)
+#if DLSM_H_FIRST
+        pipe_h_prefetch<D, IM, G>(c, pb, be, nb, t, k, p, lane, hp);
+#endif
+        pipe_eval_item<D, IM, TP, G, false, false, DLSM_H_FIRST != 0, DLSM_H_FIRST != 0>(
+            c, pb, be, nb, t, k, p, lane, pp_sH, nullptr, pre, hp
 #ifdef DLSM_PIPE_TIMING
             , l + 1, gw
 #endif

@@ -74,6 +74,21 @@ for l in range(24):
     row['span_us'] = round(float((max(ends) - t0) * 0.01), 2)
     out.append(row)
     print(json.dumps(row))
+# per wavefront: how long each phase takes, by the wavefront's rank on its SIMD (wavefronts w, w + 4,
+# w + 8, w + 12 of a workgroup share SIMD w % 4: rank = w / 4)
+it = items[8].astype(np.int64)
+ok = it[:, 0] > 0
+t0 = it[ok, 0].min()
+names = ['entry', 'first trip done', 'last prefetched trip done', 'record stored', 'H operands here', 'exit']
+for rank in range(4):
+    sel = ok & ((np.arange(4096) % 16) // 4 == rank)
+    rel = np.where(it[sel] > 0, (it[sel] - t0) * 0.01, np.nan)
+    dur = np.diff(rel, axis=1)
+    print('launch 8, SIMD rank %d: stamps us (median) %s ; phase durations us (median) %s'
+          % (rank, [round(float(np.nanmedian(rel[:, i])), 2) for i in range(6)],
+             [round(float(np.nanmedian(dur[:, i])), 2) for i in range(5)]))
+    out.append({'launch8_simd_rank': rank, 'stamps_us_median': [round(float(np.nanmedian(rel[:, i])), 2) for i in range(6)],
+                'phase_us_median': [round(float(np.nanmedian(dur[:, i])), 2) for i in range(5)], 'phases': names})
 # the dispatch ramp of one full launch: entry and exit of the workgroups in blockIdx order
 it = items[8].astype(np.int64)
 ok = it[:, 0] > 0
