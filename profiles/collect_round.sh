@@ -8,7 +8,15 @@ TAG=${1:-round}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
-for m in lsm hdp cc; do bash $ROOT/profiles/collect.sh $TAG $m all > $OUT/collect_$m.log 2>&1; done
+# 1. the profiler's passes; 2. this round's stored durations and traffic (what the bench lines' rooflines divide by:
+#    written where bench.py reads them, and into $OUT for the way home); 3. the bench lines
+for m in lsm hdp cc; do bash $ROOT/profiles/collect.sh $TAG $m profile > $OUT/collect_$m.log 2>&1; done
+cd $ROOT
+for m in lsm hdp cc; do cp $OUT/kernel_stats_$m.csv profiles/${TAG}_kernel_stats_$m.csv; cp $OUT/traffic_$m.json profiles/${TAG}_traffic_$m.json; done
+python3 profiles/kernel_durations.py $TAG > profiles/kernel_durations.json
+python3 profiles/merge_traffic.py $TAG > profiles/traffic.json
+cp profiles/kernel_durations.json profiles/traffic.json $OUT/
+for m in lsm hdp cc; do bash $ROOT/profiles/collect.sh $TAG $m bench >> $OUT/collect_$m.log 2>&1; done
 cd $ROOT
 python3 bench.py < /dev/null > $OUT/bench_default.json 2> $OUT/bench_default.err
 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver_args.json 2> $OUT/bench_driver_args.err
