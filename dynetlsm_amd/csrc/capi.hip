@@ -1039,7 +1039,7 @@ static int launch_sweep_pipe(dlsm_chain *h, IterRef iter, bool alloc_only = fals
     const size_t n_full0 = (size_t)2 * G * T * PP_B * parts * 2;
     const size_t n_h = (size_t)2 * G * T * PP_B * PP_B;
     const size_t n_hx = (size_t)2 * G * T * xr * PP_B;
-    const size_t n_acc = even2(((size_t)T * 2 * G * (PP_B + 1) + 1) / 2);   // int32 pairs
+    const size_t n_acc = even2(((size_t)T * 2 * G * PP_ACC + 1) / 2);   // int32 pairs
     // persistent form: ticket counter, resolved[t], done[t][b], one 64-byte line each
     const int n_sync = persist ? 1 + T + T * nbat : 0;
     const size_t n_syncd = (size_t)n_sync * PS_STRIDE * sizeof(int32_t) / sizeof(double);
@@ -1069,10 +1069,10 @@ static int launch_sweep_pipe(dlsm_chain *h, IterRef iter, bool alloc_only = fals
     pb.G = G; pb.xr = xr;
     pb.per = ((N + parts - 1) / parts + 63) / 64 * 64;      // parts start on a 64-neighbour boundary
     pb.nctrl = h->nctrl;
-    const size_t lds = (size_t)PP_B * PP_B * sizeof(double);
-    // persistent form: the resolvers' diagonal block by rows of PR_LD, the evaluators' exp table
-    // and staged neighbour rows
-    const size_t lds_persist = (size_t)PP_B * PR_LD * sizeof(double);
+    // the resolvers' diagonal block by rows of PR_LD (an odd stride: row_resolve), the evaluators' exp table
+    // (and, persistent form, their staged neighbour rows)
+    const size_t lds = (size_t)PP_B * PR_LD * sizeof(double);
+    const size_t lds_persist = lds;
     if (persist && ((size_t)EXPTAB11_N + (size_t)pb.per * DD) * sizeof(double) > lds_persist)
         FAIL(h, DLSM_E_LIMIT, "algo 7: a part of %d neighbours does not fit the evaluators' LDS", pb.per);
     auto ku = k_pipe_step<DD, DLSM_UNDIRECTED>;

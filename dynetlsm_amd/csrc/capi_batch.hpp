@@ -4,7 +4,7 @@
 
 struct dlsm_batch {
     std::vector<dlsm_chain *> ch;
-    hipStream_t stream = nullptr;           // = ch[0]'s own stream
+    hipStream_t stream = nullptr;           // the batch's own stream: every member chain's calls order on it
     long merged_iterations = 0, single_iterations = 0;
     std::string err;
 };
@@ -67,7 +67,7 @@ int batch_enqueue_iteration(dlsm_batch *b, int it, int procrustes_ref) {
         f.pa = PostFusedArgs{xref ? 1 : 0, nip, h->partials + (size_t)ll_blocks(h) * 4, nwg + T, (nbat - 1) * PP_B,
                              T > 1 ? 1 : 0, xref, h->trace_X};
     }
-    const size_t lds = (size_t)PP_B * PP_B * sizeof(double);
+    const size_t lds = (size_t)PP_B * PR_LD * sizeof(double);
     const bool lng = pa.pb[0].per > 64 * pipe_prefetch_trips(DD);
     {
         static bool armed = false;          // per instantiation
@@ -153,7 +153,11 @@ int dlsm_batch_create(dlsm_chain *const *chains, int n, dlsm_batch **out) {
     }
     dlsm_batch *b = new dlsm_batch();
     b->ch.assign(chains, chains + n);
-    b->stream = h0->stream;
+    // (a stream of the batch's own: a member chain destroyed before the batch takes its own stream with it)
+    if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete b;
+        FAIL(nullh, DLSM_E_HIP, "hipStreamCreate failed");
+    }
     for (int c = 0; c < n; ++c) {
         dlsm_chain *h = chains[c];
         drop_graph(h);
@@ -173,6 +177,7 @@ void dlsm_batch_destroy(dlsm_batch *b) {
         h->stream = h->own_stream; h->own_stream = nullptr; h->batch = nullptr;
         h->prop_drawn_for = -1;
     }
+    if (b->stream) hipStreamDestroy(b->stream);
     delete b;
 }
 

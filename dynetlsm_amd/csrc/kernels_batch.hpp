@@ -53,12 +53,18 @@ __global__ __launch_bounds__(PP_THREADS) void k_pipe_step_batch(PipeBatchArgs a,
     if (bx < nres) {
         const int ci = bx / T, t = bx - ci * T;
         const int b = l - (t & 1);
-        if (b >= 0 && b < a.pb[ci].nbat)
-            pipe_resolve<D, 1>(a.c[ci], a.pb[ci], b, t, pp_sH, sPart, sMask, sPrev, sSat, sOwn, false
+        if (b >= 0 && b < a.pb[ci].nbat) {
+            __shared__ double sCross[PP_B];
+            __shared__ unsigned long long sSatMask[2];
+            __shared__ double sTab[EXPTAB_N];
+            exp_table_fill(sTab, threadIdx.x);
+            __syncthreads();
+            row_resolve<D, false>(a.c[ci], a.pb[ci], b, t, pp_sH, sPart, sMask, nullptr, sCross, sSatMask, sTab
 #ifdef DLSM_PIPE_TIMING
-                               , l + 1
+                                  , l + 1
 #endif
-                               );
+                                  );
+        }
         __syncthreads();                    // the block's LDS is free for the evaluators' table
     }
     const PipeBuf &pb0 = a.pb[0];

@@ -59,6 +59,10 @@ constexpr int PP_THREADS = 1024;
 constexpr int PP_WAVES = PP_THREADS / 64;
 constexpr int PP_B = 128;               // nodes per batch (two 64-lane halves)
 constexpr int PP_MAXPARTS = 8;
+// per (slice, batch slot) of PipeBuf::acc: [0] count, [1 .. PP_B] the accepted nodes ascending (the [m][k]
+// resolver's gather list), [PP_ACC_MASK ..] the same set as two 64-bit masks (the row resolver's)
+constexpr int PP_ACC = PP_B + 8;
+constexpr int PP_ACC_MASK = PP_B + 4;
 
 // G batches are resolved (and G evaluated) per launch.  Batch b is evaluated while the batches
 // from ws(b) = G (b / G - 1) on are still unresolved - its WINDOW: G = 1: the previous batch;
@@ -69,7 +73,7 @@ struct PipeBuf {
     double *Hd;      // [2G][T][PP_B][PP_B] : Hd[m][k], k > m, both in the batch: the FACTOR
                      //                      exp(H[k][m]) of node m's acceptance
     double *Hx;      // [2G][T][xr][PP_B] : Hx[m][k], m the m-th node of the window's earlier batches
-    int32_t *acc;    // [T][2G][PP_B + 1] : count, accepted nodes of the batch in that slot
+    int32_t *acc;    // [T][2G][PP_ACC] : count, accepted nodes of the batch in that slot, their masks
     double *consts;  // [2] : E = exp(sum of intercepts), flush interval
     const int32_t *nctrl;   // case-control: valid controls per (t, i, direction)
     int parts, per, nbat;
@@ -348,7 +352,10 @@ __device__ __forceinline__ void pipe_h_entry(const ChainView &c, const PipeBuf &
     const int ncross = j0 - jprev;
     const int bb = be & (2 * G - 1);
     const double E = pb.consts[0];
-    char *hbase = (char *)(pb.Hd + ((size_t)bb * c.T + t) * PP_B * (COH ? 2 * PP_B : PP_B));
+    // one batch per launch (and the persistent launch): the blocks by ROWS of the later node (row_resolve);
+    // two batches per launch keep the [m][k] blocks of pipe_resolve
+    constexpr bool HROWS = COH || G == 1;
+    char *hbase = (char *)(pb.Hd + ((size_t)bb * c.T + t) * PP_B * (HROWS ? 2 * PP_B : PP_B));
     const uint32_t hx_off = (uint32_t)((const char *)(pb.Hx + ((size_t)bb * c.T + t) * ((2 * G - 1) * PP_B) * PP_B) -
                                        (const char *)hbase);                          // one allocation
     const int jm_ = jprev + e;                 // jprev + ncross == j0
@@ -406,9 +413,9 @@ __device__ __forceinline__ void pipe_h_entry(const ChainView &c, const PipeBuf &
 #if defined(DLSM_X_H) && DLSM_X_H == 3     // measurement only: arithmetic, no store
     if (h != 123.456) return;
 #endif
-    if (COH)        // persistent launch: one row of 2 PP_B factors per later node kk - its window's
-                    // nodes, then its own batch's - so that a wavefront's entries are contiguous
-        coh_store<true>((double *)(hbase + (uint32_t)(kk * (2 * PP_B) + (cross ? e : PP_B + m)) * 8u), h);
+    if (HROWS)      // one row of 2 PP_B factors per later node kk - its window's nodes, then its own
+                    // batch's - so that a wavefront's entries are contiguous
+        coh_store<COH>((double *)(hbase + (uint32_t)(kk * (2 * PP_B) + (cross ? e : PP_B + m)) * 8u), h);
     else
         coh_store<false>((double *)(hbase + ((cross ? hx_off : 0u) + (uint32_t)(m * PP_B + kk) * 8u)), h);
 }
@@ -892,8 +899,8 @@ __device__ __forceinline__ void pipe_resolve(const ChainView &c, const PipeBuf &
     const bool valid = k < nb;
     const double *Hd = pb.Hd + ((size_t)bb * c.T + t) * PP_B * PP_B;
     const double *Hx = pb.Hx + ((size_t)bb * c.T + t) * ((G2 - 1) * PP_B) * PP_B;
-    int32_t *acct = pb.acc + (size_t)t * G2 * (PP_B + 1);
-    int32_t *accg = acct + (size_t)bb * (PP_B + 1);            // this batch's list
+    int32_t *acct = pb.acc + (size_t)t * G2 * PP_ACC;
+    int32_t *accg = acct + (size_t)bb * PP_ACC;                // this batch's list
     const int ws = pipe_window_start(b, G);
     const int nwin = b - ws;                                    // earlier batches of the window: <= 3
     // diagonal block -> LDS (unconditional clamped loads, see k_spec_resolve)
@@ -909,14 +916,14 @@ __device__ __forceinline__ void pipe_resolve(const ChainView &c, const PipeBuf &
     for (int w = 0; w < G2 - 1; ++w)
         if (w < nwin) {
             const bool own = COH || (own_prev && ws + w == b - 1);
-            cntw[w] = own ? sOwn[0] : acct[(size_t)((ws + w) & (G2 - 1)) * (PP_B + 1)];
+            cntw[w] = own ? sOwn[0] : acct[(size_t)((ws + w) & (G2 - 1)) * PP_ACC];
         }
     const int nprev = cntw[0] + cntw[1] + cntw[2];
 #pragma unroll
     for (int w = 0; w < G2 - 1; ++w)
         if (w < nwin) {
             const bool own = COH || (own_prev && ws + w == b - 1);
-            const int32_t *lst = own ? sOwn : acct + (size_t)((ws + w) & (G2 - 1)) * (PP_B + 1);
+            const int32_t *lst = own ? sOwn : acct + (size_t)((ws + w) & (G2 - 1)) * PP_ACC;
             const int off = w == 0 ? 0 : (w == 1 ? cntw[0] : cntw[0] + cntw[1]);
             for (int a = tid; a < cntw[w]; a += PP_THREADS) sPrev[off + a] = w * PP_B + lst[1 + a];
         }
@@ -1089,6 +1096,254 @@ __device__ __forceinline__ void pipe_resolve(const ChainView &c, const PipeBuf &
 #endif
 }
 
+// ---- the resolver for H blocks stored BY ROWS (round 3: the persistent launch; round 4: every launch-per-batch
+// kernel with one batch per launch) --------------------------------------------------------------------------
+// The evaluators file the factors of later node kk as ONE row [window (PP_B) | own batch (PP_B)]: a wavefront's
+// 64 entries - consecutive entries of one row in the flat list of pipe_h_decode - are 512 contiguous bytes
+// instead of 64 stores a kilobyte apart (the [m][k] blocks: 2.15 MB written and 7.9 MB fetched per launch, each
+// 128-byte line assembled from 16 wavefronts on eight XCDs).
+constexpr int PR_LD = PP_B + 1;          // LDS row stride of the diagonal block (doubles)
+
+// the product (or, for a node resolved in the log domain, the sum) over the 8 adjacent lanes
+// that share a node: quad_perm xor 1, xor 2, then the half-row mirror
+__device__ __forceinline__ double group8_prod(double v) {
+    v *= dpp_move<0xB1>(v);
+    v *= dpp_move<0x4E>(v);
+    v *= dpp_move<0x141>(v);
+    return v;
+}
+__device__ __forceinline__ double group8_sum(double v) {
+    v += dpp_move<0xB1>(v);
+    v += dpp_move<0x4E>(v);
+    v += dpp_move<0x141>(v);
+    return v;
+}
+
+template <int D, bool COH>
+__device__ __forceinline__ void row_resolve(const ChainView &c, const PipeBuf &pb, int b, int t,
+                                                double *sD, double *sPart,
+                                                unsigned long long (*sMask)[2],
+                                                unsigned long long *sMaskPrev, double *sCross,
+                                                unsigned long long *sSatMask, const double *sTab
+#ifdef DLSM_PIPE_TIMING
+                                                , int tl
+#endif
+                                                ) {
+    constexpr int PW = 2 * D + 2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef DLSM_PIPE_TIMING
+    unsigned long long ts[5] = {0, 0, 0, 0, 0};
+#endif
+    DLSM_STAMP(0, (double)tid)
+    const int N = c.N;
+    const int j0 = b * PP_B;
+    const int nb = min(PP_B, N - j0);
+    const int bb = b & 1;
+    const int half = wave & 1, part = wave >> 1;
+    const int k = 64 * half + lane;
+    const bool owner = wave < 2;
+    const bool valid = k < nb;
+    const double *H = pb.Hd + ((size_t)bb * c.T + t) * PP_B * (2 * PP_B);
+    // ---- every load of the batch, at once ------------------------------------------------------
+    // cross factors: node kx = tid / 8; trip u: window nodes 16 u + 2 jx, + 1 - the 8 lanes of a
+    // node read one 128-byte line per trip
+    const int kx = tid >> 3, jx = tid & 7;
+    double cr[16];
+    const uint32_t cr_off = (uint32_t)((kx * (2 * PP_B) + 2 * jx) * sizeof(double));
+    if (b > 0) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const double2 v = coh_load2<COH>(H, cr_off, (uint32_t)(16 * u * sizeof(double)));
+            cr[2 * u] = v.x; cr[2 * u + 1] = v.y;
+        }
+    }
+    // diagonal block: 16 bytes per thread and trip, a wavefront per row (rows >= nb and columns
+    // >= the row's node were never written: never read either)
+    // (trip u: row 16 u + wave, columns 2 lane, 2 lane + 1)
+    double2 blk[8];
+    const uint32_t blk_off = (uint32_t)((wave * (2 * PP_B) + PP_B + 2 * lane) * sizeof(double));
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+        blk[u] = coh_load2<COH>(H, blk_off, (uint32_t)(u * PP_WAVES * (2 * PP_B) * sizeof(double)));
+    // the owners' inputs (requested now, used once the blocks above have left their registers)
+    double2 tv[4];
+    double x1[D], x0[D], uk = 1.0, st = 0.0;
+    int32_t na = 0, ns = 0, un = 0;
+    const int kc = min(k, nb - 1);
+    const int p1 = pb.parts;
+    const double2 *frec = (const double2 *)pb.full0 + ((size_t)bb * c.T + t) * PP_B * pb.parts;
+#pragma unroll
+    for (int d = 0; d < D; ++d) { x1[d] = 0.0; x0[d] = 0.0; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) tv[u] = make_double2(0.0, 1.0);
+    if (owner) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            tv[u] = coh_load2<COH>(frec, (uint32_t)((kc * p1 + min(u, p1 - 1)) * sizeof(double2)));
+        const double *pr = pb.prop + ((size_t)t * N + j0 + kc) * PW;
+#pragma unroll
+        for (int d = 0; d < D; ++d) { x1[d] = pr[d]; x0[d] = pr[D + 2 + d]; }
+        uk = pr[D];
+        const size_t tjc = (size_t)t * N + j0 + kc;
+        st = c.step[tjc]; na = c.nacc[tjc]; ns = c.nsteps[tjc]; un = c.until[tjc];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        double *dst = sD + (u * PP_WAVES + wave) * PR_LD + 2 * lane;
+        dst[0] = blk[u].x; dst[1] = blk[u].y;
+    }
+    // the window's accepted nodes among this thread's 16 factors: cr[2 u + i] belongs to node
+    // 16 u + 2 jx + i -> bit 2 u + i of mp.  Multiplicative domain; a node that turns out to be
+    // resolved in the log domain (below) redoes its part from memory.
+    unsigned int mp = 0u;
+    if (b > 0) {
+        // the previous batch's acceptances: in LDS inside the persistent launch (this workgroup resolved
+        // that batch), in memory for the launch-per-batch kernels (the launch before left them)
+        const unsigned long long *pmg = (const unsigned long long *)(pb.acc + ((size_t)t * 2 + ((b - 1) & 1)) * PP_ACC +
+                                                                     PP_ACC_MASK);
+        const unsigned long long pm0 = COH ? sMaskPrev[0] : pmg[0], pm1 = COH ? sMaskPrev[1] : pmg[1];
+        const unsigned long long mlo = pm0 >> (2 * jx), mhi = pm1 >> (2 * jx);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            mp |= ((unsigned int)((u < 4 ? mlo : mhi) >> (16 * (u & 3))) & 3u) << (2 * u);
+        double prod = 1.0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) prod *= (mp >> i) & 1u ? cr[i] : 1.0;
+        const double v = group8_prod(prod);
+        if (jx == 0) sCross[kx] = v;
+    }
+    // multiplicative domain: r = exp(log-ratio of node k), lu = its uniform draw.  A node whose
+    // log-ratio is beyond +-700 (exp would saturate) is resolved in the log domain instead
+    // (pipe_resolve)
+    double r = 0.0, lu = 0.0, lr = 0.0;
+    bool sat = false;
+    if (owner) {
+        double tot = tv[0].x, pr_ = tv[0].y;
+#pragma unroll
+        for (int u = 1; u < 4; ++u)
+            if (u < p1) { tot += tv[u].x; pr_ *= tv[u].y; }
+        for (int u = 4; u < p1; ++u) {                 // more than four parts (short slices, many CUs)
+            const double2 w = coh_load2<COH>(frec, (uint32_t)((kc * p1 + u) * sizeof(double2)));
+            tot += w.x; pr_ *= w.y;
+        }
+        // prior terms of the step's logp closure, the neighbouring slices as they are now (the
+        // odd slices wait for the even ones: header)
+        const double prior = node_log_prior<D, COH>(c, t, j0 + kc, x1) -
+                             node_log_prior<D, COH>(c, t, j0 + kc, x0);
+        const double ek = tot + prior;
+        sat = !(fabs(ek) <= 700.0);
+        // (the table exponential: the compiler's exp() keeps a dozen float64 constants alive through
+        // the whole batch loop, in registers the blocks above need - it spilled them)
+        r = sat ? 1.0 : tab_exp(sat ? 0.0 : ek, sTab) * pr_;
+        lu = uk;
+        if (sat) { lr = ek + log(pr_); lu = log(lu); }
+        const unsigned long long sm = __ballot(sat);
+        if (lane == 0) sSatMask[half] = sm;
+    }
+    __syncthreads();                                   // sD, sCross, sSatMask visible
+    DLSM_STAMP(1, (double)tid)
+    const unsigned long long sat0 = sSatMask[0], sat1 = sSatMask[1];
+    const bool anysat = (sat0 | sat1) != 0ull;         // workgroup-uniform; practically never
+    const bool satk = (((half ? sat1 : sat0) >> lane) & 1ull) != 0ull;
+    if (anysat && b > 0) {
+        // slow path: the log-domain nodes' cross terms as sums of logs
+        const bool satx = ((((kx >> 6) ? sat1 : sat0) >> (kx & 63)) & 1ull) != 0ull;
+        if (__ballot(satx) != 0ull) {
+            double lsum = 0.0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const double2 v = coh_load2<COH>(H, cr_off, (uint32_t)(16 * u * sizeof(double)));
+                if (satx && ((mp >> (2 * u)) & 1u)) lsum += log(v.x);
+                if (satx && ((mp >> (2 * u + 1)) & 1u)) lsum += log(v.y);
+            }
+            const double vs = group8_sum(lsum);
+            if (satx && jx == 0) sCross[kx] = vs;
+        }
+        __syncthreads();
+    }
+    if (owner) {
+        if (b > 0) { const double vk = sCross[k]; if (sat) lr += vk; else r *= vk; }
+        const unsigned long long g = __ballot(valid && !(sat ? lu >= lr : lu >= r));
+        if (lane == 0) sMask[0][half] = g;
+    }
+    __syncthreads();
+    DLSM_STAMP(2, (double)tid)
+    int cur = 0;
+    for (int pass = 0; pass < 2 * PP_B + 2; ++pass) {
+        const unsigned long long gm = sMask[cur][part >> 2];
+        unsigned int bits = (unsigned int)(gm >> (16 * (part & 3))) & 0xFFFFu;
+        const int mbase = 16 * part;
+        double sum = 1.0, lsum = 0.0;
+        if (half == 1 || part < 4) {                   // rows >= 64 never touch half 0
+            const double *rowk = sD + k * PR_LD;
+            while (bits) {
+                int f[4];
+                double h[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    f[u] = bits ? mbase + __builtin_ctz(bits) : 1 << 20;
+                    bits &= bits - 1u;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) h[u] = rowk[f[u] < (1 << 20) ? f[u] : 0];
+                if (!anysat) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) sum *= k > f[u] ? h[u] : 1.0;
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (k > f[u]) { if (satk) lsum += log(h[u]); else sum *= h[u]; }
+                }
+            }
+        }
+        sPart[wave * 64 + lane] = satk ? lsum : sum;
+        __syncthreads();
+        if (owner) {
+            double q = sat ? lr : r;
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const double v = sPart[(2 * p + half) * 64 + lane];
+                if (sat) q += v; else q *= v;
+            }
+            const unsigned long long g = __ballot(valid && !(lu >= q));
+            if (lane == 0) sMask[cur ^ 1][half] = g;
+        }
+        __syncthreads();
+        const bool same = sMask[cur ^ 1][0] == sMask[cur][0] &&
+                          sMask[cur ^ 1][1] == sMask[cur][1];
+        cur ^= 1;
+        if (same) break;
+    }
+    DLSM_STAMP(3, (double)cur)
+    if (owner) {
+        const unsigned long long m0 = sMask[cur][0], m1 = sMask[cur][1];
+        const unsigned long long mine = half == 0 ? m0 : m1;
+        const int accepted = (int)((mine >> lane) & 1ull);
+        if (valid) {
+            const size_t tj = (size_t)t * N + j0 + k;
+            if (accepted) {
+#pragma unroll
+                for (int d = 0; d < D; ++d) coh_store<COH>(&c.X[tj * D + d], x1[d]);
+            }
+            metropolis_bookkeeping(st, na, ns, un, c.tune, c.tune_interval, accepted);
+            c.step[tj] = st; c.nacc[tj] = na; c.nsteps[tj] = ns; c.until[tj] = un;
+        }
+        // the next batch's window: this batch's acceptances, as a mask
+        if (tid == 0) {
+            if (COH) { sMaskPrev[0] = m0; sMaskPrev[1] = m1; }
+            else {
+                unsigned long long *pmw = (unsigned long long *)(pb.acc + ((size_t)t * 2 + (b & 1)) * PP_ACC + PP_ACC_MASK);
+                pmw[0] = m0; pmw[1] = m1;
+            }
+        }
+    }
+#ifdef DLSM_PIPE_TIMING
+    DLSM_STAMP(4, (double)cur)
+    if (tid == 0 && tl >= 0 && tl < 24 && t < 32)
+        for (int i = 0; i < 5; ++i) g_pipe_res_t[tl][t][i] = ts[i];
+#endif
+}
+
 // Launch l: even slices resolve batches G l .. G l + G - 1 and evaluate batches G (l + 1) ..;
 // odd slices run one launch behind (batches outside [0, nbat) do nothing).
 // Workgroups [0, T) are the resolvers, the rest evaluate one item per wavefront and round.
@@ -1099,15 +1354,32 @@ template <int D, int MODEL_, int G = 1>
 __global__ __launch_bounds__(PP_THREADS) void k_pipe_step(ChainView c, PipeBuf pb, int l) {
     constexpr int MODEL = MODEL_ == PIPE_UNDIRECTED_LONG ? DLSM_UNDIRECTED : MODEL_;
     constexpr bool TP = MODEL_ != DLSM_UNDIRECTED;
-    extern __shared__ __attribute__((aligned(16))) double pp_sH[];      // 128 x 128
+    extern __shared__ __attribute__((aligned(16))) double pp_sH[];      // 128 x PR_LD
     __shared__ double sPart[PP_WAVES * 64];
     __shared__ unsigned long long sMask[2][2];
     __shared__ int sPrev[3 * PP_B];
     __shared__ int sOwn[PP_B + 1];
     __shared__ unsigned char sSat[PP_B];
     const int T = c.T;
+    // one batch per launch, exact likelihoods: the H blocks by rows and their resolver (row_resolve)
+    constexpr bool ROWS = G == 1 && MODEL != DLSM_DIRECTED_CASE_CONTROL;
     if ((int)blockIdx.x < T) {
         const int t = blockIdx.x;
+        if (ROWS) {
+            __shared__ double sCross[PP_B];
+            __shared__ unsigned long long sSatMask[2];
+            __shared__ double sTab[EXPTAB_N];
+            const int b = l - (t & 1);
+            if (b < 0 || b >= pb.nbat) return;
+            exp_table_fill(sTab, threadIdx.x);
+            __syncthreads();
+            row_resolve<D, false>(c, pb, b, t, pp_sH, sPart, sMask, nullptr, sCross, sSatMask, sTab
+#ifdef DLSM_PIPE_TIMING
+                                  , l + 1
+#endif
+                                  );
+            return;
+        }
         bool own_prev = false;
         for (int g = 0; g < G; ++g) {
             const int b = G * (l - (t & 1)) + g;
@@ -1225,12 +1497,18 @@ __device__ __forceinline__ void pipe_last_ride_wg(const ChainView &c, const Pipe
         const int t = bx, tid = threadIdx.x;
         const int b = l - (t & 1);
         const bool mine = b >= 0 && b < pb.nbat;
-        if (mine)
-            pipe_resolve<D, 1>(c, pb, b, t, pp_sH, sPart, sMask, sPrev, sSat, sOwn, false
+        if (mine) {
+            __shared__ double sCross[PP_B];
+            __shared__ unsigned long long sSatMask[2];
+            __shared__ double sTab[EXPTAB_N];
+            exp_table_fill(sTab, threadIdx.x);
+            __syncthreads();
+            row_resolve<D, false>(c, pb, b, t, pp_sH, sPart, sMask, nullptr, sCross, sSatMask, sTab
 #ifdef DLSM_PIPE_TIMING
-                               , l + 1
+                                  , l + 1
 #endif
-                               );
+                                  );
+        }
         __syncthreads();                    // the accepted positions of this workgroup are in memory
         double acc[W];
 #pragma unroll
