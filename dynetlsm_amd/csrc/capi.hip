@@ -4,6 +4,7 @@
 #include <hip/hip_ext.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -33,6 +34,7 @@
 using namespace dlsm;
 
 static thread_local std::string g_err;
+static std::atomic<int> g_live_chains{0};       // handles alive in this process (capi_hdp.hpp, hdp_fork_arm)
 
 #define FAIL(h, code, ...)                                      \
     do {                                                        \
@@ -239,8 +241,9 @@ int launch_loglik_records(dlsm_chain *h, int M, const double *d_ic,
     LoglikCand cand{d_ic, {r0, r1}};
     ProfScope ps(h, DLSM_K_LOGLIK);
     if (h->model == DLSM_UNDIRECTED) {
-        if (M == 1) hipLaunchKernelGGL((k_loglik_undirected<DD, 1>), dim3(nb), dim3(LLU_THREADS), 0, h->stream, v, cand, h->partials);
-        else hipLaunchKernelGGL((k_loglik_undirected<DD, 2>), dim3(nb), dim3(LLU_THREADS), 0, h->stream, v, cand, h->partials);
+        // (ll_pad_lds: unused dynamic LDS that caps the pass's workgroups per CU - the HDP loop's second queue)
+        if (M == 1) hipLaunchKernelGGL((k_loglik_undirected<DD, 1>), dim3(nb), dim3(LLU_THREADS), h->ll_pad_lds, h->stream, v, cand, h->partials);
+        else hipLaunchKernelGGL((k_loglik_undirected<DD, 2>), dim3(nb), dim3(LLU_THREADS), h->ll_pad_lds, h->stream, v, cand, h->partials);
     } else if (h->model == DLSM_DIRECTED) {
         if (M == 1) hipLaunchKernelGGL((k_loglik_directed<DD, 1>), dim3(nb), dim3(LL_THREADS), 0, h->stream, v, cand, h->partials);
         else hipLaunchKernelGGL((k_loglik_directed<DD, 2>), dim3(nb), dim3(LL_THREADS), 0, h->stream, v, cand, h->partials);
@@ -325,6 +328,7 @@ int dlsm_create(int device, int T, int N, int D, int model, uint64_t seed,
              device, prop.gcnArchName);
     HIPCHK(nullh, hipSetDevice(device));
     dlsm_chain *h = new dlsm_chain();
+    g_live_chains.fetch_add(1);
     h->device = device; h->T = T; h->N = N; h->D = D; h->model = model;
     h->seed = seed; h->chain = chain_id;
     h->W = ((N + 31) / 32 + 3) / 4 * 4;
@@ -386,6 +390,10 @@ void dlsm_destroy(dlsm_chain *h) {
     if (h->ev_a) hipEventDestroy(h->ev_a);
     if (h->ev_b) hipEventDestroy(h->ev_b);
     if (h->stream2) { hipStreamSynchronize(h->stream2); hipStreamDestroy(h->stream2); }
+    if (h->fork_stream) { hipStreamSynchronize(h->fork_stream); hipStreamDestroy(h->fork_stream); }
+    if (h->fork_ev) hipEventDestroy(h->fork_ev);
+    if (h->fork_flags) hipFree(h->fork_flags);
+    g_live_chains.fetch_sub(1);
     if (h->graph_exec) hipGraphExecDestroy(h->graph_exec);
     if (h->graph) hipGraphDestroy(h->graph);
     if (h->stream) hipStreamDestroy(h->stream);
@@ -988,6 +996,17 @@ static void launch_pipe_step(dlsm_chain *h, const ChainView &v, const PipeBuf &p
 
 // the sticky error word of the persistent sweep (algo 7): a bounded wait ran out of its budget
 static int check_pipe_err(dlsm_chain *h) {
+    if (h->fork_flags && h->fork_ticket > 0) {      // the HDP loop's two queues (kernels_hdploop.hpp, HdpFork)
+        int32_t e = 0;
+        HIPCHK(h, hipMemcpy(&e, h->fork_flags + HF_ERR, sizeof(e), hipMemcpyDeviceToHost));
+        if (e != 0) {
+            HIPCHK(h, hipMemsetAsync(h->fork_flags + HF_ERR, 0, sizeof(e), h->stream));
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            FAIL(h, DLSM_E_HIP, "HDP-LPCM loop: a hand-over between the chain's two queues ran out of its poll "
+                 "budget (flags %d) - the chain's state is undefined (more streams alive than hardware "
+                 "queues?); set the state again and run with DLSM_HDP_QUEUES=1", e);
+        }
+    }
     if (!h->pipe_err || !h->pipe_err_armed) return DLSM_OK;
     int32_t e = 0;
     HIPCHK(h, hipMemcpy(&e, h->pipe_err, sizeof(e), hipMemcpyDeviceToHost));
@@ -1396,7 +1415,8 @@ static bool labels_wave_forced() {
 }
 
 template <int KS>
-int launch_labels_mfma(dlsm_chain *h, const ChainView &v, uint32_t iter, hipStream_t q) {
+int launch_labels_mfma(dlsm_chain *h, const ChainView &v, uint32_t iter, hipStream_t q, int32_t *flag,
+                       int32_t flag_val) {
     auto kern = k_sample_labels_mfma<KS>;
     const size_t lds = lm_lds_bytes(h->T, h->K, h->D);
     static size_t armed = 0;                    // per instantiation: the largest size asked for
@@ -1406,24 +1426,29 @@ int launch_labels_mfma(dlsm_chain *h, const ChainView &v, uint32_t iter, hipStre
         armed = lds;
     }
     hipLaunchKernelGGL(kern, dim3((h->N + LM_NODES - 1) / LM_NODES), dim3(LM_THREADS), lds, q, v, h->lab_w, iter,
-                       h->z);
+                       h->z, flag, flag_val);
     return DLSM_OK;
+}
+
+// the label update goes to the matrix-core kernel (and can carry the HDP loop's hand-over flag)
+static bool labels_mfma_path(const dlsm_chain *h) {
+    return h->K <= 4 * LM_MAX_KS && lm_lds_bytes(h->T, h->K, h->D) <= 150 * 1024 && !labels_wave_forced();
 }
 
 template <int DD>
 int launch_sample_labels(dlsm_chain *h, const ChainView &v, uint32_t iter, uint8_t *trace_row,
-                         hipStream_t q) {
+                         hipStream_t q, int32_t *flag = nullptr, int32_t flag_val = 0, bool counts = true) {
     const int T = h->T, K = h->K, N = h->N;
     // The matrix-core kernel up to 32 components (KS = K / 4 <= 8 unrolled steps: no scratch memory;
     // above that its unrolled tiles spill - 44 to 303 scratch instructions at KS = 9 .. 16 - and the
     // wavefront-per-node kernel, which has no such limit, takes over)
-    if (K <= 4 * LM_MAX_KS && lm_lds_bytes(T, K, h->D) <= 150 * 1024 && !labels_wave_forced()) {
+    if (labels_mfma_path(h)) {
         int rc;
         switch (lm_ksteps(K)) {
-#define DLSM_LM_CASE(KS_) case KS_: rc = launch_labels_mfma<KS_>(h, v, iter, q); break;
+#define DLSM_LM_CASE(KS_) case KS_: rc = launch_labels_mfma<KS_>(h, v, iter, q, flag, flag_val); break;
             DLSM_LM_CASE(1) DLSM_LM_CASE(2) DLSM_LM_CASE(3) DLSM_LM_CASE(4) DLSM_LM_CASE(5)
             DLSM_LM_CASE(6) DLSM_LM_CASE(7)
-            default: rc = launch_labels_mfma<LM_MAX_KS>(h, v, iter, q); break;
+            default: rc = launch_labels_mfma<LM_MAX_KS>(h, v, iter, q, flag, flag_val); break;
 #undef DLSM_LM_CASE
         }
         if (rc) return rc;
@@ -1441,8 +1466,10 @@ int launch_sample_labels(dlsm_chain *h, const ChainView &v, uint32_t iter, uint8
         hipLaunchKernelGGL(kern, dim3((N + LAB_WAVES - 1) / LAB_WAVES), dim3(64 * LAB_WAVES), lds, q, v,
                            h->lab_w, iter, h->z);
     }
-    hipLaunchKernelGGL(k_label_counts, dim3(T), dim3(LC_THREADS), (size_t)(K * K + K) * sizeof(int32_t), q,
-                       h->z, N, K, (int32_t *)h->lab_n, (int32_t *)h->lab_nk, trace_row);
+    // (the HDP-LPCM loop counts inside its next launch: k_hdp_stage1's counts + tables role)
+    if (counts)
+        hipLaunchKernelGGL(k_label_counts, dim3(T), dim3(LC_THREADS), (size_t)(K * K + K) * sizeof(int32_t), q,
+                           h->z, N, K, (int32_t *)h->lab_n, (int32_t *)h->lab_nk, trace_row);
     return DLSM_OK;
 }
 

@@ -38,6 +38,8 @@ void hdp_free_trace(dlsm_chain *h) {
     h->htr_z = nullptr; h->htr_n = 0; h->htr_K = 0;
 }
 
+constexpr int HDP_FORK_BUDGET = 1 << 22;            // polls of ~1 us (kernels_hdploop.hpp, HdpFork)
+
 template <int DD>
 int enqueue_hdp_iteration(dlsm_chain *h, int it, bool draw_next) {
     const IterRef ir{(uint32_t)it, nullptr};
@@ -108,38 +110,41 @@ int enqueue_hdp_iteration(dlsm_chain *h, int it, bool draw_next) {
     if (rc) return rc;
     }
     // The label block update needs the centred positions and last iteration's mixture, not the
-    // intercept's likelihood records (33 us at config 3), and those do not need the labels: with
-    // DLSM_HDP_QUEUES=2 the labels go to a second queue beside them.  Opt-in: on MI355X the two
-    // event hand-overs between the queues cost more than the 20 us they hide (C3 2836 -> 2609 it/s,
-    // profiles/r03_labels_notes.md).
-    static const bool one_queue = [] { const char *e = getenv("DLSM_HDP_QUEUES"); return !(e && atoi(e) == 2); }();
-    const bool fork = !one_queue && !h->profiling;
-    if (fork && !h->stream2) {
-        HIPCHK(h, hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
-        HIPCHK(h, hipEventCreateWithFlags(&h->ev_a, hipEventDisableTiming));
-        HIPCHK(h, hipEventCreateWithFlags(&h->ev_b, hipEventDisableTiming));
-    }
+    // intercept's likelihood records (31 us at config 3), and those do not need the labels: with
+    // `fork` the pass and the intercept step go to a queue of their own beside the label update and
+    // the conjugate draws, handed over through device flags (kernels_hdploop.hpp, HdpFork; the
+    // event form of round 3 lost more in its two hand-overs than it hid: profiles/r03_labels_notes.md)
+    const bool fork = h->fork_armed && !directed;
     ChainView v = h->view();
     HdpLoopBuf hb = hdp_loop_buf(h);
+    HdpFork fk{nullptr, 0, 0};
+    if (fork) fk = HdpFork{h->fork_flags, ++h->fork_ticket, HDP_FORK_BUDGET};
     {   // label block update (sample_labels.py:134-190) with the transition matrices on the device
         ProfScope ps(h, DLSM_K_LABELS);
-        if (fork) {
-            HIPCHK(h, hipEventRecord(h->ev_a, h->stream));
-            HIPCHK(h, hipStreamWaitEvent(h->stream2, h->ev_a, 0));
-        }
-        rc = launch_sample_labels<DD>(h, v, (uint32_t)it, h->htr_z + (size_t)it * T * N,
-                                      fork ? h->stream2 : h->stream);
+        rc = launch_sample_labels<DD>(h, v, (uint32_t)it, nullptr, h->stream,
+                                      fork ? h->fork_flags + HF_CENTRED : nullptr, fk.ticket, false);
         if (rc) return rc;
-        if (fork) HIPCHK(h, hipEventRecord(h->ev_b, h->stream2));
     }
     int nrec = 0;
-    if (!directed) { rc = loglik_records(h, 2, h->lsm->cand, nullptr, nullptr, &nrec); if (rc) return rc; }
-    if (fork) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_b, 0));
+    if (fork) {
+        hipLaunchKernelGGL(k_hdp_gate, dim3(1), dim3(64), 0, h->fork_stream, fk, (int)HF_CENTRED);
+        hipStream_t keep = h->stream;
+        h->stream = h->fork_stream;
+        static const size_t pad = [] { const char *e = getenv("DLSM_HDP_FORK_LDS"); return e ? (size_t)atoi(e) : (size_t)0; }();
+        h->ll_pad_lds = pad;
+        rc = loglik_records(h, 2, h->lsm->cand, nullptr, nullptr, &nrec);
+        h->ll_pad_lds = 0;
+        h->stream = keep;
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_hdp_intercept_fork, dim3(1), dim3(HDP_THREADS), 0, h->fork_stream, h->partials, nrec,
+                           h->lsm, h->hdp, h->intercept, h->trace_ic, it, fk);
+    } else if (!directed) { rc = loglik_records(h, 2, h->lsm->cand, nullptr, nullptr, &nrec); if (rc) return rc; }
     ProfScope ps(h, DLSM_K_HDP_TAIL);
-    const int n_tab = (T * K * K + HT_WAVES - 1) / HT_WAVES;
+    const int n_tab = T * hdp_tab_groups(K);    // (the label counts are a role of this launch)
     // (directed models: the intercepts were settled above - the launch goes without the role's workgroup)
-    hipLaunchKernelGGL((k_hdp_stage1<DD>), dim3(n_tab + K * T + (directed ? 0 : 1)), dim3(HDP_THREADS), 0,
-                       h->stream, v, hb, h->hdp, h->lsm, h->partials, nrec, h->intercept, h->trace_ic, ir);
+    hipLaunchKernelGGL((k_hdp_stage1<DD>), dim3(n_tab + K * T + (directed || fork ? 0 : 1)), dim3(HDP_THREADS),
+                       (size_t)(K * K + K) * sizeof(int32_t), h->stream, v, hb, h->hdp, h->lsm, h->partials, nrec,
+                       h->intercept, h->trace_ic, ir, h->htr_z + (size_t)it * T * N);
     hipLaunchKernelGGL((k_hdp_stage2<DD>), dim3(2 + K * T), dim3(HDP_THREADS), 0, h->stream, v, hb,
                        h->hdp, ir);
     hipLaunchKernelGGL((k_hdp_stage3<DD>), dim3(HW_SPLIT * (T - 1) + 1 + K * T), dim3(HDP_THREADS),
@@ -148,10 +153,14 @@ int enqueue_hdp_iteration(dlsm_chain *h, int it, bool draw_next) {
                 h->htr_lambda, h->htr_hyper};
     if (draw_next && h->next_prop_ok) {     // with the next sweep's proposal pass (kernels_tail_propose.hpp)
         hipLaunchKernelGGL((k_hdp_hypers_propose<DD>), dim3(1 + propose_blocks(T, N)), dim3(HH_THREADS), 0,
-                           h->stream, v, hb, h->hdp, tr, ir, h->next_prop);
+                           h->stream, v, hb, h->hdp, tr, ir, h->next_prop, fk);
         h->prop_drawn_for = (long)it + 1;
-    } else
+    } else {
         hipLaunchKernelGGL(k_hdp_hypers, dim3(1), dim3(HH_THREADS), 0, h->stream, v, hb, h->hdp, tr, ir);
+        // whatever follows on the chain's queue (a sweep with its own proposal pass) starts from the
+        // settled intercept
+        if (fork) hipLaunchKernelGGL(k_hdp_gate, dim3(1), dim3(64), 0, h->stream, fk, (int)HF_SETTLED);
+    }
     HIPCHK(h, hipGetLastError());
     return DLSM_OK;
 }
@@ -178,6 +187,39 @@ int enqueue_hdp_logp_batch(dlsm_chain *h, int first, int count) {
                            per * sizeof(double), h->stream, v, tv, s0, h->hdp, h->lsm, LP, cnt);
     }
     HIPCHK(h, hipGetLastError());
+    return DLSM_OK;
+}
+
+// The likelihood pass on a queue of its own: the undirected model with the matrix-core label kernel
+// (which carries the hand-over flag), outside profiling runs (their per-launch events serialise the
+// queues).  DLSM_HDP_QUEUES=1 never, =2 always; otherwise only while this is the process's only live
+// chain: the waits are device-side polls, and with more streams alive than the runtime has hardware
+// queues the two queues of a chain can land on one, where a poll would wait for a launch queued
+// behind it (the poll budget turns that into an error instead of a hang; here it is avoided).
+int hdp_fork_arm(dlsm_chain *h) {
+    const char *e = getenv("DLSM_HDP_QUEUES");
+    const int mode = e ? atoi(e) : 0;
+    h->fork_armed = false;
+    if (mode == 1 || h->model != DLSM_UNDIRECTED || h->profiling || h->batch || !labels_mfma_path(h)) return DLSM_OK;
+    if (mode != 2 && g_live_chains.load() != 1) return DLSM_OK;
+    if (!h->fork_stream) {
+        int lo = 0, hi = 0;                        // (numerically greatest = lowest priority: the pass
+        HIPCHK(h, hipDeviceGetStreamPriorityRange(&lo, &hi));   // yields to the chain's small launches)
+        const char *ec = getenv("DLSM_HDP_FORK_CUS"), *ep = getenv("DLSM_HDP_FORK_PRIO");
+        if (ec && atoi(ec) > 0) {                  // (experiment: the pass on a subset of the CUs)
+            const int ncu = atoi(ec);
+            uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int i = 0; i < ncu && i < 256; ++i) mask[i >> 5] |= 1u << (i & 31);
+            HIPCHK(h, hipExtStreamCreateWithCUMask(&h->fork_stream, 8, mask));
+        } else
+        HIPCHK(h, hipStreamCreateWithPriority(&h->fork_stream, hipStreamNonBlocking, ep && atoi(ep) == 0 ? 0 : (ep && atoi(ep) == 2 ? hi : lo)));
+        HIPCHK(h, hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming));
+        HIPCHK(h, hipMalloc((void **)&h->fork_flags, 64));
+        HIPCHK(h, hipMemset(h->fork_flags, 0, 64));
+        h->fork_ticket = 0;
+    }
+    h->fork_armed = true;
+    if (getenv("DLSM_DEBUG")) fprintf(stderr, "dlsm: HDP-LPCM loop on two queues (live chains %d)\n", g_live_chains.load());
     return DLSM_OK;
 }
 
@@ -342,10 +384,16 @@ int dlsm_hdp_run(dlsm_chain *h, int first, int count) {
     // (read per call: the tests switch it inside one process)
     const bool ride = !(getenv("DLSM_TAIL_PROPOSE") && atoi(getenv("DLSM_TAIL_PROPOSE")) == 0);
     h->prop_drawn_for = -1;
+    rc = hdp_fork_arm(h); if (rc) return rc;
     for (int it = first; it < first + count; ++it) {
         DISPATCH_D(h, h->D, rc = enqueue_hdp_iteration<DD>(h, it, ride && it + 1 < first + count));
-        if (rc) return rc;
+        if (rc) break;
     }
+    if (h->fork_armed && count > 0) {       // ONE event per call: the second queue's last intercept step
+        HIPCHK(h, hipEventRecord(h->fork_ev, h->fork_stream));
+        HIPCHK(h, hipStreamWaitEvent(h->stream, h->fork_ev, 0));
+    }
+    if (rc) return rc;
     h->prop_drawn_for = -1;
     // the log-posterior trace of these rows: one batched pass over the trace, behind the iterations
     if (count > 0) DISPATCH_D(h, h->D, rc = enqueue_hdp_logp_batch<DD>(h, first, count));

@@ -13,7 +13,7 @@
 //   Dirichlet  hdp_lpcm.py:887-898        gamma variates (Marsaglia-Tsang, attempt a: normal from
 //                                         attempt 2a, uniforms from 2a + 1) normalised by their sum
 //   mu, sigma, lambda, hyper-parameters, concentration parameters: see each kernel.
-// Launch order per iteration (capi_hdp.hpp): [labels], k_hdp_stage1 (tables | MEAN sums),
+// Launch order per iteration (capi_hdp.hpp): [labels], k_hdp_stage1 (label counts + tables | MEAN sums),
 // k_hdp_stage2 (override variables, m_bar, beta, w0 | the alpha + kappa grid | mu + RESIDUAL sums),
 // k_hdp_stage3 (w | eight gamma variates | sigma + LAMBDA sums), k_hdp_hypers (+ the sample's trace
 // rows); the intercept's accept / reject is one more role of stage 1.  The log-posterior trace is
@@ -211,31 +211,80 @@ struct HdpTrace {
     double *ic, *logp, *mu, *sigma, *beta, *w, *lambda, *hyper;
 };
 
-// ---- tables: one wavefront per (t, j, k) cell ------------------------------------------------
+// ---- label counts + tables: workgroup (t, g) counts time step t, then draws HT_CELLS of its cells ------
+// The counts the conjugate updates need (sample_labels.py:176-188: n[0][0][k] initial labels, n[t][j][k]
+// transitions j -> k into time t, nk[t][k] labels in use) were a launch of their own between the label
+// update and this one (k_label_counts: T workgroups, 4.6 us of which 2.6 are the launch).  The only
+// role of THIS launch that reads them is the tables', and a time step's histogram is 2 N labels into
+// K K + K LDS counters (integer atomics: order independent): every tables workgroup of a time step
+// counts it for itself, group 0 files n / nk for the later launches, each group files its share of the
+// sample's label trace row (bytes).  Then one wavefront per (t, j, k) cell, as before.
 constexpr int HT_WAVES = 4;
-__device__ __forceinline__ void hdp_tables_wg(const ChainView &c, const HdpLoopBuf &hb,
-                                              const HdpDeviceState *hs, uint32_t iter, int wg) {
-    const int K = hb.K, T = c.T;
-    const int lane = threadIdx.x & 63;
-    const int cell = wg * HT_WAVES + (threadIdx.x >> 6);
-    if (cell >= T * K * K) return;
-    const int t = cell / (K * K), r = cell - t * K * K, j = r / K, k = r - j * K;
-    int cnt = 0;
-    if (t > 0 || j == 0) {          // t = 0: only the initial distribution's row (0, 0, :)
-        const int n = hb.n[cell];
-        const double p = t == 0 ? hs->alpha_init * hb.beta[k]
-                                : hs->alpha * hb.beta[k] + (j == k ? hs->kappa : 0.0);
-        const HdpRng g = hdp_rng(c, iter);
-        for (int a0 = 0; 2 * a0 < n; a0 += 64) {
-            const int att = a0 + lane, i0 = 2 * att;
-            double u0 = 2.0, u1 = 2.0;
-            if (i0 < n) g.u2(HK_TABLES, (uint32_t)cell, (uint32_t)att, u0, u1);
-            const bool s0 = i0 < n && u0 <= p / (p + (double)i0);
-            const bool s1 = i0 + 1 < n && u1 <= p / (p + (double)(i0 + 1));
-            cnt += __popcll(__ballot(s0)) + __popcll(__ballot(s1));
+constexpr int HT_CELLS = 8;                 // cells of a time step per workgroup: two per wavefront
+__host__ __device__ inline int hdp_tab_groups(int K) { return (K * K + HT_CELLS - 1) / HT_CELLS; }
+__device__ __forceinline__ void hdp_counts_tables_wg(const ChainView &c, const HdpLoopBuf &hb,
+                                                     const HdpDeviceState *hs, uint32_t iter, int wg,
+                                                     int32_t *hist /* K K + K */, uint8_t *trace_row) {
+    const int K = hb.K, N = c.N, tid = threadIdx.x;
+    const int G = hdp_tab_groups(K);
+    const int t = wg / G, g = wg - t * G;
+    const int32_t *zt = c.z + (size_t)t * N;
+    const int32_t *zp = t > 0 ? c.z + (size_t)(t - 1) * N : nullptr;
+    const int per = (N + G - 1) / G;        // nodes whose trace bytes this group files
+    constexpr int PRE = 8;                  // labels requested together (one round trip at N = 2000)
+    int a[PRE], b[PRE];
+#pragma unroll
+    for (int u = 0; u < PRE; ++u) {
+        const int i = tid + u * HDP_THREADS;
+        a[u] = i < N ? zt[i] : -1;
+        b[u] = i < N && t > 0 ? zp[i] : 0;
+    }
+    for (int q = tid; q < K * K + K; q += HDP_THREADS) hist[q] = 0;
+    __syncthreads();
+    for (int i0 = tid;;) {
+#pragma unroll
+        for (int u = 0; u < PRE; ++u) {
+            const int i = i0 + u * HDP_THREADS;
+            if (a[u] < 0) continue;
+            atomicAdd(&hist[b[u] * K + a[u]], 1);
+            atomicAdd(&hist[K * K + a[u]], 1);
+            if (trace_row && i / per == g) trace_row[(size_t)t * N + i] = (uint8_t)a[u];
+        }
+        i0 += PRE * HDP_THREADS;
+        if (i0 - tid >= N) break;
+#pragma unroll
+        for (int u = 0; u < PRE; ++u) {
+            const int i = i0 + u * HDP_THREADS;
+            a[u] = i < N ? zt[i] : -1;
+            b[u] = i < N && t > 0 ? zp[i] : 0;
         }
     }
-    if (lane == 0) hb.m[cell] = cnt;
+    __syncthreads();
+    if (g == 0) {
+        int32_t *n_out = (int32_t *)hb.n, *nk_out = (int32_t *)hb.nk;
+        for (int q = tid; q < K * K; q += HDP_THREADS) n_out[(size_t)t * K * K + q] = hist[q];
+        for (int q = tid; q < K; q += HDP_THREADS) nk_out[t * K + q] = hist[K * K + q];
+    }
+    const int lane = tid & 63;
+    const HdpRng rg = hdp_rng(c, iter);
+    for (int cl = g * HT_CELLS + (tid >> 6); cl < min(K * K, (g + 1) * HT_CELLS); cl += HT_WAVES) {
+        const int cell = t * K * K + cl, j = cl / K, k = cl - j * K;
+        int cnt = 0;
+        if (t > 0 || j == 0) {          // t = 0: only the initial distribution's row (0, 0, :)
+            const int n = hist[cl];
+            const double p = t == 0 ? hs->alpha_init * hb.beta[k]
+                                    : hs->alpha * hb.beta[k] + (j == k ? hs->kappa : 0.0);
+            for (int a0 = 0; 2 * a0 < n; a0 += 64) {
+                const int att = a0 + lane, i0 = 2 * att;
+                double u0 = 2.0, u1 = 2.0;
+                if (i0 < n) rg.u2(HK_TABLES, (uint32_t)cell, (uint32_t)att, u0, u1);
+                const bool s0 = i0 < n && u0 <= p / (p + (double)i0);
+                const bool s1 = i0 + 1 < n && u1 <= p / (p + (double)(i0 + 1));
+                cnt += __popcll(__ballot(s0)) + __popcll(__ballot(s1));
+            }
+        }
+        if (lane == 0) hb.m[cell] = cnt;
+    }
 }
 
 // ---- override variables, m_bar, beta, w0: one workgroup -----------------------------------------
@@ -713,7 +762,39 @@ __device__ __forceinline__ void hdp_intercept_wg(const double *__restrict__ part
     }
 }
 
-// ---- the three multi-role launches between the label counts and k_hdp_hypers -------------------------
+// ---- the intercept's likelihood pass on a queue of its own (undirected model; round 4) ----------------
+// The intercept step (a chip-filling 31 us pass + one workgroup) reads the centred positions and
+// nothing else of the iteration; the label update and the conjugate draws behind it (six launches of
+// a few busy workgroups, ~60 us) do not read what it produces.  Two queues with event hand-overs
+// lost more than they hid (profiles/r03_labels_notes.md); here the hand-overs are words in device
+// memory and no event is recorded inside an iteration:
+//   flags[HF_CENTRED]  ticket of the last iteration whose centred positions are final - stored by the
+//                      label kernel at its entry (it follows the centring launch on the chain's queue,
+//                      whose end-of-kernel release has made the positions visible to the device);
+//                      k_hdp_gate, ahead of the pass on the second queue, polls it
+//   flags[HF_SETTLED]  ticket of the last iteration whose intercept step is done (k_hdp_intercept_fork:
+//                      one thread stores the results, fences and stores the flag); polled by the
+//                      iteration's last launch before it takes the intercept for the next sweep
+//   flags[HF_ERR]      sticky: a bounded wait ran out of its budget (reported by the host)
+// A wait only ever outlasts one iteration's launches on the other queue unless both queues were
+// mapped onto one hardware queue (more streams alive than the runtime has queues): the budget turns
+// that deadlock into an error.
+enum : int { HF_CENTRED = 0, HF_SETTLED = 1, HF_ERR = 2 };
+struct HdpFork { int32_t *flags; int32_t ticket; int32_t budget; };
+
+__device__ __forceinline__ void hdp_fork_wait(const HdpFork &f, int which) {
+    for (int n = 0; n < f.budget; ++n) {
+        if (coh_load_i32(f.flags + which) - f.ticket >= 0) return;
+        __builtin_amdgcn_s_sleep(4);
+    }
+    atomicOr(f.flags + HF_ERR, 1 << which);
+}
+
+__global__ __launch_bounds__(64) void k_hdp_gate(HdpFork f, int which) {
+    if (threadIdx.x == 0) hdp_fork_wait(f, which);
+}
+
+
 // Two chains of work follow the label update and meet only in k_hdp_hypers: tables -> override
 // variables, m_bar, beta, w0 -> w  and  MEAN sums -> mu + RESIDUAL sums -> sigma + LAMBDA sums.
 // Their k-th links share a launch (workgroup ranges = roles), together with the hyper-parameter
@@ -723,11 +804,13 @@ __global__ __launch_bounds__(HDP_THREADS) void k_hdp_stage1(ChainView c, HdpLoop
                                                             HdpDeviceState *hs, LsmDeviceState *lsm,
                                                             const double *__restrict__ partials,
                                                             int nrec, double *__restrict__ intercept,
-                                                            double *__restrict__ trace_ic, IterRef ir) {
+                                                            double *__restrict__ trace_ic, IterRef ir,
+                                                            uint8_t *__restrict__ trace_row) {
     DLSM_HDP_STAMP(0)
+    extern __shared__ int32_t sHist[];          // K K + K (the counts + tables role)
     const int K = hb.K, T = c.T;
-    const int n_tab = (T * K * K + HT_WAVES - 1) / HT_WAVES;
-    if ((int)blockIdx.x < n_tab) { hdp_tables_wg(c, hb, hs, ir.get(), blockIdx.x); return; }
+    const int n_tab = T * hdp_tab_groups(K);
+    if ((int)blockIdx.x < n_tab) { hdp_counts_tables_wg(c, hb, hs, ir.get(), blockIdx.x, sHist, trace_row); return; }
     if ((int)blockIdx.x == n_tab + K * T) {
         hdp_intercept_wg(partials, nrec, lsm, hs, intercept, trace_ic, (int)ir.get());
         return;
@@ -737,6 +820,28 @@ __global__ __launch_bounds__(HDP_THREADS) void k_hdp_stage1(ChainView c, HdpLoop
 #pragma unroll
     for (int d = 0; d < D; ++d) mk[d] = 0.0;
     hdp_label_sums_wg<D, HDP_SUMS_MEAN>(c, k, t, mk, 1.0, hs->lmbda, 0.0, 0.0, nullptr, hb.S);
+}
+
+// the intercept step behind its pass on the second queue: the role of stage 1's last workgroup, then
+// the hand-over (the stores above are thread 0's: drained, released to the device, then the flag)
+__global__ __launch_bounds__(256) void k_hdp_intercept_fork(const double *__restrict__ partials, int nrec,
+                                                            LsmDeviceState *lsm, HdpDeviceState *hs,
+                                                            double *__restrict__ intercept,
+                                                            double *__restrict__ trace_ic, int it, HdpFork f) {
+    hdp_intercept_wg(partials, nrec, lsm, hs, intercept, trace_ic, it);
+    if (threadIdx.x == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        coh_store_i32(f.flags + HF_SETTLED, f.ticket);
+    }
+}
+
+// consumer side, one lane: the settled intercept (poll, acquire, then a plain load)
+__device__ __forceinline__ void hdp_fork_acquire_settled(const HdpFork &f) {
+    hdp_fork_wait(f, HF_SETTLED);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 template <int D>

@@ -213,8 +213,12 @@ __host__ __device__ inline size_t lm_lds_bytes(int T, int K, int D) {
 
 template <int KS>
 __global__ __launch_bounds__(LM_THREADS) void k_sample_labels_mfma(
-    ChainView c, const double *__restrict__ w, uint32_t iter, int32_t *__restrict__ z_out) {
+    ChainView c, const double *__restrict__ w, uint32_t iter, int32_t *__restrict__ z_out,
+    int32_t *flag, int32_t flag_val) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
+    // (HDP-LPCM loop with the likelihood pass on a second queue: this launch follows the centring
+    // launch on the chain's queue - the centred positions are final, the pass may start)
+    if (flag && blockIdx.x == 0 && threadIdx.x == 0) coh_store_i32(flag, flag_val);
     constexpr int KT = (KS + 3) / 4, S = 16 * KT + 1, WS = (4 * KS) | 1;
     const int T = c.T, K = c.K, N = c.N, D = c.D;
     double *wt = smem;                                  // [T][K][WS] transition matrices, zero padded

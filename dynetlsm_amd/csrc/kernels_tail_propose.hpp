@@ -89,10 +89,17 @@ static_assert(HH_THREADS == 256, "the proposal pass is laid out for 256 threads"
 template <int D>
 __global__ __launch_bounds__(HH_THREADS) void k_hdp_hypers_propose(ChainView c, HdpLoopBuf hb,
                                                                    HdpDeviceState *hs, HdpTrace tr,
-                                                                   IterRef ir, ProposeBuf nb) {
+                                                                   IterRef ir, ProposeBuf nb, HdpFork fk) {
     if (blockIdx.x == 0) {
-        // the intercept of the next sweep was settled in stage 1
-        if (threadIdx.x == 0) pipe_propose_consts(c, nb.consts, c.intercept);   // (nb.lsm_draw is NULL here)
+        // the intercept of the next sweep was settled in stage 1 - or, with the likelihood pass on a
+        // queue of its own (HdpFork), by k_hdp_intercept_fork: then a lane of the wavefronts that draw
+        // nothing waits for its flag
+        if (fk.flags) {
+            if (threadIdx.x == HH_THREADS - 1) {
+                hdp_fork_acquire_settled(fk);
+                pipe_propose_consts(c, nb.consts, c.intercept);
+            }
+        } else if (threadIdx.x == 0) pipe_propose_consts(c, nb.consts, c.intercept);   // (nb.lsm_draw is NULL here)
         hdp_hypers_wg(c, hb, hs, tr, ir);
         return;
     }
