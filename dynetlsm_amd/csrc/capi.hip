@@ -241,9 +241,8 @@ int launch_loglik_records(dlsm_chain *h, int M, const double *d_ic,
     LoglikCand cand{d_ic, {r0, r1}};
     ProfScope ps(h, DLSM_K_LOGLIK);
     if (h->model == DLSM_UNDIRECTED) {
-        // (ll_pad_lds: unused dynamic LDS that caps the pass's workgroups per CU - the HDP loop's second queue)
-        if (M == 1) hipLaunchKernelGGL((k_loglik_undirected<DD, 1>), dim3(nb), dim3(LLU_THREADS), h->ll_pad_lds, h->stream, v, cand, h->partials);
-        else hipLaunchKernelGGL((k_loglik_undirected<DD, 2>), dim3(nb), dim3(LLU_THREADS), h->ll_pad_lds, h->stream, v, cand, h->partials);
+        if (M == 1) hipLaunchKernelGGL((k_loglik_undirected<DD, 1>), dim3(nb), dim3(LLU_THREADS), 0, h->stream, v, cand, h->partials);
+        else hipLaunchKernelGGL((k_loglik_undirected<DD, 2>), dim3(nb), dim3(LLU_THREADS), 0, h->stream, v, cand, h->partials);
     } else if (h->model == DLSM_DIRECTED) {
         if (M == 1) hipLaunchKernelGGL((k_loglik_directed<DD, 1>), dim3(nb), dim3(LL_THREADS), 0, h->stream, v, cand, h->partials);
         else hipLaunchKernelGGL((k_loglik_directed<DD, 2>), dim3(nb), dim3(LL_THREADS), 0, h->stream, v, cand, h->partials);

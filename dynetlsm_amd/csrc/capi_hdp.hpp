@@ -130,10 +130,7 @@ int enqueue_hdp_iteration(dlsm_chain *h, int it, bool draw_next) {
         hipLaunchKernelGGL(k_hdp_gate, dim3(1), dim3(64), 0, h->fork_stream, fk, (int)HF_CENTRED);
         hipStream_t keep = h->stream;
         h->stream = h->fork_stream;
-        static const size_t pad = [] { const char *e = getenv("DLSM_HDP_FORK_LDS"); return e ? (size_t)atoi(e) : (size_t)0; }();
-        h->ll_pad_lds = pad;
         rc = loglik_records(h, 2, h->lsm->cand, nullptr, nullptr, &nrec);
-        h->ll_pad_lds = 0;
         h->stream = keep;
         if (rc) return rc;
         hipLaunchKernelGGL(k_hdp_intercept_fork, dim3(1), dim3(HDP_THREADS), 0, h->fork_stream, h->partials, nrec,
@@ -205,14 +202,16 @@ int hdp_fork_arm(dlsm_chain *h) {
     if (!h->fork_stream) {
         int lo = 0, hi = 0;                        // (numerically greatest = lowest priority: the pass
         HIPCHK(h, hipDeviceGetStreamPriorityRange(&lo, &hi));   // yields to the chain's small launches)
-        const char *ec = getenv("DLSM_HDP_FORK_CUS"), *ep = getenv("DLSM_HDP_FORK_PRIO");
+        // (measured, profiles/r04_hdp_two_queues.md: the priority changes nothing; capping the pass's
+        // workgroups per CU with unused LDS changes nothing; a CU mask of 160 is +0.5 %, 192 .. 240 are -1 %)
+        const char *ec = getenv("DLSM_HDP_FORK_CUS");
         if (ec && atoi(ec) > 0) {                  // (experiment: the pass on a subset of the CUs)
             const int ncu = atoi(ec);
             uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             for (int i = 0; i < ncu && i < 256; ++i) mask[i >> 5] |= 1u << (i & 31);
             HIPCHK(h, hipExtStreamCreateWithCUMask(&h->fork_stream, 8, mask));
         } else
-        HIPCHK(h, hipStreamCreateWithPriority(&h->fork_stream, hipStreamNonBlocking, ep && atoi(ep) == 0 ? 0 : (ep && atoi(ep) == 2 ? hi : lo)));
+        HIPCHK(h, hipStreamCreateWithPriority(&h->fork_stream, hipStreamNonBlocking, lo));
         HIPCHK(h, hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming));
         HIPCHK(h, hipMalloc((void **)&h->fork_flags, 64));
         HIPCHK(h, hipMemset(h->fork_flags, 0, 64));

@@ -106,7 +106,6 @@ struct dlsm_chain {
     // update and the conjugate draws, handed over through device flags (kernels_hdploop.hpp, HdpFork)
     hipStream_t fork_stream = nullptr; hipEvent_t fork_ev = nullptr;
     int32_t *fork_flags = nullptr; int32_t fork_ticket = 0; bool fork_armed = false;
-    size_t ll_pad_lds = 0;                  // dynamic LDS of the undirected likelihood pass's launch (unused bytes)
     // network
     int W = 0;
     uint32_t *ybits = nullptr, *ytbits = nullptr;
