@@ -612,10 +612,13 @@ class HdpWorkload(object):
         extra['ms_label_kernels_per_iteration'] = round(ms_lb / max(P, 1), 4)
         extra['ms_hdp_draws_and_logp_per_iteration'] = round(ms_tl / max(P, 1), 4)
         extra['ms_finalize'] = round(ms_fi / max(n_fi, 1), 4)
-        # what follows the likelihood pass: the label block update (two launches) and the HDP's
-        # conjugate draws (four).  Neither bandwidth nor arithmetic bounds it: 6 dependent
-        # launches of 1 .. 250 workgroups, each a chain of dependent draws (phase
-        # stamps in profiles/r03_labels_notes.md and profiles/hdp_tail_timing.py).  `achieved` is
+        # what follows the centring pass: the label block update and the HDP's conjugate draws (four
+        # launches; the label counts are a role of the first).  Neither bandwidth nor arithmetic bounds
+        # it: 5 dependent launches of 1 .. 760 workgroups, each a chain of dependent draws (DESIGN.md,
+        # phase stamps in profiles/r03_labels_notes.md and profiles/hdp_tail_timing.py); in the timed
+        # run the intercept's likelihood pass runs BESIDE them on the chain's second queue
+        # (`hdp_queues`; profiles/r04_hdp_two_queues.md) - the per-launch figures here are from the
+        # profiled steps, which keep one queue (their events serialise the launches).  `achieved` is
         # the label update's algorithmic rate (backward messages 2 (T-1) N K^2 flop + forward
         # draws 2 T N K) against the f64 matrix peak, for the record: 1-2 % of it.
         T, N, K = a.T, a.N, a.K
@@ -623,12 +626,12 @@ class HdpWorkload(object):
         lab_s = max(ms_lb / max(P, 1), 1e-9) * 1e-3
         tail_us = 1e3 * (ms_lb + ms_tl) / max(P, 1)
         extra['roofline_tail'] = {
-            'bound': 'latency', 'kernels': ['k_sample_labels_mfma', 'k_label_counts', 'k_hdp_stage1',
+            'bound': 'latency', 'kernels': ['k_sample_labels_mfma', 'k_hdp_stage1(+label counts)',
                                             'k_hdp_stage2', 'k_hdp_stage3', 'k_hdp_hypers(+proposal pass)'],
-            'launches': 6, 'us_per_iteration': round(tail_us, 2),
+            'launches': 5, 'us_per_iteration': round(tail_us, 2),
             'us_label_update': round(1e3 * ms_lb / max(P, 1), 2),
             'us_conjugate_draws': round(1e3 * ms_tl / max(P, 1), 2),
-            'us_floor_launch_boundaries': round(6 * 1.7, 1),
+            'us_floor_launch_boundaries': round(5 * 1.7, 1),
             'achieved': round(lab_flop / lab_s / 1e12, 4), 'peak': FP64_MATRIX_PEAK_TFLOPS,
             'unit': 'TFLOP/s', 'frac': round(lab_flop / lab_s / 1e12 / FP64_MATRIX_PEAK_TFLOPS, 5),
             'note': 'label update only in achieved / peak; the draws are scalar chains (gamma, beta, '
@@ -1013,6 +1016,8 @@ def run_rank(args):
                     'gathered': {k: list(v.shape) for k, v in gathered.items()},
                     'X_mean_rms_between_chains': (round(float(np.sqrt(((xm - xm.mean(0)) ** 2).mean())), 5)
                                                   if world * C > 1 else 0.0)}
+                if name == 'hdp':       # queues of the timed run's calls (2: the intercept's pass beside the tail)
+                    line['config']['hdp_queues'] = wl.model.chain_.hdp_queues()
                 if name == 'lsm':
                     line['config']['iteration'] = ('sweep + procrustes + centring + intercept MH + '
                                                    'logp trace')

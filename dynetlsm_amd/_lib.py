@@ -127,6 +127,7 @@ SIGNATURES = {
     'dlsm_hdp_trace_write': (C.c_int, [handle_t, C.c_int, C.c_int, c_double_p, c_double_p, c_double_p,
                                        c_double_p, c_double_p, c_i64_p, c_double_p, c_double_p,
                                        c_double_p]),
+    'dlsm_hdp_queues': (C.c_int, [handle_t, C.POINTER(C.c_int)]),
     'dlsm_hdp_get_aux': (C.c_int, [handle_t, c_i64_p, c_double_p, c_i64_p, c_i64_p, c_i64_p]),
     'dlsm_init_shortest_paths': (C.c_int, [handle_t]),
     'dlsm_init_get_dissimilarity': (C.c_int, [handle_t, C.c_int, c_double_p]),

@@ -399,6 +399,12 @@ int dlsm_hdp_run(dlsm_chain *h, int first, int count) {
     return rc;
 }
 
+int dlsm_hdp_queues(dlsm_chain *h, int *queues) {
+    NEED(h, h && queues, "null argument");
+    *queues = h->fork_armed ? 2 : 1;
+    return DLSM_OK;
+}
+
 int dlsm_hdp_trace_read(dlsm_chain *h, int first, int count, double *Xs, double *intercepts,
                         double *logps, double *mus, double *sigmas, int64_t *zs, double *betas,
                         double *weights, double *lambdas, double *hypers) {

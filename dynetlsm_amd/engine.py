@@ -505,6 +505,13 @@ class Chain(object):
             f(logps, ()), f(mus, (K, D)), f(sigmas, (K,)), None if zz is None else _p(zz),
             f(betas, (K,)), f(weights, (T, K, K)), f(lambdas, ())))
 
+    def hdp_queues(self):
+        """queues the last ``hdp_run`` used: 2 when the intercept's likelihood pass ran beside the
+        label update and the conjugate draws (undirected model, the process's only live chain)"""
+        q = C.c_int(0)
+        self._ck(self._L.dlsm_hdp_queues(self._h, C.byref(q)))
+        return int(q.value)
+
     def hdp_get_aux(self):
         """auxiliary variables of the last iteration: m, m_bar, w_over, n, nk"""
         T, K = self.T, self.K

@@ -279,8 +279,16 @@ int dlsm_hdp_get_config(dlsm_chain *h, dlsm_hdp_config *cfg);
  * buffers), mus_, sigmas_, zs_, betas_, weights_, lambdas_ and the six resampled
  * hyper-parameters; row 0 = the current state, logp0 given */
 int dlsm_hdp_trace_alloc(dlsm_chain *h, int n_total, double logp0);
-/* enqueue iterations first .. first+count-1.  Asynchronous. */
+/* enqueue iterations first .. first+count-1.  Asynchronous.
+ * Undirected model: the intercept step's likelihood pass (sample_coefficients.py:76-86 inside
+ * hdp_lpcm.py:855-874) runs on a second queue of the handle beside the label update and the conjugate
+ * draws (hdp_lpcm.py:876-1023), which do not read its result; the queues hand over through words in
+ * device memory and are joined before the call's log-posterior pass, so the call still orders like one
+ * stream.  Chosen while the handle is the process's only live chain (environment: DLSM_HDP_QUEUES=1
+ * never, =2 always); the trace is bit for bit the one-queue trace. */
 int dlsm_hdp_run(dlsm_chain *h, int first, int count);
+/* queues the last dlsm_hdp_run call of this handle used: 1 or 2 */
+int dlsm_hdp_queues(dlsm_chain *h, int *queues);
 /* rows first .. first+count-1; any pointer may be NULL.  zs count*T*N int64, hypers count*6
  * [gamma, alpha_init, alpha, kappa, mean_variance_prior, b]; intercepts count*2 (undirected
  * model: the second column carries the network log-likelihood of the stored state) */

@@ -173,6 +173,38 @@ def test_device_loop_proposals_drawn_by_the_previous_iteration(eng, monkeypatch)
     assert not np.array_equal(out['1']['Xs'][8], out['1']['Xs'][4])
 
 
+@pytest.mark.parametrize('T,N,K,ride', [(4, 600, 20, '1'), (3, 260, 7, '1'), (5, 700, 12, '0')])
+def test_device_loop_on_two_queues_is_the_one_queue_trace(eng, monkeypatch, T, N, K, ride):
+    """the intercept's likelihood pass on a queue of its own beside the label update and the
+    conjugate draws, handed over through device flags (kernels_hdploop.hpp, HdpFork): forced
+    (DLSM_HDP_QUEUES=2), chosen by the engine (one live chain: unset) and switched off (=1) - bit
+    for bit the same trace, over several calls and with the proposal pass riding or not"""
+    Y, X, mu, sigma, z, beta, w = _case(T, N, K, 33)
+    hp = _hyper()
+    monkeypatch.setenv('DLSM_TAIL_PROPOSE', ride)
+    out = {}
+    for mode in ('1', '2', None):
+        if mode is None:
+            monkeypatch.delenv('DLSM_HDP_QUEUES', raising=False)
+        else:
+            monkeypatch.setenv('DLSM_HDP_QUEUES', mode)
+        with eng.Chain(T, N, 2, 'undirected', seed=9, chain_id=2) as c:
+            c.upload_network(Y); c.set_positions(X); c.set_intercepts([0.6])
+            c.set_samplers(eng.SamplerGrid(T, N, 0.15, tune=4, tune_interval=2))
+            c.set_prior_mixture(mu, sigma, 0.8, z)
+            c.hdp_configure(hp, beta, w, 0.5, 2.0, step_size_intercept=0.1, tune=4,
+                            tune_interval=100, sweep_algo=4)
+            c.hdp_trace_alloc(13)
+            c.hdp_run(1, 1); c.hdp_run(2, 6); c.hdp_run(8, 5)
+            out[mode] = c.hdp_trace_read(0, 13)
+            aux = c.hdp_get_aux()
+            out[mode]['aux_n'], out[mode]['aux_nk'] = aux['n'], aux['nk']
+    for mode in ('2', None):
+        for key in out['1']:
+            np.testing.assert_array_equal(out['1'][key], out[mode][key], err_msg='%s (queues %s)' % (key, mode))
+    assert not np.array_equal(out['2']['intercepts'][12], out['2']['intercepts'][1])
+
+
 def test_truncated_normal_far_tails(eng):
     """the blending coefficient's draw when its conditional sits far outside [0, 1] or is very
     sharp: the device's log-space quantile against scipy's (through the oracle)"""
