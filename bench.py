@@ -931,6 +931,7 @@ def measure(wl, args, group):
     group.barrier()
     t0 = time.perf_counter()
     wl.run(K)
+    wl.host_enqueue_seconds = time.perf_counter() - t0     # the host's share: the calls return when all is enqueued
     wl.synchronize()
     torch.cuda.synchronize()
     group.barrier()
@@ -1010,6 +1011,9 @@ def run_rank(args):
                     # uses the slowest)
                     'per_rank_value': [round(C * K / sec, 3) for sec in wl.per_rank_seconds],
                     'barrier_ms': round(wl.barrier_ms, 4),
+                    # how long the host took to enqueue the timed steps (asynchronous launches): well below
+                    # ms_per_step = the device is the limit, not the launching thread
+                    'host_enqueue_ms_per_step': round(1e3 * wl.host_enqueue_seconds / K, 4),
                     'roofline': roofline, 'cpu_baseline': cpu,
                     'chain_summaries[intercept_mean,intercept_sd,logp_mean,logp_last]':
                         chain_summaries(gathered),

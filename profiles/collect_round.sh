@@ -12,6 +12,11 @@ mkdir -p $OUT
 #    written where bench.py reads them, and into $OUT for the way home); 3. the bench lines
 for m in lsm hdp cc; do bash $ROOT/profiles/collect.sh $TAG $m profile > $OUT/collect_$m.log 2>&1; done
 cd $ROOT
+# the HDP-LPCM iteration launch by launch, on its two queues (the trace above) and on one (a trace of its own)
+python3 profiles/iteration_timeline.py $OUT/stats_hdp/bench_kernel_trace.csv > $OUT/hdp_timeline_two_queues.txt 2>&1
+(cd /tmp && export TMPDIR=/tmp && DLSM_HDP_QUEUES=1 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace_hdp_one_queue -o bench -- python3 $ROOT/bench.py --model hdp --no-cpu --steps 50 --warmup 10 --profile-steps 0 > $OUT/trace_hdp_one_queue.log 2>&1)
+python3 profiles/iteration_timeline.py $OUT/trace_hdp_one_queue/bench_kernel_trace.csv > $OUT/hdp_timeline_one_queue.txt 2>&1
+rm -rf $OUT/trace_hdp_one_queue
 for m in lsm hdp cc; do cp $OUT/kernel_stats_$m.csv profiles/${TAG}_kernel_stats_$m.csv; cp $OUT/traffic_$m.json profiles/${TAG}_traffic_$m.json; done
 python3 profiles/kernel_durations.py $TAG > profiles/kernel_durations.json
 python3 profiles/merge_traffic.py $TAG > profiles/traffic.json
