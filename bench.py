@@ -972,6 +972,8 @@ def run_rank(args):
     if args.share_device0:
         local_rank = 0
         os.environ['LOCAL_RANK'] = '0'
+        # (processes sharing a GPU: the HDP-LPCM loop stays on one queue - multichain.launch_ranks)
+        os.environ.setdefault('DLSM_HDP_QUEUES', '1')
     # one process per GPU; collectives over RCCL (backend "nccl") unless told otherwise
     group = init_chain_group(backend=(args.backend or 'nccl') if (world > 1 or args.force_collectives)
                              else 'gloo', force=args.force_collectives)

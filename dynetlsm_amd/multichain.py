@@ -222,6 +222,12 @@ def launch_ranks(argv, n, env_extra=None, relay_rank0=True, local_ranks=None):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(lr), WORLD_SIZE=str(n),
                    LOCAL_WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
         env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        # ranks that share a device keep the HDP-LPCM loop on one queue: its second queue (the
+        # intercept's likelihood pass beside the label update and the conjugate draws) pays on a
+        # device of its own and loses badly when the queues of two PROCESSES take turns on one GPU
+        # (measured: two ranks on one MI355X 4442 it/s on one queue each, 1824 on two)
+        if local_ranks is not None and list(local_ranks).count(lr) > 1:
+            env.setdefault('DLSM_HDP_QUEUES', '1')
         if env_extra:
             env.update(env_extra)
         procs.append(subprocess.Popen(list(argv), env=env,

@@ -285,7 +285,9 @@ int dlsm_hdp_trace_alloc(dlsm_chain *h, int n_total, double logp0);
  * draws (hdp_lpcm.py:876-1023), which do not read its result; the queues hand over through words in
  * device memory and are joined before the call's log-posterior pass, so the call still orders like one
  * stream.  Chosen while the handle is the process's only live chain (environment: DLSM_HDP_QUEUES=1
- * never, =2 always); the trace is bit for bit the one-queue trace. */
+ * never, =2 always); the trace is bit for bit the one-queue trace.  Processes that SHARE a device
+ * should set DLSM_HDP_QUEUES=1 (multichain.launch_ranks does): queues of two processes taking turns on
+ * one GPU lose more than the second queue hides. */
 int dlsm_hdp_run(dlsm_chain *h, int first, int count);
 /* queues the last dlsm_hdp_run call of this handle used: 1 or 2 */
 int dlsm_hdp_queues(dlsm_chain *h, int *queues);

@@ -34,7 +34,7 @@ python3 bench.py --model lsm --chains-per-gpu 8 --share-launches 0 --no-cpu --pr
 python3 profiles/posterior_mixing.py > $OUT/posterior_mixing.txt 2>&1
 python3 profiles/instr_counts.py > $OUT/instr_counts.json 2>&1
 python3 profiles/instr_counts.py scratch > $OUT/hot_kernel_registers.txt 2>&1
-python3 bench.py --gpus 2 --backend gloo --share-device0 --no-cpu > $OUT/bench_2ranks_one_gpu.json 2> $OUT/bench_2ranks.err
+python3 bench.py --gpus 2 --backend gloo --share-device0 --no-cpu 2> $OUT/bench_2ranks.err | grep "^{" > $OUT/bench_2ranks_one_gpu.json   # (gloo greets on stdout)
 python3 bench.py --model lsm --cpu-procs 8 > $OUT/bench_lsm_cpu8.json 2> $OUT/bench_lsm_cpu8.err
 if [ -f tmp_timing/libtiming.so ]; then
   python3 profiles/pipe_timing.py tmp_timing/libtiming.so $OUT/pipe_timing.json > $OUT/pipe_timing.log 2>&1
