@@ -807,6 +807,7 @@ __global__ __launch_bounds__(HDP_THREADS) void k_hdp_stage1(ChainView c, HdpLoop
                                                             double *__restrict__ trace_ic, IterRef ir,
                                                             uint8_t *__restrict__ trace_row) {
     DLSM_HDP_STAMP(0)
+    __builtin_amdgcn_s_setprio(3);          // ahead of the second queue's likelihood pass on a shared SIMD
     extern __shared__ int32_t sHist[];          // K K + K (the counts + tables role)
     const int K = hb.K, T = c.T;
     const int n_tab = T * hdp_tab_groups(K);
@@ -848,6 +849,7 @@ template <int D>
 __global__ __launch_bounds__(HDP_THREADS) void k_hdp_stage2(ChainView c, HdpLoopBuf hb,
                                                             HdpDeviceState *hs, IterRef ir) {
     DLSM_HDP_STAMP(1)
+    __builtin_amdgcn_s_setprio(3);          // ahead of the second queue's likelihood pass on a shared SIMD
     const int K = hb.K;
     if (blockIdx.x == 0) { hdp_globals_wg(c, hb, hs, ir.get()); return; }
     if (blockIdx.x == 1) { hdp_akgrid_wg(c, hb, hs, ir.get()); return; }
@@ -859,6 +861,7 @@ template <int D>
 __global__ __launch_bounds__(HDP_THREADS) void k_hdp_stage3(ChainView c, HdpLoopBuf hb,
                                                             const HdpDeviceState *hs, IterRef ir) {
     DLSM_HDP_STAMP(2)
+    __builtin_amdgcn_s_setprio(3);          // ahead of the second queue's likelihood pass on a shared SIMD
     extern __shared__ double sGam[];            // K * K + K (the weights' role)
     const int K = hb.K, T = c.T;
     const int nw = HW_SPLIT * (T - 1);

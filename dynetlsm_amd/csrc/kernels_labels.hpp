@@ -219,6 +219,7 @@ __global__ __launch_bounds__(LM_THREADS) void k_sample_labels_mfma(
     // (HDP-LPCM loop with the likelihood pass on a second queue: this launch follows the centring
     // launch on the chain's queue - the centred positions are final, the pass may start)
     if (flag && blockIdx.x == 0 && threadIdx.x == 0) coh_store_i32(flag, flag_val);
+    __builtin_amdgcn_s_setprio(3);          // ahead of the second queue's likelihood pass on a shared SIMD
     constexpr int KT = (KS + 3) / 4, S = 16 * KT + 1, WS = (4 * KS) | 1;
     const int T = c.T, K = c.K, N = c.N, D = c.D;
     double *wt = smem;                                  // [T][K][WS] transition matrices, zero padded

@@ -90,6 +90,7 @@ template <int D>
 __global__ __launch_bounds__(HH_THREADS) void k_hdp_hypers_propose(ChainView c, HdpLoopBuf hb,
                                                                    HdpDeviceState *hs, HdpTrace tr,
                                                                    IterRef ir, ProposeBuf nb, HdpFork fk) {
+    __builtin_amdgcn_s_setprio(3);
     if (blockIdx.x == 0) {
         // the intercept of the next sweep was settled in stage 1 - or, with the likelihood pass on a
         // queue of its own (HdpFork), by k_hdp_intercept_fork: then a lane of the wavefronts that draw
