@@ -284,6 +284,25 @@ __device__ __forceinline__ void hdp_counts_tables_wg(const ChainView &c, const H
             }
         }
         if (lane == 0) hb.m[cell] = cnt;
+        // The override variable of (t - 1, j) (sample_auxillary.py:37-42) is a binomial over exactly this
+        // cell's tables, m[t, j, j], with a success probability made of LAST iteration's beta and
+        // concentration parameters: drawn here, its trials on the lanes like the tables' (the same
+        // uniforms as hdp_binomial's sequential loop - trial i = uniform i & 1 of attempt i >> 1 - and an
+        // integer count).  In stage 2's globals workgroup, a lane per binomial, the longest of them
+        // (hundreds of trials one after the other) was 10 of the launch's 16 us.
+        if (t > 0 && j == k) {
+            const double rho = hs->kappa / (hs->alpha + hs->kappa);
+            const double p = rho / (rho + hb.beta[j] * (1 - rho));
+            const uint32_t q = (uint32_t)((t - 1) * K + j);
+            int w = 0;
+            for (int a0 = 0; 2 * a0 < cnt; a0 += 64) {
+                const int att = a0 + lane, i0 = 2 * att;
+                double u0 = 2.0, u1 = 2.0;
+                if (i0 < cnt) rg.u2(HK_OVERRIDE, q, (uint32_t)att, u0, u1);
+                w += __popcll(__ballot(i0 < cnt && u0 <= p)) + __popcll(__ballot(i0 + 1 < cnt && u1 <= p));
+            }
+            if (lane == 0) hb.wover[q] = w;
+        }
     }
 }
 
@@ -295,15 +314,18 @@ __device__ __forceinline__ void hdp_globals_wg(const ChainView &c, const HdpLoop
     // This workgroup is stage 2's long pole (profiles/hdp_tail_timing.py: 17 us against 9 for the
     // other roles), and its three chains ran one after the other: a lane per override binomial
     // (6.6 us), the tables' column sums a cell per trip through an LDS atomic (4.8 us), a lane per
-    // gamma variate of beta (4.0 us).  Now wavefronts 0-2 draw the binomials while wavefront 3
-    // stages the tables in LDS, sums their columns from there and draws the shape-independent
-    // part of beta's variates; what is left behind the barrier is the variates' shape-dependent
-    // part.  Same draws, integer sums: the same values (17.4 -> 11.7 us).
+    // gamma variate of beta (4.0 us).  Round 3: wavefronts 0-2 drew the binomials while wavefront 3
+    // staged the tables in LDS, summed their columns and drew the shape-independent part of beta's
+    // variates (17.4 -> 15 us: both sides ~10 us).  Round 4: the binomials are drawn in stage 1 beside
+    // the tables they are binomials over (a wavefront's lanes = the trials), so wavefronts 0-2 sum the
+    // override variables and the tables' columns (nine threads per column at config 3) while
+    // wavefront 3 only draws the shape-independent part of the variates; what is left behind the
+    // barrier is the variates' shape-dependent part.  Same draws, integer sums: the same values.
     // (Built and measured slower: the binomials' trials dealt out over all threads - 1800 pairs
     // at config 3 - through a scan and a pair -> cell search: 7.8 us; a column's rows read from
     // global memory by nine threads: 9.2 us.)
     __shared__ int sMsum[64], sWsum[64], sTot[4];
-    __shared__ double sBeta[64], sG[64];
+    __shared__ double sG[64];
     __shared__ int sMt[HG_MCAP];
     __shared__ int sReady;
     const int K = hb.K, T = c.T, tid = threadIdx.x, wave = tid >> 6;
@@ -312,50 +334,51 @@ __device__ __forceinline__ void hdp_globals_wg(const ChainView &c, const HdpLoop
     const HdpRng g = hdp_rng(c, iter);
     if (tid < 64) { sMsum[tid] = 0; sWsum[tid] = 0; }
     if (tid < 4) sTot[tid] = 0;
-    if (tid < K) sBeta[tid] = hb.beta[tid];
     if (tid == 0) sReady = 0;
     __syncthreads();
     DLSM_HDP_PHASE(0)
-    // every thread stages its share of the tables (one burst of loads); only wavefront 3 reads
-    // them, so only wavefront 3 waits for the others' shares - on a counter in LDS, the binomials'
-    // wavefronts go on at once
+    // every thread stages its share of the tables (one burst of loads); the wavefronts that sum the
+    // columns wait for the shares on a counter in LDS, wavefront 3 goes on at once
+    const int wfirst = wave < 3 && tid < (T - 1) * K ? hb.wover[tid] : 0;
     if (mlds) {
-        for (int q0 = tid; q0 < TKK; q0 += 8 * HG_THREADS) {
-            int v[8];
+        constexpr int NB = 16;                      // (config 3: the 4000 cells in ONE burst)
+        for (int q0 = tid; q0 < TKK; q0 += NB * HG_THREADS) {
+            int v[NB];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = q0 + u * HG_THREADS < TKK ? hb.m[q0 + u * HG_THREADS] : 0;
+            for (int u = 0; u < NB; ++u) v[u] = q0 + u * HG_THREADS < TKK ? hb.m[q0 + u * HG_THREADS] : 0;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) if (q0 + u * HG_THREADS < TKK) sMt[q0 + u * HG_THREADS] = v[u];
+            for (int u = 0; u < NB; ++u) if (q0 + u * HG_THREADS < TKK) sMt[q0 + u * HG_THREADS] = v[u];
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);         // lgkmcnt(0): this wavefront's LDS writes landed
         __builtin_amdgcn_wave_barrier();
         if ((tid & 63) == 0) atomicAdd(&sReady, 1);
     }
-    const double rho = hs->kappa / (hs->alpha + hs->kappa);
     HdpGammaPre gp{0.0, 0.0, 0.0, 0.0};
     const int l3 = tid - 3 * 64;                    // lane of wavefront 3 = component
-    if (wave < 3) {
-        // override variables (sample_auxillary.py:37-42)
-        int wsum = 0;
-        for (int q = tid; q < (T - 1) * K; q += 3 * 64) {
-            const int t = q / K, j = q - t * K;
-            const int mjj = hb.m[((size_t)(t + 1) * K + j) * K + j];
-            const double p = rho / (rho + sBeta[j] * (1 - rho));
-            const int w = hdp_binomial(g, HK_OVERRIDE, (uint32_t)q, mjj, p);
-            hb.wover[q] = w;
+    if (wave == 3) {
+        // the shape-independent part of beta's variates: needs nothing summed here
+        if (l3 < K) gp = hdp_gamma_pre(g, HK_BETA, (uint32_t)l3);
+    } else {
+        // sums of the override variables (sample_auxillary.py:37-42; drawn in stage 1 beside the tables
+        // they are binomials over: hdp_counts_tables_wg; the first 192 were requested with the tables)
+        int wsum = wfirst;
+        if (tid < (T - 1) * K) atomicAdd(&sWsum[tid % K], wfirst);
+        for (int q = tid + 3 * 64; q < (T - 1) * K; q += 3 * 64) {
+            const int j = q % K;
+            const int w = hb.wover[q];
             atomicAdd(&sWsum[j], w);
             wsum += w;
         }
         atomicAdd(&sTot[0], wsum);
-    } else {
         // column sums of the tables: m_bar[k] = sum_{t >= 1, j} m[t, j, k] - sum_t w[t, k] + m[0, 0, k]
-        // (nsub lanes per column, four rows requested per trip: a row per trip is an LDS round trip
-        // per row, 200 in a row at config 3)
+        // (nsub threads per column, four rows requested per trip: a row per trip is an LDS round trip
+        // per row, 200 in a row at config 3) - by the three wavefronts that used to draw the binomials
         if (mlds)
             while (*(volatile int *)&sReady < HG_THREADS / 64) __builtin_amdgcn_s_sleep(1);
-        const int nsub = max(1, 64 / K);
-        for (int k0 = 0; k0 < K; k0 += 64) {
-            const int k = k0 + l3 % min(K, 64), sub = l3 / min(K, 64);
+        const int KK = min(K, 3 * 64);
+        const int nsub = max(1, (3 * 64) / KK);
+        for (int k0 = 0; k0 < K; k0 += 3 * 64) {
+            const int k = k0 + tid % KK, sub = tid / KK;
             if (k >= K || sub >= nsub) continue;
             int acc = 0, rest = 0;
             for (int r0 = sub; r0 < T * K; r0 += 4 * nsub) {        // row r = (t, j)
@@ -376,7 +399,6 @@ __device__ __forceinline__ void hdp_globals_wg(const ChainView &c, const HdpLoop
             atomicAdd(&sMsum[k], acc);
             atomicAdd(&sTot[1], rest);
         }
-        if (l3 < K) gp = hdp_gamma_pre(g, HK_BETA, (uint32_t)l3);
     }
     __syncthreads();
     DLSM_HDP_PHASE(2)
@@ -645,9 +667,25 @@ __device__ __forceinline__ void hdp_hypers_wg(const ChainView &c, const HdpLoopB
     // the two sums of the variance hyper-parameters.
     if (wave == 1) {
         // sums of the lambda update over the cells (t >= 1, k) with members (hdp_lpcm.py:941-950)
+        // (counts and sums of four trips requested together: a trip at a time was two dependent round
+        // trips per trip, count then sums, on the launch's longest chain; a lane still adds its cells in
+        // ascending order)
         double a0 = 0.0, a1 = 0.0;
-        for (int q = K + lane; q < T * K; q += 64)
-            if (hb.nk[q] > 0) { a0 += hb.L[2 * (size_t)q]; a1 += hb.L[2 * (size_t)q + 1]; }
+        constexpr int NQ = 4;
+        for (int q0 = K + lane; q0 < T * K; q0 += NQ * 64) {
+            int nkv[NQ];
+            double l0[NQ], l1[NQ];
+#pragma unroll
+            for (int u = 0; u < NQ; ++u) {
+                const int q = min(q0 + u * 64, T * K - 1);
+                nkv[u] = q0 + u * 64 < T * K ? hb.nk[q] : 0;
+                l0[u] = hb.L[2 * (size_t)q];
+                l1[u] = hb.L[2 * (size_t)q + 1];
+            }
+#pragma unroll
+            for (int u = 0; u < NQ; ++u)
+                if (nkv[u] > 0) { a0 += l0[u]; a1 += l1[u]; }
+        }
         const double ml_sum = wave_sum_all(a0);
         const double sl_sum = wave_sum_all(a1);
         if (lane == 0) {
