@@ -190,9 +190,11 @@ int enqueue_hdp_logp_batch(dlsm_chain *h, int first, int count) {
 // The likelihood pass on a queue of its own: the undirected model with the matrix-core label kernel
 // (which carries the hand-over flag), outside profiling runs (their per-launch events serialise the
 // queues).  DLSM_HDP_QUEUES=1 never, =2 always; otherwise only while this is the process's only live
-// chain: the waits are device-side polls, and with more streams alive than the runtime has hardware
-// queues the two queues of a chain can land on one, where a poll would wait for a launch queued
-// behind it (the poll budget turns that into an error instead of a hang; here it is avoided).
+// chain.  Every waiter is ENQUEUED after the launch it waits for, so even two queues that the runtime
+// has mapped onto one hardware queue (more streams alive than it has queues) cannot wait for each
+// other for ever - they only lose the overlap; the poll budget is the net under that argument.  The
+// rule is about what was measured: one chain alone on its device gains, chains that share a device
+// (threads of one process: untested; processes: 2.4 times slower, multichain.launch_ranks) do not.
 int hdp_fork_arm(dlsm_chain *h) {
     const char *e = getenv("DLSM_HDP_QUEUES");
     const int mode = e ? atoi(e) : 0;

@@ -814,9 +814,9 @@ __device__ __forceinline__ void hdp_intercept_wg(const double *__restrict__ part
 //                      one thread stores the results, fences and stores the flag); polled by the
 //                      iteration's last launch before it takes the intercept for the next sweep
 //   flags[HF_ERR]      sticky: a bounded wait ran out of its budget (reported by the host)
-// A wait only ever outlasts one iteration's launches on the other queue unless both queues were
-// mapped onto one hardware queue (more streams alive than the runtime has queues): the budget turns
-// that deadlock into an error.
+// Every waiter is enqueued (host order) after the launch that stores what it waits for, so a wait ends
+// even when the runtime has mapped both queues onto one hardware queue, where launches start in that
+// order; the poll budget and the error word are the net under that argument.
 enum : int { HF_CENTRED = 0, HF_SETTLED = 1, HF_ERR = 2 };
 struct HdpFork { int32_t *flags; int32_t ticket; int32_t budget; };
 
