@@ -55,6 +55,25 @@ namespace dlsm {
 #ifndef DLSM_H_MID
 #define DLSM_H_MID 0
 #endif
+// 1: a wavefront's issue priority falls as its item advances (s_setprio 3 for the first quarter of the
+// prefetched trips .. 0 for the last).  The arbiter serves a SIMD's ready wavefronts oldest first: its four
+// items ran nearly one after the other (first trip done after 0.7 / 1.4 / 3.0 / 4.5 us, exit after 3.8 / 5.3 /
+// 7.1 / 8.6: profiles/r04_h_entry_ablation.md), and the youngest ran its tail alone, with nobody to fill the
+// slots its dependent float64 instructions leave.  With the priority tied to progress the four advance
+// together and end together: k_pipe_step 10.53 -> 10.08 us per launch, C2 4300 -> 4470 it/s.  (Boundaries at
+// the quarters or one trip later: the same; two levels instead of four: half the gain.)
+#ifndef DLSM_TRIP_PRIO
+#define DLSM_TRIP_PRIO 1
+#endif
+#if DLSM_TRIP_PRIO
+#define DLSM_TRIP_PRIO_STEP(U_)                                                                \
+        if ((U_) == 0) __builtin_amdgcn_s_setprio(3);                                          \
+        else if ((U_) == (PP_NPRE * 1) / 4) __builtin_amdgcn_s_setprio(2);                     \
+        else if ((U_) == (PP_NPRE * 2) / 4) __builtin_amdgcn_s_setprio(1);                     \
+        else if ((U_) == (PP_NPRE * 3) / 4) __builtin_amdgcn_s_setprio(0);
+#else
+#define DLSM_TRIP_PRIO_STEP(U_)
+#endif
 constexpr int PP_THREADS = 1024;
 constexpr int PP_WAVES = PP_THREADS / 64;
 constexpr int PP_B = 128;               // nodes per batch (two 64-lane halves)
@@ -696,6 +715,7 @@ __device__ __forceinline__ void pipe_eval_item(const ChainView &c, const PipeBuf
 #define DLSM_PIPE_LOOPS(FLUSH_, SQ_)                                                          \
     _Pragma("unroll")                                                                         \
     for (int u = 0; u < PP_NPRE; ++u) {                                                       \
+        DLSM_TRIP_PRIO_STEP(u)                                                                \
         DLSM_PIPE_MASKS(u)                                                                    \
         if (LDSX) {     /* rows are staged up to the part's end; a clamped lane is masked */  \
             const double *row_ = sX + (size_t)min(64 * u + lane, pb.per - 1) * D;             \
