@@ -60,8 +60,12 @@ namespace dlsm {
 // items ran nearly one after the other (first trip done after 0.7 / 1.4 / 3.0 / 4.5 us, exit after 3.8 / 5.3 /
 // 7.1 / 8.6: profiles/r04_h_entry_ablation.md), and the youngest ran its tail alone, with nobody to fill the
 // slots its dependent float64 instructions leave.  With the priority tied to progress the four advance
-// together and end together: k_pipe_step 10.53 -> 10.08 us per launch, C2 4300 -> 4470 it/s.  (Boundaries at
-// the quarters or one trip later: the same; two levels instead of four: half the gain.)
+// together and end together: k_pipe_step 10.53 -> 10.08 us per launch, C2 4300 -> 4470 it/s (boundaries at
+// the quarters or one trip later: the same; two levels instead of four: half the gain); with priority 3 from
+// the item's FIRST instruction (pipe_item_prologue: a wavefront that enters late gets its loads out at once)
+// 9.90 us, 4570 it/s.  (The table's fill + barrier moved behind the item's operand requests, so that the two
+// round trips overlap: 10.65 us - the barrier then holds all sixteen wavefronts until the last one's operands
+// have arrived; dropped.)
 #ifndef DLSM_TRIP_PRIO
 #define DLSM_TRIP_PRIO 1
 #endif
@@ -531,6 +535,9 @@ __device__ __forceinline__ void pipe_item_prologue(const ChainView &c, const Pip
                                                    int k, int p, int lane, PipeItemPre<D> &q) {
     constexpr int PW = 2 * D + 2;
     const int N = c.N, W = c.W;
+#if DLSM_TRIP_PRIO
+    __builtin_amdgcn_s_setprio(3);          // from the item's first instruction: its loads leave at once
+#endif
     const int jk = be * PP_B + k;
     const double *props = pb.prop + (size_t)t * N * PW;
     const uint32_t *yr = c.ybits + ((size_t)t * N + jk) * W;
