@@ -55,6 +55,13 @@ namespace dlsm {
 #ifndef DLSM_H_MID
 #define DLSM_H_MID 0
 #endif
+// 1: the last wavefront of a SIMD hands its first-round H entries to the first one (pipe_item_finish).  Under
+// oldest-first issue this measured slower (10.77 against 10.54 us); with the items advancing together
+// (DLSM_TRIP_PRIO) the first wavefront of a SIMD still leaves ~1.8 us before the last one, whose entry is the
+// launch's tail: 9.82 -> 9.58 us per launch, C2 4565 -> 4660 it/s
+#ifndef DLSM_H_SHIFT
+#define DLSM_H_SHIFT 1
+#endif
 // 1: a wavefront's issue priority falls as its item advances (s_setprio 3 for the first quarter of the
 // prefetched trips .. 0 for the last).  The arbiter serves a SIMD's ready wavefronts oldest first: its four
 // items ran nearly one after the other (first trip done after 0.7 / 1.4 / 3.0 / 4.5 us, exit after 3.8 / 5.3 /
@@ -508,13 +515,31 @@ __device__ __forceinline__ void pipe_item_finish(const ChainView &c, const PipeB
             f += hround;
         }
     }
+    // HSHIFT (the launch-per-batch evaluators: a workgroup's 16 wavefronts hold items k0 .. k0 + 15 of one
+    // part, wavefronts w, w + 4, w + 8, w + 12 share a SIMD): the LAST wavefront of a SIMD hands its
+    // first-round entries to the FIRST one - the same arithmetic on the same SIMD, but no longer the launch's tail
+    constexpr bool HSHIFT = DLSM_H_SHIFT != 0 && !COH && !HPF && !HDONE;
+    const int wig = (int)(threadIdx.x >> 6);
+    bool first = true;
+    if (HSHIFT && wig >= 12 && f < hround) f += hround;           // handed over (its later rounds stay)
     for (; f < hl.nslots; f += hround) {
         int kk, e;
-        if (!pipe_h_decode(f, hl, ncross, nb, kk, e)) continue;
-        PipeHPre<D> o;
-        pipe_h_operands<D, MODEL>(c, props, yrows, ytrows, jprev + e, j0 + kk, o);
-        if (c.squared) DLSM_H_CALL(true, kk, e, o, !HPF && !HDONE && f == hf0);
-        else DLSM_H_CALL(false, kk, e, o, !HPF && !HDONE && f == hf0);
+        if (pipe_h_decode(f, hl, ncross, nb, kk, e)) {
+            PipeHPre<D> o;
+            pipe_h_operands<D, MODEL>(c, props, yrows, ytrows, jprev + e, j0 + kk, o);
+            if (c.squared) DLSM_H_CALL(true, kk, e, o, !HPF && !HDONE && f == hf0);
+            else DLSM_H_CALL(false, kk, e, o, !HPF && !HDONE && f == hf0);
+        }
+        if (HSHIFT && first && wig < 4 && k + 12 < nb) {
+            // ... and the first-round entries of item k + 12 (same part, same slice: the SIMD's last wavefront)
+            const int f2 = hf0 + 12 * pb.parts * 64;
+            if (f2 < hl.nslots && pipe_h_decode(f2, hl, ncross, nb, kk, e)) {
+                PipeHPre<D> o;
+                pipe_h_operands<D, MODEL>(c, props, yrows, ytrows, jprev + e, j0 + kk, o);
+                if (c.squared) DLSM_H_CALL(true, kk, e, o, false); else DLSM_H_CALL(false, kk, e, o, false);
+            }
+        }
+        first = false;
     }
 #undef DLSM_H_CALL
 #undef DLSM_H_TS
