@@ -163,6 +163,9 @@ __device__ inline double dev_ndtri_exp(double y) {
     }
     for (int i = 0; i < polish; ++i) {
         const double l = dev_log_ndtr(x);
+        // (converged: the remaining steps would move x by less than an ulp - each is three dependent
+        // transcendental calls on the launch's longest chain, k_hdp_hypers)
+        if (fabs(l - y) <= 4.4e-16 * fabs(y)) break;
         // d/dx log ndtr = phi / ndtr
         const double dl = x < 0.0 ? 0.79788456080286535588 / erfcx(-x * 0.70710678118654752440)
                                   : exp(-0.5 * x * x - 0.91893853320467274178 - l);
