@@ -1153,6 +1153,10 @@ static int launch_sweep_pipe(dlsm_chain *h, IterRef iter, bool alloc_only = fals
     const int nlaunch = (nbat + G - 1) / G;
     const int last = T > 1 ? nlaunch : nlaunch - 1;
     for (int l = -1; l <= last; ++l) {
+        // (the head - the proposal pass above and launch -1 - may have been enqueued on the chain's second
+        // queue already, beside the previous iteration's conjugate draws: capi_hdp.hpp)
+        if (l == -1 && !iter.ptr && h->head_done_for == (long)iter.value) continue;
+        if (h->sweep_part == 1 && l >= 0) break;
         const bool any_eval = (G * (l + 1) < nbat) || (T > 1 && l >= 0 && G * l < nbat);
         const int grid = T + (any_eval ? ne_wg : 0);
         const bool lng = pb.per > 64 * pipe_prefetch_trips(DD);
@@ -1347,6 +1351,7 @@ static int enqueue_sweep(dlsm_chain *h, IterRef iter, int algo, bool alloc_only 
     if (!alloc_only) {              // only a pipelined sweep leaves proposal buffers a tail can fill
         if (!h->pipe_touched) h->next_prop_ok = false;
         h->prop_drawn_for = -1;
+        if (h->sweep_part == 0) h->head_done_for = -1;
     }
     return rc;
 }

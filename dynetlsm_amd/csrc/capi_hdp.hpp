@@ -126,6 +126,7 @@ int enqueue_hdp_iteration(dlsm_chain *h, int it, bool draw_next) {
         if (rc) return rc;
     }
     int nrec = 0;
+    bool head = false;
     if (fork) {
         hipLaunchKernelGGL(k_hdp_gate, dim3(1), dim3(64), 0, h->fork_stream, fk, (int)HF_CENTRED);
         hipStream_t keep = h->stream;
@@ -133,8 +134,28 @@ int enqueue_hdp_iteration(dlsm_chain *h, int it, bool draw_next) {
         rc = loglik_records(h, 2, h->lsm->cand, nullptr, nullptr, &nrec);
         h->stream = keep;
         if (rc) return rc;
+        // ... and, when another iteration follows and its sweep is the pipelined one, the HEAD of that sweep:
+        // the proposal pass and the first, evaluate-only launch need the settled intercept, the positions and
+        // the step sizes - nothing the label update or the conjugate draws produce - so they run here, beside
+        // those, and the chain's queue starts the sweep at its second launch.  The flag then says "head done".
+        head = draw_next && h->next_prop_ok && resolve_sweep_algo(h, h->hdp_cfg.sweep_algo) == 4 &&
+               !(getenv("DLSM_HDP_HEAD") && atoi(getenv("DLSM_HDP_HEAD")) == 0);
+        if (head)       // (the intercept step and the proposal pass in one launch)
+            hipLaunchKernelGGL((k_hdp_intercept_fork_propose<DD>), dim3(1 + propose_blocks(T, N)), dim3(256), 0,
+                               h->fork_stream, h->partials, nrec, h->lsm, h->hdp, h->intercept, h->trace_ic, it,
+                               v, h->next_prop);
+        else
         hipLaunchKernelGGL(k_hdp_intercept_fork, dim3(1), dim3(HDP_THREADS), 0, h->fork_stream, h->partials, nrec,
-                           h->lsm, h->hdp, h->intercept, h->trace_ic, it, fk);
+                           h->lsm, h->hdp, h->intercept, h->trace_ic, it, fk, (int)HF_SETTLED);
+        if (head) {
+            h->prop_drawn_for = (long)it + 1;      // (the sweep's head below finds its proposals drawn)
+            h->stream = h->fork_stream; h->sweep_part = 1;
+            rc = enqueue_sweep(h, IterRef{(uint32_t)(it + 1), nullptr}, h->hdp_cfg.sweep_algo);
+            h->sweep_part = 0; h->stream = keep;
+            if (rc) return rc;
+            hipLaunchKernelGGL(k_fork_set, dim3(1), dim3(64), 0, h->fork_stream, fk, (int)HF_SETTLED);
+            h->prop_drawn_for = (long)it + 1; h->head_done_for = (long)it + 1;
+        }
     } else if (!directed) { rc = loglik_records(h, 2, h->lsm->cand, nullptr, nullptr, &nrec); if (rc) return rc; }
     ProfScope ps(h, DLSM_K_HDP_TAIL);
     const int n_tab = T * hdp_tab_groups(K);    // (the label counts are a role of this launch)
@@ -148,7 +169,12 @@ int enqueue_hdp_iteration(dlsm_chain *h, int it, bool draw_next) {
                        (size_t)(K * K + K) * sizeof(double), h->stream, v, hb, h->hdp, ir);
     HdpTrace tr{h->trace_ic, h->trace_logp, h->htr_mu, h->htr_sigma, h->htr_beta, h->htr_w,
                 h->htr_lambda, h->htr_hyper};
-    if (draw_next && h->next_prop_ok) {     // with the next sweep's proposal pass (kernels_tail_propose.hpp)
+    if (head) {                             // the sweep's head is on the second queue: this launch waits for it
+        ProposeBuf none = h->next_prop;
+        none.consts = nullptr;
+        hipLaunchKernelGGL((k_hdp_hypers_propose<DD>), dim3(1), dim3(HH_THREADS), 0, h->stream, v, hb, h->hdp, tr,
+                           ir, none, fk);
+    } else if (draw_next && h->next_prop_ok) {     // with the next sweep's proposal pass (kernels_tail_propose.hpp)
         hipLaunchKernelGGL((k_hdp_hypers_propose<DD>), dim3(1 + propose_blocks(T, N)), dim3(HH_THREADS), 0,
                            h->stream, v, hb, h->hdp, tr, ir, h->next_prop, fk);
         h->prop_drawn_for = (long)it + 1;
@@ -384,7 +410,7 @@ int dlsm_hdp_run(dlsm_chain *h, int first, int count) {
     int rc = check_ready_hdp(h); if (rc) return rc;
     // (read per call: the tests switch it inside one process)
     const bool ride = !(getenv("DLSM_TAIL_PROPOSE") && atoi(getenv("DLSM_TAIL_PROPOSE")) == 0);
-    h->prop_drawn_for = -1;
+    h->prop_drawn_for = -1; h->head_done_for = -1;
     rc = hdp_fork_arm(h); if (rc) return rc;
     for (int it = first; it < first + count; ++it) {
         DISPATCH_D(h, h->D, rc = enqueue_hdp_iteration<DD>(h, it, ride && it + 1 < first + count));
@@ -394,6 +420,7 @@ int dlsm_hdp_run(dlsm_chain *h, int first, int count) {
         HIPCHK(h, hipEventRecord(h->fork_ev, h->fork_stream));
         HIPCHK(h, hipStreamWaitEvent(h->stream, h->fork_ev, 0));
     }
+    h->head_done_for = -1;
     if (rc) return rc;
     h->prop_drawn_for = -1;
     // the log-posterior trace of these rows: one batched pass over the trace, behind the iterations

@@ -869,14 +869,21 @@ __global__ __launch_bounds__(HDP_THREADS) void k_hdp_stage1(ChainView c, HdpLoop
 __global__ __launch_bounds__(256) void k_hdp_intercept_fork(const double *__restrict__ partials, int nrec,
                                                             LsmDeviceState *lsm, HdpDeviceState *hs,
                                                             double *__restrict__ intercept,
-                                                            double *__restrict__ trace_ic, int it, HdpFork f) {
+                                                            double *__restrict__ trace_ic, int it, HdpFork f,
+                                                            int which_flag) {
     hdp_intercept_wg(partials, nrec, lsm, hs, intercept, trace_ic, it);
     if (threadIdx.x == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        coh_store_i32(f.flags + HF_SETTLED, f.ticket);
+        if (which_flag >= 0) coh_store_i32(f.flags + which_flag, f.ticket);
     }
+}
+
+// the word that says "everything ahead of this launch on its queue has ended" (a kernel boundary lies
+// between: what those launches stored is visible to whoever starts behind the flag)
+__global__ __launch_bounds__(64) void k_fork_set(HdpFork f, int which) {
+    if (threadIdx.x == 0) coh_store_i32(f.flags + which, f.ticket);
 }
 
 // consumer side, one lane: the settled intercept (poll, acquire, then a plain load)

@@ -85,6 +85,21 @@ __global__ __launch_bounds__(256) void k_lsm_finalize_apply_propose(
                                      (int)blockIdx.x, (int)gridDim.x - 1);
 }
 
+// HDP-LPCM loop on two queues with the next sweep's head on the second one: the intercept step behind its
+// pass (k_hdp_intercept_fork's workgroup, which also leaves the sweep's two constants) and the sweep's
+// proposal pass in ONE launch of that queue - the rows' proposals need positions and step sizes only
+template <int D>
+__global__ __launch_bounds__(256) void k_hdp_intercept_fork_propose(
+    const double *__restrict__ partials, int nrec, LsmDeviceState *lsm, HdpDeviceState *hs,
+    double *__restrict__ intercept, double *__restrict__ trace_ic, int it, ChainView c, ProposeBuf nb) {
+    if (blockIdx.x == 0) {
+        hdp_intercept_wg(partials, nrec, lsm, hs, intercept, trace_ic, it);
+        if (threadIdx.x == 0) pipe_propose_consts(c, nb.consts, intercept);     // behind its own stores
+        return;
+    }
+    pipe_propose_rows<D>(c, nb, (uint32_t)it + 1u, (int)blockIdx.x - 1, (int)threadIdx.x);
+}
+
 static_assert(HH_THREADS == 256, "the proposal pass is laid out for 256 threads");
 template <int D>
 __global__ __launch_bounds__(HH_THREADS) void k_hdp_hypers_propose(ChainView c, HdpLoopBuf hb,
@@ -98,7 +113,9 @@ __global__ __launch_bounds__(HH_THREADS) void k_hdp_hypers_propose(ChainView c, 
         if (fk.flags) {
             if (threadIdx.x == HH_THREADS - 1) {
                 hdp_fork_acquire_settled(fk);
-                pipe_propose_consts(c, nb.consts, c.intercept);
+                // (consts == NULL: the sweep's head - proposal pass, constants, first launch - was enqueued on
+                // the second queue and the flag says it has ended)
+                if (nb.consts) pipe_propose_consts(c, nb.consts, c.intercept);
             }
         } else if (threadIdx.x == 0) pipe_propose_consts(c, nb.consts, c.intercept);   // (nb.lsm_draw is NULL here)
         hdp_hypers_wg(c, hb, hs, tr, ir);

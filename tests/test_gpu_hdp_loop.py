@@ -178,14 +178,20 @@ def test_device_loop_on_two_queues_is_the_one_queue_trace(eng, monkeypatch, T, N
     """the intercept's likelihood pass on a queue of its own beside the label update and the
     conjugate draws, handed over through device flags (kernels_hdploop.hpp, HdpFork): forced
     (DLSM_HDP_QUEUES=2), chosen by the engine (one live chain: unset) and switched off (=1) - bit
-    for bit the same trace, over several calls and with the proposal pass riding or not"""
+    for bit the same trace, over several calls and with the proposal pass riding or not; with the
+    next sweep's head (proposal pass + first launch) on the second queue as well, or not
+    (DLSM_HDP_HEAD=0)"""
     Y, X, mu, sigma, z, beta, w = _case(T, N, K, 33)
     hp = _hyper()
     monkeypatch.setenv('DLSM_TAIL_PROPOSE', ride)
     out = {}
-    for mode in ('1', '2', None):
+    for mode in ('1', '2', None, '2-nohead'):
+        monkeypatch.delenv('DLSM_HDP_HEAD', raising=False)
         if mode is None:
             monkeypatch.delenv('DLSM_HDP_QUEUES', raising=False)
+        elif mode == '2-nohead':            # the next sweep's head stays on the chain's queue
+            monkeypatch.setenv('DLSM_HDP_QUEUES', '2')
+            monkeypatch.setenv('DLSM_HDP_HEAD', '0')
         else:
             monkeypatch.setenv('DLSM_HDP_QUEUES', mode)
         with eng.Chain(T, N, 2, 'undirected', seed=9, chain_id=2) as c:
@@ -199,7 +205,7 @@ def test_device_loop_on_two_queues_is_the_one_queue_trace(eng, monkeypatch, T, N
             out[mode] = c.hdp_trace_read(0, 13)
             aux = c.hdp_get_aux()
             out[mode]['aux_n'], out[mode]['aux_nk'] = aux['n'], aux['nk']
-    for mode in ('2', None):
+    for mode in ('2', None, '2-nohead'):
         for key in out['1']:
             np.testing.assert_array_equal(out['1'][key], out[mode][key], err_msg='%s (queues %s)' % (key, mode))
     assert not np.array_equal(out['2']['intercepts'][12], out['2']['intercepts'][1])
