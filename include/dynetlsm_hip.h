@@ -281,8 +281,9 @@ int dlsm_hdp_get_config(dlsm_chain *h, dlsm_hdp_config *cfg);
 int dlsm_hdp_trace_alloc(dlsm_chain *h, int n_total, double logp0);
 /* enqueue iterations first .. first+count-1.  Asynchronous.
  * Undirected model: the intercept step's likelihood pass (sample_coefficients.py:76-86 inside
- * hdp_lpcm.py:855-874) runs on a second queue of the handle beside the label update and the conjugate
- * draws (hdp_lpcm.py:876-1023), which do not read its result; the queues hand over through words in
+ * hdp_lpcm.py:855-874) - and behind it the head of the next iteration's sweep, which reads positions,
+ * step sizes and the settled intercept only - runs on a second queue of the handle beside the label
+ * update and the conjugate draws (hdp_lpcm.py:876-1023), which do not read its result; the queues hand over through words in
  * device memory and are joined before the call's log-posterior pass, so the call still orders like one
  * stream.  Chosen while the handle is the process's only live chain (environment: DLSM_HDP_QUEUES=1
  * never, =2 always); the trace is bit for bit the one-queue trace.  Processes that SHARE a device
