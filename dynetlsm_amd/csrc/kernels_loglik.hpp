@@ -756,6 +756,89 @@ __device__ __forceinline__ double node_log_prior(const ChainView &c, int t, int 
     return lp;
 }
 
+// node_log_prior with its operands requested ahead of their use (the launch-per-batch resolvers: the
+// terms' loads were a round trip of their own - two with the mixture prior, label then component -
+// behind everything else the resolver had asked for).  request1: the neighbouring slices' rows, the
+// labels, the blending coefficient; request2, once the labels are in: the components' means and
+// variances; value(x): node_log_prior's arithmetic, term for term, on the operands at hand.
+template <int D>
+struct NodePriorPre {
+    double xp[D], xn[D], m[D], mn[D], st, sn, lm;
+    int zt, zn;
+    bool has_p, has_n, mixture;
+    double tau_sq, sigma_sq;
+    __device__ __forceinline__ void request1(const ChainView &c, int t, int j) {
+        const int N = c.N;
+        mixture = c.prior_kind != DLSM_PRIOR_RANDOM_WALK;
+        has_p = t > 0; has_n = t < c.T - 1;
+        tau_sq = c.tau_sq; sigma_sq = c.sigma_sq;
+        const double *rp = c.X + ((size_t)(has_p ? t - 1 : t) * N + j) * D;
+        const double *rn = c.X + ((size_t)(has_n ? t + 1 : t) * N + j) * D;
+#pragma unroll
+        for (int d = 0; d < D; ++d) { xp[d] = rp[d]; xn[d] = rn[d]; }
+        lm = 0.0; zt = 0; zn = 0;
+        if (mixture) {
+            lm = c.lmbda_p[0];
+            zt = c.z[(size_t)t * N + j];
+            zn = c.z[(size_t)(has_n ? t + 1 : t) * N + j];
+        }
+    }
+    __device__ __forceinline__ void request2(const ChainView &c) {
+        st = 1.0; sn = 1.0;
+#pragma unroll
+        for (int d = 0; d < D; ++d) { m[d] = 0.0; mn[d] = 0.0; }
+        if (mixture) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) { m[d] = c.mu[(size_t)zt * D + d]; mn[d] = c.mu[(size_t)zn * D + d]; }
+            st = c.sigma[zt]; sn = c.sigma[zn];
+        }
+    }
+    __device__ __forceinline__ double value(const double *x) const {
+        double lp = 0.0;
+        if (!mixture) {
+            double s = 0.0;
+            if (!has_p) {
+#pragma unroll
+                for (int d = 0; d < D; ++d) s += x[d] * x[d];
+                lp -= 0.5 * s / tau_sq;
+            } else {
+#pragma unroll
+                for (int d = 0; d < D; ++d) { const double df = x[d] - xp[d]; s += df * df; }
+                lp -= 0.5 * s / sigma_sq;
+            }
+            if (has_n) {
+                s = 0.0;
+#pragma unroll
+                for (int d = 0; d < D; ++d) { const double df = xn[d] - x[d]; s += df * df; }
+                lp -= 0.5 * s / sigma_sq;
+            }
+        } else {
+            double s = 0.0;
+            if (!has_p) {
+#pragma unroll
+                for (int d = 0; d < D; ++d) s += (x[d] - m[d]) * (x[d] - m[d]);
+            } else {
+#pragma unroll
+                for (int d = 0; d < D; ++d) {
+                    double df = x[d] - (1 - lm) * xp[d] - lm * m[d];
+                    s += df * df;
+                }
+            }
+            lp -= 0.5 * s / st;
+            if (has_n) {
+                s = 0.0;
+#pragma unroll
+                for (int d = 0; d < D; ++d) {
+                    double df = xn[d] - (1 - lm) * x[d] - lm * mn[d];
+                    s += df * df;
+                }
+                lp -= 0.5 * s / sn;
+            }
+        }
+        return lp;
+    }
+};
+
 // ---------------------------------------------------------------------------
 // Per-node partial log-likelihood (a1/a2/a3), the function seam used by the
 // parity tests.  Grid (N, T), 256 threads; one node per workgroup.  Written in

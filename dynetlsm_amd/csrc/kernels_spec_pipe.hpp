@@ -1221,6 +1221,7 @@ __device__ __forceinline__ void row_resolve(const ChainView &c, const PipeBuf &p
     double2 tv[4];
     double x1[D], x0[D], uk = 1.0, st = 0.0;
     int32_t na = 0, ns = 0, un = 0;
+    NodePriorPre<D> npre;
     const int kc = min(k, nb - 1);
     const int p1 = pb.parts;
     const double2 *frec = (const double2 *)pb.full0 + ((size_t)bb * c.T + t) * PP_B * pb.parts;
@@ -1238,12 +1239,14 @@ __device__ __forceinline__ void row_resolve(const ChainView &c, const PipeBuf &p
         uk = pr[D];
         const size_t tjc = (size_t)t * N + j0 + kc;
         st = c.step[tjc]; na = c.nacc[tjc]; ns = c.nsteps[tjc]; un = c.until[tjc];
+        if (!COH) npre.request1(c, t, j0 + kc);        // the prior terms' operands, with everything else
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
         double *dst = sD + (u * PP_WAVES + wave) * PR_LD + 2 * lane;
         dst[0] = blk[u].x; dst[1] = blk[u].y;
     }
+    if (owner && !COH) npre.request2(c);               // (the labels are in: the components' means and variances)
     // the window's accepted nodes among this thread's 16 factors: cr[2 u + i] belongs to node
     // 16 u + 2 jx + i -> bit 2 u + i of mp.  Multiplicative domain; a node that turns out to be
     // resolved in the log domain (below) redoes its part from memory.
@@ -1280,8 +1283,9 @@ __device__ __forceinline__ void row_resolve(const ChainView &c, const PipeBuf &p
         }
         // prior terms of the step's logp closure, the neighbouring slices as they are now (the
         // odd slices wait for the even ones: header)
-        const double prior = node_log_prior<D, COH>(c, t, j0 + kc, x1) -
-                             node_log_prior<D, COH>(c, t, j0 + kc, x0);
+        const double prior = COH ? node_log_prior<D, COH>(c, t, j0 + kc, x1) -
+                                   node_log_prior<D, COH>(c, t, j0 + kc, x0)
+                                 : npre.value(x1) - npre.value(x0);
         const double ek = tot + prior;
         sat = !(fabs(ek) <= 700.0);
         // (the table exponential: the compiler's exp() keeps a dozen float64 constants alive through
