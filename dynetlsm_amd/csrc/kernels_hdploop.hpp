@@ -475,18 +475,32 @@ __device__ __forceinline__ void hdp_mu_of(const ChainView &c, const HdpLoopBuf &
     double pk = 1.0 / hs->mvp, mk[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) mk[d] = 0.0;
-    for (int t = 0; t < T; ++t) {
-        const int cnt = hb.nk[t * K + k];
-        if (cnt <= 0) continue;
-        const double *S = hb.S + ((size_t)t * K + k) * D;
-        if (t == 0) {
-            pk += (double)cnt / sk;
+    // (eight time steps' counts and sums requested together, added in the same order)
+    constexpr int NT = 8;
+    for (int t0 = 0; t0 < T; t0 += NT) {
+        int nv[NT];
+        double sv[NT][D];
 #pragma unroll
-            for (int d = 0; d < D; ++d) mk[d] += (1.0 / sk) * S[d];
-        } else {
-            pk += (lm * lm / sk) * (double)cnt;
+        for (int u = 0; u < NT; ++u) {
+            const int t = min(t0 + u, T - 1);
+            nv[u] = t0 + u < T ? hb.nk[t * K + k] : 0;
+            const double *S = hb.S + ((size_t)t * K + k) * D;
 #pragma unroll
-            for (int d = 0; d < D; ++d) mk[d] += (lm / sk) * S[d];
+            for (int d = 0; d < D; ++d) sv[u][d] = S[d];
+        }
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {
+            const int cnt = nv[u];
+            if (cnt <= 0) continue;
+            if (t0 + u == 0) {
+                pk += (double)cnt / sk;
+#pragma unroll
+                for (int d = 0; d < D; ++d) mk[d] += (1.0 / sk) * sv[u][d];
+            } else {
+                pk += (lm * lm / sk) * (double)cnt;
+#pragma unroll
+                for (int d = 0; d < D; ++d) mk[d] += (lm / sk) * sv[u][d];
+            }
         }
     }
     pk = 1.0 / pk;
@@ -507,10 +521,23 @@ __device__ __forceinline__ double hdp_sigma_of(const ChainView &c, const HdpLoop
     const HdpRng g = hdp_rng(c, iter);
     long cnt = 0;
     double bk = 0.5 * hs->b;
-    for (int t = 0; t < T; ++t) {
-        const int ntk = hb.nk[t * K + k];
-        cnt += ntk;
-        if (ntk > 0) bk += 0.5 * hb.Q[(size_t)t * K + k];
+    // (eight time steps' counts and sums requested together - a step at a time was two dependent round
+    // trips per step on stage 3's longest chain -, added in the same order)
+    constexpr int NT = 8;
+    for (int t0 = 0; t0 < T; t0 += NT) {
+        int nv[NT];
+        double qv[NT];
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {
+            const int t = min(t0 + u, T - 1);
+            nv[u] = t0 + u < T ? hb.nk[t * K + k] : 0;
+            qv[u] = hb.Q[(size_t)t * K + k];
+        }
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {
+            cnt += nv[u];
+            if (nv[u] > 0) bk += 0.5 * qv[u];
+        }
     }
     const double ak = 0.5 * ((double)cnt * c.D + hs->a);
     return 1.0 / (hdp_gamma(g, HK_SIGMA, (uint32_t)k, ak) * (1.0 / bk));
