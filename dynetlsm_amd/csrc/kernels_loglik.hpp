@@ -647,8 +647,21 @@ __device__ __forceinline__ void reduce_records(const double *__restrict__ rec,
         const int nq = min(4, width - q0);
         double s[4] = {0.0, 0.0, 0.0, 0.0};
         if (tid < 256) {
-            // (four records per thread requested together; they are added in the same order)
+            // (twelve, then four records per thread requested together - the thread's whole share in one
+            // round trip at configs 2 to 4; they are added in the same order)
             int r = tid;
+            for (; r + 11 * 256 < nrec; r += 12 * 256) {
+                double v[12][4];
+#pragma unroll
+                for (int u = 0; u < 12; ++u)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        v[u][q] = q < nq ? rec[(size_t)(r + u * 256) * width + q0 + q] : 0.0;
+#pragma unroll
+                for (int u = 0; u < 12; ++u)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) if (q < nq) s[q] += v[u][q];
+            }
             for (; r + 3 * 256 < nrec; r += 4 * 256) {
                 double v[4][4];
 #pragma unroll
