@@ -193,7 +193,8 @@ int ll_blocks(const dlsm_chain *h) {
     if (h->model == DLSM_DIRECTED_CASE_CONTROL)
         return (int)(((long)h->T * h->N + LLCC_NODES - 1) / LLCC_NODES);
     int nt = (h->N + LL_TILE - 1) / LL_TILE;
-    return h->T * (nt * (nt + 1) / 2) * (h->model == DLSM_UNDIRECTED ? LLU_SPLIT : 1);    // row strips of a tile
+    // (undirected: two row halves per tile above the diagonal, one workgroup per diagonal tile: kernels_loglik.hpp)
+    return h->model == DLSM_UNDIRECTED ? h->T * llu_blocks_per_slice(nt) : h->T * (nt * (nt + 1) / 2);
 }
 
 int check_ready_loglik(dlsm_chain *h) {

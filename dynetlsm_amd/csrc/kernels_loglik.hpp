@@ -125,10 +125,21 @@ constexpr int LLU_SPLIT = 128 / LLU_ROWS;         // workgroups per tile
 #ifdef DLSM_PIPE_TIMING
 __device__ unsigned long long g_ll_t[8192][3];     // per wavefront: entry, exit (100 MHz), HW_ID
 #endif
+// workgroups of the undirected pass per time step: two (row halves) per tile above the diagonal, ONE per
+// diagonal tile (below) - nt (nt - 1) + nt = nt^2
+__host__ __device__ inline int llu_blocks_per_slice(int nt) { return nt * nt; }
+// Diagonal tiles.  Of a diagonal tile's four 64 x 64 blocks one is full (rows 0-63 x columns 64-127), two are
+// triangles (i < j inside rows / columns 0-63 and inside 64-127) and one is empty; as two half-tile workgroups
+// that was four wavefronts of 64 row steps each for 1.5 wavefronts of work - and 2720 workgroups at config 2,
+// 5.3 wavefronts per SIMD: some SIMDs carried six, some four, and the launch lasted as long as the sixes
+// (profiles/r04_loglik_timing.json).  Now a diagonal tile is one workgroup: wavefront 1 takes the full block,
+// wavefront 0 BOTH triangles - at row step r its lanes j > r pair row r with column j (the first triangle), its
+// lanes j < r pair row 127 - r with column 127 - j (the second one, mirrored: 127 - r < 127 - j), every lane but
+// one busy at every step.  2560 workgroups at config 2: five wavefronts on every SIMD, all of the same length.
 template <int D, int M>
-__global__ __launch_bounds__(LLU_THREADS) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_loglik_undirected(
+__global__ __launch_bounds__(LLU_THREADS) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_loglik_undirected(
     ChainView c, LoglikCand cand, double *__restrict__ partials) {
-    __shared__ double sXi[LLU_ROWS * D];
+    __shared__ double sXi[LL_TILE * D];
     __shared__ double sRed[2 * (2 + M)];
     __shared__ __attribute__((aligned(16))) double sTab[EXPTAB_N];      // tab_exp (device_common.hpp)
     const int tid = threadIdx.x;
@@ -142,14 +153,22 @@ __global__ __launch_bounds__(LLU_THREADS) __attribute__((amdgpu_waves_per_eu(6, 
     sTab[tid] = c_exp2_tab[tid];                   // visible after the staging barrier below
     sTab[tid + LLU_THREADS] = c_exp2_tab[tid + LLU_THREADS];
     const int nt = (N + LL_TILE - 1) / LL_TILE;
-    const int ntri = nt * (nt + 1) / 2;
-    const int tile = blockIdx.x / LLU_SPLIT;
-    const int t = tile / ntri;
-    int ti, tj;
-    tile_decode(tile % ntri, nt, ti, tj);
-    const int i0 = ti * LL_TILE + (blockIdx.x % LLU_SPLIT) * LLU_ROWS, j0 = tj * LL_TILE;
+    static_assert(LLU_SPLIT == 2 && LLU_ROWS == 64 && LLU_THREADS == 128, "the diagonal tiles' pairing");
+    const int per_t = llu_blocks_per_slice(nt), noff = nt * (nt - 1);     // (half tiles above the diagonal)
+    const int t = blockIdx.x / per_t, wq = blockIdx.x - t * per_t;
+    const bool diag = wq >= noff;
+    int ti, tj, half = 0;
+    if (diag) { ti = tj = wq - noff; }
+    else {                                          // the (wq / 2)-th tile with ti < tj, row-major
+        int r = wq >> 1, rowlen = nt - 1;
+        ti = 0;
+        while (r >= rowlen) { r -= rowlen; ++ti; --rowlen; }
+        tj = ti + 1 + r;
+        half = wq & 1;
+    }
+    const int i0 = ti * LL_TILE + half * LLU_ROWS, j0 = tj * LL_TILE;
     const double *Xt = c.X + (size_t)t * N * D;
-    for (int k = tid; k < LLU_ROWS * D; k += LLU_THREADS) {
+    for (int k = tid; k < (diag ? LL_TILE : LLU_ROWS) * D; k += LLU_THREADS) {
         const int gi = i0 * D + k;
         sXi[k] = gi < N * D ? Xt[gi] : 0.0;
     }
@@ -188,10 +207,22 @@ __global__ __launch_bounds__(LLU_THREADS) __attribute__((amdgpu_waves_per_eu(6, 
     const unsigned long long *ywords = c.ycm + ((size_t)t * (c.W >> 1) + (j0 >> 6) + wave) * c.Ncm + i0;
     // a half tile strictly above the diagonal with all its columns inside the network
     // needs no per-dyad validity test
-    const bool whole = i0 + LLU_ROWS <= j0 && j0 + LL_TILE <= N;
+    // (wavefront 1 of a diagonal tile - rows 0-63, columns 64-127 - is such a block too)
+    const bool whole = (i0 + LLU_ROWS <= j0 || (diag && wave == 1)) && j0 + LL_TILE <= N;
     int cnt = 0;
+    // issue priority by progress (as the sweep's items, kernels_spec_pipe.hpp): the wavefronts of a SIMD end together
+#ifdef DLSM_LLU_NOPRIO
+#define DLSM_LLU_PRIO(R_)
+#else
+#define DLSM_LLU_PRIO(R_)                                                                      \
+        if ((R_) == 0) __builtin_amdgcn_s_setprio(3);                                          \
+        else if ((R_) == LLU_ROWS / 4) __builtin_amdgcn_s_setprio(2);                          \
+        else if ((R_) == LLU_ROWS / 2) __builtin_amdgcn_s_setprio(1);                          \
+        else if ((R_) == 3 * LLU_ROWS / 4) __builtin_amdgcn_s_setprio(0);
+#endif
 #define DLSM_LLU_TRIPS(WHOLE_, SQ_)                                                            \
     for (int r = 0; r < LLU_ROWS; r += U) {                                                    \
+        DLSM_LLU_PRIO(r)                                                                       \
         unsigned long long ym[U];                                                              \
         _Pragma("unroll")                                                                      \
         for (int u = 0; u < U; ++u)                                                            \
@@ -222,10 +253,72 @@ __global__ __launch_bounds__(LLU_THREADS) __attribute__((amdgpu_waves_per_eu(6, 
             cnt = 0;                                                                           \
         }                                                                                      \
     }
-    if (c.squared) { DLSM_LLU_TRIPS(false, 1) }
+    // wavefront 0 of a diagonal tile: both triangles (header).  Lane l holds column j0 + l (xj) for the first
+    // and column j0 + 127 - l (xjb) for the mirrored second; row words: the first triangle's are this
+    // wavefront's (ywords), the second's those of column block + 1 at rows i0 + 64 .. (bit 63 - l of the
+    // word of row 127 - r = bit l of its bit reversal)
+#define DLSM_LLU_TRIPS_DIAG(SQ_)                                                               \
+    {                                                                                          \
+        const int lane_ = tid;                                                                 \
+        const int jb_ = j0 + (LL_TILE - 1) - lane_;                                            \
+        double xjb[D];                                                                         \
+        _Pragma("unroll")                                                                      \
+        for (int d = 0; d < D; ++d) xjb[d] = jb_ < N ? Xt[(size_t)jb_ * D + d] : 0.0;          \
+        const unsigned long long va_ = __ballot(j < N), vb_ = __ballot(jb_ < N);               \
+        const unsigned long long *ywb = ywords + c.Ncm + LLU_ROWS;                             \
+        for (int r = 0; r < LLU_ROWS; r += U) {                                                \
+            DLSM_LLU_PRIO(r)                                                                   \
+            unsigned long long ya[U], yb[U];                                                   \
+            _Pragma("unroll")                                                                  \
+            for (int u = 0; u < U; ++u) { ya[u] = ywords[r + u]; yb[u] = ywb[LLU_ROWS - 1 - (r + u)]; } \
+            double dd[U], e[U];                                                                \
+            unsigned long long okm[U];                                                         \
+            _Pragma("unroll")                                                                  \
+            for (int u = 0; u < U; ++u) {                                                      \
+                const int rr = r + u;                                                          \
+                const unsigned long long lo_ = (1ull << rr) - 1ull;                            \
+                const unsigned long long hi_ = rr == 63 ? 0ull : ~((2ull << rr) - 1ull);       \
+                const bool first_ = lane_ > rr;                                                \
+                const double *xi_ = sXi + (first_ ? rr : LL_TILE - 1 - rr) * D;                \
+                double xs_[D];                                                                 \
+                _Pragma("unroll")                                                              \
+                for (int d = 0; d < D; ++d) xs_[d] = first_ ? xj[d] : xjb[d];                  \
+                dd[u] = dist_fast<D>(xi_, xs_, SQ_);                                           \
+                okm[u] = (hi_ & va_) | (lo_ & vb_);                                            \
+                ya[u] = (ya[u] & hi_) | (__builtin_bitreverse64(yb[u]) & lo_);                 \
+            }                                                                                  \
+            _Pragma("unroll")                                                                  \
+            for (int u = 0; u < U; ++u)                                                        \
+                e[u] = (SQ_) ? tab_exp_clamped(-dd[u], sTab) : tab_exp(-dd[u], sTab);          \
+            _Pragma("unroll")                                                                  \
+            for (int u = 0; u < U; ++u) {                                                      \
+                const unsigned long long live = ya[u] & okm[u];                                \
+                sy += __popcll(live);                                                          \
+                syd = fma(__builtin_amdgcn_inverse_ballot_w64(live) ? 1.0 : 0.0, dd[u], syd);  \
+                if (__builtin_amdgcn_inverse_ballot_w64(okm[u])) {                             \
+                    _Pragma("unroll")                                                          \
+                    for (int k = 0; k < M; ++k) P[u][k] *= fma(E[k], e[u], 1.0);               \
+                }                                                                              \
+            }                                                                                  \
+            if (++cnt >= nflush) {                                                             \
+                _Pragma("unroll")                                                              \
+                for (int k = 0; k < M; ++k) {                                                  \
+                    _Pragma("unroll")                                                          \
+                    for (int u = 0; u < U; ++u) { S[k] += fast_log(P[u][k]); P[u][k] = 1.0; }  \
+                }                                                                              \
+                cnt = 0;                                                                       \
+            }                                                                                  \
+        }                                                                                      \
+    }
+    if (diag && wave == 0) {
+        if (c.squared) { DLSM_LLU_TRIPS_DIAG(1) } else { DLSM_LLU_TRIPS_DIAG(0) }
+    }
+    else if (c.squared) { DLSM_LLU_TRIPS(false, 1) }
     else if (whole) { DLSM_LLU_TRIPS(true, 0) }
     else { DLSM_LLU_TRIPS(false, 0) }
 #undef DLSM_LLU_TRIPS
+#undef DLSM_LLU_TRIPS_DIAG
+#undef DLSM_LLU_PRIO
     // nflush == 64: all chains together hold <= 64 factors (1 + E) <= e^(600 / 64) each
     if (nflush >= LLU_ROWS) {
 #pragma unroll
