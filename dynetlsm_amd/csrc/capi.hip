@@ -242,8 +242,9 @@ int launch_loglik_records(dlsm_chain *h, int M, const double *d_ic,
     LoglikCand cand{d_ic, {r0, r1}};
     ProfScope ps(h, DLSM_K_LOGLIK);
     if (h->model == DLSM_UNDIRECTED) {
-        if (M == 1) hipLaunchKernelGGL((k_loglik_undirected<DD, 1>), dim3(nb), dim3(LLU_THREADS), 0, h->stream, v, cand, h->partials);
-        else hipLaunchKernelGGL((k_loglik_undirected<DD, 2>), dim3(nb), dim3(LLU_THREADS), 0, h->stream, v, cand, h->partials);
+        const int prio = h->ll_beside_chain ? 0 : 1;      // (issue priority by progress, unless the chain's launches run beside)
+        if (M == 1) hipLaunchKernelGGL((k_loglik_undirected<DD, 1>), dim3(nb), dim3(LLU_THREADS), 0, h->stream, v, cand, h->partials, prio);
+        else hipLaunchKernelGGL((k_loglik_undirected<DD, 2>), dim3(nb), dim3(LLU_THREADS), 0, h->stream, v, cand, h->partials, prio);
     } else if (h->model == DLSM_DIRECTED) {
         if (M == 1) hipLaunchKernelGGL((k_loglik_directed<DD, 1>), dim3(nb), dim3(LL_THREADS), 0, h->stream, v, cand, h->partials);
         else hipLaunchKernelGGL((k_loglik_directed<DD, 2>), dim3(nb), dim3(LL_THREADS), 0, h->stream, v, cand, h->partials);

@@ -130,9 +130,9 @@ int enqueue_hdp_iteration(dlsm_chain *h, int it, bool draw_next) {
     if (fork) {
         hipLaunchKernelGGL(k_hdp_gate, dim3(1), dim3(64), 0, h->fork_stream, fk, (int)HF_CENTRED);
         hipStream_t keep = h->stream;
-        h->stream = h->fork_stream;
+        h->stream = h->fork_stream; h->ll_beside_chain = true;
         rc = loglik_records(h, 2, h->lsm->cand, nullptr, nullptr, &nrec);
-        h->stream = keep;
+        h->stream = keep; h->ll_beside_chain = false;
         if (rc) return rc;
         // ... and, when another iteration follows and its sweep is the pipelined one, the HEAD of that sweep:
         // the proposal pass and the first, evaluate-only launch need the settled intercept, the positions and

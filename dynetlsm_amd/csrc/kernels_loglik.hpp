@@ -138,7 +138,7 @@ __host__ __device__ inline int llu_blocks_per_slice(int nt) { return nt * nt; }
 // one busy at every step.  2560 workgroups at config 2: five wavefronts on every SIMD, all of the same length.
 template <int D, int M>
 __global__ __launch_bounds__(LLU_THREADS) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_loglik_undirected(
-    ChainView c, LoglikCand cand, double *__restrict__ partials) {
+    ChainView c, LoglikCand cand, double *__restrict__ partials, int prio) {
     __shared__ double sXi[LL_TILE * D];
     __shared__ double sRed[2 * (2 + M)];
     __shared__ __attribute__((aligned(16))) double sTab[EXPTAB_N];      // tab_exp (device_common.hpp)
@@ -214,11 +214,15 @@ __global__ __launch_bounds__(LLU_THREADS) __attribute__((amdgpu_waves_per_eu(5, 
 #ifdef DLSM_LLU_NOPRIO
 #define DLSM_LLU_PRIO(R_)
 #else
+    // (prio == 0: the pass stays at the default priority - the HDP-LPCM loop's second queue, where priority 3
+    // belongs to the chain's small launches beside it: capi_hdp.hpp)
 #define DLSM_LLU_PRIO(R_)                                                                      \
-        if ((R_) == 0) __builtin_amdgcn_s_setprio(3);                                          \
-        else if ((R_) == LLU_ROWS / 4) __builtin_amdgcn_s_setprio(2);                          \
-        else if ((R_) == LLU_ROWS / 2) __builtin_amdgcn_s_setprio(1);                          \
-        else if ((R_) == 3 * LLU_ROWS / 4) __builtin_amdgcn_s_setprio(0);
+        if (prio) {                                                                            \
+            if ((R_) == 0) __builtin_amdgcn_s_setprio(3);                                      \
+            else if ((R_) == LLU_ROWS / 4) __builtin_amdgcn_s_setprio(2);                      \
+            else if ((R_) == LLU_ROWS / 2) __builtin_amdgcn_s_setprio(1);                      \
+            else if ((R_) == 3 * LLU_ROWS / 4) __builtin_amdgcn_s_setprio(0);                  \
+        }
 #endif
 #define DLSM_LLU_TRIPS(WHOLE_, SQ_)                                                            \
     for (int r = 0; r < LLU_ROWS; r += U) {                                                    \
