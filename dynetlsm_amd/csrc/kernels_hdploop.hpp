@@ -800,13 +800,14 @@ __global__ __launch_bounds__(HH_THREADS) void k_hdp_hypers(ChainView c, HdpLoopB
 
 // intercept step (sample_coefficients.py:76-86 around the fused two-candidate pass whose records
 // are in `partials`): one workgroup; nothing inside the iteration reads its results
+template <int NF = 12>
 __device__ __forceinline__ void hdp_intercept_wg(const double *__restrict__ partials, int nrec,
                                                  LsmDeviceState *lsm, HdpDeviceState *hs,
                                                  double *__restrict__ intercept,
                                                  double *__restrict__ trace_ic, int it) {
     __shared__ double scratch[4 * 256];
     __shared__ double sums[4];
-    reduce_records(partials, nrec, 4, sums, scratch, threadIdx.x);
+    reduce_records<NF>(partials, nrec, 4, sums, scratch, threadIdx.x);
     if (threadIdx.x == 0) {
         const double b0 = lsm->cand[0], b1 = lsm->cand[1];
         const double ll0 = b0 * sums[0] - sums[1] - sums[2];
@@ -881,7 +882,7 @@ __global__ __launch_bounds__(HDP_THREADS) void k_hdp_stage1(ChainView c, HdpLoop
     const int n_tab = T * hdp_tab_groups(K);
     if ((int)blockIdx.x < n_tab) { hdp_counts_tables_wg(c, hb, hs, ir.get(), blockIdx.x, sHist, trace_row); return; }
     if ((int)blockIdx.x == n_tab + K * T) {
-        hdp_intercept_wg(partials, nrec, lsm, hs, intercept, trace_ic, (int)ir.get());
+        hdp_intercept_wg<4>(partials, nrec, lsm, hs, intercept, trace_ic, (int)ir.get());
         return;
     }
     const int q = (int)blockIdx.x - n_tab, k = q % K, t = q / K;

@@ -735,6 +735,9 @@ __global__ __launch_bounds__(256) void k_loglik_casecontrol_pf(
 
 // Deterministic final reduction of `nrec` records of `width` doubles: one
 // workgroup, fixed strided order + fixed tree.  out[q] = sum_r rec[r][q].
+// NF: records a thread has in flight at a time (12: its whole share in one round trip at configs 2 to 4; 4 where
+// the registers matter more - stage 1 of the HDP-LPCM loop, whose other roles run beside the likelihood pass)
+template <int NF = 12>
 __device__ __forceinline__ void reduce_records(const double *__restrict__ rec,
                                                int nrec, int width, double *sums,
                                                double *scratch /*4 * 256*/, int tid) {
@@ -747,15 +750,15 @@ __device__ __forceinline__ void reduce_records(const double *__restrict__ rec,
             // (twelve, then four records per thread requested together - the thread's whole share in one
             // round trip at configs 2 to 4; they are added in the same order)
             int r = tid;
-            for (; r + 11 * 256 < nrec; r += 12 * 256) {
-                double v[12][4];
+            for (; NF > 4 && r + (NF - 1) * 256 < nrec; r += NF * 256) {
+                double v[NF][4];
 #pragma unroll
-                for (int u = 0; u < 12; ++u)
+                for (int u = 0; u < NF; ++u)
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
                         v[u][q] = q < nq ? rec[(size_t)(r + u * 256) * width + q0 + q] : 0.0;
 #pragma unroll
-                for (int u = 0; u < 12; ++u)
+                for (int u = 0; u < NF; ++u)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) if (q < nq) s[q] += v[u][q];
             }
