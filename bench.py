@@ -112,14 +112,6 @@ def parse(argv=None):
     ap.add_argument('--chains-per-gpu', type=int, default=1,
                     help='independent chains per GPU, each on its own handle and stream, '
                          'enqueued by its own host thread (aggregate throughput)')
-    ap.add_argument('--share-launches', type=int, default=0, choices=[0, 1],
-                    help='with --chains-per-gpu C > 1: 1 = the undirected LSM chains of a GPU run as ONE '
-                         'batch through shared launches (dlsm_batch_*: the chains\' resolver workgroups '
-                         'side by side, one pool of evaluator items, launch floors paid once); 0 (default) '
-                         '= one stream and host thread per chain.  Measured on MI355X (profiles/'
-                         'r04_chains_per_gpu.jsonl): streams 5324 / 5664 it/s at C = 2 / 4, shared launches '
-                         '4680 / 5411 / 5793 at C = 2 / 4 / 8 - both sit on the evaluators\' float64 issue '
-                         'rate (15 items per SIMD and launch at C = 4), which sharing a launch does not change')
     ap.add_argument('--algo', type=int, default=0, help='sweep algorithm (0 auto)')
     ap.add_argument('--profile-steps', type=int, default=100,
                     help='iterations of the per-kernel event phase that precedes the warm-up steps '
@@ -227,21 +219,10 @@ class LsmWorkload(object):
                              n_iter_procrustes=0, sweep_algo=args.algo)
             ch.trace_alloc(1 + W + K + P + args.settle_steps, logp0=0.0)
         self.next_it = 1
-        self.batch = None
-
-    def _join_batch(self):
-        # (after the single-chain profile phase: the chains of this GPU through shared launches)
-        if self.batch is None and len(self.chains) > 1 and self.args.share_launches:
-            from dynetlsm_amd import ChainBatch
-            self.batch = ChainBatch(self.chains)
 
     def run(self, count):
         it = self.next_it
-        self._join_batch()
-        if self.batch is not None:
-            self.batch.lsm_run(it, count, procrustes_ref=0)
-        else:
-            in_threads([(lambda ch=ch: ch.lsm_run(it, count, procrustes_ref=0)) for ch in self.chains])
+        in_threads([(lambda ch=ch: ch.lsm_run(it, count, procrustes_ref=0)) for ch in self.chains])
         self.next_it += count
 
     def synchronize(self):
@@ -323,8 +304,6 @@ class LsmWorkload(object):
         return cpu
 
     def close(self):
-        if self.batch is not None:
-            self.batch.close()
         for ch in self.chains:
             ch.close()
 
@@ -1002,7 +981,6 @@ def run_rank(args):
                     'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
                     'config': {'workload': wl.workload(), 'density': round(wl.density, 4),
                                'chains': world * C, 'chains_per_gpu': C,
-                               'chains_share_launches': bool(getattr(wl, 'batch', None) is not None),
                                'sweep_algo': (wl.model.chain_ if name == 'hdp' else wl.chain)
                                .resolve_sweep_algo(args.algo),
                                'mh_acceptance_rate': round(acc, 3),

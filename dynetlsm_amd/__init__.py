@@ -5,7 +5,7 @@ Importing the package does not touch the GPU; the HIP library is loaded on
 first use and there is no CPU fallback (``dynetlsm_amd._lib.load`` raises when
 ``libdynetlsm_hip.so`` has not been built).
 """
-from .engine import Chain, ChainBatch, SamplerGrid, EngineError  # noqa
+from .engine import Chain, SamplerGrid, EngineError  # noqa
 from . import network_likelihoods  # noqa
 from .lsm import DynamicNetworkLSM  # noqa
 from .hdp_lpcm import DynamicNetworkHDPLPCM  # noqa
@@ -14,6 +14,6 @@ from .case_control import DirectedCaseControlSampler  # noqa
 from . import metrics  # noqa
 
 __version__ = '0.1.0'
-__all__ = ['Chain', 'ChainBatch', 'SamplerGrid', 'EngineError', 'network_likelihoods',
+__all__ = ['Chain', 'SamplerGrid', 'EngineError', 'network_likelihoods',
            'DynamicNetworkLSM', 'DynamicNetworkHDPLPCM', 'DynamicNetworkLPCM',
            'DirectedCaseControlSampler']

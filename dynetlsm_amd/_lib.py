@@ -162,12 +162,6 @@ SIGNATURES = {
     'dlsm_profile_read_eval_stamps': (C.c_int, [handle_t, c_double_p, C.POINTER(C.c_int)]),
     'dlsm_timer_start': (C.c_int, [handle_t]),
     'dlsm_timer_stop': (C.c_int, [handle_t, c_double_p]),
-    'dlsm_batch_create': (C.c_int, [C.POINTER(handle_t), C.c_int, C.POINTER(handle_t)]),
-    'dlsm_batch_destroy': (None, [handle_t]),
-    'dlsm_batch_lsm_run': (C.c_int, [handle_t, C.c_int, C.c_int, C.c_int]),
-    'dlsm_batch_synchronize': (C.c_int, [handle_t]),
-    'dlsm_batch_stats': (C.c_int, [handle_t, c_i64_p, c_i64_p]),
-    'dlsm_batch_last_error': (C.c_char_p, [handle_t]),
 }
 
 _LIB = None

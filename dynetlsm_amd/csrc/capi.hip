@@ -22,13 +22,11 @@
 #include "kernels_spec.hpp"
 #include "kernels_spec_sweep.hpp"
 #include "kernels_spec_pipe.hpp"
-#include "kernels_pipe_persist.hpp"
 #include "kernels_tail_propose.hpp"
 #include "kernels_ccpipe.hpp"
 #include "kernels_init.hpp"
 #include "kernels_post.hpp"
 #include "kernels_forecast.hpp"
-#include "kernels_batch.hpp"
 #include "host_draws.hpp"
 
 using namespace dlsm;
@@ -71,7 +69,6 @@ static std::atomic<int> g_live_chains{0};       // handles alive in this process
 // them drops the graph (it is rebuilt by the next dlsm_lsm_run).
 static int check_pipe_err(dlsm_chain *h);
 static int check_sweep_algo(dlsm_chain *h, int algo);
-static void batch_forget(dlsm_chain *h);
 static int build_colmajor(dlsm_chain *h);
 
 static void drop_graph(dlsm_chain *h) {
@@ -371,10 +368,6 @@ void dlsm_destroy(dlsm_chain *h) {
     if (!h) return;
     hipSetDevice(h->device);
     if (h->stream) hipStreamSynchronize(h->stream);
-    if (h->batch) {                 // still in a batch: its stream is the batch's, not this chain's to destroy
-        batch_forget(h);
-        h->stream = h->own_stream; h->own_stream = nullptr; h->batch = nullptr;
-    }
     drain_profile(h);
     void *ptrs[] = {h->ycm, h->ybits, h->ytbits, h->in_edges, h->out_edges, h->degree,
                     h->ctrl_in, h->ctrl_out, h->X, h->intercept, h->radii,
@@ -383,7 +376,7 @@ void dlsm_destroy(dlsm_chain *h) {
                     h->lab_nk, h->lab_w, h->spec, h->nctrl, h->stamps, h->lsm, h->trace_X, h->trace_ic,
                     h->trace_logp, h->hops, h->hops_max, h->pipe, h->post_zt, h->post_cooc,
                     h->trace_radii, h->hdp, h->hdp_buf, h->htr_mu, h->htr_sigma, h->htr_beta,
-                    h->htr_w, h->htr_lambda, h->htr_hyper, h->htr_z, h->xr, h->pipe_err};
+                    h->htr_w, h->htr_lambda, h->htr_hyper, h->htr_z, h->xr};
     for (void *p : ptrs) if (p) hipFree(p);
     if (h->hsmall) hipHostFree(h->hsmall);
     if (h->timer0) hipEventDestroy(h->timer0);
@@ -995,7 +988,7 @@ static void launch_pipe_step(dlsm_chain *h, const ChainView &v, const PipeBuf &p
     if (h->profiling) h->prof[DLSM_K_SWEEP_EVAL].pending.emplace_back(e0, e1);
 }
 
-// the sticky error word of the persistent sweep (algo 7): a bounded wait ran out of its budget
+// the sticky error word of the HDP-LPCM loop's two queues: a bounded wait ran out of its budget
 static int check_pipe_err(dlsm_chain *h) {
     if (h->fork_flags && h->fork_ticket > 0) {      // the HDP loop's two queues (kernels_hdploop.hpp, HdpFork)
         int32_t e = 0;
@@ -1008,39 +1001,14 @@ static int check_pipe_err(dlsm_chain *h) {
                  "queues?); set the state again and run with DLSM_HDP_QUEUES=1", e);
         }
     }
-    if (!h->pipe_err || !h->pipe_err_armed) return DLSM_OK;
-    int32_t e = 0;
-    HIPCHK(h, hipMemcpy(&e, h->pipe_err, sizeof(e), hipMemcpyDeviceToHost));
-    if (e != 0) {
-        // reported ONCE: the word is cleared on the handle's own stream (a non-blocking stream
-        // does not order against the null stream) and disarmed, so that a caller who re-uploads
-        // the state and switches to sweep_algo 4 - what the message recommends - can go on with
-        // this handle
-        HIPCHK(h, hipMemsetAsync(h->pipe_err, 0, 64, h->stream));
-        HIPCHK(h, hipStreamSynchronize(h->stream));
-        h->pipe_err_armed = false;
-        FAIL(h, DLSM_E_HIP, "persistent sweep (algo 7): a wait inside the launch ran out of its poll "
-             "budget - the chain's state is undefined (device shared with a long-running kernel?); "
-             "set the state again and use sweep_algo 4");
-    }
     return DLSM_OK;
 }
 
-// algo 7: the whole sweep in one launch (kernels_pipe_persist.hpp); shares algo 4's buffers
-template <int DD, int MODEL>
-static void launch_pipe_persist(dlsm_chain *h, const ChainView &v, const PipeBuf &pb,
-                                const PipeSync &ps, int grid, size_t lds) {
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (h->profiling) { hipEventCreate(&e0); hipEventCreate(&e1); }
-    hipExtLaunchKernelGGL((k_pipe_persist<DD, MODEL>), dim3(grid), dim3(PP_THREADS), lds, h->stream,
-                          e0, e1, 0, v, pb, ps);
-    if (h->profiling) h->prof[DLSM_K_SWEEP_EVAL].pending.emplace_back(e0, e1);
-}
-
-// G = batches resolved (and evaluated) per launch: algo 4: 1, algo 6: 2; persist: algo 7 (G = 1)
+// one batch resolved (and one evaluated) per launch (the kernels' template parameter G = 1: the two-batch
+// form, algo 6, and the single persistent launch, algo 7, measured slower and were removed in round 5)
 template <int DD>
-static int launch_sweep_pipe(dlsm_chain *h, IterRef iter, bool alloc_only = false, int G = 1,
-                             bool persist = false, PipeBuf *pb_out = nullptr) {
+static int launch_sweep_pipe(dlsm_chain *h, IterRef iter, bool alloc_only = false) {
+    constexpr int G = 1;
     const int N = h->N, T = h->T;
     const int nbat = (N + PP_B - 1) / PP_B;
     const bool cc = h->model == DLSM_DIRECTED_CASE_CONTROL;
@@ -1054,24 +1022,12 @@ static int launch_sweep_pipe(dlsm_chain *h, IterRef iter, bool alloc_only = fals
     }
     auto even2 = [](size_t n) { return (n + 1) / 2 * 2; };
     const size_t n_prop = even2((size_t)T * N * (2 * DD + 2));
-    if (cc) G = 1;      // its correction columns are sized for a window of one batch
     const int xr = (2 * G - 1) * PP_B;
     const size_t n_full0 = (size_t)2 * G * T * PP_B * parts * 2;
     const size_t n_h = (size_t)2 * G * T * PP_B * PP_B;
     const size_t n_hx = (size_t)2 * G * T * xr * PP_B;
     const size_t n_acc = even2(((size_t)T * 2 * G * PP_ACC + 1) / 2);   // int32 pairs
-    // persistent form: ticket counter, resolved[t], done[t][b], one 64-byte line each
-    const int n_sync = persist ? 1 + T + T * nbat : 0;
-    const size_t n_syncd = (size_t)n_sync * PS_STRIDE * sizeof(int32_t) / sizeof(double);
-    const size_t need = (n_prop + n_full0 + n_h + n_hx + n_acc + 2 + n_syncd) * sizeof(double);
-    if (persist) {
-        NEED(h, !cc, "algo 7 is for the exact likelihoods");
-        NEED(h, T + 1 <= h->n_cu, "algo 7 needs a compute unit per slice and one to evaluate");
-        if (!h->pipe_err) {
-            HIPCHK(h, hipMalloc((void **)&h->pipe_err, 64));
-            HIPCHK(h, hipMemset(h->pipe_err, 0, 64));
-        }
-    }
+    const size_t need = (n_prop + n_full0 + n_h + n_hx + n_acc + 2) * sizeof(double);
     if (h->pipe_cap < need) {
         if (h->pipe) hipFree(h->pipe);
         h->pipe = nullptr; h->pipe_cap = 0;
@@ -1082,38 +1038,18 @@ static int launch_sweep_pipe(dlsm_chain *h, IterRef iter, bool alloc_only = fals
     pb.prop = h->pipe; pb.full0 = pb.prop + n_prop; pb.Hd = pb.full0 + n_full0;
     pb.Hx = pb.Hd + n_h; pb.acc = (int32_t *)(pb.Hx + n_hx);
     pb.consts = pb.Hx + n_hx + n_acc;
-    pb.sync = persist ? (int32_t *)(pb.consts + 2) : nullptr;
-    pb.nsync = n_sync; pb.queue0 = ne_wg;
+    pb.sync = nullptr; pb.nsync = 0; pb.queue0 = ne_wg;
     pb.lsm_draw = h->loop_draws_intercept ? h->lsm : nullptr;
     pb.parts = parts; pb.nbat = nbat;
     pb.G = G; pb.xr = xr;
     pb.per = ((N + parts - 1) / parts + 63) / 64 * 64;      // parts start on a 64-neighbour boundary
     pb.nctrl = h->nctrl;
     // the resolvers' diagonal block by rows of PR_LD (an odd stride: row_resolve), the evaluators' exp table
-    // (and, persistent form, their staged neighbour rows)
     const size_t lds = (size_t)PP_B * PR_LD * sizeof(double);
-    const size_t lds_persist = lds;
-    if (persist && ((size_t)EXPTAB11_N + (size_t)pb.per * DD) * sizeof(double) > lds_persist)
-        FAIL(h, DLSM_E_LIMIT, "algo 7: a part of %d neighbours does not fit the evaluators' LDS", pb.per);
     auto ku = k_pipe_step<DD, DLSM_UNDIRECTED>;
     auto kl = k_pipe_step<DD, PIPE_UNDIRECTED_LONG>;
     auto kd = k_pipe_step<DD, DLSM_DIRECTED>;
     auto kc = k_pipe_step<DD, DLSM_DIRECTED_CASE_CONTROL>;
-    auto ku2 = k_pipe_step<DD, DLSM_UNDIRECTED, 2>;
-    auto kl2 = k_pipe_step<DD, PIPE_UNDIRECTED_LONG, 2>;
-    auto kd2 = k_pipe_step<DD, DLSM_DIRECTED, 2>;
-    auto pu = k_pipe_persist<DD, DLSM_UNDIRECTED>;
-    auto pd = k_pipe_persist<DD, DLSM_DIRECTED>;
-    HIPCHK(h, hipFuncSetAttribute((const void *)pu, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds_persist));
-    HIPCHK(h, hipFuncSetAttribute((const void *)pd, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds_persist));
-    HIPCHK(h, hipFuncSetAttribute((const void *)ku2, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds));
-    HIPCHK(h, hipFuncSetAttribute((const void *)kl2, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds));
-    HIPCHK(h, hipFuncSetAttribute((const void *)kd2, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds));
     HIPCHK(h, hipFuncSetAttribute((const void *)ku, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds));
     HIPCHK(h, hipFuncSetAttribute((const void *)kl, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1124,7 +1060,6 @@ static int launch_sweep_pipe(dlsm_chain *h, IterRef iter, bool alloc_only = fals
                                   (int)lds));
     HIPCHK(h, hipFuncSetAttribute((const void *)k_pipe_last_ride<DD>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    if (pb_out) { *pb_out = pb; return DLSM_OK; }      // (the batch form launches its own kernels)
     if (alloc_only) return DLSM_OK;
     ChainView v = h->view();
     {   // the proposal pass, unless the previous iteration's last launch carried it
@@ -1136,19 +1071,6 @@ static int launch_sweep_pipe(dlsm_chain *h, IterRef iter, bool alloc_only = fals
             hipLaunchKernelGGL((k_pipe_propose<DD>), dim3((N + 255) / 256, T), dim3(256), 0, h->stream, v,
                                pb, iter);
         h->next_prop = nb; h->next_prop_ok = true; h->prop_drawn_for = -1; h->pipe_touched = true;
-    }
-    if (persist) {
-        PipeSync ps;
-        ps.words = pb.sync; ps.err = h->pipe_err;
-        ps.spin_budget = getenv("DLSM_PERSIST_BUDGET") ? atoi(getenv("DLSM_PERSIST_BUDGET")) : (1 << 20);
-        const int grid = T + ne_wg;
-        if (h->model == DLSM_UNDIRECTED)
-            launch_pipe_persist<DD, DLSM_UNDIRECTED>(h, v, pb, ps, grid, lds_persist);
-        else
-            launch_pipe_persist<DD, DLSM_DIRECTED>(h, v, pb, ps, grid, lds_persist);
-        h->pipe_err_armed = true;
-        HIPCHK(h, hipGetLastError());
-        return DLSM_OK;
     }
     // launch l: even slices resolve batches G l .. / evaluate G (l + 1) .., odd slices one launch
     // behind; with a single slice (T == 1) the trailing odd-only launch is empty
@@ -1175,16 +1097,10 @@ static int launch_sweep_pipe(dlsm_chain *h, IterRef iter, bool alloc_only = fals
             h->post_ride_done = true; h->post_ride_nwg = nwg + T; h->post_ride_jl = pr.jl; h->post_ride_par = pr.par;
             continue;
         }
-        if (h->model == DLSM_UNDIRECTED && lng && G == 2)
-            launch_pipe_step<DD, PIPE_UNDIRECTED_LONG, 2>(h, v, pb, grid, lds, l);
-        else if (h->model == DLSM_UNDIRECTED && lng)
+        if (h->model == DLSM_UNDIRECTED && lng)
             launch_pipe_step<DD, PIPE_UNDIRECTED_LONG>(h, v, pb, grid, lds, l);
-        else if (h->model == DLSM_UNDIRECTED && G == 2)
-            launch_pipe_step<DD, DLSM_UNDIRECTED, 2>(h, v, pb, grid, lds, l);
         else if (h->model == DLSM_UNDIRECTED)
             launch_pipe_step<DD, DLSM_UNDIRECTED>(h, v, pb, grid, lds, l);
-        else if (h->model == DLSM_DIRECTED && G == 2)
-            launch_pipe_step<DD, DLSM_DIRECTED, 2>(h, v, pb, grid, lds, l);
         else if (h->model == DLSM_DIRECTED)
             launch_pipe_step<DD, DLSM_DIRECTED>(h, v, pb, grid, lds, l);
         else
@@ -1297,8 +1213,6 @@ static int launch_sweep(dlsm_chain *h, IterRef iter, int algo, bool alloc_only =
     }
     algo = resolve_sweep_algo(h, algo);
     if (algo == 4) return launch_sweep_pipe<DD>(h, iter, alloc_only);
-    if (algo == 6) return launch_sweep_pipe<DD>(h, iter, alloc_only, 2);
-    if (algo == 7) return launch_sweep_pipe<DD>(h, iter, alloc_only, 1, true);
     if (algo == 2) return launch_sweep_spec<DD>(h, iter, 1, alloc_only);
     if (algo == 3)
         return launch_sweep_spec<DD>(h, iter, getenv("DLSM_SPEC_S") ? atoi(getenv("DLSM_SPEC_S")) : 2,
@@ -1332,10 +1246,8 @@ static int launch_sweep(dlsm_chain *h, IterRef iter, int algo, bool alloc_only =
 
 // the sweep algorithms a caller may name (dlsm_sweep_positions, the loops' configurations)
 static int check_sweep_algo(dlsm_chain *h, int algo) {
-    NEED(h, algo >= 0 && algo <= 7, "algo must be 0..7");
+    NEED(h, algo >= 0 && algo <= 5, "algo must be 0..5 (6 and 7, measured slower than 4, were removed in round 5)");
     NEED(h, algo != 5 || h->model == DLSM_DIRECTED_CASE_CONTROL, "algo 5 is the case-control sweep");
-    NEED(h, (algo != 6 && algo != 7) || h->model != DLSM_DIRECTED_CASE_CONTROL,
-         "algo 6 and 7 are for the exact likelihoods");
     return DLSM_OK;
 }
 
@@ -2007,7 +1919,6 @@ int dlsm_timer_stop(dlsm_chain *h, double *ms) {
 #include "capi_post.hpp"
 #include "capi_forecast.hpp"
 #include "capi_hdp.hpp"
-#include "capi_batch.hpp"
 
 extern "C" int dlsm_host_sample_tables(void *numpy_bitgen, int T, int K, const double *n,
                                        const double *beta, double alpha_init, double alpha,
@@ -2022,12 +1933,6 @@ extern "C" int dlsm_debug_pipe_timing(unsigned long long *items, unsigned long l
     if (hipDeviceSynchronize() != hipSuccess) return -1;
     if (hipMemcpyFromSymbol(items, HIP_SYMBOL(dlsm::g_pipe_item_t), sizeof(dlsm::g_pipe_item_t)) != hipSuccess) return -2;
     if (hipMemcpyFromSymbol(res, HIP_SYMBOL(dlsm::g_pipe_res_t), sizeof(dlsm::g_pipe_res_t)) != hipSuccess) return -3;
-    return 0;
-}
-extern "C" int dlsm_debug_persist_timing(unsigned long long *res, unsigned long long *ev) {
-    if (hipDeviceSynchronize() != hipSuccess) return -1;
-    if (hipMemcpyFromSymbol(res, HIP_SYMBOL(dlsm::g_persist_res_t), sizeof(dlsm::g_persist_res_t)) != hipSuccess) return -2;
-    if (hipMemcpyFromSymbol(ev, HIP_SYMBOL(dlsm::g_persist_ev_t), sizeof(dlsm::g_persist_ev_t)) != hipSuccess) return -3;
     return 0;
 }
 extern "C" int dlsm_debug_ccpipe_timing(unsigned long long *res, unsigned long long *items) {

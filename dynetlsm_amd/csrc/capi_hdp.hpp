@@ -225,7 +225,7 @@ int hdp_fork_arm(dlsm_chain *h) {
     const char *e = getenv("DLSM_HDP_QUEUES");
     const int mode = e ? atoi(e) : 0;
     h->fork_armed = false;
-    if (mode == 1 || h->model != DLSM_UNDIRECTED || h->profiling || h->batch || !labels_mfma_path(h)) return DLSM_OK;
+    if (mode == 1 || h->model != DLSM_UNDIRECTED || h->profiling || !labels_mfma_path(h)) return DLSM_OK;
     if (mode != 2 && g_live_chains.load() != 1) return DLSM_OK;
     if (!h->fork_stream) {
         int lo = 0, hi = 0;                        // (numerically greatest = lowest priority: the pass

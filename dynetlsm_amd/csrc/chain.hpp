@@ -98,8 +98,6 @@ struct dlsm_chain {
     uint64_t seed = 0; uint32_t chain = 0;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;          // second queue of the speculative sweep
-    // member of a dlsm_batch: `stream` is the batch's shared stream, the chain's own is parked here
-    hipStream_t own_stream = nullptr; void *batch = nullptr;
     void *stage = nullptr;                  // pinned host staging for the small copies of the C-ABI
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
     // HDP-LPCM loop, undirected: the intercept's likelihood pass on a queue of its own beside the label
@@ -158,7 +156,6 @@ struct dlsm_chain {
     const double *post_ride_xref = nullptr;
     int post_ride_jl = -1, post_ride_par = 0, post_ride_nwg = 0;
     dlsm::ProposeBuf next_prop{}; bool next_prop_ok = false, pipe_touched = false; long prop_drawn_for = -1;
-    int32_t *pipe_err = nullptr; bool pipe_err_armed = false;   // persistent sweep (algo 7): sticky error word
     int n_cu = 256;
     int32_t *nctrl = nullptr; size_t nctrl_cap = 0;     // valid controls per (t, i, dir)
     bool nctrl_valid = false;

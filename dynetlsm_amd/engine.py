@@ -11,7 +11,7 @@ from . import _lib
 from ._lib import (EngineError, LsmConfig, HdpConfig, c_double_p, c_i32_p, c_i64_p,
                    UNDIRECTED, DIRECTED, DIRECTED_CASE_CONTROL)
 
-__all__ = ['Chain', 'ChainBatch', 'SamplerGrid', 'EngineError', 'MAX_FEATURES', 'check_n_features']
+__all__ = ['Chain', 'SamplerGrid', 'EngineError', 'MAX_FEATURES', 'check_n_features']
 
 # The kernels take the latent dimension as a template parameter, instantiated for 1..4 (the
 # reference takes any n_features, lsm.py:235,254; its examples and the paper use 2).
@@ -695,62 +695,3 @@ class Chain(object):
         ms = C.c_double(0.0)
         self._ck(self._L.dlsm_timer_stop(self._h, C.byref(ms)))
         return ms.value
-
-
-class ChainBatch(object):
-    """Several chains of ONE network on one GPU driven through shared launches
-    (``dlsm_batch_*``, csrc/kernels_batch.hpp): the reference refits seeds one after the other
-    (examples/homogeneous_simulation.py:177-184); here up to 8 undirected chains share every
-    launch of the pipelined sweep.  The chains stay ordinary ``Chain`` objects - state,
-    configuration, trace and Philox chain id of their own - and ``lsm_run`` does for all of
-    them what ``Chain.lsm_run`` does for one, with bit for bit the same traces.
-
-    Close the batch before its chains (``with ChainBatch(chains) as b: ...``)."""
-
-    MAX_CHAINS = 8
-
-    def __init__(self, chains):
-        self._L = _lib.load()
-        self.chains = list(chains)
-        arr = (_lib.handle_t * len(self.chains))(*[c._h for c in self.chains])
-        self._h = _lib.handle_t()
-        rc = self._L.dlsm_batch_create(arr, len(self.chains), C.byref(self._h))
-        if rc != 0:
-            msg = self._L.dlsm_batch_last_error(None)
-            self._h = None
-            raise EngineError(rc, msg.decode() if msg else 'dlsm_batch_create failed')
-
-    def _ck(self, rc):
-        if rc != 0:
-            msg = self._L.dlsm_batch_last_error(self._h)
-            raise EngineError(rc, msg.decode() if msg else '?')
-
-    def lsm_run(self, first, count, procrustes_ref=-1):
-        """iterations first .. first + count - 1 of every chain (asynchronous)"""
-        self._ck(self._L.dlsm_batch_lsm_run(self._h, int(first), int(count), int(procrustes_ref)))
-
-    def synchronize(self):
-        self._ck(self._L.dlsm_batch_synchronize(self._h))
-
-    def stats(self):
-        """(iterations run through shared launches, iterations run chain by chain)"""
-        m, s = np.zeros(1, dtype=np.int64), np.zeros(1, dtype=np.int64)
-        self._ck(self._L.dlsm_batch_stats(self._h, _p(m), _p(s)))
-        return int(m[0]), int(s[0])
-
-    def close(self):
-        if getattr(self, '_h', None):
-            self._L.dlsm_batch_destroy(self._h)
-            self._h = None
-
-    def __del__(self):
-        try:
-            self.close()
-        except Exception:       # noqa: BLE001
-            pass
-
-    def __enter__(self):
-        return self
-
-    def __exit__(self, *a):
-        self.close()

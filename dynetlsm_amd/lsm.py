@@ -87,7 +87,7 @@ class DynamicNetworkLSM(FittedQuantities):
 
     Constructor parameters are the reference's (lsm.py:234-268) plus
     ``device`` (GPU index), ``chain_id`` (Philox stream of this chain) and
-    ``sweep_algo`` (0 auto; 1 .. 7 as ``dlsm_sweep_positions`` in include/dynetlsm_hip.h)."""
+    ``sweep_algo`` (0 auto; 1 .. 5 as ``dlsm_sweep_positions`` in include/dynetlsm_hip.h)."""
 
     def __init__(self, n_features=2, is_directed=False, n_iter=5000, tune=2500,
                  tune_interval=100, burn=2500, intercept_prior='auto',

@@ -201,6 +201,34 @@ def split_rhat(chains):
     return float(np.sqrt(((n - 1.0) / n * W + B / n) / W))
 
 
+def visible_gpu_count():
+    """GPUs this process would see, counted WITHOUT a HIP / HSA call (the parent of
+    ``launch_ranks`` must not initialise the runtime its children are about to use:
+    ``torch.cuda.device_count()`` falls back to hipGetDeviceCount when amdsmi is absent): the
+    kernel driver's topology nodes with SIMDs, cut by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES /
+    CUDA_VISIBLE_DEVICES when one of them is set."""
+    n = 0
+    root = '/sys/class/kfd/kfd/topology/nodes'
+    try:
+        for node in sorted(os.listdir(root)):
+            try:
+                with open(os.path.join(root, node, 'properties')) as f:
+                    props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+            except OSError:
+                continue
+            if int(props.get('simd_count', '0')) > 0:
+                n += 1
+    except OSError:
+        n = 0
+    for var in ('HIP_VISIBLE_DEVICES', 'ROCR_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
+        v = os.environ.get(var)
+        if v is not None:
+            ids = [x for x in v.split(',') if x.strip() != '']
+            n = min(n, len(ids)) if n else len(ids)
+            break
+    return n
+
+
 def _free_port():
     sk = socket.socket()
     sk.bind(('127.0.0.1', 0))
@@ -209,13 +237,16 @@ def _free_port():
     return port
 
 
-def launch_ranks(argv, n, env_extra=None, relay_rank0=True, local_ranks=None):
+def launch_ranks(argv, n, env_extra=None, relay_rank0=True, local_ranks=None, timeout=None):
     """Start ``argv`` n times as child processes with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*
     set (one rank per GPU) and wait for them: the caller makes no GPU call, so nothing is
     inherited.  Rank 0 inherits stdout when ``relay_rank0`` (its output is the job's), the
     others' goes to stderr.  When a rank fails the others are terminated - exactly the PIDs
-    started here - and the first non-zero exit code is returned."""
+    started here - and the first non-zero exit code is returned.  ``timeout`` (seconds): ranks
+    still alive after it are terminated, then killed, and 124 is returned (a rank wedged in a
+    collective must not hold the caller for ever)."""
     port = _free_port()
+    deadline = None if timeout is None else time.monotonic() + float(timeout)
     procs = []
     for r in range(n):
         lr = r if local_ranks is None else local_ranks[r]
@@ -245,6 +276,19 @@ def launch_ranks(argv, n, env_extra=None, relay_rank0=True, local_ranks=None):
                 print('rank %d exited with %d; stopping the others' % (r, code), file=sys.stderr)
                 for q in alive:
                     procs[q].terminate()
+        if alive and deadline is not None and time.monotonic() > deadline:
+            print('launch_ranks: %d rank(s) still running after %.0f s; stopping them'
+                  % (len(alive), float(timeout)), file=sys.stderr)
+            for q in alive:
+                procs[q].terminate()
+            t_kill = time.monotonic() + 5.0
+            while any(procs[q].poll() is None for q in alive) and time.monotonic() < t_kill:
+                time.sleep(0.05)
+            for q in alive:
+                if procs[q].poll() is None:
+                    procs[q].kill()
+                procs[q].wait()
+            return rc or 124
         time.sleep(0.05)
     return rc
 
@@ -301,6 +345,16 @@ def _chain_results(est, seconds):
     return out
 
 
+def _kept_from(est):
+    """index of the first kept row of the estimator's STORED traces: ``n_burn_`` counts
+    iterations, a thinned estimator stores every ``thin``-th of them (hdp_lpcm.py:1072-1083 thins
+    the traces, :1085 on then works with n_burn // thin - as ``_finish`` and forecast.py do)"""
+    n_burn = int(getattr(est, 'n_burn_', 0) or 0)
+    thin = int(getattr(est, 'thin', None) or 1)
+    n_rows = int(np.asarray(est.logps_).shape[0])
+    return max(0, min(n_burn // thin, n_rows - 1))
+
+
 def _fit_as_rank(estimator, Y, init, group, seed_stride=1):
     """this rank's part of ``fit_chains``: network from rank 0, fit with the rank's chain id and
     seed, final gather"""
@@ -315,8 +369,7 @@ def _fit_as_rank(estimator, Y, init, group, seed_stride=1):
     est.fit(Y, init=init) if init is not None else est.fit(Y)
     secs = time.perf_counter() - t0
     gathered = group.gather_results(_chain_results(est, secs))
-    n_burn = getattr(est, 'n_burn_', 0)
-    return ChainsResult(gathered, n_burn, est)
+    return ChainsResult(gathered, _kept_from(est), est)
 
 
 def fit_chains(estimator, Y, n_chains=None, init=None, backend=None, share_device0=False,
@@ -337,14 +390,15 @@ def fit_chains(estimator, Y, n_chains=None, init=None, backend=None, share_devic
     if 'RANK' in os.environ:
         if share_device0:
             os.environ['LOCAL_RANK'] = '0'
+            if backend is None:
+                backend = 'gloo'        # (RCCL refuses two ranks on one device)
         group = init_chain_group(backend=backend)
         try:
             return _fit_as_rank(estimator, Y, init, group)
         finally:
             group.close()
     if n_chains is None:
-        import torch
-        n_chains = max(1, torch.cuda.device_count())      # (counting devices initialises nothing)
+        n_chains = max(1, visible_gpu_count())
     n_chains = int(n_chains)
     if backend is None:
         backend = 'gloo' if share_device0 else 'nccl'
@@ -361,7 +415,7 @@ def fit_chains(estimator, Y, n_chains=None, init=None, backend=None, share_devic
         code = 'import sys; from dynetlsm_amd.multichain import _rank_main; _rank_main(sys.argv[1])'
         rc = launch_ranks([sys.executable, '-c', code, job], n_chains,
                           env_extra=env, relay_rank0=False,
-                          local_ranks=[0] * n_chains if share_device0 else None)
+                          local_ranks=[0] * n_chains if share_device0 else None, timeout=timeout)
         if rc != 0:
             raise RuntimeError('fit_chains: a rank exited with code %d (its messages are on stderr)' % rc)
         with open(os.path.join(job, 'result.pkl'), 'rb') as f:

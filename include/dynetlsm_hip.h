@@ -137,15 +137,9 @@ int dlsm_loglik_partial_all(dlsm_chain *h, int with_prior, double *out);
  * 4 = pipelined speculative batches: one fused launch resolves batch b and
  *     evaluates batch b + 1, both parities in the same launches,
  * 5 = (case-control model) the pipelined form with sparse correction lists and batches
- *     of 512 nodes,
- * 6 = (exact likelihoods) the pipelined form with two batches resolved and two evaluated
- *     per launch: half the launches, larger correction blocks (measured slower than 4),
- * 7 = (exact likelihoods) algo 4's roles in ONE persistent launch per sweep: per-slice flags
- *     instead of kernel boundaries, evaluator work drawn from a ticket counter (progress with
- *     any number of resident workgroups), every wait bounded by a poll budget - a wait that
- *     runs out sets a sticky error word and the next synchronising call returns DLSM_E_HIP.
- *     Needs a compute unit per time slice.  Decisions identical to algo 4; measured slower
- *     (the flag hand-offs cost more than the boundaries they replace), never picked by auto. */
+ *     of 512 nodes.
+ * (6 = two batches per launch and 7 = one persistent launch per sweep existed in rounds 2-4,
+ *  measured slower than 4 and were removed in round 5: DLSM_E_ARG.) */
 int dlsm_sweep_positions(dlsm_chain *h, uint32_t iter, int algo);
 /* the algorithm `algo` resolves to for this handle (what 0 = auto picks): 1, 2, 4 or 5; a
  * non-zero `algo` is returned as it is after the same checks as dlsm_sweep_positions */
@@ -210,28 +204,6 @@ int dlsm_trace_read(dlsm_chain *h, int first, int count, double *Xs,
                     double *intercepts, double *logps);
 /* rows first .. first+count-1 of the radii trace (count*N), directed models */
 int dlsm_trace_read_radii(dlsm_chain *h, int first, int count, double *radii);
-
-/* ---- several chains of one network in shared launches ------------------------------------
- * The reference refits seeds one after the other (examples/homogeneous_simulation.py:177-184:
- * `for i in range(n_reps): ... random_state=i`).  A batch drives up to 8 chains of the SAME
- * network on one GPU (undirected model; same device, shape and `squared`; the networks are
- * compared word for word at creation) through shared launches of the pipelined sweep: the
- * chains' resolver workgroups side by side, ONE pool of evaluator items over all chains, the
- * launch floors paid once per batch instead of once per chain.  Every chain keeps its own state,
- * configuration, trace and Philox chain id, and every other entry point of this header keeps
- * working on a member chain (its calls order on the batch's stream); a chain's trace is bit for
- * bit the one dlsm_lsm_run produces for it alone.  Destroy the batch before its chains. */
-typedef struct dlsm_batch dlsm_batch;
-int dlsm_batch_create(dlsm_chain *const *chains, int n, dlsm_batch **out);
-void dlsm_batch_destroy(dlsm_batch *b);
-/* dlsm_lsm_run(first, count, procrustes_ref) for every chain of the batch.  Asynchronous. */
-int dlsm_batch_lsm_run(dlsm_batch *b, int first, int count, int procrustes_ref);
-int dlsm_batch_synchronize(dlsm_batch *b);
-/* iterations that ran through shared launches / chain by chain so far (the first and the last
- * iteration of a call run chain by chain, as in dlsm_lsm_run; so does every iteration when the
- * chains are configured differently or use another sweep than algo 4) */
-int dlsm_batch_stats(dlsm_batch *b, int64_t *merged, int64_t *single);
-const char *dlsm_batch_last_error(const dlsm_batch *b);
 
 /* ---- device-resident HDP-LPCM chain (hdp_lpcm.py:823-1069) --------------------------
  * the whole Gibbs iteration of DynamicNetworkHDPLPCM._fit on the device -

@@ -54,6 +54,9 @@ for l in range(32):
         rel = (it - t0) * 0.01
         row['evaluator_entry_us_p50_max'] = [round(float(np.median(rel[:, 0])), 2), round(float(rel[:, 0].max()), 2)]
         row['evaluator_exit_us_p50_max'] = [round(float(np.median(rel[:, 1])), 2), round(float(rel[:, 1].max()), 2)]
+        row['evaluator_exit_us_p90_p99_p999'] = [round(float(np.percentile(rel[:, 1], q)), 2) for q in (90, 99, 99.9)]
+        dur = rel[:, 1] - rel[:, 0]
+        row['evaluator_item_us_p50_p90_p99_max'] = [round(float(np.percentile(dur, q)), 2) for q in (50, 90, 99, 100)]
     out.append(row)
     print(json.dumps(row))
 if len(sys.argv) > 2:

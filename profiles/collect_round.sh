@@ -27,10 +27,6 @@ python3 bench.py < /dev/null > $OUT/bench_default.json 2> $OUT/bench_default.err
 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver_args.json 2> $OUT/bench_driver_args.err
 : > $OUT/chains_per_gpu.jsonl
 for C in 2 3 4; do python3 bench.py --chains-per-gpu $C --no-cpu >> $OUT/chains_per_gpu.jsonl 2>> $OUT/chains_per_gpu.err; done
-# the undirected LSM chains of a GPU through SHARED launches (dlsm_batch_*) beside the per-chain streams above
-: > $OUT/chains_shared_launches.jsonl
-for C in 2 4 8; do python3 bench.py --model lsm --chains-per-gpu $C --share-launches 1 --no-cpu --profile-steps 0 >> $OUT/chains_shared_launches.jsonl 2>> $OUT/chains_per_gpu.err; done
-python3 bench.py --model lsm --chains-per-gpu 8 --share-launches 0 --no-cpu --profile-steps 0 >> $OUT/chains_shared_launches.jsonl 2>> $OUT/chains_per_gpu.err
 python3 profiles/posterior_mixing.py > $OUT/posterior_mixing.txt 2>&1
 python3 profiles/instr_counts.py > $OUT/instr_counts.json 2>&1
 python3 profiles/instr_counts.py scratch > $OUT/hot_kernel_registers.txt 2>&1
@@ -42,7 +38,6 @@ if [ -f tmp_timing/libtiming.so ]; then
   python3 profiles/ccpipe_timing.py tmp_timing/libtiming.so $OUT/ccpipe_timing.json > $OUT/ccpipe_timing.log 2>&1
   python3 profiles/labels_phases.py tmp_timing/libtiming.so $OUT/labels_phases.json > $OUT/labels_phases.log 2>&1
   python3 profiles/hdp_tail_timing.py tmp_timing/libtiming.so $OUT/hdp_tail_timing.json > $OUT/hdp_tail_timing.log 2>&1
-  python3 profiles/persist_timing.py tmp_timing/libtiming.so $OUT/persist_timing.json > $OUT/persist_timing.log 2>&1
 fi
 [ -x tmp_timing/valu_rates ] && ./tmp_timing/valu_rates > $OUT/valu_rates.txt 2>&1
 [ -x tmp_timing/sqrt_acc ] && ./tmp_timing/sqrt_acc > $OUT/sqrt_acc.txt 2>&1

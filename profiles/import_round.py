@@ -24,7 +24,7 @@ for m in ('lsm', 'hdp', 'cc'):
 for a in ('bench_default.json', 'bench_driver_args.json', 'chains_per_gpu.jsonl', 'chains_shared_launches.jsonl',
           'bench_2ranks_one_gpu.json', 'bench_lsm_cpu8.json', 'posterior_mixing.txt', 'instr_counts.json',
           'hot_kernel_registers.txt', 'end_to_end_fit.jsonl', 'pipe_timing.json', 'loglik_timing.json',
-          'ccpipe_timing.json', 'labels_phases.json', 'hdp_tail_timing.json', 'persist_timing.json',
+          'ccpipe_timing.json', 'labels_phases.json', 'hdp_tail_timing.json',
           'valu_rates.txt', 'sqrt_acc.txt', 'hdp_timeline_two_queues.txt', 'hdp_timeline_one_queue.txt'):
     p = os.path.join(src, a)
     if os.path.exists(p) and os.path.getsize(p) > 0:

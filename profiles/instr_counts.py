@@ -164,8 +164,7 @@ def kernel_metadata(lib_path=None):
 # may touch scratch memory (round-3 verdict: k_pipe_last_ride<2> had 12 scratch instructions)
 HOT_KERNELS = [
     'k_pipe_step<2,0,1>', 'k_pipe_last_ride<2>', 'k_loglik_undirected<2,2>',
-    'k_lsm_finalize_apply_propose<2>', 'k_pipe_step_batch<2,0>', 'k_pipe_last_ride_batch<2>',
-    'k_lsm_finalize_apply_propose_batch<2>',
+    'k_lsm_finalize_apply_propose<2>',
     'k_post_apply<2>', 'k_sample_labels_mfma<5>', 'k_label_counts', 'k_hdp_stage1<2>', 'k_hdp_stage2<2>',
     'k_hdp_stage3<2>', 'k_hdp_hypers_propose<2>', 'k_hdp_logp_batch_sums<2>', 'k_hdp_logp_batch_finish<2>',
     'k_ccpipe_step<2>', 'k_ccpipe_pack<2>', 'k_loglik_casecontrol_pf<2,1>', 'k_loglik_casecontrol_pf<2,2>',

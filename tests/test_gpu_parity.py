@@ -132,7 +132,7 @@ def test_directed_large_exponent_corner(eng):
         c.set_prior_random_walk(2.0, 0.1)
         big = 0
         res47 = {}
-        for algo in (4, 7, 1):
+        for algo in (4, 1):
             c.set_positions(X)
             c.set_samplers(eng.SamplerGrid(T, N, 0.02, tune=None))
             res = []
@@ -146,7 +146,7 @@ def test_directed_large_exponent_corner(eng):
                     big = max(big, float(np.abs(c.loglik_partial_all(with_prior=True) - pa).max()))
             if algo != 1:
                 res47[algo] = res
-        for algo in (4, 7):            # (7: the persistent launch's resolver has its own log-domain path)
+        for algo in (4,):
             for (X4, a4), (X1, a1) in zip(res47[algo], res):
                 np.testing.assert_array_equal(a4, a1)
                 np.testing.assert_allclose(X4, X1, atol=1e-12)
@@ -327,7 +327,7 @@ def test_sweep_squared_distances(eng):
     evaluator and the log-likelihood pass have their own squared-distance loops)"""
     from dynetlsm_amd import Chain, SamplerGrid
     X, Yd, Yu, radii = _rand_net(77, 3, 200, 2)
-    for algo in (1, 2, 3, 4, 6, 7):
+    for algo in (1, 2, 3, 4):
         og = orc.SamplerGrid(3, 200, 0.1, tune=None)
         st = orc.ChainState(X, og, Y=Yu, intercept=[0.5], squared=True, tau_sq=2.0,
                             sigma_sq=0.1, seed=8, chain=0)
@@ -392,12 +392,10 @@ def test_sweep_pipelined_many_slices(eng):
                                         ('undirected', 3, 1100, 2), ('directed', 4, 260, 2),
                                         ('directed', 3, 128, 3), ('undirected', 5, 129, 1),
                                         ('undirected', 2, 257, 4)])
-@pytest.mark.parametrize('algo', [2, 3, 4, 6, 7])
+@pytest.mark.parametrize('algo', [2, 3, 4])
 def test_sweep_speculative_batches(eng, name, T, N, D, prior, algo):
-    """algo 2 / 3 (chip-wide speculative batches), 4 (the pipelined form: batch b + 1
-    evaluated beside the resolve of batch b), 6 (two batches resolved and two evaluated
-    per launch: windows of two and three batches) and 7 (algo 4's roles in ONE persistent
-    launch, per-slice flags instead of kernel boundaries) are the same Gauss-Seidel scan:
+    """algo 2 / 3 (chip-wide speculative batches) and 4 (the pipelined form: batch b + 1
+    evaluated beside the resolve of batch b) are the same Gauss-Seidel scan:
     identical decisions, positions equal to rounding.  N = 10 < one batch,
     129 / 257 / 300 leave ragged last batches."""
     _sweep_case(eng, name, prior, T=T, N=N, D=D, n_sweeps=3, algo=algo,
@@ -432,17 +430,6 @@ def test_sweep_case_control_sparse_lists_other_dimensions(eng, D):
                 density=0.01)
 
 
-@pytest.mark.parametrize('name,T,N,D,prior', [('undirected', 3, 1290, 2, 'mix'), ('undirected', 2, 640, 3, 'rw'),
-                                              ('undirected', 1, 770, 2, 'rw'), ('directed', 3, 520, 2, 'rw'),
-                                              ('undirected', 5, 385, 1, 'mix')])
-def test_sweep_two_batches_per_launch(eng, name, T, N, D, prior):
-    """algo 6 over odd and even batch counts (11, 5, 7, 5, 4 batches; the last one ragged or a
-    single node), a single slice, both exact models: the windows of two and three batches, the
-    workgroup's second fixed point fed from the first's list in LDS"""
-    _sweep_case(eng, name, prior, T=T, N=N, D=D, n_sweeps=3, algo=6,
-                scale=1.0 if name == 'undirected' else 0.05)
-
-
 def _run_sweeps(eng, algo, T, N, D, name, prior, n_sweeps, seed=5):
     # (directed networks at the scale of their radii, as everywhere in this file: at scale 1 the
     # linear predictors reach 1e3 - 1e4 and every batched form drifts from the sequential sweep
@@ -470,67 +457,6 @@ def _run_sweeps(eng, algo, T, N, D, name, prior, n_sweeps, seed=5):
             out.append(c.get_positions().copy())
         c.get_samplers(g)
     return out, g
-
-
-@pytest.mark.parametrize('T,N,D,name,prior', [(4, 300, 2, 'undirected', 'rw'), (3, 1100, 2, 'undirected', 'mix'),
-                                              (1, 770, 2, 'undirected', 'rw'), (5, 129, 1, 'undirected', 'mix'),
-                                              (4, 260, 2, 'directed', 'rw'), (2, 257, 4, 'undirected', 'rw'),
-                                              (3, 128, 3, 'directed', 'mix'), (37, 140, 2, 'undirected', 'mix'),
-                                              (10, 1500, 2, 'undirected', 'rw')])
-def test_sweep_persistent_launch_is_bitwise_the_launch_per_batch_sweep(eng, T, N, D, name, prior):
-    """algo 7 runs algo 4's items and algo 4's fixed-point system inside one launch; a proposal is
-    either taken or not, so as long as no decision flips (the two resolvers multiply a node's
-    cross factors in different orders: a flip needs a uniform within an ulp of its ratio) positions
-    and sampler state agree BIT FOR BIT sweep after sweep - and a stale read of any handed-off byte
-    (final positions, records, H factors, flags) shows up as a difference.  Odd and even batch
-    counts, one slice, 37 slices, d = 1 .. 4, both exact models, both priors."""
-    a, ga = _run_sweeps(eng, 4, T, N, D, name, prior, 4)
-    b, gb = _run_sweeps(eng, 7, T, N, D, name, prior, 4)
-    for x, y in zip(a, b):
-        np.testing.assert_array_equal(x, y)
-    np.testing.assert_array_equal(ga.step_size, gb.step_size)
-    np.testing.assert_array_equal(ga.n_accepted, gb.n_accepted)
-    np.testing.assert_array_equal(ga.n_steps, gb.n_steps)
-    np.testing.assert_array_equal(ga.steps_until_tune, gb.steps_until_tune)
-
-
-def test_sweep_persistent_launch_waits_are_bounded(eng, monkeypatch):
-    """every wait inside the persistent launch has a poll budget: with a budget of zero the first
-    unsatisfied wait gives up, every role leaves (nothing hangs), the sticky error word makes
-    the following launches leave at once, and the host reports DLSM_E_HIP"""
-    X, Yd, Yu, radii = _rand_net(3, 4, 600, 2)
-    with eng.Chain(4, 600, 2, 'undirected', seed=1) as c:
-        c.upload_network(Yu); c.set_positions(X); c.set_intercepts([0.5])
-        c.set_prior_random_walk(2.0, 0.1)
-        c.set_samplers(eng.SamplerGrid(4, 600, 0.2, tune=None))
-        c.sweep_positions(1, algo=7)                       # fine with the default budget
-        monkeypatch.setenv('DLSM_PERSIST_BUDGET', '0')
-        with pytest.raises(RuntimeError, match='poll budget'):
-            c.sweep_positions(2, algo=7)
-        monkeypatch.delenv('DLSM_PERSIST_BUDGET')
-        # reported once: the caller sets the state again and goes on with the same handle, as the
-        # message says (round-3 advice: the word used to stay set for the handle's lifetime)
-        c.set_positions(X)
-        c.set_samplers(eng.SamplerGrid(4, 600, 0.2, tune=None))
-        c.sweep_positions(3, algo=4)
-        Xa = c.get_positions()
-        c.set_positions(X)
-        c.set_samplers(eng.SamplerGrid(4, 600, 0.2, tune=None))
-        c.sweep_positions(3, algo=7)                       # and the persistent form works again
-        np.testing.assert_array_equal(c.get_positions(), Xa)
-
-
-def test_sweep_persistent_launch_refuses_what_it_cannot_place(eng):
-    """a resolver workgroup per slice has to be resident: more slices than compute units, and the
-    case-control model, are refused (algo 4 handles both)"""
-    X, Yd, Yu, radii = _rand_net(3, 300, 130, 2)
-    with eng.Chain(300, 130, 2, 'undirected', seed=1) as c:
-        c.upload_network(Yu); c.set_positions(X); c.set_intercepts([0.5])
-        c.set_prior_random_walk(2.0, 0.1)
-        c.set_samplers(eng.SamplerGrid(300, 130, 0.2, tune=None))
-        with pytest.raises(RuntimeError, match='compute unit'):
-            c.sweep_positions(1, algo=7)
-        c.sweep_positions(1, algo=4)
 
 
 def test_sweep_auto_picks_a_valid_algorithm(eng):
@@ -738,7 +664,7 @@ def test_lsm_device_loop_equals_oracle_iterations(eng, monks, N, algo):
     np.testing.assert_allclose(cfg.i_step_size[0], isamp.step_size, rtol=1e-14)
 
 
-@pytest.mark.parametrize('algo', [4, 6, 7])
+@pytest.mark.parametrize('algo', [4])
 def test_lsm_device_loop_proposals_drawn_by_the_previous_iteration(eng, algo, monkeypatch):
     """inside dlsm_lsm_run the sweep's proposal pass rides in the previous iteration's last
     launch (kernels_tail_propose.hpp; DLSM_TAIL_PROPOSE=0: its own launch): same trace bit for

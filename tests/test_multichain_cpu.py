@@ -160,3 +160,56 @@ def test_fit_chains_reports_a_failing_rank():
     with pytest.raises(RuntimeError, match='rank exited'):
         fit_chains(StandInEstimator(n_iter=20, fail_on_chain=1), np.zeros((2, 5, 5)), n_chains=2,
                    backend='gloo')
+
+
+def test_fit_chains_with_a_thinned_estimator_keeps_its_post_burn_in_rows():
+    """round-4 advice: n_burn_ counts iterations, a thinned estimator stores every thin-th row - the
+    kept slice starts at n_burn_ // thin (hdp_lpcm.py:1072-1085), not at n_burn_ (an empty slice,
+    NaN R-hat and best_chain silently 0 with thin=10, n_iter=5000, burn=2500)"""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import numpy as np
+    from dynetlsm_amd.multichain import fit_chains, split_rhat
+    from standin_estimator import StandInEstimator
+    Y = np.zeros((2, 6, 6))
+    res = fit_chains(StandInEstimator(n_iter=400, random_state=1, thin=10, burn=300), Y, n_chains=2,
+                     backend='gloo')
+    assert res.traces['logps'].shape == (2, 40) and res.n_burn == 30
+    assert np.isfinite(res.rhat['logps']) and np.isfinite(res.logp_mean).all()
+    assert res.rhat['logps'] == split_rhat(res.traces['logps'][:, 30:])
+    assert res.best_chain == int(np.argmax(res.traces['logps'][:, 30:].mean(axis=1)))
+    # a burn-in longer than the chain still leaves the last row (as _finish does)
+    res = fit_chains(StandInEstimator(n_iter=50, random_state=1, thin=5, burn=80), Y, n_chains=2,
+                     backend='gloo')
+    assert res.n_burn == 9 and np.isfinite(res.logp_mean).all()
+
+
+def test_fit_chains_timeout_stops_a_wedged_rank():
+    """a rank that never returns (wedged in a collective, say) does not hold the caller: after
+    `timeout` seconds the ranks are terminated and the call raises"""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import time
+    import numpy as np
+    import pytest
+    from dynetlsm_amd.multichain import fit_chains
+    from standin_estimator import StandInEstimator
+    t0 = time.monotonic()
+    with pytest.raises(RuntimeError, match='rank exited'):
+        fit_chains(StandInEstimator(n_iter=20, hang_on_chain=1), np.zeros((2, 5, 5)), n_chains=2,
+                   backend='gloo', timeout=20)
+    assert time.monotonic() - t0 < 120
+
+
+def test_visible_gpu_count_makes_no_runtime_call(monkeypatch):
+    """the parent of launch_ranks counts devices from the driver's topology files and the
+    *_VISIBLE_DEVICES variables: no HIP / HSA call before its children exist"""
+    sys.path.insert(0, ROOT)
+    from dynetlsm_amd import multichain
+    monkeypatch.delenv('ROCR_VISIBLE_DEVICES', raising=False)
+    monkeypatch.delenv('CUDA_VISIBLE_DEVICES', raising=False)
+    monkeypatch.setenv('HIP_VISIBLE_DEVICES', '0,1,2')
+    n = multichain.visible_gpu_count()
+    assert 0 <= n <= 3 and (n == 3 or os.path.isdir('/sys/class/kfd/kfd/topology/nodes'))
+    monkeypatch.setenv('HIP_VISIBLE_DEVICES', '')
+    assert multichain.visible_gpu_count() == 0
