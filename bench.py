@@ -1000,6 +1000,11 @@ def run_rank(args):
                     'gathered': {k: list(v.shape) for k, v in gathered.items()},
                     'X_mean_rms_between_chains': (round(float(np.sqrt(((xm - xm.mean(0)) ** 2).mean())), 5)
                                                   if world * C > 1 else 0.0)}
+                if world > 1 or args.force_collectives:
+                    # what the collective backend itself reported for rank 0's group and what its data
+                    # collectives moved (network broadcast, starting values, final gather): a first run on
+                    # an 8-GPU node is checkable from this line alone
+                    line['collectives'] = group.describe()
                 if name == 'hdp':       # queues of the timed run's calls (2: the intercept's pass beside the tail)
                     line['config']['hdp_queues'] = wl.model.chain_.hdp_queues()
                 if name == 'lsm':

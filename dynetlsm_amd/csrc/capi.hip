@@ -376,7 +376,7 @@ void dlsm_destroy(dlsm_chain *h) {
                     h->lab_nk, h->lab_w, h->spec, h->nctrl, h->stamps, h->lsm, h->trace_X, h->trace_ic,
                     h->trace_logp, h->hops, h->hops_max, h->pipe, h->post_zt, h->post_cooc,
                     h->trace_radii, h->hdp, h->hdp_buf, h->htr_mu, h->htr_sigma, h->htr_beta,
-                    h->htr_w, h->htr_lambda, h->htr_hyper, h->htr_z, h->xr};
+                    h->htr_w, h->htr_lambda, h->htr_hyper, h->htr_z, h->xr, h->cc_terms};
     for (void *p : ptrs) if (p) hipFree(p);
     if (h->hsmall) hipHostFree(h->hsmall);
     if (h->timer0) hipEventDestroy(h->timer0);
@@ -542,6 +542,7 @@ int dlsm_upload_edges(dlsm_chain *h, const int64_t *in_edges, int Din,
     if (rc) return rc;
     h->Din = Din; h->Dout = Dout;
     h->have_edges = true;
+    h->cc_terms_valid = false;
     return DLSM_OK;
 }
 
@@ -553,7 +554,7 @@ int dlsm_set_controls(dlsm_chain *h, const int64_t *ctrl_in, const int64_t *ctrl
     HIPCHK(h, hipSetDevice(h->device));
     const size_t TN = (size_t)h->T * h->N;
     h->have_controls = false;                       // (as dlsm_upload_edges)
-    h->nctrl_valid = false;
+    h->nctrl_valid = false; h->cc_terms_valid = false;
     int rc = upload_i64_as_i32(h, &h->ctrl_in, ctrl_in, TN * C, -1, h->N, "control_nodes_in");
     if (rc) return rc;                              // -1 = padding
     rc = upload_i64_as_i32(h, &h->ctrl_out, ctrl_out, TN * C, -1, h->N, "control_nodes_out");
@@ -603,7 +604,7 @@ int dlsm_resample_controls(dlsm_chain *h, uint32_t iter, int n_control) {
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->have_controls = true;
-    h->nctrl_valid = false;
+    h->nctrl_valid = false; h->cc_terms_valid = false;
     return DLSM_OK;
 }
 
@@ -1134,7 +1135,21 @@ static int launch_sweep_ccpipe(dlsm_chain *h, IterRef iter, bool alloc_only = fa
         HIPCHK(h, hipMalloc((void **)&h->pipe, need));
         h->pipe_cap = need;
     }
+    // the nodes' term rows: rebuilt when the edge tables or the controls have changed
+    const int tw = cp_terms_width(cap);
+    const size_t n_terms = (size_t)T * N * tw;
+    if (h->cc_terms_cap < n_terms) {
+        if (h->cc_terms) hipFree(h->cc_terms);
+        h->cc_terms = nullptr; h->cc_terms_cap = 0; h->cc_terms_valid = false;
+        HIPCHK(h, hipMalloc((void **)&h->cc_terms, n_terms * sizeof(int32_t)));
+        h->cc_terms_cap = n_terms;
+    }
     if (alloc_only) return DLSM_OK;
+    if (!h->cc_terms_valid) {
+        hipLaunchKernelGGL(k_ccpipe_terms, dim3((unsigned)(((size_t)T * N + 3) / 4)), dim3(256), 0, h->stream,
+                           h->view(), h->nctrl, h->cc_terms, tw);
+        h->cc_terms_valid = true;
+    }
     CcPipeBuf pb;
     pb.prop = h->pipe; pb.tot = pb.prop + n_prop; pb.xval = pb.tot + n_tot; pb.oval = pb.xval + n_ent;
     double *consts = pb.oval + n_ent;
@@ -1142,6 +1157,7 @@ static int launch_sweep_ccpipe(dlsm_chain *h, IterRef iter, bool alloc_only = fa
     pb.xidx = (int32_t *)(pb.snap + n_rec); pb.oidx = pb.xidx + n_ent; pb.cnt = pb.oidx + n_ent;
     pb.accmask = (unsigned long long *)(pb.xidx + even2(2 * n_ent + n_cnt));
     pb.nctrl = h->nctrl; pb.cap = cap; pb.nbat = nbat;
+    pb.terms = h->cc_terms; pb.tw = tw;
     PipeBuf pp{};                   // the proposal kernel's view: proposals + its two constants
     pp.prop = pb.prop; pp.consts = consts;
     ChainView v = h->view();

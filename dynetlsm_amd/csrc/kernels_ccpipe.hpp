@@ -45,8 +45,38 @@ struct CcPipeBuf {
     double *cur, *snap;      // [T][N][RW] : (x[D], r) records of the current / the snapshot positions
     unsigned long long *accmask;   // [T][CP_WAVES] : accepted nodes of the last resolved batch
     const int32_t *nctrl;    // valid controls per (t, i, direction)
-    int cap, nbat;
+    const int32_t *terms;    // [T][N][tw] : (in_deg, out_deg, nci, nco | in-edges, out-edges, in-controls, out-controls)
+    int cap, nbat, tw;
 };
+
+// A node's gathered terms as ONE row (round 5): its four counts and then its in-edges, out-edges,
+// in-controls and out-controls back to back - the order cc_term walks.  The evaluator used to read
+// the counts first and the four lists behind them (two round trips through a memory system that
+// 2560 wavefronts of gathers keep busy: ~1.9 us each, profiles/r05_ccpipe_timing.json); with the
+// row it requests the counts and the first 256 indices at once, as coalesced 256-byte reads.  The
+// rows change only when the edge tables or the controls do (upload / set / resample: every
+// n_resample_control = 100 iterations), k_ccpipe_terms rebuilds them then.
+__host__ __device__ constexpr int cp_terms_width(int cap) { return (4 + cap + 3) / 4 * 4; }
+__global__ __launch_bounds__(256) void k_ccpipe_terms(ChainView c, const int32_t *nctrl, int32_t *terms, int tw) {
+    const long node = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (node >= (long)c.T * c.N) return;
+    const int in_deg = c.degree[node * 2], out_deg = c.degree[node * 2 + 1];
+    const int nci = nctrl[node * 2], nco = nctrl[node * 2 + 1];
+    int32_t *row = terms + node * tw;
+    if (lane < 4) row[lane] = lane == 0 ? in_deg : (lane == 1 ? out_deg : (lane == 2 ? nci : nco));
+    const int total = in_deg + out_deg + nci + nco;
+    for (int q = lane; q < tw - 4; q += 64) {
+        int r = q, e = 0;
+        if (q < total) {
+            if (r < in_deg) e = c.in_edges[node * c.Din + r];
+            else if ((r -= in_deg) < out_deg) e = c.out_edges[node * c.Dout + r];
+            else if ((r -= out_deg) < nci) e = c.ctrl_in[node * c.C + r];
+            else e = c.ctrl_out[node * c.C + (r - nci)];
+        }
+        row[4 + q] = e;
+    }
+}
 
 // A gathered term needs its partner's position and radius: one record (32 bytes up to d = 3)
 // instead of two arrays halves the cache-line requests the evaluator is bound by.  `cur` follows
@@ -78,25 +108,6 @@ struct CcNode {
     int in_deg, out_deg, nci, nco, total;
     double adj_in, adj_out;
 };
-__device__ __forceinline__ CcNode cc_node(const ChainView &c, const int32_t *nctrl, int t, int jk) {
-    CcNode n;
-    n.node = (size_t)t * c.N + jk;
-    n.in_deg = c.degree[n.node * 2]; n.out_deg = c.degree[n.node * 2 + 1];
-    n.nci = nctrl[n.node * 2]; n.nco = nctrl[n.node * 2 + 1];
-    n.adj_in = (double)(c.N - n.in_deg - 1) / (double)n.nci;
-    n.adj_out = (double)(c.N - n.out_deg - 1) / (double)n.nco;
-    n.total = n.in_deg + n.out_deg + n.nci + n.nco;
-    return n;
-}
-__device__ __forceinline__ int cc_term(const ChainView &c, const CcNode &n, int q, int &kind) {
-    int r = q;
-    if (r < n.in_deg) { kind = 0; return c.in_edges[n.node * c.Din + r]; }
-    if ((r -= n.in_deg) < n.out_deg) { kind = 1; return c.out_edges[n.node * c.Dout + r]; }
-    if ((r -= n.out_deg) < n.nci) { kind = 2; return c.ctrl_in[n.node * c.C + r]; }
-    kind = 3;
-    return c.ctrl_out[n.node * c.C + (r - n.nci)];
-}
-
 // log-ratio contribution of one gathered term of node k when k moves x0 -> x1, its partner
 // at xn (directed_likelihoods_fast.pyx:107-180):
 //   edges    (eta1 - eta0) - [softplus(eta1) - softplus(eta0)]
@@ -137,10 +148,12 @@ __device__ __forceinline__ double cc_term_delta_fast(const double *xn, const dou
 
 // per-wavefront scratch of the evaluator: the window terms of a node, compacted in term order
 constexpr int CP_WCAP = 128;
+template <int D>
 struct CcWin {
     int e[CP_WCAP];            // partner | kind << 28
     double contrib[CP_WCAP];   // the term with the partner at its snapshot position
     double re[CP_WCAP];        // the partner's radius
+    double xp[CP_WCAP][D];     // the partner's proposal (requested with its record: round 5)
 };
 
 // One wavefront: node k of batch `be` in slice t, its terms four 64-term chunks at a time with
@@ -152,7 +165,7 @@ struct CcWin {
 // mostly idle evaluation per chunk.
 template <int D>
 __device__ __forceinline__ void ccpipe_eval_item(const ChainView &c, const CcPipeBuf &pb, int be,
-                                                 int t, int k, int lane, CcWin &sw) {
+                                                 int t, int k, int lane, CcWin<D> &sw) {
     constexpr int PW = 2 * D + 2;
     constexpr int RW = cp_record_width(D);
     constexpr int NCH = 4;
@@ -160,7 +173,19 @@ __device__ __forceinline__ void ccpipe_eval_item(const ChainView &c, const CcPip
     const int j0 = be * CP_B, jk = j0 + k;
     const int jprev = max(0, j0 - CP_B);       // nodes >= jprev: snapshot positions
     const int bb = be & 1;
-    const CcNode nd = cc_node(c, pb.nctrl, t, jk);
+    // the node's row: counts and the first 64 * NCH indices leave together
+    const int32_t *row = pb.terms + ((size_t)t * N + jk) * pb.tw;
+    const int4 hdr = *(const int4 *)row;
+    int e_first[NCH];
+#pragma unroll
+    for (int u = 0; u < NCH; ++u) e_first[u] = row[4 + min(64 * u + lane, pb.tw - 5)];
+    CcNode nd;
+    nd.node = (size_t)t * N + jk;
+    nd.in_deg = hdr.x; nd.out_deg = hdr.y; nd.nci = hdr.z; nd.nco = hdr.w;
+    nd.adj_in = (double)(N - nd.in_deg - 1) / (double)nd.nci;
+    nd.adj_out = (double)(N - nd.out_deg - 1) / (double)nd.nco;
+    nd.total = nd.in_deg + nd.out_deg + nd.nci + nd.nco;
+    const int k_oe = nd.in_deg, k_ci = nd.in_deg + nd.out_deg, k_co = nd.in_deg + nd.out_deg + nd.nci;
     const double *cur = pb.cur + (size_t)t * N * RW, *snap = pb.snap + (size_t)t * N * RW;
     const double *props = pb.prop + (size_t)t * N * PW;
     double xk0[D], xk1[D];
@@ -187,7 +212,7 @@ __device__ __forceinline__ void ccpipe_eval_item(const ChainView &c, const CcPip
             if (live) {
                 double xe1[D];
 #pragma unroll
-                for (int d = 0; d < D; ++d) xe1[d] = props[(size_t)e * PW + d];
+                for (int d = 0; d < D; ++d) xe1[d] = sw.xp[i][d];
                 const bool in_dir = (kind == 0 || kind == 2);
                 const double wsp = kind < 2 ? 1.0 : (kind == 2 ? nd.adj_in : nd.adj_out);
                 h = cc_term_delta_fast<D>(xe1, xk0, xk1, false, in_dir, kind < 2, wsp, bin, bout, irj,
@@ -213,10 +238,12 @@ __device__ __forceinline__ void ccpipe_eval_item(const ChainView &c, const CcPip
 #pragma unroll
         for (int u = 0; u < NCH; ++u) {
             const int q = q0 + 64 * u + lane;
-            kind[u] = 0;
-            e[u] = q < nd.total ? cc_term(c, nd, q, kind[u]) : -1;
+            kind[u] = q < k_oe ? 0 : (q < k_ci ? 1 : (q < k_co ? 2 : 3));
+            const int er = q0 == 0 ? e_first[u] : row[4 + min(q, pb.tw - 5)];
+            e[u] = q < nd.total ? er : -1;
         }
-        double xe[NCH][D], re[NCH];
+        double xe[NCH][D], re[NCH], xp[NCH][D];
+        bool win[NCH];
 #pragma unroll
         for (int u = 0; u < NCH; ++u) {
             const int ee = max(e[u], 0);
@@ -224,6 +251,11 @@ __device__ __forceinline__ void ccpipe_eval_item(const ChainView &c, const CcPip
 #pragma unroll
             for (int d = 0; d < D; ++d) xe[u][d] = src[d];
             re[u] = src[D];
+            // a partner inside the window gets its second evaluation at its proposal: requested now,
+            // with the record, instead of one round trip later (flush reads it from LDS)
+            win[u] = e[u] >= jprev && e[u] < jk;
+#pragma unroll
+            for (int d = 0; d < D; ++d) xp[u][d] = win[u] ? props[(size_t)ee * PW + d] : 0.0;
         }
 #pragma unroll
         for (int u = 0; u < NCH; ++u) {
@@ -236,15 +268,16 @@ __device__ __forceinline__ void ccpipe_eval_item(const ChainView &c, const CcPip
                                                 bin, bout, irj, re[u], c.squared);
                 acc += contrib;
             }
-            const bool win = e[u] >= jprev && e[u] < jk;    // its acceptance changes this term
-            const unsigned long long mw = __ballot(win);
+            const unsigned long long mw = __ballot(win[u]);   // its acceptance changes this term
             const int nw = __popcll(mw);
             if (wcnt + nw > CP_WCAP) flush();
-            if (win) {
+            if (win[u]) {
                 const int pos = wcnt + __popcll(mw & below);
                 sw.e[pos] = e[u] | (kind[u] << 28);
                 sw.contrib[pos] = contrib;
                 sw.re[pos] = re[u];
+#pragma unroll
+                for (int d = 0; d < D; ++d) sw.xp[pos][d] = xp[u][d];
             }
             wcnt += nw;
         }
@@ -393,46 +426,66 @@ __device__ __forceinline__ void ccpipe_resolve(const ChainView &c, const CcPipeB
     for (int e = 0; e < CP_OWN_REGS; ++e) oi[e] = e < nown ? oi[e] : 0;
     __syncthreads();                                   // sCross visible
     if (!upper) r += sCross[k];
-    {
-        const unsigned long long g = __ballot(valid && !(lu >= r));
-        if (lane == 0) sMask[0][wave] = g;
-    }
-    if (tid < 3) sChanged[tid] = 0;
+    // Fixed point of a -> F(a) WITHOUT workgroup barriers (round 5).  The eight wavefronts that own
+    // the batch's nodes iterate on their own: a pass reads the other wavefronts' mask words as they
+    // are at that moment (whatever a neighbour has already corrected is used at once, Gauss-Seidel
+    // fashion, instead of one barrier later), re-ballots, and publishes its word only when it
+    // changed - word first, then the version counter sCtl[0].  A wavefront that has seen two passes
+    // in a row with the same version and no change of its own files that version in sCtl[1 + w];
+    // the system is solved when every wavefront's filed version IS the current one: word stores
+    // precede their version increment, so a store still in flight belongs to a wavefront whose own
+    // filed version must then predate it, and the earliest such store would have had to come from
+    // reads identical to the ones that produced no change - the words are a fixed point, and the
+    // fixed point of the triangular system is the sequential scan's result.  (The barrier form was
+    // ~10 passes of 0.45 us each, half of the resolver: profiles/r04_ccpipe_timing.json.)
+    volatile unsigned long long *sW = sMask[0];
+    volatile int *sCtl = sChanged;                      // [0] version, [1 + w] version filed by wavefront w
+    constexpr int NRW = CP_B / 64;                      // wavefronts that own nodes
+    unsigned long long mine = __ballot(valid && !(lu >= r));
+    if (!upper && lane == 0) { sW[wave] = mine; sCtl[1 + wave] = -1; }
+    if (tid == 0) sCtl[0] = 0;
     __syncthreads();
     DLSM_CC_STAMP(3, ov[0])
-    // fixed point of a -> F(a); one barrier per pass: pass p raises flag p % 3 and clears flag
-    // (p + 1) % 3, whose last readers (pass p - 2) are two barriers behind
-    int cur = 0;
-    for (int pass = 0; pass < CP_B + 2; ++pass) {
-        double s_own = 0.0;
+    if (!upper) {
+        int last_v = -2;
+        bool quiet = false;                             // the previous pass changed nothing
+        for (int pass = 0; pass < (1 << 20); ++pass) {
+            const int v = sCtl[0];
+            const int filed = sCtl[1 + (lane & (NRW - 1))];     // lane w: the version wavefront w has filed
+            double s_own = 0.0;
 #pragma unroll
-        for (int e = 0; e < CP_OWN_REGS; ++e)
-            if (e < nown && ((sMask[cur][oi[e] >> 6] >> (oi[e] & 63)) & 1ull)) s_own += ov[e];
-        for (int e0 = CP_OWN_REGS; e0 < nown; e0 += 8) {    // the long list: from memory, eight
-            int m[8];                                       // loads in flight per trip
-            double h[8];
+            for (int e = 0; e < CP_OWN_REGS; ++e)
+                if (e < nown && ((sW[oi[e] >> 6] >> (oi[e] & 63)) & 1ull)) s_own += ov[e];
+            for (int e0 = CP_OWN_REGS; e0 < nown; e0 += 8) {    // the long list: from memory, eight
+                int m[8];                                       // loads in flight per trip
+                double h[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const size_t p = lbase + (size_t)min(e0 + u, nown - 1) * CP_B;
-                m[u] = pb.oidx[p];
-                h[u] = pb.oval[p];
+                for (int u = 0; u < 8; ++u) {
+                    const size_t p = lbase + (size_t)min(e0 + u, nown - 1) * CP_B;
+                    m[u] = pb.oidx[p];
+                    h[u] = pb.oval[p];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (e0 + u < nown && ((sW[m[u] >> 6] >> (m[u] & 63)) & 1ull)) s_own += h[u];
             }
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (e0 + u < nown && ((sMask[cur][m[u] >> 6] >> (m[u] & 63)) & 1ull)) s_own += h[u];
+            if (__ballot(filed != v) == 0ull) break;            // every wavefront has filed the current version
+            const unsigned long long g = __ballot(valid && !(lu >= r + s_own));
+            if (g != mine) {
+                mine = g;
+                if (lane == 0) {
+                    sW[wave] = g;                       // the word before the version (release)
+                    __hip_atomic_fetch_add(&sChanged[0], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                quiet = false;
+            } else {
+                if (quiet && last_v == v && lane == 0) sCtl[1 + wave] = v;
+                quiet = true;
+            }
+            last_v = v;
         }
-        const unsigned long long g = __ballot(valid && !(lu >= r + s_own));
-        if (lane == 0) {
-            sMask[cur ^ 1][wave] = g;
-            if (g != sMask[cur][wave]) atomicOr(&sChanged[pass % 3], 1);
-        }
-        if (tid == 0) sChanged[(pass + 1) % 3] = 0;
-        __syncthreads();
-        cur ^= 1;
-        if (!sChanged[pass % 3]) break;
     }
-    DLSM_CC_STAMP(4, (double)cur)
-    const unsigned long long mine = sMask[cur][wave];
+    DLSM_CC_STAMP(4, (double)lane)
     const int accepted = (int)((mine >> lane) & 1ull);
     if (valid) {
         const size_t tj = (size_t)t * N + j0 + k;
@@ -446,9 +499,9 @@ __device__ __forceinline__ void ccpipe_resolve(const ChainView &c, const CcPipeB
         metropolis_bookkeeping(st, na, ns, un, c.tune, c.tune_interval, accepted);
         c.step[tj] = st; c.nacc[tj] = na; c.nsteps[tj] = ns; c.until[tj] = un;
     }
-    if (lane == 0) accg[wave] = mine;
+    if (!upper && lane == 0) accg[wave] = mine;
 #ifdef DLSM_PIPE_TIMING
-    DLSM_CC_STAMP(5, (double)cur)
+    DLSM_CC_STAMP(5, (double)lane)
     if (tid == 0 && tl >= 0 && tl < 32 && t < 16) for (int i = 0; i < 6; ++i) g_cc_res_t[tl][t][i] = cts[i];
 #endif
 }
@@ -459,9 +512,9 @@ template <int D>
 __global__ __launch_bounds__(CP_THREADS) void k_ccpipe_step(ChainView c, CcPipeBuf pb, int l) {
     __shared__ unsigned long long sMask[2][CP_WAVES];
     __shared__ unsigned long long sPrev[CP_WAVES];
-    __shared__ int sChanged[3];
+    __shared__ int sChanged[1 + CP_B / 64];
     __shared__ double sCross[CP_B];
-    __shared__ CcWin sWin[CP_WAVES];
+    __shared__ CcWin<D> sWin[CP_WAVES];
     const int T = c.T;
     if ((int)blockIdx.x < T) {
         const int t = blockIdx.x;

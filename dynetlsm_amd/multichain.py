@@ -58,6 +58,12 @@ class ChainGroup(object):
         self._ctl = None
         if not self._solo and backend == 'nccl':
             self._ctl = dist.new_group(backend='gloo')
+        # what the data collectives of this rank moved and how long they took (host clock around
+        # the call + the synchronisation that ends it): `describe()` puts them on the N > 1 bench
+        # line, so that the first run on a real 8-GPU node can be checked from its JSON alone
+        self.stats = {'broadcast_calls': 0, 'broadcast_bytes': 0, 'broadcast_ms': 0.0,
+                      'network_broadcast_bytes': 0, 'network_broadcast_ms': 0.0,
+                      'gather_calls': 0, 'gather_bytes_per_rank': 0, 'gather_ms': 0.0}
 
     @property
     def chain_id(self):
@@ -70,6 +76,33 @@ class ChainGroup(object):
     def _tensor_device(self):
         t = self._torch
         return t.device('cuda', self.local_rank) if self.backend == 'nccl' else t.device('cpu')
+
+    def describe(self):
+        """what the backend itself reports for this group (not what the caller asked for) and the
+        traffic counters: {'world_size', 'rank', 'backend', 'control_backend', 'device', ...stats}"""
+        d = {'world_size': self.world, 'rank': self.rank, 'backend': self.backend, 'control_backend': None,
+             'device': None, 'solo': bool(self._solo)}
+        if not self._solo:
+            d['world_size'] = int(self._dist.get_world_size())
+            d['rank'] = int(self._dist.get_rank())
+            d['backend'] = str(self._dist.get_backend())
+            d['control_backend'] = str(self._dist.get_backend(self._ctl)) if self._ctl is not None else d['backend']
+            d['device'] = str(self._tensor_device())
+        d.update({k: (round(v, 4) if isinstance(v, float) else v) for k, v in self.stats.items()})
+        return d
+
+    def _timed(self, kind, nbytes, t0):
+        if self.backend == 'nccl':
+            self._torch.cuda.current_stream().synchronize()
+        ms = 1e3 * (time.perf_counter() - t0)
+        if kind == 'gather':
+            self.stats['gather_calls'] += 1; self.stats['gather_bytes_per_rank'] += int(nbytes)
+            self.stats['gather_ms'] += ms
+        else:
+            self.stats['broadcast_calls'] += 1; self.stats['broadcast_bytes'] += int(nbytes)
+            self.stats['broadcast_ms'] += ms
+            if kind == 'network':
+                self.stats['network_broadcast_bytes'] += int(nbytes); self.stats['network_broadcast_ms'] += ms
 
     def barrier(self):
         if not self._solo:
@@ -96,7 +129,9 @@ class ChainGroup(object):
             buf = t.from_numpy(Y.astype(np.int8)).to(dev)
         else:
             buf = t.empty(shp, dtype=t.int8, device=dev)
+        t0 = time.perf_counter()
         self._dist.broadcast(buf, src)
+        self._timed('network', buf.numel(), t0)
         return buf.cpu().numpy().astype(np.float64)
 
     def broadcast_chain_network(self, chain, src=0):
@@ -110,9 +145,9 @@ class ChainGroup(object):
         buf = t.empty(n, dtype=t.int32, device=self._tensor_device())
         if self.rank == src:
             chain.get_network_packed(buf.data_ptr(), n)
+        t0 = time.perf_counter()
         self._dist.broadcast(buf, src)
-        if self.backend == 'nccl':
-            t.cuda.current_stream().synchronize()      # the chain copies on its own stream
+        self._timed('network', 4 * n, t0)              # (synchronises: the chain copies on its own stream)
         if self.rank != src:
             chain.set_network_packed(buf.data_ptr(), n)
 
@@ -122,7 +157,9 @@ class ChainGroup(object):
             return np.asarray(a, dtype=np.float64)
         t = self._torch
         buf = t.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(self._tensor_device())
+        t0 = time.perf_counter()
         self._dist.broadcast(buf, src)
+        self._timed('array', 8 * buf.numel(), t0)
         return buf.cpu().numpy()
 
     def gather_arrays(self, a):
@@ -133,7 +170,9 @@ class ChainGroup(object):
         t = self._torch
         mine = t.from_numpy(a).to(self._tensor_device())
         out = [t.empty_like(mine) for _ in range(self.world)]
+        t0 = time.perf_counter()
         self._dist.all_gather(out, mine)
+        self._timed('gather', 8 * mine.numel(), t0)
         return [o.cpu().numpy() for o in out]
 
     def gather_results(self, results):

@@ -6,11 +6,12 @@ DynamicNetworkLSM); the reference's generator is O(T N^2) Python-side.
 """
 import numpy as np
 
-__all__ = ['synthetic_lsm_network', 'synthetic_hdp_network', 'synthetic_sparse_directed']
+__all__ = ['synthetic_lsm_network', 'synthetic_hdp_network', 'synthetic_sparse_directed',
+           'synthetic_directed_from_model']
 
 
 def _expit(x):
-    return 1.0 / (1.0 + np.exp(-x))
+    return 1.0 / (1.0 + np.exp(-np.maximum(x, -700.0)))
 
 
 def _pairwise(X):
@@ -142,3 +143,104 @@ def synthetic_sparse_directed(T=5, N=10000, deg=20, seed=0):
             in_edges[t, e, fill[t, e]] = i       # sources arrive in increasing i
             fill[t, e] += 1
     return X, radii, degree, in_edges, out_edges
+
+
+def synthetic_directed_from_model(T=5, N=10000, mean_degree=20.0, seed=0, intercepts=(0.3, 0.7),
+                                  walk=0.1, chunk=1000, use_torch=None):
+    """A sparse DIRECTED network drawn from the model itself at config 4's size (the posterior
+    tests' network: `synthetic_sparse_directed` above draws its edges uniformly, which no
+    parameter of the model generates).  Radii ~ Dirichlet(10) (mean 1 / N), positions a Gaussian
+    cloud whose width is solved for the target mean out-degree, x_t = x_{t-1} + walk * width *
+    N(0, I) (the directed generators of samples_generator.py:123-131, 249-253 at N = 10 000:
+    radii from a Dirichlet, intercepts (0.3, 0.7), positions at the scale of the radii), edges
+    i -> j ~ Bernoulli(expit(b_in (1 - d_ij / r_j) + b_out (1 - d_ij / r_i)))
+    (directed_likelihoods_fast.pyx:185-205).  The T x N x N tensor is never formed: rows are drawn
+    `chunk` at a time - with torch on the GPU when one is there (``use_torch=None``: if available;
+    5e8 Bernoulli draws take numpy a minute), so the network depends on where it was drawn; the
+    parameters do not.
+
+    Returns dict(X, radii, intercepts, degree[T, N, 2], in_edges, out_edges, width) with the
+    tables in the layouts of case_control_likelihood.py:45-68 (zero padded, sources in increasing
+    order)."""
+    rng = np.random.RandomState(seed)
+    b_in, b_out = float(intercepts[0]), float(intercepts[1])
+    radii = rng.dirichlet(np.ones(N) * 10)
+    Z0 = rng.randn(N, 2)
+    steps = rng.randn(T - 1, N, 2) if T > 1 else np.zeros((0, N, 2))
+
+    def rows_proba(Xt, lo, hi):
+        d = np.sqrt(((Xt[lo:hi, None, :] - Xt[None, :, :]) ** 2).sum(axis=2))
+        eta = b_in * (1.0 - d / radii[None, :]) + b_out * (1.0 - d / radii[lo:hi, None])
+        p = _expit(eta)
+        p[np.arange(hi - lo), np.arange(lo, hi)] = 0.0
+        return p
+
+    # width of the cloud: bisection on the expected out-degree of a sample of rows at t = 0
+    sample = np.sort(rng.choice(N, size=min(N, 400), replace=False))
+    lo_w, hi_w = 1e-6, 1.0
+    for _ in range(40):
+        w = np.sqrt(lo_w * hi_w)
+        Xt = w * Z0
+        d = np.sqrt(((Xt[sample, None, :] - Xt[None, :, :]) ** 2).sum(axis=2))
+        eta = b_in * (1.0 - d / radii[None, :]) + b_out * (1.0 - d / radii[sample, None])
+        deg = _expit(eta).sum(axis=1).mean() - _expit(b_in + b_out)
+        if deg > mean_degree:
+            lo_w = w
+        else:
+            hi_w = w
+    width = float(np.sqrt(lo_w * hi_w))
+    X = np.zeros((T, N, 2))
+    X[0] = width * Z0
+    for t in range(1, T):
+        X[t] = X[t - 1] + walk * width * steps[t - 1]
+    X -= X.mean(axis=(0, 1))
+    src, dst = [], []
+    tch = None
+    if use_torch is None or use_torch:
+        try:
+            import torch as tch
+            if not tch.cuda.is_available():
+                if use_torch:
+                    raise RuntimeError('use_torch=True without a GPU')
+                tch = None
+        except ImportError:
+            if use_torch:
+                raise
+            tch = None
+    if tch is not None:
+        gen = tch.Generator(device='cuda'); gen.manual_seed(int(seed))
+        r_d = tch.as_tensor(radii, device='cuda')
+    for t in range(T):
+        s_t, d_t = [], []
+        if tch is not None:
+            Xd = tch.as_tensor(X[t], device='cuda')
+        for lo in range(0, N, chunk):
+            hi = min(N, lo + chunk)
+            if tch is not None:
+                d = tch.cdist(Xd[lo:hi], Xd, compute_mode='donot_use_mm_for_euclid_dist')
+                eta = b_in * (1.0 - d / r_d[None, :]) + b_out * (1.0 - d / r_d[lo:hi, None])
+                hit = tch.rand(eta.shape, generator=gen, device='cuda', dtype=tch.float64) < tch.sigmoid(eta)
+                hit[tch.arange(hi - lo), tch.arange(lo, hi)] = False
+                ij = tch.nonzero(hit).cpu().numpy()
+                i, j = ij[:, 0], ij[:, 1]
+            else:
+                hit = rng.rand(hi - lo, N) < rows_proba(X[t], lo, hi)
+                i, j = np.nonzero(hit)
+            s_t.append(i + lo); d_t.append(j)
+        src.append(np.concatenate(s_t)); dst.append(np.concatenate(d_t))
+    degree = np.zeros((T, N, 2), dtype=np.int64)
+    for t in range(T):
+        degree[t, :, 1] = np.bincount(src[t], minlength=N)
+        degree[t, :, 0] = np.bincount(dst[t], minlength=N)
+    out_edges = np.zeros((T, N, max(1, int(degree[:, :, 1].max()))), dtype=np.int64)
+    in_edges = np.zeros((T, N, max(1, int(degree[:, :, 0].max()))), dtype=np.int64)
+    for t in range(T):
+        # rows arrive sorted by source, targets increasing inside a row
+        start = np.concatenate([[0], np.cumsum(degree[t, :, 1])[:-1]])
+        out_edges[t, src[t], np.arange(src[t].size) - start[src[t]]] = dst[t]
+        order = np.lexsort((src[t], dst[t]))           # by target, sources increasing
+        ds, ss = dst[t][order], src[t][order]
+        start = np.concatenate([[0], np.cumsum(degree[t, :, 0])[:-1]])
+        in_edges[t, ds, np.arange(ds.size) - start[ds]] = ss
+    return dict(X=X, radii=radii, intercepts=np.array([b_in, b_out]), degree=degree,
+                in_edges=in_edges, out_edges=out_edges, width=width)

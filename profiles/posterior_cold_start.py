@@ -154,3 +154,66 @@ if 'c4' in what:
     print(json.dumps(out))
     for ch in chains:
         ch.close()
+
+if 'c4m' in what:
+    # config 4's size with a network drawn FROM the model (synthetic_directed_from_model), chains
+    # started at the generating values + noise: do two chains agree, do they stay at the truth?
+    from dynetlsm_amd.synthetic import synthetic_directed_from_model
+    T, N, Cn = 5, 10000, 100
+    t0 = time.perf_counter()
+    net = synthetic_directed_from_model(T, N, 20.0, seed=0)
+    print(json.dumps(dict(config='C4 model network', seconds=round(time.perf_counter() - t0, 2), width=net['width'],
+                          mean_degree=float(net['degree'][:, :, 1].mean()), Din=int(net['in_edges'].shape[2]),
+                          Dout=int(net['out_edges'].shape[2]))))
+    w = net['width']
+    n_burn, n_keep, n_res = 4000, 16000, 100
+    chains = []
+    rs = np.random.RandomState(1)
+    X0 = net['X'] + 0.05 * w * rs.randn(*net['X'].shape)
+    t0 = time.perf_counter()
+    for cid in (0, 1):
+        ch = da.Chain(T, N, 2, 'case_control', seed=20240229, chain_id=cid)
+        ch.upload_edges(net['in_edges'], net['out_edges'], net['degree'])
+        ch.resample_controls(0, Cn)
+        ch.set_positions(X0); ch.set_radii(net['radii']); ch.set_intercepts(net['intercepts'])
+        ch.set_prior_random_walk(w * w, (0.1 * w) ** 2)
+        ch.set_samplers(da.SamplerGrid(T, N, step_size=0.02 * w, tune=n_burn, tune_interval=100))
+        ch.lsm_configure(net['intercepts'], 2.0, step_size_intercept=0.01, tune=n_burn, tune_interval=100,
+                         n_iter_procrustes=0, sweep_algo=0, step_size_radii=175000., radii_tune=n_burn,
+                         radii_tune_interval=100)
+        ch.trace_alloc(1 + n_burn + n_keep, logp0=0.0)
+        chains.append(ch)
+    it = 1
+    while it <= n_burn + n_keep:
+        nxt = min(n_burn + n_keep + 1, (it // n_res + 1) * n_res)
+        for ch in chains:
+            if it % n_res == 0:
+                ch.resample_controls(it, Cn)
+            ch.lsm_run(it, nxt - it, procrustes_ref=0)
+        it = nxt
+    for ch in chains:
+        ch.synchronize()
+    secs = time.perf_counter() - t0
+    tr = [ch.trace_read(0, 1 + n_burn + n_keep, positions=False) for ch in chains]
+    out = {'config': 'C4 model network, two chains', 'seconds': round(secs, 2), 'generating': [0.3, 0.7]}
+    out.update(windows(np.stack([t[1][:, 0] for t in tr]), 'b_in', 1 + n_burn))
+    out.update(windows(np.stack([t[1][:, 1] for t in tr]), 'b_out', 1 + n_burn))
+    out.update(windows(np.stack([t[2] for t in tr]), 'logp', 1 + n_burn))
+    for ch in chains:
+        g = ch.get_samplers(da.SamplerGrid(T, N, 0.002, tune=None))
+        cfg = ch.lsm_get_config()
+        out.setdefault('acc', []).append(round(float(g.n_accepted.sum()) / max(1.0, float(g.n_steps.sum())), 3))
+        out.setdefault('steps', []).append([float(np.median(g.step_size)), float(cfg.i_step_size[0]),
+                                            float(cfg.i_step_size[1]), float(cfg.r_step_size),
+                                            int(cfg.i_n_accepted[0]), int(cfg.i_n_accepted[1]), int(cfg.r_n_accepted)])
+        rad = ch.trace_read_radii(n_burn + n_keep, 1)[0]
+        out.setdefault('radii_rel_rms', []).append(float(np.sqrt(np.mean((rad / net['radii'] - 1) ** 2))))
+        Xl = ch.get_positions()
+        out.setdefault('X_rms_over_width', []).append(aligned_rms(Xl, net['X'])[0] / w)
+    b_in = np.stack([t[1][:, 0] for t in tr]); b_out = np.stack([t[1][:, 1] for t in tr]); lp = np.stack([t[2] for t in tr])
+    out['b_in_block_means'] = [[round(float(x[i:i + 2000].mean()), 4) for i in range(1, x.shape[0] - 1, 2000)] for x in b_in]
+    out['b_out_block_means'] = [[round(float(x[i:i + 2000].mean()), 4) for i in range(1, x.shape[0] - 1, 2000)] for x in b_out]
+    out['logp_block_means'] = [[round(float(x[i:i + 2000].mean()), 1) for i in range(1, x.shape[0] - 1, 2000)] for x in lp]
+    print(json.dumps(out))
+    for ch in chains:
+        ch.close()

@@ -177,6 +177,11 @@ def test_bench_through_rccl_in_a_group_of_one():
     line = _run_bench('--force-collectives', '--backend', 'nccl', *common)
     assert line['n_gpus'] == 1 and line['value'] > 0
     assert 'nccl' in line['config']['network_broadcast']
+    co = line['collectives']            # what RCCL itself reported, and what went through it
+    assert co['backend'] == 'nccl' and co['world_size'] == 1 and co['device'] == 'cuda:0'
+    assert co['control_backend'] == 'gloo'
+    assert co['network_broadcast_bytes'] >= 10 * 2000 * 64 * 4 and co['network_broadcast_ms'] > 0
+    assert co['gather_calls'] >= 3 and co['gather_bytes_per_rank'] >= 10 * 2000 * 2 * 8
     assert line['gathered']['X_mean'] == [1, 10, 2000, 2]
     assert line['per_rank_value'] == [line['value']]
     # the collectives sit outside the timed region: the rate is the plain single-GPU run's
@@ -219,3 +224,54 @@ def test_fit_chains_two_ranks_on_one_gpu_are_the_single_chain_fits(eng):
                      share_device0=True)
     assert res.traces['logps'].shape == (2, 60) and res.z is None and res.X_mean.shape == (2, T, N, 2)
     assert not np.array_equal(res.traces['logps'][0], res.traces['logps'][1])
+
+
+def test_bench_config5_eight_ranks_share_the_one_gpu():
+    """BASELINE.json configs[4] - eight independent HDP-LPCM chains, one per rank - with the eight
+    ranks of `bench.py --gpus 8` on the box's one GPU over gloo (one queue each): the launcher, the
+    packed-network broadcast, eight chains with eight Philox chain ids, the gathers and the line's
+    per-rank fields exactly as an 8-GPU node will produce them over RCCL (there the same command
+    without --backend gloo --share-device0)"""
+    line = _run_bench('--gpus', '8', '--backend', 'gloo', '--share-device0', '--steps', '10',
+                      '--warmup', '2', '--profile-steps', '0', '--no-cpu', '--model', 'hdp')
+    assert line['n_gpus'] == 8 and line['steps'] == 10 and line['scaling'] == 'weak'
+    assert 'DynamicNetworkHDPLPCM' in line['config']['workload'] and line['config']['chains'] == 8
+    assert line['config']['hdp_queues'] == 1           # ranks that share a device keep one queue each
+    pr = line['per_rank_value']
+    assert len(pr) == 8 and len(set(pr)) == 8 and min(pr) > 0
+    assert abs(line['value'] - 8 * 10 / (line['ms_per_step'] * 10 / 1e3)) < 0.01 * line['value']
+    assert line['value'] <= sum(pr) * 1.0001           # the slowest rank sets the aggregate
+    summ = line['chain_summaries[intercept_mean,intercept_sd,logp_mean,logp_last]']
+    assert len(summ) == 8 and len({tuple(x) for x in summ}) == 8
+    lp = np.array([x[2] for x in summ])
+    assert np.isfinite(lp).all() and np.ptp(lp) < 0.02 * abs(lp.mean())     # one network, one posterior
+    assert line['X_mean_rms_between_chains'] > 0
+    assert line['gathered']['X_mean'] == [8, 10, 2000, 2] and line['gathered']['logps'] == [8, 10]
+    assert line['gathered']['lambdas'][:2] == [8, 10]
+    assert len(line['n_clusters_used_last']) == 8
+    co = line['collectives']
+    assert co['world_size'] == 8 and co['backend'] == 'gloo' and co['rank'] == 0
+    assert co['network_broadcast_bytes'] >= 10 * 2000 * 64 * 4 and co['network_broadcast_ms'] > 0
+    assert co['gather_calls'] >= 4
+
+
+def test_fit_chains_eight_ranks_on_one_gpu(eng):
+    """multichain.fit_chains(..., n_chains=8): config 5 as one estimator-level call, eight ranks on
+    cuda:0 over gloo; eight different chains of one posterior, split R-hat over them reported"""
+    from dynetlsm_amd.multichain import fit_chains
+    rng = np.random.RandomState(7)
+    T, N = 3, 120
+    Y = (rng.rand(T, N, N) < 0.1).astype(np.float64)
+    Y = np.triu(Y, 1); Y = Y + Y.transpose(0, 2, 1)
+    res = fit_chains(eng.DynamicNetworkHDPLPCM(n_iter=300, tune=100, burn=100, n_components=5,
+                                               selection_type='map', random_state=2),
+                     Y, n_chains=8, share_device0=True, timeout=900)
+    assert res.n_chains == 8 and res.n_burn == 200
+    assert res.traces['logps'].shape == (8, 500) and res.traces['lambdas'].shape == (8, 500, 1)
+    assert res.X_mean.shape == (8, T, N, 2) and res.z.shape == (8, T, N)
+    assert len({res.traces['logps'][r].tobytes() for r in range(8)}) == 8       # eight different chains
+    for k in ('logps', 'intercepts[0]', 'lambdas[0]'):
+        assert np.isfinite(res.rhat[k]), (k, res.rhat)
+    assert res.rhat['logps'] < 1.5, res.rhat              # short chains of one small posterior
+    assert 0 <= res.best_chain < 8 and len(res.summary()['seconds']) == 8
+    print('fit_chains, 8 ranks on one GPU:', res.summary())

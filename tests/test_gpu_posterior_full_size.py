@@ -104,10 +104,12 @@ def test_c2_two_chains_agree_and_recover_the_generating_intercept(c2_chains):
     d = abs(ic[0].mean() - ic[1].mean())
     assert d < 4 * np.hypot(mcse(ic[0]), mcse(ic[1])), (d, mcse(ic[0]), mcse(ic[1]))
     # The generating value lies where the posterior puts its mass: within 4 (posterior sd + MC
-    # error) of the posterior mean, plus the shrinkage of the positions' Gaussian random-walk
-    # prior (tau^2 = 2, sigma^2 = 0.1 against the generator's 1.5^2 and 0.3^2), which pulls the
-    # distances - and with them the intercept - down by a few per cent.
-    assert abs(m_ic - net['intercept']) < 4 * (sd_ic + se_ic) + 0.05 * abs(net['intercept']), \
+    # error) of the posterior mean.  The positions' Gaussian random-walk prior (tau^2 = 2,
+    # sigma^2 = 0.1 against the generator's 1.5^2 and 0.3^2) pulls the distances - and with them
+    # the intercept - by a measured 0.0047 = 1.7 posterior sd (profiles/r04_posterior_mixing.txt;
+    # 0.0048 from a cold start, round 5); the allowance for it is 1 % of |b| = 0.015, not 5 %
+    # (round-4 verdict: the old tolerance was 27 posterior sd wide).
+    assert abs(m_ic - net['intercept']) < 4 * (sd_ic + se_ic) + 0.01 * abs(net['intercept']), \
         (m_ic, net['intercept'], sd_ic, se_ic)
     # acceptance rate of the position sweeps: inside the range the step-size rule aims for
     g = chains[0].get_samplers(__import__('dynetlsm_amd').SamplerGrid(T, N, 0.1, tune=None))
@@ -207,7 +209,7 @@ def test_c3_two_chains_agree_and_recover_the_generating_structure(c3_fits):
     # the generating values inside the posterior's mass (4 posterior sd + MC error; the
     # intercept with the same few per cent of prior shrinkage as in the LSM)
     assert abs(m_lam - 0.8) < 4 * (lam.std() + se_lam), (m_lam, lam.std(), se_lam)
-    assert abs(m_ic - net['intercept']) < 4 * (ic.std() + se_ic) + 0.05 * abs(net['intercept'])
+    assert abs(m_ic - net['intercept']) < 4 * (ic.std() + se_ic) + 0.01 * abs(net['intercept'])
     # six generating clusters: every kept sample uses at least six components; the posterior
     # mean number in use stays within one of it (the HDP opens and closes small extra clusters)
     assert ncl.min() >= N_TRUE and abs(ncl.mean() - N_TRUE) < 1.0, (ncl.min(), ncl.mean())

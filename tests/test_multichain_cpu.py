@@ -57,6 +57,12 @@ WORKER = textwrap.dedent('''
     for r, s in enumerate(allsum):
         assert s[0] == r and s[1] == ref.sum() + r
     assert g.max_over_ranks(10.0 + g.rank) == 11.0
+    # what the backend reports and what went through it (the N > 1 bench line carries this)
+    d = g.describe()
+    assert d['world_size'] == 2 and d['rank'] == g.rank and d['backend'] == 'gloo' and d['device'] == 'cpu'
+    assert d['network_broadcast_bytes'] == 3 * 17 * 17 + 4 * 3 * 17 * 4 and d['network_broadcast_ms'] > 0
+    assert d['broadcast_calls'] == 3 and d['broadcast_bytes'] == d['network_broadcast_bytes'] + 32
+    assert d['gather_calls'] == 3 and d['gather_bytes_per_rank'] == 8 * (3 * 17 * 2 + 5 + 3)
     g.barrier()
     g.close()
     print('rank %%d ok' %% g.rank)
