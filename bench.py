@@ -90,9 +90,11 @@ def _kernel_instr_per_term():
         import instr_counts
         c = instr_counts.counts()
         return (c.get('k_pipe_step<2,0,1>', {}).get('valu_per_term'),
-                c.get('k_loglik_undirected<2,2>', {}).get('valu_per_candidate_term'))
+                c.get('k_loglik_undirected<2,2>', {}).get('valu_per_candidate_term'),
+                c.get('k_pipe_step<2,0,1>', {}).get('issue_slots_per_term'),
+                c.get('k_loglik_undirected<2,2>', {}).get('issue_slots_per_candidate_term'))
     except Exception:       # noqa: BLE001
-        return None, None
+        return None, None, None, None
 
 
 def parse(argv=None):
@@ -409,8 +411,9 @@ def sweep_rooflines(chain, a, P, sweep_ms, ll_ms, ms_ev, n_ev, ms_rs, n_rs, post
     prof_ms = stored['avg_us'] * 1e-3 if stored else k_ms
     ach, frac = valu(k_terms, OPS_PER_TERM_SWEEP, prof_ms)
     ach_ev, frac_ev = valu(k_terms, OPS_PER_TERM_SWEEP, k_ms)
-    ipt_sweep, ipt_ll = kernel_instr_per_term()
+    ipt_sweep, ipt_ll, slots_sweep, slots_ll = kernel_instr_per_term()
     frac_x = valu(k_terms, ipt_sweep, prof_ms)[1] if ipt_sweep else None
+    frac_slots = valu(k_terms, slots_sweep, prof_ms)[1] if slots_sweep else None
     roofline = {
         'bound': 'fp64_valu', 'kernel': kname, 'achieved': ach, 'peak': F64_VALU_PEAK_TFLOPS,
         'unit': 'TFLOP/s', 'frac': frac, 'traffic': traffic,
@@ -425,6 +428,11 @@ def sweep_rooflines(chain, a, P, sweep_ms, ll_ms, ms_ev, n_ev, ms_rs, n_rs, post
         # (its code object, profiles/instr_counts.py): issue utilisation of the neighbour loop
         'valu_instr_per_term_in_kernel': ipt_sweep,
         'frac_executed': frac_x,
+        # ... and with every instruction weighted by its measured issue cost (a v_rsq_f64 occupies the
+        # pipe for 16.1 cycles against 4.15 for an fma: profiles/r04_valu_rates.txt): the fraction of the
+        # SIMDs' issue slots the neighbour loop's instructions fill over the whole launch
+        'issue_slots_per_term_in_kernel': slots_sweep,
+        'frac_issue_slots': frac_slots,
         'instr_source': 'profiles/instr_counts.py on the built library (llvm-objdump of the hot loop)',
         'peak_note': 'nominal float64 vector peak (fma = 2 flop).  `frac` prices the ALGORITHMIC '
                      'operations of a dyad term as fma slots - 34, fixed since round 1 so that '
@@ -458,6 +466,7 @@ def sweep_rooflines(chain, a, P, sweep_ms, ll_ms, ms_ev, n_ev, ms_rs, n_rs, post
         'f64_ops_per_term': OPS_PER_TERM_LOGLIK,
         'valu_instr_per_candidate_term_in_kernel': ipt_ll,
         'frac_executed': (valu(ll_terms, ipt_ll, ll_prof_ms)[1] if ipt_ll else None),
+        'frac_issue_slots': (valu(ll_terms, slots_ll, ll_prof_ms)[1] if slots_ll else None),
         'algorithmic_GBps': round(ll_bytes / (ll_ms * 1e-3) / 1e9, 1),
         'algorithmic_frac_of_hbm': round(ll_bytes / (ll_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
         'frac_of_sustained': round(frac_l / F64_VALU_SUSTAINED_FRAC, 4)}

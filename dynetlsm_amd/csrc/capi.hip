@@ -1173,8 +1173,8 @@ static int launch_sweep_ccpipe(dlsm_chain *h, IterRef iter, bool alloc_only = fa
     hipLaunchKernelGGL((k_ccpipe_pack<DD>), dim3((unsigned)(((size_t)T * N + 255) / 256)), dim3(256), 0,
                        h->stream, v, pb);
     const int nodes_max = ((T + 1) / 2 + T / 2) * std::min(CP_B, N);
-    const int ne_wg = std::max(1, std::min(std::max(h->n_cu / 2, h->n_cu - T),
-                                           (nodes_max + CP_WAVES - 1) / CP_WAVES));
+    // one evaluator workgroup per remaining CU; the items are dealt out over all of them (kernels_ccpipe.hpp)
+    const int ne_wg = std::max(1, std::min(std::max(h->n_cu / 2, h->n_cu - T), nodes_max));
     const int last = T > 1 ? nbat : nbat - 1;
     for (int l = -1; l <= last; ++l) {
         const bool any_eval = (l + 1 < nbat) || (T > 1 && l >= 0 && l < nbat);

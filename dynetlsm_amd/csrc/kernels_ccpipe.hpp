@@ -35,6 +35,8 @@ constexpr int CP_WAVES = CP_THREADS / 64;
 // (12 / 24 up front measured best at config 4: 8 / 16 1637, 10 / 20 1679, 12 / 24 1731-1744,
 // 14 / 24 1739, 12 / 32 1700, 16 / 32 1557 it/s - every own entry is an LDS read per pass)
 constexpr int CP_OWN_REGS = 12;         // own entries a resolver thread keeps in registers
+constexpr int CP_OWN_LDS = 4;           // ... and the next ones in LDS (one node in a hundred has more than 12,
+                                        // so every other wavefront holds one: a trip to memory per pass otherwise)
 
 struct CcPipeBuf {
     double *prop;            // [T][N][2D + 2] : x1[D], u, (unused), x0[D] (snapshot)
@@ -45,18 +47,21 @@ struct CcPipeBuf {
     double *cur, *snap;      // [T][N][RW] : (x[D], r) records of the current / the snapshot positions
     unsigned long long *accmask;   // [T][CP_WAVES] : accepted nodes of the last resolved batch
     const int32_t *nctrl;    // valid controls per (t, i, direction)
-    const int32_t *terms;    // [T][N][tw] : (in_deg, out_deg, nci, nco | in-edges, out-edges, in-controls, out-controls)
+    const int32_t *terms;    // [T][N][tw] : (in_deg, out_deg, nci, nco, adj_in, adj_out | in-edges, out-edges, in-controls, out-controls)
     int cap, nbat, tw;
 };
 
-// A node's gathered terms as ONE row (round 5): its four counts and then its in-edges, out-edges,
-// in-controls and out-controls back to back - the order cc_term walks.  The evaluator used to read
+// A node's gathered terms as ONE row (round 5): its four counts, the two control weights
+// adj = (N - deg - 1) / n_controls (directed_likelihoods_fast.pyx:131,170 - two float64 divisions per item
+// otherwise, ~60 of its ~800 vector instructions) and then its in-edges, out-edges, in-controls and
+// out-controls back to back.  The evaluator used to read
 // the counts first and the four lists behind them (two round trips through a memory system that
 // 2560 wavefronts of gathers keep busy: ~1.9 us each, profiles/r05_ccpipe_timing.json); with the
 // row it requests the counts and the first 256 indices at once, as coalesced 256-byte reads.  The
 // rows change only when the edge tables or the controls do (upload / set / resample: every
 // n_resample_control = 100 iterations), k_ccpipe_terms rebuilds them then.
-__host__ __device__ constexpr int cp_terms_width(int cap) { return (4 + cap + 3) / 4 * 4; }
+constexpr int CP_HDR = 8;           // int32 slots of a row's header
+__host__ __device__ constexpr int cp_terms_width(int cap) { return (CP_HDR + cap + 3) / 4 * 4; }
 __global__ __launch_bounds__(256) void k_ccpipe_terms(ChainView c, const int32_t *nctrl, int32_t *terms, int tw) {
     const long node = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -65,8 +70,10 @@ __global__ __launch_bounds__(256) void k_ccpipe_terms(ChainView c, const int32_t
     const int nci = nctrl[node * 2], nco = nctrl[node * 2 + 1];
     int32_t *row = terms + node * tw;
     if (lane < 4) row[lane] = lane == 0 ? in_deg : (lane == 1 ? out_deg : (lane == 2 ? nci : nco));
+    if (lane == 4) ((double *)row)[2] = (double)(c.N - in_deg - 1) / (double)nci;
+    if (lane == 5) ((double *)row)[3] = (double)(c.N - out_deg - 1) / (double)nco;
     const int total = in_deg + out_deg + nci + nco;
-    for (int q = lane; q < tw - 4; q += 64) {
+    for (int q = lane; q < tw - CP_HDR; q += 64) {
         int r = q, e = 0;
         if (q < total) {
             if (r < in_deg) e = c.in_edges[node * c.Din + r];
@@ -74,12 +81,14 @@ __global__ __launch_bounds__(256) void k_ccpipe_terms(ChainView c, const int32_t
             else if ((r -= out_deg) < nci) e = c.ctrl_in[node * c.C + r];
             else e = c.ctrl_out[node * c.C + (r - nci)];
         }
-        row[4 + q] = e;
+        row[CP_HDR + q] = e;
     }
 }
 
 // A gathered term needs its partner's position and radius: one record (32 bytes up to d = 3)
-// instead of two arrays halves the cache-line requests the evaluator is bound by.  `cur` follows
+// instead of two arrays halves the cache-line requests the evaluator is bound by.  The record holds
+// 1 / r (round 5): the linear predictor needs b / r, and a reciprocal per gathered term was five of
+// the evaluator's ~110 float64 instructions per term (the radii change once per iteration).  `cur` follows
 // the chain (the resolver writes accepted positions into it), `snap` keeps the positions of
 // the sweep's start for the nodes that are not resolved yet.
 __host__ __device__ constexpr int cp_record_width(int D) { return D + 1 <= 4 ? 4 : 8; }
@@ -93,7 +102,7 @@ __global__ __launch_bounds__(256) void k_ccpipe_pack(ChainView c, CcPipeBuf pb) 
     for (int d = 0; d < RW; ++d) rec[d] = 0.0;
 #pragma unroll
     for (int d = 0; d < D; ++d) rec[d] = c.X[q * D + d];
-    rec[D] = c.radii[q % c.N];
+    rec[D] = 1.0 / c.radii[q % c.N];
 #pragma unroll
     for (int d = 0; d < RW; d += 2) {
         *(double2 *)(pb.cur + q * RW + d) = make_double2(rec[d], rec[d + 1]);
@@ -112,37 +121,26 @@ struct CcNode {
 // at xn (directed_likelihoods_fast.pyx:107-180):
 //   edges    (eta1 - eta0) - [softplus(eta1) - softplus(eta0)]
 //   controls - adj [softplus(eta1) - softplus(eta0)],  adj = (N - deg - 1) / n_controls
-template <int D>
-__device__ __forceinline__ double cc_term_delta(const double *xn, const double *xk0,
-                                                const double *xk1, bool self, bool in_dir,
-                                                bool edge, double wsp, double bin, double bout,
-                                                double rj, double re, int squared) {
-    const double d0 = self ? 0.0 : dist_of<D>(xn, xk0, squared);
-    const double d1 = self ? 0.0 : dist_of<D>(xn, xk1, squared);
-    const double e0 = in_dir ? bin * (1 - d0 / rj) + bout * (1 - d0 / re)
-                             : bin * (1 - d0 / re) + bout * (1 - d0 / rj);
-    const double e1 = in_dir ? bin * (1 - d1 / rj) + bout * (1 - d1 / re)
-                             : bin * (1 - d1 / re) + bout * (1 - d1 / rj);
-    const double sp = log((1.0 + exp(e1)) / (1.0 + exp(e0)));
-    return (edge ? (e1 - e0) : 0.0) - wsp * sp;
-}
-
-// The same with the lean forms of device_common.hpp: eta = B - d a with B = b_in + b_out and
-// a = b_in / r + b_out / r' from reciprocals (irj = 1 / r_k is the caller's, 1 / r_e a
-// v_rcp_f64 + two Newton steps), the correctly rounded lean root, the ~1 ulp lean exp and one
-// reciprocal instead of the division: a third of the instructions, equal to rounding.
+// With the lean forms of device_common.hpp: eta = B - d a with B = b_in + b_out and
+// a = b_in / r + b_out / r' from reciprocals (irj = 1 / r_k is the caller's, ire = 1 / r_e comes with
+// the partner's record), the lean root, the table exponential and one reciprocal instead of the
+// division: a third of the instructions of the plain expressions, equal to rounding.
 template <int D>
 __device__ __forceinline__ double cc_term_delta_fast(const double *xn, const double *xk0,
                                                      const double *xk1, bool self, bool in_dir,
                                                      bool edge, double wsp, double bin, double bout,
-                                                     double irj, double re, int squared) {
+                                                     double irj, double ire, int squared, const double *etab) {
     const double d0 = self ? 0.0 : dist_fast<D>(xn, xk0, squared);
     const double d1 = self ? 0.0 : dist_fast<D>(xn, xk1, squared);
-    const double ire = fast_rcp(re);
     const double a = in_dir ? fma(bin, irj, bout * ire) : fma(bin, ire, bout * irj);
     const double B = bin + bout;
     const double e0 = fma(-d0, a, B), e1 = fma(-d1, a, B);
-    const double sp = fast_log((1.0 + fast_exp(e1)) * fast_rcp(1.0 + fast_exp(e0)));
+    // (the 256-entry table exponential of device_common.hpp: 13 instructions + an LDS read for 18;
+    // the clamp keeps the table's index inside its range wherever a chain could go, and e^x is 0 in
+    // double below -745 anyway.  Its fill - a trip to memory and a workgroup barrier in front of the
+    // evaluators' first loads - costs less than the ten instructions per term: +1.7 % on config 4)
+    const double sp = fast_log((1.0 + tab_exp(fmax(e1, -1000.0), etab)) *
+                               fast_rcp(1.0 + tab_exp(fmax(e0, -1000.0), etab)));
     return (edge ? (e1 - e0) : 0.0) - wsp * sp;
 }
 
@@ -152,7 +150,7 @@ template <int D>
 struct CcWin {
     int e[CP_WCAP];            // partner | kind << 28
     double contrib[CP_WCAP];   // the term with the partner at its snapshot position
-    double re[CP_WCAP];        // the partner's radius
+    double re[CP_WCAP];        // 1 / the partner's radius
     double xp[CP_WCAP][D];     // the partner's proposal (requested with its record: round 5)
 };
 
@@ -165,28 +163,37 @@ struct CcWin {
 // mostly idle evaluation per chunk.
 template <int D>
 __device__ __forceinline__ void ccpipe_eval_item(const ChainView &c, const CcPipeBuf &pb, int be,
-                                                 int t, int k, int lane, CcWin<D> &sw) {
+                                                 int t, int k, int lane, CcWin<D> &sw, const double *etab) {
     constexpr int PW = 2 * D + 2;
     constexpr int RW = cp_record_width(D);
-    constexpr int NCH = 4;
+    constexpr int NCH = D <= 2 ? 4 : 2;      // 64-term chunks in flight (d = 3, 4: two - their records and proposals would spill)
     const int N = c.N;
     const int j0 = be * CP_B, jk = j0 + k;
     const int jprev = max(0, j0 - CP_B);       // nodes >= jprev: snapshot positions
     const int bb = be & 1;
     // the node's row: counts and the first 64 * NCH indices leave together
-    const int32_t *row = pb.terms + ((size_t)t * N + jk) * pb.tw;
+    // (every gather of the item is a 32-bit lane offset from a wave-uniform base: 64-bit lane addresses cost
+    // three vector instructions and two registers each, and the compiler hoisted and spilled the row's)
+    const char *row = (const char *)(pb.terms + ((size_t)t * N + jk) * pb.tw);
     const int4 hdr = *(const int4 *)row;
+    const double2 adj = *(const double2 *)(row + 16);
+    // (the lane as the row's offsets see it, opaque per item: the compiler otherwise hoists the four offsets
+    // out of the workgroup's item loop - a wavefront runs one item, rarely two - and spills them)
+    int lane_r = lane;
+    asm volatile("" : "+v"(lane_r));
+    constexpr uint32_t HB = CP_HDR * sizeof(int32_t);
     int e_first[NCH];
 #pragma unroll
-    for (int u = 0; u < NCH; ++u) e_first[u] = row[4 + min(64 * u + lane, pb.tw - 5)];
+    for (int u = 0; u < NCH; ++u)
+        e_first[u] = *(const int32_t *)(row + (HB + 4u * (uint32_t)min(64 * u + lane_r, pb.tw - CP_HDR - 1)));
     CcNode nd;
     nd.node = (size_t)t * N + jk;
     nd.in_deg = hdr.x; nd.out_deg = hdr.y; nd.nci = hdr.z; nd.nco = hdr.w;
-    nd.adj_in = (double)(N - nd.in_deg - 1) / (double)nd.nci;
-    nd.adj_out = (double)(N - nd.out_deg - 1) / (double)nd.nco;
+    nd.adj_in = adj.x; nd.adj_out = adj.y;
     nd.total = nd.in_deg + nd.out_deg + nd.nci + nd.nco;
     const int k_oe = nd.in_deg, k_ci = nd.in_deg + nd.out_deg, k_co = nd.in_deg + nd.out_deg + nd.nci;
     const double *cur = pb.cur + (size_t)t * N * RW, *snap = pb.snap + (size_t)t * N * RW;
+    const uint32_t snap_off = (uint32_t)((const char *)snap - (const char *)cur);
     const double *props = pb.prop + (size_t)t * N * PW;
     double xk0[D], xk1[D];
 #pragma unroll
@@ -195,7 +202,7 @@ __device__ __forceinline__ void ccpipe_eval_item(const ChainView &c, const CcPip
         xk1[d] = props[(size_t)jk * PW + d];
     }
     const double bin = c.intercept[0], bout = c.intercept[1];
-    const double irj = 1.0 / c.radii[jk];
+    const double irj = snap[(size_t)jk * RW + D];          // 1 / r_k (k_ccpipe_pack)
     const size_t lbase = ((size_t)bb * c.T + t) * pb.cap * CP_B + k;      // + entry * CP_B
     const unsigned long long below = (1ull << lane) - 1ull;
     double acc = 0.0;
@@ -216,7 +223,7 @@ __device__ __forceinline__ void ccpipe_eval_item(const ChainView &c, const CcPip
                 const bool in_dir = (kind == 0 || kind == 2);
                 const double wsp = kind < 2 ? 1.0 : (kind == 2 ? nd.adj_in : nd.adj_out);
                 h = cc_term_delta_fast<D>(xe1, xk0, xk1, false, in_dir, kind < 2, wsp, bin, bout, irj,
-                                          sw.re[i], c.squared) - sw.contrib[i];
+                                          sw.re[i], c.squared, etab) - sw.contrib[i];
             }
             const bool isx = live && e < j0, iso = live && e >= j0;
             const unsigned long long mx = __ballot(isx), mo = __ballot(iso);
@@ -239,7 +246,8 @@ __device__ __forceinline__ void ccpipe_eval_item(const ChainView &c, const CcPip
         for (int u = 0; u < NCH; ++u) {
             const int q = q0 + 64 * u + lane;
             kind[u] = q < k_oe ? 0 : (q < k_ci ? 1 : (q < k_co ? 2 : 3));
-            const int er = q0 == 0 ? e_first[u] : row[4 + min(q, pb.tw - 5)];
+            const int er = q0 == 0 ? e_first[u]
+                                   : *(const int32_t *)(row + (HB + 4u * (uint32_t)min(q, pb.tw - CP_HDR - 1)));
             e[u] = q < nd.total ? er : -1;
         }
         double xe[NCH][D], re[NCH], xp[NCH][D];
@@ -247,15 +255,18 @@ __device__ __forceinline__ void ccpipe_eval_item(const ChainView &c, const CcPip
 #pragma unroll
         for (int u = 0; u < NCH; ++u) {
             const int ee = max(e[u], 0);
-            const double *src = (ee < jprev ? cur : snap) + (size_t)ee * RW;
+            // (`snap` lies behind `cur` in one allocation: the choice is part of the lane's offset)
+            const double *src = (const double *)((const char *)cur + (__umul24((uint32_t)ee, (uint32_t)(RW * sizeof(double))) +
+                                                                     (ee < jprev ? 0u : snap_off)));
 #pragma unroll
             for (int d = 0; d < D; ++d) xe[u][d] = src[d];
             re[u] = src[D];
             // a partner inside the window gets its second evaluation at its proposal: requested now,
             // with the record, instead of one round trip later (flush reads it from LDS)
             win[u] = e[u] >= jprev && e[u] < jk;
+            const double *prow = (const double *)((const char *)props + __umul24((uint32_t)ee, (uint32_t)(PW * sizeof(double))));
 #pragma unroll
-            for (int d = 0; d < D; ++d) xp[u][d] = win[u] ? props[(size_t)ee * PW + d] : 0.0;
+            for (int d = 0; d < D; ++d) xp[u][d] = win[u] ? prow[d] : 0.0;
         }
 #pragma unroll
         for (int u = 0; u < NCH; ++u) {
@@ -265,7 +276,7 @@ __device__ __forceinline__ void ccpipe_eval_item(const ChainView &c, const CcPip
                 const bool in_dir = (kind[u] == 0 || kind[u] == 2);
                 const double wsp = kind[u] < 2 ? 1.0 : (kind[u] == 2 ? nd.adj_in : nd.adj_out);
                 contrib = cc_term_delta_fast<D>(xe[u], xk0, xk1, e[u] == jk, in_dir, kind[u] < 2, wsp,
-                                                bin, bout, irj, re[u], c.squared);
+                                                bin, bout, irj, re[u], c.squared, etab);
                 acc += contrib;
             }
             const unsigned long long mw = __ballot(win[u]);   // its acceptance changes this term
@@ -313,7 +324,7 @@ template <int D>
 __device__ __forceinline__ void ccpipe_resolve(const ChainView &c, const CcPipeBuf &pb, int b, int t,
                                                unsigned long long (*sMask)[CP_WAVES],
                                                unsigned long long *sPrev, int *sChanged,
-                                               double *sCross
+                                               double *sCross, double (*sOv)[CP_B], int (*sOi)[CP_B]
 #ifdef DLSM_PIPE_TIMING
                                                , int tl
 #endif
@@ -406,6 +417,14 @@ __device__ __forceinline__ void ccpipe_resolve(const ChainView &c, const CcPipeB
             oi[e] = pb.oidx[p];
             ov[e] = pb.oval[p];
         }
+        int oi2[CP_OWN_LDS];
+        double ov2[CP_OWN_LDS];
+#pragma unroll
+        for (int e = 0; e < CP_OWN_LDS; ++e) {
+            const size_t p = lbase + (size_t)min(CP_OWN_REGS + e, pb.cap - 1) * CP_B;
+            oi2[e] = pb.oidx[p];
+            ov2[e] = pb.oval[p];
+        }
         r = pb.tot[slot];
         const double *pr = pb.prop + ((size_t)t * N + j0 + kc) * PW;
         double x0[D];
@@ -418,6 +437,11 @@ __device__ __forceinline__ void ccpipe_resolve(const ChainView &c, const CcPipeB
         const size_t tjc = (size_t)t * N + j0 + kc;
         st = c.step[tjc];
         na = c.nacc[tjc]; ns = c.nsteps[tjc]; un = c.until[tjc];
+#pragma unroll
+        for (int e = 0; e < CP_OWN_LDS; ++e) {          // (this thread's own column: read back by itself only)
+            sOi[e][k] = CP_OWN_REGS + e < nown ? oi2[e] : 0;
+            sOv[e][k] = ov2[e];
+        }
         cc_barrier_arrive_after_lds_stores();          // (the upper half's barrier; sPrev is this half's store)
     }
     DLSM_CC_STAMP(2, r)
@@ -430,33 +454,72 @@ __device__ __forceinline__ void ccpipe_resolve(const ChainView &c, const CcPipeB
     // the batch's nodes iterate on their own: a pass reads the other wavefronts' mask words as they
     // are at that moment (whatever a neighbour has already corrected is used at once, Gauss-Seidel
     // fashion, instead of one barrier later), re-ballots, and publishes its word only when it
-    // changed - word first, then the version counter sCtl[0].  A wavefront that has seen two passes
-    // in a row with the same version and no change of its own files that version in sCtl[1 + w];
-    // the system is solved when every wavefront's filed version IS the current one: word stores
-    // precede their version increment, so a store still in flight belongs to a wavefront whose own
-    // filed version must then predate it, and the earliest such store would have had to come from
-    // reads identical to the ones that produced no change - the words are a fixed point, and the
-    // fixed point of the triangular system is the sequential scan's result.  (The barrier form was
-    // ~10 passes of 0.45 us each, half of the resolver: profiles/r04_ccpipe_timing.json.)
-    volatile unsigned long long *sW = sMask[0];
-    volatile int *sCtl = sChanged;                      // [0] version, [1 + w] version filed by wavefront w
+    // changed - word first, then the version counter sCtl[0] (release).  A wavefront whose last pass
+    // changed nothing and was based on the version it still reads stands at that version: it files the
+    // version in sCtl[1 + w] and polls (one LDS read) instead of recomputing.  The system is solved
+    // when all eight have filed the CURRENT version v: a wavefront that has filed v recomputes only
+    // after the version has moved, a wavefront that changes its word at v never files v, so eight
+    // filings of v mean no word changed while the version was v, and every pass behind a filing read
+    // exactly those words (a word's store precedes the increment that ends the version it was
+    // computed at) - they are a fixed point, and the fixed point of the triangular system is the
+    // sequential scan's result.  (The barrier form cost ~10 passes x 0.45 us for every wavefront.)
+    unsigned long long *sW = sMask[0];
+    uint32_t *sW32 = (uint32_t *)sMask[0];              // (bit b of word w = bit b & 31 of half-word 2 w + (b >> 5))
+    int *sCtl = sChanged;                               // [0] version, [1 + w] version filed by wavefront w
     constexpr int NRW = CP_B / 64;                      // wavefronts that own nodes
+    // (relaxed workgroup-scope atomics, not `volatile`: a volatile access is followed by a full wait in
+    // this compiler, which made a pass fourteen LDS round trips one behind the other - 0.9 us; the
+    // atomics are re-read every pass like volatile ones and their waits are batched)
+#define CC_LD64(P_) __hip_atomic_load((P_), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define CC_LD32(P_) __hip_atomic_load((P_), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
     unsigned long long mine = __ballot(valid && !(lu >= r));
     if (!upper && lane == 0) { sW[wave] = mine; sCtl[1 + wave] = -1; }
     if (tid == 0) sCtl[0] = 0;
     __syncthreads();
     DLSM_CC_STAMP(3, ov[0])
     if (!upper) {
-        int last_v = -2;
-        bool quiet = false;                             // the previous pass changed nothing
-        for (int pass = 0; pass < (1 << 20); ++pass) {
-            const int v = sCtl[0];
-            const int filed = sCtl[1 + (lane & (NRW - 1))];     // lane w: the version wavefront w has filed
-            double s_own = 0.0;
+        int computed_v = -2, filed_v = -2;                  // version my last pass was based on / I have filed
+        bool quiet = false;                                 // ... and that pass changed nothing
+        for (int spin = 0; spin < (1 << 22); ++spin) {
+            const int v = CC_LD32(&sCtl[0]);
+            if (quiet && v == computed_v) {
+                // nothing has been published since the version read in front of my last pass, and that pass
+                // changed nothing: my word stands at version v.  File it (once) and poll - a poll is one LDS
+                // round trip and leaves the SIMD's issue slots to the wavefronts that still compute.
+                // (Requesting the pass's words with every poll - one round trip less per link of a chain of
+                // flips - measured 0.4 % slower.)
+                if (filed_v != v) {
+                    if (lane == 0) __hip_atomic_store(&sCtl[1 + wave], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    filed_v = v;
+                }
+                const int filed = CC_LD32(&sCtl[1 + (lane & (NRW - 1))]);   // lane w: the version wavefront w has filed
+                if (__ballot(filed != v) == 0ull) break;        // every wavefront stands at the current version
+                continue;
+            }
+            computed_v = v;                                 // (read BEFORE the words of this pass)
+            uint32_t wd[CP_OWN_REGS];                       // every word of the pass requested before the first use
+#pragma unroll
+            for (int e = 0; e < CP_OWN_REGS; ++e) wd[e] = CC_LD32(&sW32[oi[e] >> 5]);
+            double tm[CP_OWN_REGS];
 #pragma unroll
             for (int e = 0; e < CP_OWN_REGS; ++e)
-                if (e < nown && ((sW[oi[e] >> 6] >> (oi[e] & 63)) & 1ull)) s_own += ov[e];
-            for (int e0 = CP_OWN_REGS; e0 < nown; e0 += 8) {    // the long list: from memory, eight
+                tm[e] = (e < nown && ((wd[e] >> (oi[e] & 31)) & 1u)) ? ov[e] : 0.0;
+            static_assert(CP_OWN_REGS == 12, "the sum below is a tree over twelve terms");
+            double s_own = (((tm[0] + tm[1]) + (tm[2] + tm[3])) + ((tm[4] + tm[5]) + (tm[6] + tm[7]))) +
+                           ((tm[8] + tm[9]) + (tm[10] + tm[11]));
+            if (nown > CP_OWN_REGS) {                           // the next entries: from this thread's LDS column
+                int m2[CP_OWN_LDS];
+                uint32_t w2[CP_OWN_LDS];
+                double h2[CP_OWN_LDS];
+#pragma unroll
+                for (int e = 0; e < CP_OWN_LDS; ++e) { m2[e] = sOi[e][k]; h2[e] = sOv[e][k]; }
+#pragma unroll
+                for (int e = 0; e < CP_OWN_LDS; ++e) w2[e] = CC_LD32(&sW32[m2[e] >> 5]);
+#pragma unroll
+                for (int e = 0; e < CP_OWN_LDS; ++e)
+                    s_own += (CP_OWN_REGS + e < nown && ((w2[e] >> (m2[e] & 31)) & 1u)) ? h2[e] : 0.0;
+            }
+            for (int e0 = CP_OWN_REGS + CP_OWN_LDS; e0 < nown; e0 += 8) {   // the long list: from memory, eight
                 int m[8];                                       // loads in flight per trip
                 double h[8];
 #pragma unroll
@@ -467,24 +530,25 @@ __device__ __forceinline__ void ccpipe_resolve(const ChainView &c, const CcPipeB
                 }
 #pragma unroll
                 for (int u = 0; u < 8; ++u)
-                    if (e0 + u < nown && ((sW[m[u] >> 6] >> (m[u] & 63)) & 1ull)) s_own += h[u];
+                    if (e0 + u < nown && ((CC_LD64(&sW[m[u] >> 6]) >> (m[u] & 63)) & 1ull)) s_own += h[u];
             }
-            if (__ballot(filed != v) == 0ull) break;            // every wavefront has filed the current version
             const unsigned long long g = __ballot(valid && !(lu >= r + s_own));
-            if (g != mine) {
+            quiet = g == mine;
+            if (!quiet) {
                 mine = g;
                 if (lane == 0) {
-                    sW[wave] = g;                       // the word before the version (release)
-                    __hip_atomic_fetch_add(&sChanged[0], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_store(&sW[wave], g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    // the word before the version (release)
+                    __hip_atomic_fetch_add(&sCtl[0], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
-                quiet = false;
-            } else {
-                if (quiet && last_v == v && lane == 0) sCtl[1 + wave] = v;
-                quiet = true;
             }
-            last_v = v;
+#ifdef DLSM_PIPE_TIMING
+            cts[6] += 1;
+#endif
         }
     }
+#undef CC_LD64
+#undef CC_LD32
     DLSM_CC_STAMP(4, (double)lane)
     const int accepted = (int)((mine >> lane) & 1ull);
     if (valid) {
@@ -502,7 +566,7 @@ __device__ __forceinline__ void ccpipe_resolve(const ChainView &c, const CcPipeB
     if (!upper && lane == 0) accg[wave] = mine;
 #ifdef DLSM_PIPE_TIMING
     DLSM_CC_STAMP(5, (double)lane)
-    if (tid == 0 && tl >= 0 && tl < 32 && t < 16) for (int i = 0; i < 6; ++i) g_cc_res_t[tl][t][i] = cts[i];
+    if (tid == 0 && tl >= 0 && tl < 32 && t < 16) for (int i = 0; i < 7; ++i) g_cc_res_t[tl][t][i] = cts[i];
 #endif
 }
 
@@ -514,18 +578,23 @@ __global__ __launch_bounds__(CP_THREADS) void k_ccpipe_step(ChainView c, CcPipeB
     __shared__ unsigned long long sPrev[CP_WAVES];
     __shared__ int sChanged[1 + CP_B / 64];
     __shared__ double sCross[CP_B];
+    __shared__ double sOv[CP_OWN_LDS][CP_B];
+    __shared__ int sOi[CP_OWN_LDS][CP_B];
     __shared__ CcWin<D> sWin[CP_WAVES];
     const int T = c.T;
     if ((int)blockIdx.x < T) {
         const int t = blockIdx.x;
         const int b = l - (t & 1);
-        if (b >= 0 && b < pb.nbat) ccpipe_resolve<D>(c, pb, b, t, sMask, sPrev, sChanged, sCross
+        if (b >= 0 && b < pb.nbat) ccpipe_resolve<D>(c, pb, b, t, sMask, sPrev, sChanged, sCross, sOv, sOi
 #ifdef DLSM_PIPE_TIMING
                                                      , l + 1
 #endif
                                                      );
         return;
     }
+    __shared__ double sTab[EXPTAB_N];                   // 2^(j / 256): the evaluators' exponential
+    exp_table_fill(sTab, threadIdx.x);
+    __syncthreads();
     const int lane = threadIdx.x & 63;
     const int nE = (T + 1) / 2, nO = T / 2;
     const int beE = l + 1, beO = l;
@@ -533,8 +602,12 @@ __global__ __launch_bounds__(CP_THREADS) void k_ccpipe_step(ChainView c, CcPipeB
     const int nbO = (beO >= 0 && beO < pb.nbat) ? min(CP_B, c.N - beO * CP_B) : 0;
     const int nodesE = nE * nbE, nodes = nodesE + nO * nbO;
     const int nwaves = ((int)gridDim.x - T) * CP_WAVES;
+    // item q -> wavefront (q / workgroups) of workgroup (q % workgroups): a launch's items are spread over
+    // every evaluator CU (2560 items on 251 CUs: 10 or 11 wavefronts each, 2 - 3 per SIMD) instead of filling
+    // 160 CUs with four wavefronts per SIMD - the item is ~720 float64 vector instructions and four of them
+    // on one SIMD take turns issuing (round 5: profiles/r05_ccpipe_timing.json)
     const int gw = __builtin_amdgcn_readfirstlane(
-        ((int)blockIdx.x - T) * CP_WAVES + (int)(threadIdx.x >> 6));
+        (int)(threadIdx.x >> 6) * ((int)gridDim.x - T) + ((int)blockIdx.x - T));
     for (int q = gw; q < nodes; q += nwaves) {
         const bool odd = q >= nodesE;
         const int qq = odd ? q - nodesE : q;
@@ -545,7 +618,7 @@ __global__ __launch_bounds__(CP_THREADS) void k_ccpipe_step(ChainView c, CcPipeB
         unsigned long long cts[2];
         DLSM_CC_STAMP(0, (double)lane)
 #endif
-        ccpipe_eval_item<D>(c, pb, odd ? beO : beE, t, k, lane, sWin[threadIdx.x >> 6]);
+        ccpipe_eval_item<D>(c, pb, odd ? beO : beE, t, k, lane, sWin[threadIdx.x >> 6], sTab);
 #ifdef DLSM_PIPE_TIMING
         DLSM_CC_STAMP(1, (double)lane)
         if (lane == 0 && l + 1 >= 0 && l + 1 < 32 && gw < 4096) { g_cc_item_t[l + 1][gw][0] = cts[0]; g_cc_item_t[l + 1][gw][1] = cts[1]; }

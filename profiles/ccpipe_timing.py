@@ -50,6 +50,7 @@ for l in range(32):
         rel = (r[:, :6] - t0) * 0.01
         row['resolver_us_median'] = [round(float(np.median(rel[:, i])), 2) for i in range(6)]
         row['resolver_us_max'] = [round(float(rel[:, i].max()), 2) for i in range(6)]
+        row['resolver_fixed_point_passes_wave0'] = [int(v) for v in r[:, 6]]
     if it.size:
         rel = (it - t0) * 0.01
         row['evaluator_entry_us_p50_max'] = [round(float(np.median(rel[:, 0])), 2), round(float(rel[:, 0].max()), 2)]

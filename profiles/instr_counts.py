@@ -76,8 +76,22 @@ def _trips(ins, roots_per_trip):
         seg = ins[a:b]
         if sum(1 for l in seg if l.startswith('v_rsq_f64')) != roots_per_trip:
             continue
-        out.append((sum(1 for l in seg if l.startswith('v_')), b - a))
+        out.append((sum(1 for l in seg if l.startswith('v_')), b - a,
+                    sum(1 for l in seg if l.startswith(QUARTER_RATE))))
     return out
+
+
+# issue cost of a vector instruction in cycles, measured on the MI355X with four wavefronts per SIMD
+# (profiles/micro/valu_rates.hip -> profiles/r04_valu_rates.txt): v_fma_f64 and the other full-rate
+# instructions 4.15, the quarter-rate float64 transcendentals 16.1
+QUARTER_RATE = ('v_rsq_f64', 'v_rcp_f64', 'v_sqrt_f64')
+CYCLES_FULL, CYCLES_QUARTER = 4.15, 16.1
+
+
+def issue_slots(valu, quarter):
+    """issue slots (units of one full-rate instruction) of `valu` vector instructions of which
+    `quarter` are quarter-rate"""
+    return (valu - quarter) + quarter * CYCLES_QUARTER / CYCLES_FULL
 
 
 def _modal_run(trips, min_run):
@@ -88,7 +102,7 @@ def _modal_run(trips, min_run):
         while j + 1 < len(trips) and abs(trips[j + 1][1] - trips[i][1]) <= 2:
             j += 1
         if j - i + 1 >= min_run and (best is None or trips[i][0] < best[0]):
-            best = (trips[i][0], j - i + 1)
+            best = (trips[i][0], j - i + 1, trips[i][2])
         i = j + 1
     return best
 
@@ -112,15 +126,21 @@ def counts(lib_path=None):
         e = pos[g + 3]
         while e < len(ll) and not ll[e].startswith('s_cmp_ge'):
             e += 1
-        bodies.append((sum(1 for l in ll[a:e] if l.startswith('v_')), e - a))
+        bodies.append((sum(1 for l in ll[a:e] if l.startswith('v_')), e - a,
+                       sum(1 for l in ll[a:e] if l.startswith(QUARTER_RATE))))
     body = min(bodies) if bodies else None
     out = {'library': os.path.relpath(lib_path, ROOT)}
     if s:
         out['k_pipe_step<2,0,1>'] = {'valu_per_trip_of_64_neighbours_2_positions': s[0],
-                                    'unrolled_trips_found': s[1], 'valu_per_term': round(s[0] / 2.0, 1)}
+                                    'unrolled_trips_found': s[1], 'valu_per_term': round(s[0] / 2.0, 1),
+                                    'quarter_rate_per_trip': s[2],
+                                    'issue_slots_per_term': round(issue_slots(s[0], s[2]) / 2.0, 2)}
     if body:
         out['k_loglik_undirected<2,2>'] = {'valu_per_trip_of_4_rows_2_candidates': body[0],
-                                           'valu_per_candidate_term': round(body[0] / 8.0, 1)}
+                                           'valu_per_candidate_term': round(body[0] / 8.0, 1),
+                                           'quarter_rate_per_trip': body[2],
+                                           'issue_slots_per_candidate_term':
+                                               round(issue_slots(body[0], body[2]) / 8.0, 2)}
     return out
 
 

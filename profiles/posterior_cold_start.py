@@ -217,3 +217,71 @@ if 'c4m' in what:
     print(json.dumps(out))
     for ch in chains:
         ch.close()
+
+if 'c4long' in what:
+    # the same two chains over 100 000 iterations, in segments that carry the state over into a fresh
+    # handle (a 5000-row positions trace is 4 GB at this size; the segment's Philox chain id keys its draws)
+    from dynetlsm_amd.synthetic import synthetic_directed_from_model
+    T, N, Cn = 5, 10000, 100
+    net = synthetic_directed_from_model(T, N, 20.0, seed=0)
+    w = net['width']
+    seg, n_seg, n_res, n_tune_seg = 5000, 20, 100, 2
+    rs = np.random.RandomState(1)
+    X0 = net['X'] + 0.05 * w * rs.randn(*net['X'].shape)
+    state = [dict(X=X0, radii=net['radii'], b=net['intercepts'], grid=da.SamplerGrid(T, N, 0.02 * w, tune=seg, tune_interval=100),
+                  ist=None, rstep=175000.) for _ in range(2)]
+    traces = [[], []]
+    t0 = time.perf_counter()
+    for s in range(n_seg):
+        tuning = s < n_tune_seg
+        chains = []
+        for cid in (0, 1):
+            st = state[cid]
+            ch = da.Chain(T, N, 2, 'case_control', seed=20240229, chain_id=cid + 2 * s)
+            ch.upload_edges(net['in_edges'], net['out_edges'], net['degree'])
+            ch.resample_controls(0, Cn)
+            ch.set_positions(st['X']); ch.set_radii(st['radii']); ch.set_intercepts(st['b'])
+            ch.set_prior_random_walk(w * w, (0.1 * w) ** 2)
+            g = st['grid']
+            g.tune = seg if tuning else None
+            g.n_accepted[:] = 0; g.n_steps[:] = 0; g.steps_until_tune[:] = 100
+            ch.set_samplers(g)
+            ch.lsm_configure(net['intercepts'], 2.0, step_size_intercept=0.01, tune=seg if tuning else None,
+                             tune_interval=100, n_iter_procrustes=0, sweep_algo=0, step_size_radii=st['rstep'],
+                             radii_tune=seg if tuning else None, radii_tune_interval=100, state=st['ist'])
+            ch.trace_alloc(1 + seg, logp0=0.0)
+            chains.append(ch)
+        it = 1
+        while it <= seg:
+            nxt = min(seg + 1, (it // n_res + 1) * n_res)
+            for ch in chains:
+                if it % n_res == 0:
+                    ch.resample_controls(it, Cn)
+                ch.lsm_run(it, nxt - it, procrustes_ref=0)
+            it = nxt
+        for cid, ch in enumerate(chains):
+            ch.synchronize()
+            _, ics, lps = ch.trace_read(1, seg, positions=False)
+            traces[cid].append((ics.copy(), lps.copy()))
+            cfg = ch.lsm_get_config()
+            st = state[cid]
+            st['X'] = ch.get_positions(); st['radii'] = ch.get_radii(); st['b'] = ics[-1].copy()
+            st['grid'] = ch.get_samplers(st['grid'])
+            st['ist'] = [(cfg.i_step_size[k], 0, 0, 100) for k in range(2)]
+            st['rstep'] = float(cfg.r_step_size)
+            ch.close()
+    secs = time.perf_counter() - t0
+    b_in = np.stack([np.concatenate([x[0][:, 0] for x in tr]) for tr in traces])
+    b_out = np.stack([np.concatenate([x[0][:, 1] for x in tr]) for tr in traces])
+    lp = np.stack([np.concatenate([x[1] for x in tr]) for tr in traces])
+    out = {'config': 'C4 model network, 2 chains x %d iterations in segments of %d' % (seg * n_seg, seg),
+           'seconds': round(secs, 1)}
+    for nb in (10000, 20000, 40000):
+        for k in (20000, 40000, 60000, 80000):
+            if nb + k <= seg * n_seg:
+                out['rhat_burn%d_keep%d' % (nb, k)] = [round(split_rhat(x[:, nb:nb + k]), 4) for x in (b_in, b_out, lp)]
+    out['ess_after_20000'] = [[round(effective_n(x[20000:]), 0) for x in v] for v in (b_in, b_out, lp)]
+    out['b_in_block_means'] = [[round(float(x[i:i + 10000].mean()), 4) for i in range(0, x.shape[0], 10000)] for x in b_in]
+    out['b_out_block_means'] = [[round(float(x[i:i + 10000].mean()), 4) for i in range(0, x.shape[0], 10000)] for x in b_out]
+    out['b_sd_after_20000'] = [round(float(b_in[:, 20000:].std()), 5), round(float(b_out[:, 20000:].std()), 5)]
+    print(json.dumps(out))

@@ -46,6 +46,19 @@ def split_rhat(chains):
     return float(np.sqrt(((n - 1.0) / n * W + B / n) / W))
 
 
+def rhat(chains):
+    """the potential-scale-reduction factor WITHOUT splitting (Gelman & Rubin 1992): between- against
+    within-chain variance of whole chains - it asks whether the chains sit in the same place; the split form
+    above additionally asks every chain to be stationary over its own length"""
+    c = np.asarray(chains, dtype=np.float64)
+    n = c.shape[1]
+    W = c.var(axis=1, ddof=1).mean()
+    B = n * c.mean(axis=1).var(ddof=1)
+    if W == 0.0:
+        return 1.0
+    return float(np.sqrt(((n - 1.0) / n * W + B / n) / W))
+
+
 def pooled_mean_and_se(chains, maxlags=100):
     """mean over all chains and its Monte Carlo standard error (independent chains: the
     per-chain errors add in quadrature)"""
