@@ -15,6 +15,7 @@
 #include "device_common.hpp"
 #include "kernels_labels.hpp"
 #include "kernels_hdp.hpp"
+#include "cc_rows.hpp"
 #include "kernels_loglik.hpp"
 #include "kernels_hdploop.hpp"
 #include "kernels_sweep.hpp"
@@ -205,6 +206,44 @@ int check_ready_loglik(dlsm_chain *h) {
     return DLSM_OK;
 }
 
+// Case-control model: the valid controls per node and direction (k_count_controls) and the nodes' term rows
+// (cc_rows.hpp), rebuilt on the chain's stream when the edge tables or the controls have changed (upload /
+// set / resample clear the two flags).  alloc_only: buffers only (configure calls).
+static int ensure_cc_rows(dlsm_chain *h, bool alloc_only = false) {
+    const size_t TN = (size_t)h->T * h->N;
+    if (h->nctrl_cap < TN * 2) {
+        if (h->nctrl) hipFree(h->nctrl);
+        h->nctrl = nullptr; h->nctrl_cap = 0;
+        HIPCHK(h, hipMalloc((void **)&h->nctrl, TN * 2 * sizeof(int32_t)));
+        h->nctrl_cap = TN * 2;
+        h->nctrl_valid = false;
+    }
+    const int cap = std::max(1, h->Din + h->Dout + 2 * h->C);
+    const int tw = cp_terms_width(cap);
+    const size_t n_terms = TN * tw;
+    if (h->cc_terms_cap < n_terms || h->cc_tw != tw) {
+        if (h->cc_terms_cap < n_terms) {
+            if (h->cc_terms) hipFree(h->cc_terms);
+            h->cc_terms = nullptr; h->cc_terms_cap = 0;
+            HIPCHK(h, hipMalloc((void **)&h->cc_terms, n_terms * sizeof(int32_t)));
+            h->cc_terms_cap = n_terms;
+        }
+        h->cc_tw = tw; h->cc_terms_valid = false;
+    }
+    if (alloc_only) return DLSM_OK;
+    if (!h->nctrl_valid) {      // the control lists change only in set / resample
+        hipLaunchKernelGGL(k_count_controls, dim3((unsigned)((TN + 255) / 256)), dim3(256),
+                           0, h->stream, h->ctrl_in, h->ctrl_out, (long)TN, h->C, h->nctrl);
+        h->nctrl_valid = true; h->cc_terms_valid = false;
+    }
+    if (!h->cc_terms_valid) {
+        hipLaunchKernelGGL(k_cc_rows, dim3((unsigned)((TN + 3) / 4)), dim3(256), 0, h->stream, h->view(),
+                           h->nctrl, h->cc_terms, tw);
+        h->cc_terms_valid = true;
+    }
+    return DLSM_OK;
+}
+
 // the case-control pass with every load up front (k_loglik_casecontrol_pf): when a node's
 // out-edges fit one trip and its controls two
 static bool cc_prefetch_form(const dlsm_chain *h) {
@@ -254,7 +293,12 @@ int launch_loglik_records(dlsm_chain *h, int M, const double *d_ic,
                 hipLaunchKernelGGL((k_pack_xr<DD>), dim3((unsigned)((nodes + 255) / 256)), dim3(256), 0,
                                    h->stream, h->X, r0, M > 1 ? r1 : r0, (long)nodes, h->N, h->xr);
         }
-        if (pf && M == 1) hipLaunchKernelGGL((k_loglik_casecontrol_pf<DD, 1>), dim3(nb), dim3(256), 0, h->stream, v, cand, h->xr, h->partials, rslot);
+        // the rows form (round 5): out-edges and out-controls as dense 64-term trips from the node's row
+        const bool rows = pf && !getenv("DLSM_CC_LOGLIK_SLOTS");
+        if (rows) { int rc3 = ensure_cc_rows(h); if (rc3) return rc3; }
+        if (rows && M == 1) hipLaunchKernelGGL((k_loglik_casecontrol_rows<DD, 1>), dim3(nb), dim3(LLCR_THREADS), 0, h->stream, v, cand, h->xr, h->cc_terms, h->cc_tw, h->partials, rslot);
+        else if (rows) hipLaunchKernelGGL((k_loglik_casecontrol_rows<DD, 2>), dim3(nb), dim3(LLCR_THREADS), 0, h->stream, v, cand, h->xr, h->cc_terms, h->cc_tw, h->partials, 0);
+        else if (pf && M == 1) hipLaunchKernelGGL((k_loglik_casecontrol_pf<DD, 1>), dim3(nb), dim3(256), 0, h->stream, v, cand, h->xr, h->partials, rslot);
         else if (pf) hipLaunchKernelGGL((k_loglik_casecontrol_pf<DD, 2>), dim3(nb), dim3(256), 0, h->stream, v, cand, h->xr, h->partials, 0);
         else if (M == 1) hipLaunchKernelGGL((k_loglik_casecontrol<DD, 1>), dim3(nb), dim3(256), 0, h->stream, v, cand, h->partials);
         else hipLaunchKernelGGL((k_loglik_casecontrol<DD, 2>), dim3(nb), dim3(256), 0, h->stream, v, cand, h->partials);
@@ -1136,20 +1180,9 @@ static int launch_sweep_ccpipe(dlsm_chain *h, IterRef iter, bool alloc_only = fa
         h->pipe_cap = need;
     }
     // the nodes' term rows: rebuilt when the edge tables or the controls have changed
-    const int tw = cp_terms_width(cap);
-    const size_t n_terms = (size_t)T * N * tw;
-    if (h->cc_terms_cap < n_terms) {
-        if (h->cc_terms) hipFree(h->cc_terms);
-        h->cc_terms = nullptr; h->cc_terms_cap = 0; h->cc_terms_valid = false;
-        HIPCHK(h, hipMalloc((void **)&h->cc_terms, n_terms * sizeof(int32_t)));
-        h->cc_terms_cap = n_terms;
-    }
+    { int rc_ = ensure_cc_rows(h, alloc_only); if (rc_) return rc_; }
+    const int tw = h->cc_tw;
     if (alloc_only) return DLSM_OK;
-    if (!h->cc_terms_valid) {
-        hipLaunchKernelGGL(k_ccpipe_terms, dim3((unsigned)(((size_t)T * N + 3) / 4)), dim3(256), 0, h->stream,
-                           h->view(), h->nctrl, h->cc_terms, tw);
-        h->cc_terms_valid = true;
-    }
     CcPipeBuf pb;
     pb.prop = h->pipe; pb.tot = pb.prop + n_prop; pb.xval = pb.tot + n_tot; pb.oval = pb.xval + n_ent;
     double *consts = pb.oval + n_ent;
@@ -1194,20 +1227,8 @@ static int launch_sweep(dlsm_chain *h, IterRef iter, int algo, bool alloc_only =
     ChainView v = h->view();
     ProfScope ps(h, DLSM_K_SWEEP);
     if (h->model == DLSM_DIRECTED_CASE_CONTROL) {
-        // number of valid (non -1) controls per node and direction
-        const size_t TN = (size_t)h->T * h->N;
-        if (h->nctrl_cap < TN * 2) {
-            if (h->nctrl) hipFree(h->nctrl);
-            h->nctrl = nullptr; h->nctrl_cap = 0;
-            HIPCHK(h, hipMalloc((void **)&h->nctrl, TN * 2 * sizeof(int32_t)));
-            h->nctrl_cap = TN * 2;
-            h->nctrl_valid = false;
-        }
-        if (!h->nctrl_valid) {      // the control lists change only in set / resample
-            hipLaunchKernelGGL(k_count_controls, dim3((unsigned)((TN + 255) / 256)), dim3(256),
-                               0, h->stream, h->ctrl_in, h->ctrl_out, (long)TN, h->C, h->nctrl);
-            h->nctrl_valid = true;
-        }
+        // number of valid (non -1) controls per node and direction, and the nodes' term rows
+        { int rc_ = ensure_cc_rows(h, alloc_only); if (rc_) return rc_; }
         algo = resolve_sweep_algo(h, algo);
         if (alloc_only) {
             hipStreamSynchronize(h->stream);

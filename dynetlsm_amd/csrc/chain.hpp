@@ -159,8 +159,8 @@ struct dlsm_chain {
     int n_cu = 256;
     int32_t *nctrl = nullptr; size_t nctrl_cap = 0;     // valid controls per (t, i, dir)
     bool nctrl_valid = false;
-    // algo 5: a node's counts and its four index lists as one row (kernels_ccpipe.hpp, k_ccpipe_terms)
-    int32_t *cc_terms = nullptr; size_t cc_terms_cap = 0; bool cc_terms_valid = false;
+    // case-control model: a node's counts, control weights and its four index lists as one row (cc_rows.hpp)
+    int32_t *cc_terms = nullptr; size_t cc_terms_cap = 0; bool cc_terms_valid = false; int cc_tw = 0;
     unsigned long long *stamps = nullptr;               // in-kernel timestamps (profiling)
     size_t stamps_cap = 0, stamps_used = 0;             // in [start, end] pairs
     std::vector<std::pair<size_t, size_t>> stamp_launches;   // (first pair, pairs) per launch

@@ -26,6 +26,7 @@
 // one-batch lag of the odd slices, same decisions as the dense form and the CPU oracle.
 #pragma once
 #include "kernels_spec_pipe.hpp"
+#include "cc_rows.hpp"
 
 namespace dlsm {
 
@@ -50,40 +51,6 @@ struct CcPipeBuf {
     const int32_t *terms;    // [T][N][tw] : (in_deg, out_deg, nci, nco, adj_in, adj_out | in-edges, out-edges, in-controls, out-controls)
     int cap, nbat, tw;
 };
-
-// A node's gathered terms as ONE row (round 5): its four counts, the two control weights
-// adj = (N - deg - 1) / n_controls (directed_likelihoods_fast.pyx:131,170 - two float64 divisions per item
-// otherwise, ~60 of its ~800 vector instructions) and then its in-edges, out-edges, in-controls and
-// out-controls back to back.  The evaluator used to read
-// the counts first and the four lists behind them (two round trips through a memory system that
-// 2560 wavefronts of gathers keep busy: ~1.9 us each, profiles/r05_ccpipe_timing.json); with the
-// row it requests the counts and the first 256 indices at once, as coalesced 256-byte reads.  The
-// rows change only when the edge tables or the controls do (upload / set / resample: every
-// n_resample_control = 100 iterations), k_ccpipe_terms rebuilds them then.
-constexpr int CP_HDR = 8;           // int32 slots of a row's header
-__host__ __device__ constexpr int cp_terms_width(int cap) { return (CP_HDR + cap + 3) / 4 * 4; }
-__global__ __launch_bounds__(256) void k_ccpipe_terms(ChainView c, const int32_t *nctrl, int32_t *terms, int tw) {
-    const long node = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (node >= (long)c.T * c.N) return;
-    const int in_deg = c.degree[node * 2], out_deg = c.degree[node * 2 + 1];
-    const int nci = nctrl[node * 2], nco = nctrl[node * 2 + 1];
-    int32_t *row = terms + node * tw;
-    if (lane < 4) row[lane] = lane == 0 ? in_deg : (lane == 1 ? out_deg : (lane == 2 ? nci : nco));
-    if (lane == 4) ((double *)row)[2] = (double)(c.N - in_deg - 1) / (double)nci;
-    if (lane == 5) ((double *)row)[3] = (double)(c.N - out_deg - 1) / (double)nco;
-    const int total = in_deg + out_deg + nci + nco;
-    for (int q = lane; q < tw - CP_HDR; q += 64) {
-        int r = q, e = 0;
-        if (q < total) {
-            if (r < in_deg) e = c.in_edges[node * c.Din + r];
-            else if ((r -= in_deg) < out_deg) e = c.out_edges[node * c.Dout + r];
-            else if ((r -= out_deg) < nci) e = c.ctrl_in[node * c.C + r];
-            else e = c.ctrl_out[node * c.C + (r - nci)];
-        }
-        row[CP_HDR + q] = e;
-    }
-}
 
 // A gathered term needs its partner's position and radius: one record (32 bytes up to d = 3)
 // instead of two arrays halves the cache-line requests the evaluator is bound by.  The record holds
@@ -110,8 +77,7 @@ __global__ __launch_bounds__(256) void k_ccpipe_pack(ChainView c, CcPipeBuf pb) 
     }
 }
 
-// terms of the four lists of a node in one order: in-edges, out-edges, in-controls,
-// out-controls (kinds 0..3)
+// a node's term lists: kinds 0 in-edge, 1 out-edge, 2 in-control, 3 out-control
 struct CcNode {
     size_t node;
     int in_deg, out_deg, nci, nco, total;
@@ -191,7 +157,8 @@ __device__ __forceinline__ void ccpipe_eval_item(const ChainView &c, const CcPip
     nd.in_deg = hdr.x; nd.out_deg = hdr.y; nd.nci = hdr.z; nd.nco = hdr.w;
     nd.adj_in = adj.x; nd.adj_out = adj.y;
     nd.total = nd.in_deg + nd.out_deg + nd.nci + nd.nco;
-    const int k_oe = nd.in_deg, k_ci = nd.in_deg + nd.out_deg, k_co = nd.in_deg + nd.out_deg + nd.nci;
+    // (the row's order: out-edges, out-controls, in-edges, in-controls - cc_rows.hpp)
+    const int k_oc = nd.out_deg, k_ie = nd.out_deg + nd.nco, k_ic = nd.out_deg + nd.nco + nd.in_deg;
     const double *cur = pb.cur + (size_t)t * N * RW, *snap = pb.snap + (size_t)t * N * RW;
     const uint32_t snap_off = (uint32_t)((const char *)snap - (const char *)cur);
     const double *props = pb.prop + (size_t)t * N * PW;
@@ -245,7 +212,7 @@ __device__ __forceinline__ void ccpipe_eval_item(const ChainView &c, const CcPip
 #pragma unroll
         for (int u = 0; u < NCH; ++u) {
             const int q = q0 + 64 * u + lane;
-            kind[u] = q < k_oe ? 0 : (q < k_ci ? 1 : (q < k_co ? 2 : 3));
+            kind[u] = q < k_oc ? 1 : (q < k_ie ? 3 : (q < k_ic ? 0 : 2));
             const int er = q0 == 0 ? e_first[u]
                                    : *(const int32_t *)(row + (HB + 4u * (uint32_t)min(q, pb.tw - CP_HDR - 1)));
             e[u] = q < nd.total ? er : -1;

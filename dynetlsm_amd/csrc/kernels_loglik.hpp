@@ -733,6 +733,152 @@ __global__ __launch_bounds__(256) void k_loglik_casecontrol_pf(
     }
 }
 
+// The same from the nodes' term ROWS (cc_rows.hpp; round 5).  The prefetch form above gives a node three
+// fixed 64-lane slots - its out-edges (20 of 64 lanes busy at config 4), controls 0-63, controls 64-127
+// (36 of 64) - so 38 % of the lanes it computes and gathers for are idle.  A row lists the node's out-edges
+// and out-controls back to back at a known offset: ~120 terms fill TWO dense trips, their indices leave with
+// the row's header (no degree round trip), and the control weight (N - deg - 1) / n_controls comes with the
+// header instead of a float64 division per node.  Any out-degree and any number of controls: terms beyond
+// the first 128 of a node take further trips.  Same records, same arithmetic per term, the same record per
+// workgroup as the forms above; a lane tells edges from controls by its position in the row.
+constexpr int LLCR_THREADS = 512;        // 8 wavefronts x 2 nodes: the same LLCC_NODES nodes (and one record) per workgroup
+template <int D, int M>
+__global__ __launch_bounds__(LLCR_THREADS) void k_loglik_casecontrol_rows(
+    ChainView c, LoglikCand cand, const double *__restrict__ XR, const int32_t *__restrict__ terms, int tw,
+    double *__restrict__ partials, int rslot) {
+    constexpr int NWV = LLCR_THREADS / 64, NPW = LLCC_NODES / NWV;   // two nodes per wavefront: ~90 registers,
+    constexpr int RW = llcc_record_width(D);                         // five wavefronts per SIMD (four nodes: 150 - 180, two or three)
+    constexpr int NS = 2;                      // 64-term trips requested up front per node
+    __shared__ double sRed[NWV * M];
+    __shared__ __attribute__((aligned(16))) double sTab[EXPTAB_N];       // tab_exp (device_common.hpp)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    exp_table_fill(sTab, tid);                 // the first 256 threads: one entry each; barrier below
+    const long nodes = (long)c.T * c.N;
+    const bool two_radii = M > 1 && cand.radii[M - 1] != cand.radii[0];
+    long node[NPW];
+    int outdeg[NPW], nt[NPW], e[NPW][NS];
+    double adj[NPW];
+    const char *rows[NPW];
+    constexpr uint32_t HB = CP_HDR * sizeof(int32_t);
+#pragma unroll
+    for (int r = 0; r < NPW; ++r) {
+        node[r] = ((long)blockIdx.x * NPW + r) * NWV + wave;
+        const long nn = node[r] < nodes ? node[r] : 0;
+        rows[r] = (const char *)(terms + nn * tw);
+        const int4 hdr = *(const int4 *)rows[r];
+        adj[r] = *(const double *)(rows[r] + 24);                       // adj_out
+        outdeg[r] = node[r] < nodes ? hdr.y : 0;
+        nt[r] = node[r] < nodes ? hdr.y + hdr.w : 0;                    // out-edges + out-controls
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+            e[r][s] = *(const int32_t *)(rows[r] + (HB + 4u * (uint32_t)min(64 * s + lane, tw - CP_HDR - 1)));
+    }
+#pragma unroll
+    for (int r = 0; r < NPW; ++r)
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+            if (64 * s + lane >= nt[r]) e[r][s] = -1;
+    __syncthreads();                           // sTab visible
+    double xi[NPW][D], xe[NPW][NS][D], re0[NPW][NS], re1[NPW][NS], ri0[NPW], ri1[NPW];
+#pragma unroll
+    for (int r = 0; r < NPW; ++r) {
+        const long nn = node[r] < nodes ? node[r] : 0;
+        const int t = (int)(nn / c.N);
+        const char *Rt = (const char *)(XR + (size_t)t * c.N * RW);
+        {
+            const double *rec = XR + (size_t)nn * RW;
+#pragma unroll
+            for (int d = 0; d < D; ++d) xi[r][d] = rec[d];
+            ri0[r] = rec[D + (M == 1 ? rslot : 0)];
+            ri1[r] = rec[D + 1];
+        }
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const double *rec = (const double *)(Rt + __umul24((uint32_t)max(e[r][s], 0), (uint32_t)(RW * sizeof(double))));
+#pragma unroll
+            for (int d = 0; d < D; ++d) xe[r][s][d] = rec[d];
+            re0[r][s] = rec[D + (M == 1 ? rslot : 0)];
+            re1[r][s] = rec[D + 1];
+        }
+    }
+    double bin[M], bout[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) { bin[m] = cand.intercepts[2 * m]; bout[m] = cand.intercepts[2 * m + 1]; }
+    double L[M], Pe[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) { L[m] = 0.0; Pe[m] = 1.0; }
+    // one term: the partner's position xq and radii (rq0 / rq1) against node r's; edge: an out-edge
+    // (directed_likelihoods_fast.pyx:236-247), else an out-control (:250-268)
+#define DLSM_CCR_TERM(XQ_, RQ0_, RQ1_, EDGE_)                                                          \
+    {                                                                                                  \
+        const double dd_ = dist_fast<D>(XQ_, xi[r], c.squared);                                        \
+        const double ire0_ = fast_rcp(RQ0_);                                                           \
+        const double ire1_ = two_radii ? fast_rcp(RQ1_) : ire0_;                                       \
+        _Pragma("unroll")                                                                              \
+        for (int m = 0; m < M; ++m) {                                                                  \
+            const double ire_ = m == 0 ? ire0_ : ire1_;                                                \
+            const double eta_ = bin[m] * (1.0 - dd_ * ire_) + bout[m] * (1.0 - dd_ * iri[m]);          \
+            /* log(1 + e^eta) = eta beyond 130: such a term adds nothing to an edge's sum and eta to a \
+               control's (selects, not branches) */                                                    \
+            const bool big_ = eta_ > 130.0;                                                            \
+            const double f_ = big_ ? 1.0 : 1.0 + tab_exp(fmin(fmax(eta_, -700.0), 130.0), sTab);      \
+            L[m] += ((EDGE_) && !big_) ? eta_ : 0.0;                                                   \
+            ctl[m] += (!(EDGE_) && big_) ? eta_ : 0.0;                                                 \
+            if (__builtin_amdgcn_ballot_w64(Pe[m] > 1e250))                                            \
+                if (Pe[m] > 1e250) { L[m] -= fast_log(Pe[m]); Pe[m] = 1.0; }                           \
+            if (__builtin_amdgcn_ballot_w64(Pc[m] > 1e250))                                            \
+                if (Pc[m] > 1e250) { ctl[m] += fast_log(Pc[m]); Pc[m] = 1.0; }                         \
+            Pe[m] *= (EDGE_) ? f_ : 1.0;                                                               \
+            Pc[m] *= (EDGE_) ? 1.0 : f_;                                                               \
+        }                                                                                              \
+    }
+#pragma unroll
+    for (int r = 0; r < NPW; ++r) {
+        if (node[r] >= nodes) continue;                   // wave-uniform
+        double iri[M], Pc[M], ctl[M];
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            iri[m] = 1.0 / (m == 0 || !two_radii ? ri0[r] : ri1[r]);   // (same radii: slot 1 may hold a proposal)
+            Pc[m] = 1.0; ctl[m] = 0.0;
+        }
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            if (64 * s >= nt[r]) continue;                // wave-uniform
+            if (e[r][s] >= 0) DLSM_CCR_TERM(xe[r][s], re0[r][s], re1[r][s], 64 * s + lane < outdeg[r])
+        }
+        // a node with more than 64 NS out-edges and out-controls: its further terms trip by trip
+        const long nn = node[r];
+        const char *Rt = (const char *)(XR + (size_t)(nn / c.N) * c.N * RW);
+        for (int q0 = 64 * NS; q0 < nt[r]; q0 += 64) {
+            const int q = q0 + lane;
+            const int eq = q < nt[r] ? *(const int32_t *)(rows[r] + (HB + 4u * (uint32_t)q)) : -1;
+            if (eq >= 0) {
+                const double *rec = (const double *)(Rt + __umul24((uint32_t)eq, (uint32_t)(RW * sizeof(double))));
+                double xq[D];
+#pragma unroll
+                for (int d = 0; d < D; ++d) xq[d] = rec[d];
+                const double rq0 = rec[D + (M == 1 ? rslot : 0)], rq1 = rec[D + 1];
+                DLSM_CCR_TERM(xq, rq0, rq1, q < outdeg[r])
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < M; ++m) L[m] -= adj[r] * (ctl[m] + fast_log(Pc[m]));
+    }
+#undef DLSM_CCR_TERM
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+        L[m] -= fast_log(Pe[m]);
+        double v = wave_sum_all(L[m]);
+        if (lane == 0) sRed[wave * M + m] = v;
+    }
+    __syncthreads();
+    if (tid < M) {
+        double s = 0.0;
+        for (int w = 0; w < NWV; ++w) s += sRed[w * M + tid];
+        partials[(size_t)blockIdx.x * M + tid] = s;
+    }
+}
+
 // Deterministic final reduction of `nrec` records of `width` doubles: one
 // workgroup, fixed strided order + fixed tree.  out[q] = sum_r rec[r][q].
 // NF: records a thread has in flight at a time (12: its whole share in one round trip at configs 2 to 4; 4 where
