@@ -119,11 +119,16 @@ def parse(argv=None):
                     help='iterations of the per-kernel event phase that precedes the warm-up steps '
                          '(averages over 100 x 18 sweep launches; it also leaves the device in its '
                          'running state: a short timed window right after an idle device reads 3-5 %% low)')
-    ap.add_argument('--settle-steps', type=int, default=0,
+    ap.add_argument('--settle-steps', type=int, default=300,
                     help='plain iterations of every chain between the event-instrumented profile phase '
-                         'and the W warm-up steps (untimed, reported in the line).  Measured on MI355X: '
-                         '0 / 100 / 300 read 3850 / 3790-3825 / 3821-3836 it/s on --steps 20 --warmup 5: '
-                         'no gain, so off by default (the profile phase already precedes the warm-up)')
+                         'and the W warm-up steps (untimed, reported in the line as '
+                         'untimed_steps_before_warmup).  A call of the loop costs 20 / 140 / 130 us beyond its '
+                         'iterations (LSM / HDP-LPCM / case-control: profiles/per_call_cost.py), yet a 20-step '
+                         'window behind the profile phase - whose host-side event bookkeeping leaves the device '
+                         'idle for milliseconds - read 3 / 7 %% below a 200-step window: the device is not in its '
+                         'running state yet.  Measured on one MI355X (round 5, --steps 20 --warmup 5): LSM '
+                         '4515-4609 without / 4520-4679 with 300 settle steps (200 steps: 4714); HDP-LPCM '
+                         '3614-3679 / 3837-3857 (200 steps: 3940).  0 switches them off')
     ap.add_argument('--cpu-iters', type=int, default=8,
                     help='oracle iterations timed for cpu_baseline (0 = skip)')
     ap.add_argument('--cpu-procs', type=int, default=1,

@@ -431,6 +431,7 @@ void dlsm_destroy(dlsm_chain *h) {
     if (h->fork_stream) { hipStreamSynchronize(h->fork_stream); hipStreamDestroy(h->fork_stream); }
     if (h->fork_ev) hipEventDestroy(h->fork_ev);
     if (h->fork_flags) hipFree(h->fork_flags);
+    if (h->fork_err_host) hipHostFree(h->fork_err_host);
     g_live_chains.fetch_sub(1);
     if (h->graph_exec) hipGraphExecDestroy(h->graph_exec);
     if (h->graph) hipGraphDestroy(h->graph);
@@ -1035,12 +1036,11 @@ static void launch_pipe_step(dlsm_chain *h, const ChainView &v, const PipeBuf &p
 
 // the sticky error word of the HDP-LPCM loop's two queues: a bounded wait ran out of its budget
 static int check_pipe_err(dlsm_chain *h) {
-    if (h->fork_flags && h->fork_ticket > 0) {      // the HDP loop's two queues (kernels_hdploop.hpp, HdpFork)
-        int32_t e = 0;
-        HIPCHK(h, hipMemcpy(&e, h->fork_flags + HF_ERR, sizeof(e), hipMemcpyDeviceToHost));
+    if (h->fork_err_host && h->fork_ticket > 0) {   // the HDP loop's two queues (kernels_hdploop.hpp, HdpFork)
+        // (behind a synchronisation of the handle's stream: the word is host memory the device stores to)
+        const int32_t e = *(volatile int32_t *)h->fork_err_host;
         if (e != 0) {
-            HIPCHK(h, hipMemsetAsync(h->fork_flags + HF_ERR, 0, sizeof(e), h->stream));
-            HIPCHK(h, hipStreamSynchronize(h->stream));
+            *(volatile int32_t *)h->fork_err_host = 0;
             FAIL(h, DLSM_E_HIP, "HDP-LPCM loop: a hand-over between the chain's two queues ran out of its poll "
                  "budget (flags %d) - the chain's state is undefined (more streams alive than hardware "
                  "queues?); set the state again and run with DLSM_HDP_QUEUES=1", e);

@@ -38,7 +38,26 @@ void hdp_free_trace(dlsm_chain *h) {
     h->htr_z = nullptr; h->htr_n = 0; h->htr_K = 0;
 }
 
-constexpr int HDP_FORK_BUDGET = 1 << 22;            // polls of ~1 us (kernels_hdploop.hpp, HdpFork)
+// polls of ~1 us of the waits INSIDE kernels (kernels_hdploop.hpp, HdpFork); DLSM_HDP_FORK_BUDGET overrides it
+static int hdp_fork_budget() {
+    const char *e = getenv("DLSM_HDP_FORK_BUDGET");
+    return e ? atoi(e) : (1 << 22);
+}
+
+// "queue `s` goes on when flags[which] has reached the ticket": a wait of the QUEUE itself
+// (hipStreamWaitValue32: the command processor polls the word, no wavefront does and no budget runs out -
+// round-4 advice: a gate kernel enqueued while the chain's queue still held seconds of earlier work used up
+// its polls and turned a slow but correct run into an error) where the device offers it, else the
+// one-wavefront gate kernel with its poll budget.  DLSM_HDP_GATE=kernel forces the latter.
+static int hdp_queue_wait(dlsm_chain *h, hipStream_t s, const HdpFork &fk, int which) {
+    if (h->fork_wait_value) {
+        HIPCHK(h, hipStreamWaitValue32(s, h->fork_flags + which, (uint32_t)fk.ticket, hipStreamWaitValueGte,
+                                       0xFFFFFFFFu));
+        return DLSM_OK;
+    }
+    hipLaunchKernelGGL(k_hdp_gate, dim3(1), dim3(64), 0, s, fk, which);
+    return DLSM_OK;
+}
 
 template <int DD>
 int enqueue_hdp_iteration(dlsm_chain *h, int it, bool draw_next) {
@@ -117,8 +136,8 @@ int enqueue_hdp_iteration(dlsm_chain *h, int it, bool draw_next) {
     const bool fork = h->fork_armed && !directed;
     ChainView v = h->view();
     HdpLoopBuf hb = hdp_loop_buf(h);
-    HdpFork fk{nullptr, 0, 0};
-    if (fork) fk = HdpFork{h->fork_flags, ++h->fork_ticket, HDP_FORK_BUDGET};
+    HdpFork fk{nullptr, 0, 0, nullptr};
+    if (fork) fk = HdpFork{h->fork_flags, ++h->fork_ticket, hdp_fork_budget(), h->fork_err_dev};
     {   // label block update (sample_labels.py:134-190) with the transition matrices on the device
         ProfScope ps(h, DLSM_K_LABELS);
         rc = launch_sample_labels<DD>(h, v, (uint32_t)it, nullptr, h->stream,
@@ -128,7 +147,7 @@ int enqueue_hdp_iteration(dlsm_chain *h, int it, bool draw_next) {
     int nrec = 0;
     bool head = false;
     if (fork) {
-        hipLaunchKernelGGL(k_hdp_gate, dim3(1), dim3(64), 0, h->fork_stream, fk, (int)HF_CENTRED);
+        rc = hdp_queue_wait(h, h->fork_stream, fk, (int)HF_CENTRED); if (rc) return rc;
         hipStream_t keep = h->stream;
         h->stream = h->fork_stream; h->ll_beside_chain = true;
         rc = loglik_records(h, 2, h->lsm->cand, nullptr, nullptr, &nrec);
@@ -182,7 +201,7 @@ int enqueue_hdp_iteration(dlsm_chain *h, int it, bool draw_next) {
         hipLaunchKernelGGL(k_hdp_hypers, dim3(1), dim3(HH_THREADS), 0, h->stream, v, hb, h->hdp, tr, ir);
         // whatever follows on the chain's queue (a sweep with its own proposal pass) starts from the
         // settled intercept
-        if (fork) hipLaunchKernelGGL(k_hdp_gate, dim3(1), dim3(64), 0, h->stream, fk, (int)HF_SETTLED);
+        if (fork) { rc = hdp_queue_wait(h, h->stream, fk, (int)HF_SETTLED); if (rc) return rc; }
     }
     HIPCHK(h, hipGetLastError());
     return DLSM_OK;
@@ -243,6 +262,15 @@ int hdp_fork_arm(dlsm_chain *h) {
         HIPCHK(h, hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming));
         HIPCHK(h, hipMalloc((void **)&h->fork_flags, 64));
         HIPCHK(h, hipMemset(h->fork_flags, 0, 64));
+        // the sticky error word: host memory the device can store to (read by the host without a copy)
+        HIPCHK(h, hipHostMalloc((void **)&h->fork_err_host, 64, hipHostMallocMapped));
+        memset(h->fork_err_host, 0, 64);
+        HIPCHK(h, hipHostGetDevicePointer((void **)&h->fork_err_dev, h->fork_err_host, 0));
+        int can = 0;
+        if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, h->device) != hipSuccess) can = 0;
+        (void)hipGetLastError();
+        const char *eg = getenv("DLSM_HDP_GATE");
+        h->fork_wait_value = can != 0 && !(eg && strcmp(eg, "kernel") == 0);
         h->fork_ticket = 0;
     }
     h->fork_armed = true;

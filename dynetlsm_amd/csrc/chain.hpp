@@ -104,6 +104,8 @@ struct dlsm_chain {
     // update and the conjugate draws, handed over through device flags (kernels_hdploop.hpp, HdpFork)
     hipStream_t fork_stream = nullptr; hipEvent_t fork_ev = nullptr;
     int32_t *fork_flags = nullptr; int32_t fork_ticket = 0; bool fork_armed = false;
+    int32_t *fork_err_host = nullptr, *fork_err_dev = nullptr;      // sticky error word (mapped host memory)
+    bool fork_wait_value = false;           // the queues' waits are hipStreamWaitValue32 (else the gate kernel)
     bool ll_beside_chain = false;           // the next undirected likelihood pass runs on the second queue
     // the pipelined sweep in two pieces (HDP-LPCM loop on two queues): sweep_part 1 = its head only (the
     // proposal pass and the first, evaluate-only launch - neither reads what the conjugate draws produce);

@@ -116,7 +116,8 @@ __device__ __forceinline__ void dir_radii_terms_wg(const ChainView &c, const Lsm
         radii_alt[i] = x;
         if (xr) {
             constexpr int RW = llcc_record_width(D);
-            for (int t = 0; t < c.T; ++t) xr[((size_t)t * c.N + i) * RW + D + 1] = x;
+            const double ix = 1.0 / x;            // (the records hold RECIPROCAL radii: k_pack_xr)
+            for (int t = 0; t < c.T; ++t) xr[((size_t)t * c.N + i) * RW + D + 1] = ix;
         }
         v[0] = lgamma(step * x);
         v[1] = (step * x - 1.0) * log(r);
@@ -160,7 +161,8 @@ __device__ __forceinline__ void dir_radii_finish_wg(const ChainView &c, LsmDevic
             radii_alt[i] = x;
             if (xr) {
                 constexpr int RW = llcc_record_width(D);
-                for (int t = 0; t < c.T; ++t) xr[((size_t)t * N + i) * RW + D + 1] = x;
+                const double ix = 1.0 / x;        // (the records hold RECIPROCAL radii: k_pack_xr)
+                for (int t = 0; t < c.T; ++t) xr[((size_t)t * N + i) * RW + D + 1] = ix;
             }
             A += lgamma(step * x); B += (step * x - 1.0) * log(r);
             Cc += lgamma(step * r); E += (step * r - 1.0) * log(x);

