@@ -129,6 +129,9 @@ def parse(argv=None):
                          'running state yet.  Measured on one MI355X (round 5, --steps 20 --warmup 5): LSM '
                          '4515-4609 without / 4520-4679 with 300 settle steps (200 steps: 4714); HDP-LPCM '
                          '3614-3679 / 3837-3857 (200 steps: 3940).  0 switches them off')
+    ap.add_argument('--windows', type=int, default=1,
+                    help='diagnostic: time this many further windows of K steps behind the contract\'s one '
+                         '(reported as later_windows; `value` is always the first window)')
     ap.add_argument('--cpu-iters', type=int, default=8,
                     help='oracle iterations timed for cpu_baseline (0 = skip)')
     ap.add_argument('--cpu-procs', type=int, default=1,
@@ -224,7 +227,7 @@ class LsmWorkload(object):
             ch.set_samplers(SamplerGrid(T, N, step_size=0.1, tune=None))
             ch.lsm_configure([self.b_init], 2.0, step_size_intercept=0.1, tune=None,
                              n_iter_procrustes=0, sweep_algo=args.algo)
-            ch.trace_alloc(1 + W + K + P + args.settle_steps, logp0=0.0)
+            ch.trace_alloc(1 + W + K * max(args.windows, 1) + P + args.settle_steps, logp0=0.0)
         self.next_it = 1
 
     def run(self, count):
@@ -541,7 +544,7 @@ class HdpWorkload(object):
         self.models = []
         for c in range(C):
             m = DynamicNetworkHDPLPCM(
-                n_iter=1 + W + K + P + args.settle_steps, tune=None, burn=None, n_components=Kc, n_features=D,
+                n_iter=1 + W + K * max(args.windows, 1) + P + args.settle_steps, tune=None, burn=None, n_components=Kc, n_features=D,
                 random_state=1 + rank * C + c, device=local_rank, chain_id=rank * C + c,
                 sweep_algo=args.algo, selection_type='map')
             first = self.models[0].chain_ if self.models else None
@@ -736,7 +739,7 @@ class CcWorkload(object):
             ch.lsm_configure([1.0, 0.5], 2.0, step_size_intercept=0.1, tune=None,
                              n_iter_procrustes=0, sweep_algo=args.algo, step_size_radii=175000.,
                              radii_tune=None)
-            ch.trace_alloc(1 + W + K + P + args.settle_steps, logp0=0.0)
+            ch.trace_alloc(1 + W + K * max(args.windows, 1) + P + args.settle_steps, logp0=0.0)
             self.chains.append(ch)
         self.chain = self.chains[0]
         self.next_it = 1
@@ -910,6 +913,10 @@ def measure(wl, args, group):
     barriers + synchronisation, max over ranks; the final gather follows outside the timed region"""
     import torch
     K, W = args.steps, args.warmup
+    # (torch initialises its device state lazily: the first torch.cuda.synchronize() of the process here, not
+    # between the warm-up and the timed window)
+    torch.cuda.synchronize()
+    group.barrier()
     # the per-kernel profile (P steps with HIP events around every launch) comes first: it is
     # part of every run anyway, and placed here the timed steps do not start on a device that has
     # just sat idle through the host-side generation of the network
@@ -922,9 +929,13 @@ def measure(wl, args, group):
     wl.synchronize()
     torch.cuda.synchronize()
     group.barrier()
+    probe = getattr(wl, 'chain', None) if args.windows > 1 and args.chains_per_gpu == 1 else None
     t0 = time.perf_counter()
+    if probe is not None:
+        probe.timer_start()         # (diagnostic runs only: events on the chain's stream around the window)
     wl.run(K)
     wl.host_enqueue_seconds = time.perf_counter() - t0     # the host's share: the calls return when all is enqueued
+    wl.first_window_device_ms = probe.timer_stop() if probe is not None else None
     wl.synchronize()
     torch.cuda.synchronize()
     group.barrier()
@@ -934,6 +945,15 @@ def measure(wl, args, group):
     group.barrier()                 # what the closing barrier of the timed region costs by itself
     wl.barrier_ms = 1e3 * (time.perf_counter() - tb)
     wl.per_rank_seconds = [float(v[0]) for v in group.gather_arrays(np.array([mine]))]
+    wl.later_windows = []
+    for _ in range(max(args.windows, 1) - 1):       # (diagnostic: the same window again, behind the first)
+        group.barrier()
+        tw = time.perf_counter()
+        wl.run(K)
+        wl.synchronize()
+        torch.cuda.synchronize()
+        group.barrier()
+        wl.later_windows.append(group.max_over_ranks(time.perf_counter() - tw))
     acc = wl.acceptance()
     P = args.profile_steps if args.profile_steps > 0 else 0
     gathered = group.gather_results(wl.results(1 + P + args.settle_steps + W, K))
@@ -1008,6 +1028,9 @@ def run_rank(args):
                     # how long the host took to enqueue the timed steps (asynchronous launches): well below
                     # ms_per_step = the device is the limit, not the launching thread
                     'host_enqueue_ms_per_step': round(1e3 * wl.host_enqueue_seconds / K, 4),
+                    'later_windows_it_per_s': [round(world * C * K / sec, 1) for sec in wl.later_windows],
+                    'first_window_device_it_per_s': (round(K / (wl.first_window_device_ms * 1e-3), 1)
+                                                     if wl.first_window_device_ms else None),
                     'roofline': roofline, 'cpu_baseline': cpu,
                     'chain_summaries[intercept_mean,intercept_sd,logp_mean,logp_last]':
                         chain_summaries(gathered),
