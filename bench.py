@@ -834,7 +834,7 @@ class CcWorkload(object):
         rec_ll = float(T) * N * (float(self.mean_out) + self.C)     # out-edges + out-controls
         roofline_ll = {
             'bound': 'gather rate (one cache-line look-up per CU per clock)',
-            'kernel': 'k_loglik_casecontrol_pf',
+            'kernel': 'k_loglik_casecontrol_rows',
             'achieved': round(rec_ll / (ll_ms * 1e-3) / 1e9, 2), 'peak': GATHER_PEAK_GRECS,
             'unit': 'G records/s', 'frac': round(rec_ll / (ll_ms * 1e-3) / 1e9 / GATHER_PEAK_GRECS, 4),
             'records_per_pass': rec_ll, 'us_per_pass': round(1e3 * ll_ms, 2),

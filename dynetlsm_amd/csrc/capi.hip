@@ -244,11 +244,9 @@ static int ensure_cc_rows(dlsm_chain *h, bool alloc_only = false) {
     return DLSM_OK;
 }
 
-// the case-control pass with every load up front (k_loglik_casecontrol_pf): when a node's
-// out-edges fit one trip and its controls two
+// the case-control pass reads packed gather records (k_pack_xr) - any out-degree, any number of controls
 static bool cc_prefetch_form(const dlsm_chain *h) {
-    return h->model == DLSM_DIRECTED_CASE_CONTROL && h->Dout <= 64 && h->C <= 128 &&
-           !getenv("DLSM_CC_LOGLIK_PLAIN");
+    return h->model == DLSM_DIRECTED_CASE_CONTROL;
 }
 // its gather records (positions and both candidates' radii, one record per node)
 template <int DD>
@@ -293,15 +291,10 @@ int launch_loglik_records(dlsm_chain *h, int M, const double *d_ic,
                 hipLaunchKernelGGL((k_pack_xr<DD>), dim3((unsigned)((nodes + 255) / 256)), dim3(256), 0,
                                    h->stream, h->X, r0, M > 1 ? r1 : r0, (long)nodes, h->N, h->xr);
         }
-        // the rows form (round 5): out-edges and out-controls as dense 64-term trips from the node's row
-        const bool rows = pf && !getenv("DLSM_CC_LOGLIK_SLOTS");
-        if (rows) { int rc3 = ensure_cc_rows(h); if (rc3) return rc3; }
-        if (rows && M == 1) hipLaunchKernelGGL((k_loglik_casecontrol_rows<DD, 1>), dim3(nb), dim3(LLCR_THREADS), 0, h->stream, v, cand, h->xr, h->cc_terms, h->cc_tw, h->partials, rslot);
-        else if (rows) hipLaunchKernelGGL((k_loglik_casecontrol_rows<DD, 2>), dim3(nb), dim3(LLCR_THREADS), 0, h->stream, v, cand, h->xr, h->cc_terms, h->cc_tw, h->partials, 0);
-        else if (pf && M == 1) hipLaunchKernelGGL((k_loglik_casecontrol_pf<DD, 1>), dim3(nb), dim3(256), 0, h->stream, v, cand, h->xr, h->partials, rslot);
-        else if (pf) hipLaunchKernelGGL((k_loglik_casecontrol_pf<DD, 2>), dim3(nb), dim3(256), 0, h->stream, v, cand, h->xr, h->partials, 0);
-        else if (M == 1) hipLaunchKernelGGL((k_loglik_casecontrol<DD, 1>), dim3(nb), dim3(256), 0, h->stream, v, cand, h->partials);
-        else hipLaunchKernelGGL((k_loglik_casecontrol<DD, 2>), dim3(nb), dim3(256), 0, h->stream, v, cand, h->partials);
+        // out-edges and out-controls as dense 64-term trips from the node's row (cc_rows.hpp)
+        { int rc3 = ensure_cc_rows(h); if (rc3) return rc3; }
+        if (M == 1) hipLaunchKernelGGL((k_loglik_casecontrol_rows<DD, 1>), dim3(nb), dim3(LLCR_THREADS), 0, h->stream, v, cand, h->xr, h->cc_terms, h->cc_tw, h->partials, rslot);
+        else hipLaunchKernelGGL((k_loglik_casecontrol_rows<DD, 2>), dim3(nb), dim3(LLCR_THREADS), 0, h->stream, v, cand, h->xr, h->cc_terms, h->cc_tw, h->partials, 0);
     }
     HIPCHK(h, hipGetLastError());
     *nrec_out = nb;

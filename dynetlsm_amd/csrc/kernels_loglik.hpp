@@ -465,115 +465,12 @@ __global__ __launch_bounds__(LL_THREADS) void k_loglik_directed(
 }
 
 // ---------------------------------------------------------------------------
-// Case-control full log-likelihood (a6): one wave per (t, i); lanes stride over
-// the node's out-edges and out-controls (gathers of X / radii through L2).
-// Record per workgroup: [L_0 .. L_{M-1}]
+// Case-control full log-likelihood (a6, directed_likelihoods_fast.pyx:208-270): k_loglik_casecontrol_rows
+// below.  LLCC_NODES nodes per workgroup and one record [L_0 .. L_{M-1}] per workgroup: fewer records for
+// the single-workgroup reduction that follows.  (Rounds 1-4 had a wave-per-node form with the loads where
+// they were used and a prefetch form with three fixed 64-lane slots per node; the rows form replaced both.)
 // ---------------------------------------------------------------------------
 constexpr int LLCC_NODES = 16;
-
-template <int D, int M>
-__global__ __launch_bounds__(256) void k_loglik_casecontrol(
-    ChainView c, LoglikCand cand, double *__restrict__ partials) {
-    __shared__ double sRed[4 * M];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // LLCC_NODES nodes per workgroup (4 waves x LLCC_NODES / 4 in turn): fewer records for
-    // the single-workgroup reduction that follows
-    double L[M];
-#pragma unroll
-    for (int m = 0; m < M; ++m) L[m] = 0.0;
-    for (int rep = 0; rep < LLCC_NODES / 4; ++rep) {
-    const long node = ((long)blockIdx.x * (LLCC_NODES / 4) + rep) * 4 + wave;       // over T*N
-    if (node < (long)c.T * c.N) {
-        const int t = (int)(node / c.N), i = (int)(node % c.N);
-        const double *Xt = c.X + (size_t)t * c.N * D;
-        double xi[D];
-#pragma unroll
-        for (int d = 0; d < D; ++d) xi[d] = Xt[(size_t)i * D + d];
-        const int out_deg = c.degree[node * 2 + 1];
-        const int32_t *oe = c.out_edges + node * c.Dout;
-        const int32_t *co = c.ctrl_out + node * c.C;
-        double bin[M], bout[M], iri[M];
-#pragma unroll
-        for (int m = 0; m < M; ++m) {
-            bin[m] = cand.intercepts[2 * m];
-            bout[m] = cand.intercepts[2 * m + 1];
-            iri[m] = 1.0 / cand.radii[m][i];
-        }
-        // sum log(1 + e^eta) = log prod (1 + e^eta): per-lane running products, flushed
-        // through one log before they could leave the double range (a factor is at most
-        // e^130: beyond that log(1 + e^eta) = eta to the last bit and is added as such)
-        double Pe[M], Pc[M];
-#pragma unroll
-        for (int m = 0; m < M; ++m) { Pe[m] = 1.0; Pc[m] = 1.0; }
-        // out edges : directed_likelihoods_fast.pyx:236-247
-        for (int k = lane; k < out_deg; k += 64) {
-            const int e = oe[k];
-            const double dd = dist_fast<D>(&Xt[(size_t)e * D], xi, c.squared);
-            double ire[M];              // 1 / r_e per candidate (one reciprocal when they share radii)
-            ire[0] = fast_rcp(cand.radii[0][e]);
-#pragma unroll
-            for (int m = 1; m < M; ++m)
-                ire[m] = cand.radii[m] == cand.radii[0] ? ire[0] : fast_rcp(cand.radii[m][e]);
-#pragma unroll
-            for (int m = 0; m < M; ++m) {
-                const double eta = bin[m] * (1.0 - dd * ire[m]) + bout[m] * (1.0 - dd * iri[m]);
-                L[m] += eta;
-                if (eta > 130.0) { L[m] -= eta; continue; }      // log(1 + e^eta) = eta there
-                if (Pe[m] > 1e250) { L[m] -= log(Pe[m]); Pe[m] = 1.0; }
-                Pe[m] *= 1.0 + fast_exp(fmax(eta, -700.0));
-            }
-        }
-#pragma unroll
-        for (int m = 0; m < M; ++m) L[m] -= log(Pe[m]);
-        // control estimate : :250-268 (the list is -1 terminated)
-        double ctl[M];
-#pragma unroll
-        for (int m = 0; m < M; ++m) ctl[m] = 0.0;
-        int nctl = 0;
-        for (int k0 = 0; k0 < c.C; k0 += 64) {
-            const int k = k0 + lane;
-            const int e = k < c.C ? co[k] : -1;
-            unsigned long long valid = __ballot(e >= 0);
-            // entries after the first -1 are ignored (break at the sentinel)
-            unsigned long long inv = ~valid;
-            int first_bad = inv ? __builtin_ctzll(inv) : 64;
-            if (lane < first_bad) {
-                const double dd = dist_fast<D>(&Xt[(size_t)e * D], xi, c.squared);
-                double ire[M];
-                ire[0] = fast_rcp(cand.radii[0][e]);
-#pragma unroll
-                for (int m = 1; m < M; ++m)
-                    ire[m] = cand.radii[m] == cand.radii[0] ? ire[0] : fast_rcp(cand.radii[m][e]);
-#pragma unroll
-                for (int m = 0; m < M; ++m) {
-                    const double eta = bin[m] * (1.0 - dd * ire[m]) + bout[m] * (1.0 - dd * iri[m]);
-                    if (eta > 130.0) { ctl[m] += eta; continue; }
-                    if (Pc[m] > 1e250) { ctl[m] += log(Pc[m]); Pc[m] = 1.0; }
-                    Pc[m] *= 1.0 + fast_exp(fmax(eta, -700.0));
-                }
-            }
-            nctl += first_bad;
-            if (first_bad < 64) break;
-        }
-#pragma unroll
-        for (int m = 0; m < M; ++m) ctl[m] += log(Pc[m]);
-        const double adj = (double)(c.N - out_deg - 1) / (double)nctl;
-#pragma unroll
-        for (int m = 0; m < M; ++m) L[m] -= adj * ctl[m];
-    }
-    }
-#pragma unroll
-    for (int m = 0; m < M; ++m) {
-        double v = wave_sum_all(L[m]);
-        if (lane == 0) sRed[wave * M + m] = v;
-    }
-    __syncthreads();
-    if (tid < M) {
-        double s = 0.0;
-        for (int w = 0; w < 4; ++w) s += sRed[w * M + tid];
-        partials[(size_t)blockIdx.x * M + tid] = s;
-    }
-}
 
 // Packed records for the gathers of the case-control log-likelihood: [T][N][RW] doubles
 // (x[D], r, r') with r / r' the radii of the two candidates.  A term gathers the position and
@@ -604,145 +501,17 @@ __global__ __launch_bounds__(256) void k_pack_xr(const double *__restrict__ X,
         *(double2 *)(XR + q * RW + d) = make_double2(rec[d], rec[d + 1]);
 }
 
-// The same with every load of a wavefront's LLCC_NODES / 4 nodes issued before the first
-// use (degrees, then the out-edge and control indices, then the gathered positions and
-// radii): the kernel is a chain of gather latencies, and four nodes in turn are four chains.
-// For out-degrees <= 64 and at most 128 controls (the launcher checks); same record layout
-// and the same arithmetic per term.
-// rslot: which of the record's two radii a single candidate (M == 1) reads
-template <int D, int M>
-__global__ __launch_bounds__(256) void k_loglik_casecontrol_pf(
-    ChainView c, LoglikCand cand, const double *__restrict__ XR, double *__restrict__ partials,
-    int rslot) {
-    constexpr int NPW = LLCC_NODES / 4;
-    constexpr int RW = llcc_record_width(D);
-    __shared__ double sRed[4 * M];
-    __shared__ __attribute__((aligned(16))) double sTab[EXPTAB_N];       // tab_exp (device_common.hpp)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    exp_table_fill(sTab, tid);                 // 256 threads: one entry each; barrier below
-    const long nodes = (long)c.T * c.N;
-    const bool two_radii = M > 1 && cand.radii[M - 1] != cand.radii[0];
-    long node[NPW];
-    int outdeg[NPW], e[NPW][3], nctl[NPW];
-#pragma unroll
-    for (int r = 0; r < NPW; ++r) {
-        node[r] = ((long)blockIdx.x * NPW + r) * 4 + wave;
-        outdeg[r] = node[r] < nodes ? c.degree[node[r] * 2 + 1] : 0;
-    }
-    // (the edge row is requested whatever the degree turns out to be - Dout <= 64 slots - and cut
-    // to the degree afterwards: the index loads do not wait for the degree's round trip)
-#pragma unroll
-    for (int r = 0; r < NPW; ++r) {
-        const bool live = node[r] < nodes;
-        const long nn = live ? node[r] : 0;
-        e[r][0] = live && lane < c.Dout ? c.out_edges[nn * c.Dout + lane] : -1;
-        e[r][1] = live && lane < c.C ? c.ctrl_out[nn * c.C + lane] : -1;
-        e[r][2] = live && 64 + lane < c.C ? c.ctrl_out[nn * c.C + 64 + lane] : -1;
-    }
-#pragma unroll
-    for (int r = 0; r < NPW; ++r)
-        if (lane >= outdeg[r]) e[r][0] = -1;
-    __syncthreads();                           // sTab visible
-#pragma unroll
-    for (int r = 0; r < NPW; ++r) {     // the control list ends at its first -1
-        const unsigned long long bad1 = ~__ballot(e[r][1] >= 0);
-        const int fb1 = bad1 ? __builtin_ctzll(bad1) : 64;
-        if (lane >= fb1) e[r][1] = -1;
-        const unsigned long long bad2 = ~__ballot(e[r][2] >= 0);
-        const int fb2 = fb1 < 64 ? 0 : (bad2 ? __builtin_ctzll(bad2) : 64);
-        if (lane >= fb2) e[r][2] = -1;
-        nctl[r] = fb1 + fb2;
-    }
-    double xi[NPW][D], xe[NPW][3][D], re0[NPW][3], re1[NPW][3], ri0[NPW], ri1[NPW];
-#pragma unroll
-    for (int r = 0; r < NPW; ++r) {
-        const long nn = node[r] < nodes ? node[r] : 0;
-        const int t = (int)(nn / c.N);
-        const double *Rt = XR + (size_t)t * c.N * RW;
-        {
-            const double *rec = XR + (size_t)nn * RW;
-#pragma unroll
-            for (int d = 0; d < D; ++d) xi[r][d] = rec[d];
-            ri0[r] = rec[D + (M == 1 ? rslot : 0)];
-            ri1[r] = rec[D + 1];
-        }
-#pragma unroll
-        for (int s = 0; s < 3; ++s) {
-            const double *rec = Rt + (size_t)max(e[r][s], 0) * RW;
-#pragma unroll
-            for (int d = 0; d < D; ++d) xe[r][s][d] = rec[d];
-            re0[r][s] = rec[D + (M == 1 ? rslot : 0)];
-            re1[r][s] = rec[D + 1];
-        }
-    }
-    double bin[M], bout[M];
-#pragma unroll
-    for (int m = 0; m < M; ++m) { bin[m] = cand.intercepts[2 * m]; bout[m] = cand.intercepts[2 * m + 1]; }
-    double L[M], Pe[M];
-#pragma unroll
-    for (int m = 0; m < M; ++m) { L[m] = 0.0; Pe[m] = 1.0; }
-#pragma unroll
-    for (int r = 0; r < NPW; ++r) {
-        if (node[r] >= nodes) continue;                   // wave-uniform
-        double iri[M], Pc[M], ctl[M];
-#pragma unroll
-        for (int m = 0; m < M; ++m) {
-            iri[m] = m == 0 || !two_radii ? ri0[r] : ri1[r];   // (reciprocals; same radii: slot 1 may hold a proposal)
-            Pc[m] = 1.0; ctl[m] = 0.0;
-        }
-#pragma unroll
-        for (int s = 0; s < 3; ++s) {
-            if (e[r][s] < 0) continue;
-            const double dd = dist_fast<D>(xe[r][s], xi[r], c.squared);
-            const double ire0 = re0[r][s];
-            const double ire1 = two_radii ? re1[r][s] : ire0;
-#pragma unroll
-            for (int m = 0; m < M; ++m) {
-                const double ire = m == 0 ? ire0 : ire1;
-                const double eta = bin[m] * (1.0 - dd * ire) + bout[m] * (1.0 - dd * iri[m]);
-                // log(1 + e^eta) = eta beyond 130: such a term adds nothing to an edge's sum and eta to
-                // a control's.  Selects, not branches: the exponential is computed for every lane
-                // anyway, and a lane-wise branch costs an exec-mask round trip per candidate; the
-                // flush test is one wavefront-wide question
-                const bool big = eta > 130.0;
-                const double f = 1.0 + tab_exp(fmin(fmax(eta, -700.0), 130.0), sTab);
-                if (s == 0) {               // out edge : directed_likelihoods_fast.pyx:236-247
-                    L[m] += big ? 0.0 : eta;
-                    if (__builtin_amdgcn_ballot_w64(Pe[m] > 1e250))
-                        if (Pe[m] > 1e250) { L[m] -= fast_log(Pe[m]); Pe[m] = 1.0; }
-                    Pe[m] *= big ? 1.0 : f;
-                } else {                    // control : :250-268
-                    ctl[m] += big ? eta : 0.0;
-                    Pc[m] *= big ? 1.0 : f;
-                }
-            }
-        }
-        const double adj = (double)(c.N - outdeg[r] - 1) / (double)nctl[r];
-#pragma unroll
-        for (int m = 0; m < M; ++m) L[m] -= adj * (ctl[m] + fast_log(Pc[m]));
-    }
-#pragma unroll
-    for (int m = 0; m < M; ++m) {
-        L[m] -= fast_log(Pe[m]);
-        double v = wave_sum_all(L[m]);
-        if (lane == 0) sRed[wave * M + m] = v;
-    }
-    __syncthreads();
-    if (tid < M) {
-        double s = 0.0;
-        for (int w = 0; w < 4; ++w) s += sRed[w * M + tid];
-        partials[(size_t)blockIdx.x * M + tid] = s;
-    }
-}
-
-// The same from the nodes' term ROWS (cc_rows.hpp; round 5).  The prefetch form above gives a node three
-// fixed 64-lane slots - its out-edges (20 of 64 lanes busy at config 4), controls 0-63, controls 64-127
-// (36 of 64) - so 38 % of the lanes it computes and gathers for are idle.  A row lists the node's out-edges
+// The pass from the nodes' term ROWS (cc_rows.hpp; round 5).  Its predecessor gave a node three fixed
+// 64-lane slots - its out-edges (20 of 64 lanes busy at config 4), controls 0-63, controls 64-127 (36 of
+// 64) - so 38 % of the lanes it computed and gathered for were idle.  A row lists the node's out-edges
 // and out-controls back to back at a known offset: ~120 terms fill TWO dense trips, their indices leave with
 // the row's header (no degree round trip), and the control weight (N - deg - 1) / n_controls comes with the
 // header instead of a float64 division per node.  Any out-degree and any number of controls: terms beyond
-// the first 128 of a node take further trips.  Same records, same arithmetic per term, the same record per
-// workgroup as the forms above; a lane tells edges from controls by its position in the row.
+// the first 128 of a node take further trips.  A lane tells edges from controls by its position in the row;
+// two nodes per wavefront and eight wavefronts per workgroup (94 / 114 registers: five / four wavefronts per
+// SIMD - with four nodes per wavefront, 150 / 182 registers, the pass was slower than the slots it replaced).
+// rslot: which of the record's two (reciprocal) radii a single candidate (M == 1) reads.
+// 47.7 -> 41.9 us per pass at config 4 (average of the iteration's three passes, round 5).
 constexpr int LLCR_THREADS = 512;        // 8 wavefronts x 2 nodes: the same LLCC_NODES nodes (and one record) per workgroup
 template <int D, int M>
 __global__ __launch_bounds__(LLCR_THREADS) void k_loglik_casecontrol_rows(

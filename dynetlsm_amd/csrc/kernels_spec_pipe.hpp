@@ -587,7 +587,7 @@ __device__ __forceinline__ void pipe_item_prologue(const ChainView &c, const Pip
 
 // trips of 64 neighbours whose operands an undirected item loads up front
 __host__ __device__ constexpr int pipe_prefetch_trips(int D) {
-    return D == 1 ? 16 : D == 2 ? 11 : D == 3 ? 7 : 5;
+    return D == 1 ? 16 : D == 2 ? 11 : D == 3 ? 6 : 4;      // (d = 3, 4: one trip fewer than would fit on paper - seven / five spilled)
 }
 
 // One wavefront: part p of node k of batch `be` in slice t.  TP: the trips beyond the
@@ -633,7 +633,9 @@ __device__ __forceinline__ void pipe_eval_item(const ChainView &c, const PipeBuf
     const double lE = bin + bout;              // log E (directed model)
     const int lo = p * pb.per, hi = min(N, lo + pb.per);
     // neighbours per lane loaded up front (the directed model carries more per neighbour)
-    constexpr int PP_NPRE = MODEL == DLSM_UNDIRECTED ? pipe_prefetch_trips(D) : 1;
+    // (TP with the undirected model = parts longer than the prefetch: the software-pipelined trips behind
+    // it hold a row in flight - one prefetched trip fewer, or four registers spill)
+    constexpr int PP_NPRE = MODEL == DLSM_UNDIRECTED ? pipe_prefetch_trips(D) - (TP ? 1 : 0) : 1;
     // The item is a chain of dependent latencies, so the neighbours' loads are issued before
     // the first use: PP_NPRE per lane (clamped addresses, no predication) - all 11 trips of a
     // part at C2.
@@ -1212,10 +1214,14 @@ __device__ __forceinline__ void row_resolve(const ChainView &c, const PipeBuf &p
     // diagonal block: 16 bytes per thread and trip, a wavefront per row (rows >= nb and columns
     // >= the row's node were never written: never read either)
     // (trip u: row 16 u + wave, columns 2 lane, 2 lane + 1)
-    double2 blk[8];
+    // (d = 3, 4: the block in two halves - the owners' positions, proposals and prior operands are 8 d
+    // registers more, and all of it at once spilled 3 - 35 registers: the second half is requested once
+    // the first has left for LDS, one round trip later, on instantiations no benchmark configuration runs)
+    constexpr int BLK_H = D <= 2 ? 8 : 4;
+    double2 blk[BLK_H];
     const uint32_t blk_off = (uint32_t)((wave * (2 * PP_B) + PP_B + 2 * lane) * sizeof(double));
 #pragma unroll
-    for (int u = 0; u < 8; ++u)
+    for (int u = 0; u < BLK_H; ++u)
         blk[u] = coh_load2<COH>(H, blk_off, (uint32_t)(u * PP_WAVES * (2 * PP_B) * sizeof(double)));
     // the owners' inputs (requested now, used once the blocks above have left their registers)
     double2 tv[4];
@@ -1229,7 +1235,7 @@ __device__ __forceinline__ void row_resolve(const ChainView &c, const PipeBuf &p
     for (int d = 0; d < D; ++d) { x1[d] = 0.0; x0[d] = 0.0; }
 #pragma unroll
     for (int u = 0; u < 4; ++u) tv[u] = make_double2(0.0, 1.0);
-    if (owner) {
+    auto owner_loads = [&]() {
 #pragma unroll
         for (int u = 0; u < 4; ++u)
             tv[u] = coh_load2<COH>(frec, (uint32_t)((kc * p1 + min(u, p1 - 1)) * sizeof(double2)));
@@ -1240,11 +1246,23 @@ __device__ __forceinline__ void row_resolve(const ChainView &c, const PipeBuf &p
         const size_t tjc = (size_t)t * N + j0 + kc;
         st = c.step[tjc]; na = c.nacc[tjc]; ns = c.nsteps[tjc]; un = c.until[tjc];
         if (!COH) npre.request1(c, t, j0 + kc);        // the prior terms' operands, with everything else
-    }
+    };
+    if (owner) owner_loads();
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < BLK_H; ++u) {
         double *dst = sD + (u * PP_WAVES + wave) * PR_LD + 2 * lane;
         dst[0] = blk[u].x; dst[1] = blk[u].y;
+    }
+    if (BLK_H < 8) {
+        __builtin_amdgcn_sched_barrier(0);              // (not hoisted among the loads above)
+#pragma unroll
+        for (int u = 0; u < 8 - BLK_H; ++u)
+            blk[u] = coh_load2<COH>(H, blk_off, (uint32_t)((BLK_H + u) * PP_WAVES * (2 * PP_B) * sizeof(double)));
+#pragma unroll
+        for (int u = 0; u < 8 - BLK_H; ++u) {
+            double *dst = sD + ((BLK_H + u) * PP_WAVES + wave) * PR_LD + 2 * lane;
+            dst[0] = blk[u].x; dst[1] = blk[u].y;
+        }
     }
     if (owner && !COH) npre.request2(c);               // (the labels are in: the components' means and variances)
     // the window's accepted nodes among this thread's 16 factors: cr[2 u + i] belongs to node
