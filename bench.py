@@ -77,7 +77,7 @@ def kernel_instr_per_term():
     disassembler is not at hand.  Disassembling takes a second or two of host time: run_rank calls
     this once BEFORE any device work, so that the profile phase, the warm-up and the timed steps
     follow each other without an idle device in between (a short timed window behind an idle
-    device reads 3-5 % low)."""
+    device reads 5-9 % low)."""
     if _INSTR_CACHE:
         return _INSTR_CACHE[0]
     _INSTR_CACHE.append(_kernel_instr_per_term())
