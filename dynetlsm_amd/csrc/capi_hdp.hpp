@@ -270,7 +270,10 @@ int hdp_fork_arm(dlsm_chain *h) {
         if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, h->device) != hipSuccess) can = 0;
         (void)hipGetLastError();
         const char *eg = getenv("DLSM_HDP_GATE");
-        h->fork_wait_value = can != 0 && !(eg && strcmp(eg, "kernel") == 0);
+        // (under rocprofv3's counter collection - it serialises the dispatches of all queues - the queue-level
+        // wait never returned: a process the profiler's tool library is loaded into keeps the gate kernel)
+        const bool profiler = getenv("ROCP_TOOL_LIBRARIES") != nullptr || getenv("ROCPROFILER_REGISTER_FORCE_LOAD") != nullptr;
+        h->fork_wait_value = can != 0 && !profiler && !(eg && strcmp(eg, "kernel") == 0);
         h->fork_ticket = 0;
     }
     h->fork_armed = true;

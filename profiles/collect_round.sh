@@ -28,6 +28,13 @@ python3 bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver_args.json 2>
 : > $OUT/chains_per_gpu.jsonl
 for C in 2 3 4; do python3 bench.py --chains-per-gpu $C --no-cpu >> $OUT/chains_per_gpu.jsonl 2>> $OUT/chains_per_gpu.err; done
 python3 profiles/posterior_mixing.py > $OUT/posterior_mixing.txt 2>&1
+# round 5: what a call of the device loops costs beyond its iterations; windows behind different predecessors;
+# the case-control iteration launch by launch
+python3 profiles/per_call_cost.py > $OUT/per_call_cost.jsonl 2> $OUT/per_call_cost.err
+python3 profiles/window_probe.py > $OUT/window_probe.jsonl 2> $OUT/window_probe.err
+python3 profiles/iteration_timeline.py $OUT/stats_cc/bench_kernel_trace.csv k_post_reduce_dir > $OUT/cc_timeline.txt 2>&1
+python3 bench.py --model lsm --no-cpu --steps 20 --warmup 5 --windows 6 > $OUT/bench_windows_lsm.json 2> $OUT/bench_windows.err
+python3 bench.py --model hdp --no-cpu --steps 20 --warmup 5 --windows 6 > $OUT/bench_windows_hdp.json 2>> $OUT/bench_windows.err
 python3 profiles/instr_counts.py > $OUT/instr_counts.json 2>&1
 python3 profiles/instr_counts.py scratch > $OUT/hot_kernel_registers.txt 2>&1
 python3 bench.py --gpus 2 --backend gloo --share-device0 --no-cpu 2> $OUT/bench_2ranks.err | grep "^{" > $OUT/bench_2ranks_one_gpu.json   # (gloo greets on stdout)

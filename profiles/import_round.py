@@ -21,11 +21,13 @@ for m in ('lsm', 'hdp', 'cc'):
         f = glob.glob(os.path.join(src, 'pmc_%s_%s' % (kind, m), '*counter_collection.csv'))
         if f:
             shutil.copy(f[0], os.path.join(HERE, '%s_pmc_%s_size_%s.csv' % (tag, kind, m))); n += 1
-for a in ('bench_default.json', 'bench_driver_args.json', 'chains_per_gpu.jsonl', 'chains_shared_launches.jsonl',
+for a in ('bench_default.json', 'bench_driver_args.json', 'chains_per_gpu.jsonl',
           'bench_2ranks_one_gpu.json', 'bench_lsm_cpu8.json', 'posterior_mixing.txt', 'instr_counts.json',
           'hot_kernel_registers.txt', 'end_to_end_fit.jsonl', 'pipe_timing.json', 'loglik_timing.json',
           'ccpipe_timing.json', 'labels_phases.json', 'hdp_tail_timing.json',
-          'valu_rates.txt', 'sqrt_acc.txt', 'hdp_timeline_two_queues.txt', 'hdp_timeline_one_queue.txt'):
+          'valu_rates.txt', 'sqrt_acc.txt', 'hdp_timeline_two_queues.txt', 'hdp_timeline_one_queue.txt',
+          'per_call_cost.jsonl', 'window_probe.jsonl', 'cc_timeline.txt', 'bench_windows_lsm.json',
+          'bench_windows_hdp.json'):
     p = os.path.join(src, a)
     if os.path.exists(p) and os.path.getsize(p) > 0:
         shutil.copy(p, os.path.join(HERE, '%s_%s' % (tag, a))); n += 1
