@@ -294,6 +294,7 @@ int launch_loglik_records(dlsm_chain *h, int M, const double *d_ic,
         // out-edges and out-controls as dense 64-term trips from the node's row (cc_rows.hpp)
         { int rc3 = ensure_cc_rows(h); if (rc3) return rc3; }
         if (M == 1) hipLaunchKernelGGL((k_loglik_casecontrol_rows<DD, 1>), dim3(nb), dim3(LLCR_THREADS), 0, h->stream, v, cand, h->xr, h->cc_terms, h->cc_tw, h->partials, rslot);
+        else if (M == 4) hipLaunchKernelGGL((k_loglik_casecontrol_rows<DD, 4>), dim3(nb), dim3(LLCR_THREADS), 0, h->stream, v, cand, h->xr, h->cc_terms, h->cc_tw, h->partials, 0);
         else hipLaunchKernelGGL((k_loglik_casecontrol_rows<DD, 2>), dim3(nb), dim3(LLCR_THREADS), 0, h->stream, v, cand, h->xr, h->cc_terms, h->cc_tw, h->partials, 0);
     }
     HIPCHK(h, hipGetLastError());
@@ -1691,6 +1692,14 @@ static int enqueue_lsm_iteration(dlsm_chain *h, int it, bool counter, int procru
                                                    prec, nbp, h->lsm, ir, h->trace_X, xr, nbp, rg));
         }
         ProfScope ps(h, DLSM_K_FINALIZE);
+        if (pf && !getenv("DLSM_CC_TWO_PASSES")) {
+            // case-control: both intercept steps behind ONE four-candidate pass (kernels_dirloop.hpp)
+            rc = loglik_records(h, 4, h->lsm->cand8, h->radii, h->radii, &nrec, true);
+            if (rc) return rc;
+            const DirRider rd{3, nblk, h->radii, h->radii_alt, rrec, rrec2, xr};
+            DISPATCH_D(h, h->D, hipLaunchKernelGGL((k_dir_reduce_accept_both<DD>), dim3(2), dim3(256), 0, h->stream,
+                                                   h->partials, nrec, ll2, v, h->lsm, h->intercept, ir, rd));
+        } else
         for (int which = 0; which < 2; ++which) {
             const int M = which == 0 ? 2 : 1;
             rc = loglik_records(h, M, h->lsm->cand, h->radii, h->radii, &nrec, pf || which == 1);

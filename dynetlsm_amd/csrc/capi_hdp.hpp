@@ -106,6 +106,13 @@ int enqueue_hdp_iteration(dlsm_chain *h, int it, bool draw_next) {
         {
             ProfScope psf(h, DLSM_K_FINALIZE);
             int nrec_d = 0;
+            if (pf && !getenv("DLSM_CC_TWO_PASSES")) {      // (as the directed LSM loop: capi.hip)
+                rc = loglik_records(h, 4, h->lsm->cand8, h->radii, h->radii, &nrec_d, true);
+                if (rc) return rc;
+                const DirRider rd{3, nblk, h->radii, h->radii_alt, rrec, rrec2, xr};
+                hipLaunchKernelGGL((k_dir_reduce_accept_both<DD>), dim3(2), dim3(256), 0, h->stream, h->partials,
+                                   nrec_d, ll2, vd, h->lsm, h->intercept, ir, rd);
+            } else
             for (int which = 0; which < 2; ++which) {
                 const int M = which == 0 ? 2 : 1;
                 rc = loglik_records(h, M, h->lsm->cand, h->radii, h->radii, &nrec_d, pf || which == 1);

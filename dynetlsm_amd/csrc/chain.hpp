@@ -67,6 +67,10 @@ struct LsmDeviceState {
     double ll_cur, dir_q;
     double r_logu;              // log-uniform of the radii step's accept test (its own word: the proposal
                                 // is closed while the intercept steps still use `logu`)
+    // case-control loop: BOTH intercept steps around one four-candidate pass (kernels_dirloop.hpp):
+    // (b_in', b_out), (b_in, b_out), (b_in', b_out'), (b_in, b_out') and the second step's log-uniform
+    double cand8[8];
+    double logu2;
 };
 
 // Device-resident HDP-LPCM loop (hdp_lpcm.py:823-1069): hyper-parameters the loop resamples,

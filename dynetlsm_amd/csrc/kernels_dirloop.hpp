@@ -219,6 +219,38 @@ __global__ __launch_bounds__(256) void k_dir_reduce_accept_intercept(
     if (next_which >= 0) dir_propose_intercept(c, lsm, intercept, next_which, ir.get());
 }
 
+// Case-control loop (round 5): BOTH intercept steps behind ONE four-candidate pass (records' columns:
+// (b_in', b_out), (b_in, b_out), (b_in', b_out'), (b_in, b_out'); dir_propose_both).  Workgroup 0 sums the
+// four columns in the fixed order and runs the two accept / reject rules one after the other - the second
+// with the pair the first one left: exactly the values, the draws and the bookkeeping of the two launches
+// around two passes this replaces (one gather pass of ~40 us and one launch less per iteration).
+// Workgroup 1: the radii proposal's closing sums (rider kind 3), as in the first of the two launches.
+template <int D>
+__global__ __launch_bounds__(256) void k_dir_reduce_accept_both(
+    const double *__restrict__ partials, int nrec, double *__restrict__ ll_out, ChainView c,
+    LsmDeviceState *lsm, double *__restrict__ intercept, IterRef ir, DirRider rd) {
+    if (blockIdx.x > 0) {
+        dir_radii_finish_wg<D, 256>(c, lsm, rd.radii, rd.radii_alt, rd.rec2, rd.nblk, rd.xr, ir);
+        return;
+    }
+    __shared__ double scratch[4 * 256];
+    __shared__ double sums[8];
+    reduce_records(partials, nrec, 4, sums, scratch, threadIdx.x);
+    if (threadIdx.x != 0) return;
+    ll_out[0] = sums[0]; ll_out[1] = sums[1];
+    // step 1: intercept_in, [at the proposal, at the current pair] = columns 0, 1
+    const double ll01[2] = {sums[0], sums[1]};
+    const double b_in_before = intercept[0];
+    dir_accept_intercept(ll01, lsm, intercept, 0, 0);
+    const bool acc0 = intercept[0] != b_in_before || lsm->cand[0] == b_in_before;
+    // step 2: intercept_out at the intercept_in the first step left; its current value is carried (ll_cur)
+    lsm->cand[0] = intercept[0]; lsm->cand[1] = lsm->cand8[5];
+    lsm->cand[2] = intercept[0]; lsm->cand[3] = intercept[1];
+    lsm->logu = lsm->logu2;
+    const double ll23[2] = {acc0 ? sums[2] : sums[3], 0.0};
+    dir_accept_intercept(ll23, lsm, intercept, 1, 1);
+}
+
 // The centring launches of the directed loops with the radii proposal riding in them: the gamma
 // variates beside the sums (pass 1), normalisation + density terms beside the rotation / shift
 // (pass 2: it leaves the records' second radius slot to the riders).  Neither reads what the other

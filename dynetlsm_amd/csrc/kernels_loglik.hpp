@@ -525,7 +525,9 @@ __global__ __launch_bounds__(LLCR_THREADS) void k_loglik_casecontrol_rows(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     exp_table_fill(sTab, tid);                 // the first 256 threads: one entry each; barrier below
     const long nodes = (long)c.T * c.N;
-    const bool two_radii = M > 1 && cand.radii[M - 1] != cand.radii[0];
+    // (M = 2: the second candidate may differ in its radii; M = 4 - the case-control loop's two intercept
+    // steps at once - differs in intercepts only)
+    const bool two_radii = M == 2 && cand.radii[1] != cand.radii[0];
     long node[NPW];
     int outdeg[NPW], nt[NPW], e[NPW][NS];
     double adj[NPW];

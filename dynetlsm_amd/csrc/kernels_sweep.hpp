@@ -489,6 +489,26 @@ __device__ __forceinline__ void dir_propose_intercept(const ChainView &c, LsmDev
     philox_uniform2(c.seed, (uint32_t)which, 1, iter, stream_word(c.chain, STREAM_INTERCEPT), u0, u1);
     lsm->logu = log(u0);
 }
+// ... and BOTH intercept steps' proposals at once (the case-control loop's four-candidate pass): the second
+// step's proposal b_out' = b_out + step_out z and its uniform are functions of (seed, iteration) and of a
+// step size the first step does not touch, so they can be drawn before the first step is decided
+// (sample_coefficients.py:12-75: the same draws, the same two accept / reject rules in the same order).
+// Leaves cand / logu as dir_propose_intercept(which = 0) does.
+__device__ __forceinline__ void dir_propose_both(const ChainView &c, LsmDeviceState *lsm,
+                                                 const double *__restrict__ intercept, uint32_t iter) {
+    dir_propose_intercept(c, lsm, intercept, 0, iter);
+    double u0, u1, z0, z1;
+    philox_uniform2(c.seed, 1u, 0, iter, stream_word(c.chain, STREAM_INTERCEPT), u0, u1);
+    box_muller(u0, u1, z0, z1);
+    const double b0 = intercept[0], b1 = intercept[1];
+    const double p0 = lsm->cand[0], p1 = b1 + lsm->i_step[1] * z0;
+    lsm->cand8[0] = p0; lsm->cand8[1] = b1;
+    lsm->cand8[2] = b0; lsm->cand8[3] = b1;
+    lsm->cand8[4] = p0; lsm->cand8[5] = p1;
+    lsm->cand8[6] = b0; lsm->cand8[7] = p1;
+    philox_uniform2(c.seed, 1u, 1, iter, stream_word(c.chain, STREAM_INTERCEPT), u0, u1);
+    lsm->logu2 = log(u0);
+}
 // Pass 2 (many workgroups): every workgroup sums the records in the same fixed
 // order, gets R (one-sided Jacobi polar factor of M) and the mean, and applies
 // x <- x R - mean R to its rows.  Workgroup 0 also leaves the LSM bookkeeping.
@@ -559,8 +579,9 @@ __device__ __forceinline__ void post_apply_wg(
                 if (!draw_intercept) {
                     // (drawn with the sweep's proposals: pipe_propose_intercept)
                 } else if (c.model != DLSM_UNDIRECTED) {
-                    // the first of the two intercept steps of the directed loops
-                    dir_propose_intercept(c, lsm, c.intercept, 0, iter);
+                    // the first of the two intercept steps of the directed loops (and, for the case-control
+                    // loop's four-candidate pass, the second one's proposal with it)
+                    dir_propose_both(c, lsm, c.intercept, iter);
                 } else {
                     double u0, u1, z0, z1;
                     philox_uniform2(c.seed, 0, 0, iter, stream_word(c.chain, STREAM_INTERCEPT),
