@@ -203,7 +203,7 @@ def test_fit_chains_timeout_stops_a_wedged_rank():
     t0 = time.monotonic()
     with pytest.raises(RuntimeError, match='rank exited'):
         fit_chains(StandInEstimator(n_iter=20, hang_on_chain=1), np.zeros((2, 5, 5)), n_chains=2,
-                   backend='gloo', timeout=20)
+                   backend='gloo', timeout=8)
     assert time.monotonic() - t0 < 120
 
 
