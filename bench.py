@@ -818,9 +818,9 @@ class CcWorkload(object):
                     'algorithmic_bytes_per_launch': round(k_bytes, 1),
                     'gathered_terms_per_s_sweep': round(2.0 * T * N * self.mean_terms /
                                                         (sweep_ms * 1e-3), 0),
-                    'note': 'gather-latency bound: each term is a dependent chain list index -> '
-                            'X[e], radii[e] through L2 (the working set, 2.4 MB, is cache '
-                            'resident: HBM traffic is far below the algorithmic bytes)'}
+                    'note': 'not an HBM kernel: the term rows and records (2.4 MB a slice) are L2 resident, HBM '
+                            'traffic is far below the algorithmic bytes; its evaluator is bound by float64 vector '
+                            'issue (roofline_valu), its resolver by the dependency chain of accepted moves'}
         # The bound that fits both kernels: a gathered term is one 32-byte record from a random
         # node of the slice, and a CU's vector L1 looks up one cache line per clock, whatever
         # the hit rate (the records are L2 resident): 256 CUs x 2.4 GHz records per second.
@@ -830,6 +830,31 @@ class CcWorkload(object):
             'achieved': round(rec_sweep / (sweep_ms * 1e-3) / 1e9, 2), 'peak': GATHER_PEAK_GRECS,
             'unit': 'G records/s', 'frac': round(rec_sweep / (sweep_ms * 1e-3) / 1e9 / GATHER_PEAK_GRECS, 4),
             'records_per_sweep': rec_sweep}
+        # What the evaluator of k_ccpipe_step is actually bound by (profiles/r05_ccpipe_notes.md): float64 vector
+        # issue.  One item (node) is one wavefront's pass over its gathered terms; its vector instructions are
+        # counted in the library's code object (profiles/instr_counts.py, quarter-rate float64 instructions at
+        # four issue slots); a SIMD issues one slot per clock.
+        roofline_valu = None
+        if algo == 5:
+            try:
+                sys.path.insert(0, os.path.join(ROOT, 'profiles'))
+                import instr_counts
+                cc = instr_counts.counts().get('k_ccpipe_step<2>')
+            except Exception:       # noqa: BLE001
+                cc = None
+            if cc:
+                items = float(T) * N / max(launches, 1)
+                slots = items * cc['issue_slots_per_item']
+                peak_slots = 4 * 256 * 2.4e9                            # SIMDs x clocks a second
+                roofline_valu = {
+                    'bound': 'vector issue (one slot per SIMD per clock; float64 mul/fma/add take four)',
+                    'kernel': kname, 'items_per_launch': round(items, 1),
+                    'valu_per_item': cc['valu_per_item'], 'issue_slots_per_item': cc['issue_slots_per_item'],
+                    'achieved': round(slots / (k_ms * 1e-3) / 1e12, 3), 'peak': round(peak_slots / 1e12, 3),
+                    'unit': 'T issue slots/s', 'frac': round(slots / (k_ms * 1e-3) / peak_slots, 4),
+                    'note': 'over the whole launch, the serial resolver included (the evaluator wavefronts finish '
+                            'in about the first third of it; while they run the SIMDs that hold them issue at '
+                            'about three times this fraction)'}
         ll_ms = ms_ll / max(n_ll, 1)
         rec_ll = float(T) * N * (float(self.mean_out) + self.C)     # out-edges + out-controls
         roofline_ll = {
@@ -840,10 +865,10 @@ class CcWorkload(object):
             'records_per_pass': rec_ll, 'us_per_pass': round(1e3 * ll_ms, 2),
             'algorithmic_bytes_per_pass': rec_ll * (4 + 32),
             'hbm_equivalent_GBs': round(rec_ll * 36 / (ll_ms * 1e-3) / 1e9, 1),
-            'note': 'average over the iteration\'s three passes (one of two candidates, two of one); '
-                    'index 4 B + record 32 B per term; every load of a wavefront\'s four nodes is '
-                    'issued before the first use'}
-        extra = {'roofline_gather': roofline_gather, 'roofline_loglik': roofline_ll,
+            'note': 'average over the iteration\'s two passes (the four candidates of both intercept steps in '
+                    'one, the radii\'s in the other); index 4 B + record 32 B per term; every load of a '
+                    'wavefront\'s two nodes is issued before the first use'}
+        extra = {'roofline_gather': roofline_gather, 'roofline_valu': roofline_valu, 'roofline_loglik': roofline_ll,
                  'ms_sweep': round(sweep_ms, 4),
                  'ms_per_loglik_pass': round(ms_ll / max(n_ll, 1), 4),
                  'loglik_passes_per_iteration': round(n_ll / float(max(P, 1)), 2),

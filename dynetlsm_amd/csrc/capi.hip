@@ -63,7 +63,11 @@ static std::atomic<int> g_live_chains{0};       // handles alive in this process
         case 2: { constexpr int DD = 2; __VA_ARGS__; } break;               \
         case 3: { constexpr int DD = 3; __VA_ARGS__; } break;               \
         case 4: { constexpr int DD = 4; __VA_ARGS__; } break;               \
-        default: FAIL(h, DLSM_E_LIMIT, "n_features=%d unsupported (1..4)", D_); \
+        case 5: { constexpr int DD = 5; __VA_ARGS__; } break;               \
+        case 6: { constexpr int DD = 6; __VA_ARGS__; } break;               \
+        case 7: { constexpr int DD = 7; __VA_ARGS__; } break;               \
+        case 8: { constexpr int DD = 8; __VA_ARGS__; } break;               \
+        default: FAIL(h, DLSM_E_LIMIT, "n_features=%d unsupported (1..8)", D_); \
     }
 
 // A captured iteration freezes pointers and scalars of the chain: anything that changes
@@ -347,8 +351,8 @@ int dlsm_create(int device, int T, int N, int D, int model, uint64_t seed,
     dlsm_chain *nullh = nullptr;
     if (!out) FAIL(nullh, DLSM_E_ARG, "out is NULL");
     *out = nullptr;
-    if (T < 1 || N < 2 || D < 1 || D > 4)
-        FAIL(nullh, DLSM_E_ARG, "bad shape T=%d N=%d D=%d (need T>=1, N>=2, 1<=D<=4)", T, N, D);
+    if (T < 1 || N < 2 || D < 1 || D > DLSM_D_MAX)
+        FAIL(nullh, DLSM_E_ARG, "bad shape T=%d N=%d D=%d (need T>=1, N>=2, 1<=D<=%d)", T, N, D, DLSM_D_MAX);
     if (T > 65535) FAIL(nullh, DLSM_E_LIMIT, "T=%d > 65535", T);
     if (model < 0 || model > 2) FAIL(nullh, DLSM_E_ARG, "bad model %d", model);
     if (chain_id >= (1u << 24)) FAIL(nullh, DLSM_E_ARG, "chain_id must be < 2^24");
@@ -384,7 +388,7 @@ int dlsm_create(int device, int T, int N, int D, int model, uint64_t seed,
     rc |= dev_alloc(h, &h->nacc, TN);
     rc |= dev_alloc(h, &h->nsteps, TN);
     rc |= dev_alloc(h, &h->until, TN);
-    rc |= dev_alloc(h, &h->dsmall, 64);
+    rc |= dev_alloc(h, &h->dsmall, 128);
     rc |= dev_alloc(h, &h->xref, TN * D);
     rc |= dev_alloc(h, &h->lsm, 1);
     rc |= dev_alloc(h, &h->z, TN);
@@ -1011,6 +1015,9 @@ static int launch_sweep_spec(dlsm_chain *h, IterRef iter, int S, bool alloc_only
 // workgroup per slice
 static int resolve_sweep_algo(const dlsm_chain *h, int algo) {
     if (algo != 0) return algo;
+    // n_features 5..8: the slice-in-LDS and the speculative-batch sweeps (the pipelined ones are built and
+    // tuned for the 1..4 dimensions of the reference's examples and the paper)
+    if (h->D > DLSM_D_PIPE_MAX) return h->N >= 256 ? 2 : 1;
     // case-control: sparse correction lists once a slice has several batches of 512
     if (h->model == DLSM_DIRECTED_CASE_CONTROL)
         return h->N >= 2048 ? 5 : (h->N >= 512 ? 4 : (h->N >= 256 ? 2 : 1));
@@ -1226,12 +1233,16 @@ static int launch_sweep(dlsm_chain *h, IterRef iter, int algo, bool alloc_only =
         algo = resolve_sweep_algo(h, algo);
         if (alloc_only) {
             hipStreamSynchronize(h->stream);
-            if (algo == 5) return launch_sweep_ccpipe<DD>(h, iter, true);
-            if (algo == 4) return launch_sweep_pipe<DD>(h, iter, true);
+            if constexpr (DD <= DLSM_D_PIPE_MAX) {
+                if (algo == 5) return launch_sweep_ccpipe<DD>(h, iter, true);
+                if (algo == 4) return launch_sweep_pipe<DD>(h, iter, true);
+            }
             return algo >= 2 ? launch_sweep_spec<DD>(h, iter, 1, true) : DLSM_OK;
         }
-        if (algo == 5) return launch_sweep_ccpipe<DD>(h, iter);
-        if (algo == 4) return launch_sweep_pipe<DD>(h, iter);
+        if constexpr (DD <= DLSM_D_PIPE_MAX) {
+            if (algo == 5) return launch_sweep_ccpipe<DD>(h, iter);
+            if (algo == 4) return launch_sweep_pipe<DD>(h, iter);
+        }
         if (algo >= 2) return launch_sweep_spec<DD>(h, iter, 1);
         for (int parity = 0; parity < 2; ++parity) {
             int nsl = (h->T - parity + 1) / 2;
@@ -1243,7 +1254,9 @@ static int launch_sweep(dlsm_chain *h, IterRef iter, int algo, bool alloc_only =
         return DLSM_OK;
     }
     algo = resolve_sweep_algo(h, algo);
-    if (algo == 4) return launch_sweep_pipe<DD>(h, iter, alloc_only);
+    if constexpr (DD <= DLSM_D_PIPE_MAX) {
+        if (algo == 4) return launch_sweep_pipe<DD>(h, iter, alloc_only);
+    }
     if (algo == 2) return launch_sweep_spec<DD>(h, iter, 1, alloc_only);
     if (algo == 3)
         return launch_sweep_spec<DD>(h, iter, getenv("DLSM_SPEC_S") ? atoi(getenv("DLSM_SPEC_S")) : 2,
@@ -1279,6 +1292,8 @@ static int launch_sweep(dlsm_chain *h, IterRef iter, int algo, bool alloc_only =
 static int check_sweep_algo(dlsm_chain *h, int algo) {
     NEED(h, algo >= 0 && algo <= 5, "algo must be 0..5 (6 and 7, measured slower than 4, were removed in round 5)");
     NEED(h, algo != 5 || h->model == DLSM_DIRECTED_CASE_CONTROL, "algo 5 is the case-control sweep");
+    NEED(h, (algo != 4 && algo != 5) || h->D <= DLSM_D_PIPE_MAX,
+         "the pipelined sweeps (algo 4, 5) are built for n_features <= 4; 5..8 take algo 0, 1, 2 or 3");
     return DLSM_OK;
 }
 
@@ -1442,10 +1457,10 @@ int dlsm_procrustes(dlsm_chain *h, const double *X_ref, double *R_out) {
     NEED(h, h->have_X, "latent positions not set");
     HIPCHK(h, hipSetDevice(h->device));
     int rc = h2d(h, h->xref, X_ref, (size_t)h->T * h->N * h->D); if (rc) return rc;
-    DISPATCH_D(h, h->D, rc = launch_post<DD>(h, h->xref, -1, 0, nullptr, IterRef{0, nullptr}, h->dsmall + 32));
+    DISPATCH_D(h, h->D, rc = launch_post<DD>(h, h->xref, -1, 0, nullptr, IterRef{0, nullptr}, h->dsmall + 64));
     if (rc) return rc;
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    if (R_out) return d2h(h, R_out, h->dsmall + 32, (size_t)h->D * h->D);
+    if (R_out) return d2h(h, R_out, h->dsmall + 64, (size_t)h->D * h->D);
     return DLSM_OK;
 }
 
@@ -1612,7 +1627,7 @@ static int enqueue_lsm_iteration(dlsm_chain *h, int it, bool counter, int procru
                         !(getenv("DLSM_POST_RIDE") && atoi(getenv("DLSM_POST_RIDE")) == 0);
     h->post_ride_done = false;
     if (h->post_ride_want) {
-        rc = ensure_partials(h, (size_t)ll_blocks(h) * 4 + (size_t)PS_BLOCKS * 26); if (rc) return rc;
+        rc = ensure_partials(h, (size_t)ll_blocks(h) * 4 + (size_t)PS_BLOCKS * POST_W_MAX); if (rc) return rc;
         const int nip = h->lsm_cfg.n_iter_procrustes;
         h->post_ride_xref = (xref && (nip < 0 || it > nip)) ? xref : nullptr;
     }
@@ -1653,7 +1668,7 @@ static int enqueue_lsm_iteration(dlsm_chain *h, int it, bool counter, int procru
         if (rc) return rc;
     }
     if (alloc_only)     // (the directed loops' records: likelihood | centring | radii proposal)
-        return ensure_partials(h, (size_t)ll_blocks(h) * 4 + (size_t)PS_BLOCKS * 26 +
+        return ensure_partials(h, (size_t)ll_blocks(h) * 4 + (size_t)PS_BLOCKS * POST_W_MAX +
                                   (size_t)((h->N + DP_THREADS - 1) / DP_THREADS) * (1 + DP_COLS));
     int nrec = 0;
     if (h->model != DLSM_UNDIRECTED) {
@@ -1672,7 +1687,7 @@ static int enqueue_lsm_iteration(dlsm_chain *h, int it, bool counter, int procru
         // the last pass's sum, the radii's accept / reject and the trace row share the last
         // launch, which can carry the next sweep's proposal pass.
         const int nblk = (h->N + DP_THREADS - 1) / DP_THREADS;
-        constexpr int PW_MAX = 2 * 4 + 4 * 4 + 2;           // PostRec<4>::W
+        constexpr int PW_MAX = POST_W_MAX;
         const size_t n_post = (size_t)PS_BLOCKS * PW_MAX;
         rc = ensure_partials(h, (size_t)ll_blocks(h) * 4 + n_post + (size_t)nblk * (1 + DP_COLS));
         if (rc) return rc;

@@ -68,7 +68,7 @@ int enqueue_hdp_iteration(dlsm_chain *h, int it, bool draw_next) {
                         !(getenv("DLSM_POST_RIDE") && atoi(getenv("DLSM_POST_RIDE")) == 0);
     h->post_ride_done = false; h->post_ride_xref = nullptr;
     int rc = DLSM_OK;
-    if (h->post_ride_want) { rc = ensure_partials(h, (size_t)ll_blocks(h) * 4 + (size_t)PS_BLOCKS * 26); if (rc) return rc; }
+    if (h->post_ride_want) { rc = ensure_partials(h, (size_t)ll_blocks(h) * 4 + (size_t)PS_BLOCKS * POST_W_MAX); if (rc) return rc; }
     rc = enqueue_sweep(h, ir, h->hdp_cfg.sweep_algo);
     h->post_ride_want = false;
     if (rc) return rc;
@@ -86,7 +86,7 @@ int enqueue_hdp_iteration(dlsm_chain *h, int it, bool draw_next) {
         ChainView vd = h->view();
         double *ll2 = h->dsmall + 16;
         const int nblk = (h->N + DP_THREADS - 1) / DP_THREADS;
-        constexpr int PW_MAX = 2 * 4 + 4 * 4 + 2;           // PostRec<4>::W
+        constexpr int PW_MAX = POST_W_MAX;
         const size_t n_post = (size_t)PS_BLOCKS * PW_MAX;
         rc = ensure_partials(h, (size_t)ll_blocks(h) * 4 + n_post + (size_t)nblk * (1 + DP_COLS));
         if (rc) return rc;

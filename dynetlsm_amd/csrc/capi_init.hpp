@@ -90,7 +90,7 @@ int run_gmds_step(dlsm_chain *h, int t, const double *X_prev, double lmbda, int 
     const int nblk = (N + SM_ROWS - 1) / SM_ROWS;
     std::vector<double> hab(2 * kmax);
     std::vector<std::vector<double>> Sh;
-    double theta[4] = {0, 0, 0, 0};
+    double theta[DLSM_D_MAX] = {};
     int k_used = 0;
     double resid = 0.0;
     {

@@ -145,7 +145,7 @@ struct dlsm_chain {
     // scratch
     double *partials = nullptr; size_t partials_cap = 0;   // doubles
     double *xr = nullptr; size_t xr_cap = 0;               // packed (x, r, r') records (case-control)
-    double *dsmall = nullptr;      // 64 doubles of device scratch
+    double *dsmall = nullptr;      // 128 doubles of device scratch ([64, 128): a d x d rotation, d <= 8)
     double *hsmall = nullptr;      // 64 doubles of pinned host scratch
     double *xref = nullptr;        // T*N*D (procrustes reference staging)
     int32_t *lab_n = nullptr, *lab_nk = nullptr; double *lab_w = nullptr;

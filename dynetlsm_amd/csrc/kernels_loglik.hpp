@@ -137,7 +137,7 @@ __host__ __device__ inline int llu_blocks_per_slice(int nt) { return nt * nt; }
 // lanes j < r pair row 127 - r with column 127 - j (the second one, mirrored: 127 - r < 127 - j), every lane but
 // one busy at every step.  2560 workgroups at config 2: five wavefronts on every SIMD, all of the same length.
 template <int D, int M>
-__global__ __launch_bounds__(LLU_THREADS) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_loglik_undirected(
+__global__ __launch_bounds__(LLU_THREADS) __attribute__((amdgpu_waves_per_eu(D <= 3 ? 5 : (D == 4 ? 4 : 3), 8))) void k_loglik_undirected(
     ChainView c, LoglikCand cand, double *__restrict__ partials, int prio) {
     __shared__ double sXi[LL_TILE * D];
     __shared__ double sRed[2 * (2 + M)];
@@ -477,7 +477,8 @@ constexpr int LLCC_NODES = 16;
 // the radius of a random node: from separate arrays those are two cache-line requests for 16 +
 // 8 useful bytes, and the kernel is bound by exactly that request rate (6 M terms per pass at
 // C4); from one 32-byte record (64 at d > 2) it is one.
-__host__ __device__ constexpr int llcc_record_width(int D) { return D + 2 <= 4 ? 4 : 8; }
+// (d = 7, 8: 96 bytes)
+__host__ __device__ constexpr int llcc_record_width(int D) { return D + 2 <= 4 ? 4 : (D + 2 <= 8 ? 8 : 12); }
 template <int D>
 __global__ __launch_bounds__(256) void k_pack_xr(const double *__restrict__ X,
                                                  const double *__restrict__ r0,

@@ -374,6 +374,7 @@ __device__ void jacobi_polar(const double (&M)[D][D], double (&R)[D][D]) {
 constexpr int PS_BLOCKS = 64;
 constexpr int PS2_THREADS = 256;
 template <int D> struct PostRec { static constexpr int W = 2 * D + D * D + 2; };
+constexpr int POST_W_MAX = PostRec<DLSM_D_MAX>::W;      // buffers sized before the dimension is dispatched
 
 // one row's contributions to the W sums from its operands (x, the row of the slice before, the
 // reference's row).  own: everything that needs the row itself (sum x, M, the t = 0 sums); diff: the

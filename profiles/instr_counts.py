@@ -135,6 +135,12 @@ def counts(lib_path=None):
                                     'unrolled_trips_found': s[1], 'valu_per_term': round(s[0] / 2.0, 1),
                                     'quarter_rate_per_trip': s[2],
                                     'issue_slots_per_term': round(issue_slots(s[0], s[2]) / 2.0, 2)}
+    try:
+        cc = ccpipe_item_counts(lib_path)
+        if cc:
+            out['k_ccpipe_step<2>'] = cc
+    except StopIteration:
+        pass
     if body:
         out['k_loglik_undirected<2,2>'] = {'valu_per_trip_of_4_rows_2_candidates': body[0],
                                            'valu_per_candidate_term': round(body[0] / 8.0, 1),
@@ -142,6 +148,28 @@ def counts(lib_path=None):
                                            'issue_slots_per_candidate_term':
                                                round(issue_slots(body[0], body[2]) / 8.0, 2)}
     return out
+
+
+def ccpipe_item_counts(lib_path=None):
+    """vector instructions of ONE evaluator item of the sparse case-control sweep (k_ccpipe_step<2>: a node of
+    <= 256 gathered terms = one trip of four 64-term chunks + one flush of its window terms), from the code
+    object: the chunk loop is peeled (first trip / later trips: eight roots each), the flush has two roots.
+    An estimate with stated parts, for the bench line's issue-rate view of the kernel."""
+    lib_path = lib_path or os.path.join(ROOT, 'dynetlsm_amd', 'libdynetlsm_hip.so')
+    funcs = disassemble(lib_path)
+    ins = next(v for k, v in funcs.items() if re.match(r'_ZN4dlsm13k_ccpipe_stepILi2E', k))
+    pos = [k for k, l in enumerate(ins) if l.startswith('v_rsq_f64')]
+    if len(pos) < 18:
+        return None
+    bar = [k for k, l in enumerate(ins[:pos[0]]) if l.startswith('s_barrier')]
+    start = bar[-1] if bar else max(0, pos[0] - 200)         # behind the table's barrier: the item's prologue
+    valu = lambda a, b: sum(1 for l in ins[a:b] if l.startswith('v_'))
+    quarter = lambda a, b: sum(1 for l in ins[a:b] if l.startswith(QUARTER_RATE))
+    first_trip = (valu(start, pos[8] - 20), quarter(start, pos[8] - 20))
+    flush = (valu(pos[16] - 60, min(len(ins), pos[17] + 160)), quarter(pos[16] - 60, min(len(ins), pos[17] + 160)))
+    v, q = first_trip[0] + flush[0], first_trip[1] + flush[1]
+    return {'valu_per_item': v, 'quarter_rate_per_item': q, 'issue_slots_per_item': round(issue_slots(v, q), 1),
+            'parts': {'prologue_and_first_trip_of_4_chunks': first_trip[0], 'flush_of_the_window_terms': flush[0]}}
 
 
 def kernel_metadata(lib_path=None):

@@ -19,19 +19,37 @@ def load_golden(name):
     return np.load(os.path.join(GOLDEN, name))
 
 
+class _Merged:
+    """several .npz files with disjoint keys read as one"""
+
+    def __init__(self, *names):
+        self.files = [load_golden(n) for n in names]
+
+    def __getitem__(self, key):
+        for f in self.files:
+            if key in f.files:
+                return f[key]
+        raise KeyError(key)
+
+
+# tags of the likelihood fixtures: a, b (n_features 2), c (3) and, from `make_golden.py wide`, e (5), f (8), g (6)
+LIK_TAGS = ['a', 'b', 'c', 'e', 'f', 'g']
+
+
 @pytest.fixture(scope='session')
 def golden_lik():
-    return load_golden('likelihoods.npz')
+    return _Merged('likelihoods.npz', 'wide_likelihoods.npz')
 
 
-@pytest.fixture(scope='session')
-def golden_sweeps():
-    return load_golden('sweeps.npz')
+# the sweep and fit fixtures exist at n_features = 2 and at 5 (wide_*.npz: same generators, same keys)
+@pytest.fixture(scope='session', params=['sweeps.npz', 'wide_sweeps.npz'], ids=['d2', 'd5'])
+def golden_sweeps(request):
+    return load_golden(request.param)
 
 
-@pytest.fixture(scope='session')
-def golden_fits():
-    return load_golden('fit_traces.npz')
+@pytest.fixture(scope='session', params=['fit_traces.npz', 'wide_fit_traces.npz'], ids=['d2', 'd5'])
+def golden_fits(request):
+    return load_golden(request.param)
 
 
 @pytest.fixture(scope='session')
@@ -39,6 +57,10 @@ def monks():
     return load_golden('monks.npz')
 
 
+# initialisation cases (tag, directed, n_features): init.npz and, from `make_golden.py wide`, wide_init.npz
+INIT_CASES = [('u', False, 2), ('d', True, 2), ('u3', False, 3), ('u5', False, 5), ('d6', True, 6), ('u8', False, 8)]
+
+
 @pytest.fixture(scope='session')
 def golden_init():
-    return load_golden('init.npz')
+    return _Merged('init.npz', 'wide_init.npz')

@@ -83,7 +83,12 @@ def make_inputs(seed, T, N, D=2, density=0.4):
     return X, Yd, Yu, radii
 
 
-def gen_likelihoods(ref):
+LIKELIHOOD_CASES = {'a': (12345, 3, 7, 2, 0.4), 'b': (777, 2, 32, 2, 0.15), 'c': (4242, 2, 9, 3, 0.3)}
+# n_features above the four of the engine's pipelined kernels (wide_*.npz: `python make_golden.py wide`)
+WIDE_LIKELIHOOD_CASES = {'e': (5151, 3, 9, 5, 0.35), 'f': (8181, 2, 21, 8, 0.2), 'g': (6161, 2, 12, 6, 0.3)}
+
+
+def gen_likelihoods(ref, cases=None, fname='likelihoods.npz'):
     from dynetlsm.static_network_fast import partial_loglikelihood
     from dynetlsm.directed_likelihoods_fast import (
         directed_partial_loglikelihood, approx_directed_partial_loglikelihood,
@@ -96,9 +101,7 @@ def gen_likelihoods(ref):
     from dynetlsm.case_control_likelihood import DirectedCaseControlSampler
 
     out = {}
-    for tag, (seed, T, N, D, dens) in {
-            'a': (12345, 3, 7, 2, 0.4), 'b': (777, 2, 32, 2, 0.15),
-            'c': (4242, 2, 9, 3, 0.3)}.items():
+    for tag, (seed, T, N, D, dens) in (cases or LIKELIHOOD_CASES).items():
         X, Yd, Yu, radii = make_inputs(seed, T, N, D, dens)
         b, b_in, b_out = 0.75, 0.3, 0.7
         out[tag + '_X'], out[tag + '_Yd'], out[tag + '_Yu'] = X, Yd, Yu
@@ -162,8 +165,8 @@ def gen_likelihoods(ref):
                 tab[i] = compute_gaussian_likelihood(X[:, i], mu, sigma, lmbda,
                                                      normalize=bool(nz))
             out['%s_gauss_norm%d' % (tag, nz)] = tab
-    np.savez_compressed(os.path.join(HERE, 'likelihoods.npz'), **out)
-    print('likelihoods.npz: %d arrays' % len(out))
+    np.savez_compressed(os.path.join(HERE, fname), **out)
+    print('%s: %d arrays' % (fname, len(out)))
 
 
 def sampler_state(samplers):
@@ -173,7 +176,7 @@ def sampler_state(samplers):
             np.array([[s.steps_until_tune for s in row] for row in samplers]))
 
 
-def gen_sweeps(ref):
+def gen_sweeps(ref, D=2, fname='sweeps.npz'):
     """direct calls of sample_latent_positions / _mixture / sample_labels_block
     with the reference's own Metropolis objects"""
     from dynetlsm.metropolis import Metropolis
@@ -183,7 +186,7 @@ def gen_sweeps(ref):
     from dynetlsm.case_control_likelihood import DirectedCaseControlSampler
 
     out = {}
-    T, N, D = 3, 10, 2
+    T, N = 3, 10
     X, Yd, Yu, radii = make_inputs(2024, T, N, D, 0.3)
     out['X0'], out['Yd'], out['Yu'], out['radii'] = X, Yd, Yu, radii
     n_sweeps, tune, tune_interval = 6, 5, 2
@@ -251,8 +254,8 @@ def gen_sweeps(ref):
                                              random_state=np.random.RandomState(3))
     out['lab_X'], out['lab_mu'], out['lab_sigma'], out['lab_w'] = Xl, mul, sgl, w
     out['lab_z'], out['lab_n'], out['lab_nk'], out['lab_resp'] = zl, nl, nkl, respl
-    np.savez_compressed(os.path.join(HERE, 'sweeps.npz'), **out)
-    print('sweeps.npz: %d arrays' % len(out))
+    np.savez_compressed(os.path.join(HERE, fname), **out)
+    print('%s: %d arrays' % (fname, len(out)))
 
 
 def gen_monks(ref):
@@ -301,18 +304,18 @@ def capture_fit(ref, Y, **kw):
     return res
 
 
-def gen_fit_traces(ref, Yd, Yu):
+def gen_fit_traces(ref, Yd, Yu, fname='fit_traces.npz', **kw):
     out = {}
-    r = capture_fit(ref, Yu, seed=42, n_iter=10, tune=4, burn=2, tune_interval=2)
+    r = capture_fit(ref, Yu, seed=42, n_iter=10, tune=4, burn=2, tune_interval=2, **kw)
     out.update({'monks_u_' + k: v for k, v in r.items()})
     r = capture_fit(ref, Yd, seed=43, n_iter=8, tune=4, burn=2, tune_interval=2,
-                    is_directed=True)
+                    is_directed=True, **kw)
     out.update({'monks_d_' + k: v for k, v in r.items()})
     r = capture_fit(ref, Yd, seed=44, n_iter=8, tune=4, burn=2, tune_interval=2,
-                    is_directed=True, n_control=5, n_resample_control=1000)
+                    is_directed=True, n_control=5, n_resample_control=1000, **kw)
     out.update({'monks_cc_' + k: v for k, v in r.items()})
-    np.savez_compressed(os.path.join(HERE, 'fit_traces.npz'), **out)
-    print('fit_traces.npz: %d arrays' % len(out))
+    np.savez_compressed(os.path.join(HERE, fname), **out)
+    print('%s: %d arrays' % (fname, len(out)))
 
 
 def gen_chain_envelopes(ref, Yu):
@@ -552,7 +555,11 @@ def latent_network(seed, T, N, directed, intercept=1.0, drift=0.1):
     return Y
 
 
-def gen_init(ref):
+INIT_CASES = [('u', 4, 40, False, 11, 2), ('d', 3, 30, True, 12, 2), ('u3', 3, 25, False, 13, 3)]
+WIDE_INIT_CASES = [('u5', 3, 30, False, 14, 5), ('d6', 2, 28, True, 15, 6), ('u8', 2, 24, False, 16, 8)]
+
+
+def gen_init(ref, cases=None, fname='init.npz'):
     """the initialisation pipeline: shortest-path dissimilarities,
     generalized_mds (sklearn SMACOF + Sarkar-Moore eigen steps), initialize_radii and
     the conditional MLEs with their gradients, all from the reference's functions."""
@@ -568,14 +575,13 @@ def gen_init(ref):
     from dynetlsm.latent_space import calculate_distances
     out = {'sklearn_version': np.array(sklearn.__version__),
            'scipy_version': np.array(scipy.__version__)}
-    cases = [('u', 4, 40, False, 11), ('d', 3, 30, True, 12), ('u3', 3, 25, False, 13)]
-    for tag, T, N, directed, seed in cases:
+    wide = cases is not None
+    for tag, T, N, directed, seed, D in (cases or INIT_CASES):
         Y = latent_network(seed, T, N, directed)
         if tag == 'u':
             # two components and an isolated node in slice 1 (the imputed distance path)
             Y[1, :5, 5:] = 0; Y[1, 5:, :5] = 0
             Y[1, 7, :] = 0; Y[1, :, 7] = 0
-        D = 3 if tag == 'u3' else 2
         out[tag + '_Y'] = Y
         out[tag + '_D'] = np.stack([shortest_path_dissimilarity(Y[t]) for t in range(T)])
         rng = np.random.RandomState(100 + seed)
@@ -605,6 +611,10 @@ def gen_init(ref):
             out[tag + '_mle_f'] = f
             out[tag + '_mle_g'] = g
             out[tag + '_mle'] = np.array(scale_intercept_mle(Y, X))
+    if wide:
+        np.savez_compressed(os.path.join(HERE, fname), **out)
+        print(fname)
+        return
     # static network path (2-d Y -> squeeze) and radii with an isolated node
     Ys = latent_network(21, 1, 20, False)[0]
     out['static_Y'] = Ys
@@ -807,6 +817,14 @@ if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'lpcm':
         gen_lpcm_trace(ref)
         gen_lpcm_envelopes(ref)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'wide':
+        # the same generators at n_features 5, 6 and 8 (the reference takes any n_features: lsm.py:235,254)
+        gen_likelihoods(ref, WIDE_LIKELIHOOD_CASES, 'wide_likelihoods.npz')
+        gen_sweeps(ref, D=5, fname='wide_sweeps.npz')
+        mk = np.load(os.path.join(HERE, 'monks.npz'))
+        gen_fit_traces(ref, mk['Y_directed'], mk['Y_undirected'], fname='wide_fit_traces.npz', n_features=5)
+        gen_init(ref, WIDE_INIT_CASES, 'wide_init.npz')
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'imputer':
         gen_imputer(ref)

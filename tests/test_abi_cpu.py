@@ -168,15 +168,15 @@ def test_integration_document_quotes_the_header_signatures():
 
 
 def test_n_features_beyond_the_kernels_is_a_value_error_before_any_device_call():
-    """the reference takes any n_features (lsm.py:235,254); the kernels are instantiated for 1..4:
+    """the reference takes any n_features (lsm.py:235,254); the kernels are instantiated for 1..8:
     fit() says so by name, on a box without a GPU too (no device call has been made yet)"""
     import numpy as np
     import dynetlsm_amd as da
     Y = np.zeros((2, 6, 6))
-    for est in (da.DynamicNetworkLSM(n_features=5, n_iter=3, tune=None, burn=None),
-                da.DynamicNetworkHDPLPCM(n_features=7, n_iter=3, tune=None, burn=None),
+    for est in (da.DynamicNetworkLSM(n_features=9, n_iter=3, tune=None, burn=None),
+                da.DynamicNetworkHDPLPCM(n_features=12, n_iter=3, tune=None, burn=None),
                 da.DynamicNetworkLPCM(n_features=0, n_iter=3, tune=None, burn=None)):
-        with pytest.raises(ValueError, match='1 <= n_features <= 4'):
+        with pytest.raises(ValueError, match='1 <= n_features <= 8'):
             est.fit(Y)
-    with pytest.raises(ValueError, match='n_features=5'):
-        da.Chain(2, 6, 5, 'undirected')
+    with pytest.raises(ValueError, match='n_features=9'):
+        da.Chain(2, 6, 9, 'undirected')

@@ -15,7 +15,7 @@ from oracle import init_oracle as io
 
 pytestmark = pytest.mark.gpu
 
-CASES = [('u', False, 2), ('d', True, 2), ('u3', False, 3)]
+from conftest import INIT_CASES as CASES       # noqa: E402
 
 
 @pytest.fixture(scope='module')
@@ -129,7 +129,7 @@ def test_generalized_mds_matches_reference(eng, golden_init, tag, directed, D):
 def test_mle_sums_and_mles(eng, golden_init):
     from dynetlsm_amd import initialization as init_mod
     g = golden_init
-    for tag, D in (('u', 2), ('u3', 3)):
+    for tag, D in (('u', 2), ('u3', 3), ('u5', 5), ('u8', 8)):
         Y, X = g[tag + '_Y'], g[tag + '_X']
         with _chain(eng, Y, D, False) as c:
             c.set_positions(X)
@@ -145,18 +145,19 @@ def test_mle_sums_and_mles(eng, golden_init):
             c.set_squared(0)
             got = init_mod.scale_intercept_mle(c, X)
             np.testing.assert_allclose(got, g[tag + '_mle'], rtol=1e-5, atol=1e-6)
-    Y, X, radii = g['d_Y'], g['d_X'], g['d_radii']
-    with _chain(eng, Y, 2, True) as c:
-        c.set_positions(X)
-        c.set_radii(radii)
-        for p, f in zip(g['d_mle_points'], g['d_mle_f']):
-            s = c.init_mle_sums(p[0], p[1])
-            np.testing.assert_allclose(s[0], f, rtol=1e-11)
-            # the reference's in-gradient is uninitialised (see the oracle's test)
-            np.testing.assert_allclose(s, io.mle_sums_directed(Y, X, radii, p[0], p[1]),
-                                       rtol=1e-10, atol=1e-9)
-        got = init_mod.directed_intercept_mle(c, X, radii)
-        np.testing.assert_allclose(got, g['d_mle'], rtol=1e-5, atol=1e-6)
+    for tag, D in (('d', 2), ('d6', 6)):
+        Y, X, radii = g[tag + '_Y'], g[tag + '_X'], g[tag + '_radii']
+        with _chain(eng, Y, D, True) as c:
+            c.set_positions(X)
+            c.set_radii(radii)
+            for p, f in zip(g[tag + '_mle_points'], g[tag + '_mle_f']):
+                s = c.init_mle_sums(p[0], p[1])
+                np.testing.assert_allclose(s[0], f, rtol=1e-11)
+                # the reference's in-gradient is uninitialised (see the oracle's test)
+                np.testing.assert_allclose(s, io.mle_sums_directed(Y, X, radii, p[0], p[1]),
+                                           rtol=1e-10, atol=1e-9)
+            got = init_mod.directed_intercept_mle(c, X, radii)
+            np.testing.assert_allclose(got, g[tag + '_mle'], rtol=1e-5, atol=1e-6)
 
 
 def test_init_errors(eng):

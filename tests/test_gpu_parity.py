@@ -7,6 +7,8 @@ sums) / 1e-9 absolute on positions after several sweeps."""
 import numpy as np
 import pytest
 
+from conftest import LIK_TAGS
+
 from oracle import oracle as orc
 
 pytestmark = pytest.mark.gpu
@@ -55,7 +57,7 @@ def _cc_lists(Yd, n_control, seed):
 
 
 # ------------------------------------------------------------ function seam
-@pytest.mark.parametrize('tag', ['a', 'b', 'c'])
+@pytest.mark.parametrize('tag', LIK_TAGS)
 @pytest.mark.parametrize('sq', [0, 1])
 def test_function_seam_against_reference_goldens(eng, golden_lik, tag, sq):
     """the reference's own outputs, through the reference's own signatures"""
@@ -248,7 +250,7 @@ def test_bad_inputs_fail_loudly(eng):
         c.upload_network(Yu); c.set_positions(X)
         with pytest.raises(eng.EngineError):
             c.sweep_positions(1)                   # samplers / prior missing
-    with pytest.raises(ValueError, match='1 <= n_features <= 4'):
+    with pytest.raises(ValueError, match='1 <= n_features <= 8'):
         eng.Chain(2, 10, 9, 'undirected')          # unsupported n_features: named before any device call
 
 
@@ -626,12 +628,15 @@ def test_resample_controls_valid_and_uniform(eng):
 @pytest.mark.parametrize('N,algo', [(18, 1), (300, 1), (300, 2), (300, 3), (700, 3),
                                     (300, 4), (700, 4)])
 def test_lsm_device_loop_equals_oracle_iterations(eng, monks, N, algo):
-    import ctypes as C
+    lsm_loop_case(eng, monks, N, algo)
+
+
+def lsm_loop_case(eng, monks, N, algo, D=2):
     if N == 18:
         Y = monks['Y_undirected']
-        X = np.random.RandomState(0).randn(3, 18, 2)
+        X = np.random.RandomState(0).randn(3, 18, D)
     else:
-        X, _, Y, _ = _rand_net(21, 4, N)
+        X, _, Y, _ = _rand_net(21, 4, N, D)
     T = Y.shape[0]
     b0, prior_b, var_b = 0.3, 0.1, 2.0
     n_total = 9
@@ -645,7 +650,7 @@ def test_lsm_device_loop_equals_oracle_iterations(eng, monks, N, algo):
         st.c.iter = it
         want_lp.append(orc.lsm_iteration_undirected(st, isamp, prior_b, var_b))
         want_b.append(st.c.intercept[0]); want_X.append(st.X.copy())
-    with eng.Chain(T, N, 2, 'undirected', seed=17, chain_id=5) as c:
+    with eng.Chain(T, N, D, 'undirected', seed=17, chain_id=5) as c:
         c.upload_network(Y); c.set_positions(X); c.set_intercepts([b0])
         c.set_prior_random_walk(2.0, 0.1); c.set_samplers(gg)
         c.lsm_configure([prior_b], var_b, step_size_intercept=0.1, tune=6,
@@ -884,8 +889,12 @@ def test_lsm_directed_device_loop_equals_oracle_iterations(eng, name, N, algo):
     """dlsm_lsm_run for the directed models (sweep, Procrustes / centring, intercept_in,
     intercept_out, radii with the scaled-Dirichlet proposal) against the oracle's
     Philox-driven restatement: same decisions, traces equal to rounding"""
+    directed_loop_case(eng, name, N, algo)
+
+
+def directed_loop_case(eng, name, N, algo, D=2):
     T, n_total, n_proc = 3, 8, 4
-    X, Yd, _, radii = _rand_net(31 + N, T, N, scale=0.05, density=0.1)
+    X, Yd, _, radii = _rand_net(31 + N, T, N, D, scale=0.05, density=0.1)
     b0 = np.array([0.4, 0.7])
     prior_b, var_b = np.array([0.3, 0.5]), 2.0
     og = orc.SamplerGrid(T, N, 0.01, tune=6, tune_interval=2)
@@ -918,7 +927,7 @@ def test_lsm_directed_device_loop_equals_oracle_iterations(eng, name, N, algo):
         lp = orc.lsm_iteration_directed(st, it, loglik, isamp, rsamp, prior_b, var_b, X_ref=ref)
         want['X'].append(st.X.copy()); want['b'].append(st.intercept.copy())
         want['r'].append(st.radii.copy()); want['lp'].append(lp)
-    with eng.Chain(T, N, 2, name, seed=23, chain_id=2) as c:
+    with eng.Chain(T, N, D, name, seed=23, chain_id=2) as c:
         if name == 'case_control':
             c.upload_edges(ie, oe, deg)
             c.set_controls(ci, co)

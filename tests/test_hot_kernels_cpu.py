@@ -72,18 +72,31 @@ KNOWN_SCRATCH = {
     'k_pipe_step<2,3,1>': 8, 'k_pipe_step<2,2,1>': 28,
     # initialisation pipeline at d = 3 / 4 (one workgroup, once per fit: d x d Jacobi on indexed local arrays)
     'k_gmds_finish<3>': 548, 'k_gmds_finish<4>': 1448, 'k_lanczos_init<4>': 36, 'k_lanczos_step<4>': 32,
-    'k_loglik_undirected<4,2>': 12, 'k_partial_all<3>': 32,
+    'k_partial_all<3>': 32,
     # 8 bytes of an indexed local array each, no spilled register
-    'k_hdp_hypers': 8, 'k_hdp_hypers_propose<1>': 8, 'k_hdp_hypers_propose<2>': 8, 'k_hdp_hypers_propose<3>': 8,
-    'k_hdp_hypers_propose<4>': 8, 'k_hdp_logp_batch_finish<1>': 8, 'k_hdp_logp_batch_finish<2>': 8,
-    'k_hdp_logp_batch_finish<3>': 8, 'k_hdp_logp_batch_finish<4>': 8,
+    'k_hdp_hypers': 8,
+    **{'k_hdp_hypers_propose<%d>' % d: 8 for d in range(1, 9)},
+    **{'k_hdp_logp_batch_finish<%d>' % d: 8 for d in range(1, 9)},
+    # n_features 5 .. 8 (built in round 5; off every benchmark configuration).  The initialisation pipeline, once
+    # per fit: Lanczos vectors and the d x d Jacobi of one 1024-thread workgroup
+    'k_lanczos_init<5>': 164, 'k_lanczos_step<5>': 160, 'k_gmds_finish<5>': 2596,
+    'k_lanczos_init<6>': 292, 'k_lanczos_step<6>': 288, 'k_gmds_finish<6>': 4000,
+    'k_lanczos_init<7>': 420, 'k_lanczos_step<7>': 416, 'k_gmds_finish<7>': 5672,
+    'k_lanczos_init<8>': 548, 'k_lanczos_step<8>': 544, 'k_gmds_finish<8>': 7592,
+    # the per-node partials of the function seam (an indexed local array, no spilled register) and the slice
+    # sweep's two registers beyond the 128 of its 1024-thread workgroup at d = 7, 8
+    'k_partial_all<5>': 48, 'k_partial_all<6>': 64, 'k_partial_all<7>': 64,
+    'k_sweep_slice<7,0>': 12, 'k_sweep_slice<8,0>': 12,
 }
+# vector registers parked in accumulation registers (no memory traffic: scratch_bytes is 0)
+KNOWN_AGPR_PARKED = {'k_post_apply<8>', 'k_lsm_finalize_apply_propose<8>', 'k_post_apply_dir<8>', 'k_post_align<8>'}
 
 
 def test_no_kernel_outside_the_known_list_touches_scratch_memory(code_object):
     ic, md, funcs = code_object
     over = {k: v['scratch_bytes'] for k, v in md.items()
-            if v['scratch_bytes'] > KNOWN_SCRATCH.get(k, 0) or (v['vgpr_spill'] and k not in KNOWN_SCRATCH)}
+            if v['scratch_bytes'] > KNOWN_SCRATCH.get(k, 0) or
+            (v['vgpr_spill'] and k not in KNOWN_SCRATCH and k not in KNOWN_AGPR_PARKED)}
     assert not over, 'kernels with more scratch memory than recorded: %s' % over
     # the list does not rot: an entry whose kernel is clean now must be removed
     stale = [k for k in KNOWN_SCRATCH if k in md and md[k]['scratch_bytes'] == 0]

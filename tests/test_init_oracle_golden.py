@@ -6,7 +6,7 @@ import pytest
 
 from oracle import init_oracle as io
 
-CASES = [('u', False, 2), ('d', True, 2), ('u3', False, 3)]
+from conftest import INIT_CASES as CASES       # noqa: E402
 
 
 def test_hop_matrix_matches_csgraph(golden_init):

@@ -3,6 +3,8 @@
 import numpy as np
 import pytest
 
+from conftest import LIK_TAGS
+
 from oracle import oracle as orc
 
 RTOL = 1e-12
@@ -14,7 +16,7 @@ def _cc(g, tag, t):
             g[tag + '_ctrl_out'][t])
 
 
-@pytest.mark.parametrize('tag', ['a', 'b', 'c'])
+@pytest.mark.parametrize('tag', LIK_TAGS)
 @pytest.mark.parametrize('sq', [0, 1])
 def test_partials_and_fulls(golden_lik, tag, sq):
     g = golden_lik
@@ -53,7 +55,7 @@ def test_known_answer_anchors(golden_lik):
     assert abs(g['a_full_directed_sq0'] - (-2804.043510394001)) < 1e-7
 
 
-@pytest.mark.parametrize('tag', ['a', 'b', 'c'])
+@pytest.mark.parametrize('tag', LIK_TAGS)
 @pytest.mark.parametrize('sq', [0, 1])
 def test_case_control(golden_lik, tag, sq):
     g = golden_lik
@@ -82,7 +84,7 @@ def test_case_control(golden_lik, tag, sq):
     np.testing.assert_allclose(fa, g['%s_full_approx_sq%d' % (tag, sq)], rtol=RTOL)
 
 
-@pytest.mark.parametrize('tag', ['a', 'b', 'c'])
+@pytest.mark.parametrize('tag', LIK_TAGS)
 def test_case_control_exhaustive_equals_exact(golden_lik, tag):
     g = golden_lik
     X, radii, Yd = g[tag + '_X'], g[tag + '_radii'], g[tag + '_Yd']
@@ -95,7 +97,7 @@ def test_case_control_exhaustive_equals_exact(golden_lik, tag):
     np.testing.assert_allclose(fa, fd, rtol=1e-11)
 
 
-@pytest.mark.parametrize('tag', ['a', 'b', 'c'])
+@pytest.mark.parametrize('tag', LIK_TAGS)
 def test_case_control_init(golden_lik, tag):
     g = golden_lik
     deg, ie, oe = orc.case_control_init(g[tag + '_Yd'])
@@ -104,7 +106,7 @@ def test_case_control_init(golden_lik, tag):
     np.testing.assert_array_equal(oe, g[tag + '_out_edges'])
 
 
-@pytest.mark.parametrize('tag', ['a', 'b', 'c'])
+@pytest.mark.parametrize('tag', LIK_TAGS)
 @pytest.mark.parametrize('nz', [0, 1])
 def test_gaussian_likelihood(golden_lik, tag, nz):
     g = golden_lik
