@@ -378,6 +378,12 @@ int dlsm_create(int device, int T, int N, int D, int model, uint64_t seed,
         { h->err = "hipStreamCreate failed"; return bail(DLSM_E_HIP); }
     if (hipHostMalloc(&h->stage, STAGE_BYTES, hipHostMallocDefault) != hipSuccess)
         h->stage = nullptr;                     // the copies then take the runtime's path
+    // the sticky error word of the in-kernel waits (the HDP-LPCM loop's two queues, the case-control sweep's
+    // helper workgroups): host memory the device can store to, read by the host without a copy
+    if (hipHostMalloc((void **)&h->fork_err_host, 64, hipHostMallocMapped) == hipSuccess) {
+        memset(h->fork_err_host, 0, 64);
+        if (hipHostGetDevicePointer((void **)&h->fork_err_dev, h->fork_err_host, 0) != hipSuccess) h->fork_err_dev = nullptr;
+    } else { h->fork_err_host = nullptr; (void)hipGetLastError(); }
     const size_t TN = (size_t)T * N;
     int rc = 0;
     rc |= dev_alloc(h, &h->X, TN * D);
@@ -1035,13 +1041,17 @@ static void launch_pipe_step(dlsm_chain *h, const ChainView &v, const PipeBuf &p
     if (h->profiling) h->prof[DLSM_K_SWEEP_EVAL].pending.emplace_back(e0, e1);
 }
 
-// the sticky error word of the HDP-LPCM loop's two queues: a bounded wait ran out of its budget
+// the sticky error word: a bounded in-kernel wait ran out of its budget
 static int check_pipe_err(dlsm_chain *h) {
-    if (h->fork_err_host && h->fork_ticket > 0) {   // the HDP loop's two queues (kernels_hdploop.hpp, HdpFork)
+    if (h->fork_err_host) {
         // (behind a synchronisation of the handle's stream: the word is host memory the device stores to)
         const int32_t e = *(volatile int32_t *)h->fork_err_host;
         if (e != 0) {
             *(volatile int32_t *)h->fork_err_host = 0;
+            if (e & CC_ERR_HELPER)
+                FAIL(h, DLSM_E_HIP, "case-control sweep: a resolver ran out of its poll budget waiting for its helper "
+                     "workgroup (word %#x) - the chain's state is undefined; set the state again and run with "
+                     "DLSM_CC_HELPERS=0", e);
             FAIL(h, DLSM_E_HIP, "HDP-LPCM loop: a hand-over between the chain's two queues ran out of its poll "
                  "budget (flags %d) - the chain's state is undefined (more streams alive than hardware "
                  "queues?); set the state again and run with DLSM_HDP_QUEUES=1", e);
@@ -1169,9 +1179,10 @@ static int launch_sweep_ccpipe(dlsm_chain *h, IterRef iter, bool alloc_only = fa
     const size_t n_ent = (size_t)2 * T * cap * CP_B;
     const size_t n_cnt = (size_t)2 * T * CP_B * 2;
     const size_t n_rec = (size_t)T * N * cp_record_width(DD);
-    // doubles: prop | tot | xval | oval | consts(2) | cur | snap ; int32: xidx | oidx | cnt ;
+    // doubles: prop | tot | xval | oval | consts(2) | cur | snap | xsum ; int32: xidx | oidx | cnt ;
     // uint64: accmask
-    const size_t need = (n_prop + n_tot + 2 * n_ent + 2 + 2 * n_rec) * sizeof(double) +
+    const size_t n_xsum = (size_t)T * CP_B;
+    const size_t need = (n_prop + n_tot + 2 * n_ent + 2 + 2 * n_rec + n_xsum) * sizeof(double) +
                         even2(2 * n_ent + n_cnt) * sizeof(int32_t) +
                         (size_t)T * CP_WAVES * sizeof(unsigned long long);
     if (h->pipe_cap < need) {
@@ -1188,8 +1199,16 @@ static int launch_sweep_ccpipe(dlsm_chain *h, IterRef iter, bool alloc_only = fa
     pb.prop = h->pipe; pb.tot = pb.prop + n_prop; pb.xval = pb.tot + n_tot; pb.oval = pb.xval + n_ent;
     double *consts = pb.oval + n_ent;
     pb.cur = consts + 2; pb.snap = pb.cur + n_rec;
-    pb.xidx = (int32_t *)(pb.snap + n_rec); pb.oidx = pb.xidx + n_ent; pb.cnt = pb.oidx + n_ent;
+    pb.xsum = pb.snap + n_rec;
+    pb.xidx = (int32_t *)(pb.xsum + n_xsum); pb.oidx = pb.xidx + n_ent; pb.cnt = pb.oidx + n_ent;
     pb.accmask = (unsigned long long *)(pb.xidx + even2(2 * n_ent + n_cnt));
+    // a helper workgroup per resolver (kernels_ccpipe.hpp, ccpipe_cross_helper) when the launch still fits the
+    // device in one wave of workgroups - a resolver waits for its helper INSIDE the launch, so both must be
+    // resident; DLSM_CC_HELPERS=0 keeps the resolvers on their own
+    const char *eh = getenv("DLSM_CC_HELPERS");
+    pb.helpers = (eh ? atoi(eh) != 0 : true) && h->n_cu >= 4 * T && h->fork_err_dev != nullptr;
+    pb.budget = 1 << 22;
+    pb.err = h->fork_err_dev;
     pb.nctrl = h->nctrl; pb.cap = cap; pb.nbat = nbat;
     pb.terms = h->cc_terms; pb.tw = tw;
     PipeBuf pp{};                   // the proposal kernel's view: proposals + its two constants
@@ -1208,11 +1227,12 @@ static int launch_sweep_ccpipe(dlsm_chain *h, IterRef iter, bool alloc_only = fa
                        h->stream, v, pb);
     const int nodes_max = ((T + 1) / 2 + T / 2) * std::min(CP_B, N);
     // one evaluator workgroup per remaining CU; the items are dealt out over all of them (kernels_ccpipe.hpp)
-    const int ne_wg = std::max(1, std::min(std::max(h->n_cu / 2, h->n_cu - T), nodes_max));
+    const int n_front = pb.helpers ? 2 * T : T;         // resolvers (+ their helpers) in front of the evaluators
+    const int ne_wg = std::max(1, std::min(std::max(h->n_cu / 2, h->n_cu - n_front), nodes_max));
     const int last = T > 1 ? nbat : nbat - 1;
     for (int l = -1; l <= last; ++l) {
         const bool any_eval = (l + 1 < nbat) || (T > 1 && l >= 0 && l < nbat);
-        const int grid = T + (any_eval ? ne_wg : 0);
+        const int grid = n_front + (any_eval ? ne_wg : 0);
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (h->profiling) { hipEventCreate(&e0); hipEventCreate(&e1); }
         hipExtLaunchKernelGGL((k_ccpipe_step<DD>), dim3(grid), dim3(CP_THREADS), 0, h->stream, e0, e1,

@@ -269,10 +269,7 @@ int hdp_fork_arm(dlsm_chain *h) {
         HIPCHK(h, hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming));
         HIPCHK(h, hipMalloc((void **)&h->fork_flags, 64));
         HIPCHK(h, hipMemset(h->fork_flags, 0, 64));
-        // the sticky error word: host memory the device can store to (read by the host without a copy)
-        HIPCHK(h, hipHostMalloc((void **)&h->fork_err_host, 64, hipHostMallocMapped));
-        memset(h->fork_err_host, 0, 64);
-        HIPCHK(h, hipHostGetDevicePointer((void **)&h->fork_err_dev, h->fork_err_host, 0));
+        NEED(h, h->fork_err_dev != nullptr, "no mapped host memory for the error word of the in-kernel waits");
         int can = 0;
         if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, h->device) != hipSuccess) can = 0;
         (void)hipGetLastError();

@@ -35,6 +35,7 @@ constexpr int CP_THREADS = 1024;
 constexpr int CP_WAVES = CP_THREADS / 64;
 // (12 / 24 up front measured best at config 4: 8 / 16 1637, 10 / 20 1679, 12 / 24 1731-1744,
 // 14 / 24 1739, 12 / 32 1700, 16 / 32 1557 it/s - every own entry is an LDS read per pass)
+constexpr int CP_XCH = 24;              // cross entries of a node requested up front (see ccpipe_resolve)
 constexpr int CP_OWN_REGS = 12;         // own entries a resolver thread keeps in registers
 constexpr int CP_OWN_LDS = 4;           // ... and the next ones in LDS (one node in a hundred has more than 12,
                                         // so every other wavefront holds one: a trip to memory per pass otherwise)
@@ -50,7 +51,16 @@ struct CcPipeBuf {
     const int32_t *nctrl;    // valid controls per (t, i, direction)
     const int32_t *terms;    // [T][N][tw] : (in_deg, out_deg, nci, nco, adj_in, adj_out | in-edges, out-edges, in-controls, out-controls)
     int cap, nbat, tw;
+    // the cross-sum helpers (ccpipe_cross_helper): helpers != 0 puts T such workgroups between the resolvers
+    // and the evaluators
+    double *xsum;            // [T][CP_B] : a slice's cross sums, from its helper to its resolver (CC_XS_EMPTY: not yet)
+    int32_t *err;            // sticky error word (mapped host memory): a hand-over ran out of its poll budget
+    int helpers, budget;
 };
+constexpr int CC_ERR_HELPER = 1 << 30;
+// "no sum yet": a NaN payload no arithmetic produces (the hardware's own NaN is 0x7FF8000000000000, and the
+// entries that are summed carry no payloads)
+constexpr unsigned long long CC_XS_EMPTY = 0x7FF8C0DE5EED0001ull;
 
 // A gathered term needs its partner's position and radius: one record (32 bytes up to d = 3)
 // instead of two arrays halves the cache-line requests the evaluator is bound by.  The record holds
@@ -269,6 +279,39 @@ __device__ __forceinline__ void ccpipe_eval_item(const ChainView &c, const CcPip
     }
 }
 
+// The cross sums of a batch (its nodes' corrections for the previous batch's acceptances, final by now): the
+// first CP_XCH entries of every node requested in one go, whatever the counts will turn out to be; a list
+// longer than that comes sixteen entries per trip.  In list order, by the node's thread alone: the same sum
+// whoever computes it - the slice's helper workgroup or, without helpers, the upper half of its resolver.
+// (macros: the loads stay in flight across the barrier that publishes sPrev between the two)
+#define cc_cross_loads \
+        int xm[CP_XCH];                                                                                 \
+        double xh[CP_XCH];                                                                              \
+_Pragma("unroll")                                                                                    \
+        for (int u = 0; u < CP_XCH; ++u) {                                                              \
+            const size_t p = lbase + (size_t)min(u, pb.cap - 1) * CP_B;                              \
+            xm[u] = pb.xidx[p];                                                                      \
+            xh[u] = pb.xval[p];                                                                      \
+        }
+#define cc_cross_sums \
+        double xs = 0.0;                                                                             \
+_Pragma("unroll")                                                                                    \
+        for (int u = 0; u < CP_XCH; ++u)                                                                \
+            if (u < ncx && ((sPrev[xm[u] >> 6] >> (xm[u] & 63)) & 1ull)) xs += xh[u];                \
+        for (int e0 = CP_XCH; e0 < ncx; e0 += 16) {                                                     \
+            int m[16];                                                                               \
+            double h[16];                                                                            \
+_Pragma("unroll")                                                                                    \
+            for (int u = 0; u < 16; ++u) {                                                           \
+                const size_t p = lbase + (size_t)min(e0 + u, ncx - 1) * CP_B;                        \
+                m[u] = pb.xidx[p];                                                                   \
+                h[u] = pb.xval[p];                                                                   \
+            }                                                                                        \
+_Pragma("unroll")                                                                                    \
+            for (int u = 0; u < 16; ++u)                                                             \
+                if (e0 + u < ncx && ((sPrev[m[u] >> 6] >> (m[u] & 63)) & 1ull)) xs += h[u];          \
+        }
+
 // Resolve batch b of slice t: thread k owns node k of the batch.
 #ifdef DLSM_PIPE_TIMING
 // resolver phase stamps and evaluator entry / exit of the last sweep (profiles/ccpipe_timing.py)
@@ -311,7 +354,7 @@ __device__ __forceinline__ void ccpipe_resolve(const ChainView &c, const CcPipeB
     // memory leaves in ONE go without either thread holding both lists in registers
     // (profiles/ccpipe_timing.py: the resolver is the launch's critical path, and was four
     // memory round trips of 3 - 4 us in sequence - state, cross entries, own entries, each behind
-    // a count).  The first XCH cross / CP_OWN_REGS own entries are requested whatever the counts
+    // a count).  The first CP_XCH cross / CP_OWN_REGS own entries are requested whatever the counts
     // will turn out to be (the lists are entry-major with room for `cap` entries; what lies
     // beyond a count is ignored).
     static_assert(CP_THREADS == 2 * CP_B, "two threads per node");
@@ -326,7 +369,6 @@ __device__ __forceinline__ void ccpipe_resolve(const ChainView &c, const CcPipeB
     // Cross entries up front: 24 (a node of config 4 has 12 on average, more than 16 in one of
     // eight cases, and a second trip to memory for the few costs every wavefront 3.6 us); the two
     // halves are separate code paths, so neither holds the other's registers.
-    constexpr int XCH = 24;
     const int nlist = pb.cnt[slot * 2 + (upper ? 0 : 1)];
     const int ncx = upper ? nlist : 0, nown = upper ? 0 : nlist;
     int oi[CP_OWN_REGS];
@@ -337,15 +379,27 @@ __device__ __forceinline__ void ccpipe_resolve(const ChainView &c, const CcPipeB
     for (int d = 0; d < D; ++d) x1[d] = 0.0;
 #pragma unroll
     for (int e = 0; e < CP_OWN_REGS; ++e) { oi[e] = 0; ov[e] = 0.0; }
-    if (upper) {
-        int xm[XCH];
-        double xh[XCH];
-#pragma unroll
-        for (int u = 0; u < XCH; ++u) {
-            const size_t p = lbase + (size_t)min(u, pb.cap - 1) * CP_B;
-            xm[u] = pb.xidx[p];
-            xh[u] = pb.xval[p];
+    if (upper && pb.helpers) {
+        // the slice's helper workgroup (another CU) has summed the cross entries: wait for its announcement,
+        // take the sums past the L1
+        cc_barrier_arrive();                           // (the lower half's barrier: it waits for sPrev's store)
+        // (the sums announce themselves: a slot holds CC_XS_EMPTY until its sum is stored - one trip to the L2 less
+        // than a flag and then the sums, 0.7 us on the launch's critical path)
+        const unsigned long long *slotp = (const unsigned long long *)&pb.xsum[(size_t)t * CP_B + k];
+        unsigned long long got = CC_XS_EMPTY;
+        for (int n = 0; n < pb.budget; ++n) {
+            got = __hip_atomic_load(slotp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__ballot(got == CC_XS_EMPTY) == 0ull) break;
+            __builtin_amdgcn_s_sleep(1);
         }
+        if (__ballot(got == CC_XS_EMPTY) != 0ull && lane == 0)
+            __hip_atomic_fetch_or(pb.err, CC_ERR_HELPER, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        sCross[k] = __longlong_as_double((long long)got);
+        // taken: empty again for the next launch (a plain store: the kernel boundary publishes it; the helper
+        // stores each slot once per launch, before this)
+        pb.xsum[(size_t)t * CP_B + k] = __longlong_as_double((long long)CC_XS_EMPTY);
+    } else if (upper) {
+        cc_cross_loads
         // Each half of the workgroup meets the other at its OWN s_barrier: the halves are whole
         // wavefronts - `upper` is wave-uniform - and the hardware counts a workgroup's ARRIVALS,
         // whatever the instruction address (gfx950 ISA: s_barrier).  That is a contract of the
@@ -356,26 +410,7 @@ __device__ __forceinline__ void ccpipe_resolve(const ChainView &c, const CcPipeB
         // (One barrier behind the if / else was built: both halves' operands are then live at one
         // program point, 119 -> 128 VGPRs and 14 spilled, on the kernel's critical path.)
         cc_barrier_arrive();                           // sPrev visible
-        // the previous batch's acceptances, final by now: the node's cross entries in list order
-        // (a list longer than the 24 at hand comes sixteen entries per trip, their loads issued
-        // together), handed over through LDS
-        double xs = 0.0;
-#pragma unroll
-        for (int u = 0; u < XCH; ++u)
-            if (u < ncx && ((sPrev[xm[u] >> 6] >> (xm[u] & 63)) & 1ull)) xs += xh[u];
-        for (int e0 = XCH; e0 < ncx; e0 += 16) {
-            int m[16];
-            double h[16];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const size_t p = lbase + (size_t)min(e0 + u, ncx - 1) * CP_B;
-                m[u] = pb.xidx[p];
-                h[u] = pb.xval[p];
-            }
-#pragma unroll
-            for (int u = 0; u < 16; ++u)
-                if (e0 + u < ncx && ((sPrev[m[u] >> 6] >> (m[u] & 63)) & 1ull)) xs += h[u];
-        }
+        cc_cross_sums
         sCross[k] = xs;
     } else {
 #pragma unroll
@@ -533,12 +568,53 @@ __device__ __forceinline__ void ccpipe_resolve(const ChainView &c, const CcPipeB
     if (!upper && lane == 0) accg[wave] = mine;
 #ifdef DLSM_PIPE_TIMING
     DLSM_CC_STAMP(5, (double)lane)
-    if (tid == 0 && tl >= 0 && tl < 32 && t < 16) for (int i = 0; i < 7; ++i) g_cc_res_t[tl][t][i] = cts[i];
+    if (tid == 0 && tl >= 0 && tl < 32 && t < 16) for (int i = 0; i < 7; ++i) if (i != 1) g_cc_res_t[tl][t][i] = cts[i];   // ([1], [7]: the helper's)
 #endif
 }
 
+// The helper of slice t's resolver: the cross sums of batch b (cc_cross_loads / _sums above) on a CU of its own.
+// The resolver's first trip to memory was 250 KB through ONE CU's vector L1 - 147 KB of them the cross entries -
+// and lasted 4.7 us, with the cross sums' barrier at 7 us (profiles/r05_ccpipe_timing.json); a build without
+// the cross entries ran the launch in 10.7 instead of 12.55 us.  The helper takes those 147 KB through another
+// CU's L1 and stores the 512 sums past its L1 into slots that hold CC_XS_EMPTY; the resolver's upper half polls
+// its nodes' slots past ITS L1 until none is empty, and empties them again behind its read (device_common.hpp:
+// the sc1 / sc1 hand-off, with the datum as its own flag).  A launch whose resolver runs has its helper run; the
+// sweep's first launch, which resolves nothing, empties every slot.
+template <int D>
+__device__ __forceinline__ void ccpipe_cross_helper(const ChainView &c, const CcPipeBuf &pb, int b, int t,
+                                                    unsigned long long *sPrev
+#ifdef DLSM_PIPE_TIMING
+                                                    , int tl
+#endif
+                                                    ) {
+    const int tid = threadIdx.x;
+#ifdef DLSM_PIPE_TIMING
+    unsigned long long cts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    DLSM_CC_STAMP(1, (double)tid)
+#endif
+    const int nb = min(CP_B, c.N - b * CP_B);
+    const int bb = b & 1;
+    if (tid < CP_WAVES) sPrev[tid] = b > 0 ? pb.accmask[(size_t)t * CP_WAVES + tid] : 0ull;
+    if (tid < CP_B) {                                   // (whole wavefronts: see the resolver's note on s_barrier)
+        const int k = tid, kc = min(k, nb - 1);
+        const size_t slot = ((size_t)bb * c.T + t) * CP_B + kc;
+        const size_t lbase = ((size_t)bb * c.T + t) * pb.cap * CP_B + kc;
+        const int ncx = pb.cnt[slot * 2];
+        cc_cross_loads
+        cc_barrier_arrive_after_lds_stores();           // sPrev (wavefront 0's store) visible; the 48 loads stay in flight
+        cc_cross_sums
+        coh_store<true>(&pb.xsum[(size_t)t * CP_B + k], xs);       // (an 8-byte store past the L1: the announcement)
+#ifdef DLSM_PIPE_TIMING
+        DLSM_CC_STAMP(7, xs)
+        if (tid == 0 && tl >= 0 && tl < 32 && t < 16) { g_cc_res_t[tl][t][1] = cts[1]; g_cc_res_t[tl][t][7] = cts[7]; }
+#endif
+    } else {                                            // (the workgroup's other eight wavefronts: an arrival only)
+        cc_barrier_arrive();
+    }
+}
+
 // Launch l: even slices resolve batch l and evaluate batch l + 1; odd slices resolve batch
-// l - 1 and evaluate batch l.  Workgroups [0, T) resolve, the rest evaluate.
+// l - 1 and evaluate batch l.  Workgroups [0, T) resolve, [T, 2 T) are their helpers (pb.helpers), the rest evaluate.
 template <int D>
 __global__ __launch_bounds__(CP_THREADS) void k_ccpipe_step(ChainView c, CcPipeBuf pb, int l) {
     __shared__ unsigned long long sMask[2][CP_WAVES];
@@ -552,6 +628,9 @@ __global__ __launch_bounds__(CP_THREADS) void k_ccpipe_step(ChainView c, CcPipeB
     if ((int)blockIdx.x < T) {
         const int t = blockIdx.x;
         const int b = l - (t & 1);
+        // (the sweep's first launch resolves nothing: it empties the helpers' hand-over slots)
+        if (l < 0 && pb.helpers && (int)threadIdx.x < CP_B)
+            pb.xsum[(size_t)t * CP_B + threadIdx.x] = __longlong_as_double((long long)CC_XS_EMPTY);
         if (b >= 0 && b < pb.nbat) ccpipe_resolve<D>(c, pb, b, t, sMask, sPrev, sChanged, sCross, sOv, sOi
 #ifdef DLSM_PIPE_TIMING
                                                      , l + 1
@@ -559,22 +638,35 @@ __global__ __launch_bounds__(CP_THREADS) void k_ccpipe_step(ChainView c, CcPipeB
                                                      );
         return;
     }
+    const int nres = pb.helpers ? 2 * T : T;            // workgroups in front of the evaluators
+    if ((int)blockIdx.x < nres) {
+        const int t = (int)blockIdx.x - T;
+        const int b = l - (t & 1);
+        if (b >= 0 && b < pb.nbat) ccpipe_cross_helper<D>(c, pb, b, t, sPrev
+#ifdef DLSM_PIPE_TIMING
+                                                           , l + 1
+#endif
+                                                           );
+        return;
+    }
     __shared__ double sTab[EXPTAB_N];                   // 2^(j / 256): the evaluators' exponential
-    exp_table_fill(sTab, threadIdx.x);
-    __syncthreads();
     const int lane = threadIdx.x & 63;
     const int nE = (T + 1) / 2, nO = T / 2;
     const int beE = l + 1, beO = l;
     const int nbE = (beE >= 0 && beE < pb.nbat) ? min(CP_B, c.N - beE * CP_B) : 0;
     const int nbO = (beO >= 0 && beO < pb.nbat) ? min(CP_B, c.N - beO * CP_B) : 0;
     const int nodesE = nE * nbE, nodes = nodesE + nO * nbO;
-    const int nwaves = ((int)gridDim.x - T) * CP_WAVES;
+    const int n_wg = (int)gridDim.x - nres, wg = (int)blockIdx.x - nres;
+    const int nwaves = n_wg * CP_WAVES;
     // item q -> wavefront (q / workgroups) of workgroup (q % workgroups): a launch's items are spread over
-    // every evaluator CU (2560 items on 251 CUs: 10 or 11 wavefronts each, 2 - 3 per SIMD) instead of filling
-    // 160 CUs with four wavefronts per SIMD - the item is ~720 float64 vector instructions and four of them
+    // every evaluator CU (2560 items on 246 CUs: 10 or 11 wavefronts each, 2 - 3 per SIMD) instead of filling
+    // 160 CUs with four wavefronts per SIMD - the item is ~900 float64 vector instructions and four of them
     // on one SIMD take turns issuing (round 5: profiles/r05_ccpipe_timing.json)
-    const int gw = __builtin_amdgcn_readfirstlane(
-        (int)(threadIdx.x >> 6) * ((int)gridDim.x - T) + ((int)blockIdx.x - T));
+    const int gw = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6) * n_wg + wg);
+    // (Built and dropped, round 5: the workgroup's wavefronts without an item - five or six of sixteen - requesting
+    // the term rows of the NEXT launch's items into this XCD's L2: 2475 it/s against 2533 without.)
+    exp_table_fill(sTab, threadIdx.x);
+    __syncthreads();
     for (int q = gw; q < nodes; q += nwaves) {
         const bool odd = q >= nodesE;
         const int qq = odd ? q - nodesE : q;

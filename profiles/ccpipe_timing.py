@@ -1,6 +1,6 @@
 """Phase stamps of the sparse pipelined case-control sweep (k_ccpipe_step, algo 5) at config 4:
 resolver workgroups (stamps 0 entry, 2 state and lists loaded + cross sums handed over,
-3 first ballot, 4 fixed point reached, 5 exit; 1 unused) and evaluator wavefronts (entry / exit), last sweep; engine built with
+3 first ballot, 4 fixed point reached, 5 exit; 1 / 7 the helper workgroup's entry / announcement) and evaluator wavefronts (entry / exit), last sweep; engine built with
 -DDLSM_PIPE_TIMING.
     python profiles/ccpipe_timing.py tmp_timing/libtiming.so [out.json]
 """
@@ -51,6 +51,10 @@ for l in range(32):
         row['resolver_us_median'] = [round(float(np.median(rel[:, i])), 2) for i in range(6)]
         row['resolver_us_max'] = [round(float(rel[:, i].max()), 2) for i in range(6)]
         row['resolver_fixed_point_passes_wave0'] = [int(v) for v in r[:, 6]]
+        if (r[:, 7] > 0).any():         # the cross-sum helpers (ccpipe_cross_helper): entry, sums announced
+            hh = r[r[:, 7] > 0]
+            row['helper_entry_exit_us_median'] = [round(float(np.median((hh[:, 1] - t0) * 0.01)), 2),
+                                                  round(float(np.median((hh[:, 7] - t0) * 0.01)), 2)]
     if it.size:
         rel = (it - t0) * 0.01
         row['evaluator_entry_us_p50_max'] = [round(float(np.median(rel[:, 0])), 2), round(float(rel[:, 0].max()), 2)]
