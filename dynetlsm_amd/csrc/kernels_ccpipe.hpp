@@ -664,7 +664,8 @@ __global__ __launch_bounds__(CP_THREADS) void k_ccpipe_step(ChainView c, CcPipeB
     // on one SIMD take turns issuing (round 5: profiles/r05_ccpipe_timing.json)
     const int gw = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6) * n_wg + wg);
     // (Built and dropped, round 5: the workgroup's wavefronts without an item - five or six of sixteen - requesting
-    // the term rows of the NEXT launch's items into this XCD's L2: 2475 it/s against 2533 without.)
+    // the term rows of the NEXT launch's items into this XCD's L2: 2475 it/s against 2533 without; the first item's
+    // row head requested before the table's barrier: 2483 against 2519, three spilled registers.)
     exp_table_fill(sTab, threadIdx.x);
     __syncthreads();
     for (int q = gw; q < nodes; q += nwaves) {

@@ -432,6 +432,31 @@ def test_sweep_case_control_sparse_lists_other_dimensions(eng, D):
                 density=0.01)
 
 
+def test_sweep_case_control_sparse_lists_with_and_without_helper_workgroups(eng, monkeypatch):
+    """algo 5's cross sums by the resolvers' helper workgroups (default; kernels_ccpipe.hpp, ccpipe_cross_helper)
+    and by the resolvers themselves (DLSM_CC_HELPERS=0): the same sums in the same order - the same bits - and
+    both the oracle's decisions"""
+    res = {}
+    for mode in ('1', '0'):
+        monkeypatch.setenv('DLSM_CC_HELPERS', mode)
+        _sweep_case(eng, 'case_control', 'rw', T=3, N=2300, D=2, n_sweeps=2, algo=5, scale=0.05, cc_C=12,
+                    density=0.004)
+        X, Yd, _, radii = _rand_net(77, 3, 1700, 2, density=0.006, scale=0.05)
+        cc = _cc_lists(Yd, 10, 77)
+        g = eng.SamplerGrid(3, 1700, 0.01, tune=5, tune_interval=2)
+        with eng.Chain(3, 1700, 2, 'case_control', seed=99, chain_id=3) as c:
+            c.upload_edges(cc['in_edges'], cc['out_edges'], cc['degree'])
+            c.set_controls(cc['control_nodes_in'], cc['control_nodes_out'])
+            c.set_positions(X); c.set_intercepts([0.3, 0.7]); c.set_radii(radii)
+            c.set_prior_random_walk(2.0, 0.1); c.set_samplers(g)
+            for it in range(1, 6):
+                c.sweep_positions(it, algo=5)
+            res[mode] = (c.get_positions().copy(), c.get_samplers(g).n_accepted.copy())
+    np.testing.assert_array_equal(res['1'][0], res['0'][0])
+    np.testing.assert_array_equal(res['1'][1], res['0'][1])
+    assert res['1'][1].sum() > 0
+
+
 def _run_sweeps(eng, algo, T, N, D, name, prior, n_sweeps, seed=5):
     # (directed networks at the scale of their radii, as everywhere in this file: at scale 1 the
     # linear predictors reach 1e3 - 1e4 and every batched form drifts from the sequential sweep
