@@ -74,6 +74,12 @@ __device__ __forceinline__ void box_muller(double u0, double u1, double &z0,
     z1 = r * s;
 }
 
+// latent dimensions: every kernel is a template of n_features; 1..DLSM_D_MAX are built.  The pipelined sweeps
+// (k_pipe_step, k_ccpipe_step: register budgets tuned per dimension) stop at DLSM_D_PIPE_MAX, the dimensions of
+// the reference's examples and of the paper; above it the slice and speculative-batch sweeps run.
+constexpr int DLSM_D_MAX = 8;
+constexpr int DLSM_D_PIPE_MAX = 4;
+
 // ---- cross-workgroup hand-offs inside one launch -----------------------------------------
 // A CU's vector L1 is never refreshed by another CU's stores, and a kernel boundary is the only
 // implicit write-back / invalidate.  Bytes that one workgroup of a persistent launch hands to
@@ -84,11 +90,6 @@ __device__ __forceinline__ void box_muller(double u0, double u1, double &z0,
 // COH = false gives the plain accesses of the launch-per-batch kernels.
 typedef unsigned int dlsm_u4 __attribute__((ext_vector_type(4)));
 typedef unsigned int dlsm_u2 __attribute__((ext_vector_type(2)));
-// latent dimensions: every kernel is a template of n_features; 1..DLSM_D_MAX are built.  The pipelined sweeps
-// (k_pipe_step, k_ccpipe_step: register budgets tuned per dimension) stop at DLSM_D_PIPE_MAX, the dimensions of
-// the reference's examples and of the paper; above it the slice and speculative-batch sweeps run.
-constexpr int DLSM_D_MAX = 8;
-constexpr int DLSM_D_PIPE_MAX = 4;
 constexpr int DLSM_AUX_SC1 = 16;                 // cache-policy bit of the buffer builtins
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t coh_rsrc(const void *base) {
     // wave-uniform base (forced into scalar registers), byte offsets from the lanes
