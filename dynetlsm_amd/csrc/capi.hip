@@ -1207,7 +1207,10 @@ static int launch_sweep_ccpipe(dlsm_chain *h, IterRef iter, bool alloc_only = fa
     // resident; DLSM_CC_HELPERS=0 keeps the resolvers on their own
     const char *eh = getenv("DLSM_CC_HELPERS");
     pb.helpers = (eh ? atoi(eh) != 0 : true) && h->n_cu >= 4 * T && h->fork_err_dev != nullptr;
-    pb.budget = 1 << 22;
+    {   // polls of a resolver's wait for its helper before the sticky error word is set (DLSM_CC_HELPER_BUDGET)
+        const char *ebud = getenv("DLSM_CC_HELPER_BUDGET");
+        pb.budget = ebud ? atoi(ebud) : (1 << 22);
+    }
     pb.err = h->fork_err_dev;
     pb.nctrl = h->nctrl; pb.cap = cap; pb.nbat = nbat;
     pb.terms = h->cc_terms; pb.tw = tw;

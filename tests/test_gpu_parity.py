@@ -457,6 +457,34 @@ def test_sweep_case_control_sparse_lists_with_and_without_helper_workgroups(eng,
     assert res['1'][1].sum() > 0
 
 
+def test_sweep_case_control_helper_wait_is_bounded_and_reported(eng, monkeypatch):
+    """a resolver's wait for its helper workgroup has a poll budget (DLSM_CC_HELPER_BUDGET): with a budget of
+    zero it gives up at once, nothing hangs, and the sticky error word makes the call fail with DLSM_E_HIP;
+    reported once, after which the same handle sweeps on"""
+    X, Yd, _, radii = _rand_net(78, 2, 1300, 2, density=0.006, scale=0.05)
+    cc = _cc_lists(Yd, 10, 78)
+    g = eng.SamplerGrid(2, 1300, 0.01, tune=None)
+    with eng.Chain(2, 1300, 2, 'case_control', seed=99, chain_id=3) as c:
+        c.upload_edges(cc['in_edges'], cc['out_edges'], cc['degree'])
+        c.set_controls(cc['control_nodes_in'], cc['control_nodes_out'])
+
+        def start():
+            c.set_positions(X); c.set_intercepts([0.3, 0.7]); c.set_radii(radii)
+            c.set_prior_random_walk(2.0, 0.1); c.set_samplers(g)
+        start()
+        c.sweep_positions(1, algo=5)
+        good = c.get_positions().copy()
+        monkeypatch.setenv('DLSM_CC_HELPER_BUDGET', '0')
+        start()
+        with pytest.raises(RuntimeError, match='poll budget'):
+            c.sweep_positions(1, algo=5)
+        c.synchronize()                                   # reported once
+        monkeypatch.delenv('DLSM_CC_HELPER_BUDGET')
+        start()
+        c.sweep_positions(1, algo=5)
+        np.testing.assert_array_equal(c.get_positions(), good)
+
+
 def _run_sweeps(eng, algo, T, N, D, name, prior, n_sweeps, seed=5):
     # (directed networks at the scale of their radii, as everywhere in this file: at scale 1 the
     # linear predictors reach 1e3 - 1e4 and every batched form drifts from the sequential sweep
