@@ -89,6 +89,9 @@ class ChainGroup(object):
             d['control_backend'] = str(self._dist.get_backend(self._ctl)) if self._ctl is not None else d['backend']
             d['device'] = str(self._tensor_device())
         d.update({k: (round(v, 4) if isinstance(v, float) else v) for k, v in self.stats.items()})
+        if getattr(self, 'fallback_reason', None):
+            d['requested_backend'] = 'nccl'
+            d['fallback_reason'] = self.fallback_reason
         return d
 
     def _timed(self, kind, nbytes, t0):
@@ -209,16 +212,47 @@ def init_chain_group(backend=None, force=False):
     import torch.distributed as dist
     if backend is None:
         backend = 'nccl' if torch.cuda.is_available() else 'gloo'
-    if backend == 'nccl':
-        torch.cuda.set_device(local_rank)
+    fallback_reason = None
     if world > 1 or force:
         kw = {}
         if backend == 'nccl':
             kw['device_id'] = torch.device('cuda', local_rank)
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29511')
-        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
-    return ChainGroup(rank, world, local_rank, backend, dist, torch, force=force)
+        try:
+            if backend == 'nccl':
+                torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+            if backend == 'nccl':
+                # the communicator really works (one element summed over the ranks) before anything relies on it
+                probe = torch.ones(1, device=torch.device('cuda', local_rank))
+                dist.all_reduce(probe)
+                torch.cuda.synchronize()
+                if int(probe.item()) != world:
+                    raise RuntimeError('RCCL all_reduce probe returned %r for %d ranks' % (probe.item(), world))
+        except Exception as exc:        # noqa: BLE001
+            # The chains are independent: the collectives carry the network once, the final gather and the
+            # barriers - none of them is on the data path.  An RCCL that does not come up on a node (its
+            # environment, not this code) must not cost the run: the same collectives go through gloo, and the
+            # bench line's `collectives` block says so.  DLSM_NO_BACKEND_FALLBACK=1 keeps the failure.
+            if backend != 'nccl' or os.environ.get('DLSM_NO_BACKEND_FALLBACK') == '1':
+                raise
+            fallback_reason = '%s: %s' % (type(exc).__name__, str(exc)[:300])
+            print('dynetlsm_amd: RCCL process group failed on rank %d (%s); collectives go through gloo'
+                  % (rank, fallback_reason), file=sys.stderr)
+            try:
+                if dist.is_initialized():
+                    dist.destroy_process_group()
+            except Exception:           # noqa: BLE001
+                pass
+            os.environ['MASTER_PORT'] = str(int(os.environ['MASTER_PORT']) + 1)     # (the failed group's store)
+            backend = 'gloo'
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    elif backend == 'nccl':
+        torch.cuda.set_device(local_rank)
+    g = ChainGroup(rank, world, local_rank, backend, dist, torch, force=force)
+    g.fallback_reason = fallback_reason
+    return g
 
 
 # ------------------------------------------------------------------------------------

@@ -219,3 +219,36 @@ def test_visible_gpu_count_makes_no_runtime_call(monkeypatch):
     assert 0 <= n <= 3 and (n == 3 or os.path.isdir('/sys/class/kfd/kfd/topology/nodes'))
     monkeypatch.setenv('HIP_VISIBLE_DEVICES', '')
     assert multichain.visible_gpu_count() == 0
+
+
+def test_rccl_that_does_not_come_up_falls_back_to_gloo_and_says_so():
+    """init_chain_group(backend='nccl') where RCCL cannot start (here: no GPU) - the chains are independent and
+    no collective is on the data path, so the setup collectives go through gloo and `describe()` (the bench
+    line's `collectives` block) names the requested backend and the reason; DLSM_NO_BACKEND_FALLBACK=1 keeps
+    the failure"""
+    code = textwrap.dedent('''
+        import json, sys
+        sys.path.insert(0, %r)
+        import numpy as np
+        from dynetlsm_amd.multichain import init_chain_group
+        g = init_chain_group(backend='nccl', force=True)
+        out = g.gather_arrays(np.arange(3.0))
+        d = g.describe()
+        g.close()
+        print(json.dumps({'backend': g.backend, 'reason': g.fallback_reason, 'describe': d,
+                          'gathered': [a.tolist() for a in out]}))
+    ''') % ROOT
+    env = dict(os.environ, RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1',
+               MASTER_PORT=str(_free_port()))
+    r = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=180)
+    assert r.returncode == 0, r.stderr[-2000:]
+    import json
+    res = json.loads(r.stdout.strip().splitlines()[-1])
+    assert res['backend'] == 'gloo' and res['reason']
+    assert res['describe']['requested_backend'] == 'nccl' and res['describe']['backend'] == 'gloo'
+    assert res['gathered'] == [[0.0, 1.0, 2.0]]
+    assert 'collectives go through gloo' in r.stderr
+    env['DLSM_NO_BACKEND_FALLBACK'] = '1'
+    env['MASTER_PORT'] = str(_free_port())
+    r = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=180)
+    assert r.returncode != 0
