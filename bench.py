@@ -116,19 +116,15 @@ def parse(argv=None):
                          'enqueued by its own host thread (aggregate throughput)')
     ap.add_argument('--algo', type=int, default=0, help='sweep algorithm (0 auto)')
     ap.add_argument('--profile-steps', type=int, default=100,
-                    help='iterations of the per-kernel event phase that precedes the warm-up steps '
-                         '(averages over 100 x 18 sweep launches; it also leaves the device in its '
-                         'running state: a short timed window right after an idle device reads 3-5 %% low)')
+                    help='iterations of the per-kernel event phase (averages over 100 x 18 sweep launches); it runs '
+                         'BEHIND the timed window since round 5: a 20-step window behind it read 2-6 %% low')
     ap.add_argument('--settle-steps', type=int, default=300,
-                    help='plain iterations of every chain between the event-instrumented profile phase '
-                         'and the W warm-up steps (untimed, reported in the line as '
-                         'untimed_steps_before_warmup).  A call of the loop costs 20 / 140 / 130 us beyond its '
-                         'iterations (LSM / HDP-LPCM / case-control: profiles/per_call_cost.py), yet a 20-step '
-                         'window behind the profile phase - whose host-side event bookkeeping leaves the device '
-                         'idle for milliseconds - read 3 / 7 %% below a 200-step window: the device is not in its '
-                         'running state yet.  Measured on one MI355X (round 5, --steps 20 --warmup 5): LSM '
-                         '4515-4609 without / 4520-4679 with 300 settle steps (200 steps: 4714); HDP-LPCM '
-                         '3614-3679 / 3837-3857 (200 steps: 3940).  0 switches them off')
+                    help='plain untimed iterations of every chain in front of the W warm-up steps (reported in the '
+                         'line as untimed_steps_before_warmup): the chain starts on a device that sat idle through '
+                         'the host-side generation of the network, and a window behind 50 ms of idle device reads '
+                         '9 %% low, the next one still 5 %% (profiles/window_probe.py).  A call of the loop itself '
+                         'costs 20 / 140 / 130 us beyond its iterations (LSM / HDP-LPCM / case-control: '
+                         'profiles/per_call_cost.py).  0 switches them off')
     ap.add_argument('--windows', type=int, default=1,
                     help='diagnostic: time this many further windows of K steps behind the contract\'s one '
                          '(reported as later_windows; `value` is always the first window)')
@@ -935,20 +931,21 @@ class CcWorkload(object):
 
 
 def measure(wl, args, group):
-    """the roofline profile (P steps), W untimed warm-up steps, then exactly K steps between
-    barriers + synchronisation, max over ranks; the final gather follows outside the timed region"""
+    """untimed settle steps, W untimed warm-up steps, then exactly K steps between barriers +
+    synchronisation, max over ranks; the final gather and the roofline profile (P steps with events
+    around every launch) follow outside the timed region"""
     import torch
     K, W = args.steps, args.warmup
     # (torch initialises its device state lazily: the first torch.cuda.synchronize() of the process here, not
     # between the warm-up and the timed window)
     torch.cuda.synchronize()
     group.barrier()
-    # the per-kernel profile (P steps with HIP events around every launch) comes first: it is
-    # part of every run anyway, and placed here the timed steps do not start on a device that has
-    # just sat idle through the host-side generation of the network
+    # Untimed settle steps, the W warm-up steps, the timed window - and the per-kernel profile (P steps with HIP
+    # events around every launch) BEHIND it.  Round 5 measured what the profile phase does to a window that follows
+    # it, 300 settle steps and the warm-up notwithstanding (same box, alternating, device events of the window):
+    # 4430-4596 it/s behind the profile phase, 4680-4709 without one - its ~2000 events keep the runtime busy on
+    # the device's side for a while; every later window ran at 4650-4710 either way.
     roofline, extra = (None, {})
-    if args.profile_steps > 0:
-        roofline, extra = wl.profile()
     if args.settle_steps > 0:
         wl.run(args.settle_steps)
     wl.run(W)
@@ -981,8 +978,9 @@ def measure(wl, args, group):
         group.barrier()
         wl.later_windows.append(group.max_over_ranks(time.perf_counter() - tw))
     acc = wl.acceptance()
-    P = args.profile_steps if args.profile_steps > 0 else 0
-    gathered = group.gather_results(wl.results(1 + P + args.settle_steps + W, K))
+    gathered = group.gather_results(wl.results(1 + args.settle_steps + W, K))
+    if args.profile_steps > 0:
+        roofline, extra = wl.profile()
     # (ranks, chains per GPU, ...) -> (chains, ...)
     gathered = {k: v.reshape((-1,) + v.shape[2:]) for k, v in gathered.items()}
     return elapsed, roofline, extra, acc, gathered
@@ -1035,8 +1033,8 @@ def run_rank(args):
                 line = {
                     'metric': wl.metric(), 'value': round(value, 3), 'unit': 'Gibbs iterations/s',
                     'n_gpus': world, 'steps': K, 'warmup': W,
-                    'untimed_steps_before_warmup': {'profile_steps': max(args.profile_steps, 0),
-                                                    'settle_steps': args.settle_steps},
+                    'untimed_steps_before_warmup': {'settle_steps': args.settle_steps},
+                    'profile_steps_behind_the_timed_window': max(args.profile_steps, 0),
                     'ms_per_step': round(1e3 * elapsed / K, 4), 'higher_is_better': True,
                     'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
                     'config': {'workload': wl.workload(), 'density': round(wl.density, 4),
