@@ -86,6 +86,14 @@ def test_sweep_medium_every_algorithm_the_wide_dimensions_have(eng, name, N, alg
                   density=(0.004 if big else 0.05) if name == 'case_control' else 0.2)
 
 
+@pytest.mark.parametrize('name,D', [('undirected', 6), ('directed', 5), ('undirected', 8)])
+def test_sweep_at_the_headline_size(eng, name, D):
+    """T = 2, N = 2000 (BASELINE.json's N) at a wide dimension: the speculative-batch sweep the automatic choice
+    resolves to, against the oracle"""
+    P._sweep_case(eng, name, 'rw', T=2, N=2000, D=D, n_sweeps=1, algo=0,
+                  scale=1.0 if name == 'undirected' else 0.05, density=0.03)
+
+
 def test_pipelined_sweeps_refuse_the_wide_dimensions(eng):
     with eng.Chain(2, 600, 5, 'undirected') as c:
         assert c.resolve_sweep_algo(0) == 2
