@@ -1021,12 +1021,10 @@ static int launch_sweep_spec(dlsm_chain *h, IterRef iter, int S, bool alloc_only
 // workgroup per slice
 static int resolve_sweep_algo(const dlsm_chain *h, int algo) {
     if (algo != 0) return algo;
-    // n_features 5..8: the slice-in-LDS and the speculative-batch sweeps (the pipelined ones are built and
-    // tuned for the 1..4 dimensions of the reference's examples and the paper)
-    if (h->D > DLSM_D_PIPE_MAX) return h->N >= 256 ? 2 : 1;
-    // case-control: sparse correction lists once a slice has several batches of 512
+    if (h->D > DLSM_D_PIPE_MAX) return h->N >= 256 ? 2 : 1;       // (none today: the pipelined sweep is built to DLSM_D_MAX)
+    // case-control: sparse correction lists once a slice has several batches of 512 (n_features <= 4: its records)
     if (h->model == DLSM_DIRECTED_CASE_CONTROL)
-        return h->N >= 2048 ? 5 : (h->N >= 512 ? 4 : (h->N >= 256 ? 2 : 1));
+        return (h->N >= 2048 && h->D <= DLSM_D_CCPIPE_MAX) ? 5 : (h->N >= 512 ? 4 : (h->N >= 256 ? 2 : 1));
     return h->N >= 512 ? 4 : (h->N >= 256 ? 2 : 1);
 }
 
@@ -1256,14 +1254,18 @@ static int launch_sweep(dlsm_chain *h, IterRef iter, int algo, bool alloc_only =
         algo = resolve_sweep_algo(h, algo);
         if (alloc_only) {
             hipStreamSynchronize(h->stream);
-            if constexpr (DD <= DLSM_D_PIPE_MAX) {
+            if constexpr (DD <= DLSM_D_CCPIPE_MAX) {
                 if (algo == 5) return launch_sweep_ccpipe<DD>(h, iter, true);
+            }
+            if constexpr (DD <= DLSM_D_PIPE_MAX) {
                 if (algo == 4) return launch_sweep_pipe<DD>(h, iter, true);
             }
             return algo >= 2 ? launch_sweep_spec<DD>(h, iter, 1, true) : DLSM_OK;
         }
-        if constexpr (DD <= DLSM_D_PIPE_MAX) {
+        if constexpr (DD <= DLSM_D_CCPIPE_MAX) {
             if (algo == 5) return launch_sweep_ccpipe<DD>(h, iter);
+        }
+        if constexpr (DD <= DLSM_D_PIPE_MAX) {
             if (algo == 4) return launch_sweep_pipe<DD>(h, iter);
         }
         if (algo >= 2) return launch_sweep_spec<DD>(h, iter, 1);
@@ -1315,8 +1317,9 @@ static int launch_sweep(dlsm_chain *h, IterRef iter, int algo, bool alloc_only =
 static int check_sweep_algo(dlsm_chain *h, int algo) {
     NEED(h, algo >= 0 && algo <= 5, "algo must be 0..5 (6 and 7, measured slower than 4, were removed in round 5)");
     NEED(h, algo != 5 || h->model == DLSM_DIRECTED_CASE_CONTROL, "algo 5 is the case-control sweep");
-    NEED(h, (algo != 4 && algo != 5) || h->D <= DLSM_D_PIPE_MAX,
-         "the pipelined sweeps (algo 4, 5) are built for n_features <= 4; 5..8 take algo 0, 1, 2 or 3");
+    NEED(h, algo != 4 || h->D <= DLSM_D_PIPE_MAX, "the pipelined sweep (algo 4) is built for n_features <= 8");
+    NEED(h, algo != 5 || h->D <= DLSM_D_CCPIPE_MAX,
+         "the sparse case-control sweep (algo 5) is built for n_features <= 4; 5..8 take algo 0 .. 4");
     return DLSM_OK;
 }
 

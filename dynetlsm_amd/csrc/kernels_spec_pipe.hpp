@@ -587,7 +587,9 @@ __device__ __forceinline__ void pipe_item_prologue(const ChainView &c, const Pip
 
 // trips of 64 neighbours whose operands an undirected item loads up front
 __host__ __device__ constexpr int pipe_prefetch_trips(int D) {
-    return D == 1 ? 16 : D == 2 ? 11 : D == 3 ? 6 : 4;      // (d = 3, 4: one trip fewer than would fit on paper - seven / five spilled)
+    // (d = 3, 4: one trip fewer than would fit on paper - seven / five spilled; d = 5 .. 8: what is left beside the
+    // item's own 4 d registers of positions)
+    return D == 1 ? 16 : D == 2 ? 11 : D == 3 ? 6 : D == 4 ? 4 : D <= 6 ? 3 : 2;
 }
 
 // One wavefront: part p of node k of batch `be` in slice t.  TP: the trips beyond the

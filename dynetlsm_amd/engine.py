@@ -15,7 +15,7 @@ __all__ = ['Chain', 'SamplerGrid', 'EngineError', 'MAX_FEATURES', 'check_n_featu
 
 # The kernels take the latent dimension as a template parameter, instantiated for 1..8 (csrc/device_common.hpp
 # DLSM_D_MAX; the reference takes any n_features, lsm.py:235,254; its examples and the paper use 2).  The
-# pipelined sweeps stop at 4: above it the slice / speculative-batch sweeps run (capi.hip resolve_sweep_algo).
+# sparse case-control sweep (algo 5) stops at 4 (capi.hip resolve_sweep_algo).
 MAX_FEATURES = 8
 
 

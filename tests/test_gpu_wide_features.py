@@ -5,7 +5,8 @@ Every row of the path at the wide dimensions, against the oracle - which tests/t
 and tests/test_init_oracle_golden.py pin to the reference itself at n_features 5, 6 and 8
 (tests/golden/wide_*.npz: `python tests/golden/make_golden.py wide`).  The cases are those of the
 1..4 tests, called with the wide dimensions.  Above four dimensions the slice-in-LDS sweep (algo 1)
-and the speculative-batch sweeps (2, 3) run; the pipelined ones (4, 5) say so and refuse.
+the speculative-batch sweeps (2, 3) and the pipelined sweep (4) run; the sparse case-control sweep (5) says so
+and refuses.
 """
 import numpy as np
 import pytest
@@ -75,7 +76,8 @@ def test_sweep_slice_small(eng, name, prior, D):
 @pytest.mark.parametrize('name,N,algo', [('undirected', 300, 1), ('undirected', 300, 2), ('undirected', 700, 3),
                                          ('directed', 260, 1), ('directed', 300, 2),
                                          ('case_control', 300, 1), ('case_control', 300, 2),
-                                         ('undirected', 300, 0), ('case_control', 2300, 0)])
+                                         ('undirected', 300, 0), ('case_control', 2300, 0),
+                                         ('undirected', 700, 4), ('directed', 600, 4), ('case_control', 700, 4)])
 def test_sweep_medium_every_algorithm_the_wide_dimensions_have(eng, name, N, algo, D):
     """crosses the proposal-chunk (256) and the workgroup (1024) boundaries; algo 0 resolves to the
     speculative batches from 256 nodes on (capi.hip resolve_sweep_algo), case-control N = 2300 included"""
@@ -94,15 +96,15 @@ def test_sweep_at_the_headline_size(eng, name, D):
                   scale=1.0 if name == 'undirected' else 0.05, density=0.03)
 
 
-def test_pipelined_sweeps_refuse_the_wide_dimensions(eng):
+def test_sweep_algorithms_of_the_wide_dimensions(eng):
+    """the pipelined sweep (algo 4) runs to n_features = 8; the sparse case-control sweep (algo 5) stops at 4
+    and says so"""
     with eng.Chain(2, 600, 5, 'undirected') as c:
-        assert c.resolve_sweep_algo(0) == 2
-        with pytest.raises(eng.EngineError, match='n_features <= 4'):
-            c.resolve_sweep_algo(4)
+        assert c.resolve_sweep_algo(0) == 4
     with eng.Chain(2, 100, 8, 'undirected') as c:
         assert c.resolve_sweep_algo(0) == 1
     with eng.Chain(2, 3000, 6, 'case_control') as c:
-        assert c.resolve_sweep_algo(0) == 2
+        assert c.resolve_sweep_algo(0) == 4
         with pytest.raises(eng.EngineError, match='n_features <= 4'):
             c.resolve_sweep_algo(5)
 
@@ -144,7 +146,7 @@ def test_hdp_label_sums(eng, T, N, D, K):
 
 # ------------------------------------------------------------ the device-resident loops
 @pytest.mark.parametrize('D', WIDE)
-@pytest.mark.parametrize('N,algo', [(18, 1), (300, 1), (300, 2), (700, 0)])
+@pytest.mark.parametrize('N,algo', [(18, 1), (300, 1), (300, 2), (700, 0), (700, 4)])
 def test_lsm_device_loop_equals_oracle_iterations(eng, monks, N, algo, D):
     P.lsm_loop_case(eng, monks, N, algo, D)
 

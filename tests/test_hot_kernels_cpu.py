@@ -87,6 +87,14 @@ KNOWN_SCRATCH = {
     # sweep's two registers beyond the 128 of its 1024-thread workgroup at d = 7, 8
     'k_partial_all<5>': 48, 'k_partial_all<6>': 64, 'k_partial_all<7>': 64,
     'k_sweep_slice<7,0>': 12, 'k_sweep_slice<8,0>': 12,
+    # the pipelined sweep at d = 5 .. 8 (its register plan is d = 2's: the item's own 4 d registers of positions and
+    # two or three prefetched trips of d registers each no longer fit the 128 of a 1024-thread workgroup; 2910 it/s at
+    # d = 5, 1465 at d = 8 against 1660 / 1330 for the speculative sweep - DESIGN.md 9)
+    'k_pipe_last_ride<5>': 76, 'k_pipe_last_ride<6>': 148, 'k_pipe_last_ride<7>': 300, 'k_pipe_last_ride<8>': 500,
+    'k_pipe_step<5,0,1>': 84, 'k_pipe_step<5,1,1>': 100, 'k_pipe_step<5,2,1>': 108, 'k_pipe_step<5,3,1>': 84,
+    'k_pipe_step<6,0,1>': 140, 'k_pipe_step<6,1,1>': 188, 'k_pipe_step<6,2,1>': 164, 'k_pipe_step<6,3,1>': 136,
+    'k_pipe_step<7,0,1>': 180, 'k_pipe_step<7,1,1>': 216, 'k_pipe_step<7,2,1>': 208, 'k_pipe_step<7,3,1>': 188,
+    'k_pipe_step<8,0,1>': 236, 'k_pipe_step<8,1,1>': 304, 'k_pipe_step<8,2,1>': 248, 'k_pipe_step<8,3,1>': 240,
 }
 # vector registers parked in accumulation registers (no memory traffic: scratch_bytes is 0)
 KNOWN_AGPR_PARKED = {'k_post_apply<8>', 'k_lsm_finalize_apply_propose<8>', 'k_post_apply_dir<8>', 'k_post_align<8>'}
