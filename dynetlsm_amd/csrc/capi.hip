@@ -1022,7 +1022,7 @@ static int launch_sweep_spec(dlsm_chain *h, IterRef iter, int S, bool alloc_only
 static int resolve_sweep_algo(const dlsm_chain *h, int algo) {
     if (algo != 0) return algo;
     if (h->D > DLSM_D_PIPE_MAX) return h->N >= 256 ? 2 : 1;       // (none today: the pipelined sweep is built to DLSM_D_MAX)
-    // case-control: sparse correction lists once a slice has several batches of 512 (n_features <= 4: its records)
+    // case-control: sparse correction lists once a slice has several batches of 512
     if (h->model == DLSM_DIRECTED_CASE_CONTROL)
         return (h->N >= 2048 && h->D <= DLSM_D_CCPIPE_MAX) ? 5 : (h->N >= 512 ? 4 : (h->N >= 256 ? 2 : 1));
     return h->N >= 512 ? 4 : (h->N >= 256 ? 2 : 1);
@@ -1319,7 +1319,7 @@ static int check_sweep_algo(dlsm_chain *h, int algo) {
     NEED(h, algo != 5 || h->model == DLSM_DIRECTED_CASE_CONTROL, "algo 5 is the case-control sweep");
     NEED(h, algo != 4 || h->D <= DLSM_D_PIPE_MAX, "the pipelined sweep (algo 4) is built for n_features <= 8");
     NEED(h, algo != 5 || h->D <= DLSM_D_CCPIPE_MAX,
-         "the sparse case-control sweep (algo 5) is built for n_features <= 4; 5..8 take algo 0 .. 4");
+         "the sparse case-control sweep (algo 5) is not built for this n_features");
     return DLSM_OK;
 }
 

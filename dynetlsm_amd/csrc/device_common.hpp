@@ -78,7 +78,7 @@ __device__ __forceinline__ void box_muller(double u0, double u1, double &z0,
 // and the paper use 2; k_pipe_step's register plan is tuned for 1..4 and spills above)
 constexpr int DLSM_D_MAX = 8;
 constexpr int DLSM_D_PIPE_MAX = 8;        // k_pipe_step (algo 4)
-constexpr int DLSM_D_CCPIPE_MAX = 4;      // k_ccpipe_step (algo 5): its records and register plan
+constexpr int DLSM_D_CCPIPE_MAX = 8;      // k_ccpipe_step (algo 5)
 
 // ---- cross-workgroup hand-offs inside one launch -----------------------------------------
 // A CU's vector L1 is never refreshed by another CU's stores, and a kernel boundary is the only

@@ -68,7 +68,7 @@ constexpr unsigned long long CC_XS_EMPTY = 0x7FF8C0DE5EED0001ull;
 // the evaluator's ~110 float64 instructions per term (the radii change once per iteration).  `cur` follows
 // the chain (the resolver writes accepted positions into it), `snap` keeps the positions of
 // the sweep's start for the nodes that are not resolved yet.
-__host__ __device__ constexpr int cp_record_width(int D) { return D + 1 <= 4 ? 4 : 8; }
+__host__ __device__ constexpr int cp_record_width(int D) { return D + 1 <= 4 ? 4 : (D + 1 <= 8 ? 8 : 12); }
 template <int D>
 __global__ __launch_bounds__(256) void k_ccpipe_pack(ChainView c, CcPipeBuf pb) {
     constexpr int RW = cp_record_width(D);
@@ -121,13 +121,15 @@ __device__ __forceinline__ double cc_term_delta_fast(const double *xn, const dou
 }
 
 // per-wavefront scratch of the evaluator: the window terms of a node, compacted in term order
-constexpr int CP_WCAP = 128;
+// (128 window terms before a flush; 64 at d >= 6, where sixteen wavefronts' proposals would not fit the LDS)
+template <int D> struct CcWcap { static constexpr int N = D <= 5 ? 128 : 64; };
 template <int D>
 struct CcWin {
-    int e[CP_WCAP];            // partner | kind << 28
-    double contrib[CP_WCAP];   // the term with the partner at its snapshot position
-    double re[CP_WCAP];        // 1 / the partner's radius
-    double xp[CP_WCAP][D];     // the partner's proposal (requested with its record: round 5)
+    static constexpr int WCAP = CcWcap<D>::N;
+    int e[WCAP];            // partner | kind << 28
+    double contrib[WCAP];   // the term with the partner at its snapshot position
+    double re[WCAP];        // 1 / the partner's radius
+    double xp[WCAP][D];     // the partner's proposal (requested with its record: round 5)
 };
 
 // One wavefront: node k of batch `be` in slice t, its terms four 64-term chunks at a time with
@@ -258,7 +260,7 @@ __device__ __forceinline__ void ccpipe_eval_item(const ChainView &c, const CcPip
             }
             const unsigned long long mw = __ballot(win[u]);   // its acceptance changes this term
             const int nw = __popcll(mw);
-            if (wcnt + nw > CP_WCAP) flush();
+            if (wcnt + nw > CcWin<D>::WCAP) flush();
             if (win[u]) {
                 const int pos = wcnt + __popcll(mw & below);
                 sw.e[pos] = e[u] | (kind[u] << 28);

@@ -14,8 +14,7 @@ from ._lib import (EngineError, LsmConfig, HdpConfig, c_double_p, c_i32_p, c_i64
 __all__ = ['Chain', 'SamplerGrid', 'EngineError', 'MAX_FEATURES', 'check_n_features']
 
 # The kernels take the latent dimension as a template parameter, instantiated for 1..8 (csrc/device_common.hpp
-# DLSM_D_MAX; the reference takes any n_features, lsm.py:235,254; its examples and the paper use 2).  The
-# sparse case-control sweep (algo 5) stops at 4 (capi.hip resolve_sweep_algo).
+# DLSM_D_MAX; the reference takes any n_features, lsm.py:235,254; its examples and the paper use 2).
 MAX_FEATURES = 8
 
 

@@ -5,8 +5,7 @@ Every row of the path at the wide dimensions, against the oracle - which tests/t
 and tests/test_init_oracle_golden.py pin to the reference itself at n_features 5, 6 and 8
 (tests/golden/wide_*.npz: `python tests/golden/make_golden.py wide`).  The cases are those of the
 1..4 tests, called with the wide dimensions.  Above four dimensions the slice-in-LDS sweep (algo 1)
-the speculative-batch sweeps (2, 3) and the pipelined sweep (4) run; the sparse case-control sweep (5) says so
-and refuses.
+the speculative-batch sweeps (2, 3) and the pipelined sweeps (4, 5) run.
 """
 import numpy as np
 import pytest
@@ -97,16 +96,21 @@ def test_sweep_at_the_headline_size(eng, name, D):
 
 
 def test_sweep_algorithms_of_the_wide_dimensions(eng):
-    """the pipelined sweep (algo 4) runs to n_features = 8; the sparse case-control sweep (algo 5) stops at 4
-    and says so"""
+    """the automatic choice is the one of n_features <= 4: the pipelined sweeps (algo 4, 5) run to 8"""
     with eng.Chain(2, 600, 5, 'undirected') as c:
         assert c.resolve_sweep_algo(0) == 4
     with eng.Chain(2, 100, 8, 'undirected') as c:
         assert c.resolve_sweep_algo(0) == 1
     with eng.Chain(2, 3000, 6, 'case_control') as c:
-        assert c.resolve_sweep_algo(0) == 4
-        with pytest.raises(eng.EngineError, match='n_features <= 4'):
-            c.resolve_sweep_algo(5)
+        assert c.resolve_sweep_algo(0) == 5 and c.resolve_sweep_algo(4) == 4
+
+
+@pytest.mark.parametrize('D', WIDE + [7])
+@pytest.mark.parametrize('T,N,C,density,prior', [(3, 2300, 12, 0.004, 'rw'), (2, 1025, 30, 0.01, 'mix')])
+def test_sweep_case_control_sparse_lists(eng, T, N, C, density, prior, D):
+    """algo 5 (k_ccpipe_step) at the wide dimensions: records of 8 / 12 doubles, 64 window terms per flush from
+    d = 6 on; several batches of 512 nodes, both priors"""
+    P._sweep_case(eng, 'case_control', prior, T=T, N=N, D=D, n_sweeps=2, algo=5, scale=0.05, cc_C=C, density=density)
 
 
 # ------------------------------------------------------------ a14: centring and Procrustes
@@ -153,7 +157,7 @@ def test_lsm_device_loop_equals_oracle_iterations(eng, monks, N, algo, D):
 
 @pytest.mark.parametrize('D', [5, 8])
 @pytest.mark.parametrize('name,N,algo', [('directed', 30, 1), ('directed', 300, 0), ('case_control', 300, 0),
-                                         ('case_control', 40, 1)])
+                                         ('case_control', 40, 1), ('case_control', 700, 5)])
 def test_lsm_directed_device_loop_equals_oracle_iterations(eng, name, N, algo, D):
     P.directed_loop_case(eng, name, N, algo, D)
 

@@ -95,6 +95,8 @@ KNOWN_SCRATCH = {
     'k_pipe_step<6,0,1>': 140, 'k_pipe_step<6,1,1>': 188, 'k_pipe_step<6,2,1>': 164, 'k_pipe_step<6,3,1>': 136,
     'k_pipe_step<7,0,1>': 180, 'k_pipe_step<7,1,1>': 216, 'k_pipe_step<7,2,1>': 208, 'k_pipe_step<7,3,1>': 188,
     'k_pipe_step<8,0,1>': 236, 'k_pipe_step<8,1,1>': 304, 'k_pipe_step<8,2,1>': 248, 'k_pipe_step<8,3,1>': 240,
+    # ... and the sparse case-control sweep there (two chunks of records and proposals of d doubles in flight)
+    'k_ccpipe_step<5>': 16, 'k_ccpipe_step<6>': 76, 'k_ccpipe_step<7>': 116, 'k_ccpipe_step<8>': 148,
 }
 # vector registers parked in accumulation registers (no memory traffic: scratch_bytes is 0)
 KNOWN_AGPR_PARKED = {'k_post_apply<8>', 'k_lsm_finalize_apply_propose<8>', 'k_post_apply_dir<8>', 'k_post_align<8>'}
