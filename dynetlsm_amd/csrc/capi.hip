@@ -57,6 +57,15 @@ static std::atomic<int> g_live_chains{0};       // handles alive in this process
     } while (0)
 
 // dispatch on the compile-time latent dimension
+// (DLSM_DEV_ONLY_D2: development builds that instantiate n_features = 2 only - an eighth of the compile time
+// for A/B libraries under tmp_timing/; never the shipped library)
+#ifdef DLSM_DEV_ONLY_D2
+#define DISPATCH_D(h, D_, ...)                                              \
+    switch (D_) {                                                           \
+        case 2: { constexpr int DD = 2; __VA_ARGS__; } break;               \
+        default: FAIL(h, DLSM_E_LIMIT, "n_features=%d: this development build holds n_features = 2 only", D_); \
+    }
+#else
 #define DISPATCH_D(h, D_, ...)                                              \
     switch (D_) {                                                           \
         case 1: { constexpr int DD = 1; __VA_ARGS__; } break;               \
@@ -69,6 +78,7 @@ static std::atomic<int> g_live_chains{0};       // handles alive in this process
         case 8: { constexpr int DD = 8; __VA_ARGS__; } break;               \
         default: FAIL(h, DLSM_E_LIMIT, "n_features=%d unsupported (1..8)", D_); \
     }
+#endif
 
 // A captured iteration freezes pointers and scalars of the chain: anything that changes
 // them drops the graph (it is rebuilt by the next dlsm_lsm_run).
@@ -1030,11 +1040,11 @@ static int resolve_sweep_algo(const dlsm_chain *h, int algo) {
 
 // algo 4: one fused launch per batch, resolve(b) beside eval(b + 1) (kernels_spec_pipe.hpp)
 template <int DD, int MODEL, int G = 1>
-static void launch_pipe_step(dlsm_chain *h, const ChainView &v, const PipeBuf &pb, int grid,
+static void launch_pipe_step(dlsm_chain *h, const ChainView &v, const PipeBuf &pb, dim3 grid,
                              size_t lds, int l) {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (h->profiling) { hipEventCreate(&e0); hipEventCreate(&e1); }
-    hipExtLaunchKernelGGL((k_pipe_step<DD, MODEL, G>), dim3(grid), dim3(PP_THREADS), lds, h->stream,
+    hipExtLaunchKernelGGL((k_pipe_step<DD, MODEL, G>), grid, dim3(PP_THREADS), lds, h->stream,
                           e0, e1, 0, v, pb, l);
     if (h->profiling) h->prof[DLSM_K_SWEEP_EVAL].pending.emplace_back(e0, e1);
 }
@@ -1046,6 +1056,10 @@ static int check_pipe_err(dlsm_chain *h) {
         const int32_t e = *(volatile int32_t *)h->fork_err_host;
         if (e != 0) {
             *(volatile int32_t *)h->fork_err_host = 0;
+            if (e & PP_ERR_XSERVE)
+                FAIL(h, DLSM_E_HIP, "pipelined sweep: a resolver ran out of its poll budget waiting for a cross product "
+                     "from the launch's evaluators (word %#x) - the chain's state is undefined; set the state again "
+                     "and run with DLSM_PIPE_XSERVE=0", e);
             if (e & CC_ERR_HELPER)
                 FAIL(h, DLSM_E_HIP, "case-control sweep: a resolver ran out of its poll budget waiting for its helper "
                      "workgroup (word %#x) - the chain's state is undefined; set the state again and run with "
@@ -1070,6 +1084,11 @@ static int launch_sweep_pipe(dlsm_chain *h, IterRef iter, bool alloc_only = fals
     int parts = (int)((double)ne_wg * PP_WAVES / ((double)T * PP_B) + 0.5);
     if (getenv("DLSM_PIPE_PARTS")) parts = atoi(getenv("DLSM_PIPE_PARTS"));
     parts = std::max(1, std::min(parts, PP_MAXPARTS));
+    // (undirected model: the evaluators of kernels_pipe_lds.hpp take ONE round of items - a part less when
+    // rounding up would leave items for a second round)
+    if (h->model == DLSM_UNDIRECTED && parts > 1 && (long)parts * T * PP_B > (long)ne_wg * PP_WAVES &&
+        !getenv("DLSM_PIPE_PARTS"))
+        --parts;
     if (cc) {           // CC_PARTS wavefronts per node, four nodes per workgroup round
         parts = CC_PARTS;
         ne_wg = std::min(ne_wg, (T * PP_B * CC_PARTS + PP_WAVES - 1) / PP_WAVES);
@@ -1081,17 +1100,19 @@ static int launch_sweep_pipe(dlsm_chain *h, IterRef iter, bool alloc_only = fals
     const size_t n_h = (size_t)2 * G * T * PP_B * PP_B;
     const size_t n_hx = (size_t)2 * G * T * xr * PP_B;
     const size_t n_acc = even2(((size_t)T * 2 * G * PP_ACC + 1) / 2);   // int32 pairs
-    const size_t need = (n_prop + n_full0 + n_h + n_hx + n_acc + 2) * sizeof(double);
+    const size_t n_xp = (size_t)T * PP_B;
+    const size_t need = (n_prop + n_full0 + n_h + n_hx + n_acc + 2 + n_xp) * sizeof(double);
     if (h->pipe_cap < need) {
         if (h->pipe) hipFree(h->pipe);
         h->pipe = nullptr; h->pipe_cap = 0;
         HIPCHK(h, hipMalloc((void **)&h->pipe, need));
         h->pipe_cap = need;
     }
-    PipeBuf pb;
+    PipeBuf pb{};
     pb.prop = h->pipe; pb.full0 = pb.prop + n_prop; pb.Hd = pb.full0 + n_full0;
     pb.Hx = pb.Hd + n_h; pb.acc = (int32_t *)(pb.Hx + n_hx);
     pb.consts = pb.Hx + n_hx + n_acc;
+    pb.xprod = pb.consts + 2;
     pb.sync = nullptr; pb.nsync = 0; pb.queue0 = ne_wg;
     pb.lsm_draw = h->loop_draws_intercept ? h->lsm : nullptr;
     pb.parts = parts; pb.nbat = nbat;
@@ -1100,6 +1121,30 @@ static int launch_sweep_pipe(dlsm_chain *h, IterRef iter, bool alloc_only = fals
     pb.nctrl = h->nctrl;
     // the resolvers' diagonal block by rows of PR_LD (an odd stride: row_resolve), the evaluators' exp table
     const size_t lds = (size_t)PP_B * PR_LD * sizeof(double);
+    // undirected model: rows staged in LDS, interleaved parts, H factors inside the trips (kernels_pipe_lds.hpp)
+    // whenever the longest part's rows fit beside the exp table
+    // and the launch's wavefronts cover its items in one round
+    pb.lds_eval = h->model == DLSM_UNDIRECTED && pipe_lds_eval_bytes(N, DD, parts) <= lds &&
+                  (long)parts * T * PP_B <= (long)ne_wg * PP_WAVES &&
+                  !(getenv("DLSM_PIPE_LDS") && atoi(getenv("DLSM_PIPE_LDS")) == 0);
+    pb.lds_cap = pipe_lds_trip_cap((N + 63) / 64, parts);
+    // the resolvers' cross products by the evaluators (pipe_xserve_*): one wavefront in xstride takes a row.  A
+    // resolver waits INSIDE the launch for wavefronts that wait for nothing - they only have to start; with so
+    // many chains on the device that their resolver workgroups alone could fill it, the resolvers keep the work
+    {
+        const char *ex = getenv("DLSM_PIPE_XSERVE"), *ebud = getenv("DLSM_PIPE_XBUDGET");
+        pb.err = h->fork_err_dev;
+        pb.budget = ebud ? atoi(ebud) : (1 << 22);
+        pb.xstride = 1;                     // (per launch, below)
+        pb.inv_xstride = 0.0f;
+        pb.xserve = pb.lds_eval && pb.err != nullptr && (ex ? atoi(ex) != 0 : true) &&
+                    T < 128 && (long)g_live_chains.load() * T * 2 <= (long)h->n_cu;
+    }
+    const int xserve_sweep = pb.xserve;         // (a launch whose workgroups cannot cover the rows keeps the resolvers' own products)
+    pb.xserve = 0;
+    for (int nw = 1; nw <= 4; ++nw)
+        for (int p = 0; p < PP_MAXPARTS; ++p)
+            pb.plan[nw - 1][p] = p < parts ? pipe_plan_entry((N + 63) / 64, parts, nw, p) : 0u;
     auto ku = k_pipe_step<DD, DLSM_UNDIRECTED>;
     auto kl = k_pipe_step<DD, PIPE_UNDIRECTED_LONG>;
     auto kd = k_pipe_step<DD, DLSM_DIRECTED>;
@@ -1137,7 +1182,7 @@ static int launch_sweep_pipe(dlsm_chain *h, IterRef iter, bool alloc_only = fals
         if (h->sweep_part == 1 && l >= 0) break;
         const bool any_eval = (G * (l + 1) < nbat) || (T > 1 && l >= 0 && G * l < nbat);
         const int grid = T + (any_eval ? ne_wg : 0);
-        const bool lng = pb.per > 64 * pipe_prefetch_trips(DD);
+        const bool lng = !pb.lds_eval && pb.per > 64 * pipe_prefetch_trips(DD);
         if (l == last && !any_eval && h->post_ride_want && G == 1 && h->model == DLSM_UNDIRECTED &&
             !h->profiling && l >= 0 && T + 4 <= PS_BLOCKS) {
             // the centring sums ride in the resolve-only launch (kernels_spec_pipe.hpp): nwg rider
@@ -1152,13 +1197,27 @@ static int launch_sweep_pipe(dlsm_chain *h, IterRef iter, bool alloc_only = fals
             continue;
         }
         if (h->model == DLSM_UNDIRECTED && lng)
-            launch_pipe_step<DD, PIPE_UNDIRECTED_LONG>(h, v, pb, grid, lds, l);
-        else if (h->model == DLSM_UNDIRECTED)
-            launch_pipe_step<DD, DLSM_UNDIRECTED>(h, v, pb, grid, lds, l);
+            launch_pipe_step<DD, PIPE_UNDIRECTED_LONG>(h, v, pb, dim3(grid), lds, l);
+        else if (h->model == DLSM_UNDIRECTED && pb.lds_eval && any_eval) {
+            // kernels_pipe_lds.hpp: plane 0 = the resolvers (padded to the planes' size), plane p + 1 = part p's
+            // evaluators, 16 consecutive nodes (x) of one active slice (y) per workgroup
+            const int beE = l + 1, beO = l, nE = (T + 1) / 2, nO = T / 2;
+            pb.beE = beE; pb.beO = beO;
+            pb.nbE = (beE >= 0 && beE < nbat) ? std::min(PP_B, N - beE * PP_B) : 0;
+            pb.nbO = (beO >= 0 && beO < nbat) ? std::min(PP_B, N - beO * PP_B) : 0;
+            pb.nslE = pb.nbE > 0 ? nE : 0; pb.nslO = pb.nbO > 0 ? nO : 0;
+            const int gx = PP_B / PP_WAVES;
+            const int ny = std::max(pb.nslE + pb.nslO, (T + gx - 1) / gx);
+            // serving wavefronts per evaluator workgroup (pipe_xserve_request)
+            pb.xstride = (T * PP_B + parts * ny * gx - 1) / (parts * ny * gx);
+            pb.xserve = xserve_sweep && pb.xstride <= PP_WAVES;
+            launch_pipe_step<DD, DLSM_UNDIRECTED>(h, v, pb, dim3(gx, ny, parts + 1), lds, l);
+        } else if (h->model == DLSM_UNDIRECTED)
+            launch_pipe_step<DD, DLSM_UNDIRECTED>(h, v, pb, dim3(grid), lds, l);
         else if (h->model == DLSM_DIRECTED)
-            launch_pipe_step<DD, DLSM_DIRECTED>(h, v, pb, grid, lds, l);
+            launch_pipe_step<DD, DLSM_DIRECTED>(h, v, pb, dim3(grid), lds, l);
         else
-            launch_pipe_step<DD, DLSM_DIRECTED_CASE_CONTROL>(h, v, pb, grid, lds, l);
+            launch_pipe_step<DD, DLSM_DIRECTED_CASE_CONTROL>(h, v, pb, dim3(grid), lds, l);
     }
     HIPCHK(h, hipGetLastError());
     return DLSM_OK;

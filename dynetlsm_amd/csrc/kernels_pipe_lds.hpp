@@ -1,0 +1,429 @@
+// The undirected evaluators of the pipelined sweep (k_pipe_step, algo 4), round 6: neighbour rows staged in
+// LDS once per workgroup, parts that INTERLEAVE the trips of 64 neighbours, and the H factors computed inside
+// the trips that hold their operands.  (Included by kernels_spec_pipe.hpp in front of k_pipe_step.)
+//
+// What it replaces (pipe_eval_item, still the directed model's evaluator): every wavefront prefetched the
+// rows of its part into registers - the 16 wavefronts of a workgroup the SAME rows, eleven 1 KB requests
+// each through the CU's vector L1 - and computed, at its tail, one H entry per lane from a flat list: index
+// decode, a gather of two proposal rows and a bit word, FOUR distances and exponentials, a scattered 8-byte
+// store; the last wavefront's entry was the launch's tail (profiles/r04_h_entry_ablation.md: a launch without
+// H entries ran 2.4 us shorter).
+//
+//   * H[k][m] (how node m's acceptance changes node k's ratio, m in k's window: the previous batch and the
+//     earlier nodes of its own) needs d(m0, k0), d(m0, k1), d(m1, k0), d(m1, k1).  The first two - and their
+//     exponentials, and the factors 1 + E e^{-d} - are what the item of node k computes anyway in the trip
+//     that holds neighbour m at its snapshot position.  That trip now also reads m's PROPOSAL (staged
+//     beside the rows) and finishes the factor: two distances and exponentials instead of four, no decode,
+//     no gather, and a wavefront's 64 factors are 512 contiguous bytes of row k.
+//   * The window is 2 .. 4 consecutive trips (128 + k nodes), so with contiguous parts one item of a node
+//     would carry all of them.  A part is therefore a LIST of trips (pipe_plan): the window's trips dealt
+//     round robin over the parts, then runs of the other trips sized so that the parts cost the same with a
+//     window trip counted as two (it is 2.3: 61 + 49 vector instructions against 49).
+//   * The 16 wavefronts of a workgroup are 16 nodes of one (slice, part): one copy of the part's rows in
+//     LDS (11 KB at config 2) serves them all, the registers the prefetch held are free, and the rows are
+//     requested once, by the whole workgroup, in front of the exp table's barrier.
+//   * A node's row of the network: the 64 bits under a trip are one aligned 8-byte word at a wave-uniform
+//     address - a scalar load straight into the lane mask of "y = 1" (was: a word per lane and two
+//     v_readlane per trip).
+// Values: the same arithmetic on the same operands as pipe_h_entry / the old trips - H blocks bit for bit,
+// records equal up to the order in which a node's neighbours are summed (parts interleaved, not contiguous).
+#pragma once
+
+namespace dlsm {
+
+#define DLSM_CONSTANT_AS __attribute__((address_space(4)))
+
+// wave-uniform 8-byte word through the scalar cache (read-only data: the packed network)
+__device__ __forceinline__ unsigned long long scalar_load_u64(const unsigned long long *p) {
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+    return *(const DLSM_CONSTANT_AS unsigned long long *)p;
+#pragma clang diagnostic pop
+}
+
+constexpr int PL_WIN = 4;           // window trips a part can hold (P = 1: all four)
+
+// trips (and LDS rows) the longest part can hold
+__host__ __device__ inline int pipe_lds_trip_cap(int ntrip, int parts) { return (ntrip + parts - 1) / parts + PL_WIN; }
+// bytes of dynamic LDS the evaluators need: exp table, the longest part's rows, its window trips' proposals
+__host__ __device__ inline size_t pipe_lds_eval_bytes(int N, int D, int parts) {
+    const int ntrip = (N + 63) / 64;
+    return ((size_t)EXPTAB11_N + (size_t)(pipe_lds_trip_cap(ntrip, parts) + PL_WIN) * 64 * D) * sizeof(double);
+}
+
+// The trips of a node of batch `be` (its workgroup's first node k0) as P parts.  Window trips: [glo, glo + nwin)
+// = the previous batch's two (be > 0), trip 2 be of the own batch, and trip 2 be + 1 when the workgroup's nodes
+// reach into it (k0 >= 64); window trip i goes to part i mod P and is the part's trip i / P.  The other ntrip -
+// nwin trips, in ascending order, are cut into runs r_0 .. r_{P-1} with r_j + 2 w_j as equal as integers allow.
+// (w, r, s) depend on (nwin, p) only: the host computes the 4 P triples once (pipe_plan_entry) and the launch
+// carries them as kernel arguments (PipeBuf::plan) - the evaluators' row requests wait for nothing but a decode.
+struct PipePlan {
+    int glo, nwin;      // the window's trips
+    int w, r, s;        // this part: window trips, other trips, rank of its first other trip
+    __device__ __forceinline__ int trips() const { return w + r; }
+    __device__ __forceinline__ int trip(int u, int p, int P) const {      // the part's u-th trip
+        if (u < w) return glo + p + P * u;
+        const int rho = s + (u - w);
+        return rho < glo ? rho : rho + nwin;
+    }
+};
+// w | r << 3 | s << 16 of part p when the window holds nwin trips (1 .. 4) of ntrip
+inline uint32_t pipe_plan_entry(int ntrip, int P, int nwin, int p) {
+    auto wof = [&](int j) { return j < nwin ? (nwin - j + P - 1) / P : 0; };
+    const int R = ntrip - nwin, S = R + 2 * nwin;
+    const int q = S / P, rem = S % P;
+    const bool balanced = R >= 0 && q >= 2 * wof(0);             // (tiny N: plain runs of the other trips)
+    const int Rp = R > 0 ? R : 0;
+    int s = 0, w = 0, r = 0;
+    for (int j = 0; j <= p; ++j) {
+        const int wj = wof(j);
+        const int rj = balanced ? q + (j < rem ? 1 : 0) - 2 * wj : Rp / P + (j < Rp % P ? 1 : 0);
+        if (j < p) s += rj; else { w = wj; r = rj; }
+    }
+    return (uint32_t)w | ((uint32_t)r << 3) | ((uint32_t)s << 16);
+}
+__device__ __forceinline__ PipePlan pipe_plan(const PipeBuf &pb, int ntrip, int p, int be, int k0) {
+    PipePlan pl;
+    pl.glo = be > 0 ? 2 * be - 2 : 0;
+    const int ghi = min(2 * be + (k0 >= 64 ? 1 : 0), ntrip - 1);
+    pl.nwin = ghi - pl.glo + 1;                                  // 1 .. 4 (trip 2 be exists: the batch has nodes)
+    const uint32_t e = pb.plan[pl.nwin - 1][p];
+    pl.w = (int)(e & 7u); pl.r = (int)((e >> 3) & 0x1fffu); pl.s = (int)(e >> 16);
+    return pl;
+}
+
+// the rest of H[k][m] from what the trip holds: a0 = d(m0, k0), a1 = d(m0, k1), their exponentials ea0, ea1
+// and factors fa = 1 + E ea (pipe_h_entry's arithmetic on the same operands)
+template <int D, bool SQ>
+__device__ __forceinline__ double pipe_h_finish(const double (&xm1)[D], const double (&xk0)[D],
+                                                const double (&xk1)[D], double a0, double a1, double ea0,
+                                                double ea1, double fa0, double fa1, bool y1, double E,
+                                                const double *etab) {
+    const double b0 = dist_fast<D>(xm1, xk0, SQ ? 1 : 0);
+    const double b1 = dist_fast<D>(xm1, xk1, SQ ? 1 : 0);
+    const double eb0 = SQ ? tab_exp11_clamped(-b0, etab) : tab_exp11(-b0, etab);
+    const double eb1 = SQ ? tab_exp11_clamped(-b1, etab) : tab_exp11(-b1, etab);
+    double num = fma(E, eb0, 1.0) * fa1;
+    double den = fma(E, eb1, 1.0) * fa0;
+    // the edge's factor e^{(b0 - b1) - (a0 - a1)} from the four exponentials at hand; a fifth one only
+    // when their product left the normal range (distances > 300)
+    const double fn = eb1 * ea0, fd = eb0 * ea1;
+    const bool tiny = y1 && !(fd > 1e-290 && fn > 1e-290);
+    if (y1 && !tiny) { num *= fn; den *= fd; }
+    double h = num * fast_rcp(den);
+    // (the table exponential here too: fast_exp's dozen constants would sit in registers through every trip)
+    if (__builtin_amdgcn_ballot_w64(tiny)) { if (tiny) h *= tab_exp11_clamped((b0 - b1) - (a0 - a1), etab); }
+    return h;
+}
+
+// Rows beyond the slice's last node (the last trip's idle lanes) are staged as a point this far away on the first
+// axis: e^{-d} underflows to 0, the factor 1 + E e^{-d} is exactly 1 and the row's (zero) padding bits keep the
+// linear term out - so the trips need no "i < N" lane mask.  (Inside the table exponential's range, |x| < 7.2e5.)
+constexpr double PL_FAR = 3.0e5;
+
+// the trips of one item: part p of node k (batch be, slice t); rows in sX, window proposals in sM.
+// The SIMD issues one scalar instruction per cycle slot just as it issues one vector instruction, and the four
+// items of a SIMD share both ports: what a trip spends on masks, trip numbers and addresses competes with the
+// other items' arithmetic (the first form of this loop: 60 scalar instructions beside 47 vector ones, and no
+// faster than the item it replaced).  So the part's window trips - the only ones that hold the node itself, an H
+// entry or a partial lane mask - run first, in a loop of their own, and the other trips run bare: full exec
+// mask, consecutive bit words, a countdown for the issue priority.
+template <int D, bool FLUSH, bool SQ>
+__device__ __forceinline__ void pipe_lds_trips(const ChainView &c, int P, const PipePlan &pl, int p, int be,
+                                               int k, int jk, int lane, const double (&xk0)[D],
+                                               const double (&xk1)[D], double E, int nflush,
+                                               const unsigned long long *yrow, unsigned long long ym,
+                                               const double *etab, const double *sX, const double *sM, double *hrow,
+                                               RatioAcc &ra
+#ifdef DLSM_PIPE_TIMING
+                                               , unsigned long long *ts
+#endif
+                                               ) {
+    const int ntp = pl.trips();
+    const int nw64 = c.W >> 1;                              // 8-byte words of a row
+    const double *row = sX + lane * D;                      // this lane's neighbour of trip 0, 1, ..: stride 64 D
+    double xi[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) xi[d] = row[d];
+    // first trip behind the window's: rank pl.s of the other trips
+    int g = pl.w > 0 ? pl.glo + p : (pl.s < pl.glo ? pl.s : pl.s + pl.nwin);   // (ym: its bits, requested by the caller)
+    const int greg = pl.s < pl.glo ? pl.s : pl.s + pl.nwin;
+#define DLSM_LDS_TERM()                                                                                   \
+        const bool yb = __builtin_amdgcn_inverse_ballot_w64(ym);                                          \
+        const double d0 = dist_fast<D>(xi, xk0, SQ ? 1 : 0);                                              \
+        const double d1 = dist_fast<D>(xi, xk1, SQ ? 1 : 0);                                              \
+        const double e0 = SQ ? tab_exp11_clamped(-d0, etab) : tab_exp11(-d0, etab);                       \
+        const double e1 = SQ ? tab_exp11_clamped(-d1, etab) : tab_exp11(-d1, etab);                       \
+        const double f0 = fma(E, e0, 1.0), f1 = fma(E, e1, 1.0);                                          \
+        ra.lin = fma(yb ? 1.0 : 0.0, d0 - d1, ra.lin);                                                    \
+        ra.P0 *= f0;                                                                                      \
+        ra.P1 *= f1;                                                                                      \
+        if (FLUSH) if (++ra.cnt >= nflush) ra.flush();
+    // ---- the window's trips (previous batch: g = 2 be - 2, 2 be - 1; own batch: 2 be, 2 be + 1) ----------------
+    for (int u = 0; u < pl.w; ++u) {
+        const int gn = u + 1 < pl.w ? g + P : greg;
+        double xn[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) xn[d] = row[(size_t)(u + 1) * 64 * D + d];
+        const unsigned long long ymn = scalar_load_u64(yrow + min(gn, nw64 - 1));
+        const int self = jk - 64 * g;                       // the node itself sits in one of its own batch's trips
+        const unsigned long long vm = self >= 0 && self < 64 ? ~(1ull << self) : ~0ull;
+        const int wq = g - 2 * be;
+        const int nh = wq < 0 ? 64 : k - 64 * wq;           // lanes with m < k
+        if (__builtin_amdgcn_inverse_ballot_w64(vm)) {
+            DLSM_LDS_TERM()
+            if (nh > 0) {
+                const unsigned long long hm = nh >= 64 ? ~0ull : (1ull << nh) - 1ull;
+                if (__builtin_amdgcn_inverse_ballot_w64(hm)) {
+                    double xm1[D];
+                    const double *rowm = sM + ((size_t)u * 64 + lane) * D;
+#pragma unroll
+                    for (int d = 0; d < D; ++d) xm1[d] = rowm[d];
+#ifdef DLSM_X_LDS_H1
+                    const double h = fma(0.0, xm1[0], 1.0);
+#else
+                    const double h = pipe_h_finish<D, SQ>(xm1, xk0, xk1, d0, d1, e0, e1, f0, f1, yb, E, etab);
+#endif
+                    hrow[(wq + 2) * 64 + lane] = h;         // [previous batch (128) | own batch (128)]
+                }
+            }
+        }
+        if (u == 0) { DLSM_STAMP(1, ra.P0) }
+#pragma unroll
+        for (int d = 0; d < D; ++d) xi[d] = xn[d];
+        ym = ymn; g = gn;
+    }
+    // ---- the other trips: ascending, consecutive but for the jump over the window ---------------------------
+    row += (size_t)pl.w * 64 * D;
+    const int quarter = max((ntp + 3) >> 2, 1);
+    int left = max(quarter - pl.w, 1), level = 3;           // issue priority 3 -> 0 by quarters of the item
+    const int glast = nw64 - 1;
+    for (int i = 0; i < pl.r; ++i) {
+        int gn = g + 1;
+        if (gn == pl.glo) gn += pl.nwin;
+        double xn[D];
+        row += 64 * D;                                      // (the slot behind the last trip is LDS of this launch too)
+#pragma unroll
+        for (int d = 0; d < D; ++d) xn[d] = row[d];
+        const unsigned long long ymn = scalar_load_u64(yrow + min(gn, glast));
+        {
+            DLSM_LDS_TERM()
+        }
+        if (pl.w == 0 && i == 0) { DLSM_STAMP(1, ra.P0) }
+#if DLSM_TRIP_PRIO
+        if (--left == 0) {
+            left = quarter;
+            if (level == 3) __builtin_amdgcn_s_setprio(2);
+            else if (level == 2) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+            --level;
+        }
+#endif
+#pragma unroll
+        for (int d = 0; d < D; ++d) xi[d] = xn[d];
+        ym = ymn; g = gn;
+    }
+#undef DLSM_LDS_TERM
+    DLSM_STAMP(2, ra.P0)
+}
+
+// ---- the resolvers' cross products, by the evaluators ------------------------------------------------------
+// Row k of the slice-t batch that THIS launch resolves needs prod_{m accepted in the batch before} Hx[k][m]: 128
+// factors the previous launch stored and two mask words it left.  The resolver workgroup read all 128 rows (128
+// KB through one CU: 1.8 of the 4.1 us before its fixed point could start) while every evaluator wavefront sat
+// out a memory round trip behind its staging requests.  Now one wavefront in `xstride` takes a row: its 128
+// factors are one 16-byte request per lane in front of the staging requests, the product is reduced across
+// the wavefront while those are in flight, and lane 0 stores it past the L1 into the row's slot (PipeBuf::xprod).
+// A wavefront waits for nothing here: the resolver can only be kept waiting by evaluators that have not started.
+struct PipeXServe { double2 v; unsigned long long m; double *slot; bool on; };
+__device__ __forceinline__ double wave_prod_tp(double v, int lane) {     // product over the wavefront, every lane
+    v *= dpp_move<0xB1>(v);
+    v *= dpp_move<0x4E>(v);
+    v *= dpp_move<0x141>(v);
+    v *= dpp_move<0x140>(v);
+    v *= lane_get(v, (lane ^ 16) << 2);
+    v *= lane_get(v, (lane ^ 32) << 2);
+    return v;
+}
+// workgroup `wg` of the evaluators, wavefront `wave`: the first pb.xstride wavefronts of a workgroup serve rows
+// wg * xstride + wave (xstride = ceil(rows / evaluator workgroups): no quotient to compute)
+__device__ __forceinline__ void pipe_xserve_request(const ChainView &c, const PipeBuf &pb, int l, int wg, int wave,
+                                                    int lane, PipeXServe &xs) {
+    xs.on = false;
+    if (!pb.xserve || wave >= pb.xstride) return;
+    const int row = wg * pb.xstride + wave;
+    if (row >= c.T * PP_B) return;
+    const int t = row >> 7, k = row & (PP_B - 1);
+    const int b = l - (t & 1);                                            // the batch slice t resolves in this launch
+    if (b < 1 || b >= pb.nbat || k >= min(PP_B, c.N - b * PP_B)) return;
+    // (32-bit offsets from the launch's base pointers: T < 2^7 slices of 2 x 128 x 256 factors)
+    const uint32_t moff = (uint32_t)(t * 2 + ((b - 1) & 1)) * PP_ACC + PP_ACC_MASK;
+    // (the lane's half of the mask as a VECTOR load: a scalar load from memory this cold would hold up every
+    // scalar wait behind it - the kernel arguments the staging addresses are made of)
+    const unsigned long long *pmg = (const unsigned long long *)(pb.acc + moff);
+    xs.m = __builtin_nontemporal_load(pmg + (lane >> 5));
+    const uint32_t hoff = (uint32_t)((((b & 1) * c.T + t) * PP_B + k) * (2 * PP_B) + 2 * lane);
+    xs.v = *(const double2 *)(pb.Hd + hoff);                              // factors of window nodes 2 lane, 2 lane + 1
+    xs.slot = pb.xprod + (uint32_t)row;
+    xs.on = true;
+}
+__device__ __forceinline__ void pipe_xserve_finish(const PipeXServe &xs, int lane) {
+    if (!xs.on) return;
+    const unsigned long long w = xs.m >> (2 * (lane & 31));
+    const double f = ((w & 1ull) ? xs.v.x : 1.0) * ((w & 2ull) ? xs.v.y : 1.0);
+    const double prod = wave_prod_tp(f, lane);
+    if (lane == 0) __hip_atomic_store(xs.slot, prod, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+#ifdef DLSM_PIPE_TIMING
+#define DLSM_LDS_TS , ts
+#else
+#define DLSM_LDS_TS
+#endif
+template <int D>
+__device__ __forceinline__ void pipe_eval_lds(const ChainView &c, const PipeBuf &pb, int l, double *lds
+#ifdef DLSM_PIPE_TIMING
+                                              , unsigned long long t_kernel
+#endif
+                                              ) {
+    constexpr int PW = 2 * D + 2;
+    const int T = c.T, N = c.N;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int P = pb.parts;
+    const int ntrip = (N + 63) >> 6;
+    double *sTab = lds;
+    double *sX = lds + EXPTAB11_N;                                      // [trip cap][64][D]
+    double *sM = sX + (size_t)pb.lds_cap * 64 * D;                      // [PL_WIN][64][D]
+    // the workgroup's role from its coordinates: 16 consecutive nodes (x) of one active slice (y) and part (z - 1);
+    // batches, sizes and slice counts of the launch from the host (PipeBuf) - the four wavefronts of a SIMD issue
+    // this prologue one after the other, so what it does not compute is time the barrier below comes earlier
+    constexpr bool first = true;
+    const int wgx = (int)blockIdx.x, si = (int)blockIdx.y, p = (int)blockIdx.z - 1;
+    const int wg = (p * (int)gridDim.y + si) * (int)gridDim.x + wgx;     // (the row server's index)
+    PipeXServe xs;
+    {
+        const int k0 = wgx * PP_WAVES;
+        const int nslE = pb.nslE;
+        const bool odd = si >= nslE;
+        const int be = odd ? pb.beO : pb.beE;
+        const int nb = si < nslE + pb.nslO ? (odd ? pb.nbO : pb.nbE) : 0;
+        if (k0 >= nb) {         // (workgroup-uniform) no items here: the serving wavefronts have nothing else to do
+            pipe_xserve_request(c, pb, l, wg, wave, lane, xs);
+            pipe_xserve_finish(xs, lane);
+            return;
+        }
+        const int t = odd ? 2 * (si - nslE) + 1 : 2 * si;
+        const int k = k0 + wave;
+        const bool live = k < nb;
+#ifdef DLSM_PIPE_TIMING
+        // stamps (profiles/pipe_timing.py): 0 entry, 4 rows + table staged (behind the barrier), 1 first trip done,
+        // 2 last trip done, 3 = 5 record stored
+        unsigned long long ts[6] = {0, 0, 0, 0, 0, 0};
+#endif
+        DLSM_STAMP(0, (double)lane)
+        const int j0 = be * PP_B, jk = j0 + min(k, nb - 1);
+        const int jprev = max(j0 - PP_B, 0);                             // nodes >= jprev: snapshot positions
+        const double *Xt = c.X + (size_t)t * N * D;
+        const double *props = pb.prop + (size_t)t * N * PW;
+#if DLSM_TRIP_PRIO
+        __builtin_amdgcn_s_setprio(3);
+#endif
+        // ---- every request of the round, then the LDS stores, then ONE barrier ----------------------------
+        double2 tabv = make_double2(0.0, 0.0);
+        if (first) tabv = ((const double2 *)c_exp2_tab11)[tid];          // 1024 threads x 2 entries
+        static_assert(PP_THREADS * 2 == EXPTAB11_N, "two table entries per thread");
+        // staging list: the part's trips u = 0 .. ntp - 1 (rows), then the proposals of its window trips (its
+        // first pl.w trips)
+        const PipePlan pl = pipe_plan(pb, ntrip, p, be, k0);
+        const int ntp = pl.trips();
+        const int nst = ntp + pl.w;
+        // (one entry per wavefront when the list has <= 16: config 2 holds 10 + 2 or 11 + 1)
+        double stg[D];
+        int s = wave;
+        auto stage_request = [&](int s_) {
+            const bool win = s_ >= ntp;
+            const int g = pl.trip(win ? s_ - ntp : s_, p, P);
+            const int n = min(64 * g + lane, N - 1);
+            // a trip's 64 neighbours are all on one side of jprev (both multiples of 64)
+            const bool snap = win || 64 * g >= jprev;
+            const char *src = snap ? (const char *)(props + (win ? 0 : D + 2)) : (const char *)Xt;
+            const uint32_t off = __umul24((uint32_t)n, (uint32_t)((snap ? PW : D) * sizeof(double)));
+            coh_load_row<D, false>(src, off, stg);
+        };
+        auto stage_store = [&](int s_) {
+            const int g = pl.trip(s_ >= ntp ? s_ - ntp : s_, p, P);
+            if (64 * g + 63 >= N) {             // the slice's last trip: its idle lanes hold the far point
+                const bool idle = 64 * g + lane >= N;
+#pragma unroll
+                for (int d = 0; d < D; ++d) stg[d] = idle ? (d == 0 ? PL_FAR : 0.0) : stg[d];
+            }
+            double *dst = (s_ >= ntp ? sM + (size_t)(s_ - ntp) * 64 * D : sX + (size_t)s_ * 64 * D) + lane * D;
+#pragma unroll
+            for (int d = 0; d < D; ++d) dst[d] = stg[d];
+        };
+        if (s < nst) stage_request(s);
+        // the wavefront's own node and the launch constants
+        double xk0[D], xk1[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            xk0[d] = props[(size_t)jk * PW + D + 2 + d];
+            xk1[d] = props[(size_t)jk * PW + d];
+        }
+        const double E = pb.consts[0];
+        const int nflush = (int)pb.consts[1];
+        // the node's row of the network: the bits under its first trip
+        const unsigned long long *yrow = (const unsigned long long *)(c.ybits + ((size_t)t * N + jk) * c.W);
+        const unsigned long long ym0 = scalar_load_u64(yrow + pl.trip(0, p, P));
+        double *hrow = pb.Hd + (((size_t)(be & 1) * T + t) * PP_B + min(k, nb - 1)) * (2 * PP_B);
+#if defined(DLSM_PIPE_TIMING) && DLSM_PIPE_TIMING == 2      // (prologue probe: slot 1 = requests issued, slot 2 = at the barrier)
+        DLSM_STAMP(1, (double)lane)
+#endif
+        if (first) ((double2 *)sTab)[tid] = tabv;
+        if (s < nst) stage_store(s);
+        for (s += PP_WAVES; s < nst; s += PP_WAVES) { stage_request(s); stage_store(s); }
+#if defined(DLSM_PIPE_TIMING) && DLSM_PIPE_TIMING == 2
+        DLSM_STAMP(2, xk0[0])
+        unsigned long long ts1 = ts[1], ts2 = ts[2];
+#endif
+        __syncthreads();
+        // The whole of it behind the barrier: in front of it the four wavefronts of a SIMD issue their prologues
+        // one after the other and every instruction of a serving wavefront keeps the workgroup's other fifteen
+        // waiting (+0.35 us on the barrier, measured); behind it a wavefront that sits out its request's round
+        // trip costs nothing - the SIMD's other three have trips to issue.
+        pipe_xserve_request(c, pb, l, wg, wave, lane, xs);
+        pipe_xserve_finish(xs, lane);
+        DLSM_STAMP(4, xk0[0])
+        if (live) {
+            RatioAcc ra;
+            const bool noflush = nflush >= 64 * ntp && !c.squared;
+            if (noflush) pipe_lds_trips<D, false, false>(c, P, pl, p, be, k, jk, lane, xk0, xk1, E, nflush, yrow, ym0, sTab, sX, sM, hrow, ra DLSM_LDS_TS);
+            else if (c.squared) pipe_lds_trips<D, true, true>(c, P, pl, p, be, k, jk, lane, xk0, xk1, E, nflush, yrow, ym0, sTab, sX, sM, hrow, ra DLSM_LDS_TS);
+            else pipe_lds_trips<D, true, false>(c, P, pl, p, be, k, jk, lane, xk0, xk1, E, nflush, yrow, ym0, sTab, sX, sM, hrow, ra DLSM_LDS_TS);
+            double tot_l, tot_r;
+            if (noflush) {
+                // the products of the whole wave stay in range: multiply across lanes
+                pipe_reduce(ra.lin + ra.lg, ra.P0, ra.P1, lane, tot_l, tot_r);
+            } else {
+                tot_l = wave_sum_all(ra.value()); tot_r = 1.0;
+            }
+            if (lane == 0) {
+                double2 *f = (double2 *)pb.full0 + (((size_t)(be & 1) * T + t) * PP_B + k) * P + p;
+                *f = make_double2(tot_l, tot_r);
+            }
+#ifdef DLSM_PIPE_TIMING
+            DLSM_STAMP(3, tot_r)
+            ts[5] = ts[3];
+#if DLSM_PIPE_TIMING == 2
+            ts[1] = ts1; ts[2] = ts2;
+#endif
+            ts[0] = t_kernel;           // (the round's entry stamp gives way to the wavefront's first stamp in the kernel)
+            const int tgw = wg * PP_WAVES + wave;
+            if (lane == 0 && l + 1 >= 0 && l + 1 < 24 && tgw < 4096)
+                for (int i = 0; i < 6; ++i) g_pipe_item_t[l + 1][tgw][i] = ts[i];
+#endif
+        }
+    }
+}
+
+}  // namespace dlsm

@@ -112,7 +112,20 @@ struct PipeBuf {
     // by the propose kernel; word 0 (the ticket counter) starts at queue0
     int32_t *sync; int nsync, queue0;
     LsmDeviceState *lsm_draw;   // not NULL: the proposal pass also draws the intercept proposal
+    uint32_t plan[4][PP_MAXPARTS];      // kernels_pipe_lds.hpp: the parts' trip lists (pipe_plan_entry)
+    // the cross products by the evaluators (kernels_pipe_lds.hpp, pipe_xserve): slot [t][k] holds PP_XP_EMPTY
+    // until the wavefront that serves row k of slice t has stored prod_{m accepted} Hx[k][m]; the row's owner in
+    // the resolver workgroup polls it past its L1 and empties it again
+    double *xprod; int32_t *err; int xserve, xstride, budget; float inv_xstride;
+    int lds_cap;     // rows of LDS the longest part may hold (pipe_lds_trip_cap)
+    // per launch, from the host (the grid of such a launch is (PP_B / 16, slices, parts + 1): plane 0 holds the
+    // resolvers, plane p + 1 the evaluators of part p - a workgroup reads its role off its coordinates)
+    int beE, beO, nbE, nbO, nslE, nslO;     // batch evaluated / its nodes / active slices, even and odd slices
+    int lds_eval;    // undirected model: the evaluators of kernels_pipe_lds.hpp (rows staged in LDS, interleaved
+                     // parts, H factors inside the trips); 0: pipe_eval_item
 };
+constexpr unsigned long long PP_XP_EMPTY = 0x7FF8C0DE5EED0002ull;     // a NaN payload no arithmetic produces
+constexpr int PP_ERR_XSERVE = 1 << 29;          // sticky error word: a resolver ran out of its poll budget
 // first batch of the window of batch b
 __host__ __device__ __forceinline__ int pipe_window_start(int b, int G) {
     const int ws = G * (b / G - 1);
@@ -1180,7 +1193,7 @@ __device__ __forceinline__ void row_resolve(const ChainView &c, const PipeBuf &p
                                                 double *sD, double *sPart,
                                                 unsigned long long (*sMask)[2],
                                                 unsigned long long *sMaskPrev, double *sCross,
-                                                unsigned long long *sSatMask, const double *sTab
+                                                unsigned long long *sSatMask, double *sTab, bool served
 #ifdef DLSM_PIPE_TIMING
                                                 , int tl
 #endif
@@ -1206,10 +1219,16 @@ __device__ __forceinline__ void row_resolve(const ChainView &c, const PipeBuf &p
     const int kx = tid >> 3, jx = tid & 7;
     double cr[16];
     const uint32_t cr_off = (uint32_t)((kx * (2 * PP_B) + 2 * jx) * sizeof(double));
-    if (b > 0) {
+    // (served: the launch's evaluators multiply the accepted factors of every row and hand over one number per
+    // node - the 128 KB of the cross block were 1.8 us of this workgroup's 4.1 us until its blocks were in LDS)
+    if (b > 0 && !served) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
+#if defined(DLSM_X_RES) && (DLSM_X_RES & 1)      // measurement only: no cross block
+            const double2 v = make_double2(1.0, 1.0);
+#else
             const double2 v = coh_load2<COH>(H, cr_off, (uint32_t)(16 * u * sizeof(double)));
+#endif
             cr[2 * u] = v.x; cr[2 * u + 1] = v.y;
         }
     }
@@ -1224,7 +1243,11 @@ __device__ __forceinline__ void row_resolve(const ChainView &c, const PipeBuf &p
     const uint32_t blk_off = (uint32_t)((wave * (2 * PP_B) + PP_B + 2 * lane) * sizeof(double));
 #pragma unroll
     for (int u = 0; u < BLK_H; ++u)
+#if defined(DLSM_X_RES) && (DLSM_X_RES & 2)      // measurement only: no diagonal block
+        blk[u] = make_double2(1.0, 1.0);
+#else
         blk[u] = coh_load2<COH>(H, blk_off, (uint32_t)(u * PP_WAVES * (2 * PP_B) * sizeof(double)));
+#endif
     // the owners' inputs (requested now, used once the blocks above have left their registers)
     double2 tv[4];
     double x1[D], x0[D], uk = 1.0, st = 0.0;
@@ -1250,6 +1273,11 @@ __device__ __forceinline__ void row_resolve(const ChainView &c, const PipeBuf &p
         if (!COH) npre.request1(c, t, j0 + kc);        // the prior terms' operands, with everything else
     };
     if (owner) owner_loads();
+    // the owners' exponential table (tab_exp), requested with everything else: it is read behind the barrier
+    // below (round 6: its own fill + barrier in front of this function kept every request of the batch
+    // a memory round trip late - the resolver is the launch's critical path once the evaluators are shorter)
+    double tabv = 0.0;
+    if (tid < EXPTAB_N) tabv = c_exp2_tab[tid];
 #pragma unroll
     for (int u = 0; u < BLK_H; ++u) {
         double *dst = sD + (u * PP_WAVES + wave) * PR_LD + 2 * lane;
@@ -1281,11 +1309,13 @@ __device__ __forceinline__ void row_resolve(const ChainView &c, const PipeBuf &p
 #pragma unroll
         for (int u = 0; u < 8; ++u)
             mp |= ((unsigned int)((u < 4 ? mlo : mhi) >> (16 * (u & 3))) & 3u) << (2 * u);
-        double prod = 1.0;
+        if (!served) {
+            double prod = 1.0;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) prod *= (mp >> i) & 1u ? cr[i] : 1.0;
-        const double v = group8_prod(prod);
-        if (jx == 0) sCross[kx] = v;
+            for (int i = 0; i < 16; ++i) prod *= (mp >> i) & 1u ? cr[i] : 1.0;
+            const double v = group8_prod(prod);
+            if (jx == 0) sCross[kx] = v;
+        }
     }
     // multiplicative domain: r = exp(log-ratio of node k), lu = its uniform draw.  A node whose
     // log-ratio is beyond +-700 (exp would saturate) is resolved in the log domain instead
@@ -1308,15 +1338,19 @@ __device__ __forceinline__ void row_resolve(const ChainView &c, const PipeBuf &p
                                  : npre.value(x1) - npre.value(x0);
         const double ek = tot + prior;
         sat = !(fabs(ek) <= 700.0);
-        // (the table exponential: the compiler's exp() keeps a dozen float64 constants alive through
-        // the whole batch loop, in registers the blocks above need - it spilled them)
-        r = sat ? 1.0 : tab_exp(sat ? 0.0 : ek, sTab) * pr_;
+        // (r = exp(ek) pr_ behind the barrier: the table is in LDS by then)
+        r = sat ? 1.0 : pr_;
+        lr = ek;
         lu = uk;
         if (sat) { lr = ek + log(pr_); lu = log(lu); }
         const unsigned long long sm = __ballot(sat);
         if (lane == 0) sSatMask[half] = sm;
     }
-    __syncthreads();                                   // sD, sCross, sSatMask visible
+    if (tid < EXPTAB_N) sTab[tid] = tabv;
+    __syncthreads();                                   // sD, sCross, sSatMask, sTab visible
+    // (the table exponential: the compiler's exp() keeps a dozen float64 constants alive through
+    // the whole batch loop, in registers the blocks above need - it spilled them)
+    if (owner && !sat) r *= tab_exp(lr, sTab);
     DLSM_STAMP(1, (double)tid)
     const unsigned long long sat0 = sSatMask[0], sat1 = sSatMask[1];
     const bool anysat = (sat0 | sat1) != 0ull;         // workgroup-uniform; practically never
@@ -1338,7 +1372,32 @@ __device__ __forceinline__ void row_resolve(const ChainView &c, const PipeBuf &p
         __syncthreads();
     }
     if (owner) {
-        if (b > 0) { const double vk = sCross[k]; if (sat) lr += vk; else r *= vk; }
+        if (b > 0) {
+            double vk;
+            if (served && !sat) {
+                // the product announces itself: the slot is PP_XP_EMPTY until the serving wavefront has stored it
+                vk = 1.0;
+                if (valid) {
+                    const unsigned long long *slotp = (const unsigned long long *)&pb.xprod[(size_t)t * PP_B + k];
+                    unsigned long long got = PP_XP_EMPTY;
+                    for (int n = 0; n < pb.budget; ++n) {
+                        got = __hip_atomic_load(slotp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (__ballot(got == PP_XP_EMPTY) == 0ull) break;
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                    if (got == PP_XP_EMPTY)
+                        __hip_atomic_fetch_or(pb.err, PP_ERR_XSERVE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    vk = __longlong_as_double((long long)got);
+                    // taken: empty again for the next launch (the kernel boundary publishes the plain store)
+                    pb.xprod[(size_t)t * PP_B + k] = __longlong_as_double((long long)PP_XP_EMPTY);
+                }
+            } else {
+                if (served && valid)    // (a node resolved in the log domain: its slot is emptied, its sum is sCross's)
+                    pb.xprod[(size_t)t * PP_B + k] = __longlong_as_double((long long)PP_XP_EMPTY);
+                vk = sCross[k];
+            }
+            if (sat) lr += vk; else r *= vk;
+        }
         const unsigned long long g = __ballot(valid && !(sat ? lu >= lr : lu >= r));
         if (lane == 0) sMask[0][half] = g;
     }
@@ -1420,6 +1479,10 @@ __device__ __forceinline__ void row_resolve(const ChainView &c, const PipeBuf &p
 #endif
 }
 
+}  // namespace dlsm
+#include "kernels_pipe_lds.hpp"
+namespace dlsm {
+
 // Launch l: even slices resolve batches G l .. G l + G - 1 and evaluate batches G (l + 1) ..;
 // odd slices run one launch behind (batches outside [0, nbat) do nothing).
 // Workgroups [0, T) are the resolvers, the rest evaluate one item per wavefront and round.
@@ -1439,17 +1502,36 @@ __global__ __launch_bounds__(PP_THREADS) void k_pipe_step(ChainView c, PipeBuf p
     const int T = c.T;
     // one batch per launch, exact likelihoods: the H blocks by rows and their resolver (row_resolve)
     constexpr bool ROWS = G == 1 && MODEL != DLSM_DIRECTED_CASE_CONTROL;
-    if ((int)blockIdx.x < T) {
-        const int t = blockIdx.x;
+    int bx = (int)blockIdx.x;
+    const bool grid3 = MODEL_ == DLSM_UNDIRECTED && G == 1 && gridDim.z > 1;    // kernels_pipe_lds.hpp's evaluators
+    if (grid3) {
+        if (blockIdx.z == 0) {
+            bx = (int)blockIdx.x + (int)gridDim.x * (int)blockIdx.y;
+            if (bx >= T) return;                       // (plane 0 is padded to the evaluators' planes)
+        } else {
+#ifdef DLSM_PIPE_TIMING
+            const unsigned long long t_kernel = pipe_clock((double)threadIdx.x);    // the wavefront's first instruction
+#endif
+            pipe_eval_lds<D>(c, pb, l, pp_sH
+#ifdef DLSM_PIPE_TIMING
+                             , t_kernel
+#endif
+                             );
+            return;
+        }
+    }
+    if (bx < T) {
+        const int t = bx;
         if (ROWS) {
             __shared__ double sCross[PP_B];
             __shared__ unsigned long long sSatMask[2];
             __shared__ double sTab[EXPTAB_N];
             const int b = l - (t & 1);
+            const bool served = pb.xserve != 0 && grid3;                  // (both sides decide by the same rule)
+            if (l == -1 && threadIdx.x < PP_B)                            // the sweep's first launch: every slot empty
+                pb.xprod[(size_t)t * PP_B + threadIdx.x] = __longlong_as_double((long long)PP_XP_EMPTY);
             if (b < 0 || b >= pb.nbat) return;
-            exp_table_fill(sTab, threadIdx.x);
-            __syncthreads();
-            row_resolve<D, false>(c, pb, b, t, pp_sH, sPart, sMask, nullptr, sCross, sSatMask, sTab
+            row_resolve<D, false>(c, pb, b, t, pp_sH, sPart, sMask, nullptr, sCross, sSatMask, sTab, served
 #ifdef DLSM_PIPE_TIMING
                                   , l + 1
 #endif
@@ -1470,6 +1552,9 @@ __global__ __launch_bounds__(PP_THREADS) void k_pipe_step(ChainView c, PipeBuf p
         }
         return;
     }
+#ifdef DLSM_PIPE_TIMING
+    const unsigned long long t_kernel = pipe_clock((double)threadIdx.x);    // the wavefront's first instruction
+#endif
     const int lane = threadIdx.x & 63;
     const int nE = (T + 1) / 2, nO = T / 2;
     const int beE = G * (l + 1), beO = G * l;        // first batch evaluated (even / odd slices)
@@ -1545,6 +1630,11 @@ __global__ __launch_bounds__(PP_THREADS) void k_pipe_step(ChainView c, PipeBuf p
             , l + 1, gw
 #endif
             );
+#ifdef DLSM_PIPE_TIMING
+        // (slot 4, "H operands here", gives way to the wavefront's first stamp in the kernel: both evaluators
+        // on one time axis)
+        if (lane == 0 && l + 1 >= 0 && l + 1 < 24 && q < 4096) g_pipe_item_t[l + 1][q][4] = t_kernel;
+#endif
     }
 }
 
@@ -1577,9 +1667,7 @@ __device__ __forceinline__ void pipe_last_ride_wg(const ChainView &c, const Pipe
             __shared__ double sCross[PP_B];
             __shared__ unsigned long long sSatMask[2];
             __shared__ double sTab[EXPTAB_N];
-            exp_table_fill(sTab, threadIdx.x);
-            __syncthreads();
-            row_resolve<D, false>(c, pb, b, t, pp_sH, sPart, sMask, nullptr, sCross, sSatMask, sTab
+            row_resolve<D, false>(c, pb, b, t, pp_sH, sPart, sMask, nullptr, sCross, sSatMask, sTab, false
 #ifdef DLSM_PIPE_TIMING
                                   , l + 1
 #endif
