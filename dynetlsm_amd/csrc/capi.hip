@@ -1127,7 +1127,6 @@ static int launch_sweep_pipe(dlsm_chain *h, IterRef iter, bool alloc_only = fals
     pb.lds_eval = h->model == DLSM_UNDIRECTED && pipe_lds_eval_bytes(N, DD, parts) <= lds &&
                   (long)parts * T * PP_B <= (long)ne_wg * PP_WAVES &&
                   !(getenv("DLSM_PIPE_LDS") && atoi(getenv("DLSM_PIPE_LDS")) == 0);
-    pb.lds_cap = pipe_lds_trip_cap((N + 63) / 64, parts);
     // the resolvers' cross products by the evaluators (pipe_xserve_*): one wavefront in xstride takes a row.  A
     // resolver waits INSIDE the launch for wavefronts that wait for nothing - they only have to start; with so
     // many chains on the device that their resolver workgroups alone could fill it, the resolvers keep the work
@@ -1135,16 +1134,22 @@ static int launch_sweep_pipe(dlsm_chain *h, IterRef iter, bool alloc_only = fals
         const char *ex = getenv("DLSM_PIPE_XSERVE"), *ebud = getenv("DLSM_PIPE_XBUDGET");
         pb.err = h->fork_err_dev;
         pb.budget = ebud ? atoi(ebud) : (1 << 22);
-        pb.xstride = 1;                     // (per launch, below)
-        pb.inv_xstride = 0.0f;
         pb.xserve = pb.lds_eval && pb.err != nullptr && (ex ? atoi(ex) != 0 : true) &&
                     T < 128 && (long)g_live_chains.load() * T * 2 <= (long)h->n_cu;
     }
     const int xserve_sweep = pb.xserve;         // (a launch whose workgroups cannot cover the rows keeps the resolvers' own products)
     pb.xserve = 0;
+    ChainView v = h->view();
+    {   // the evaluators' arguments (kernels_pipe_lds.hpp) in one piece
+        PipeLds &a = pb.lds;
+        a.X = v.X; a.ybits = v.ybits; a.prop = pb.prop; a.full0 = pb.full0; a.Hd = pb.Hd; a.acc = pb.acc;
+        a.consts = pb.consts; a.xprod = pb.xprod;
+        a.T = T; a.N = N; a.W = v.W; a.squared = v.squared; a.parts = parts; a.nbat = nbat;
+        a.lds_cap = pipe_lds_trip_cap((N + 63) / 64, parts); a.xserve = 0;
+    }
     for (int nw = 1; nw <= 4; ++nw)
         for (int p = 0; p < PP_MAXPARTS; ++p)
-            pb.plan[nw - 1][p] = p < parts ? pipe_plan_entry((N + 63) / 64, parts, nw, p) : 0u;
+            pb.lds.plan[nw - 1][p] = p < parts ? pipe_plan_entry((N + 63) / 64, parts, nw, p) : 0u;
     auto ku = k_pipe_step<DD, DLSM_UNDIRECTED>;
     auto kl = k_pipe_step<DD, PIPE_UNDIRECTED_LONG>;
     auto kd = k_pipe_step<DD, DLSM_DIRECTED>;
@@ -1160,7 +1165,6 @@ static int launch_sweep_pipe(dlsm_chain *h, IterRef iter, bool alloc_only = fals
     HIPCHK(h, hipFuncSetAttribute((const void *)k_pipe_last_ride<DD>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (alloc_only) return DLSM_OK;
-    ChainView v = h->view();
     {   // the proposal pass, unless the previous iteration's last launch carried it
         const ProposeBuf nb{pb.prop, pb.consts, pb.sync, pb.nsync, pb.queue0, pb.lsm_draw};
         const bool drawn = !iter.ptr && h->prop_drawn_for == (long)iter.value && h->next_prop_ok &&
@@ -1202,16 +1206,18 @@ static int launch_sweep_pipe(dlsm_chain *h, IterRef iter, bool alloc_only = fals
             // kernels_pipe_lds.hpp: plane 0 = the resolvers (padded to the planes' size), plane p + 1 = part p's
             // evaluators, 16 consecutive nodes (x) of one active slice (y) per workgroup
             const int beE = l + 1, beO = l, nE = (T + 1) / 2, nO = T / 2;
-            pb.beE = beE; pb.beO = beO;
-            pb.nbE = (beE >= 0 && beE < nbat) ? std::min(PP_B, N - beE * PP_B) : 0;
-            pb.nbO = (beO >= 0 && beO < nbat) ? std::min(PP_B, N - beO * PP_B) : 0;
-            pb.nslE = pb.nbE > 0 ? nE : 0; pb.nslO = pb.nbO > 0 ? nO : 0;
-            const int gx = PP_B / PP_WAVES;
-            const int ny = std::max(pb.nslE + pb.nslO, (T + gx - 1) / gx);
-            // serving wavefronts per evaluator workgroup (pipe_xserve_request)
-            pb.xstride = (T * PP_B + parts * ny * gx - 1) / (parts * ny * gx);
-            pb.xserve = xserve_sweep && pb.xstride <= PP_WAVES;
-            launch_pipe_step<DD, DLSM_UNDIRECTED>(h, v, pb, dim3(gx, ny, parts + 1), lds, l);
+            PipeLds &a = pb.lds;
+            a.beE = beE; a.beO = beO;
+            a.nbE = (beE >= 0 && beE < nbat) ? std::min(PP_B, N - beE * PP_B) : 0;
+            a.nbO = (beO >= 0 && beO < nbat) ? std::min(PP_B, N - beO * PP_B) : 0;
+            a.nslE = a.nbE > 0 ? nE : 0; a.nslO = a.nbO > 0 ? nO : 0;
+            const int gx = PP_B / PP_WAVES, nsl = a.nslE + a.nslO;
+            a.nsl_magic = (65536u + (uint32_t)nsl - 1u) / (uint32_t)nsl;
+            // serving wavefronts per evaluator workgroup (pipe_xserve_request): every launched one can serve
+            a.xstride = (T * PP_B + ne_wg - 1) / ne_wg;
+            pb.xserve = a.xserve = xserve_sweep && a.xstride <= PP_WAVES;
+            (void)gx;
+            launch_pipe_step<DD, DLSM_UNDIRECTED>(h, v, pb, dim3(grid), lds, l);
         } else if (h->model == DLSM_UNDIRECTED)
             launch_pipe_step<DD, DLSM_UNDIRECTED>(h, v, pb, dim3(grid), lds, l);
         else if (h->model == DLSM_DIRECTED)

@@ -82,12 +82,12 @@ inline uint32_t pipe_plan_entry(int ntrip, int P, int nwin, int p) {
     }
     return (uint32_t)w | ((uint32_t)r << 3) | ((uint32_t)s << 16);
 }
-__device__ __forceinline__ PipePlan pipe_plan(const PipeBuf &pb, int ntrip, int p, int be, int k0) {
+__device__ __forceinline__ PipePlan pipe_plan(const PipeBuf &pb, int ntrip, int p, int be, int k0) {     // (pb: the kernel argument itself - a scalar load at a computed offset)
     PipePlan pl;
     pl.glo = be > 0 ? 2 * be - 2 : 0;
     const int ghi = min(2 * be + (k0 >= 64 ? 1 : 0), ntrip - 1);
     pl.nwin = ghi - pl.glo + 1;                                  // 1 .. 4 (trip 2 be exists: the batch has nodes)
-    const uint32_t e = pb.plan[pl.nwin - 1][p];
+    const uint32_t e = pb.lds.plan[pl.nwin - 1][p];
     pl.w = (int)(e & 7u); pl.r = (int)((e >> 3) & 0x1fffu); pl.s = (int)(e >> 16);
     return pl;
 }
@@ -129,7 +129,7 @@ constexpr double PL_FAR = 3.0e5;
 // entry or a partial lane mask - run first, in a loop of their own, and the other trips run bare: full exec
 // mask, consecutive bit words, a countdown for the issue priority.
 template <int D, bool FLUSH, bool SQ>
-__device__ __forceinline__ void pipe_lds_trips(const ChainView &c, int P, const PipePlan &pl, int p, int be,
+__device__ __forceinline__ void pipe_lds_trips(int nw64, int P, const PipePlan &pl, int p, int be,
                                                int k, int jk, int lane, const double (&xk0)[D],
                                                const double (&xk1)[D], double E, int nflush,
                                                const unsigned long long *yrow, unsigned long long ym,
@@ -140,7 +140,7 @@ __device__ __forceinline__ void pipe_lds_trips(const ChainView &c, int P, const 
 #endif
                                                ) {
     const int ntp = pl.trips();
-    const int nw64 = c.W >> 1;                              // 8-byte words of a row
+    // (nw64: 8-byte words of a row of the network)
     const double *row = sX + lane * D;                      // this lane's neighbour of trip 0, 1, ..: stride 64 D
     double xi[D];
 #pragma unroll
@@ -247,24 +247,24 @@ __device__ __forceinline__ double wave_prod_tp(double v, int lane) {     // prod
 }
 // workgroup `wg` of the evaluators, wavefront `wave`: the first pb.xstride wavefronts of a workgroup serve rows
 // wg * xstride + wave (xstride = ceil(rows / evaluator workgroups): no quotient to compute)
-__device__ __forceinline__ void pipe_xserve_request(const ChainView &c, const PipeBuf &pb, int l, int wg, int wave,
+__device__ __forceinline__ void pipe_xserve_request(const PipeLds &a, int l, int wg, int wave,
                                                     int lane, PipeXServe &xs) {
     xs.on = false;
-    if (!pb.xserve || wave >= pb.xstride) return;
-    const int row = wg * pb.xstride + wave;
-    if (row >= c.T * PP_B) return;
+    if (!a.xserve || wave >= a.xstride) return;
+    const int row = wg * a.xstride + wave;
+    if (row >= a.T * PP_B) return;
     const int t = row >> 7, k = row & (PP_B - 1);
     const int b = l - (t & 1);                                            // the batch slice t resolves in this launch
-    if (b < 1 || b >= pb.nbat || k >= min(PP_B, c.N - b * PP_B)) return;
+    if (b < 1 || b >= a.nbat || k >= min(PP_B, a.N - b * PP_B)) return;
     // (32-bit offsets from the launch's base pointers: T < 2^7 slices of 2 x 128 x 256 factors)
     const uint32_t moff = (uint32_t)(t * 2 + ((b - 1) & 1)) * PP_ACC + PP_ACC_MASK;
     // (the lane's half of the mask as a VECTOR load: a scalar load from memory this cold would hold up every
     // scalar wait behind it - the kernel arguments the staging addresses are made of)
-    const unsigned long long *pmg = (const unsigned long long *)(pb.acc + moff);
+    const unsigned long long *pmg = (const unsigned long long *)(a.acc + moff);
     xs.m = __builtin_nontemporal_load(pmg + (lane >> 5));
-    const uint32_t hoff = (uint32_t)((((b & 1) * c.T + t) * PP_B + k) * (2 * PP_B) + 2 * lane);
-    xs.v = *(const double2 *)(pb.Hd + hoff);                              // factors of window nodes 2 lane, 2 lane + 1
-    xs.slot = pb.xprod + (uint32_t)row;
+    const uint32_t hoff = (uint32_t)((((b & 1) * a.T + t) * PP_B + k) * (2 * PP_B) + 2 * lane);
+    xs.v = *(const double2 *)(a.Hd + hoff);                              // factors of window nodes 2 lane, 2 lane + 1
+    xs.slot = a.xprod + (uint32_t)row;
     xs.on = true;
 }
 __device__ __forceinline__ void pipe_xserve_finish(const PipeXServe &xs, int lane) {
@@ -287,29 +287,43 @@ __device__ __forceinline__ void pipe_eval_lds(const ChainView &c, const PipeBuf 
 #endif
                                               ) {
     constexpr int PW = 2 * D + 2;
-    const int T = c.T, N = c.N;
+    // the launch's arguments in one piece (PipeLds): the pointers and scalars below are 128 contiguous bytes of the
+    // kernel's argument block, pinned here so that they are requested together by the first instructions
+    PipeLds a;
+    a.X = pb.lds.X; a.ybits = pb.lds.ybits; a.prop = pb.lds.prop; a.full0 = pb.lds.full0; a.Hd = pb.lds.Hd;
+    a.acc = pb.lds.acc; a.consts = pb.lds.consts; a.xprod = pb.lds.xprod;
+    a.T = pb.lds.T; a.N = pb.lds.N; a.W = pb.lds.W; a.squared = pb.lds.squared; a.parts = pb.lds.parts;
+    a.nbat = pb.lds.nbat; a.lds_cap = pb.lds.lds_cap; a.xserve = pb.lds.xserve;
+    a.beE = pb.lds.beE; a.beO = pb.lds.beO; a.nbE = pb.lds.nbE; a.nbO = pb.lds.nbO; a.nslE = pb.lds.nslE;
+    a.nslO = pb.lds.nslO; a.xstride = pb.lds.xstride; a.nsl_magic = pb.lds.nsl_magic;
+    asm volatile("" :: "s"(a.X), "s"(a.ybits), "s"(a.prop), "s"(a.full0), "s"(a.Hd), "s"(a.acc), "s"(a.consts), "s"(a.xprod));
+    asm volatile("" :: "s"(a.T), "s"(a.N), "s"(a.W), "s"(a.squared), "s"(a.parts), "s"(a.nbat), "s"(a.lds_cap), "s"(a.xserve),
+                 "s"(a.beE), "s"(a.beO), "s"(a.nbE), "s"(a.nbO), "s"(a.nslE), "s"(a.nslO), "s"(a.xstride), "s"(a.nsl_magic));
+    const int T = a.T, N = a.N;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int P = pb.parts;
+    const int P = a.parts;
     const int ntrip = (N + 63) >> 6;
     double *sTab = lds;
     double *sX = lds + EXPTAB11_N;                                      // [trip cap][64][D]
-    double *sM = sX + (size_t)pb.lds_cap * 64 * D;                      // [PL_WIN][64][D]
-    // the workgroup's role from its coordinates: 16 consecutive nodes (x) of one active slice (y) and part (z - 1);
+    double *sM = sX + (size_t)a.lds_cap * 64 * D;                       // [PL_WIN][64][D]
+    // the workgroup's items: 16 consecutive nodes (wg mod 8) of one active slice and part, wg / 8 = p nsl + si;
     // batches, sizes and slice counts of the launch from the host (PipeBuf) - the four wavefronts of a SIMD issue
     // this prologue one after the other, so what it does not compute is time the barrier below comes earlier
     constexpr bool first = true;
-    const int wgx = (int)blockIdx.x, si = (int)blockIdx.y, p = (int)blockIdx.z - 1;
-    const int wg = (p * (int)gridDim.y + si) * (int)gridDim.x + wgx;     // (the row server's index)
+    const int wg = (int)blockIdx.x - T;                                  // (also the row server's index)
+    const int wgx = wg & (PP_B / PP_WAVES - 1), wr = wg >> 3;
+    const int p = (int)(((uint32_t)wr * a.nsl_magic) >> 16);
+    const int si = wr - p * (a.nslE + a.nslO);
     PipeXServe xs;
     {
         const int k0 = wgx * PP_WAVES;
-        const int nslE = pb.nslE;
+        const int nslE = a.nslE;
         const bool odd = si >= nslE;
-        const int be = odd ? pb.beO : pb.beE;
-        const int nb = si < nslE + pb.nslO ? (odd ? pb.nbO : pb.nbE) : 0;
+        const int be = odd ? a.beO : a.beE;
+        const int nb = p < P ? (odd ? a.nbO : a.nbE) : 0;              // (workgroups behind the last item: p = P)
         if (k0 >= nb) {         // (workgroup-uniform) no items here: the serving wavefronts have nothing else to do
-            pipe_xserve_request(c, pb, l, wg, wave, lane, xs);
+            pipe_xserve_request(a, l, wg, wave, lane, xs);
             pipe_xserve_finish(xs, lane);
             return;
         }
@@ -324,8 +338,8 @@ __device__ __forceinline__ void pipe_eval_lds(const ChainView &c, const PipeBuf 
         DLSM_STAMP(0, (double)lane)
         const int j0 = be * PP_B, jk = j0 + min(k, nb - 1);
         const int jprev = max(j0 - PP_B, 0);                             // nodes >= jprev: snapshot positions
-        const double *Xt = c.X + (size_t)t * N * D;
-        const double *props = pb.prop + (size_t)t * N * PW;
+        const double *Xt = a.X + (size_t)t * N * D;
+        const double *props = a.prop + (size_t)t * N * PW;
 #if DLSM_TRIP_PRIO
         __builtin_amdgcn_s_setprio(3);
 #endif
@@ -370,12 +384,12 @@ __device__ __forceinline__ void pipe_eval_lds(const ChainView &c, const PipeBuf 
             xk0[d] = props[(size_t)jk * PW + D + 2 + d];
             xk1[d] = props[(size_t)jk * PW + d];
         }
-        const double E = pb.consts[0];
-        const int nflush = (int)pb.consts[1];
+        const double E = a.consts[0];
+        const int nflush = (int)a.consts[1];
         // the node's row of the network: the bits under its first trip
-        const unsigned long long *yrow = (const unsigned long long *)(c.ybits + ((size_t)t * N + jk) * c.W);
+        const unsigned long long *yrow = (const unsigned long long *)(a.ybits + ((size_t)t * N + jk) * a.W);
         const unsigned long long ym0 = scalar_load_u64(yrow + pl.trip(0, p, P));
-        double *hrow = pb.Hd + (((size_t)(be & 1) * T + t) * PP_B + min(k, nb - 1)) * (2 * PP_B);
+        double *hrow = a.Hd + (((size_t)(be & 1) * T + t) * PP_B + min(k, nb - 1)) * (2 * PP_B);
 #if defined(DLSM_PIPE_TIMING) && DLSM_PIPE_TIMING == 2      // (prologue probe: slot 1 = requests issued, slot 2 = at the barrier)
         DLSM_STAMP(1, (double)lane)
 #endif
@@ -391,15 +405,15 @@ __device__ __forceinline__ void pipe_eval_lds(const ChainView &c, const PipeBuf 
         // one after the other and every instruction of a serving wavefront keeps the workgroup's other fifteen
         // waiting (+0.35 us on the barrier, measured); behind it a wavefront that sits out its request's round
         // trip costs nothing - the SIMD's other three have trips to issue.
-        pipe_xserve_request(c, pb, l, wg, wave, lane, xs);
+        pipe_xserve_request(a, l, wg, wave, lane, xs);
         pipe_xserve_finish(xs, lane);
         DLSM_STAMP(4, xk0[0])
         if (live) {
             RatioAcc ra;
-            const bool noflush = nflush >= 64 * ntp && !c.squared;
-            if (noflush) pipe_lds_trips<D, false, false>(c, P, pl, p, be, k, jk, lane, xk0, xk1, E, nflush, yrow, ym0, sTab, sX, sM, hrow, ra DLSM_LDS_TS);
-            else if (c.squared) pipe_lds_trips<D, true, true>(c, P, pl, p, be, k, jk, lane, xk0, xk1, E, nflush, yrow, ym0, sTab, sX, sM, hrow, ra DLSM_LDS_TS);
-            else pipe_lds_trips<D, true, false>(c, P, pl, p, be, k, jk, lane, xk0, xk1, E, nflush, yrow, ym0, sTab, sX, sM, hrow, ra DLSM_LDS_TS);
+            const bool noflush = nflush >= 64 * ntp && !a.squared;
+            if (noflush) pipe_lds_trips<D, false, false>(a.W >> 1, P, pl, p, be, k, jk, lane, xk0, xk1, E, nflush, yrow, ym0, sTab, sX, sM, hrow, ra DLSM_LDS_TS);
+            else if (a.squared) pipe_lds_trips<D, true, true>(a.W >> 1, P, pl, p, be, k, jk, lane, xk0, xk1, E, nflush, yrow, ym0, sTab, sX, sM, hrow, ra DLSM_LDS_TS);
+            else pipe_lds_trips<D, true, false>(a.W >> 1, P, pl, p, be, k, jk, lane, xk0, xk1, E, nflush, yrow, ym0, sTab, sX, sM, hrow, ra DLSM_LDS_TS);
             double tot_l, tot_r;
             if (noflush) {
                 // the products of the whole wave stay in range: multiply across lanes
@@ -408,7 +422,7 @@ __device__ __forceinline__ void pipe_eval_lds(const ChainView &c, const PipeBuf 
                 tot_l = wave_sum_all(ra.value()); tot_r = 1.0;
             }
             if (lane == 0) {
-                double2 *f = (double2 *)pb.full0 + (((size_t)(be & 1) * T + t) * PP_B + k) * P + p;
+                double2 *f = (double2 *)a.full0 + (((size_t)(be & 1) * T + t) * PP_B + k) * P + p;
                 *f = make_double2(tot_l, tot_r);
             }
 #ifdef DLSM_PIPE_TIMING

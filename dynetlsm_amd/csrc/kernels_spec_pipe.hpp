@@ -88,11 +88,27 @@ namespace dlsm {
 constexpr int PP_THREADS = 1024;
 constexpr int PP_WAVES = PP_THREADS / 64;
 constexpr int PP_B = 128;               // nodes per batch (two 64-lane halves)
-constexpr int PP_MAXPARTS = 8;
+constexpr int PP_MAXPARTS = 8;          // (PipeLds::plan holds 8 parts)
 // per (slice, batch slot) of PipeBuf::acc: [0] count, [1 .. PP_B] the accepted nodes ascending (the [m][k]
 // resolver's gather list), [PP_ACC_MASK ..] the same set as two 64-bit masks (the row resolver's)
 constexpr int PP_ACC = PP_B + 8;
 constexpr int PP_ACC_MASK = PP_B + 4;
+
+// What an evaluator of kernels_pipe_lds.hpp reads of the launch's arguments, in ONE piece at the head of PipeBuf's
+// tail: its first 128 bytes are requested together by the wavefront's first instructions (the compiler fetches a
+// kernel argument where it is first used - a dozen scalar loads, each with a wait of its own, in a prologue that
+// the four wavefronts of a SIMD issue one after the other).
+struct PipeLds {
+    const double *X; const uint32_t *ybits; double *prop; double *full0; double *Hd; int32_t *acc; double *consts;
+    double *xprod;
+    int T, N, W, squared, parts, nbat, lds_cap, xserve;
+    // per launch: the batch evaluated / its nodes / the active slices (even and odd slices); evaluator workgroup e
+    // (blockIdx.x - T) holds 16 consecutive nodes (e mod 8) of active slice si and part p, e / 8 = p nsl + si with
+    // the quotient as a multiplication: r / nsl = r nsl_magic >> 16 (nsl_magic = ceil(2^16 / nsl), r < 2^16 / nsl)
+    int beE, beO, nbE, nbO, nslE, nslO, xstride; uint32_t nsl_magic;
+    uint32_t plan[4][8];        // the parts' trip lists (pipe_plan_entry), by (window trips - 1, part)
+};
+static_assert(sizeof(PipeLds) == 256, "PipeLds: two 64-byte halves of scalars and the plan table");
 
 // G batches are resolved (and G evaluated) per launch.  Batch b is evaluated while the batches
 // from ws(b) = G (b / G - 1) on are still unresolved - its WINDOW: G = 1: the previous batch;
@@ -112,15 +128,11 @@ struct PipeBuf {
     // by the propose kernel; word 0 (the ticket counter) starts at queue0
     int32_t *sync; int nsync, queue0;
     LsmDeviceState *lsm_draw;   // not NULL: the proposal pass also draws the intercept proposal
-    uint32_t plan[4][PP_MAXPARTS];      // kernels_pipe_lds.hpp: the parts' trip lists (pipe_plan_entry)
+    PipeLds lds;     // kernels_pipe_lds.hpp: the evaluators' arguments (filled by the host per launch)
     // the cross products by the evaluators (kernels_pipe_lds.hpp, pipe_xserve): slot [t][k] holds PP_XP_EMPTY
     // until the wavefront that serves row k of slice t has stored prod_{m accepted} Hx[k][m]; the row's owner in
     // the resolver workgroup polls it past its L1 and empties it again
-    double *xprod; int32_t *err; int xserve, xstride, budget; float inv_xstride;
-    int lds_cap;     // rows of LDS the longest part may hold (pipe_lds_trip_cap)
-    // per launch, from the host (the grid of such a launch is (PP_B / 16, slices, parts + 1): plane 0 holds the
-    // resolvers, plane p + 1 the evaluators of part p - a workgroup reads its role off its coordinates)
-    int beE, beO, nbE, nbO, nslE, nslO;     // batch evaluated / its nodes / active slices, even and odd slices
+    double *xprod; int32_t *err; int xserve, budget;
     int lds_eval;    // undirected model: the evaluators of kernels_pipe_lds.hpp (rows staged in LDS, interleaved
                      // parts, H factors inside the trips); 0: pipe_eval_item
 };
@@ -1502,13 +1514,10 @@ __global__ __launch_bounds__(PP_THREADS) void k_pipe_step(ChainView c, PipeBuf p
     const int T = c.T;
     // one batch per launch, exact likelihoods: the H blocks by rows and their resolver (row_resolve)
     constexpr bool ROWS = G == 1 && MODEL != DLSM_DIRECTED_CASE_CONTROL;
-    int bx = (int)blockIdx.x;
-    const bool grid3 = MODEL_ == DLSM_UNDIRECTED && G == 1 && gridDim.z > 1;    // kernels_pipe_lds.hpp's evaluators
+    const int bx = (int)blockIdx.x;
+    const bool grid3 = MODEL_ == DLSM_UNDIRECTED && G == 1 && pb.lds_eval && (int)gridDim.x > T;    // kernels_pipe_lds.hpp's evaluators
     if (grid3) {
-        if (blockIdx.z == 0) {
-            bx = (int)blockIdx.x + (int)gridDim.x * (int)blockIdx.y;
-            if (bx >= T) return;                       // (plane 0 is padded to the evaluators' planes)
-        } else {
+        if (bx >= T) {
 #ifdef DLSM_PIPE_TIMING
             const unsigned long long t_kernel = pipe_clock((double)threadIdx.x);    // the wavefront's first instruction
 #endif
