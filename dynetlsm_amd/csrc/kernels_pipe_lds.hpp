@@ -148,6 +148,12 @@ __device__ __forceinline__ void pipe_lds_trips(int nw64, int P, const PipePlan &
     // first trip behind the window's: rank pl.s of the other trips
     int g = pl.w > 0 ? pl.glo + p : (pl.s < pl.glo ? pl.s : pl.s + pl.nwin);   // (ym: its bits, requested by the caller)
     const int greg = pl.s < pl.glo ? pl.s : pl.s + pl.nwin;
+// the edges' linear term: under the lanes of "y = 1" (a select less per trip than lin += y (d0 - d1))
+#ifndef DLSM_LDS_LIN_FMA
+#define DLSM_LDS_LIN() if (yb) ra.lin += d0 - d1;
+#else
+#define DLSM_LDS_LIN() ra.lin = fma(yb ? 1.0 : 0.0, d0 - d1, ra.lin);
+#endif
 #define DLSM_LDS_TERM()                                                                                   \
         const bool yb = __builtin_amdgcn_inverse_ballot_w64(ym);                                          \
         const double d0 = dist_fast<D>(xi, xk0, SQ ? 1 : 0);                                              \
@@ -155,7 +161,7 @@ __device__ __forceinline__ void pipe_lds_trips(int nw64, int P, const PipePlan &
         const double e0 = SQ ? tab_exp11_clamped(-d0, etab) : tab_exp11(-d0, etab);                       \
         const double e1 = SQ ? tab_exp11_clamped(-d1, etab) : tab_exp11(-d1, etab);                       \
         const double f0 = fma(E, e0, 1.0), f1 = fma(E, e1, 1.0);                                          \
-        ra.lin = fma(yb ? 1.0 : 0.0, d0 - d1, ra.lin);                                                    \
+        DLSM_LDS_LIN()                                                                                    \
         ra.P0 *= f0;                                                                                      \
         ra.P1 *= f1;                                                                                      \
         if (FLUSH) if (++ra.cnt >= nflush) ra.flush();
@@ -224,6 +230,7 @@ __device__ __forceinline__ void pipe_lds_trips(int nw64, int P, const PipePlan &
         ym = ymn; g = gn;
     }
 #undef DLSM_LDS_TERM
+#undef DLSM_LDS_LIN
     DLSM_STAMP(2, ra.P0)
 }
 
