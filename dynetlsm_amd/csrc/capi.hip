@@ -1186,7 +1186,7 @@ static int launch_sweep_pipe(dlsm_chain *h, IterRef iter, bool alloc_only = fals
         if (h->sweep_part == 1 && l >= 0) break;
         const bool any_eval = (G * (l + 1) < nbat) || (T > 1 && l >= 0 && G * l < nbat);
         const int grid = T + (any_eval ? ne_wg : 0);
-        const bool lng = !pb.lds_eval && pb.per > 64 * pipe_prefetch_trips(DD);
+        const bool lng = !pb.lds_eval;       // (undirected model without the LDS evaluators: pipe_eval_item's pipelined trips)
         if (l == last && !any_eval && h->post_ride_want && G == 1 && h->model == DLSM_UNDIRECTED &&
             !h->profiling && l >= 0 && T + 4 <= PS_BLOCKS) {
             // the centring sums ride in the resolve-only launch (kernels_spec_pipe.hpp): nwg rider

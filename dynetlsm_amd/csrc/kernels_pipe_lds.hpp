@@ -204,31 +204,53 @@ __device__ __forceinline__ void pipe_lds_trips(int nw64, int P, const PipePlan &
     const int quarter = max((ntp + 3) >> 2, 1);
     int left = max(quarter - pl.w, 1), level = 3;           // issue priority 3 -> 0 by quarters of the item
     const int glast = nw64 - 1;
-    for (int i = 0; i < pl.r; ++i) {
-        int gn = g + 1;
-        if (gn == pl.glo) gn += pl.nwin;
-        double xn[D];
-        row += 64 * D;                                      // (the slot behind the last trip is LDS of this launch too)
+    // two trips per iteration, the rows and bit words of one requested under the other's arithmetic, in registers
+    // of their own (the single-trip form handed the next row over through four copies per trip)
+#if DLSM_TRIP_PRIO
+#define DLSM_LDS_PRIO_STEP()                                                                              \
+        if (--left == 0) {                                                                                \
+            left = quarter;                                                                               \
+            if (level == 3) __builtin_amdgcn_s_setprio(2);                                                \
+            else if (level == 2) __builtin_amdgcn_s_setprio(1);                                           \
+            else __builtin_amdgcn_s_setprio(0);                                                           \
+            --level;                                                                                      \
+        }
+#else
+#define DLSM_LDS_PRIO_STEP()
+#endif
+#define DLSM_LDS_NEXT(G_) { ++G_; if (G_ == pl.glo) G_ += pl.nwin; }
+    int i = 0;
+    for (; i + 1 < pl.r; i += 2) {
+        double xb[D];
+        int gb = g;
+        DLSM_LDS_NEXT(gb)
 #pragma unroll
-        for (int d = 0; d < D; ++d) xn[d] = row[d];
-        const unsigned long long ymn = scalar_load_u64(yrow + min(gn, glast));
+        for (int d = 0; d < D; ++d) xb[d] = row[64 * D + d];
+        const unsigned long long ymb = scalar_load_u64(yrow + min(gb, glast));
         {
             DLSM_LDS_TERM()
         }
         if (pl.w == 0 && i == 0) { DLSM_STAMP(1, ra.P0) }
-#if DLSM_TRIP_PRIO
-        if (--left == 0) {
-            left = quarter;
-            if (level == 3) __builtin_amdgcn_s_setprio(2);
-            else if (level == 2) __builtin_amdgcn_s_setprio(1);
-            else __builtin_amdgcn_s_setprio(0);
-            --level;
-        }
-#endif
+        DLSM_LDS_PRIO_STEP()
+        g = gb;
+        DLSM_LDS_NEXT(g)
+        row += 2 * 64 * D;                                  // (the slots behind the last trip are LDS of this launch too)
 #pragma unroll
-        for (int d = 0; d < D; ++d) xi[d] = xn[d];
-        ym = ymn; g = gn;
+        for (int d = 0; d < D; ++d) xi[d] = row[d];
+        ym = scalar_load_u64(yrow + min(g, glast));
+        {
+            const double (&xi)[D] = xb;
+            const unsigned long long ym = ymb;
+            DLSM_LDS_TERM()
+        }
+        DLSM_LDS_PRIO_STEP()
     }
+    if (i < pl.r) {
+        DLSM_LDS_TERM()
+        if (pl.w == 0 && i == 0) { DLSM_STAMP(1, ra.P0) }
+    }
+#undef DLSM_LDS_NEXT
+#undef DLSM_LDS_PRIO_STEP
 #undef DLSM_LDS_TERM
 #undef DLSM_LDS_LIN
     DLSM_STAMP(2, ra.P0)

@@ -1561,6 +1561,10 @@ __global__ __launch_bounds__(PP_THREADS) void k_pipe_step(ChainView c, PipeBuf p
         }
         return;
     }
+    // (the undirected model's evaluators are kernels_pipe_lds.hpp's above; when their rows do not fit the LDS or
+    // the items need a second round the host launches the PIPE_UNDIRECTED_LONG instantiation, whose evaluators are
+    // pipe_eval_item's software-pipelined trips below)
+    if (MODEL_ == DLSM_UNDIRECTED) return;
 #ifdef DLSM_PIPE_TIMING
     const unsigned long long t_kernel = pipe_clock((double)threadIdx.x);    // the wavefront's first instruction
 #endif

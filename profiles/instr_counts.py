@@ -41,7 +41,8 @@ def extract_code_object(lib_path, arch='gfx950'):
     raise RuntimeError('no %s code object in %s' % (arch, lib_path))
 
 
-def disassemble(lib_path):
+def disassemble(lib_path, with_addresses=False):
+    """{mangled kernel name: [instruction text]} (with_addresses: [(byte address, text)])"""
     co = extract_code_object(lib_path)
     with tempfile.NamedTemporaryFile(suffix='.co', delete=False) as f:
         f.write(co)
@@ -61,7 +62,11 @@ def disassemble(lib_path):
         elif name and line.strip() and not line.startswith('Disassembly'):
             ins = line.strip().split('//')[0].strip()
             if ins:
-                cur.append(ins)
+                if with_addresses:
+                    m2 = re.search(r'//\s*([0-9A-Fa-f]+):', line)
+                    cur.append((int(m2.group(1), 16) if m2 else -1, ins))
+                else:
+                    cur.append(ins)
     if name:
         funcs[name] = cur
     return funcs
@@ -107,12 +112,51 @@ def _modal_run(trips, min_run):
     return best
 
 
+def _rolled_trip_loops(ains):
+    """(VALU, length, quarter-rate, SALU) of every loop (a backward branch and its target, by byte addresses: a
+    branch's operand counts 4-byte words from the instruction behind it) that holds exactly two roots and stores
+    nothing to memory: the bare trips of kernels_pipe_lds.hpp's evaluators (round 6: the neighbour loop is rolled -
+    one trip of 64 neighbours at two positions per iteration)"""
+    addr = [a for a, _ in ains]
+    index = {a: i for i, a in enumerate(addr)}
+    out = []
+    for i, (a, l) in enumerate(ains):
+        if not (l.startswith('s_cbranch') or l.startswith('s_branch')):
+            continue
+        t = l.split()[-1]
+        if not t.isdigit() or int(t) < 32768:
+            continue
+        target = a + 4 + 4 * (int(t) - 65536)
+        if target not in index:
+            continue
+        body = [x for _, x in ains[index[target]:i + 1]]
+        nroot = sum(1 for x in body if x.startswith('v_rsq_f64'))
+        if nroot not in (2, 4):                         # one trip per iteration, or two (the unrolled form)
+            continue
+        ntrip = nroot // 2
+        if any(x.startswith('global_store') or x.startswith('s_barrier') for x in body):
+            continue
+        out.append((sum(1 for x in body if x.startswith('v_')) / ntrip, len(body) / ntrip,
+                    sum(1 for x in body if x.startswith(QUARTER_RATE)) / ntrip,
+                    sum(1 for x in body if x.startswith('s_') and not x.startswith(('s_waitcnt', 's_nop'))) / ntrip))
+    return out
+
+
 def counts(lib_path=None):
     lib_path = lib_path or os.path.join(ROOT, 'dynetlsm_amd', 'libdynetlsm_hip.so')
     funcs = disassemble(lib_path)
     sweep = next(v for k, v in funcs.items() if re.match(r'_ZN4dlsm11k_pipe_stepILi2ELi0ELi1E', k))
     ll = next(v for k, v in funcs.items() if re.match(r'_ZN4dlsm19k_loglik_undirectedILi2ELi2E', k))
     s = _modal_run(_trips(sweep, 2), 8)
+    asweep = next(v for k, v in disassemble(lib_path, with_addresses=True).items()
+                  if re.match(r'_ZN4dlsm11k_pipe_stepILi2ELi0ELi1E', k))
+    rolled = _rolled_trip_loops(asweep)
+    if rolled:          # the no-flush variant is the shortest of the three (flush counter / squared distances)
+        r = min(rolled)
+        s = (r[0], 1, r[2])
+        salu_per_trip = r[3]
+    else:
+        salu_per_trip = None
     # the log-likelihood loops are rolled, one per variant (whole tile / ragged tile; the squared-
     # distance one has no root): a trip runs from the loop's head (behind the previous branch) to the
     # flush test behind its four roots (s_cmp_ge: the logarithms behind it run once per `nflush`
@@ -132,6 +176,8 @@ def counts(lib_path=None):
     out = {'library': os.path.relpath(lib_path, ROOT)}
     if s:
         out['k_pipe_step<2,0,1>'] = {'valu_per_trip_of_64_neighbours_2_positions': s[0],
+                                    'loop': 'rolled (kernels_pipe_lds.hpp)' if rolled else 'unrolled',
+                                    'salu_per_trip': salu_per_trip,
                                     'unrolled_trips_found': s[1], 'valu_per_term': round(s[0] / 2.0, 1),
                                     'quarter_rate_per_trip': s[2],
                                     'issue_slots_per_term': round(issue_slots(s[0], s[2]) / 2.0, 2)}
