@@ -41,20 +41,6 @@
 
 namespace dlsm {
 
-// 1: the lane's H entry at the head of the item (operands requested ahead of the neighbour rows);
-// 0: at its tail.  Measured in round 4 (profiles/r04_h_entry_ablation.md): the head form is no faster
-// (11.2 against 10.9 us per launch) and costs two spilled registers - the tail form stays.
-#ifndef DLSM_H_FIRST
-#define DLSM_H_FIRST 0
-#endif
-// > 0: the operands of the lane's H entry are requested that many trips before the last prefetched
-// trip of the item (into registers the finished trips have released); 0: behind the record's store.
-// Measured in round 4: wherever the request sits (1 or 3 trips early, with scheduling barriers around
-// it) the allocator answers with 20 spilled registers, three prefetched rows and a constant that every
-// trip reloads among them - the 11-trip prefetch already uses all 128 registers.  Off.
-#ifndef DLSM_H_MID
-#define DLSM_H_MID 0
-#endif
 // 1: the last wavefront of a SIMD hands its first-round H entries to the first one (pipe_item_finish).  Under
 // oldest-first issue this measured slower (10.77 against 10.54 us); with the items advancing together
 // (DLSM_TRIP_PRIO) the first wavefront of a SIMD still leaves ~1.8 us before the last one, whose entry is the
@@ -124,8 +110,7 @@ struct PipeBuf {
     const int32_t *nctrl;   // case-control: valid controls per (t, i, direction)
     int parts, per, nbat;
     int G, xr;       // batches per launch; rows of an Hx block = (2G - 1) PP_B
-    // persistent form (kernels_pipe_persist.hpp): nsync flag words, one per 64-byte line, zeroed
-    // by the propose kernel; word 0 (the ticket counter) starts at queue0
+    // (ProposeBuf's flag words of the persistent form removed in round 5: always null / 0 here)
     int32_t *sync; int nsync, queue0;
     LsmDeviceState *lsm_draw;   // not NULL: the proposal pass also draws the intercept proposal
     PipeLds lds;     // kernels_pipe_lds.hpp: the evaluators' arguments (filled by the host per launch)
@@ -335,7 +320,7 @@ __device__ __forceinline__ void pipe_reduce(double s, double a, double b, int la
 }
 
 // Operands of a lane's FIRST H entry (proposal / snapshot rows of the two nodes, the edge's bit,
-// the directed model's radii): static too - the persistent launch requests them early.
+// the directed model's radii).
 template <int D>
 struct PipeHPre {
     double xm0[D], xm1[D], xa0[D], xa1[D], rm, rkk;
@@ -355,15 +340,6 @@ __device__ __forceinline__ void pipe_h_operands(const ChainView &c, const double
         o.xa0[d] = rowk[D + 2 + d];
         o.xa1[d] = rowk[d];
     }
-#if defined(DLSM_X_H) && (DLSM_X_H == 4 || DLSM_X_H == 7)     // measurement only: no operand loads (arithmetic on constants of the lane)
-#pragma unroll
-    for (int d = 0; d < D; ++d) {
-        o.xm0[d] = 0.001 * (double)jm_; o.xm1[d] = 0.002 * (double)jm_ + d;
-        o.xa0[d] = 0.003 * (double)jkk; o.xa1[d] = 0.004 * (double)jkk + d;
-    }
-    o.yw = (uint32_t)jm_; o.yw2 = 0u; o.rm = 1.0; o.rkk = 1.0;
-    return;
-#endif
     const uint32_t woff = ((uint32_t)jkk * (uint32_t)c.W + ((uint32_t)jm_ >> 5)) * 4u;
     o.yw = *(const uint32_t *)(yrows + woff);
     o.yw2 = 0u; o.rm = 1.0; o.rkk = 1.0;
@@ -372,30 +348,9 @@ __device__ __forceinline__ void pipe_h_operands(const ChainView &c, const double
         o.rm = c.radii[jm_]; o.rkk = c.radii[jkk];
     }
 }
-// the lane's first entry of batch `be` (flat index hf0; false: the lane has none)
-template <int D, int MODEL, int G>
-__device__ __forceinline__ bool pipe_h_prefetch(const ChainView &c, const PipeBuf &pb, int be, int nb,
-                                                int t, int k, int p, int lane, PipeHPre<D> &o) {
-    constexpr int PW = 2 * D + 2;
-    const int N = c.N, W = c.W;
-    const int j0 = be * PP_B;
-    const int jprev = pipe_window_start(be, G) * PP_B;
-    const int ncross = j0 - jprev;
-    const PipeHList hl = pipe_h_list(ncross, nb);
-    const int hf0 = (k * pb.parts + p) * 64 + lane;
-    int kk, e;
-    const bool live = pipe_h_decode(min(hf0, max(hl.nslots - 1, 0)), hl, ncross, nb, kk, e);
-    e = min(e, max(ncross + kk - 1, 0));                    // (an idle slot: clamped, its entry is not stored)
-    const double *props = pb.prop + (size_t)t * N * PW;
-    const char *yrows = (const char *)(c.ybits + (size_t)t * N * W);
-    const char *ytrows = MODEL == DLSM_DIRECTED ? (const char *)(c.ytbits + (size_t)t * N * W) : nullptr;
-    pipe_h_operands<D, MODEL>(c, props, yrows, ytrows, jprev + e, j0 + kk, o);
-    return hf0 < hl.nslots && live && ncross + kk > 0;
-}
-
 // One H entry: flat index f of (slice t, batch be), operands o.  Rows of the H blocks are addressed as
 // 32-bit offsets from a scalar base.
-template <int D, int MODEL, int G, bool COH, bool SQ>
+template <int D, int MODEL, int G, bool SQ>
 __device__ __forceinline__ void pipe_h_entry(const ChainView &c, const PipeBuf &pb, int be, int nb, int t,
                                              const double *etab, int kk, int e, const PipeHPre<D> &o, bool stamp
 #ifdef DLSM_PIPE_TIMING
@@ -407,9 +362,9 @@ __device__ __forceinline__ void pipe_h_entry(const ChainView &c, const PipeBuf &
     const int ncross = j0 - jprev;
     const int bb = be & (2 * G - 1);
     const double E = pb.consts[0];
-    // one batch per launch (and the persistent launch): the blocks by ROWS of the later node (row_resolve);
-    // two batches per launch keep the [m][k] blocks of pipe_resolve
-    constexpr bool HROWS = COH || G == 1;
+    // one batch per launch: the blocks by ROWS of the later node (row_resolve); the [m][k] blocks of pipe_resolve
+    // are the dense case-control form's
+    constexpr bool HROWS = G == 1;
     char *hbase = (char *)(pb.Hd + ((size_t)bb * c.T + t) * PP_B * (HROWS ? 2 * PP_B : PP_B));
     const uint32_t hx_off = (uint32_t)((const char *)(pb.Hx + ((size_t)bb * c.T + t) * ((2 * G - 1) * PP_B) * PP_B) -
                                        (const char *)hbase);                          // one allocation
@@ -459,32 +414,19 @@ __device__ __forceinline__ void pipe_h_entry(const ChainView &c, const PipeBuf &
         // exp(delta(b) - delta(a)) without the logs: the products divide out
         h = ((rb.P0 * rq.P1) / (rb.P1 * rq.P0)) * exp((rb.lin - rq.lin) + (eb - eq));
     }
-#if defined(DLSM_X_H) && DLSM_X_H == 6     // measurement only: operands loaded, no arithmetic, the neutral factor stored
-    h = fma(0.0, (xm0[0] + xm1[0]) + (xa0[0] + xa1[0]) + (double)y1, 1.0);
-#endif
-#if defined(DLSM_X_H) && (DLSM_X_H == 7 || DLSM_X_H == 8)     // measurement only: full arithmetic, the neutral factor stored
-    h = h != 123.456 ? 1.0 : h;
-#endif
-#if defined(DLSM_X_H) && DLSM_X_H == 3     // measurement only: arithmetic, no store
-    if (h != 123.456) return;
-#endif
     if (HROWS)      // one row of 2 PP_B factors per later node kk - its window's nodes, then its own
                     // batch's - so that a wavefront's entries are contiguous
-        coh_store<COH>((double *)(hbase + (uint32_t)(kk * (2 * PP_B) + (cross ? e : PP_B + m)) * 8u), h);
+        coh_store<false>((double *)(hbase + (uint32_t)(kk * (2 * PP_B) + (cross ? e : PP_B + m)) * 8u), h);
     else
         coh_store<false>((double *)(hbase + ((cross ? hx_off : 0u) + (uint32_t)(m * PP_B + kk) * 8u)), h);
 }
 
 // The item's tail: wavefront reductions, the (sum, ratio) record, and this lane's share of the
-// batch's H entries.  Shared by the launch-per-batch item (neighbours prefetched from memory) and
-// the persistent launch's item (neighbours staged in LDS, kernels_pipe_persist.hpp).
-// HPF: `hpre` holds the operands of the lane's first H entry (by reference and under a template
-// flag: a pointer that may be null kept the structure in scratch memory)
-template <int D, int MODEL, int G, bool COH, bool HPF, bool HDONE = false>
+// batch's H entries.
+template <int D, int MODEL, int G>
 __device__ __forceinline__ void pipe_item_finish(const ChainView &c, const PipeBuf &pb, int be, int nb,
                                                  int t, int k, int p, int lane, const double *etab,
-                                                 double acc, RatioAcc &ra, bool noflush,
-                                                 const PipeHPre<D> &hpre
+                                                 double acc, RatioAcc &ra, bool noflush
 #ifdef DLSM_PIPE_TIMING
                                                  , unsigned long long *ts
 #endif
@@ -509,7 +451,7 @@ __device__ __forceinline__ void pipe_item_finish(const ChainView &c, const PipeB
     }
     if (lane == 0) {
         double2 *f = (double2 *)pb.full0 + (((size_t)bb * c.T + t) * PP_B + k) * pb.parts + p;
-        coh_store2<COH>(f, 0u, make_double2(tot_l, tot_r));
+        coh_store2<false>(f, 0u, make_double2(tot_l, tot_r));
     }
     DLSM_STAMP(3, tot_r)
     // this lane's H entries (pipe_h_decode).  Rows of `props` and the bits are addressed as
@@ -517,33 +459,17 @@ __device__ __forceinline__ void pipe_item_finish(const ChainView &c, const PipeB
     const char *yrows = (const char *)(c.ybits + (size_t)t * N * W);
     const char *ytrows = MODEL == DLSM_DIRECTED ? (const char *)(c.ytbits + (size_t)t * N * W) : nullptr;
     int f = hf0;
-#ifdef DLSM_X_NOH       // measurement only (wrong results): what the launches cost without any H entry
-    f = hl.nslots;
-#endif
 #define DLSM_H_CALL(SQ_, KK_, E_, O_, STAMP_)                                                         \
-    pipe_h_entry<D, MODEL, G, COH, SQ_>(c, pb, be, nb, t, etab, KK_, E_, O_, STAMP_ DLSM_H_TS)
+    pipe_h_entry<D, MODEL, G, SQ_>(c, pb, be, nb, t, etab, KK_, E_, O_, STAMP_ DLSM_H_TS)
 #ifdef DLSM_PIPE_TIMING
 #define DLSM_H_TS , ts
 #else
 #define DLSM_H_TS
 #endif
-    if (HDONE) {        // the lane's first entry was computed at the head of the item (pipe_eval_item)
-        f += hround;
-    } else if (HPF) {   // the first entry's operands were requested before the batch was released (its own
-                        // copy of the code: selecting between `hpre` and fresh loads inside ONE loop left
-                        // the structure in scratch memory)
-        if (f < hl.nslots) {
-            int kk, e;
-            if (pipe_h_decode(f, hl, ncross, nb, kk, e)) {
-                if (c.squared) DLSM_H_CALL(true, kk, e, hpre, true); else DLSM_H_CALL(false, kk, e, hpre, true);
-            }
-            f += hround;
-        }
-    }
     // HSHIFT (the launch-per-batch evaluators: a workgroup's 16 wavefronts hold items k0 .. k0 + 15 of one
     // part, wavefronts w, w + 4, w + 8, w + 12 share a SIMD): the LAST wavefront of a SIMD hands its
     // first-round entries to the FIRST one - the same arithmetic on the same SIMD, but no longer the launch's tail
-    constexpr bool HSHIFT = DLSM_H_SHIFT != 0 && !COH && !HPF && !HDONE;
+    constexpr bool HSHIFT = DLSM_H_SHIFT != 0;
     const int wig = (int)(threadIdx.x >> 6);
     bool first = true;
     if (HSHIFT && wig >= 12 && f < hround) f += hround;           // handed over (its later rounds stay)
@@ -552,8 +478,8 @@ __device__ __forceinline__ void pipe_item_finish(const ChainView &c, const PipeB
         if (pipe_h_decode(f, hl, ncross, nb, kk, e)) {
             PipeHPre<D> o;
             pipe_h_operands<D, MODEL>(c, props, yrows, ytrows, jprev + e, j0 + kk, o);
-            if (c.squared) DLSM_H_CALL(true, kk, e, o, !HPF && !HDONE && f == hf0);
-            else DLSM_H_CALL(false, kk, e, o, !HPF && !HDONE && f == hf0);
+            if (c.squared) DLSM_H_CALL(true, kk, e, o, f == hf0);
+            else DLSM_H_CALL(false, kk, e, o, f == hf0);
         }
         if (HSHIFT && first && wig < 4 && k + 12 < nb) {
             // ... and the first-round entries of item k + 12 (same part, same slice: the SIMD's last wavefront)
@@ -572,8 +498,7 @@ __device__ __forceinline__ void pipe_item_finish(const ChainView &c, const PipeB
 }
 
 // What an item reads about its OWN node before the first neighbour: static for the whole sweep
-// (proposal and snapshot from the propose kernel, the node's row of the network), so the
-// persistent launch requests it while it still waits for the batch it depends on.
+// (proposal and snapshot from the propose kernel, the node's row of the network).
 template <int D>
 struct PipeItemPre {
     double xk0[D], xk1[D], E, bin, bout, irk;
@@ -617,22 +542,15 @@ __host__ __device__ constexpr int pipe_prefetch_trips(int D) {
     return D == 1 ? 16 : D == 2 ? 11 : D == 3 ? 6 : D == 4 ? 4 : D <= 6 ? 3 : 2;
 }
 
-// One wavefront: part p of node k of batch `be` in slice t.  TP: the trips beyond the
-// prefetched ones are software-pipelined (directed model; undirected parts longer than the
-// prefetch, where it is worth +3 % - at C2, where everything is prefetched, it costs 1 %).
-// COH: the item runs inside the persistent launch (kernels_pipe_persist.hpp): final positions come
-// from resolver workgroups of the same launch and its records go to them - sc1 accesses.
-// LDSX: the part's neighbour rows were staged in LDS by the workgroup (sX[row - lo][D]): the
-// "prefetch" is LDS reads and the trips beyond it read LDS as they go.
-// HFIRST (with HPF): the lane's first H entry is computed at the HEAD of the item - its operands were
-// requested before the neighbours', so they arrive first and the entry's arithmetic runs under the
-// neighbour rows' flight instead of behind a round trip of its own at the item's tail
-template <int D, int MODEL, bool TP, int G, bool COH = false, bool LDSX = false, bool HPF = false,
-          bool HFIRST = false>
+// One wavefront: part p of node k of batch `be` in slice t - the evaluator of the directed model and of the
+// undirected model where kernels_pipe_lds.hpp's does not apply (PIPE_UNDIRECTED_LONG).  TP: the trips beyond the
+// prefetched ones are software-pipelined.  (Round 6 removed the forms measured and dropped in rounds 3 - 5: rows
+// staged in LDS by a persistent launch, the lane's H entry at the head of the item or requested mid-way, and
+// their measurement switches - profiles/r04_h_entry_ablation.md holds their numbers.)
+template <int D, int MODEL, bool TP, int G>
 __device__ __forceinline__ void pipe_eval_item(const ChainView &c, const PipeBuf &pb, int be,
                                                int nb, int t, int k, int p, int lane,
-                                               const double *etab, const double *sX,
-                                               const PipeItemPre<D> &pre, const PipeHPre<D> &hpre
+                                               const double *etab, const PipeItemPre<D> &pre
 #ifdef DLSM_PIPE_TIMING
                                                , int tl, int tgw
 #endif
@@ -682,11 +600,9 @@ __device__ __forceinline__ void pipe_eval_item(const ChainView &c, const PipeBuf
 #pragma unroll
     for (int u = 0; u < PP_NPRE; ++u) {
         const int ic = min(lo + lane + 64 * u, N - 1);
-        if (!LDSX) {            // (LDSX: the trip reads its row where it uses it - LDS is near)
-            uint32_t off;
-            const char *base = x_source(lo + 64 * u, ic, off);
-            coh_load_row<D, COH>(base, off, xpre[u]);
-        }
+        uint32_t off;
+        const char *base = x_source(lo + 64 * u, ic, off);
+        coh_load_row<D, false>(base, off, xpre[u]);
         if (MODEL == DLSM_DIRECTED) rpre[u] = c.radii[ic];
     }
     // H entries of the batch: (node kk, entry e), e < ncross + kk: the previous batch (cross
@@ -695,33 +611,7 @@ __device__ __forceinline__ void pipe_eval_item(const ChainView &c, const PipeBuf
     // entry counts differ by 2x - through the flat list of pipe_h_decode; one entry per lane when
     // there are >= 3 parts.  Their operands are loaded where they are used, after the neighbour
     // loop: the registers a prefetch would hold are worth more as prefetched neighbours
-    // (measured: +6 % at C2; computing the entry at the head of the item instead, DLSM_H_FIRST,
-    // measured no better in round 4).
-    if (HFIRST && HPF) {
-#ifndef DLSM_X_NOH
-        const PipeHList hl = pipe_h_list(ncross, nb);
-        const int hf0 = (k * pb.parts + p) * 64 + lane;
-        int kk, e;
-        if (hf0 < hl.nslots && pipe_h_decode(hf0, hl, ncross, nb, kk, e)) {
-            if (c.squared)
-                pipe_h_entry<D, MODEL, G, COH, true>(c, pb, be, nb, t, etab, kk, e, hpre, true
-#ifdef DLSM_PIPE_TIMING
-                                                     , ts
-#endif
-                                                     );
-            else
-                pipe_h_entry<D, MODEL, G, COH, false>(c, pb, be, nb, t, etab, kk, e, hpre, true
-#ifdef DLSM_PIPE_TIMING
-                                                      , ts
-#endif
-                                                      );
-        }
-#endif
-    }
-
-    // HMID: request the first H entry's operands DLSM_H_MID trips before the last prefetched one
-    constexpr bool HMID = DLSM_H_MID > 0 && !COH && !LDSX && !HPF && PP_NPRE >= DLSM_H_MID + 3;
-    PipeHPre<D> hmid;
+    // (measured: +6 % at C2).
     double acc = 0.0;
     RatioAcc ra;
 #define DLSM_PIPE_TERM(XI_, YB_, YCB_, RI_, FLUSH_, SQ_)                                      \
@@ -770,7 +660,7 @@ __device__ __forceinline__ void pipe_eval_item(const ChainView &c, const PipeBuf
         const int in_ = min(lo + 64 * (U_) + lane, N - 1);                                    \
         uint32_t off_;                                                                        \
         const char *base_src_ = x_source(lo + 64 * (U_), in_, off_);                          \
-        coh_load_row<D, COH>(base_src_, off_, xn);                                            \
+        coh_load_row<D, false>(base_src_, off_, xn);                                            \
         if (MODEL == DLSM_DIRECTED) rn = c.radii[in_];                                        \
     }
 #define DLSM_PIPE_LOOPS(FLUSH_, SQ_)                                                          \
@@ -778,22 +668,10 @@ __device__ __forceinline__ void pipe_eval_item(const ChainView &c, const PipeBuf
     for (int u = 0; u < PP_NPRE; ++u) {                                                       \
         DLSM_TRIP_PRIO_STEP(u)                                                                \
         DLSM_PIPE_MASKS(u)                                                                    \
-        if (LDSX) {     /* rows are staged up to the part's end; a clamped lane is masked */  \
-            const double *row_ = sX + (size_t)min(64 * u + lane, pb.per - 1) * D;             \
-            _Pragma("unroll")                                                                 \
-            for (int d = 0; d < D; ++d) xpre[u][d] = row_[d];                                 \
-        }                                                                                     \
         if (__builtin_amdgcn_inverse_ballot_w64(vm_))                                         \
             DLSM_PIPE_TERM(xpre[u], yb_, ycb_, rpre[MODEL == DLSM_DIRECTED ? u : 0], FLUSH_, SQ_) \
         if (u == 0) { DLSM_STAMP(1, ra.P0) }                                                  \
         if (u == PP_NPRE - 1) { DLSM_STAMP(2, ra.P0) }                                        \
-        if (HMID && u == PP_NPRE - 1 - DLSM_H_MID) {                                          \
-            /* the lane's H entry: operands requested HERE, into the registers the trips     \
-               behind us have released, so that they are at hand when the record is stored */ \
-            __builtin_amdgcn_sched_barrier(0);   /* not hoisted among the prologue's loads */ \
-            pipe_h_prefetch<D, MODEL, G>(c, pb, be, nb, t, k, p, lane, hmid);                 \
-            __builtin_amdgcn_sched_barrier(0);                                                \
-        }                                                                                     \
     }                                                                                         \
     /* the trips beyond the prefetched ones.  TP: each trip requests the next one's operands   \
        (clamped address, no predication) before it computes. */                               \
@@ -811,15 +689,9 @@ __device__ __forceinline__ void pipe_eval_item(const ChainView &c, const PipeBuf
         DLSM_PIPE_MASKS(u)                                                                    \
         if (__builtin_amdgcn_inverse_ballot_w64(vm_)) {                                       \
             if (!TP) {                                                                        \
-                if (LDSX) {                                                                   \
-                    const double *row_ = sX + (size_t)(64 * u + lane) * D;                    \
-                    _Pragma("unroll")                                                         \
-                    for (int d = 0; d < D; ++d) xi[d] = row_[d];                              \
-                } else {                                                                      \
-                    uint32_t off_;                                                            \
-                    const char *base_src_ = x_source(base_, i_, off_);                        \
-                    coh_load_row<D, COH>(base_src_, off_, xi);                                \
-                }                                                                             \
+                uint32_t off_;                                                                \
+                const char *base_src_ = x_source(base_, i_, off_);                            \
+                coh_load_row<D, false>(base_src_, off_, xi);                                    \
                 if (MODEL == DLSM_DIRECTED) ri = c.radii[min(i_, N - 1)];                     \
             }                                                                                 \
             DLSM_PIPE_TERM(xi, yb_, ycb_, ri, FLUSH_, SQ_)                                    \
@@ -832,8 +704,7 @@ __device__ __forceinline__ void pipe_eval_item(const ChainView &c, const PipeBuf
 #undef DLSM_PIPE_REQUEST
 #undef DLSM_PIPE_MASKS
 #undef DLSM_PIPE_TERM
-    pipe_item_finish<D, MODEL, G, COH, HPF || HMID, HFIRST && HPF>(c, pb, be, nb, t, k, p, lane, etab, acc, ra, noflush,
-                                                                   HMID ? hmid : hpre
+    pipe_item_finish<D, MODEL, G>(c, pb, be, nb, t, k, p, lane, etab, acc, ra, noflush
 #ifdef DLSM_PIPE_TIMING
                                        , ts
 #endif
@@ -951,10 +822,7 @@ __device__ __forceinline__ void pipe_cc_writeout(const ChainView &c, const PipeB
 // acceptances of its window's earlier batches (pipe_window_start) entering through gathered rows
 // of the cross block.  With G > 1 a workgroup resolves G batches one after the other; the list
 // of the batch it has just resolved is in sOwn (own_prev), the others come from memory.
-// COH: inside the persistent launch - evaluator records and the neighbouring slices' positions
-// are read past the L1, the positions are stored write-through, the previous batch's list lives
-// in LDS only (own_prev).
-template <int D, int G, bool COH = false>
+template <int D, int G>
 __device__ __forceinline__ void pipe_resolve(const ChainView &c, const PipeBuf &pb, int b, int t,
                                              double *sH, double *sPart,
                                              unsigned long long (*sMask)[2], int *sPrev,
@@ -989,21 +857,21 @@ __device__ __forceinline__ void pipe_resolve(const ChainView &c, const PipeBuf &
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
         const int q = min(u * PP_THREADS + tid, nb * (PP_B / 2) - 1);
-        blk[u] = coh_load2<COH>(Hd, (uint32_t)(((q >> 6) * PP_B + 2 * (q & 63)) * sizeof(double)));
+        blk[u] = coh_load2<false>(Hd, (uint32_t)(((q >> 6) * PP_B + 2 * (q & 63)) * sizeof(double)));
     }
     // their accepted nodes as rows of the cross block: row = 128 (batch - ws) + node
     int cntw[3] = {0, 0, 0};
 #pragma unroll
     for (int w = 0; w < G2 - 1; ++w)
         if (w < nwin) {
-            const bool own = COH || (own_prev && ws + w == b - 1);
+            const bool own = own_prev && ws + w == b - 1;
             cntw[w] = own ? sOwn[0] : acct[(size_t)((ws + w) & (G2 - 1)) * PP_ACC];
         }
     const int nprev = cntw[0] + cntw[1] + cntw[2];
 #pragma unroll
     for (int w = 0; w < G2 - 1; ++w)
         if (w < nwin) {
-            const bool own = COH || (own_prev && ws + w == b - 1);
+            const bool own = own_prev && ws + w == b - 1;
             const int32_t *lst = own ? sOwn : acct + (size_t)((ws + w) & (G2 - 1)) * PP_ACC;
             const int off = w == 0 ? 0 : (w == 1 ? cntw[0] : cntw[0] + cntw[1]);
             for (int a = tid; a < cntw[w]; a += PP_THREADS) sPrev[off + a] = w * PP_B + lst[1 + a];
@@ -1024,7 +892,7 @@ __device__ __forceinline__ void pipe_resolve(const ChainView &c, const PipeBuf &
         double2 tv[PP_MAXPARTS];
 #pragma unroll
         for (int u = 0; u < PP_MAXPARTS; ++u)
-            tv[u] = coh_load2<COH>(f, (uint32_t)((kc * p1 + min(u, p1 - 1)) * sizeof(double2)));
+            tv[u] = coh_load2<false>(f, (uint32_t)((kc * p1 + min(u, p1 - 1)) * sizeof(double2)));
         double tot = tv[0].x, pr_ = tv[0].y;
 #pragma unroll
         for (int u = 1; u < PP_MAXPARTS; ++u) {
@@ -1037,8 +905,8 @@ __device__ __forceinline__ void pipe_resolve(const ChainView &c, const PipeBuf &
         for (int d = 0; d < D; ++d) { x1[d] = pr[d]; x0[d] = pr[D + 2 + d]; }
         // prior terms of the step's logp closure, with the neighbouring slices as they
         // are now (see the header: the odd slices run one batch behind)
-        const double prior = node_log_prior<D, COH>(c, t, j0 + kc, x1) -
-                             node_log_prior<D, COH>(c, t, j0 + kc, x0);
+        const double prior = node_log_prior<D, false>(c, t, j0 + kc, x1) -
+                             node_log_prior<D, false>(c, t, j0 + kc, x0);
         const double ek = tot + prior;
         sat = !(fabs(ek) <= 700.0);
         r = sat ? 1.0 : exp(ek) * pr_;
@@ -1067,14 +935,14 @@ __device__ __forceinline__ void pipe_resolve(const ChainView &c, const PipeBuf &
                 double hh[PP_B / 8];
 #pragma unroll
                 for (int u = 0; u < PP_B / 8; ++u)
-                    hh[u] = coh_load<COH>(colp + (size_t)sPrev[min(base + a + 8 * u, nprev - 1)] * PP_B);
+                    hh[u] = coh_load<false>(colp + (size_t)sPrev[min(base + a + 8 * u, nprev - 1)] * PP_B);
 #pragma unroll
                 for (int u = 0; u < PP_B / 8; ++u) prod *= base + a + 8 * u < nprev ? hh[u] : 1.0;
             }
         } else {
             double lsum = 0.0;
             for (; a < nprev; a += 8) {
-                const double h = coh_load<COH>(colp + (size_t)sPrev[a] * PP_B);
+                const double h = coh_load<false>(colp + (size_t)sPrev[a] * PP_B);
                 if (satk) lsum += log(h); else prod *= h;
             }
             if (satk) prod = lsum;
@@ -1151,7 +1019,7 @@ __device__ __forceinline__ void pipe_resolve(const ChainView &c, const PipeBuf &
             const size_t tj = (size_t)t * N + j0 + k;
             if (accepted) {
 #pragma unroll
-                for (int d = 0; d < D; ++d) coh_store<COH>(&c.X[tj * D + d], x1[d]);
+                for (int d = 0; d < D; ++d) coh_store<false>(&c.X[tj * D + d], x1[d]);
             }
             metropolis_bookkeeping(st, na, ns, un, c.tune, c.tune_interval, accepted);
             c.step[tj] = st; c.nacc[tj] = na; c.nsteps[tj] = ns; c.until[tj] = un;
@@ -1161,12 +1029,12 @@ __device__ __forceinline__ void pipe_resolve(const ChainView &c, const PipeBuf &
         if (accepted) {
             const int base = half == 0 ? 0 : __popcll(m0);
             const int at = 1 + base + __popcll(mine & ((1ull << lane) - 1ull));
-            if (!COH) accg[at] = k;
+            accg[at] = k;
             sOwn[at] = k;
         }
         if (tid == 0) {
             const int cnt = __popcll(m0) + __popcll(m1);
-            if (!COH) accg[0] = cnt;
+            accg[0] = cnt;
             sOwn[0] = cnt;
         }
     }
@@ -1177,8 +1045,7 @@ __device__ __forceinline__ void pipe_resolve(const ChainView &c, const PipeBuf &
 #endif
 }
 
-// ---- the resolver for H blocks stored BY ROWS (round 3: the persistent launch; round 4: every launch-per-batch
-// kernel with one batch per launch) --------------------------------------------------------------------------
+// ---- the resolver for H blocks stored BY ROWS (every launch of the exact-likelihood models) ----------------------
 // The evaluators file the factors of later node kk as ONE row [window (PP_B) | own batch (PP_B)]: a wavefront's
 // 64 entries - consecutive entries of one row in the flat list of pipe_h_decode - are 512 contiguous bytes
 // instead of 64 stores a kilobyte apart (the [m][k] blocks: 2.15 MB written and 7.9 MB fetched per launch, each
@@ -1200,11 +1067,11 @@ __device__ __forceinline__ double group8_sum(double v) {
     return v;
 }
 
-template <int D, bool COH>
+template <int D>
 __device__ __forceinline__ void row_resolve(const ChainView &c, const PipeBuf &pb, int b, int t,
                                                 double *sD, double *sPart,
                                                 unsigned long long (*sMask)[2],
-                                                unsigned long long *sMaskPrev, double *sCross,
+                                                double *sCross,
                                                 unsigned long long *sSatMask, double *sTab, bool served
 #ifdef DLSM_PIPE_TIMING
                                                 , int tl
@@ -1239,7 +1106,7 @@ __device__ __forceinline__ void row_resolve(const ChainView &c, const PipeBuf &p
 #if defined(DLSM_X_RES) && (DLSM_X_RES & 1)      // measurement only: no cross block
             const double2 v = make_double2(1.0, 1.0);
 #else
-            const double2 v = coh_load2<COH>(H, cr_off, (uint32_t)(16 * u * sizeof(double)));
+            const double2 v = coh_load2<false>(H, cr_off, (uint32_t)(16 * u * sizeof(double)));
 #endif
             cr[2 * u] = v.x; cr[2 * u + 1] = v.y;
         }
@@ -1258,7 +1125,7 @@ __device__ __forceinline__ void row_resolve(const ChainView &c, const PipeBuf &p
 #if defined(DLSM_X_RES) && (DLSM_X_RES & 2)      // measurement only: no diagonal block
         blk[u] = make_double2(1.0, 1.0);
 #else
-        blk[u] = coh_load2<COH>(H, blk_off, (uint32_t)(u * PP_WAVES * (2 * PP_B) * sizeof(double)));
+        blk[u] = coh_load2<false>(H, blk_off, (uint32_t)(u * PP_WAVES * (2 * PP_B) * sizeof(double)));
 #endif
     // the owners' inputs (requested now, used once the blocks above have left their registers)
     double2 tv[4];
@@ -1275,14 +1142,14 @@ __device__ __forceinline__ void row_resolve(const ChainView &c, const PipeBuf &p
     auto owner_loads = [&]() {
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-            tv[u] = coh_load2<COH>(frec, (uint32_t)((kc * p1 + min(u, p1 - 1)) * sizeof(double2)));
+            tv[u] = coh_load2<false>(frec, (uint32_t)((kc * p1 + min(u, p1 - 1)) * sizeof(double2)));
         const double *pr = pb.prop + ((size_t)t * N + j0 + kc) * PW;
 #pragma unroll
         for (int d = 0; d < D; ++d) { x1[d] = pr[d]; x0[d] = pr[D + 2 + d]; }
         uk = pr[D];
         const size_t tjc = (size_t)t * N + j0 + kc;
         st = c.step[tjc]; na = c.nacc[tjc]; ns = c.nsteps[tjc]; un = c.until[tjc];
-        if (!COH) npre.request1(c, t, j0 + kc);        // the prior terms' operands, with everything else
+        npre.request1(c, t, j0 + kc);        // the prior terms' operands, with everything else
     };
     if (owner) owner_loads();
     // the owners' exponential table (tab_exp), requested with everything else: it is read behind the barrier
@@ -1299,24 +1166,23 @@ __device__ __forceinline__ void row_resolve(const ChainView &c, const PipeBuf &p
         __builtin_amdgcn_sched_barrier(0);              // (not hoisted among the loads above)
 #pragma unroll
         for (int u = 0; u < 8 - BLK_H; ++u)
-            blk[u] = coh_load2<COH>(H, blk_off, (uint32_t)((BLK_H + u) * PP_WAVES * (2 * PP_B) * sizeof(double)));
+            blk[u] = coh_load2<false>(H, blk_off, (uint32_t)((BLK_H + u) * PP_WAVES * (2 * PP_B) * sizeof(double)));
 #pragma unroll
         for (int u = 0; u < 8 - BLK_H; ++u) {
             double *dst = sD + ((BLK_H + u) * PP_WAVES + wave) * PR_LD + 2 * lane;
             dst[0] = blk[u].x; dst[1] = blk[u].y;
         }
     }
-    if (owner && !COH) npre.request2(c);               // (the labels are in: the components' means and variances)
+    if (owner) npre.request2(c);               // (the labels are in: the components' means and variances)
     // the window's accepted nodes among this thread's 16 factors: cr[2 u + i] belongs to node
     // 16 u + 2 jx + i -> bit 2 u + i of mp.  Multiplicative domain; a node that turns out to be
     // resolved in the log domain (below) redoes its part from memory.
     unsigned int mp = 0u;
     if (b > 0) {
-        // the previous batch's acceptances: in LDS inside the persistent launch (this workgroup resolved
-        // that batch), in memory for the launch-per-batch kernels (the launch before left them)
+        // the previous batch's acceptances (the launch before left them)
         const unsigned long long *pmg = (const unsigned long long *)(pb.acc + ((size_t)t * 2 + ((b - 1) & 1)) * PP_ACC +
                                                                      PP_ACC_MASK);
-        const unsigned long long pm0 = COH ? sMaskPrev[0] : pmg[0], pm1 = COH ? sMaskPrev[1] : pmg[1];
+        const unsigned long long pm0 = pmg[0], pm1 = pmg[1];
         const unsigned long long mlo = pm0 >> (2 * jx), mhi = pm1 >> (2 * jx);
 #pragma unroll
         for (int u = 0; u < 8; ++u)
@@ -1340,14 +1206,12 @@ __device__ __forceinline__ void row_resolve(const ChainView &c, const PipeBuf &p
         for (int u = 1; u < 4; ++u)
             if (u < p1) { tot += tv[u].x; pr_ *= tv[u].y; }
         for (int u = 4; u < p1; ++u) {                 // more than four parts (short slices, many CUs)
-            const double2 w = coh_load2<COH>(frec, (uint32_t)((kc * p1 + u) * sizeof(double2)));
+            const double2 w = coh_load2<false>(frec, (uint32_t)((kc * p1 + u) * sizeof(double2)));
             tot += w.x; pr_ *= w.y;
         }
         // prior terms of the step's logp closure, the neighbouring slices as they are now (the
         // odd slices wait for the even ones: header)
-        const double prior = COH ? node_log_prior<D, COH>(c, t, j0 + kc, x1) -
-                                   node_log_prior<D, COH>(c, t, j0 + kc, x0)
-                                 : npre.value(x1) - npre.value(x0);
+        const double prior = npre.value(x1) - npre.value(x0);
         const double ek = tot + prior;
         sat = !(fabs(ek) <= 700.0);
         // (r = exp(ek) pr_ behind the barrier: the table is in LDS by then)
@@ -1374,7 +1238,7 @@ __device__ __forceinline__ void row_resolve(const ChainView &c, const PipeBuf &p
             double lsum = 0.0;
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const double2 v = coh_load2<COH>(H, cr_off, (uint32_t)(16 * u * sizeof(double)));
+                const double2 v = coh_load2<false>(H, cr_off, (uint32_t)(16 * u * sizeof(double)));
                 if (satx && ((mp >> (2 * u)) & 1u)) lsum += log(v.x);
                 if (satx && ((mp >> (2 * u + 1)) & 1u)) lsum += log(v.y);
             }
@@ -1470,18 +1334,15 @@ __device__ __forceinline__ void row_resolve(const ChainView &c, const PipeBuf &p
             const size_t tj = (size_t)t * N + j0 + k;
             if (accepted) {
 #pragma unroll
-                for (int d = 0; d < D; ++d) coh_store<COH>(&c.X[tj * D + d], x1[d]);
+                for (int d = 0; d < D; ++d) coh_store<false>(&c.X[tj * D + d], x1[d]);
             }
             metropolis_bookkeeping(st, na, ns, un, c.tune, c.tune_interval, accepted);
             c.step[tj] = st; c.nacc[tj] = na; c.nsteps[tj] = ns; c.until[tj] = un;
         }
         // the next batch's window: this batch's acceptances, as a mask
         if (tid == 0) {
-            if (COH) { sMaskPrev[0] = m0; sMaskPrev[1] = m1; }
-            else {
-                unsigned long long *pmw = (unsigned long long *)(pb.acc + ((size_t)t * 2 + (b & 1)) * PP_ACC + PP_ACC_MASK);
-                pmw[0] = m0; pmw[1] = m1;
-            }
+            unsigned long long *pmw = (unsigned long long *)(pb.acc + ((size_t)t * 2 + (b & 1)) * PP_ACC + PP_ACC_MASK);
+            pmw[0] = m0; pmw[1] = m1;
         }
     }
 #ifdef DLSM_PIPE_TIMING
@@ -1540,7 +1401,7 @@ __global__ __launch_bounds__(PP_THREADS) void k_pipe_step(ChainView c, PipeBuf p
             if (l == -1 && threadIdx.x < PP_B)                            // the sweep's first launch: every slot empty
                 pb.xprod[(size_t)t * PP_B + threadIdx.x] = __longlong_as_double((long long)PP_XP_EMPTY);
             if (b < 0 || b >= pb.nbat) return;
-            row_resolve<D, false>(c, pb, b, t, pp_sH, sPart, sMask, nullptr, sCross, sSatMask, sTab, served
+            row_resolve<D>(c, pb, b, t, pp_sH, sPart, sMask, sCross, sSatMask, sTab, served
 #ifdef DLSM_PIPE_TIMING
                                   , l + 1
 #endif
@@ -1629,16 +1490,8 @@ __global__ __launch_bounds__(PP_THREADS) void k_pipe_step(ChainView c, PipeBuf p
         const int t = odd ? 2 * (si - nslE) + 1 : 2 * si;
         constexpr int IM = MODEL == DLSM_DIRECTED_CASE_CONTROL ? DLSM_DIRECTED : MODEL;
         PipeItemPre<D> pre;
-        PipeHPre<D> hp;
         pipe_item_prologue<D, IM>(c, pb, be, t, k, p, lane, pre);
-        // the lane's H entry: operands requested here, ahead of the neighbour rows, and the entry
-        // computed at the head of the item (round 4: at the item's tail its loads were a round trip of
-        // their own that every wavefront of the SIMD sat out - 2.5 of a launch's 10.9 us went to H)
-#if DLSM_H_FIRST
-        pipe_h_prefetch<D, IM, G>(c, pb, be, nb, t, k, p, lane, hp);
-#endif
-        pipe_eval_item<D, IM, TP, G, false, false, DLSM_H_FIRST != 0, DLSM_H_FIRST != 0>(
-            c, pb, be, nb, t, k, p, lane, pp_sH, nullptr, pre, hp
+        pipe_eval_item<D, IM, TP, G>(c, pb, be, nb, t, k, p, lane, pp_sH, pre
 #ifdef DLSM_PIPE_TIMING
             , l + 1, gw
 #endif
@@ -1680,7 +1533,7 @@ __device__ __forceinline__ void pipe_last_ride_wg(const ChainView &c, const Pipe
             __shared__ double sCross[PP_B];
             __shared__ unsigned long long sSatMask[2];
             __shared__ double sTab[EXPTAB_N];
-            row_resolve<D, false>(c, pb, b, t, pp_sH, sPart, sMask, nullptr, sCross, sSatMask, sTab, false
+            row_resolve<D>(c, pb, b, t, pp_sH, sPart, sMask, sCross, sSatMask, sTab, false
 #ifdef DLSM_PIPE_TIMING
                                   , l + 1
 #endif
