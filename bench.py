@@ -102,7 +102,10 @@ def parse(argv=None):
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=20)
-    ap.add_argument('--model', default='all', choices=['lsm', 'hdp', 'cc', 'all'])
+    ap.add_argument('--model', default='all', choices=['lsm', 'hdp', 'cc', 'ccu', 'all'],
+                    help="cc: config 4 on a network drawn FROM the model (the quoted figure); ccu: on the "
+                         "degree-regular network of rounds 1-5 (every node draws 20 out-neighbours uniformly: "
+                         "the labelled easy case); all: lsm, hdp, cc, ccu, monks and lsm at 4 chains per GPU")
     ap.add_argument('--T', type=int, default=10)
     ap.add_argument('--N', type=int, default=2000)
     ap.add_argument('--D', type=int, default=2)
@@ -693,22 +696,38 @@ class CcWorkload(object):
     n_resample_control = 100 iterations (case_control_likelihood.py:27-33).  The network is
     given as edge tables (the dense tensor would be 4 GB)."""
     name = 'cc'
+    network = 'model'
 
     def __init__(self, args, group, local_rank):
         from dynetlsm_amd import Chain, SamplerGrid
-        from dynetlsm_amd.synthetic import synthetic_sparse_directed
+        from dynetlsm_amd.synthetic import synthetic_sparse_directed, synthetic_directed_from_model
         self.args, self.group = args, group
         T, N, C = args.cc_T, args.cc_N, args.cc_controls
         self.T, self.N, self.C = T, N, C
         rank = group.rank
         K, W, P = args.steps, args.warmup, args.profile_steps
+        # starting state and samplers: the degree-regular network as in rounds 1-5; the model-drawn one as in
+        # tests/test_gpu_c4_full_size.py (generating intercepts, priors and step sizes at the scale of the cloud)
+        self.b0, self.tau_sq, self.sigma_sq, self.step_x, self.step_b = [1.0, 0.5], 1e-4, 1e-5, 0.002, 0.1
         if rank == 0:
-            X, radii, degree, in_edges, out_edges = synthetic_sparse_directed(T, N, 20, 0)
-            shp = np.array([in_edges.shape[2], out_edges.shape[2]], dtype=np.float64)
+            if self.network == 'model':
+                net = synthetic_directed_from_model(T, N, 20.0, seed=0)
+                X, radii, degree, in_edges, out_edges = (net['X'], net['radii'], net['degree'], net['in_edges'],
+                                                          net['out_edges'])
+                w = float(net['width'])
+                par = np.array([net['intercepts'][0], net['intercepts'][1], w * w, (0.1 * w) ** 2, 0.02 * w, 0.01])
+            else:
+                X, radii, degree, in_edges, out_edges = synthetic_sparse_directed(T, N, 20, 0)
+                par = np.array(self.b0 + [self.tau_sq, self.sigma_sq, self.step_x, self.step_b])
+            shp = np.array([in_edges.shape[2], out_edges.shape[2]] + list(par), dtype=np.float64)
         else:
-            shp = np.zeros(2)
+            shp = np.zeros(8)
         shp = group.broadcast_array(shp)
         Din, Dout = int(shp[0]), int(shp[1])
+        self.b0 = [float(shp[2]), float(shp[3])]
+        self.tau_sq, self.sigma_sq, self.step_x, self.step_b = (float(v) for v in shp[4:8])
+        if os.environ.get('DLSM_BENCH_CC_STEP_SCALE'):      # (experiments: the positions' step size, hence the acceptance rate)
+            self.step_x *= float(os.environ['DLSM_BENCH_CC_STEP_SCALE'])
         if rank != 0:
             X, radii = np.zeros((T, N, 2)), np.zeros(N)
             degree = np.zeros((T, N, 2)); in_edges = np.zeros((T, N, Din))
@@ -720,6 +739,12 @@ class CcWorkload(object):
         self.density = float(degree[:, :, 1].mean() / (N - 1))
         self.mean_terms = float(degree.sum(axis=2).mean() + 2 * C)
         self.mean_out = float(degree[:, :, 1].mean())
+        # how uneven the nodes' term rows are (the uniform network: out-degree 20 +- 0, in-degree Poisson(20))
+        tot = degree.sum(axis=2)
+        self.degree_stats = {'out_max': int(degree[:, :, 1].max()), 'out_p99': float(np.percentile(degree[:, :, 1], 99)),
+                             'in_max': int(degree[:, :, 0].max()), 'in_p99': float(np.percentile(degree[:, :, 0], 99)),
+                             'terms_per_node_mean': float(tot.mean() + 2 * C),
+                             'terms_per_node_max': int(tot.max() + 2 * C)}
         self.tables = (X, radii, degree, in_edges, out_edges) if rank == 0 else None
         self.chains = []
         for c in range(args.chains_per_gpu):
@@ -729,10 +754,10 @@ class CcWorkload(object):
             ch.resample_controls(0, C)
             if rank == 0 and c == 0:        # the controls the first 99 iterations use (CPU leg)
                 self.controls0 = ch.get_controls()
-            ch.set_positions(X); ch.set_radii(radii); ch.set_intercepts([1.0, 0.5])
-            ch.set_prior_random_walk(1e-4, 1e-5)
-            ch.set_samplers(SamplerGrid(T, N, step_size=0.002, tune=None))
-            ch.lsm_configure([1.0, 0.5], 2.0, step_size_intercept=0.1, tune=None,
+            ch.set_positions(X); ch.set_radii(radii); ch.set_intercepts(self.b0)
+            ch.set_prior_random_walk(self.tau_sq, self.sigma_sq)
+            ch.set_samplers(SamplerGrid(T, N, step_size=self.step_x, tune=None))
+            ch.lsm_configure(self.b0, 2.0, step_size_intercept=self.step_b, tune=None,
                              n_iter_procrustes=0, sweep_algo=args.algo, step_size_radii=175000.,
                              radii_tune=None)
             ch.trace_alloc(1 + W + K * max(args.windows, 1) + P + args.settle_steps, logp0=0.0)
@@ -760,13 +785,17 @@ class CcWorkload(object):
             ch.synchronize()
 
     def workload(self):
-        return ('DynamicNetworkLSM directed case-control T=%d N=%d d=2, n_control=%d, mean degree '
-                '%.1f, %d chain%s per GPU' % (self.T, self.N, self.C, self.density * (self.N - 1),
+        return ('DynamicNetworkLSM directed case-control T=%d N=%d d=2, n_control=%d, network %s, mean degree '
+                '%.1f, %d chain%s per GPU' % (self.T, self.N, self.C,
+                                              'drawn from the model (synthetic_directed_from_model)'
+                                              if self.network == 'model' else
+                                              'degree-regular (20 uniform out-neighbours per node: the easy case)',
+                                              self.density * (self.N - 1),
                                               len(self.chains), '' if len(self.chains) == 1 else 's'))
 
     def metric(self):
-        return ('Gibbs iterations/sec, directed case-control T=%d N=%d d=2 n_control=%d'
-                % (self.T, self.N, self.C))
+        return ('Gibbs iterations/sec, directed case-control T=%d N=%d d=2 n_control=%d, %s network'
+                % (self.T, self.N, self.C, 'model-drawn' if self.network == 'model' else 'degree-regular'))
 
     def profile(self):
         from dynetlsm_amd import _lib
@@ -793,7 +822,7 @@ class CcWorkload(object):
         sweep_bytes = 2.0 * T * N * self.mean_terms * (8 + 16 + 8)
         k_bytes = sweep_bytes / max(launches, 1)
         k_ms_events = k_ms
-        stored = stored_kernel_us(kname, 'cc')      # the rocprofv3 average under profiles/, as in the headline
+        stored = stored_kernel_us(kname, self.name)     # the rocprofv3 average under profiles/, as in the headline
         if stored:
             k_ms = stored['avg_us'] * 1e-3
         ach = k_bytes / (k_ms * 1e-3) / 1e9
@@ -881,7 +910,7 @@ class CcWorkload(object):
 
     def acceptance(self):
         from dynetlsm_amd import SamplerGrid
-        g = self.chain.get_samplers(SamplerGrid(self.T, self.N, 0.002, tune=None))
+        g = self.chain.get_samplers(SamplerGrid(self.T, self.N, self.step_x, tune=None))
         return float(g.n_accepted.sum()) / max(float(g.n_steps.sum()), 1.0)
 
     def cpu_baseline(self):
@@ -893,21 +922,21 @@ class CcWorkload(object):
         ci, co = self.controls0
         cc = dict(in_edges=in_edges, out_edges=out_edges, degree=degree, control_nodes_in=ci,
                   control_nodes_out=co)
-        st = orc.ChainState(X, orc.SamplerGrid(T, N, 0.002, tune=None), model=2, intercept=[1.0, 0.5],
-                            radii=radii.copy(), case_control=cc, tau_sq=1e-4, sigma_sq=1e-5,
+        st = orc.ChainState(X, orc.SamplerGrid(T, N, self.step_x, tune=None), model=2, intercept=list(self.b0),
+                            radii=radii.copy(), case_control=cc, tau_sq=self.tau_sq, sigma_sq=self.sigma_sq,
                             seed=20240229, chain=0)
 
         def loglik(Xc, b, r):
             return orc.approx_directed_network_loglikelihood(Xc, r, in_edges, out_edges, degree, co,
                                                              b[0], b[1])
-        isamp = [orc.ScalarMetropolis(0.1, None, 100) for _ in range(2)]
+        isamp = [orc.ScalarMetropolis(self.step_b, None, 100) for _ in range(2)]
         rsamp = orc.ScalarMetropolis(175000., None, 100)
         n_it = min(max(2, self.args.cpu_iters), self.n_resample - 1)
         X_ref = X.copy()            # the engine rotates every iteration onto its trace row 0 (lsm.py:495-498)
         tc = time.perf_counter()
         lps, snaps = [], []
         for it in range(1, n_it + 1):
-            lps.append(orc.lsm_iteration_directed(st, it, loglik, isamp, rsamp, np.array([1.0, 0.5]), 2.0,
+            lps.append(orc.lsm_iteration_directed(st, it, loglik, isamp, rsamp, np.array(self.b0), 2.0,
                                                   X_ref=X_ref))
             snaps.append((st.X.copy(), st.intercept.copy(), st.radii.copy()))
         tc = time.perf_counter() - tc
@@ -928,6 +957,13 @@ class CcWorkload(object):
     def close(self):
         for ch in self.chains:
             ch.close()
+
+
+class CcUniformWorkload(CcWorkload):
+    """config 4 on the degree-regular network rounds 1-5 timed (every node draws 20 out-neighbours uniformly: no
+    parameter of the model generates it - equal-length term rows and lists, the easy case)"""
+    name = 'ccu'
+    network = 'uniform'
 
 
 def measure(wl, args, group):
@@ -1018,10 +1054,11 @@ def run_rank(args):
     K, W = args.steps, args.warmup
     if args.profile_steps > 0:
         kernel_instr_per_term()         # host-only, cached: not between the profile phase and the timed steps
-    models = ['lsm', 'hdp', 'cc'] if args.model == 'all' else [args.model]
+    models = ['lsm', 'hdp', 'cc', 'ccu'] if args.model == 'all' else [args.model]
     lines = []
-    def run_model(name):
-            wl = {'lsm': LsmWorkload, 'hdp': HdpWorkload, 'cc': CcWorkload}[name](args, group, local_rank)
+    def run_model(name, args=args):
+            wl = {'lsm': LsmWorkload, 'hdp': HdpWorkload, 'cc': CcWorkload,
+                  'ccu': CcUniformWorkload}[name](args, group, local_rank)
             elapsed, roofline, extra, acc, gathered = measure(wl, args, group)
             cpu = None
             if rank == 0 and world == 1 and not args.no_cpu and args.cpu_iters > 0:      # at N = 1 only
@@ -1072,7 +1109,9 @@ def run_rank(args):
                     line['config']['iteration'] = ('sweep + procrustes + centring + intercept MH + '
                                                    'logp trace')
                     line['iteration_fp64_valu'] = iteration_valu_fraction(1e3 * elapsed / K, args)
-                elif name == 'cc':
+                elif name in ('cc', 'ccu'):
+                    line['config']['network'] = wl.network
+                    line['config']['degrees'] = wl.degree_stats
                     line['config']['iteration'] = ('sweep (case-control partial likelihoods) + centring + '
                                                    'intercept_in / intercept_out / radii MH around '
                                                    'case-control log-likelihood passes + logp trace; '
@@ -1140,10 +1179,53 @@ def run_rank(args):
             import traceback
             traceback.print_exc(file=sys.stderr)
             lines.append({'metric': 'monks', 'error': '%s: %s' % (type(e).__name__, e)})
+    if rank == 0 and world == 1 and args.model == 'all' and args.chains_per_gpu == 1:
+        # chains-per-GPU scaling is the sweep's defensible utilisation figure - config 2 again with four
+        # chains on the GPU (one handle, stream and host thread each), the same window
+        try:
+            import copy
+            a4 = copy.copy(args)
+            a4.chains_per_gpu = 4; a4.profile_steps = 0; a4.windows = 1
+            n0 = len(lines)
+            run_model('lsm', a4)
+            l4 = lines.pop()
+            assert len(lines) == n0
+            c2 = lines[0]
+            iv = c2.get('iteration_fp64_valu') or {}
+            lines.append({'metric': l4['metric'], 'chains_per_gpu': 4, 'aggregate_it_per_s': l4['value'],
+                          'per_chain_it_per_s': round(l4['value'] / 4.0, 1),
+                          'ratio_to_one_chain': round(l4['value'] / c2['value'], 3),
+                          'ms_per_step_all_chains': l4['ms_per_step'],
+                          'config': {'workload': l4['config']['workload']},
+                          # the sweep kernel's issue-slot fraction and the iteration's float64 fraction at one
+                          # chain, scaled by the aggregate rate: how busy the vector pipes are when the launch gaps
+                          # of one chain are filled by the others
+                          'frac_issue_slots': (round((c2.get('roofline') or {}).get('frac_issue_slots') *
+                                                     l4['value'] / c2['value'], 4)
+                                               if (c2.get('roofline') or {}).get('frac_issue_slots') else None),
+                          'iteration_frac_fp64_valu': (round(iv['frac'] * l4['value'] / c2['value'], 4)
+                                                       if 'frac' in iv else None)})
+        except Exception as e:      # noqa: BLE001
+            import traceback
+            traceback.print_exc(file=sys.stderr)
+            lines.append({'metric': 'lsm, 4 chains per GPU', 'error': '%s: %s' % (type(e).__name__, e)})
     if rank == 0:
         head = lines[0]
         if len(lines) > 1:
             head['extra_configs'] = lines[1:]
+            # the other configurations' figures as flat numbers inside `config` (the driver's record keeps `config`
+            # whole and only the tail of everything else)
+            def val(pred):
+                for ln in lines[1:]:
+                    if pred(ln) and 'error' not in ln:
+                        return ln.get('value', ln.get('aggregate_it_per_s'))
+                return None
+            head['config'].update({
+                'also_c3_hdp_lpcm_it_per_s': val(lambda ln: 'HDP' in ln['metric'] or 'hdp' in ln['metric'].lower()),
+                'also_c4_model_network_it_per_s': val(lambda ln: 'model-drawn' in ln['metric']),
+                'also_c4_degree_regular_network_it_per_s': val(lambda ln: 'degree-regular' in ln['metric']),
+                'also_c1_monks_it_per_s': val(lambda ln: 'monks' in ln['metric']),
+                'also_c2_4_chains_per_gpu_aggregate_it_per_s': val(lambda ln: ln.get('chains_per_gpu') == 4)})
         print(json.dumps(head), flush=True)
     group.close()
 

@@ -202,8 +202,8 @@ int ensure_label_bufs(dlsm_chain *h) {
 }
 
 int ll_blocks(const dlsm_chain *h) {
-    if (h->model == DLSM_DIRECTED_CASE_CONTROL)
-        return (int)(((long)h->T * h->N + LLCC_NODES - 1) / LLCC_NODES);
+    if (h->model == DLSM_DIRECTED_CASE_CONTROL)     // (k_loglik_casecontrol_rows: whole workgroups per slice)
+        return h->T * ((h->N + LLCC_NODES - 1) / LLCC_NODES);
     int nt = (h->N + LL_TILE - 1) / LL_TILE;
     // (undirected: two row halves per tile above the diagonal, one workgroup per diagonal tile: kernels_loglik.hpp)
     return h->model == DLSM_UNDIRECTED ? h->T * llu_blocks_per_slice(nt) : h->T * (nt * (nt + 1) / 2);
@@ -244,6 +244,12 @@ static int ensure_cc_rows(dlsm_chain *h, bool alloc_only = false) {
         }
         h->cc_tw = tw; h->cc_terms_valid = false;
     }
+    if (h->cc_pos_cap < TN) {
+        if (h->cc_pos) hipFree(h->cc_pos);
+        h->cc_pos = nullptr; h->cc_pos_cap = 0;
+        HIPCHK(h, hipMalloc((void **)&h->cc_pos, TN * sizeof(int32_t)));
+        h->cc_pos_cap = TN; h->cc_terms_valid = false;
+    }
     if (alloc_only) return DLSM_OK;
     if (!h->nctrl_valid) {      // the control lists change only in set / resample
         hipLaunchKernelGGL(k_count_controls, dim3((unsigned)((TN + 255) / 256)), dim3(256),
@@ -251,8 +257,10 @@ static int ensure_cc_rows(dlsm_chain *h, bool alloc_only = false) {
         h->nctrl_valid = true; h->cc_terms_valid = false;
     }
     if (!h->cc_terms_valid) {
+        hipLaunchKernelGGL(k_cc_pos, dim3((unsigned)((h->N + CC_SORT_B - 1) / CC_SORT_B), (unsigned)h->T),
+                           dim3(CC_SORT_B), 0, h->stream, h->view(), h->nctrl, h->cc_pos);
         hipLaunchKernelGGL(k_cc_rows, dim3((unsigned)((TN + 3) / 4)), dim3(256), 0, h->stream, h->view(),
-                           h->nctrl, h->cc_terms, tw);
+                           h->nctrl, h->cc_pos, h->cc_terms, tw);
         h->cc_terms_valid = true;
     }
     return DLSM_OK;
@@ -434,7 +442,7 @@ void dlsm_destroy(dlsm_chain *h) {
                     h->lab_nk, h->lab_w, h->spec, h->nctrl, h->stamps, h->lsm, h->trace_X, h->trace_ic,
                     h->trace_logp, h->hops, h->hops_max, h->pipe, h->post_zt, h->post_cooc,
                     h->trace_radii, h->hdp, h->hdp_buf, h->htr_mu, h->htr_sigma, h->htr_beta,
-                    h->htr_w, h->htr_lambda, h->htr_hyper, h->htr_z, h->xr, h->cc_terms};
+                    h->htr_w, h->htr_lambda, h->htr_hyper, h->htr_z, h->xr, h->cc_terms, h->cc_pos};
     for (void *p : ptrs) if (p) hipFree(p);
     if (h->hsmall) hipHostFree(h->hsmall);
     if (h->timer0) hipEventDestroy(h->timer0);

@@ -31,6 +31,7 @@
 namespace dlsm {
 
 constexpr int CP_B = 512;               // nodes per batch (<= CP_THREADS: the resolver's thread = node)
+static_assert(CP_B == CC_SORT_B, "the term rows are sorted inside the sweep's batches (cc_rows.hpp)");
 constexpr int CP_THREADS = 1024;
 constexpr int CP_WAVES = CP_THREADS / 64;
 // (12 / 24 up front measured best at config 4: 8 / 16 1637, 10 / 20 1679, 12 / 24 1731-1744,
@@ -139,22 +140,27 @@ struct CcWin {
 // whose partner sits in the window (~15 % at C4) are collected in LDS and get their second
 // evaluation - the partner at its proposal - together, a full wavefront at a time, instead of one
 // mostly idle evaluation per chunk.
+// (round 6: the item is the batch's `rank`-th row - the rows of a batch are stored by descending term count,
+// cc_rows.hpp - and learns its node from the row's header, which arrives with the counts and the first indices)
 template <int D>
 __device__ __forceinline__ void ccpipe_eval_item(const ChainView &c, const CcPipeBuf &pb, int be,
-                                                 int t, int k, int lane, CcWin<D> &sw, const double *etab) {
+                                                 int t, int rank, int lane, CcWin<D> &sw, const double *etab) {
     constexpr int PW = 2 * D + 2;
     constexpr int RW = cp_record_width(D);
     constexpr int NCH = D <= 2 ? 4 : 2;      // 64-term chunks in flight (d = 3, 4: two - their records and proposals would spill)
     const int N = c.N;
-    const int j0 = be * CP_B, jk = j0 + k;
+    const int j0 = be * CP_B;
     const int jprev = max(0, j0 - CP_B);       // nodes >= jprev: snapshot positions
     const int bb = be & 1;
     // the node's row: counts and the first 64 * NCH indices leave together
     // (every gather of the item is a 32-bit lane offset from a wave-uniform base: 64-bit lane addresses cost
     // three vector instructions and two registers each, and the compiler hoisted and spilled the row's)
-    const char *row = (const char *)(pb.terms + ((size_t)t * N + jk) * pb.tw);
+    const char *row = (const char *)(pb.terms + ((size_t)t * N + j0 + rank) * pb.tw);
     const int4 hdr = *(const int4 *)row;
     const double2 adj = *(const double2 *)(row + 16);
+    // (every lane's copy: as a scalar it cost the kernel its last free scalar registers - 36 bytes of scratch)
+    const int jk = *(const int32_t *)(row + 32);       // the row's node
+    const int k = jk - j0;
     // (the lane as the row's offsets see it, opaque per item: the compiler otherwise hoists the four offsets
     // out of the workgroup's item loop - a wavefront runs one item, rarely two - and spills them)
     int lane_r = lane;
@@ -657,7 +663,12 @@ __global__ __launch_bounds__(CP_THREADS) void k_ccpipe_step(ChainView c, CcPipeB
     const int beE = l + 1, beO = l;
     const int nbE = (beE >= 0 && beE < pb.nbat) ? min(CP_B, c.N - beE * CP_B) : 0;
     const int nbO = (beO >= 0 && beO < pb.nbat) ? min(CP_B, c.N - beO * CP_B) : 0;
-    const int nodesE = nE * nbE, nodes = nodesE + nO * nbO;
+    // items rank-major: q -> (rank q / slices, slice q mod slices) - ascending q is descending term count, so the
+    // longest items take the wavefront slots 0 .. 3 of the workgroups (one per SIMD, first to start) and the
+    // shortest the slots that give a SIMD its third item
+    const int nslE = nbE > 0 ? nE : 0, nslO = nbO > 0 ? nO : 0, nsl = max(nslE + nslO, 1);
+    const int nodes = nsl * max(nbE, nbO);
+    const float inv_nsl = __builtin_amdgcn_rcpf((float)nsl);
     const int n_wg = (int)gridDim.x - nres, wg = (int)blockIdx.x - nres;
     const int nwaves = n_wg * CP_WAVES;
     // item q -> wavefront (q / workgroups) of workgroup (q % workgroups): a launch's items are spread over
@@ -671,11 +682,11 @@ __global__ __launch_bounds__(CP_THREADS) void k_ccpipe_step(ChainView c, CcPipeB
     exp_table_fill(sTab, threadIdx.x);
     __syncthreads();
     for (int q = gw; q < nodes; q += nwaves) {
-        const bool odd = q >= nodesE;
-        const int qq = odd ? q - nodesE : q;
-        const int nb = odd ? nbO : nbE;
-        const int k = qq % nb;
-        const int t = 2 * (qq / nb) + (odd ? 1 : 0);
+        const int k = (int)(((float)q + 0.5f) * inv_nsl);          // q / nsl (q < 2^20): the rank inside the batch
+        const int si = q - k * nsl;
+        const bool odd = si >= nslE;
+        if (k >= (odd ? nbO : nbE)) continue;                        // (a ragged last batch beside a full one)
+        const int t = odd ? 2 * (si - nslE) + 1 : 2 * si;
 #ifdef DLSM_PIPE_TIMING
         unsigned long long cts[2];
         DLSM_CC_STAMP(0, (double)lane)

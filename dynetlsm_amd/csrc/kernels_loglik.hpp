@@ -529,17 +529,28 @@ __global__ __launch_bounds__(LLCR_THREADS) void k_loglik_casecontrol_rows(
     // (M = 2: the second candidate may differ in its radii; M = 4 - the case-control loop's two intercept
     // steps at once - differs in intercepts only)
     const bool two_radii = M == 2 && cand.radii[1] != cand.radii[0];
-    long node[NPW];
+    // (round 6: `node` is a ROW of the slice - rows are stored by descending term count inside every 512 nodes,
+    // cc_rows.hpp - and a wavefront takes the rows `pi` from the head and `pi` from the tail of its batch: a long
+    // node beside a short one, every wavefront about the same number of trips; `who` is the node a row belongs to.
+    // Workgroup -> (slice, batch, 8 such pairs): T ceil(N / 16) workgroups, as ll_blocks() counts them)
+    long node[NPW], who[NPW];
+    static_assert(NPW == 2 && CC_SORT_B % LLCC_NODES == 0, "pairs of rows, whole workgroups per batch");
+    const int wps = (c.N + LLCC_NODES - 1) / LLCC_NODES;
+    const int sl = (int)blockIdx.x / wps, ws = (int)blockIdx.x - sl * wps;
+    const int bj0 = (ws / (CC_SORT_B / LLCC_NODES)) * CC_SORT_B, bnb = min(CC_SORT_B, c.N - bj0);
+    const int pi = (ws % (CC_SORT_B / LLCC_NODES)) * NWV + wave;
     int outdeg[NPW], nt[NPW], e[NPW][NS];
     double adj[NPW];
     const char *rows[NPW];
     constexpr uint32_t HB = CP_HDR * sizeof(int32_t);
 #pragma unroll
     for (int r = 0; r < NPW; ++r) {
-        node[r] = ((long)blockIdx.x * NPW + r) * NWV + wave;
+        const bool have = r == 0 ? pi < (bnb + 1) / 2 : pi < bnb / 2;
+        node[r] = have ? (long)sl * c.N + bj0 + (r == 0 ? pi : bnb - 1 - pi) : nodes;
         const long nn = node[r] < nodes ? node[r] : 0;
         rows[r] = (const char *)(terms + nn * tw);
         const int4 hdr = *(const int4 *)rows[r];
+        who[r] = nn / c.N * c.N + *(const int32_t *)(rows[r] + 32);
         adj[r] = *(const double *)(rows[r] + 24);                       // adj_out
         outdeg[r] = node[r] < nodes ? hdr.y : 0;
         nt[r] = node[r] < nodes ? hdr.y + hdr.w : 0;                    // out-edges + out-controls
@@ -556,7 +567,7 @@ __global__ __launch_bounds__(LLCR_THREADS) void k_loglik_casecontrol_rows(
     double xi[NPW][D], xe[NPW][NS][D], re0[NPW][NS], re1[NPW][NS], ri0[NPW], ri1[NPW];
 #pragma unroll
     for (int r = 0; r < NPW; ++r) {
-        const long nn = node[r] < nodes ? node[r] : 0;
+        const long nn = node[r] < nodes ? who[r] : 0;
         const int t = (int)(nn / c.N);
         const char *Rt = (const char *)(XR + (size_t)t * c.N * RW);
         {

@@ -10,18 +10,18 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 # 1. the profiler's passes; 2. this round's stored durations and traffic (what the bench lines' rooflines divide by:
 #    written where bench.py reads them, and into $OUT for the way home); 3. the bench lines
-for m in lsm hdp cc; do bash $ROOT/profiles/collect.sh $TAG $m profile > $OUT/collect_$m.log 2>&1; done
+for m in lsm hdp cc ccu; do bash $ROOT/profiles/collect.sh $TAG $m profile > $OUT/collect_$m.log 2>&1; done
 cd $ROOT
 # the HDP-LPCM iteration launch by launch, on its two queues (the trace above) and on one (a trace of its own)
 python3 profiles/iteration_timeline.py $OUT/stats_hdp/bench_kernel_trace.csv > $OUT/hdp_timeline_two_queues.txt 2>&1
 (cd /tmp && export TMPDIR=/tmp && DLSM_HDP_QUEUES=1 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace_hdp_one_queue -o bench -- python3 $ROOT/bench.py --model hdp --no-cpu --steps 50 --warmup 10 --profile-steps 0 > $OUT/trace_hdp_one_queue.log 2>&1)
 python3 profiles/iteration_timeline.py $OUT/trace_hdp_one_queue/bench_kernel_trace.csv > $OUT/hdp_timeline_one_queue.txt 2>&1
 rm -rf $OUT/trace_hdp_one_queue
-for m in lsm hdp cc; do cp $OUT/kernel_stats_$m.csv profiles/${TAG}_kernel_stats_$m.csv; cp $OUT/traffic_$m.json profiles/${TAG}_traffic_$m.json; done
+for m in lsm hdp cc ccu; do cp $OUT/kernel_stats_$m.csv profiles/${TAG}_kernel_stats_$m.csv; cp $OUT/traffic_$m.json profiles/${TAG}_traffic_$m.json; done
 python3 profiles/kernel_durations.py $TAG > profiles/kernel_durations.json
 python3 profiles/merge_traffic.py $TAG > profiles/traffic.json
 cp profiles/kernel_durations.json profiles/traffic.json $OUT/
-for m in lsm hdp cc; do bash $ROOT/profiles/collect.sh $TAG $m bench >> $OUT/collect_$m.log 2>&1; done
+for m in lsm hdp cc ccu; do bash $ROOT/profiles/collect.sh $TAG $m bench >> $OUT/collect_$m.log 2>&1; done
 cd $ROOT
 python3 bench.py < /dev/null > $OUT/bench_default.json 2> $OUT/bench_default.err
 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver_args.json 2> $OUT/bench_driver_args.err

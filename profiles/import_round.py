@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 tag = sys.argv[1]
 src = os.path.join(os.path.dirname(HERE), 'gpurun_out', tag)
 n = 0
-for m in ('lsm', 'hdp', 'cc'):
+for m in ('lsm', 'hdp', 'cc', 'ccu'):
     for a in ('bench_%s.json', 'kernel_stats_%s.csv', 'traffic_%s.json', 'pipe_roles_%s.txt'):
         p = os.path.join(src, a % m)
         if os.path.exists(p) and os.path.getsize(p) > 0:

@@ -26,7 +26,7 @@ def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else 'r04'
     out = {'_source': 'profiles/%s_kernel_stats_{lsm,hdp,cc}.csv (rocprofv3 --kernel-trace --stats of '
                       'bench.py --model M --no-cpu --steps 50 --warmup 10 --profile-steps 0)' % tag}
-    for model in ('lsm', 'hdp', 'cc'):
+    for model in ('lsm', 'hdp', 'cc', 'ccu'):
         path = os.path.join(HERE, '%s_kernel_stats_%s.csv' % (tag, model))
         if not os.path.exists(path):
             continue

@@ -9,7 +9,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 tag = sys.argv[1] if len(sys.argv) > 1 else 'r04'
 m = {}
-for model in ('lsm', 'hdp', 'cc'):
+for model in ('lsm', 'hdp', 'cc', 'ccu'):
     path = os.path.join(HERE, '%s_traffic_%s.json' % (tag, model))
     if not os.path.exists(path):
         continue

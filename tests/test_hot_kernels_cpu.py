@@ -66,7 +66,7 @@ def test_matrix_core_label_kernel_is_built_for_the_sizes_that_stay_in_registers(
 # bytes of private segment per thread at HEAD:
 KNOWN_SCRATCH = {
     # d = 3 / 4 instantiations of the pipelined sweep (resolver: the blocks' 64 registers + 8 d of the owners)
-    'k_pipe_step<3,1,1>': 12, 'k_pipe_step<3,2,1>': 52, 'k_pipe_step<4,0,1>': 36, 'k_pipe_step<4,3,1>': 36,
+    'k_pipe_step<3,1,1>': 12, 'k_pipe_step<3,2,1>': 52, 'k_pipe_step<4,0,1>': 20, 'k_pipe_step<4,3,1>': 52,
     'k_pipe_step<4,1,1>': 60, 'k_pipe_step<4,2,1>': 84, 'k_pipe_last_ride<4>': 36,
     # d = 2: parts longer than the prefetch (N > 2112 at T = 10), the dense case-control form (512 <= N < 2048)
     'k_pipe_step<2,3,1>': 8, 'k_pipe_step<2,2,1>': 28,
@@ -91,12 +91,12 @@ KNOWN_SCRATCH = {
     # two or three prefetched trips of d registers each no longer fit the 128 of a 1024-thread workgroup; 2910 it/s at
     # d = 5, 1465 at d = 8 against 1660 / 1330 for the speculative sweep - DESIGN.md 9)
     'k_pipe_last_ride<5>': 76, 'k_pipe_last_ride<6>': 148, 'k_pipe_last_ride<7>': 300, 'k_pipe_last_ride<8>': 500,
-    'k_pipe_step<5,0,1>': 84, 'k_pipe_step<5,1,1>': 100, 'k_pipe_step<5,2,1>': 108, 'k_pipe_step<5,3,1>': 84,
-    'k_pipe_step<6,0,1>': 140, 'k_pipe_step<6,1,1>': 188, 'k_pipe_step<6,2,1>': 164, 'k_pipe_step<6,3,1>': 136,
-    'k_pipe_step<7,0,1>': 180, 'k_pipe_step<7,1,1>': 216, 'k_pipe_step<7,2,1>': 208, 'k_pipe_step<7,3,1>': 188,
-    'k_pipe_step<8,0,1>': 236, 'k_pipe_step<8,1,1>': 304, 'k_pipe_step<8,2,1>': 248, 'k_pipe_step<8,3,1>': 240,
+    'k_pipe_step<5,0,1>': 72, 'k_pipe_step<5,1,1>': 108, 'k_pipe_step<5,2,1>': 108, 'k_pipe_step<5,3,1>': 84,
+    'k_pipe_step<6,0,1>': 116, 'k_pipe_step<6,1,1>': 180, 'k_pipe_step<6,2,1>': 164, 'k_pipe_step<6,3,1>': 144,
+    'k_pipe_step<7,0,1>': 172, 'k_pipe_step<7,1,1>': 224, 'k_pipe_step<7,2,1>': 208, 'k_pipe_step<7,3,1>': 200,
+    'k_pipe_step<8,0,1>': 212, 'k_pipe_step<8,1,1>': 312, 'k_pipe_step<8,2,1>': 248, 'k_pipe_step<8,3,1>': 240,
     # ... and the sparse case-control sweep there (two chunks of records and proposals of d doubles in flight)
-    'k_ccpipe_step<5>': 16, 'k_ccpipe_step<6>': 76, 'k_ccpipe_step<7>': 116, 'k_ccpipe_step<8>': 148,
+    'k_ccpipe_step<5>': 24, 'k_ccpipe_step<6>': 72, 'k_ccpipe_step<7>': 136, 'k_ccpipe_step<8>': 168,
 }
 # vector registers parked in accumulation registers (no memory traffic: scratch_bytes is 0)
 KNOWN_AGPR_PARKED = {'k_post_apply<8>', 'k_lsm_finalize_apply_propose<8>', 'k_post_apply_dir<8>', 'k_post_align<8>'}
