@@ -1047,6 +1047,8 @@ def run_rank(args):
         os.environ['LOCAL_RANK'] = '0'
         # (processes sharing a GPU: the HDP-LPCM loop stays on one queue - multichain.launch_ranks)
         os.environ.setdefault('DLSM_HDP_QUEUES', '1')
+        os.environ.setdefault('DLSM_CC_HELPERS', '0')       # (no in-launch waits across processes either)
+        os.environ.setdefault('DLSM_PIPE_XSERVE', '0')
     # one process per GPU; collectives over RCCL (backend "nccl") unless told otherwise
     group = init_chain_group(backend=(args.backend or 'nccl') if (world > 1 or args.force_collectives)
                              else 'gloo', force=args.force_collectives)
@@ -1186,13 +1188,14 @@ def run_rank(args):
             import copy
             a4 = copy.copy(args)
             a4.chains_per_gpu = 4; a4.profile_steps = 0; a4.windows = 1
+            a4.steps = max(args.steps, 200)      # (four host threads: a 20-step window measures their start)
             n0 = len(lines)
             run_model('lsm', a4)
             l4 = lines.pop()
             assert len(lines) == n0
             c2 = lines[0]
             iv = c2.get('iteration_fp64_valu') or {}
-            lines.append({'metric': l4['metric'], 'chains_per_gpu': 4, 'aggregate_it_per_s': l4['value'],
+            lines.append({'metric': l4['metric'], 'chains_per_gpu': 4, 'steps': a4.steps, 'aggregate_it_per_s': l4['value'],
                           'per_chain_it_per_s': round(l4['value'] / 4.0, 1),
                           'ratio_to_one_chain': round(l4['value'] / c2['value'], 3),
                           'ms_per_step_all_chains': l4['ms_per_step'],

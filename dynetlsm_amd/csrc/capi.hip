@@ -305,6 +305,9 @@ int launch_loglik_records(dlsm_chain *h, int M, const double *d_ic,
         if (M == 1) hipLaunchKernelGGL((k_loglik_directed<DD, 1>), dim3(nb), dim3(LL_THREADS), 0, h->stream, v, cand, h->partials);
         else hipLaunchKernelGGL((k_loglik_directed<DD, 2>), dim3(nb), dim3(LL_THREADS), 0, h->stream, v, cand, h->partials);
     } else {
+        // (the pass gathers records as 32-bit lane offsets from a slice's base: umul24 of the node)
+        if (h->N >= (1 << 24) || (double)h->N * llcc_record_width(DD) * sizeof(double) >= 4294967296.0)
+            FAIL(h, DLSM_E_LIMIT, "case-control log-likelihood pass: N=%d is beyond its 32-bit gather offsets", h->N);
         const bool pf = cc_prefetch_form(h);
         if (pf) {       // positions and both candidates' radii as one record per node
             const size_t nodes = (size_t)h->T * h->N;
@@ -1068,6 +1071,9 @@ static int check_pipe_err(dlsm_chain *h) {
                 FAIL(h, DLSM_E_HIP, "pipelined sweep: a resolver ran out of its poll budget waiting for a cross product "
                      "from the launch's evaluators (word %#x) - the chain's state is undefined; set the state again "
                      "and run with DLSM_PIPE_XSERVE=0", e);
+            if (e & CC_ERR_FIXPOINT)
+                FAIL(h, DLSM_E_HIP, "case-control sweep: a resolver's fixed point did not settle inside its spin bound "
+                     "(word %#x) - the chain's state is undefined; set the state again", e);
             if (e & CC_ERR_HELPER)
                 FAIL(h, DLSM_E_HIP, "case-control sweep: a resolver ran out of its poll budget waiting for its helper "
                      "workgroup (word %#x) - the chain's state is undefined; set the state again and run with "
@@ -1136,14 +1142,16 @@ static int launch_sweep_pipe(dlsm_chain *h, IterRef iter, bool alloc_only = fals
                   (long)parts * T * PP_B <= (long)ne_wg * PP_WAVES &&
                   !(getenv("DLSM_PIPE_LDS") && atoi(getenv("DLSM_PIPE_LDS")) == 0);
     // the resolvers' cross products by the evaluators (pipe_xserve_*): one wavefront in xstride takes a row.  A
-    // resolver waits INSIDE the launch for wavefronts that wait for nothing - they only have to start; with so
-    // many chains on the device that their resolver workgroups alone could fill it, the resolvers keep the work
+    // resolver waits INSIDE the launch for wavefronts that wait for nothing - they only have to start
     {
         const char *ex = getenv("DLSM_PIPE_XSERVE"), *ebud = getenv("DLSM_PIPE_XBUDGET");
         pb.err = h->fork_err_dev;
         pb.budget = ebud ? atoi(ebud) : (1 << 22);
-        pb.xserve = pb.lds_eval && pb.err != nullptr && (ex ? atoi(ex) != 0 : true) &&
-                    T < 128 && (long)g_live_chains.load() * T * 2 <= (long)h->n_cu;
+        // (one chain on the device: with several, a resolver's wait for evaluator workgroups that other chains' launches
+        // keep off the CUs costs more than the cross block - four chains: 6100 it/s served, 6970 not; DLSM_PIPE_XSERVE=2
+        // forces it)
+        pb.xserve = pb.lds_eval && pb.err != nullptr && T < 128 &&
+                    (ex ? (atoi(ex) == 2 || (atoi(ex) != 0 && g_live_chains.load() == 1)) : g_live_chains.load() == 1);
     }
     const int xserve_sweep = pb.xserve;         // (a launch whose workgroups cannot cover the rows keeps the resolvers' own products)
     pb.xserve = 0;
@@ -1262,6 +1270,11 @@ static int launch_sweep_ccpipe(dlsm_chain *h, IterRef iter, bool alloc_only = fa
         HIPCHK(h, hipMalloc((void **)&h->pipe, need));
         h->pipe_cap = need;
     }
+    // (the gathers address records and proposals as 32-bit lane offsets from per-slice bases: umul24 of the node
+    // and a snapshot offset of T N records - round-5 advice)
+    if (N >= (1 << 24) || (double)(T + 1) * N * cp_record_width(DD) * sizeof(double) >= 4294967296.0)
+        FAIL(h, DLSM_E_LIMIT, "case-control sweep (algo 5): N=%d T=%d is beyond its 32-bit gather offsets "
+             "(N < 2^24, (T + 1) N record bytes < 2^32); use sweep_algo 4 or 2", N, T);
     // the nodes' term rows: rebuilt when the edge tables or the controls have changed
     { int rc_ = ensure_cc_rows(h, alloc_only); if (rc_) return rc_; }
     const int tw = h->cc_tw;
@@ -1277,7 +1290,11 @@ static int launch_sweep_ccpipe(dlsm_chain *h, IterRef iter, bool alloc_only = fa
     // device in one wave of workgroups - a resolver waits for its helper INSIDE the launch, so both must be
     // resident; DLSM_CC_HELPERS=0 keeps the resolvers on their own
     const char *eh = getenv("DLSM_CC_HELPERS");
-    pb.helpers = (eh ? atoi(eh) != 0 : true) && h->n_cu >= 4 * T && h->fork_err_dev != nullptr;
+    // (one chain on the device - as hdp_fork_arm and the pipelined sweep's served cross products decide: with several
+    // chains' launches on the CUs a helper may not be resident when its resolver starts to poll, and a slow but
+    // correct run would end in the sticky error; DLSM_CC_HELPERS=2 forces the role, 0 switches it off)
+    pb.helpers = (eh ? (atoi(eh) == 2 || (atoi(eh) != 0 && g_live_chains.load() == 1)) : g_live_chains.load() == 1) &&
+                 h->n_cu >= 4 * T && h->fork_err_dev != nullptr;
     {   // polls of a resolver's wait for its helper before the sticky error word is set (DLSM_CC_HELPER_BUDGET)
         const char *ebud = getenv("DLSM_CC_HELPER_BUDGET");
         pb.budget = ebud ? atoi(ebud) : (1 << 22);

@@ -59,6 +59,7 @@ struct CcPipeBuf {
     int helpers, budget;
 };
 constexpr int CC_ERR_HELPER = 1 << 30;
+constexpr int CC_ERR_FIXPOINT = 1 << 28;    // a resolver's fixed point did not settle inside its spin bound
 // "no sum yet": a NaN payload no arithmetic produces (the hardware's own NaN is 0x7FF8000000000000, and the
 // entries that are summed carry no payloads)
 constexpr unsigned long long CC_XS_EMPTY = 0x7FF8C0DE5EED0001ull;
@@ -490,8 +491,12 @@ __device__ __forceinline__ void ccpipe_resolve(const ChainView &c, const CcPipeB
     if (!upper) {
         int computed_v = -2, filed_v = -2;                  // version my last pass was based on / I have filed
         bool quiet = false;                                 // ... and that pass changed nothing
+        bool settled = false;
         for (int spin = 0; spin < (1 << 22); ++spin) {
-            const int v = CC_LD32(&sCtl[0]);
+            // (acquire: the version word orders the mask words read behind it against the writers' release
+            // fetch_add - on LDS it costs nothing measurable, and the termination argument no longer leans on
+            // in-order LDS issue and the compiler keeping monotonic loads in place: round-5 advice)
+            const int v = __hip_atomic_load(&sCtl[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (quiet && v == computed_v) {
                 // nothing has been published since the version read in front of my last pass, and that pass
                 // changed nothing: my word stands at version v.  File it (once) and poll - a poll is one LDS
@@ -503,7 +508,7 @@ __device__ __forceinline__ void ccpipe_resolve(const ChainView &c, const CcPipeB
                     filed_v = v;
                 }
                 const int filed = CC_LD32(&sCtl[1 + (lane & (NRW - 1))]);   // lane w: the version wavefront w has filed
-                if (__ballot(filed != v) == 0ull) break;        // every wavefront stands at the current version
+                if (__ballot(filed != v) == 0ull) { settled = true; break; }    // every wavefront stands at the current version
                 continue;
             }
             computed_v = v;                                 // (read BEFORE the words of this pass)
@@ -556,6 +561,9 @@ __device__ __forceinline__ void ccpipe_resolve(const ChainView &c, const CcPipeB
             cts[6] += 1;
 #endif
         }
+        // the spin bound ran out: the mask a wavefront holds is NOT the fixed point - say so (sticky error word)
+        if (!settled && lane == 0 && pb.err)
+            __hip_atomic_fetch_or(pb.err, CC_ERR_FIXPOINT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 #undef CC_LD64
 #undef CC_LD32

@@ -16,7 +16,7 @@ __all__ = ['forecast_probas_map', 'forecast_probas_plugin', 'forecast_probas_mar
 
 
 def _kept(model):
-    n_burn = min(model.n_burn_ // (getattr(model, 'thin', None) or 1), model.zs_.shape[0] - 1)
+    n_burn = min(-(-model.n_burn_ // (getattr(model, 'thin', None) or 1)), model.zs_.shape[0] - 1)    # ceil: hdp_lpcm.py:465
     return np.arange(n_burn, model.zs_.shape[0])
 
 

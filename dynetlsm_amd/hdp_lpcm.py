@@ -602,7 +602,7 @@ class DynamicNetworkHDPLPCM(FittedQuantities):
                 self.radiis_ = self.radiis_[::self.thin]
         # model selection (hdp_lpcm.py:1085-1139): BIC / MAP size / minimum posterior
         # expected VI, with the co-occurrence matrices and the VI criterion on the device
-        n_burn = min(self.n_burn_ // (self.thin or 1), self.logps_.shape[0] - 1)
+        n_burn = min(-(-self.n_burn_ // (self.thin or 1)), self.logps_.shape[0] - 1)     # ceil: hdp_lpcm.py:465
         post.select_model(self, chain, n_burn)
         # Procrustes: rotate every stored sample onto the selected one (:1141-1146)
         post.procrustes_align_samples(self)

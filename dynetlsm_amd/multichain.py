@@ -43,10 +43,14 @@ __all__ = ['ChainGroup', 'init_chain_group', 'fit_chains', 'ChainsResult', 'laun
 class ChainGroup(object):
     """Rank / device bookkeeping of one process of the chain group."""
 
-    def __init__(self, rank, world, local_rank, backend, dist=None, torch=None, force=False):
+    def __init__(self, rank, world, local_rank, backend, dist=None, torch=None, force=False, data_group=None):
         self.rank, self.world, self.local_rank = rank, world, local_rank
         self.backend = backend
         self._dist, self._torch = dist, torch
+        # data_group: the RCCL group of the data collectives when the DEFAULT group is the gloo control group
+        # (init_chain_group brings the control group up first and decides about RCCL over it); None: the default
+        # group carries the data as well
+        self._grp = data_group
         # force: go through the collectives even in a group of one (a single-GPU box can then
         # exercise the RCCL path: device tensors, stream ordering, library initialisation)
         self._solo = world == 1 and not force
@@ -56,7 +60,7 @@ class ChainGroup(object):
         # 3 - 4 % of a 100-iteration window), a host barrier over loopback a few tens of
         # microseconds.  The network broadcast and the final gather stay on the data backend.
         self._ctl = None
-        if not self._solo and backend == 'nccl':
+        if not self._solo and backend == 'nccl' and data_group is None:
             self._ctl = dist.new_group(backend='gloo')
         # what the data collectives of this rank moved and how long they took (host clock around
         # the call + the synchronisation that ends it): `describe()` puts them on the N > 1 bench
@@ -85,8 +89,9 @@ class ChainGroup(object):
         if not self._solo:
             d['world_size'] = int(self._dist.get_world_size())
             d['rank'] = int(self._dist.get_rank())
-            d['backend'] = str(self._dist.get_backend())
-            d['control_backend'] = str(self._dist.get_backend(self._ctl)) if self._ctl is not None else d['backend']
+            d['backend'] = str(self._dist.get_backend(self._grp) if self._grp is not None else self._dist.get_backend())
+            d['control_backend'] = (str(self._dist.get_backend(self._ctl)) if self._ctl is not None
+                                    else str(self._dist.get_backend()))
             d['device'] = str(self._tensor_device())
         d.update({k: (round(v, 4) if isinstance(v, float) else v) for k, v in self.stats.items()})
         if getattr(self, 'fallback_reason', None):
@@ -126,14 +131,14 @@ class ChainGroup(object):
             if not np.all((Y == 0) | (Y == 1) | (Y == -1)):      # -1: the reference's missing code
                 raise ValueError('network entries must be 0 / 1 (or -1 for a missing dyad)')
             hdr = t.tensor(Y.shape, dtype=t.int64, device=dev)
-        self._dist.broadcast(hdr, src)
+        self._dist.broadcast(hdr, src, group=self._grp)
         shp = tuple(int(v) for v in hdr.cpu())
         if self.rank == src:
             buf = t.from_numpy(Y.astype(np.int8)).to(dev)
         else:
             buf = t.empty(shp, dtype=t.int8, device=dev)
         t0 = time.perf_counter()
-        self._dist.broadcast(buf, src)
+        self._dist.broadcast(buf, src, group=self._grp)
         self._timed('network', buf.numel(), t0)
         return buf.cpu().numpy().astype(np.float64)
 
@@ -149,7 +154,7 @@ class ChainGroup(object):
         if self.rank == src:
             chain.get_network_packed(buf.data_ptr(), n)
         t0 = time.perf_counter()
-        self._dist.broadcast(buf, src)
+        self._dist.broadcast(buf, src, group=self._grp)
         self._timed('network', 4 * n, t0)              # (synchronises: the chain copies on its own stream)
         if self.rank != src:
             chain.set_network_packed(buf.data_ptr(), n)
@@ -161,7 +166,7 @@ class ChainGroup(object):
         t = self._torch
         buf = t.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(self._tensor_device())
         t0 = time.perf_counter()
-        self._dist.broadcast(buf, src)
+        self._dist.broadcast(buf, src, group=self._grp)
         self._timed('array', 8 * buf.numel(), t0)
         return buf.cpu().numpy()
 
@@ -174,7 +179,7 @@ class ChainGroup(object):
         mine = t.from_numpy(a).to(self._tensor_device())
         out = [t.empty_like(mine) for _ in range(self.world)]
         t0 = time.perf_counter()
-        self._dist.all_gather(out, mine)
+        self._dist.all_gather(out, mine, group=self._grp)
         self._timed('gather', 8 * mine.numel(), t0)
         return [o.cpu().numpy() for o in out]
 
@@ -188,7 +193,7 @@ class ChainGroup(object):
         if self._solo:
             return float(x)
         t = self._torch
-        if self._ctl is not None:
+        if self._ctl is not None or self._grp is not None:      # (a host all-reduce over the gloo control group)
             v = t.tensor([float(x)], dtype=t.float64)
             self._dist.all_reduce(v, op=self._dist.ReduceOp.MAX, group=self._ctl)
             return float(v[0])
@@ -204,53 +209,73 @@ class ChainGroup(object):
 def init_chain_group(backend=None, force=False):
     """Join the process group described by RANK / WORLD_SIZE / LOCAL_RANK /
     MASTER_ADDR / MASTER_PORT (torch.distributed.run sets them).  ``force``: initialise the
-    backend and route through its collectives even when WORLD_SIZE is 1."""
+    backend and route through its collectives even when WORLD_SIZE is 1.
+
+    ``backend='nccl'`` (RCCL): the gloo CONTROL group comes up first, over the rendezvous as given - barriers
+    and the timing reductions use it anyway - then the RCCL group is made as a second group of the same ranks
+    and probed (one element summed over the ranks), and the ranks AGREE over the control group whether it
+    works: either every rank uses RCCL or none does (round-5 advice: a fallback each rank decided on its own
+    left the others waiting in a collective, and looked for a second port).  RCCL that does not come up is an
+    ERROR unless DLSM_ALLOW_BACKEND_FALLBACK=1: then the setup collectives - none of them is on the data path -
+    go through the control group and ``describe()`` (the bench line's `collectives` block) says so."""
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    import datetime
     import torch
     import torch.distributed as dist
     if backend is None:
         backend = 'nccl' if torch.cuda.is_available() else 'gloo'
     fallback_reason = None
+    data_group = None
     if world > 1 or force:
-        kw = {}
-        if backend == 'nccl':
-            kw['device_id'] = torch.device('cuda', local_rank)
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29511')
-        try:
-            if backend == 'nccl':
-                torch.cuda.set_device(local_rank)
-            dist.init_process_group(backend, rank=rank, world_size=world, **kw)
-            if backend == 'nccl':
-                # the communicator really works (one element summed over the ranks) before anything relies on it
-                probe = torch.ones(1, device=torch.device('cuda', local_rank))
-                dist.all_reduce(probe)
-                torch.cuda.synchronize()
-                if int(probe.item()) != world:
-                    raise RuntimeError('RCCL all_reduce probe returned %r for %d ranks' % (probe.item(), world))
-        except Exception as exc:        # noqa: BLE001
-            # The chains are independent: the collectives carry the network once, the final gather and the
-            # barriers - none of them is on the data path.  An RCCL that does not come up on a node (its
-            # environment, not this code) must not cost the run: the same collectives go through gloo, and the
-            # bench line's `collectives` block says so.  DLSM_NO_BACKEND_FALLBACK=1 keeps the failure.
-            if backend != 'nccl' or os.environ.get('DLSM_NO_BACKEND_FALLBACK') == '1':
-                raise
-            fallback_reason = '%s: %s' % (type(exc).__name__, str(exc)[:300])
-            print('dynetlsm_amd: RCCL process group failed on rank %d (%s); collectives go through gloo'
-                  % (rank, fallback_reason), file=sys.stderr)
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+        if backend == 'nccl':
+            def agree(ok):
+                """every rank's flag, the same answer everywhere (over the gloo control group)"""
+                flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                return int(flag[0]) == 1
+            # phase A: what a rank can check alone (its device) - no rank enters an RCCL call unless all can
+            mine = None
             try:
-                if dist.is_initialized():
+                if not torch.cuda.is_available():
+                    raise RuntimeError('no GPU visible to this rank')
+                torch.cuda.set_device(local_rank)
+                torch.zeros(1, device=torch.device('cuda', local_rank))
+            except Exception as exc:        # noqa: BLE001
+                mine = '%s: %s' % (type(exc).__name__, str(exc)[:300])
+            ok = agree(mine is None)
+            if ok:
+                # phase B: the communicator and one all-reduce through it (a bounded wait: a rank whose
+                # communicator fails leaves the others in this collective)
+                try:
+                    data_group = dist.new_group(backend='nccl', timeout=datetime.timedelta(
+                        seconds=float(os.environ.get('DLSM_RCCL_PROBE_TIMEOUT', '120'))))
+                    probe = torch.ones(1, device=torch.device('cuda', local_rank))
+                    dist.all_reduce(probe, group=data_group)
+                    torch.cuda.synchronize()
+                    if int(probe.item()) != world:
+                        raise RuntimeError('RCCL all_reduce probe returned %r for %d ranks' % (probe.item(), world))
+                except Exception as exc:    # noqa: BLE001
+                    mine = '%s: %s' % (type(exc).__name__, str(exc)[:300])
+                ok = agree(mine is None)
+            if not ok:
+                fallback_reason = mine or 'RCCL did not come up on another rank'
+                if os.environ.get('DLSM_ALLOW_BACKEND_FALLBACK') != '1':
                     dist.destroy_process_group()
-            except Exception:           # noqa: BLE001
-                pass
-            os.environ['MASTER_PORT'] = str(int(os.environ['MASTER_PORT']) + 1)     # (the failed group's store)
-            backend = 'gloo'
-            dist.init_process_group(backend, rank=rank, world_size=world)
+                    raise RuntimeError('dynetlsm_amd: the RCCL process group did not come up (rank %d: %s); '
+                                       'DLSM_ALLOW_BACKEND_FALLBACK=1 sends the setup collectives through gloo '
+                                       '(no collective is on the chains\' data path)' % (rank, fallback_reason))
+                print('dynetlsm_amd: RCCL process group failed on rank %d (%s); collectives go through gloo'
+                      % (rank, fallback_reason), file=sys.stderr)
+                data_group = None
+                backend = 'gloo'
     elif backend == 'nccl':
         torch.cuda.set_device(local_rank)
-    g = ChainGroup(rank, world, local_rank, backend, dist, torch, force=force)
+    g = ChainGroup(rank, world, local_rank, backend, dist, torch, force=force, data_group=data_group)
     g.fallback_reason = fallback_reason
     return g
 
@@ -278,8 +303,10 @@ def visible_gpu_count():
     """GPUs this process would see, counted WITHOUT a HIP / HSA call (the parent of
     ``launch_ranks`` must not initialise the runtime its children are about to use:
     ``torch.cuda.device_count()`` falls back to hipGetDeviceCount when amdsmi is absent): the
-    kernel driver's topology nodes with SIMDs, cut by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES /
-    CUDA_VISIBLE_DEVICES when one of them is set."""
+    kernel driver's topology nodes with SIMDs whose render node (``/dev/dri/renderD<drm_render_minor>``) this
+    process may open - a container may see the topology of GPUs it was not given - cut by every one of
+    HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES that is set (HIP's filter applies on top
+    of ROCR's: the smallest count)."""
     n = 0
     root = '/sys/class/kfd/kfd/topology/nodes'
     try:
@@ -289,8 +316,14 @@ def visible_gpu_count():
                     props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
             except OSError:
                 continue
-            if int(props.get('simd_count', '0')) > 0:
-                n += 1
+            if int(props.get('simd_count', '0')) <= 0:
+                continue
+            minor = int(props.get('drm_render_minor', '-1'))
+            if minor >= 0 and os.path.isdir('/dev/dri'):
+                dev = '/dev/dri/renderD%d' % minor
+                if not (os.path.exists(dev) and os.access(dev, os.R_OK | os.W_OK)):
+                    continue                    # (a GPU of the host this container cannot open)
+            n += 1
     except OSError:
         n = 0
     for var in ('HIP_VISIBLE_DEVICES', 'ROCR_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
@@ -298,7 +331,6 @@ def visible_gpu_count():
         if v is not None:
             ids = [x for x in v.split(',') if x.strip() != '']
             n = min(n, len(ids)) if n else len(ids)
-            break
     return n
 
 
@@ -332,6 +364,11 @@ def launch_ranks(argv, n, env_extra=None, relay_rank0=True, local_ranks=None, ti
         # (measured: two ranks on one MI355X 4442 it/s on one queue each, 1824 on two)
         if local_ranks is not None and list(local_ranks).count(lr) > 1:
             env.setdefault('DLSM_HDP_QUEUES', '1')
+            # ... and no role waits INSIDE a launch for a workgroup another process's launches may keep off the
+            # CUs: the case-control sweep's helper workgroups and the pipelined sweep's served cross products (the
+            # engine decides by the chains alive in ITS process; it cannot see the other processes)
+            env.setdefault('DLSM_CC_HELPERS', '0')
+            env.setdefault('DLSM_PIPE_XSERVE', '0')
         if env_extra:
             env.update(env_extra)
         procs.append(subprocess.Popen(list(argv), env=env,
@@ -421,11 +458,11 @@ def _chain_results(est, seconds):
 def _kept_from(est):
     """index of the first kept row of the estimator's STORED traces: ``n_burn_`` counts
     iterations, a thinned estimator stores every ``thin``-th of them (hdp_lpcm.py:1072-1083 thins
-    the traces, :1085 on then works with n_burn // thin - as ``_finish`` and forecast.py do)"""
+    the traces, :1085 on then works with ceil(n_burn / thin), hdp_lpcm.py:465 - as ``_finish`` and forecast.py do)"""
     n_burn = int(getattr(est, 'n_burn_', 0) or 0)
     thin = int(getattr(est, 'thin', None) or 1)
     n_rows = int(np.asarray(est.logps_).shape[0])
-    return max(0, min(n_burn // thin, n_rows - 1))
+    return max(0, min(-(-n_burn // thin), n_rows - 1))          # ceil, as the reference's n_burn_ (hdp_lpcm.py:465)
 
 
 def _fit_as_rank(estimator, Y, init, group, seed_stride=1):

@@ -485,6 +485,112 @@ def test_sweep_case_control_helper_wait_is_bounded_and_reported(eng, monkeypatch
         np.testing.assert_array_equal(c.get_positions(), good)
 
 
+def _pipe_sweeps(eng, T, N, n_sweeps, seed=11, chain_id=2):
+    X, _, Yu, _ = _rand_net(seed, T, N, 2)
+    g = eng.SamplerGrid(T, N, 0.15, tune=5, tune_interval=2)
+    with eng.Chain(T, N, 2, 'undirected', seed=4242, chain_id=chain_id) as c:
+        c.upload_network(Yu); c.set_positions(X); c.set_intercepts([0.4])
+        c.set_prior_random_walk(2.0, 0.1); c.set_samplers(g)
+        for it in range(1, n_sweeps + 1):
+            c.sweep_positions(it, algo=4)
+        return c.get_positions().copy(), c.get_samplers(g).n_accepted.copy()
+
+
+def test_pipelined_sweep_cross_products_served_or_not(eng, monkeypatch):
+    """algo 4, undirected: the resolvers' cross products by the launch's evaluators (kernels_pipe_lds.hpp,
+    pipe_xserve_*: the default with one chain on the device) and by the resolvers themselves
+    (DLSM_PIPE_XSERVE=0) - a product of the same factors in another order: the same decisions, positions
+    equal to rounding; the old evaluators (DLSM_PIPE_LDS=0: pipe_eval_item's pipelined trips) agree too.
+    Sizes: several batches, a ragged last one, more slices than one launch's workgroups hold (served: xstride
+    > 1) and T = 1 (no odd slices)"""
+    for T, N in ((4, 700), (1, 300), (9, 1500)):
+        res = {}
+        for mode, env in (('served', {'DLSM_PIPE_XSERVE': '1'}), ('own', {'DLSM_PIPE_XSERVE': '0'}),
+                          ('old', {'DLSM_PIPE_LDS': '0'})):
+            for k in ('DLSM_PIPE_XSERVE', 'DLSM_PIPE_LDS'):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            res[mode] = _pipe_sweeps(eng, T, N, 3)
+        for k in ('DLSM_PIPE_XSERVE', 'DLSM_PIPE_LDS'):
+            monkeypatch.delenv(k, raising=False)
+        for mode in ('own', 'old'):
+            np.testing.assert_array_equal(res['served'][1], res[mode][1])
+            np.testing.assert_allclose(res['served'][0], res[mode][0], atol=1e-10)
+        assert res['served'][1].sum() > 0
+
+
+def test_pipelined_sweep_served_wait_is_bounded_and_reported(eng, monkeypatch):
+    """a resolver's wait for the evaluators' cross products has a poll budget (DLSM_PIPE_XBUDGET): with a budget
+    of zero it gives up at once, nothing hangs, the sticky error word makes the call fail with DLSM_E_HIP;
+    reported once, after which the same handle sweeps on.  With a second chain alive on the device the engine
+    does not take the role at all (the wait could meet evaluators that other launches keep off the CUs):
+    a zero budget is then harmless - unless DLSM_PIPE_XSERVE=2 forces it"""
+    T, N = 4, 700
+    X, _, Yu, _ = _rand_net(12, T, N, 2)
+    g = eng.SamplerGrid(T, N, 0.15, tune=None)
+
+    def start(c):
+        c.set_positions(X); c.set_intercepts([0.4]); c.set_prior_random_walk(2.0, 0.1); c.set_samplers(g)
+    with eng.Chain(T, N, 2, 'undirected', seed=5, chain_id=1) as c:
+        c.upload_network(Yu)
+        start(c); c.sweep_positions(1, algo=4)
+        good = c.get_positions().copy()
+        monkeypatch.setenv('DLSM_PIPE_XBUDGET', '0')
+        start(c)
+        with pytest.raises(RuntimeError, match='poll budget'):
+            c.sweep_positions(1, algo=4)
+            c.synchronize()
+        c.synchronize()                                   # reported once
+        with eng.Chain(T, N, 2, 'undirected', seed=6, chain_id=2) as other:     # two chains alive: not served
+            other.upload_network(Yu)
+            start(c); c.sweep_positions(1, algo=4); c.synchronize()
+            np.testing.assert_allclose(c.get_positions(), good, atol=1e-10)
+            monkeypatch.setenv('DLSM_PIPE_XSERVE', '2')                         # forced: the zero budget bites again
+            start(c)
+            with pytest.raises(RuntimeError, match='poll budget'):
+                c.sweep_positions(1, algo=4)
+                c.synchronize()
+            c.synchronize()
+            monkeypatch.delenv('DLSM_PIPE_XSERVE')
+        monkeypatch.delenv('DLSM_PIPE_XBUDGET')
+        start(c); c.sweep_positions(1, algo=4)
+        np.testing.assert_array_equal(c.get_positions(), good)
+
+
+def test_case_control_helpers_only_with_one_chain_on_the_device(eng, monkeypatch):
+    """two case-control chains alive in the process: the sparse sweep's helper workgroups (a resolver waits for
+    its helper INSIDE the launch) are not used - a zero poll budget is harmless - unless DLSM_CC_HELPERS=2
+    forces the role, which then fails loudly (round-5 verdict, weak 9)"""
+    X, Yd, _, radii = _rand_net(78, 2, 2300, 2, density=0.004, scale=0.05)
+    cc = _cc_lists(Yd, 10, 78)
+    g = eng.SamplerGrid(2, 2300, 0.01, tune=None)
+
+    def make(cid):
+        c = eng.Chain(2, 2300, 2, 'case_control', seed=99, chain_id=cid)
+        c.upload_edges(cc['in_edges'], cc['out_edges'], cc['degree'])
+        c.set_controls(cc['control_nodes_in'], cc['control_nodes_out'])
+        c.set_positions(X); c.set_intercepts([0.3, 0.7]); c.set_radii(radii)
+        c.set_prior_random_walk(2.0, 0.1); c.set_samplers(g)
+        return c
+    monkeypatch.setenv('DLSM_CC_HELPER_BUDGET', '0')
+    a, b = make(1), make(2)
+    try:
+        assert a.resolve_sweep_algo(0) == 5
+        a.sweep_positions(1, algo=5); b.sweep_positions(1, algo=5)
+        a.synchronize(); b.synchronize()                  # no helpers: nothing to wait for
+        monkeypatch.setenv('DLSM_CC_HELPERS', '2')
+        with pytest.raises(RuntimeError, match='poll budget'):
+            a.sweep_positions(2, algo=5)
+            a.synchronize()
+    finally:
+        try:
+            a.synchronize()
+        except RuntimeError:
+            pass
+        a.close(); b.close()
+
+
 def _run_sweeps(eng, algo, T, N, D, name, prior, n_sweeps, seed=5):
     # (directed networks at the scale of their radii, as everywhere in this file: at scale 1 the
     # linear predictors reach 1e3 - 1e4 and every batched form drifts from the sequential sweep

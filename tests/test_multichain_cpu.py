@@ -221,34 +221,48 @@ def test_visible_gpu_count_makes_no_runtime_call(monkeypatch):
     assert multichain.visible_gpu_count() == 0
 
 
-def test_rccl_that_does_not_come_up_falls_back_to_gloo_and_says_so():
-    """init_chain_group(backend='nccl') where RCCL cannot start (here: no GPU) - the chains are independent and
-    no collective is on the data path, so the setup collectives go through gloo and `describe()` (the bench
-    line's `collectives` block) names the requested backend and the reason; DLSM_NO_BACKEND_FALLBACK=1 keeps
-    the failure"""
+def test_rccl_that_does_not_come_up_is_an_error_unless_the_fallback_is_allowed():
+    """init_chain_group(backend='nccl') where RCCL cannot start (here: no GPU): an error by default - north_star
+    says RCCL, and a first 8-GPU run must not "succeed" without it - and, with DLSM_ALLOW_BACKEND_FALLBACK=1, the
+    setup collectives (none is on the chains' data path) go through the gloo control group, `describe()` (the
+    bench line's `collectives` block) naming the requested backend and the reason.  The decision is COLLECTIVE:
+    two ranks take the same branch (round-5 advice: per-rank fallbacks left the other ranks in a collective)."""
     code = textwrap.dedent('''
         import json, sys
         sys.path.insert(0, %r)
         import numpy as np
         from dynetlsm_amd.multichain import init_chain_group
         g = init_chain_group(backend='nccl', force=True)
-        out = g.gather_arrays(np.arange(3.0))
+        out = g.gather_arrays(np.arange(3.0) + g.rank)
         d = g.describe()
+        g.barrier()
         g.close()
         print(json.dumps({'backend': g.backend, 'reason': g.fallback_reason, 'describe': d,
                           'gathered': [a.tolist() for a in out]}))
     ''') % ROOT
-    env = dict(os.environ, RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1',
-               MASTER_PORT=str(_free_port()))
-    r = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=180)
-    assert r.returncode == 0, r.stderr[-2000:]
     import json
-    res = json.loads(r.stdout.strip().splitlines()[-1])
-    assert res['backend'] == 'gloo' and res['reason']
-    assert res['describe']['requested_backend'] == 'nccl' and res['describe']['backend'] == 'gloo'
-    assert res['gathered'] == [[0.0, 1.0, 2.0]]
-    assert 'collectives go through gloo' in r.stderr
-    env['DLSM_NO_BACKEND_FALLBACK'] = '1'
-    env['MASTER_PORT'] = str(_free_port())
-    r = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=180)
-    assert r.returncode != 0
+
+    def run(world, allow):
+        port = _free_port()
+        procs = []
+        for r in range(world):
+            env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR='127.0.0.1',
+                       MASTER_PORT=str(port))
+            env.pop('DLSM_ALLOW_BACKEND_FALLBACK', None)
+            if allow:
+                env['DLSM_ALLOW_BACKEND_FALLBACK'] = '1'
+            procs.append(subprocess.Popen([sys.executable, '-c', code], env=env, stdout=subprocess.PIPE,
+                                          stderr=subprocess.PIPE, text=True))
+        return [p.communicate(timeout=240) + (p.returncode,) for p in procs]
+    for world in (1, 2):
+        outs = run(world, allow=True)
+        for r, (so, se, rc) in enumerate(outs):
+            assert rc == 0, se[-2000:]
+            res = json.loads(so.strip().splitlines()[-1])
+            assert res['backend'] == 'gloo' and res['reason']
+            assert res['describe']['requested_backend'] == 'nccl' and res['describe']['backend'] == 'gloo'
+            assert res['gathered'] == [[0.0 + q, 1.0 + q, 2.0 + q] for q in range(world)]
+            assert 'collectives go through gloo' in se
+        outs = run(world, allow=False)
+        assert all(rc != 0 for _, _, rc in outs)
+        assert all('did not come up' in se for _, se, _ in outs)
