@@ -27,9 +27,14 @@ def eng():
     return dynetlsm_amd
 
 
-@pytest.fixture(scope='module')
-def c4_tables():
-    from dynetlsm_amd.synthetic import synthetic_sparse_directed
+@pytest.fixture(scope='module', params=['degree_regular', 'model'])
+def c4_tables(request):
+    """both timing networks of bench.py: every node's 20 out-neighbours drawn uniformly (rounds 1-5), and a network
+    drawn from the model (skewed degrees: term rows of unequal length, sorted rows - cc_rows.hpp)"""
+    from dynetlsm_amd.synthetic import synthetic_sparse_directed, synthetic_directed_from_model
+    if request.param == 'model':
+        net = synthetic_directed_from_model(T, N, 20.0, seed=0)
+        return net['X'], net['radii'], net['degree'], net['in_edges'], net['out_edges']
     return synthetic_sparse_directed(T, N, 20, 0)
 
 
@@ -141,7 +146,7 @@ def test_c4_two_chains_agree_at_full_size(eng):
     from mcmc_diag import mcse
     net = synthetic_directed_from_model(T, N, 20.0, seed=0)
     w = net['width']
-    n_burn, n_keep, n_res = 10000, 16000, 100
+    n_burn, n_keep, n_res = 20000, 40000, 100
     n_total = 1 + n_burn + n_keep
     rs = np.random.RandomState(1)
     X0 = net['X'] + 0.05 * w * rs.randn(*net['X'].shape)
@@ -195,6 +200,9 @@ def test_c4_two_chains_agree_at_full_size(eng):
              net['intercepts'][1], acc, cfg.i_n_accepted[0], cfg.i_n_accepted[1], cfg.r_n_accepted))
     assert r['logp'] < 1.05, r
     assert r2['b_in'] < 1.25 and r2['b_out'] < 1.25, (r2, r)
+    # round 6: 2 x 60 000 iterations - the intercepts' SPLIT R-hat asserted, not printed (round-5 verdict, next 3;
+    # profiles/posterior_cold_start.py c4long: 1.09 at 40 000 kept iterations)
+    assert r['b_in'] < 1.15 and r['b_out'] < 1.15, r
     for x in (b_in, b_out):
         d = abs(x[0].mean() - x[1].mean())
         e0, e1 = mcse(x[0], maxlags=2000), mcse(x[1], maxlags=2000)
@@ -202,3 +210,80 @@ def test_c4_two_chains_agree_at_full_size(eng):
     # every block of the loop moves: positions, both intercepts, radii
     assert 0.1 < acc < 0.6, acc
     assert min(cfg.i_n_accepted[0], cfg.i_n_accepted[1], cfg.r_n_accepted) > 0.05 * (n_burn + n_keep)
+
+
+def test_case_control_intercept_offset_is_the_estimators(eng):
+    """Config 4's chains agree with each other but sit well above the generating intercepts (T=5 N=10 000: b_in
+    0.387 for 0.30, ten posterior sd; round-5 verdict, weak 2).  At T=5 N=2000, where the exact directed model is
+    affordable, on ONE network drawn from the model and from one starting point:
+
+      * the EXACT model (k_loglik_directed / the pipelined directed sweep) recovers (b_in, b_out) within
+        4 (sd + Monte Carlo error);
+      * the case-control model with EXHAUSTIVE controls (n_control = N - 1: weight (N - deg - 1) / n_control = 1,
+        directed_likelihoods_fast.pyx:208-270) is the exact model - the same Philox draws give the same decisions:
+        its trace equals the exact chain's to rounding, iteration by iteration;
+      * with n_control = 100 (config 4's, and the reference's, estimator: 100 of ~1980 non-neighbours, out-controls
+        only in the full likelihood) both intercepts move UP, by +0.02 .. +0.03 (three posterior sd of that chain):
+        the offset belongs to the estimator, not to the engine.  Asserted as a regression band
+        (profiles/c4_intercept_offset.py prints the three pairs of chains)."""
+    from dynetlsm_amd.synthetic import synthetic_directed_from_model
+    from mcmc_diag import mcse
+    Ts, Ns = 5, 2000
+    net = synthetic_directed_from_model(Ts, Ns, 20.0, seed=0)
+    w = net['width']
+    gen = np.asarray(net['intercepts'])
+    rs = np.random.RandomState(1)
+    X0 = net['X'] + 0.05 * w * rs.randn(*net['X'].shape)
+
+    def run(kind, n_burn, n_keep, cid=0):
+        n_total = 1 + n_burn + n_keep
+        ch = eng.Chain(Ts, Ns, 2, 'directed' if kind == 'exact' else 'case_control', seed=SEED, chain_id=cid)
+        try:
+            Cc = None
+            if kind == 'exact':
+                Y = np.zeros((Ts, Ns, Ns))
+                for t in range(Ts):
+                    for i in range(Ns):
+                        Y[t, i, net['out_edges'][t, i, :net['degree'][t, i, 1]]] = 1.0
+                ch.upload_network(Y)
+            else:
+                Cc = Ns - 1 if kind == 'exhaustive' else 100
+                ch.upload_edges(net['in_edges'], net['out_edges'], net['degree'])
+                ch.resample_controls(0, Cc)
+            ch.set_positions(X0); ch.set_radii(net['radii']); ch.set_intercepts(gen)
+            ch.set_prior_random_walk(w * w, (0.1 * w) ** 2)
+            ch.set_samplers(eng.SamplerGrid(Ts, Ns, step_size=0.02 * w, tune=n_burn, tune_interval=100))
+            ch.lsm_configure(gen, 2.0, step_size_intercept=0.01, tune=n_burn, tune_interval=100, n_iter_procrustes=0,
+                             sweep_algo=0, step_size_radii=175000., radii_tune=n_burn, radii_tune_interval=100)
+            ch.trace_alloc(n_total, logp0=0.0)
+            it = 1
+            while it < n_total:
+                nxt = min(n_total, (it // 100 + 1) * 100)
+                if kind == 'cc100' and it % 100 == 0:
+                    ch.resample_controls(it, Cc)
+                ch.lsm_run(it, nxt - it, procrustes_ref=0)
+                it = nxt
+            ch.synchronize()
+            _, ics, lps = ch.trace_read(1, n_total - 1, positions=False)
+            return ics.copy()
+        finally:
+            ch.close()
+    n_burn, n_keep = 6000, 10000
+    t0 = time.perf_counter()
+    exact = run('exact', n_burn, n_keep)
+    # exhaustive controls: the exact chain, value for value (a shorter run is enough to show it)
+    exh = run('exhaustive', 1000, 500)
+    np.testing.assert_allclose(exh, run('exact', 1000, 500), rtol=0, atol=1e-9)
+    cc = run('cc100', n_burn, n_keep)
+    rep = {}
+    for name, tr in (('exact', exact), ('cc100', cc)):
+        k = tr[n_burn:]
+        rep[name] = [(float(k[:, j].mean()), float(k[:, j].std()), float(mcse(k[:, j], maxlags=2000))) for j in range(2)]
+    print('intercept offset at T=%d N=%d (generating %s): %s; %.1f s' % (Ts, Ns, gen, rep, time.perf_counter() - t0))
+    for j in range(2):
+        m, sd, e = rep['exact'][j]
+        assert abs(m - gen[j]) < 4 * (sd + e), ('exact', j, m, sd, e)
+    # the estimator's offset (measured: b_in +0.024 / +0.031, b_out +0.022 / +0.027 for two chain ids)
+    d_in, d_out = rep['cc100'][0][0] - gen[0], rep['cc100'][1][0] - gen[1]
+    assert 0.008 < d_in < 0.06 and 0.004 < d_out < 0.07, (d_in, d_out, rep)
+    assert d_in > 2 * (rep['exact'][0][1] + rep['exact'][0][2]), (d_in, rep)

@@ -487,7 +487,7 @@ def test_sweep_case_control_helper_wait_is_bounded_and_reported(eng, monkeypatch
 
 def _pipe_sweeps(eng, T, N, n_sweeps, seed=11, chain_id=2):
     X, _, Yu, _ = _rand_net(seed, T, N, 2)
-    g = eng.SamplerGrid(T, N, 0.15, tune=5, tune_interval=2)
+    g = eng.SamplerGrid(T, N, 0.15, tune=None)
     with eng.Chain(T, N, 2, 'undirected', seed=4242, chain_id=chain_id) as c:
         c.upload_network(Yu); c.set_positions(X); c.set_intercepts([0.4])
         c.set_prior_random_walk(2.0, 0.1); c.set_samplers(g)
