@@ -33,6 +33,8 @@
 using namespace dlsm;
 
 static thread_local std::string g_err;
+static int32_t *g_fix_err_host = nullptr;       // CC_ERR_FIXPOINT's word (kernels_ccpipe.hpp), one per process and device
+static int g_fix_err_device = -1;
 static std::atomic<int> g_live_chains{0};       // handles alive in this process (capi_hdp.hpp, hdp_fork_arm)
 
 #define FAIL(h, code, ...)                                      \
@@ -401,6 +403,19 @@ int dlsm_create(int device, int T, int N, int D, int model, uint64_t seed,
         h->stage = nullptr;                     // the copies then take the runtime's path
     // the sticky error word of the in-kernel waits (the HDP-LPCM loop's two queues, the case-control sweep's
     // helper workgroups): host memory the device can store to, read by the host without a copy
+    if (model == DLSM_DIRECTED_CASE_CONTROL && (!g_fix_err_host || g_fix_err_device != device)) {
+        // (the first case-control chain of the process on this device; a second device re-points the word)
+        int32_t *hostw = g_fix_err_host, *devw = nullptr;
+        if (!hostw && hipHostMalloc((void **)&hostw, 64, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) hostw = nullptr;
+        if (hostw) {
+            if (!g_fix_err_host) memset(hostw, 0, 64);
+            if (hipHostGetDevicePointer((void **)&devw, hostw, 0) == hipSuccess &&
+                hipMemcpyToSymbol(HIP_SYMBOL(g_cc_fixpoint_err), &devw, sizeof(devw)) == hipSuccess) {
+                g_fix_err_host = hostw; g_fix_err_device = device;
+            }
+        }
+        (void)hipGetLastError();
+    }
     if (hipHostMalloc((void **)&h->fork_err_host, 64, hipHostMallocMapped) == hipSuccess) {
         memset(h->fork_err_host, 0, 64);
         if (hipHostGetDevicePointer((void **)&h->fork_err_dev, h->fork_err_host, 0) != hipSuccess) h->fork_err_dev = nullptr;
@@ -1062,6 +1077,12 @@ static void launch_pipe_step(dlsm_chain *h, const ChainView &v, const PipeBuf &p
 
 // the sticky error word: a bounded in-kernel wait ran out of its budget
 static int check_pipe_err(dlsm_chain *h) {
+    if (g_fix_err_host && *(volatile int32_t *)g_fix_err_host != 0) {
+        const int32_t e = *(volatile int32_t *)g_fix_err_host;
+        *(volatile int32_t *)g_fix_err_host = 0;
+        FAIL(h, DLSM_E_HIP, "case-control sweep: a resolver's fixed point did not settle inside its spin bound "
+             "(word %#x) - the state of this process's case-control chains is undefined; set it again", e);
+    }
     if (h->fork_err_host) {
         // (behind a synchronisation of the handle's stream: the word is host memory the device stores to)
         const int32_t e = *(volatile int32_t *)h->fork_err_host;
@@ -1071,9 +1092,6 @@ static int check_pipe_err(dlsm_chain *h) {
                 FAIL(h, DLSM_E_HIP, "pipelined sweep: a resolver ran out of its poll budget waiting for a cross product "
                      "from the launch's evaluators (word %#x) - the chain's state is undefined; set the state again "
                      "and run with DLSM_PIPE_XSERVE=0", e);
-            if (e & CC_ERR_FIXPOINT)
-                FAIL(h, DLSM_E_HIP, "case-control sweep: a resolver's fixed point did not settle inside its spin bound "
-                     "(word %#x) - the chain's state is undefined; set the state again", e);
             if (e & CC_ERR_HELPER)
                 FAIL(h, DLSM_E_HIP, "case-control sweep: a resolver ran out of its poll budget waiting for its helper "
                      "workgroup (word %#x) - the chain's state is undefined; set the state again and run with "

@@ -60,6 +60,8 @@ struct CcPipeBuf {
 };
 constexpr int CC_ERR_HELPER = 1 << 30;
 constexpr int CC_ERR_FIXPOINT = 1 << 28;    // a resolver's fixed point did not settle inside its spin bound
+// the process's word for it (mapped host memory; set by the first dlsm_create, read by check_pipe_err)
+__device__ int32_t *g_cc_fixpoint_err = nullptr;
 // "no sum yet": a NaN payload no arithmetic produces (the hardware's own NaN is 0x7FF8000000000000, and the
 // entries that are summed carry no payloads)
 constexpr unsigned long long CC_XS_EMPTY = 0x7FF8C0DE5EED0001ull;
@@ -561,9 +563,13 @@ __device__ __forceinline__ void ccpipe_resolve(const ChainView &c, const CcPipeB
             cts[6] += 1;
 #endif
         }
-        // the spin bound ran out: the mask a wavefront holds is NOT the fixed point - say so (sticky error word)
-        if (!settled && lane == 0 && pb.err)
-            __hip_atomic_fetch_or(pb.err, CC_ERR_FIXPOINT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        // the spin bound ran out: the mask a wavefront holds is NOT the fixed point - say so.  (Through a pointer
+        // held in device memory, read here only: the launch's own error word, pb.err, kept alive across this loop
+        // cost the kernel its last scalar registers - 36 bytes of scratch in every instantiation.)
+        if (!settled && lane == 0) {
+            int32_t *w = g_cc_fixpoint_err;
+            if (w) __hip_atomic_fetch_or(w, CC_ERR_FIXPOINT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 #undef CC_LD64
 #undef CC_LD32

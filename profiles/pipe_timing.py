@@ -8,10 +8,12 @@ wavefronts relative to the launch's earliest stamp.
           -o tmp_timing/libtiming.so dynetlsm_amd/csrc/capi.hip
     python profiles/pipe_timing.py tmp_timing/libtiming.so [out.json [sweep algo: 4 | 6]]
 
-Evaluator stamps: 0 entry, 1 first trip of 64 neighbours done (its operands have arrived),
-2 last prefetched trip done, 3 wavefront reductions + record stored, 4 first H entry's operands
-arrived, 5 exit.  Resolver stamps: 0 entry, 1 H block + records in LDS, 2 cross block applied,
-3 fixed point reached, 4 exit.
+Evaluator stamps (round 6, kernels_pipe_lds.hpp; reported in this order): kernel start (the wavefront's first
+instruction), rows + table staged (behind the workgroup's barrier; a serving wavefront: behind its cross product),
+first trip of 64 neighbours done, last trip done, record stored (= exit: the H factors left inside their trips).
+(DLSM_PIPE_LDS=0, pipe_eval_item: slot order entry behind the table's barrier, first trip, last prefetched trip,
+record stored, kernel start, exit.)  Resolver stamps: 0 entry, 1 H block + records in LDS, 2 cross products
+applied, 3 fixed point reached, 4 exit.
 """
 import ctypes as C
 import json
@@ -61,7 +63,9 @@ for l in range(24):
     t0 = min([x[:, 0].min() for x in (it, rs) if x.size])
     row = {'launch': l, 'evaluator_wavefronts': int(it.shape[0]), 'resolver_workgroups': int(rs.shape[0])}
     if it.size:
-        # a stamp of 0 (no H entry for this lane 0) -> nan
+        if not os.environ.get('DLSM_PIPE_LDS') == '0':
+            it = it[:, [0, 4, 1, 2, 3, 5]]          # the LDS evaluators' slots in time order
+        # a stamp of 0 -> nan
         rel = np.where(it > 0, (it - t0) * 0.01, np.nan)
         row['evaluator_us_median'] = [round(float(np.nanmedian(rel[:, i])), 2) for i in range(6)]
         row['evaluator_us_max'] = [round(float(np.nanmax(rel[:, i])), 2) for i in range(6)]
@@ -80,6 +84,9 @@ it = items[8].astype(np.int64)
 ok = it[:, 0] > 0
 t0 = it[ok, 0].min()
 names = ['entry', 'first trip done', 'last prefetched trip done', 'record stored', 'H operands here', 'exit']
+if not os.environ.get('DLSM_PIPE_LDS') == '0':
+    names = ['kernel start', 'rows + table staged', 'first trip done', 'last trip done', 'record stored', '= exit']
+    it = it[:, [0, 4, 1, 2, 3, 5]]
 for rank in range(4):
     sel = ok & ((np.arange(4096) % 16) // 4 == rank)
     rel = np.where(it[sel] > 0, (it[sel] - t0) * 0.01, np.nan)
