@@ -1059,6 +1059,7 @@ def run_rank(args):
     models = ['lsm', 'hdp', 'cc', 'ccu'] if args.model == 'all' else [args.model]
     lines = []
     def run_model(name, args=args):
+            K, W = args.steps, args.warmup          # (the extra configurations pass their own window)
             wl = {'lsm': LsmWorkload, 'hdp': HdpWorkload, 'cc': CcWorkload,
                   'ccu': CcUniformWorkload}[name](args, group, local_rank)
             elapsed, roofline, extra, acc, gathered = measure(wl, args, group)

@@ -320,9 +320,9 @@ int launch_loglik_records(dlsm_chain *h, int M, const double *d_ic,
         }
         // out-edges and out-controls as dense 64-term trips from the node's row (cc_rows.hpp)
         { int rc3 = ensure_cc_rows(h); if (rc3) return rc3; }
-        if (M == 1) hipLaunchKernelGGL((k_loglik_casecontrol_rows<DD, 1>), dim3(nb), dim3(LLCR_THREADS), 0, h->stream, v, cand, h->xr, h->cc_terms, h->cc_tw, h->partials, rslot);
-        else if (M == 4) hipLaunchKernelGGL((k_loglik_casecontrol_rows<DD, 4>), dim3(nb), dim3(LLCR_THREADS), 0, h->stream, v, cand, h->xr, h->cc_terms, h->cc_tw, h->partials, 0);
-        else hipLaunchKernelGGL((k_loglik_casecontrol_rows<DD, 2>), dim3(nb), dim3(LLCR_THREADS), 0, h->stream, v, cand, h->xr, h->cc_terms, h->cc_tw, h->partials, 0);
+        if (M == 1) hipLaunchKernelGGL((k_loglik_casecontrol_rows<DD, 1>), dim3(nb / h->T, h->T), dim3(LLCR_THREADS), 0, h->stream, v, cand, h->xr, h->cc_terms, h->cc_tw, h->partials, rslot);
+        else if (M == 4) hipLaunchKernelGGL((k_loglik_casecontrol_rows<DD, 4>), dim3(nb / h->T, h->T), dim3(LLCR_THREADS), 0, h->stream, v, cand, h->xr, h->cc_terms, h->cc_tw, h->partials, 0);
+        else hipLaunchKernelGGL((k_loglik_casecontrol_rows<DD, 2>), dim3(nb / h->T, h->T), dim3(LLCR_THREADS), 0, h->stream, v, cand, h->xr, h->cc_terms, h->cc_tw, h->partials, 0);
     }
     HIPCHK(h, hipGetLastError());
     *nrec_out = nb;

@@ -535,8 +535,11 @@ __global__ __launch_bounds__(LLCR_THREADS) void k_loglik_casecontrol_rows(
     // Workgroup -> (slice, batch, 8 such pairs): T ceil(N / 16) workgroups, as ll_blocks() counts them)
     long node[NPW], who[NPW];
     static_assert(NPW == 2 && CC_SORT_B % LLCC_NODES == 0, "pairs of rows, whole workgroups per batch");
-    const int wps = (c.N + LLCC_NODES - 1) / LLCC_NODES;
-    const int sl = (int)blockIdx.x / wps, ws = (int)blockIdx.x - sl * wps;
+    // (grid (ceil(N / 16), T): a quotient by a launch constant in the prologue of every wavefront was part of what
+    // the first sorted-row form lost - 73 against 69 us for the four-candidate pass on the degree-regular network)
+    const int wps = (int)gridDim.x;
+    const int sl = (int)blockIdx.y, ws = (int)blockIdx.x;
+    const int lin = sl * wps + ws;                      // the workgroup's record
     const int bj0 = (ws / (CC_SORT_B / LLCC_NODES)) * CC_SORT_B, bnb = min(CC_SORT_B, c.N - bj0);
     const int pi = (ws % (CC_SORT_B / LLCC_NODES)) * NWV + wave;
     int outdeg[NPW], nt[NPW], e[NPW][NS];
@@ -660,7 +663,7 @@ __global__ __launch_bounds__(LLCR_THREADS) void k_loglik_casecontrol_rows(
     if (tid < M) {
         double s = 0.0;
         for (int w = 0; w < NWV; ++w) s += sRed[w * M + tid];
-        partials[(size_t)blockIdx.x * M + tid] = s;
+        partials[(size_t)lin * M + tid] = s;
     }
 }
 
