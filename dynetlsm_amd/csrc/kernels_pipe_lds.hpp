@@ -148,12 +148,9 @@ __device__ __forceinline__ void pipe_lds_trips(int nw64, int P, const PipePlan &
     // first trip behind the window's: rank pl.s of the other trips
     int g = pl.w > 0 ? pl.glo + p : (pl.s < pl.glo ? pl.s : pl.s + pl.nwin);   // (ym: its bits, requested by the caller)
     const int greg = pl.s < pl.glo ? pl.s : pl.s + pl.nwin;
-// the edges' linear term: under the lanes of "y = 1" (a select less per trip than lin += y (d0 - d1))
-#ifndef DLSM_LDS_LIN_FMA
-#define DLSM_LDS_LIN() if (yb) ra.lin += d0 - d1;
-#else
+// the edges' linear term: lin += y (d0 - d1) with y as a 0.0 / 1.0 select of one word (sub, select, fma: 49.5 vector
+// instructions per trip; "if (y) lin += d0 - d1" became sub, add and a two-word select: 50.5, C2 4903 against 4923 it/s)
 #define DLSM_LDS_LIN() ra.lin = fma(yb ? 1.0 : 0.0, d0 - d1, ra.lin);
-#endif
 #define DLSM_LDS_TERM()                                                                                   \
         const bool yb = __builtin_amdgcn_inverse_ballot_w64(ym);                                          \
         const double d0 = dist_fast<D>(xi, xk0, SQ ? 1 : 0);                                              \
