@@ -41,55 +41,15 @@ __device__ __forceinline__ unsigned long long scalar_load_u64(const unsigned lon
 #pragma clang diagnostic pop
 }
 
-constexpr int PL_WIN = 4;           // window trips a part can hold (P = 1: all four)
+}  // namespace dlsm
+#include "pipe_plan.hpp"        // PL_WIN, pipe_lds_trip_cap / _eval_bytes, PipePlan, pipe_plan_entry (plain C++)
+namespace dlsm {
+static_assert(PL_EXPTAB_DOUBLES == EXPTAB11_N, "pipe_plan.hpp sizes the LDS with the evaluators' exp table");
 
-// trips (and LDS rows) the longest part can hold
-__host__ __device__ inline int pipe_lds_trip_cap(int ntrip, int parts) { return (ntrip + parts - 1) / parts + PL_WIN; }
-// bytes of dynamic LDS the evaluators need: exp table, the longest part's rows, its window trips' proposals
-__host__ __device__ inline size_t pipe_lds_eval_bytes(int N, int D, int parts) {
-    const int ntrip = (N + 63) / 64;
-    return ((size_t)EXPTAB11_N + (size_t)(pipe_lds_trip_cap(ntrip, parts) + PL_WIN) * 64 * D) * sizeof(double);
-}
-
-// The trips of a node of batch `be` (its workgroup's first node k0) as P parts.  Window trips: [glo, glo + nwin)
-// = the previous batch's two (be > 0), trip 2 be of the own batch, and trip 2 be + 1 when the workgroup's nodes
-// reach into it (k0 >= 64); window trip i goes to part i mod P and is the part's trip i / P.  The other ntrip -
-// nwin trips, in ascending order, are cut into runs r_0 .. r_{P-1} with r_j + 2 w_j as equal as integers allow.
-// (w, r, s) depend on (nwin, p) only: the host computes the 4 P triples once (pipe_plan_entry) and the launch
-// carries them as kernel arguments (PipeBuf::plan) - the evaluators' row requests wait for nothing but a decode.
-struct PipePlan {
-    int glo, nwin;      // the window's trips
-    int w, r, s;        // this part: window trips, other trips, rank of its first other trip
-    __device__ __forceinline__ int trips() const { return w + r; }
-    __device__ __forceinline__ int trip(int u, int p, int P) const {      // the part's u-th trip
-        if (u < w) return glo + p + P * u;
-        const int rho = s + (u - w);
-        return rho < glo ? rho : rho + nwin;
-    }
-};
-// w | r << 3 | s << 16 of part p when the window holds nwin trips (1 .. 4) of ntrip
-inline uint32_t pipe_plan_entry(int ntrip, int P, int nwin, int p) {
-    auto wof = [&](int j) { return j < nwin ? (nwin - j + P - 1) / P : 0; };
-    const int R = ntrip - nwin, S = R + 2 * nwin;
-    const int q = S / P, rem = S % P;
-    const bool balanced = R >= 0 && q >= 2 * wof(0);             // (tiny N: plain runs of the other trips)
-    const int Rp = R > 0 ? R : 0;
-    int s = 0, w = 0, r = 0;
-    for (int j = 0; j <= p; ++j) {
-        const int wj = wof(j);
-        const int rj = balanced ? q + (j < rem ? 1 : 0) - 2 * wj : Rp / P + (j < Rp % P ? 1 : 0);
-        if (j < p) s += rj; else { w = wj; r = rj; }
-    }
-    return (uint32_t)w | ((uint32_t)r << 3) | ((uint32_t)s << 16);
-}
-__device__ __forceinline__ PipePlan pipe_plan(const PipeBuf &pb, int ntrip, int p, int be, int k0) {     // (pb: the kernel argument itself - a scalar load at a computed offset)
-    PipePlan pl;
-    pl.glo = be > 0 ? 2 * be - 2 : 0;
-    const int ghi = min(2 * be + (k0 >= 64 ? 1 : 0), ntrip - 1);
-    pl.nwin = ghi - pl.glo + 1;                                  // 1 .. 4 (trip 2 be exists: the batch has nodes)
-    const uint32_t e = pb.lds.plan[pl.nwin - 1][p];
-    pl.w = (int)(e & 7u); pl.r = (int)((e >> 3) & 0x1fffu); pl.s = (int)(e >> 16);
-    return pl;
+// (pb: the kernel argument itself - the plan entry is a scalar load at a computed offset)
+__device__ __forceinline__ PipePlan pipe_plan(const PipeBuf &pb, int ntrip, int p, int be, int k0) {
+    const int nwin = min(2 * be + (k0 >= 64 ? 1 : 0), ntrip - 1) - (be > 0 ? 2 * be - 2 : 0) + 1;
+    return pipe_plan_from_entry(pb.lds.plan[nwin - 1][p], ntrip, be, k0);
 }
 
 // the rest of H[k][m] from what the trip holds: a0 = d(m0, k0), a1 = d(m0, k1), their exponentials ea0, ea1
