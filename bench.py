@@ -1186,14 +1186,21 @@ def run_rank(args):
         # chains-per-GPU scaling is the sweep's defensible utilisation figure - config 2 again with four
         # chains on the GPU (one handle, stream and host thread each), the same window
         try:
-            import copy
-            a4 = copy.copy(args)
-            a4.chains_per_gpu = 4; a4.profile_steps = 0; a4.windows = 1
-            a4.steps = max(args.steps, 200)      # (four host threads: a 20-step window measures their start)
-            n0 = len(lines)
-            run_model('lsm', a4)
-            l4 = lines.pop()
-            assert len(lines) == n0
+            # (in a process of its own, as `python bench.py --model lsm --chains-per-gpu 4` measures it: inside this
+            # one - behind the streams of five workloads - the four chains' queues overlapped far less: 3900 - 4200
+            # it/s aggregate against 7000)
+            import subprocess
+            steps4 = max(args.steps, 200)       # (four host threads: a 20-step window measures their start)
+            cmd = [sys.executable, os.path.abspath(__file__), '--model', 'lsm', '--chains-per-gpu', '4', '--no-cpu',
+                   '--profile-steps', '0', '--steps', str(steps4), '--warmup', str(max(args.warmup, 20)),
+                   '--settle-steps', str(args.settle_steps), '--T', str(args.T), '--N', str(args.N), '--D', str(args.D),
+                   '--density', str(args.density)]
+            out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=600).stdout.decode()
+            l4 = json.loads([ln for ln in out.splitlines() if ln.startswith('{')][-1])
+
+            class _A4(object):
+                steps = steps4
+            a4 = _A4()
             c2 = lines[0]
             iv = c2.get('iteration_fp64_valu') or {}
             lines.append({'metric': l4['metric'], 'chains_per_gpu': 4, 'steps': a4.steps, 'aggregate_it_per_s': l4['value'],

@@ -324,8 +324,10 @@ __device__ __forceinline__ void pipe_eval_lds(const ChainView &c, const PipeBuf 
         DLSM_STAMP(0, (double)lane)
         const int j0 = be * PP_B, jk = j0 + min(k, nb - 1);
         const int jprev = max(j0 - PP_B, 0);                             // nodes >= jprev: snapshot positions
-        const double *Xt = a.X + (size_t)t * N * D;
-        const double *props = a.prop + (size_t)t * N * PW;
+        // (T N < 2^31: node indices in 32 bits, one 64-bit product per base)
+        const uint32_t tN = (uint32_t)t * (uint32_t)N;
+        const double *Xt = a.X + (size_t)tN * D;
+        const double *props = a.prop + (size_t)tN * PW;
 #if DLSM_TRIP_PRIO
         __builtin_amdgcn_s_setprio(3);
 #endif
@@ -340,10 +342,11 @@ __device__ __forceinline__ void pipe_eval_lds(const ChainView &c, const PipeBuf 
         const int nst = ntp + pl.w;
         // (one entry per wavefront when the list has <= 16: config 2 holds 10 + 2 or 11 + 1)
         double stg[D];
-        int s = wave;
+        int s = wave, g_stg = 0;            // (g_stg: the trip of the entry in flight - the store needs it again)
         auto stage_request = [&](int s_) {
             const bool win = s_ >= ntp;
             const int g = pl.trip(win ? s_ - ntp : s_, p, P);
+            g_stg = g;
             const int n = min(64 * g + lane, N - 1);
             // a trip's 64 neighbours are all on one side of jprev (both multiples of 64)
             const bool snap = win || 64 * g >= jprev;
@@ -352,7 +355,7 @@ __device__ __forceinline__ void pipe_eval_lds(const ChainView &c, const PipeBuf 
             coh_load_row<D, false>(src, off, stg);
         };
         auto stage_store = [&](int s_) {
-            const int g = pl.trip(s_ >= ntp ? s_ - ntp : s_, p, P);
+            const int g = g_stg;
             if (64 * g + 63 >= N) {             // the slice's last trip: its idle lanes hold the far point
                 const bool idle = 64 * g + lane >= N;
 #pragma unroll
@@ -373,9 +376,10 @@ __device__ __forceinline__ void pipe_eval_lds(const ChainView &c, const PipeBuf 
         const double E = a.consts[0];
         const int nflush = (int)a.consts[1];
         // the node's row of the network: the bits under its first trip
-        const unsigned long long *yrow = (const unsigned long long *)(a.ybits + ((size_t)t * N + jk) * a.W);
-        const unsigned long long ym0 = scalar_load_u64(yrow + pl.trip(0, p, P));
-        double *hrow = a.Hd + (((size_t)(be & 1) * T + t) * PP_B + min(k, nb - 1)) * (2 * PP_B);
+        const unsigned long long *yrow = (const unsigned long long *)(a.ybits + (size_t)(tN + (uint32_t)jk) * (uint32_t)a.W);
+        // (a part without trips - more parts than trips at tiny N - names a trip behind the row: clamped, unused)
+        const unsigned long long ym0 = scalar_load_u64(yrow + min(pl.trip(0, p, P), (a.W >> 1) - 1));
+        double *hrow = a.Hd + (size_t)((uint32_t)(((be & 1) * T + t) * PP_B + min(k, nb - 1)) * (uint32_t)(2 * PP_B));     // (< 2^31 doubles: T < 128)
 #if defined(DLSM_PIPE_TIMING) && DLSM_PIPE_TIMING == 2      // (prologue probe: slot 1 = requests issued, slot 2 = at the barrier)
         DLSM_STAMP(1, (double)lane)
 #endif
@@ -408,7 +412,7 @@ __device__ __forceinline__ void pipe_eval_lds(const ChainView &c, const PipeBuf 
                 tot_l = wave_sum_all(ra.value()); tot_r = 1.0;
             }
             if (lane == 0) {
-                double2 *f = (double2 *)a.full0 + (((size_t)(be & 1) * T + t) * PP_B + k) * P + p;
+                double2 *f = (double2 *)a.full0 + (uint32_t)((((be & 1) * T + t) * PP_B + k) * P + p);
                 *f = make_double2(tot_l, tot_r);
             }
 #ifdef DLSM_PIPE_TIMING
