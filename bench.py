@@ -883,17 +883,32 @@ class CcWorkload(object):
                             'launch ends with the resolver\'s chain of accepted moves (profiles/r05_ccpipe_notes.md)'}
         ll_ms = ms_ll / max(n_ll, 1)
         rec_ll = float(T) * N * (float(self.mean_out) + self.C)     # out-edges + out-controls
+        # (the pass since round 6: k_loglik_casecontrol_stream - streaming wavefronts, reciprocal radii in LDS, one
+        # 16-byte position gathered per term.  Its two bounds, both from counters of this kernel under rocprofv3
+        # (profiles/r06_cc_pass_notes.md): vector issue - SQ_INSTS_VALU per pass, four clocks each on 4 x n_cu
+        # SIMDs - and the vector L1's line fills - one 128-byte line per gathered term at 64 bytes per CU and clock)
+        pass_form = os.environ.get('DLSM_CC_PASS', 'stream')
+        valu_per_pass = {'stream': 0.5 * (20.32e6 + 8.98e6), 'records': 0.5 * (18.81e6 + 8.40e6),
+                         'rows': 0.5 * (39.68e6 + 16.59e6)}.get(pass_form)
+        n_cu = 256
         roofline_ll = {
-            'bound': 'gather rate (one cache-line look-up per CU per clock)',
-            'kernel': 'k_loglik_casecontrol_rows',
+            'bound': 'vector issue and L1 line fills (neither alone: see note)',
+            'kernel': 'k_loglik_casecontrol_%s' % ('rows' if pass_form == 'rows' else 'stream'),
             'achieved': round(rec_ll / (ll_ms * 1e-3) / 1e9, 2), 'peak': GATHER_PEAK_GRECS,
             'unit': 'G records/s', 'frac': round(rec_ll / (ll_ms * 1e-3) / 1e9 / GATHER_PEAK_GRECS, 4),
             'records_per_pass': rec_ll, 'us_per_pass': round(1e3 * ll_ms, 2),
             'algorithmic_bytes_per_pass': rec_ll * (4 + 32),
             'hbm_equivalent_GBs': round(rec_ll * 36 / (ll_ms * 1e-3) / 1e9, 1),
+            'valu_instructions_per_pass_measured': valu_per_pass,
+            'frac_vector_issue': (round(valu_per_pass * 4 / (4 * n_cu * 2.4e9) / (ll_ms * 1e-3), 4)
+                                  if valu_per_pass else None),
+            'frac_l1_line_fill': round(rec_ll * 128 / (n_cu * 64 * 2.4e9) / (ll_ms * 1e-3), 4),
             'note': 'average over the iteration\'s two passes (the four candidates of both intercept steps in '
-                    'one, the radii\'s in the other); index 4 B + record 32 B per term; every load of a '
-                    'wavefront\'s two nodes is issued before the first use'}
+                    'one, the radii\'s in the other).  Round 5\'s two-rows-per-wavefront kernel executed 39.7 M / 16.6 M '
+                    'vector instructions per pass (81.5 / 42 us: it was bound by vector issue, not by gathers); the '
+                    'streaming kernel executes 20.3 M / 9.0 M (running control product per run of equal out-degrees, '
+                    'brackets shared between candidates, header by lane) and gathers one 16-byte position per term '
+                    'instead of a 32-byte record in two requests: 54 / 37.5 us'}
         extra = {'roofline_gather': roofline_gather, 'roofline_valu': roofline_valu, 'roofline_loglik': roofline_ll,
                  'ms_sweep': round(sweep_ms, 4),
                  'ms_per_loglik_pass': round(ms_ll / max(n_ll, 1), 4),

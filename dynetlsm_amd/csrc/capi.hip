@@ -17,6 +17,7 @@
 #include "kernels_hdp.hpp"
 #include "cc_rows.hpp"
 #include "kernels_loglik.hpp"
+#include "kernels_loglik_ccstream.hpp"
 #include "kernels_hdploop.hpp"
 #include "kernels_sweep.hpp"
 #include "kernels_dirloop.hpp"
@@ -246,6 +247,16 @@ static int ensure_cc_rows(dlsm_chain *h, bool alloc_only = false) {
         }
         h->cc_tw = tw; h->cc_terms_valid = false;
     }
+    {   // the likelihood pass's walking order: entries of at most CC_ENT_TERMS out-terms (k_cc_order) + a count per slice
+        const int emax = std::max(1, (h->Dout + h->C + CC_ENT_TERMS - 1) / CC_ENT_TERMS);
+        if (h->cc_order_cap < TN * emax + (size_t)h->T || h->cc_emax != emax) {
+            if (h->cc_order) hipFree(h->cc_order);
+            h->cc_order = nullptr; h->cc_order_cap = 0;
+            HIPCHK(h, hipMalloc((void **)&h->cc_order, (TN * emax + (size_t)h->T) * sizeof(int32_t)));
+            h->cc_order_cap = TN * emax + (size_t)h->T; h->cc_emax = emax; h->cc_terms_valid = false;
+            h->cc_order_cnt = h->cc_order + TN * emax;
+        }
+    }
     if (h->cc_pos_cap < TN) {
         if (h->cc_pos) hipFree(h->cc_pos);
         h->cc_pos = nullptr; h->cc_pos_cap = 0;
@@ -263,6 +274,8 @@ static int ensure_cc_rows(dlsm_chain *h, bool alloc_only = false) {
                            dim3(CC_SORT_B), 0, h->stream, h->view(), h->nctrl, h->cc_pos);
         hipLaunchKernelGGL(k_cc_rows, dim3((unsigned)((TN + 3) / 4)), dim3(256), 0, h->stream, h->view(),
                            h->nctrl, h->cc_pos, h->cc_terms, tw);
+        hipLaunchKernelGGL(k_cc_order, dim3((unsigned)((h->N + 255) / 256), (unsigned)h->T), dim3(256), 0, h->stream,
+                           h->view(), h->nctrl, h->cc_pos, h->cc_emax, h->cc_order, h->cc_order_cnt);
         h->cc_terms_valid = true;
     }
     return DLSM_OK;
@@ -283,6 +296,61 @@ int ensure_xr(dlsm_chain *h) {
         h->xr_cap = need;
     }
     return DLSM_OK;
+}
+
+// The streaming case-control pass: as many workgroups per slice as stay resident together (occupancy query, once
+// per instantiation), trimmed so that every wavefront walks the same number of row pairs.
+template <int DD, int M, bool TWO, int PD, int NT>
+int launch_ccs(dlsm_chain *h, const ChainView &v, const LoglikCand &cand, int rslot, int *nrec_out) {
+    constexpr bool IR = NT == 1024;         // reciprocal radii in LDS: one workgroup per CU
+    constexpr int NWV = NT / 64;
+    const size_t lds = (size_t)(EXPTAB_N + NWV * 4 + (IR ? h->N : 0)) * sizeof(double);
+    static int bpc = 0;                     // workgroups per CU
+    if (bpc == 0) {
+        int nblk = 0;
+        if (IR) HIPCHK(h, hipFuncSetAttribute((const void *)k_loglik_casecontrol_stream<DD, M, TWO, PD, NT>,
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, k_loglik_casecontrol_stream<DD, M, TWO, PD, NT>,
+                                                                    NT, lds);
+        if (e != hipSuccess || nblk < 1) { (void)hipGetLastError(); nblk = IR ? 1 : 2; }
+        const char *eo = getenv("DLSM_CC_PASS_WG_PER_CU");     // (experiments)
+        if (eo && atoi(eo) > 0) nblk = atoi(eo);
+        bpc = nblk;
+    }
+    const int N = h->N, T = h->T;
+    // (a slice's entries - k_cc_order: N of them and a few per cent - are dealt to the wavefronts in equal
+    // contiguous shares; the grid is trimmed so that the shares are whole numbers of entries, near enough)
+    const int wps0 = std::max(1, h->n_cu * bpc / T);
+    const int rounds = (N + wps0 * NWV - 1) / (wps0 * NWV);
+    const int gb = (N + rounds - 1) / rounds;
+    int wps = std::max(1, (gb + NWV - 1) / NWV);
+    wps = std::min(wps, (N + LLCC_NODES - 1) / LLCC_NODES);     // (the records' room: ll_blocks)
+    hipLaunchKernelGGL((k_loglik_casecontrol_stream<DD, M, TWO, PD, NT>), dim3((unsigned)wps, (unsigned)T),
+                       dim3(NT), lds, h->stream, v, cand, h->xr, h->cc_terms, h->cc_tw, h->cc_order,
+                       h->cc_order_cnt, h->cc_emax, h->partials, rslot);
+    *nrec_out = wps * T;
+    return DLSM_OK;
+}
+template <int DD>
+int launch_loglik_ccstream(dlsm_chain *h, int M, bool two, const ChainView &v, const LoglikCand &cand, int rslot,
+                           int *nrec_out) {
+    // one radius per node (every pass but the two-radii form) and the reciprocals fit a CU's LDS: positions alone
+    // are gathered (DLSM_CC_PASS=records keeps the gathered records)
+    const bool ir = !two && (size_t)h->N * sizeof(double) <= 150 * 1024 &&
+                    !(getenv("DLSM_CC_PASS") && strcmp(getenv("DLSM_CC_PASS"), "records") == 0);
+    // (d <= 3: beyond it a position is as many requests as a record, and the 16-wavefront workgroup's 128 registers
+    // no longer hold two entries of d doubles per term)
+    if constexpr (DD <= 3) {
+        if (ir) {
+            if (M == 1) return launch_ccs<DD, 1, false, 2, 1024>(h, v, cand, rslot, nrec_out);
+            if (M == 4) return launch_ccs<DD, 4, false, 1, 1024>(h, v, cand, 0, nrec_out);
+            return launch_ccs<DD, 2, false, 1, 1024>(h, v, cand, 0, nrec_out);
+        }
+    }
+    if (M == 1) return launch_ccs<DD, 1, false, 1, LLCS_THREADS>(h, v, cand, rslot, nrec_out);
+    if (M == 4) return launch_ccs<DD, 4, false, 1, LLCS_THREADS>(h, v, cand, 0, nrec_out);
+    if (two) return launch_ccs<DD, 2, true, 1, LLCS_THREADS>(h, v, cand, 0, nrec_out);
+    return launch_ccs<DD, 2, false, 1, LLCS_THREADS>(h, v, cand, 0, nrec_out);
 }
 
 // Enqueue the log-likelihood record kernel for M candidates whose intercepts
@@ -320,6 +388,15 @@ int launch_loglik_records(dlsm_chain *h, int M, const double *d_ic,
         }
         // out-edges and out-controls as dense 64-term trips from the node's row (cc_rows.hpp)
         { int rc3 = ensure_cc_rows(h); if (rc3) return rc3; }
+        // (round 6: a resident wave of streaming wavefronts - kernels_loglik_ccstream.hpp; DLSM_CC_PASS=rows keeps
+        // the two-rows-per-wavefront form)
+        const bool stream_form = !(getenv("DLSM_CC_PASS") && strcmp(getenv("DLSM_CC_PASS"), "rows") == 0);
+        if (stream_form) {
+            const bool two = M == 2 && r1 != r0;
+            int rc4 = launch_loglik_ccstream<DD>(h, M, two, v, cand, rslot, nrec_out); if (rc4) return rc4;
+            HIPCHK(h, hipGetLastError());
+            return DLSM_OK;
+        }
         if (M == 1) hipLaunchKernelGGL((k_loglik_casecontrol_rows<DD, 1>), dim3(nb / h->T, h->T), dim3(LLCR_THREADS), 0, h->stream, v, cand, h->xr, h->cc_terms, h->cc_tw, h->partials, rslot);
         else if (M == 4) hipLaunchKernelGGL((k_loglik_casecontrol_rows<DD, 4>), dim3(nb / h->T, h->T), dim3(LLCR_THREADS), 0, h->stream, v, cand, h->xr, h->cc_terms, h->cc_tw, h->partials, 0);
         else hipLaunchKernelGGL((k_loglik_casecontrol_rows<DD, 2>), dim3(nb / h->T, h->T), dim3(LLCR_THREADS), 0, h->stream, v, cand, h->xr, h->cc_terms, h->cc_tw, h->partials, 0);
@@ -460,7 +537,7 @@ void dlsm_destroy(dlsm_chain *h) {
                     h->lab_nk, h->lab_w, h->spec, h->nctrl, h->stamps, h->lsm, h->trace_X, h->trace_ic,
                     h->trace_logp, h->hops, h->hops_max, h->pipe, h->post_zt, h->post_cooc,
                     h->trace_radii, h->hdp, h->hdp_buf, h->htr_mu, h->htr_sigma, h->htr_beta,
-                    h->htr_w, h->htr_lambda, h->htr_hyper, h->htr_z, h->xr, h->cc_terms, h->cc_pos};
+                    h->htr_w, h->htr_lambda, h->htr_hyper, h->htr_z, h->xr, h->cc_terms, h->cc_pos, h->cc_order};
     for (void *p : ptrs) if (p) hipFree(p);
     if (h->hsmall) hipHostFree(h->hsmall);
     if (h->timer0) hipEventDestroy(h->timer0);

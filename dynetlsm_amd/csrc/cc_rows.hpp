@@ -73,4 +73,46 @@ __global__ __launch_bounds__(256) void k_cc_rows(ChainView c, const int32_t *nct
     }
 }
 
+// The likelihood pass's walking order (round 6): a slice's rows by DESCENDING (out_deg, n_out_controls), ties by
+// node, every row cut into ENTRIES of at most CC_ENT_TERMS = 128 out-terms (two 64-term trips): entry = place of
+// the row in storage (pos) | segment << 24.
+//  * Rows with equal out-degree and control count have the same control weight adj_out = (N - out_deg - 1) /
+//    n_out_controls, and the pass keeps ONE running product of a wavefront's control factors while the weight
+//    stays the same - a logarithm per run of rows instead of per row (a third of the four-candidate pass's vector
+//    instructions).
+//  * An entry is what one step of the pass's pipeline requests ahead, so a row of 200 out-terms is two steps like
+//    any other two and a wavefront's share of the list - a contiguous run of entries - is the same work for every
+//    wavefront (rows beyond two trips used to load their further terms in place, 2 - 3 us each, all of them in
+//    the wavefronts that hold the top of the order).
+// count[t] = entries of slice t.  Ranks and entry offsets by counting, N^2 comparisons per slice, only when the
+// rows are rebuilt (grid (ceil(N / 256), T)); `order` holds T x N x emax int32.
+constexpr int CC_ENT_TERMS = 128;
+__global__ __launch_bounds__(256) void k_cc_order(ChainView c, const int32_t *nctrl, const int32_t *pos, int emax,
+                                                  int32_t *order, int32_t *count) {
+    __shared__ int key[256];
+    const int t = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x, N = c.N;
+    const long base = (long)t * N;
+    // key: (out_deg, n_out_controls); the entries of a row follow from it
+    auto key_of = [&](int j) { return c.degree[(base + j) * 2 + 1] * 65536 + nctrl[(base + j) * 2 + 1]; };
+    auto ents_of = [&](int k) { return max(1, ((k >> 16) + (k & 65535) + CC_ENT_TERMS - 1) / CC_ENT_TERMS); };
+    const int mine = i < N ? key_of(i) : -1;
+    int r = 0, start = 0;
+    for (int j0 = 0; j0 < N; j0 += 256) {
+        __syncthreads();
+        key[threadIdx.x] = j0 + threadIdx.x < N ? key_of(j0 + threadIdx.x) : -2;
+        __syncthreads();
+        const int nj = min(256, N - j0);
+        for (int m = 0; m < nj; ++m) {
+            const bool before = key[m] > mine || (key[m] == mine && j0 + m < i);
+            r += before ? 1 : 0;
+            start += before ? ents_of(key[m]) : 0;
+        }
+    }
+    if (i >= N) return;
+    const int ne = ents_of(mine);
+    int32_t *o = order + base * emax + start;
+    for (int sgm = 0; sgm < ne; ++sgm) o[sgm] = pos[base + i] | (sgm << 24);
+    if (r == N - 1) count[t] = start + ne;
+}
+
 }  // namespace dlsm

@@ -167,6 +167,8 @@ struct dlsm_chain {
     bool nctrl_valid = false;
     // case-control model: a node's counts, control weights and its four index lists as one row (cc_rows.hpp)
     int32_t *cc_terms = nullptr; size_t cc_terms_cap = 0; bool cc_terms_valid = false; int cc_tw = 0;
+    // the likelihood pass's walking order (cc_rows.hpp, k_cc_order): entries, then a count per slice
+    int32_t *cc_order = nullptr, *cc_order_cnt = nullptr; size_t cc_order_cap = 0; int cc_emax = 0;
     int32_t *cc_pos = nullptr; size_t cc_pos_cap = 0;        // where a node's row lies (cc_rows.hpp: k_cc_pos)
     unsigned long long *stamps = nullptr;               // in-kernel timestamps (profiling)
     size_t stamps_cap = 0, stamps_used = 0;             // in [start, end] pairs

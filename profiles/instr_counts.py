@@ -261,7 +261,8 @@ HOT_KERNELS = [
     'k_lsm_finalize_apply_propose<2>',
     'k_post_apply<2>', 'k_sample_labels_mfma<5>', 'k_label_counts', 'k_hdp_stage1<2>', 'k_hdp_stage2<2>',
     'k_hdp_stage3<2>', 'k_hdp_hypers_propose<2>', 'k_hdp_logp_batch_sums<2>', 'k_hdp_logp_batch_finish<2>',
-    'k_ccpipe_step<2>', 'k_ccpipe_pack<2>', 'k_loglik_casecontrol_rows<2,1>', 'k_loglik_casecontrol_rows<2,2>', 'k_cc_rows',
+    'k_ccpipe_step<2>', 'k_ccpipe_pack<2>', 'k_loglik_casecontrol_stream<2,1,false,2,1024>',
+    'k_loglik_casecontrol_stream<2,4,false,1,1024>', 'k_cc_rows', 'k_cc_order',
     'k_post_reduce_dir<2>', 'k_post_apply_dir<2>', 'k_dir_reduce_accept_intercept<2>', 'k_dir_tail<2>',
 ]
 

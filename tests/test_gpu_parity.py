@@ -225,6 +225,41 @@ def test_loglik_case_control(eng, N, C):
             np.testing.assert_allclose(got[0], exact, rtol=1e-10)
 
 
+@pytest.mark.parametrize('N,C,D', [(9, 3, 2), (130, 20, 1), (130, 20, 3), (300, 70, 5), (300, 70, 8), (700, 150, 2),
+                                   (200, 300, 2)])
+def test_loglik_case_control_pass_forms_agree(eng, monkeypatch, N, C, D):
+    """directed_likelihoods_fast.pyx:208-270 through the three forms of the pass - the streaming wavefronts with the
+    reciprocal radii in LDS (default), with gathered records (DLSM_CC_PASS=records), and two rows per wavefront
+    (rows; round 5's kernel): one, two and the radii step's two candidates; every form against the oracle, the forms
+    against each other to rounding.  N = 700 with 150 controls: rows beyond 128 out-terms (two entries of the walking
+    order); C >= N: control lists with invalid (-1) slots"""
+    X, Yd, Yu, radii = _rand_net(N + C + D, 2, N, D, density=0.08, scale=0.05)
+    cc = _cc_lists(Yd, C, 5)
+    r2 = np.random.RandomState(7).dirichlet(np.ones(N) * 5)
+    got = {}
+    for form in ('', 'records', 'rows'):
+        if form:
+            monkeypatch.setenv('DLSM_CC_PASS', form)
+        else:
+            monkeypatch.delenv('DLSM_CC_PASS', raising=False)
+        with eng.Chain(2, N, D, 'case_control') as c:
+            c.upload_edges(cc['in_edges'], cc['out_edges'], cc['degree'])
+            c.set_controls(cc['control_nodes_in'], cc['control_nodes_out'])
+            c.set_positions(X); c.set_radii(radii); c.set_intercepts([0.3, 0.7])
+            got[form] = (c.loglik_full([[0.3, 0.7]]), c.loglik_full([[0.3, 0.7], [0.9, 0.1]]),
+                         c.loglik_full_radii(r2))
+    want = [orc.approx_directed_network_loglikelihood(X, rr, cc['in_edges'], cc['out_edges'], cc['degree'],
+                                                      cc['control_nodes_out'], a, b)
+            for rr, a, b in [(radii, 0.3, 0.7), (radii, 0.9, 0.1), (r2, 0.3, 0.7)]]
+    for form, (g1, g2, g3) in got.items():
+        np.testing.assert_allclose(g1, want[:1], rtol=RTOL_LL, err_msg=form)
+        np.testing.assert_allclose(g2, want[:2], rtol=RTOL_LL, err_msg=form)
+        np.testing.assert_allclose(g3, [want[0], want[2]], rtol=RTOL_LL, err_msg=form)
+    for form in ('records', 'rows'):
+        for a, b in zip(got[''], got[form]):
+            np.testing.assert_allclose(a, b, rtol=1e-12, err_msg=form)
+
+
 def test_partial_with_explicit_position_and_prior(eng):
     X, Yd, Yu, radii = _rand_net(5, 3, 40)
     grid = orc.SamplerGrid(3, 40)

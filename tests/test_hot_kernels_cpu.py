@@ -114,6 +114,9 @@ def test_no_kernel_outside_the_known_list_touches_scratch_memory(code_object):
     # what a sweep can launch at d = 2 with the defaults (resolve_sweep_algo: 1, 2, 4, 5) and the case-control passes
     for k in ('k_sweep_slice<2,0>', 'k_sweep_slice<2,1>', 'k_sweep_casecontrol<2>', 'k_pipe_step<2,0,1>',
               'k_pipe_step<2,1,1>', 'k_ccpipe_step<1>', 'k_ccpipe_step<2>', 'k_ccpipe_step<3>', 'k_ccpipe_step<4>',
-              'k_loglik_casecontrol_rows<2,1>', 'k_loglik_casecontrol_rows<2,2>', 'k_cc_rows'):
+              'k_loglik_casecontrol_rows<2,1>', 'k_loglik_casecontrol_rows<2,2>', 'k_cc_rows', 'k_cc_order',
+              'k_loglik_casecontrol_stream<2,1,false,2,1024>', 'k_loglik_casecontrol_stream<2,4,false,1,1024>',
+              'k_loglik_casecontrol_stream<2,2,false,1,1024>', 'k_loglik_casecontrol_stream<2,2,true,1,256>',
+              'k_loglik_casecontrol_stream<2,1,false,1,256>', 'k_loglik_casecontrol_stream<2,4,false,1,256>'):
         assert k in md, k
         assert md[k]['scratch_bytes'] == 0 and md[k]['vgpr_spill'] == 0, (k, md[k])
