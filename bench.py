@@ -890,6 +890,15 @@ class CcWorkload(object):
         pass_form = os.environ.get('DLSM_CC_PASS', 'stream')
         valu_per_pass = {'stream': 0.5 * (20.32e6 + 8.98e6), 'records': 0.5 * (18.81e6 + 8.40e6),
                          'rows': 0.5 * (39.68e6 + 16.59e6)}.get(pass_form)
+        valu_source = 'profiles/r06_cc_pass_notes.md'
+        try:        # this round's stored counters of the default form (collect_round.sh -> profiles/r06_cc_pass_counters.jsonl)
+            rows = [json.loads(ln) for ln in open(os.path.join(ROOT, 'profiles', 'r06_cc_pass_counters.jsonl'))
+                    if ln.startswith('{')]
+            v = [r['SQ_INSTS_VALU'] for r in rows if 'loglik_casecontrol' in r['kernel'] and 'SQ_INSTS_VALU' in r]
+            if pass_form == 'stream' and len(v) == 2:
+                valu_per_pass, valu_source = 0.5 * sum(v), 'profiles/r06_cc_pass_counters.jsonl'
+        except Exception:       # noqa: BLE001
+            pass
         n_cu = 256
         roofline_ll = {
             'bound': 'vector issue and L1 line fills (neither alone: see note)',
@@ -899,7 +908,7 @@ class CcWorkload(object):
             'records_per_pass': rec_ll, 'us_per_pass': round(1e3 * ll_ms, 2),
             'algorithmic_bytes_per_pass': rec_ll * (4 + 32),
             'hbm_equivalent_GBs': round(rec_ll * 36 / (ll_ms * 1e-3) / 1e9, 1),
-            'valu_instructions_per_pass_measured': valu_per_pass,
+            'valu_instructions_per_pass_measured': valu_per_pass, 'valu_instructions_source': valu_source,
             'frac_vector_issue': (round(valu_per_pass * 4 / (4 * n_cu * 2.4e9) / (ll_ms * 1e-3), 4)
                                   if valu_per_pass else None),
             'frac_l1_line_fill': round(rec_ll * 128 / (n_cu * 64 * 2.4e9) / (ll_ms * 1e-3), 4),

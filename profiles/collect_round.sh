@@ -35,6 +35,14 @@ python3 profiles/window_probe.py > $OUT/window_probe.jsonl 2> $OUT/window_probe.
 python3 profiles/iteration_timeline.py $OUT/stats_cc/bench_kernel_trace.csv k_post_reduce_dir > $OUT/cc_timeline.txt 2>&1
 python3 bench.py --model lsm --no-cpu --steps 20 --warmup 5 --windows 6 > $OUT/bench_windows_lsm.json 2> $OUT/bench_windows.err
 python3 bench.py --model hdp --no-cpu --steps 20 --warmup 5 --windows 6 > $OUT/bench_windows_hdp.json 2>> $OUT/bench_windows.err
+# round 6: what the case-control kernels execute (vector / scalar / LDS / memory instructions, busy and waiting
+# clocks) - counters in runs of their own, as the traffic passes
+: > $OUT/cc_pass_counters.jsonl
+for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVES" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT"; do
+  (cd /tmp && export TMPDIR=/tmp && timeout 200 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/pmc_cc_pass -o p -- python3 $ROOT/bench.py --model cc --no-cpu --steps 4 --warmup 2 --profile-steps 0 --settle-steps 0 > $OUT/pmc_cc_pass.log 2>&1)
+  python3 profiles/pass_counters.py $OUT/pmc_cc_pass >> $OUT/cc_pass_counters.jsonl 2>> $OUT/pmc_cc_pass.log
+  rm -rf $OUT/pmc_cc_pass
+done
 python3 profiles/instr_counts.py > $OUT/instr_counts.json 2>&1
 python3 profiles/instr_counts.py scratch > $OUT/hot_kernel_registers.txt 2>&1
 python3 bench.py --gpus 2 --backend gloo --share-device0 --no-cpu 2> $OUT/bench_2ranks.err | grep "^{" > $OUT/bench_2ranks_one_gpu.json   # (gloo greets on stdout)

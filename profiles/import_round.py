@@ -27,7 +27,7 @@ for a in ('bench_default.json', 'bench_driver_args.json', 'chains_per_gpu.jsonl'
           'ccpipe_timing.json', 'labels_phases.json', 'hdp_tail_timing.json',
           'valu_rates.txt', 'sqrt_acc.txt', 'hdp_timeline_two_queues.txt', 'hdp_timeline_one_queue.txt',
           'per_call_cost.jsonl', 'window_probe.jsonl', 'cc_timeline.txt', 'bench_windows_lsm.json',
-          'bench_windows_hdp.json'):
+          'bench_windows_hdp.json', 'cc_pass_counters.jsonl'):
     p = os.path.join(src, a)
     if os.path.exists(p) and os.path.getsize(p) > 0:
         shutil.copy(p, os.path.join(HERE, '%s_%s' % (tag, a))); n += 1
