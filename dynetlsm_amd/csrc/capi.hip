@@ -390,7 +390,9 @@ int launch_loglik_records(dlsm_chain *h, int M, const double *d_ic,
         { int rc3 = ensure_cc_rows(h); if (rc3) return rc3; }
         // (round 6: a resident wave of streaming wavefronts - kernels_loglik_ccstream.hpp; DLSM_CC_PASS=rows keeps
         // the two-rows-per-wavefront form)
-        const bool stream_form = !(getenv("DLSM_CC_PASS") && strcmp(getenv("DLSM_CC_PASS"), "rows") == 0);
+        // (k_cc_order ranks by out_deg * 65536 + n_out_controls in 32 bits: lists beyond that keep the rows form)
+        const bool stream_form = !(getenv("DLSM_CC_PASS") && strcmp(getenv("DLSM_CC_PASS"), "rows") == 0) &&
+                                 h->Dout < 32768 && h->C < 65536;
         if (stream_form) {
             const bool two = M == 2 && r1 != r0;
             int rc4 = launch_loglik_ccstream<DD>(h, M, two, v, cand, rslot, nrec_out); if (rc4) return rc4;
