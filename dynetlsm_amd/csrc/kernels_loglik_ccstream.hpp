@@ -195,23 +195,15 @@ __global__ __launch_bounds__(NT) void k_loglik_casecontrol_stream(
         double xi[D];
 #pragma unroll
         for (int d = 0; d < D; ++d) xi[d] = rdl_d(bq.ov, d);
-        // (IR: the entry's LDS reads - its own reciprocal radius and both trips' partners' - requested together, in
-        // front of the bookkeeping, not one at the head of each trip)
-        double rql[NS], iri_l = 0.0;
-        if (IR) {
-            iri_l = sInv[bq.who];
-#pragma unroll
-            for (int s = 0; s < NS; ++s) rql[s] = sInv[bq.e[s]];
-        }
+        const double iri0 = IR ? uniform_d(sInv[bq.who]) : rdl_d(bq.ov, D + (M == 1 ? rslot : 0));
+        const double iri1 = TWO ? rdl_d(bq.ov, D + 1) : iri0;
         const double adj = bq.adj;
         ccs_flush<M>(L, Pe, 1.0, 1e100);                  // (then two factors of at most 1e56.5 are safe)
         ccs_row_weight<M>(L, Pc, adj_cur, adj);
-        const double iri0 = IR ? uniform_d(iri_l) : rdl_d(bq.ov, D + (M == 1 ? rslot : 0));
-        const double iri1 = TWO ? rdl_d(bq.ov, D + 1) : iri0;
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             if (64 * s >= nv) continue;                   // wave-uniform
-            const double rq0 = IR ? rql[s] : bq.re0[s];
+            const double rq0 = IR ? sInv[bq.e[s]] : bq.re0[s];
             ccs_trip<D, M, TWO>(bq.xe[s], rq0, bq.re1[s], xi, iri0, iri1, bin, bout, od - 64 * s,
                                 nv - 64 * s, lane, squared, adj, sTab, L, Pe, Pc);
         }
