@@ -223,9 +223,9 @@ int enqueue_hdp_logp_batch(dlsm_chain *h, int first, int count) {
     constexpr int CHUNK = 512;
     const size_t per = (size_t)T * K;
     const size_t need = (size_t)std::min(count, CHUNK) * per;           // doubles + int32
-    int rc = ensure_partials(h, need + (need + 1) / 2); if (rc) return rc;
-    double *LP = h->partials;
-    int32_t *cnt = (int32_t *)(h->partials + need);
+    int rc = ensure_partials(h, 2 * need + (need + 1) / 2); if (rc) return rc;
+    double *LP = h->partials, *LPD = h->partials + need;
+    int32_t *cnt = (int32_t *)(h->partials + 2 * need);
     ChainView v = h->view();
     HdpTraceView tv{h->trace_X, h->htr_z, h->trace_ic, h->htr_mu, h->htr_sigma, h->htr_beta, h->htr_w,
                     h->htr_lambda, h->htr_hyper, h->trace_logp};
@@ -233,9 +233,9 @@ int enqueue_hdp_logp_batch(dlsm_chain *h, int first, int count) {
     for (int s0 = first; s0 < first + count; s0 += CHUNK) {
         const int ns = std::min(CHUNK, first + count - s0);
         hipLaunchKernelGGL((k_hdp_logp_batch_sums<DD>), dim3(K, T, ns), dim3(HDP_THREADS), 0, h->stream,
-                           v, tv, s0, h->hdp_cfg.a, LP, cnt);
-        hipLaunchKernelGGL((k_hdp_logp_batch_finish<DD>), dim3(ns), dim3(HF_THREADS),
-                           per * sizeof(double), h->stream, v, tv, s0, h->hdp, h->lsm, LP, cnt);
+                           v, tv, s0, h->hdp_cfg.a, LP, cnt, LPD);
+        hipLaunchKernelGGL((k_hdp_logp_batch_finish<DD>), dim3(ns), dim3(HF_THREADS), 0, h->stream, v, tv, s0,
+                           h->hdp, h->lsm, LP, cnt, LPD);
     }
     HIPCHK(h, hipGetLastError());
     return DLSM_OK;

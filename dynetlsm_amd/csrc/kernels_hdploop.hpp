@@ -976,18 +976,30 @@ struct HdpTraceView {
     double *logp;
 };
 
+__device__ __forceinline__ double hdp_dirichlet_row_at(const double *beta, const double *w,
+                                                       const double *hy, int K, int j, int t, int lane);
+
 // grid (K, T, samples): LP[s][t][k] = the node terms of cluster k at time t of sample s0 + s;
-// cnt = its members
+// cnt = its members; LPD[s][t][k] = the Dirichlet log-density of row (k, t) of the sample's transition
+// weights, by the workgroup's last wavefront (round 6: the finish kernel computed a sample's T K rows on
+// eight wavefronts one after the other - 92 us for one sample or five hundred, the fixed cost of every call
+// of dlsm_hdp_run; here they are 4000 wavefronts' worth of a launch that has as many workgroups)
 template <int D>
 __global__ __launch_bounds__(HDP_THREADS) void k_hdp_logp_batch_sums(ChainView c, HdpTraceView tv,
                                                                      int s0, double a_,
                                                                      double *__restrict__ LP,
-                                                                     int32_t *__restrict__ cnt) {
+                                                                     int32_t *__restrict__ cnt,
+                                                                     double *__restrict__ LPD) {
     __shared__ double buf[HDP_THREADS / 64];
     __shared__ int sC[HDP_THREADS / 64];
     const int k = blockIdx.x, t = blockIdx.y, tid = threadIdx.x;
     const size_t s = (size_t)s0 + blockIdx.z;
     const int N = c.N, K = c.K, T = c.T;
+    if ((tid >> 6) == HDP_THREADS / 64 - 1) {
+        const double v = hdp_dirichlet_row_at(tv.beta + s * K, tv.w + s * T * K * K, tv.hyper + s * 6, K, k, t,
+                                              tid & 63);
+        if ((tid & 63) == 0) LPD[((size_t)blockIdx.z * T + t) * K + k] = v;
+    }
     const uint8_t *zt = tv.z + (s * T + t) * N;
     const uint8_t *zp = t > 0 ? tv.z + (s * T + t - 1) * N : nullptr;
     const double *Xt = tv.X + (s * T + t) * (size_t)N * D;
@@ -1078,37 +1090,25 @@ __device__ __forceinline__ double hdp_dirichlet_row_at(const double *beta, const
     return total;
 }
 
-// grid (samples): the Dirichlet rows of the sample, then k_hdp_finalize's reduction and scalars
-// (1024 threads: a row per wavefront, 16 rows at a time - with four wavefronts the (T - 1) K + 1 rows
-// of a sample, each a handful of lgamma, were 125 us in a row; the sums keep their order: the first
-// 256 threads add exactly what the 256 threads of the four-wavefront form added, the others zeros)
-// (512 threads since round 4: at 1024 the six inlined lgamma expansions did not fit 128 registers -
-// 62 spilled; the post-run pass has one workgroup per stored sample, so the width of a workgroup is
-// not what fills the chip)
-constexpr int HF_THREADS = 512;
+// grid (samples): k_hdp_finalize's reduction and scalars over the sample's node terms and Dirichlet rows
+// (k_hdp_logp_batch_sums; the sums keep their order: thread q adds what it added when the rows were computed here)
+constexpr int HF_THREADS = 256;
 template <int D>
 __global__ __launch_bounds__(HF_THREADS) void k_hdp_logp_batch_finish(ChainView c, HdpTraceView tv,
                                                                       int s0, const HdpDeviceState *hs,
                                                                       const LsmDeviceState *lsm,
                                                                       const double *__restrict__ LP,
-                                                                      const int32_t *__restrict__ cnt) {
-    extern __shared__ double sLPD[];            // T * K
+                                                                      const int32_t *__restrict__ cnt,
+                                                                      const double *__restrict__ LPD) {
     __shared__ double red[HF_THREADS / 64];
-    const int K = c.K, T = c.T, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int K = c.K, T = c.T, tid = threadIdx.x;
     const size_t s = (size_t)s0 + blockIdx.x;
-    const double *beta = tv.beta + s * K, *w = tv.w + s * T * K * K, *hy = tv.hyper + s * 6;
-    for (int q = wave; q < T * K; q += HF_THREADS / 64) {
-        const int t = q / K, j = q - t * K;
-        const double v = hdp_dirichlet_row_at(beta, w, hy, K, j, t, lane);
-        if (lane == 0) sLPD[q] = v;
-    }
-    __syncthreads();
+    const double *hy = tv.hyper + s * 6;
     double acc = 0.0;
-    if (tid < 256)
-        for (int q = tid; q < T * K; q += 256) {
-            const size_t g = (size_t)blockIdx.x * T * K + q;
-            acc += (cnt[g] > 0 ? LP[g] : 0.0) + sLPD[q];
-        }
+    for (int q = tid; q < T * K; q += 256) {
+        const size_t g = (size_t)blockIdx.x * T * K + q;
+        acc += (cnt[g] > 0 ? LP[g] : 0.0) + LPD[g];
+    }
     const double body = block_sum_all<HF_THREADS / 64>(acc, red, tid);
     if (tid != 0) return;
     // + the network log-likelihood: the undirected model's second intercept slot; the directed
