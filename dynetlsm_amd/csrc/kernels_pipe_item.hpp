@@ -139,7 +139,9 @@ __device__ __forceinline__ void pipe_h_entry(const ChainView &c, const PipeBuf &
         // (den is a product of factors >= 1 and, with an edge, of fd > 1e-290: normal, so the
         // reciprocal's Newton form applies - within 2 ulp of the division at a fifth of it)
         h = num * fast_rcp(den);
-        if (__builtin_amdgcn_ballot_w64(tiny)) { if (tiny) h *= fast_exp((b0 - b1) - (a0 - a1)); }
+        // (the table exponential, as the LDS evaluators' item - kernels_pipe_lds.hpp: the polynomial form's thirteen
+        // constants were hoisted into registers in front of the fallback's trip loop and cost it a spilled one)
+        if (__builtin_amdgcn_ballot_w64(tiny)) { if (tiny) h *= tab_exp11_clamped((b0 - b1) - (a0 - a1), etab); }
     } else {
         double bin = c.intercept[0], bout = c.intercept[1];
         const double lE = bin + bout;

@@ -68,8 +68,9 @@ KNOWN_SCRATCH = {
     # d = 3 / 4 instantiations of the pipelined sweep (resolver: the blocks' 64 registers + 8 d of the owners)
     'k_pipe_step<3,1,1>': 12, 'k_pipe_step<3,2,1>': 52, 'k_pipe_step<4,0,1>': 20, 'k_pipe_step<4,3,1>': 52,
     'k_pipe_step<4,1,1>': 60, 'k_pipe_step<4,2,1>': 84, 'k_pipe_last_ride<4>': 36,
-    # d = 2: parts longer than the prefetch (N > 2112 at T = 10), the dense case-control form (512 <= N < 2048)
-    'k_pipe_step<2,3,1>': 8, 'k_pipe_step<2,2,1>': 28,
+    # d = 2: the dense case-control form (512 <= N < 2048).  (Round 6: the fallback for parts longer than the prefetch,
+    # k_pipe_step<2,3,1>, is clean - its rare-path exponential is the table's, as the LDS evaluators'.)
+    'k_pipe_step<2,2,1>': 28,
     # initialisation pipeline at d = 3 / 4 (one workgroup, once per fit: d x d Jacobi on indexed local arrays)
     'k_gmds_finish<3>': 548, 'k_gmds_finish<4>': 1448, 'k_lanczos_init<4>': 36, 'k_lanczos_step<4>': 32,
     'k_partial_all<3>': 32,
