@@ -248,7 +248,7 @@ static int ensure_cc_rows(dlsm_chain *h, bool alloc_only = false) {
         h->cc_tw = tw; h->cc_terms_valid = false;
     }
     {   // the likelihood pass's walking order: entries of at most CC_ENT_TERMS out-terms (k_cc_order) + a count per slice
-        const int emax = std::max(1, (h->Dout + h->C + CC_ENT_TERMS - 1) / CC_ENT_TERMS);
+        const int emax = cc_order_entries_max(h->Dout, h->C);
         if (h->cc_order_cap < TN * emax + (size_t)h->T || h->cc_emax != emax) {
             if (h->cc_order) hipFree(h->cc_order);
             h->cc_order = nullptr; h->cc_order_cap = 0;
@@ -320,11 +320,7 @@ int launch_ccs(dlsm_chain *h, const ChainView &v, const LoglikCand &cand, int rs
     const int N = h->N, T = h->T;
     // (a slice's entries - k_cc_order: N of them and a few per cent - are dealt to the wavefronts in equal
     // contiguous shares; the grid is trimmed so that the shares are whole numbers of entries, near enough)
-    const int wps0 = std::max(1, h->n_cu * bpc / T);
-    const int rounds = (N + wps0 * NWV - 1) / (wps0 * NWV);
-    const int gb = (N + rounds - 1) / rounds;
-    int wps = std::max(1, (gb + NWV - 1) / NWV);
-    wps = std::min(wps, (N + LLCC_NODES - 1) / LLCC_NODES);     // (the records' room: ll_blocks)
+    const int wps = ccs_workgroups_per_slice(N, T, h->n_cu, bpc, NWV, (N + LLCC_NODES - 1) / LLCC_NODES);   // (cap: ll_blocks)
     hipLaunchKernelGGL((k_loglik_casecontrol_stream<DD, M, TWO, PD, NT>), dim3((unsigned)wps, (unsigned)T),
                        dim3(NT), lds, h->stream, v, cand, h->xr, h->cc_terms, h->cc_tw, h->cc_order,
                        h->cc_order_cnt, h->cc_emax, h->partials, rslot);
@@ -392,7 +388,7 @@ int launch_loglik_records(dlsm_chain *h, int M, const double *d_ic,
         // the two-rows-per-wavefront form)
         // (k_cc_order ranks by out_deg * 65536 + n_out_controls in 32 bits: lists beyond that keep the rows form)
         const bool stream_form = !(getenv("DLSM_CC_PASS") && strcmp(getenv("DLSM_CC_PASS"), "rows") == 0) &&
-                                 h->Dout < 32768 && h->C < 65536;
+                                 cc_order_key_holds(h->Dout, h->C);
         if (stream_form) {
             const bool two = M == 2 && r1 != r0;
             int rc4 = launch_loglik_ccstream<DD>(h, M, two, v, cand, rslot, nrec_out); if (rc4) return rc4;

@@ -2,6 +2,7 @@
 // sweep (kernels_ccpipe.hpp) and the likelihood pass (kernels_loglik.hpp, k_loglik_casecontrol_rows).
 #pragma once
 #include "device_common.hpp"
+#include "ccs_plan.hpp"
 
 namespace dlsm {
 
@@ -86,15 +87,14 @@ __global__ __launch_bounds__(256) void k_cc_rows(ChainView c, const int32_t *nct
 //    the wavefronts that hold the top of the order).
 // count[t] = entries of slice t.  Ranks and entry offsets by counting, N^2 comparisons per slice, only when the
 // rows are rebuilt (grid (ceil(N / 256), T)); `order` holds T x N x emax int32.
-constexpr int CC_ENT_TERMS = 128;
 __global__ __launch_bounds__(256) void k_cc_order(ChainView c, const int32_t *nctrl, const int32_t *pos, int emax,
                                                   int32_t *order, int32_t *count) {
     __shared__ int key[256];
     const int t = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x, N = c.N;
     const long base = (long)t * N;
     // key: (out_deg, n_out_controls); the entries of a row follow from it
-    auto key_of = [&](int j) { return c.degree[(base + j) * 2 + 1] * 65536 + nctrl[(base + j) * 2 + 1]; };
-    auto ents_of = [&](int k) { return max(1, ((k >> 16) + (k & 65535) + CC_ENT_TERMS - 1) / CC_ENT_TERMS); };
+    auto key_of = [&](int j) { return cc_order_key(c.degree[(base + j) * 2 + 1], nctrl[(base + j) * 2 + 1]); };
+    auto ents_of = [&](int k) { return cc_order_entries(k); };
     const int mine = i < N ? key_of(i) : -1;
     int r = 0, start = 0;
     for (int j0 = 0; j0 < N; j0 += 256) {

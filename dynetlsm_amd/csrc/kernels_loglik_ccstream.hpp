@@ -130,7 +130,8 @@ __global__ __launch_bounds__(NT) void k_loglik_casecontrol_stream(
     const int G = (int)gridDim.x * NWV;
     const int g = __builtin_amdgcn_readfirstlane((int)blockIdx.x * NWV + (tid >> 6));
     const int E = order_count[sl];
-    const int E0 = (int)((long long)g * E / G), nseq = (int)((long long)(g + 1) * E / G) - E0;   // this wavefront's entries
+    int E0, nseq;                                          // this wavefront's entries
+    ccs_share(g, G, E, E0, nseq);
     const int32_t *trows = terms + (size_t)sl * N * tw;
     const int32_t *ord = order + (size_t)sl * N * emax + E0;
     const char *Rt = (const char *)(XR + (size_t)sl * N * RW);
