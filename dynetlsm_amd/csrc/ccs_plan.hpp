@@ -1,7 +1,7 @@
 // The arithmetic of the case-control likelihood pass's walking order and of its launch (cc_rows.hpp: k_cc_order,
 // kernels_loglik_ccstream.hpp, capi.hip: launch_ccs) as plain C++ shared by the host, the device and a GPU-free check
-// (oracle/sanitize/check_ccs_plan.cpp, built with g++ under ASan / UBSan by tests/test_ccs_plan_cpu.py): the order's
-// key, the entries a row is cut into, the wavefronts' shares of a slice's entries, the workgroups per slice.
+// (tests/test_ccs_plan_cpu.py compiles this header with g++ under ASan / UBSan): the order's key, the entries a row is
+// cut into, the wavefronts' shares of a slice's entries, the workgroups per slice.
 #pragma once
 #include <stdint.h>
 #ifdef __HIPCC__
