@@ -1,30 +1,31 @@
 // Case-control full log-likelihood (a6, directed_likelihoods_fast.pyx:208-270) as a STREAM of term rows per
-// wavefront (round 6, second half).  k_loglik_casecontrol_rows gives a wavefront two rows and ends: 25 000
-// wavefronts at config 4, each one a chain row header -> indices -> records -> arithmetic -> workgroup sum with
-// nothing to overlap it but the SIMD's other three or four wavefronts in the same chain (81.5 / 42.1 us for
-// the four- / one-candidate pass; the arithmetic is ~25 / ~10 us of vector issue).  Here a launch is one
-// wave of RESIDENT wavefronts (workgroups per CU from the occupancy query), every wavefront walks `rounds` rows of
-// its slice and keeps the next step's records and the one after's indices in flight while it computes:
-//   step j :  wait(A[j+1]) -> request B[j+1] (records by A[j+1]'s indices) -> request A[j+2] -> compute B[j]
-// so the table fill, the barrier and the workgroup sum are paid once per ~5-14 rows and a row's two round trips
-// hide behind the arithmetic of the rows in front of it.  Rows are taken head / tail from the batches of
-// CC_SORT_B rows sorted by term count (cc_rows.hpp), pair q = g + i G for wavefront g of the slice's G: every
-// wavefront meets the same mix of long and short rows.
-// The arithmetic per term is that of the rows kernel with the bookkeeping moved out of the term:
-//   * eta_m = b_in,m (1 - d / r_q) + b_out,m (1 - d / r_i): the two brackets once per term, not per candidate;
-//   * eta > 130 (log(1 + e^eta) = eta) is a wave-level slow path, not four selects per candidate;
-//   * edge / control lanes by exec mask (a trip behind the out-edges has no edge lane at all);
-//   * the running products are checked for overflow once per row (a row's first trips multiply a product by
-//     at most (1 + e^130)^2 = 1e113), per trip only beyond them;
-//   * no separate sum for "big" control terms: they go to L with the row's weight at once.
-// One record of M sums per workgroup, rows and order fixed by (grid, N): the same bits every launch.
+// wavefront (round 6).  k_loglik_casecontrol_rows gives a wavefront two rows and ends: 25 000 wavefronts at
+// config 4 executing 39.7 M / 16.6 M vector instructions per pass (four / one candidate: 81.5 / 42.1 us, 65 / 27 of
+// them vector issue - profiles/r06_cc_pass_notes.md).  Here
+//   * a launch is one wave of RESIDENT wavefronts (workgroups per CU from the occupancy query, the grid trimmed by
+//     ccs_plan.hpp); a wavefront walks a contiguous share of its slice's ENTRIES (cc_rows.hpp, k_cc_order: rows by
+//     descending out-degree, cut into entries of at most two 64-term trips) and keeps PD entries' records and NB
+//     entries' indices in flight while it computes one:
+//       step j :  request B[j + PD] (records, by A[j + PD]'s indices) -> request A[j + PD + NB] -> compute B[j]
+//     - table fill, barrier and workgroup sum once per ~15 entries;
+//   * equal out-degrees lie side by side in the order and have the same control weight adj_out, so ONE running
+//     product of control factors lives across rows and becomes a logarithm per run of equal weights
+//     (ccs_row_weight), not per row and candidate;
+//   * the arithmetic per term is that of the rows kernel with the bookkeeping moved out of the term:
+//       eta_m = b_in,m (1 - d / r_q) + b_out,m (1 - d / r_i): the two brackets once per term, not per candidate;
+//       eta > 130 (log(1 + e^eta) = eta) is a wave-level cold path, not four selects per candidate;
+//       edge / control lanes by exec mask (a trip behind the out-edges has no edge lane at all);
+//       the running products are tested for overflow once per entry (an entry multiplies a product by at most
+//       (1 + e^130)^2 = 1e113); no separate sum for "big" control terms: they go to L with the row's weight;
+//   * NT = 1024: the reciprocal radii of all nodes in LDS, ONE 16-byte position gathered per term (below).
+// One record of M sums per workgroup; entries, shares and order fixed by (grid, rows): the same bits every launch.
 #pragma once
 #include "kernels_loglik.hpp"
 
 namespace dlsm {
 
 constexpr int LLCS_THREADS = 256;       // four wavefronts: one per SIMD
-constexpr int LLCS_NS = 2;              // 64-term trips requested ahead per row (the rest: in place)
+constexpr int LLCS_NS = 2;              // 64-term trips of an entry of the walking order (ccs_plan.hpp: CC_ENT_TERMS)
 
 __device__ __forceinline__ double uniform_d(double v) {     // a wave-uniform double into scalar registers
     const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
